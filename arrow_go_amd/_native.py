@@ -1,0 +1,145 @@
+"""ctypes binding of libarrowhip.so (the C ABI in include/arrowhip.h).
+
+This is plumbing: it declares the C signatures and turns status codes into Python
+exceptions named after the arrow-go error values a Go shim would wrap
+(arrow.ErrInvalid / ErrIndex / ErrNotImplemented — arrow/errors.go).  There is NO
+fallback: if the HIP library is missing or a symbol the header declares is not
+exported, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarrowhip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "arrowhip.h")
+
+AH_OK, AH_EINVALID, AH_EINDEX, AH_EOVERFLOW, AH_EHIP, AH_ENOTIMPL = 0, 1, 2, 3, 4, 5
+
+# arrow.Type ids (arrow/datatype.go:36-72)
+UINT8, INT8, UINT16, INT16, UINT32, INT32, UINT64, INT64, FLOAT32, FLOAT64 = 2, 3, 4, 5, 6, 7, 8, 9, 11, 12
+OP_ADD, OP_SUB, OP_MUL, OP_ABS, OP_NEGATE, OP_SIGN = 0, 1, 2, 4, 5, 20
+OP_ADD_CHECKED, OP_SUB_CHECKED, OP_MUL_CHECKED = 21, 22, 23
+CMP_EQ, CMP_NE, CMP_GT, CMP_GE = 0, 1, 2, 3
+SHAPE_AA, SHAPE_AS, SHAPE_SA = 0, 1, 2
+BIT_AND, BIT_OR, BIT_XOR, BIT_AND_NOT, BIT_XNOR = 0, 1, 2, 3, 4
+KLEENE_AND, KLEENE_OR, KLEENE_AND_NOT = 0, 1, 2
+DROP_NULLS, EMIT_NULLS = 0, 1
+
+
+class ArrowHipError(Exception):
+    """Base class; .status is the C status code."""
+
+    status = -1
+
+
+class ErrInvalid(ArrowHipError):  # arrow.ErrInvalid
+    status = AH_EINVALID
+
+
+class ErrIndex(ArrowHipError):  # arrow.ErrIndex
+    status = AH_EINDEX
+
+
+class ErrOverflow(ErrInvalid):  # arrow.ErrInvalid: "overflow"
+    status = AH_EOVERFLOW
+
+
+class ErrHip(ArrowHipError):
+    status = AH_EHIP
+
+
+class ErrNotImplemented(ArrowHipError):  # arrow.ErrNotImplemented
+    status = AH_ENOTIMPL
+
+
+_ERRS = {AH_EINVALID: ErrInvalid, AH_EINDEX: ErrIndex, AH_EOVERFLOW: ErrOverflow, AH_EHIP: ErrHip,
+         AH_ENOTIMPL: ErrNotImplemented}
+
+
+def declared_symbols(header_path: str = HEADER_PATH) -> list[str]:
+    """Every function name include/arrowhip.h declares."""
+    with open(header_path) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(ah_[a-z0-9_]+)\s*\(", text)))
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"libarrowhip.so does not export symbols declared in arrowhip.h: {missing}")
+    return lib
+
+
+lib = _load()
+
+_vp, _i64, _i32, _int, _i8, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_int8, C.c_size_t
+_pi64, _pvp, _pf, _pd, _pi32, _pint = (C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int))
+
+_SIGS = {
+    "ah_ctx_create": [_int, _pvp],
+    "ah_ctx_create_on_stream": [_int, _vp, _pvp],
+    "ah_device_count": [_pint],
+    "ah_buf_alloc": [_vp, _sz, _pvp],
+    "ah_buf_free": [_vp, _vp],
+    "ah_host_alloc_pinned": [_vp, _sz, _pvp],
+    "ah_host_free_pinned": [_vp, _vp],
+    "ah_upload_async": [_vp, _vp, _vp, _sz],
+    "ah_download_async": [_vp, _vp, _vp, _sz],
+    "ah_memset_async": [_vp, _vp, _int, _sz],
+    "ah_sync": [_vp],
+    "ah_timer_start": [_vp],
+    "ah_timer_stop": [_vp, _pf],
+    "ah_sum_float64": [_vp, _vp, _sz, _pd],
+    "ah_sum_int64": [_vp, _vp, _sz, _pi64],
+    "ah_sum_uint64": [_vp, _vp, _sz, C.POINTER(C.c_uint64)],
+    "ah_sum_float64_dev": [_vp, _vp, _sz, _vp],
+    "ah_sum_int64_dev": [_vp, _vp, _sz, _vp],
+    "ah_arithmetic_binary": [_vp, _int, _i8, _vp, _vp, _vp, _i64],
+    "ah_arithmetic_arr_scalar": [_vp, _int, _i8, _vp, _vp, _vp, _i64],
+    "ah_arithmetic_scalar_arr": [_vp, _int, _i8, _vp, _vp, _vp, _i64],
+    "ah_arithmetic_unary": [_vp, _int, _i8, _vp, _vp, _i64],
+    "ah_arithmetic_checked": [_vp, _int, _i8, _int, _vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64],
+    "ah_comparison": [_vp, _int, _int, _int, _vp, _vp, _vp, _i64, _int],
+    "ah_bitmap_op": [_vp, _int, _vp, _i64, _vp, _i64, _vp, _i64, _i64],
+    "ah_count_set_bits": [_vp, _vp, _i64, _i64, _pi64],
+    "ah_copy_bitmap": [_vp, _vp, _i64, _i64, _vp, _i64, _int],
+    "ah_set_bits_to": [_vp, _vp, _i64, _i64, _int],
+    "ah_kleene": [_vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64],
+    "ah_filter_count": [_vp, _vp, _vp, _i64, _i64, _int, _pi64],
+    "ah_filter_primitive": [_vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _int, _i64, _vp, _vp, _pi64],
+    "ah_filter_to_indices": [_vp, _vp, _vp, _i64, _i64, _int, _i64, _vp, _vp, _pi64],
+    "ah_take_primitive": [_vp, _int, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _i64, _i64, _int, _vp, _vp, _pi64, _pi64],
+    "ah_hash_u64_encode": [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _pi64, _pi32],
+    "ah_hash_sum_f64": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _pi64, _pi32],
+    "ah_hash_sum_i64": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _pi64, _pi32],
+    "ah_cmp_filter_sum_i64": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _pi64, _pi64],
+    "ah_cmp_filter_sum_f64": [_vp, _int, _vp, _vp, _i64, _i64, C.c_double, _pd, _pi64],
+    "ah_cmp_filter_sum_i64_dev": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _vp],
+    "ah_cmp_filter_sum_f64_dev": [_vp, _int, _vp, _vp, _i64, _i64, C.c_double, _vp, _vp],
+}
+for _name, _args in _SIGS.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = _int
+lib.ah_ctx_destroy.argtypes = [_vp]
+lib.ah_ctx_destroy.restype = None
+lib.ah_last_error.argtypes = [_vp]
+lib.ah_last_error.restype = C.c_char_p
+lib.ah_version.argtypes = []
+lib.ah_version.restype = C.c_char_p
+
+
+def check(ctx_handle, status: int) -> None:
+    if status == AH_OK:
+        return
+    msg = lib.ah_last_error(ctx_handle).decode() if ctx_handle else "arrowhip error"
+    raise _ERRS.get(status, ArrowHipError)(msg)

@@ -1,0 +1,128 @@
+// ah_common.h — shared host/device helpers for libarrowhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/arrowhip.h"
+
+#define AH_EXPORT extern "C" __attribute__((visibility("default")))
+
+struct ah_ctx {
+  int device;
+  hipStream_t stream;       // compute stream
+  hipStream_t copy_stream;  // uploads / downloads
+  bool owns_stream;
+  hipEvent_t ev_copy;       // orders copy stream <-> compute stream
+  hipEvent_t ev_compute;
+  hipEvent_t t0, t1;        // ah_timer_*
+  // scratch arena (device): partial sums, tile counts, hash tables ...
+  void* scratch;
+  size_t scratch_bytes;
+  // small pinned staging block for *_host results (64 x 8 bytes)
+  uint64_t* pinned;
+  // small device block for scalar results / flags (64 x 8 bytes)
+  uint64_t* dscalars;
+  int num_cu;
+  // tunables (env ARROWHIP_NT / ARROWHIP_BLOCKS_PER_CU, read at ctx creation)
+  int tune_nt;             // 1: nontemporal loads/stores on streaming kernels
+  int tune_blocks_per_cu;  // grid cap for grid-stride streaming kernels
+  char err[512];
+};
+
+// grid size for a grid-stride streaming kernel over `work_items` block-iterations
+static inline unsigned ah_stream_grid(const ah_ctx* c, int64_t work_items) {
+  int64_t cap = (int64_t)c->num_cu * c->tune_blocks_per_cu;
+  int64_t g = work_items < cap ? work_items : cap;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+// ---- host-side error plumbing ------------------------------------------------
+static inline int ah_fail(ah_ctx* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+static inline int ah_fail(ah_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define AH_HIP(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return ah_fail((ctx), AH_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                     __FILE__, __LINE__);                                              \
+  } while (0)
+
+#define AH_ENTER(ctx)                                                  \
+  do {                                                                 \
+    if (!(ctx)) return AH_EINVALID;                                    \
+    (ctx)->err[0] = 0;                                                 \
+    AH_HIP((ctx), hipSetDevice((ctx)->device));                        \
+  } while (0)
+
+#define AH_LAUNCH_CHECK(ctx) AH_HIP((ctx), hipGetLastError())
+
+// Grow-only scratch arena. Contents are undefined after the call.
+int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
+
+static inline int ah_type_width(int type) {
+  switch (type) {
+    case AH_UINT8: case AH_INT8: return 1;
+    case AH_UINT16: case AH_INT16: return 2;
+    case AH_UINT32: case AH_INT32: case AH_FLOAT32: return 4;
+    case AH_UINT64: case AH_INT64: case AH_FLOAT64: return 8;
+  }
+  return 0;
+}
+
+static inline int64_t ah_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers ------------------------------------------------------------
+#define AH_WAVE 64
+
+// 16-byte vector with only element alignment: lets the backend emit
+// global_load_dwordx4 on buffers that are merely element-aligned (Arrow slices:
+// &values[offset]); gfx950 runs in unaligned-access mode for global memory.
+template <typename T>
+struct alignas(sizeof(T)) ah_vec16 {
+  T v[16 / sizeof(T)];
+};
+
+template <typename T>
+__device__ __forceinline__ T ah_wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ int ah_lane() { return (int)(threadIdx.x & 63); }
+
+// Read bit i (LSB-first) of a bitmap; NULL bitmap = all ones.
+__device__ __forceinline__ int ah_bit(const uint8_t* __restrict__ bm, int64_t i) {
+  return bm == nullptr ? 1 : (bm[i >> 3] >> (i & 7)) & 1;
+}
+
+// 64 consecutive bits of a bitmap starting at absolute bit position `pos`
+// (any alignment), reading only whole 8-byte-aligned words that contain at least
+// one bit in [pos, pos + nvalid) — never touches a word outside the caller's
+// range, so it cannot fault on the last page of an allocation.  Bits past nvalid
+// are returned as 0.  NULL bitmap → all ones (masked to nvalid).
+__device__ __forceinline__ uint64_t ah_load_bits64(const uint8_t* __restrict__ bm, int64_t pos, int nvalid) {
+  uint64_t mask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1);
+  if (nvalid <= 0) return 0;
+  if (bm == nullptr) return mask;
+  uintptr_t addr = (uintptr_t)bm + (uintptr_t)(pos >> 3);
+  uintptr_t base = addr & ~(uintptr_t)7;
+  int shift = (int)((addr - base) * 8 + (pos & 7));  // 0..63
+  const uint64_t* w = (const uint64_t*)base;
+  uint64_t lo = w[0] >> shift;
+  if (shift != 0 && shift + nvalid > 64) lo |= w[1] << (64 - shift);
+  return lo & mask;
+}

@@ -1,0 +1,184 @@
+// ah_ctx.hip — context, device buffers, pinned staging, copies on a side stream.
+//
+// Reference counterpart: there is none on device; on the host the analogous pieces
+// are memory.Allocator (arrow/memory/allocator.go:23-27, 64-byte alignment :20) and
+// memory.Set (arrow/memory/_lib/memory.c:20-27).  A Go `memory.Allocator` backed by
+// ah_host_alloc_pinned gives Arrow buffers that hipMemcpyAsync can DMA directly.
+#include "ah_common.h"
+
+static const char* kVersion = "arrowhip 0.1 (gfx950)";
+
+AH_EXPORT const char* ah_version(void) { return kVersion; }
+
+AH_EXPORT int ah_device_count(int* n_host) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (n_host) *n_host = (e == hipSuccess) ? n : 0;
+  return e == hipSuccess ? AH_OK : AH_EHIP;
+}
+
+static int ctx_init_common(ah_ctx* c) {
+  AH_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  AH_HIP(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+  AH_HIP(c, hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
+  AH_HIP(c, hipEventCreate(&c->t0));
+  AH_HIP(c, hipEventCreate(&c->t1));
+  AH_HIP(c, hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
+  AH_HIP(c, hipMalloc((void**)&c->dscalars, 64 * sizeof(uint64_t)));
+  hipDeviceProp_t prop;
+  AH_HIP(c, hipGetDeviceProperties(&prop, c->device));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const char* e_nt = getenv("ARROWHIP_NT");
+  c->tune_nt = e_nt ? atoi(e_nt) : 1;
+  const char* e_bpc = getenv("ARROWHIP_BLOCKS_PER_CU");
+  c->tune_blocks_per_cu = e_bpc ? atoi(e_bpc) : 8;
+  if (c->tune_blocks_per_cu < 1) c->tune_blocks_per_cu = 1;
+  return AH_OK;
+}
+
+static int ctx_create(int device_id, void* stream, bool borrow, ah_ctx** out) {
+  if (!out) return AH_EINVALID;
+  *out = nullptr;
+  ah_ctx* c = (ah_ctx*)calloc(1, sizeof(ah_ctx));
+  if (!c) return AH_EINVALID;
+  c->device = device_id;
+  hipError_t e = hipSetDevice(device_id);
+  if (e != hipSuccess) { free(c); return AH_EHIP; }
+  if (borrow) {
+    c->stream = (hipStream_t)stream;
+    c->owns_stream = false;
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { free(c); return AH_EHIP; }
+    c->owns_stream = true;
+  }
+  int rc = ctx_init_common(c);
+  if (rc != AH_OK) { fprintf(stderr, "arrowhip: ctx init failed: %s\n", c->err); free(c); return rc; }
+  *out = c;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_ctx_create(int device_id, ah_ctx** out) { return ctx_create(device_id, nullptr, false, out); }
+AH_EXPORT int ah_ctx_create_on_stream(int device_id, void* hip_stream, ah_ctx** out) {
+  return ctx_create(device_id, hip_stream, true, out);
+}
+
+AH_EXPORT void ah_ctx_destroy(ah_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->copy_stream);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->dscalars) (void)hipFree(c->dscalars);
+  (void)hipEventDestroy(c->ev_copy);
+  (void)hipEventDestroy(c->ev_compute);
+  (void)hipEventDestroy(c->t0);
+  (void)hipEventDestroy(c->t1);
+  (void)hipStreamDestroy(c->copy_stream);
+  if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+  free(c);
+}
+
+AH_EXPORT const char* ah_last_error(ah_ctx* c) { return c ? c->err : "null context"; }
+
+int ah_scratch_reserve(ah_ctx* c, size_t nbytes, void** out) {
+  if (nbytes > c->scratch_bytes) {
+    // the old block may still be in use by enqueued kernels
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->scratch) AH_HIP(c, hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    size_t want = (nbytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    AH_HIP(c, hipMalloc(&c->scratch, want));
+    c->scratch_bytes = want;
+  }
+  *out = c->scratch;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_buf_alloc(ah_ctx* c, size_t nbytes, void** dptr_host) {
+  AH_ENTER(c);
+  if (!dptr_host) return ah_fail(c, AH_EINVALID, "ah_buf_alloc: null out pointer");
+  *dptr_host = nullptr;
+  if (nbytes == 0) nbytes = 1;
+  // keep the 64-byte padding rule of arrow/memory/buffer.go:137-146 so 16-byte
+  // vector accesses on the last elements stay in bounds
+  nbytes = (nbytes + 63) & ~(size_t)63;
+  AH_HIP(c, hipMalloc(dptr_host, nbytes));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_buf_free(ah_ctx* c, void* dptr) {
+  AH_ENTER(c);
+  if (dptr) AH_HIP(c, hipFree(dptr));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_host_alloc_pinned(ah_ctx* c, size_t nbytes, void** hptr_host) {
+  AH_ENTER(c);
+  if (!hptr_host) return ah_fail(c, AH_EINVALID, "ah_host_alloc_pinned: null out pointer");
+  if (nbytes == 0) nbytes = 1;
+  nbytes = (nbytes + 63) & ~(size_t)63;
+  AH_HIP(c, hipHostMalloc(hptr_host, nbytes, hipHostMallocDefault));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_host_free_pinned(ah_ctx* c, void* hptr) {
+  AH_ENTER(c);
+  if (hptr) AH_HIP(c, hipHostFree(hptr));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_upload_async(ah_ctx* c, void* dptr, const void* hptr, size_t nbytes) {
+  AH_ENTER(c);
+  if (nbytes == 0) return AH_OK;
+  // the copy must not overtake compute work that still reads/writes dptr
+  AH_HIP(c, hipEventRecord(c->ev_compute, c->stream));
+  AH_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute, 0));
+  AH_HIP(c, hipMemcpyAsync(dptr, hptr, nbytes, hipMemcpyHostToDevice, c->copy_stream));
+  AH_HIP(c, hipEventRecord(c->ev_copy, c->copy_stream));
+  AH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_download_async(ah_ctx* c, void* hptr, const void* dptr, size_t nbytes) {
+  AH_ENTER(c);
+  if (nbytes == 0) return AH_OK;
+  AH_HIP(c, hipEventRecord(c->ev_compute, c->stream));
+  AH_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute, 0));
+  AH_HIP(c, hipMemcpyAsync(hptr, dptr, nbytes, hipMemcpyDeviceToHost, c->copy_stream));
+  AH_HIP(c, hipEventRecord(c->ev_copy, c->copy_stream));
+  AH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_memset_async(ah_ctx* c, void* dptr, int byte_value, size_t nbytes) {
+  AH_ENTER(c);
+  if (nbytes == 0) return AH_OK;
+  AH_HIP(c, hipMemsetAsync(dptr, byte_value, nbytes, c->stream));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_sync(ah_ctx* c) {
+  AH_ENTER(c);
+  AH_HIP(c, hipStreamSynchronize(c->copy_stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_timer_start(ah_ctx* c) {
+  AH_ENTER(c);
+  AH_HIP(c, hipEventRecord(c->t0, c->stream));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_timer_stop(ah_ctx* c, float* ms_host) {
+  AH_ENTER(c);
+  AH_HIP(c, hipEventRecord(c->t1, c->stream));
+  AH_HIP(c, hipEventSynchronize(c->t1));
+  float ms = 0.f;
+  AH_HIP(c, hipEventElapsedTime(&ms, c->t0, c->t1));
+  if (ms_host) *ms_host = ms;
+  return AH_OK;
+}

@@ -1,0 +1,395 @@
+// ah_filter.hip — Filter: stable stream compaction of fixed-width values by a
+// boolean selection vector, with Arrow null semantics.
+//
+// Replaces: kernels.PrimitiveFilter (kernels/vector_selection.go:449-520) =
+//   getFilterOutputSize (:57-81) + preallocateData (:83-93) + primitiveFilterImpl
+//   (:267-395) + filterWriter (:397-421) over the bit-block counters
+//   (internal/bitutils/bit_block_counter.go:59-168,357-452), and GetTakeIndices
+//   (:102-236), behind compute's "filter"/"array_filter" (compute/selection.go:42-85,
+//   618-633).
+//
+// Payload contract (bit-exact, from reading the reference — SURVEY.md §8a a7):
+//   slot selected (filter valid ∧ true)  → value payload copied as is, out validity
+//                                           = value validity            (:293-297)
+//   filter slot null under EMIT_NULLS     → payload 0, validity 0       (:417-421)
+//   otherwise dropped; padding past n_out = 0 (fresh zeroed buffers).
+//
+// Three launches, all HBM-bound:
+//   1. tile_count_kernel  — popcount of the selection word per tile (reads only the
+//      bitmaps: n/8 bytes, 1/64 of the values)
+//   2. tile_scan_kernel   — exclusive scan of ≤ a few 10^4 tile counts, one block
+//   3. compact_kernel     — one workgroup per tile of 16 KiB of values: the tile's
+//      mask words and their running popcounts live in LDS, every lane derives the
+//      output rank of its elements with two popcounts (no ballot needed), loads its
+//      16-byte vector ONLY if it holds a survivor (so unselected 128-byte lines are
+//      never fetched), stages survivors in LDS at their rank, and the workgroup
+//      streams the staged run to HBM as aligned 16-byte stores.  The output
+//      validity word for 64 input rows is a software bit-compress (pext) of the
+//      value-validity word by the selection word, OR-ed into place.
+// Algorithmic bytes per input row (w = 8): 8 + 1/8 (+1/8 with value validity) read,
+// 8·s (+ s/8) written for selectivity s.
+#include "ah_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTileBytes = 16384;  // values staged per workgroup
+
+template <int W> struct UIntOf;
+template <> struct UIntOf<1> { using type = uint8_t; };
+template <> struct UIntOf<2> { using type = uint16_t; };
+template <> struct UIntOf<4> { using type = uint32_t; };
+template <> struct UIntOf<8> { using type = uint64_t; };
+
+// selection word for 64 consecutive rows starting at row `pos` (cnt valid rows):
+//   DROP: data ∧ valid          EMIT: data ∨ ¬valid  (vector_selection.go:66-77)
+__device__ __forceinline__ uint64_t sel_word(const uint8_t* __restrict__ fdata, const uint8_t* __restrict__ fvalid,
+                                             int64_t foff, int64_t pos, int cnt, int null_sel, uint64_t* fv_out) {
+  uint64_t mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
+  uint64_t fd = ah_load_bits64(fdata, foff + pos, cnt);
+  uint64_t fv = ah_load_bits64(fvalid, foff + pos, cnt);  // NULL → all ones
+  if (fv_out) *fv_out = fv;
+  return (null_sel == AH_EMIT_NULLS ? (fd | ~fv) : (fd & fv)) & mask;
+}
+
+// Hacker's Delight 7-4 "compress" (software pext): gather the bits of x selected
+// by m into the low popcount(m) bits, order preserved.
+__device__ __forceinline__ uint64_t bit_compress(uint64_t x, uint64_t m) {
+  x &= m;
+  uint64_t mk = ~m << 1;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    uint64_t mp = mk ^ (mk << 1);
+    mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16; mp ^= mp << 32;
+    uint64_t mv = mp & m;
+    m = (m ^ mv) | (mv >> (1 << i));
+    uint64_t t = x & mv;
+    x = (x ^ t) | (t >> (1 << i));
+    mk &= ~mp;
+  }
+  return x;
+}
+
+// exclusive scan of one int per thread across a 256-thread block
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+  __shared__ int wave_tot[kBlock / 64];
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; k++) {
+    int t = wave_tot[k];
+    if (k < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + inc - v;
+}
+
+// ---- 1. per-tile survivor counts -------------------------------------------------
+template <int WPT /*mask words per tile*/>
+__global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __restrict__ fdata, const uint8_t* __restrict__ fvalid,
+                                                             int64_t foff, int64_t n, int null_sel, int* __restrict__ counts,
+                                                             int64_t ntiles) {
+  // each block covers kBlock mask words = kBlock / WPT tiles
+  int64_t word = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t pos = word * 64;
+  int cnt = pos >= n ? 0 : (n - pos >= 64 ? 64 : (int)(n - pos));
+  int v = cnt > 0 ? __popcll(sel_word(fdata, fvalid, foff, pos, cnt, null_sel, nullptr)) : 0;
+  constexpr int SEG = WPT < 64 ? WPT : 64;
+#pragma unroll
+  for (int o = SEG / 2; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if (WPT <= 64) {
+    if ((threadIdx.x % WPT) == 0) {
+      int64_t tile = word / WPT;
+      if (tile < ntiles) counts[tile] = v;
+    }
+  } else {
+    __shared__ int sm[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    constexpr int WAVES_PER_TILE = WPT / 64;
+    if (threadIdx.x < kBlock / WPT) {
+      int s = 0;
+      for (int k = 0; k < WAVES_PER_TILE; k++) s += sm[threadIdx.x * WAVES_PER_TILE + k];
+      int64_t tile = (int64_t)blockIdx.x * (kBlock / WPT) + threadIdx.x;
+      if (tile < ntiles) counts[tile] = s;
+    }
+  }
+}
+
+// ---- 2. exclusive scan of tile counts (one block of 1024) --------------------------
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const int* __restrict__ counts, int64_t ntiles,
+                                                          int64_t* __restrict__ offsets, int64_t* __restrict__ total) {
+  __shared__ int64_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t chunk = (ntiles + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; i++) s += counts[i];
+  int64_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int64_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int64_t base = 0, tot = 0;
+  for (int k = 0; k < 16; k++) {
+    int64_t t = wave_tot[k];
+    if (k < wave) base += t;
+    tot += t;
+  }
+  int64_t run = base + inc - s;
+  for (int64_t i = lo; i < hi; i++) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+  if (tid == 0) *total = tot;
+}
+
+// ---- 3. compaction -------------------------------------------------------------------
+// W: value byte width.  HAS_VALID: an output validity bitmap exists (some input has
+// nulls).  INDICES: payload is the row number (GetTakeIndices), values unused.
+template <int W, bool HAS_VALID, bool INDICES>
+__global__ __launch_bounds__(kBlock) void compact_kernel(const void* __restrict__ values_v, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                          const uint8_t* __restrict__ fdata, const uint8_t* __restrict__ fvalid,
+                                                          int64_t foff, int64_t n, int null_sel,
+                                                          const int64_t* __restrict__ offsets,
+                                                          void* __restrict__ out_v, uint8_t* __restrict__ out_valid,
+                                                          unsigned long long* __restrict__ valid_total) {
+  using T = typename UIntOf<W>::type;
+  constexpr int V = 16 / W;               // elements per 16-byte vector
+  constexpr int TILE = kTileBytes / W;    // rows per tile
+  constexpr int WPT = TILE / 64;          // mask words per tile
+  constexpr int VPT = TILE / V;           // vectors per tile (= 1024)
+  constexpr int K = VPT / kBlock;         // vectors per lane (= 4)
+  static_assert(WPT <= kBlock, "one lane per mask word");
+
+  __shared__ __attribute__((aligned(16))) T stage[TILE];
+  __shared__ uint64_t s_sel[WPT], s_nullsel[WPT], s_obits[WPT + 1];
+  __shared__ int s_prefix[WPT];
+  __shared__ int s_nvalid;
+
+  const T* __restrict__ values = (const T*)values_v;
+  T* __restrict__ out = (T*)out_v;
+  const int64_t tile = blockIdx.x;
+  const int64_t b = tile * TILE;  // first row of the tile
+  const int tid = threadIdx.x;
+
+  // -- A: mask words, running popcounts, output validity bits
+  uint64_t sel = 0, vsrc = 0, fvw = ~0ull;
+  int cnt = 0;
+  if (tid < WPT) {
+    int64_t pos = b + (int64_t)tid * 64;
+    cnt = pos >= n ? 0 : (n - pos >= 64 ? 64 : (int)(n - pos));
+    if (cnt > 0) {
+      sel = sel_word(fdata, fvalid, foff, pos, cnt, null_sel, &fvw);
+      if (HAS_VALID) vsrc = sel & fvw & ah_load_bits64(INDICES ? nullptr : vvalid, voff + pos, cnt);
+    }
+    s_sel[tid] = sel;
+    s_nullsel[tid] = sel & ~fvw;  // selected only because the filter slot is null (EMIT)
+    s_obits[tid] = 0;
+  }
+  if (tid == 0) { s_obits[WPT] = 0; s_nvalid = 0; }
+  int tile_count;
+  int prefix = block_exclusive_scan(tid < WPT ? __popcll(sel) : 0, &tile_count);  // contains __syncthreads
+  if (tid < WPT) s_prefix[tid] = prefix;
+  if (HAS_VALID && tid < WPT && sel) {
+    uint64_t ob = bit_compress(vsrc, sel);
+    int c = __popcll(sel), w0 = prefix >> 6, sh = prefix & 63;
+    if (ob) {
+      atomicOr((unsigned long long*)&s_obits[w0], (unsigned long long)(ob << sh));
+      if (sh && sh + c > 64) atomicOr((unsigned long long*)&s_obits[w0 + 1], (unsigned long long)(ob >> (64 - sh)));
+      atomicAdd(&s_nvalid, __popcll(ob));
+    }
+  }
+  __syncthreads();
+  if (tile_count == 0) return;
+
+  // -- B: gather survivors into LDS at their rank
+  const int64_t rows_left = n - b;  // > 0
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int q = k * kBlock + tid;  // vector index inside the tile
+    const int e0 = q * V;            // first row of the vector inside the tile
+    const uint64_t word = s_sel[e0 >> 6];
+    const int sh = e0 & 63;
+    const unsigned bits = (unsigned)((word >> sh) & ((1u << V) - 1));
+    if (bits == 0) continue;         // nothing selected here: the line is never fetched
+    const unsigned nbits = (unsigned)((s_nullsel[e0 >> 6] >> sh) & ((1u << V) - 1));
+    int rank = s_prefix[e0 >> 6] + __popcll(word & ((1ull << sh) - 1));
+    T v[V];
+    if (INDICES) {
+#pragma unroll
+      for (int e = 0; e < V; e++) v[e] = (T)(b + e0 + e);
+    } else if (e0 + V <= rows_left) {
+      ah_vec16<T> x = *(const ah_vec16<T>*)(values + b + e0);
+#pragma unroll
+      for (int e = 0; e < V; e++) v[e] = x.v[e];
+    } else {  // ragged end of the column: stay in bounds
+#pragma unroll
+      for (int e = 0; e < V; e++) v[e] = (e0 + e < rows_left) ? values[b + e0 + e] : (T)0;
+    }
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      if (bits & (1u << e)) {
+        stage[rank] = (nbits & (1u << e)) ? (T)0 : v[e];
+        rank++;
+      }
+    }
+  }
+  __syncthreads();
+
+  // -- C: stream the staged run out (16-byte aligned body, element head/tail)
+  const int64_t obase = offsets[tile];
+  T* dst = out + obase;
+  int head = (int)(((16 - ((uintptr_t)dst & 15)) & 15) / W);
+  if (head > tile_count) head = tile_count;
+  const int nvec = (tile_count - head) / V;
+  const int tail0 = head + nvec * V;
+  if (tid < head) dst[tid] = stage[tid];
+  for (int i = tid; i < nvec; i += kBlock) {
+    ah_vec16<T> x;
+#pragma unroll
+    for (int e = 0; e < V; e++) x.v[e] = stage[head + i * V + e];
+    *(ah_vec16<T>*)(dst + head + i * V) = x;
+  }
+  if (tid < tile_count - tail0) dst[tail0 + tid] = stage[tail0 + tid];
+
+  if (HAS_VALID) {
+    // output validity bits [obase, obase + tile_count): OR 64-bit chunks into place
+    uintptr_t vaddr = (uintptr_t)out_valid;
+    unsigned long long* vbase = (unsigned long long*)(vaddr & ~(uintptr_t)7);
+    const int64_t bit0 = (int64_t)(vaddr & 7) * 8 + obase;
+    const int nchunks = (tile_count + 63) >> 6;
+    for (int i = tid; i < nchunks; i += kBlock) {
+      uint64_t chunk = s_obits[i];
+      if (!chunk) continue;
+      int64_t g = bit0 + (int64_t)i * 64;
+      int64_t w0 = g >> 6;
+      int sh = (int)(g & 63);
+      atomicOr(&vbase[w0], (unsigned long long)(chunk << sh));
+      if (sh) {
+        uint64_t hi = chunk >> (64 - sh);
+        if (hi) atomicOr(&vbase[w0 + 1], (unsigned long long)hi);
+      }
+    }
+    if (tid == 0 && s_nvalid) atomicAdd(valid_total, (unsigned long long)s_nvalid);
+  }
+}
+
+template <int W>
+int run_counts(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+               int** counts_out, int64_t** offsets_out, int64_t** total_out, int64_t* ntiles_out) {
+  constexpr int TILE = kTileBytes / W;
+  constexpr int WPT = TILE / 64;
+  int64_t ntiles = ah_ceil_div(n, TILE);
+  // scratch layout: offsets[ntiles] (int64) | counts[ntiles] (int) ; total lives in dscalars[1]
+  size_t bytes = (size_t)ntiles * sizeof(int64_t) + (size_t)ntiles * sizeof(int) + 64;
+  void* scratch;
+  int rc = ah_scratch_reserve(c, bytes, &scratch);
+  if (rc != AH_OK) return rc;
+  int64_t* offsets = (int64_t*)scratch;
+  int* counts = (int*)(offsets + ntiles);
+  int64_t* total = (int64_t*)&c->dscalars[1];
+  int64_t nwords = ah_ceil_div(n, 64);
+  unsigned grid = (unsigned)ah_ceil_div(nwords, kBlock);
+  tile_count_kernel<WPT><<<grid, kBlock, 0, c->stream>>>(fdata, fvalid, foff, n, null_sel, counts, ntiles);
+  AH_LAUNCH_CHECK(c);
+  tile_scan_kernel<<<1, 1024, 0, c->stream>>>(counts, ntiles, offsets, total);
+  AH_LAUNCH_CHECK(c);
+  *counts_out = counts; *offsets_out = offsets; *total_out = total; *ntiles_out = ntiles;
+  return AH_OK;
+}
+
+template <int W, bool INDICES>
+int run_filter(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t voff, const uint8_t* fdata,
+               const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel, int64_t n_out, void* out_values,
+               uint8_t* out_valid, int64_t* out_null_count_host) {
+  int* counts; int64_t* offsets; int64_t* total; int64_t ntiles;
+  int rc = run_counts<W>(c, fdata, fvalid, foff, n, null_sel, &counts, &offsets, &total, &ntiles);
+  if (rc != AH_OK) return rc;
+  unsigned long long* valid_total = (unsigned long long*)&c->dscalars[2];
+  if (out_valid) {
+    if (n_out < 0) return ah_fail(c, AH_EINVALID, "filter: n_out (from ah_filter_count) is required with a validity output");
+    AH_HIP(c, hipMemsetAsync(out_valid, 0, (size_t)((n_out + 7) / 8), c->stream));
+    AH_HIP(c, hipMemsetAsync(valid_total, 0, sizeof(*valid_total), c->stream));
+    compact_kernel<W, true, INDICES><<<(unsigned)ntiles, kBlock, 0, c->stream>>>(values, vvalid, voff, fdata, fvalid, foff, n, null_sel,
+                                                                                 offsets, out_values, out_valid, valid_total);
+  } else {
+    compact_kernel<W, false, INDICES><<<(unsigned)ntiles, kBlock, 0, c->stream>>>(values, vvalid, voff, fdata, fvalid, foff, n, null_sel,
+                                                                                  offsets, out_values, nullptr, valid_total);
+  }
+  AH_LAUNCH_CHECK(c);
+  if (out_null_count_host) {
+    AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[1], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    int64_t tot = (int64_t) * (volatile uint64_t*)&c->pinned[0];
+    int64_t nvalid = (int64_t) * (volatile uint64_t*)&c->pinned[1];
+    if (n_out >= 0 && tot != n_out)
+      return ah_fail(c, AH_EINVALID, "filter: n_out=%lld does not match the selection count %lld", (long long)n_out, (long long)tot);
+    *out_null_count_host = out_valid ? tot - nvalid : 0;
+  }
+  return AH_OK;
+}
+
+}  // namespace
+
+AH_EXPORT int ah_filter_count(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,
+                              int null_sel, int64_t* n_out_host) {
+  AH_ENTER(c);
+  if (!n_out_host) return ah_fail(c, AH_EINVALID, "filter_count: null result pointer");
+  if (n < 0 || foff < 0) return ah_fail(c, AH_EINVALID, "filter_count: negative length/offset");
+  *n_out_host = 0;
+  if (n == 0) return AH_OK;
+  if (!fdata) return ah_fail(c, AH_EINVALID, "filter_count: null filter data");
+  int* counts; int64_t* offsets; int64_t* total; int64_t ntiles;
+  int rc = run_counts<8>(c, fdata, fvalid, foff, n, null_sel, &counts, &offsets, &total, &ntiles);
+  if (rc != AH_OK) return rc;
+  AH_HIP(c, hipMemcpyAsync(c->pinned, total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  *n_out_host = (int64_t) * (volatile uint64_t*)c->pinned;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_filter_primitive(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                                  const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                                  int64_t n_out, void* out_values, uint8_t* out_valid, int64_t* out_null_count_host) {
+  AH_ENTER(c);
+  if (n < 0 || foff < 0 || voff < 0) return ah_fail(c, AH_EINVALID, "filter: negative length/offset");
+  if (out_null_count_host) *out_null_count_host = 0;
+  if (n == 0) return AH_OK;
+  if (!fdata || !values) return ah_fail(c, AH_EINVALID, "filter: null input buffer");
+  if (((uintptr_t)values | (uintptr_t)out_values) & (uintptr_t)(byte_width - 1))
+    return ah_fail(c, AH_EINVALID, "filter: buffer not element-aligned");
+  switch (byte_width) {
+    case 1: return run_filter<1, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
+    case 2: return run_filter<2, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
+    case 4: return run_filter<4, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
+    case 8: return run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
+  }
+  return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);  // vector_selection.go:515
+}
+
+AH_EXPORT int ah_filter_to_indices(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,
+                                   int null_sel, int64_t n_out, uint32_t* out_idx, uint8_t* out_valid,
+                                   int64_t* out_null_count_host) {
+  AH_ENTER(c);
+  if (n < 0 || foff < 0) return ah_fail(c, AH_EINVALID, "filter_to_indices: negative length/offset");
+  if (out_null_count_host) *out_null_count_host = 0;
+  if (n == 0) return AH_OK;
+  if (n >= 0xFFFFFFFFll)  // vector_selection.go:229-235
+    return ah_fail(c, AH_ENOTIMPL, "filter length exceeds UINT32_MAX, consider a different strategy for selecting elements");
+  if (!fdata) return ah_fail(c, AH_EINVALID, "filter_to_indices: null filter data");
+  return run_filter<4, true>(c, nullptr, nullptr, 0, fdata, fvalid, foff, n, null_sel, n_out, out_idx, out_valid, out_null_count_host);
+}

@@ -1,0 +1,358 @@
+// ah_hash.hip — unique / dictionary_encode / group-by-sum over 8-byte keys.
+//
+// Replaces: doAppendNumeric[uint64] (kernels/vector_hash.go:359-385) driving
+//   hashing.Table[uint64].InsertOrGet / GetOrInsertNull
+//   (internal/hashing/xxh3_memo_table_types.go:231-238,283-294; open-addressing table
+//   :45-187; hashInt internal/hashing/hash_funcs.go:60-67), the
+//   dictionaryEncodeAction (vector_hash.go:145-241) and uniqueFinalize (:721-741),
+//   behind compute's "unique" / "dictionary_encode" (compute/vector_hash.go:61,79).
+//   Int64 and Float64 columns both hash raw 64-bit patterns (vector_hash.go:604-607).
+//
+// The reference is strictly sequential: memo index = order of first insertion.  The
+// same ids are produced in parallel as follows:
+//   1. insert_kernel  — every row CASes its key into an open-addressing table keyed
+//      by the reference's hashInt (linear probing; 16-byte slots {key, first_row,
+//      id}) and atomicMin's its row number into the slot: first_row = first
+//      occurrence.  The all-ones key (the table's EMPTY marker) and the null key live
+//      in two dedicated slots past the end.  Plain loads short-circuit both atomics
+//      once a slot is settled, so low-cardinality columns do not serialise on L2.
+//   2. mark_kernel    — each used slot sets bit first_row in an n-bit "first
+//      occurrence" bitmap.
+//   3. rank kernels   — prefix popcount of that bitmap (per-64-row word prefixes inside
+//      2048-row tiles + one scan of tile totals): the number of first occurrences
+//      before row r IS the sequential memo index of the key first seen at row r.
+//   4. assign_kernel  — each used slot computes its id from (3) and writes its key to
+//      dict[id].
+//   5. emit_kernel    — out_ids[i] = id of row i's slot (remembered in step 1).
+// If more than cap/2 distinct keys show up the attempt is abandoned and repeated
+// with a 16× larger table (the reference grows ×4 at the same load factor,
+// xxh3_memo_table_types.go:109,169-179); results never depend on the capacity.
+//
+// HBM: 8 B/row of keys + random 16-byte slot traffic (atomics-bound at high
+// cardinality, cache-resident at low cardinality).
+#include "ah_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr unsigned long long kEmpty = ~0ull;
+constexpr unsigned kNoRow = ~0u;
+
+struct Slot {
+  unsigned long long key;
+  unsigned first_row;
+  unsigned id;
+};
+
+__device__ __forceinline__ uint64_t hash_int(uint64_t v) {  // hash_funcs.go:60-67, alg 0
+  return __builtin_bswap64(11400714785074694791ull * v);
+}
+
+// status words in dscalars: [4] distinct count, [5] overflow flag, [6] total ids
+__global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+                                                         int64_t off, int64_t n, int encode_nulls, Slot* __restrict__ table,
+                                                         uint64_t cap, unsigned* __restrict__ row_slot,
+                                                         unsigned long long* __restrict__ distinct, unsigned* __restrict__ overflow) {
+  const uint64_t mask = cap - 1;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (*(volatile unsigned*)overflow) return;
+    uint64_t s;
+    if (ah_bit(valid, off + i)) {
+      unsigned long long k = keys[i];
+      if (k == kEmpty) {
+        s = cap;
+      } else {
+        uint64_t idx = hash_int(k) & mask;
+        int probes = 0;
+        for (;;) {
+          unsigned long long cur = table[idx].key;  // plain load: settled slots skip the CAS
+          if (cur != k) {
+            if (cur == kEmpty) {
+              cur = atomicCAS(&table[idx].key, kEmpty, k);
+              if (cur == kEmpty) {
+                unsigned long long d = atomicAdd(distinct, 1ull) + 1;
+                if (d > cap / 2) { atomicExch(overflow, 1u); return; }
+                cur = k;
+              }
+            }
+          }
+          if (cur == k) break;
+          idx = (idx + 1) & mask;
+          if (++probes > 1 << 16) { atomicExch(overflow, 1u); return; }
+        }
+        s = idx;
+      }
+    } else if (encode_nulls) {
+      s = cap + 1;
+    } else {
+      if (row_slot) row_slot[i] = kNoRow;
+      continue;
+    }
+    if (table[s].first_row > (unsigned)i) atomicMin(&table[s].first_row, (unsigned)i);
+    if (row_slot) row_slot[i] = (unsigned)s;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void mark_kernel(const Slot* __restrict__ table, uint64_t nslots,
+                                                       unsigned long long* __restrict__ firsts) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
+    unsigned fr = table[s].first_row;
+    if (fr != kNoRow) atomicOr(&firsts[fr >> 6], 1ull << (fr & 63));
+  }
+}
+
+// per word: exclusive popcount prefix INSIDE its 32-word tile; per tile: total
+__global__ __launch_bounds__(kBlock) void word_prefix_kernel(const unsigned long long* __restrict__ firsts, int64_t nwords,
+                                                              unsigned* __restrict__ wordprefix, int* __restrict__ tilecnt) {
+  int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int lane32 = threadIdx.x & 31;
+  int v = w < nwords ? __popcll(firsts[w]) : 0;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane32 >= o) inc += t;
+  }
+  if (w < nwords) wordprefix[w] = (unsigned)(inc - v);
+  if (lane32 == 31 || w == nwords - 1) {
+    if (w < nwords) tilecnt[w >> 5] = inc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ counts, int64_t ntiles,
+                                                     int64_t* __restrict__ offsets, unsigned long long* __restrict__ total) {
+  __shared__ int64_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t chunk = (ntiles + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; i++) s += counts[i];
+  int64_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int64_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int64_t base = 0, tot = 0;
+  for (int k = 0; k < 16; k++) {
+    int64_t t = wave_tot[k];
+    if (k < wave) base += t;
+    tot += t;
+  }
+  int64_t run = base + inc - s;
+  for (int64_t i = lo; i < hi; i++) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+  if (tid == 0) *total = (unsigned long long)tot;
+}
+
+__device__ __forceinline__ unsigned rank_of_row(unsigned fr, const unsigned long long* __restrict__ firsts,
+                                                const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff) {
+  unsigned w = fr >> 6;
+  unsigned long long below = firsts[w] & ((1ull << (fr & 63)) - 1);
+  return (unsigned)(tileoff[w >> 5] + wordprefix[w] + __popcll(below));
+}
+
+__global__ __launch_bounds__(kBlock) void assign_kernel(Slot* __restrict__ table, uint64_t cap, const unsigned long long* __restrict__ firsts,
+                                                         const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff,
+                                                         unsigned long long* __restrict__ dict, int* __restrict__ null_id) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const uint64_t nslots = cap + 2;
+  for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
+    unsigned fr = table[s].first_row;
+    if (fr == kNoRow) continue;
+    unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
+    table[s].id = id;
+    if (s == cap + 1) {
+      *null_id = (int)id;
+      if (dict) dict[id] = 0;  // GetDictArrayData: the null slot keeps the fresh buffer's zero
+    } else if (dict) {
+      dict[id] = table[s].key;  // slot `cap` holds the all-ones key: key field is still kEmpty == that key
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void emit_kernel(const Slot* __restrict__ table, int32_t* __restrict__ ids, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    unsigned s = (unsigned)ids[i];
+    ids[i] = s == kNoRow ? 0 : (int32_t)table[s].id;  // masked null → index 0 (vector_hash.go:169-172)
+  }
+}
+
+template <typename VT, typename AT>
+__global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __restrict__ ids, const VT* __restrict__ vals,
+                                                            const uint8_t* __restrict__ vvalid, int64_t voff, int64_t n,
+                                                            AT* __restrict__ sums, unsigned long long* __restrict__ counts) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (!ah_bit(vvalid, voff + i)) continue;
+    int32_t g = ids[i];
+    atomicAdd(&sums[g], (AT)vals[i]);
+    atomicAdd(&counts[g], 1ull);
+  }
+}
+
+static uint64_t next_pow2_u64(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+struct EncodeResult {
+  int64_t ndict;
+  int32_t null_id;
+};
+
+// core: ids (optional, n int32), dict (optional), returns sizes.  Device pointers.
+int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
+                int32_t* out_ids, uint64_t* out_dict, EncodeResult* res) {
+  res->ndict = 0;
+  res->null_id = -1;
+  if (n == 0) return AH_OK;
+  if (n >= 0xFFFFFFFFll) return ah_fail(c, AH_ENOTIMPL, "hash: more than 2^32-2 rows per call");
+  const int64_t nwords = ah_ceil_div(n, 64);
+  const int64_t ntiles = ah_ceil_div(nwords, 32);
+  const uint64_t cap_max = next_pow2_u64((uint64_t)n * 2 < 64 ? 64 : (uint64_t)n * 2);
+  uint64_t cap = cap_max < ((uint64_t)1 << 22) ? cap_max : ((uint64_t)1 << 22);
+  unsigned long long* distinct = (unsigned long long*)&c->dscalars[4];
+  unsigned* overflow = (unsigned*)&c->dscalars[5];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[6];
+  int* null_id = (int*)&c->dscalars[7];
+  for (;;) {
+    // scratch: table | firsts | wordprefix | tilecnt | tileoff
+    size_t table_bytes = (size_t)(cap + 2) * sizeof(Slot);
+    size_t firsts_bytes = (size_t)nwords * 8;
+    size_t wp_bytes = ((size_t)nwords * 4 + 7) & ~(size_t)7;
+    size_t tc_bytes = ((size_t)ntiles * 4 + 7) & ~(size_t)7;
+    size_t to_bytes = (size_t)ntiles * 8;
+    void* scratch;
+    int rc = ah_scratch_reserve(c, table_bytes + firsts_bytes + wp_bytes + tc_bytes + to_bytes + 64, &scratch);
+    if (rc != AH_OK) return rc;
+    Slot* table = (Slot*)scratch;
+    unsigned long long* firsts = (unsigned long long*)((uint8_t*)scratch + table_bytes);
+    unsigned* wordprefix = (unsigned*)((uint8_t*)firsts + firsts_bytes);
+    int* tilecnt = (int*)((uint8_t*)wordprefix + wp_bytes);
+    int64_t* tileoff = (int64_t*)((uint8_t*)tilecnt + tc_bytes);
+
+    AH_HIP(c, hipMemsetAsync(table, 0xFF, table_bytes, c->stream));
+    AH_HIP(c, hipMemsetAsync(&c->dscalars[4], 0, 3 * sizeof(uint64_t), c->stream));
+    AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+    unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock));
+    insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, n, encode_nulls, table, cap,
+                                                  (unsigned*)out_ids, distinct, overflow);
+    AH_LAUNCH_CHECK(c);
+    AH_HIP(c, hipMemcpyAsync(c->pinned, overflow, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (*(volatile unsigned*)c->pinned) {
+      if (cap >= cap_max) return ah_fail(c, AH_EINVALID, "hash: table overflow at maximum capacity (internal error)");
+      cap = cap * 16 < cap_max ? cap * 16 : cap_max;
+      continue;
+    }
+    AH_HIP(c, hipMemsetAsync(firsts, 0, firsts_bytes, c->stream));
+    mark_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(table, cap + 2, firsts);
+    AH_LAUNCH_CHECK(c);
+    word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+    AH_LAUNCH_CHECK(c);
+    scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, ntiles, tileoff, total);
+    AH_LAUNCH_CHECK(c);
+    assign_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(
+        table, cap, firsts, wordprefix, tileoff, (unsigned long long*)out_dict, null_id);
+    AH_LAUNCH_CHECK(c);
+    if (out_ids) {
+      emit_kernel<<<grid, kBlock, 0, c->stream>>>(table, out_ids, n);
+      AH_LAUNCH_CHECK(c);
+    }
+    AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[6], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    res->ndict = (int64_t) * (volatile uint64_t*)&c->pinned[0];
+    res->null_id = *(volatile int32_t*)&c->pinned[1];
+    return AH_OK;
+  }
+}
+
+template <typename VT, typename AT>
+int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const VT* vals, const uint8_t* vvalid,
+             int64_t voff, int64_t n, uint64_t* out_keys, AT* out_sums, int64_t* out_counts, int64_t* out_ngroups_host,
+             int32_t* out_null_group_host) {
+  if (n < 0 || koff < 0 || voff < 0) return ah_fail(c, AH_EINVALID, "hash_sum: negative length/offset");
+  if (out_ngroups_host) *out_ngroups_host = 0;
+  if (out_null_group_host) *out_null_group_host = -1;
+  if (n == 0) return AH_OK;
+  if (!keys || !vals || !out_keys || !out_sums || !out_counts) return ah_fail(c, AH_EINVALID, "hash_sum: null buffer");
+  // dense group ids need a temporary int32 per row
+  int32_t* ids = nullptr;
+  AH_HIP(c, hipMalloc((void**)&ids, (size_t)n * sizeof(int32_t)));
+  EncodeResult res;
+  int rc = encode_core(c, keys, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res);
+  if (rc == AH_OK) {
+    hipError_t e1 = hipMemsetAsync(out_sums, 0, (size_t)res.ndict * sizeof(AT), c->stream);
+    hipError_t e2 = hipMemsetAsync(out_counts, 0, (size_t)res.ndict * sizeof(int64_t), c->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: memset failed");
+  }
+  if (rc == AH_OK) {
+    unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock));
+    group_sum_kernel<VT, AT><<<grid, kBlock, 0, c->stream>>>(ids, vals, vvalid, voff, n, out_sums, (unsigned long long*)out_counts);
+    if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
+  }
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(ids);
+  if (rc != AH_OK) return rc;
+  if (out_ngroups_host) *out_ngroups_host = res.ndict;
+  if (out_null_group_host) *out_null_group_host = res.null_id;
+  return AH_OK;
+}
+
+}  // namespace
+
+AH_EXPORT int ah_hash_u64_encode(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n,
+                                 int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, uint64_t* out_dict,
+                                 int64_t* out_ndict_host, int32_t* out_null_id_host) {
+  AH_ENTER(c);
+  if (n < 0 || off < 0) return ah_fail(c, AH_EINVALID, "hash: negative length/offset");
+  if (out_ndict_host) *out_ndict_host = 0;
+  if (out_null_id_host) *out_null_id_host = -1;
+  if (n == 0) return AH_OK;
+  if (!keys) return ah_fail(c, AH_EINVALID, "hash: null keys");
+  EncodeResult res;
+  int rc = encode_core(c, keys, valid, off, n, encode_nulls, out_ids, out_dict, &res);
+  if (rc != AH_OK) return rc;
+  if (out_ids_valid) {
+    // indices validity: all set when nulls are encoded (or there is no validity);
+    // otherwise the input validity (NullEncodingMask, vector_hash.go:224-230)
+    if (valid && !encode_nulls) rc = ah_copy_bitmap(c, valid, off, n, out_ids_valid, 0, 0);
+    else {
+      AH_HIP(c, hipMemsetAsync(out_ids_valid, 0, (size_t)((n + 7) / 8), c->stream));
+      rc = ah_set_bits_to(c, out_ids_valid, 0, n, 1);
+    }
+    if (rc != AH_OK) return rc;
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  if (out_ndict_host) *out_ndict_host = res.ndict;
+  if (out_null_id_host) *out_null_id_host = res.null_id;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_hash_sum_f64(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
+                              const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
+                              uint64_t* out_keys, double* out_sums, int64_t* out_counts,
+                              int64_t* out_ngroups_host, int32_t* out_null_group_host) {
+  AH_ENTER(c);
+  return hash_sum<double, double>(c, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts,
+                                  out_ngroups_host, out_null_group_host);
+}
+
+AH_EXPORT int ah_hash_sum_i64(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
+                              const int64_t* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
+                              uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                              int64_t* out_ngroups_host, int32_t* out_null_group_host) {
+  AH_ENTER(c);
+  return hash_sum<unsigned long long, unsigned long long>(c, keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff, n,
+                                                          out_keys, (unsigned long long*)out_sums, out_counts, out_ngroups_host,
+                                                          out_null_group_host);
+}

@@ -1,0 +1,274 @@
+"""Thin host-side handles over the C ABI: a context, device buffers, and one Python
+method per leaf entry point taking DeviceBuffer / raw device pointers.
+
+Harness-level plumbing used by tests/, bench.py and the array-level layer in
+arrow_go_amd.compute; it adds no semantics of its own.  Everything executes in
+libarrowhip.so on the GPU — there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _native as N
+from ._native import lib, check
+
+
+def _ptr(x) -> Optional[int]:
+    """device pointer of a DeviceBuffer / DevicePtr / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    return int(x)
+
+
+class DeviceBuffer:
+    """A device allocation owned by a Context (ah_buf_alloc / ah_buf_free)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.handle, lib.ah_buf_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def at(self, byte_offset: int) -> int:
+        return self.ptr + int(byte_offset)
+
+    def upload(self, arr: np.ndarray, byte_offset: int = 0) -> "DeviceBuffer":
+        a = np.ascontiguousarray(arr)
+        assert byte_offset + a.nbytes <= max(self.nbytes, 1), "upload out of range"
+        if a.nbytes:
+            check(self.ctx.handle, lib.ah_upload_async(self.ctx.handle, self.ptr + byte_offset, a.ctypes.data, a.nbytes))
+            self.ctx.sync()  # `a` may be a temporary
+        return self
+
+    def download(self, dtype, count: int, byte_offset: int = 0) -> np.ndarray:
+        out = np.empty(int(count), dtype=dtype)
+        if out.nbytes:
+            check(self.ctx.handle, lib.ah_download_async(self.ctx.handle, out.ctypes.data, self.ptr + byte_offset, out.nbytes))
+            self.ctx.sync()
+        return out
+
+    def memset(self, byte_value: int, nbytes: Optional[int] = None, byte_offset: int = 0) -> None:
+        check(self.ctx.handle, lib.ah_memset_async(self.ctx.handle, self.ptr + byte_offset, byte_value,
+                                                   self.nbytes if nbytes is None else nbytes))
+
+    def free(self) -> None:
+        if self.ptr:
+            lib.ah_buf_free(self.ctx.handle, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """ah_ctx: one GPU, a compute stream and a copy stream."""
+
+    def __init__(self, device_id: int = 0, stream: Optional[int] = None):
+        h = C.c_void_p()
+        if stream is None:
+            st = lib.ah_ctx_create(device_id, C.byref(h))
+        else:
+            st = lib.ah_ctx_create_on_stream(device_id, C.c_void_p(stream), C.byref(h))
+        if st != N.AH_OK:
+            raise N.ErrHip(f"ah_ctx_create(device={device_id}) failed with status {st}: is a GPU visible?")
+        self.handle = h
+        self.device_id = device_id
+
+    # ---- lifecycle / memory ---------------------------------------------------------
+    def close(self) -> None:
+        if self.handle:
+            lib.ah_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self) -> None:
+        check(self.handle, lib.ah_sync(self.handle))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr: np.ndarray, pad: int = 0) -> DeviceBuffer:
+        a = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, a.nbytes + pad).upload(a)
+
+    def timer_start(self) -> None:
+        check(self.handle, lib.ah_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(self.handle, lib.ah_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # ---- arrow/math Sum -----------------------------------------------------------------
+    def sum_float64(self, buf, n: int) -> float:
+        r = C.c_double()
+        check(self.handle, lib.ah_sum_float64(self.handle, _ptr(buf), n, C.byref(r)))
+        return r.value
+
+    def sum_int64(self, buf, n: int) -> int:
+        r = C.c_int64()
+        check(self.handle, lib.ah_sum_int64(self.handle, _ptr(buf), n, C.byref(r)))
+        return r.value
+
+    def sum_uint64(self, buf, n: int) -> int:
+        r = C.c_uint64()
+        check(self.handle, lib.ah_sum_uint64(self.handle, _ptr(buf), n, C.byref(r)))
+        return r.value
+
+    def sum_float64_dev(self, buf, n: int, res_dev) -> None:
+        check(self.handle, lib.ah_sum_float64_dev(self.handle, _ptr(buf), n, _ptr(res_dev)))
+
+    def sum_int64_dev(self, buf, n: int, res_dev) -> None:
+        check(self.handle, lib.ah_sum_int64_dev(self.handle, _ptr(buf), n, _ptr(res_dev)))
+
+    # ---- arithmetic ---------------------------------------------------------------------
+    def arithmetic(self, type_id: int, op: int, shape: int, l, r, out, n: int) -> None:
+        """l / r: device pointer, or (for the scalar side of AS / SA) a numpy scalar array."""
+        if shape == N.SHAPE_AA:
+            st = lib.ah_arithmetic_binary(self.handle, type_id, op, _ptr(l), _ptr(r), _ptr(out), n)
+        elif shape == N.SHAPE_AS:
+            s = np.ascontiguousarray(r)
+            st = lib.ah_arithmetic_arr_scalar(self.handle, type_id, op, _ptr(l), s.ctypes.data, _ptr(out), n)
+        else:
+            s = np.ascontiguousarray(l)
+            st = lib.ah_arithmetic_scalar_arr(self.handle, type_id, op, s.ctypes.data, _ptr(r), _ptr(out), n)
+        check(self.handle, st)
+
+    def arithmetic_unary(self, type_id: int, op: int, inp, out, n: int) -> None:
+        check(self.handle, lib.ah_arithmetic_unary(self.handle, type_id, op, _ptr(inp), _ptr(out), n))
+
+    def arithmetic_checked(self, type_id: int, op: int, shape: int, l, lvalid, loff, r, rvalid, roff, scalar_valid,
+                           out, n: int) -> None:
+        keep = []
+
+        def side(x, is_scalar):
+            if is_scalar:
+                s = np.ascontiguousarray(x)
+                keep.append(s)
+                return s.ctypes.data
+            return _ptr(x)
+
+        st = lib.ah_arithmetic_checked(self.handle, type_id, op, shape, side(l, shape == N.SHAPE_SA), _ptr(lvalid), loff,
+                                       side(r, shape == N.SHAPE_AS), _ptr(rvalid), roff, int(scalar_valid), _ptr(out), n)
+        check(self.handle, st)
+
+    # ---- compare ------------------------------------------------------------------------
+    def comparison(self, cmpop: int, shape: int, type_id: int, l, r, out_bits, n: int, out_bit_offset: int = 0) -> None:
+        keep = []
+
+        def side(x, is_scalar):
+            if is_scalar:
+                s = np.ascontiguousarray(x)
+                keep.append(s)
+                return s.ctypes.data
+            return _ptr(x)
+
+        st = lib.ah_comparison(self.handle, cmpop, shape, type_id, side(l, shape == N.SHAPE_SA),
+                               side(r, shape == N.SHAPE_AS), _ptr(out_bits), n, out_bit_offset)
+        check(self.handle, st)
+
+    # ---- bitmaps ------------------------------------------------------------------------
+    def bitmap_op(self, op: int, l, loff: int, r, roff: int, out, ooff: int, nbits: int) -> None:
+        check(self.handle, lib.ah_bitmap_op(self.handle, op, _ptr(l), loff, _ptr(r), roff, _ptr(out), ooff, nbits))
+
+    def count_set_bits(self, bits, off: int, nbits: int) -> int:
+        r = C.c_int64()
+        check(self.handle, lib.ah_count_set_bits(self.handle, _ptr(bits), off, nbits, C.byref(r)))
+        return r.value
+
+    def copy_bitmap(self, src, soff: int, nbits: int, dst, doff: int, invert: bool = False) -> None:
+        check(self.handle, lib.ah_copy_bitmap(self.handle, _ptr(src), soff, nbits, _ptr(dst), doff, int(invert)))
+
+    def set_bits_to(self, bits, off: int, nbits: int, value: bool) -> None:
+        check(self.handle, lib.ah_set_bits_to(self.handle, _ptr(bits), off, nbits, int(value)))
+
+    def kleene(self, op: int, lvalid, ldata, loff: int, rvalid, rdata, roff: int, ovalid, odata, ooff: int, nbits: int) -> None:
+        check(self.handle, lib.ah_kleene(self.handle, op, _ptr(lvalid), _ptr(ldata), loff, _ptr(rvalid), _ptr(rdata), roff,
+                                         _ptr(ovalid), _ptr(odata), ooff, nbits))
+
+    # ---- selection ----------------------------------------------------------------------
+    def filter_count(self, fdata, fvalid, foff: int, n: int, null_sel: int) -> int:
+        r = C.c_int64()
+        check(self.handle, lib.ah_filter_count(self.handle, _ptr(fdata), _ptr(fvalid), foff, n, null_sel, C.byref(r)))
+        return r.value
+
+    def filter_primitive(self, byte_width: int, values, vvalid, voff: int, fdata, fvalid, foff: int, n: int, null_sel: int,
+                         n_out: int, out_values, out_valid, want_null_count: bool = True) -> int:
+        r = C.c_int64()
+        check(self.handle, lib.ah_filter_primitive(self.handle, byte_width, _ptr(values), _ptr(vvalid), voff, _ptr(fdata),
+                                                   _ptr(fvalid), foff, n, null_sel, n_out, _ptr(out_values), _ptr(out_valid),
+                                                   C.byref(r) if want_null_count else None))
+        return r.value
+
+    def filter_to_indices(self, fdata, fvalid, foff: int, n: int, null_sel: int, n_out: int, out_idx, out_valid) -> int:
+        r = C.c_int64()
+        check(self.handle, lib.ah_filter_to_indices(self.handle, _ptr(fdata), _ptr(fvalid), foff, n, null_sel, n_out,
+                                                    _ptr(out_idx), _ptr(out_valid), C.byref(r)))
+        return r.value
+
+    def take_primitive(self, byte_width: int, values, vvalid, voff: int, nvalues: int, idx_byte_width: int, idx_signed: bool,
+                       idx, ivalid, ioff: int, nidx: int, bounds_check: bool, out_values, out_valid) -> int:
+        r = C.c_int64()
+        bad = C.c_int64()
+        check(self.handle, lib.ah_take_primitive(self.handle, byte_width, _ptr(values), _ptr(vvalid), voff, nvalues,
+                                                 idx_byte_width, int(idx_signed), _ptr(idx), _ptr(ivalid), ioff, nidx,
+                                                 int(bounds_check), _ptr(out_values), _ptr(out_valid), C.byref(r), C.byref(bad)))
+        return r.value
+
+    # ---- hashing ------------------------------------------------------------------------
+    def hash_u64_encode(self, keys, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_dict):
+        nd = C.c_int64()
+        nid = C.c_int32()
+        check(self.handle, lib.ah_hash_u64_encode(self.handle, _ptr(keys), _ptr(valid), off, n, int(encode_nulls), _ptr(out_ids),
+                                                  _ptr(out_ids_valid), _ptr(out_dict), C.byref(nd), C.byref(nid)))
+        return nd.value, nid.value
+
+    def hash_sum(self, kind: str, keys, kvalid, koff: int, vals, vvalid, voff: int, n: int, out_keys, out_sums, out_counts):
+        ng = C.c_int64()
+        nid = C.c_int32()
+        fn = lib.ah_hash_sum_f64 if kind == "f64" else lib.ah_hash_sum_i64
+        check(self.handle, fn(self.handle, _ptr(keys), _ptr(kvalid), koff, _ptr(vals), _ptr(vvalid), voff, n, _ptr(out_keys),
+                              _ptr(out_sums), _ptr(out_counts), C.byref(ng), C.byref(nid)))
+        return ng.value, nid.value
+
+    # ---- fused --------------------------------------------------------------------------
+    def cmp_filter_sum_i64(self, cmpop: int, x, valid, off: int, n: int, threshold: int):
+        s = C.c_int64()
+        cnt = C.c_int64()
+        check(self.handle, lib.ah_cmp_filter_sum_i64(self.handle, cmpop, _ptr(x), _ptr(valid), off, n, threshold, C.byref(s), C.byref(cnt)))
+        return s.value, cnt.value
+
+    def cmp_filter_sum_f64(self, cmpop: int, x, valid, off: int, n: int, threshold: float):
+        s = C.c_double()
+        cnt = C.c_int64()
+        check(self.handle, lib.ah_cmp_filter_sum_f64(self.handle, cmpop, _ptr(x), _ptr(valid), off, n, threshold, C.byref(s), C.byref(cnt)))
+        return s.value, cnt.value
+
+    def cmp_filter_sum_i64_dev(self, cmpop: int, x, valid, off: int, n: int, threshold: int, out_sum_count_dev) -> None:
+        check(self.handle, lib.ah_cmp_filter_sum_i64_dev(self.handle, cmpop, _ptr(x), _ptr(valid), off, n, threshold,
+                                                         _ptr(out_sum_count_dev)))
+
+    def cmp_filter_sum_f64_dev(self, cmpop: int, x, valid, off: int, n: int, threshold: float, out_sum_dev, out_count_dev) -> None:
+        check(self.handle, lib.ah_cmp_filter_sum_f64_dev(self.handle, cmpop, _ptr(x), _ptr(valid), off, n, threshold,
+                                                         _ptr(out_sum_dev), _ptr(out_count_dev)))
+
+
+def device_count() -> int:
+    n = C.c_int()
+    st = lib.ah_device_count(C.byref(n))
+    return n.value if st == N.AH_OK else 0

@@ -1,0 +1,269 @@
+/*
+ * arrowhip.h — C ABI of libarrowhip.so: MI355X (gfx950) kernels for the hot path of
+ * arrow-go's arrow/compute + arrow/math kernel registry.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one leaf the Go code
+ * reaches today through c2goasm Plan9 assembly (or a pure-Go loop); the citation on
+ * each declaration is the reference interface it replaces (paths relative to the
+ * arrow-go tree).  A Go maintainer binds these with cgo (INTEGRATION.md shows the
+ * stubs); nothing here mentions torch, C++ or HIP types.
+ *
+ * Conventions
+ *   - every function returns an int status: AH_OK or an error class; the message is
+ *     available from ah_last_error(ctx) until the next call on that ctx.
+ *   - pointers named *_host are host memory, read or written before the call
+ *     returns (the library never retains a host pointer — the cgo pointer rule);
+ *     all other data pointers are DEVICE pointers (from ah_buf_alloc, or any
+ *     hipMalloc'd / torch-allocated memory on the ctx's device).
+ *   - bitmaps are Arrow validity/boolean bitmaps: LSB-first, bit i of the logical
+ *     array is bit ((off + i) & 7) of byte ((off + i) >> 3).  A NULL validity
+ *     pointer means "all valid" (ArraySpan.Buffers[0].Buf == nil).
+ *   - kernels are enqueued on the ctx's compute stream and the call returns without
+ *     waiting, EXCEPT when the signature has a *_host output: those calls
+ *     synchronise the stream before returning.  ah_sync() waits for everything.
+ *   - an ah_ctx may be used from any OS thread (every entry point selects the
+ *     ctx's device first — Go's executor goroutine may migrate between threads,
+ *     compute/exec.go:165) but serves one call at a time.
+ *   - buffers must not alias unless stated; sizes are in ELEMENTS unless named
+ *     nbytes / nbits.
+ */
+#ifndef ARROWHIP_H
+#define ARROWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status classes ------------------------------------------------------ */
+#define AH_OK 0
+#define AH_EINVALID 1   /* arrow.ErrInvalid */
+#define AH_EINDEX 2     /* arrow.ErrIndex ("<v> out of bounds") */
+#define AH_EOVERFLOW 3  /* arrow.ErrInvalid: "overflow" (kernels/base_arithmetic.go errOverflow) */
+#define AH_EHIP 4       /* HIP runtime failure */
+#define AH_ENOTIMPL 5   /* arrow.ErrNotImplemented */
+
+/* arrow.Type ids passed verbatim — arrow/datatype.go:36-72 == kernels/_lib/types.h:20-34 */
+#define AH_UINT8 2
+#define AH_INT8 3
+#define AH_UINT16 4
+#define AH_INT16 5
+#define AH_UINT32 6
+#define AH_INT32 7
+#define AH_UINT64 8
+#define AH_INT64 9
+#define AH_FLOAT32 11
+#define AH_FLOAT64 12
+
+/* ArithmeticOp — kernels/base_arithmetic.go:37-82 == kernels/_lib/base_arithmetic.cc:31-74 */
+#define AH_OP_ADD 0
+#define AH_OP_SUB 1
+#define AH_OP_MUL 2
+#define AH_OP_ABS 4
+#define AH_OP_NEGATE 5
+#define AH_OP_SIGN 20
+#define AH_OP_ADD_CHECKED 21
+#define AH_OP_SUB_CHECKED 22
+#define AH_OP_MUL_CHECKED 23
+
+/* cmpop — kernels/_lib/scalar_comparison.cc:172-178; LESS/LESS_EQUAL are the
+ * caller's operand swap, exactly as compute/scalar_compare.go:73-99 does it. */
+#define AH_CMP_EQ 0
+#define AH_CMP_NE 1
+#define AH_CMP_GT 2
+#define AH_CMP_GE 3
+/* operand shapes: array∘array, array∘scalar, scalar∘array (kernels/helpers.go:193-236) */
+#define AH_SHAPE_AA 0
+#define AH_SHAPE_AS 1
+#define AH_SHAPE_SA 2
+/* bitOp — arrow/bitutil/bitmaps.go:494-521 */
+#define AH_BIT_AND 0
+#define AH_BIT_OR 1
+#define AH_BIT_XOR 2
+#define AH_BIT_AND_NOT 3
+#define AH_BIT_XNOR 4
+/* Kleene ops — compute/scalar_bool.go:94-110 */
+#define AH_KLEENE_AND 0
+#define AH_KLEENE_OR 1
+#define AH_KLEENE_AND_NOT 2
+/* NullSelectionBehavior — kernels/vector_selection.go:34-39 */
+#define AH_DROP_NULLS 0
+#define AH_EMIT_NULLS 1
+
+/* ---- context ------------------------------------------------------------- */
+typedef struct ah_ctx ah_ctx; /* device id, compute stream, copy stream, scratch arena */
+
+/* Own streams (compute + copy). */
+int ah_ctx_create(int device_id, ah_ctx** out);
+/* Borrow an existing hipStream_t as the compute stream (e.g. torch's current
+ * stream, so torch.distributed collectives order naturally after our kernels). */
+int ah_ctx_create_on_stream(int device_id, void* hip_stream, ah_ctx** out);
+void ah_ctx_destroy(ah_ctx* ctx);
+const char* ah_last_error(ah_ctx* ctx); /* never NULL; owned by ctx */
+const char* ah_version(void);
+int ah_device_count(int* n_host);
+
+/* ---- buffers (back a Go memory.Allocator: arrow/memory/allocator.go:23-27) - */
+int ah_buf_alloc(ah_ctx* ctx, size_t nbytes, void** dptr_host);      /* 256-B aligned, NOT zeroed */
+int ah_buf_free(ah_ctx* ctx, void* dptr);
+int ah_host_alloc_pinned(ah_ctx* ctx, size_t nbytes, void** hptr_host);
+int ah_host_free_pinned(ah_ctx* ctx, void* hptr);
+/* copies run on the copy stream; the compute stream is made to wait for an upload,
+ * a download waits for the compute work enqueued so far.  hptr should be pinned
+ * (pageable memory works but the runtime stages it). */
+int ah_upload_async(ah_ctx* ctx, void* dptr, const void* hptr, size_t nbytes);
+int ah_download_async(ah_ctx* ctx, void* hptr, const void* dptr, size_t nbytes);
+int ah_memset_async(ah_ctx* ctx, void* dptr, int byte_value, size_t nbytes); /* arrow/memory/_lib/memory.c:20-27 */
+int ah_sync(ah_ctx* ctx);
+/* hipEvent pair on the compute stream (what bench.py times kernels with). */
+int ah_timer_start(ah_ctx* ctx);
+int ah_timer_stop(ah_ctx* ctx, float* ms_host); /* synchronises */
+
+/* ---- arrow/math Sum -------------------------------------------------------
+ * replaces _sum_float64_avx2 / sum_float64_go (arrow/math/float64_avx2_amd64.go:33-42,
+ * arrow/math/float64.go:41-47; C truth arrow/math/_lib/float64.c:20-26) and the
+ * int64/uint64 twins (arrow/math/_lib/int64.c:21-27, uint64.c).  Validity is
+ * ignored exactly as the reference ignores it.  len == 0 → 0.
+ * float64: every lane accumulates in double-double (TwoSum), so the result is the
+ * exact sum rounded once (≤ 1 ULP), independent of launch geometry; see DESIGN.md
+ * for why this — not either of the reference's two mutually inconsistent orders —
+ * is the parity rule.  int64/uint64: wrapping, bit-exact. */
+int ah_sum_float64(ah_ctx* ctx, const double* buf, size_t len, double* res_host);
+int ah_sum_int64(ah_ctx* ctx, const int64_t* buf, size_t len, int64_t* res_host);
+int ah_sum_uint64(ah_ctx* ctx, const uint64_t* buf, size_t len, uint64_t* res_host);
+/* same, result left in device memory (8 bytes), no synchronisation */
+int ah_sum_float64_dev(ah_ctx* ctx, const double* buf, size_t len, double* res_dev);
+int ah_sum_int64_dev(ah_ctx* ctx, const int64_t* buf, size_t len, int64_t* res_dev);
+
+/* ---- element-wise arithmetic ------------------------------------------------
+ * replace _arithmetic_binary_avx2 / _arithmetic_arr_scalar_avx2 /
+ * _arithmetic_scalar_arr_avx2 / _arithmetic_unary_same_types_avx2
+ * (kernels/base_arithmetic_avx2_amd64.go:27-60; C truth
+ * kernels/_lib/base_arithmetic.cc:465-483).  op ∈ {ADD, SUB, MUL} (the *_CHECKED
+ * ids alias the unchecked op, as in the C source :54-57); every slot is computed,
+ * null payloads included.  Scalars are read from host memory (one element). */
+int ah_arithmetic_binary(ah_ctx* ctx, int type, int8_t op, const void* l, const void* r, void* out, int64_t len);
+int ah_arithmetic_arr_scalar(ah_ctx* ctx, int type, int8_t op, const void* l, const void* r_host, void* out, int64_t len);
+int ah_arithmetic_scalar_arr(ah_ctx* ctx, int type, int8_t op, const void* l_host, const void* r, void* out, int64_t len);
+int ah_arithmetic_unary(ah_ctx* ctx, int type, int8_t op, const void* in, void* out, int64_t len); /* ABS, NEGATE, SIGN */
+/* checked integer ADD/SUB/MUL — replaces the pure-Go ScalarBinaryNotNull path
+ * (kernels/base_arithmetic.go:249-286, kernels/helpers.go:284-380): ADD/SUB write 0
+ * under null slots and test only valid slots; MUL evaluates every slot
+ * (mulWithOverflow :84-106).  Returns AH_EOVERFLOW ("overflow") if any tested slot
+ * overflowed by the reference's own carry test; `out` is then unspecified, as the
+ * reference discards it.  For AS/SA shapes the scalar operand pointer is host
+ * memory and scalar_valid says whether the scalar is non-null.  Synchronises. */
+int ah_arithmetic_checked(ah_ctx* ctx, int type, int8_t op, int shape,
+                          const void* l, const uint8_t* lvalid, int64_t loff,
+                          const void* r, const uint8_t* rvalid, int64_t roff,
+                          int scalar_valid, void* out, int64_t len);
+
+/* ---- comparisons → packed bitmap ----------------------------------------------
+ * replaces the 12 _comparison_<op>_<shape>_avx2 symbols
+ * (kernels/scalar_comparison_avx2_amd64.go; C truth
+ * kernels/_lib/scalar_comparison.cc:210-256).  out_bits points at the byte holding
+ * the first output bit, out_bit_offset % 8 is the bit prefix inside it (the
+ * reference passes out.Offset; kernels/scalar_comparisons.go:199-218).  Only bits
+ * [prefix, prefix+length) are written. */
+int ah_comparison(ah_ctx* ctx, int cmpop, int shape, int type, const void* l, const void* r,
+                  uint8_t* out_bits, int64_t length, int out_bit_offset);
+
+/* ---- null-bitmap utilities -----------------------------------------------------
+ * replace bitutil.BitmapAnd/Or/Xor/AndNot/Xnor (arrow/bitutil/bitmaps.go:592-637 →
+ * _bitmap_aligned_*_avx2, arrow/bitutil/bitmap_ops_avx2_amd64.go:26-52, plus the Go
+ * unaligned path :568-582), CountSetBits (arrow/bitutil/bitutil.go:89-130),
+ * CopyBitmap/InvertBitmap (bitmaps.go:483-493), SetBitsTo (bitutil.go:158-204) and
+ * the Kleene word kernels (kernels/scalar_boolean.go:29-65).  Arbitrary,
+ * independent bit offsets; only bits [ooff, ooff+nbits) of the output change. */
+int ah_bitmap_op(ah_ctx* ctx, int op, const uint8_t* l, int64_t loff, const uint8_t* r, int64_t roff,
+                 uint8_t* out, int64_t ooff, int64_t nbits);
+int ah_count_set_bits(ah_ctx* ctx, const uint8_t* bits, int64_t off, int64_t nbits, int64_t* out_host);
+int ah_copy_bitmap(ah_ctx* ctx, const uint8_t* src, int64_t soff, int64_t nbits, uint8_t* dst, int64_t doff, int invert);
+int ah_set_bits_to(ah_ctx* ctx, uint8_t* bits, int64_t off, int64_t nbits, int value);
+int ah_kleene(ah_ctx* ctx, int op, const uint8_t* lvalid, const uint8_t* ldata, int64_t loff,
+              const uint8_t* rvalid, const uint8_t* rdata, int64_t roff,
+              uint8_t* ovalid, uint8_t* odata, int64_t ooff, int64_t nbits);
+
+/* ---- selection -------------------------------------------------------------------
+ * Filter: data-dependent output size and Go owns allocation, so the protocol is the
+ * reference's own two steps: ah_filter_count == getFilterOutputSize
+ * (kernels/vector_selection.go:57-81), caller allocates n_out*byte_width bytes (+
+ * ceil(n_out/8) validity bytes iff either input has nulls — preallocateData :83-93,
+ * PrimitiveFilter :486-488), then ah_filter_primitive == primitiveFilterImpl
+ * (:267-395).  n_out is the value ah_filter_count returned (the library zero-fills
+ * the ceil(n_out/8) bytes of out_valid itself and cross-checks n_out when it
+ * synchronises; pass -1 only when out_valid is NULL).  Payload rules in DESIGN.md.
+ * byte_width ∈ {1,2,4,8}.  out_null_count_host may be NULL (then no sync). */
+int ah_filter_count(ah_ctx* ctx, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,
+                    int null_sel, int64_t* n_out_host);
+int ah_filter_primitive(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                        const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                        int64_t n_out, void* out_values, uint8_t* out_valid, int64_t* out_null_count_host);
+/* GetTakeIndices (kernels/vector_selection.go:102-236), uint32 flavour: the mask as
+ * an index vector so FilterRecordBatch can gather N columns with one scan. */
+int ah_filter_to_indices(ah_ctx* ctx, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,
+                         int null_sel, int64_t n_out, uint32_t* out_idx, uint8_t* out_valid,
+                         int64_t* out_null_count_host);
+/* Take == PrimitiveTake (kernels/vector_selection.go:1162-1192 → primitiveTakeImpl
+ * :878-988): out[i] = values[idx[i]]; null index or null value → payload 0, validity
+ * 0.  idx_byte_width ∈ {1,2,4,8}; idx_signed selects the bounds rule of
+ * checkIndexBounds (kernels/helpers.go:929-957; only valid index slots are checked).
+ * An out-of-range valid index returns AH_EINDEX with the first offender (in index
+ * order) in *bad_index_host and "<v> out of bounds" as the message; the check is
+ * fused into the gather and also runs when bounds_check == 0 (where the reference
+ * would panic).  out_valid may be NULL when neither input has nulls.  Synchronises. */
+int ah_take_primitive(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                      int64_t nvalues, int idx_byte_width, int idx_signed, const void* idx,
+                      const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check,
+                      void* out_values, uint8_t* out_valid, int64_t* out_null_count_host,
+                      int64_t* bad_index_host);
+
+/* ---- hashing ------------------------------------------------------------------------
+ * unique / dictionary_encode over 8-byte keys == doAppendNumeric[uint64] over
+ * hashing.Table[uint64] (kernels/vector_hash.go:359-385,
+ * internal/hashing/xxh3_memo_table_types.go:189-294; Int64 and Float64 columns both
+ * hash their raw bit patterns, vector_hash.go:604-607).  Dense ids are in
+ * FIRST-SEEN ORDER, bit-identical to the sequential memo table.  encode_nulls = 1
+ * (unique, NullEncodingEncode): null owns the id at which it was first seen;
+ * = 0 (NullEncodingMask): null → id 0 + cleared validity bit.  out_dict must hold
+ * min(n, distinct)+1 keys — call with out_dict = NULL first to learn the size if
+ * unknown, or size it n+1.  out_ids / out_ids_valid may be NULL.  Synchronises. */
+int ah_hash_u64_encode(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n,
+                       int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, uint64_t* out_dict,
+                       int64_t* out_ndict_host, int32_t* out_null_id_host);
+/* group-by sum (NEW — arrow-go has no hash aggregate; definition in DESIGN.md): groups
+ * = dictionary_encode(keys, encode_nulls=1) ids; out_sums[g] = Σ valid vals of group
+ * g, out_counts[g] = number of valid vals.  i64 sums wrap and are exact; f64 sums
+ * use hardware fp64 atomic adds, so the accumulation ORDER is not deterministic:
+ * |err| ≤ n_g·ε·Σ|x| per group, exact whenever all partial sums are representable
+ * (e.g. integer-valued data < 2^53).  Outputs sized like out_dict above. */
+int ah_hash_sum_f64(ah_ctx* ctx, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
+                    const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
+                    uint64_t* out_keys, double* out_sums, int64_t* out_counts,
+                    int64_t* out_ngroups_host, int32_t* out_null_group_host);
+int ah_hash_sum_i64(ah_ctx* ctx, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
+                    const int64_t* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
+                    uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                    int64_t* out_ngroups_host, int32_t* out_null_group_host);
+
+/* ---- fused Compare(op scalar) → Filter(DropNulls) → Sum ------------------------------
+ * NEW entry point (no reference analogue) computing in ONE pass what the reference
+ * computes with "greater" → "array_filter" → math.Sum: Σ x[i] over valid slots with
+ * x[i] OP threshold, and the survivor count.  8 B/row of HBM traffic instead of
+ * 16.25 + 16·s.  *_dev variants leave {sum, count} (16 bytes) in device memory for a
+ * following RCCL all-reduce. */
+int ah_cmp_filter_sum_i64(ah_ctx* ctx, int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n,
+                          int64_t threshold, int64_t* out_sum_host, int64_t* out_count_host);
+int ah_cmp_filter_sum_f64(ah_ctx* ctx, int cmpop, const double* x, const uint8_t* valid, int64_t off, int64_t n,
+                          double threshold, double* out_sum_host, int64_t* out_count_host);
+int ah_cmp_filter_sum_i64_dev(ah_ctx* ctx, int cmpop, const int64_t* x, const uint8_t* valid, int64_t off,
+                              int64_t n, int64_t threshold, int64_t* out_sum_count_dev /* [2] */);
+int ah_cmp_filter_sum_f64_dev(ah_ctx* ctx, int cmpop, const double* x, const uint8_t* valid, int64_t off,
+                              int64_t n, double threshold, double* out_sum_dev, int64_t* out_count_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARROWHIP_H */

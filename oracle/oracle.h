@@ -1,0 +1,123 @@
+/*
+ * oracle.h — CPU restatement of arrow-go's compute/math hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load liboracle.so, and only as the checker / reported baseline.
+ * libarrowhip.so (arrow_go_amd/csrc) never links or calls into this file.
+ *
+ * Every function cites the reference file:line (relative to the arrow-go
+ * tree) whose algorithm it restates.  The restatement is deliberately the
+ * simplest per-element form that obeys the same payload rules — not a
+ * transliteration of the block state machines.
+ *
+ * Pinning: tests/test_oracle_golden.py checks these functions against every
+ * known-answer vector the reference's own tests hold for the path
+ *  and, where oracle/_ref/libref_*.so is built, against the
+ * reference's own AVX2 machine code on random inputs.
+ */
+#ifndef ARROWHIP_ORACLE_H
+#define ARROWHIP_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* arrow.Type ids — arrow/datatype.go:36-72 == _lib/types.h:20-34 */
+enum {
+  ORC_UINT8 = 2, ORC_INT8 = 3, ORC_UINT16 = 4, ORC_INT16 = 5, ORC_UINT32 = 6,
+  ORC_INT32 = 7, ORC_UINT64 = 8, ORC_INT64 = 9, ORC_FLOAT32 = 11, ORC_FLOAT64 = 12
+};
+/* ArithmeticOp — kernels/base_arithmetic.go:37-82 == _lib/base_arithmetic.cc:31-74 */
+enum {
+  ORC_OP_ADD = 0, ORC_OP_SUB = 1, ORC_OP_MUL = 2, ORC_OP_ABS = 4, ORC_OP_NEGATE = 5,
+  ORC_OP_SIGN = 20, ORC_OP_ADD_CHECKED = 21, ORC_OP_SUB_CHECKED = 22, ORC_OP_MUL_CHECKED = 23
+};
+/* cmpop — _lib/scalar_comparison.cc:172-178 */
+enum { ORC_CMP_EQ = 0, ORC_CMP_NE = 1, ORC_CMP_GT = 2, ORC_CMP_GE = 3 };
+enum { ORC_SHAPE_AA = 0, ORC_SHAPE_AS = 1, ORC_SHAPE_SA = 2 };
+/* bitOp — arrow/bitutil/bitmaps.go:494-521 */
+enum { ORC_BIT_AND = 0, ORC_BIT_OR = 1, ORC_BIT_XOR = 2, ORC_BIT_AND_NOT = 3, ORC_BIT_XNOR = 4 };
+/* NullSelectionBehavior — kernels/vector_selection.go:34-39 */
+enum { ORC_DROP_NULLS = 0, ORC_EMIT_NULLS = 1 };
+/* status classes shared with include/arrowhip.h */
+enum { ORC_OK = 0, ORC_EINVALID = 1, ORC_EINDEX = 2, ORC_EOVERFLOW = 3 };
+
+/* ---- arrow/math Sum ------------------------------------------------- */
+void orc_sum_float64_seq(const double* buf, size_t len, double* res);
+void orc_sum_float64_avx2order(const double* buf, size_t len, double* res);
+void orc_sum_float64_exact(const double* buf, size_t len, double* res);
+void orc_sum_int64(const int64_t* buf, size_t len, int64_t* res);
+void orc_sum_uint64(const uint64_t* buf, size_t len, uint64_t* res);
+
+/* ---- element-wise arithmetic --------------------------------------- */
+int orc_arithmetic_binary(int type, int8_t op, const void* l, const void* r, void* out, int64_t len);
+int orc_arithmetic_arr_scalar(int type, int8_t op, const void* l, const void* r, void* out, int64_t len);
+int orc_arithmetic_scalar_arr(int type, int8_t op, const void* l, const void* r, void* out, int64_t len);
+int orc_arithmetic_unary(int type, int8_t op, const void* in, void* out, int64_t len);
+/* shape: AA/AS/SA; validity may be NULL (= all valid); a null scalar is passed
+ * as scalar_valid = 0.  Returns ORC_EOVERFLOW if any valid slot overflowed. */
+int orc_arithmetic_checked(int type, int8_t op, int shape,
+                           const void* l, const uint8_t* lv, int64_t loff,
+                           const void* r, const uint8_t* rv, int64_t roff,
+                           int scalar_valid, void* out, int64_t len);
+
+/* ---- comparisons → packed bitmap ------------------------------------ */
+int orc_comparison(int cmpop, int shape, int type, const void* l, const void* r,
+                   uint8_t* out_bits, int64_t length, int out_bit_offset);
+
+/* ---- bitmaps --------------------------------------------------------- */
+int64_t orc_count_set_bits(const uint8_t* bits, int64_t off, int64_t nbits);
+void orc_bitmap_op(int op, const uint8_t* l, int64_t loff, const uint8_t* r, int64_t roff,
+                   uint8_t* out, int64_t ooff, int64_t nbits);
+void orc_copy_bitmap(const uint8_t* src, int64_t soff, int64_t nbits, uint8_t* dst, int64_t doff, int invert);
+void orc_set_bits_to(uint8_t* bits, int64_t off, int64_t nbits, int value);
+/* Kleene ops: op 0 = and_kleene, 1 = or_kleene, 2 = and_not_kleene */
+void orc_kleene(int op, const uint8_t* lvalid, const uint8_t* ldata, int64_t loff,
+                const uint8_t* rvalid, const uint8_t* rdata, int64_t roff,
+                uint8_t* ovalid, uint8_t* odata, int64_t ooff, int64_t nbits);
+
+/* ---- selection ------------------------------------------------------- */
+int64_t orc_filter_count(const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel);
+int orc_filter_primitive(int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                         const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                         void* out_values, uint8_t* out_valid, int64_t* out_len, int64_t* out_null_count);
+int orc_take_primitive(int byte_width, const void* values, const uint8_t* vvalid, int64_t voff, int64_t nvalues,
+                       int idx_byte_width, int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff,
+                       int64_t nidx, int bounds_check, void* out_values, uint8_t* out_valid,
+                       int64_t* out_null_count, int64_t* bad_index);
+int orc_filter_to_indices(const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                          uint32_t* out_idx, uint8_t* out_valid, int64_t* out_len, int64_t* out_null_count);
+
+/* ---- hashing ---------------------------------------------------------- */
+uint64_t orc_hash_int(uint64_t v, uint64_t alg);
+/* unique / dictionary_encode over 8-byte keys (raw bit patterns).
+ * encode_nulls=1 (unique, NullEncodingEncode): null gets a dictionary slot at
+ * the position it was first seen; =0 (NullEncodingMask): null → id 0, out
+ * validity cleared.  out_ids / out_ids_valid may be NULL (unique). */
+int orc_hash_u64_encode(const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
+                        int32_t* out_ids, uint8_t* out_ids_valid, uint64_t* out_dict,
+                        int64_t* out_ndict, int32_t* out_null_id);
+/* group-by (new functionality, oracle = sequential row-order accumulation) */
+int orc_hash_sum_f64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
+                     const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
+                     uint64_t* out_keys, double* out_sums, int64_t* out_counts,
+                     int64_t* out_ngroups, int32_t* out_null_group);
+int orc_hash_sum_i64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
+                     const int64_t* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
+                     uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                     int64_t* out_ngroups, int32_t* out_null_group);
+
+/* ---- fused Compare(>) → Filter → Sum (the unfused chain, restated) ---- */
+int orc_cmp_filter_sum_i64(int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n,
+                           int64_t threshold, int64_t* out_sum, int64_t* out_count);
+int orc_cmp_filter_sum_f64(int cmpop, const double* x, const uint8_t* valid, int64_t off, int64_t n,
+                           double threshold, double* out_sum_seq, double* out_sum_exact, int64_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,274 @@
+"""Two implementations of the same leaf interface, so every parity test body runs
+unchanged against (a) the CPU oracle and (b) the HIP library through the C ABI.
+
+  OracleBackend — oracle/liboracle.so (checker; `-m "not gpu"` pins it to the
+                  reference's golden vectors)
+  HipBackend    — libarrowhip.so on cuda:0 through include/arrowhip.h (`-m gpu`)
+
+All inputs/outputs are host numpy arrays; HipBackend uploads, runs, downloads.
+`misalign` (elements) shifts the device copy of a value buffer off 16-byte alignment
+the way an Arrow slice (&values[offset]) does.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from tests import oracle_lib as OL
+
+STATUS_OK, STATUS_EINVALID, STATUS_EINDEX, STATUS_EOVERFLOW = 0, 1, 2, 3
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self):
+        self.o = OL.load_oracle()
+
+    def sum(self, arr, misalign=0):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype == np.float64:
+            return float(self.o.sum_float64_exact(arr))
+        return int(self.o.sum_int64(arr)) if arr.dtype == np.int64 else int(self.o.sum_uint64(arr))
+
+    def arithmetic(self, op, shape, l, r, misalign=0):
+        return self.o.arithmetic(op, shape, l, r)
+
+    def arithmetic_unary(self, op, a, misalign=0):
+        return self.o.arithmetic_unary(op, a)
+
+    def arithmetic_checked(self, op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid=True):
+        return self.o.arithmetic_checked(op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid)
+
+    def comparison(self, cmpop, shape, l, r, out_init, out_bit_offset=0, misalign=0):
+        out = np.array(out_init, dtype=np.uint8, copy=True)
+        return self.o.comparison(cmpop, shape, l, r, out, out_bit_offset)
+
+    def count_set_bits(self, bits, off, n):
+        return self.o.count_set_bits(np.ascontiguousarray(bits), off, n)
+
+    def bitmap_op(self, op, l, loff, r, roff, out_init, ooff, n):
+        return self.o.bitmap_op(op, l, loff, r, roff, np.array(out_init, dtype=np.uint8, copy=True), ooff, n)
+
+    def copy_bitmap(self, src, soff, n, out_init, doff, invert=False):
+        return self.o.copy_bitmap(src, soff, n, np.array(out_init, dtype=np.uint8, copy=True), doff, invert)
+
+    def set_bits_to(self, out_init, off, n, value):
+        return self.o.set_bits_to(np.array(out_init, dtype=np.uint8, copy=True), off, n, value)
+
+    def kleene(self, op, lvalid, ldata, loff, rvalid, rdata, roff, ovalid_init, odata_init, ooff, n):
+        return self.o.kleene(op, lvalid, ldata, loff, rvalid, rdata, roff, np.array(ovalid_init, dtype=np.uint8, copy=True),
+                             np.array(odata_init, dtype=np.uint8, copy=True), ooff, n)
+
+    def filter_count(self, fdata, fvalid, foff, n, null_sel):
+        return self.o.filter_count(fdata, fvalid, foff, n, null_sel)
+
+    def filter(self, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid, misalign=0):
+        return self.o.filter_primitive(values, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid)
+
+    def filter_to_indices(self, fdata, fvalid, foff, n, null_sel, want_valid):
+        return self.o.filter_to_indices(fdata, fvalid, foff, n, null_sel, want_valid)
+
+    def take(self, values, vvalid, voff, idx, ivalid, ioff, bounds_check, want_valid):
+        return self.o.take_primitive(values, vvalid, voff, idx, ivalid, ioff, bounds_check, want_valid)
+
+    def hash_encode(self, keys, valid, off, encode_nulls):
+        return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
+
+    def hash_sum(self, kind, keys, kvalid, koff, vals, vvalid, voff):
+        return self.o.hash_sum(kind, keys, kvalid, koff, vals, vvalid, voff)
+
+    def cmp_filter_sum_i64(self, cmpop, x, valid, off, thr):
+        return self.o.cmp_filter_sum_i64(cmpop, x, valid, off, thr)
+
+    def cmp_filter_sum_f64(self, cmpop, x, valid, off, thr):
+        s_seq, s_exact, cnt = self.o.cmp_filter_sum_f64(cmpop, x, valid, off, thr)
+        return s_exact, cnt
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, ctx):
+        self.c = ctx
+
+    # -- helpers
+    def _up(self, arr, misalign=0):
+        """upload; returns (buffer, device pointer of element 0)"""
+        if arr is None:
+            return None, None
+        a = np.ascontiguousarray(arr)
+        lead = misalign * a.dtype.itemsize
+        buf = self.c.alloc(lead + a.nbytes + 64)
+        buf.upload(a, lead)
+        return buf, buf.ptr + lead
+
+    def _upbits(self, bits):
+        if bits is None:
+            return None, None
+        a = np.ascontiguousarray(bits, dtype=np.uint8)
+        buf = self.c.alloc(a.nbytes + 64)
+        buf.upload(a)
+        return buf, buf.ptr
+
+    def sum(self, arr, misalign=0):
+        arr = np.ascontiguousarray(arr)
+        b, p = self._up(arr, misalign)
+        if arr.dtype == np.float64:
+            return self.c.sum_float64(p, arr.size)
+        if arr.dtype == np.int64:
+            return self.c.sum_int64(p, arr.size)
+        return self.c.sum_uint64(p, arr.size)
+
+    def arithmetic(self, op, shape, l, r, misalign=0):
+        l = np.ascontiguousarray(l); r = np.ascontiguousarray(r)
+        arr = r if shape == 2 else l
+        tid = OL.TYPE_IDS[arr.dtype]
+        lb, lp = (None, l) if shape == 2 else self._up(l, misalign)
+        rb, rp = (None, r) if shape == 1 else self._up(r, misalign)
+        ob = self.c.alloc(arr.nbytes + 128)
+        op_ptr = ob.ptr + misalign * arr.dtype.itemsize
+        self.c.arithmetic(tid, op, shape, lp, rp, op_ptr, arr.size)
+        return ob.download(arr.dtype, arr.size, misalign * arr.dtype.itemsize)
+
+    def arithmetic_unary(self, op, a, misalign=0):
+        a = np.ascontiguousarray(a)
+        ib, ip = self._up(a, misalign)
+        ob = self.c.alloc(a.nbytes + 128)
+        self.c.arithmetic_unary(OL.TYPE_IDS[a.dtype], op, ip, ob.ptr + misalign * a.dtype.itemsize, a.size)
+        return ob.download(a.dtype, a.size, misalign * a.dtype.itemsize)
+
+    def arithmetic_checked(self, op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid=True):
+        import arrow_go_amd as ah
+        l = np.ascontiguousarray(l); r = np.ascontiguousarray(r)
+        arr = r if shape == 2 else l
+        lb, lp = (None, l) if shape == 2 else self._up(l)
+        rb, rp = (None, r) if shape == 1 else self._up(r)
+        lvb, lvp = self._upbits(lvalid)
+        rvb, rvp = self._upbits(rvalid)
+        ob = self.c.alloc(arr.nbytes + 64)
+        ob.memset(0xCD)
+        try:
+            self.c.arithmetic_checked(OL.TYPE_IDS[arr.dtype], op, shape, lp, lvp, loff, rp, rvp, roff, scalar_valid, ob, arr.size)
+            st = STATUS_OK
+        except ah.ErrOverflow as e:
+            assert "overflow" in str(e)
+            st = STATUS_EOVERFLOW
+        return st, ob.download(arr.dtype, arr.size)
+
+    def comparison(self, cmpop, shape, l, r, out_init, out_bit_offset=0, misalign=0):
+        l = np.ascontiguousarray(l); r = np.ascontiguousarray(r)
+        arr = r if shape == 2 else l
+        lb, lp = (None, l) if shape == 2 else self._up(l, misalign)
+        rb, rp = (None, r) if shape == 1 else self._up(r, misalign)
+        out_init = np.ascontiguousarray(out_init, dtype=np.uint8)
+        ob, op_ = self._upbits(out_init)
+        self.c.comparison(cmpop, shape, OL.TYPE_IDS[arr.dtype], lp, rp, op_, arr.size, out_bit_offset)
+        return ob.download(np.uint8, out_init.size)
+
+    def count_set_bits(self, bits, off, n):
+        b, p = self._upbits(bits)
+        return self.c.count_set_bits(p, off, n)
+
+    def bitmap_op(self, op, l, loff, r, roff, out_init, ooff, n):
+        lb, lp = self._upbits(l); rb, rp = self._upbits(r)
+        out_init = np.ascontiguousarray(out_init, dtype=np.uint8)
+        ob, op_ = self._upbits(out_init)
+        self.c.bitmap_op(op, lp, loff, rp, roff, op_, ooff, n)
+        return ob.download(np.uint8, out_init.size)
+
+    def copy_bitmap(self, src, soff, n, out_init, doff, invert=False):
+        sb, sp = self._upbits(src)
+        out_init = np.ascontiguousarray(out_init, dtype=np.uint8)
+        ob, op_ = self._upbits(out_init)
+        self.c.copy_bitmap(sp, soff, n, op_, doff, invert)
+        return ob.download(np.uint8, out_init.size)
+
+    def set_bits_to(self, out_init, off, n, value):
+        out_init = np.ascontiguousarray(out_init, dtype=np.uint8)
+        ob, op_ = self._upbits(out_init)
+        self.c.set_bits_to(op_, off, n, value)
+        return ob.download(np.uint8, out_init.size)
+
+    def kleene(self, op, lvalid, ldata, loff, rvalid, rdata, roff, ovalid_init, odata_init, ooff, n):
+        lvb, lvp = self._upbits(lvalid); ldb, ldp = self._upbits(ldata)
+        rvb, rvp = self._upbits(rvalid); rdb, rdp = self._upbits(rdata)
+        ovalid_init = np.ascontiguousarray(ovalid_init, dtype=np.uint8)
+        odata_init = np.ascontiguousarray(odata_init, dtype=np.uint8)
+        ovb, ovp = self._upbits(ovalid_init); odb, odp = self._upbits(odata_init)
+        self.c.kleene(op, lvp, ldp, loff, rvp, rdp, roff, ovp, odp, ooff, n)
+        return ovb.download(np.uint8, ovalid_init.size), odb.download(np.uint8, odata_init.size)
+
+    def filter_count(self, fdata, fvalid, foff, n, null_sel):
+        fb, fp = self._upbits(fdata); vb, vp = self._upbits(fvalid)
+        return self.c.filter_count(fp, vp, foff, n, null_sel)
+
+    def filter(self, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid, misalign=0):
+        values = np.ascontiguousarray(values)
+        w = values.dtype.itemsize
+        vb, vp = self._up(values, misalign)
+        vvb, vvp = self._upbits(vvalid)
+        fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
+        n_out = self.c.filter_count(fp, fvp, foff, n, null_sel)
+        ob = self.c.alloc(n_out * w + 128)
+        ob.memset(0xCD)  # the library must not rely on a pre-zeroed value buffer
+        ovb = self.c.alloc((n_out + 7) // 8 + 64) if want_valid else None
+        if ovb is not None:
+            ovb.memset(0xCD)
+        nulls = self.c.filter_primitive(w, vp, vvp, voff, fp, fvp, foff, n, null_sel, n_out, ob, ovb)
+        out = ob.download(values.dtype, n_out)
+        ov = ovb.download(np.uint8, (n_out + 7) // 8) if want_valid else None
+        return out, ov, nulls
+
+    def filter_to_indices(self, fdata, fvalid, foff, n, null_sel, want_valid):
+        fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
+        n_out = self.c.filter_count(fp, fvp, foff, n, null_sel)
+        ob = self.c.alloc(n_out * 4 + 128)
+        ovb = self.c.alloc((n_out + 7) // 8 + 64) if want_valid else None
+        nulls = self.c.filter_to_indices(fp, fvp, foff, n, null_sel, n_out, ob, ovb)
+        return ob.download(np.uint32, n_out), (ovb.download(np.uint8, (n_out + 7) // 8) if want_valid else None), nulls
+
+    def take(self, values, vvalid, voff, idx, ivalid, ioff, bounds_check, want_valid):
+        import arrow_go_amd as ah
+        values = np.ascontiguousarray(values); idx = np.ascontiguousarray(idx)
+        vb, vp = self._up(values); vvb, vvp = self._upbits(vvalid)
+        ib, ip = self._up(idx); ivb, ivp = self._upbits(ivalid)
+        ob = self.c.alloc(idx.size * values.dtype.itemsize + 64)
+        ob.memset(0xCD)
+        ovb = self.c.alloc((idx.size + 7) // 8 + 64) if want_valid else None
+        try:
+            nulls = self.c.take_primitive(values.dtype.itemsize, vp, vvp, voff, values.size, idx.dtype.itemsize,
+                                          idx.dtype.kind == "i", ip, ivp, ioff, idx.size, bounds_check, ob, ovb)
+        except ah.ErrIndex as e:
+            msg = str(e)
+            assert msg.endswith("out of bounds"), msg
+            return STATUS_EINDEX, None, None, 0, int(msg.split()[0])
+        out = ob.download(values.dtype, idx.size)
+        ov = ovb.download(np.uint8, (idx.size + 7) // 8) if want_valid else None
+        return STATUS_OK, out, ov, nulls, 0
+
+    def hash_encode(self, keys, valid, off, encode_nulls):
+        keys = np.ascontiguousarray(keys).view(np.uint64)
+        n = keys.size
+        kb, kp = self._up(keys); vb, vp = self._upbits(valid)
+        idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); db = self.c.alloc((n + 1) * 8 + 64)
+        nd, nid = self.c.hash_u64_encode(kp, vp, off, n, encode_nulls, idb, idvb, db)
+        return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), db.download(np.uint64, nd), nid
+
+    def hash_sum(self, kind, keys, kvalid, koff, vals, vvalid, voff):
+        keys = np.ascontiguousarray(keys).view(np.uint64); vals = np.ascontiguousarray(vals)
+        n = keys.size
+        kb, kp = self._up(keys); kvb, kvp = self._upbits(kvalid)
+        xb, xp = self._up(vals); xvb, xvp = self._upbits(vvalid)
+        okb = self.c.alloc((n + 1) * 8 + 64); osb = self.c.alloc((n + 1) * 8 + 64); ocb = self.c.alloc((n + 1) * 8 + 64)
+        ng, nid = self.c.hash_sum(kind, kp, kvp, koff, xp, xvp, voff, n, okb, osb, ocb)
+        return okb.download(np.uint64, ng), osb.download(vals.dtype, ng), ocb.download(np.int64, ng), nid
+
+    def cmp_filter_sum_i64(self, cmpop, x, valid, off, thr, misalign=0):
+        x = np.ascontiguousarray(x)
+        xb, xp = self._up(x, misalign); vb, vp = self._upbits(valid)
+        return self.c.cmp_filter_sum_i64(cmpop, xp, vp, off, x.size, int(thr))
+
+    def cmp_filter_sum_f64(self, cmpop, x, valid, off, thr, misalign=0):
+        x = np.ascontiguousarray(x)
+        xb, xp = self._up(x, misalign); vb, vp = self._upbits(valid)
+        return self.c.cmp_filter_sum_f64(cmpop, xp, vp, off, x.size, float(thr))

@@ -1,0 +1,586 @@
+"""Known-answer vectors from the reference's own tests, run against
+BOTH the CPU oracle (pins the oracle: `-m "not gpu"`) and the HIP library through the
+C ABI (`-m gpu`).  Citations are arrow-go paths.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as OL
+from tests.backends import OracleBackend, HipBackend, STATUS_OK, STATUS_EINDEX, STATUS_EOVERFLOW
+
+ADD, SUB, MUL, ABS, NEG, SIGN = 0, 1, 2, 4, 5, 20
+ADD_C, SUB_C, MUL_C = 21, 22, 23
+EQ, NE, GT, GE = 0, 1, 2, 3
+AA, AS, SA = 0, 1, 2
+AND, OR, XOR, ANDNOT, XNOR = 0, 1, 2, 3, 4
+DROP, EMIT = 0, 1
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    if request.param == "oracle":
+        return OracleBackend()
+    return HipBackend(request.getfixturevalue("ctx"))
+
+
+def mk(vals, dtype, null_fill=0):
+    """python list with None → (values array, validity bitmap or None)"""
+    valid = [v is not None for v in vals]
+    arr = np.array([null_fill if v is None else v for v in vals], dtype=dtype)
+    return arr, (None if all(valid) else OL.pack_bits(valid))
+
+
+def logical(values, validbits, off, n):
+    """values + validity → python list with None (array.ApproxEqual-style compare)"""
+    if validbits is None:
+        return list(values[:n].tolist())
+    v = OL.unpack_bits(validbits, off, n)
+    return [x if ok else None for x, ok in zip(values[:n].tolist(), v)]
+
+
+# ---- arrow/math Sum -----------------------------------------------------------------------
+# arrow/math/float64_test.go:30-48, int64_test.go, uint64_test.go: Σ 0..9999 = 49995000; empty → 0
+@pytest.mark.parametrize("dtype", [np.float64, np.int64, np.uint64])
+def test_sum_known_answer(be, dtype):
+    a = np.arange(10000, dtype=dtype)
+    assert be.sum(a) == 49995000
+    assert be.sum(np.zeros(0, dtype=dtype)) == 0
+
+
+# README.md:95-141 benchmark shape (BenchmarkFloat64Funcs_Sum_8192 — config C1)
+def test_sum_8192(be):
+    a = np.arange(8192, dtype=np.float64)
+    assert be.sum(a) == 8191 * 8192 / 2
+
+
+# ---- arithmetic ---------------------------------------------------------------------------
+# arrow/compute/arithmetic_test.go:325-359 (BinaryArithmeticSuite.TestAdd), value payloads;
+# null propagation is the executor's BitmapAnd, tested below in the bitmap section.
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+def test_add_vectors(be, dtype):
+    t = lambda x: np.array(x, dtype=dtype)
+    np.testing.assert_array_equal(be.arithmetic(ADD, AA, t([3, 2, 6]), t([1, 0, 2])), t([4, 2, 8]))
+    np.testing.assert_array_equal(be.arithmetic(ADD, SA, t([3]), t([1, 2])), t([4, 5]))
+    np.testing.assert_array_equal(be.arithmetic(ADD, AS, t([1, 2]), t([3])), t([4, 5]))
+    np.testing.assert_array_equal(be.arithmetic(SUB, AA, t([3, 2, 6]), t([1, 0, 2])), t([2, 2, 4]))
+    np.testing.assert_array_equal(be.arithmetic(SUB, SA, t([3]), t([1, 2])), t([2, 1]))
+    np.testing.assert_array_equal(be.arithmetic(SUB, AS, t([4, 5]), t([3])), t([1, 2]))
+    np.testing.assert_array_equal(be.arithmetic(MUL, AA, t([3, 2, 6]), t([1, 0, 2])), t([3, 0, 12]))
+    np.testing.assert_array_equal(be.arithmetic(MUL, SA, t([3]), t([1, 2])), t([3, 6]))
+    np.testing.assert_array_equal(be.arithmetic(MUL, AS, t([1, 2]), t([3])), t([3, 6]))
+
+
+# arithmetic_test.go:325-359: checked add, nulls → payload 0 (helpers.go:303-306); [max]+[max] → "overflow"
+@pytest.mark.parametrize("dtype", OL.INT_DTYPES, ids=str)
+def test_add_checked_vectors(be, dtype):
+    info = np.iinfo(dtype)
+    l, lv = mk([None, 1, None], dtype, null_fill=7)
+    r, rv = mk([3, 4, 5], dtype)
+    st, out = be.arithmetic_checked(ADD_C, AA, l, lv, 0, r, rv, 0)
+    assert st == STATUS_OK
+    np.testing.assert_array_equal(out, np.array([0, 5, 0], dtype=dtype))
+    l, lv = mk([None, 1, 2], dtype, null_fill=9)
+    r, rv = mk([3, 4, None], dtype, null_fill=9)
+    st, out = be.arithmetic_checked(ADD_C, AA, l, lv, 0, r, rv, 0)
+    assert st == STATUS_OK
+    np.testing.assert_array_equal(out, np.array([0, 5, 0], dtype=dtype))
+    m = np.array([info.max], dtype=dtype)
+    st, _ = be.arithmetic_checked(ADD_C, AA, m, None, 0, m, None, 0)
+    assert st == STATUS_EOVERFLOW
+    # overflow hidden under a null slot is not an error (only valid slots are tested)
+    st, out = be.arithmetic_checked(ADD_C, AA, m, OL.pack_bits([False]), 0, m, None, 0)
+    assert st == STATUS_OK and out[0] == 0
+    # scalar shapes
+    st, out = be.arithmetic_checked(ADD_C, SA, np.array([3], dtype=dtype), None, 0, *mk([None, 2], dtype), 0)
+    assert st == STATUS_OK
+    np.testing.assert_array_equal(out, np.array([0, 5], dtype=dtype))
+    st, out = be.arithmetic_checked(SUB_C, AS, np.array([5, 7], dtype=dtype), None, 0, np.array([3], dtype=dtype), None, 0)
+    assert st == STATUS_OK
+    np.testing.assert_array_equal(out, np.array([2, 4], dtype=dtype))
+    st, _ = be.arithmetic_checked(SUB_C, AA, np.array([info.min], dtype=dtype), None, 0, np.array([1], dtype=dtype), None, 0)
+    assert st == STATUS_EOVERFLOW
+    st, _ = be.arithmetic_checked(MUL_C, AA, m, None, 0, np.array([2], dtype=dtype), None, 0)
+    assert st == STATUS_EOVERFLOW
+    st, out = be.arithmetic_checked(MUL_C, AA, np.array([3, 2], dtype=dtype), None, 0, np.array([5, 7], dtype=dtype), None, 0)
+    assert st == STATUS_OK
+    np.testing.assert_array_equal(out, np.array([15, 14], dtype=dtype))
+
+
+def test_checked_add_reference_carry_quirk(be):
+    """kernels/base_arithmetic.go:249-263: `carry > 0` after an arithmetic shift by
+    bits-2 — MinInt64+MinInt64 (carry bit 63 set) is NOT reported; restated as is."""
+    mn = np.array([np.iinfo(np.int64).min], dtype=np.int64)
+    st, out = be.arithmetic_checked(ADD_C, AA, mn, None, 0, mn, None, 0)
+    assert st == STATUS_OK and out[0] == 0
+    st, _ = be.arithmetic_checked(ADD_C, AA, np.array([-1], np.int64), None, 0, mn, None, 0)
+    assert st == STATUS_OK  # same quirk: top carry bit set
+    um = np.array([np.iinfo(np.uint64).max], dtype=np.uint64)
+    st, _ = be.arithmetic_checked(ADD_C, AA, um, None, 0, np.array([1], np.uint64), None, 0)
+    assert st == STATUS_EOVERFLOW
+
+
+# arithmetic_test.go (UnaryArithmeticSuite): abs / negate / sign value semantics
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+def test_unary_vectors(be, dtype):
+    dt = np.dtype(dtype)
+    if dt.kind == "u":
+        a = np.array([0, 1, 10, 127], dtype=dtype)
+        np.testing.assert_array_equal(be.arithmetic_unary(ABS, a), a)
+        np.testing.assert_array_equal(be.arithmetic_unary(SIGN, a), np.array([0, 1, 1, 1], dtype=dtype))
+        np.testing.assert_array_equal(be.arithmetic_unary(NEG, a), (np.zeros_like(a) - a).astype(dtype))
+    else:
+        a = np.array([0, 1, -1, 10, -10, 127, -127], dtype=dtype)
+        np.testing.assert_array_equal(be.arithmetic_unary(ABS, a), np.abs(a))
+        np.testing.assert_array_equal(be.arithmetic_unary(NEG, a), -a)
+        np.testing.assert_array_equal(be.arithmetic_unary(SIGN, a), np.sign(a).astype(dtype))
+    if dt.kind == "i":  # abs(min) wraps to min in the unchecked kernel (base_arithmetic.cc:147-149)
+        mn = np.array([np.iinfo(dtype).min], dtype=dtype)
+        np.testing.assert_array_equal(be.arithmetic_unary(ABS, mn), mn)
+    if dt.kind == "f":
+        s = be.arithmetic_unary(SIGN, np.array([np.nan, -0.0, 0.0, -np.inf, np.inf], dtype=dtype))
+        assert np.isnan(s[0]) and s[1] == 0 and s[2] == 0 and s[3] == -1 and s[4] == 1
+        z = be.arithmetic_unary(ABS, np.array([-0.0, -np.inf], dtype=dtype))
+        assert not np.signbit(z[0]) and z[1] == np.inf
+
+
+# ---- compare ------------------------------------------------------------------------------
+# arrow/compute/scalar_compare_test.go:299-483 (NumericCompareSuite, values only)
+CMP_TABLE = [
+    (EQ, [0, 0, 1, 1, 2, 2], [False, False, True, True, False, False]),
+    (EQ, [0, 1, 2, 3, 4, 5], [False, True, False, False, False, False]),
+    (EQ, [5, 4, 3, 2, 1, 0], [False, False, False, False, True, False]),
+    (NE, [0, 0, 1, 1, 2, 2], [True, True, False, False, True, True]),
+    (NE, [5, 4, 3, 2, 1, 0], [True, True, True, True, False, True]),
+    (GT, [0, 0, 1, 1, 2, 2], [False, False, False, False, True, True]),
+    (GT, [0, 1, 2, 3, 4, 5], [False, False, True, True, True, True]),
+    (GT, [4, 5, 6, 7, 8, 9], [True, True, True, True, True, True]),
+    (GE, [0, 0, 1, 1, 2, 2], [False, False, True, True, True, True]),
+    (GE, [0, 1, 2, 3, 4, 5], [False, True, True, True, True, True]),
+]
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+def test_compare_array_scalar(be, dtype):
+    one = np.array([1], dtype=dtype)
+    for op, vals, exp in CMP_TABLE:
+        a = np.array(vals, dtype=dtype)
+        out = be.comparison(op, AS, a, one, np.zeros(1, np.uint8))
+        assert OL.unpack_bits(out, 0, 6).tolist() == exp, (op, vals)
+    # LESS / LESS_EQUAL are the operand swap (compute/scalar_compare.go:73-99):
+    # [0,0,1,1,2,2] < 1  ==  1 > [..]  → scalar_arr GT
+    a = np.array([0, 0, 1, 1, 2, 2], dtype=dtype)
+    out = be.comparison(GT, SA, one, a, np.zeros(1, np.uint8))
+    assert OL.unpack_bits(out, 0, 6).tolist() == [True, True, False, False, False, False]
+    out = be.comparison(GE, SA, one, a, np.zeros(1, np.uint8))
+    assert OL.unpack_bits(out, 0, 6).tolist() == [True, True, True, True, False, False]
+    # array ∘ array (scalar_compare_test.go TestSimpleCompareArrayArray shape)
+    b = np.array([1, 0, 1, 2, 2, 3], dtype=dtype)
+    out = be.comparison(GT, AA, a, b, np.zeros(1, np.uint8))
+    assert OL.unpack_bits(out, 0, 6).tolist() == [False, False, False, False, False, False]
+    out = be.comparison(EQ, AA, a, b, np.zeros(1, np.uint8))
+    assert OL.unpack_bits(out, 0, 6).tolist() == [False, True, True, False, True, False]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=str)
+def test_compare_nan(be, dtype):
+    # IEEE: every ordered compare with NaN is false, != is true (scalar_comparison.cc:31-56)
+    a = np.array([np.nan, 1.0, np.nan], dtype=dtype)
+    b = np.array([np.nan, np.nan, 1.0], dtype=dtype)
+    for op, exp in [(EQ, False), (NE, True), (GT, False), (GE, False)]:
+        out = be.comparison(op, AA, a, b, np.zeros(1, np.uint8))
+        assert OL.unpack_bits(out, 0, 3).tolist() == [exp] * 3
+
+
+def test_compare_preserves_bits_outside_range(be):
+    # scalar_comparison.cc:71-81,91-95: prefix/tail via set_bit_to keep neighbouring bits
+    a = np.arange(21, dtype=np.int32)
+    init = np.full(5, 0xFF, dtype=np.uint8)
+    out = be.comparison(GT, AS, a, np.array([100], np.int32), init, out_bit_offset=3)
+    bits = OL.unpack_bits(out, 0, 40)
+    assert bits[:3].all() and not bits[3:24].any() and bits[24:].all()
+
+
+# ---- bitmaps ------------------------------------------------------------------------------
+def bbits(*vals):
+    """arrow/internal/testing/tools/bits.go:26-40 IntsToBitsLSB: leftmost hex digit = bit 0"""
+    out = []
+    for v in vals:
+        digits = f"{v:08x}"
+        out.append(sum((1 << j) for j, ch in enumerate(digits) if ch == "1"))
+    return np.array(out, dtype=np.uint8)
+
+
+# arrow/bitutil/bitutil_test.go:155-189 TestCountSetBits
+COUNT_TABLE = [
+    (bbits(0x11000000), 0, 3, 2),
+    (bbits(0x11000011, 0x01000000), 0, 11, 5),
+    (bbits(0x11001010, 0x11110000, 0x00001111, 0x11000011, 0x11001010, 0x11110000, 0x00001111, 0x11000011, 0x10001001), 0, 72, 35),
+    (bbits(0x11111110), 0, 8, 7),
+    (bbits(0x11100001), 0, 3, 3),
+    (bbits(0x11111111, 0x11111111), 0, 11, 11),
+    (bbits(*([0x11111111] * 9)), 0, 72, 72),
+    (bbits(0x00000001), 0, 3, 0),
+    (bbits(0x00000000, 0x00000000), 0, 11, 0),
+    (bbits(*([0] * 9)), 0, 72, 0),
+    (bbits(0x11000000), 1, 3, 1),
+    (bbits(0x11000000), 2, 3, 0),
+    (bbits(0x11000011, 0x01000000, 0x00000000), 1, 11, 4),
+    (bbits(0x11000011, 0x01000000, 0x00000000), 2, 11, 3),
+    (bbits(0x11000011, 0x01000000, 0x00000000), 3, 11, 3),
+    (bbits(0x11000011, 0x01000000, 0x00000000), 6, 11, 3),
+    (bbits(0x11000011, 0x01000000, 0x00000000), 7, 11, 2),
+    (bbits(0x11000011, 0x01000000, 0x00000000), 8, 11, 1),
+]
+
+
+def test_count_set_bits_table(be):
+    for buf, off, n, exp in COUNT_TABLE:
+        assert be.count_set_bits(buf, off, n) == exp, (buf, off, n)
+
+
+def test_count_set_bits_offset_sweep(be):
+    # bitutil_test.go:191-224: 1000 random bytes, offsets {0..12,16,32,37,63,64,128,n-30,n-64}
+    rng = np.random.default_rng(0)
+    buf = rng.integers(0, 256, 1000, dtype=np.uint8)
+    nbits = 8000
+    bits = np.unpackbits(buf, bitorder="little")
+    for off in [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 32, 37, 63, 64, 128, nbits - 30, nbits - 64]:
+        assert be.count_set_bits(buf, off, nbits - off) == int(bits[off:].sum())
+
+
+def bitmap_from_slice(vals, offset):
+    """arrow/bitutil/bitmaps_test.go bitmapFromSlice: `offset` zero bits, then vals"""
+    return OL.pack_bits([False] * offset + [bool(v) for v in vals])
+
+
+LBITS = [0, 1, 1, 1, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1]
+RBITS = [0, 0, 1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 1, 0]
+BITMAP_EXPECT = {  # bitmaps_test.go:484-536
+    AND: [0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0],
+    OR: [0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1],
+    XNOR: [1, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0],
+    XOR: [0, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 1],
+    ANDNOT: [0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 1],
+}
+
+
+@pytest.mark.parametrize("op", [AND, OR, XNOR, XOR, ANDNOT])
+def test_bitmap_op_offsets(be, op):
+    # bitmaps_test.go:364-470: aligned offsets {0,8,16,24,32,...} and unaligned
+    # {0,1,3,5,7,8,13,21,38,75,120,65536} for left × right × out
+    offsets = [0, 1, 3, 5, 7, 8, 13, 21, 38, 75, 120, 65536]
+    combos = list(itertools.product(offsets, repeat=3))
+    if be.name == "hip":  # every combo is an upload + launch; keep the mixed-alignment ones
+        combos = [c for i, c in enumerate(combos) if i % 23 == 0] + [(8, 8, 8), (16, 8, 24), (65536, 1, 7)]
+    n = len(LBITS)
+    for lo, ro, oo in combos:
+        left, right = bitmap_from_slice(LBITS, lo), bitmap_from_slice(RBITS, ro)
+        for fill in (0x00, 0xFF):
+            init = np.full((oo + n + 7) // 8 + 1, fill, dtype=np.uint8)
+            out = be.bitmap_op(op, left, lo, right, ro, init, oo, n)
+            got = OL.unpack_bits(out, oo, n).astype(int).tolist()
+            assert got == BITMAP_EXPECT[op], (op, lo, ro, oo)
+            # nothing outside [oo, oo+n) may change
+            allbits = OL.unpack_bits(out, 0, out.size * 8)
+            keep = np.ones(out.size * 8, bool); keep[oo:oo + n] = False
+            assert (allbits[keep] == bool(fill)).all(), (op, lo, ro, oo, fill)
+
+
+def test_small_bitmap_op(be):
+    # bitmaps_test.go:542-556 TestSmallBitmapOp
+    left, right = np.array([127, 207], np.uint8), np.array([254, 127], np.uint8)
+    out = be.bitmap_op(AND, left, 0, right, 0, np.zeros(2, np.uint8), 0, 8)
+    assert out[0] == 126
+    out = be.bitmap_op(AND, left, 0, right, 0, np.zeros(2, np.uint8), 0, 16)
+    assert out.tolist() == [126, 79]
+
+
+def test_bitmap_op_byte_aligned_nonzero_offset(be):
+    """The case arrow/bitutil/bitmaps.go:536 (`endMask := (lOffset + length%8)`) gets
+    wrong upstream (last byte left unwritten when lOffset is a non-zero multiple of 8 and
+    the range ends on a byte boundary).  We implement the documented contract."""
+    left, right = np.array([0, 0xF0, 0xAA], np.uint8), np.array([0, 0x3C, 0xFF], np.uint8)
+    out = be.bitmap_op(AND, left, 8, right, 8, np.zeros(3, np.uint8), 8, 16)
+    assert out.tolist() == [0, 0x30, 0xAA]
+
+
+def test_copy_invert_setbits(be):
+    # bitmaps.go:483-493 CopyBitmap / InvertBitmap, bitutil.go:158-204 SetBitsTo
+    # (bitutil_test.go:226-257 TestSetBitsTo expectations)
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, 40, dtype=np.uint8)
+    sbits = np.unpackbits(src, bitorder="little")
+    for soff, doff, n in [(0, 0, 64), (3, 0, 100), (0, 5, 77), (13, 21, 200), (8, 8, 16), (1, 7, 1), (5, 9, 0)]:
+        for inv in (False, True):
+            out = be.copy_bitmap(src, soff, n, np.full(40, 0xA5, np.uint8), doff, inv)
+            exp = np.unpackbits(np.full(40, 0xA5, np.uint8), bitorder="little")
+            exp[doff:doff + n] = sbits[soff:soff + n] ^ (1 if inv else 0)
+            np.testing.assert_array_equal(np.unpackbits(out, bitorder="little"), exp)
+    # TestSetBitsTo (bitutil_test.go:226-257)
+    for fill in (0x00, 0xFF):
+        bm = be.set_bits_to(np.full(8, fill, np.uint8), 0, 0, True)
+        assert bm.tolist() == [fill] * 8
+        bm = be.set_bits_to(np.full(8, fill, np.uint8), 2, 2, True)
+        bm = be.set_bits_to(bm, 4, 2, False)
+        assert bm[0] == ((fill & ~0x3C) | 0x0C)
+        bm = be.set_bits_to(np.full(8, fill, np.uint8), 4, 8, True)
+        bm = be.set_bits_to(bm, 12, 4, False)
+        assert bm[0] == ((fill & 0x0F) | 0xF0) and bm[1] == 0x0F
+        bm = be.set_bits_to(np.full(8, fill, np.uint8), 0, 64, True)
+        assert bm.tolist() == [0xFF] * 8
+        bm = be.set_bits_to(np.full(8, fill, np.uint8), 0, 64, False)
+        assert bm.tolist() == [0x00] * 8
+
+
+def test_kleene_truth_tables(be):
+    # compute/scalar_bool_test.go (TestAndKleene/OrKleene/AndNotKleene) truth tables
+    T, F, N = True, False, None
+    vals = [T, F, N]
+    pairs = [(a, b) for a in vals for b in vals]
+    lv = OL.pack_bits([a is not None for a, _ in pairs]); ld = OL.pack_bits([a is True for a, _ in pairs])
+    rv = OL.pack_bits([b is not None for _, b in pairs]); rd = OL.pack_bits([b is True for _, b in pairs])
+
+    def k_and(a, b):
+        if a is False or b is False: return False
+        if a is None or b is None: return None
+        return True
+
+    def k_or(a, b):
+        if a is True or b is True: return True
+        if a is None or b is None: return None
+        return False
+
+    def k_not(b): return None if b is None else (not b)
+    for op, fn in [(0, k_and), (1, k_or), (2, lambda a, b: k_and(a, k_not(b)))]:
+        for off in (0, 3):
+            lvo, ldo = bitmap_from_slice(OL.unpack_bits(lv, 0, 9), off), bitmap_from_slice(OL.unpack_bits(ld, 0, 9), off)
+            ov, od = be.kleene(op, lvo, ldo, off, rv, rd, 0, np.zeros(3, np.uint8), np.zeros(3, np.uint8), 5, 9)
+            got = [(bool(d) if v else None) for v, d in zip(OL.unpack_bits(ov, 5, 9), OL.unpack_bits(od, 5, 9))]
+            assert got == [fn(a, b) for a, b in pairs], op
+
+
+# ---- filter -------------------------------------------------------------------------------
+# arrow/compute/vector_selection_test.go:449-484 (FilterKernelNumeric.TestFilterNumeric)
+FILTER_CASES = [
+    # values, filter, null_selection, expected
+    ([], [], DROP, []),
+    ([9], [False], DROP, []),
+    ([9], [True], DROP, [9]),
+    ([9], [None], DROP, []),
+    ([9], [None], EMIT, [None]),
+    ([None], [True], DROP, [None]),
+    ([7, 8, 9], [False, True, False], DROP, [8]),
+    ([7, 8, 9], [True, False, True], DROP, [7, 9]),
+    ([None, 8, 9], [False, True, False], DROP, [8]),
+    ([7, 8, 9], [None, True, False], DROP, [8]),
+    ([7, 8, 9], [None, True, False], EMIT, [None, 8]),
+    ([7, 8, 9], [True, None, True], DROP, [7, 9]),
+    ([7, 8, 9], [True, None, True], EMIT, [7, None, 9]),
+]
+
+
+def run_filter_case(be, dtype, values, filt, null_sel, sliced):
+    vals, vvalid = mk(values, dtype, null_fill=42)
+    fd, fvalid = mk(filt, np.uint8)
+    fdata = OL.pack_bits(fd.astype(bool)) if len(filt) else np.zeros(1, np.uint8)
+    voff = foff = 0
+    if sliced:
+        # vector_selection_test.go:121-144: 3 null fillers before the values, [true,false]
+        # before the filter, then slice → non-zero bit offsets everywhere
+        voff, foff = 3, 2
+        vbits = [False] * 3 + [v is not None for v in values]
+        vvalid = OL.pack_bits(vbits)
+        fbits = [True, False] + [bool(x) for x in fd.tolist()]
+        fdata = OL.pack_bits(fbits)
+        if fvalid is not None or True:
+            fvalid = OL.pack_bits([True, True] + [f is not None for f in filt])
+    n = len(values)
+    has_nulls = (vvalid is not None and not OL.unpack_bits(vvalid, voff, n).all()) or \
+                (fvalid is not None and not OL.unpack_bits(fvalid, foff, n).all())
+    out, ov, nulls = be.filter(vals, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid=has_nulls)
+    return logical(out, ov, 0, len(out)), out, nulls
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint16, np.int32, np.float32, np.int64, np.float64], ids=str)
+@pytest.mark.parametrize("sliced", [False, True])
+def test_filter_vectors(be, dtype, sliced):
+    for values, filt, null_sel, exp in FILTER_CASES:
+        got, raw, nulls = run_filter_case(be, dtype, values, filt, null_sel, sliced)
+        assert got == exp, (values, filt, null_sel)
+        assert nulls == sum(1 for e in exp if e is None)
+
+
+def test_filter_sliced_filter(be):
+    # vector_selection_test.go:474-478: filter [F,T,T,T,F,T][3:6] on [7,8,9] → [7,9]
+    vals = np.array([7, 8, 9], np.int64)
+    fdata = OL.pack_bits([False, True, True, True, False, True])
+    out, ov, _ = be.filter(vals, None, 0, fdata, None, 3, 3, DROP, want_valid=False)
+    assert out.tolist() == [7, 9]
+
+
+def test_filter_null_payload_rules(be):
+    """a7 payload contract: selected-but-null value keeps its payload; filter-null under
+    EMIT gets payload 0 (vector_selection.go:293-297,417-421)."""
+    vals = np.array([11, 22, 33, 44], np.int64)
+    vvalid = OL.pack_bits([True, False, True, True])
+    fdata = OL.pack_bits([True, True, False, True])
+    fvalid = OL.pack_bits([True, True, True, False])
+    out, ov, nulls = be.filter(vals, vvalid, 0, fdata, fvalid, 0, 4, EMIT, want_valid=True)
+    assert out.tolist() == [11, 22, 0] and OL.unpack_bits(ov, 0, 3).tolist() == [True, False, False] and nulls == 2
+    out, ov, nulls = be.filter(vals, vvalid, 0, fdata, fvalid, 0, 4, DROP, want_valid=True)
+    assert out.tolist() == [11, 22] and OL.unpack_bits(ov, 0, 2).tolist() == [True, False] and nulls == 1
+
+
+def test_filter_to_indices(be):
+    # kernels/vector_selection.go:102-236 GetTakeIndices
+    fdata = OL.pack_bits([True, False, True, True, False])
+    fvalid = OL.pack_bits([True, True, False, True, False])
+    idx, iv, nulls = be.filter_to_indices(fdata, None, 0, 5, DROP, want_valid=False)
+    assert idx.tolist() == [0, 2, 3]
+    idx, iv, nulls = be.filter_to_indices(fdata, fvalid, 0, 5, DROP, want_valid=False)
+    assert idx.tolist() == [0, 3]
+    idx, iv, nulls = be.filter_to_indices(fdata, fvalid, 0, 5, EMIT, want_valid=True)
+    assert idx.tolist() == [0, 0, 3, 0] and OL.unpack_bits(iv, 0, 4).tolist() == [True, False, True, False] and nulls == 2
+
+
+# ---- take ---------------------------------------------------------------------------------
+# arrow/compute/vector_selection_test.go:1127-1141 (TakeKernelTestNumeric) + :213-253
+TAKE_CASES = [
+    ([7, 8, 9], [], []),
+    ([7, 8, 9], [0, 1, 0], [7, 8, 7]),
+    ([None, 8, 9], [0, 1, 0], [None, 8, None]),
+    ([7, 8, 9], [None, 1, 0], [None, 8, 7]),
+    ([None, 8, 9], [], []),
+    ([7, 8, 9], [0, 0, 0, 0, 0, 0, 2], [7, 7, 7, 7, 7, 7, 9]),
+]
+
+
+@pytest.mark.parametrize("vdtype", [np.int8, np.uint16, np.float32, np.int64, np.float64], ids=str)
+@pytest.mark.parametrize("idtype", [np.int8, np.uint32, np.int32, np.int64, np.uint16], ids=str)
+def test_take_vectors(be, vdtype, idtype):
+    for values, indices, exp in TAKE_CASES:
+        vals, vvalid = mk(values, vdtype, null_fill=55)
+        idx, ivalid = mk(indices, idtype, null_fill=1)
+        want_valid = vvalid is not None or ivalid is not None
+        st, out, ov, nulls, _ = be.take(vals, vvalid, 0, idx, ivalid, 0, True, want_valid)
+        assert st == STATUS_OK
+        assert logical(out, ov, 0, len(indices)) == exp
+        if want_valid:
+            assert nulls == sum(1 for e in exp if e is None)
+            # null outputs keep payload 0 (fresh zeroed buffer, a8)
+            assert all(o == 0 for o, e in zip(out.tolist(), exp) if e is None)
+
+
+def test_take_bounds_errors(be):
+    # vector_selection_test.go:1139-1140: index 9 and -1 → ErrIndex (helpers.go:929-957)
+    vals = np.array([7, 8, 9], np.int64)
+    st, *_rest, bad = be.take(vals, None, 0, np.array([0, 9, 0], np.int8), None, 0, True, False)
+    assert st == STATUS_EINDEX and bad == 9
+    st, *_rest, bad = be.take(vals, None, 0, np.array([0, -1, 0], np.int8), None, 0, True, False)
+    assert st == STATUS_EINDEX and bad == -1
+    # first offender in index order
+    st, *_rest, bad = be.take(vals, None, 0, np.array([0, 5, 1, -3], np.int32), None, 0, True, False)
+    assert st == STATUS_EINDEX and bad == 5
+    # a NULL index slot is never bounds-checked (VisitSetBitRuns over validity)
+    idx, ivalid = np.array([0, 99, 2], np.int32), OL.pack_bits([True, False, True])
+    st, out, ov, nulls, _ = be.take(vals, None, 0, idx, ivalid, 0, True, True)
+    assert st == STATUS_OK and out.tolist() == [7, 0, 9] and nulls == 1
+
+
+def test_take_sliced(be):
+    # vector_selection_test.go:213-253: sliced values (offset 2) and sliced indices (offset 1)
+    vfull, vvalid_full = mk([None, None, 7, 8, None], np.int64, null_fill=99)
+    ifull = np.array([77, 0, 1, 2], np.int32)
+    ivalid_full = OL.pack_bits([False, True, True, True])
+    st, out, ov, nulls, _ = be.take(vfull[2:], vvalid_full, 2, ifull[1:], ivalid_full, 1, True, True)
+    assert st == STATUS_OK
+    assert logical(out, ov, 0, 3) == [7, 8, None] and nulls == 1
+
+
+# ---- hashing ------------------------------------------------------------------------------
+def test_hash_int_function(orc):
+    # internal/hashing/hash_funcs.go:60-67: bswap64(0x9E3779B185EBCA87 * v)
+    for v in [0, 1, 2, 42, 2**63, 2**64 - 1, 0xDEADBEEF]:
+        prod = (11400714785074694791 * v) % 2**64
+        assert orc.hash_int(v) == int.from_bytes(prod.to_bytes(8, "little"), "big")
+
+
+# arrow/compute/vector_hash_test.go:236-254 (PrimitiveHashKernelSuite.TestUnique)
+UNIQUE_CASES = [
+    ([2, None, 2, 1], [2, None, 1]),
+    ([None, None, 3, 1], [None, 3, 1]),
+    ([2, 1, 2, 1], [2, 1]),
+    ([5, 4, 3, 1, 1], [5, 4, 3, 1]),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.float64], ids=str)
+def test_unique_vectors(be, dtype):
+    for values, exp in UNIQUE_CASES:
+        keys, valid = mk(values, dtype, null_fill=123)
+        ids, idv, d, null_id = be.hash_encode(keys, valid, 0, True)
+        got = [None if i == null_id else x for i, x in enumerate(d.view(dtype).tolist())]
+        assert got == exp, values
+    # sliced input: [1,2,null,3,2,null][1:5] → [2,null,3]  (vector_hash_test.go:250-253)
+    keys, valid = mk([1, 2, None, 3, 2, None], dtype, null_fill=9)
+    ids, idv, d, null_id = be.hash_encode(keys[1:5], valid, 1, True)
+    got = [None if i == null_id else x for i, x in enumerate(d.view(dtype).tolist())]
+    assert got == [2, None, 3]
+
+
+def test_dictionary_encode_vectors(be):
+    # vector_hash_test.go:541-591: ["foo","bar","foo",null,"bar",null] → [0,1,0,null,1,null]
+    # (NullEncodingMask) or [0,1,0,2,1,2] + 3-entry dictionary (NullEncodingEncode) — same
+    # rule for numeric keys (doAppendNumeric, kernels/vector_hash.go:359-385)
+    keys, valid = mk([10, 20, 10, None, 20, None], np.int64, null_fill=77)
+    ids, idv, d, null_id = be.hash_encode(keys, valid, 0, False)
+    assert ids.tolist() == [0, 1, 0, 0, 1, 0]
+    assert OL.unpack_bits(idv, 0, 6).tolist() == [True, True, True, False, True, False]
+    assert d.view(np.int64).tolist() == [10, 20] and null_id == -1
+    ids, idv, d, null_id = be.hash_encode(keys, valid, 0, True)
+    assert ids.tolist() == [0, 1, 0, 2, 1, 2] and null_id == 2 and len(d) == 3
+    assert OL.unpack_bits(idv, 0, 6).all()
+    assert d.view(np.int64).tolist()[:2] == [10, 20] and d[2] == 0
+
+
+def test_dictionary_encode_resizes_memo_table(be):
+    # vector_hash_test.go:768 TestDictionaryEncodeResizesMemoTable: enough distinct keys
+    # to force table growth (initial capacity 32, grows ×4 at load 1/2)
+    keys = np.arange(1000, dtype=np.int64) * 7919
+    keys = np.concatenate([keys, keys[::-1]])
+    ids, idv, d, null_id = be.hash_encode(keys, None, 0, False)
+    assert d.view(np.int64).tolist() == (np.arange(1000) * 7919).tolist()
+    assert ids.tolist() == list(range(1000)) + list(range(999, -1, -1))
+
+
+def test_hash_float_bit_patterns(be):
+    # vector_hash.go:604-607,690-693: Float64 keys hash raw bits → +0.0 ≠ -0.0, NaN payloads distinct
+    nan1 = np.array([0x7FF8000000000001], np.uint64).view(np.float64)[0]
+    nan2 = np.array([0x7FF8000000000002], np.uint64).view(np.float64)[0]
+    keys = np.array([0.0, -0.0, nan1, nan2, nan1, 0.0], np.float64)
+    ids, idv, d, null_id = be.hash_encode(keys, None, 0, False)
+    assert ids.tolist() == [0, 1, 2, 3, 2, 0] and len(d) == 4
+
+
+def test_hash_all_ones_key(be):
+    # 0xFFFF...FFFF is a legal key (the GPU table's EMPTY marker must not swallow it)
+    keys = np.array([2**64 - 1, 5, 2**64 - 1, 0], np.uint64)
+    ids, idv, d, null_id = be.hash_encode(keys, None, 0, False)
+    assert ids.tolist() == [0, 1, 0, 2] and d.tolist() == [2**64 - 1, 5, 0]
+
+
+# ---- fused Compare→Filter→Sum ---------------------------------------------------------------
+def test_fused_equals_unfused_chain_small(be):
+    # the reference chain: "greater" → Filter(DropNulls) → math.Sum
+    x = np.array([5, -3, 10, 7, 2, 9], np.int64)
+    valid = OL.pack_bits([True, True, False, True, True, True])
+    assert be.cmp_filter_sum_i64(GT, x, None, 0, 4) == (5 + 10 + 7 + 9, 4)
+    assert be.cmp_filter_sum_i64(GT, x, valid, 0, 4) == (5 + 7 + 9, 3)
+    assert be.cmp_filter_sum_i64(GE, x, valid, 0, 7) == (7 + 9, 2)
+    assert be.cmp_filter_sum_i64(EQ, x, valid, 0, 2) == (2, 1)
+    assert be.cmp_filter_sum_i64(NE, x, valid, 0, 2) == (5 - 3 + 7 + 9, 4)
+    xf = x.astype(np.float64)
+    s, c = be.cmp_filter_sum_f64(GT, xf, valid, 0, 4.0)
+    assert (s, c) == (21.0, 3)

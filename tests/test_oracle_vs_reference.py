@@ -1,0 +1,106 @@
+"""Pins the oracle's C restatement to the REFERENCE'S OWN CODE run here:
+oracle/_ref/libref_avx2.so is the reference's AVX2 machine code (its clang-generated
+GAS files, assembled in place by oracle/Makefile) and libref_c.so its C sum kernels
+compiled strict-sequential (= the noasm order).  Skipped only if oracle/_ref was never
+built (no /root/reference and no prebuilt binaries).
+"""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as OL
+
+ref = OL.load_reference()
+pytestmark = pytest.mark.skipif(ref is None, reason="oracle/_ref not built (reference sources absent)")
+
+
+@pytest.fixture(scope="module")
+def o():
+    return OL.load_oracle()
+
+
+def rand(rng, dtype, n):
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        a = rng.standard_normal(n).astype(dt) * 1e3
+        if n > 8:
+            a[rng.integers(0, n, 4)] = [np.nan, np.inf, -np.inf, -0.0]
+        return a
+    info = np.iinfo(dt)
+    return rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 31, 32, 33, 63, 64, 65, 255, 256, 1000, 8192, 100003])
+def test_sum_orders_bit_exact(o, n):
+    rng = np.random.default_rng(n)
+    a = rng.uniform(-1, 1, n)
+    # AVX2 path: our restatement of the 32-strided-partials order == the reference's asm, bit for bit
+    assert o.sum_float64_avx2order(a).tobytes() == ref.sum("avx2", a).tobytes()
+    # noasm path: strict left-to-right == the reference's C compiled without reassociation
+    assert o.sum_float64_seq(a).tobytes() == ref.sum("seq", a).tobytes()
+    i = rand(rng, np.int64, n)
+    assert o.sum_int64(i) == ref.sum("avx2", i) == ref.sum("seq", i)
+    u = rand(rng, np.uint64, n)
+    assert o.sum_uint64(u) == ref.sum("avx2", u) == ref.sum("seq", u)
+
+
+def test_sum_exact_is_between_friends(o):
+    # the correctly rounded sum is what both reference orders approximate
+    rng = np.random.default_rng(7)
+    a = rng.uniform(-1, 1, 1 << 16)
+    import math
+    assert o.sum_float64_exact(a) == math.fsum(a.tolist())
+    big = np.array([1e308, 1.0, -1e308, 1e-300] * 5)
+    assert o.sum_float64_exact(big) == math.fsum(big.tolist())
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+@pytest.mark.parametrize("op", [0, 1, 2, 21, 22, 23])
+def test_arithmetic_matches_reference_avx2(o, dtype, op):
+    rng = np.random.default_rng(op * 100 + OL.TYPE_IDS[np.dtype(dtype)])
+    for n in [0, 1, 3, 15, 16, 17, 31, 33, 64, 1000]:
+        l, r = rand(rng, dtype, n), rand(rng, dtype, n)
+        s = rand(rng, dtype, 1)
+        for shape, a, b in [(0, l, r), (1, l, s), (2, s, r)]:
+            if n == 0 and shape != 0:
+                continue
+            got, exp = o.arithmetic(op, shape, a, b), ref.arithmetic(op, shape, a, b)
+            assert got.tobytes() == exp.tobytes(), (dtype, op, shape, n)
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+@pytest.mark.parametrize("op", [4, 5])
+def test_unary_matches_reference_avx2(o, dtype, op):
+    rng = np.random.default_rng(op)
+    for n in [1, 3, 17, 64, 1000]:
+        a = rand(rng, dtype, n)
+        assert o.arithmetic_unary(op, a).tobytes() == ref.arithmetic_unary(op, a).tobytes(), (dtype, op, n)
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+@pytest.mark.parametrize("cmpop", [0, 1, 2, 3])
+def test_compare_matches_reference_avx2(o, dtype, cmpop):
+    rng = np.random.default_rng(cmpop)
+    dt = np.dtype(dtype)
+    for n in [1, 5, 8, 31, 32, 33, 64, 100, 1000]:
+        # small value range so equality actually happens
+        l = rng.integers(0, 4, n).astype(dt); r = rng.integers(0, 4, n).astype(dt)
+        if dt.kind == "f" and n > 4:
+            l[1] = np.nan; r[2] = np.nan
+        s = np.array([2], dtype=dt)
+        for shape, a, b in [(0, l, r), (1, l, s), (2, s, r)]:
+            for offset in [0, 1, 3, 7]:
+                for fill in (0x00, 0xFF):
+                    nb = (offset + n + 7) // 8 + 1
+                    got = o.comparison(cmpop, shape, a, b, np.full(nb, fill, np.uint8), offset)
+                    exp = ref.comparison(cmpop, shape, a, b, np.full(nb, fill, np.uint8), offset)
+                    assert got.tobytes() == exp.tobytes(), (dtype, cmpop, shape, n, offset, fill)
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
+def test_bitmap_aligned_matches_reference_avx2(o, op):
+    rng = np.random.default_rng(op)
+    for nbytes in [1, 7, 31, 32, 33, 100, 4096]:
+        l = rng.integers(0, 256, nbytes, dtype=np.uint8); r = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        exp = ref.bitmap_aligned(op, l, r)
+        got = o.bitmap_op(op, l, 0, r, 0, np.zeros(nbytes, np.uint8), 0, nbytes * 8)
+        assert got.tobytes() == exp.tobytes()
