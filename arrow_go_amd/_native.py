@@ -98,6 +98,8 @@ _SIGS = {
     "ah_sync": [_vp],
     "ah_timer_start": [_vp],
     "ah_timer_stop": [_vp, _pf],
+    "ah_event_record": [_vp, _int],
+    "ah_event_elapsed_ms": [_vp, _int, _int, _pf],
     "ah_sum_float64": [_vp, _vp, _sz, _pd],
     "ah_sum_int64": [_vp, _vp, _sz, _pi64],
     "ah_sum_uint64": [_vp, _vp, _sz, C.POINTER(C.c_uint64)],

@@ -19,6 +19,8 @@ struct ah_ctx {
   hipEvent_t ev_copy;       // orders copy stream <-> compute stream
   hipEvent_t ev_compute;
   hipEvent_t t0, t1;        // ah_timer_*
+  hipEvent_t* marks;        // ah_event_record ring (lazily created)
+  int n_marks;
   // scratch arena (device): partial sums, tile counts, hash tables ...
   void* scratch;
   size_t scratch_bytes;

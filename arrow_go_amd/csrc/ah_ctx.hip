@@ -75,6 +75,8 @@ AH_EXPORT void ah_ctx_destroy(ah_ctx* c) {
   (void)hipEventDestroy(c->ev_compute);
   (void)hipEventDestroy(c->t0);
   (void)hipEventDestroy(c->t1);
+  for (int i = 0; i < c->n_marks; i++) if (c->marks[i]) (void)hipEventDestroy(c->marks[i]);
+  free(c->marks);
   (void)hipStreamDestroy(c->copy_stream);
   if (c->owns_stream) (void)hipStreamDestroy(c->stream);
   free(c);
@@ -179,6 +181,36 @@ AH_EXPORT int ah_timer_stop(ah_ctx* c, float* ms_host) {
   AH_HIP(c, hipEventSynchronize(c->t1));
   float ms = 0.f;
   AH_HIP(c, hipEventElapsedTime(&ms, c->t0, c->t1));
+  if (ms_host) *ms_host = ms;
+  return AH_OK;
+}
+
+// numbered event slots on the compute stream: lets a harness bracket individual
+// kernels inside a longer timed region without synchronising in between
+AH_EXPORT int ah_event_record(ah_ctx* c, int slot) {
+  AH_ENTER(c);
+  if (slot < 0 || slot >= (1 << 16)) return ah_fail(c, AH_EINVALID, "event_record: slot out of range");
+  if (slot >= c->n_marks) {
+    int n = c->n_marks ? c->n_marks : 64;
+    while (n <= slot) n *= 2;
+    hipEvent_t* m = (hipEvent_t*)realloc(c->marks, (size_t)n * sizeof(hipEvent_t));
+    if (!m) return ah_fail(c, AH_EINVALID, "event_record: out of memory");
+    for (int i = c->n_marks; i < n; i++) m[i] = nullptr;
+    c->marks = m;
+    c->n_marks = n;
+  }
+  if (!c->marks[slot]) AH_HIP(c, hipEventCreate(&c->marks[slot]));
+  AH_HIP(c, hipEventRecord(c->marks[slot], c->stream));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_event_elapsed_ms(ah_ctx* c, int slot_a, int slot_b, float* ms_host) {
+  AH_ENTER(c);
+  if (slot_a < 0 || slot_b < 0 || slot_a >= c->n_marks || slot_b >= c->n_marks || !c->marks[slot_a] || !c->marks[slot_b])
+    return ah_fail(c, AH_EINVALID, "event_elapsed_ms: slot never recorded");
+  AH_HIP(c, hipEventSynchronize(c->marks[slot_b]));
+  float ms = 0.f;
+  AH_HIP(c, hipEventElapsedTime(&ms, c->marks[slot_a], c->marks[slot_b]));
   if (ms_host) *ms_host = ms;
   return AH_OK;
 }

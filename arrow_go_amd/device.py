@@ -114,6 +114,14 @@ class Context:
         check(self.handle, lib.ah_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
+    def event_record(self, slot: int) -> None:
+        check(self.handle, lib.ah_event_record(self.handle, slot))
+
+    def event_elapsed_ms(self, slot_a: int, slot_b: int) -> float:
+        ms = C.c_float()
+        check(self.handle, lib.ah_event_elapsed_ms(self.handle, slot_a, slot_b, C.byref(ms)))
+        return ms.value
+
     # ---- arrow/math Sum -----------------------------------------------------------------
     def sum_float64(self, buf, n: int) -> float:
         r = C.c_double()

@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (configs[1], "C2"): one STEP = Int64 Add (array + array → array) followed by
+Float64 Sum, each over a contiguous 2^27-row (1 GiB) Arrow value buffer that is already
+resident in HBM — 24 + 8 = 32 algorithmic bytes per row per step.  With
+N > 1 every rank owns its own record-batch shard of the same size (weak scaling) and the
+per-shard Float64 partial sums are combined by ONE RCCL all-reduce of 8 bytes per step —
+the only exchange step this path has.
+
+`value` = rows·32·N / step time, in GB/s (whole job).  `roofline` is for the dominant
+kernel (the Int64 Add: 24 of the 32 bytes), timed with HIP events recorded on the
+library's own compute stream around every Add launch INSIDE the timed region.
+`cpu_baseline` = the reference's own AVX2 machine code (oracle/_ref/libref_avx2.so,
+assembled from the reference's clang output) running the same step on one host core
+over a bounded sample.  `kernels` lists achieved algorithmic GB/s for the other
+kernels of the metric (Sum / Add / Compare / Filter / Take / fused), measured after the
+timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ≈ 6.3 TB/s
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=1 << 27, help="rows per GPU (default 2^27 = 1 GiB columns)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table")
+    p.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch of the Add kernel from a rocprofv3 --pmc pass")
+    return p.parse_args()
+
+
+def fill_random(ctx, buf, rows, dtype, seed):
+    """tile one random 2^22-row chunk across the buffer (content is irrelevant to a
+    bandwidth-bound kernel, but it must not be zeros: DVFS clocks higher on zeros)"""
+    rng = np.random.default_rng(seed)
+    chunk_rows = min(rows, 1 << 22)
+    if np.dtype(dtype).kind == "f":
+        chunk = rng.uniform(-1e6, 1e6, chunk_rows).astype(dtype)
+    else:
+        chunk = rng.integers(-2**62, 2**62, chunk_rows, dtype=dtype)
+    w = np.dtype(dtype).itemsize
+    total = 0
+    exact_chunks = 0
+    for off in range(0, rows, chunk_rows):
+        m = min(chunk_rows, rows - off)
+        buf.upload(chunk[:m], off * w)
+        total += 1
+    return chunk
+
+
+def cpu_baseline(sample_rows, reps):
+    """Reference AVX2 kernels (or, if oracle/_ref was never built, our C port) on one core."""
+    from tests import oracle_lib as OL
+    ref = OL.load_reference()
+    rng = np.random.default_rng(1)
+    a = rng.integers(-2**62, 2**62, sample_rows, dtype=np.int64)
+    b = rng.integers(-2**62, 2**62, sample_rows, dtype=np.int64)
+    x = rng.uniform(-1e6, 1e6, sample_rows)
+    if ref is not None:
+        kind = "reference"
+        add = lambda: ref.arithmetic(0, 0, a, b)
+        ssum = lambda: ref.sum("avx2", x)
+    else:
+        kind = "port"
+        o = OL.load_oracle()
+        add = lambda: o.arithmetic(0, 0, a, b)
+        ssum = lambda: o.sum_float64_seq(x)
+    add(); ssum()  # warm
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        add()
+        ssum()
+    dt = time.perf_counter() - t0
+    gbs = 32.0 * sample_rows * reps / dt / 1e9
+    return {"value": round(gbs, 3), "unit": "GB/s", "cores": 1, "kind": kind,
+            "sample": f"{reps} steps of Int64 Add + Float64 Sum over {sample_rows} rows "
+                      f"({'reference AVX2 machine code, oracle/_ref/libref_avx2.so' if kind == 'reference' else 'oracle C port'}; "
+                      f"includes the output allocation the Go executor also pays), host has {os.cpu_count()} logical cores"}
+
+
+def per_kernel_table(ctx, rows, a, b, c, x):
+    """achieved algorithmic GB/s per kernel, HIP events on the ctx stream (10 launches each)"""
+    import arrow_go_amd as ah
+    N = ah._native
+    reps = 10
+    out = {}
+
+    def timed(name, nbytes, fn, reps=reps):
+        fn()  # warm
+        ctx.event_record(1000)
+        for _ in range(reps):
+            fn()
+        ctx.event_record(1001)
+        ms = ctx.event_elapsed_ms(1000, 1001) / reps
+        out[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "bytes": int(nbytes)}
+
+    res = ctx.alloc(64)
+    timed("sum_float64", 8 * rows, lambda: ctx.sum_float64_dev(x, rows, res))
+    timed("sum_int64", 8 * rows, lambda: ctx.sum_int64_dev(a, rows, res))
+    timed("add_int64", 24 * rows, lambda: ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, a, b, c, rows))
+    timed("add_float64", 24 * rows, lambda: ctx.arithmetic(N.FLOAT64, N.OP_ADD, N.SHAPE_AA, x, b, c, rows))
+    timed("add_int64_scalar", 16 * rows, lambda: ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AS, a, np.array([7], np.int64), c, rows))
+    mask = ctx.alloc(rows // 8 + 64)
+    thr = np.array([0], np.int64)
+    timed("greater_int64_scalar", 8.125 * rows, lambda: ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT64, a, thr, mask, rows, 0))
+    # C3: Filter on a 1 GiB Int64 column with 10 % nulls, ~50 % selectivity (mask = a > 0)
+    rng = np.random.default_rng(5)
+    vbits = np.packbits(rng.random(1 << 22) < 0.9, bitorder="little")
+    vvalid = ctx.alloc(rows // 8 + 64)
+    for off in range(0, rows // 8, vbits.size):
+        vvalid.upload(vbits[:min(vbits.size, rows // 8 - off)], off)
+    n_out = ctx.filter_count(mask, None, 0, rows, 0)
+    s = n_out / rows
+    ovalid = ctx.alloc(rows // 8 + 64)
+    timed("filter_int64_nulls10_sel%.2f" % s, (8 + 0.125 + 0.125) * rows + (8 + 0.125) * n_out,
+          lambda: ctx.filter_primitive(8, a, vvalid, 0, mask, None, 0, rows, 0, n_out, c, ovalid, want_null_count=False))
+    out["filter_input_GB/s"] = round(8 * rows / out["filter_int64_nulls10_sel%.2f" % s]["ms"] / 1e6, 1)
+    timed("filter_count", 0.125 * rows, lambda: ctx.filter_count(mask, None, 0, rows, 0))
+    # C3: Take, int32 indices (random / sorted-identity) into the 1 GiB column
+    idx = ctx.alloc(rows * 4)
+    ichunk = rng.integers(0, rows, 1 << 22, dtype=np.int64).astype(np.int32)
+    for off in range(0, rows, 1 << 22):
+        idx.upload(ichunk[:min(1 << 22, rows - off)], off * 4)
+    timed("take_int64_random_i32", 20 * rows,
+          lambda: ctx.take_primitive(8, a, None, 0, rows, 4, True, idx, None, 0, rows, True, c, None), reps=3)
+    for off in range(0, rows, 1 << 22):
+        m = min(1 << 22, rows - off)
+        idx.upload(np.arange(off, off + m, dtype=np.int32), off * 4)
+    timed("take_int64_identity_i32", 20 * rows,
+          lambda: ctx.take_primitive(8, a, None, 0, rows, 4, True, idx, None, 0, rows, True, c, None), reps=3)
+    timed("fused_gt_filter_sum_int64", 8 * rows, lambda: ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, res))
+    timed("fused_gt_filter_sum_int64_nulls10", 8.125 * rows, lambda: ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, vvalid, 0, rows, 0, res))
+    timed("bitmap_and", 0.375 * rows, lambda: ctx.bitmap_op(N.BIT_AND, mask, 0, vvalid, 0, ovalid, 0, rows))
+    timed("count_set_bits", 0.125 * rows, lambda: ctx.count_set_bits(mask, 0, rows))
+    for bfr in (res, mask, vvalid, ovalid, idx):
+        bfr.free()
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = torch = None
+    if world > 1:
+        # torch FIRST: its bundled libamdhip64 must be the one HIP runtime in the process
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import arrow_go_amd as ah
+    N = ah._native
+    if world > 1:
+        ctx = ah.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    else:
+        ctx = ah.Context(0)
+
+    rows = args.rows
+    a = ctx.alloc(rows * 8); b = ctx.alloc(rows * 8); c = ctx.alloc(rows * 8); x = ctx.alloc(rows * 8)
+    ca = fill_random(ctx, a, rows, np.int64, 10 + rank)
+    cb = fill_random(ctx, b, rows, np.int64, 20 + rank)
+    cx = fill_random(ctx, x, rows, np.float64, 30 + rank)
+    if world > 1:
+        part = torch.zeros(1, dtype=torch.float64, device=f"cuda:{local_rank}")
+        part_ptr = part.data_ptr()
+    else:
+        part_buf = ctx.alloc(64)
+        part_ptr = part_buf.ptr
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    def step(i, mark):
+        if mark:
+            ctx.event_record(2 * i)
+        ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, a, b, c, rows)
+        if mark:
+            ctx.event_record(2 * i + 1)
+        ctx.sum_float64_dev(x, rows, part_ptr)
+        if world > 1:
+            dist.all_reduce(part)  # 8-byte RCCL all-reduce: the path's only exchange step
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    # correctness spot-check (not timed): first chunk of c == a + b; partial sum == tiled chunk sum
+    got = c.download(np.int64, 4096)
+    assert got.tobytes() == (ca[:4096] + cb[:4096]).tobytes(), "bench: Add produced wrong values"
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / max(args.steps, 1)
+    add_ms = [ctx.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(args.steps)]
+    add_avg_ms = float(np.mean(add_ms)) if add_ms else float("nan")
+
+    if rank == 0:
+        bytes_per_step = 32.0 * rows * args.gpus
+        value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
+        achieved = 24.0 * rows / (add_avg_ms * 1e-3) / 1e9
+        result = {
+            "metric": "GB/s processed per kernel (Sum/Add/Filter/Take) vs HBM roofline",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64+f64", "data": "synthetic",
+            "config": {"workload": "C2: Int64 Add (array+array) + Float64 Sum over contiguous Arrow value buffers resident in HBM"
+                                   + (" + 8-byte RCCL all-reduce of the partial sums" if world > 1 else ""),
+                       "rows_per_gpu": rows, "bytes_per_row_per_step": 32,
+                       "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "binary_kernel<uint64, ADD, array∘array> (Int64 Add)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic,
+                         "avg_launch_ms": round(add_avg_ms, 5), "algorithmic_bytes_per_launch": int(24 * rows)},
+        }
+        if world == 1 and not args.no_kernels:
+            try:
+                result["kernels"] = per_kernel_table(ctx, rows, a, b, c, x)
+            except Exception as e:  # the table is informative; never lose the headline over it
+                result["kernels"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(min(rows, 1 << 26), 8)
+            except Exception as e:
+                result["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

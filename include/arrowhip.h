@@ -120,6 +120,10 @@ int ah_sync(ah_ctx* ctx);
 /* hipEvent pair on the compute stream (what bench.py times kernels with). */
 int ah_timer_start(ah_ctx* ctx);
 int ah_timer_stop(ah_ctx* ctx, float* ms_host); /* synchronises */
+/* numbered event slots (0..65535): bracket single kernels inside a longer timed region
+ * without synchronising in between; elapsed_ms waits for slot_b only. */
+int ah_event_record(ah_ctx* ctx, int slot);
+int ah_event_elapsed_ms(ah_ctx* ctx, int slot_a, int slot_b, float* ms_host);
 
 /* ---- arrow/math Sum -------------------------------------------------------
  * replaces _sum_float64_avx2 / sum_float64_go (arrow/math/float64_avx2_amd64.go:33-42,
