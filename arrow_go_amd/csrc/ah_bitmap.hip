@@ -82,8 +82,9 @@ __global__ __launch_bounds__(kBlock) void bitmap_op_kernel(const uint8_t* __rest
 }
 
 __global__ __launch_bounds__(kBlock) void popcount_kernel(const uint8_t* __restrict__ bits, int64_t off, int64_t nbits,
-                                                           unsigned long long* __restrict__ total) {
-  // read-side span: same word cutting, no writes
+                                                           unsigned long long* __restrict__ partials) {
+  // read-side span: same word cutting, no writes; one partial per workgroup (a single
+  // global counter would serialise ~12 ns per same-address atomic)
   OutSpan s = make_span((uint8_t*)bits, off, nbits);
   const uint64_t* w = (const uint64_t*)s.base;
   uint64_t acc = 0;
@@ -104,7 +105,22 @@ __global__ __launch_bounds__(kBlock) void popcount_kernel(const uint8_t* __restr
   if (threadIdx.x == 0) {
     uint64_t tot = 0;
     for (int k = 0; k < kBlock / 64; k++) tot += sm[k];
-    if (tot) atomicAdd(total, (unsigned long long)tot);
+    partials[blockIdx.x] = tot;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void popcount_final_kernel(const unsigned long long* __restrict__ partials, int n,
+                                                                 unsigned long long* __restrict__ total) {
+  uint64_t acc = 0;
+  for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[i];
+  acc = ah_wave_sum(acc);
+  __shared__ uint64_t sm[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t tot = 0;
+    for (int k = 0; k < kBlock / 64; k++) tot += sm[k];
+    *total = tot;
   }
 }
 
@@ -164,6 +180,18 @@ int launch_bitmap(ah_ctx* c, const uint8_t* l, int64_t loff, const uint8_t* r, i
 
 }  // namespace
 
+int ah_popcount_async(ah_ctx* c, const uint8_t* bits, int64_t off, int64_t nbits, unsigned long long* total_dev) {
+  OutSpan s = make_span((uint8_t*)bits, off, nbits);
+  int64_t g = ah_ceil_div(s.nwords, (int64_t)kBlock * 4);  // ≥ 4 words per lane
+  unsigned grid = (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+  unsigned long long* partials = (unsigned long long*)&c->dscalars[64];
+  popcount_kernel<<<grid, kBlock, 0, c->stream>>>(bits, off, nbits, partials);
+  AH_LAUNCH_CHECK(c);
+  popcount_final_kernel<<<1, kBlock, 0, c->stream>>>(partials, (int)grid, total_dev);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
+
 AH_EXPORT int ah_bitmap_op(ah_ctx* c, int op, const uint8_t* l, int64_t loff, const uint8_t* r, int64_t roff,
                            uint8_t* out, int64_t ooff, int64_t nbits) {
   AH_ENTER(c);
@@ -205,11 +233,8 @@ AH_EXPORT int ah_count_set_bits(ah_ctx* c, const uint8_t* bits, int64_t off, int
   if (nbits == 0) return AH_OK;
   if (!bits) { *out_host = nbits; return AH_OK; }
   unsigned long long* total = (unsigned long long*)c->dscalars;
-  AH_HIP(c, hipMemsetAsync(total, 0, sizeof(*total), c->stream));
-  OutSpan s = make_span((uint8_t*)bits, off, nbits);
-  unsigned grid = ah_stream_grid(c, ah_ceil_div(s.nwords, kBlock));
-  popcount_kernel<<<grid, kBlock, 0, c->stream>>>(bits, off, nbits, total);
-  AH_LAUNCH_CHECK(c);
+  int rc = ah_popcount_async(c, bits, off, nbits, total);
+  if (rc != AH_OK) return rc;
   AH_HIP(c, hipMemcpyAsync(c->pinned, total, sizeof(*total), hipMemcpyDeviceToHost, c->stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
   *out_host = (int64_t) * (volatile uint64_t*)c->pinned;

@@ -26,7 +26,8 @@ struct ah_ctx {
   size_t scratch_bytes;
   // small pinned staging block for *_host results (64 x 8 bytes)
   uint64_t* pinned;
-  // small device block for scalar results / flags (64 x 8 bytes)
+  // small device block for scalar results / flags (64 x 8 bytes) followed by a
+  // 4096-entry partials area (popcount)
   uint64_t* dscalars;
   int num_cu;
   // tunables (env ARROWHIP_NT / ARROWHIP_BLOCKS_PER_CU, read at ctx creation)
@@ -73,6 +74,9 @@ static inline int ah_fail(ah_ctx* ctx, int code, const char* fmt, ...) {
 
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
+// internal (ah_bitmap.hip): popcount of bits [off, off+nbits) into *total_dev (8 bytes,
+// device), enqueued on the compute stream; uses dscalars[16..] as partials — no scratch.
+int ah_popcount_async(ah_ctx* ctx, const uint8_t* bits, int64_t off, int64_t nbits, unsigned long long* total_dev);
 
 static inline int ah_type_width(int type) {
   switch (type) {

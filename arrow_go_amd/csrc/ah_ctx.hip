@@ -24,7 +24,7 @@ static int ctx_init_common(ah_ctx* c) {
   AH_HIP(c, hipEventCreate(&c->t0));
   AH_HIP(c, hipEventCreate(&c->t1));
   AH_HIP(c, hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
-  AH_HIP(c, hipMalloc((void**)&c->dscalars, 64 * sizeof(uint64_t)));
+  AH_HIP(c, hipMalloc((void**)&c->dscalars, (64 + 4096) * sizeof(uint64_t)));
   hipDeviceProp_t prop;
   AH_HIP(c, hipGetDeviceProperties(&prop, c->device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

@@ -55,8 +55,17 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long
                                                          unsigned long long* __restrict__ distinct, unsigned* __restrict__ overflow) {
   const uint64_t mask = cap - 1;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (*(volatile unsigned*)overflow) return;
+  unsigned fresh = 0;  // keys this lane inserted and has not yet published to `distinct`
+  unsigned it = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride, it++) {
+    // `distinct` is a load-factor guard only (results never depend on it).  A single global
+    // counter costs ~12 ns per same-address atomic, so lanes publish in batches (every 256
+    // passes; hipcc folds the wave's adds into one atomic) and poll every 64 passes.
+    if ((it & 63) == 0) {
+      if (*(volatile unsigned*)overflow) break;
+      if (*(volatile unsigned long long*)distinct > cap / 2) { atomicExch(overflow, 1u); break; }
+    }
+    if ((it & 255) == 255 && fresh) { atomicAdd(distinct, (unsigned long long)fresh); fresh = 0; }
     uint64_t s;
     if (ah_bit(valid, off + i)) {
       unsigned long long k = keys[i];
@@ -65,22 +74,18 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long
       } else {
         uint64_t idx = hash_int(k) & mask;
         int probes = 0;
+        bool dead = false;
         for (;;) {
           unsigned long long cur = table[idx].key;  // plain load: settled slots skip the CAS
-          if (cur != k) {
-            if (cur == kEmpty) {
-              cur = atomicCAS(&table[idx].key, kEmpty, k);
-              if (cur == kEmpty) {
-                unsigned long long d = atomicAdd(distinct, 1ull) + 1;
-                if (d > cap / 2) { atomicExch(overflow, 1u); return; }
-                cur = k;
-              }
-            }
+          if (cur != k && cur == kEmpty) {
+            cur = atomicCAS(&table[idx].key, kEmpty, k);
+            if (cur == kEmpty) { fresh++; cur = k; }
           }
           if (cur == k) break;
           idx = (idx + 1) & mask;
-          if (++probes > 1 << 16) { atomicExch(overflow, 1u); return; }
+          if (++probes > 1 << 12) { dead = true; break; }  // table (nearly) full
         }
+        if (dead) { atomicExch(overflow, 1u); break; }
         s = idx;
       }
     } else if (encode_nulls) {
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long
     if (table[s].first_row > (unsigned)i) atomicMin(&table[s].first_row, (unsigned)i);
     if (row_slot) row_slot[i] = (unsigned)s;
   }
+  if (fresh) atomicAdd(distinct, (unsigned long long)fresh);
 }
 
 __global__ __launch_bounds__(kBlock) void mark_kernel(const Slot* __restrict__ table, uint64_t nslots,

@@ -42,7 +42,6 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
   T* __restrict__ out = (T*)out_v;
   const int lane = threadIdx.x & 63;
   const int64_t n_iters = (nidx + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);
-  unsigned nvalid_local = 0;
   for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
     const int64_t base = it * kBlock * kUnroll + threadIdx.x;
     uint64_t u[kUnroll];
@@ -86,12 +85,10 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
             int nbytes = (int)((left + 7) >> 3);
             for (int bb = 0; bb < nbytes; bb++) p[bb] = (uint8_t)(word >> (8 * bb));
           }
-          nvalid_local += (unsigned)__popcll(word);
         }
       }
     }
   }
-  if (HAS_VALID && lane == 0 && nvalid_local) atomicAdd(valid_total, (unsigned long long)nvalid_local);
 }
 
 template <int W, typename IdxT>
@@ -156,6 +153,10 @@ AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, c
     default: return ah_fail(c, AH_EINVALID, "invalid values byte width for take");  // :1189
   }
   if (rc != AH_OK) return rc;
+  if (out_valid && out_null_count_host) {
+    rc = ah_popcount_async(c, out_valid, 0, nidx, valid_total);
+    if (rc != AH_OK) return rc;
+  }
   AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[1], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
   uint64_t bad_pos = *(volatile uint64_t*)&c->pinned[0];
