@@ -35,6 +35,22 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ≈ 6.3 TB/s
 
 
+def pmc_traffic(rows):
+    """HBM bytes per launch of the Int64 Add kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE),
+    or None if the profile is for a different size."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if d.get("rows") != rows:
+            return None
+        for k, v in d["kernels"].items():
+            if "binary_kernel<unsigned long, 0, 0, true" in k:
+                return int(v["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -240,7 +256,8 @@ def main():
                        "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "binary_kernel<uint64, ADD, array∘array> (Int64 Add)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": args.traffic if args.traffic is not None else pmc_traffic(rows),
                          "avg_launch_ms": round(add_avg_ms, 5), "algorithmic_bytes_per_launch": int(24 * rows)},
         }
         if world == 1 and not args.no_kernels:
