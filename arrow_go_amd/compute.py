@@ -1,0 +1,197 @@
+"""Array-level access to the C++ host layer (libarrowhip_compute.so), which mirrors
+arrow-go's `compute.CallFunction` / function registry / `arrow/math` API on top of the HIP
+kernels.  Arrays cross the boundary through the Arrow C Data Interface, exactly the route
+arrow-go's own `arrow/cdata` package provides; pyarrow is only the producer/consumer of
+those structs in the tests.
+
+    s = Session(0)
+    s.call_function("add", [pa.array([3, 2, 6]), pa.array([1, 0, 2])])   # → [4, 2, 8]
+    s.call_function("filter", [values, mask], "null_selection_behavior=emit_null")
+
+Errors mirror arrow-go's sentinel errors (arrow.ErrInvalid, ErrIndex, ErrNotImplemented,
+"function '…' not found").  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+
+from . import _native  # loads libarrowhip.so first (RTLD_GLOBAL)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libarrowhip_compute.so")
+if not os.path.exists(_LIB):
+    raise ImportError(f"{_LIB} is missing — run __graft_entry__.build()")
+lib = C.CDLL(_LIB)
+
+_vp = C.c_void_p
+lib.ahc_session_create.argtypes = [C.c_int, C.POINTER(_vp)]
+lib.ahc_session_destroy.argtypes = [_vp]
+lib.ahc_session_destroy.restype = None
+lib.ahc_last_error.argtypes = [_vp]
+lib.ahc_last_error.restype = C.c_char_p
+lib.ahc_datum_release.argtypes = [_vp]
+lib.ahc_datum_release.restype = None
+lib.ahc_import.argtypes = [_vp, _vp, _vp, C.POINTER(_vp)]
+lib.ahc_scalar.argtypes = [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]
+lib.ahc_datum_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                               C.POINTER(C.c_int), _vp]
+lib.ahc_call.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]
+lib.ahc_export.argtypes = [_vp, _vp, _vp, _vp]
+lib.ahc_math_sum.argtypes = [_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+lib.ahc_has_function.argtypes = [C.c_char_p]
+lib.ahc_function_num_kernels.argtypes = [C.c_char_p]
+lib.ahc_registry_add_alias.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_int]
+
+
+class ArrowError(Exception):
+    code = 0
+
+
+class ErrInvalid(ArrowError):
+    code = 1
+
+
+class ErrIndex(ArrowError):
+    code = 2
+
+
+class ErrNotImplemented(ArrowError):
+    code = 3
+
+
+class ErrType(ArrowError):
+    code = 4
+
+
+class ErrKey(ArrowError):
+    code = 5
+
+
+class ErrHip(ArrowError):
+    code = 6
+
+
+_ERRS = {1: ErrInvalid, 2: ErrIndex, 3: ErrNotImplemented, 4: ErrType, 5: ErrKey, 6: ErrHip}
+
+# arrow.Type ids
+_TYPE_IDS = {"bool": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7, "uint64": 8, "int64": 9,
+             "float": 11, "double": 12}
+_PACK = {1: "<?", 2: "<B", 3: "<b", 4: "<H", 5: "<h", 6: "<I", 7: "<i", 8: "<Q", 9: "<q", 11: "<f", 12: "<d"}
+
+
+def has_function(name: str) -> bool:
+    return bool(lib.ahc_has_function(name.encode()))
+
+
+def function_num_kernels(name: str) -> int:
+    return int(lib.ahc_function_num_kernels(name.encode()))
+
+
+def num_functions() -> int:
+    return int(lib.ahc_num_functions())
+
+
+class Session:
+    """A device session: ah_ctx + ExecCtx with its own child registry."""
+
+    def __init__(self, device_id: int = 0):
+        h = _vp()
+        rc = lib.ahc_session_create(device_id, C.byref(h))
+        if rc != 0:
+            raise ErrHip("ahc_session_create failed: is a GPU visible? (no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.ahc_session_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _ERRS.get(rc, ArrowError)(lib.ahc_last_error(self.h).decode())
+
+    # -- datum plumbing
+    def _import(self, arr):
+        import pyarrow as pa
+        if isinstance(arr, pa.ChunkedArray):
+            arr = arr.combine_chunks()
+        a = (C.c_uint8 * 80)()
+        s = (C.c_uint8 * 72)()
+        arr._export_to_c(C.addressof(a), C.addressof(s))
+        d = _vp()
+        self._check(lib.ahc_import(self.h, C.addressof(a), C.addressof(s), C.byref(d)))
+        return d
+
+    def _scalar(self, sc):
+        import pyarrow as pa
+        tid = _TYPE_IDS[str(sc.type)]
+        valid = sc.is_valid
+        buf = (C.c_uint8 * 8)()
+        if valid:
+            raw = struct.pack(_PACK[tid], sc.as_py())
+            C.memmove(buf, raw, len(raw))
+        d = _vp()
+        self._check(lib.ahc_scalar(self.h, tid, int(valid), buf, C.byref(d)))
+        return d
+
+    def _to_datum(self, x):
+        import pyarrow as pa
+        if isinstance(x, (pa.Array, pa.ChunkedArray)):
+            return self._import(x)
+        if isinstance(x, pa.Scalar):
+            return self._scalar(x)
+        raise TypeError(f"unsupported argument {type(x)}: pass a pyarrow Array or Scalar")
+
+    def _export(self, d):
+        import pyarrow as pa
+        kind, tid, length, nulls, sv = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int()
+        val = (C.c_uint8 * 8)()
+        lib.ahc_datum_info(d, C.byref(kind), C.byref(tid), C.byref(length), C.byref(nulls), C.byref(sv), val)
+        if kind.value == 1:  # scalar
+            name = {v: k for k, v in _TYPE_IDS.items()}[tid.value]
+            typ = {"float": pa.float32(), "double": pa.float64(), "bool": pa.bool_()}.get(name) or getattr(pa, name)()
+            if not sv.value:
+                return pa.scalar(None, type=typ)
+            fmt = _PACK[tid.value]
+            return pa.scalar(struct.unpack(fmt, bytes(val)[:struct.calcsize(fmt)])[0], type=typ)
+        a = (C.c_uint8 * 80)()
+        s = (C.c_uint8 * 72)()
+        self._check(lib.ahc_export(self.h, d, C.addressof(a), C.addressof(s)))
+        return pa.Array._import_from_c(C.addressof(a), C.addressof(s))
+
+    # -- compute.CallFunction
+    def call_function(self, name: str, args, options: str = ""):
+        datums = [self._to_datum(x) for x in args]
+        try:
+            arr = (_vp * len(datums))(*datums)
+            out = _vp()
+            self._check(lib.ahc_call(self.h, name.encode(), options.encode(), len(datums), arr, C.byref(out)))
+            try:
+                return self._export(out)
+            finally:
+                lib.ahc_datum_release(out)
+        finally:
+            for d in datums:
+                lib.ahc_datum_release(d)
+
+    # -- arrow/math
+    def math_sum(self, arr):
+        d = self._import(arr)
+        try:
+            f, i, u = C.c_double(), C.c_int64(), C.c_uint64()
+            self._check(lib.ahc_math_sum(self.h, d, C.byref(f), C.byref(i), C.byref(u)))
+            t = str(arr.type)
+            return f.value if t == "double" else (i.value if t == "int64" else u.value)
+        finally:
+            lib.ahc_datum_release(d)
+
+    def add_alias(self, alias: str, existing: str, allow_overwrite: bool = False):
+        self._check(lib.ahc_registry_add_alias(self.h, alias.encode(), existing.encode(), int(allow_overwrite)))

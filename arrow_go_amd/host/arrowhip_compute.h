@@ -1,0 +1,322 @@
+// arrowhip_compute.h — host-side mirror of arrow-go's compute plugin interface for the
+// hot path, above the C ABI of libarrowhip.so.
+//
+// Why C++: the reference's host side is Go and there is no Go toolchain in this
+// image, so the layer a Go maintainer would write with cgo is
+// restated here in C++ with the SAME names, argument meaning and error behaviour:
+//
+//   arrowhip::exec::{ArraySpan, ExecValue, ExecSpan, ExecResult, KernelCtx,
+//                    NullHandling, MemAlloc, ScalarKernel, VectorKernel}
+//                                   ≙ arrow/compute/exec/{span.go:76-88,548-576,
+//                                     kernel.go:78-93,457-499,617-727}
+//   arrowhip::compute::{Function, ScalarFunction, VectorFunction, MetaFunction,
+//                    FunctionRegistry, GetFunctionRegistry, NewChildRegistry, ExecCtx,
+//                    Datum, CallFunction}
+//                                   ≙ arrow/compute/{functions.go:30-41,239-420,
+//                                     registry.go:30-120, executor.go:46-122,
+//                                     datum.go:35-40, exec.go:59-191}
+//   the scalar executor (length check, output preallocation, propagateNulls) and the
+//   vector executor               ≙ arrow/compute/executor.go:237-349,498-702,896-1100
+//   arrowhip::math::{Float64, Int64, Uint64}.Sum
+//                                   ≙ arrow/math/{float64,int64,uint64}.go:25-47
+//
+// Arrays live in HBM: ArrayData buffers are device allocations owned by a Session's
+// ah_ctx.  Every kernel ExecFn in kernels.cc is a thin adapter from ArraySpan to one
+// leaf of include/arrowhip.h — no arithmetic happens on the host.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/arrowhip.h"
+
+namespace arrowhip {
+
+// ---- arrow.Type / arrow.DataType (arrow/datatype.go:36-72) ---------------------------
+enum class Type : int {
+  NA = 0, BOOL = 1, UINT8 = 2, INT8 = 3, UINT16 = 4, INT16 = 5, UINT32 = 6, INT32 = 7,
+  UINT64 = 8, INT64 = 9, FLOAT16 = 10, FLOAT32 = 11, FLOAT64 = 12, DICTIONARY = 36
+};
+
+struct DataType {
+  Type id;
+  int bit_width;       // arrow.FixedWidthDataType.BitWidth()
+  const char* name;    // DataType.Name()
+  const char* format;  // Arrow C Data Interface format string
+};
+const DataType* GetDataType(Type id);  // singletons; nullptr if unsupported
+bool IsInteger(Type id);
+bool IsSignedInteger(Type id);
+bool IsFloating(Type id);
+bool IsNumeric(Type id);
+
+// ---- errors (arrow/errors.go) ---------------------------------------------------------
+enum class StatusCode { OK = 0, Invalid, Index, NotImplemented, TypeError, KeyError, Hip };
+struct Status {
+  StatusCode code = StatusCode::OK;
+  std::string msg;
+  bool ok() const { return code == StatusCode::OK; }
+  static Status OK() { return Status(); }
+  static Status Make(StatusCode c, std::string m) { Status s; s.code = c; s.msg = std::move(m); return s; }
+  std::string ToString() const;  // "invalid: …" like fmt.Errorf("%w: …", arrow.ErrInvalid)
+};
+#define AHC_RETURN_NOT_OK(expr) do { ::arrowhip::Status s__ = (expr); if (!s__.ok()) return s__; } while (0)
+
+// ---- device memory (memory.Allocator / memory.Buffer: arrow/memory/allocator.go:23-27,
+//      buffer.go:26) ---------------------------------------------------------------------
+class Session;  // owns the ah_ctx
+struct Buffer {
+  Session* session = nullptr;
+  void* dptr = nullptr;
+  int64_t size = 0;
+  ~Buffer();
+};
+using BufferPtr = std::shared_ptr<Buffer>;
+
+class Session {
+ public:
+  static Status Create(int device_id, std::unique_ptr<Session>* out);
+  ~Session();
+  ah_ctx* ctx() const { return ctx_; }
+  // zero-filled like GoAllocator / Mallocator (quirk 4 in SURVEY.md §8a): kernels rely on it
+  Status Allocate(int64_t nbytes, BufferPtr* out);
+  Status AllocateBitmap(int64_t nbits, BufferPtr* out);
+  Status FromStatus(int ah_status) const;  // AH_* → Status with ah_last_error()
+ private:
+  ah_ctx* ctx_ = nullptr;
+};
+
+// ---- arrow.ArrayData (arrow/array.go:54-86) / scalar.Scalar ----------------------------
+constexpr int64_t kUnknownNullCount = -1;  // array.UnknownNullCount
+struct ArrayData {
+  const DataType* type = nullptr;
+  int64_t length = 0;
+  int64_t null_count = kUnknownNullCount;
+  int64_t offset = 0;
+  BufferPtr buffers[2];                    // [0] validity, [1] values / boolean data
+  std::shared_ptr<ArrayData> dictionary;   // for DICTIONARY results (dictionary_encode)
+  const DataType* dict_value_type = nullptr;
+};
+using ArrayDataPtr = std::shared_ptr<ArrayData>;
+
+struct Scalar {
+  const DataType* type = nullptr;
+  bool valid = false;
+  alignas(8) uint8_t value[8] = {0};  // little-endian payload of width type->bit_width (bool: value[0])
+};
+using ScalarPtr = std::shared_ptr<Scalar>;
+
+namespace exec {
+
+// exec.BufferSpan / exec.ArraySpan (arrow/compute/exec/span.go:43-88)
+struct BufferSpan {
+  uint8_t* buf = nullptr;  // DEVICE pointer (nil ⇔ no buffer)
+  int64_t len = 0;
+  BufferPtr owner;
+  bool self_alloc = false;
+  void WrapBuffer(const BufferPtr& b) { buf = b ? (uint8_t*)b->dptr : nullptr; len = b ? b->size : 0; owner = b; self_alloc = true; }
+};
+struct ArraySpan {
+  const DataType* type = nullptr;
+  int64_t len = 0, nulls = kUnknownNullCount, offset = 0;
+  BufferSpan buffers[3];
+  ArrayDataPtr dictionary;  // DICTIONARY outputs (exec.ArraySpan.Dictionary, span.go:159-168)
+  void SetMembers(const ArrayData& d);
+  bool MayHaveNulls() const { return nulls != 0 && buffers[0].buf != nullptr; }  // span.go:127-129
+  // ArraySpan.UpdateNullCount (span.go:112-125): popcount of the validity on the device
+  Status UpdateNullCount(Session* s, int64_t* out = nullptr);
+  ArrayDataPtr MakeData() const;  // ArraySpan.MakeData (span.go:238-)
+};
+struct ExecValue {
+  ArraySpan array;
+  const Scalar* scalar = nullptr;
+  bool IsArray() const { return scalar == nullptr; }
+  bool IsScalar() const { return scalar != nullptr; }
+  const DataType* type() const { return scalar ? scalar->type : array.type; }
+};
+struct ExecSpan {
+  int64_t len = 0;
+  std::vector<ExecValue> values;
+};
+using ExecResult = ArraySpan;
+
+// exec.NullHandling / exec.MemAlloc (arrow/compute/exec/kernel.go:457-499)
+enum class NullHandling { NullIntersection, NullComputedPrealloc, NullComputedNoPrealloc, NullNoOutput };
+enum class MemAlloc { MemPrealloc, MemNoPrealloc };
+
+// exec.KernelCtx (kernel.go:78-93)
+struct KernelCtx {
+  Session* session = nullptr;
+  const void* state = nullptr;   // KernelState: the FunctionOptions for vector kernels
+  const void* kernel_data = nullptr;  // Kernel.Data
+  Status Allocate(int64_t nbytes, BufferPtr* out) { return session->Allocate(nbytes, out); }
+  Status AllocateBitmap(int64_t nbits, BufferPtr* out) { return session->AllocateBitmap(nbits, out); }
+};
+
+using ArrayKernelExec = std::function<Status(KernelCtx*, const ExecSpan&, ExecResult*)>;  // kernel.go:617
+
+// exec.KernelSignature with exact-type matching (kernel.go:330-452, reduced to what the
+// path needs: fixed input types, output = a fixed type or the first input's type)
+struct KernelSignature {
+  std::vector<Type> in_types;
+  bool out_is_first_input = true;
+  Type out_type = Type::NA;
+  bool MatchesInputs(const std::vector<const DataType*>& types) const;
+};
+
+struct ScalarKernel {  // kernel.go:632-672
+  KernelSignature sig;
+  ArrayKernelExec exec_fn;
+  NullHandling null_handling = NullHandling::NullIntersection;  // defaults :660-661
+  MemAlloc mem_alloc = MemAlloc::MemPrealloc;
+  std::shared_ptr<void> data;
+};
+using FinalizeFn = std::function<Status(KernelCtx*, std::vector<ArraySpan>*)>;
+struct VectorKernel {  // kernel.go:686-727
+  KernelSignature sig;
+  ArrayKernelExec exec_fn;
+  NullHandling null_handling = NullHandling::NullComputedNoPrealloc;  // defaults :724-725
+  MemAlloc mem_alloc = MemAlloc::MemNoPrealloc;
+  bool can_execute_chunkwise = true;
+  bool output_is_dictionary = false;
+};
+
+}  // namespace exec
+
+namespace compute {
+
+// FunctionOptions structs (compute/arithmetic.go ArithmeticOptions, kernels FilterOptions
+// vector_selection.go:41-43, TakeOptions :49-51, DictionaryEncodeOptions vector_hash.go:96-99)
+struct FunctionOptions { virtual ~FunctionOptions() = default; virtual const char* TypeName() const = 0; };
+struct ArithmeticOptions : FunctionOptions { bool NoCheckOverflow = false; const char* TypeName() const override { return "ArithmeticOptions"; } };
+enum NullSelectionBehavior { DropNulls = 0, EmitNulls = 1 };
+struct FilterOptions : FunctionOptions { NullSelectionBehavior NullSelection = DropNulls; const char* TypeName() const override { return "FilterOptions"; } };
+struct TakeOptions : FunctionOptions { bool BoundsCheck = true; const char* TypeName() const override { return "TakeOptions"; } };
+enum NullEncodingBehavior { NullEncodingMask = 0, NullEncodingEncode = 1 };
+struct DictionaryEncodeOptions : FunctionOptions { NullEncodingBehavior NullEncoding = NullEncodingMask; const char* TypeName() const override { return "DictionaryEncodeOptions"; } };
+struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
+
+// compute.Datum (datum.go:35-40): array or scalar
+enum class DatumKind { None, Scalar, Array };
+struct Datum {
+  DatumKind kind = DatumKind::None;
+  ArrayDataPtr array;
+  ScalarPtr scalar;
+  static Datum Of(ArrayDataPtr a) { Datum d; d.kind = DatumKind::Array; d.array = std::move(a); return d; }
+  static Datum Of(ScalarPtr s) { Datum d; d.kind = DatumKind::Scalar; d.scalar = std::move(s); return d; }
+  const DataType* type() const { return kind == DatumKind::Array ? array->type : (kind == DatumKind::Scalar ? scalar->type : nullptr); }
+  int64_t Len() const { return kind == DatumKind::Array ? array->length : 1; }
+};
+
+class FunctionRegistry;
+// compute.ExecCtx (executor.go:46-64) — the registry travels with the context, so a child
+// registry carrying the GPU kernels is selected per call exactly like SetExecCtx does in Go
+struct ExecCtx {
+  FunctionRegistry* Registry = nullptr;
+  Session* session = nullptr;
+};
+
+enum class FuncKind { Scalar, Vector, Meta };  // functions.go:88-100
+struct Arity { int NArgs; bool IsVarArgs; };
+
+class Function {  // functions.go:30-41
+ public:
+  Function(std::string name, Arity arity, FuncKind kind, const FunctionOptions* default_opts = nullptr)
+      : name_(std::move(name)), arity_(arity), kind_(kind), default_opts_(default_opts) {}
+  virtual ~Function() = default;
+  const std::string& Name() const { return name_; }
+  FuncKind Kind() const { return kind_; }
+  Arity GetArity() const { return arity_; }
+  const FunctionOptions* DefaultOptions() const { return default_opts_; }
+  virtual int NumKernels() const = 0;
+  virtual Status Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) = 0;
+  Status CheckArity(size_t nargs) const;  // functions.go:130-146 checkArity
+ protected:
+  std::string name_;
+  Arity arity_;
+  FuncKind kind_;
+  const FunctionOptions* default_opts_;
+};
+
+class ScalarFunction : public Function {  // functions.go:239-290
+ public:
+  ScalarFunction(std::string name, Arity arity) : Function(std::move(name), arity, FuncKind::Scalar) {}
+  Status AddKernel(exec::ScalarKernel k);
+  int NumKernels() const override { return (int)kernels_.size(); }
+  // funcImpl.Kernels() (functions.go:220-226): live pointers — the in-place swap route
+  std::vector<exec::ScalarKernel*> Kernels();
+  Status DispatchExact(const std::vector<const DataType*>& types, const exec::ScalarKernel** out) const;  // :199-218
+  Status Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) override;
+  // set for "less"/"less_equal": swap the two arguments and run `flipped` (scalar_compare.go:73-99)
+  std::string flipped_of;
+ private:
+  std::vector<exec::ScalarKernel> kernels_;
+};
+
+class VectorFunction : public Function {  // functions.go:290-360
+ public:
+  VectorFunction(std::string name, Arity arity, const FunctionOptions* def = nullptr) : Function(std::move(name), arity, FuncKind::Vector, def) {}
+  Status AddKernel(exec::VectorKernel k);
+  int NumKernels() const override { return (int)kernels_.size(); }
+  Status DispatchExact(const std::vector<const DataType*>& types, const exec::VectorKernel** out) const;
+  Status Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) override;
+ private:
+  std::vector<exec::VectorKernel> kernels_;
+};
+
+using MetaImpl = std::function<Status(ExecCtx*, const FunctionOptions*, const std::vector<Datum>&, Datum*)>;
+class MetaFunction : public Function {  // functions.go:360-420
+ public:
+  MetaFunction(std::string name, Arity arity, const FunctionOptions* def, MetaImpl impl)
+      : Function(std::move(name), arity, FuncKind::Meta, def), impl_(std::move(impl)) {}
+  int NumKernels() const override { return 0; }
+  Status Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) override;
+ private:
+  MetaImpl impl_;
+};
+
+class FunctionRegistry {  // registry.go:30-120
+ public:
+  explicit FunctionRegistry(FunctionRegistry* parent = nullptr) : parent_(parent) {}
+  // AddFunction(fn, allowOverwrite): ErrKey "already have a function registered with name …"
+  Status AddFunction(std::shared_ptr<Function> fn, bool allow_overwrite);
+  Status AddAlias(const std::string& target, const std::string& source);
+  Function* GetFunction(const std::string& name) const;  // nullptr ⇔ (nil, false)
+  std::vector<std::string> GetFunctionNames() const;
+  int NumFunctions() const;
+  bool CanAddFunction(const std::shared_ptr<Function>& fn, bool allow_overwrite) const;
+ private:
+  FunctionRegistry* parent_;
+  std::map<std::string, std::shared_ptr<Function>> fns_;
+};
+FunctionRegistry* GetFunctionRegistry();  // registry.go:47 — process default, GPU kernels pre-registered
+std::unique_ptr<FunctionRegistry> NewChildRegistry(FunctionRegistry* parent);  // registry.go:69-73
+
+// compute.CallFunction (exec.go:191): "function '%s' not found" → KeyError
+Status CallFunction(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out);
+
+// registration entry points (≙ RegisterScalarArithmetic, RegisterScalarComparisons,
+// RegisterScalarBoolean, RegisterVectorSelection, RegisterVectorHash in arrow/compute)
+void RegisterScalarArithmetic(FunctionRegistry* reg);
+void RegisterScalarComparisons(FunctionRegistry* reg);
+void RegisterScalarBoolean(FunctionRegistry* reg);
+void RegisterVectorSelection(FunctionRegistry* reg);
+void RegisterVectorHash(FunctionRegistry* reg);
+void RegisterFusedExtensions(FunctionRegistry* reg);
+
+}  // namespace compute
+
+// ---- arrow/math (float64.go:25-39, int64.go, uint64.go) ---------------------------------
+namespace math {
+struct Float64Funcs { Status Sum(Session* s, const ArrayData& a, double* out) const; };
+struct Int64Funcs { Status Sum(Session* s, const ArrayData& a, int64_t* out) const; };
+struct Uint64Funcs { Status Sum(Session* s, const ArrayData& a, uint64_t* out) const; };
+extern const Float64Funcs Float64;
+extern const Int64Funcs Int64;
+extern const Uint64Funcs Uint64;
+}  // namespace math
+
+}  // namespace arrowhip

@@ -1,0 +1,288 @@
+// capi.cc — C entry points of libarrowhip_compute.so: the array-level face of the host
+// layer, spoken in the Arrow C Data Interface so that ANY Arrow producer (pyarrow in the
+// tests; arrow-go's own arrow/cdata package — cdata.go:72, exports.go — in production)
+// can hand over arrays.  Import copies the host buffers into HBM (pinned staging →
+// hipMemcpyAsync on the copy stream); export copies results back.
+//
+//   ahc_call(session, "add", "", 2, args, &out)  ≙  compute.CallFunction(ctx, "add", nil, a, b)
+//
+// The struct layouts are the public Arrow C Data Interface ABI (arrow/cdata/abi.h:50-79).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "arrowhip_compute.h"
+
+extern "C" {
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+}
+
+using namespace arrowhip;
+using compute::Datum;
+using compute::DatumKind;
+
+struct ahc_session {
+  std::unique_ptr<Session> session;
+  std::unique_ptr<compute::FunctionRegistry> child_registry;  // per-session registry, like SetExecCtx
+  compute::ExecCtx ectx;
+  std::string err;
+};
+struct ahc_datum {
+  Datum d;
+};
+
+#define AHC_EXPORT extern "C" __attribute__((visibility("default")))
+
+static int Fail(ahc_session* s, const Status& st) {
+  if (s) s->err = st.ToString();
+  return (int)st.code;
+}
+
+AHC_EXPORT int ahc_session_create(int device_id, ahc_session** out) {
+  auto* s = new ahc_session();
+  Status st = Session::Create(device_id, &s->session);
+  if (!st.ok()) { fprintf(stderr, "arrowhip_compute: %s\n", st.ToString().c_str()); delete s; *out = nullptr; return (int)st.code; }
+  s->child_registry = compute::NewChildRegistry(compute::GetFunctionRegistry());
+  s->ectx.Registry = s->child_registry.get();
+  s->ectx.session = s->session.get();
+  *out = s;
+  return 0;
+}
+AHC_EXPORT void ahc_session_destroy(ahc_session* s) { delete s; }
+AHC_EXPORT const char* ahc_last_error(ahc_session* s) { return s ? s->err.c_str() : "null session"; }
+AHC_EXPORT void ahc_datum_release(ahc_datum* d) { delete d; }
+AHC_EXPORT int ahc_num_functions(void) { return compute::GetFunctionRegistry()->NumFunctions(); }
+AHC_EXPORT int ahc_has_function(const char* name) { return compute::GetFunctionRegistry()->GetFunction(name) != nullptr; }
+AHC_EXPORT int ahc_function_num_kernels(const char* name) {
+  auto* f = compute::GetFunctionRegistry()->GetFunction(name);
+  return f ? f->NumKernels() : -1;
+}
+
+static const DataType* TypeFromFormat(const char* f) {
+  if (!f || !f[0] || f[1]) return nullptr;
+  for (int i = 0; i <= (int)Type::FLOAT64; i++) {
+    const DataType* t = GetDataType((Type)i);
+    if (t && t->format[0] == f[0] && t->id != Type::NA) return t;
+  }
+  return nullptr;
+}
+
+// ImportCArray-like (arrow/cdata/interface.go:153): host buffers → device; releases the source
+AHC_EXPORT int ahc_import(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, ahc_datum** out) {
+  *out = nullptr;
+  const DataType* t = TypeFromFormat(schema->format);
+  Status st;
+  if (!t) st = Status::Make(StatusCode::NotImplemented, std::string("unsupported Arrow format '") + (schema->format ? schema->format : "") + "'");
+  auto d = std::make_shared<ArrayData>();
+  if (st.ok()) {
+    d->type = t;
+    d->length = arr->length;
+    d->null_count = arr->null_count;
+    d->offset = arr->offset;
+    Session* ss = s->session.get();
+    int64_t nbits = arr->offset + arr->length;
+    int64_t vbytes = (nbits + 7) / 8;
+    int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
+    if (arr->n_buffers >= 1 && arr->buffers[0] != nullptr && arr->null_count != 0) {
+      st = ss->Allocate(vbytes, &d->buffers[0]);
+      if (st.ok()) st = ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[0]->dptr, arr->buffers[0], (size_t)vbytes));
+    } else {
+      d->null_count = 0;
+    }
+    if (st.ok()) st = ss->Allocate(dbytes, &d->buffers[1]);
+    if (st.ok() && dbytes > 0 && arr->n_buffers >= 2 && arr->buffers[1] != nullptr)
+      st = ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[1]->dptr, arr->buffers[1], (size_t)dbytes));
+    if (st.ok()) st = ss->FromStatus(ah_sync(ss->ctx()));
+  }
+  if (arr->release) arr->release(arr);
+  if (schema->release) schema->release(schema);
+  if (!st.ok()) return Fail(s, st);
+  *out = new ahc_datum{Datum::Of(d)};
+  return 0;
+}
+
+AHC_EXPORT int ahc_scalar(ahc_session* s, int type_id, int valid, const void* value8, ahc_datum** out) {
+  const DataType* t = GetDataType((Type)type_id);
+  if (!t) return Fail(s, Status::Make(StatusCode::NotImplemented, "unsupported scalar type"));
+  auto sc = std::make_shared<Scalar>();
+  sc->type = t;
+  sc->valid = valid != 0;
+  if (value8) memcpy(sc->value, value8, 8);
+  *out = new ahc_datum{Datum::Of(sc)};
+  return 0;
+}
+
+AHC_EXPORT int ahc_datum_info(ahc_datum* d, int* kind, int* type_id, int64_t* length, int64_t* null_count, int* scalar_valid, void* scalar_value8) {
+  *kind = (int)d->d.kind;
+  *type_id = d->d.type() ? (int)d->d.type()->id : 0;
+  *length = d->d.Len();
+  *null_count = d->d.kind == DatumKind::Array ? d->d.array->null_count : 0;
+  if (d->d.kind == DatumKind::Scalar) {
+    *scalar_valid = d->d.scalar->valid;
+    if (scalar_value8) memcpy(scalar_value8, d->d.scalar->value, 8);
+  }
+  return 0;
+}
+
+// options: "key=value;key=value"; keys follow the Go struct tags
+//   null_selection_behavior=drop|emit_null   bounds_check=0|1   null_encoding_behavior=mask|encode
+struct ParsedOptions {
+  compute::FilterOptions filter;
+  compute::TakeOptions take;
+  compute::DictionaryEncodeOptions dict;
+  const compute::FunctionOptions* pick = nullptr;
+};
+static void ParseOptions(const char* text, ParsedOptions* p) {
+  std::string t = text ? text : "";
+  size_t pos = 0;
+  while (pos < t.size()) {
+    size_t end = t.find(';', pos);
+    if (end == std::string::npos) end = t.size();
+    std::string kv = t.substr(pos, end - pos);
+    size_t eq = kv.find('=');
+    if (eq != std::string::npos) {
+      std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+      if (k == "null_selection_behavior") { p->filter.NullSelection = v == "emit_null" ? compute::EmitNulls : compute::DropNulls; p->pick = &p->filter; }
+      if (k == "bounds_check") { p->take.BoundsCheck = v != "0"; p->pick = &p->take; }
+      if (k == "null_encoding_behavior") { p->dict.NullEncoding = v == "encode" ? compute::NullEncodingEncode : compute::NullEncodingMask; p->pick = &p->dict; }
+    }
+    pos = end + 1;
+  }
+}
+
+AHC_EXPORT int ahc_call(ahc_session* s, const char* name, const char* options, int nargs, ahc_datum** args, ahc_datum** out) {
+  *out = nullptr;
+  std::vector<Datum> a;
+  for (int i = 0; i < nargs; i++) a.push_back(args[i]->d);
+  ParsedOptions po;
+  ParseOptions(options, &po);
+  Datum res;
+  Status st = compute::CallFunction(&s->ectx, name, po.pick, a, &res);
+  if (!st.ok()) return Fail(s, st);
+  *out = new ahc_datum{res};
+  return 0;
+}
+
+AHC_EXPORT int ahc_math_sum(ahc_session* s, ahc_datum* d, double* f64, int64_t* i64, uint64_t* u64) {
+  if (d->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "math.Sum needs an array"));
+  const ArrayData& a = *d->d.array;
+  Status st;
+  switch (a.type->id) {
+    case Type::FLOAT64: st = math::Float64.Sum(s->session.get(), a, f64); break;
+    case Type::INT64: st = math::Int64.Sum(s->session.get(), a, i64); break;
+    case Type::UINT64: st = math::Uint64.Sum(s->session.get(), a, u64); break;
+    default: st = Status::Make(StatusCode::TypeError, "arrow/math has Float64, Int64 and Uint64 Sum only");
+  }
+  return st.ok() ? 0 : Fail(s, st);
+}
+
+// registry plumbing, exercised by the tests the way compute/registry_test.go does
+AHC_EXPORT int ahc_registry_add_alias(ahc_session* s, const char* alias, const char* existing, int allow_overwrite) {
+  auto* f = s->ectx.Registry->GetFunction(existing);
+  if (!f) return Fail(s, Status::Make(StatusCode::KeyError, std::string("function '") + existing + "' not found"));
+  // a MetaFunction forwarding to `existing`, registered under `alias` in the session's child registry
+  std::string target = existing;
+  auto fn = std::make_shared<compute::MetaFunction>(alias, f->GetArity(), f->DefaultOptions(),
+      [target](compute::ExecCtx* c, const compute::FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
+        return compute::CallFunction(c, target, o, args, out);
+      });
+  Status st = s->ectx.Registry->AddFunction(fn, allow_overwrite != 0);
+  return st.ok() ? 0 : Fail(s, st);
+}
+
+// ---- export ------------------------------------------------------------------------------------
+struct ExportPriv {
+  void* bufs[2] = {nullptr, nullptr};
+  const void* buffer_ptrs[2] = {nullptr, nullptr};
+  ArrowArray* dict = nullptr;
+  ArrowSchema* dict_schema = nullptr;
+};
+static void ReleaseArray(ArrowArray* a) {
+  auto* p = (ExportPriv*)a->private_data;
+  if (p) {
+    free(p->bufs[0]);
+    free(p->bufs[1]);
+    if (p->dict) { if (p->dict->release) p->dict->release(p->dict); free(p->dict); }
+    delete p;
+  }
+  a->release = nullptr;
+}
+static void ReleaseSchema(ArrowSchema* sc) {
+  if (sc->dictionary) { if (sc->dictionary->release) sc->dictionary->release(sc->dictionary); free(sc->dictionary); }
+  sc->release = nullptr;
+}
+
+static Status ExportOne(Session* ss, const ArrayData& a, const DataType* t, ArrowArray* arr, ArrowSchema* schema) {
+  memset(arr, 0, sizeof(*arr));
+  memset(schema, 0, sizeof(*schema));
+  auto* p = new ExportPriv();
+  int64_t nbits = a.offset + a.length;
+  int64_t vbytes = (nbits + 7) / 8;
+  int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
+  if (a.buffers[0] && a.null_count != 0) {
+    p->bufs[0] = calloc(1, (size_t)vbytes + 64);
+    AHC_RETURN_NOT_OK(ss->FromStatus(ah_download_async(ss->ctx(), p->bufs[0], a.buffers[0]->dptr, (size_t)vbytes)));
+  }
+  p->bufs[1] = calloc(1, (size_t)dbytes + 64);
+  if (a.buffers[1] && dbytes > 0)
+    AHC_RETURN_NOT_OK(ss->FromStatus(ah_download_async(ss->ctx(), p->bufs[1], a.buffers[1]->dptr, (size_t)dbytes)));
+  AHC_RETURN_NOT_OK(ss->FromStatus(ah_sync(ss->ctx())));
+  p->buffer_ptrs[0] = p->bufs[0];
+  p->buffer_ptrs[1] = p->bufs[1];
+  arr->length = a.length;
+  arr->null_count = p->bufs[0] ? a.null_count : 0;
+  arr->offset = a.offset;
+  arr->n_buffers = 2;
+  arr->buffers = p->buffer_ptrs;
+  arr->release = ReleaseArray;
+  arr->private_data = p;
+  schema->format = t->format;
+  schema->name = "";
+  schema->flags = 2;  // ARROW_FLAG_NULLABLE
+  schema->release = ReleaseSchema;
+  return Status::OK();
+}
+
+// ExportArrowArray-like (arrow/cdata/exports.go): device → freshly malloc'ed host buffers
+AHC_EXPORT int ahc_export(ahc_session* s, ahc_datum* d, ArrowArray* arr, ArrowSchema* schema) {
+  if (d->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "only array datums can be exported"));
+  const ArrayData& a = *d->d.array;
+  Session* ss = s->session.get();
+  if (a.type->id == Type::DICTIONARY) {
+    Status st = ExportOne(ss, a, GetDataType(Type::INT32), arr, schema);
+    if (!st.ok()) return Fail(s, st);
+    auto* da = (ArrowArray*)calloc(1, sizeof(ArrowArray));
+    auto* ds = (ArrowSchema*)calloc(1, sizeof(ArrowSchema));
+    st = ExportOne(ss, *a.dictionary, a.dictionary->type, da, ds);
+    if (!st.ok()) return Fail(s, st);
+    arr->dictionary = da;
+    ((ExportPriv*)arr->private_data)->dict = da;
+    schema->dictionary = ds;
+    return 0;
+  }
+  Status st = ExportOne(ss, a, a.type, arr, schema);
+  return st.ok() ? 0 : Fail(s, st);
+}

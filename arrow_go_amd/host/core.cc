@@ -1,0 +1,483 @@
+// core.cc — data types, device session, function registry and the two executors.
+// Mirrors arrow/compute/{registry.go, functions.go, exec.go, executor.go}; every
+// non-trivial rule cites the line it restates.  No arithmetic on the host: null
+// propagation, popcounts and fills are enqueued on the GPU through include/arrowhip.h.
+#include "arrowhip_compute.h"
+
+#include <cstring>
+#include <mutex>
+#include <sstream>
+
+namespace arrowhip {
+
+// ---- data types -------------------------------------------------------------------------
+static const DataType kTypes[] = {
+    {Type::NA, 0, "null", "n"},        {Type::BOOL, 1, "bool", "b"},       {Type::UINT8, 8, "uint8", "C"},
+    {Type::INT8, 8, "int8", "c"},      {Type::UINT16, 16, "uint16", "S"},  {Type::INT16, 16, "int16", "s"},
+    {Type::UINT32, 32, "uint32", "I"}, {Type::INT32, 32, "int32", "i"},    {Type::UINT64, 64, "uint64", "L"},
+    {Type::INT64, 64, "int64", "l"},   {Type::FLOAT16, 16, "float16", "e"}, {Type::FLOAT32, 32, "float32", "f"},
+    {Type::FLOAT64, 64, "float64", "g"}};
+static const DataType kDictType = {Type::DICTIONARY, 32, "dictionary", "i"};
+
+const DataType* GetDataType(Type id) {
+  if (id == Type::DICTIONARY) return &kDictType;
+  int i = (int)id;
+  if (i < 0 || i > (int)Type::FLOAT64 || id == Type::FLOAT16) return nullptr;
+  return &kTypes[i];
+}
+bool IsSignedInteger(Type id) { return id == Type::INT8 || id == Type::INT16 || id == Type::INT32 || id == Type::INT64; }
+bool IsInteger(Type id) { return IsSignedInteger(id) || id == Type::UINT8 || id == Type::UINT16 || id == Type::UINT32 || id == Type::UINT64; }
+bool IsFloating(Type id) { return id == Type::FLOAT32 || id == Type::FLOAT64; }
+bool IsNumeric(Type id) { return IsInteger(id) || IsFloating(id); }
+
+std::string Status::ToString() const {
+  static const char* names[] = {"ok", "invalid", "index error", "not implemented", "type error", "key error", "hip error"};
+  if (ok()) return "ok";
+  return std::string(names[(int)code]) + ": " + msg;
+}
+
+// ---- session / buffers ------------------------------------------------------------------
+Buffer::~Buffer() {
+  if (dptr && session && session->ctx()) ah_buf_free(session->ctx(), dptr);
+}
+
+Status Session::Create(int device_id, std::unique_ptr<Session>* out) {
+  std::unique_ptr<Session> s(new Session());
+  int rc = ah_ctx_create(device_id, &s->ctx_);
+  if (rc != AH_OK) return Status::Make(StatusCode::Hip, "ah_ctx_create failed (no GPU visible?) — there is no CPU fallback");
+  *out = std::move(s);
+  return Status::OK();
+}
+Session::~Session() {
+  if (ctx_) ah_ctx_destroy(ctx_);
+}
+Status Session::FromStatus(int st) const {
+  if (st == AH_OK) return Status::OK();
+  StatusCode c = StatusCode::Invalid;
+  switch (st) {
+    case AH_EINVALID: case AH_EOVERFLOW: c = StatusCode::Invalid; break;  // errOverflow wraps arrow.ErrInvalid
+    case AH_EINDEX: c = StatusCode::Index; break;
+    case AH_ENOTIMPL: c = StatusCode::NotImplemented; break;
+    default: c = StatusCode::Hip; break;
+  }
+  return Status::Make(c, ah_last_error(ctx_));
+}
+Status Session::Allocate(int64_t nbytes, BufferPtr* out) {
+  auto b = std::make_shared<Buffer>();
+  b->session = this;
+  b->size = nbytes;
+  AHC_RETURN_NOT_OK(FromStatus(ah_buf_alloc(ctx_, (size_t)(nbytes > 0 ? nbytes : 1), &b->dptr)));
+  // ctx.Allocate → memory.NewResizableBuffer is zero-filled (executor.go:600 prepareOutput;
+  // SURVEY §8a quirk 4): null slots "hold 0" because of this
+  size_t padded = ((size_t)(nbytes > 0 ? nbytes : 1) + 63) & ~(size_t)63;
+  AHC_RETURN_NOT_OK(FromStatus(ah_memset_async(ctx_, b->dptr, 0, padded)));
+  *out = std::move(b);
+  return Status::OK();
+}
+Status Session::AllocateBitmap(int64_t nbits, BufferPtr* out) { return Allocate((nbits + 7) / 8, out); }
+
+// ---- spans ------------------------------------------------------------------------------
+namespace exec {
+
+void ArraySpan::SetMembers(const ArrayData& d) {
+  type = d.type;
+  len = d.length;
+  nulls = d.null_count;
+  offset = d.offset;
+  for (int i = 0; i < 2; i++) {
+    buffers[i].owner = d.buffers[i];
+    buffers[i].buf = d.buffers[i] ? (uint8_t*)d.buffers[i]->dptr : nullptr;
+    buffers[i].len = d.buffers[i] ? d.buffers[i]->size : 0;
+    buffers[i].self_alloc = false;
+  }
+  // span.go:322-333: no validity buffer ⇒ null count is 0
+  if (buffers[0].buf == nullptr) nulls = 0;
+}
+
+Status ArraySpan::UpdateNullCount(Session* s, int64_t* out) {
+  if (nulls == kUnknownNullCount) {
+    if (buffers[0].buf == nullptr) {
+      nulls = 0;
+    } else {
+      int64_t set = 0;
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_count_set_bits(s->ctx(), buffers[0].buf, offset, len, &set)));
+      nulls = len - set;
+    }
+  }
+  if (out) *out = nulls;
+  return Status::OK();
+}
+
+ArrayDataPtr ArraySpan::MakeData() const {
+  auto d = std::make_shared<ArrayData>();
+  d->type = type;
+  d->length = len;
+  d->null_count = nulls;
+  d->offset = offset;
+  d->buffers[0] = buffers[0].owner;
+  d->buffers[1] = buffers[1].owner;
+  // span.go:243-247: a known-zero null count drops the validity buffer
+  if (nulls == 0) d->buffers[0] = nullptr;
+  return d;
+}
+
+bool KernelSignature::MatchesInputs(const std::vector<const DataType*>& types) const {
+  if (types.size() != in_types.size()) return false;
+  for (size_t i = 0; i < types.size(); i++)
+    if (!types[i] || types[i]->id != in_types[i]) return false;
+  return true;
+}
+
+}  // namespace exec
+
+namespace compute {
+
+// ---- Function base ----------------------------------------------------------------------
+Status Function::CheckArity(size_t nargs) const {
+  // functions.go:130-146
+  if (arity_.IsVarArgs && (int)nargs < arity_.NArgs)
+    return Status::Make(StatusCode::Invalid, "varargs function '" + name_ + "' needs at least " + std::to_string(arity_.NArgs) +
+                                                 " arguments, but only " + std::to_string(nargs) + " passed");
+  if (!arity_.IsVarArgs && (int)nargs != arity_.NArgs)
+    return Status::Make(StatusCode::Invalid, "function '" + name_ + "' accepts " + std::to_string(arity_.NArgs) +
+                                                 " arguments but " + std::to_string(nargs) + " passed");
+  return Status::OK();
+}
+
+static std::string TypesToString(const std::vector<const DataType*>& types) {
+  std::string s = "(";
+  for (size_t i = 0; i < types.size(); i++) s += std::string(i ? ", " : "") + (types[i] ? types[i]->name : "?");
+  return s + ")";
+}
+
+static Status ArgTypes(const std::vector<Datum>& args, std::vector<const DataType*>* types) {
+  for (auto& a : args) {
+    if (a.kind == DatumKind::None) return Status::Make(StatusCode::Invalid, "invalid datum");
+    types->push_back(a.type());
+  }
+  return Status::OK();
+}
+
+// ---- ScalarFunction ------------------------------------------------------------------------
+Status ScalarFunction::AddKernel(exec::ScalarKernel k) {
+  if ((int)k.sig.in_types.size() != arity_.NArgs)  // functions.go:246-252 checkArity on the signature
+    return Status::Make(StatusCode::Invalid, "kernel signature does not match the arity of function '" + name_ + "'");
+  kernels_.push_back(std::move(k));
+  return Status::OK();
+}
+std::vector<exec::ScalarKernel*> ScalarFunction::Kernels() {
+  std::vector<exec::ScalarKernel*> out;
+  for (auto& k : kernels_) out.push_back(&k);
+  return out;
+}
+Status ScalarFunction::DispatchExact(const std::vector<const DataType*>& types, const exec::ScalarKernel** out) const {
+  for (auto& k : kernels_)  // first matching signature wins (functions.go:209-213)
+    if (k.sig.MatchesInputs(types)) { *out = &k; return Status::OK(); }
+  return Status::Make(StatusCode::NotImplemented, "function '" + name_ + "' has no kernel matching input types " + TypesToString(types));
+}
+
+// propagateNulls (executor.go:237-349), preallocated-output branch (the scalar executor here
+// always preallocates a validity bitmap unless it can be elided, setupPrealloc :658-702)
+static Status PropagateNulls(Session* s, const exec::ExecSpan& batch, exec::ArraySpan* out) {
+  ah_ctx* c = s->ctx();
+  std::vector<const exec::ArraySpan*> with_nulls;
+  bool all_null = false;
+  for (auto& v : batch.values) {
+    if (v.IsScalar()) {  // getNullGen :190-213
+      if (!v.scalar->valid) all_null = true;
+      continue;
+    }
+    const exec::ArraySpan& a = v.array;
+    if (a.nulls == 0 || a.buffers[0].buf == nullptr) continue;  // nullGenAllValid
+    if (a.nulls == a.len) all_null = true;
+    with_nulls.push_back(&a);
+  }
+  uint8_t* ob = out->buffers[0].buf;
+  if (all_null) {
+    out->nulls = out->len;
+    return s->FromStatus(ah_set_bits_to(c, ob, out->offset, out->len, 0));
+  }
+  out->nulls = kUnknownNullCount;
+  if (with_nulls.empty()) {
+    out->nulls = 0;
+    return s->FromStatus(ah_set_bits_to(c, ob, out->offset, out->len, 1));
+  }
+  if (with_nulls.size() == 1) {
+    out->nulls = with_nulls[0]->nulls;
+    return s->FromStatus(ah_copy_bitmap(c, with_nulls[0]->buffers[0].buf, with_nulls[0]->offset, out->len, ob, out->offset, 0));
+  }
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_bitmap_op(c, AH_BIT_AND, with_nulls[0]->buffers[0].buf, with_nulls[0]->offset,
+                                              with_nulls[1]->buffers[0].buf, with_nulls[1]->offset, ob, out->offset, out->len)));
+  for (size_t i = 2; i < with_nulls.size(); i++)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_bitmap_op(c, AH_BIT_AND, ob, out->offset, with_nulls[i]->buffers[0].buf,
+                                                with_nulls[i]->offset, ob, out->offset, out->len)));
+  return Status::OK();
+}
+
+// all-scalar calls: arrow-go promotes scalars to length-1 arrays and unboxes the result
+// (executor.go:462-496 execute → haveAllScalars; exec.go:172 WrapResults).  Here: upload 1
+// element, run the same array kernel, download 1 element.
+static Status ScalarToArray(Session* s, const Scalar& sc, ArrayDataPtr* out) {
+  auto d = std::make_shared<ArrayData>();
+  d->type = sc.type;
+  d->length = 1;
+  d->null_count = sc.valid ? 0 : 1;
+  AHC_RETURN_NOT_OK(s->Allocate(8, &d->buffers[1]));
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_upload_async(s->ctx(), d->buffers[1]->dptr, sc.value, 8)));
+  if (!sc.valid) AHC_RETURN_NOT_OK(s->AllocateBitmap(1, &d->buffers[0]));  // zero = null
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+  *out = d;
+  return Status::OK();
+}
+static Status ArrayToScalar(Session* s, const ArrayData& a, ScalarPtr* out) {
+  auto sc = std::make_shared<Scalar>();
+  sc->type = a.type;
+  uint8_t tmp[8] = {0};
+  int w = a.type->bit_width == 1 ? 1 : a.type->bit_width / 8;
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), tmp, a.buffers[1]->dptr, (size_t)w)));
+  uint8_t vbyte = 1;
+  if (a.buffers[0]) AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), &vbyte, a.buffers[0]->dptr, 1)));
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+  sc->valid = (vbyte & 1) != 0 && a.null_count != 1;
+  if (a.type->id == Type::BOOL) tmp[0] &= 1;
+  memcpy(sc->value, tmp, 8);
+  *out = sc;
+  return Status::OK();
+}
+
+Status ScalarFunction::Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args_in, Datum* out) {
+  AHC_RETURN_NOT_OK(CheckArity(args_in.size()));
+  if (!flipped_of.empty()) {  // scalar_compare.go:73-99 flippedCompare
+    std::vector<Datum> swapped = {args_in[1], args_in[0]};
+    return CallFunction(ctx, flipped_of, opts, swapped, out);
+  }
+  Session* s = ctx->session;
+  if (!s) return Status::Make(StatusCode::Invalid, "ExecCtx has no device session");
+  std::vector<Datum> args = args_in;
+  std::vector<const DataType*> types;
+  AHC_RETURN_NOT_OK(ArgTypes(args, &types));
+  const exec::ScalarKernel* kernel = nullptr;
+  AHC_RETURN_NOT_OK(DispatchExact(types, &kernel));
+
+  // inferBatchLength (executor.go:352-390): arrays must agree; all scalars → length 1
+  int64_t length = -1;
+  bool all_scalar = true;
+  for (auto& a : args) {
+    if (a.kind != DatumKind::Array) continue;
+    all_scalar = false;
+    if (length < 0) length = a.array->length;
+    else if (length != a.array->length)
+      return Status::Make(StatusCode::Invalid, "array arguments must all be the same length");
+  }
+  if (all_scalar) {
+    for (auto& a : args) {
+      ArrayDataPtr arr;
+      AHC_RETURN_NOT_OK(ScalarToArray(s, *a.scalar, &arr));
+      a = Datum::Of(arr);
+    }
+    length = 1;
+  }
+
+  exec::ExecSpan span;
+  span.len = length;
+  for (auto& a : args) {
+    exec::ExecValue v;
+    if (a.kind == DatumKind::Array) v.array.SetMembers(*a.array);
+    else v.scalar = a.scalar.get();
+    span.values.push_back(std::move(v));
+  }
+
+  exec::ExecResult res;
+  res.type = kernel->sig.out_is_first_input ? types[0] : GetDataType(kernel->sig.out_type);
+  res.len = length;
+  res.offset = 0;
+  // setupPrealloc (executor.go:658-702)
+  bool elide_validity = false, prealloc_validity = false;
+  switch (kernel->null_handling) {
+    case exec::NullHandling::NullComputedPrealloc: prealloc_validity = true; break;
+    case exec::NullHandling::NullIntersection: {
+      elide_validity = true;
+      for (auto& v : span.values) {
+        bool all_valid = v.IsScalar() ? v.scalar->valid : (v.array.nulls == 0 || v.array.buffers[0].buf == nullptr);
+        elide_validity = elide_validity && all_valid;
+      }
+      prealloc_validity = !elide_validity;
+      break;
+    }
+    case exec::NullHandling::NullNoOutput: elide_validity = true; break;
+    default: break;
+  }
+  if (prealloc_validity) {
+    BufferPtr b;
+    AHC_RETURN_NOT_OK(s->AllocateBitmap(length, &b));
+    res.buffers[0].WrapBuffer(b);
+  }
+  if (kernel->mem_alloc == exec::MemAlloc::MemPrealloc) {
+    BufferPtr b;
+    int64_t nbytes = res.type->bit_width == 1 ? (length + 7) / 8 : length * (res.type->bit_width / 8);
+    AHC_RETURN_NOT_OK(s->Allocate(nbytes, &b));
+    res.buffers[1].WrapBuffer(b);
+  }
+  // executeSingleSpan (executor.go:644-656)
+  if (kernel->null_handling == exec::NullHandling::NullIntersection) {
+    if (!elide_validity) AHC_RETURN_NOT_OK(PropagateNulls(s, span, &res));
+    else res.nulls = 0;
+  } else if (kernel->null_handling == exec::NullHandling::NullNoOutput) {
+    res.nulls = 0;
+  }
+  exec::KernelCtx kctx;
+  kctx.session = s;
+  kctx.state = opts ? opts : default_opts_;
+  kctx.kernel_data = kernel->data.get();
+  AHC_RETURN_NOT_OK(kernel->exec_fn(&kctx, span, &res));
+
+  ArrayDataPtr result = res.MakeData();
+  if (all_scalar) {
+    ScalarPtr sc;
+    AHC_RETURN_NOT_OK(ArrayToScalar(s, *result, &sc));
+    *out = Datum::Of(sc);
+  } else {
+    *out = Datum::Of(result);
+  }
+  return Status::OK();
+}
+
+// ---- VectorFunction ------------------------------------------------------------------------
+Status VectorFunction::AddKernel(exec::VectorKernel k) {
+  if ((int)k.sig.in_types.size() != arity_.NArgs)
+    return Status::Make(StatusCode::Invalid, "kernel signature does not match the arity of function '" + name_ + "'");
+  kernels_.push_back(std::move(k));
+  return Status::OK();
+}
+Status VectorFunction::DispatchExact(const std::vector<const DataType*>& types, const exec::VectorKernel** out) const {
+  for (auto& k : kernels_)
+    if (k.sig.MatchesInputs(types)) { *out = &k; return Status::OK(); }
+  return Status::Make(StatusCode::NotImplemented, "function '" + name_ + "' has no kernel matching input types " + TypesToString(types));
+}
+Status VectorFunction::Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) {
+  AHC_RETURN_NOT_OK(CheckArity(args.size()));
+  Session* s = ctx->session;
+  if (!s) return Status::Make(StatusCode::Invalid, "ExecCtx has no device session");
+  std::vector<const DataType*> types;
+  AHC_RETURN_NOT_OK(ArgTypes(args, &types));
+  const exec::VectorKernel* kernel = nullptr;
+  AHC_RETURN_NOT_OK(DispatchExact(types, &kernel));
+  // vectorExecutor.Execute (executor.go:896-960): one span (the whole array); nothing
+  // preallocated (VectorKernel defaults NullComputedNoPrealloc + MemNoPrealloc)
+  exec::ExecSpan span;
+  for (auto& a : args) {
+    if (a.kind != DatumKind::Array)
+      return Status::Make(StatusCode::NotImplemented, "vector function '" + name_ + "' needs array arguments");
+    exec::ExecValue v;
+    v.array.SetMembers(*a.array);
+    span.values.push_back(std::move(v));
+  }
+  span.len = span.values.empty() ? 0 : span.values[0].array.len;
+  exec::ExecResult res;
+  res.type = kernel->sig.out_is_first_input ? types[0] : GetDataType(kernel->sig.out_type);
+  exec::KernelCtx kctx;
+  kctx.session = s;
+  kctx.state = opts ? opts : default_opts_;
+  AHC_RETURN_NOT_OK(kernel->exec_fn(&kctx, span, &res));
+  ArrayDataPtr result = res.MakeData();
+  if (kernel->output_is_dictionary) {
+    result->type = GetDataType(Type::DICTIONARY);
+    result->dict_value_type = types[0];
+    result->dictionary = res.dictionary;
+  }
+  *out = Datum::Of(result);
+  return Status::OK();
+}
+
+Status MetaFunction::Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) {
+  AHC_RETURN_NOT_OK(CheckArity(args.size()));  // functions.go:417-428
+  return impl_(ctx, opts ? opts : default_opts_, args, out);
+}
+
+// ---- registry ---------------------------------------------------------------------------
+static std::mutex g_reg_mu;
+
+bool FunctionRegistry::CanAddFunction(const std::shared_ptr<Function>& fn, bool allow_overwrite) const {
+  if (parent_ && !parent_->CanAddFunction(fn, allow_overwrite)) return false;  // registry.go:83-95
+  return allow_overwrite || fns_.find(fn->Name()) == fns_.end();
+}
+Status FunctionRegistry::AddFunction(std::shared_ptr<Function> fn, bool allow_overwrite) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  if (!CanAddFunction(fn, allow_overwrite))
+    return Status::Make(StatusCode::KeyError, "already have a function registered with name: " + fn->Name());  // registry.go:104-111
+  fns_[fn->Name()] = std::move(fn);
+  return Status::OK();
+}
+Status FunctionRegistry::AddAlias(const std::string& target, const std::string& source) {
+  Function* f = GetFunction(source);
+  if (!f) return Status::Make(StatusCode::KeyError, "no function registered with name: " + source);
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (auto& kv : fns_)
+    if (kv.second.get() == f) { fns_[target] = kv.second; return Status::OK(); }
+  return Status::Make(StatusCode::KeyError, "alias source lives in a parent registry: " + source);
+}
+Function* FunctionRegistry::GetFunction(const std::string& name) const {
+  auto it = fns_.find(name);
+  if (it != fns_.end()) return it->second.get();
+  return parent_ ? parent_->GetFunction(name) : nullptr;  // registry.go:120-131
+}
+std::vector<std::string> FunctionRegistry::GetFunctionNames() const {
+  std::vector<std::string> names = parent_ ? parent_->GetFunctionNames() : std::vector<std::string>();
+  for (auto& kv : fns_) names.push_back(kv.first);
+  return names;
+}
+int FunctionRegistry::NumFunctions() const { return (int)fns_.size() + (parent_ ? parent_->NumFunctions() : 0); }
+
+FunctionRegistry* GetFunctionRegistry() {
+  static FunctionRegistry* reg = [] {
+    auto* r = new FunctionRegistry();
+    RegisterScalarArithmetic(r);
+    RegisterScalarComparisons(r);
+    RegisterScalarBoolean(r);
+    RegisterVectorSelection(r);
+    RegisterVectorHash(r);
+    RegisterFusedExtensions(r);
+    return r;
+  }();
+  return reg;
+}
+std::unique_ptr<FunctionRegistry> NewChildRegistry(FunctionRegistry* parent) {
+  return std::unique_ptr<FunctionRegistry>(new FunctionRegistry(parent));
+}
+
+Status CallFunction(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) {
+  FunctionRegistry* reg = ctx && ctx->Registry ? ctx->Registry : GetFunctionRegistry();
+  Function* fn = reg->GetFunction(name);
+  if (!fn) return Status::Make(StatusCode::KeyError, "function '" + name + "' not found");  // exec.go:191-199
+  return fn->Execute(ctx, opts, args, out);
+}
+
+}  // namespace compute
+
+// ---- arrow/math ----------------------------------------------------------------------------
+namespace math {
+const Float64Funcs Float64{};
+const Int64Funcs Int64{};
+const Uint64Funcs Uint64{};
+
+static const void* ValuesPtr(const ArrayData& a) {
+  return (const uint8_t*)a.buffers[1]->dptr + a.offset * (a.type->bit_width / 8);  // Float64Values(): offset applied
+}
+Status Float64Funcs::Sum(Session* s, const ArrayData& a, double* out) const {
+  if (a.type->id != Type::FLOAT64) return Status::Make(StatusCode::TypeError, "math.Float64.Sum needs a float64 array");
+  if (a.length == 0) { *out = 0; return Status::OK(); }  // float64.go:35-37
+  return s->FromStatus(ah_sum_float64(s->ctx(), (const double*)ValuesPtr(a), (size_t)a.length, out));
+}
+Status Int64Funcs::Sum(Session* s, const ArrayData& a, int64_t* out) const {
+  if (a.type->id != Type::INT64) return Status::Make(StatusCode::TypeError, "math.Int64.Sum needs an int64 array");
+  if (a.length == 0) { *out = 0; return Status::OK(); }
+  return s->FromStatus(ah_sum_int64(s->ctx(), (const int64_t*)ValuesPtr(a), (size_t)a.length, out));
+}
+Status Uint64Funcs::Sum(Session* s, const ArrayData& a, uint64_t* out) const {
+  if (a.type->id != Type::UINT64) return Status::Make(StatusCode::TypeError, "math.Uint64.Sum needs a uint64 array");
+  if (a.length == 0) { *out = 0; return Status::OK(); }
+  return s->FromStatus(ah_sum_uint64(s->ctx(), (const uint64_t*)ValuesPtr(a), (size_t)a.length, out));
+}
+}  // namespace math
+
+}  // namespace arrowhip

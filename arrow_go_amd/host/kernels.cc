@@ -1,0 +1,435 @@
+// kernels.cc — the kernel library: one ExecFn per function family, each a thin adapter
+// from exec.ArraySpan to a leaf of include/arrowhip.h, plus the Register* entry points.
+//
+// ≙ arrow/compute/internal/kernels/{helpers.go:193-236 (ScalarBinary), :284-380
+//   (ScalarBinaryNotNull), scalar_arithmetic.go, scalar_comparisons.go:199-218,
+//   scalar_boolean.go:67-347, vector_selection.go:449-520,1162-1192,
+//   vector_hash.go:620-741} and arrow/compute/{arithmetic.go, scalar_compare.go,
+//   scalar_bool.go:94-110, selection.go:42-114,618-650, vector_hash.go:61-100}.
+#include "arrowhip_compute.h"
+
+#include <cstring>
+
+namespace arrowhip {
+namespace compute {
+
+using exec::ArraySpan;
+using exec::ExecResult;
+using exec::ExecSpan;
+using exec::KernelCtx;
+
+static const Type kNumericTypes[] = {Type::UINT8, Type::INT8,  Type::UINT16, Type::INT16,   Type::UINT32,
+                                     Type::INT32, Type::UINT64, Type::INT64, Type::FLOAT32, Type::FLOAT64};
+
+// exec.GetSpanValues (exec/utils.go:38-45): values pointer with the span offset applied
+static inline const uint8_t* Values(const ArraySpan& a) { return a.buffers[1].buf + a.offset * (a.type->bit_width / 8); }
+static inline uint8_t* Values(ArraySpan* a) { return a->buffers[1].buf + a->offset * (a->type->bit_width / 8); }
+
+static int ShapeOf(const ExecSpan& b) {
+  if (b.values[0].IsArray()) return b.values[1].IsArray() ? AH_SHAPE_AA : AH_SHAPE_AS;
+  return AH_SHAPE_SA;
+}
+
+// ---- arithmetic ---------------------------------------------------------------------------
+struct ArithData { int op; bool checked; };
+
+// ScalarBinary (helpers.go:193-236) over the unchecked SIMD leaves
+static Status ExecArithUnchecked(KernelCtx* k, const ExecSpan& b, ExecResult* out, int op) {
+  Session* s = k->session;
+  int type = (int)out->type->id;
+  int shape = ShapeOf(b);
+  if (out->len == 0) return Status::OK();
+  switch (shape) {
+    case AH_SHAPE_AA:
+      return s->FromStatus(ah_arithmetic_binary(s->ctx(), type, (int8_t)op, Values(b.values[0].array), Values(b.values[1].array), Values(out), out->len));
+    case AH_SHAPE_AS:
+      return s->FromStatus(ah_arithmetic_arr_scalar(s->ctx(), type, (int8_t)op, Values(b.values[0].array), b.values[1].scalar->value, Values(out), out->len));
+    default:
+      return s->FromStatus(ah_arithmetic_scalar_arr(s->ctx(), type, (int8_t)op, b.values[0].scalar->value, Values(b.values[1].array), Values(out), out->len));
+  }
+}
+
+// ScalarBinaryNotNull (helpers.go:284-380) for the checked integer ops
+static Status ExecArithChecked(KernelCtx* k, const ExecSpan& b, ExecResult* out, int op) {
+  Session* s = k->session;
+  int type = (int)out->type->id;
+  if (IsFloating(out->type->id)) return ExecArithUnchecked(k, b, out, op);  // base_arithmetic_amd64.go:109-117
+  if (out->len == 0) return Status::OK();
+  int shape = ShapeOf(b);
+  const void *l, *r;
+  const uint8_t *lv = nullptr, *rv = nullptr;
+  int64_t lo = 0, ro = 0;
+  int scalar_valid = 1;
+  if (b.values[0].IsArray()) { l = Values(b.values[0].array); lv = b.values[0].array.buffers[0].buf; lo = b.values[0].array.offset; }
+  else { l = b.values[0].scalar->value; scalar_valid = b.values[0].scalar->valid; }
+  if (b.values[1].IsArray()) { r = Values(b.values[1].array); rv = b.values[1].array.buffers[0].buf; ro = b.values[1].array.offset; }
+  else { r = b.values[1].scalar->value; scalar_valid = b.values[1].scalar->valid; }
+  return s->FromStatus(ah_arithmetic_checked(s->ctx(), type, (int8_t)op, shape, l, lv, lo, r, rv, ro, scalar_valid, Values(out), out->len));
+}
+
+static Status ExecUnary(KernelCtx* k, const ExecSpan& b, ExecResult* out, int op) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  return s->FromStatus(ah_arithmetic_unary(s->ctx(), (int)out->type->id, (int8_t)op, Values(b.values[0].array), Values(out), out->len));
+}
+
+static std::shared_ptr<ScalarFunction> MakeArith(const std::string& name, int op, bool checked) {
+  auto fn = std::make_shared<ScalarFunction>(name, Arity{2, false});
+  for (Type t : kNumericTypes) {
+    exec::ScalarKernel k;
+    k.sig.in_types = {t, t};
+    k.sig.out_is_first_input = true;
+    k.exec_fn = checked ? exec::ArrayKernelExec([op](KernelCtx* c, const ExecSpan& b, ExecResult* o) { return ExecArithChecked(c, b, o, op); })
+                        : exec::ArrayKernelExec([op](KernelCtx* c, const ExecSpan& b, ExecResult* o) { return ExecArithUnchecked(c, b, o, op); });
+    fn->AddKernel(std::move(k));
+  }
+  return fn;
+}
+
+void RegisterScalarArithmetic(FunctionRegistry* reg) {
+  // compute/arithmetic.go: "add" / "subtract" / "multiply" are the CHECKED kernels (the
+  // default of compute.Add, :1090-1104), "*_unchecked" the wrapping SIMD ones
+  reg->AddFunction(MakeArith("add", AH_OP_ADD_CHECKED, true), false);
+  reg->AddFunction(MakeArith("add_unchecked", AH_OP_ADD, false), false);
+  reg->AddFunction(MakeArith("subtract", AH_OP_SUB_CHECKED, true), false);
+  reg->AddFunction(MakeArith("subtract_unchecked", AH_OP_SUB, false), false);
+  reg->AddFunction(MakeArith("multiply", AH_OP_MUL_CHECKED, true), false);
+  reg->AddFunction(MakeArith("multiply_unchecked", AH_OP_MUL, false), false);
+  struct U { const char* name; int op; };
+  for (U u : {U{"abs_unchecked", AH_OP_ABS}, U{"negate_unchecked", AH_OP_NEGATE}, U{"sign", AH_OP_SIGN}}) {
+    auto fn = std::make_shared<ScalarFunction>(u.name, Arity{1, false});
+    for (Type t : kNumericTypes) {
+      exec::ScalarKernel k;
+      k.sig.in_types = {t};
+      int op = u.op;
+      k.exec_fn = [op](KernelCtx* c, const ExecSpan& b, ExecResult* o) { return ExecUnary(c, b, o, op); };
+      fn->AddKernel(std::move(k));
+    }
+    reg->AddFunction(fn, false);
+  }
+}
+
+// ---- comparisons --------------------------------------------------------------------------
+// compareKernel[T] (scalar_comparisons.go:199-218): out bitmap starts at byte out.Offset/8,
+// bit prefix out.Offset%8
+static Status ExecCompare(KernelCtx* k, const ExecSpan& b, ExecResult* out, int cmpop) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  int shape = ShapeOf(b);
+  const DataType* in_type = b.values[0].type();
+  const void* l = b.values[0].IsArray() ? (const void*)Values(b.values[0].array) : (const void*)b.values[0].scalar->value;
+  const void* r = b.values[1].IsArray() ? (const void*)Values(b.values[1].array) : (const void*)b.values[1].scalar->value;
+  return s->FromStatus(ah_comparison(s->ctx(), cmpop, shape, (int)in_type->id, l, r, out->buffers[1].buf + out->offset / 8, out->len, (int)(out->offset % 8)));
+}
+
+void RegisterScalarComparisons(FunctionRegistry* reg) {
+  struct C { const char* name; int op; };
+  for (C c : {C{"equal", AH_CMP_EQ}, C{"not_equal", AH_CMP_NE}, C{"greater", AH_CMP_GT}, C{"greater_equal", AH_CMP_GE}}) {
+    auto fn = std::make_shared<ScalarFunction>(c.name, Arity{2, false});
+    for (Type t : kNumericTypes) {
+      exec::ScalarKernel k;
+      k.sig.in_types = {t, t};
+      k.sig.out_is_first_input = false;
+      k.sig.out_type = Type::BOOL;
+      int op = c.op;
+      k.exec_fn = [op](KernelCtx* kc, const ExecSpan& b, ExecResult* o) { return ExecCompare(kc, b, o, op); };
+      fn->AddKernel(std::move(k));
+    }
+    reg->AddFunction(fn, false);
+  }
+  // scalar_compare.go:73-99: less / less_equal = flipped greater / greater_equal
+  auto less = std::make_shared<ScalarFunction>("less", Arity{2, false});
+  less->flipped_of = "greater";
+  reg->AddFunction(less, false);
+  auto le = std::make_shared<ScalarFunction>("less_equal", Arity{2, false});
+  le->flipped_of = "greater_equal";
+  reg->AddFunction(le, false);
+}
+
+// ---- boolean --------------------------------------------------------------------------------
+// a boolean scalar operand is materialised as a constant bitmap (SetBitsTo) so every shape
+// runs through the same bitmap kernels — scalar_boolean.go:75-88 does CopyBitmap/SetBitsTo too
+static Status BoolOperand(KernelCtx* k, const exec::ExecValue& v, int64_t len, const uint8_t** data, int64_t* off, BufferPtr* keep) {
+  if (v.IsArray()) { *data = v.array.buffers[1].buf; *off = v.array.offset; return Status::OK(); }
+  AHC_RETURN_NOT_OK(k->AllocateBitmap(len, keep));
+  if (v.scalar->value[0] & 1)
+    AHC_RETURN_NOT_OK(k->session->FromStatus(ah_set_bits_to(k->session->ctx(), (uint8_t*)(*keep)->dptr, 0, len, 1)));
+  *data = (const uint8_t*)(*keep)->dptr;
+  *off = 0;
+  return Status::OK();
+}
+
+static Status ExecBoolBinary(KernelCtx* k, const ExecSpan& b, ExecResult* out, int bitop) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  const uint8_t *l, *r; int64_t lo, ro; BufferPtr kl, kr;
+  AHC_RETURN_NOT_OK(BoolOperand(k, b.values[0], out->len, &l, &lo, &kl));
+  AHC_RETURN_NOT_OK(BoolOperand(k, b.values[1], out->len, &r, &ro, &kr));
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_bitmap_op(s->ctx(), bitop, l, lo, r, ro, out->buffers[1].buf, out->offset, out->len)));
+  if (kl || kr) AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));  // temporaries die with this frame
+  return Status::OK();
+}
+
+static Status ExecKleene(KernelCtx* k, const ExecSpan& b, ExecResult* out, int op) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  const uint8_t *ld, *rd, *lv = nullptr, *rv = nullptr; int64_t lo, ro; BufferPtr kl, kr, klv, krv;
+  AHC_RETURN_NOT_OK(BoolOperand(k, b.values[0], out->len, &ld, &lo, &kl));
+  AHC_RETURN_NOT_OK(BoolOperand(k, b.values[1], out->len, &rd, &ro, &kr));
+  if (b.values[0].IsArray()) lv = b.values[0].array.buffers[0].buf;
+  else if (!b.values[0].scalar->valid) { AHC_RETURN_NOT_OK(k->AllocateBitmap(out->len, &klv)); lv = (const uint8_t*)klv->dptr; }
+  if (b.values[1].IsArray()) rv = b.values[1].array.buffers[0].buf;
+  else if (!b.values[1].scalar->valid) { AHC_RETURN_NOT_OK(k->AllocateBitmap(out->len, &krv)); rv = (const uint8_t*)krv->dptr; }
+  // validity bitmaps share the data offset of their array (ArraySpan.Offset)
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_kleene(s->ctx(), op, lv, ld, lo, rv, rd, ro, out->buffers[0].buf, out->buffers[1].buf, out->offset, out->len)));
+  out->nulls = kUnknownNullCount;
+  if (kl || kr || klv || krv) AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+  return Status::OK();
+}
+
+void RegisterScalarBoolean(FunctionRegistry* reg) {
+  struct B { const char* name; int op; };
+  for (B bo : {B{"and", AH_BIT_AND}, B{"or", AH_BIT_OR}, B{"xor", AH_BIT_XOR}, B{"and_not", AH_BIT_AND_NOT}}) {
+    auto fn = std::make_shared<ScalarFunction>(bo.name, Arity{2, false});
+    exec::ScalarKernel k;
+    k.sig.in_types = {Type::BOOL, Type::BOOL};
+    int op = bo.op;
+    k.exec_fn = [op](KernelCtx* kc, const ExecSpan& b, ExecResult* o) { return ExecBoolBinary(kc, b, o, op); };
+    fn->AddKernel(std::move(k));
+    reg->AddFunction(fn, false);
+  }
+  for (B bo : {B{"and_kleene", AH_KLEENE_AND}, B{"or_kleene", AH_KLEENE_OR}, B{"and_not_kleene", AH_KLEENE_AND_NOT}}) {
+    auto fn = std::make_shared<ScalarFunction>(bo.name, Arity{2, false});
+    exec::ScalarKernel k;
+    k.sig.in_types = {Type::BOOL, Type::BOOL};
+    k.null_handling = exec::NullHandling::NullComputedPrealloc;  // scalar_bool.go:101-109
+    int op = bo.op;
+    k.exec_fn = [op](KernelCtx* kc, const ExecSpan& b, ExecResult* o) { return ExecKleene(kc, b, o, op); };
+    fn->AddKernel(std::move(k));
+    reg->AddFunction(fn, false);
+  }
+  auto inv = std::make_shared<ScalarFunction>("invert", Arity{1, false});
+  exec::ScalarKernel k;
+  k.sig.in_types = {Type::BOOL};
+  k.exec_fn = [](KernelCtx* kc, const ExecSpan& b, ExecResult* o) {
+    if (o->len == 0) return Status::OK();
+    const ArraySpan& a = b.values[0].array;  // NotExecKernel (scalar_boolean.go:334-347)
+    return kc->session->FromStatus(ah_copy_bitmap(kc->session->ctx(), a.buffers[1].buf, a.offset, a.len, o->buffers[1].buf, o->offset, 1));
+  };
+  inv->AddKernel(std::move(k));
+  reg->AddFunction(inv, false);
+}
+
+// ---- selection --------------------------------------------------------------------------------
+// PrimitiveFilter (vector_selection.go:449-520)
+static Status ExecFilter(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  ArraySpan values = b.values[0].array, filter = b.values[1].array;
+  const FilterOptions* opts = static_cast<const FilterOptions*>(k->state);
+  int null_sel = opts ? (int)opts->NullSelection : DropNulls;
+  AHC_RETURN_NOT_OK(values.UpdateNullCount(s));
+  AHC_RETURN_NOT_OK(filter.UpdateNullCount(s));
+  const uint8_t* fvalid = filter.MayHaveNulls() ? filter.buffers[0].buf : nullptr;
+  int64_t n_out = 0;
+  if (values.len > 0)  // getFilterOutputSize :57-81
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_count(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, filter.len, null_sel, &n_out)));
+  // :464-468
+  out->nulls = (values.nulls == 0 && (null_sel == DropNulls || filter.nulls == 0)) ? 0 : kUnknownNullCount;
+  bool allocate_validity = values.nulls != 0 || filter.nulls != 0;  // :486-488
+  int w = values.type->bit_width / 8;
+  if (values.type->bit_width == 1)
+    return Status::Make(StatusCode::NotImplemented, "boolean-valued filter is outside the accelerated path");
+  out->len = n_out;  // preallocateData :83-93
+  BufferPtr vb, db;
+  if (allocate_validity) { AHC_RETURN_NOT_OK(k->AllocateBitmap(n_out, &vb)); out->buffers[0].WrapBuffer(vb); }
+  AHC_RETURN_NOT_OK(k->Allocate(n_out * w, &db));
+  out->buffers[1].WrapBuffer(db);
+  if (values.len == 0) return Status::OK();
+  int64_t nulls = 0;
+  const uint8_t* vvalid = values.MayHaveNulls() ? values.buffers[0].buf : nullptr;
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_primitive(s->ctx(), w, Values(values), vvalid, values.offset, filter.buffers[1].buf, fvalid,
+                                                      filter.offset, values.len, null_sel, n_out, db->dptr,
+                                                      allocate_validity ? (uint8_t*)vb->dptr : nullptr, allocate_validity ? &nulls : nullptr)));
+  if (allocate_validity) out->nulls = nulls;
+  return Status::OK();
+}
+
+// PrimitiveTake (vector_selection.go:1162-1192)
+static Status ExecTake(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  ArraySpan values = b.values[0].array, indices = b.values[1].array;
+  const TakeOptions* opts = static_cast<const TakeOptions*>(k->state);
+  AHC_RETURN_NOT_OK(values.UpdateNullCount(s));
+  AHC_RETURN_NOT_OK(indices.UpdateNullCount(s));
+  if (values.type->bit_width == 1)
+    return Status::Make(StatusCode::NotImplemented, "boolean-valued take is outside the accelerated path");
+  int w = values.type->bit_width / 8, iw = indices.type->bit_width / 8;
+  bool allocate_validity = values.nulls != 0 || indices.nulls != 0;  // :1176
+  out->len = indices.len;
+  BufferPtr vb, db;
+  if (allocate_validity) { AHC_RETURN_NOT_OK(k->AllocateBitmap(indices.len, &vb)); out->buffers[0].WrapBuffer(vb); }
+  AHC_RETURN_NOT_OK(k->Allocate(indices.len * w, &db));
+  out->buffers[1].WrapBuffer(db);
+  if (indices.len == 0) { out->nulls = 0; return Status::OK(); }
+  int64_t nulls = 0, bad = 0;
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_take_primitive(
+      s->ctx(), w, values.buffers[1].buf ? Values(values) : nullptr, values.MayHaveNulls() ? values.buffers[0].buf : nullptr, values.offset,
+      values.len, iw, IsSignedInteger(indices.type->id) ? 1 : 0, Values(indices), indices.MayHaveNulls() ? indices.buffers[0].buf : nullptr,
+      indices.offset, indices.len, opts ? (int)opts->BoundsCheck : 1, db->dptr, allocate_validity ? (uint8_t*)vb->dptr : nullptr, &nulls, &bad)));
+  out->nulls = allocate_validity ? nulls : 0;
+  return Status::OK();
+}
+
+static const FilterOptions kDefaultFilterOptions;
+static const TakeOptions kDefaultTakeOptions;
+static const DictionaryEncodeOptions kDefaultDictOptions;
+
+void RegisterVectorSelection(FunctionRegistry* reg) {
+  auto af = std::make_shared<VectorFunction>("array_filter", Arity{2, false}, &kDefaultFilterOptions);
+  for (Type t : kNumericTypes) {
+    exec::VectorKernel k;
+    k.sig.in_types = {t, Type::BOOL};
+    k.exec_fn = ExecFilter;
+    af->AddKernel(std::move(k));
+  }
+  reg->AddFunction(af, false);
+  auto at = std::make_shared<VectorFunction>("array_take", Arity{2, false}, &kDefaultTakeOptions);
+  for (Type t : kNumericTypes)
+    for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
+      exec::VectorKernel k;
+      k.sig.in_types = {t, it};
+      k.exec_fn = ExecTake;
+      k.can_execute_chunkwise = false;  // selection.go:639
+      at->AddKernel(std::move(k));
+    }
+  reg->AddFunction(at, false);
+  // filterMetaFunc (selection.go:42-85): validates, then dispatches on the values kind
+  reg->AddFunction(std::make_shared<MetaFunction>("filter", Arity{2, false}, &kDefaultFilterOptions,
+      [](ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
+        if (args[1].type()->id != Type::BOOL)
+          return Status::Make(StatusCode::NotImplemented, "filter argument must be boolean type");  // :45-48
+        if (args[0].kind == DatumKind::Array && args[1].kind == DatumKind::Array && args[0].Len() != args[1].Len())
+          return Status::Make(StatusCode::Invalid, "filter inputs must all be the same length");  // FilterArray check
+        return CallFunction(ctx, "array_filter", o, args, out);
+      }), false);
+  // takeMetaFunc (selection.go:93-114)
+  reg->AddFunction(std::make_shared<MetaFunction>("take", Arity{2, false}, &kDefaultTakeOptions,
+      [](ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
+        if (!IsInteger(args[1].type()->id))
+          return Status::Make(StatusCode::NotImplemented, "take indices must be an integer type");
+        return CallFunction(ctx, "array_take", o, args, out);
+      }), false);
+}
+
+// ---- hashing -----------------------------------------------------------------------------------
+// regularHashState over Table[uint64] (vector_hash.go:243-286,359-385,604-607)
+static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool dict_encode) {
+  Session* s = k->session;
+  ArraySpan keys = b.values[0].array;
+  if (keys.type->bit_width != 64)
+    return Status::Make(StatusCode::NotImplemented, std::string("hash kernels are accelerated for 8-byte keys (int64/uint64/float64), got ") + keys.type->name);
+  const DictionaryEncodeOptions* opts = static_cast<const DictionaryEncodeOptions*>(k->state);
+  int encode_nulls = dict_encode ? (opts && opts->NullEncoding == NullEncodingEncode) : 1;  // uniqueAction.ShouldEncodeNulls() == true
+  AHC_RETURN_NOT_OK(keys.UpdateNullCount(s));
+  const uint8_t* valid = keys.MayHaveNulls() ? keys.buffers[0].buf : nullptr;
+  int64_t n = keys.len;
+  BufferPtr ids, ids_valid, dict;
+  AHC_RETURN_NOT_OK(k->Allocate((n + 1) * 8, &dict));
+  if (dict_encode) {
+    AHC_RETURN_NOT_OK(k->Allocate(n * 4, &ids));
+    if (valid && !encode_nulls) AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &ids_valid));
+  }
+  int64_t ndict = 0; int32_t null_id = -1;
+  if (n > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_hash_u64_encode(s->ctx(), (const uint64_t*)Values(keys), valid, keys.offset, n, encode_nulls,
+                                                       ids ? (int32_t*)ids->dptr : nullptr, ids_valid ? (uint8_t*)ids_valid->dptr : nullptr,
+                                                       (uint64_t*)dict->dptr, &ndict, &null_id)));
+  // GetDictArrayData (arrow/array/util.go:321-390): values by memo index; if the table holds
+  // a null, validity = all ones with that bit cleared
+  auto d = std::make_shared<ArrayData>();
+  d->type = keys.type;
+  d->length = ndict;
+  d->null_count = null_id >= 0 ? 1 : 0;
+  d->buffers[1] = dict;
+  dict->size = ndict * 8;
+  if (null_id >= 0) {
+    BufferPtr dv;
+    AHC_RETURN_NOT_OK(k->AllocateBitmap(ndict, &dv));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), dv->dptr, 0xFF, (size_t)((ndict + 7) / 8))));  // memory.Set(…, 0xFF), util.go:381
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_set_bits_to(s->ctx(), (uint8_t*)dv->dptr, null_id, 1, 0)));
+    d->buffers[0] = dv;
+  }
+  if (!dict_encode) {  // uniqueFinalize (vector_hash.go:721-741): the result IS the dictionary
+    out->type = d->type;
+    out->len = d->length;
+    out->nulls = d->null_count;
+    out->buffers[0].WrapBuffer(d->buffers[0]);
+    out->buffers[1].WrapBuffer(d->buffers[1]);
+    return Status::OK();
+  }
+  out->len = n;
+  out->nulls = ids_valid ? keys.nulls : 0;  // dictionaryEncodeAction.Flush :188-209
+  out->buffers[0].WrapBuffer(ids_valid);
+  out->buffers[1].WrapBuffer(ids);
+  out->dictionary = d;
+  return Status::OK();
+}
+
+void RegisterVectorHash(FunctionRegistry* reg) {
+  auto uq = std::make_shared<VectorFunction>("unique", Arity{1, false});
+  auto de = std::make_shared<VectorFunction>("dictionary_encode", Arity{1, false}, &kDefaultDictOptions);
+  for (Type t : kNumericTypes) {
+    exec::VectorKernel ku;
+    ku.sig.in_types = {t};
+    ku.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHash(k, b, o, false); };
+    uq->AddKernel(std::move(ku));
+    exec::VectorKernel kd;
+    kd.sig.in_types = {t};
+    kd.output_is_dictionary = true;
+    kd.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHash(k, b, o, true); };
+    de->AddKernel(std::move(kd));
+  }
+  reg->AddFunction(uq, false);
+  reg->AddFunction(de, false);
+}
+
+// ---- fused extension (no reference analogue) --------------------------------
+// "greater_filter_sum"(x, scalar) etc.: Σ x over valid slots with x OP scalar, as a 1-element
+// array of x's type — what "greater" → "filter" → math.Sum computes in three calls.
+void RegisterFusedExtensions(FunctionRegistry* reg) {
+  struct F { const char* name; int op; };
+  for (F f : {F{"equal_filter_sum", AH_CMP_EQ}, F{"not_equal_filter_sum", AH_CMP_NE}, F{"greater_filter_sum", AH_CMP_GT}, F{"greater_equal_filter_sum", AH_CMP_GE}}) {
+    int op = f.op;
+    reg->AddFunction(std::make_shared<MetaFunction>(f.name, Arity{2, false}, nullptr,
+        [op](ExecCtx* ctx, const FunctionOptions*, const std::vector<Datum>& args, Datum* out) {
+          Session* s = ctx->session;
+          if (args[0].kind != DatumKind::Array || args[1].kind != DatumKind::Scalar)
+            return Status::Make(StatusCode::Invalid, "fused compare-filter-sum needs (array, scalar)");
+          const ArrayData& a = *args[0].array;
+          if (a.type->id != args[1].scalar->type->id) return Status::Make(StatusCode::TypeError, "operand types differ");
+          if (!args[1].scalar->valid) return Status::Make(StatusCode::Invalid, "null threshold");
+          auto sc = std::make_shared<Scalar>();
+          sc->type = a.type;
+          sc->valid = true;
+          const uint8_t* valid = a.buffers[0] ? (const uint8_t*)a.buffers[0]->dptr : nullptr;
+          const uint8_t* vals = a.length ? (const uint8_t*)a.buffers[1]->dptr + a.offset * 8 : nullptr;
+          int64_t cnt = 0;
+          if (a.type->id == Type::INT64) {
+            int64_t thr, sum = 0; memcpy(&thr, args[1].scalar->value, 8);
+            AHC_RETURN_NOT_OK(s->FromStatus(ah_cmp_filter_sum_i64(s->ctx(), op, (const int64_t*)vals, valid, a.offset, a.length, thr, &sum, &cnt)));
+            memcpy(sc->value, &sum, 8);
+          } else if (a.type->id == Type::FLOAT64) {
+            double thr, sum = 0; memcpy(&thr, args[1].scalar->value, 8);
+            AHC_RETURN_NOT_OK(s->FromStatus(ah_cmp_filter_sum_f64(s->ctx(), op, (const double*)vals, valid, a.offset, a.length, thr, &sum, &cnt)));
+            memcpy(sc->value, &sum, 8);
+          } else {
+            return Status::Make(StatusCode::NotImplemented, "fused compare-filter-sum is implemented for int64 and float64");
+          }
+          *out = Datum::Of(sc);
+          return Status::OK();
+        }), false);
+  }
+}
+
+}  // namespace compute
+}  // namespace arrowhip

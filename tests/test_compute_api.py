@@ -1,0 +1,322 @@
+"""Array-level tests of the host layer that mirrors arrow-go's compute API
+(arrowhip::compute::CallFunction, the registry, the scalar/vector executors, arrow/math).
+They read like the reference's own table-driven tests: inputs and expectations are the
+JSON-ish literals of arrow/compute/*_test.go, compared logically (values + validity),
+which is what array.ApproxEqual does.  pyarrow.compute (Arrow C++) serves as an
+independent semantic cross-check on random data.
+"""
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+NUMERIC = [pa.uint8(), pa.int8(), pa.uint16(), pa.int16(), pa.uint32(), pa.int32(), pa.uint64(), pa.int64(),
+           pa.float32(), pa.float64()]
+INTS = NUMERIC[:8]
+
+
+@pytest.fixture(scope="module")
+def sess():
+    from arrow_go_amd import compute as ac
+    s = ac.Session(0)
+    yield s
+    s.close()
+
+
+# ---- registry (no GPU needed) -----------------------------------------------------------------
+def test_registry_has_the_path_functions():
+    # compute/registry_test.go + the names registered by RegisterScalarArithmetic /
+    # RegisterScalarComparisons / RegisterScalarBoolean / RegisterVectorSelection / RegisterVectorHash
+    from arrow_go_amd import compute as ac
+    for name in ["add", "add_unchecked", "subtract", "subtract_unchecked", "multiply", "multiply_unchecked",
+                 "abs_unchecked", "negate_unchecked", "sign", "equal", "not_equal", "greater", "greater_equal", "less",
+                 "less_equal", "and", "or", "xor", "and_not", "invert", "and_kleene", "or_kleene", "and_not_kleene",
+                 "filter", "array_filter", "take", "array_take", "unique", "dictionary_encode", "greater_filter_sum"]:
+        assert ac.has_function(name), name
+    assert not ac.has_function("no_such_function")
+    assert ac.function_num_kernels("add") == 10            # one per numeric type
+    assert ac.function_num_kernels("array_take") == 80      # 10 value types × 8 index types
+    assert ac.function_num_kernels("filter") == 0           # MetaFunction
+    assert ac.num_functions() >= 30
+
+
+# ---- arithmetic -----------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+@pytest.mark.parametrize("fn", ["add", "add_unchecked"])
+def test_add(sess, typ, fn):
+    # arrow/compute/arithmetic_test.go:325-359 (BinaryArithmeticSuite.TestAdd)
+    A = lambda v: pa.array(v, type=typ)
+    S = lambda v: pa.scalar(v, type=typ)
+    call = lambda l, r: sess.call_function(fn, [l, r]).to_pylist()
+    assert call(A([]), A([])) == []
+    assert call(A([3, 2, 6]), A([1, 0, 2])) == [4, 2, 8]
+    assert call(A([None, 1, None]), A([3, 4, 5])) == [None, 5, None]
+    assert call(A([None, 1, 2]), A([3, 4, None])) == [None, 5, None]
+    assert call(A([None]), A([None])) == [None]
+    assert call(S(3), A([1, 2])) == [4, 5]
+    assert call(S(3), A([None, 2])) == [None, 5]
+    assert call(S(None), A([1, 2])) == [None, None]
+    assert call(A([1, 2]), S(3)) == [4, 5]
+    assert call(A([None, 2]), S(3)) == [None, 5]
+    # scalar ∘ scalar (arithmetic_test.go:115-132)
+    assert sess.call_function(fn, [S(3), S(4)]).as_py() == 7
+    assert sess.call_function(fn, [S(None), S(4)]).as_py() is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", INTS, ids=str)
+def test_add_overflow(sess, typ):
+    from arrow_go_amd import compute as ac
+    info = np.iinfo(typ.to_pandas_dtype())
+    mx = pa.array([info.max], type=typ)
+    with pytest.raises(ac.ErrInvalid, match="overflow"):      # arithmetic_test.go:352-358
+        sess.call_function("add", [mx, mx])
+    wrapped = sess.call_function("add_unchecked", [mx, mx]).to_pylist()
+    with np.errstate(over="ignore"):
+        npm = np.array([info.max], dtype=typ.to_pandas_dtype())
+        assert wrapped == (npm + npm).tolist()
+    # overflow under a null slot is ignored by the checked kernel
+    assert sess.call_function("add", [pa.array([None], type=typ), mx]).to_pylist() == [None]
+    with pytest.raises(ac.ErrInvalid, match="overflow"):
+        sess.call_function("multiply", [mx, pa.array([2], type=typ)])
+    with pytest.raises(ac.ErrInvalid, match="overflow"):
+        sess.call_function("subtract", [pa.array([info.min], type=typ), pa.array([1], type=typ)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+def test_sub_mul_unary(sess, typ):
+    A = lambda v: pa.array(v, type=typ)
+    assert sess.call_function("subtract", [A([3, 2, 6]), A([1, 0, 2])]).to_pylist() == [2, 2, 4]
+    assert sess.call_function("multiply", [A([3, 2, None]), A([1, 0, 2])]).to_pylist() == [3, 0, None]
+    assert sess.call_function("sign", [A([0, 5, None])]).to_pylist() == [0, 1, None]
+    if not pa.types.is_unsigned_integer(typ):
+        assert sess.call_function("negate_unchecked", [A([1, -2, None])]).to_pylist() == [-1, 2, None]
+        assert sess.call_function("abs_unchecked", [A([1, -2, None])]).to_pylist() == [1, 2, None]
+
+
+@pytest.mark.gpu
+def test_add_sliced_inputs(sess):
+    # non-zero ArraySpan.Offset on both sides: value pointers and validity bit offsets
+    a = pa.array([9, 9, 9, 1, None, 3, 4, None], type=pa.int64()).slice(3, 5)
+    b = pa.array([7, 10, 20, None, 40, 50], type=pa.int64()).slice(1, 5)
+    assert sess.call_function("add", [a, b]).to_pylist() == [11, None, None, 44, None]
+    f = pa.array([0.5, 1.5, None, 2.5], type=pa.float64()).slice(1, 3)
+    assert sess.call_function("multiply", [f, pa.scalar(2.0)]).to_pylist() == [3.0, None, 5.0]
+
+
+@pytest.mark.gpu
+def test_dispatch_errors(sess):
+    from arrow_go_amd import compute as ac
+    with pytest.raises(ac.ErrKey, match="function 'nope' not found"):                # exec.go:191-199
+        sess.call_function("nope", [pa.array([1])])
+    with pytest.raises(ac.ErrInvalid, match="accepts 2 arguments but 1 passed"):     # functions.go:130-146
+        sess.call_function("add", [pa.array([1])])
+    with pytest.raises(ac.ErrInvalid, match="same length"):                          # executor.go inferBatchLength
+        sess.call_function("add", [pa.array([1, 2]), pa.array([1, 2, 3])])
+    with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
+        sess.call_function("add", [pa.array([1], pa.int32()), pa.array([1], pa.int64())])  # implicit casts: out of scope
+
+
+@pytest.mark.gpu
+def test_child_registry_alias(sess):
+    # registry.go:69-73 NewChildRegistry + AddFunction(allowOverwrite)
+    from arrow_go_amd import compute as ac
+    sess.add_alias("plus", "add_unchecked")
+    assert sess.call_function("plus", [pa.array([1, 2]), pa.array([10, 20])]).to_pylist() == [11, 22]
+    with pytest.raises(ac.ErrKey, match="already have a function registered"):
+        sess.add_alias("plus", "add")
+    sess.add_alias("plus", "add", allow_overwrite=True)
+    assert not ac.has_function("plus")  # the process-default registry is untouched
+
+
+# ---- compare ----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+def test_compare(sess, typ):
+    # scalar_compare_test.go:299-483
+    one = pa.scalar(1, type=typ)
+    A = lambda v: pa.array(v, type=typ)
+    call = lambda fn, l, r: sess.call_function(fn, [l, r]).to_pylist()
+    assert call("equal", A([]), one) == []
+    assert call("equal", A([None]), one) == [None]
+    assert call("equal", A([0, 0, 1, 1, 2, 2]), one) == [False, False, True, True, False, False]
+    assert call("equal", A([None, 0, 1, 1]), one) == [None, False, True, True]
+    assert call("not_equal", A([5, 4, 3, 2, 1, 0]), one) == [True, True, True, True, False, True]
+    assert call("greater", A([0, 1, 2, 3, 4, 5]), one) == [False, False, True, True, True, True]
+    assert call("greater_equal", A([None, 0, 1, 1]), one) == [None, False, True, True]
+    assert call("less", A([0, 0, 1, 1, 2, 2]), one) == [True, True, False, False, False, False]
+    assert call("less_equal", A([None, 0, 1, 1]), one) == [None, True, True, True]
+    assert call("equal", one, A([0, 1, 2, 3, 4, 5])) == [False, True, False, False, False, False]
+    assert call("greater", A([1, 2, None]), A([0, 2, 5])) == [True, False, None]
+    assert sess.call_function("less", [one, pa.scalar(None, type=typ)]).as_py() is None
+
+
+@pytest.mark.gpu
+def test_compare_random_vs_arrow_cpp(sess):
+    # scalar_compare_test.go:93-158 randomized compare vs slowCompare — here vs Arrow C++
+    rng = np.random.default_rng(0)
+    for n in [1, 65, 1000, 70001]:
+        for null_p in (0.0, 0.3):
+            mask = rng.random(n) < null_p
+            l = pa.array(rng.integers(0, 10, n), mask=mask, type=pa.int32())
+            r = pa.array(rng.integers(0, 10, n), mask=rng.random(n) < null_p, type=pa.int32())
+            for fn in ["equal", "not_equal", "greater", "greater_equal", "less", "less_equal"]:
+                assert sess.call_function(fn, [l, r]).equals(getattr(pc, fn)(l, r)), (fn, n)
+                assert sess.call_function(fn, [l, pa.scalar(4, pa.int32())]).equals(getattr(pc, fn)(l, pa.scalar(4, pa.int32())))
+
+
+# ---- boolean ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_boolean_vs_arrow_cpp(sess):
+    rng = np.random.default_rng(1)
+    for n in [1, 9, 64, 1000, 70001]:
+        l = pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2)
+        r = pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2)
+        for fn in ["and", "or", "xor", "and_not", "and_kleene", "or_kleene", "and_not_kleene"]:
+            got, exp = sess.call_function(fn, [l, r]), getattr(pc, fn)(l, r)
+            assert got.equals(exp), (fn, n)
+            # sliced (offset) operands
+            if n > 20:
+                ls, rs = l.slice(3, n - 10), r.slice(7, n - 10)
+                assert sess.call_function(fn, [ls, rs]).equals(getattr(pc, fn)(ls, rs)), (fn, n, "sliced")
+        assert sess.call_function("invert", [l]).equals(pc.invert(l))
+        for sv in (True, False, None):
+            sc = pa.scalar(sv, pa.bool_())
+            for fn in ["and_kleene", "or_kleene", "and", "or"]:
+                assert sess.call_function(fn, [l, sc]).equals(getattr(pc, fn)(l, sc)), (fn, sv)
+
+
+# ---- filter -------------------------------------------------------------------------------------------
+FILTER_CASES = [  # vector_selection_test.go:449-484
+    ([], [], "drop", []),
+    ([9], [False], "drop", []),
+    ([9], [True], "drop", [9]),
+    ([9], [None], "drop", []),
+    ([9], [None], "emit_null", [None]),
+    ([None], [True], "drop", [None]),
+    ([7, 8, 9], [False, True, False], "drop", [8]),
+    ([7, 8, 9], [True, False, True], "drop", [7, 9]),
+    ([None, 8, 9], [False, True, False], "drop", [8]),
+    ([7, 8, 9], [None, True, False], "drop", [8]),
+    ([7, 8, 9], [None, True, False], "emit_null", [None, 8]),
+    ([7, 8, 9], [True, None, True], "drop", [7, 9]),
+    ([7, 8, 9], [True, None, True], "emit_null", [7, None, 9]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+def test_filter(sess, typ):
+    for values, filt, sel, exp in FILTER_CASES:
+        v, f = pa.array(values, type=typ), pa.array(filt, type=pa.bool_())
+        assert sess.call_function("filter", [v, f], f"null_selection_behavior={sel}").to_pylist() == exp
+        # vector_selection_test.go:121-144: null fillers / [true,false] prepended, then sliced
+        vs = pa.concat_arrays([pa.array([None] * 3, type=typ), v]).slice(3)
+        fs = pa.concat_arrays([pa.array([True, False]), f]).slice(2)
+        assert sess.call_function("filter", [vs, fs], f"null_selection_behavior={sel}").to_pylist() == exp
+
+
+@pytest.mark.gpu
+def test_filter_errors_and_sliced_filter(sess):
+    from arrow_go_amd import compute as ac
+    v = pa.array([7, 8, 9], pa.int64())
+    f = pa.array([False, True, True, True, False, True]).slice(3, 3)
+    assert sess.call_function("filter", [v, f]).to_pylist() == [7, 9]                 # :474-478
+    with pytest.raises(ac.ErrInvalid, match="same length"):                            # :480-483
+        sess.call_function("filter", [v, pa.array([True, False])])
+    with pytest.raises(ac.ErrNotImplemented):
+        sess.call_function("filter", [v, pa.array([1, 0, 1])])
+
+
+@pytest.mark.gpu
+def test_filter_random_vs_arrow_cpp(sess):
+    # vector_selection_test.go:554-613 (compare-then-filter on random data, lengths 8..512 and beyond)
+    rng = np.random.default_rng(2)
+    for n in [8, 64, 512, 4099, 70001]:
+        for null_p in (0.0, 0.1):
+            v = pa.array(rng.integers(-100, 100, n), mask=rng.random(n) < null_p, type=pa.int64())
+            mask = sess.call_function("greater", [v, pa.scalar(0, pa.int64())])
+            for sel, pcsel in (("drop", "drop"), ("emit_null", "emit_null")):
+                got = sess.call_function("filter", [v, mask], f"null_selection_behavior={sel}")
+                assert got.equals(pc.filter(v, mask, null_selection_behavior=pcsel)), (n, null_p, sel)
+
+
+# ---- take ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+@pytest.mark.parametrize("ityp", [pa.int8(), pa.uint32(), pa.int64()], ids=str)
+def test_take(sess, typ, ityp):
+    from arrow_go_amd import compute as ac
+    A = lambda v: pa.array(v, type=typ)
+    I = lambda v: pa.array(v, type=ityp)
+    call = lambda v, i: sess.call_function("take", [v, i]).to_pylist()
+    assert call(A([7, 8, 9]), I([])) == []                                             # :1127-1141
+    assert call(A([7, 8, 9]), I([0, 1, 0])) == [7, 8, 7]
+    assert call(A([None, 8, 9]), I([0, 1, 0])) == [None, 8, None]
+    assert call(A([7, 8, 9]), I([None, 1, 0])) == [None, 8, 7]
+    assert call(A([None, 8, 9]), I([])) == []
+    assert call(A([7, 8, 9]), I([0, 0, 0, 0, 0, 0, 2])) == [7, 7, 7, 7, 7, 7, 9]
+    with pytest.raises(ac.ErrIndex, match="9 out of bounds"):
+        call(A([7, 8, 9]), I([0, 9, 0]))
+    if pa.types.is_signed_integer(ityp):
+        with pytest.raises(ac.ErrIndex, match="-1 out of bounds"):
+            call(A([7, 8, 9]), I([0, -1, 0]))
+    # sliced values and sliced indices (:213-253)
+    vs = pa.concat_arrays([A([None, None]), A([7, 8, 9])]).slice(2)
+    is_ = pa.concat_arrays([I([1]), I([2, None, 0])]).slice(1)
+    assert call(vs, is_) == [9, None, 7]
+
+
+@pytest.mark.gpu
+def test_take_random_vs_arrow_cpp(sess):
+    rng = np.random.default_rng(3)
+    for nv, ni in [(100, 1000), (5000, 70001)]:
+        v = pa.array(rng.integers(-1000, 1000, nv), mask=rng.random(nv) < 0.1, type=pa.int64())
+        i = pa.array(rng.integers(0, nv, ni), mask=rng.random(ni) < 0.1, type=pa.int32())
+        assert sess.call_function("take", [v, i]).equals(pc.take(v, i))
+
+
+# ---- hash ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", [pa.int64(), pa.uint64(), pa.float64()], ids=str)
+def test_unique_and_dictionary_encode(sess, typ):
+    A = lambda v: pa.array(v, type=typ)
+    uq = lambda v: sess.call_function("unique", [v]).to_pylist()
+    assert uq(A([2, None, 2, 1])) == [2, None, 1]                                      # vector_hash_test.go:236-254
+    assert uq(A([None, None, 3, 1])) == [None, 3, 1]
+    assert uq(A([1, 2, None, 3, 2, None]).slice(1, 4)) == [2, None, 3]
+    d = sess.call_function("dictionary_encode", [A([10, 20, 10, None, 20, None])])    # :541-591 (numeric twin)
+    assert d.indices.to_pylist() == [0, 1, 0, None, 1, None] and d.dictionary.to_pylist() == [10, 20]
+    d = sess.call_function("dictionary_encode", [A([10, 20, 10, None, 20, None])], "null_encoding_behavior=encode")
+    assert d.indices.to_pylist() == [0, 1, 0, 2, 1, 2] and d.dictionary.to_pylist() == [10, 20, None]
+    # random vs Arrow C++ (same first-seen-order contract)
+    rng = np.random.default_rng(4)
+    v = pa.array(rng.integers(0, 500, 70001), mask=rng.random(70001) < 0.05, type=typ)
+    assert sess.call_function("unique", [v]).equals(pc.unique(v))
+    got, exp = sess.call_function("dictionary_encode", [v]), pc.dictionary_encode(v)
+    assert got.indices.equals(exp.indices) and got.dictionary.equals(exp.dictionary)
+
+
+# ---- arrow/math + fused -------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_math_sum(sess):
+    # arrow/math/float64_test.go:30-48: Σ 0..9999, empty → 0; validity is ignored (float64.go:41-46)
+    assert sess.math_sum(pa.array(np.arange(10000, dtype=np.float64))) == 49995000.0
+    assert sess.math_sum(pa.array(np.arange(10000, dtype=np.int64))) == 49995000
+    assert sess.math_sum(pa.array(np.arange(10000, dtype=np.uint64))) == 49995000
+    assert sess.math_sum(pa.array([], pa.float64())) == 0.0
+    assert sess.math_sum(pa.array(np.arange(100, dtype=np.int64)).slice(10, 5)) == 10 + 11 + 12 + 13 + 14
+
+
+@pytest.mark.gpu
+def test_fused_equals_three_calls(sess):
+    rng = np.random.default_rng(5)
+    n = 100003
+    x = pa.array(rng.integers(-10**6, 10**6, n), mask=rng.random(n) < 0.1, type=pa.int64())
+    thr = pa.scalar(1234, pa.int64())
+    mask = sess.call_function("greater", [x, thr])
+    kept = sess.call_function("filter", [x, mask])
+    assert kept.null_count == 0
+    assert sess.call_function("greater_filter_sum", [x, thr]).as_py() == sess.math_sum(kept) == pc.sum(kept).as_py()
