@@ -166,7 +166,8 @@ __device__ __forceinline__ unsigned rank_of_row(unsigned fr, const unsigned long
 
 __global__ __launch_bounds__(kBlock) void assign_kernel(Slot* __restrict__ table, uint64_t cap, const unsigned long long* __restrict__ firsts,
                                                          const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff,
-                                                         unsigned long long* __restrict__ dict, int* __restrict__ null_id) {
+                                                         unsigned long long* __restrict__ dict, int* __restrict__ null_id,
+                                                         long long* __restrict__ first_rows) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const uint64_t nslots = cap + 2;
   for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(Slot* __restrict__ table
     if (fr == kNoRow) continue;
     unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
     table[s].id = id;
+    if (first_rows) first_rows[id] = (long long)fr;
     if (s == cap + 1) {
       *null_id = (int)id;
       if (dict) dict[id] = 0;  // GetDictArrayData: the null slot keeps the fresh buffer's zero
@@ -217,7 +219,7 @@ struct EncodeResult {
 
 // core: ids (optional, n int32), dict (optional), returns sizes.  Device pointers.
 int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
-                int32_t* out_ids, uint64_t* out_dict, EncodeResult* res) {
+                int32_t* out_ids, uint64_t* out_dict, EncodeResult* res, int64_t* out_first_rows = nullptr) {
   res->ndict = 0;
   res->null_id = -1;
   if (n == 0) return AH_OK;
@@ -268,7 +270,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
     scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, ntiles, tileoff, total);
     AH_LAUNCH_CHECK(c);
     assign_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(
-        table, cap, firsts, wordprefix, tileoff, (unsigned long long*)out_dict, null_id);
+        table, cap, firsts, wordprefix, tileoff, (unsigned long long*)out_dict, null_id, (long long*)out_first_rows);
     AH_LAUNCH_CHECK(c);
     if (out_ids) {
       emit_kernel<<<grid, kBlock, 0, c->stream>>>(table, out_ids, n);
@@ -284,8 +286,8 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
 
 template <typename VT, typename AT>
 int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const VT* vals, const uint8_t* vvalid,
-             int64_t voff, int64_t n, uint64_t* out_keys, AT* out_sums, int64_t* out_counts, int64_t* out_ngroups_host,
-             int32_t* out_null_group_host) {
+             int64_t voff, int64_t n, uint64_t* out_keys, AT* out_sums, int64_t* out_counts, int64_t* out_first_rows,
+             int64_t* out_ngroups_host, int32_t* out_null_group_host) {
   if (n < 0 || koff < 0 || voff < 0) return ah_fail(c, AH_EINVALID, "hash_sum: negative length/offset");
   if (out_ngroups_host) *out_ngroups_host = 0;
   if (out_null_group_host) *out_null_group_host = -1;
@@ -295,7 +297,7 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
   int32_t* ids = nullptr;
   AH_HIP(c, hipMalloc((void**)&ids, (size_t)n * sizeof(int32_t)));
   EncodeResult res;
-  int rc = encode_core(c, keys, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res);
+  int rc = encode_core(c, keys, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows);
   if (rc == AH_OK) {
     hipError_t e1 = hipMemsetAsync(out_sums, 0, (size_t)res.ndict * sizeof(AT), c->stream);
     hipError_t e2 = hipMemsetAsync(out_counts, 0, (size_t)res.ndict * sizeof(int64_t), c->stream);
@@ -346,19 +348,19 @@ AH_EXPORT int ah_hash_u64_encode(ah_ctx* c, const uint64_t* keys, const uint8_t*
 
 AH_EXPORT int ah_hash_sum_f64(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                               const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                              uint64_t* out_keys, double* out_sums, int64_t* out_counts,
+                              uint64_t* out_keys, double* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                               int64_t* out_ngroups_host, int32_t* out_null_group_host) {
   AH_ENTER(c);
-  return hash_sum<double, double>(c, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts,
+  return hash_sum<double, double>(c, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows,
                                   out_ngroups_host, out_null_group_host);
 }
 
 AH_EXPORT int ah_hash_sum_i64(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                               const int64_t* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                              uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                              uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                               int64_t* out_ngroups_host, int32_t* out_null_group_host) {
   AH_ENTER(c);
   return hash_sum<unsigned long long, unsigned long long>(c, keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff, n,
-                                                          out_keys, (unsigned long long*)out_sums, out_counts, out_ngroups_host,
-                                                          out_null_group_host);
+                                                          out_keys, (unsigned long long*)out_sums, out_counts, out_first_rows,
+                                                          out_ngroups_host, out_null_group_host);
 }

@@ -246,12 +246,13 @@ class Context:
                                                   _ptr(out_ids_valid), _ptr(out_dict), C.byref(nd), C.byref(nid)))
         return nd.value, nid.value
 
-    def hash_sum(self, kind: str, keys, kvalid, koff: int, vals, vvalid, voff: int, n: int, out_keys, out_sums, out_counts):
+    def hash_sum(self, kind: str, keys, kvalid, koff: int, vals, vvalid, voff: int, n: int, out_keys, out_sums, out_counts,
+                 out_first_rows=None):
         ng = C.c_int64()
         nid = C.c_int32()
         fn = lib.ah_hash_sum_f64 if kind == "f64" else lib.ah_hash_sum_i64
         check(self.handle, fn(self.handle, _ptr(keys), _ptr(kvalid), koff, _ptr(vals), _ptr(vvalid), voff, n, _ptr(out_keys),
-                              _ptr(out_sums), _ptr(out_counts), C.byref(ng), C.byref(nid)))
+                              _ptr(out_sums), _ptr(out_counts), _ptr(out_first_rows), C.byref(ng), C.byref(nid)))
         return ng.value, nid.value
 
     # ---- fused --------------------------------------------------------------------------

@@ -242,14 +242,16 @@ int ah_hash_u64_encode(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, 
  * g, out_counts[g] = number of valid vals.  i64 sums wrap and are exact; f64 sums
  * use hardware fp64 atomic adds, so the accumulation ORDER is not deterministic:
  * |err| ≤ n_g·ε·Σ|x| per group, exact whenever all partial sums are representable
- * (e.g. integer-valued data < 2^53).  Outputs sized like out_dict above. */
+ * (e.g. integer-valued data < 2^53).  out_first_rows (nullable) receives each group's first
+ * row index — what a cross-GPU merge needs to restore the global first-seen order.
+ * Outputs sized like out_dict above. */
 int ah_hash_sum_f64(ah_ctx* ctx, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                     const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                    uint64_t* out_keys, double* out_sums, int64_t* out_counts,
+                    uint64_t* out_keys, double* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                     int64_t* out_ngroups_host, int32_t* out_null_group_host);
 int ah_hash_sum_i64(ah_ctx* ctx, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                     const int64_t* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                    uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                    uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                     int64_t* out_ngroups_host, int32_t* out_null_group_host);
 
 /* ---- fused Compare(op scalar) → Filter(DropNulls) → Sum ------------------------------

@@ -104,11 +104,11 @@ int orc_hash_u64_encode(const uint64_t* keys, const uint8_t* valid, int64_t off,
 /* group-by (new functionality, oracle = sequential row-order accumulation) */
 int orc_hash_sum_f64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                      const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                     uint64_t* out_keys, double* out_sums, int64_t* out_counts,
+                     uint64_t* out_keys, double* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                      int64_t* out_ngroups, int32_t* out_null_group);
 int orc_hash_sum_i64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                      const int64_t* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                     uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                     uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                      int64_t* out_ngroups, int32_t* out_null_group);
 
 /* ---- fused Compare(>) → Filter → Sum (the unfused chain, restated) ---- */

@@ -121,7 +121,7 @@ int orc_hash_u64_encode(const uint64_t* keys, const uint8_t* valid, int64_t off,
     int id;                                                                                       \
     if (bget_opt(kvalid, koff + i)) { int f; id = table_insert_or_get(&t, keys[i], &f); }         \
     else id = table_get_or_insert_null(&t);                                                       \
-    if (id >= ng) { out_sums[id] = 0; out_counts[id] = 0; out_keys[id] = bget_opt(kvalid, koff + i) ? keys[i] : 0; ng = id + 1; } \
+    if (id >= ng) { out_sums[id] = 0; out_counts[id] = 0; out_keys[id] = bget_opt(kvalid, koff + i) ? keys[i] : 0; if (out_first_rows) out_first_rows[id] = i; ng = id + 1; } \
     if (bget_opt(vvalid, voff + i)) { out_sums[id] = (ACC_T)(out_sums[id] + (ACC_T)vals[i]); out_counts[id]++; } \
   }                                                                                               \
   *out_ngroups = ng;                                                                              \
@@ -131,14 +131,14 @@ int orc_hash_u64_encode(const uint64_t* keys, const uint8_t* valid, int64_t off,
 
 int orc_hash_sum_f64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                      const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                     uint64_t* out_keys, double* out_sums, int64_t* out_counts,
+                     uint64_t* out_keys, double* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                      int64_t* out_ngroups, int32_t* out_null_group) {
   HASH_SUM_BODY(double, double)
 }
 
 int orc_hash_sum_i64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                      const int64_t* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                     uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                     uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                      int64_t* out_ngroups, int32_t* out_null_group) {
   uint64_t* usums = (uint64_t*)out_sums;
   (void)usums;

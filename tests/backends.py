@@ -260,8 +260,9 @@ class HipBackend:
         kb, kp = self._up(keys); kvb, kvp = self._upbits(kvalid)
         xb, xp = self._up(vals); xvb, xvp = self._upbits(vvalid)
         okb = self.c.alloc((n + 1) * 8 + 64); osb = self.c.alloc((n + 1) * 8 + 64); ocb = self.c.alloc((n + 1) * 8 + 64)
-        ng, nid = self.c.hash_sum(kind, kp, kvp, koff, xp, xvp, voff, n, okb, osb, ocb)
-        return okb.download(np.uint64, ng), osb.download(vals.dtype, ng), ocb.download(np.int64, ng), nid
+        ofb = self.c.alloc((n + 1) * 8 + 64)
+        ng, nid = self.c.hash_sum(kind, kp, kvp, koff, xp, xvp, voff, n, okb, osb, ocb, ofb)
+        return okb.download(np.uint64, ng), osb.download(vals.dtype, ng), ocb.download(np.int64, ng), nid, ofb.download(np.int64, ng)
 
     def cmp_filter_sum_i64(self, cmpop, x, valid, off, thr, misalign=0):
         x = np.ascontiguousarray(x)

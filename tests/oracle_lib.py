@@ -68,8 +68,8 @@ class Oracle:
             "orc_filter_to_indices": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
-            "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp]),
-            "orc_hash_sum_i64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp]),
+            "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
+            "orc_hash_sum_i64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
             "orc_cmp_filter_sum_i64": (it, [it, vp, vp, i64, i64, i64, vp, vp]),
             "orc_cmp_filter_sum_f64": (it, [it, vp, vp, i64, i64, C.c_double, vp, vp, vp]),
         }
@@ -195,12 +195,13 @@ class Oracle:
         keys = np.ascontiguousarray(keys).view(np.uint64); vals = np.ascontiguousarray(vals)
         n = keys.size
         ok = np.zeros(n + 1, np.uint64); os_ = np.zeros(n + 1, vals.dtype); oc = np.zeros(n + 1, np.int64)
+        of = np.zeros(n + 1, np.int64)
         ng = np.zeros(1, np.int64); nid = np.zeros(1, np.int32)
         fn = self.lib.orc_hash_sum_f64 if kind == "f64" else self.lib.orc_hash_sum_i64
-        st = fn(_p(keys), _p(kvalid), koff, _p(vals), _p(vvalid), voff, n, _p(ok), _p(os_), _p(oc), _p(ng), _p(nid))
+        st = fn(_p(keys), _p(kvalid), koff, _p(vals), _p(vvalid), voff, n, _p(ok), _p(os_), _p(oc), _p(of), _p(ng), _p(nid))
         assert st == 0, st
         g = int(ng[0])
-        return ok[:g], os_[:g], oc[:g], int(nid[0])
+        return ok[:g], os_[:g], oc[:g], int(nid[0]), of[:g]
 
     # ---- fused --------------------------------------------------------------------------
     def cmp_filter_sum_i64(self, cmpop, x, valid, off, thr):

@@ -1,0 +1,135 @@
+"""world_size-2 gloo tests (CPU) of the record-batch sharding layer
+(arrow_go_amd/distributed.py): shard bounds, the 16-byte all-reduce of the fused
+Compare→Filter→Sum partials, the rank-ordered float64 combine, and the key-hash-owner
+all-to-all merge of the hash group-by.
+
+The per-shard leaf compute is injected: here it is a stand-in backed by the CPU oracle
+(test infrastructure), so what runs under test is the product's SHARDING / COLLECTIVE /
+MERGE code.  On GPUs the same class is driven by HipLocal (libarrowhip.so) over RCCL.
+"""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from arrow_go_amd.distributed import shard_bounds, owner_of, hash_int
+
+GT = 2
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in [0, 1, 7, 8, 1000, 2**27 + 5]:
+        for world in [1, 2, 3, 8]:
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_owner_uses_reference_hash(orc):
+    keys = np.array([0, 1, 2, 42, 2**63, 2**64 - 1], dtype=np.uint64)
+    h = hash_int(keys)
+    for k, hv in zip(keys.tolist(), h.tolist()):
+        assert hv == orc.hash_int(k)          # internal/hashing/hash_funcs.go:60-67
+    own = owner_of(np.arange(100000, dtype=np.uint64), 8)
+    assert set(own.tolist()) == set(range(8))
+    assert np.bincount(own, minlength=8).min() > 100000 / 8 * 0.9   # balanced partition
+
+
+class OracleLocal:
+    """stand-in for HipLocal: x/valid are host numpy arrays, results are written through the
+    raw pointers of the (CPU) torch tensors exactly like the GPU kernels write device memory"""
+
+    def __init__(self):
+        from tests import oracle_lib as OL
+        self.o = OL.load_oracle()
+
+    def cmp_filter_sum_partial(self, cmpop, x, valid, off, n, thr, dtype, out_sum_ptr, out_count_ptr):
+        if np.dtype(dtype) == np.int64:
+            s, c = self.o.cmp_filter_sum_i64(cmpop, x[:n], valid, off, thr)
+            buf = np.array([s, c], np.int64)
+            ctypes.memmove(out_sum_ptr, buf.ctypes.data, 16)
+        else:
+            _, s, c = self.o.cmp_filter_sum_f64(cmpop, x[:n], valid, off, thr)
+            ctypes.memmove(out_sum_ptr, np.array([s], np.float64).ctypes.data, 8)
+            ctypes.memmove(out_count_ptr, np.array([c], np.int64).ctypes.data, 8)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from tests import oracle_lib as OL
+    from arrow_go_amd.distributed import ShardedCompute
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = OL.load_oracle()
+        sc = ShardedCompute(dist, torch.device("cpu"), OracleLocal())
+        rng = np.random.default_rng(1234)  # identical "table" on every rank; each takes its shard
+        n = 100003
+        x = rng.integers(-10**9, 10**9, n, dtype=np.int64)
+        valid_bits = rng.random(n) < 0.9
+        xf = rng.uniform(-1, 1, n)
+        lo, hi = shard_bounds(n, rank, world)
+        vshard = np.packbits(valid_bits[lo:hi], bitorder="little")
+        # C4 int64: exact, must equal the unsharded oracle
+        got = sc.cmp_filter_sum(torch, GT, x[lo:hi], vshard, 0, hi - lo, 0, np.int64)
+        exp = o.cmp_filter_sum_i64(GT, x, np.packbits(valid_bits, bitorder="little"), 0, 0)
+        assert got == exp, (got, exp)
+        # C4 float64: rank-ordered sum of the per-shard exact partials, identical on every rank
+        gotf = sc.cmp_filter_sum(torch, GT, xf[lo:hi], vshard, 0, hi - lo, 0.25, np.float64)
+        parts = []
+        for r in range(world):
+            l2, h2 = shard_bounds(n, r, world)
+            _, s_exact, _c = o.cmp_filter_sum_f64(GT, xf[l2:h2], np.packbits(valid_bits[l2:h2], bitorder="little"), 0, 0.25)
+            parts.append(s_exact)
+        tot = 0.0
+        for p in parts:
+            tot += p
+        assert gotf[0] == tot and gotf[1] == int(((xf > 0.25) & valid_bits).sum())
+        # C5: local aggregate per shard → owner all-to-all → merge → global first-seen order
+        keys = rng.integers(0, 777, n).astype(np.int64) * 1000003
+        vals = rng.integers(-2**40, 2**40, n, dtype=np.int64)
+        lk, ls, lc, _nid, lf = o.hash_sum("i64", keys[lo:hi], None, 0, vals[lo:hi], None, 0)
+        mk, ms, mc, mf = sc.merge_groups(torch, lk, ls, lc, lf, lo)
+        ek, es, ec, _nid, ef = o.hash_sum("i64", keys, None, 0, vals, None, 0)
+        assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes()
+        assert mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes()
+        # float flavour: integer-valued data → exact in any merge order
+        fv = rng.integers(-1000, 1000, n).astype(np.float64)
+        lk, ls, lc, _nid, lf = o.hash_sum("f64", keys[lo:hi], None, 0, fv[lo:hi], None, 0)
+        mk, ms, mc, mf = sc.merge_groups(torch, lk, ls, lc, lf, lo)
+        ek, es, ec, _nid, ef = o.hash_sum("f64", keys, None, 0, fv, None, 0)
+        assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes()
+        q.put((rank, "ok"))
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_reductions_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"

@@ -1,0 +1,20 @@
+"""The multi-GPU path on a real GPU with world_size 1 (the only size a 1-GPU box allows):
+torch.distributed "nccl" (= RCCL) + libarrowhip.so sharing torch's stream.  Runs in a
+subprocess because torch must be imported BEFORE libarrowhip.so there (its bundled HIP
+runtime has to be the only one in the process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_rccl_path_world1():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dist_gpu_check.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "dist_gpu_check ok" in r.stdout
