@@ -161,7 +161,7 @@ int launch_binary(ah_ctx* c, const void* a, const void* b, void* out, int64_t le
   constexpr int V = 16 / sizeof(T);
   bool aligned = (((uintptr_t)a | (uintptr_t)out | (SHAPE == 0 ? (uintptr_t)b : 0)) & 15) == 0;
   int64_t iters = ah_ceil_div(len / V + 1, (int64_t)kBlock * kUnroll);
-  unsigned grid = ah_stream_grid(c, iters);
+  unsigned grid = ah_stream_grid(c, iters, /*default_bpc=*/0);
   const T* pa = (const T*)a; const T* pb = (const T*)b; T* po = (T*)out;
   if (aligned) {
     if (c->tune_nt) binary_kernel<T, OP, SHAPE, true, true><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar);
@@ -218,7 +218,7 @@ template <typename ST>
 int dispatch_unary(ah_ctx* c, int op, const void* in, void* out, int64_t len) {
   constexpr int V = 16 / sizeof(ST);
   bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
-  unsigned grid = ah_stream_grid(c, ah_ceil_div(len / V + 1, kBlock));
+  unsigned grid = ah_stream_grid(c, ah_ceil_div(len / V + 1, kBlock), /*default_bpc=*/0);
   const ST* a = (const ST*)in; ST* o = (ST*)out;
 #define AH_UNARY(OPC)                                                                          \
   if (aligned) unary_kernel<ST, OPC, true, true><<<grid, kBlock, 0, c->stream>>>(a, o, len);   \

@@ -36,9 +36,13 @@ struct ah_ctx {
   char err[512];
 };
 
-// grid size for a grid-stride streaming kernel over `work_items` block-iterations
-static inline unsigned ah_stream_grid(const ah_ctx* c, int64_t work_items) {
-  int64_t cap = (int64_t)c->num_cu * c->tune_blocks_per_cu;
+// grid size for a grid-stride streaming kernel over `work_items` block-iterations.
+// default_bpc: the kernel's own default cap in workgroups per CU (0 = no cap: one
+// iteration per workgroup, measured fastest for pure element-wise streams — 6.4-6.5 TB/s
+// vs 6.0 with 8/CU, scripts/micro/add_variants.hip); ARROWHIP_BLOCKS_PER_CU overrides.
+static inline unsigned ah_stream_grid(const ah_ctx* c, int64_t work_items, int default_bpc = 8) {
+  int bpc = c->tune_blocks_per_cu > 0 ? c->tune_blocks_per_cu : default_bpc;
+  int64_t cap = bpc > 0 ? (int64_t)c->num_cu * bpc : ((int64_t)1 << 30);
   int64_t g = work_items < cap ? work_items : cap;
   return (unsigned)(g < 1 ? 1 : g);
 }

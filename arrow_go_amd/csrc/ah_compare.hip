@@ -143,7 +143,7 @@ int launch_compare(ah_ctx* c, const void* a, const void* b, T scalar, uint8_t* o
   const T* pa = (const T*)a; const T* pb = (const T*)b;
   bool aligned = ((((uintptr_t)(pa + prefix_len)) | (SHAPE == 0 ? (uintptr_t)(pb + prefix_len) : 0)) & 15) == 0;
   int64_t nvec = (length - prefix_len + V - 1) / V;
-  unsigned grid = ah_stream_grid(c, ah_ceil_div(nvec > 0 ? nvec : 1, (int64_t)kBlock * kUnroll));
+  unsigned grid = ah_stream_grid(c, ah_ceil_div(nvec > 0 ? nvec : 1, (int64_t)kBlock * kUnroll), /*default_bpc=*/0);
   if (aligned) {
     if (c->tune_nt) compare_kernel<T, OP, SHAPE, true, true><<<grid, kBlock, 0, c->stream>>>(pa, pb, scalar, out, length, prefix);
     else compare_kernel<T, OP, SHAPE, true, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, scalar, out, length, prefix);

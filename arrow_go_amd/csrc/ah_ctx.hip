@@ -31,8 +31,7 @@ static int ctx_init_common(ah_ctx* c) {
   const char* e_nt = getenv("ARROWHIP_NT");
   c->tune_nt = e_nt ? atoi(e_nt) : 1;
   const char* e_bpc = getenv("ARROWHIP_BLOCKS_PER_CU");
-  c->tune_blocks_per_cu = e_bpc ? atoi(e_bpc) : 8;
-  if (c->tune_blocks_per_cu < 1) c->tune_blocks_per_cu = 1;
+  c->tune_blocks_per_cu = e_bpc ? atoi(e_bpc) : 0;  // 0 = each kernel's own default
   return AH_OK;
 }
 

