@@ -1,0 +1,196 @@
+// Package arrowhip binds libarrowhip.so (include/arrowhip.h) into arrow-go.
+//
+// UNVERIFIED IN THIS REPOSITORY'S BUILD ENVIRONMENT: the image has no Go toolchain, so this
+// package has never been compiled.  It is the reference-side binding a maintainer would add;
+// the same C ABI is exercised end to end by the C++ mirror in arrow_go_amd/host and the pytest
+// suite.  Build with:  go build -tags hip ./go/arrowhip
+//
+//go:build hip
+
+package arrowhip
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../arrow_go_amd -larrowhip -Wl,-rpath,${SRCDIR}/../../arrow_go_amd
+#include <stdlib.h>
+#include "arrowhip.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"runtime"
+	"unsafe"
+
+	"github.com/apache/arrow-go/v18/arrow"
+)
+
+// Context owns one GPU: ah_ctx (device id, compute stream, copy stream, scratch arena).
+// Every C entry point selects the device itself, so a Context may be used from whatever OS
+// thread the executor goroutine lands on (arrow/compute/exec.go:165); it serves one call at a
+// time — pool Contexts for concurrency, like scalarExecPool does (executor.go:867-873).
+type Context struct{ c *C.ah_ctx }
+
+func NewContext(device int) (*Context, error) {
+	var c *C.ah_ctx
+	if st := C.ah_ctx_create(C.int(device), &c); st != C.AH_OK {
+		return nil, fmt.Errorf("arrowhip: ah_ctx_create(%d) failed (status %d): no GPU, no fallback", device, int(st))
+	}
+	ctx := &Context{c: c}
+	runtime.SetFinalizer(ctx, func(x *Context) { x.Close() })
+	return ctx, nil
+}
+
+func (x *Context) Close() {
+	if x.c != nil {
+		C.ah_ctx_destroy(x.c)
+		x.c = nil
+	}
+}
+
+// err maps the C status classes onto arrow-go's sentinel errors so callers can errors.Is().
+func (x *Context) err(st C.int) error {
+	if st == C.AH_OK {
+		return nil
+	}
+	msg := C.GoString(C.ah_last_error(x.c))
+	switch st {
+	case C.AH_EINVALID, C.AH_EOVERFLOW:
+		return fmt.Errorf("%w: %s", arrow.ErrInvalid, msg)
+	case C.AH_EINDEX:
+		return fmt.Errorf("%w: %s", arrow.ErrIndex, msg)
+	case C.AH_ENOTIMPL:
+		return fmt.Errorf("%w: %s", arrow.ErrNotImplemented, msg)
+	}
+	return fmt.Errorf("arrowhip: HIP failure: %s", msg)
+}
+
+// DeviceBuffer is a device allocation (ah_buf_alloc); Ptr is a DEVICE pointer.
+type DeviceBuffer struct {
+	ctx  *Context
+	Ptr  unsafe.Pointer
+	Size int
+}
+
+func (x *Context) Alloc(nbytes int) (*DeviceBuffer, error) {
+	var p unsafe.Pointer
+	if err := x.err(C.ah_buf_alloc(x.c, C.size_t(nbytes), &p)); err != nil {
+		return nil, err
+	}
+	return &DeviceBuffer{ctx: x, Ptr: p, Size: nbytes}, nil
+}
+
+func (b *DeviceBuffer) Free() {
+	if b.Ptr != nil {
+		C.ah_buf_free(b.ctx.c, b.Ptr)
+		b.Ptr = nil
+	}
+}
+
+// Upload copies a Go slice to the device.  The C side never retains the host pointer past
+// the call when followed by Sync (cgo pointer rule); pass pinned memory (PinnedAllocator) to
+// get true async DMA.
+func (b *DeviceBuffer) Upload(src []byte) error {
+	if len(src) == 0 {
+		return nil
+	}
+	if err := b.ctx.err(C.ah_upload_async(b.ctx.c, b.Ptr, unsafe.Pointer(&src[0]), C.size_t(len(src)))); err != nil {
+		return err
+	}
+	return b.ctx.Sync()
+}
+
+func (b *DeviceBuffer) Download(dst []byte) error {
+	if len(dst) == 0 {
+		return nil
+	}
+	if err := b.ctx.err(C.ah_download_async(b.ctx.c, unsafe.Pointer(&dst[0]), b.Ptr, C.size_t(len(dst)))); err != nil {
+		return err
+	}
+	return b.ctx.Sync()
+}
+
+func (x *Context) Sync() error { return x.err(C.ah_sync(x.c)) }
+
+// ---- arrow/math ---------------------------------------------------------------------------
+
+// SumFloat64 replaces _sum_float64_avx2 (arrow/math/float64_avx2_amd64.go:33-42) for a
+// device-resident value buffer of n float64.
+func (x *Context) SumFloat64(values unsafe.Pointer, n int) (float64, error) {
+	var r C.double
+	err := x.err(C.ah_sum_float64(x.c, (*C.double)(values), C.size_t(n), &r))
+	return float64(r), err
+}
+
+func (x *Context) SumInt64(values unsafe.Pointer, n int) (int64, error) {
+	var r C.int64_t
+	err := x.err(C.ah_sum_int64(x.c, (*C.int64_t)(values), C.size_t(n), &r))
+	return int64(r), err
+}
+
+// ---- element-wise -------------------------------------------------------------------------
+
+// ArithmeticBinary replaces arithmeticAvx2 (kernels/base_arithmetic_avx2_amd64.go:37-39):
+// typ is the arrow.Type id, op the kernels.ArithmeticOp value, all pointers device memory.
+func (x *Context) ArithmeticBinary(typ arrow.Type, op int8, l, r, out unsafe.Pointer, n int64) error {
+	return x.err(C.ah_arithmetic_binary(x.c, C.int(typ), C.int8_t(op), l, r, out, C.int64_t(n)))
+}
+
+// ArithmeticArrScalar: the scalar is HOST memory (one element), exactly like the asm leaf.
+func (x *Context) ArithmeticArrScalar(typ arrow.Type, op int8, l, rHost, out unsafe.Pointer, n int64) error {
+	return x.err(C.ah_arithmetic_arr_scalar(x.c, C.int(typ), C.int8_t(op), l, rHost, out, C.int64_t(n)))
+}
+
+// Comparison replaces the 12 _comparison_*_avx2 leaves (kernels/scalar_comparison_avx2_amd64.go).
+func (x *Context) Comparison(cmpop, shape int, typ arrow.Type, l, r, outBits unsafe.Pointer, n int64, outBitOffset int) error {
+	return x.err(C.ah_comparison(x.c, C.int(cmpop), C.int(shape), C.int(typ), l, r, (*C.uint8_t)(outBits), C.int64_t(n), C.int(outBitOffset)))
+}
+
+// BitmapAnd replaces bitutil.BitmapAnd (arrow/bitutil/bitmaps.go:601) on device bitmaps.
+func (x *Context) BitmapAnd(l unsafe.Pointer, lOff int64, r unsafe.Pointer, rOff int64, out unsafe.Pointer, oOff, n int64) error {
+	return x.err(C.ah_bitmap_op(x.c, C.AH_BIT_AND, (*C.uint8_t)(l), C.int64_t(lOff), (*C.uint8_t)(r), C.int64_t(rOff), (*C.uint8_t)(out), C.int64_t(oOff), C.int64_t(n)))
+}
+
+func (x *Context) CountSetBits(bits unsafe.Pointer, off, n int64) (int64, error) {
+	var r C.int64_t
+	err := x.err(C.ah_count_set_bits(x.c, (*C.uint8_t)(bits), C.int64_t(off), C.int64_t(n), &r))
+	return int64(r), err
+}
+
+// ---- selection ----------------------------------------------------------------------------
+
+// FilterCount == getFilterOutputSize (kernels/vector_selection.go:57-81).
+func (x *Context) FilterCount(fdata, fvalid unsafe.Pointer, foff, n int64, nullSel int) (int64, error) {
+	var r C.int64_t
+	err := x.err(C.ah_filter_count(x.c, (*C.uint8_t)(fdata), (*C.uint8_t)(fvalid), C.int64_t(foff), C.int64_t(n), C.int(nullSel), &r))
+	return int64(r), err
+}
+
+// FilterPrimitive == primitiveFilterImpl (vector_selection.go:267-395); nOut from FilterCount.
+func (x *Context) FilterPrimitive(byteWidth int, values, vvalid unsafe.Pointer, voff int64, fdata, fvalid unsafe.Pointer,
+	foff, n int64, nullSel int, nOut int64, outValues, outValid unsafe.Pointer) (nulls int64, err error) {
+	var r C.int64_t
+	err = x.err(C.ah_filter_primitive(x.c, C.int(byteWidth), values, (*C.uint8_t)(vvalid), C.int64_t(voff), (*C.uint8_t)(fdata),
+		(*C.uint8_t)(fvalid), C.int64_t(foff), C.int64_t(n), C.int(nullSel), C.int64_t(nOut), outValues, (*C.uint8_t)(outValid), &r))
+	return int64(r), err
+}
+
+// TakePrimitive == PrimitiveTake (vector_selection.go:1162-1192) with the bounds check fused.
+func (x *Context) TakePrimitive(byteWidth int, values, vvalid unsafe.Pointer, voff, nvalues int64, idxWidth int, idxSigned bool,
+	idx, ivalid unsafe.Pointer, ioff, nidx int64, outValues, outValid unsafe.Pointer) (nulls int64, err error) {
+	var r, bad C.int64_t
+	s := C.int(0)
+	if idxSigned {
+		s = 1
+	}
+	err = x.err(C.ah_take_primitive(x.c, C.int(byteWidth), values, (*C.uint8_t)(vvalid), C.int64_t(voff), C.int64_t(nvalues),
+		C.int(idxWidth), s, idx, (*C.uint8_t)(ivalid), C.int64_t(ioff), C.int64_t(nidx), 1, outValues, (*C.uint8_t)(outValid), &r, &bad))
+	return int64(r), err
+}
+
+// CmpFilterSumInt64 is the fused Compare→Filter→Sum (no reference analogue).
+func (x *Context) CmpFilterSumInt64(cmpop int, values, valid unsafe.Pointer, off, n, threshold int64) (sum, count int64, err error) {
+	var s, c C.int64_t
+	err = x.err(C.ah_cmp_filter_sum_i64(x.c, C.int(cmpop), (*C.int64_t)(values), (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n), C.int64_t(threshold), &s, &c))
+	return int64(s), int64(c), err
+}

@@ -11,10 +11,13 @@
  * simplest per-element form that obeys the same payload rules — not a
  * transliteration of the block state machines.
  *
- * Pinning: tests/test_oracle_golden.py checks these functions against every
- * known-answer vector the reference's own tests hold for the path
- *  and, where oracle/_ref/libref_*.so is built, against the
- * reference's own AVX2 machine code on random inputs.
+ * Pinning: tests/test_golden.py checks these functions against every known-answer
+ * vector the reference's own tests hold for the path, and
+ * tests/test_oracle_vs_reference.py checks them bit for bit against the
+ * reference's own AVX2 machine code (oracle/_ref/libref_avx2.so, assembled in
+ * place by oracle/Makefile) on random inputs.  Not pinned by any reference test:
+ * float Sum on non-integer data, payload bytes under nulls, group-by / fused
+ * (no reference implementation) — see DESIGN.md §5.
  */
 #ifndef ARROWHIP_ORACLE_H
 #define ARROWHIP_ORACLE_H
