@@ -17,7 +17,7 @@
 // Three launches, all HBM-bound:
 //   1. tile_count_kernel  — popcount of the selection word per tile (reads only the
 //      bitmaps: n/8 bytes, 1/64 of the values); tile prefixes inside 256-tile super tiles
-//   2. super_scan_kernel  — exclusive scan of the (n / 2^19) super-tile totals, one block
+//   2. super_scan_kernel  — exclusive scan of the (n / 2^16) super-tile totals, one block
 //   3. compact_kernel     — one workgroup per tile of 16 KiB of values: the tile's
 //      mask words and their running popcounts live in LDS, every lane derives the
 //      output rank of its elements with two popcounts (no ballot needed), loads its
@@ -95,11 +95,13 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
 }
 
 // ---- 1. per-tile survivor counts -------------------------------------------------
-// One workgroup covers kSuper = 256 consecutive tiles (a "super tile").  It writes, per
+// One workgroup covers kSuper = 32 consecutive tiles (a "super tile"; 2048 workgroups for
+// 2^27 rows — 256-tile super tiles left one workgroup per CU and made this pass
+// latency-bound at 25 µs).  It writes, per
 // tile, the number of survivors in the tiles BEFORE it inside the super tile
 // (tile_local[tile]) and, per super tile, its total (super_total[s]).  The mask words
 // are read coalesced: in iteration j lane t reads word j*256 + t of the super tile.
-constexpr int kSuper = 256;
+constexpr int kSuper = 32;
 
 template <int WPT /*mask words per tile*/>
 __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __restrict__ fdata, const uint8_t* __restrict__ fvalid,
@@ -109,12 +111,13 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __res
   const int tid = threadIdx.x;
   const int64_t super = blockIdx.x;
   const int64_t word0 = super * (int64_t)kSuper * WPT;  // first mask word of the super tile
-  s_cnt[tid] = 0;
+  if (tid < kSuper) s_cnt[tid] = 0;
   __syncthreads();
   // tiles are WPT consecutive words: iteration j covers words [j*256, j*256+256) =
   // tiles [j*256/WPT, ...) — each lane adds its popcount into its tile's LDS counter
-  constexpr int ITERS = WPT;  // kSuper * WPT / kBlock
-#pragma unroll 4
+  constexpr int ITERS = kSuper * WPT / kBlock;
+  static_assert(kSuper * WPT % kBlock == 0, "super tile must be a whole number of block passes");
+#pragma unroll
   for (int j = 0; j < ITERS; j++) {
     const int wl = j * kBlock + tid;  // word index inside the super tile
     const int64_t pos = (word0 + wl) * 64;
@@ -132,10 +135,10 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __res
   }
   __syncthreads();
   int total;
-  int c = s_cnt[tid];
+  int c = tid < kSuper ? s_cnt[tid] : 0;
   int excl = block_exclusive_scan(c, &total);
   const int64_t tile = super * kSuper + tid;
-  if (tile < ntiles) tile_local[tile] = excl;
+  if (tid < kSuper && tile < ntiles) tile_local[tile] = excl;
   if (tid == 0) super_total[super] = total;
 }
 
