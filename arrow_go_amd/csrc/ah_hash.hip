@@ -49,23 +49,19 @@ __device__ __forceinline__ uint64_t hash_int(uint64_t v) {  // hash_funcs.go:60-
 }
 
 // status words in dscalars: [4] distinct count, [5] overflow flag, [6] total ids
+// Inserts rows [lo, hi).  Probe chains longer than kProbeLimit mean the table is far beyond
+// the load it was sized for (at load ≤ ½ the chance of a 256-long linear-probing cluster is
+// ≈ 0.82^256 ≈ 1e-22 per insert) → flag overflow; the host retries with a larger table.
+constexpr int kProbeLimit = 256;
+
 __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
-                                                         int64_t off, int64_t n, int encode_nulls, Slot* __restrict__ table,
+                                                         int64_t off, int64_t lo, int64_t hi, int encode_nulls, Slot* __restrict__ table,
                                                          uint64_t cap, unsigned* __restrict__ row_slot,
                                                          unsigned long long* __restrict__ distinct, unsigned* __restrict__ overflow) {
   const uint64_t mask = cap - 1;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  unsigned fresh = 0;  // keys this lane inserted and has not yet published to `distinct`
-  unsigned it = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride, it++) {
-    // `distinct` is a load-factor guard only (results never depend on it).  A single global
-    // counter costs ~12 ns per same-address atomic, so lanes publish in batches (every 256
-    // passes; hipcc folds the wave's adds into one atomic) and poll every 64 passes.
-    if ((it & 63) == 0) {
-      if (*(volatile unsigned*)overflow) break;
-      if (*(volatile unsigned long long*)distinct > cap / 2) { atomicExch(overflow, 1u); break; }
-    }
-    if ((it & 255) == 255 && fresh) { atomicAdd(distinct, (unsigned long long)fresh); fresh = 0; }
+  unsigned fresh = 0;  // keys this lane inserted (published once, at the end: same-address atomics cost ~12 ns each)
+  for (int64_t i = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < hi; i += stride) {
     uint64_t s;
     if (ah_bit(valid, off + i)) {
       unsigned long long k = keys[i];
@@ -83,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long
           }
           if (cur == k) break;
           idx = (idx + 1) & mask;
-          if (++probes > 1 << 12) { dead = true; break; }  // table (nearly) full
+          if (++probes > kProbeLimit) { dead = true; break; }
         }
         if (dead) { atomicExch(overflow, 1u); break; }
         s = idx;
@@ -280,10 +276,37 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
     AH_HIP(c, hipMemsetAsync(table, 0xFF, table_bytes, c->stream));
     AH_HIP(c, hipMemsetAsync(&c->dscalars[4], 0, 3 * sizeof(uint64_t), c->stream));
     AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+    // Capacity planning without a wasted pass: insert a PREFIX of the rows first and look at
+    // how many distinct keys it produced.  Low-cardinality columns (the common case) just carry
+    // on into the same table; a prefix that already fills a quarter of the table means the
+    // column needs a table sized from the extrapolated distinct count — restart with that.
+    const int64_t prefix = n < ((int64_t)1 << 21) ? n : ((int64_t)1 << 21);
     unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock));
-    insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, n, encode_nulls, table, cap,
-                                                  (unsigned*)out_ids, distinct, overflow);
+    unsigned pgrid = ah_stream_grid(c, ah_ceil_div(prefix, kBlock));
+    insert_kernel<<<pgrid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, 0, prefix, encode_nulls, table, cap,
+                                                   (unsigned*)out_ids, distinct, overflow);
     AH_LAUNCH_CHECK(c);
+    bool restart = false;
+    if (prefix < n && cap < cap_max) {
+      AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[4], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      AH_HIP(c, hipStreamSynchronize(c->stream));
+      uint64_t d0 = *(volatile uint64_t*)&c->pinned[0];
+      bool ovf = *(volatile unsigned*)&c->pinned[1] != 0;
+      if (ovf || d0 > cap / 4) {
+        // extrapolate: a prefix that is mostly distinct says "about one key per row"
+        double est = d0 * 2 > (uint64_t)prefix ? (double)n : (double)d0 * ((double)n / (double)prefix);
+        uint64_t want = next_pow2_u64((uint64_t)(est * 2.5) + 64);
+        if (want < cap * 4) want = cap * 4;
+        cap = want < cap_max ? want : cap_max;
+        restart = true;
+      }
+    }
+    if (restart) continue;
+    if (prefix < n) {
+      insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, prefix, n, encode_nulls, table, cap,
+                                                    (unsigned*)out_ids, distinct, overflow);
+      AH_LAUNCH_CHECK(c);
+    }
     AH_HIP(c, hipMemcpyAsync(c->pinned, overflow, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     AH_HIP(c, hipStreamSynchronize(c->stream));
     if (*(volatile unsigned*)c->pinned) {
