@@ -13,7 +13,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libarrowhip.so")
+LIB_PATH = os.environ.get("ARROWHIP_LIB") or os.path.join(_HERE, "libarrowhip.so")  # env: kernel-variant experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "arrowhip.h")
 
 AH_OK, AH_EINVALID, AH_EINDEX, AH_EOVERFLOW, AH_EHIP, AH_ENOTIMPL = 0, 1, 2, 3, 4, 5

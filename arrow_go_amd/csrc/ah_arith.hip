@@ -236,40 +236,64 @@ int dispatch_unary(ah_ctx* c, int op, const void* in, void* out, int64_t len) {
 
 // ---- checked integer ops ---------------------------------------------------------
 // flag word: bit 0 set ⇔ some tested slot overflowed by the reference's carry test.
+template <typename ST, int OP>
+__device__ __forceinline__ ST checked_one(ST a, ST b, bool valid, bool& ovf) {
+  using U = typename std::make_unsigned<ST>::type;
+  constexpr bool kSigned = (ST)-1 < (ST)0;
+  constexpr int bits = sizeof(ST) * 8;
+  if (OP == OP_MUL) {
+    // mulWithOverflow (base_arithmetic.go:84-106), every slot (ScalarBinary), null payloads included
+    constexpr ST tmin = kSigned ? (ST)((U)1 << (bits - 1)) : (ST)0;
+    constexpr ST tmax = kSigned ? (ST)(~((U)1 << (bits - 1))) : (ST)~(U)0;
+    bool o = false;
+    if (a > 0) { if (b > 0) { if (a > (ST)(tmax / b)) o = true; } else { if (b < (ST)(tmin / a)) o = true; } }
+    else if (b > 0) { if (a < (ST)(tmin / b)) o = true; }
+    else { if (a != 0 && b < (ST)(tmax / a)) o = true; }
+    ovf |= o;
+    return o ? (ST)0 : (ST)((U)a * (U)b);
+  }
+  if (!valid) return (ST)0;  // helpers.go:303-306: null slots hold the zero value
+  U ua = (U)a, ub = (U)b, o, cy;
+  if (OP == OP_ADD) { o = (U)(ua + ub); cy = (U)((ua & ub) | ((ua | ub) & (U)~o)); }
+  else { o = (U)(ua - ub); cy = (U)(((U)~ua & ub) | ((U) ~(ua ^ ub) & o)); }
+  // `carry > 0` after an ARITHMETIC shift by bits-2 for signed T, logical shift by bits-1 for
+  // unsigned T (base_arithmetic.go:250-262): signed ⇒ top carry bit clear ∧ next bit set
+  bool top = (cy >> (bits - 1)) & 1, next = (cy >> (bits - 2)) & 1;
+  ovf |= kSigned ? (!top && next) : top;
+  return (ST)o;
+}
+
+// One 16-byte vector per lane per operand, validity as V bits per lane out of the bitmaps
+// (two aligned 8-byte loads at most), result zeroed under nulls, 16-byte store.
 template <typename ST, int OP /*OP_ADD, OP_SUB, OP_MUL*/, int SHAPE>
 __global__ __launch_bounds__(kBlock) void checked_kernel(const ST* __restrict__ l, const uint8_t* __restrict__ lv, int64_t loff,
                                                           const ST* __restrict__ r, const uint8_t* __restrict__ rv, int64_t roff,
                                                           ST scalar, ST* __restrict__ out, int64_t len, unsigned* __restrict__ flag) {
-  using U = typename std::make_unsigned<ST>::type;
-  constexpr bool kSigned = (ST)-1 < (ST)0;
-  constexpr int bits = sizeof(ST) * 8;
-  constexpr ST tmin = kSigned ? (ST)((U)1 << (bits - 1)) : (ST)0;
-  constexpr ST tmax = kSigned ? (ST)(~((U)1 << (bits - 1))) : (ST)~(U)0;
+  constexpr int V = 16 / sizeof(ST);
+  using VT = ah_vec16<ST>;
   bool ovf = false;
+  const int64_t nvec = len / V;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += stride) {
-    ST a = SHAPE == 2 ? scalar : l[i];
-    ST b = SHAPE == 1 ? scalar : r[i];
-    if (OP == OP_MUL) {
-      // mulWithOverflow (base_arithmetic.go:84-106), every slot (ScalarBinary)
-      bool o = false;
-      if (a > 0) { if (b > 0) { if (a > (ST)(tmax / b)) o = true; } else { if (b < (ST)(tmin / a)) o = true; } }
-      else if (b > 0) { if (a < (ST)(tmin / b)) o = true; }
-      else { if (a != 0 && b < (ST)(tmax / a)) o = true; }
-      ovf |= o;
-      out[i] = o ? (ST)0 : (ST)((U)a * (U)b);
-      continue;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    VT a, b, o;
+    if (SHAPE != 2) a = ((const VT*)l)[i];
+    if (SHAPE != 1) b = ((const VT*)r)[i];
+    unsigned vbits = (1u << V) - 1;
+    if (OP != OP_MUL) {
+      if (SHAPE != 2 && lv) vbits &= (unsigned)ah_load_bits64(lv, loff + i * V, V);
+      if (SHAPE != 1 && rv) vbits &= (unsigned)ah_load_bits64(rv, roff + i * V, V);
     }
-    bool valid = (SHAPE == 2 || ah_bit(lv, loff + i)) && (SHAPE == 1 || ah_bit(rv, roff + i));
-    if (!valid) { out[i] = 0; continue; }  // helpers.go:303-306
-    U ua = (U)a, ub = (U)b, o, cy;
-    if (OP == OP_ADD) { o = (U)(ua + ub); cy = (U)((ua & ub) | ((ua | ub) & (U)~o)); }
-    else { o = (U)(ua - ub); cy = (U)(((U)~ua & ub) | ((U) ~(ua ^ ub) & o)); }
-    // `carry > 0` after an ARITHMETIC shift by bits-2 for signed T, logical shift by
-    // bits-1 for unsigned T (base_arithmetic.go:250-262): signed ⇒ top clear ∧ next set
-    bool top = (cy >> (bits - 1)) & 1, next = (cy >> (bits - 2)) & 1;
-    ovf |= kSigned ? (!top && next) : top;
-    out[i] = (ST)o;
+#pragma unroll
+    for (int e = 0; e < V; e++)
+      o.v[e] = checked_one<ST, OP>(SHAPE == 2 ? scalar : a.v[e], SHAPE == 1 ? scalar : b.v[e], (vbits >> e) & 1, ovf);
+    ((VT*)out)[i] = o;
+  }
+  if (blockIdx.x == 0) {  // < V trailing elements
+    int64_t j = nvec * V + threadIdx.x;
+    if (j < len) {
+      bool valid = (SHAPE == 2 || ah_bit(lv, loff + j)) && (SHAPE == 1 || ah_bit(rv, roff + j));
+      out[j] = checked_one<ST, OP>(SHAPE == 2 ? scalar : l[j], SHAPE == 1 ? scalar : r[j], valid, ovf);
+    }
   }
   if (__any(ovf) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
@@ -280,7 +304,7 @@ int dispatch_checked(ah_ctx* c, int op, int shape, const void* l, const uint8_t*
   ST scalar = 0;
   if (shape == AH_SHAPE_AS) memcpy(&scalar, r, sizeof(ST));
   if (shape == AH_SHAPE_SA) memcpy(&scalar, l, sizeof(ST));
-  unsigned grid = ah_stream_grid(c, ah_ceil_div(len, kBlock));
+  unsigned grid = ah_stream_grid(c, ah_ceil_div(len / (16 / (int64_t)sizeof(ST)) + 1, kBlock), /*default_bpc=*/0);
   const ST* pl = (const ST*)l; const ST* pr = (const ST*)r; ST* po = (ST*)out;
 #define AH_CHK(OPC)                                                                                                       \
   switch (shape) {                                                                                                        \

@@ -33,7 +33,11 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kTileBytes = 16384;  // values staged per workgroup
+#ifndef AH_FILTER_TILE_BYTES
+#define AH_FILTER_TILE_BYTES 16384
+#endif
+constexpr int kTileBytesMax = AH_FILTER_TILE_BYTES;  // values staged per workgroup (W = 1 is capped at 16 KiB: one lane per mask word)
+template <int W> constexpr int TileBytes() { return (W == 1 && kTileBytesMax > 16384) ? 16384 : kTileBytesMax; }
 
 template <int W> struct UIntOf;
 template <> struct UIntOf<1> { using type = uint8_t; };
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const void* __restrict_
                                                           unsigned long long* __restrict__ valid_total) {
   using T = typename UIntOf<W>::type;
   constexpr int V = 16 / W;               // elements per 16-byte vector
-  constexpr int TILE = kTileBytes / W;    // rows per tile
+  constexpr int TILE = TileBytes<W>() / W;    // rows per tile
   constexpr int WPT = TILE / 64;          // mask words per tile
   constexpr int VPT = TILE / V;           // vectors per tile (= 1024)
   constexpr int K = VPT / kBlock;         // vectors per lane (= 4)
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const void* __restrict_
 template <int W>
 int run_counts(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
                int** tile_local_out, int64_t** super_off_out, int64_t** total_out, int64_t* ntiles_out) {
-  constexpr int TILE = kTileBytes / W;
+  constexpr int TILE = TileBytes<W>() / W;
   constexpr int WPT = TILE / 64;
   int64_t ntiles = ah_ceil_div(n, TILE);
   int64_t nsuper = ah_ceil_div(ntiles, kSuper);

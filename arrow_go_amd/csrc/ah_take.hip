@@ -23,7 +23,10 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kUnroll = 4;
+#ifndef AH_TAKE_UNROLL
+#define AH_TAKE_UNROLL 4
+#endif
+constexpr int kUnroll = AH_TAKE_UNROLL;
 
 template <int W> struct UIntOf;
 template <> struct UIntOf<1> { using type = uint8_t; };
