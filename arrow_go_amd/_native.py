@@ -27,6 +27,12 @@ SHAPE_AA, SHAPE_AS, SHAPE_SA = 0, 1, 2
 BIT_AND, BIT_OR, BIT_XOR, BIT_AND_NOT, BIT_XNOR = 0, 1, 2, 3, 4
 KLEENE_AND, KLEENE_OR, KLEENE_AND_NOT = 0, 1, 2
 DROP_NULLS, EMIT_NULLS = 0, 1
+BOOL = 1
+X_FIELD, X_LITERAL = 1, 2
+X_ADD, X_SUB, X_MUL, X_ADD_CHECKED, X_SUB_CHECKED, X_MUL_CHECKED = 10, 11, 12, 13, 14, 15
+X_NEGATE, X_ABS, X_SIGN = 20, 21, 22
+X_EQ, X_NE, X_GT, X_GE, X_LT, X_LE = 30, 31, 32, 33, 34, 35
+X_AND, X_OR, X_XOR, X_AND_NOT, X_INVERT = 40, 41, 42, 43, 44
 
 
 class ArrowHipError(Exception):
@@ -128,6 +134,11 @@ _SIGS = {
     "ah_cmp_filter_sum_i64_dev": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _vp],
     "ah_cmp_filter_sum_f64_dev": [_vp, _int, _vp, _vp, _i64, _i64, C.c_double, _vp, _vp],
 }
+_SIGS.update({
+    "ah_expr_compile": [_vp, _vp, _int, _vp, _int, _vp, _int, _pvp, _pint],
+    "ah_expr_execute": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "ah_expr_codegen": [_vp, _int, _vp, _int, _vp, _int, _int, C.c_char_p, _sz, C.c_char_p, _sz, _pint],
+})
 for _name, _args in _SIGS.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
@@ -136,6 +147,8 @@ lib.ah_ctx_destroy.argtypes = [_vp]
 lib.ah_ctx_destroy.restype = None
 lib.ah_last_error.argtypes = [_vp]
 lib.ah_last_error.restype = C.c_char_p
+lib.ah_expr_source.argtypes = [_vp]
+lib.ah_expr_source.restype = C.c_char_p
 lib.ah_version.argtypes = []
 lib.ah_version.restype = C.c_char_p
 

@@ -43,6 +43,7 @@ lib.ahc_math_sum.argtypes = [_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int6
 lib.ahc_has_function.argtypes = [C.c_char_p]
 lib.ahc_function_num_kernels.argtypes = [C.c_char_p]
 lib.ahc_registry_add_alias.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_int]
+lib.ahc_expr_eval.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]
 
 
 class ArrowError(Exception):
@@ -180,6 +181,28 @@ class Session:
                 lib.ahc_datum_release(out)
         finally:
             for d in datums:
+                lib.ahc_datum_release(d)
+
+    # -- compute.Expression / exprs.ExecuteScalarExpression
+    def eval_expression(self, text: str, columns, literals=(), fuse: bool = True, raw: bool = False):
+        """Evaluate an expression tree over a batch.  `text` is prefix notation with `$i` for
+        column i and `#k` for literal k, e.g. "greater(multiply_unchecked(add($0,$1),$2),#0)".
+        fuse=True → one JIT-compiled kernel when the tree is fusible; fuse=False → one kernel per
+        call node (the reference's executeScalarBatch).  Returns (result, fused)."""
+        cols = [self._to_datum(c) for c in columns]
+        lits = [self._to_datum(l) for l in literals]
+        try:
+            ca = (_vp * max(len(cols), 1))(*cols)
+            la = (_vp * max(len(lits), 1))(*lits)
+            out = _vp()
+            fused = C.c_int()
+            self._check(lib.ahc_expr_eval(self.h, text.encode(), len(cols), ca, len(lits), la, int(fuse), C.byref(out), C.byref(fused)))
+            try:
+                return self._export(out), bool(fused.value)
+            finally:
+                lib.ahc_datum_release(out)
+        finally:
+            for d in cols + lits:
                 lib.ahc_datum_release(d)
 
     # -- arrow/math

@@ -33,6 +33,7 @@ struct ah_ctx {
   // tunables (env ARROWHIP_NT / ARROWHIP_BLOCKS_PER_CU, read at ctx creation)
   int tune_nt;             // 1: nontemporal loads/stores on streaming kernels
   int tune_blocks_per_cu;  // grid cap for grid-stride streaming kernels
+  void* expr_cache;        // compiled expression programs (ah_expr.hip)
   char err[512];
 };
 
@@ -76,6 +77,7 @@ static inline int ah_fail(ah_ctx* ctx, int code, const char* fmt, ...) {
 
 #define AH_LAUNCH_CHECK(ctx) AH_HIP((ctx), hipGetLastError())
 
+void ah_expr_cache_free(ah_ctx* ctx);  // ah_expr.hip
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // internal (ah_bitmap.hip): popcount of bits [off, off+nbits) into *total_dev (8 bytes,

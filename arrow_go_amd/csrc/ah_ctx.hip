@@ -67,6 +67,7 @@ AH_EXPORT void ah_ctx_destroy(ah_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->copy_stream);
+  ah_expr_cache_free(c);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->dscalars) (void)hipFree(c->dscalars);

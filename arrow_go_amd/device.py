@@ -255,6 +255,32 @@ class Context:
                               _ptr(out_sums), _ptr(out_counts), _ptr(out_first_rows), C.byref(ng), C.byref(nid)))
         return ng.value, nid.value
 
+    # ---- fused expressions --------------------------------------------------------------
+    def expr_compile(self, nodes, col_types, lit_types):
+        """nodes: [(opcode, arg), …] postfix.  Returns (handle, out_type)."""
+        na = _nodes_array(nodes)
+        ct = (C.c_int * max(len(col_types), 1))(*col_types)
+        lt = (C.c_int * max(len(lit_types), 1))(*lit_types)
+        h = C.c_void_p()
+        ot = C.c_int()
+        check(self.handle, lib.ah_expr_compile(self.handle, na, len(nodes), ct, len(col_types), lt, len(lit_types), C.byref(h), C.byref(ot)))
+        return h, ot.value
+
+    def expr_execute(self, handle, col_values, col_valid, col_offsets, lit_values, lit_valid, n: int, out_values, out_valid) -> None:
+        nc = max(len(col_values), 1)
+        cv = (C.c_void_p * nc)(*[_ptr(x) for x in col_values])
+        cvd = (C.c_void_p * nc)(*[_ptr(x) for x in col_valid])
+        co = (C.c_int64 * nc)(*col_offsets)
+        nl = max(len(lit_values), 1)
+        lv = (C.c_uint8 * (8 * nl))()
+        for i, raw in enumerate(lit_values):  # raw: bytes (≤ 8) little-endian payload
+            C.memmove(C.addressof(lv) + 8 * i, raw, len(raw))
+        lvd = (C.c_int * nl)(*[int(x) for x in lit_valid]) if lit_valid else (C.c_int * nl)()
+        check(self.handle, lib.ah_expr_execute(self.handle, handle, cv, cvd, co, lv, lvd, n, _ptr(out_values), _ptr(out_valid)))
+
+    def expr_source(self, handle) -> str:
+        return lib.ah_expr_source(handle).decode()
+
     # ---- fused --------------------------------------------------------------------------
     def cmp_filter_sum_i64(self, cmpop: int, x, valid, off: int, n: int, threshold: int):
         s = C.c_int64()
@@ -275,6 +301,29 @@ class Context:
     def cmp_filter_sum_f64_dev(self, cmpop: int, x, valid, off: int, n: int, threshold: float, out_sum_dev, out_count_dev) -> None:
         check(self.handle, lib.ah_cmp_filter_sum_f64_dev(self.handle, cmpop, _ptr(x), _ptr(valid), off, n, threshold,
                                                          _ptr(out_sum_dev), _ptr(out_count_dev)))
+
+
+def _nodes_array(nodes):
+    arr = (C.c_int32 * (2 * len(nodes)))()
+    for i, (op, arg) in enumerate(nodes):
+        arr[2 * i], arr[2 * i + 1] = op, arg
+    return arr
+
+
+def expr_codegen(nodes, col_types, lit_types, compile_it: bool = True):
+    """Stateless: generate (and hiprtc-compile for gfx950) the fused kernel of a postfix
+    program; works without a GPU.  Returns (source, out_type); raises on error."""
+    na = _nodes_array(nodes)
+    ct = (C.c_int * max(len(col_types), 1))(*col_types)
+    lt = (C.c_int * max(len(lit_types), 1))(*lit_types)
+    src = C.create_string_buffer(1 << 16)
+    err = C.create_string_buffer(1024)
+    ot = C.c_int()
+    st = lib.ah_expr_codegen(na, len(nodes), ct, len(col_types), lt, len(lit_types), int(compile_it), src, len(src), err, len(err),
+                             C.byref(ot))
+    if st != N.AH_OK:
+        raise N._ERRS.get(st, N.ArrowHipError)(err.value.decode())
+    return src.value.decode(), ot.value
 
 
 def device_count() -> int:

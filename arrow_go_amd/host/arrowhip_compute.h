@@ -307,6 +307,39 @@ void RegisterVectorSelection(FunctionRegistry* reg);
 void RegisterVectorHash(FunctionRegistry* reg);
 void RegisterFusedExtensions(FunctionRegistry* reg);
 
+// ---- compute.Expression (arrow/compute/expression.go:59-78,596-620) and its executor
+// (arrow/compute/exprs/exec.go:440-700 ExecuteScalarExpression / executeScalarBatch) --------
+struct Expression;
+using ExprPtr = std::shared_ptr<Expression>;
+struct Expression {
+  enum Kind { LITERAL, FIELD_REF, CALL } kind = LITERAL;
+  Datum literal;                 // LITERAL: a scalar datum
+  int field_index = -1;          // FIELD_REF: position in the input batch …
+  std::string field_name;        // … or its name (resolved against the batch's names)
+  std::string function;          // CALL
+  std::vector<ExprPtr> args;
+  std::shared_ptr<FunctionOptions> options;
+  std::string ToString() const;  // Call.String(): "add(a, multiply(b, 2))"
+};
+ExprPtr NewLiteral(ScalarPtr s);
+ExprPtr NewFieldRef(const std::string& name);   // expression.go:610
+ExprPtr NewRef(int index);                      // expression.go:605 (FieldRef by position)
+ExprPtr NewCall(const std::string& name, std::vector<ExprPtr> args, std::shared_ptr<FunctionOptions> opts = nullptr);  // :617
+
+// the input record batch: named, equal-length device arrays (compute.ExecBatch)
+struct ExecBatch {
+  std::vector<std::string> names;
+  std::vector<Datum> values;
+  int64_t len = 0;
+};
+// Evaluates `expr` over `batch`.  fuse = true: if the whole tree is made of fusible scalar
+// calls (arithmetic, comparisons, plain boolean ops) over same-typed operands, it runs as ONE
+// JIT-compiled kernel (ah_expr_*); otherwise — and always with fuse = false — it is evaluated
+// exactly like executeScalarBatch: one CallFunction per call node, intermediates materialised.
+// Both routes give bit-identical results.  *fused_out (nullable) reports which one ran.
+Status ExecuteScalarExpression(ExecCtx* ctx, const ExprPtr& expr, const ExecBatch& batch, Datum* out, bool fuse = true,
+                               bool* fused_out = nullptr);
+
 }  // namespace compute
 
 // ---- arrow/math (float64.go:25-39, int64.go, uint64.go) ---------------------------------

@@ -286,3 +286,67 @@ AHC_EXPORT int ahc_export(ahc_session* s, ahc_datum* d, ArrowArray* arr, ArrowSc
   Status st = ExportOne(ss, a, a.type, arr, schema);
   return st.ok() ? 0 : Fail(s, st);
 }
+
+// ---- expressions ----------------------------------------------------------------------------------
+// text form used by the tests:  call := name '(' arg {',' arg} ')' ;  arg := call | '$'N (column N) | '#'N (literal N)
+namespace {
+struct ExprParser {
+  const char* p;
+  std::vector<Datum>* lits;
+  std::string err;
+  void ws() { while (*p == ' ') p++; }
+  compute::ExprPtr parse() {
+    ws();
+    if (*p == '$' || *p == '#') {
+      char k = *p++;
+      int n = 0, digits = 0;
+      while (*p >= '0' && *p <= '9') { n = n * 10 + (*p++ - '0'); digits++; }
+      if (!digits) { err = "expected an index"; return nullptr; }
+      if (k == '$') return compute::NewRef(n);
+      if (n >= (int)lits->size() || (*lits)[n].kind != DatumKind::Scalar) { err = "bad literal index"; return nullptr; }
+      return compute::NewLiteral((*lits)[n].scalar);
+    }
+    std::string name;
+    while ((*p >= 'a' && *p <= 'z') || *p == '_' || (*p >= '0' && *p <= '9')) name += *p++;
+    ws();
+    if (name.empty() || *p != '(') { err = "expected name("; return nullptr; }
+    p++;
+    std::vector<compute::ExprPtr> args;
+    for (;;) {
+      auto a = parse();
+      if (!a) return nullptr;
+      args.push_back(a);
+      ws();
+      if (*p == ',') { p++; continue; }
+      if (*p == ')') { p++; break; }
+      err = "expected , or )";
+      return nullptr;
+    }
+    return compute::NewCall(name, args);
+  }
+};
+}  // namespace
+
+// ExecuteScalarExpression over a batch of columns; fuse = 1 → single JIT kernel when possible
+AHC_EXPORT int ahc_expr_eval(ahc_session* s, const char* text, int ncols, ahc_datum** cols, int nlits, ahc_datum** lits, int fuse,
+                             ahc_datum** out, int* fused_out) {
+  *out = nullptr;
+  std::vector<Datum> lit_datums;
+  for (int i = 0; i < nlits; i++) lit_datums.push_back(lits[i]->d);
+  ExprParser parser{text, &lit_datums, ""};
+  compute::ExprPtr e = parser.parse();
+  if (!e) return Fail(s, Status::Make(StatusCode::Invalid, "expression syntax: " + parser.err));
+  compute::ExecBatch batch;
+  for (int i = 0; i < ncols; i++) {
+    batch.names.push_back("c" + std::to_string(i));
+    batch.values.push_back(cols[i]->d);
+    if (cols[i]->d.kind == DatumKind::Array) batch.len = cols[i]->d.array->length;
+  }
+  Datum res;
+  bool fused = false;
+  Status st = compute::ExecuteScalarExpression(&s->ectx, e, batch, &res, fuse != 0, &fused);
+  if (!st.ok()) return Fail(s, st);
+  if (fused_out) *fused_out = fused;
+  *out = new ahc_datum{res};
+  return 0;
+}

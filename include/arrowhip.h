@@ -269,6 +269,58 @@ int ah_cmp_filter_sum_i64_dev(ah_ctx* ctx, int cmpop, const int64_t* x, const ui
 int ah_cmp_filter_sum_f64_dev(ah_ctx* ctx, int cmpop, const double* x, const uint8_t* valid, int64_t off,
                               int64_t n, double threshold, double* out_sum_dev, int64_t* out_count_dev);
 
+/* ---- fused scalar-expression evaluation (row §8(f)-1: the expression executor) ---------
+ * What compute.Expression trees — NewCall / NewFieldRef / NewLiteral, arrow/compute/
+ * expression.go:596-620 — evaluate to through executeScalarBatch (arrow/compute/exprs/
+ * exec.go:542-700: one scalar kernel per call node, every intermediate materialised),
+ * computed in ONE kernel generated for the tree and JIT-compiled with hiprtc.  The tree is a
+ * postfix program; results are bit-identical to executing the calls one by one through the
+ * entry points above (same wraparound / IEEE / checked-overflow / null-intersection rules;
+ * no implicit casts: operand types of a call must match → AH_ENOTIMPL). */
+typedef struct { int32_t op; int32_t arg; } ah_expr_node;
+typedef struct ah_expr ah_expr;
+#define AH_X_FIELD 1        /* push input column `arg` */
+#define AH_X_LITERAL 2      /* push literal `arg` (value given at execute time) */
+#define AH_X_ADD 10         /* add_unchecked / subtract_unchecked / multiply_unchecked */
+#define AH_X_SUB 11
+#define AH_X_MUL 12
+#define AH_X_ADD_CHECKED 13 /* add / subtract / multiply (checked on integers) */
+#define AH_X_SUB_CHECKED 14
+#define AH_X_MUL_CHECKED 15
+#define AH_X_NEGATE 20      /* negate_unchecked, abs_unchecked, sign */
+#define AH_X_ABS 21
+#define AH_X_SIGN 22
+#define AH_X_EQ 30          /* equal, not_equal, greater, greater_equal, less, less_equal */
+#define AH_X_NE 31
+#define AH_X_GT 32
+#define AH_X_GE 33
+#define AH_X_LT 34
+#define AH_X_LE 35
+#define AH_X_AND 40         /* and, or, xor, and_not, invert (plain, non-Kleene) */
+#define AH_X_OR 41
+#define AH_X_XOR 42
+#define AH_X_AND_NOT 43
+#define AH_X_INVERT 44
+/* column / literal types are arrow.Type ids (1 = BOOL: bitmap column).  Compiled programs are
+ * cached per context by (program, types); the returned handle is owned by the context. */
+int ah_expr_compile(ah_ctx* ctx, const ah_expr_node* nodes, int n_nodes, const int* col_types, int n_cols,
+                    const int* lit_types, int n_lits, ah_expr** out, int* out_type_host);
+/* col_values[i]: element 0 of column i (offset applied) — for BOOL columns the bitmap base;
+ * col_valid[i] (nullable) and BOOL data are addressed with bit offset col_offsets[i].
+ * lit_values_host: n_lits × 8 bytes (little-endian payload), lit_valid_host: n_lits flags.
+ * out_values: len elements (BOOL: ceil(len/8) bytes, 8-byte aligned); out_valid (nullable:
+ * pass NULL when no input can be null) receives the AND of all referenced validities.
+ * Returns AH_EOVERFLOW ("overflow") like ah_arithmetic_checked when a checked node overflows
+ * in a valid slot (synchronises only if the program has checked integer nodes). */
+int ah_expr_execute(ah_ctx* ctx, ah_expr* expr, const void* const* col_values, const uint8_t* const* col_valid,
+                    const int64_t* col_offsets, const void* lit_values_host, const int* lit_valid_host, int64_t len,
+                    void* out_values, uint8_t* out_valid);
+const char* ah_expr_source(ah_expr* expr); /* generated HIP source, for inspection */
+/* stateless: generate (and optionally hiprtc-compile for gfx950) without a GPU or a context;
+ * src_buf/err_buf may be NULL.  Used by the CPU test-suite. */
+int ah_expr_codegen(const ah_expr_node* nodes, int n_nodes, const int* col_types, int n_cols, const int* lit_types, int n_lits,
+                    int do_compile, char* src_buf, size_t src_cap, char* err_buf, size_t err_cap, int* out_type_host);
+
 #ifdef __cplusplus
 }
 #endif
