@@ -97,7 +97,10 @@ __device__ __forceinline__ u64 load_bits64(const unsigned char* bm, long long po
   unsigned long long addr = (unsigned long long)bm + (unsigned long long)(pos >> 3);
   unsigned long long base = addr & ~7ull;
   int shift = (int)((addr - base) * 8 + (pos & 7));
-  const u64* w = (const u64*)base;
+  // constant address space + wave-uniform address → scalar loads (s_load_dwordx2): the bitmap
+  // words cost nothing on the vector memory pipe.  Inputs are never written by this kernel.
+  typedef const __attribute__((address_space(4))) u64 cu64;
+  const cu64* w = (const cu64*)base;
   u64 lo = w[0] >> shift;
   if (shift != 0 && shift + cnt > 64) lo |= w[1] << (64 - shift);
   return lo & mask;
@@ -226,7 +229,9 @@ int Generate(ah_ctx* c, const ah_expr_node* nodes, int n_nodes, const int* col_t
          "  const int lane = threadIdx.x & 63;\n"
          "  const long long nchunks = (p.n + 63) >> 6;\n"
          "  const long long nwaves = (long long)gridDim.x * 4;\n"
-         "  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);\n"
+         "  // wave-uniform on purpose (readfirstlane): row0 / cnt / bitmap addresses then live in SGPRs and\n"
+         "  // the validity words are fetched once per wave instead of once per lane\n"
+         "  const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
          "  bool ovf = false;\n";
   for (int l = 0; l < n_lits; l++) {
     std::string li = std::to_string(l);
