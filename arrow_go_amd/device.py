@@ -238,6 +238,21 @@ class Context:
                                                  int(bounds_check), _ptr(out_values), _ptr(out_valid), C.byref(r), C.byref(bad)))
         return r.value
 
+    # ---- cumulative_sum -----------------------------------------------------------------
+    def cumulative_sum(self, type_id: int, values, valid, off: int, n: int, start: Optional[bytes], skip_nulls: bool, checked: bool,
+                       out_values, out_valid) -> int:
+        """start: little-endian payload of one element of the type, or None (= 0).  Returns the output null count."""
+        nulls = C.c_int64()
+        sbuf = None
+        if start is not None:
+            sbuf = (C.c_uint8 * 8)()
+            C.memmove(sbuf, start, len(start))
+        check(self.handle, lib.ah_cumulative_sum(self.handle, type_id, _ptr(values), _ptr(valid), off, n,
+                                                 C.addressof(sbuf) if sbuf is not None else None, int(skip_nulls), int(checked),
+                                                 _ptr(out_values), _ptr(out_valid),
+                                                 C.byref(nulls) if out_valid is not None else None))  # no validity → no sync
+        return nulls.value
+
     # ---- hashing ------------------------------------------------------------------------
     def hash_u64_encode(self, keys, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_dict):
         nd = C.c_int64()

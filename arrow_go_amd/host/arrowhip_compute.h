@@ -197,6 +197,8 @@ struct FilterOptions : FunctionOptions { NullSelectionBehavior NullSelection = D
 struct TakeOptions : FunctionOptions { bool BoundsCheck = true; const char* TypeName() const override { return "TakeOptions"; } };
 enum NullEncodingBehavior { NullEncodingMask = 0, NullEncodingEncode = 1 };
 struct DictionaryEncodeOptions : FunctionOptions { NullEncodingBehavior NullEncoding = NullEncodingMask; const char* TypeName() const override { return "DictionaryEncodeOptions"; } };
+// kernels.CumulativeOptions (vector_cumulative.go:30-39): nil Start = zero of the input type
+struct CumulativeOptions : FunctionOptions { ScalarPtr Start; bool SkipNulls = false; const char* TypeName() const override { return "CumulativeOptions"; } };
 struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
 
 // compute.Datum (datum.go:35-40): array or scalar
@@ -303,6 +305,7 @@ Status CallFunction(ExecCtx* ctx, const std::string& name, const FunctionOptions
 void RegisterScalarArithmetic(FunctionRegistry* reg);
 void RegisterScalarComparisons(FunctionRegistry* reg);
 void RegisterScalarBoolean(FunctionRegistry* reg);
+void RegisterVectorCumulative(FunctionRegistry* reg);
 void RegisterVectorSelection(FunctionRegistry* reg);
 void RegisterVectorHash(FunctionRegistry* reg);
 void RegisterFusedExtensions(FunctionRegistry* reg);

@@ -149,12 +149,42 @@ AHC_EXPORT int ahc_datum_info(ahc_datum* d, int* kind, int* type_id, int64_t* le
 
 // options: "key=value;key=value"; keys follow the Go struct tags
 //   null_selection_behavior=drop|emit_null   bounds_check=0|1   null_encoding_behavior=mask|encode
+//   skip_nulls=0|1   start=<type>:<value>|null:<type>   (e.g. start=int64:10, start=double:1.5, start=null:int32)
 struct ParsedOptions {
   compute::FilterOptions filter;
   compute::TakeOptions take;
   compute::DictionaryEncodeOptions dict;
+  compute::CumulativeOptions cumulative;
   const compute::FunctionOptions* pick = nullptr;
 };
+static const struct { const char* name; Type id; } kTypeNames[] = {
+    {"uint8", Type::UINT8}, {"int8", Type::INT8}, {"uint16", Type::UINT16}, {"int16", Type::INT16}, {"uint32", Type::UINT32},
+    {"int32", Type::INT32}, {"uint64", Type::UINT64}, {"int64", Type::INT64}, {"float", Type::FLOAT32}, {"double", Type::FLOAT64}};
+// "<type>:<value>" or "null:<type>" → Scalar (scalar.ParseScalar for the numeric types)
+static ScalarPtr ParseScalarText(const std::string& v) {
+  size_t c = v.find(':');
+  if (c == std::string::npos) return nullptr;
+  std::string a = v.substr(0, c), b = v.substr(c + 1);
+  bool is_null = a == "null";
+  const std::string& tname = is_null ? b : a;
+  auto sc = std::make_shared<Scalar>();
+  for (auto& tn : kTypeNames)
+    if (tname == tn.name) sc->type = GetDataType(tn.id);
+  if (!sc->type) return nullptr;
+  sc->valid = !is_null;
+  if (is_null) return sc;
+  if (IsFloating(sc->type->id)) {
+    double d = strtod(b.c_str(), nullptr);
+    if (sc->type->id == Type::FLOAT32) { float f = (float)d; memcpy(sc->value, &f, 4); } else memcpy(sc->value, &d, 8);
+  } else if (IsSignedInteger(sc->type->id)) {
+    long long x = strtoll(b.c_str(), nullptr, 10);
+    memcpy(sc->value, &x, sc->type->bit_width / 8);
+  } else {
+    unsigned long long x = strtoull(b.c_str(), nullptr, 10);
+    memcpy(sc->value, &x, sc->type->bit_width / 8);
+  }
+  return sc;
+}
 static void ParseOptions(const char* text, ParsedOptions* p) {
   std::string t = text ? text : "";
   size_t pos = 0;
@@ -167,6 +197,8 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
       std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
       if (k == "null_selection_behavior") { p->filter.NullSelection = v == "emit_null" ? compute::EmitNulls : compute::DropNulls; p->pick = &p->filter; }
       if (k == "bounds_check") { p->take.BoundsCheck = v != "0"; p->pick = &p->take; }
+      if (k == "skip_nulls") { p->cumulative.SkipNulls = v != "0"; p->pick = &p->cumulative; }
+      if (k == "start") { p->cumulative.Start = ParseScalarText(v); p->pick = &p->cumulative; }
       if (k == "null_encoding_behavior") { p->dict.NullEncoding = v == "encode" ? compute::NullEncodingEncode : compute::NullEncodingMask; p->pick = &p->dict; }
     }
     pos = end + 1;

@@ -365,10 +365,19 @@ Status VectorFunction::Execute(ExecCtx* ctx, const FunctionOptions* opts, const 
   // vectorExecutor.Execute (executor.go:896-960): one span (the whole array); nothing
   // preallocated (VectorKernel defaults NullComputedNoPrealloc + MemNoPrealloc)
   exec::ExecSpan span;
+  bool all_scalar = !args.empty();
+  for (auto& a : args) all_scalar = all_scalar && a.kind == DatumKind::Scalar;
+  std::vector<ArrayDataPtr> promoted;  // checkIfAllScalar → PromoteExecSpanScalars (executor.go:951-954)
   for (auto& a : args) {
-    if (a.kind != DatumKind::Array)
+    if (a.kind != DatumKind::Array && !all_scalar)
       return Status::Make(StatusCode::NotImplemented, "vector function '" + name_ + "' needs array arguments");
     exec::ExecValue v;
+    if (all_scalar) {
+      ArrayDataPtr arr;
+      AHC_RETURN_NOT_OK(ScalarToArray(s, *a.scalar, &arr));
+      promoted.push_back(arr);
+      v.array.SetMembers(*arr);
+    } else
     v.array.SetMembers(*a.array);
     span.values.push_back(std::move(v));
   }
@@ -436,6 +445,7 @@ FunctionRegistry* GetFunctionRegistry() {
     RegisterScalarBoolean(r);
     RegisterVectorSelection(r);
     RegisterVectorHash(r);
+    RegisterVectorCumulative(r);
     RegisterFusedExtensions(r);
     return r;
   }();

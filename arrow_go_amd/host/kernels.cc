@@ -6,6 +6,7 @@
 //   scalar_boolean.go:67-347, vector_selection.go:449-520,1162-1192,
 //   vector_hash.go:620-741} and arrow/compute/{arithmetic.go, scalar_compare.go,
 //   scalar_bool.go:94-110, selection.go:42-114,618-650, vector_hash.go:61-100}.
+#include <cmath>
 #include "arrowhip_compute.h"
 
 #include <cstring>
@@ -391,6 +392,120 @@ void RegisterVectorHash(FunctionRegistry* reg) {
   }
   reg->AddFunction(uq, false);
   reg->AddFunction(de, false);
+}
+
+// ---- cumulative_sum / cumulative_sum_checked ---------------------------------------------------
+// Safe numeric cast of the Start scalar to the input type — what safeCastScalar → CastDatum(SafeCastOptions)
+// decides (compute/vector_cumulative.go:53-70, kernels/vector_cumulative.go:71-90): integer targets
+// need an in-range, integral value; an integer start for a float target must be exactly representable;
+// float → float is always allowed.  Failure is arrow.ErrInvalid.
+static Status SafeCastStart(const Scalar& start, const DataType* to, uint8_t out[8]) {
+  auto fail = [&](const char* why) {
+    return Status::Make(StatusCode::Invalid, std::string("cannot cast cumulative sum start value to ") + to->name + ": " + why);
+  };
+  memset(out, 0, 8);
+  Type from = start.type->id;
+  if (from == to->id) { memcpy(out, start.value, 8); return Status::OK(); }
+  if (!IsInteger(from) && !IsFloating(from)) return fail("start value is not numeric");
+  // widen the source to (sign, magnitude) or a double
+  bool src_float = IsFloating(from);
+  double f = 0; bool neg = false; uint64_t mag = 0;
+  if (src_float) {
+    if (from == Type::FLOAT32) { float t; memcpy(&t, start.value, 4); f = t; } else memcpy(&f, start.value, 8);
+  } else if (IsSignedInteger(from)) {
+    int64_t v = 0;
+    switch (start.type->bit_width) {
+      case 8: { int8_t t; memcpy(&t, start.value, 1); v = t; break; }
+      case 16: { int16_t t; memcpy(&t, start.value, 2); v = t; break; }
+      case 32: { int32_t t; memcpy(&t, start.value, 4); v = t; break; }
+      default: memcpy(&v, start.value, 8);
+    }
+    neg = v < 0;
+    mag = neg ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+  } else {
+    memcpy(&mag, start.value, start.type->bit_width / 8);
+  }
+  if (IsFloating(to->id)) {
+    if (src_float) {  // float64 → float32: plain conversion
+      float t = (float)f; memcpy(out, &t, 4);
+      return Status::OK();
+    }
+    const uint64_t lim = to->id == Type::FLOAT32 ? (1ull << 24) : (1ull << 53);  // exactly representable integers
+    if (mag > lim) return fail("integer value not exactly representable in the float type");
+    double d = neg ? -(double)mag : (double)mag;
+    if (to->id == Type::FLOAT32) { float t = (float)d; memcpy(out, &t, 4); } else memcpy(out, &d, 8);
+    return Status::OK();
+  }
+  // integer target
+  if (src_float) {
+    if (!(f == f) || f != std::trunc(f)) return fail("float value would be truncated");
+    if (std::fabs(f) >= 18446744073709551616.0) return fail("value out of range");
+    neg = f < 0;
+    mag = (uint64_t)std::fabs(f);
+  }
+  int bits = to->bit_width;
+  if (IsSignedInteger(to->id)) {
+    uint64_t maxpos = (1ull << (bits - 1)) - 1;
+    if (neg ? mag > maxpos + 1 : mag > maxpos) return fail("value out of range");
+    int64_t v = neg ? (int64_t)((uint64_t)0 - mag) : (int64_t)mag;
+    memcpy(out, &v, bits / 8);
+  } else {
+    if (neg && mag != 0) return fail("value out of range");
+    if (bits < 64 && mag >> bits) return fail("value out of range");
+    memcpy(out, &mag, bits / 8);
+  }
+  return Status::OK();
+}
+
+// cumulativeSumExec → cumulativeSumSpans (kernels/vector_cumulative.go:320-360)
+static Status ExecCumulativeSum(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool checked) {
+  Session* s = k->session;
+  ArraySpan in = b.values[0].array;
+  const CumulativeOptions* opts = static_cast<const CumulativeOptions*>(k->state);
+  // initCumulativeSum :118-146 → cumulativeStartValue :92-116
+  uint8_t start[8] = {0};
+  bool have_start = false;
+  if (opts && opts->Start) {
+    if (!opts->Start->valid) return Status::Make(StatusCode::Invalid, "cumulative sum start value must be valid");
+    AHC_RETURN_NOT_OK(SafeCastStart(*opts->Start, in.type, start));
+    have_start = true;
+  }
+  out->len = in.len;
+  if (in.len == 0) return Status::OK();
+  AHC_RETURN_NOT_OK(in.UpdateNullCount(s));
+  bool needs_validity = in.MayHaveNulls();  // :354
+  int w = in.type->bit_width / 8;
+  BufferPtr vb, db;
+  AHC_RETURN_NOT_OK(k->Allocate(in.len * w, &db));  // prepareCumulativeOutput :211-226
+  out->buffers[1].WrapBuffer(db);
+  if (needs_validity) {
+    AHC_RETURN_NOT_OK(k->AllocateBitmap(in.len, &vb));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), vb->dptr, 0xFF, (size_t)((in.len + 7) / 8))));  // memory.Set(validity, 0xFF)
+    out->buffers[0].WrapBuffer(vb);
+  }
+  int64_t nulls = 0;
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_cumulative_sum(s->ctx(), (int)in.type->id, Values(in), needs_validity ? in.buffers[0].buf : nullptr, in.offset,
+                                                    in.len, have_start ? start : nullptr, opts && opts->SkipNulls, checked ? 1 : 0, db->dptr,
+                                                    needs_validity ? (uint8_t*)vb->dptr : nullptr, needs_validity ? &nulls : nullptr)));
+  out->nulls = nulls;
+  return Status::OK();
+}
+
+static const CumulativeOptions kDefaultCumulativeOptions;
+
+// RegisterVectorCumulative (compute/vector_cumulative.go:72-94)
+void RegisterVectorCumulative(FunctionRegistry* reg) {
+  for (bool checked : {false, true}) {
+    auto fn = std::make_shared<VectorFunction>(checked ? "cumulative_sum_checked" : "cumulative_sum", Arity{1, false}, &kDefaultCumulativeOptions);
+    for (Type t : kNumericTypes) {
+      exec::VectorKernel k;
+      k.sig.in_types = {t};
+      k.can_execute_chunkwise = false;  // newCumulativeSumKernel :383-384
+      k.exec_fn = [checked](KernelCtx* kc, const ExecSpan& b, ExecResult* o) { return ExecCumulativeSum(kc, b, o, checked); };
+      fn->AddKernel(std::move(k));
+    }
+    reg->AddFunction(fn, false);
+  }
 }
 
 // ---- fused extension (no reference analogue) --------------------------------

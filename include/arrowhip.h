@@ -269,6 +269,19 @@ int ah_cmp_filter_sum_i64_dev(ah_ctx* ctx, int cmpop, const int64_t* x, const ui
 int ah_cmp_filter_sum_f64_dev(ah_ctx* ctx, int cmpop, const double* x, const uint8_t* valid, int64_t off,
                               int64_t n, double threshold, double* out_sum_dev, int64_t* out_count_dev);
 
+/* ---- cumulative_sum (row §8(f)-2) -----------------------------------------------------------
+ * replaces cumulativeSumExec → cumulativeSum{NoNulls,WithNulls}[Checked]
+ * (kernels/vector_cumulative.go:228-360) behind "cumulative_sum" / "cumulative_sum_checked"
+ * (compute/vector_cumulative.go:76-96): out[i] = start + Σ_{j≤i, valid} in[j]; a null row gives a
+ * null output (payload 0) and, unless skip_nulls, turns every later row null as well; checked →
+ * AH_EOVERFLOW ("overflow") as soon as a running sum leaves the type's range.  One pass over HBM
+ * (decoupled look-back scan).  start_host: one element of `type` or NULL (= 0).  out_valid must be
+ * given iff `valid` is (ceil(n/8) bytes, offset 0).  Integers bit-exact; floats are summed in a
+ * parallel order (tolerance in DESIGN.md).  Synchronises if checked or out_null_count_host. */
+int ah_cumulative_sum(ah_ctx* ctx, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n,
+                      const void* start_host, int skip_nulls, int checked, void* out_values, uint8_t* out_valid,
+                      int64_t* out_null_count_host);
+
 /* ---- fused scalar-expression evaluation (row §8(f)-1: the expression executor) ---------
  * What compute.Expression trees — NewCall / NewFieldRef / NewLiteral, arrow/compute/
  * expression.go:596-620 — evaluate to through executeScalarBatch (arrow/compute/exprs/

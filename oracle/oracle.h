@@ -114,6 +114,11 @@ int orc_hash_sum_i64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                      uint64_t* out_keys, int64_t* out_sums, int64_t* out_counts, int64_t* out_first_rows,
                      int64_t* out_ngroups, int32_t* out_null_group);
 
+/* ---- cumulative_sum (kernels/vector_cumulative.go:228-360), sequential restatement ---- */
+int orc_cumulative_sum(int type, const void* values, const uint8_t* valid, int64_t off, int64_t n,
+                       const void* start, int skip_nulls, int checked, void* out_values, uint8_t* out_valid,
+                       int64_t* out_null_count);
+
 /* ---- fused Compare(>) → Filter → Sum (the unfused chain, restated) ---- */
 int orc_cmp_filter_sum_i64(int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n,
                            int64_t threshold, int64_t* out_sum, int64_t* out_count);

@@ -71,6 +71,9 @@ class OracleBackend:
     def take(self, values, vvalid, voff, idx, ivalid, ioff, bounds_check, want_valid):
         return self.o.take_primitive(values, vvalid, voff, idx, ivalid, ioff, bounds_check, want_valid)
 
+    def cumulative_sum(self, values, valid, off, start=None, skip_nulls=False, checked=False, misalign=0):
+        return self.o.cumulative_sum(values, valid, off, start, skip_nulls, checked)
+
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
@@ -245,6 +248,28 @@ class HipBackend:
         out = ob.download(values.dtype, idx.size)
         ov = ovb.download(np.uint8, (idx.size + 7) // 8) if want_valid else None
         return STATUS_OK, out, ov, nulls, 0
+
+    def cumulative_sum(self, values, valid, off, start=None, skip_nulls=False, checked=False, misalign=0):
+        import arrow_go_amd as ah
+        values = np.ascontiguousarray(values)
+        n = values.size
+        w = values.dtype.itemsize
+        vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
+        ob = self.c.alloc(n * w + 128)
+        ob.memset(0xCD)  # the library must write every row, including the zero payload of null rows
+        ovb = self.c.alloc((n + 7) // 8 + 64) if valid is not None else None
+        if ovb is not None:
+            ovb.memset(0xFF)  # prepareCumulativeOutput pre-fills the validity with ones; only bits [0, n) are the library's
+        sb = np.array([start], dtype=values.dtype).tobytes() if start is not None else None
+        try:
+            nulls = self.c.cumulative_sum(OL.TYPE_IDS[values.dtype], vp, vvp, off, n, sb, skip_nulls, checked,
+                                          ob.ptr + misalign * w, ovb)
+        except ah.ErrOverflow as e:
+            assert "overflow" in str(e)
+            return STATUS_EOVERFLOW, None, None, 0
+        out = ob.download(values.dtype, n, misalign * w)
+        ov = ovb.download(np.uint8, (n + 7) // 8) if ovb is not None else None
+        return STATUS_OK, out, ov, nulls
 
     def hash_encode(self, keys, valid, off, encode_nulls):
         keys = np.ascontiguousarray(keys).view(np.uint64)

@@ -66,6 +66,7 @@ class Oracle:
             "orc_filter_primitive": (it, [it, vp, vp, i64, vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_take_primitive": (it, [it, vp, vp, i64, i64, it, it, vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_filter_to_indices": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp]),
+            "orc_cumulative_sum": (it, [it, vp, vp, i64, i64, vp, it, it, vp, vp, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -178,6 +179,19 @@ class Oracle:
                                          int(idx.dtype.kind == "i"), _p(idx), _p(ivalid), ioff, idx.size, int(bounds_check),
                                          _p(out), _p(ov), _p(onull), _p(bad))
         return st, out[:idx.size], (ov[:(idx.size + 7) // 8] if want_valid else None), int(onull[0]), int(bad[0])
+
+    # ---- cumulative sum ----------------------------------------------------------------
+    def cumulative_sum(self, values, valid, off, start, skip_nulls, checked):
+        """→ (status, out, out_valid or None, null_count).  start: numpy scalar of values.dtype or None."""
+        values = np.ascontiguousarray(values)
+        n = values.size
+        out = np.zeros(max(n, 1), dtype=values.dtype)
+        ov = np.zeros((n + 7) // 8 + 1, np.uint8) if valid is not None else None
+        nulls = np.zeros(1, np.int64)
+        sv = np.array([start], dtype=values.dtype) if start is not None else None
+        st = self.lib.orc_cumulative_sum(TYPE_IDS[values.dtype], _p(values), _p(valid), off, n, _p(sv), int(skip_nulls), int(checked),
+                                         _p(out), _p(ov), _p(nulls))
+        return st, out[:n], (ov[:(n + 7) // 8] if ov is not None else None), int(nulls[0])
 
     # ---- hashing ------------------------------------------------------------------------
     def hash_int(self, v, alg=0): return int(self.lib.orc_hash_int(int(v) & (2**64 - 1), alg))

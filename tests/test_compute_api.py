@@ -31,12 +31,14 @@ def test_registry_has_the_path_functions():
     for name in ["add", "add_unchecked", "subtract", "subtract_unchecked", "multiply", "multiply_unchecked",
                  "abs_unchecked", "negate_unchecked", "sign", "equal", "not_equal", "greater", "greater_equal", "less",
                  "less_equal", "and", "or", "xor", "and_not", "invert", "and_kleene", "or_kleene", "and_not_kleene",
-                 "filter", "array_filter", "take", "array_take", "unique", "dictionary_encode", "greater_filter_sum"]:
+                 "filter", "array_filter", "take", "array_take", "unique", "dictionary_encode", "greater_filter_sum",
+                 "cumulative_sum", "cumulative_sum_checked"]:
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
     assert ac.function_num_kernels("array_take") == 80      # 10 value types × 8 index types
     assert ac.function_num_kernels("filter") == 0           # MetaFunction
+    assert ac.function_num_kernels("cumulative_sum") == 10 and ac.function_num_kernels("cumulative_sum_checked") == 10
     assert ac.num_functions() >= 30
 
 
@@ -297,6 +299,76 @@ def test_unique_and_dictionary_encode(sess, typ):
     assert sess.call_function("unique", [v]).equals(pc.unique(v))
     got, exp = sess.call_function("dictionary_encode", [v]), pc.dictionary_encode(v)
     assert got.indices.equals(exp.indices) and got.dictionary.equals(exp.dictionary)
+
+
+# ---- cumulative_sum (arrow/compute/vector_cumulative_test.go) -----------------------------------------------
+@pytest.mark.gpu
+def test_cumulative_sum_reference_tables(sess):
+    from arrow_go_amd import compute as ac
+    I32 = lambda v: pa.array(v, type=pa.int32())
+    cs = lambda a, o="": sess.call_function("cumulative_sum", [a], o).to_pylist()
+    csc = lambda a, o="": sess.call_function("cumulative_sum_checked", [a], o).to_pylist()
+    assert cs(I32([1, 2, 3, 4])) == [1, 3, 6, 10]                                   # TestCumulativeSum :41
+    assert cs(I32([])) == [] and cs(I32([None, None])) == [None, None]               # AdditionalInputs :94
+    assert cs(pa.array([1, 2, 3], pa.uint8())) == [1, 3, 6]
+    assert cs(pa.array([1.5, 2.5], pa.float32())) == [1.5, 4.0] and cs(pa.array([1.5, 2.5], pa.float64())) == [1.5, 4.0]
+    assert cs(I32([0, 1, 2, 3]).slice(1, 2)) == [1, 3]
+    assert cs(I32([9, None, 2, 3, 99]).slice(1, 3)) == [None, None, None]
+    assert cs(I32([9, None, 2, 3, 99]).slice(1, 3), "skip_nulls=1") == [None, 2, 5]
+    r = sess.call_function("cumulative_sum", [pa.scalar(3, pa.int32())])              # scalar input → 1-row array
+    assert isinstance(r, pa.Array) and r.to_pylist() == [3]
+    v = I32([1, None, 2, None, 3])                                                   # NullsAndStart :238
+    assert cs(v) == [1, None, None, None, None]
+    assert cs(v, "skip_nulls=1") == [1, None, 3, None, 6]
+    assert cs(v, "skip_nulls=1;start=int64:10") == [11, None, 13, None, 16]          # Start is safe-cast to the input type
+    out = sess.call_function("cumulative_sum", [v], "skip_nulls=1")
+    assert out.null_count == 2 and out.type == pa.int32()
+    # TestCumulativeSumNullScalarInput :172
+    for typ in NUMERIC:
+        for fn in ("cumulative_sum", "cumulative_sum_checked"):
+            for o in ("", "skip_nulls=1", "start=%s:10" % typ, "start=%s:10;skip_nulls=1" % typ):
+                assert sess.call_function(fn, [pa.scalar(None, typ)], o).to_pylist() == [None]
+    # typed null start / unsafe start casts are arrow.ErrInvalid (:277-344)
+    for fn in ("cumulative_sum", "cumulative_sum_checked"):
+        with pytest.raises(ac.ErrInvalid, match="start value must be valid"):
+            sess.call_function(fn, [I32([1])], "start=null:int32")
+    for typ, start in ((pa.int8(), "int64:128"), (pa.int8(), "int64:-129"), (pa.uint8(), "int64:-1"), (pa.int32(), "double:1.5")):
+        with pytest.raises(ac.ErrInvalid, match="cannot cast cumulative sum start value"):
+            sess.call_function("cumulative_sum", [pa.array([0], typ)], "start=" + start)
+    assert cs(pa.array([0], pa.int8()), "start=int64:127") == [127]
+    assert cs(pa.array([1.0], pa.float64()), "start=int32:2") == [3.0]
+    # checked (:750-840)
+    assert cs(pa.array([127, 1], pa.int8())) == [127, -128]
+    for typ in INTS:
+        lo, hi = (0, 2**typ.bit_width - 1) if pa.types.is_unsigned_integer(typ) else (-2**(typ.bit_width - 1), 2**(typ.bit_width - 1) - 1)
+        with pytest.raises(ac.ErrInvalid, match="overflow"):
+            csc(pa.array([hi, 1], typ))
+        assert csc(pa.array([hi - 1, 1], typ)) == [hi - 1, hi]
+        if lo < 0:
+            with pytest.raises(ac.ErrInvalid, match="overflow"):
+                csc(pa.array([lo, -1], typ))
+            assert csc(pa.array([lo + 1, -1], typ)) == [lo + 1, lo]
+    with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
+        cs(pa.array([True, False]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+def test_cumulative_sum_random_vs_arrow_cpp(sess, typ):
+    # Arrow C++'s cumulative_sum has the same contract (wraparound, skip_nulls, start)
+    rng = np.random.default_rng(typ.bit_width)
+    n = 50021
+    if pa.types.is_floating(typ):
+        vals = rng.integers(-100, 100, n).astype(typ.to_pandas_dtype())   # integer-valued: every summation order is exact
+    else:
+        info = np.iinfo(typ.to_pandas_dtype())
+        vals = rng.integers(info.min, info.max, n, dtype=typ.to_pandas_dtype(), endpoint=True)
+    for p_null, skip in ((0.0, False), (0.2, True), (0.0001, False)):
+        a = pa.array(vals, mask=rng.random(n) < p_null if p_null else None, type=typ).slice(17, n - 30)
+        got = sess.call_function("cumulative_sum", [a], "skip_nulls=%d;start=%s:3" % (skip, typ))
+        exp = pc.cumulative_sum(a, start=pa.scalar(3, typ), skip_nulls=skip)
+        assert got.equals(exp), (typ, p_null, skip)
+        assert got.null_count == exp.null_count
 
 
 # ---- arrow/math + fused -------------------------------------------------------------------------------------

@@ -584,3 +584,99 @@ def test_fused_equals_unfused_chain_small(be):
     xf = x.astype(np.float64)
     s, c = be.cmp_filter_sum_f64(GT, xf, valid, 0, 4.0)
     assert (s, c) == (21.0, 3)
+
+
+# ---- cumulative_sum / cumulative_sum_checked ----------------------------------------------
+# arrow/compute/vector_cumulative_test.go
+def run_cumsum(be, dtype, vals, start=None, skip_nulls=False, checked=False, sl=None):
+    """vals: python list with None; sl = (lo, hi) slices the input like array.NewSlice."""
+    arr, valid = mk(vals, dtype, null_fill=77)  # junk under nulls: the payload must not leak into the sums
+    lo, hi = sl if sl else (0, len(vals))
+    st, out, ov, nulls = be.cumulative_sum(arr[lo:hi], valid, lo, None if start is None else np.dtype(dtype).type(start),
+                                           skip_nulls, checked)
+    if st != STATUS_OK:
+        return st, None
+    n = hi - lo
+    got = logical(out, ov, 0, n)
+    assert nulls == sum(g is None for g in got)
+    if ov is not None:  # null rows keep the zero of the fresh output buffer (prepareCumulativeOutput :211-226)
+        assert all(out[i] == 0 for i in range(n) if got[i] is None)
+    return st, got
+
+
+def test_cumulative_sum_basic(be):
+    # TestCumulativeSum :41-55, TestCumulativeSumValueOptions :57-75
+    assert run_cumsum(be, np.int32, [1, 2, 3, 4]) == (STATUS_OK, [1, 3, 6, 10])
+    assert run_cumsum(be, np.int32, [1, 2, 3]) == (STATUS_OK, [1, 3, 6])
+
+
+def test_cumulative_sum_additional_inputs(be):
+    # TestCumulativeSumAdditionalInputs :94-170
+    assert run_cumsum(be, np.int32, []) == (STATUS_OK, [])
+    assert run_cumsum(be, np.int32, [None, None]) == (STATUS_OK, [None, None])
+    assert run_cumsum(be, np.uint8, [1, 2, 3]) == (STATUS_OK, [1, 3, 6])
+    assert run_cumsum(be, np.float32, [1.5, 2.5]) == (STATUS_OK, [1.5, 4.0])
+    assert run_cumsum(be, np.float64, [1.5, 2.5]) == (STATUS_OK, [1.5, 4.0])
+    assert run_cumsum(be, np.int32, [3]) == (STATUS_OK, [3])                      # scalar input → 1-row array
+    assert run_cumsum(be, np.int32, [0, 1, 2, 3], sl=(1, 3)) == (STATUS_OK, [1, 3])  # sliced
+    # sliced nulls
+    assert run_cumsum(be, np.int32, [9, None, 2, 3, 99], sl=(1, 4)) == (STATUS_OK, [None, None, None])
+    assert run_cumsum(be, np.int32, [9, None, 2, 3, 99], sl=(1, 4), skip_nulls=True) == (STATUS_OK, [None, 2, 5])
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+@pytest.mark.parametrize("checked", [False, True])
+def test_cumulative_sum_null_scalar_input(be, dtype, checked):
+    # TestCumulativeSumNullScalarInput :172-236 — a null scalar is a 1-row all-null array
+    for start in (None, 10):
+        for skip in (False, True):
+            assert run_cumsum(be, dtype, [None], start=start, skip_nulls=skip, checked=checked) == (STATUS_OK, [None])
+
+
+def test_cumulative_sum_nulls_and_start(be):
+    # TestCumulativeSumNullsAndStart :238-275
+    v = [1, None, 2, None, 3]
+    assert run_cumsum(be, np.int32, v) == (STATUS_OK, [1, None, None, None, None])
+    assert run_cumsum(be, np.int32, v, skip_nulls=True) == (STATUS_OK, [1, None, 3, None, 6])
+    assert run_cumsum(be, np.int32, v, start=10, skip_nulls=True) == (STATUS_OK, [11, None, 13, None, 16])
+
+
+def test_cumulative_sum_state_across_chunks(be):
+    # TestCumulativeSumStateAcrossChunks :646-679 — chunks [1,2] [null] [3]: one running state; here one array
+    assert run_cumsum(be, np.int32, [1, 2, None, 3]) == (STATUS_OK, [1, 3, None, None])
+    assert run_cumsum(be, np.int32, [1, 2, None, 3], skip_nulls=True) == (STATUS_OK, [1, 3, None, 6])
+
+
+def test_cumulative_sum_checked(be):
+    # TestCumulativeSumChecked :750-767 — unchecked wraps, checked reports
+    assert run_cumsum(be, np.int8, [127, 1]) == (STATUS_OK, [127, -128])
+    assert run_cumsum(be, np.int8, [127, 1], checked=True)[0] == STATUS_EOVERFLOW
+
+
+_LIM = {np.dtype(d): (np.iinfo(d).min, np.iinfo(d).max) for d in OL.INT_DTYPES}
+
+
+@pytest.mark.parametrize("dtype", OL.INT_DTYPES, ids=str)
+def test_cumulative_sum_checked_integer_overflow(be, dtype):
+    # TestCumulativeSumCheckedIntegerOverflow :769-806
+    lo, hi = _LIM[np.dtype(dtype)]
+    assert run_cumsum(be, dtype, [hi, 1], checked=True)[0] == STATUS_EOVERFLOW
+    if lo < 0:
+        assert run_cumsum(be, dtype, [lo, -1], checked=True)[0] == STATUS_EOVERFLOW
+    # the start value takes part in the running sum (cumulativeSumState.current)
+    assert run_cumsum(be, dtype, [1], start=hi, checked=True)[0] == STATUS_EOVERFLOW
+    # rows behind a null (propagated) or null rows themselves never overflow
+    assert run_cumsum(be, dtype, [hi, None, 1], checked=True) == (STATUS_OK, [hi, None, None])
+    assert run_cumsum(be, dtype, [hi, None, 1], checked=True, skip_nulls=True)[0] == STATUS_EOVERFLOW
+
+
+@pytest.mark.parametrize("dtype", OL.INT_DTYPES, ids=str)
+def test_cumulative_sum_checked_integer_boundaries(be, dtype):
+    # TestCumulativeSumCheckedIntegerBoundaries :808-840
+    lo, hi = _LIM[np.dtype(dtype)]
+    assert run_cumsum(be, dtype, [hi - 1, 1], checked=True) == (STATUS_OK, [hi - 1, hi])
+    if lo < 0:
+        assert run_cumsum(be, dtype, [lo + 1, -1], checked=True) == (STATUS_OK, [lo + 1, lo])
+        # leaves the range and comes back: still an overflow (the reference stops at the first one)
+        assert run_cumsum(be, dtype, [hi, 1, -5], checked=True)[0] == STATUS_EOVERFLOW
+        assert run_cumsum(be, dtype, [hi, -5, 1], checked=True) == (STATUS_OK, [hi, hi - 5, hi - 4])

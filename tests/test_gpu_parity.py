@@ -377,6 +377,116 @@ def test_fused_equals_separate_gpu_kernels(hip, ctx):
     assert (hip.sum(kept), len(kept)) == hip.cmp_filter_sum_i64(GT, x, None, 0, thr)
 
 
+# ---- cumulative_sum ------------------------------------------------------------------------
+CUMSUM_SIZES = [1, 2, 3, 15, 17, 63, 65, 255, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 8191, 8192, 8193, 16385, 70001, 300007, 1200011]
+
+
+def cumsum_valid_equal(got, exp, n):
+    """only bits [0, n) belong to the result; the reference pre-fills whole bytes with ones"""
+    return bool(np.array_equal(OL.unpack_bits(got, 0, n), OL.unpack_bits(exp, 0, n)))
+
+
+@pytest.mark.parametrize("dtype", OL.INT_DTYPES, ids=str)
+def test_cumulative_sum_int_bit_exact(hip, orc_be, dtype):
+    """Unchecked integer running sums wrap exactly like Go's `current += v`; bit-exact for every
+    width, with / without nulls, both null modes, sliced validity, misaligned values, a start value."""
+    rng = np.random.default_rng(1000 + np.dtype(dtype).itemsize)
+    for k, n in enumerate(CUMSUM_SIZES):
+        x = rand(rng, dtype, n)
+        start = None if k % 3 == 0 else x.dtype.type(rng.integers(0, 100))
+        mis = k % 4
+        st_e, e, _, _ = orc_be.cumulative_sum(x, None, 0, start, False, False)
+        st_g, g, _, _ = hip.cumulative_sum(x, None, 0, start, False, False, misalign=mis)
+        assert st_e == st_g == STATUS_OK and g.tobytes() == e.tobytes(), (dtype, n)
+        off = int(rng.integers(0, 70))
+        for p_null, skip in ((0.3, True), (0.3, False), (2.0 / max(n, 1), False), (0.999, True)):
+            bits = OL.pack_bits([True] * off + list(rng.random(n) >= p_null))
+            st_e, e, ev, en = orc_be.cumulative_sum(x, bits, off, start, skip, False)
+            st_g, g, gv, gn = hip.cumulative_sum(x, bits, off, start, skip, False, misalign=mis)
+            assert st_e == st_g == STATUS_OK
+            assert g.tobytes() == e.tobytes(), (dtype, n, p_null, skip)
+            assert cumsum_valid_equal(gv, ev, n) and gn == en, (dtype, n, p_null, skip)
+
+
+@pytest.mark.parametrize("dtype", OL.INT_DTYPES, ids=str)
+def test_cumulative_sum_checked_parity(hip, orc_be, dtype):
+    """checked: same values when no running sum leaves the range, "overflow" exactly when one does —
+    including sums that leave the range and return, and overflows only reachable through null rows."""
+    rng = np.random.default_rng(2000 + np.dtype(dtype).itemsize)
+    info = np.iinfo(dtype)
+    n_over = 0
+    for n in (5, 64, 257, 1024, 2049, 9000, 70001):
+        for trial in range(6):
+            # steps sized so that roughly half the trials overflow somewhere
+            amp = max(1, int(1.5 * info.max / math.sqrt(n))) if trial % 2 == 0 else max(1, int(info.max // (4 * n)))
+            lo = -amp if info.min < 0 else 0
+            x = rng.integers(lo, min(amp, int(info.max)), n, endpoint=True, dtype=dtype)
+            bits = None if trial < 2 else OL.pack_bits(list(rng.random(n) >= 0.1))
+            skip = trial % 3 != 0
+            st_e, e, ev, en = orc_be.cumulative_sum(x, bits, 0, None, skip, True)
+            st_g, g, gv, gn = hip.cumulative_sum(x, bits, 0, None, skip, True)
+            assert st_e == st_g, (dtype, n, trial, st_e, st_g)
+            n_over += st_e != STATUS_OK
+            if st_e == STATUS_OK:
+                assert g.tobytes() == e.tobytes()
+                if bits is not None:
+                    assert cumsum_valid_equal(gv, ev, n) and gn == en
+    assert n_over > 0
+    # a single out-of-range running sum in the middle of a long column, then back in range
+    n = 500000
+    x = np.zeros(n, dtype)
+    x[1234] = info.max; x[300000] = 1; x[300001] = np.array(-1 if info.min < 0 else 0).astype(dtype)
+    assert hip.cumulative_sum(x, None, 0, None, False, True)[0] == orc_be.cumulative_sum(x, None, 0, None, False, True)[0] != STATUS_OK
+    x[300000] = 0
+    st_g, g, _, _ = hip.cumulative_sum(x, None, 0, None, False, True)
+    st_e, e, _, _ = orc_be.cumulative_sum(x, None, 0, None, False, True)
+    assert st_g == st_e == STATUS_OK and g.tobytes() == e.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=str)
+def test_cumulative_sum_float(hip, orc_be, dtype):
+    """Floats: the reference adds sequentially in T; the scan adds in a parallel order in float64.
+    (1) integer-valued data whose sums stay below 2^24 / 2^53: every order is exact → bit-exact.
+    (2) general data, tolerance stated here and in DESIGN.md §4: with E = the exact prefix sums,
+        |gpu − E| ≤ (n/1024 + 64)·2^-53·Σ_{j≤i}|x_j|  (+ ½ulp_T(E) for the final rounding to T);
+        the reference's own bound for the same data is (i+1)·eps_T·Σ|x| — ours is the tighter one."""
+    rng = np.random.default_rng(3000 + np.dtype(dtype).itemsize)
+    eps_t = float(np.finfo(dtype).eps)
+    for k, n in enumerate(CUMSUM_SIZES):
+        xi = rng.integers(-3, 4, n).astype(dtype)
+        bits = OL.pack_bits(list(rng.random(n) >= 0.2)) if k % 2 else None
+        st_e, e, ev, en = orc_be.cumulative_sum(xi, bits, 0, dtype(2), True, False)
+        st_g, g, gv, gn = hip.cumulative_sum(xi, bits, 0, dtype(2), True, False, misalign=k % 3)
+        assert st_e == st_g == STATUS_OK and g.tobytes() == e.tobytes(), (dtype, n)
+        if bits is not None:
+            assert cumsum_valid_equal(gv, ev, n) and gn == en
+        x = (rng.standard_normal(n) * 1e3).astype(dtype)
+        st_g, g, _, _ = hip.cumulative_sum(x, None, 0, None, False, False)
+        st_e, e, _, _ = orc_be.cumulative_sum(x, None, 0, None, False, False)
+        exact = np.cumsum(x.astype(np.longdouble))
+        mag = np.cumsum(np.abs(x.astype(np.longdouble)))
+        tol = (n / 1024 + 64) * 2.0**-53 * mag + 0.5 * eps_t * np.abs(exact)
+        assert np.all(np.abs(g.astype(np.longdouble) - exact) <= tol), (dtype, n)
+        # and the oracle (the reference's order) sits inside ITS bound around the same exact values
+        assert np.all(np.abs(e.astype(np.longdouble) - exact) <= (np.arange(n) + 1) * eps_t * mag)
+    # non-finite values propagate like the sequential loop: from the first NaN/inf on
+    x = np.ones(5000, dtype); x[4000] = np.inf; x[4500] = -np.inf
+    g = hip.cumulative_sum(x, None, 0, None, False, False)[1]
+    e = orc_be.cumulative_sum(x, None, 0, None, False, False)[1]
+    assert np.array_equal(g[:4500], e[:4500]) and np.all(np.isnan(g[4500:])) and np.all(np.isnan(e[4500:]))
+
+
+def test_cumulative_sum_large_lookback(hip, orc_be):
+    """many tiles (2^24 rows of int8 = 1024 tiles of 16384; of int64 = 8192 tiles): the look-back chain"""
+    rng = np.random.default_rng(77)
+    for dtype, n in ((np.int64, (1 << 24) + 3), (np.int8, (1 << 24) + 5), (np.uint32, (1 << 23) + 1)):
+        x = rand(rng, dtype, n)
+        e = orc_be.cumulative_sum(x, None, 0, None, False, False)[1]
+        for rep in range(3):  # scheduling differs from run to run
+            g = hip.cumulative_sum(x, None, 0, None, False, False)[1]
+            assert g.tobytes() == e.tobytes(), (dtype, rep)
+
+
 # ---- full-size properties (BASELINE.json configs; no oracle pass needed) -------------------
 def test_full_size_properties(ctx):
     """C2/C3 sizes (2^27 rows = 1 GiB columns) checked through size-independent
@@ -423,5 +533,11 @@ def test_full_size_properties(ctx):
     assert ctx.sum_int64(out, n) == sa
     ctx.take_primitive(8, out, None, 0, n, 4, True, idx, None, 0, n, True, b, None)
     assert b.download(np.int64, 1000, 12345 * 8).tobytes() == a.download(np.int64, 1000, 12345 * 8).tobytes()
+    # cumulative_sum: last element = Sum; first differences give the input back
+    ctx.cumulative_sum(N.INT64, a, None, 0, n, None, False, False, out, None)
+    assert out.download(np.int64, 1, (n - 1) * 8)[0] == np.int64(sa)
+    ctx.arithmetic(N.INT64, N.OP_SUB, N.SHAPE_AA, out.at(8), out, b, n - 1)   # b[i] = out[i+1] - out[i]
+    ctx.comparison(N.CMP_EQ, N.SHAPE_AA, N.INT64, b, a.at(8), mask, n - 1, 0)
+    assert ctx.count_set_bits(mask, 0, n - 1) == n - 1
     for buf in (a, b, out, mask, idx):
         buf.free()
