@@ -1,4 +1,4 @@
-// ah_scan.hip — cumulative_sum / cumulative_sum_checked: single-pass prefix scan.
+// ah_scan.hip — cumulative_sum / cumulative_sum_checked: reduce-then-scan prefix sums.
 //
 // Row §8(f)-2 (same registry, same boundary).  Replaces cumulativeSumExec →
 //   cumulativeSumSpans → cumulativeSum{NoNulls,WithNulls}[Checked]
@@ -10,18 +10,23 @@
 //   sum leaves the type's range (checkedAddSigned/Unsigned :147-160 — the textbook test, unlike
 //   the checked Add kernel's carry quirk).
 //
-// The reference is a sequential loop; here it is ONE pass over HBM (8 B read + 8 B written per
-// Int64 row) with the decoupled look-back scan: workgroups take tiles in ticket order, publish
-// their tile aggregate, and a wave looks back over predecessors' {aggregate | inclusive prefix}
-// records until it meets an inclusive one.  Cross-workgroup hand-off uses self-validating 64-bit
-// words {marker | 32 payload bits} moved with relaxed agent-scope atomics — no fences (see the
-// note at `Words`).  Ticket order makes it deadlock-free under any dispatch order: a tile only
-// waits for tiles whose workgroups are already running.
+// The reference is one sequential loop.  Here: three kernels, no inter-workgroup waiting —
+//   1. tile_sums_kernel     Σ of the valid rows of every tile            (reads  w B/row)
+//   2. super_prefix_kernel  exclusive scan of per-8-tile sums (+ start)  (tiny)
+//   3. tile_scan_kernel     in-tile scan + tile prefix → out             (reads w, writes w B/row)
+// i.e. 3w bytes of traffic per row against 2w algorithmic.  The one-pass alternative (decoupled
+// look-back, kept as scripts/micro/scan_lookback_variant.hip.txt) was built and measured first:
+// with fence-free self-validating records it reached 0.69–0.88 ms for 2^27 Int64 rows, because
+// every tile's prefix has to cross XCDs through sc1 (L2-bypassing) accesses whose round trip is
+// ≈3 µs behind the streaming traffic, and twice that sits on every tile's critical path; it
+// also needs spin-waits (a co-residency deadlock was observed with an over-subscribed persistent
+// grid) and its float results depend on timing.  This version is 0.49 ms, deterministic — the
+// summation tree is a fixed function of n — and cannot hang.
 //
-// Accumulator: unchecked ints scan in uint64 (wraparound commutes with truncation); checked ints
-// scan EXACTLY in int64 (≤ 32-bit types) or __int128 (64-bit types) so "some running sum left the
-// range" is decided exactly; floats scan in double (parallel order — the reference's sequential
-// order cannot be reproduced; tolerance in DESIGN.md §4).
+// Accumulator: unchecked ints scan in uint32 / uint64 (wraparound commutes with truncation); checked
+// ints scan EXACTLY in int64 (≤ 32-bit types) or __int128 (64-bit types) so "some running sum
+// left the range" is decided exactly; floats scan in double (parallel order — the reference's
+// sequential order cannot be reproduced; tolerance in DESIGN.md §4).
 #include <limits>
 #include <type_traits>
 #include "ah_common.h"
@@ -29,7 +34,6 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kVecPerThread = 4;  // 16-byte vectors per lane per tile
 
 typedef __int128 i128;
 
@@ -55,195 +59,192 @@ template <> __device__ __forceinline__ i128 shfl_any<i128>(i128 v, int l) {
   return (i128)(((unsigned __int128)hi << 64) | lo);
 }
 
-// exclusive scan of one A per thread across the block; *total = block sum.  No subtraction
-// anywhere (inclusive − own would turn ±inf into NaN and lose bits for floats).
-template <typename A>
-__device__ __forceinline__ A block_exclusive_scan(A v, A* total, A* sm /*kBlock/64 + 1 entries*/) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  A inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    A t = shfl_up_any<A>(inc, o);
-    if (lane >= o) inc += t;
-  }
-  __syncthreads();  // previous use of sm is finished
-  if (lane == 63) sm[wave] = inc;
-  __syncthreads();
-  A base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < kBlock / 64; k++) {
-    A t = sm[k];
-    if (k < wave) base += t;
-    tot += t;
-  }
-  *total = tot;
-  A prev = shfl_up_any<A>(inc, 1);
-  if (lane == 0) prev = 0;
-  return base + prev;
-}
-
-// Cross-workgroup records.  Every 64-bit word is self-validating: {marker:32 | payload:32}, written
-// and read with relaxed agent-scope atomics (sc1 accesses, coherent across the 8 XCD L2s).  A
-// record of sizeof(A) bytes is sizeof(A)/4 such words and is complete when every word carries the
-// marker — no release/acquire fence at all.  (The fence form — plain store, agent release fence,
-// flag — costs a `buffer_wbl2 sc1` per publish, i.e. a write-back of every dirty line the output
-// stream left in that XCD's L2: measured 90 ns per tile, serialised, 6.2 ms for 2^27 Int64 rows.)
-template <typename A> struct Words { static constexpr int N = sizeof(A) / 4; };
-
-template <typename A> __device__ __forceinline__ void to_words(A v, unsigned (&w)[Words<A>::N]) {
-  if constexpr (sizeof(A) == 8) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    w[0] = (unsigned)u; w[1] = (unsigned)(u >> 32);
-  } else {
-    unsigned __int128 u = (unsigned __int128)v;
-    w[0] = (unsigned)u; w[1] = (unsigned)(u >> 32); w[2] = (unsigned)(u >> 64); w[3] = (unsigned)(u >> 96);
-  }
-}
-template <typename A> __device__ __forceinline__ A from_words(const unsigned (&w)[Words<A>::N]) {
-  if constexpr (sizeof(A) == 8) {
-    unsigned long long u = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
-    return __builtin_bit_cast(A, u);
-  } else {
-    unsigned __int128 u = (unsigned __int128)w[0] | ((unsigned __int128)w[1] << 32) | ((unsigned __int128)w[2] << 64) | ((unsigned __int128)w[3] << 96);
-    return (A)u;
-  }
-}
-
-constexpr unsigned long long kMarker = 1ull << 32;
-
-template <typename A>
-struct ScanState {
-  unsigned long long* agg;   // [ntiles][Words<A>::N]  tile aggregate
-  unsigned long long* incl;  // [ntiles][Words<A>::N]  inclusive prefix (start included)
-  unsigned* ticket;
-  unsigned* overflow;
+// Tile geometry: a tile is 4 wave chunks; a wave's chunk is contiguous (vector k of lane l sits at
+// chunk + (k·64 + l)·16 bytes: coalesced), so the in-tile scan is shuffles within a wave plus ONE
+// LDS exchange of four wave totals.  VPT = 16-byte vectors per lane per tile.
+template <typename T, int VPT>
+struct Geom {
+  static constexpr int V = 16 / sizeof(T);
+  static constexpr int WCHUNK = 64 * VPT * V;
+  static constexpr int TILE = (kBlock / 64) * WCHUNK;
 };
 
-template <typename A>
-__device__ __forceinline__ void publish(unsigned long long* slot, A value) {
-  unsigned w[Words<A>::N];
-  to_words<A>(value, w);
-#pragma unroll
-  for (int k = 0; k < Words<A>::N; k++) __hip_atomic_store(slot + k, kMarker | w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename A>
-__device__ __forceinline__ bool try_read(const unsigned long long* slot, A* value) {
-  unsigned w[Words<A>::N];
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < Words<A>::N; k++) {
-    unsigned long long x = __hip_atomic_load(slot + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok = ok && (x >> 32) == 1ull;
-    w[k] = (unsigned)x;
-  }
-  *value = from_words<A>(w);
-  return ok;
-}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// T: element type; A: accumulator; CHECKED: range test of every running sum at a valid row
-template <typename T, typename A, bool CHECKED>
-__global__ __launch_bounds__(kBlock) void scan_kernel(const T* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off,
-                                                       int64_t n, int64_t limit /*rows ≥ limit are null (first null, !skip_nulls)*/,
-                                                       A start, T* __restrict__ out, ScanState<A> st) {
+// rows of one wave chunk + their validity bits (bit j = element j of the vector), with rows at or
+// beyond `limit` (first null, !skip_nulls) and beyond n masked off.  ALN: the buffer is 16-byte
+// aligned → nontemporal ext-vector loads (the column is streamed, not reused).
+template <typename T, int VPT, bool ALN>
+__device__ __forceinline__ void load_chunk(const T* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+                                           int64_t limit, int64_t wbase, int lane, T (&x)[VPT][16 / sizeof(T)], unsigned (&vb)[VPT]) {
   constexpr int V = 16 / sizeof(T);
-  constexpr int TILE = kBlock * kVecPerThread * V;
-  __shared__ A sm[kBlock / 64 + 1];
-  __shared__ unsigned s_tile;
-  __shared__ A s_excl;
-  if (threadIdx.x == 0) s_tile = atomicAdd(st.ticket, 1u);
-  __syncthreads();
-  const int64_t tile = s_tile;
-  const int64_t base = tile * TILE;
-  const int lane = threadIdx.x & 63;
-
-  // ---- load the tile (16-byte vectors, element-aligned), per-lane element sums
-  T x[kVecPerThread][V];
-  bool ok[kVecPerThread][V];
-  A vsum[kVecPerThread];
 #pragma unroll
-  for (int k = 0; k < kVecPerThread; k++) {
-    const int64_t e0 = base + ((int64_t)k * kBlock + threadIdx.x) * V;
+  for (int k = 0; k < VPT; k++) {
+    const int64_t e0 = wbase + ((int64_t)k * 64 + lane) * V;
     if (e0 + V <= n) {
-      ah_vec16<T> v = *(const ah_vec16<T>*)(in + e0);
+      ah_vec16<T> v;
+      if (ALN) v = __builtin_bit_cast(ah_vec16<T>, __builtin_nontemporal_load((const u32x4*)(in + e0)));
+      else v = *(const ah_vec16<T>*)(in + e0);
 #pragma unroll
       for (int j = 0; j < V; j++) x[k][j] = v.v[j];
     } else {
 #pragma unroll
       for (int j = 0; j < V; j++) x[k][j] = (e0 + j < n) ? in[e0 + j] : (T)0;
     }
-    unsigned vb = e0 < n ? (valid ? (unsigned)ah_load_bits64(valid, off + e0, (n - e0) >= V ? V : (int)(n - e0)) : ~0u) : 0u;
-    A s = 0;
-#pragma unroll
-    for (int j = 0; j < V; j++) {
-      ok[k][j] = ((vb >> j) & 1) && (e0 + j < limit) && (e0 + j < n);
-      s += ok[k][j] ? (A)x[k][j] : (A)0;
-    }
-    vsum[k] = s;
+    const int cnt = e0 >= n ? 0 : ((n - e0) >= V ? V : (int)(n - e0));
+    unsigned b = cnt == 0 ? 0u : (valid ? (unsigned)ah_load_bits64(valid, off + e0, cnt) : ~0u);
+    if (cnt < V) b &= (1u << cnt) - 1u;
+    if (e0 + V > limit) b &= e0 >= limit ? 0u : ((1u << (int)(limit - e0)) - 1u);
+    vb[k] = b;
   }
-  // ---- tile-local scan: kVecPerThread block scans chained by a running carry
-  A vexcl[kVecPerThread];  // exclusive prefix (within the tile) at the START of this lane's vector k
-  A carry = 0;
-#pragma unroll
-  for (int k = 0; k < kVecPerThread; k++) {
-    A tot;
-    A exc = block_exclusive_scan<A>(vsum[k], &tot, sm);
-    vexcl[k] = carry + exc;
-    carry += tot;
-  }
-  const A tile_total = carry;
+}
 
-  // ---- publish the aggregate, look back for the exclusive prefix
-  constexpr int NW = Words<A>::N;
-  if (tile == 0) {
-    if (threadIdx.x == 0) {
-      s_excl = start;
-      publish<A>(st.incl, start + tile_total);
-    }
-  } else {
-    if (threadIdx.x == 0) publish<A>(st.agg + tile * NW, tile_total);
-    if (threadIdx.x < 64) {
-      A excl = 0;
-      int64_t look = tile - 1;
-      for (;;) {
-        const int64_t t = look - lane;
-        bool inclusive = true;
-        A v = 0;
-        if (t >= 0) {
-          for (;;) {
-            if (try_read<A>(st.incl + t * NW, &v)) break;
-            if (try_read<A>(st.agg + t * NW, &v)) { inclusive = false; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        const unsigned long long done = __ballot(inclusive);
-        const int first = __ffsll((long long)done) - 1;  // nearest predecessor with an inclusive prefix
-        A part = (first < 0 || lane <= first) ? v : (A)0;
+constexpr int kSuper = 8;  // tiles per workgroup in the sums pass = tiles per thread-step in the prefix pass
+
+// 1. tile sums: a workgroup streams kSuper consecutive tiles, one barrier at the end
+template <typename T, typename A, int VPT, bool ALN>
+__global__ __launch_bounds__(kBlock) void tile_sums_kernel(const T* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off,
+                                                            int64_t n, int64_t limit, A* __restrict__ tile_sum, A* __restrict__ super_sum,
+                                                            int64_t ntiles) {
+  using G = Geom<T, VPT>;
+  __shared__ A s_p[kSuper][kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t0 = (int64_t)blockIdx.x * kSuper;
+#pragma unroll 2
+  for (int s = 0; s < kSuper; s++) {
+    const int64_t tile = t0 + s;
+    if (tile >= ntiles) break;
+    T x[VPT][G::V];
+    unsigned vb[VPT];
+    load_chunk<T, VPT, ALN>(in, valid, off, n, limit, tile * G::TILE + (int64_t)wave * G::WCHUNK, lane, x, vb);
+    A acc = 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += shfl_down_any<A>(part, o);
-        excl += shfl_any<A>(part, 0);
-        if (first >= 0) break;
-        look -= 64;
-      }
-      if (threadIdx.x == 0) {
-        s_excl = excl;
-        publish<A>(st.incl + tile * NW, excl + tile_total);
-      }
+    for (int k = 0; k < VPT; k++) {
+#pragma unroll
+      for (int j = 0; j < G::V; j++) acc += ((vb[k] >> j) & 1u) ? (A)x[k][j] : (A)0;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += shfl_down_any<A>(acc, o);
+    if (lane == 0) s_p[s][wave] = acc;
   }
   __syncthreads();
-  const A excl = s_excl;
+  if (threadIdx.x < 64) {  // lanes 0..kSuper-1 hold the tile sums; their sum (in tile order) is the super sum
+    A t = 0;
+    if (threadIdx.x < kSuper && t0 + threadIdx.x < ntiles) {
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; w++) t += s_p[threadIdx.x][w];
+      tile_sum[t0 + threadIdx.x] = t;
+    }
+    A sup = 0;
+#pragma unroll
+    for (int k = 0; k < kSuper; k++) sup += shfl_any<A>(t, k);
+    if (threadIdx.x == 0) super_sum[blockIdx.x] = sup;
+  }
+}
 
-  // ---- outputs
+// 2. exclusive scan of the SUPER sums, `start` folded in: one workgroup, each thread a contiguous run.
+// (Scanning all tile sums here cost 56 µs for 32768 tiles — 8-byte accesses at a 256-byte lane
+// stride; the scan pass instead adds the ≤ 7 tile sums in front of its tile with scalar loads.)
+constexpr int kPrefixBlock = 1024;
+template <typename A>
+__global__ __launch_bounds__(kPrefixBlock) void super_prefix_kernel(const A* __restrict__ super_sum, A* __restrict__ super_excl, int64_t nsuper,
+                                                                     A start) {
+  __shared__ A s_w[kPrefixBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t per = (nsuper + kPrefixBlock - 1) / kPrefixBlock;
+  const int64_t lo = (int64_t)threadIdx.x * per;
+  const int64_t hi = lo + per < nsuper ? lo + per : nsuper;
+  A local = 0;
+#pragma unroll 4
+  for (int64_t q = lo; q < hi; q++) local += super_sum[q];
+  A inc = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    A t = shfl_up_any<A>(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  A base = start;
+  for (int w = 0; w < wave; w++) base += s_w[w];
+  A prev = shfl_up_any<A>(inc, 1);
+  if (lane == 0) prev = 0;
+  A run = base + prev;
+#pragma unroll 4
+  for (int64_t q = lo; q < hi; q++) {
+    A t = super_sum[q];
+    super_excl[q] = run;
+    run += t;
+  }
+}
+
+// 3. in-tile scan + tile prefix (= super prefix + the tile sums in front of this tile within its
+// super tile: workgroup-uniform, scalar loads).  super_excl == nullptr: a single tile, prefix = start.
+template <typename T, typename A, bool CHECKED, int VPT, bool ALN>
+__global__ __launch_bounds__(kBlock) void tile_scan_kernel(const T* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off,
+                                                            int64_t n, int64_t limit, A start, const A* __restrict__ super_excl,
+                                                            const A* __restrict__ tile_sum, T* __restrict__ out,
+                                                            unsigned* __restrict__ overflow) {
+  using G = Geom<T, VPT>;
+  constexpr int V = G::V;
   constexpr bool kIsInt = std::is_integral<T>::value;
+  __shared__ A s_w[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t wb = tile * G::TILE + (int64_t)wave * G::WCHUNK;
+  T x[VPT][V];
+  unsigned vb[VPT];
+  load_chunk<T, VPT, ALN>(in, valid, off, n, limit, wb, lane, x, vb);
+  A excl = start;
+  if (super_excl) {
+    const int64_t sup = tile / kSuper;
+    const int in_super = (int)(tile - sup * kSuper);
+    excl = super_excl[sup];
+    for (int k = 0; k < in_super; k++) excl += tile_sum[sup * kSuper + k];
+  }
+
+  // per-lane vector sums, wave scans chained over the VPT vectors
+  A inc[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; k++) {
+    A sacc = 0;
+#pragma unroll
+    for (int j = 0; j < V; j++) sacc += ((vb[k] >> j) & 1u) ? (A)x[k][j] : (A)0;
+    inc[k] = sacc;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      A t = shfl_up_any<A>(inc[k], o);
+      if (lane >= o) inc[k] += t;
+    }
+  }
+  A vexcl[VPT];  // exclusive prefix within the wave chunk at the START of this lane's vector k (no subtraction:
+  A carry = 0;   // inclusive − own would turn ±inf into NaN and lose bits for floats)
+#pragma unroll
+  for (int k = 0; k < VPT; k++) {
+    A prev = shfl_up_any<A>(inc[k], 1);
+    if (lane == 0) prev = 0;
+    vexcl[k] = carry + prev;
+    carry += shfl_any<A>(inc[k], 63);
+  }
+  if (lane == 0) s_w[wave] = carry;
+  __syncthreads();
+  A pre = excl;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; w++)
+    if (w < wave) pre += s_w[w];
+
   bool ovf = false;
 #pragma unroll
-  for (int k = 0; k < kVecPerThread; k++) {
-    const int64_t e0 = base + ((int64_t)k * kBlock + threadIdx.x) * V;
-    A run = excl + vexcl[k];  // exclusive prefix at this vector's first element
+  for (int k = 0; k < VPT; k++) {
+    const int64_t e0 = wb + ((int64_t)k * 64 + lane) * V;
+    A run = pre + vexcl[k];  // exclusive prefix at this vector's first element
     ah_vec16<T> o;
 #pragma unroll
     for (int j = 0; j < V; j++) {
-      if (ok[k][j]) {
+      if ((vb[k] >> j) & 1u) {
         run += (A)x[k][j];
         if (CHECKED && kIsInt) {
           using L = std::numeric_limits<T>;
@@ -255,13 +256,14 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const T* __restrict__ in, 
       }
     }
     if (e0 + V <= n) {
-      *(ah_vec16<T>*)(out + e0) = o;
+      if (ALN) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), (u32x4*)(out + e0));
+      else *(ah_vec16<T>*)(out + e0) = o;
     } else {
 #pragma unroll
       for (int j = 0; j < V; j++) if (e0 + j < n) out[e0 + j] = o.v[j];
     }
   }
-  if (CHECKED && __any(ovf) && lane == 0) atomicOr(st.overflow, 1u);
+  if (CHECKED && __any(ovf) && lane == 0) atomicOr(overflow, 1u);
 }
 
 // first zero bit of a validity bitmap (or n): where encounteredNull turns on
@@ -293,26 +295,48 @@ __global__ __launch_bounds__(kBlock) void first_null_kernel(const uint8_t* __res
   }
 }
 
-template <typename T, typename A, bool CHECKED>
+template <typename T, typename A, bool CHECKED, int VPT, bool ALN>
 int run_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t limit, A start, void* out) {
-  constexpr int V = 16 / sizeof(T);
-  constexpr int TILE = kBlock * kVecPerThread * V;
-  const int64_t ntiles = ah_ceil_div(n, TILE);
-  // scratch: agg[ntiles][NW] | incl[ntiles][NW] (64-bit words) ; ticket + overflow in dscalars[12], [13]
-  size_t rec_bytes = (((size_t)ntiles * Words<A>::N * 8) + 63) & ~(size_t)63;
-  void* scratch;
-  int rc = ah_scratch_reserve(c, 2 * rec_bytes + 64, &scratch);
-  if (rc != AH_OK) return rc;
-  ScanState<A> st;
-  st.agg = (unsigned long long*)scratch;
-  st.incl = (unsigned long long*)((uint8_t*)scratch + rec_bytes);
-  st.ticket = (unsigned*)&c->dscalars[12];
-  st.overflow = (unsigned*)&c->dscalars[13];
-  AH_HIP(c, hipMemsetAsync(scratch, 0, 2 * rec_bytes, c->stream));
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[12], 0, 2 * sizeof(uint64_t), c->stream));
-  scan_kernel<T, A, CHECKED><<<(unsigned)ntiles, kBlock, 0, c->stream>>>((const T*)values, valid, off, n, limit, start, (T*)out, st);
+  using G = Geom<T, VPT>;
+  const int64_t ntiles = ah_ceil_div(n, G::TILE);
+  unsigned* overflow = (unsigned*)&c->dscalars[13];
+  if (CHECKED) AH_HIP(c, hipMemsetAsync(overflow, 0, sizeof(uint64_t), c->stream));
+  const A *super_excl = nullptr, *tile_sum = nullptr;
+  if (ntiles > 1) {
+    const int64_t nsuper = ah_ceil_div(ntiles, kSuper);
+    size_t tbytes = (((size_t)ntiles * sizeof(A)) + 127) & ~(size_t)127;
+    size_t sbytes = (((size_t)nsuper * sizeof(A)) + 127) & ~(size_t)127;
+    void* scratch;
+    int rc = ah_scratch_reserve(c, tbytes + 2 * sbytes, &scratch);
+    if (rc != AH_OK) return rc;
+    A* sums = (A*)scratch;
+    A* ssum = (A*)((uint8_t*)scratch + tbytes);
+    A* sexcl = (A*)((uint8_t*)scratch + tbytes + sbytes);
+    tile_sums_kernel<T, A, VPT, ALN><<<(unsigned)nsuper, kBlock, 0, c->stream>>>((const T*)values, valid, off, n, limit, sums, ssum, ntiles);
+    AH_LAUNCH_CHECK(c);
+    super_prefix_kernel<A><<<1, kPrefixBlock, 0, c->stream>>>(ssum, sexcl, nsuper, start);
+    AH_LAUNCH_CHECK(c);
+    super_excl = sexcl;
+    tile_sum = sums;
+  }
+  tile_scan_kernel<T, A, CHECKED, VPT, ALN><<<(unsigned)ntiles, kBlock, 0, c->stream>>>((const T*)values, valid, off, n, limit, start,
+                                                                                        super_excl, tile_sum, (T*)out, overflow);
   AH_LAUNCH_CHECK(c);
   return AH_OK;
+}
+
+template <typename T, typename A, bool CHECKED, int VPT>
+int run_scan_aln(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t limit, A start, void* out) {
+  const bool aligned = ((((uintptr_t)values) | ((uintptr_t)out)) & 15) == 0 && c->tune_nt;
+  return aligned ? run_scan<T, A, CHECKED, VPT, true>(c, values, valid, off, n, limit, start, out)
+                 : run_scan<T, A, CHECKED, VPT, false>(c, values, valid, off, n, limit, start, out);
+}
+
+template <typename T, typename A, bool CHECKED>
+int run_scan_vpt(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t limit, A start, void* out) {
+  static const int vpt = getenv("ARROWHIP_SCAN_VPT") ? atoi(getenv("ARROWHIP_SCAN_VPT")) : (sizeof(T) >= 4 ? 8 : 4);
+  if (vpt == 8) return run_scan_aln<T, A, CHECKED, 8>(c, values, valid, off, n, limit, start, out);
+  return run_scan_aln<T, A, CHECKED, 4>(c, values, valid, off, n, limit, start, out);
 }
 
 template <typename T>
@@ -321,11 +345,15 @@ int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t o
   T start = 0;
   if (start_host) memcpy(&start, start_host, sizeof(T));
   if constexpr (std::is_floating_point<T>::value) {
-    return run_scan<T, double, false>(c, values, valid, off, n, limit, (double)start, out);
+    return run_scan_vpt<T, double, false>(c, values, valid, off, n, limit, (double)start, out);
   } else {
-    if (!checked) return run_scan<T, unsigned long long, false>(c, values, valid, off, n, limit, (unsigned long long)start, out);
-    if constexpr (sizeof(T) == 8) return run_scan<T, i128, true>(c, values, valid, off, n, limit, (i128)start, out);
-    else return run_scan<T, long long, true>(c, values, valid, off, n, limit, (long long)start, out);
+    // unchecked: wraparound commutes with truncation, so the narrowest accumulator ≥ T does
+    if (!checked) {
+      if constexpr (sizeof(T) == 8) return run_scan_vpt<T, unsigned long long, false>(c, values, valid, off, n, limit, (unsigned long long)start, out);
+      else return run_scan_vpt<T, unsigned, false>(c, values, valid, off, n, limit, (unsigned)start, out);
+    }
+    if constexpr (sizeof(T) == 8) return run_scan_vpt<T, i128, true>(c, values, valid, off, n, limit, (i128)start, out);
+    else return run_scan_vpt<T, long long, true>(c, values, valid, off, n, limit, (long long)start, out);
   }
 }
 

@@ -445,10 +445,13 @@ def test_cumulative_sum_checked_parity(hip, orc_be, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=str)
 def test_cumulative_sum_float(hip, orc_be, dtype):
-    """Floats: the reference adds sequentially in T; the scan adds in a parallel order in float64.
+    """Floats: the reference adds sequentially in T; the scan adds in float64 along a fixed tree
+    (element → 16-byte vector → 64-lane wave scan → ≤ 8 vectors → 4 waves → ≤ 7 tiles → super-tile
+    scan): at most 64 + n/2^20 additions lie on the path to any output, and the result is a pure
+    function of the data (no timing dependence).
     (1) integer-valued data whose sums stay below 2^24 / 2^53: every order is exact → bit-exact.
     (2) general data, tolerance stated here and in DESIGN.md §4: with E = the exact prefix sums,
-        |gpu − E| ≤ (n/1024 + 64)·2^-53·Σ_{j≤i}|x_j|  (+ ½ulp_T(E) for the final rounding to T);
+        |gpu − E| ≤ (64 + n/2^20)·2^-53·Σ_{j≤i}|x_j|  (+ ½ulp_T(E) for the final rounding to T);
         the reference's own bound for the same data is (i+1)·eps_T·Σ|x| — ours is the tighter one."""
     rng = np.random.default_rng(3000 + np.dtype(dtype).itemsize)
     eps_t = float(np.finfo(dtype).eps)
@@ -465,7 +468,7 @@ def test_cumulative_sum_float(hip, orc_be, dtype):
         st_e, e, _, _ = orc_be.cumulative_sum(x, None, 0, None, False, False)
         exact = np.cumsum(x.astype(np.longdouble))
         mag = np.cumsum(np.abs(x.astype(np.longdouble)))
-        tol = (n / 1024 + 64) * 2.0**-53 * mag + 0.5 * eps_t * np.abs(exact)
+        tol = (n / 2**20 + 64) * 2.0**-53 * mag + 0.5 * eps_t * np.abs(exact)
         assert np.all(np.abs(g.astype(np.longdouble) - exact) <= tol), (dtype, n)
         # and the oracle (the reference's order) sits inside ITS bound around the same exact values
         assert np.all(np.abs(e.astype(np.longdouble) - exact) <= (np.arange(n) + 1) * eps_t * mag)
@@ -476,15 +479,19 @@ def test_cumulative_sum_float(hip, orc_be, dtype):
     assert np.array_equal(g[:4500], e[:4500]) and np.all(np.isnan(g[4500:])) and np.all(np.isnan(e[4500:]))
 
 
-def test_cumulative_sum_large_lookback(hip, orc_be):
-    """many tiles (2^24 rows of int8 = 1024 tiles of 16384; of int64 = 8192 tiles): the look-back chain"""
+def test_cumulative_sum_many_tiles(hip, orc_be):
+    """many tiles and super tiles (2^24 rows): tile sums → super-tile prefix → in-tile scan; and the
+    result does not change from run to run (also for floats: the summation tree is fixed)"""
     rng = np.random.default_rng(77)
     for dtype, n in ((np.int64, (1 << 24) + 3), (np.int8, (1 << 24) + 5), (np.uint32, (1 << 23) + 1)):
         x = rand(rng, dtype, n)
         e = orc_be.cumulative_sum(x, None, 0, None, False, False)[1]
-        for rep in range(3):  # scheduling differs from run to run
+        for rep in range(2):
             g = hip.cumulative_sum(x, None, 0, None, False, False)[1]
             assert g.tobytes() == e.tobytes(), (dtype, rep)
+    xf = (rng.standard_normal((1 << 23) + 7) * 1e3)
+    runs = [hip.cumulative_sum(xf, None, 0, None, False, False)[1].tobytes() for _ in range(3)]
+    assert runs[0] == runs[1] == runs[2]
 
 
 # ---- full-size properties (BASELINE.json configs; no oracle pass needed) -------------------
