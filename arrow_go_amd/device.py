@@ -253,6 +253,15 @@ class Context:
                                                  C.byref(nulls) if out_valid is not None else None))  # no validity → no sync
         return nulls.value
 
+    # ---- cast ---------------------------------------------------------------------------
+    def cast_numeric(self, in_type: int, out_type: int, values, valid, off: int, n: int, allow_int_overflow: bool,
+                     allow_float_truncate: bool, out_values) -> None:
+        check(self.handle, lib.ah_cast_numeric(self.handle, in_type, out_type, _ptr(values), _ptr(valid), off, n,
+                                               int(allow_int_overflow), int(allow_float_truncate), _ptr(out_values)))
+
+    def cast_bool_to_numeric(self, out_type: int, bits, off: int, n: int, out_values) -> None:
+        check(self.handle, lib.ah_cast_bool_to_numeric(self.handle, out_type, _ptr(bits), off, n, _ptr(out_values)))
+
     # ---- hashing ------------------------------------------------------------------------
     def hash_u64_encode(self, keys, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_dict):
         nd = C.c_int64()

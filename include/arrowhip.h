@@ -282,6 +282,22 @@ int ah_cumulative_sum(ah_ctx* ctx, int type, const void* values, const uint8_t* 
                       const void* start_host, int skip_nulls, int checked, void* out_values, uint8_t* out_valid,
                       int64_t* out_null_count_host);
 
+/* ---- numeric cast (row §8(f)-2) ----------------------------------------------------------------
+ * replaces castNumberToNumberUnsafe → castNumericUnsafe (kernels/cast_numeric.go:28-131; AVX2 leaf
+ * cast_type_numeric_avx2(itype, otype, in, out, len), kernels/_lib/cast_numeric.cc:62) together with
+ * the safe-cast checks the reference runs as separate passes: intsCanFit / intsInRange
+ * (helpers.go:496-652), checkIntToFloatTrunc (numeric_cast.go:698-729), checkFloatTrunc (:613-660) —
+ * behind compute's "cast" with CastOptions{ToType, AllowIntOverflow, AllowFloatTruncate}
+ * (kernels/cast.go:27-35).  Every slot is converted (valid or not); only VALID slots can fail a check
+ * (valid = NULL: all valid).  Failure → AH_EINVALID with the reference's text for the first offending
+ * row: "integer value %d not in range: %d to %d" / "float value %f was truncated converting to %s".
+ * Synchronises only when a check is active.  in_type == out_type is a device copy. */
+int ah_cast_numeric(ah_ctx* ctx, int in_type, int out_type, const void* values, const uint8_t* valid, int64_t off, int64_t n,
+                    int allow_int_overflow, int allow_float_truncate, void* out_values);
+/* boolToNum (numeric_cast.go:555-569): out[i] = bit(off + i) ? 1 : 0.  (numeric → bool is
+ * isNonZero, boolean_cast.go:30-36 = ah_comparison(AH_CMP_NE, AH_SHAPE_AS, type, values, &zero).) */
+int ah_cast_bool_to_numeric(ah_ctx* ctx, int out_type, const uint8_t* bits, int64_t off, int64_t n, void* out_values);
+
 /* ---- fused scalar-expression evaluation (row §8(f)-1: the expression executor) ---------
  * What compute.Expression trees — NewCall / NewFieldRef / NewLiteral, arrow/compute/
  * expression.go:596-620 — evaluate to through executeScalarBatch (arrow/compute/exprs/

@@ -119,6 +119,12 @@ int orc_cumulative_sum(int type, const void* values, const uint8_t* valid, int64
                        const void* start, int skip_nulls, int checked, void* out_values, uint8_t* out_valid,
                        int64_t* out_null_count);
 
+/* ---- numeric cast (kernels/cast_numeric.go, numeric_cast.go:37-71,613-729, helpers.go:496-652) ----
+ * msg: 256-byte buffer receiving the reference's error text on ORC_EINVALID; bad_index: the offending row */
+int orc_cast_numeric(int in_type, int out_type, const void* in, const uint8_t* valid, int64_t off, int64_t n,
+                     int allow_int_overflow, int allow_float_truncate, void* out, int64_t* bad_index, char* msg);
+int orc_cast_bool_to_numeric(int out_type, const uint8_t* bits, int64_t off, int64_t n, void* out);
+
 /* ---- fused Compare(>) → Filter → Sum (the unfused chain, restated) ---- */
 int orc_cmp_filter_sum_i64(int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n,
                            int64_t threshold, int64_t* out_sum, int64_t* out_count);

@@ -74,6 +74,12 @@ class OracleBackend:
     def cumulative_sum(self, values, valid, off, start=None, skip_nulls=False, checked=False, misalign=0):
         return self.o.cumulative_sum(values, valid, off, start, skip_nulls, checked)
 
+    def cast_numeric(self, values, out_dtype, valid=None, off=0, allow_int_overflow=False, allow_float_truncate=False, misalign=0):
+        return self.o.cast_numeric(values, out_dtype, valid, off, allow_int_overflow, allow_float_truncate)
+
+    def cast_bool_to_numeric(self, bits, off, n, out_dtype):
+        return self.o.cast_bool_to_numeric(bits, off, n, out_dtype)
+
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
@@ -270,6 +276,28 @@ class HipBackend:
         out = ob.download(values.dtype, n, misalign * w)
         ov = ovb.download(np.uint8, (n + 7) // 8) if ovb is not None else None
         return STATUS_OK, out, ov, nulls
+
+    def cast_numeric(self, values, out_dtype, valid=None, off=0, allow_int_overflow=False, allow_float_truncate=False, misalign=0):
+        import arrow_go_amd as ah
+        values = np.ascontiguousarray(values)
+        od = np.dtype(out_dtype)
+        vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
+        ob = self.c.alloc(values.size * od.itemsize + 128)
+        ob.memset(0xCD)
+        try:
+            self.c.cast_numeric(OL.TYPE_IDS[values.dtype], OL.TYPE_IDS[od], vp, vvp, off, values.size, allow_int_overflow,
+                                allow_float_truncate, ob.ptr + misalign * od.itemsize)
+        except ah.ErrInvalid as e:
+            return STATUS_EINVALID, None, str(e)
+        return STATUS_OK, ob.download(od, values.size, misalign * od.itemsize), ""
+
+    def cast_bool_to_numeric(self, bits, off, n, out_dtype):
+        od = np.dtype(out_dtype)
+        bb, bp = self._upbits(bits)
+        ob = self.c.alloc(n * od.itemsize + 64)
+        ob.memset(0xCD)
+        self.c.cast_bool_to_numeric(OL.TYPE_IDS[od], bp, off, n, ob)
+        return ob.download(od, n)
 
     def hash_encode(self, keys, valid, off, encode_nulls):
         keys = np.ascontiguousarray(keys).view(np.uint64)

@@ -67,6 +67,8 @@ class Oracle:
             "orc_take_primitive": (it, [it, vp, vp, i64, i64, it, it, vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_filter_to_indices": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_cumulative_sum": (it, [it, vp, vp, i64, i64, vp, it, it, vp, vp, vp]),
+            "orc_cast_numeric": (it, [it, it, vp, vp, i64, i64, it, it, vp, vp, vp]),
+            "orc_cast_bool_to_numeric": (it, [it, vp, i64, i64, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -193,6 +195,23 @@ class Oracle:
                                          _p(out), _p(ov), _p(nulls))
         return st, out[:n], (ov[:(n + 7) // 8] if ov is not None else None), int(nulls[0])
 
+    # ---- cast ---------------------------------------------------------------------------
+    def cast_numeric(self, values, out_dtype, valid=None, off=0, allow_int_overflow=False, allow_float_truncate=False):
+        """→ (status, out, message)"""
+        values = np.ascontiguousarray(values)
+        out = np.zeros(max(values.size, 1), dtype=out_dtype)
+        bad = np.zeros(1, np.int64)
+        msg = C.create_string_buffer(256)
+        st = self.lib.orc_cast_numeric(TYPE_IDS[values.dtype], TYPE_IDS[np.dtype(out_dtype)], _p(values), _p(valid), off, values.size,
+                                       int(allow_int_overflow), int(allow_float_truncate), _p(out), _p(bad), msg)
+        return st, out[:values.size], msg.value.decode()
+
+    def cast_bool_to_numeric(self, bits, off, n, out_dtype):
+        out = np.zeros(max(n, 1), dtype=out_dtype)
+        st = self.lib.orc_cast_bool_to_numeric(TYPE_IDS[np.dtype(out_dtype)], _p(bits), off, n, _p(out))
+        assert st == 0, st
+        return out[:n]
+
     # ---- hashing ------------------------------------------------------------------------
     def hash_int(self, v, alg=0): return int(self.lib.orc_hash_int(int(v) & (2**64 - 1), alg))
 
@@ -271,6 +290,16 @@ class Reference:
         f.restype = None
         f.argtypes = [C.c_int, C.c_int8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         f(TYPE_IDS[arr.dtype], op, _p(l), _p(r), _p(out), arr.size)
+        return out
+
+    def cast_numeric(self, a, out_dtype):
+        """cast_type_numeric_avx2 (kernels/_lib/cast_numeric.cc:62): the unchecked conversion"""
+        a = np.ascontiguousarray(a)
+        out = np.zeros(a.size, dtype=out_dtype)
+        f = self.avx2.cast_type_numeric_avx2
+        f.restype = None
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        f(TYPE_IDS[a.dtype], TYPE_IDS[np.dtype(out_dtype)], _p(a), _p(out), a.size)
         return out
 
     def arithmetic_unary(self, op, a):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_lib as OL
-from tests.backends import OracleBackend, HipBackend, STATUS_OK, STATUS_EINDEX, STATUS_EOVERFLOW
+from tests.backends import OracleBackend, HipBackend, STATUS_OK, STATUS_EINVALID, STATUS_EINDEX, STATUS_EOVERFLOW
 
 ADD, SUB, MUL, ABS, NEG, SIGN = 0, 1, 2, 4, 5, 20
 ADD_C, SUB_C, MUL_C = 21, 22, 23
@@ -680,3 +680,104 @@ def test_cumulative_sum_checked_integer_boundaries(be, dtype):
         # leaves the range and comes back: still an overflow (the reference stops at the first one)
         assert run_cumsum(be, dtype, [hi, 1, -5], checked=True)[0] == STATUS_EOVERFLOW
         assert run_cumsum(be, dtype, [hi, -5, 1], checked=True) == (STATUS_OK, [hi, hi - 5, hi - 4])
+
+
+# ---- numeric cast --------------------------------------------------------------------------
+# arrow/compute/cast_test.go
+def run_cast(be, in_dtype, out_dtype, vals, safe=True, allow_int_overflow=False, allow_float_truncate=False, sl=None):
+    arr, valid = mk(vals, in_dtype, null_fill=0)
+    lo, hi = sl if sl else (0, len(vals))
+    st, out, msg = be.cast_numeric(arr[lo:hi], out_dtype, valid, lo, allow_int_overflow or not safe, allow_float_truncate or not safe)
+    if st != STATUS_OK:
+        return st, msg
+    return st, logical(out, valid, lo, hi - lo)  # NullIntersection: the output validity IS the input validity
+
+
+def test_cast_int_upcast(be):
+    # TestToIntUpcast :483-489
+    assert run_cast(be, np.int8, np.int32, [0, None, 127, -1, 0]) == (STATUS_OK, [0, None, 127, -1, 0])
+    assert run_cast(be, np.uint8, np.int16, [0, 100, 200, 255, 0]) == (STATUS_OK, [0, 100, 200, 255, 0])
+
+
+def test_cast_int_downcast_safe(be):
+    # TestToIntDowncastSafe :491-518
+    assert run_cast(be, np.int16, np.uint8, [0, None, 200, 1, 2]) == (STATUS_OK, [0, None, 200, 1, 2])
+    assert run_cast(be, np.int16, np.uint8, [0, None, 256, 0, 0]) == (STATUS_EINVALID, "integer value 256 not in range: 0 to 255")
+    assert run_cast(be, np.int16, np.uint8, [0, None, -1, 0, 0]) == (STATUS_EINVALID, "integer value -1 not in range: 0 to 255")
+    assert run_cast(be, np.int32, np.int16, [0, None, 2000, 1, 2]) == (STATUS_OK, [0, None, 2000, 1, 2])
+    assert run_cast(be, np.int32, np.int16, [0, None, 2000, 70000, 2]) == (STATUS_EINVALID, "integer value 70000 not in range: -32768 to 32767")
+    assert run_cast(be, np.int32, np.int16, [0, None, 2000, -70000, 2])[0] == STATUS_EINVALID
+    assert run_cast(be, np.int32, np.uint8, [0, None, 2000, -70000, 2]) == (STATUS_EINVALID, "integer value 2000 not in range: 0 to 255")
+
+
+def test_cast_integer_signed_to_unsigned(be):
+    # TestIntegerSignedToUnsigned :520-552
+    i32 = [-2147483648, None, -1, 65535, 2147483647]
+    for to in (np.uint32, np.uint64, np.uint16):
+        assert run_cast(be, np.int32, to, i32)[0] == STATUS_EINVALID
+    assert run_cast(be, np.int32, np.uint32, i32, allow_int_overflow=True) == (STATUS_OK, [2147483648, None, 4294967295, 65535, 2147483647])
+    assert run_cast(be, np.int32, np.uint64, i32, allow_int_overflow=True) == \
+        (STATUS_OK, [18446744071562067968, None, 18446744073709551615, 65535, 2147483647])
+    i32 = [0, None, 0, 65536, 2147483647]
+    assert run_cast(be, np.int32, np.uint16, i32) == (STATUS_EINVALID, "integer value 65536 not in range: 0 to 65535")
+    assert run_cast(be, np.int32, np.uint16, i32, allow_int_overflow=True) == (STATUS_OK, [0, None, 0, 0, 65535])
+
+
+def test_cast_integer_unsigned_to_signed(be):
+    # TestIntegerUnsignedToSigned :554-571
+    u32 = [4294967295, None, 0, 32768]
+    assert run_cast(be, np.uint32, np.int32, u32) == (STATUS_EINVALID, "integer value 4294967295 not in range: 0 to 2147483647")
+    assert run_cast(be, np.uint32, np.int16, u32)[0] == STATUS_EINVALID
+    assert run_cast(be, np.uint32, np.int16, u32, sl=(1, 4)) == (STATUS_EINVALID, "integer value 32768 not in range: 0 to 32767")
+    assert run_cast(be, np.uint32, np.int32, u32, allow_int_overflow=True) == (STATUS_OK, [-1, None, 0, 32768])
+    assert run_cast(be, np.uint32, np.int64, u32, allow_int_overflow=True) == (STATUS_OK, [4294967295, None, 0, 32768])
+    assert run_cast(be, np.uint32, np.int16, u32, allow_int_overflow=True) == (STATUS_OK, [-1, None, 0, -32768])
+
+
+def test_cast_int_downcast_unsafe(be):
+    # TestToIntDowncastUnsafe :573-586
+    u = dict(allow_int_overflow=True)
+    assert run_cast(be, np.int16, np.uint8, [0, None, 200, 1, 2], **u) == (STATUS_OK, [0, None, 200, 1, 2])
+    assert run_cast(be, np.int16, np.uint8, [0, None, 256, 1, 2, -1], **u) == (STATUS_OK, [0, None, 0, 1, 2, 255])
+    assert run_cast(be, np.int32, np.int16, [0, None, 2000, 1, 2, -1], **u) == (STATUS_OK, [0, None, 2000, 1, 2, -1])
+    assert run_cast(be, np.int32, np.int16, [0, None, 2000, 70000, -70000], **u) == (STATUS_OK, [0, None, 2000, 4464, -4464])
+
+
+@pytest.mark.parametrize("frm", [np.float32, np.float64], ids=str)
+@pytest.mark.parametrize("to", [np.int32, np.int64], ids=str)
+def test_cast_floating_to_int(be, frm, to):
+    # TestFloatingToInt :588-603
+    assert run_cast(be, frm, to, [1.0, None, 0.0, -1.0, 5.0]) == (STATUS_OK, [1, None, 0, -1, 5])
+    assert run_cast(be, frm, to, [1.5, 0.0, None, 0.5, -1.5, 5.5]) == \
+        (STATUS_EINVALID, "float value 1.500000 was truncated converting to " + np.dtype(to).name)
+    assert run_cast(be, frm, to, [1.5, 0.0, None, 0.5, -1.5, 5.5], allow_float_truncate=True) == (STATUS_OK, [1, 0, None, 0, -1, 5])
+
+
+def test_cast_int_to_floating(be):
+    # TestIntToFloating :611-629
+    for frm in (np.uint32, np.int32):
+        assert run_cast(be, frm, np.float32, [16777216, 16777217])[0] == STATUS_EINVALID
+        assert run_cast(be, frm, np.float32, [16777216]) == (STATUS_OK, [16777216.0])
+    i64 = [-9223372036854775808, -9223372036854775807, 0, 9223372036854775806, 9223372036854775807]
+    assert run_cast(be, np.int64, np.float64, i64) == \
+        (STATUS_EINVALID, "integer value -9223372036854775808 not in range: -9007199254740992 to 9007199254740992")
+    # masked: the offenders are null → the cast succeeds (maskArrayWithNullsAt {0,1,3,4})
+    arr = np.array(i64, np.int64)
+    valid = OL.pack_bits([False, False, True, False, False])
+    st, out, _ = be.cast_numeric(arr, np.float64, valid, 0, False, False)
+    assert st == STATUS_OK and out[2] == 0.0
+    assert run_cast(be, np.uint64, np.float64, [9007199254740992, 9007199254740993]) == \
+        (STATUS_EINVALID, "integer value 9007199254740993 not in range: 0 to 9007199254740992")
+    # small integers never need the check (checkIntToFloatTrunc :700-703), int32 → float64 neither
+    assert run_cast(be, np.int16, np.float32, [-32768, 32767]) == (STATUS_OK, [-32768.0, 32767.0])
+    assert run_cast(be, np.int32, np.float64, [-2147483648, 2147483647]) == (STATUS_OK, [-2147483648.0, 2147483647.0])
+
+
+def test_cast_float_to_float_and_bool(be):
+    assert run_cast(be, np.float64, np.float32, [1.5, None, 0.1, -2.5e-50, 1e300]) == \
+        (STATUS_OK, [1.5, None, float(np.float32(0.1)), -0.0, float("inf")])
+    assert run_cast(be, np.float32, np.float64, [1.5, None, 3.25]) == (STATUS_OK, [1.5, None, 3.25])
+    # boolToNum (numeric_cast.go:555-569)
+    bits = OL.pack_bits([False, False, True, True, False, True, False, False, True, True, True])
+    for dt in OL.ALL_DTYPES:
+        assert be.cast_bool_to_numeric(bits, 2, 9, dt).tolist() == [1, 1, 0, 1, 0, 0, 1, 1, 1]

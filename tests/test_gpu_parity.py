@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_lib as OL
-from tests.backends import OracleBackend, HipBackend, STATUS_OK, STATUS_EINDEX
+from tests.backends import OracleBackend, HipBackend, STATUS_OK, STATUS_EINVALID, STATUS_EINDEX
 
 pytestmark = pytest.mark.gpu
 
@@ -492,6 +492,103 @@ def test_cumulative_sum_many_tiles(hip, orc_be):
     xf = (rng.standard_normal((1 << 23) + 7) * 1e3)
     runs = [hip.cumulative_sum(xf, None, 0, None, False, False)[1].tobytes() for _ in range(3)]
     assert runs[0] == runs[1] == runs[2]
+
+
+# ---- numeric cast --------------------------------------------------------------------------
+CAST_SIZES = [1, 3, 15, 17, 63, 65, 1023, 1025, 4097, 16385, 70001, 300007]
+
+
+def cast_input(rng, frm, to, n, in_range):
+    fd, td = np.dtype(frm), np.dtype(to)
+    if fd.kind == "f" and td.kind != "f":
+        if in_range:
+            info = np.iinfo(td)
+            a = np.trunc(rng.uniform(max(float(info.min), -2.0**52), min(float(info.max), 2.0**52), n)).astype(fd)
+            hi = fd.type(float(info.max)) if float(fd.type(float(info.max))) <= float(info.max) else np.nextafter(fd.type(float(info.max)), fd.type(0))
+            return np.clip(a, fd.type(float(info.min)), hi)
+        a = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 25, n)).astype(fd)
+        if n > 8:
+            a[rng.integers(0, n, 4)] = [np.nan, np.inf, -np.inf, -0.0]
+        return a
+    if fd.kind != "f" and in_range:  # values every target can hold
+        return rng.integers(0, 100, n).astype(fd)
+    return rand(rng, frm, n)
+
+
+@pytest.mark.parametrize("frm", OL.ALL_DTYPES, ids=str)
+def test_cast_unchecked_bit_exact(hip, orc_be, frm):
+    """allow_int_overflow + allow_float_truncate: every slot converted, bit-exact against the oracle for
+    all 9 targets — wraparound, sign extension, round-to-nearest-even int → float and f64 → f32, and the
+    stated float → int rule (truncate into 64 bits saturating, NaN → 0, keep the low bits)."""
+    rng = np.random.default_rng(4000 + OL.TYPE_IDS[np.dtype(frm)])
+    for to in OL.ALL_DTYPES:
+        if to == frm:
+            continue
+        for k, n in enumerate(CAST_SIZES):
+            a = cast_input(rng, frm, to, n, in_range=False)
+            st_e, e, _ = orc_be.cast_numeric(a, to, None, 0, True, True)
+            st_g, g, _ = hip.cast_numeric(a, to, None, 0, True, True, misalign=k % 3)
+            assert st_e == st_g == STATUS_OK
+            assert same_bits_or_both_nan(g, e), (frm, to, n)
+
+
+@pytest.mark.parametrize("frm", OL.ALL_DTYPES, ids=str)
+def test_cast_safe_parity(hip, orc_be, frm):
+    """safe casts: same values when nothing fails; the same FIRST offender and the reference's message
+    when something does; offenders under null slots never fail."""
+    rng = np.random.default_rng(5000 + OL.TYPE_IDS[np.dtype(frm)])
+    n_fail = 0
+    for to in OL.ALL_DTYPES:
+        if to == frm:
+            continue
+        for k, n in enumerate(CAST_SIZES):
+            ok_in = cast_input(rng, frm, to, n, in_range=True)
+            st_e, e, _ = orc_be.cast_numeric(ok_in, to)
+            st_g, g, _ = hip.cast_numeric(ok_in, to, misalign=k % 2)
+            assert st_e == st_g == STATUS_OK, (frm, to, n)
+            assert g.tobytes() == e.tobytes(), (frm, to, n)
+            # now with offenders: under nulls → still fine; one valid offender → the same error text
+            bad_in = cast_input(rng, frm, to, n, in_range=False)
+            off = int(rng.integers(0, 9))
+            st_all, _, msg_all = orc_be.cast_numeric(bad_in, to)
+            if st_all == STATUS_OK:
+                continue
+            # find the offending rows through the oracle: null them all → success
+            flags = np.ones(n, bool)
+            pos = []
+            while True:
+                bits = OL.pack_bits([True] * off + flags.tolist())
+                st_e, e, msg = orc_be.cast_numeric(bad_in, to, bits, off)
+                if st_e == STATUS_OK or len(pos) > 3:
+                    break
+                # the message names the value; mask the first row holding an offender by bisection on prefixes
+                lo_, hi_ = 0, n
+                while hi_ - lo_ > 1:
+                    mid = (lo_ + hi_) // 2
+                    f2 = flags.copy(); f2[mid:] = False
+                    st_m, _, _ = orc_be.cast_numeric(bad_in, to, OL.pack_bits([True] * off + f2.tolist()), off)
+                    if st_m == STATUS_OK:
+                        lo_ = mid
+                    else:
+                        hi_ = mid
+                pos.append(lo_)
+                st_g, g, msg_g = hip.cast_numeric(bad_in, to, bits, off)
+                assert st_g == STATUS_EINVALID and msg_g.endswith(msg), (frm, to, n, msg_g, msg)
+                n_fail += 1
+                flags[lo_] = False
+            if st_e == STATUS_OK:
+                st_g, g, _ = hip.cast_numeric(bad_in, to, bits, off)
+                assert st_g == STATUS_OK and same_bits_or_both_nan(g, e), (frm, to, n)
+    assert n_fail > 0
+
+
+def test_cast_bool_to_numeric_random(hip, orc_be):
+    rng = np.random.default_rng(6000)
+    for n in (1, 7, 64, 65, 1000, 70001):
+        off = int(rng.integers(0, 70))
+        bits = OL.pack_bits(list(rng.random(off + n) < 0.5))
+        for dt in OL.ALL_DTYPES:
+            assert hip.cast_bool_to_numeric(bits, off, n, dt).tobytes() == orc_be.cast_bool_to_numeric(bits, off, n, dt).tobytes()
 
 
 # ---- full-size properties (BASELINE.json configs; no oracle pass needed) -------------------

@@ -104,3 +104,40 @@ def test_bitmap_aligned_matches_reference_avx2(o, op):
         exp = ref.bitmap_aligned(op, l, r)
         got = o.bitmap_op(op, l, 0, r, 0, np.zeros(nbytes, np.uint8), 0, nbytes * 8)
         assert got.tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("frm", OL.ALL_DTYPES, ids=str)
+@pytest.mark.parametrize("to", OL.ALL_DTYPES, ids=str)
+def test_cast_matches_reference_avx2(o, frm, to):
+    """cast_type_numeric_avx2 is static_cast per element.  Integer inputs and float → float: every
+    value, bit for bit.  Float → int: only values the target can hold — beyond that static_cast is
+    undefined and the reference's own machine code disagrees with itself (see the next test)."""
+    if frm == to:
+        pytest.skip("identity")
+    rng = np.random.default_rng(OL.TYPE_IDS[np.dtype(frm)] * 16 + OL.TYPE_IDS[np.dtype(to)])
+    fd, td = np.dtype(frm), np.dtype(to)
+    for n in [0, 1, 3, 15, 16, 17, 33, 64, 1000]:
+        if fd.kind == "f" and td.kind != "f":
+            info = np.iinfo(td)
+            lo, hi = max(float(info.min), -2.0**31 + 1024), min(float(info.max), 2.0**31 - 1024)
+            a = rng.uniform(lo, hi, n).astype(fd)
+            a = np.clip(a, fd.type(lo), fd.type(hi))
+        else:
+            a = rand(rng, frm, n)
+        st, got, _ = o.cast_numeric(a, to, None, 0, True, True)
+        assert st == 0
+        exp = ref.cast_numeric(a, to)
+        if td.kind == "f":
+            nan = np.isnan(exp)
+            assert np.array_equal(np.isnan(got), nan)
+            assert got[~nan].tobytes() == exp[~nan].tobytes(), (frm, to, n)
+        else:
+            assert got.tobytes() == exp.tobytes(), (frm, to, n)
+
+
+def test_reference_float_to_narrow_int_out_of_range_is_inconsistent():
+    """Why out-of-range float → int is not pinned: the reference's AVX2 kernel SATURATES in its
+    vector body (packus/packss) and WRAPS in its scalar tail — same call, same value, two answers."""
+    a = np.full(40, 300.0, np.float32)
+    out = ref.cast_numeric(a, np.uint8)
+    assert set(out.tolist()) == {255, 44}, out
