@@ -14,7 +14,8 @@
 // row (atomicMin on its index; failures are the rare path) with the reference's message.
 //
 // float → int for values the target cannot hold is undefined in C++ and implementation-specific in
-// Go; the reference stores whatever the CPU produced.  The rule here (same as oracle/orc_cast.c):
+// Go; the reference stores whatever the CPU produced (its AVX2 kernel saturates in the vector body and
+// wraps in the scalar tail).  The rule here (the CPU checker restates the same one):
 // truncate toward zero into 64 bits, saturating, NaN → 0, then keep the low bits — identical to
 // x86 for every |v| < 2^31 and for everything a 64-bit target can hold.
 #include "ah_cast_impl.h"

@@ -16,6 +16,33 @@ struct alignas(sizeof(T)) VecE {
   T v[E];
 };
 
+// raw carrier of N bytes for nontemporal accesses (the column is streamed once; keep it out of L2)
+template <int N> struct Raw;
+template <> struct Raw<1> { using type = uint8_t; };
+template <> struct Raw<2> { using type = uint16_t; };
+template <> struct Raw<4> { using type = uint32_t; };
+template <> struct Raw<8> { using type = uint64_t; };
+template <> struct Raw<16> { typedef unsigned type __attribute__((ext_vector_type(4))); };
+
+template <typename V, bool NT>
+__device__ __forceinline__ V load_vec(const void* p) {
+  if constexpr (NT) {
+    using R = typename Raw<sizeof(V)>::type;
+    return __builtin_bit_cast(V, __builtin_nontemporal_load((const R*)p));
+  } else {
+    return *(const V*)p;
+  }
+}
+template <typename V, bool NT>
+__device__ __forceinline__ void store_vec(void* p, const V& v) {
+  if constexpr (NT) {
+    using R = typename Raw<sizeof(V)>::type;
+    __builtin_nontemporal_store(__builtin_bit_cast(R, v), (R*)p);
+  } else {
+    *(V*)p = v;
+  }
+}
+
 template <typename OUT>
 __device__ __forceinline__ OUT float_to_int(double v) {
   unsigned long long bits;
@@ -55,7 +82,8 @@ __device__ __forceinline__ bool is_bad(IN v, IN lo, IN hi) {
   }
 }
 
-template <typename IN, typename OUT, int CHK>
+// NT: both buffers are aligned to their per-lane vector → nontemporal vector accesses
+template <typename IN, typename OUT, int CHK, bool NT>
 __global__ __launch_bounds__(kBlock) void cast_kernel(const IN* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
                                                        OUT* __restrict__ out, IN lo, IN hi, unsigned long long* __restrict__ first_bad) {
   constexpr int W = sizeof(IN) > sizeof(OUT) ? sizeof(IN) : sizeof(OUT);
@@ -68,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const IN* __restrict__ in,
   for (int k = 0; k < kUnroll; k++) {
     const int64_t e0 = (j0 + (int64_t)k * kBlock) * E;
     if (e0 + E <= n) {
-      x[k] = *(const VI*)(in + e0);
+      x[k] = load_vec<VI, NT>(in + e0);
     } else {
 #pragma unroll
       for (int e = 0; e < E; e++) x[k].v[e] = e0 + e < n ? in[e0 + e] : (IN)0;
@@ -96,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void cast_kernel(const IN* __restrict__ in,
       }
     }
     if (e0 + E <= n) {
-      *(VO*)(out + e0) = o;
+      store_vec<VO, NT>(out + e0, o);
     } else {
 #pragma unroll
       for (int e = 0; e < E; e++) if (e0 + e < n) out[e0 + e] = o.v[e];
@@ -117,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void bool_to_num_kernel(const uint8_t* __re
 #pragma unroll
   for (int e = 0; e < E; e++) o.v[e] = (b >> e) & 1u ? (OUT)1 : (OUT)0;
   if (cnt == E) {
-    *(VO*)(out + e0) = o;
+    if (((uintptr_t)(out + e0) & 15) == 0) store_vec<VO, true>(out + e0, o);
+    else *(VO*)(out + e0) = o;
   } else {
     for (int e = 0; e < cnt; e++) out[e0 + e] = o.v[e];
   }
@@ -128,8 +157,11 @@ int launch_cast(ah_ctx* c, const void* in, const uint8_t* valid, int64_t off, in
   constexpr int W = sizeof(IN) > sizeof(OUT) ? sizeof(IN) : sizeof(OUT);
   constexpr int E = 16 / W;
   const int64_t per_block = (int64_t)kBlock * kUnroll * E;
-  cast_kernel<IN, OUT, CHK><<<(unsigned)ah_ceil_div(n, per_block), kBlock, 0, c->stream>>>((const IN*)in, valid, off, n, (OUT*)out, lo, hi,
-                                                                                           (unsigned long long*)&c->dscalars[12]);
+  const unsigned grid = (unsigned)ah_ceil_div(n, per_block);
+  unsigned long long* first_bad = (unsigned long long*)&c->dscalars[12];
+  const bool nt = c->tune_nt && ((uintptr_t)in % (E * sizeof(IN))) == 0 && ((uintptr_t)out % (E * sizeof(OUT))) == 0;
+  if (nt) cast_kernel<IN, OUT, CHK, true><<<grid, kBlock, 0, c->stream>>>((const IN*)in, valid, off, n, (OUT*)out, lo, hi, first_bad);
+  else cast_kernel<IN, OUT, CHK, false><<<grid, kBlock, 0, c->stream>>>((const IN*)in, valid, off, n, (OUT*)out, lo, hi, first_bad);
   AH_LAUNCH_CHECK(c);
   return AH_OK;
 }

@@ -197,6 +197,19 @@ struct FilterOptions : FunctionOptions { NullSelectionBehavior NullSelection = D
 struct TakeOptions : FunctionOptions { bool BoundsCheck = true; const char* TypeName() const override { return "TakeOptions"; } };
 enum NullEncodingBehavior { NullEncodingMask = 0, NullEncodingEncode = 1 };
 struct DictionaryEncodeOptions : FunctionOptions { NullEncodingBehavior NullEncoding = NullEncodingMask; const char* TypeName() const override { return "DictionaryEncodeOptions"; } };
+// kernels.CastOptions (kernels/cast.go:27-35); NewCastOptions(dt, safe) / SafeCastOptions / UnsafeCastOptions (compute/cast.go)
+struct CastOptions : FunctionOptions {
+  const DataType* ToType = nullptr;
+  bool AllowIntOverflow = false, AllowTimeTruncate = false, AllowTimeOverflow = false, AllowDecimalTruncate = false,
+       AllowFloatTruncate = false, AllowInvalidUtf8 = false;
+  const char* TypeName() const override { return "CastOptions"; }
+  static CastOptions Safe(const DataType* to) { CastOptions o; o.ToType = to; return o; }
+  static CastOptions Unsafe(const DataType* to) {
+    CastOptions o; o.ToType = to;
+    o.AllowIntOverflow = o.AllowTimeTruncate = o.AllowTimeOverflow = o.AllowDecimalTruncate = o.AllowFloatTruncate = o.AllowInvalidUtf8 = true;
+    return o;
+  }
+};
 // kernels.CumulativeOptions (vector_cumulative.go:30-39): nil Start = zero of the input type
 struct CumulativeOptions : FunctionOptions { ScalarPtr Start; bool SkipNulls = false; const char* TypeName() const override { return "CumulativeOptions"; } };
 struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
@@ -254,6 +267,11 @@ class ScalarFunction : public Function {  // functions.go:239-290
   Status Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) override;
   // set for "less"/"less_equal": swap the two arguments and run `flipped` (scalar_compare.go:73-99)
   std::string flipped_of;
+  // arithmeticFunction.DispatchBest (arithmetic.go:112-142) / compareFunction.DispatchBest
+  // (scalar_compare.go:37-63): when no kernel matches exactly, both arguments are promoted to
+  // commonNumeric (utils.go:178-240) and implicitly SAFE-cast (exec.go:105-114)
+  bool promote_numeric = false;
+  Status DispatchBest(std::vector<const DataType*>* types, const exec::ScalarKernel** out) const;
  private:
   std::vector<exec::ScalarKernel> kernels_;
 };
@@ -306,6 +324,10 @@ void RegisterScalarArithmetic(FunctionRegistry* reg);
 void RegisterScalarComparisons(FunctionRegistry* reg);
 void RegisterScalarBoolean(FunctionRegistry* reg);
 void RegisterVectorCumulative(FunctionRegistry* reg);
+void RegisterScalarCast(FunctionRegistry* reg);
+const DataType* CommonNumeric(const std::vector<const DataType*>& types);  // utils.go:178-240; nullptr if none
+// compute.CastDatum / CastArray (cast.go:917-935)
+Status CastDatum(ExecCtx* ctx, const Datum& in, const CastOptions& opts, Datum* out);
 void RegisterVectorSelection(FunctionRegistry* reg);
 void RegisterVectorHash(FunctionRegistry* reg);
 void RegisterFusedExtensions(FunctionRegistry* reg);

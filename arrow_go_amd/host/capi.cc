@@ -149,12 +149,14 @@ AHC_EXPORT int ahc_datum_info(ahc_datum* d, int* kind, int* type_id, int64_t* le
 
 // options: "key=value;key=value"; keys follow the Go struct tags
 //   null_selection_behavior=drop|emit_null   bounds_check=0|1   null_encoding_behavior=mask|encode
+//   to_type=<type>   safe=0|1   allow_int_overflow=0|1   allow_float_truncate=0|1       (CastOptions)
 //   skip_nulls=0|1   start=<type>:<value>|null:<type>   (e.g. start=int64:10, start=double:1.5, start=null:int32)
 struct ParsedOptions {
   compute::FilterOptions filter;
   compute::TakeOptions take;
   compute::DictionaryEncodeOptions dict;
   compute::CumulativeOptions cumulative;
+  compute::CastOptions cast;
   const compute::FunctionOptions* pick = nullptr;
 };
 static const struct { const char* name; Type id; } kTypeNames[] = {
@@ -197,6 +199,14 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
       std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
       if (k == "null_selection_behavior") { p->filter.NullSelection = v == "emit_null" ? compute::EmitNulls : compute::DropNulls; p->pick = &p->filter; }
       if (k == "bounds_check") { p->take.BoundsCheck = v != "0"; p->pick = &p->take; }
+      if (k == "to_type") {
+        p->cast.ToType = v == "bool" ? GetDataType(Type::BOOL) : nullptr;
+        for (auto& tn : kTypeNames) if (v == tn.name) p->cast.ToType = GetDataType(tn.id);
+        p->pick = &p->cast;
+      }
+      if (k == "safe" && v == "0") { const DataType* t = p->cast.ToType; p->cast = compute::CastOptions::Unsafe(t); p->pick = &p->cast; }
+      if (k == "allow_int_overflow") { p->cast.AllowIntOverflow = v != "0"; p->pick = &p->cast; }
+      if (k == "allow_float_truncate") { p->cast.AllowFloatTruncate = v != "0"; p->pick = &p->cast; }
       if (k == "skip_nulls") { p->cumulative.SkipNulls = v != "0"; p->pick = &p->cumulative; }
       if (k == "start") { p->cumulative.Start = ParseScalarText(v); p->pick = &p->cumulative; }
       if (k == "null_encoding_behavior") { p->dict.NullEncoding = v == "encode" ? compute::NullEncodingEncode : compute::NullEncodingMask; p->pick = &p->dict; }

@@ -2,6 +2,7 @@
 // Mirrors arrow/compute/{registry.go, functions.go, exec.go, executor.go}; every
 // non-trivial rule cites the line it restates.  No arithmetic on the host: null
 // propagation, popcounts and fills are enqueued on the GPU through include/arrowhip.h.
+#include <algorithm>
 #include "arrowhip_compute.h"
 
 #include <cstring>
@@ -257,7 +258,14 @@ Status ScalarFunction::Execute(ExecCtx* ctx, const FunctionOptions* opts, const 
   std::vector<const DataType*> types;
   AHC_RETURN_NOT_OK(ArgTypes(args, &types));
   const exec::ScalarKernel* kernel = nullptr;
-  AHC_RETURN_NOT_OK(DispatchExact(types, &kernel));
+  AHC_RETURN_NOT_OK(DispatchBest(&types, &kernel));
+  // cast arguments if necessary (execInternal, exec.go:105-114): implicit casts are SAFE casts
+  for (size_t i = 0; i < args.size(); i++) {
+    if (args[i].type()->id == types[i]->id) continue;
+    Datum casted;
+    AHC_RETURN_NOT_OK(CastDatum(ctx, args[i], CastOptions::Safe(types[i]), &casted));
+    args[i] = casted;
+  }
 
   // inferBatchLength (executor.go:352-390): arrays must agree; all scalars → length 1
   int64_t length = -1;
@@ -340,6 +348,49 @@ Status ScalarFunction::Execute(ExecCtx* ctx, const FunctionOptions* opts, const 
     *out = Datum::Of(result);
   }
   return Status::OK();
+}
+
+// commonNumeric (compute/utils.go:178-240)
+const DataType* CommonNumeric(const std::vector<const DataType*>& types) {
+  for (auto* t : types)
+    if (!IsInteger(t->id) && !IsFloating(t->id)) return nullptr;
+  for (auto* t : types) if (t->id == Type::FLOAT64) return GetDataType(Type::FLOAT64);
+  for (auto* t : types) if (t->id == Type::FLOAT32) return GetDataType(Type::FLOAT32);
+  int max_signed = 0, max_unsigned = 0;
+  for (auto* t : types) {
+    if (IsSignedInteger(t->id)) max_signed = std::max(max_signed, t->bit_width);
+    else max_unsigned = std::max(max_unsigned, t->bit_width);
+  }
+  if (max_signed == 0) {
+    if (max_unsigned >= 64) return GetDataType(Type::UINT64);
+    if (max_unsigned == 32) return GetDataType(Type::UINT32);
+    if (max_unsigned == 16) return GetDataType(Type::UINT16);
+    return GetDataType(Type::UINT8);
+  }
+  if (max_signed <= max_unsigned) {  // bitutil.NextPowerOf2(maxWidthUnsigned + 1)
+    int w = 8;
+    while (w < max_unsigned + 1) w *= 2;
+    max_signed = w;
+  }
+  if (max_signed >= 64) return GetDataType(Type::INT64);
+  if (max_signed == 32) return GetDataType(Type::INT32);
+  if (max_signed == 16) return GetDataType(Type::INT16);
+  return GetDataType(Type::INT8);
+}
+
+Status ScalarFunction::DispatchBest(std::vector<const DataType*>* types, const exec::ScalarKernel** out) const {
+  Status st = DispatchExact(*types, out);
+  if (st.ok() || !promote_numeric || types->size() != 2) return st;
+  if (const DataType* common = CommonNumeric(*types)) {
+    std::vector<const DataType*> promoted(types->size(), common);
+    Status st2 = DispatchExact(promoted, out);
+    if (st2.ok()) { *types = promoted; return st2; }
+  }
+  return st;
+}
+
+Status CastDatum(ExecCtx* ctx, const Datum& in, const CastOptions& opts, Datum* out) {
+  return CallFunction(ctx, "cast", &opts, {in}, out);
 }
 
 // ---- VectorFunction ------------------------------------------------------------------------
@@ -446,6 +497,7 @@ FunctionRegistry* GetFunctionRegistry() {
     RegisterVectorSelection(r);
     RegisterVectorHash(r);
     RegisterVectorCumulative(r);
+    RegisterScalarCast(r);
     RegisterFusedExtensions(r);
     return r;
   }();

@@ -84,6 +84,7 @@ static std::shared_ptr<ScalarFunction> MakeArith(const std::string& name, int op
                         : exec::ArrayKernelExec([op](KernelCtx* c, const ExecSpan& b, ExecResult* o) { return ExecArithUnchecked(c, b, o, op); });
     fn->AddKernel(std::move(k));
   }
+  fn->promote_numeric = true;  // arithmeticFunction.DispatchBest (arithmetic.go:112-142)
   return fn;
 }
 
@@ -136,6 +137,7 @@ void RegisterScalarComparisons(FunctionRegistry* reg) {
       k.exec_fn = [op](KernelCtx* kc, const ExecSpan& b, ExecResult* o) { return ExecCompare(kc, b, o, op); };
       fn->AddKernel(std::move(k));
     }
+    fn->promote_numeric = true;  // compareFunction.DispatchBest (scalar_compare.go:37-63)
     reg->AddFunction(fn, false);
   }
   // scalar_compare.go:73-99: less / less_equal = flipped greater / greater_equal
@@ -392,6 +394,94 @@ void RegisterVectorHash(FunctionRegistry* reg) {
   }
   reg->AddFunction(uq, false);
   reg->AddFunction(de, false);
+}
+
+// ---- cast (numeric ↔ numeric, bool ↔ numeric) -------------------------------------------------------
+// CastIntToInt / CastFloatingToInteger / CastIntegerToFloating / CastFloatingToFloating
+// (kernels/numeric_cast.go:37-71): conversion and safe-cast check in one pass on the device
+static Status ExecCastNumeric(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  const CastOptions* opts = static_cast<const CastOptions*>(k->state);
+  const ArraySpan& in = b.values[0].array;
+  return s->FromStatus(ah_cast_numeric(s->ctx(), (int)in.type->id, (int)out->type->id, Values(in), in.MayHaveNulls() ? in.buffers[0].buf : nullptr,
+                                       in.offset, in.len, opts && opts->AllowIntOverflow, opts && opts->AllowFloatTruncate, Values(out)));
+}
+// boolToNum (numeric_cast.go:555-569)
+static Status ExecCastBoolToNumeric(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  const ArraySpan& in = b.values[0].array;
+  return s->FromStatus(ah_cast_bool_to_numeric(s->ctx(), (int)out->type->id, in.buffers[1].buf, in.offset, in.len, Values(out)));
+}
+// isNonZero (boolean_cast.go:30-36): v != 0 — the array∘scalar "not_equal" kernel
+static Status ExecCastNumericToBool(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  const ArraySpan& in = b.values[0].array;
+  alignas(8) uint8_t zero[8] = {0};
+  return s->FromStatus(ah_comparison(s->ctx(), AH_CMP_NE, AH_SHAPE_AS, (int)in.type->id, Values(in), zero, out->buffers[1].buf + out->offset / 8,
+                                     out->len, (int)(out->offset % 8)));
+}
+
+static const char* CastFunctionName(Type t) {
+  switch (t) {
+    case Type::BOOL: return "cast_boolean";
+    case Type::UINT8: return "cast_uint8"; case Type::INT8: return "cast_int8"; case Type::UINT16: return "cast_uint16";
+    case Type::INT16: return "cast_int16"; case Type::UINT32: return "cast_uint32"; case Type::INT32: return "cast_int32";
+    case Type::UINT64: return "cast_uint64"; case Type::INT64: return "cast_int64"; case Type::FLOAT32: return "cast_float";
+    case Type::FLOAT64: return "cast_double";
+    default: return nullptr;
+  }
+}
+
+// RegisterScalarCast (compute/cast.go:83-85) + the per-target cast functions getCastFunction resolves
+// (cast.go:190-260: "cast_int32" …), numeric and boolean targets
+void RegisterScalarCast(FunctionRegistry* reg) {
+  for (Type to : kNumericTypes) {
+    auto fn = std::make_shared<ScalarFunction>(CastFunctionName(to), Arity{1, false});
+    for (Type from : kNumericTypes) {
+      if (from == to) continue;
+      exec::ScalarKernel k;
+      k.sig.in_types = {from};
+      k.sig.out_is_first_input = false;
+      k.sig.out_type = to;
+      k.exec_fn = ExecCastNumeric;
+      fn->AddKernel(std::move(k));
+    }
+    exec::ScalarKernel kb;
+    kb.sig.in_types = {Type::BOOL};
+    kb.sig.out_is_first_input = false;
+    kb.sig.out_type = to;
+    kb.exec_fn = ExecCastBoolToNumeric;
+    fn->AddKernel(std::move(kb));
+    reg->AddFunction(fn, false);
+  }
+  auto fb = std::make_shared<ScalarFunction>(CastFunctionName(Type::BOOL), Arity{1, false});
+  for (Type from : kNumericTypes) {
+    exec::ScalarKernel k;
+    k.sig.in_types = {from};
+    k.sig.out_is_first_input = false;
+    k.sig.out_type = Type::BOOL;
+    k.exec_fn = ExecCastNumericToBool;
+    fb->AddKernel(std::move(k));
+  }
+  reg->AddFunction(fb, false);
+  // castMetaFunc (cast.go:45-81)
+  reg->AddFunction(std::make_shared<MetaFunction>("cast", Arity{1, false}, nullptr,
+      [](ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
+        const CastOptions* opts = dynamic_cast<const CastOptions*>(o);
+        if (!opts || !opts->ToType)
+          return Status::Make(StatusCode::Invalid, "cast requires that options be passed with a ToType");
+        if (args[0].type()->id == opts->ToType->id) { *out = args[0]; return Status::OK(); }  // TypeEqual → the input itself
+        const char* name = CastFunctionName(opts->ToType->id);
+        if (!name)
+          return Status::Make(StatusCode::NotImplemented, std::string("unsupported cast to ") + opts->ToType->name + " from " + args[0].type()->name);
+        Status st = CallFunction(ctx, name, o, args, out);
+        if (!st.ok() && st.code == StatusCode::NotImplemented)
+          return Status::Make(StatusCode::NotImplemented, std::string("unsupported cast to ") + opts->ToType->name + " from " + args[0].type()->name);
+        return st;
+      }), false);
 }
 
 // ---- cumulative_sum / cumulative_sum_checked ---------------------------------------------------

@@ -32,12 +32,13 @@ def test_registry_has_the_path_functions():
                  "abs_unchecked", "negate_unchecked", "sign", "equal", "not_equal", "greater", "greater_equal", "less",
                  "less_equal", "and", "or", "xor", "and_not", "invert", "and_kleene", "or_kleene", "and_not_kleene",
                  "filter", "array_filter", "take", "array_take", "unique", "dictionary_encode", "greater_filter_sum",
-                 "cumulative_sum", "cumulative_sum_checked"]:
+                 "cumulative_sum", "cumulative_sum_checked", "cast", "cast_int32", "cast_double", "cast_boolean"]:
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
     assert ac.function_num_kernels("array_take") == 80      # 10 value types × 8 index types
     assert ac.function_num_kernels("filter") == 0           # MetaFunction
+    assert ac.function_num_kernels("cast_int64") == 10       # 9 other numeric types + bool
     assert ac.function_num_kernels("cumulative_sum") == 10 and ac.function_num_kernels("cumulative_sum_checked") == 10
     assert ac.num_functions() >= 30
 
@@ -118,7 +119,7 @@ def test_dispatch_errors(sess):
     with pytest.raises(ac.ErrInvalid, match="same length"):                          # executor.go inferBatchLength
         sess.call_function("add", [pa.array([1, 2]), pa.array([1, 2, 3])])
     with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
-        sess.call_function("add", [pa.array([1], pa.int32()), pa.array([1], pa.int64())])  # implicit casts: out of scope
+        sess.call_function("abs_unchecked", [pa.array([True])])                       # functions.go:199-218 DispatchExact
 
 
 @pytest.mark.gpu
@@ -369,6 +370,130 @@ def test_cumulative_sum_random_vs_arrow_cpp(sess, typ):
         exp = pc.cumulative_sum(a, start=pa.scalar(3, typ), skip_nulls=skip)
         assert got.equals(exp), (typ, p_null, skip)
         assert got.null_count == exp.null_count
+
+
+# ---- cast + implicit numeric promotion (arrow/compute/cast_test.go, arithmetic.go DispatchBest) -----------
+_PA = {"uint8": pa.uint8(), "int8": pa.int8(), "uint16": pa.uint16(), "int16": pa.int16(), "uint32": pa.uint32(), "int32": pa.int32(),
+       "uint64": pa.uint64(), "int64": pa.int64(), "float": pa.float32(), "double": pa.float64(), "bool": pa.bool_()}
+
+
+def _tname(t):
+    return [k for k, v in _PA.items() if v == t][0]
+
+
+@pytest.mark.gpu
+def test_cast_reference_tables(sess):
+    from arrow_go_amd import compute as ac
+    cast = lambda arr, to, o="": sess.call_function("cast", [arr], "to_type=%s;%s" % (_tname(to), o)).to_pylist()
+    A = lambda v, t: pa.array(v, type=t)
+    # TestToIntUpcast / TestToIntDowncastSafe / Unsafe (cast_test.go:483-586)
+    assert cast(A([0, None, 127, -1, 0], pa.int8()), pa.int32()) == [0, None, 127, -1, 0]
+    assert cast(A([0, 100, 200, 255, 0], pa.uint8()), pa.int16()) == [0, 100, 200, 255, 0]
+    assert cast(A([0, None, 200, 1, 2], pa.int16()), pa.uint8()) == [0, None, 200, 1, 2]
+    with pytest.raises(ac.ErrInvalid, match="integer value 256 not in range: 0 to 255"):
+        cast(A([0, None, 256, 0, 0], pa.int16()), pa.uint8())
+    with pytest.raises(ac.ErrInvalid, match="integer value -70000 not in range: -32768 to 32767"):
+        cast(A([0, None, 2000, -70000, 2], pa.int32()), pa.int16())
+    assert cast(A([0, None, 256, 1, 2, -1], pa.int16()), pa.uint8(), "allow_int_overflow=1") == [0, None, 0, 1, 2, 255]
+    assert cast(A([0, None, 2000, 70000, -70000], pa.int32()), pa.int16(), "safe=0") == [0, None, 2000, 4464, -4464]
+    # TestIntegerSignedToUnsigned / UnsignedToSigned (:520-571)
+    i32 = A([-2147483648, None, -1, 65535, 2147483647], pa.int32())
+    for to in (pa.uint32(), pa.uint64(), pa.uint16()):
+        with pytest.raises(ac.ErrInvalid, match="not in range"):
+            cast(i32, to)
+    assert cast(i32, pa.uint64(), "allow_int_overflow=1") == [18446744071562067968, None, 18446744073709551615, 65535, 2147483647]
+    u32 = A([4294967295, None, 0, 32768], pa.uint32())
+    with pytest.raises(ac.ErrInvalid, match="integer value 32768 not in range: 0 to 32767"):
+        cast(u32.slice(1), pa.int16())
+    assert cast(u32, pa.int16(), "allow_int_overflow=1") == [-1, None, 0, -32768]
+    # TestFloatingToInt (:588-603)
+    for frm in (pa.float32(), pa.float64()):
+        for to in (pa.int32(), pa.int64()):
+            assert cast(A([1.0, None, 0.0, -1.0, 5.0], frm), to) == [1, None, 0, -1, 5]
+            with pytest.raises(ac.ErrInvalid, match="float value 1.500000 was truncated converting to " + str(to)):
+                cast(A([1.5, 0.0, None, 0.5, -1.5, 5.5], frm), to)
+            assert cast(A([1.5, 0.0, None, 0.5, -1.5, 5.5], frm), to, "allow_float_truncate=1") == [1, 0, None, 0, -1, 5]
+    # TestIntToFloating (:611-629)
+    for frm in (pa.uint32(), pa.int32()):
+        with pytest.raises(ac.ErrInvalid, match="integer value 16777217 not in range"):
+            cast(A([16777216, 16777217], frm), pa.float32())
+        assert cast(A([16777216], frm), pa.float32()) == [16777216.0]
+    i64 = A([-9223372036854775808, -9223372036854775807, 0, 9223372036854775806, 9223372036854775807], pa.int64())
+    with pytest.raises(ac.ErrInvalid, match="not in range: -9007199254740992 to 9007199254740992"):
+        cast(i64, pa.float64())
+    masked = pa.array(i64.to_pylist(), mask=np.array([True, True, False, True, True]), type=pa.int64())
+    assert cast(masked, pa.float64()) == [None, None, 0.0, None, None]
+    # TestNumericToBool (:456-468) + bool → numeric
+    for t in NUMERIC:
+        assert cast(A([0, None, 127, 1, 0], t), pa.bool_()) == [False, None, True, True, False]
+        assert cast(pa.array([True, None, False, True]), t) == [1, None, 0, 1]
+    assert cast(A([0, None, 127, -1, 0], pa.int8()), pa.bool_()) == [False, None, True, True, False]
+    assert cast(A([0.0, None, float("nan"), -1.0, -0.0], pa.float64()), pa.bool_()) == [False, None, True, True, False]
+    # identity → the input itself; scalar input → scalar; missing ToType
+    same = sess.call_function("cast", [A([1, None], pa.int32())], "to_type=int32")
+    assert same.to_pylist() == [1, None] and same.type == pa.int32()
+    sc = sess.call_function("cast", [pa.scalar(7, pa.int8())], "to_type=double")
+    assert isinstance(sc, pa.Scalar) and sc.as_py() == 7.0 and sc.type == pa.float64()
+    with pytest.raises(ac.ErrInvalid, match="cast requires that options be passed with a ToType"):
+        sess.call_function("cast", [A([1], pa.int32())], "allow_int_overflow=1")
+    out = sess.call_function("cast", [A([1, None, 3], pa.int16()).slice(1)], "to_type=int64")
+    assert out.type == pa.int64() and out.null_count == 1 and out.to_pylist() == [None, 3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frm", NUMERIC, ids=str)
+def test_cast_random_vs_arrow_cpp(sess, frm):
+    # Arrow C++ cast: the same safe / unsafe contract; values every target can hold → safe cast succeeds
+    rng = np.random.default_rng(frm.bit_width + 7)
+    n = 20011
+    vals = rng.integers(0, 100, n).astype(frm.to_pandas_dtype())
+    a = pa.array(vals, mask=rng.random(n) < 0.1, type=frm).slice(5, n - 11)
+    for to in NUMERIC:
+        got = sess.call_function("cast", [a], "to_type=" + _tname(to))
+        exp = pc.cast(a, to)
+        assert got.equals(exp) and got.type == to, (frm, to)
+    # unsafe int narrowing wraps like Arrow C++
+    if pa.types.is_integer(frm):
+        info = np.iinfo(frm.to_pandas_dtype())
+        wide = pa.array(rng.integers(info.min, info.max, n, dtype=frm.to_pandas_dtype(), endpoint=True), type=frm)
+        for to in INTS:
+            got = sess.call_function("cast", [wide], "to_type=%s;safe=0" % _tname(to))
+            assert got.equals(pc.cast(wide, to, safe=False)), (frm, to)
+
+
+@pytest.mark.gpu
+def test_implicit_numeric_promotion(sess):
+    """DispatchBest: no exact kernel → both sides go to commonNumeric through a SAFE cast
+    (arithmetic.go:112-142, scalar_compare.go:37-63, utils.go:178-240, exec.go:105-114)."""
+    from arrow_go_amd import compute as ac
+    A = lambda v, t: pa.array(v, type=t)
+    pairs = [(pa.int32(), pa.int64(), pa.int64()), (pa.int8(), pa.uint8(), pa.int16()), (pa.uint16(), pa.uint32(), pa.uint32()),
+             (pa.int16(), pa.uint32(), pa.int64()), (pa.uint64(), pa.int8(), pa.int64()), (pa.int64(), pa.float32(), pa.float32()),
+             (pa.float32(), pa.float64(), pa.float64()), (pa.uint8(), pa.float64(), pa.float64()), (pa.uint32(), pa.int32(), pa.int64())]
+    for lt, rt, common in pairs:
+        l, r = A([1, None, 3, 40], lt), A([5, 6, None, 2], rt)
+        for fn in ("add", "subtract_unchecked", "multiply"):
+            if fn.startswith("subtract") and pa.types.is_unsigned_integer(common):
+                l2, r2 = A([10, None, 30, 40], lt), r
+            else:
+                l2, r2 = l, r
+            got = sess.call_function(fn, [l2, r2])
+            exp = getattr(pc, fn.replace("_unchecked", ""))(l2, r2)
+            assert got.type == common, (lt, rt, fn, got.type)
+            assert got.to_pylist() == exp.to_pylist(), (lt, rt, fn)
+        for fn in ("equal", "greater", "less_equal"):
+            assert sess.call_function(fn, [l, r]).to_pylist() == getattr(pc, fn)(l, r).to_pylist(), (lt, rt, fn)
+        # array ∘ scalar of another type
+        assert sess.call_function("add", [l, pa.scalar(2, rt)]).to_pylist() == pc.add(l, pa.scalar(2, rt)).to_pylist()
+        assert sess.call_function("greater", [pa.scalar(2, lt), r]).to_pylist() == pc.greater(pa.scalar(2, lt), r).to_pylist()
+    # the implicit cast is SAFE: a uint64 beyond int64 cannot be promoted next to a signed operand
+    with pytest.raises(ac.ErrInvalid, match="integer value 18446744073709551615 not in range: 0 to 9223372036854775807"):
+        sess.call_function("add", [A([2**64 - 1], pa.uint64()), A([1], pa.int8())])
+    with pytest.raises(ac.ErrInvalid, match="not in range"):
+        sess.call_function("equal", [A([2**53 + 1], pa.int64()), A([1.0], pa.float64())])
+    # non-numeric operands are not promoted
+    with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
+        sess.call_function("add", [pa.array([True]), A([1], pa.int8())])
 
 
 # ---- arrow/math + fused -------------------------------------------------------------------------------------

@@ -145,8 +145,10 @@ def test_unfusible_trees_fall_back(sess):
     got, fused = sess.eval_expression("and_kleene($0,invert($1))", [a, b])
     assert not fused and got.equals(pc.and_kleene(a, pc.invert(b)))
     from arrow_go_amd import compute as ac
-    with pytest.raises(ac.ErrNotImplemented, match="no kernel matching"):   # mixed types: the reference would cast
-        sess.eval_expression("add($0,$1)", [pa.array([1], pa.int32()), pa.array([1], pa.int64())])
+    # mixed operand types: not fusible (the generator has no casts) → per-call execution, where DispatchBest
+    # promotes both sides to the common numeric type exactly like the reference
+    mixed, fused = sess.eval_expression("add($0,$1)", [pa.array([1, None], pa.int32()), pa.array([1, 2], pa.int64())])
+    assert not fused and mixed.type == pa.int64() and mixed.to_pylist() == [2, None]
     with pytest.raises(ac.ErrKey, match="not found"):
         sess.eval_expression("frobnicate($0)", [pa.array([1])])
     with pytest.raises(ac.ErrInvalid, match="out of range"):
