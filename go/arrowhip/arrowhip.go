@@ -23,6 +23,7 @@ import (
 	"unsafe"
 
 	"github.com/apache/arrow-go/v18/arrow"
+	"github.com/apache/arrow-go/v18/arrow/compute"
 )
 
 // Context owns one GPU: ah_ctx (device id, compute stream, copy stream, scratch arena).
@@ -193,4 +194,28 @@ func (x *Context) CmpFilterSumInt64(cmpop int, values, valid unsafe.Pointer, off
 	var s, c C.int64_t
 	err = x.err(C.ah_cmp_filter_sum_i64(x.c, C.int(cmpop), (*C.int64_t)(values), (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n), C.int64_t(threshold), &s, &c))
 	return int64(s), int64(c), err
+}
+
+// CumulativeSum mirrors kernels.cumulativeSumExec (vector_cumulative.go:340-350): start is one
+// element of the input type (nil = zero); outValid must be given iff valid is.
+func (x *Context) CumulativeSum(typ arrow.Type, values, valid unsafe.Pointer, off, n int64, start unsafe.Pointer, skipNulls, checked bool,
+	out, outValid unsafe.Pointer) (nulls int64, err error) {
+	var c C.int64_t
+	st := C.ah_cumulative_sum(x.c, C.int(typ), values, (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n), start,
+		boolInt(skipNulls), boolInt(checked), out, (*C.uint8_t)(outValid), &c)
+	return int64(c), x.err(st)
+}
+
+// CastNumeric mirrors castNumericUnsafe + the safe-cast checks (numeric_cast.go:37-71): the error
+// carries the reference's text ("integer value %d not in range: %d to %d", …) as arrow.ErrInvalid.
+func (x *Context) CastNumeric(in, out arrow.Type, values, valid unsafe.Pointer, off, n int64, opts compute.CastOptions, dst unsafe.Pointer) error {
+	return x.err(C.ah_cast_numeric(x.c, C.int(in), C.int(out), values, (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n),
+		boolInt(opts.AllowIntOverflow), boolInt(opts.AllowFloatTruncate), dst))
+}
+
+func boolInt(b bool) C.int {
+	if b {
+		return 1
+	}
+	return 0
 }
