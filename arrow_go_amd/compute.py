@@ -169,12 +169,20 @@ class Session:
         return pa.Array._import_from_c(C.addressof(a), C.addressof(s))
 
     # -- compute.CallFunction
-    def call_function(self, name: str, args, options: str = ""):
+    def call_function(self, name: str, args, options: str = "", value_set=None):
+        """options: "key=value;…" (Go struct tags).  value_set: the SetOptions.ValueSet array of is_in."""
         datums = [self._to_datum(x) for x in args]
+        if value_set is not None:
+            vs = self._to_datum(value_set)
+            datums.append(vs)  # released with the arguments
+            options = (options + ";" if options else "") + "value_set=@%x" % vs.value
+            nargs = len(datums) - 1
+        else:
+            nargs = len(datums)
         try:
             arr = (_vp * len(datums))(*datums)
             out = _vp()
-            self._check(lib.ahc_call(self.h, name.encode(), options.encode(), len(datums), arr, C.byref(out)))
+            self._check(lib.ahc_call(self.h, name.encode(), options.encode(), nargs, arr, C.byref(out)))
             try:
                 return self._export(out)
             finally:

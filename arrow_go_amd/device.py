@@ -262,6 +262,12 @@ class Context:
     def cast_bool_to_numeric(self, out_type: int, bits, off: int, n: int, out_values) -> None:
         check(self.handle, lib.ah_cast_bool_to_numeric(self.handle, out_type, _ptr(bits), off, n, _ptr(out_values)))
 
+    # ---- set lookup ---------------------------------------------------------------------
+    def is_in(self, byte_width: int, values, valid, off: int, n: int, set_values, set_valid, set_off: int, set_n: int,
+              null_behavior: int, out_data, out_valid, out_bit_offset: int = 0) -> None:
+        check(self.handle, lib.ah_is_in(self.handle, byte_width, _ptr(values), _ptr(valid), off, n, _ptr(set_values), _ptr(set_valid),
+                                        set_off, set_n, null_behavior, _ptr(out_data), _ptr(out_valid), out_bit_offset))
+
     # ---- hashing ------------------------------------------------------------------------
     def hash_u64_encode(self, keys, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_dict):
         nd = C.c_int64()

@@ -210,6 +210,13 @@ struct CastOptions : FunctionOptions {
     return o;
   }
 };
+// compute.SetOptions (scalar_set_lookup.go:62-65) + kernels.NullMatchingBehavior (kernels/scalar_set_lookup.go:31-38)
+enum NullMatchingBehavior { NullMatchingMatch = 0, NullMatchingSkip = 1, NullMatchingEmitNull = 2, NullMatchingInconclusive = 3 };
+struct SetOptions : FunctionOptions {
+  ArrayDataPtr ValueSet;  // device array (ArrayDatum)
+  NullMatchingBehavior NullBehavior = NullMatchingMatch;
+  const char* TypeName() const override { return "SetOptions"; }
+};
 // kernels.CumulativeOptions (vector_cumulative.go:30-39): nil Start = zero of the input type
 struct CumulativeOptions : FunctionOptions { ScalarPtr Start; bool SkipNulls = false; const char* TypeName() const override { return "CumulativeOptions"; } };
 struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
@@ -325,6 +332,7 @@ void RegisterScalarComparisons(FunctionRegistry* reg);
 void RegisterScalarBoolean(FunctionRegistry* reg);
 void RegisterVectorCumulative(FunctionRegistry* reg);
 void RegisterScalarCast(FunctionRegistry* reg);
+void RegisterScalarSetLookup(FunctionRegistry* reg);
 const DataType* CommonNumeric(const std::vector<const DataType*>& types);  // utils.go:178-240; nullptr if none
 // compute.CastDatum / CastArray (cast.go:917-935)
 Status CastDatum(ExecCtx* ctx, const Datum& in, const CastOptions& opts, Datum* out);

@@ -150,6 +150,7 @@ AHC_EXPORT int ahc_datum_info(ahc_datum* d, int* kind, int* type_id, int64_t* le
 // options: "key=value;key=value"; keys follow the Go struct tags
 //   null_selection_behavior=drop|emit_null   bounds_check=0|1   null_encoding_behavior=mask|encode
 //   to_type=<type>   safe=0|1   allow_int_overflow=0|1   allow_float_truncate=0|1       (CastOptions)
+//   value_set=@<ahc_datum* in hex>   null_matching_behavior=match|skip|emit_null|inconclusive      (SetOptions)
 //   skip_nulls=0|1   start=<type>:<value>|null:<type>   (e.g. start=int64:10, start=double:1.5, start=null:int32)
 struct ParsedOptions {
   compute::FilterOptions filter;
@@ -157,6 +158,7 @@ struct ParsedOptions {
   compute::DictionaryEncodeOptions dict;
   compute::CumulativeOptions cumulative;
   compute::CastOptions cast;
+  compute::SetOptions set;
   const compute::FunctionOptions* pick = nullptr;
 };
 static const struct { const char* name; Type id; } kTypeNames[] = {
@@ -207,6 +209,16 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
       if (k == "safe" && v == "0") { const DataType* t = p->cast.ToType; p->cast = compute::CastOptions::Unsafe(t); p->pick = &p->cast; }
       if (k == "allow_int_overflow") { p->cast.AllowIntOverflow = v != "0"; p->pick = &p->cast; }
       if (k == "allow_float_truncate") { p->cast.AllowFloatTruncate = v != "0"; p->pick = &p->cast; }
+      if (k == "value_set" && v.size() > 1 && v[0] == '@') {
+        ahc_datum* d = (ahc_datum*)(uintptr_t)strtoull(v.c_str() + 1, nullptr, 16);
+        if (d && d->d.kind == DatumKind::Array) p->set.ValueSet = d->d.array;
+        p->pick = &p->set;
+      }
+      if (k == "null_matching_behavior") {
+        p->set.NullBehavior = v == "skip" ? compute::NullMatchingSkip : v == "emit_null" ? compute::NullMatchingEmitNull
+                            : v == "inconclusive" ? compute::NullMatchingInconclusive : compute::NullMatchingMatch;
+        p->pick = &p->set;
+      }
       if (k == "skip_nulls") { p->cumulative.SkipNulls = v != "0"; p->pick = &p->cumulative; }
       if (k == "start") { p->cumulative.Start = ParseScalarText(v); p->pick = &p->cumulative; }
       if (k == "null_encoding_behavior") { p->dict.NullEncoding = v == "encode" ? compute::NullEncodingEncode : compute::NullEncodingMask; p->pick = &p->dict; }

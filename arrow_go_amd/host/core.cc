@@ -498,6 +498,7 @@ FunctionRegistry* GetFunctionRegistry() {
     RegisterVectorHash(r);
     RegisterVectorCumulative(r);
     RegisterScalarCast(r);
+    RegisterScalarSetLookup(r);
     RegisterFusedExtensions(r);
     return r;
   }();

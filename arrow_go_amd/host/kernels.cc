@@ -484,6 +484,54 @@ void RegisterScalarCast(FunctionRegistry* reg) {
       }), false);
 }
 
+// ---- is_in -------------------------------------------------------------------------------------------
+// initSetLookup + execIsIn (compute/scalar_set_lookup.go:67-172): the value set is SAFE-cast to the
+// input type when the types differ; the kernel writes data and validity (NullComputedPrealloc)
+static Status ExecIsIn(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  const SetOptions* opts = dynamic_cast<const SetOptions*>(static_cast<const FunctionOptions*>(k->state));
+  if (!opts) return Status::Make(StatusCode::Invalid, "calling a set lookup function without SetOptions");
+  if (!opts->ValueSet) return Status::Make(StatusCode::Invalid, "expected array-like datum, got nil");
+  const ArraySpan& in = b.values[0].array;
+  ArrayDataPtr vset = opts->ValueSet;
+  if (vset->type->id != in.type->id) {
+    ExecCtx ectx;
+    ectx.session = s;
+    Datum casted;
+    Status st = CastDatum(&ectx, Datum::Of(vset), CastOptions::Safe(in.type), &casted);
+    if (!st.ok()) {
+      if (st.code == StatusCode::NotImplemented)
+        return Status::Make(StatusCode::Invalid, std::string("array type doesn't match type of values set: ") + in.type->name + " vs " + vset->type->name);
+      return st;
+    }
+    vset = casted.array;
+  }
+  if (out->len == 0) return Status::OK();
+  int w = in.type->bit_width / 8;
+  const uint8_t* set_vals = vset->length ? (const uint8_t*)vset->buffers[1]->dptr + vset->offset * w : nullptr;
+  const uint8_t* set_valid = vset->buffers[0] ? (const uint8_t*)vset->buffers[0]->dptr : nullptr;
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_is_in(s->ctx(), w, Values(in), in.MayHaveNulls() ? in.buffers[0].buf : nullptr, in.offset, in.len, set_vals,
+                                           set_valid, vset->offset, vset->length, opts->NullBehavior, out->buffers[1].buf, out->buffers[0].buf,
+                                           out->offset)));
+  out->nulls = kUnknownNullCount;
+  return Status::OK();
+}
+
+// RegisterScalarSetLookup (compute/scalar_set_lookup.go:175-232), fixed-width numeric inputs
+void RegisterScalarSetLookup(FunctionRegistry* reg) {
+  auto fn = std::make_shared<ScalarFunction>("is_in", Arity{1, false});
+  for (Type t : kNumericTypes) {
+    exec::ScalarKernel k;
+    k.sig.in_types = {t};
+    k.sig.out_is_first_input = false;
+    k.sig.out_type = Type::BOOL;
+    k.null_handling = exec::NullHandling::NullComputedPrealloc;  // :186-187
+    k.exec_fn = ExecIsIn;
+    fn->AddKernel(std::move(k));
+  }
+  reg->AddFunction(fn, false);
+}
+
 // ---- cumulative_sum / cumulative_sum_checked ---------------------------------------------------
 // Safe numeric cast of the Start scalar to the input type — what safeCastScalar → CastDatum(SafeCastOptions)
 // decides (compute/vector_cumulative.go:53-70, kernels/vector_cumulative.go:71-90): integer targets

@@ -164,6 +164,12 @@ def per_kernel_table(ctx, rows, a, b, c, x):
           lambda: ctx.take_primitive(8, a, None, 0, rows, 4, True, idx, None, 0, rows, True, c, None), reps=3)
     timed("fused_gt_filter_sum_int64", 8 * rows, lambda: ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, res))
     timed("fused_gt_filter_sum_int64_nulls10", 8.125 * rows, lambda: ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, vvalid, 0, rows, 0, res))
+    # (f) rows: cumulative_sum (16 B/row algorithmic; 24 moved: reduce-then-scan) and numeric cast (w_in + w_out)
+    timed("cumulative_sum_int64", 16 * rows, lambda: ctx.cumulative_sum(N.INT64, a, None, 0, rows, None, False, False, c, None))
+    timed("cumulative_sum_float64", 16 * rows, lambda: ctx.cumulative_sum(N.FLOAT64, x, None, 0, rows, None, False, False, c, None))
+    timed("cast_int64_to_int32_unsafe", 12 * rows, lambda: ctx.cast_numeric(N.INT64, N.INT32, a, None, 0, rows, True, True, c))
+    timed("cast_int32_to_int64", 12 * rows, lambda: ctx.cast_numeric(N.INT32, N.INT64, a, None, 0, rows, False, False, c))
+    timed("cast_float64_to_float32", 12 * rows, lambda: ctx.cast_numeric(N.FLOAT64, N.FLOAT32, x, None, 0, rows, False, False, c))
     timed("bitmap_and", 0.375 * rows, lambda: ctx.bitmap_op(N.BIT_AND, mask, 0, vvalid, 0, ovalid, 0, rows))
     timed("count_set_bits", 0.125 * rows, lambda: ctx.count_set_bits(mask, 0, rows))
     for bfr in (res, mask, vvalid, ovalid, idx):

@@ -298,6 +298,20 @@ int ah_cast_numeric(ah_ctx* ctx, int in_type, int out_type, const void* values, 
  * isNonZero, boolean_cast.go:30-36 = ah_comparison(AH_CMP_NE, AH_SHAPE_AS, type, values, &zero).) */
 int ah_cast_bool_to_numeric(ah_ctx* ctx, int out_type, const uint8_t* bits, int64_t off, int64_t n, void* out_values);
 
+/* ---- is_in (row §8(f)-2) -----------------------------------------------------------------------
+ * replaces SetLookupState.Init + isInKernelExec (kernels/scalar_set_lookup.go:192-244, 374-413)
+ * behind compute's "is_in" with SetOptions{ValueSet, NullBehavior} (compute/scalar_set_lookup.go:
+ * 62-65, 175-200).  Keys are the raw bits of a 1/2/4/8-byte value.  Writes the result's data AND
+ * validity bits [out_bit_offset, out_bit_offset + n) (NullComputedPrealloc) and preserves every other
+ * bit.  No host synchronisation. */
+#define AH_NULL_MATCH 0        /* NullMatchingBehavior, kernels/scalar_set_lookup.go:31-38 */
+#define AH_NULL_SKIP 1
+#define AH_NULL_EMIT_NULL 2
+#define AH_NULL_INCONCLUSIVE 3
+int ah_is_in(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* valid, int64_t off, int64_t n,
+             const void* set_values, const uint8_t* set_valid, int64_t set_off, int64_t set_n, int null_behavior,
+             uint8_t* out_data, uint8_t* out_valid, int64_t out_bit_offset);
+
 /* ---- fused scalar-expression evaluation (row §8(f)-1: the expression executor) ---------
  * What compute.Expression trees — NewCall / NewFieldRef / NewLiteral, arrow/compute/
  * expression.go:596-620 — evaluate to through executeScalarBatch (arrow/compute/exprs/

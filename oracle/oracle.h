@@ -46,6 +46,8 @@ enum { ORC_SHAPE_AA = 0, ORC_SHAPE_AS = 1, ORC_SHAPE_SA = 2 };
 enum { ORC_BIT_AND = 0, ORC_BIT_OR = 1, ORC_BIT_XOR = 2, ORC_BIT_AND_NOT = 3, ORC_BIT_XNOR = 4 };
 /* NullSelectionBehavior — kernels/vector_selection.go:34-39 */
 enum { ORC_DROP_NULLS = 0, ORC_EMIT_NULLS = 1 };
+/* NullMatchingBehavior — kernels/scalar_set_lookup.go:31-38 */
+enum { ORC_NULL_MATCH = 0, ORC_NULL_SKIP = 1, ORC_NULL_EMIT_NULL = 2, ORC_NULL_INCONCLUSIVE = 3 };
 /* status classes shared with include/arrowhip.h */
 enum { ORC_OK = 0, ORC_EINVALID = 1, ORC_EINDEX = 2, ORC_EOVERFLOW = 3 };
 
@@ -124,6 +126,12 @@ int orc_cumulative_sum(int type, const void* values, const uint8_t* valid, int64
 int orc_cast_numeric(int in_type, int out_type, const void* in, const uint8_t* valid, int64_t off, int64_t n,
                      int allow_int_overflow, int allow_float_truncate, void* out, int64_t* bad_index, char* msg);
 int orc_cast_bool_to_numeric(int out_type, const uint8_t* bits, int64_t off, int64_t n, void* out);
+
+/* ---- is_in (kernels/scalar_set_lookup.go:192-244,374-413): keys are the raw bits of the fixed-width
+ * value; out_data / out_valid bits [out_off, out_off + n) are written, every other bit is preserved */
+int orc_is_in(int byte_width, const void* values, const uint8_t* valid, int64_t off, int64_t n,
+              const void* set_values, const uint8_t* set_valid, int64_t set_off, int64_t set_n, int null_behavior,
+              uint8_t* out_data, uint8_t* out_valid, int64_t out_off);
 
 /* ---- fused Compare(>) → Filter → Sum (the unfused chain, restated) ---- */
 int orc_cmp_filter_sum_i64(int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n,

@@ -80,6 +80,9 @@ class OracleBackend:
     def cast_bool_to_numeric(self, bits, off, n, out_dtype):
         return self.o.cast_bool_to_numeric(bits, off, n, out_dtype)
 
+    def is_in(self, values, valid, off, set_values, set_valid, set_off, null_behavior, out_off=0, fill=0, misalign=0):
+        return self.o.is_in(values, valid, off, set_values, set_valid, set_off, null_behavior, out_off, fill)
+
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
@@ -298,6 +301,17 @@ class HipBackend:
         ob.memset(0xCD)
         self.c.cast_bool_to_numeric(OL.TYPE_IDS[od], bp, off, n, ob)
         return ob.download(od, n)
+
+    def is_in(self, values, valid, off, set_values, set_valid, set_off, null_behavior, out_off=0, fill=0, misalign=0):
+        values = np.ascontiguousarray(values); set_values = np.ascontiguousarray(set_values)
+        n = values.size
+        vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
+        sb, sp = self._up(set_values) if set_values.size else (None, None); svb, svp = self._upbits(set_valid)
+        nb = (out_off + n + 7) // 8 + 1
+        odb = self.c.alloc(nb + 64); ovb = self.c.alloc(nb + 64)
+        odb.memset(fill); ovb.memset(fill)
+        self.c.is_in(values.dtype.itemsize, vp, vvp, off, n, sp, svp, set_off, set_values.size, null_behavior, odb, ovb, out_off)
+        return odb.download(np.uint8, nb), ovb.download(np.uint8, nb)
 
     def hash_encode(self, keys, valid, off, encode_nulls):
         keys = np.ascontiguousarray(keys).view(np.uint64)

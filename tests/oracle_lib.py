@@ -69,6 +69,7 @@ class Oracle:
             "orc_cumulative_sum": (it, [it, vp, vp, i64, i64, vp, it, it, vp, vp, vp]),
             "orc_cast_numeric": (it, [it, it, vp, vp, i64, i64, it, it, vp, vp, vp]),
             "orc_cast_bool_to_numeric": (it, [it, vp, i64, i64, vp]),
+            "orc_is_in": (it, [it, vp, vp, i64, i64, vp, vp, i64, i64, it, vp, vp, i64]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -211,6 +212,18 @@ class Oracle:
         st = self.lib.orc_cast_bool_to_numeric(TYPE_IDS[np.dtype(out_dtype)], _p(bits), off, n, _p(out))
         assert st == 0, st
         return out[:n]
+
+    # ---- set lookup ---------------------------------------------------------------------
+    def is_in(self, values, valid, off, set_values, set_valid, set_off, null_behavior, out_off=0, fill=0):
+        """→ (data bits, validity bits) covering out_off + n bits, pre-filled with `fill` bytes"""
+        values = np.ascontiguousarray(values); set_values = np.ascontiguousarray(set_values)
+        n = values.size
+        nb = (out_off + n + 7) // 8 + 1
+        od = np.full(nb, fill, np.uint8); ov = np.full(nb, fill, np.uint8)
+        st = self.lib.orc_is_in(values.dtype.itemsize, _p(values), _p(valid), off, n, _p(set_values), _p(set_valid), set_off,
+                                set_values.size, null_behavior, _p(od), _p(ov), out_off)
+        assert st == 0, st
+        return od, ov
 
     # ---- hashing ------------------------------------------------------------------------
     def hash_int(self, v, alg=0): return int(self.lib.orc_hash_int(int(v) & (2**64 - 1), alg))

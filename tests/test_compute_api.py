@@ -32,7 +32,7 @@ def test_registry_has_the_path_functions():
                  "abs_unchecked", "negate_unchecked", "sign", "equal", "not_equal", "greater", "greater_equal", "less",
                  "less_equal", "and", "or", "xor", "and_not", "invert", "and_kleene", "or_kleene", "and_not_kleene",
                  "filter", "array_filter", "take", "array_take", "unique", "dictionary_encode", "greater_filter_sum",
-                 "cumulative_sum", "cumulative_sum_checked", "cast", "cast_int32", "cast_double", "cast_boolean"]:
+                 "cumulative_sum", "cumulative_sum_checked", "cast", "cast_int32", "cast_double", "cast_boolean", "is_in"]:
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
@@ -494,6 +494,48 @@ def test_implicit_numeric_promotion(sess):
     # non-numeric operands are not promoted
     with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
         sess.call_function("add", [pa.array([True]), A([1], pa.int8())])
+
+
+# ---- is_in (arrow/compute/scalar_set_lookup_test.go:104-168) -------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+def test_is_in_primitive(sess, typ):
+    T, F, N = True, False, None
+    A = lambda v: pa.array(v, type=typ)
+    isin = lambda vals, vset, nb: sess.call_function("is_in", [A(vals)], "null_matching_behavior=" + nb, value_set=A(vset)).to_pylist()
+    cases = [
+        ([0, 1, 2, 3, 2], [2, 1], {"match": [F, T, T, F, T]}),
+        ([None, 1, 2, 3, 2], [2, 1], {"match": [F, T, T, F, T], "skip": [F, T, T, F, T], "emit_null": [N, T, T, F, T], "inconclusive": [N, T, T, F, T]}),
+        ([0, 1, 2, 3, 2], [2, None, 1], {"match": [F, T, T, F, T], "skip": [F, T, T, F, T], "emit_null": [F, T, T, F, T], "inconclusive": [N, T, T, N, T]}),
+        ([None, 1, 2, 3, 2], [2, None, 1], {"match": [T, T, T, F, T], "skip": [F, T, T, F, T], "emit_null": [N, T, T, F, T], "inconclusive": [N, T, T, N, T]}),
+        ([None, 1, 2, 3, 2], [None, 2, 2, None, 1, 1], {"match": [T, T, T, F, T], "skip": [F, T, T, F, T], "emit_null": [N, T, T, F, T],
+                                                        "inconclusive": [N, T, T, N, T]}),
+        ([], [], {"match": []}),
+    ]
+    for vals, vset, exp in cases:
+        for nb, want in exp.items():
+            assert isin(vals, vset, nb) == want, (vals, vset, nb)
+
+
+@pytest.mark.gpu
+def test_is_in_options_casts_and_arrow_cpp(sess):
+    from arrow_go_amd import compute as ac
+    with pytest.raises(ac.ErrInvalid, match="without SetOptions"):
+        sess.call_function("is_in", [pa.array([1])])
+    # the value set is safe-cast to the input type (initSetLookup, scalar_set_lookup.go:93-112)
+    got = sess.call_function("is_in", [pa.array([1, 2, 300], pa.int32())], value_set=pa.array([2, 300], pa.int64()))
+    assert got.to_pylist() == [False, True, True]
+    with pytest.raises(ac.ErrInvalid, match="not in range"):
+        sess.call_function("is_in", [pa.array([1], pa.int8())], value_set=pa.array([1000], pa.int64()))
+    # sliced input and sliced value set, random, against Arrow C++ (default = match nulls; skip_nulls=True = skip)
+    rng = np.random.default_rng(11)
+    n = 50021
+    a = pa.array(rng.integers(0, 4000, n), mask=rng.random(n) < 0.1, type=pa.int64()).slice(7, n - 20)
+    vs = pa.array(rng.integers(0, 4000, 900), mask=rng.random(900) < 0.05, type=pa.int64()).slice(3, 800)
+    assert sess.call_function("is_in", [a], value_set=vs).equals(pc.is_in(a, value_set=vs))
+    assert sess.call_function("is_in", [a], "null_matching_behavior=skip", value_set=vs).equals(pc.is_in(a, value_set=vs, skip_nulls=True))
+    f = pa.array([0.0, -0.0, 1.5, None], pa.float64())
+    assert sess.call_function("is_in", [f], value_set=pa.array([0.0, None], pa.float64())).to_pylist() == [True, False, False, True]
 
 
 # ---- arrow/math + fused -------------------------------------------------------------------------------------

@@ -781,3 +781,58 @@ def test_cast_float_to_float_and_bool(be):
     bits = OL.pack_bits([False, False, True, True, False, True, False, False, True, True, True])
     for dt in OL.ALL_DTYPES:
         assert be.cast_bool_to_numeric(bits, 2, 9, dt).tolist() == [1, 1, 0, 1, 0, 0, 1, 1, 1]
+
+
+# ---- is_in ---------------------------------------------------------------------------------
+# arrow/compute/scalar_set_lookup_test.go:104-168 TestIsInPrimitive
+MATCH, SKIP, EMIT_NULL, INCONCLUSIVE = 0, 1, 2, 3
+
+
+def run_is_in(be, dtype, vals, vset, nb, out_off=0, fill=0):
+    arr, valid = mk(vals, dtype, null_fill=2)       # a null slot carries a payload that IS in the set: it must not match by value
+    sarr, svalid = mk(vset, dtype, null_fill=3)     # and a null set entry carries a payload that is probed for
+    od, ov = be.is_in(arr, valid, 0, sarr, svalid, 0, nb, out_off, fill)
+    n = len(vals)
+    d = OL.unpack_bits(od, out_off, n); v = OL.unpack_bits(ov, out_off, n)
+    return [bool(x) if ok else None for x, ok in zip(d, v)], od, ov
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+def test_is_in_primitive(be, dtype):
+    T, F, N = True, False, None
+    cases = [
+        ([0, 1, 2, 3, 2], [2, 1], {MATCH: [F, T, T, F, T]}),
+        ([None, 1, 2, 3, 2], [2, 1], {MATCH: [F, T, T, F, T], SKIP: [F, T, T, F, T], EMIT_NULL: [N, T, T, F, T], INCONCLUSIVE: [N, T, T, F, T]}),
+        ([0, 1, 2, 3, 2], [2, None, 1], {MATCH: [F, T, T, F, T], SKIP: [F, T, T, F, T], EMIT_NULL: [F, T, T, F, T], INCONCLUSIVE: [N, T, T, N, T]}),
+        ([None, 1, 2, 3, 2], [2, None, 1], {MATCH: [T, T, T, F, T], SKIP: [F, T, T, F, T], EMIT_NULL: [N, T, T, F, T], INCONCLUSIVE: [N, T, T, N, T]}),
+        ([None, 1, 2, 3, 2], [None, 2, 2, None, 1, 1], {MATCH: [T, T, T, F, T], SKIP: [F, T, T, F, T], EMIT_NULL: [N, T, T, F, T],
+                                                        INCONCLUSIVE: [N, T, T, N, T]}),
+        ([], [], {MATCH: []}),
+    ]
+    for vals, vset, exp in cases:
+        for nb, want in exp.items():
+            assert run_is_in(be, dtype, vals, vset, nb)[0] == want, (vals, vset, nb)
+    # an empty set matches nothing; values are keyed on their bits
+    assert run_is_in(be, dtype, [1, None], [], MATCH)[0] == [F, F]
+    assert run_is_in(be, dtype, [1, None], [], EMIT_NULL)[0] == [F, N]
+
+
+def test_is_in_bit_patterns_and_output_range(be):
+    # floats are looked up by bit pattern (SetLookupState[uint64], scalar_set_lookup.go:106-133)
+    nan1 = np.array([0x7FF8000000000001], np.uint64).view(np.float64)[0]
+    vals = np.array([0.0, -0.0, np.nan, nan1, 1.5], np.float64)
+    got = be.is_in(vals, None, 0, np.array([0.0, np.nan], np.float64), None, 0, MATCH)[0]
+    assert OL.unpack_bits(got, 0, 5).tolist() == [1, 0, 1, 0, 0]
+    # the all-ones key and key 0 are ordinary members
+    k = np.array([2**64 - 1, 0, 5], np.uint64)
+    assert OL.unpack_bits(be.is_in(k, None, 0, np.array([2**64 - 1], np.uint64), None, 0, MATCH)[0], 0, 3).tolist() == [1, 0, 0]
+    assert OL.unpack_bits(be.is_in(k, None, 0, np.array([0], np.uint64), None, 0, MATCH)[0], 0, 3).tolist() == [0, 1, 0]
+    # bits outside [out_off, out_off + n) are preserved, whatever they were
+    for fill in (0x00, 0xFF):
+        for out_off in (0, 3, 13, 64, 67):
+            exp, od, ov = run_is_in(be, np.int32, [None, 1, 2, 3, 2] * 30, [2, None, 1], INCONCLUSIVE, out_off, fill)
+            assert exp == [None, True, True, None, True] * 30
+            n = 150
+            for buf in (od, ov):
+                bits = OL.unpack_bits(buf, 0, len(buf) * 8)
+                assert all(b == (fill & 1) for b in bits[:out_off]) and all(b == (fill & 1) for b in bits[out_off + n:])

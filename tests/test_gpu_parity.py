@@ -591,6 +591,45 @@ def test_cast_bool_to_numeric_random(hip, orc_be):
             assert hip.cast_bool_to_numeric(bits, off, n, dt).tobytes() == orc_be.cast_bool_to_numeric(bits, off, n, dt).tobytes()
 
 
+# ---- is_in -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.int32, np.float32, np.int64, np.uint64, np.float64], ids=str)
+def test_is_in_random(hip, orc_be, dtype):
+    """bitmap path (1/2-byte keys), LDS table (small sets), HBM table (large sets): data and validity
+    bitmaps bit-exact for all four null behaviours, sliced validity on both sides, output at a bit offset."""
+    rng = np.random.default_rng(7000 + OL.TYPE_IDS[np.dtype(dtype)])
+    dt = np.dtype(dtype)
+    for n in (1, 63, 64, 65, 1000, 4097, 70001):
+        for set_n in (0, 1, 7, 300, 5000):
+            universe = max(4, 3 * set_n)
+            def draw(m):
+                if dt.kind == "f":
+                    return rng.integers(0, universe, m).astype(dt)
+                return rng.integers(0, min(universe, int(np.iinfo(dt).max)), m).astype(dt)
+            vals, vset = draw(n), draw(set_n)
+            if dt.itemsize == 8 and set_n > 1:
+                vset[0] = np.array([2**64 - 1], np.uint64).view(dt)[0]; vals[n // 2] = vset[0]   # the all-ones key
+            off, soff = int(rng.integers(0, 20)), int(rng.integers(0, 20))
+            valid = OL.pack_bits([True] * off + list(rng.random(n) >= 0.2)) if n % 2 else None
+            svalid = OL.pack_bits([True] * soff + list(rng.random(set_n) >= 0.3)) if set_n % 2 else None
+            for nb in (0, 1, 2, 3):
+                out_off = int(rng.integers(0, 70)) if nb % 2 else 0
+                fill = 0xFF if nb == 3 else 0
+                ed, ev = orc_be.is_in(vals, valid, off, vset, svalid, soff, nb, out_off, fill)
+                gd, gv = hip.is_in(vals, valid, off, vset, svalid, soff, nb, out_off, fill, misalign=n % 3)
+                assert gd.tobytes() == ed.tobytes() and gv.tobytes() == ev.tobytes(), (dtype, n, set_n, nb, out_off)
+
+
+def test_is_in_large_set(hip, orc_be):
+    rng = np.random.default_rng(7100)
+    vset = rng.integers(-2**62, 2**62, 200003, dtype=np.int64)
+    vals = np.concatenate([rng.choice(vset, 150000), rng.integers(-2**62, 2**62, 150001, dtype=np.int64)])
+    rng.shuffle(vals)
+    ed, ev = orc_be.is_in(vals, None, 0, vset, None, 0, 0)
+    gd, gv = hip.is_in(vals, None, 0, vset, None, 0, 0)
+    assert gd.tobytes() == ed.tobytes() and gv.tobytes() == ev.tobytes()
+    assert 140000 < int(np.unpackbits(gd, bitorder="little")[:vals.size].sum()) < 160000
+
+
 # ---- full-size properties (BASELINE.json configs; no oracle pass needed) -------------------
 def test_full_size_properties(ctx):
     """C2/C3 sizes (2^27 rows = 1 GiB columns) checked through size-independent
