@@ -1,0 +1,309 @@
+// ah_sort.hip — sort_indices of one numeric array: stable LSD radix sort (row §8(f)-2).
+//
+// Replaces kernels.SortIndices for a single key over one array (arrow/compute/internal/kernels/
+// vector_sort.go:388-481 → arraySortOneColumnRange, vector_sort_internal.go:252-273) behind
+// compute's "sort_indices" (compute/vector_sort.go:42-52):
+//   stable; nulls partitioned to the end or the start (key.NullPlacement), NaNs next to them
+//   ([rest, NaNs, nulls] / [nulls, NaNs, rest] — partitionNullLikes :90-140: NaN placement follows the
+//   null placement, not the order), the rest ordered by cmp.Compare, negated for Descending
+//   (vector_sort_support.go:88-94): ties keep their input order in BOTH directions, −0.0 == +0.0.
+// The reference is partition + slices.SortStableFunc with a comparator closure per pair.
+//
+// Here: (1) one stable 3-way partition pass straight off the column (category = rest / NaN / null)
+// that also maps every value to an order-preserving unsigned key (sign flip for ints, the IEEE trick
+// for floats with −0 → +0, complemented for Descending) and pairs it with its 32-bit row number;
+// (2) a bitwise AND / OR reduction of the keys tells which key bytes vary at all; (3) one stable
+// 8-bit LSD pass per varying byte over the `rest` range only — per pass: tile histograms →
+// exclusive scan → scatter, the in-tile ranks from wave-level match-any (8 ballots) so the pass is
+// stable by construction; (4) widening the row numbers to the uint64 output.  Equal keys never
+// change relative order in any pass, which is exactly SortStableFunc's contract, and the NaN / null
+// groups keep their input order because only pass (1) ever moves them.
+// Traffic: 8 (+1/8) B/row for (1) and (2), ≈ 32 B/row per LSD pass ((key, row) read twice, written
+// once), 12 B/row for (4): an Int64 column with all 8 bytes varying moves ≈ 290 B/row.
+#include <type_traits>
+#include "ah_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kItems = 8;                       // rounds of 64 rows per wave per tile
+constexpr int kTile = kBlock * kItems;          // 2048 rows
+constexpr int kRadix = 256;
+
+enum { kCatRest = 0, kCatNaN = 1, kCatNull = 2 };
+
+// order-preserving unsigned key, zero-extended to 64 bits
+template <typename T>
+__device__ __forceinline__ unsigned long long make_key(T v, bool descending) {
+  using U = typename std::make_unsigned<typename std::conditional<std::is_floating_point<T>::value,
+                                                                    typename std::conditional<sizeof(T) == 4, int, long long>::type, T>::type>::type;
+  constexpr U sign = (U)1 << (sizeof(T) * 8 - 1);
+  U k;
+  if constexpr (std::is_floating_point<T>::value) {
+    if (v == (T)0) v = (T)0;  // −0.0 → +0.0: they tie (cmp.Compare)
+    U b = __builtin_bit_cast(U, v);
+    k = (b & sign) ? (U)~b : (U)(b | sign);
+  } else if constexpr (std::is_signed<T>::value) {
+    k = (U)v ^ sign;
+  } else {
+    k = (U)v;
+  }
+  if (descending) k = (U)~k;
+  return (unsigned long long)k;
+}
+
+// ---- the element source of a pass -------------------------------------------------------------
+// Column<T>: pass (1) — reads the column, digit = category, emits (key, row).
+// Pairs:     an LSD pass — reads (key, row) pairs, digit = a key byte.
+template <typename T>
+struct Column {
+  const T* values;
+  const uint8_t* valid;
+  int64_t off;
+  int descending, nulls_at_start;
+  __device__ __forceinline__ void load(int64_t i, unsigned long long* key, unsigned* row, unsigned* digit) const {
+    const T v = values[i];
+    int cat = kCatRest;
+    if (!ah_bit(valid, off + i)) cat = kCatNull;
+    else if (std::is_floating_point<T>::value && v != v) cat = kCatNaN;
+    *key = cat == kCatRest ? make_key<T>(v, descending) : 0ull;
+    *row = (unsigned)i;
+    *digit = nulls_at_start ? (unsigned)(2 - cat) : (unsigned)cat;  // [nulls, NaNs, rest] or [rest, NaNs, nulls]
+  }
+};
+struct Pairs {
+  const unsigned long long* keys;
+  const unsigned* rows;
+  int shift;
+  __device__ __forceinline__ void load(int64_t i, unsigned long long* key, unsigned* row, unsigned* digit) const {
+    *key = keys[i];
+    *row = rows[i];
+    *digit = (unsigned)(*key >> shift) & 255u;
+  }
+};
+
+// tile histogram → hist[digit * ntiles + tile]
+template <typename SRC>
+__global__ __launch_bounds__(kBlock) void hist_kernel(SRC src, int64_t n, unsigned* __restrict__ hist, int64_t ntiles) {
+  __shared__ unsigned s_h[kWaves][kRadix];
+  for (int i = threadIdx.x; i < kWaves * kRadix; i += kBlock) (&s_h[0][0])[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t wbase = tile * kTile + (int64_t)wave * (kItems * 64);
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int64_t i = wbase + r * 64 + lane;
+    if (i < n) {
+      unsigned long long key; unsigned row, digit;
+      src.load(i, &key, &row, &digit);
+      atomicAdd(&s_h[wave][digit], 1u);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < kRadix; d += kBlock) {
+    unsigned t = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) t += s_h[w][d];
+    hist[(int64_t)d * ntiles + tile] = t;
+  }
+}
+
+// stable scatter: offs = INCLUSIVE scan of hist (digit-major)
+template <typename SRC>
+__global__ __launch_bounds__(kBlock) void scatter_kernel(SRC src, int64_t n, const unsigned* __restrict__ offs, int64_t ntiles,
+                                                          unsigned long long* __restrict__ out_keys, unsigned* __restrict__ out_rows) {
+  __shared__ unsigned s_cnt[kWaves][kRadix];   // per wave: rows of each digit seen in earlier rounds; later: wave bases
+  __shared__ unsigned s_base[kRadix];          // global position of the tile's first row of each digit
+  for (int i = threadIdx.x; i < kWaves * kRadix; i += kBlock) (&s_cnt[0][0])[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t wbase = tile * kTile + (int64_t)wave * (kItems * 64);
+  unsigned long long key[kItems];
+  unsigned row[kItems], digit[kItems], rank[kItems];
+  bool live[kItems];
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int64_t i = wbase + r * 64 + lane;
+    live[r] = i < n;
+    key[r] = 0; row[r] = 0; digit[r] = 0;
+    if (live[r]) src.load(i, &key[r], &row[r], &digit[r]);
+  }
+  // in-wave ranks, round by round: element order inside the tile is (wave, round, lane)
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    // match-any on the 8-bit digit: peers = lanes holding the same digit
+    unsigned long long peers = __ballot(live[r]);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const unsigned long long bal = __ballot((digit[r] >> b) & 1u);
+      peers &= ((digit[r] >> b) & 1u) ? bal : ~bal;
+    }
+    if (live[r]) {
+      // atomic accesses: ANOTHER lane of this wave advanced the counter in the previous round — a value
+      // the per-thread memory model would otherwise let the compiler keep in a register
+      unsigned* cnt = &s_cnt[wave][digit[r]];
+      const unsigned before = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // every peer reads the same counter …
+      rank[r] = before + (unsigned)__popcll(peers & below);
+      if ((peers & below) == 0)  // … the lowest one advances it
+        __hip_atomic_store(cnt, before + (unsigned)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    // LDS operations of one wave execute in order; keep the compiler from moving them across rounds
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // per digit: exclusive prefix over the waves, and the tile's global base
+  for (int d = threadIdx.x; d < kRadix; d += kBlock) {
+    unsigned run = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+      const unsigned t = s_cnt[w][d];
+      s_cnt[w][d] = run;
+      run += t;
+    }
+    s_base[d] = offs[(int64_t)d * ntiles + tile] - run;  // inclusive scan − own count
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    if (live[r]) {
+      const unsigned pos = s_base[digit[r]] + s_cnt[wave][digit[r]] + rank[r];
+      out_keys[pos] = key[r];
+      out_rows[pos] = row[r];
+    }
+  }
+}
+
+// which key bits vary at all: res[0] = AND of all keys, res[1] = OR
+__global__ __launch_bounds__(kBlock) void and_or_kernel(const unsigned long long* __restrict__ keys, int64_t n, unsigned long long* __restrict__ res) {
+  unsigned long long a = ~0ull, o = 0ull;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const unsigned long long k = keys[i];
+    a &= k; o |= k;
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    a &= __shfl_down(a, s, 64);
+    o |= __shfl_down(o, s, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAnd(&res[0], a); atomicOr(&res[1], o); }
+}
+
+__global__ __launch_bounds__(kBlock) void emit_kernel(const unsigned* __restrict__ rows, int64_t n, uint64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = rows[i];
+}
+
+struct Temp {  // temporaries of one call (the context's scratch arena is used by the scan this calls)
+  ah_ctx* c;
+  void* p[8];
+  int n = 0;
+  explicit Temp(ah_ctx* ctx) : c(ctx) {}
+  int get(size_t bytes, void** out) {
+    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return ah_fail(c, AH_EHIP, "sort: out of device memory (%zu bytes)", bytes); }
+    p[n++] = *out;
+    return AH_OK;
+  }
+  ~Temp() {
+    (void)hipStreamSynchronize(c->stream);  // kernels of this call may still be reading them
+    for (int i = 0; i < n; i++) (void)hipFree(p[i]);
+  }
+};
+
+template <typename SRC>
+int radix_pass(ah_ctx* c, SRC src, int64_t n, unsigned* hist, unsigned* offs, unsigned long long* out_keys, unsigned* out_rows) {
+  const int64_t ntiles = ah_ceil_div(n, kTile);
+  hist_kernel<SRC><<<(unsigned)ntiles, kBlock, 0, c->stream>>>(src, n, hist, ntiles);
+  AH_LAUNCH_CHECK(c);
+  int rc = ah_cumulative_sum(c, AH_UINT32, hist, nullptr, 0, (int64_t)kRadix * ntiles, nullptr, 0, 0, offs, nullptr, nullptr);
+  if (rc != AH_OK) return rc;
+  scatter_kernel<SRC><<<(unsigned)ntiles, kBlock, 0, c->stream>>>(src, n, offs, ntiles, out_keys, out_rows);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
+
+template <typename T>
+int sort_typed(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending, int nulls_at_start, uint64_t* out) {
+  Temp tmp(c);
+  unsigned long long *ka, *kb, *andor;
+  unsigned *ra, *rb, *hist, *offs;
+  const int64_t ntiles = ah_ceil_div(n, kTile);
+  int rc;
+  if ((rc = tmp.get((size_t)n * 8, (void**)&ka)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)n * 8, (void**)&kb)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)n * 4, (void**)&ra)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)n * 4, (void**)&rb)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&hist)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&offs)) != AH_OK) return rc;
+  if ((rc = tmp.get(64, (void**)&andor)) != AH_OK) return rc;
+  // (1) partition by category, keys and row numbers come into being
+  Column<T> col{(const T*)values, valid, off, descending, nulls_at_start};
+  if ((rc = radix_pass(c, col, n, hist, offs, ka, ra)) != AH_OK) return rc;
+  // how many rows of each category?  offs (inclusive scan, digit-major): the last tile's entry of digit d
+  unsigned ends[3];
+  for (int d = 0; d < 3; d++)
+    AH_HIP(c, hipMemcpyAsync(&c->pinned[d], offs + ((int64_t)d + 1) * ntiles - 1, 4, hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  for (int d = 0; d < 3; d++) ends[d] = *(volatile unsigned*)&c->pinned[d];
+  // the `rest` category is digit 0 (nulls at end) or digit 2 (nulls at start)
+  const int64_t rest_lo = nulls_at_start ? ends[1] : 0;
+  const int64_t rest_n = nulls_at_start ? (int64_t)ends[2] - ends[1] : ends[0];
+  unsigned long long *kcur = ka + rest_lo, *kalt = kb + rest_lo;
+  unsigned *rcur = ra + rest_lo, *ralt = rb + rest_lo;
+  if (rest_n > 1) {
+    // (2) which key bytes vary
+    AH_HIP(c, hipMemsetAsync(andor, 0xFF, 8, c->stream));
+    AH_HIP(c, hipMemsetAsync(andor + 1, 0, 8, c->stream));
+    and_or_kernel<<<ah_stream_grid(c, ah_ceil_div(rest_n, kBlock), 4), kBlock, 0, c->stream>>>(kcur, rest_n, andor);
+    AH_LAUNCH_CHECK(c);
+    AH_HIP(c, hipMemcpyAsync(c->pinned, andor, 16, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    const unsigned long long varying = ((volatile unsigned long long*)c->pinned)[0] ^ ((volatile unsigned long long*)c->pinned)[1];
+    // (3) one stable pass per varying byte, least significant first
+    for (int b = 0; b < (int)sizeof(T); b++) {
+      if (((varying >> (8 * b)) & 0xFFull) == 0) continue;
+      Pairs src{kcur, rcur, 8 * b};
+      if ((rc = radix_pass(c, src, rest_n, hist, offs, kalt, ralt)) != AH_OK) return rc;
+      unsigned long long* tk = kcur; kcur = kalt; kalt = tk;
+      unsigned* tr = rcur; rcur = ralt; ralt = tr;
+    }
+  }
+  // (4) row numbers → uint64 output: NaN / null groups from pass (1)'s buffer, the rest from the last pass
+  const unsigned g = ah_stream_grid(c, ah_ceil_div(n, kBlock), 8);
+  if (rest_lo > 0) { emit_kernel<<<g, kBlock, 0, c->stream>>>(ra, rest_lo, out); AH_LAUNCH_CHECK(c); }
+  if (rest_n > 0) { emit_kernel<<<g, kBlock, 0, c->stream>>>(rcur, rest_n, out + rest_lo); AH_LAUNCH_CHECK(c); }
+  if (rest_lo + rest_n < n) { emit_kernel<<<g, kBlock, 0, c->stream>>>(ra + rest_lo + rest_n, n - rest_lo - rest_n, out + rest_lo + rest_n); AH_LAUNCH_CHECK(c); }
+  return AH_OK;
+}
+
+}  // namespace
+
+AH_EXPORT int ah_sort_indices(ah_ctx* c, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
+                              int nulls_at_start, uint64_t* out_indices) {
+  AH_ENTER(c);
+  if (n < 0 || off < 0) return ah_fail(c, AH_EINVALID, "sort_indices: negative length/offset");
+  if (n == 0) return AH_OK;
+  if (!values || !out_indices) return ah_fail(c, AH_EINVALID, "sort_indices: null buffer");
+  if (n >= ((int64_t)1 << 32)) return ah_fail(c, AH_ENOTIMPL, "sort_indices: more than 2^32 - 1 rows in one array");
+  const int w = ah_type_width(type);
+  if (!w) return ah_fail(c, AH_ENOTIMPL, "sorting not supported for type %d", type);  // vector_sort.go:266-268
+  if ((uintptr_t)values & (uintptr_t)(w - 1)) return ah_fail(c, AH_EINVALID, "sort_indices: buffer not element-aligned");
+  switch (type) {
+    case AH_UINT8: return sort_typed<uint8_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_INT8: return sort_typed<int8_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_UINT16: return sort_typed<uint16_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_INT16: return sort_typed<int16_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_UINT32: return sort_typed<uint32_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_INT32: return sort_typed<int32_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_UINT64: return sort_typed<uint64_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_INT64: return sort_typed<int64_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_FLOAT32: return sort_typed<float>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+    case AH_FLOAT64: return sort_typed<double>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+  }
+  return ah_fail(c, AH_ENOTIMPL, "sorting not supported for type %d", type);
+}

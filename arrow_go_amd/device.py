@@ -268,6 +268,11 @@ class Context:
         check(self.handle, lib.ah_is_in(self.handle, byte_width, _ptr(values), _ptr(valid), off, n, _ptr(set_values), _ptr(set_valid),
                                         set_off, set_n, null_behavior, _ptr(out_data), _ptr(out_valid), out_bit_offset))
 
+    # ---- sort ---------------------------------------------------------------------------
+    def sort_indices(self, type_id: int, values, valid, off: int, n: int, descending: bool, nulls_at_start: bool, out_indices) -> None:
+        check(self.handle, lib.ah_sort_indices(self.handle, type_id, _ptr(values), _ptr(valid), off, n, int(descending), int(nulls_at_start),
+                                               _ptr(out_indices)))
+
     # ---- hashing ------------------------------------------------------------------------
     def hash_u64_encode(self, keys, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_dict):
         nd = C.c_int64()

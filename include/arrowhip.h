@@ -312,6 +312,15 @@ int ah_is_in(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* val
              const void* set_values, const uint8_t* set_valid, int64_t set_off, int64_t set_n, int null_behavior,
              uint8_t* out_data, uint8_t* out_valid, int64_t out_bit_offset);
 
+/* ---- sort_indices (row §8(f)-2) ----------------------------------------------------------------
+ * replaces kernels.SortIndices for one key over one array (kernels/vector_sort.go:388-481 →
+ * arraySortOneColumnRange, vector_sort_internal.go:252-273) behind compute's "sort_indices"
+ * (compute/vector_sort.go:42-52): a STABLE permutation of [0, n) as uint64 row numbers; nulls at the
+ * end (default) or the start, NaNs next to them, the rest ascending or descending with ties in
+ * input order.  Stable LSD radix sort; synchronises (two small read-backs). */
+int ah_sort_indices(ah_ctx* ctx, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n,
+                    int descending, int nulls_at_start, uint64_t* out_indices);
+
 /* ---- fused scalar-expression evaluation (row §8(f)-1: the expression executor) ---------
  * What compute.Expression trees — NewCall / NewFieldRef / NewLiteral, arrow/compute/
  * expression.go:596-620 — evaluate to through executeScalarBatch (arrow/compute/exprs/

@@ -133,6 +133,11 @@ int orc_is_in(int byte_width, const void* values, const uint8_t* valid, int64_t 
               const void* set_values, const uint8_t* set_valid, int64_t set_off, int64_t set_n, int null_behavior,
               uint8_t* out_data, uint8_t* out_valid, int64_t out_off);
 
+/* ---- sort_indices of one numeric array (kernels/vector_sort.go:388-481, vector_sort_internal.go:252-273):
+ * stable; [rest, NaNs, nulls] (nulls at end) or [nulls, NaNs, rest] (at start); out: n uint64 row numbers */
+int orc_sort_indices(int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
+                     int nulls_at_start, uint64_t* out_indices);
+
 /* ---- fused Compare(>) → Filter → Sum (the unfused chain, restated) ---- */
 int orc_cmp_filter_sum_i64(int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n,
                            int64_t threshold, int64_t* out_sum, int64_t* out_count);

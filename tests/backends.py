@@ -83,6 +83,9 @@ class OracleBackend:
     def is_in(self, values, valid, off, set_values, set_valid, set_off, null_behavior, out_off=0, fill=0, misalign=0):
         return self.o.is_in(values, valid, off, set_values, set_valid, set_off, null_behavior, out_off, fill)
 
+    def sort_indices(self, values, valid, off, descending=False, nulls_at_start=False, misalign=0):
+        return self.o.sort_indices(values, valid, off, descending, nulls_at_start)
+
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
@@ -312,6 +315,15 @@ class HipBackend:
         odb.memset(fill); ovb.memset(fill)
         self.c.is_in(values.dtype.itemsize, vp, vvp, off, n, sp, svp, set_off, set_values.size, null_behavior, odb, ovb, out_off)
         return odb.download(np.uint8, nb), ovb.download(np.uint8, nb)
+
+    def sort_indices(self, values, valid, off, descending=False, nulls_at_start=False, misalign=0):
+        values = np.ascontiguousarray(values)
+        n = values.size
+        vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
+        ob = self.c.alloc(n * 8 + 64)
+        ob.memset(0xCD)
+        self.c.sort_indices(OL.TYPE_IDS[values.dtype], vp, vvp, off, n, descending, nulls_at_start, ob)
+        return ob.download(np.uint64, n)
 
     def hash_encode(self, keys, valid, off, encode_nulls):
         keys = np.ascontiguousarray(keys).view(np.uint64)

@@ -70,6 +70,7 @@ class Oracle:
             "orc_cast_numeric": (it, [it, it, vp, vp, i64, i64, it, it, vp, vp, vp]),
             "orc_cast_bool_to_numeric": (it, [it, vp, i64, i64, vp]),
             "orc_is_in": (it, [it, vp, vp, i64, i64, vp, vp, i64, i64, it, vp, vp, i64]),
+            "orc_sort_indices": (it, [it, vp, vp, i64, i64, it, it, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -224,6 +225,14 @@ class Oracle:
                                 set_values.size, null_behavior, _p(od), _p(ov), out_off)
         assert st == 0, st
         return od, ov
+
+    # ---- sort ---------------------------------------------------------------------------
+    def sort_indices(self, values, valid, off, descending, nulls_at_start):
+        values = np.ascontiguousarray(values)
+        out = np.zeros(max(values.size, 1), np.uint64)
+        st = self.lib.orc_sort_indices(TYPE_IDS[values.dtype], _p(values), _p(valid), off, values.size, int(descending), int(nulls_at_start), _p(out))
+        assert st == 0, st
+        return out[:values.size]
 
     # ---- hashing ------------------------------------------------------------------------
     def hash_int(self, v, alg=0): return int(self.lib.orc_hash_int(int(v) & (2**64 - 1), alg))

@@ -836,3 +836,59 @@ def test_is_in_bit_patterns_and_output_range(be):
             for buf in (od, ov):
                 bits = OL.unpack_bits(buf, 0, len(buf) * 8)
                 assert all(b == (fill & 1) for b in bits[:out_off]) and all(b == (fill & 1) for b in bits[out_off + n:])
+
+
+# ---- sort_indices ----------------------------------------------------------------------------
+# arrow/compute/vector_sort_test.go
+def run_sort(be, dtype, vals, descending=False, nulls_at_start=False, sl=None):
+    arr, valid = mk(vals, dtype, null_fill=0)
+    lo, hi = sl if sl else (0, len(vals))
+    return be.sort_indices(arr[lo:hi], valid, lo, descending, nulls_at_start).tolist()
+
+
+def test_sort_indices_reference_table(be):
+    # TestSortIndices :40-300
+    assert run_sort(be, np.int32, [3, 1, 4, 1, 5, 9, 2, 6]) == [1, 3, 6, 0, 2, 4, 7, 5]
+    assert run_sort(be, np.int32, [3, 1, 4, 1, 5, 9, 2, 6], descending=True) == [5, 7, 4, 2, 0, 6, 1, 3]
+    assert run_sort(be, np.int32, [3, None, 4, 0, 5]) == [3, 0, 2, 4, 1]
+    assert run_sort(be, np.int32, [3, None, 4, 0, 5], nulls_at_start=True) == [1, 3, 0, 2, 4]
+    assert run_sort(be, np.float64, [3.14, float("nan"), 2.71, 1.41, float("nan")]) == [3, 2, 0, 1, 4]
+    assert run_sort(be, np.int32, []) == []
+    assert run_sort(be, np.int32, [None, None, None]) == [0, 1, 2]
+    assert run_sort(be, np.int32, [1, 2, 1, 2, 1]) == [0, 2, 4, 1, 3]                       # StableSort
+    assert run_sort(be, np.uint64, [100, 50, 200, 25]) == [3, 1, 0, 2]
+    assert run_sort(be, np.float32, [3.0, 1.0, 4.0, 1.0, 5.0, 9.0, 2.0, 6.0]) == [1, 3, 6, 0, 2, 4, 7, 5]
+
+
+def test_sort_indices_cpp_parity_vectors(be):
+    # TestVectorSortIndicesCppArrayParity :1186-1240
+    v = [0, 1, None, -3, None, -42, 5]
+    assert run_sort(be, np.int16, v) == [5, 3, 0, 1, 6, 2, 4]
+    assert run_sort(be, np.int16, v, descending=True, nulls_at_start=True) == [2, 4, 6, 1, 0, 3, 5]
+    f = [None, 1, 3.3, None, 2, 5.3]
+    assert run_sort(be, np.float64, f) == [1, 4, 2, 5, 0, 3]
+    assert run_sort(be, np.float64, f, nulls_at_start=True) == [0, 3, 1, 4, 2, 5]
+    assert run_sort(be, np.float64, f, descending=True) == [5, 2, 4, 1, 0, 3]
+    assert run_sort(be, np.float64, f, descending=True, nulls_at_start=True) == [0, 3, 5, 2, 4, 1]
+    u = [255, None, 0, 255, 10, None, 128, 0]
+    assert run_sort(be, np.uint8, u) == [2, 7, 4, 6, 0, 3, 1, 5]
+    assert run_sort(be, np.uint8, u, nulls_at_start=True) == [1, 5, 2, 7, 4, 6, 0, 3]
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+def test_sort_indices_rules(be, dtype):
+    # ties keep their input order in BOTH directions; NaNs sit next to the nulls whatever the order;
+    # −0.0 and +0.0 tie; a slice sorts its own rows (indices relative to the slice)
+    assert run_sort(be, dtype, [2, 1, 2, 1], descending=True) == [0, 2, 1, 3]
+    assert run_sort(be, dtype, [9, 5, None, 7, 5], sl=(1, 5)) == [0, 3, 2, 1]
+    if np.dtype(dtype).kind == "f":
+        nan = float("nan")
+        v = [1.0, nan, None, -0.0, 0.0, float("-inf"), nan, float("inf")]
+        assert run_sort(be, dtype, v) == [5, 3, 4, 0, 7, 1, 6, 2]
+        assert run_sort(be, dtype, v, descending=True) == [7, 0, 3, 4, 5, 1, 6, 2]
+        assert run_sort(be, dtype, v, nulls_at_start=True) == [2, 1, 6, 5, 3, 4, 0, 7]
+        assert run_sort(be, dtype, v, descending=True, nulls_at_start=True) == [2, 1, 6, 7, 0, 3, 4, 5]
+    else:
+        info = np.iinfo(dtype)
+        assert run_sort(be, dtype, [info.max, info.min, 1, info.max]) == [1, 2, 0, 3]
+        assert run_sort(be, dtype, [info.max, info.min, 1, info.max], descending=True) == [0, 3, 2, 1]

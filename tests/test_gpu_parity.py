@@ -630,6 +630,48 @@ def test_is_in_large_set(hip, orc_be):
     assert 140000 < int(np.unpackbits(gd, bitorder="little")[:vals.size].sum()) < 160000
 
 
+# ---- sort_indices ----------------------------------------------------------------------------
+SORT_SIZES = [1, 2, 63, 64, 65, 511, 2047, 2048, 2049, 4097, 70001, 300007]
+
+
+@pytest.mark.parametrize("dtype", OL.ALL_DTYPES, ids=str)
+def test_sort_indices_bit_exact(hip, orc_be, dtype):
+    """the permutation itself is compared (a stable sort has exactly one answer): heavy duplicates,
+    full-range values, nulls, NaN / ±inf / ±0, both orders and both null placements, sliced validity"""
+    rng = np.random.default_rng(8000 + OL.TYPE_IDS[np.dtype(dtype)])
+    dt = np.dtype(dtype)
+    for k, n in enumerate(SORT_SIZES):
+        for flavour in range(3):
+            if flavour == 0:      # few distinct values: ties everywhere
+                a = rng.integers(0, 7, n).astype(dt)
+            elif flavour == 1:    # full range
+                a = rand(rng, dtype, n)
+            else:                 # small range around zero, negative where the type allows
+                a = (rng.integers(0, 2000, n) - (1000 if dt.kind != "u" else 0)).astype(dt)
+            if dt.kind == "f" and n > 16:
+                a[rng.integers(0, n, 6)] = [np.nan, -np.nan, np.inf, -np.inf, -0.0, 0.0]
+            off = int(rng.integers(0, 40))
+            valid = OL.pack_bits([True] * off + list(rng.random(n) >= 0.15)) if (k + flavour) % 2 else None
+            desc, at_start = bool((k + flavour) & 1), bool((k >> 1) & 1)
+            e = orc_be.sort_indices(a, valid, off, desc, at_start)
+            g = hip.sort_indices(a, valid, off, desc, at_start, misalign=k % 3)
+            assert g.tobytes() == e.tobytes(), (dtype, n, flavour, desc, at_start)
+
+
+def test_sort_indices_many_tiles(hip, orc_be):
+    rng = np.random.default_rng(8100)
+    n = (1 << 22) + 77
+    for dtype in (np.int64, np.float64, np.uint16):
+        a = rand(rng, dtype, n) if dtype != np.uint16 else rng.integers(0, 65536, n).astype(np.uint16)
+        valid = OL.pack_bits(list(rng.random(n) >= 0.05))
+        e = orc_be.sort_indices(a, valid, 0, False, False)
+        g = hip.sort_indices(a, valid, 0, False, False)
+        assert g.tobytes() == e.tobytes(), dtype
+    # already sorted / reverse sorted / constant columns
+    for a in (np.arange(n, dtype=np.int64), np.arange(n, 0, -1, dtype=np.int64), np.full(n, 42, np.int64)):
+        assert hip.sort_indices(a, None, 0, True, False).tobytes() == orc_be.sort_indices(a, None, 0, True, False).tobytes()
+
+
 # ---- full-size properties (BASELINE.json configs; no oracle pass needed) -------------------
 def test_full_size_properties(ctx):
     """C2/C3 sizes (2^27 rows = 1 GiB columns) checked through size-independent
