@@ -217,6 +217,15 @@ struct SetOptions : FunctionOptions {
   NullMatchingBehavior NullBehavior = NullMatchingMatch;
   const char* TypeName() const override { return "SetOptions"; }
 };
+// kernels.SortKey / compute.SortOptions (kernels/vector_sort.go:27-58, compute/vector_sort.go:88-104): one key per
+// sort column; for a bare array only the first key is used and ColumnIndex is ignored
+enum SortOrder { SortOrderAscending = 0, SortOrderDescending = 1 };
+enum NullPlacement { SortNullsAtEnd = 0, SortNullsAtStart = 1 };
+struct SortKey { int ColumnIndex = 0; SortOrder Order = SortOrderAscending; NullPlacement Placement = SortNullsAtEnd; };
+struct SortOptions : FunctionOptions {
+  std::vector<SortKey> Keys;
+  const char* TypeName() const override { return "SortKeys"; }
+};
 // kernels.CumulativeOptions (vector_cumulative.go:30-39): nil Start = zero of the input type
 struct CumulativeOptions : FunctionOptions { ScalarPtr Start; bool SkipNulls = false; const char* TypeName() const override { return "CumulativeOptions"; } };
 struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
@@ -333,6 +342,7 @@ void RegisterScalarBoolean(FunctionRegistry* reg);
 void RegisterVectorCumulative(FunctionRegistry* reg);
 void RegisterScalarCast(FunctionRegistry* reg);
 void RegisterScalarSetLookup(FunctionRegistry* reg);
+void RegisterVectorSort(FunctionRegistry* reg);
 const DataType* CommonNumeric(const std::vector<const DataType*>& types);  // utils.go:178-240; nullptr if none
 // compute.CastDatum / CastArray (cast.go:917-935)
 Status CastDatum(ExecCtx* ctx, const Datum& in, const CastOptions& opts, Datum* out);

@@ -151,6 +151,7 @@ AHC_EXPORT int ahc_datum_info(ahc_datum* d, int* kind, int* type_id, int64_t* le
 //   null_selection_behavior=drop|emit_null   bounds_check=0|1   null_encoding_behavior=mask|encode
 //   to_type=<type>   safe=0|1   allow_int_overflow=0|1   allow_float_truncate=0|1       (CastOptions)
 //   value_set=@<ahc_datum* in hex>   null_matching_behavior=match|skip|emit_null|inconclusive      (SetOptions)
+//   order=ascending|descending   null_placement=at_end|at_start                                   (SortOptions, one key)
 //   skip_nulls=0|1   start=<type>:<value>|null:<type>   (e.g. start=int64:10, start=double:1.5, start=null:int32)
 struct ParsedOptions {
   compute::FilterOptions filter;
@@ -159,6 +160,7 @@ struct ParsedOptions {
   compute::CumulativeOptions cumulative;
   compute::CastOptions cast;
   compute::SetOptions set;
+  compute::SortOptions sort;
   const compute::FunctionOptions* pick = nullptr;
 };
 static const struct { const char* name; Type id; } kTypeNames[] = {
@@ -218,6 +220,12 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
         p->set.NullBehavior = v == "skip" ? compute::NullMatchingSkip : v == "emit_null" ? compute::NullMatchingEmitNull
                             : v == "inconclusive" ? compute::NullMatchingInconclusive : compute::NullMatchingMatch;
         p->pick = &p->set;
+      }
+      if (k == "order" || k == "null_placement") {
+        if (p->sort.Keys.empty()) p->sort.Keys.push_back(compute::SortKey());
+        if (k == "order") p->sort.Keys[0].Order = v == "descending" ? compute::SortOrderDescending : compute::SortOrderAscending;
+        else p->sort.Keys[0].Placement = v == "at_start" ? compute::SortNullsAtStart : compute::SortNullsAtEnd;
+        p->pick = &p->sort;
       }
       if (k == "skip_nulls") { p->cumulative.SkipNulls = v != "0"; p->pick = &p->cumulative; }
       if (k == "start") { p->cumulative.Start = ParseScalarText(v); p->pick = &p->cumulative; }

@@ -499,6 +499,7 @@ FunctionRegistry* GetFunctionRegistry() {
     RegisterVectorCumulative(r);
     RegisterScalarCast(r);
     RegisterScalarSetLookup(r);
+    RegisterVectorSort(r);
     RegisterFusedExtensions(r);
     return r;
   }();

@@ -532,6 +532,46 @@ void RegisterScalarSetLookup(FunctionRegistry* reg) {
   reg->AddFunction(fn, false);
 }
 
+// ---- sort_indices / sort ------------------------------------------------------------------------------
+// sortIndicesMetaFunc → sortIndicesImpl (compute/vector_sort.go:42-52, 117-190) → kernels.SortIndices
+// (kernels/vector_sort.go:388-481), array input: one key, ColumnIndex ignored; uint64 indices, no nulls
+static Status SortIndicesImpl(ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
+  const SortOptions* opts = dynamic_cast<const SortOptions*>(o);
+  if (!opts || opts->Keys.empty()) return Status::Make(StatusCode::Invalid, "must provide at least one sort key");  // :119-121
+  if (args[0].kind != DatumKind::Array)
+    return Status::Make(StatusCode::NotImplemented, "unsupported type for sort_indices operation: the accelerated path sorts arrays");
+  Session* s = ctx->session;
+  const ArrayData& a = *args[0].array;
+  if (!IsInteger(a.type->id) && !IsFloating(a.type->id))
+    return Status::Make(StatusCode::NotImplemented, std::string("sorting not supported for type ") + a.type->name);  // :266-268
+  const SortKey& key = opts->Keys[0];
+  auto res = std::make_shared<ArrayData>();
+  res->type = GetDataType(Type::UINT64);
+  res->length = a.length;
+  res->null_count = 0;
+  AHC_RETURN_NOT_OK(s->Allocate(a.length * 8, &res->buffers[1]));
+  if (a.length > 0) {
+    int w = a.type->bit_width / 8;
+    const uint8_t* valid = (a.buffers[0] && a.null_count != 0) ? (const uint8_t*)a.buffers[0]->dptr : nullptr;
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_sort_indices(s->ctx(), (int)a.type->id, (const uint8_t*)a.buffers[1]->dptr + a.offset * w, valid, a.offset,
+                                                    a.length, key.Order == SortOrderDescending, key.Placement == SortNullsAtStart,
+                                                    (uint64_t*)res->buffers[1]->dptr)));
+  }
+  *out = Datum::Of(res);
+  return Status::OK();
+}
+
+void RegisterVectorSort(FunctionRegistry* reg) {
+  reg->AddFunction(std::make_shared<MetaFunction>("sort_indices", Arity{1, false}, nullptr, SortIndicesImpl), false);
+  // sortMetaFunc (compute/vector_sort.go:66-85): take(input, sort_indices(input, options))
+  reg->AddFunction(std::make_shared<MetaFunction>("sort", Arity{1, false}, nullptr,
+      [](ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
+        Datum indices;
+        AHC_RETURN_NOT_OK(CallFunction(ctx, "sort_indices", o, args, &indices));
+        return CallFunction(ctx, "take", nullptr, {args[0], indices}, out);
+      }), false);
+}
+
 // ---- cumulative_sum / cumulative_sum_checked ---------------------------------------------------
 // Safe numeric cast of the Start scalar to the input type — what safeCastScalar → CastDatum(SafeCastOptions)
 // decides (compute/vector_cumulative.go:53-70, kernels/vector_cumulative.go:71-90): integer targets

@@ -32,7 +32,7 @@ def test_registry_has_the_path_functions():
                  "abs_unchecked", "negate_unchecked", "sign", "equal", "not_equal", "greater", "greater_equal", "less",
                  "less_equal", "and", "or", "xor", "and_not", "invert", "and_kleene", "or_kleene", "and_not_kleene",
                  "filter", "array_filter", "take", "array_take", "unique", "dictionary_encode", "greater_filter_sum",
-                 "cumulative_sum", "cumulative_sum_checked", "cast", "cast_int32", "cast_double", "cast_boolean", "is_in"]:
+                 "cumulative_sum", "cumulative_sum_checked", "cast", "cast_int32", "cast_double", "cast_boolean", "is_in", "sort_indices", "sort"]:
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
@@ -536,6 +536,48 @@ def test_is_in_options_casts_and_arrow_cpp(sess):
     assert sess.call_function("is_in", [a], "null_matching_behavior=skip", value_set=vs).equals(pc.is_in(a, value_set=vs, skip_nulls=True))
     f = pa.array([0.0, -0.0, 1.5, None], pa.float64())
     assert sess.call_function("is_in", [f], value_set=pa.array([0.0, None], pa.float64())).to_pylist() == [True, False, False, True]
+
+
+# ---- sort_indices / sort (arrow/compute/vector_sort_test.go) ------------------------------------------------
+@pytest.mark.gpu
+def test_sort_indices_reference_tables(sess):
+    from arrow_go_amd import compute as ac
+    si = lambda a, o="order=ascending": sess.call_function("sort_indices", [a], o).to_pylist()
+    I32 = lambda v: pa.array(v, type=pa.int32())
+    assert si(I32([3, 1, 4, 1, 5, 9, 2, 6])) == [1, 3, 6, 0, 2, 4, 7, 5]                                  # TestSortIndices :40
+    assert si(I32([3, 1, 4, 1, 5, 9, 2, 6]), "order=descending") == [5, 7, 4, 2, 0, 6, 1, 3]
+    assert si(I32([3, None, 4, 0, 5])) == [3, 0, 2, 4, 1]
+    assert si(I32([3, None, 4, 0, 5]), "null_placement=at_start") == [1, 3, 0, 2, 4]
+    assert si(pa.array([3.14, float("nan"), 2.71, 1.41, float("nan")])) == [3, 2, 0, 1, 4]
+    assert si(I32([])) == [] and si(I32([None, None, None])) == [0, 1, 2]
+    assert si(I32([1, 2, 1, 2, 1])) == [0, 2, 4, 1, 3]
+    v = pa.array([0, 1, None, -3, None, -42, 5], pa.int16())                                             # CppArrayParity :1186
+    assert si(v) == [5, 3, 0, 1, 6, 2, 4]
+    assert si(v, "order=descending;null_placement=at_start") == [2, 4, 6, 1, 0, 3, 5]
+    out = sess.call_function("sort_indices", [v], "order=ascending")
+    assert out.type == pa.uint64() and out.null_count == 0
+    # sort = take(input, sort_indices(input))  (TestSortArray :326)
+    assert sess.call_function("sort", [v], "order=ascending").to_pylist() == [-42, -3, 0, 1, 5, None, None]
+    assert sess.call_function("sort", [v.slice(1, 5)], "order=descending").to_pylist() == [1, -3, -42, None, None]
+    with pytest.raises(ac.ErrInvalid, match="at least one sort key"):
+        sess.call_function("sort_indices", [v])
+    with pytest.raises(ac.ErrNotImplemented, match="sorting not supported"):
+        sess.call_function("sort_indices", [pa.array([True, False])], "order=ascending")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", NUMERIC, ids=str)
+def test_sort_indices_random_vs_arrow_cpp(sess, typ):
+    # Arrow C++ sort_indices is stable with the same null / NaN placement rules
+    rng = np.random.default_rng(typ.bit_width + 31)
+    n = 30011
+    vals = rng.integers(0, 50, n).astype(typ.to_pandas_dtype())
+    a = pa.array(vals, mask=rng.random(n) < 0.1, type=typ).slice(9, n - 20)
+    for order in ("ascending", "descending"):
+        for npl in ("at_end", "at_start"):
+            got = sess.call_function("sort_indices", [a], "order=%s;null_placement=%s" % (order, npl))
+            exp = pc.sort_indices(a, sort_keys=[("x", order)], null_placement=npl) if False else pc.array_sort_indices(a, order=order, null_placement=npl)
+            assert got.to_pylist() == exp.to_pylist(), (typ, order, npl)
 
 
 # ---- arrow/math + fused -------------------------------------------------------------------------------------
