@@ -43,7 +43,73 @@ lib.ahc_math_sum.argtypes = [_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int6
 lib.ahc_has_function.argtypes = [C.c_char_p]
 lib.ahc_function_num_kernels.argtypes = [C.c_char_p]
 lib.ahc_registry_add_alias.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_int]
+lib.ahc_import_device.argtypes = [_vp, _vp, _vp, C.POINTER(_vp)]
+lib.ahc_export_device.argtypes = [_vp, _vp, _vp, _vp]
+lib.ahc_datum_buffers.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]
 lib.ahc_expr_eval.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]
+
+
+# ---- Arrow C (Device) Data Interface structs (arrow/cdata/abi.h) ------------------------------------
+class CArrowSchema(C.Structure):
+    pass
+
+
+CArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+                         ("n_children", C.c_int64), ("children", _vp), ("dictionary", _vp),
+                         ("release", C.CFUNCTYPE(None, C.POINTER(CArrowSchema))), ("private_data", _vp)]
+
+
+class CArrowArray(C.Structure):
+    pass
+
+
+CArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                        ("n_children", C.c_int64), ("buffers", C.POINTER(_vp)), ("children", _vp), ("dictionary", _vp),
+                        ("release", C.CFUNCTYPE(None, C.POINTER(CArrowArray))), ("private_data", _vp)]
+
+
+class CArrowDeviceArray(C.Structure):
+    _fields_ = [("array", CArrowArray), ("device_id", C.c_int64), ("device_type", C.c_int32), ("sync_event", _vp),
+                ("reserved", C.c_int64 * 3)]
+
+
+ARROW_DEVICE_CPU, ARROW_DEVICE_ROCM, ARROW_DEVICE_ROCM_HOST = 1, 10, 11
+_FORMATS = {"bool": b"b", "int8": b"c", "uint8": b"C", "int16": b"s", "uint16": b"S", "int32": b"i", "uint32": b"I", "int64": b"l",
+            "uint64": b"L", "float": b"f", "double": b"g"}
+
+
+class DeviceArray:
+    """An array datum that stays in HBM (an ahc_datum handle).  Pass it to call_function like a
+    pyarrow array; `to_arrow()` downloads, `export_device()` hands the buffers to another ROCm consumer
+    through the Arrow C Device Data Interface without a copy."""
+
+    def __init__(self, session, handle):
+        self.session, self.h = session, handle
+
+    def buffers(self):
+        v, d = _vp(), _vp()
+        lib.ahc_datum_buffers(self.h, C.byref(v), C.byref(d))
+        return v.value, d.value
+
+    def to_arrow(self):
+        return self.session._export(self.h)
+
+    def export_device(self):
+        """→ (CArrowDeviceArray, CArrowSchema); the caller owns them and must call array.release."""
+        darr, sch = CArrowDeviceArray(), CArrowSchema()
+        self.session._check(lib.ahc_export_device(self.session.h, self.h, C.addressof(darr), C.addressof(sch)))
+        return darr, sch
+
+    def release(self):
+        if self.h:
+            lib.ahc_datum_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class ArrowError(Exception):
@@ -103,6 +169,7 @@ class Session:
         if rc != 0:
             raise ErrHip("ahc_session_create failed: is a GPU visible? (no CPU fallback)")
         self.h = h
+        self.device_id = device_id
 
     def close(self):
         if self.h:
@@ -143,8 +210,48 @@ class Session:
         self._check(lib.ahc_scalar(self.h, tid, int(valid), buf, C.byref(d)))
         return d
 
+    def import_device(self, type_name: str, length: int, data_ptr, validity_ptr=None, null_count: int = 0, offset: int = 0,
+                      sync_event=None, on_release=None, device_type: int = ARROW_DEVICE_ROCM, device_id=None) -> "DeviceArray":
+        """Consumer side of the Arrow C Device Data Interface (arrow/cdata/abi.h:66-128): wrap device
+        buffers produced elsewhere WITHOUT copying them.  `on_release` is called when the library lets
+        go of the producer's array (its release callback)."""
+        bufs = (_vp * 2)(validity_ptr, data_ptr)
+        fmt = _FORMATS[type_name]
+        keep = {"bufs": bufs, "fmt": fmt}
+
+        def _release_array(ptr):
+            ptr.contents.release = C.cast(None, CArrowArray._fields_[8][1])
+            if on_release:
+                on_release()
+            keep.clear()
+
+        def _release_schema(ptr):
+            ptr.contents.release = C.cast(None, CArrowSchema._fields_[7][1])
+
+        rel_a = CArrowArray._fields_[8][1](_release_array)
+        rel_s = CArrowSchema._fields_[7][1](_release_schema)
+        keep["cb"] = (rel_a, rel_s)
+        self._device_imports = getattr(self, "_device_imports", [])
+        self._device_imports.append(keep)  # callbacks must outlive the C side's use of them
+        darr = CArrowDeviceArray()
+        darr.array.length, darr.array.null_count, darr.array.offset = length, null_count, offset
+        darr.array.n_buffers, darr.array.n_children = 2, 0
+        darr.array.buffers = C.cast(bufs, C.POINTER(_vp))
+        darr.array.release = rel_a
+        darr.device_id = self.device_id if device_id is None else device_id
+        darr.device_type = device_type
+        darr.sync_event = sync_event
+        sch = CArrowSchema()
+        sch.format, sch.name, sch.flags = fmt, b"", 2
+        sch.release = rel_s
+        d = _vp()
+        self._check(lib.ahc_import_device(self.h, C.addressof(darr), C.addressof(sch), C.byref(d)))
+        return DeviceArray(self, d)
+
     def _to_datum(self, x):
         import pyarrow as pa
+        if isinstance(x, DeviceArray):
+            return x.h
         if isinstance(x, (pa.Array, pa.ChunkedArray)):
             return self._import(x)
         if isinstance(x, pa.Scalar):
@@ -169,9 +276,11 @@ class Session:
         return pa.Array._import_from_c(C.addressof(a), C.addressof(s))
 
     # -- compute.CallFunction
-    def call_function(self, name: str, args, options: str = "", value_set=None):
-        """options: "key=value;…" (Go struct tags).  value_set: the SetOptions.ValueSet array of is_in."""
+    def call_function(self, name: str, args, options: str = "", value_set=None, keep_on_device: bool = False):
+        """options: "key=value;…" (Go struct tags).  value_set: the SetOptions.ValueSet array of is_in.
+        keep_on_device: return a DeviceArray (no download) — chain calls without leaving HBM."""
         datums = [self._to_datum(x) for x in args]
+        borrowed_handles = [x.h.value for x in list(args) + ([value_set] if value_set is not None else []) if isinstance(x, DeviceArray)]
         if value_set is not None:
             vs = self._to_datum(value_set)
             datums.append(vs)  # released with the arguments
@@ -183,13 +292,16 @@ class Session:
             arr = (_vp * len(datums))(*datums)
             out = _vp()
             self._check(lib.ahc_call(self.h, name.encode(), options.encode(), nargs, arr, C.byref(out)))
+            if keep_on_device:
+                return DeviceArray(self, out)
             try:
                 return self._export(out)
             finally:
                 lib.ahc_datum_release(out)
         finally:
             for d in datums:
-                lib.ahc_datum_release(d)
+                if d.value not in borrowed_handles:  # DeviceArray arguments stay owned by their wrappers
+                    lib.ahc_datum_release(d)
 
     # -- compute.Expression / exprs.ExecuteScalarExpression
     def eval_expression(self, text: str, columns, literals=(), fuse: bool = True, raw: bool = False):

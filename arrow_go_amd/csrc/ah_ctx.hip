@@ -214,3 +214,13 @@ AH_EXPORT int ah_event_elapsed_ms(ah_ctx* c, int slot_a, int slot_b, float* ms_h
   if (ms_host) *ms_host = ms;
   return AH_OK;
 }
+
+// ArrowDeviceArray.sync_event for ARROW_DEVICE_ROCM is a hipEvent_t* (arrow/cdata/abi.h:104-128)
+AH_EXPORT int ah_wait_event(ah_ctx* c, void* hip_event_ptr) {
+  AH_ENTER(c);
+  if (!hip_event_ptr) return AH_OK;
+  AH_HIP(c, hipStreamWaitEvent(c->stream, *(hipEvent_t*)hip_event_ptr, 0));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_device_id(ah_ctx* c) { return c ? c->device : -1; }

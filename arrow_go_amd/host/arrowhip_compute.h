@@ -72,6 +72,10 @@ struct Buffer {
   Session* session = nullptr;
   void* dptr = nullptr;
   int64_t size = 0;
+  // foreign device memory (Arrow C Device Data Interface import): not freed here; `owner` keeps the
+  // producer's ArrowArray alive and calls its release callback when the last buffer goes away
+  bool owned = true;
+  std::shared_ptr<void> owner;
   ~Buffer();
 };
 using BufferPtr = std::shared_ptr<Buffer>;

@@ -38,6 +38,17 @@ struct ArrowArray {
   void (*release)(struct ArrowArray*);
   void* private_data;
 };
+// Arrow C Device Data Interface (arrow/cdata/abi.h:66-128)
+#define ARROW_DEVICE_CPU 1
+#define ARROW_DEVICE_ROCM 10
+#define ARROW_DEVICE_ROCM_HOST 11
+struct ArrowDeviceArray {
+  struct ArrowArray array;
+  int64_t device_id;
+  int32_t device_type;
+  void* sync_event;
+  int64_t reserved[3];
+};
 }
 
 using namespace arrowhip;
@@ -347,6 +358,125 @@ AHC_EXPORT int ahc_export(ahc_session* s, ahc_datum* d, ArrowArray* arr, ArrowSc
   }
   Status st = ExportOne(ss, a, a.type, arr, schema);
   return st.ok() ? 0 : Fail(s, st);
+}
+
+// ---- Arrow C Device Data Interface (row §8(f)-3; arrow/cdata/abi.h:66-128, the producer / consumer contract of
+// arrow/cdata/interface.go applied to device memory) ------------------------------------------------------------
+// Import.  ARROW_DEVICE_ROCM on this session's device: ZERO COPY — the buffers are wrapped, the producer's
+// ArrowArray is moved into a holder whose destructor calls its release callback once the last buffer of the
+// datum (or of anything computed as a view of it) is gone; the compute stream waits for sync_event.
+// ARROW_DEVICE_CPU / ARROW_DEVICE_ROCM_HOST: the host-array path (upload).
+namespace {
+struct ImportHolder {
+  ArrowArray arr;
+  ~ImportHolder() { if (arr.release) arr.release(&arr); }
+};
+}  // namespace
+
+AHC_EXPORT int ahc_import_device(ahc_session* s, ArrowDeviceArray* darr, ArrowSchema* schema, ahc_datum** out) {
+  *out = nullptr;
+  if (darr->device_type == ARROW_DEVICE_CPU || darr->device_type == ARROW_DEVICE_ROCM_HOST)
+    return ahc_import(s, &darr->array, schema, out);
+  Session* ss = s->session.get();
+  Status st;
+  const DataType* t = TypeFromFormat(schema->format);
+  if (darr->device_type != ARROW_DEVICE_ROCM)
+    st = Status::Make(StatusCode::NotImplemented, "ArrowDeviceArray: device type " + std::to_string(darr->device_type) + " is not ROCm / CPU");
+  else if (darr->device_id != ah_device_id(ss->ctx()))
+    st = Status::Make(StatusCode::Invalid, "ArrowDeviceArray lives on device " + std::to_string(darr->device_id) + ", the session on device " +
+                                               std::to_string(ah_device_id(ss->ctx())));
+  else if (!t)
+    st = Status::Make(StatusCode::NotImplemented, std::string("unsupported Arrow format '") + (schema->format ? schema->format : "") + "'");
+  else if (darr->array.n_buffers < 2 || darr->array.n_children != 0 || darr->array.dictionary)
+    st = Status::Make(StatusCode::NotImplemented, "ArrowDeviceArray: fixed-width primitive layout only");
+  if (st.ok()) st = ss->FromStatus(ah_wait_event(ss->ctx(), darr->sync_event));
+  if (!st.ok()) {
+    if (darr->array.release) darr->array.release(&darr->array);
+    if (schema->release) schema->release(schema);
+    return Fail(s, st);
+  }
+  auto holder = std::make_shared<ImportHolder>();
+  holder->arr = darr->array;       // move: the consumer owns the struct now …
+  darr->array.release = nullptr;   // … and marks the source released (C Data Interface "moving")
+  const ArrowArray& a = holder->arr;
+  auto d = std::make_shared<ArrayData>();
+  d->type = t;
+  d->length = a.length;
+  d->null_count = a.null_count;
+  d->offset = a.offset;
+  const int64_t nbits = a.offset + a.length;
+  const int64_t vbytes = (nbits + 7) / 8;
+  const int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
+  auto wrap = [&](const void* p, int64_t size) {
+    auto b = std::make_shared<Buffer>();
+    b->session = ss;
+    b->dptr = const_cast<void*>(p);
+    b->size = size;
+    b->owned = false;
+    b->owner = holder;
+    return b;
+  };
+  if (a.buffers[0] != nullptr && a.null_count != 0) d->buffers[0] = wrap(a.buffers[0], vbytes);
+  else d->null_count = 0;
+  if (a.buffers[1] != nullptr) d->buffers[1] = wrap(a.buffers[1], dbytes);
+  else st = ss->Allocate(dbytes, &d->buffers[1]);  // zero-length arrays may carry no data buffer
+  if (schema->release) schema->release(schema);
+  if (!st.ok()) return Fail(s, st);
+  *out = new ahc_datum{Datum::Of(d)};
+  return 0;
+}
+
+// Export.  The datum's device buffers are handed out as they are (no copy); the ArrowDeviceArray keeps the
+// ArrayData alive until the consumer calls release.  The compute stream is synchronised first, so
+// sync_event = NULL ("no synchronisation needed", abi.h:118-124).
+namespace {
+struct DeviceExportPriv {
+  ArrayDataPtr keep;
+  const void* buffer_ptrs[2] = {nullptr, nullptr};
+};
+void ReleaseDeviceArray(ArrowArray* a) {
+  delete (DeviceExportPriv*)a->private_data;
+  a->release = nullptr;
+}
+}  // namespace
+
+AHC_EXPORT int ahc_export_device(ahc_session* s, ahc_datum* d, ArrowDeviceArray* out, ArrowSchema* schema) {
+  if (d->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "only array datums can be exported"));
+  const ArrayDataPtr& a = d->d.array;
+  if (a->type->id == Type::DICTIONARY) return Fail(s, Status::Make(StatusCode::NotImplemented, "device export of dictionary arrays"));
+  Session* ss = s->session.get();
+  Status st = ss->FromStatus(ah_sync(ss->ctx()));
+  if (!st.ok()) return Fail(s, st);
+  memset(out, 0, sizeof(*out));
+  memset(schema, 0, sizeof(*schema));
+  auto* p = new DeviceExportPriv();
+  p->keep = a;
+  const bool has_nulls = a->buffers[0] && a->null_count != 0;
+  p->buffer_ptrs[0] = has_nulls ? a->buffers[0]->dptr : nullptr;
+  p->buffer_ptrs[1] = a->buffers[1] ? a->buffers[1]->dptr : nullptr;
+  out->array.length = a->length;
+  out->array.null_count = has_nulls ? a->null_count : 0;
+  out->array.offset = a->offset;
+  out->array.n_buffers = 2;
+  out->array.buffers = p->buffer_ptrs;
+  out->array.release = ReleaseDeviceArray;
+  out->array.private_data = p;
+  out->device_id = ah_device_id(ss->ctx());
+  out->device_type = ARROW_DEVICE_ROCM;
+  out->sync_event = nullptr;
+  schema->format = a->type->format;
+  schema->name = "";
+  schema->flags = 2;  // ARROW_FLAG_NULLABLE
+  schema->release = ReleaseSchema;
+  return 0;
+}
+
+// test / interop introspection: the device pointers behind an array datum
+AHC_EXPORT int ahc_datum_buffers(ahc_datum* d, void** validity, void** data) {
+  if (d->d.kind != DatumKind::Array) return 1;
+  *validity = d->d.array->buffers[0] ? d->d.array->buffers[0]->dptr : nullptr;
+  *data = d->d.array->buffers[1] ? d->d.array->buffers[1]->dptr : nullptr;
+  return 0;
 }
 
 // ---- expressions ----------------------------------------------------------------------------------

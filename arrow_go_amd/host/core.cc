@@ -39,7 +39,7 @@ std::string Status::ToString() const {
 
 // ---- session / buffers ------------------------------------------------------------------
 Buffer::~Buffer() {
-  if (dptr && session && session->ctx()) ah_buf_free(session->ctx(), dptr);
+  if (owned && dptr && session && session->ctx()) ah_buf_free(session->ctx(), dptr);
 }
 
 Status Session::Create(int device_id, std::unique_ptr<Session>* out) {

@@ -282,6 +282,13 @@ int ah_cumulative_sum(ah_ctx* ctx, int type, const void* values, const uint8_t* 
                       const void* start_host, int skip_nulls, int checked, void* out_values, uint8_t* out_valid,
                       int64_t* out_null_count_host);
 
+/* ---- device interchange (row §8(f)-3) ---------------------------------------------------------------
+ * ArrowDeviceArray.sync_event (arrow/cdata/abi.h:104-128; for ARROW_DEVICE_ROCM a hipEvent_t*): make
+ * the context's compute stream wait for the producer's event before touching imported buffers.
+ * NULL = already synchronised.  No host synchronisation. */
+int ah_wait_event(ah_ctx* ctx, void* hip_event_ptr);
+int ah_device_id(ah_ctx* ctx);
+
 /* ---- numeric cast (row §8(f)-2) ----------------------------------------------------------------
  * replaces castNumberToNumberUnsafe → castNumericUnsafe (kernels/cast_numeric.go:28-131; AVX2 leaf
  * cast_type_numeric_avx2(itype, otype, in, out, len), kernels/_lib/cast_numeric.cc:62) together with
