@@ -268,6 +268,12 @@ class Context:
         check(self.handle, lib.ah_is_in(self.handle, byte_width, _ptr(values), _ptr(valid), off, n, _ptr(set_values), _ptr(set_valid),
                                         set_off, set_n, null_behavior, _ptr(out_data), _ptr(out_valid), out_bit_offset))
 
+    # ---- min / max ----------------------------------------------------------------------
+    def min_max(self, type_id: int, values, n: int, dtype):
+        lo, hi = np.zeros(1, dtype), np.zeros(1, dtype)
+        check(self.handle, lib.ah_min_max(self.handle, type_id, _ptr(values), n, lo.ctypes.data, hi.ctypes.data))
+        return lo[0], hi[0]
+
     # ---- sort ---------------------------------------------------------------------------
     def sort_indices(self, type_id: int, values, valid, off: int, n: int, descending: bool, nulls_at_start: bool, out_indices) -> None:
         check(self.handle, lib.ah_sort_indices(self.handle, type_id, _ptr(values), _ptr(valid), off, n, int(descending), int(nulls_at_start),

@@ -289,6 +289,13 @@ int ah_cumulative_sum(ah_ctx* ctx, int type, const void* values, const uint8_t* 
 int ah_wait_event(ah_ctx* ctx, void* hip_event_ptr);
 int ah_device_id(ah_ctx* ctx);
 
+/* ---- min_max (row §8(f)-2) -----------------------------------------------------------------------
+ * replaces utils.GetMinMax{Int8…Uint64} (internal/utils/min_max.go:161-215; AVX2 leaves
+ * _int64_max_min_avx2(values, len, &min, &max) …, internal/utils/min_max_avx2_amd64.go; C:
+ * internal/utils/_lib/min_max.c:23-126).  Integer types; validity is not consulted (as in the
+ * reference); an empty input returns (MaxOf, MinOf).  One pass, w bytes per row; synchronises. */
+int ah_min_max(ah_ctx* ctx, int type, const void* values, int64_t n, void* out_min_host, void* out_max_host);
+
 /* ---- numeric cast (row §8(f)-2) ----------------------------------------------------------------
  * replaces castNumberToNumberUnsafe → castNumericUnsafe (kernels/cast_numeric.go:28-131; AVX2 leaf
  * cast_type_numeric_avx2(itype, otype, in, out, len), kernels/_lib/cast_numeric.cc:62) together with

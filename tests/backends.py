@@ -86,6 +86,9 @@ class OracleBackend:
     def sort_indices(self, values, valid, off, descending=False, nulls_at_start=False, misalign=0):
         return self.o.sort_indices(values, valid, off, descending, nulls_at_start)
 
+    def min_max(self, values, misalign=0):
+        return self.o.min_max(values)
+
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
@@ -315,6 +318,11 @@ class HipBackend:
         odb.memset(fill); ovb.memset(fill)
         self.c.is_in(values.dtype.itemsize, vp, vvp, off, n, sp, svp, set_off, set_values.size, null_behavior, odb, ovb, out_off)
         return odb.download(np.uint8, nb), ovb.download(np.uint8, nb)
+
+    def min_max(self, values, misalign=0):
+        values = np.ascontiguousarray(values)
+        vb, vp = self._up(values, misalign) if values.size else (None, None)
+        return self.c.min_max(OL.TYPE_IDS[values.dtype], vp, values.size, values.dtype)
 
     def sort_indices(self, values, valid, off, descending=False, nulls_at_start=False, misalign=0):
         values = np.ascontiguousarray(values)

@@ -71,6 +71,7 @@ class Oracle:
             "orc_cast_bool_to_numeric": (it, [it, vp, i64, i64, vp]),
             "orc_is_in": (it, [it, vp, vp, i64, i64, vp, vp, i64, i64, it, vp, vp, i64]),
             "orc_sort_indices": (it, [it, vp, vp, i64, i64, it, it, vp]),
+            "orc_min_max": (it, [it, vp, i64, vp, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -226,6 +227,14 @@ class Oracle:
         assert st == 0, st
         return od, ov
 
+    # ---- min / max ----------------------------------------------------------------------
+    def min_max(self, values):
+        values = np.ascontiguousarray(values)
+        lo, hi = np.zeros(1, values.dtype), np.zeros(1, values.dtype)
+        st = self.lib.orc_min_max(TYPE_IDS[values.dtype], _p(values), values.size, _p(lo), _p(hi))
+        assert st == 0, st
+        return lo[0], hi[0]
+
     # ---- sort ---------------------------------------------------------------------------
     def sort_indices(self, values, valid, off, descending, nulls_at_start):
         values = np.ascontiguousarray(values)
@@ -323,6 +332,16 @@ class Reference:
         f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         f(TYPE_IDS[a.dtype], TYPE_IDS[np.dtype(out_dtype)], _p(a), _p(out), a.size)
         return out
+
+    def min_max(self, a):
+        """int64_max_min_avx2(values, len, &min, &max) … (internal/utils/_lib/min_max.c:23-126)"""
+        a = np.ascontiguousarray(a)
+        lo, hi = np.zeros(1, a.dtype), np.zeros(1, a.dtype)
+        f = getattr(self.avx2, f"{a.dtype.name}_max_min_avx2")
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        f(_p(a), a.size, _p(lo), _p(hi))
+        return lo[0], hi[0]
 
     def arithmetic_unary(self, op, a):
         a = np.ascontiguousarray(a)

@@ -892,3 +892,18 @@ def test_sort_indices_rules(be, dtype):
         info = np.iinfo(dtype)
         assert run_sort(be, dtype, [info.max, info.min, 1, info.max]) == [1, 2, 0, 3]
         assert run_sort(be, dtype, [info.max, info.min, 1, info.max], descending=True) == [0, 3, 2, 1]
+
+
+# ---- min_max ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", OL.INT_DTYPES, ids=str)
+def test_min_max(be, dtype):
+    # internal/utils/min_max.go:30-148; internal/utils/min_max_test.go (random slices vs a plain loop)
+    info = np.iinfo(dtype)
+    assert be.min_max(np.array([], dtype)) == (info.max, info.min)          # empty: the accumulators' start values
+    assert be.min_max(np.array([5], dtype)) == (5, 5)
+    assert be.min_max(np.array([3, 1, 4, 1, 5, 9, 2, 6], dtype)) == (1, 9)
+    assert be.min_max(np.array([info.max, 7, info.min, 7], dtype)) == (info.min, info.max)
+    rng = np.random.default_rng(np.dtype(dtype).itemsize)
+    for n in (1, 2, 15, 16, 17, 255, 1000, 4099, 70001):
+        a = rng.integers(info.min, info.max, n, dtype=dtype, endpoint=True)
+        assert be.min_max(a) == (a.min(), a.max()), n

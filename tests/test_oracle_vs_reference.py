@@ -141,3 +141,12 @@ def test_reference_float_to_narrow_int_out_of_range_is_inconsistent():
     a = np.full(40, 300.0, np.float32)
     out = ref.cast_numeric(a, np.uint8)
     assert set(out.tolist()) == {255, 44}, out
+
+
+@pytest.mark.parametrize("dtype", OL.INT_DTYPES, ids=str)
+def test_min_max_matches_reference_avx2(o, dtype):
+    rng = np.random.default_rng(77 + np.dtype(dtype).itemsize)
+    info = np.iinfo(dtype)
+    for n in [1, 3, 15, 16, 17, 31, 33, 64, 1000, 100003]:
+        a = rng.integers(info.min, info.max, n, dtype=dtype, endpoint=True)
+        assert o.min_max(a) == ref.min_max(a), (dtype, n)
