@@ -423,3 +423,24 @@ AH_EXPORT int ah_hash_sum_i64(ah_ctx* c, const uint64_t* keys, const uint8_t* kv
                                                           out_keys, (unsigned long long*)out_sums, out_counts, out_first_rows,
                                                           out_ngroups_host, out_null_group_host);
 }
+
+// ---- key → owner partition for the multi-GPU merge (SURVEY.md §8e plan A) ----------------------
+// owner = (hashInt(key) >> 40) mod nparts, hashInt as in internal/hashing/hash_funcs.go:60-67: every
+// rank computes the same owner for a key, so partial groups of one key all meet on one GPU.
+namespace {
+__global__ __launch_bounds__(kBlock) void partition_kernel(const unsigned long long* __restrict__ keys, int64_t n, unsigned nparts,
+                                                            int32_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = (int32_t)((hash_int(keys[i]) >> 40) % nparts);
+}
+}  // namespace
+
+AH_EXPORT int ah_hash_partition_u64(ah_ctx* c, const uint64_t* keys, int64_t n, int nparts, int32_t* out_part) {
+  AH_ENTER(c);
+  if (n < 0 || nparts < 1) return ah_fail(c, AH_EINVALID, "hash_partition: bad length / partition count");
+  if (n == 0) return AH_OK;
+  if (!keys || !out_part) return ah_fail(c, AH_EINVALID, "hash_partition: null buffer");
+  partition_kernel<<<ah_stream_grid(c, ah_ceil_div(n, kBlock), 8), kBlock, 0, c->stream>>>((const unsigned long long*)keys, n, (unsigned)nparts, out_part);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}

@@ -296,6 +296,9 @@ class Context:
                               _ptr(out_sums), _ptr(out_counts), _ptr(out_first_rows), C.byref(ng), C.byref(nid)))
         return ng.value, nid.value
 
+    def hash_partition(self, keys, n: int, nparts: int, out_part) -> None:
+        check(self.handle, lib.ah_hash_partition_u64(self.handle, _ptr(keys), n, nparts, _ptr(out_part)))
+
     # ---- fused expressions --------------------------------------------------------------
     def expr_compile(self, nodes, col_types, lit_types):
         """nodes: [(opcode, arg), …] postfix.  Returns (handle, out_type)."""

@@ -11,7 +11,9 @@ collective for them.  Exactly one exchange step exists, for reductions:
   * hash group-by (config C5): local aggregate per shard → groups bucketed by key-hash
     owner (the reference's hashInt, top bits) → all-to-all of (key, sum, count, first_row)
     tuples — O(groups) bytes on the wire, never O(rows) → owner merges → groups ordered by
-    global first occurrence.
+    global first occurrence.  Bucketing, owner merge and final ordering are `local` provider
+    steps: on the GPU for HipLocal (hash partition + compactions, two group-by passes + a
+    gather, radix sort + gathers) — the tuples never visit host memory.
 
 One process per GPU (`torchrun`), `torch.distributed` with backend "nccl" (= RCCL over
 xGMI) in production, "gloo" in the CPU tests.  torch is plumbing here: process group,
@@ -66,6 +68,67 @@ class HipLocal:
             self.ctx.cmp_filter_sum_f64_dev(cmpop, x_ptr, valid_ptr, off, n, float(thr), out_sum_ptr, out_count_ptr)
 
 
+    # ---- the three compute steps of the group merge, on device tensors ---------------------------------
+    def partition_by_owner(self, torch, cols, world: int):
+        """cols [4, g] int64 (row 0 = key bits) → per destination rank a [4, g_r] tensor: owner =
+        (hashInt(key) >> 40) mod world (ah_hash_partition_u64), then one compare + four stream
+        compactions per destination — all on the GPU."""
+        g = cols.shape[1]
+        dev = cols.device
+        if world == 1 or g == 0:
+            return [cols] + [torch.zeros((4, 0), dtype=torch.int64, device=dev) for _ in range(world - 1)]
+        owner = torch.empty(g, dtype=torch.int32, device=dev)
+        self.ctx.hash_partition(cols[0].data_ptr(), g, world, owner.data_ptr())
+        mask = torch.zeros((g + 7) // 8 + 64, dtype=torch.uint8, device=dev)
+        out = []
+        for r in range(world):
+            self.ctx.comparison(self.N.CMP_EQ, self.N.SHAPE_AS, self.N.INT32, owner.data_ptr(), np.array([r], np.int32), mask.data_ptr(), g, 0)
+            n_r = self.ctx.filter_count(mask.data_ptr(), None, 0, g, 0)
+            part = torch.empty((4, n_r), dtype=torch.int64, device=dev)
+            for c in range(4):
+                self.ctx.filter_primitive(8, cols[c].data_ptr(), None, 0, mask.data_ptr(), None, 0, g, 0, n_r, part[c].data_ptr(), None,
+                                          want_null_count=False)
+            out.append(part)
+        return out
+
+    def merge_tuples(self, torch, got, is_float: bool):
+        """got [4, m]: tuples received for the keys this rank owns, source ranks ascending → [4, g]:
+        per key the sum of the partial sums, the sum of the counts, and the first row of the FIRST
+        tuple (= the smallest global first row, because lower ranks hold lower row ranges) —
+        two device group-by passes (ah_hash_sum_*) and one gather."""
+        m = got.shape[1]
+        dev = got.device
+        if m == 0:
+            return got
+        ok = torch.empty(m + 1, dtype=torch.int64, device=dev); osum = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        oc = torch.empty(m + 1, dtype=torch.int64, device=dev); ofirst = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        ng, _ = self.ctx.hash_sum("f64" if is_float else "i64", got[0].data_ptr(), None, 0, got[1].data_ptr(), None, 0, m,
+                                  ok.data_ptr(), osum.data_ptr(), oc.data_ptr(), ofirst.data_ptr())
+        ok2 = torch.empty(m + 1, dtype=torch.int64, device=dev); csum = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        oc2 = torch.empty(m + 1, dtype=torch.int64, device=dev)
+        ng2, _ = self.ctx.hash_sum("i64", got[0].data_ptr(), None, 0, got[2].data_ptr(), None, 0, m, ok2.data_ptr(), csum.data_ptr(),
+                                   oc2.data_ptr(), None)
+        assert ng2 == ng
+        out = torch.empty((4, ng), dtype=torch.int64, device=dev)
+        out[0] = ok[:ng]; out[1] = osum[:ng]; out[2] = csum[:ng]
+        self.ctx.take_primitive(8, got[3].data_ptr(), None, 0, m, 8, True, ofirst.data_ptr(), None, 0, ng, True, out[3].data_ptr(), None)
+        return out
+
+    def order_by_first(self, torch, rows):
+        """rows [4, G] → the same tuples ascending by row 3 (global first row): device radix sort
+        (ah_sort_indices) + four gathers."""
+        G = rows.shape[1]
+        if G <= 1:
+            return rows
+        dev = rows.device
+        idx = torch.empty(G, dtype=torch.int64, device=dev)
+        self.ctx.sort_indices(self.N.INT64, rows[3].data_ptr(), None, 0, G, False, False, idx.data_ptr())
+        out = torch.empty_like(rows)
+        for c in range(4):
+            self.ctx.take_primitive(8, rows[c].data_ptr(), None, 0, G, 8, False, idx.data_ptr(), None, 0, G, False, out[c].data_ptr(), None)
+        return out
+
+
 class ShardedCompute:
     """Collective layer over a `local` leaf provider."""
 
@@ -99,57 +162,47 @@ class ShardedCompute:
     # ---- C5: hash group-by sum ----------------------------------------------------------------
     def merge_groups(self, torch, keys: np.ndarray, sums: np.ndarray, counts: np.ndarray, first_rows: np.ndarray,
                      row_offset: int):
-        """Plan A merge.  Inputs: this rank's LOCAL aggregate (host arrays of equal length:
-        group key bit patterns (uint64), partial sum, valid-value count, first local row).
-        Returns the global groups owned by... every rank gets the full, globally ordered
-        result: (keys, sums, counts) sorted by global first occurrence.  Bytes exchanged are
-        O(groups), never O(rows)."""
-        world = self.world
-        gfirst = first_rows.astype(np.int64) + np.int64(row_offset)
-        own = owner_of(keys, world)
+        """Plan A merge, host-array convenience form: this rank's LOCAL aggregate (group key bit
+        patterns (uint64), partial sum, valid-value count, first local row) → the global groups in
+        order of global first occurrence, on every rank.  The work happens in merge_groups_t."""
         is_float = sums.dtype == np.float64
-        # pack tuples per destination: [key, sum(bits), count, first_row] as int64
-        send = []
-        for r in range(world):
-            m = own == r
-            buf = np.stack([keys[m].view(np.int64), sums[m].view(np.int64), counts[m].astype(np.int64), gfirst[m]], axis=1)
-            send.append(torch.from_numpy(np.ascontiguousarray(buf)).to(self.device))
-        # exchange sizes, then payloads (all_to_all of ragged lists)
-        sizes = torch.tensor([t.shape[0] for t in send], dtype=torch.int64, device=self.device)
+        cols = np.stack([keys.view(np.int64), sums.view(np.int64), counts.astype(np.int64),
+                         first_rows.astype(np.int64) + np.int64(row_offset)])
+        rows = self.merge_groups_t(torch, torch.from_numpy(np.ascontiguousarray(cols)).to(self.device), is_float).cpu().numpy()
+        out_sums = rows[1].view(np.float64) if is_float else rows[1]
+        return rows[0].view(np.uint64), out_sums, rows[2], rows[3]
+
+    def merge_groups_t(self, torch, cols, is_float: bool):
+        """cols: [4, g] int64 tensor on this rank's device — rows = key bits, sum bits, count,
+        GLOBAL first row of this rank's local groups.  Returns the merged [4, G] tensor (every rank
+        gets all groups, ordered by global first occurrence).  Bytes exchanged are O(groups), never
+        O(rows); every compute step (owner bucketing, owner-side re-aggregation, final ordering)
+        runs through the `local` provider — on the GPU for HipLocal."""
+        world = self.world
+        # 1. bucket this rank's groups by owner rank
+        send = self.local.partition_by_owner(torch, cols, world)          # list of [4, g_r]
+        # 2. sizes, then payloads (ragged all-to-all)
+        sizes = torch.tensor([t.shape[1] for t in send], dtype=torch.int64, device=self.device)
         rsizes = torch.zeros(world, dtype=torch.int64, device=self.device)
         self.dist.all_to_all_single(rsizes, sizes)
-        recv = [torch.zeros((int(k), 4), dtype=torch.int64, device=self.device) for k in rsizes.tolist()]
-        self._all_to_all(recv, send)
-        got = torch.cat(recv, dim=0).cpu().numpy() if recv else np.zeros((0, 4), np.int64)
-        # owner-side merge of its keys: deterministic — sort by (key, source order) then segment-reduce;
-        # float partials are added in ascending global-first-row order of the contributing shard
-        order = np.lexsort((got[:, 3], got[:, 0].view(np.uint64)))
-        g = got[order]
-        k = g[:, 0].view(np.uint64)
-        starts = np.flatnonzero(np.concatenate([[True], k[1:] != k[:-1]])) if len(k) else np.zeros(0, np.int64)
-        mk = k[starts]
-        mc = np.add.reduceat(g[:, 2], starts) if len(k) else np.zeros(0, np.int64)
-        mf = np.minimum.reduceat(g[:, 3], starts) if len(k) else np.zeros(0, np.int64)
-        if is_float:
-            ms = np.add.reduceat(g[:, 1].view(np.float64), starts) if len(k) else np.zeros(0, np.float64)
-        else:
-            with np.errstate(over="ignore"):
-                ms = np.add.reduceat(g[:, 1].view(np.uint64), starts).view(np.int64) if len(k) else np.zeros(0, np.int64)
-        # all-gather the owners' merged groups and order by global first occurrence
-        mine = torch.from_numpy(np.ascontiguousarray(np.stack([mk.view(np.int64), ms.view(np.int64), mc, mf], axis=1))).to(self.device)
-        n_mine = torch.tensor([mine.shape[0]], dtype=torch.int64, device=self.device)
+        recv = [torch.zeros((4, int(k)), dtype=torch.int64, device=self.device) for k in rsizes.tolist()]
+        self._all_to_all(recv, [t.contiguous() for t in send])
+        got = torch.cat(recv, dim=1).contiguous()                         # source ranks in ascending order
+        # 3. the owner re-aggregates its keys (sum of partial sums, sum of counts, first of the firsts)
+        mine = self.local.merge_tuples(torch, got, is_float)              # [4, g_owned]
+        # 4. every rank gets every owner's groups …
+        n_mine = torch.tensor([mine.shape[1]], dtype=torch.int64, device=self.device)
         all_n = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(world)]
         self.dist.all_gather(all_n, n_mine)
-        mx = max(int(t.item()) for t in all_n)
-        pad = torch.zeros((mx, 4), dtype=torch.int64, device=self.device)
-        pad[: mine.shape[0]] = mine
-        gathered = [torch.zeros((mx, 4), dtype=torch.int64, device=self.device) for _ in range(world)]
+        counts = [int(t.item()) for t in all_n]
+        mx = max(counts) if counts else 0
+        pad = torch.zeros((4, mx), dtype=torch.int64, device=self.device)
+        pad[:, : mine.shape[1]] = mine
+        gathered = [torch.zeros((4, mx), dtype=torch.int64, device=self.device) for _ in range(world)]
         self.dist.all_gather(gathered, pad)
-        rows = np.concatenate([gathered[r][: int(all_n[r].item())].cpu().numpy() for r in range(world)], axis=0) \
-            if mx else np.zeros((0, 4), np.int64)
-        rows = rows[np.argsort(rows[:, 3], kind="stable")]
-        out_sums = rows[:, 1].view(np.float64) if is_float else rows[:, 1]
-        return rows[:, 0].view(np.uint64), out_sums, rows[:, 2], rows[:, 3]
+        rows = torch.cat([gathered[r][:, : counts[r]] for r in range(world)], dim=1).contiguous()
+        # 5. … ordered by global first occurrence (what a single-process `unique` would produce)
+        return self.local.order_by_first(torch, rows)
 
     def _all_to_all(self, recv, send):
         """ragged all-to-all; gloo has no all_to_all for CPU tensors in every build, so fall

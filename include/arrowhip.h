@@ -296,6 +296,10 @@ int ah_device_id(ah_ctx* ctx);
  * reference); an empty input returns (MaxOf, MinOf).  One pass, w bytes per row; synchronises. */
 int ah_min_max(ah_ctx* ctx, int type, const void* values, int64_t n, void* out_min_host, void* out_max_host);
 
+/* ---- multi-GPU group merge helper: owner of a key = (hashInt(key) >> 40) mod nparts,
+ * hashInt = internal/hashing/hash_funcs.go:60-67.  No reference analogue (the reference is single-process). */
+int ah_hash_partition_u64(ah_ctx* ctx, const uint64_t* keys, int64_t n, int nparts, int32_t* out_part);
+
 /* ---- numeric cast (row §8(f)-2) ----------------------------------------------------------------
  * replaces castNumberToNumberUnsafe → castNumericUnsafe (kernels/cast_numeric.go:28-131; AVX2 leaf
  * cast_type_numeric_avx2(itype, otype, in, out, len), kernels/_lib/cast_numeric.cc:62) together with

@@ -56,6 +56,28 @@ lk = ok[:ng].cpu().numpy().view(np.uint64); ls = osum[:ng].cpu().numpy(); lc = o
 mk, ms, mc, mf = sc.merge_groups(torch, lk, ls, lc, lf, lo)
 ek, es, ec, _nid, ef = o.hash_sum("i64", keys, None, 0, vals, None, 0)
 assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes()
+# the three merge steps of the collective layer on the GPU, against their numpy restatement: bucket a
+# group list for a 3-rank world, re-aggregate tuples with duplicate keys, order by first row
+from arrow_go_amd.distributed import owner_of  # noqa: E402
+g = 50021
+gk = (rng.integers(0, 9000, g).astype(np.int64) * 7919)
+cols = np.stack([gk, rng.integers(-2**40, 2**40, g, dtype=np.int64), rng.integers(1, 50, g, dtype=np.int64),
+                 np.sort(rng.choice(10**7, g, replace=False)).astype(np.int64)])
+ct = torch.from_numpy(cols).cuda()
+parts = local.partition_by_owner(torch, ct, 3)
+own = owner_of(gk.view(np.uint64), 3)
+for r in range(3):
+    assert parts[r].cpu().numpy().tobytes() == np.ascontiguousarray(cols[:, own == r]).tobytes(), r
+merged = local.merge_tuples(torch, ct, False).cpu().numpy()
+uk, first_pos = np.unique(gk, return_index=True)
+seen = np.argsort(first_pos, kind="stable")
+assert merged[0].tolist() == uk[seen].tolist()
+for j, key in enumerate(merged[0][:200].tolist()):
+    m_ = gk == key
+    assert merged[1][j] == cols[1][m_].sum() and merged[2][j] == cols[2][m_].sum() and merged[3][j] == cols[3][m_][0]
+shuf = ct[:, torch.randperm(g, device="cuda")].contiguous()
+ordered = local.order_by_first(torch, shuf).cpu().numpy()
+assert ordered.tobytes() == cols.tobytes()       # first rows are distinct and ascending in `cols`
 dist.barrier()
 dist.destroy_process_group()
 if rank == 0:

@@ -58,6 +58,37 @@ class OracleLocal:
             ctypes.memmove(out_count_ptr, np.array([c], np.int64).ctypes.data, 8)
 
 
+    # ---- the three merge steps, numpy on CPU tensors (HipLocal runs them on the GPU) ----
+    def partition_by_owner(self, torch, cols, world):
+        from arrow_go_amd.distributed import owner_of
+        c = cols.numpy()
+        own = owner_of(c[0].view(np.uint64), world)
+        return [torch.from_numpy(np.ascontiguousarray(c[:, own == r])) for r in range(world)]
+
+    def merge_tuples(self, torch, got, is_float):
+        g = got.numpy()
+        if g.shape[1] == 0:
+            return got
+        k = g[0].view(np.uint64)
+        order = np.lexsort((np.arange(k.size), k))            # by key, source order inside a key
+        ks = k[order]
+        starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+        first_pos = order[starts]                                # position of each key's first tuple
+        mc = np.add.reduceat(g[2][order], starts)
+        if is_float:
+            ms = np.add.reduceat(g[1].view(np.float64)[order], starts).view(np.int64)
+        else:
+            with np.errstate(over="ignore"):
+                ms = np.add.reduceat(g[1].view(np.uint64)[order], starts).view(np.int64)
+        seen = np.argsort(first_pos, kind="stable")              # first-seen order, like the device hash table
+        out = np.stack([ks[starts].view(np.int64)[seen], ms[seen], mc[seen], g[3][first_pos][seen]])
+        return torch.from_numpy(np.ascontiguousarray(out))
+
+    def order_by_first(self, torch, rows):
+        r = rows.numpy()
+        return torch.from_numpy(np.ascontiguousarray(r[:, np.argsort(r[3], kind="stable")]))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
