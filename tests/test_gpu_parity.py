@@ -726,3 +726,39 @@ def test_full_size_properties(ctx):
     assert ctx.count_set_bits(mask, 0, n - 1) == n - 1
     for buf in (a, b, out, mask, idx):
         buf.free()
+
+
+def test_beyond_2_31_rows(ctx):
+    """The reference's leaves take a 32-bit length (`int len`, _lib/base_arithmetic.cc:238) and are undefined
+    past 2^31 − 1 elements; this ABI is int64 throughout.  One-byte columns of 2^31 + 1027 rows through
+    add / compare / popcount / filter / cast / cumulative_sum / min_max / is_in, checked by properties."""
+    import arrow_go_amd as ah
+    N = ah._native
+    n = (1 << 31) + 1027
+    a = ctx.alloc(n); b = ctx.alloc(n); out = ctx.alloc(2 * n + 64)
+    a.memset(3); b.memset(4)
+    tail = np.arange(1027, dtype=np.int8) % 100                 # the rows past 2^31 are distinguishable
+    a.upload(tail, 1 << 31)
+    ctx.arithmetic(N.INT8, N.OP_ADD, N.SHAPE_AA, a, b, out, n)
+    assert out.download(np.int8, 1027, 1 << 31).tolist() == (tail + 4).tolist()
+    assert out.download(np.int8, 4, (1 << 31) - 4).tolist() == [7, 7, 7, 7]
+    mask = ctx.alloc(n // 8 + 64)
+    ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT8, a, np.array([50], np.int8), mask, n, 0)
+    expect = int((tail > 50).sum())
+    assert ctx.count_set_bits(mask, 0, n) == expect
+    assert ctx.filter_count(mask, None, 0, n, 0) == expect
+    ctx.filter_primitive(1, a, None, 0, mask, None, 0, n, 0, expect, out, None)
+    assert out.download(np.int8, expect).tolist() == tail[tail > 50].tolist()
+    ctx.cast_numeric(N.INT8, N.INT16, a, None, 0, n, False, False, out)
+    assert out.download(np.int16, 1027, 2 * (1 << 31)).tolist() == tail.tolist()
+    assert ctx.min_max(N.INT8, a, n, np.int8) == (0, 99)
+    # running sum in int64 terms: 3·2^31 + Σ tail, observed modulo 256 in the int8 output
+    ctx.cumulative_sum(N.INT8, a, None, 0, n, None, False, False, out, None)
+    want_last = (3 * (1 << 31) + int(tail.astype(np.int64).sum())) % 256
+    assert int(out.download(np.uint8, 1, n - 1)[0]) == want_last
+    od = ctx.alloc(n // 8 + 64); ov = ctx.alloc(n // 8 + 64)
+    vs = ctx.to_device(np.array([99, 98], np.int8))
+    ctx.is_in(1, a, None, 0, n, vs, None, 0, 2, 0, od, ov, 0)
+    assert ctx.count_set_bits(od, 0, n) == int(np.isin(tail, [99, 98]).sum()) and ctx.count_set_bits(ov, 0, n) == n
+    for buf in (a, b, out, mask, od, ov):
+        buf.free()
