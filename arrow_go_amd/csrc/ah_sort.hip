@@ -62,13 +62,15 @@ struct Column {
   const uint8_t* valid;
   int64_t off;
   int descending, nulls_at_start;
+  const unsigned* rows_in;  // the order produced by the less significant sort keys; NULL = input order
   __device__ __forceinline__ void load(int64_t i, unsigned long long* key, unsigned* row, unsigned* digit) const {
-    const T v = values[i];
+    const unsigned r = rows_in ? rows_in[i] : (unsigned)i;
+    const T v = values[r];
     int cat = kCatRest;
-    if (!ah_bit(valid, off + i)) cat = kCatNull;
+    if (!ah_bit(valid, off + r)) cat = kCatNull;
     else if (std::is_floating_point<T>::value && v != v) cat = kCatNaN;
     *key = cat == kCatRest ? make_key<T>(v, descending) : 0ull;
-    *row = (unsigned)i;
+    *row = r;
     *digit = nulls_at_start ? (unsigned)(2 - cat) : (unsigned)cat;  // [nulls, NaNs, rest] or [rest, NaNs, nulls]
   }
 };
@@ -227,83 +229,125 @@ int radix_pass(ah_ctx* c, SRC src, int64_t n, unsigned* hist, unsigned* offs, un
   return AH_OK;
 }
 
-template <typename T>
-int sort_typed(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending, int nulls_at_start, uint64_t* out) {
-  Temp tmp(c);
+struct SortBuffers {  // temporaries shared by all keys of one call
   unsigned long long *ka, *kb, *andor;
-  unsigned *ra, *rb, *hist, *offs;
+  unsigned *ra, *rb, *rc;  // ra / rb: ping-pong of a key's passes; rc: the previous key's result
+  unsigned *hist, *offs;
+};
+
+// Stable sort of the current row order (rows_in, or the input order) by ONE column.  Leaves the new
+// order in b.ra; returns through *result which buffer holds it (always b.ra).
+template <typename T>
+int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
+                   int nulls_at_start, const unsigned* rows_in) {
   const int64_t ntiles = ah_ceil_div(n, kTile);
   int rc;
-  if ((rc = tmp.get((size_t)n * 8, (void**)&ka)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)n * 8, (void**)&kb)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)n * 4, (void**)&ra)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)n * 4, (void**)&rb)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&hist)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&offs)) != AH_OK) return rc;
-  if ((rc = tmp.get(64, (void**)&andor)) != AH_OK) return rc;
   // (1) partition by category, keys and row numbers come into being
-  Column<T> col{(const T*)values, valid, off, descending, nulls_at_start};
-  if ((rc = radix_pass(c, col, n, hist, offs, ka, ra)) != AH_OK) return rc;
+  Column<T> col{(const T*)values, valid, off, descending, nulls_at_start, rows_in};
+  if ((rc = radix_pass(c, col, n, b.hist, b.offs, b.ka, b.ra)) != AH_OK) return rc;
   // how many rows of each category?  offs (inclusive scan, digit-major): the last tile's entry of digit d
   unsigned ends[3];
   for (int d = 0; d < 3; d++)
-    AH_HIP(c, hipMemcpyAsync(&c->pinned[d], offs + ((int64_t)d + 1) * ntiles - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipMemcpyAsync(&c->pinned[d], b.offs + ((int64_t)d + 1) * ntiles - 1, 4, hipMemcpyDeviceToHost, c->stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
   for (int d = 0; d < 3; d++) ends[d] = *(volatile unsigned*)&c->pinned[d];
   // the `rest` category is digit 0 (nulls at end) or digit 2 (nulls at start)
   const int64_t rest_lo = nulls_at_start ? ends[1] : 0;
   const int64_t rest_n = nulls_at_start ? (int64_t)ends[2] - ends[1] : ends[0];
-  unsigned long long *kcur = ka + rest_lo, *kalt = kb + rest_lo;
-  unsigned *rcur = ra + rest_lo, *ralt = rb + rest_lo;
+  unsigned long long *kcur = b.ka + rest_lo, *kalt = b.kb + rest_lo;
+  unsigned *rcur = b.ra + rest_lo, *ralt = b.rb + rest_lo;
   if (rest_n > 1) {
     // (2) which key bytes vary
-    AH_HIP(c, hipMemsetAsync(andor, 0xFF, 8, c->stream));
-    AH_HIP(c, hipMemsetAsync(andor + 1, 0, 8, c->stream));
-    and_or_kernel<<<ah_stream_grid(c, ah_ceil_div(rest_n, kBlock), 4), kBlock, 0, c->stream>>>(kcur, rest_n, andor);
+    AH_HIP(c, hipMemsetAsync(b.andor, 0xFF, 8, c->stream));
+    AH_HIP(c, hipMemsetAsync(b.andor + 1, 0, 8, c->stream));
+    and_or_kernel<<<ah_stream_grid(c, ah_ceil_div(rest_n, kBlock), 4), kBlock, 0, c->stream>>>(kcur, rest_n, b.andor);
     AH_LAUNCH_CHECK(c);
-    AH_HIP(c, hipMemcpyAsync(c->pinned, andor, 16, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipMemcpyAsync(c->pinned, b.andor, 16, hipMemcpyDeviceToHost, c->stream));
     AH_HIP(c, hipStreamSynchronize(c->stream));
     const unsigned long long varying = ((volatile unsigned long long*)c->pinned)[0] ^ ((volatile unsigned long long*)c->pinned)[1];
     // (3) one stable pass per varying byte, least significant first
-    for (int b = 0; b < (int)sizeof(T); b++) {
-      if (((varying >> (8 * b)) & 0xFFull) == 0) continue;
-      Pairs src{kcur, rcur, 8 * b};
-      if ((rc = radix_pass(c, src, rest_n, hist, offs, kalt, ralt)) != AH_OK) return rc;
+    for (int by = 0; by < (int)sizeof(T); by++) {
+      if (((varying >> (8 * by)) & 0xFFull) == 0) continue;
+      Pairs src{kcur, rcur, 8 * by};
+      if ((rc = radix_pass(c, src, rest_n, b.hist, b.offs, kalt, ralt)) != AH_OK) return rc;
       unsigned long long* tk = kcur; kcur = kalt; kalt = tk;
       unsigned* tr = rcur; rcur = ralt; ralt = tr;
     }
+    // the rest range must end up in ra, next to the NaN / null groups pass (1) left there
+    if (rcur != b.ra + rest_lo) AH_HIP(c, hipMemcpyAsync(b.ra + rest_lo, rcur, (size_t)rest_n * 4, hipMemcpyDeviceToDevice, c->stream));
   }
-  // (4) row numbers → uint64 output: NaN / null groups from pass (1)'s buffer, the rest from the last pass
-  const unsigned g = ah_stream_grid(c, ah_ceil_div(n, kBlock), 8);
-  if (rest_lo > 0) { emit_kernel<<<g, kBlock, 0, c->stream>>>(ra, rest_lo, out); AH_LAUNCH_CHECK(c); }
-  if (rest_n > 0) { emit_kernel<<<g, kBlock, 0, c->stream>>>(rcur, rest_n, out + rest_lo); AH_LAUNCH_CHECK(c); }
-  if (rest_lo + rest_n < n) { emit_kernel<<<g, kBlock, 0, c->stream>>>(ra + rest_lo + rest_n, n - rest_lo - rest_n, out + rest_lo + rest_n); AH_LAUNCH_CHECK(c); }
+  return AH_OK;
+}
+
+int sort_dispatch(ah_ctx* c, SortBuffers& b, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
+                  int nulls_at_start, const unsigned* rows_in) {
+  switch (type) {
+#define AH_SORT(ID, T) case ID: return sort_by_column<T>(c, b, values, valid, off, n, descending, nulls_at_start, rows_in);
+    AH_SORT(AH_UINT8, uint8_t) AH_SORT(AH_INT8, int8_t) AH_SORT(AH_UINT16, uint16_t) AH_SORT(AH_INT16, int16_t)
+    AH_SORT(AH_UINT32, uint32_t) AH_SORT(AH_INT32, int32_t) AH_SORT(AH_UINT64, uint64_t) AH_SORT(AH_INT64, int64_t)
+    AH_SORT(AH_FLOAT32, float) AH_SORT(AH_FLOAT64, double)
+#undef AH_SORT
+  }
+  return ah_fail(c, AH_ENOTIMPL, "sorting not supported for type %d", type);  // vector_sort.go:266-268
+}
+
+int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values, const uint8_t* const* valids, const int64_t* offs, int64_t n,
+              const int* descending, const int* nulls_at_start, uint64_t* out) {
+  Temp tmp(c);
+  SortBuffers b;
+  const int64_t ntiles = ah_ceil_div(n, kTile);
+  int rc;
+  if ((rc = tmp.get((size_t)n * 8, (void**)&b.ka)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)n * 8, (void**)&b.kb)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)n * 4, (void**)&b.ra)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)n * 4, (void**)&b.rb)) != AH_OK) return rc;
+  b.rc = nullptr;
+  if (nkeys > 1 && (rc = tmp.get((size_t)n * 4, (void**)&b.rc)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&b.hist)) != AH_OK) return rc;
+  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&b.offs)) != AH_OK) return rc;
+  if ((rc = tmp.get(64, (void**)&b.andor)) != AH_OK) return rc;
+  // lexicographic order by keys 0..k−1 = stable sorts by key k−1, …, key 0 in turn (every pass is stable)
+  const unsigned* rows_in = nullptr;
+  for (int k = nkeys - 1; k >= 0; k--) {
+    if ((rc = sort_dispatch(c, b, types[k], values[k], valids[k], offs[k], n, descending[k], nulls_at_start[k], rows_in)) != AH_OK) return rc;
+    if (k > 0) {
+      AH_HIP(c, hipMemcpyAsync(b.rc, b.ra, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+      rows_in = b.rc;
+    }
+  }
+  emit_kernel<<<ah_stream_grid(c, ah_ceil_div(n, kBlock), 8), kBlock, 0, c->stream>>>(b.ra, n, out);
+  AH_LAUNCH_CHECK(c);
   return AH_OK;
 }
 
 }  // namespace
 
-AH_EXPORT int ah_sort_indices(ah_ctx* c, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
-                              int nulls_at_start, uint64_t* out_indices) {
-  AH_ENTER(c);
-  if (n < 0 || off < 0) return ah_fail(c, AH_EINVALID, "sort_indices: negative length/offset");
-  if (n == 0) return AH_OK;
-  if (!values || !out_indices) return ah_fail(c, AH_EINVALID, "sort_indices: null buffer");
-  if (n >= ((int64_t)1 << 32)) return ah_fail(c, AH_ENOTIMPL, "sort_indices: more than 2^32 - 1 rows in one array");
+static int check_column(ah_ctx* c, int type, const void* values) {
   const int w = ah_type_width(type);
   if (!w) return ah_fail(c, AH_ENOTIMPL, "sorting not supported for type %d", type);  // vector_sort.go:266-268
+  if (!values) return ah_fail(c, AH_EINVALID, "sort_indices: null buffer");
   if ((uintptr_t)values & (uintptr_t)(w - 1)) return ah_fail(c, AH_EINVALID, "sort_indices: buffer not element-aligned");
-  switch (type) {
-    case AH_UINT8: return sort_typed<uint8_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_INT8: return sort_typed<int8_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_UINT16: return sort_typed<uint16_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_INT16: return sort_typed<int16_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_UINT32: return sort_typed<uint32_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_INT32: return sort_typed<int32_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_UINT64: return sort_typed<uint64_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_INT64: return sort_typed<int64_t>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_FLOAT32: return sort_typed<float>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
-    case AH_FLOAT64: return sort_typed<double>(c, values, valid, off, n, descending, nulls_at_start, out_indices);
+  return AH_OK;
+}
+
+AH_EXPORT int ah_sort_indices(ah_ctx* c, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
+                              int nulls_at_start, uint64_t* out_indices) {
+  return ah_sort_indices_multi(c, 1, &type, &values, &valid, &off, n, &descending, &nulls_at_start, out_indices);
+}
+
+AH_EXPORT int ah_sort_indices_multi(ah_ctx* c, int nkeys, const int* types, const void* const* values, const uint8_t* const* valids,
+                                    const int64_t* offs, int64_t n, const int* descending, const int* nulls_at_start, uint64_t* out_indices) {
+  AH_ENTER(c);
+  if (nkeys < 1) return ah_fail(c, AH_EINVALID, "must provide at least one sort key");  // compute/vector_sort.go:119-121
+  if (n < 0) return ah_fail(c, AH_EINVALID, "sort_indices: negative length");
+  for (int k = 0; k < nkeys; k++)
+    if (offs[k] < 0) return ah_fail(c, AH_EINVALID, "sort_indices: negative offset");
+  if (n == 0) return AH_OK;
+  if (!out_indices) return ah_fail(c, AH_EINVALID, "sort_indices: null buffer");
+  if (n >= ((int64_t)1 << 32)) return ah_fail(c, AH_ENOTIMPL, "sort_indices: more than 2^32 - 1 rows in one batch");
+  for (int k = 0; k < nkeys; k++) {
+    int rc = check_column(c, types[k], values[k]);
+    if (rc != AH_OK) return rc;
   }
-  return ah_fail(c, AH_ENOTIMPL, "sorting not supported for type %d", type);
+  return sort_keys(c, nkeys, types, values, valids, offs, n, descending, nulls_at_start, out_indices);
 }

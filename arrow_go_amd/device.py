@@ -279,6 +279,17 @@ class Context:
         check(self.handle, lib.ah_sort_indices(self.handle, type_id, _ptr(values), _ptr(valid), off, n, int(descending), int(nulls_at_start),
                                                _ptr(out_indices)))
 
+    def sort_indices_multi(self, keys, n: int, out_indices) -> None:
+        """keys: [(type_id, values, valid, off, descending, nulls_at_start), …] — most significant first"""
+        k = len(keys)
+        types = (C.c_int * k)(*[x[0] for x in keys])
+        vals = (C.c_void_p * k)(*[_ptr(x[1]) for x in keys])
+        valids = (C.c_void_p * k)(*[_ptr(x[2]) for x in keys])
+        offs = (C.c_int64 * k)(*[x[3] for x in keys])
+        desc = (C.c_int * k)(*[int(x[4]) for x in keys])
+        nfirst = (C.c_int * k)(*[int(x[5]) for x in keys])
+        check(self.handle, lib.ah_sort_indices_multi(self.handle, k, types, vals, valids, offs, n, desc, nfirst, _ptr(out_indices)))
+
     # ---- hashing ------------------------------------------------------------------------
     def hash_u64_encode(self, keys, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_dict):
         nd = C.c_int64()

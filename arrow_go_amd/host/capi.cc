@@ -163,6 +163,7 @@ AHC_EXPORT int ahc_datum_info(ahc_datum* d, int* kind, int* type_id, int64_t* le
 //   to_type=<type>   safe=0|1   allow_int_overflow=0|1   allow_float_truncate=0|1       (CastOptions)
 //   value_set=@<ahc_datum* in hex>   null_matching_behavior=match|skip|emit_null|inconclusive      (SetOptions)
 //   order=ascending|descending   null_placement=at_end|at_start                                   (SortOptions, one key)
+//   sort_keys=<col>:<asc|desc>:<at_end|at_start>,…                                                (SortOptions, several keys)
 //   skip_nulls=0|1   start=<type>:<value>|null:<type>   (e.g. start=int64:10, start=double:1.5, start=null:int32)
 struct ParsedOptions {
   compute::FilterOptions filter;
@@ -231,6 +232,25 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
         p->set.NullBehavior = v == "skip" ? compute::NullMatchingSkip : v == "emit_null" ? compute::NullMatchingEmitNull
                             : v == "inconclusive" ? compute::NullMatchingInconclusive : compute::NullMatchingMatch;
         p->pick = &p->set;
+      }
+      if (k == "sort_keys") {
+        p->sort.Keys.clear();
+        size_t q = 0;
+        while (q < v.size()) {
+          size_t e = v.find(',', q);
+          if (e == std::string::npos) e = v.size();
+          std::string item = v.substr(q, e - q);
+          compute::SortKey key;
+          size_t c1 = item.find(':'), c2 = c1 == std::string::npos ? c1 : item.find(':', c1 + 1);
+          key.ColumnIndex = atoi(item.substr(0, c1).c_str());
+          std::string ord = c1 == std::string::npos ? "" : item.substr(c1 + 1, c2 == std::string::npos ? std::string::npos : c2 - c1 - 1);
+          std::string npl = c2 == std::string::npos ? "" : item.substr(c2 + 1);
+          key.Order = ord == "desc" || ord == "descending" ? compute::SortOrderDescending : compute::SortOrderAscending;
+          key.Placement = npl == "at_start" ? compute::SortNullsAtStart : compute::SortNullsAtEnd;
+          p->sort.Keys.push_back(key);
+          q = e + 1;
+        }
+        p->pick = &p->sort;
       }
       if (k == "order" || k == "null_placement") {
         if (p->sort.Keys.empty()) p->sort.Keys.push_back(compute::SortKey());

@@ -538,31 +538,54 @@ void RegisterScalarSetLookup(FunctionRegistry* reg) {
 static Status SortIndicesImpl(ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
   const SortOptions* opts = dynamic_cast<const SortOptions*>(o);
   if (!opts || opts->Keys.empty()) return Status::Make(StatusCode::Invalid, "must provide at least one sort key");  // :119-121
-  if (args[0].kind != DatumKind::Array)
-    return Status::Make(StatusCode::NotImplemented, "unsupported type for sort_indices operation: the accelerated path sorts arrays");
   Session* s = ctx->session;
-  const ArrayData& a = *args[0].array;
-  if (!IsInteger(a.type->id) && !IsFloating(a.type->id))
-    return Status::Make(StatusCode::NotImplemented, std::string("sorting not supported for type ") + a.type->name);  // :266-268
-  const SortKey& key = opts->Keys[0];
+  // one array: the first key, ColumnIndex ignored (:130-141); several arrays = the columns of a record batch,
+  // every key names its column (:153-166)
+  std::vector<SortKey> keys = opts->Keys;
+  if (args.size() == 1) { keys.resize(1); keys[0].ColumnIndex = 0; }
+  if (keys.size() > 8)  // maxRadixSortKeys (kernels/vector_sort.go:60): beyond it the reference switches comparator
+    return Status::Make(StatusCode::NotImplemented, "sort_indices: more than 8 sort keys");
+  int64_t length = -1;
+  for (auto& a : args) {
+    if (a.kind != DatumKind::Array)
+      return Status::Make(StatusCode::NotImplemented, "unsupported type for sort_indices operation: the accelerated path sorts arrays");
+    if (length < 0) length = a.array->length;
+    else if (length != a.array->length) return Status::Make(StatusCode::Invalid, "all columns must have the same length");  // kernels :403-407
+  }
+  std::vector<int> types, desc, nfirst;
+  std::vector<const void*> values;
+  std::vector<const uint8_t*> valids;
+  std::vector<int64_t> offs;
+  for (size_t i = 0; i < keys.size(); i++) {
+    const SortKey& key = keys[i];
+    if (key.ColumnIndex < 0 || key.ColumnIndex >= (int)args.size())
+      return Status::Make(StatusCode::Invalid, "sort key " + std::to_string(i) + " has invalid column index " + std::to_string(key.ColumnIndex));  // :158-160
+    const ArrayData& a = *args[key.ColumnIndex].array;
+    if (!IsInteger(a.type->id) && !IsFloating(a.type->id))
+      return Status::Make(StatusCode::NotImplemented, std::string("sorting not supported for type ") + a.type->name);  // :266-268
+    int w = a.type->bit_width / 8;
+    types.push_back((int)a.type->id);
+    values.push_back(a.length ? (const uint8_t*)a.buffers[1]->dptr + a.offset * w : nullptr);
+    valids.push_back((a.buffers[0] && a.null_count != 0) ? (const uint8_t*)a.buffers[0]->dptr : nullptr);
+    offs.push_back(a.offset);
+    desc.push_back(key.Order == SortOrderDescending);
+    nfirst.push_back(key.Placement == SortNullsAtStart);
+  }
   auto res = std::make_shared<ArrayData>();
   res->type = GetDataType(Type::UINT64);
-  res->length = a.length;
+  res->length = length;
   res->null_count = 0;
-  AHC_RETURN_NOT_OK(s->Allocate(a.length * 8, &res->buffers[1]));
-  if (a.length > 0) {
-    int w = a.type->bit_width / 8;
-    const uint8_t* valid = (a.buffers[0] && a.null_count != 0) ? (const uint8_t*)a.buffers[0]->dptr : nullptr;
-    AHC_RETURN_NOT_OK(s->FromStatus(ah_sort_indices(s->ctx(), (int)a.type->id, (const uint8_t*)a.buffers[1]->dptr + a.offset * w, valid, a.offset,
-                                                    a.length, key.Order == SortOrderDescending, key.Placement == SortNullsAtStart,
-                                                    (uint64_t*)res->buffers[1]->dptr)));
-  }
+  AHC_RETURN_NOT_OK(s->Allocate(length * 8, &res->buffers[1]));
+  if (length > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_sort_indices_multi(s->ctx(), (int)keys.size(), types.data(), values.data(), valids.data(), offs.data(), length,
+                                                          desc.data(), nfirst.data(), (uint64_t*)res->buffers[1]->dptr)));
   *out = Datum::Of(res);
   return Status::OK();
 }
 
 void RegisterVectorSort(FunctionRegistry* reg) {
-  reg->AddFunction(std::make_shared<MetaFunction>("sort_indices", Arity{1, false}, nullptr, SortIndicesImpl), false);
+  // Arity: one array, or the columns of a record batch as separate arguments (this layer has no RecordBatch datum)
+  reg->AddFunction(std::make_shared<MetaFunction>("sort_indices", Arity{1, true}, nullptr, SortIndicesImpl), false);
   // sortMetaFunc (compute/vector_sort.go:66-85): take(input, sort_indices(input, options))
   reg->AddFunction(std::make_shared<MetaFunction>("sort", Arity{1, false}, nullptr,
       [](ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {

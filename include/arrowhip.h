@@ -338,6 +338,11 @@ int ah_is_in(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* val
  * input order.  Stable LSD radix sort; synchronises (two small read-backs). */
 int ah_sort_indices(ah_ctx* ctx, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n,
                     int descending, int nulls_at_start, uint64_t* out_indices);
+/* several sort keys over equal-length columns (record batch / table: radixRecordBatchSortRange,
+ * kernels/vector_sort_internal.go, and multiColumnComparator, vector_sort.go:103-120): lexicographic
+ * by key 0, then key 1, …, each with its own order and null placement; stable.  Arrays of nkeys entries. */
+int ah_sort_indices_multi(ah_ctx* ctx, int nkeys, const int* types, const void* const* values, const uint8_t* const* valids,
+                          const int64_t* offs, int64_t n, const int* descending, const int* nulls_at_start, uint64_t* out_indices);
 
 /* ---- fused scalar-expression evaluation (row §8(f)-1: the expression executor) ---------
  * What compute.Expression trees — NewCall / NewFieldRef / NewLiteral, arrow/compute/

@@ -138,6 +138,9 @@ int orc_is_in(int byte_width, const void* values, const uint8_t* valid, int64_t 
 int orc_sort_indices(int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
                      int nulls_at_start, uint64_t* out_indices);
 
+int orc_sort_indices_multi(int nkeys, const int* types, const void* const* values, const uint8_t* const* valids, const int64_t* offs,
+                           int64_t n, const int* descending, const int* nulls_at_start, uint64_t* out_indices);
+
 /* ---- utils.GetMinMax* (internal/utils/min_max.go:30-215): empty → (MaxOf, MinOf) ---- */
 int orc_min_max(int type, const void* values, int64_t n, void* out_min, void* out_max);
 

@@ -75,3 +75,57 @@ int orc_sort_indices(int type, const void* values, const uint8_t* valid, int64_t
   free(fin); free(nan); free(nul); free(tmp);
   return ORC_OK;
 }
+
+/* ---- several keys (record batch): radixRecordBatchSortRange, vector_sort_internal.go:167-205 —
+ * per key: [rest, NaNs, nulls] or [nulls, NaNs, rest], the rest ordered by value; NaN ties, null ties and
+ * value ties are broken by the next key; stable.  Restated as ONE stable merge sort with the
+ * lexicographic comparator over (category, value) per key. */
+typedef struct { int type; const void* values; const uint8_t* valid; int64_t off; int desc; int nulls_first; } orc_key;
+static const orc_key* g_keys;
+static int g_nkeys;
+
+static int cat_of(const orc_key* k, uint64_t r) {
+  if (!bget_opt(k->valid, k->off + (int64_t)r)) return 2;
+  if (k->type == ORC_FLOAT32) { float v = ((const float*)k->values)[r]; if (v != v) return 1; }
+  if (k->type == ORC_FLOAT64) { double v = ((const double*)k->values)[r]; if (v != v) return 1; }
+  return 0;
+}
+
+static int cmp_multi(uint64_t a, uint64_t b) {
+  for (int i = 0; i < g_nkeys; i++) {
+    const orc_key* k = &g_keys[i];
+    int ca = cat_of(k, a), cb = cat_of(k, b);
+    if (k->nulls_first) { ca = 2 - ca; cb = 2 - cb; }
+    if (ca != cb) return ca < cb ? -1 : 1;
+    if (cat_of(k, a) != 0) continue;  /* both NaN or both null: tie on this key */
+    g_type = k->type; g_desc = k->desc; g_vals = k->values;
+    int c = cmp_rows(a, b);
+    if (c) return c;
+  }
+  return 0;
+}
+
+static void merge_sort_multi(uint64_t* a, uint64_t* tmp, int64_t lo, int64_t hi) {
+  if (hi - lo <= 1) return;
+  int64_t mid = lo + (hi - lo) / 2;
+  merge_sort_multi(a, tmp, lo, mid);
+  merge_sort_multi(a, tmp, mid, hi);
+  int64_t i = lo, j = mid, k = lo;
+  while (i < mid && j < hi) tmp[k++] = cmp_multi(a[j], a[i]) < 0 ? a[j++] : a[i++];
+  while (i < mid) tmp[k++] = a[i++];
+  while (j < hi) tmp[k++] = a[j++];
+  memcpy(a + lo, tmp + lo, (size_t)(hi - lo) * 8);
+}
+
+int orc_sort_indices_multi(int nkeys, const int* types, const void* const* values, const uint8_t* const* valids, const int64_t* offs,
+                           int64_t n, const int* descending, const int* nulls_at_start, uint64_t* out_indices) {
+  if (nkeys < 1 || nkeys > 64) return ORC_EINVALID;
+  orc_key keys[64];
+  for (int i = 0; i < nkeys; i++) keys[i] = (orc_key){types[i], values[i], valids[i], offs[i], descending[i], nulls_at_start[i]};
+  g_keys = keys; g_nkeys = nkeys;
+  uint64_t* tmp = (uint64_t*)malloc((size_t)(n > 0 ? n : 1) * 8);
+  for (int64_t i = 0; i < n; i++) out_indices[i] = (uint64_t)i;
+  merge_sort_multi(out_indices, tmp, 0, n);
+  free(tmp);
+  return ORC_OK;
+}

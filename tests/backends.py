@@ -89,6 +89,9 @@ class OracleBackend:
     def min_max(self, values, misalign=0):
         return self.o.min_max(values)
 
+    def sort_indices_multi(self, columns):
+        return self.o.sort_indices_multi(columns)
+
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
@@ -318,6 +321,18 @@ class HipBackend:
         odb.memset(fill); ovb.memset(fill)
         self.c.is_in(values.dtype.itemsize, vp, vvp, off, n, sp, svp, set_off, set_values.size, null_behavior, odb, ovb, out_off)
         return odb.download(np.uint8, nb), ovb.download(np.uint8, nb)
+
+    def sort_indices_multi(self, columns):
+        keep, keys = [], []
+        n = np.asarray(columns[0][0]).size
+        for values, valid, off, desc, nfirst in columns:
+            values = np.ascontiguousarray(values)
+            vb, vp = self._up(values); vvb, vvp = self._upbits(valid)
+            keep += [vb, vvb]
+            keys.append((OL.TYPE_IDS[values.dtype], vp, vvp, off, desc, nfirst))
+        ob = self.c.alloc(n * 8 + 64)
+        self.c.sort_indices_multi(keys, n, ob)
+        return ob.download(np.uint64, n)
 
     def min_max(self, values, misalign=0):
         values = np.ascontiguousarray(values)

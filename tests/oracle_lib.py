@@ -72,6 +72,7 @@ class Oracle:
             "orc_is_in": (it, [it, vp, vp, i64, i64, vp, vp, i64, i64, it, vp, vp, i64]),
             "orc_sort_indices": (it, [it, vp, vp, i64, i64, it, it, vp]),
             "orc_min_max": (it, [it, vp, i64, vp, vp]),
+            "orc_sort_indices_multi": (it, [it, vp, vp, vp, vp, i64, vp, vp, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -242,6 +243,21 @@ class Oracle:
         st = self.lib.orc_sort_indices(TYPE_IDS[values.dtype], _p(values), _p(valid), off, values.size, int(descending), int(nulls_at_start), _p(out))
         assert st == 0, st
         return out[:values.size]
+
+    def sort_indices_multi(self, columns):
+        """columns: [(values, valid, off, descending, nulls_at_start), …] most significant first"""
+        cols = [(np.ascontiguousarray(c[0]),) + tuple(c[1:]) for c in columns]
+        k, n = len(cols), cols[0][0].size
+        types = (C.c_int * k)(*[TYPE_IDS[c[0].dtype] for c in cols])
+        vals = (C.c_void_p * k)(*[c[0].ctypes.data for c in cols])
+        valids = (C.c_void_p * k)(*[c[1].ctypes.data if c[1] is not None else None for c in cols])
+        offs = (C.c_int64 * k)(*[c[2] for c in cols])
+        desc = (C.c_int * k)(*[int(c[3]) for c in cols])
+        nfirst = (C.c_int * k)(*[int(c[4]) for c in cols])
+        out = np.zeros(max(n, 1), np.uint64)
+        st = self.lib.orc_sort_indices_multi(k, types, vals, valids, offs, n, desc, nfirst, _p(out))
+        assert st == 0, st
+        return out[:n]
 
     # ---- hashing ------------------------------------------------------------------------
     def hash_int(self, v, alg=0): return int(self.lib.orc_hash_int(int(v) & (2**64 - 1), alg))

@@ -566,6 +566,35 @@ def test_sort_indices_reference_tables(sess):
 
 
 @pytest.mark.gpu
+def test_sort_indices_record_batch(sess):
+    """several sort keys over the columns of a record batch (TestVectorSortIndicesCppRecordBatchParity :1346,
+    TestSortRecordBatch :554), and random data against Arrow C++'s table sort"""
+    from arrow_go_amd import compute as ac
+    nan = float("nan")
+    a = pa.array([None, 1, 3, None, nan, nan, nan, 1], pa.float32()); b = pa.array([5, 3, None, None, None, nan, 5, 5], pa.float64())
+    si = lambda cols, keys: sess.call_function("sort_indices", cols, "sort_keys=" + keys).to_pylist()
+    assert si([a, b], "0:asc:at_end,1:desc:at_end") == [7, 1, 2, 6, 5, 4, 0, 3]
+    assert si([a, b], "0:asc:at_start,1:desc:at_start") == [3, 0, 4, 5, 6, 7, 1, 2]
+    u = pa.array([3, 1, 3, 0, 2, 1, 1], pa.uint8()); v = pa.array([5, 3, 4, 6, 5, 5, 3], pa.uint32())
+    assert si([u, v], "0:asc:at_end,1:desc:at_end") == [3, 5, 1, 6, 4, 0, 2]
+    assert si([v, u], "1:asc:at_end,0:desc:at_end") == [3, 5, 1, 6, 4, 0, 2]          # keys name their columns
+    with pytest.raises(ac.ErrInvalid, match="sort key 1 has invalid column index 5"):
+        si([u, v], "0:asc:at_end,5:desc:at_end")
+    with pytest.raises(ac.ErrInvalid, match="same length"):
+        si([u, pa.array([1, 2], pa.int8())], "0:asc:at_end,1:asc:at_end")
+    rng = np.random.default_rng(2)
+    n = 40009
+    c0 = pa.array(rng.integers(0, 5, n), mask=rng.random(n) < 0.1, type=pa.int8())
+    c1 = pa.array(rng.integers(0, 9, n).astype(np.float64), mask=rng.random(n) < 0.1)
+    c2 = pa.array(rng.integers(0, 10**6, n), type=pa.int64())
+    tbl = pa.table({"a": c0, "b": c1, "c": c2})
+    for npl in ("at_end", "at_start"):
+        got = si([c0, c1, c2], "0:asc:%s,1:desc:%s,2:asc:%s" % (npl, npl, npl))
+        exp = pc.sort_indices(tbl, sort_keys=[("a", "ascending"), ("b", "descending"), ("c", "ascending")], null_placement=npl)
+        assert got == exp.to_pylist(), npl
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("typ", NUMERIC, ids=str)
 def test_sort_indices_random_vs_arrow_cpp(sess, typ):
     # Arrow C++ sort_indices is stable with the same null / NaN placement rules

@@ -907,3 +907,38 @@ def test_min_max(be, dtype):
     for n in (1, 2, 15, 16, 17, 255, 1000, 4099, 70001):
         a = rng.integers(info.min, info.max, n, dtype=dtype, endpoint=True)
         assert be.min_max(a) == (a.min(), a.max()), n
+
+
+# ---- sort_indices, several keys (record batch) -----------------------------------------------
+def run_sort_multi(be, cols):
+    """cols: [(dtype, values-with-None, descending, nulls_at_start), …]"""
+    args = []
+    for dtype, vals, desc, nfirst in cols:
+        arr, valid = mk(vals, dtype, null_fill=0)
+        args.append((arr, valid, 0, desc, nfirst))
+    return be.sort_indices_multi(args).tolist()
+
+
+def test_sort_indices_record_batch_cpp_parity(be):
+    # TestVectorSortIndicesCppRecordBatchParity :1346-1460 — keys (a ascending, b descending)
+    nan = float("nan")
+    for nfirst in (False, True):
+        assert run_sort_multi(be, [(np.uint8, [3, 1, 3, 0, 2, 1, 1], False, nfirst), (np.uint32, [5, 3, 4, 6, 5, 5, 3], True, nfirst)]) == [3, 5, 1, 6, 4, 0, 2]
+    a = [None, 1, 3, None, 2, 1, 3]; b = [5, 3, None, None, 5, 5, 5]
+    assert run_sort_multi(be, [(np.uint8, a, False, False), (np.uint32, b, True, False)]) == [5, 1, 4, 6, 2, 0, 3]
+    assert run_sort_multi(be, [(np.uint8, a, False, True), (np.uint32, b, True, True)]) == [3, 0, 5, 1, 4, 2, 6]
+    a = [3, 1, 3, 0, nan, nan, nan, 1]; b = [5, nan, 4, 6, 5, nan, 5, 5]
+    assert run_sort_multi(be, [(np.float32, a, False, False), (np.float64, b, True, False)]) == [3, 7, 1, 0, 2, 4, 6, 5]
+    assert run_sort_multi(be, [(np.float32, a, False, True), (np.float64, b, True, True)]) == [5, 4, 6, 3, 1, 7, 0, 2]
+    a = [None, 1, 3, None, nan, nan, nan, 1]; b = [5, 3, None, None, None, nan, 5, 5]
+    assert run_sort_multi(be, [(np.float32, a, False, False), (np.float64, b, True, False)]) == [7, 1, 2, 6, 5, 4, 0, 3]
+    assert run_sort_multi(be, [(np.float32, a, False, True), (np.float64, b, True, True)]) == [3, 0, 4, 5, 6, 7, 1, 2]
+
+
+def test_sort_indices_record_batch_table(be):
+    # TestSortRecordBatch :554-700: (value asc) and (category asc, priority desc)-style keys, three keys, mixed placement
+    assert run_sort_multi(be, [(np.int32, [30, 10, 20], False, False)]) == [1, 2, 0]
+    cat = [2, 1, 2, 1]; val = [1, 1, 2, 2]; pri = [100, 200, 300, 400]
+    assert run_sort_multi(be, [(np.int32, val, False, False), (np.int32, pri, True, True)]) == [1, 0, 3, 2]
+    assert run_sort_multi(be, [(np.int8, cat, False, False), (np.int32, val, True, False), (np.int64, pri, False, False)]) == [3, 1, 2, 0]
+    assert run_sort_multi(be, [(np.int8, [1, 1, 1], False, False), (np.float64, [None, 2.5, None], False, True), (np.uint16, [9, 8, 7], False, False)]) == [2, 0, 1]

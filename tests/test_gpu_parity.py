@@ -672,6 +672,27 @@ def test_sort_indices_many_tiles(hip, orc_be):
         assert hip.sort_indices(a, None, 0, True, False).tobytes() == orc_be.sort_indices(a, None, 0, True, False).tobytes()
 
 
+def test_sort_indices_multi_key(hip, orc_be):
+    """record-batch sort: 1–4 keys of mixed types, orders and null placements, few distinct values per key
+    so that later keys decide most positions; the permutation must equal the oracle's exactly"""
+    rng = np.random.default_rng(8200)
+    dts = [np.int8, np.uint16, np.int32, np.float32, np.int64, np.float64, np.uint64]
+    for n in (1, 65, 2049, 70001):
+        for trial in range(6):
+            nk = 1 + trial % 4
+            cols = []
+            for k in range(nk):
+                dt = np.dtype(dts[int(rng.integers(0, len(dts)))])
+                a = rng.integers(0, 4 if k < nk - 1 else 50, n).astype(dt)
+                if dt.kind == "f" and n > 8:
+                    a[rng.integers(0, n, 3)] = np.nan
+                valid = OL.pack_bits(list(rng.random(n) >= 0.1)) if rng.random() < 0.6 else None
+                cols.append((a, valid, 0, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+            e = orc_be.sort_indices_multi(cols)
+            g = hip.sort_indices_multi(cols)
+            assert g.tobytes() == e.tobytes(), (n, trial, [(c[0].dtype, c[3], c[4]) for c in cols])
+
+
 # ---- full-size properties (BASELINE.json configs; no oracle pass needed) -------------------
 def test_full_size_properties(ctx):
     """C2/C3 sizes (2^27 rows = 1 GiB columns) checked through size-independent
