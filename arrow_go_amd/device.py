@@ -290,6 +290,20 @@ class Context:
         nfirst = (C.c_int * k)(*[int(x[5]) for x in keys])
         check(self.handle, lib.ah_sort_indices_multi(self.handle, k, types, vals, valids, offs, n, desc, nfirst, _ptr(out_indices)))
 
+    # ---- var-length take ------------------------------------------------------------------
+    def take_binary_offsets(self, offset_width: int, offsets, vvalid, voff: int, nvalues: int, idx_byte_width: int, idx_signed: bool,
+                            idx, ivalid, ioff: int, nidx: int, out_offsets, out_valid):
+        """→ (null_count, total_bytes)"""
+        nulls, total, bad = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.handle, lib.ah_take_binary_offsets(self.handle, offset_width, _ptr(offsets), _ptr(vvalid), voff, nvalues, idx_byte_width,
+                                                      int(idx_signed), _ptr(idx), _ptr(ivalid), ioff, nidx, 1, _ptr(out_offsets),
+                                                      _ptr(out_valid), C.byref(nulls), C.byref(total), C.byref(bad)))
+        return nulls.value, total.value
+
+    def take_binary_data(self, offset_width: int, offsets, data, voff: int, idx_byte_width: int, idx, nidx: int, out_offsets, out_data) -> None:
+        check(self.handle, lib.ah_take_binary_data(self.handle, offset_width, _ptr(offsets), _ptr(data), voff, idx_byte_width, _ptr(idx), nidx,
+                                                   _ptr(out_offsets), _ptr(out_data)))
+
     # ---- hashing ------------------------------------------------------------------------
     def hash_u64_encode(self, keys, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_dict):
         nd = C.c_int64()

@@ -344,6 +344,25 @@ int ah_sort_indices(ah_ctx* ctx, int type, const void* values, const uint8_t* va
 int ah_sort_indices_multi(ah_ctx* ctx, int nkeys, const int* types, const void* const* values, const uint8_t* const* valids,
                           const int64_t* offs, int64_t n, const int* descending, const int* nulls_at_start, uint64_t* out_indices);
 
+/* ---- var-length Take / Filter (row §8(f)-4) ------------------------------------------------------
+ * replaces VarBinaryImpl (kernels/vector_selection.go:1925-1992) under takeExec / filterExec
+ * (:1460-1598, 1821-1923) for Binary / String (offset_width 4) and LargeBinary / LargeString (8).
+ * `offsets`: the values' offsets buffer (element voff + i and voff + i + 1 delimit value i; vvalid
+ * bit voff + i).  Two calls with the caller's allocation in between:
+ *   _offsets: out_offsets[0..nidx] (offset_width each, starting at 0), out_valid (nullable), the null
+ *             count, the number of data bytes, AH_EINDEX "<v> out of bounds" for the first offending
+ *             valid index, AH_EINVALID "binary output offset overflow" (:1245) — synchronises;
+ *   _data:    the bytes, into a buffer of that many bytes.
+ * A null output (null value or null index) has zero length.  Filter of a binary column =
+ * ah_filter_count → ah_filter_to_indices → these two (GetTakeIndices, as compute/selection.go:687 does
+ * for record batches); uint32 indices, so < 2^32 rows. */
+int ah_take_binary_offsets(ah_ctx* ctx, int offset_width, const void* offsets, const uint8_t* vvalid, int64_t voff, int64_t nvalues,
+                           int idx_byte_width, int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx,
+                           int bounds_check, void* out_offsets, uint8_t* out_valid, int64_t* out_null_count_host,
+                           int64_t* out_total_bytes_host, int64_t* bad_index_host);
+int ah_take_binary_data(ah_ctx* ctx, int offset_width, const void* offsets, const uint8_t* data, int64_t voff, int idx_byte_width,
+                        const void* idx, int64_t nidx, const void* out_offsets, uint8_t* out_data);
+
 /* ---- fused scalar-expression evaluation (row §8(f)-1: the expression executor) ---------
  * What compute.Expression trees — NewCall / NewFieldRef / NewLiteral, arrow/compute/
  * expression.go:596-620 — evaluate to through executeScalarBatch (arrow/compute/exprs/

@@ -97,6 +97,15 @@ int orc_take_primitive(int byte_width, const void* values, const uint8_t* vvalid
 int orc_filter_to_indices(const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
                           uint32_t* out_idx, uint8_t* out_valid, int64_t* out_len, int64_t* out_null_count);
 
+/* ---- var-length (binary / string) Take and Filter: VarBinaryImpl, kernels/vector_selection.go:1925-1992 ---- */
+int orc_take_binary(int offset_width, const void* offsets, const uint8_t* data, const uint8_t* vvalid, int64_t voff, int64_t nvalues,
+                    int idx_byte_width, int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx,
+                    int bounds_check, void* out_offsets, uint8_t* out_data, uint8_t* out_valid, int64_t* out_null_count,
+                    int64_t* out_total_bytes, int64_t* bad_index);
+int orc_filter_binary(int offset_width, const void* offsets, const uint8_t* data, const uint8_t* vvalid, int64_t voff,
+                      const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel, void* out_offsets,
+                      uint8_t* out_data, uint8_t* out_valid, int64_t* out_len, int64_t* out_null_count, int64_t* out_total_bytes);
+
 /* ---- hashing ---------------------------------------------------------- */
 uint64_t orc_hash_int(uint64_t v, uint64_t alg);
 /* unique / dictionary_encode over 8-byte keys (raw bit patterns).

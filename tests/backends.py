@@ -92,6 +92,12 @@ class OracleBackend:
     def sort_indices_multi(self, columns):
         return self.o.sort_indices_multi(columns)
 
+    def take_binary(self, offsets, data, vvalid, voff, nvalues, idx, ivalid, ioff, want_valid):
+        return self.o.take_binary(offsets, data, vvalid, voff, nvalues, idx, ivalid, ioff, want_valid)
+
+    def filter_binary(self, offsets, data, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid):
+        return self.o.filter_binary(offsets, data, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid)
+
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
@@ -321,6 +327,42 @@ class HipBackend:
         odb.memset(fill); ovb.memset(fill)
         self.c.is_in(values.dtype.itemsize, vp, vvp, off, n, sp, svp, set_off, set_values.size, null_behavior, odb, ovb, out_off)
         return odb.download(np.uint8, nb), ovb.download(np.uint8, nb)
+
+    def take_binary(self, offsets, data, vvalid, voff, nvalues, idx, ivalid, ioff, want_valid):
+        import arrow_go_amd as ah
+        offsets = np.ascontiguousarray(offsets); idx = np.ascontiguousarray(idx)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = idx.size
+        w = offsets.dtype.itemsize
+        ofb, ofp = self._up(offsets); db, dp = self._up(data) if data.size else (None, None)
+        vvb, vvp = self._upbits(vvalid); ib, ip = self._up(idx) if n else (None, None); ivb, ivp = self._upbits(ivalid)
+        oob = self.c.alloc((n + 1) * w + 64); oob.memset(0xCD)
+        ovb = self.c.alloc((n + 7) // 8 + 64) if want_valid else None
+        try:
+            nulls, total = self.c.take_binary_offsets(w, ofp, vvp, voff, nvalues, idx.dtype.itemsize, idx.dtype.kind == "i", ip, ivp, ioff, n, oob, ovb)
+        except ah.ErrIndex as e:
+            return STATUS_EINDEX, None, None, None, 0, int(str(e).split()[0])
+        odb = self.c.alloc(total + 64); odb.memset(0xCD)
+        self.c.take_binary_data(w, ofp, dp, voff, idx.dtype.itemsize, ip, n, oob, odb)
+        return (STATUS_OK, oob.download(offsets.dtype, n + 1), odb.download(np.uint8, total),
+                (ovb.download(np.uint8, (n + 7) // 8) if want_valid else None), nulls, 0)
+
+    def filter_binary(self, offsets, data, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid):
+        """filter = GetTakeIndices + var-length take (ah_filter_count → ah_filter_to_indices → ah_take_binary_*)"""
+        offsets = np.ascontiguousarray(offsets); data = np.ascontiguousarray(data, dtype=np.uint8)
+        w = offsets.dtype.itemsize
+        ofb, ofp = self._up(offsets); db, dp = self._up(data) if data.size else (None, None)
+        vvb, vvp = self._upbits(vvalid); fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
+        n_out = self.c.filter_count(fp, fvp, foff, n, null_sel)
+        ib = self.c.alloc(n_out * 4 + 64); ivb = self.c.alloc((n_out + 7) // 8 + 64)
+        idx_nulls = self.c.filter_to_indices(fp, fvp, foff, n, null_sel, n_out, ib, ivb)
+        oob = self.c.alloc((n_out + 1) * w + 64)
+        ovb = self.c.alloc((n_out + 7) // 8 + 64) if want_valid else None
+        nulls, total = self.c.take_binary_offsets(w, ofp, vvp, voff, n, 4, False, ib, ivb if idx_nulls else None, 0, n_out, oob, ovb)
+        odb = self.c.alloc(total + 64)
+        self.c.take_binary_data(w, ofp, dp, voff, 4, ib, n_out, oob, odb)
+        return (oob.download(offsets.dtype, n_out + 1), odb.download(np.uint8, total),
+                (ovb.download(np.uint8, (n_out + 7) // 8) if want_valid else None), nulls)
 
     def sort_indices_multi(self, columns):
         keep, keys = [], []

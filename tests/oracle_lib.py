@@ -73,6 +73,8 @@ class Oracle:
             "orc_sort_indices": (it, [it, vp, vp, i64, i64, it, it, vp]),
             "orc_min_max": (it, [it, vp, i64, vp, vp]),
             "orc_sort_indices_multi": (it, [it, vp, vp, vp, vp, i64, vp, vp, vp]),
+            "orc_take_binary": (it, [it, vp, vp, vp, i64, i64, it, it, vp, vp, i64, i64, it, vp, vp, vp, vp, vp, vp]),
+            "orc_filter_binary": (it, [it, vp, vp, vp, i64, vp, vp, i64, i64, it, vp, vp, vp, vp, vp, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -258,6 +260,33 @@ class Oracle:
         st = self.lib.orc_sort_indices_multi(k, types, vals, valids, offs, n, desc, nfirst, _p(out))
         assert st == 0, st
         return out[:n]
+
+    # ---- var-length take / filter -------------------------------------------------------
+    def take_binary(self, offsets, data, vvalid, voff, nvalues, idx, ivalid, ioff, want_valid, bounds_check=True):
+        """→ (status, out_offsets, out_data, out_valid, nulls, bad_index)"""
+        offsets = np.ascontiguousarray(offsets); idx = np.ascontiguousarray(idx)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = idx.size
+        oo = np.zeros(n + 1, offsets.dtype)
+        od = np.zeros(max(int(data.size) * max(n, 1), 1), np.uint8) if n * max(data.size, 1) < (1 << 26) else np.zeros(1 << 26, np.uint8)
+        ov = np.zeros((n + 7) // 8 + 1, np.uint8) if want_valid else None
+        nulls, total, bad = np.zeros(1, np.int64), np.zeros(1, np.int64), np.zeros(1, np.int64)
+        st = self.lib.orc_take_binary(offsets.dtype.itemsize, _p(offsets), _p(data), _p(vvalid), voff, nvalues, idx.dtype.itemsize,
+                                      int(idx.dtype.kind == "i"), _p(idx), _p(ivalid), ioff, n, int(bounds_check), _p(oo), _p(od), _p(ov),
+                                      _p(nulls), _p(total), _p(bad))
+        return st, oo, od[:int(total[0])], (ov[:(n + 7) // 8] if want_valid else None), int(nulls[0]), int(bad[0])
+
+    def filter_binary(self, offsets, data, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid):
+        """→ (out_offsets[:n_out+1], out_data, out_valid, nulls)"""
+        offsets = np.ascontiguousarray(offsets); data = np.ascontiguousarray(data, dtype=np.uint8)
+        oo = np.zeros(n + 1, offsets.dtype); od = np.zeros(max(data.size, 1), np.uint8)
+        ov = np.zeros((n + 7) // 8 + 1, np.uint8) if want_valid else None
+        n_out, nulls, total = np.zeros(1, np.int64), np.zeros(1, np.int64), np.zeros(1, np.int64)
+        st = self.lib.orc_filter_binary(offsets.dtype.itemsize, _p(offsets), _p(data), _p(vvalid), voff, _p(fdata), _p(fvalid), foff, n,
+                                        null_sel, _p(oo), _p(od), _p(ov), _p(n_out), _p(nulls), _p(total))
+        assert st == 0, st
+        m = int(n_out[0])
+        return oo[:m + 1], od[:int(total[0])], (ov[:(m + 7) // 8] if want_valid else None), int(nulls[0])
 
     # ---- hashing ------------------------------------------------------------------------
     def hash_int(self, v, alg=0): return int(self.lib.orc_hash_int(int(v) & (2**64 - 1), alg))

@@ -942,3 +942,79 @@ def test_sort_indices_record_batch_table(be):
     assert run_sort_multi(be, [(np.int32, val, False, False), (np.int32, pri, True, True)]) == [1, 0, 3, 2]
     assert run_sort_multi(be, [(np.int8, cat, False, False), (np.int32, val, True, False), (np.int64, pri, False, False)]) == [3, 1, 2, 0]
     assert run_sort_multi(be, [(np.int8, [1, 1, 1], False, False), (np.float64, [None, 2.5, None], False, True), (np.uint16, [9, 8, 7], False, False)]) == [2, 0, 1]
+
+
+# ---- var-length (binary / string) Take and Filter ----------------------------------------------
+def mk_binary(vals, offset_dtype, pad=b""):
+    """python list of bytes / None → (offsets, data, validity or None); nulls carry `pad` as payload
+    so that a null's bytes must not leak into the output"""
+    offs, data, valid = [0], b"", []
+    for v in vals:
+        b = pad if v is None else v
+        data += b
+        offs.append(len(data))
+        valid.append(v is not None)
+    return np.array(offs, offset_dtype), np.frombuffer(data, np.uint8), (None if all(valid) else OL.pack_bits(valid))
+
+
+def un_binary(offsets, data, valid, n):
+    bits = OL.unpack_bits(valid, 0, n) if valid is not None else [1] * n
+    out = []
+    for i in range(n):
+        lo, hi = int(offsets[i]), int(offsets[i + 1])
+        if not bits[i]:
+            assert lo == hi          # a null output has zero length (VarBinaryImpl :1979-1982)
+            out.append(None)
+        else:
+            out.append(bytes(data[lo:hi]))
+    return out
+
+
+def run_take_binary(be, odt, vals, idtype, idx, sl=None):
+    offsets, data, vvalid = mk_binary(vals, odt, pad=b"??")
+    ia, ivalid = mk(idx, idtype)
+    lo, hi = sl if sl else (0, len(vals))
+    st, oo, od, ov, nulls, bad = be.take_binary(offsets, data, vvalid, lo, hi - lo, ia, ivalid, 0, True)
+    if st != STATUS_OK:
+        return st, bad
+    assert oo[0] == 0 and oo[-1] == len(od)
+    got = un_binary(oo, od, ov, len(idx))
+    assert nulls == sum(g is None for g in got)
+    return st, got
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64], ids=["binary", "large_binary"])
+def test_take_string(be, odt):
+    # TestTakeString :1193-1210 (a, b, c)
+    a, b, c = b"a", b"b", b"c"
+    assert run_take_binary(be, odt, [a, b, c], np.int32, [0, 1, 0]) == (STATUS_OK, [a, b, a])
+    assert run_take_binary(be, odt, [None, b, c], np.int32, [0, 1, 0]) == (STATUS_OK, [None, b, None])
+    assert run_take_binary(be, odt, [a, b, c], np.int32, [None, 1, 0]) == (STATUS_OK, [None, b, a])
+    assert run_take_binary(be, odt, [a, b, c], np.int8, [0, 9, 0]) == (STATUS_EINDEX, 9)
+    assert run_take_binary(be, odt, [a, b, c], np.int64, [2, 5]) == (STATUS_EINDEX, 5)
+    # longer values, empty strings, repeats, a sliced values array (Offset applies to offsets and validity)
+    v = [b"", b"hello world, this is a longer value " * 3, None, b"x", b"", b"\x00\xff binary"]
+    assert run_take_binary(be, odt, v, np.uint16, [5, 1, 1, 0, 4, 2, 3]) == (STATUS_OK, [v[5], v[1], v[1], b"", b"", None, b"x"])
+    assert run_take_binary(be, odt, v, np.int32, [0, 3, 1], sl=(2, 6)) == (STATUS_OK, [None, v[5], b"x"])
+    assert run_take_binary(be, odt, v, np.int32, []) == (STATUS_OK, [])
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64], ids=["binary", "large_binary"])
+def test_filter_string(be, odt):
+    # TestFilterString :698-704
+    a, b, c = b"a", b"b", b"c"
+
+    def run(vals, filt, null_sel):
+        offsets, data, vvalid = mk_binary(vals, odt, pad=b"??")
+        fd = OL.pack_bits([bool(x) for x in filt]); fv = None if all(x is not None for x in filt) else OL.pack_bits([x is not None for x in filt])
+        oo, od, ov, nulls = be.filter_binary(offsets, data, vvalid, 0, fd, fv, 0, len(vals), null_sel, True)
+        got = un_binary(oo, od, ov, len(oo) - 1)
+        assert nulls == sum(g is None for g in got)
+        return got
+
+    assert run([a, b, c], [False, True, False], DROP) == [b]
+    assert run([None, b, c], [False, True, False], DROP) == [b]
+    assert run([a, b, c], [None, True, False], EMIT) == [None, b]
+    assert run([a, b, c], [None, True, False], DROP) == [b]
+    assert run([a, None, c * 40, b""], [True, True, True, True], DROP) == [a, None, c * 40, b""]
+    assert run([], [], DROP) == []

@@ -693,6 +693,63 @@ def test_sort_indices_multi_key(hip, orc_be):
             assert g.tobytes() == e.tobytes(), (n, trial, [(c[0].dtype, c[3], c[4]) for c in cols])
 
 
+# ---- var-length take / filter -----------------------------------------------------------------
+def random_binary(rng, n, odt, mean_len, p_null):
+    lens = rng.geometric(1.0 / (mean_len + 1), n) - 1
+    lens[rng.random(n) < 0.1] = 0
+    offsets = np.zeros(n + 1, odt)
+    offsets[1:] = np.cumsum(lens)
+    data = rng.integers(0, 256, int(offsets[-1]), dtype=np.uint8)
+    valid = OL.pack_bits(list(rng.random(n) >= p_null)) if p_null > 0 else None
+    return offsets, data, valid
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64], ids=["binary", "large_binary"])
+def test_take_binary_bit_exact(hip, orc_be, odt):
+    """offsets, data bytes, validity and null count all byte-identical; short and long values, repeats,
+    nulls on both sides, every index width, sliced values"""
+    rng = np.random.default_rng(9000 + np.dtype(odt).itemsize)
+    for nvals, mean_len in ((1, 3), (50, 0), (300, 7), (4000, 40), (2000, 700)):
+        offsets, data, vvalid = random_binary(rng, nvals, odt, mean_len, 0.15 if nvals % 2 == 0 else 0.0)
+        for n, idt in ((1, np.int8), (63, np.uint8), (1025, np.int16), (70001, np.int32), (5000, np.uint64)):
+            voff = int(rng.integers(0, max(1, nvals // 3)))
+            avail = nvals - voff
+            hi = min(avail, np.iinfo(idt).max + 1)
+            idx = rng.integers(0, hi, n).astype(idt)
+            ivalid = OL.pack_bits(list(rng.random(n) >= 0.1)) if n % 2 else None
+            want_valid = vvalid is not None or ivalid is not None
+            e = orc_be.take_binary(offsets, data, vvalid, voff, avail, idx, ivalid, 0, want_valid)
+            g = hip.take_binary(offsets, data, vvalid, voff, avail, idx, ivalid, 0, want_valid)
+            assert e[0] == g[0] == STATUS_OK
+            assert g[1].tobytes() == e[1].tobytes(), ("offsets", nvals, n, idt)
+            assert g[2].tobytes() == e[2].tobytes(), ("data", nvals, n, idt)
+            if want_valid:
+                assert g[3].tobytes() == e[3].tobytes() and g[4] == e[4]
+    # first offending index wins, null index slots are not checked
+    idx = np.array([0, 7, 1000, -3, 2000], np.int32)
+    ivalid = OL.pack_bits([True, True, False, True, True])
+    offsets, data, vvalid = random_binary(rng, 10, odt, 5, 0.0)
+    assert hip.take_binary(offsets, data, None, 0, 10, idx, ivalid, 0, True)[0::5] == (STATUS_EINDEX, -3)
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64], ids=["binary", "large_binary"])
+def test_filter_binary_bit_exact(hip, orc_be, odt):
+    rng = np.random.default_rng(9100 + np.dtype(odt).itemsize)
+    for n, mean_len in ((1, 4), (65, 0), (3000, 12), (70001, 9), (20000, 300)):
+        offsets, data, vvalid = random_binary(rng, n + 7, odt, mean_len, 0.2 if n % 2 else 0.0)
+        voff = 7
+        foff = int(rng.integers(0, 30))
+        for sel, null_sel, p_fnull in ((0.5, DROP, 0.0), (0.1, EMIT, 0.2), (0.95, DROP, 0.2), (0.0, DROP, 0.0), (1.0, EMIT, 0.0)):
+            fd = OL.pack_bits([False] * foff + list(rng.random(n) < sel))
+            fv = OL.pack_bits([True] * foff + list(rng.random(n) >= p_fnull)) if p_fnull else None
+            want_valid = vvalid is not None or fv is not None
+            e = orc_be.filter_binary(offsets, data, vvalid, voff, fd, fv, foff, n, null_sel, want_valid)
+            g = hip.filter_binary(offsets, data, vvalid, voff, fd, fv, foff, n, null_sel, want_valid)
+            assert g[0].tobytes() == e[0].tobytes() and g[1].tobytes() == e[1].tobytes(), (n, sel, null_sel)
+            if want_valid:
+                assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+
+
 # ---- full-size properties (BASELINE.json configs; no oracle pass needed) -------------------
 def test_full_size_properties(ctx):
     """C2/C3 sizes (2^27 rows = 1 GiB columns) checked through size-independent
