@@ -38,12 +38,13 @@ namespace arrowhip {
 // ---- arrow.Type / arrow.DataType (arrow/datatype.go:36-72) ---------------------------
 enum class Type : int {
   NA = 0, BOOL = 1, UINT8 = 2, INT8 = 3, UINT16 = 4, INT16 = 5, UINT32 = 6, INT32 = 7,
-  UINT64 = 8, INT64 = 9, FLOAT16 = 10, FLOAT32 = 11, FLOAT64 = 12, DICTIONARY = 36
+  UINT64 = 8, INT64 = 9, FLOAT16 = 10, FLOAT32 = 11, FLOAT64 = 12, STRING = 13, BINARY = 14,
+  LARGE_STRING = 34, LARGE_BINARY = 35, DICTIONARY = 36
 };
 
 struct DataType {
   Type id;
-  int bit_width;       // arrow.FixedWidthDataType.BitWidth()
+  int bit_width;       // arrow.FixedWidthDataType.BitWidth(); base-binary types: the OFFSET width (32 / 64)
   const char* name;    // DataType.Name()
   const char* format;  // Arrow C Data Interface format string
 };
@@ -52,6 +53,7 @@ bool IsInteger(Type id);
 bool IsSignedInteger(Type id);
 bool IsFloating(Type id);
 bool IsNumeric(Type id);
+bool IsBaseBinary(Type id);  // String, Binary, LargeString, LargeBinary: buffers = [validity, offsets, data]
 
 // ---- errors (arrow/errors.go) ---------------------------------------------------------
 enum class StatusCode { OK = 0, Invalid, Index, NotImplemented, TypeError, KeyError, Hip };
@@ -100,7 +102,7 @@ struct ArrayData {
   int64_t length = 0;
   int64_t null_count = kUnknownNullCount;
   int64_t offset = 0;
-  BufferPtr buffers[2];                    // [0] validity, [1] values / boolean data
+  BufferPtr buffers[3];                    // [0] validity, [1] values / boolean data / offsets, [2] var-length data
   std::shared_ptr<ArrayData> dictionary;   // for DICTIONARY results (dictionary_encode)
   const DataType* dict_value_type = nullptr;
 };

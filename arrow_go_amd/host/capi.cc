@@ -94,6 +94,8 @@ AHC_EXPORT int ahc_function_num_kernels(const char* name) {
 
 static const DataType* TypeFromFormat(const char* f) {
   if (!f || !f[0] || f[1]) return nullptr;
+  for (Type bt : {Type::STRING, Type::BINARY, Type::LARGE_STRING, Type::LARGE_BINARY})
+    if (GetDataType(bt)->format[0] == f[0]) return GetDataType(bt);
   for (int i = 0; i <= (int)Type::FLOAT64; i++) {
     const DataType* t = GetDataType((Type)i);
     if (t && t->format[0] == f[0] && t->id != Type::NA) return t;
@@ -117,7 +119,17 @@ AHC_EXPORT int ahc_import(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, 
     int64_t nbits = arr->offset + arr->length;
     int64_t vbytes = (nbits + 7) / 8;
     int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
-    if (arr->n_buffers >= 1 && arr->buffers[0] != nullptr && arr->null_count != 0) {
+    int64_t data_bytes = 0;
+    if (IsBaseBinary(t->id)) {  // [validity, offsets (offset + length + 1 entries), data (up to the last offset)]
+      dbytes = (nbits + 1) * (t->bit_width / 8);
+      if (arr->n_buffers >= 3 && arr->buffers[1] != nullptr)
+        data_bytes = t->bit_width == 32 ? (int64_t)((const int32_t*)arr->buffers[1])[nbits] : ((const int64_t*)arr->buffers[1])[nbits];
+      st = ss->Allocate(data_bytes, &d->buffers[2]);
+      if (st.ok() && data_bytes > 0 && arr->buffers[2] != nullptr)
+        st = ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[2]->dptr, arr->buffers[2], (size_t)data_bytes));
+    }
+    if (!st.ok()) {
+    } else if (arr->n_buffers >= 1 && arr->buffers[0] != nullptr && arr->null_count != 0) {
       st = ss->Allocate(vbytes, &d->buffers[0]);
       if (st.ok()) st = ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[0]->dptr, arr->buffers[0], (size_t)vbytes));
     } else {
@@ -308,8 +320,8 @@ AHC_EXPORT int ahc_registry_add_alias(ahc_session* s, const char* alias, const c
 
 // ---- export ------------------------------------------------------------------------------------
 struct ExportPriv {
-  void* bufs[2] = {nullptr, nullptr};
-  const void* buffer_ptrs[2] = {nullptr, nullptr};
+  void* bufs[3] = {nullptr, nullptr, nullptr};
+  const void* buffer_ptrs[3] = {nullptr, nullptr, nullptr};
   ArrowArray* dict = nullptr;
   ArrowSchema* dict_schema = nullptr;
 };
@@ -318,6 +330,7 @@ static void ReleaseArray(ArrowArray* a) {
   if (p) {
     free(p->bufs[0]);
     free(p->bufs[1]);
+    free(p->bufs[2]);
     if (p->dict) { if (p->dict->release) p->dict->release(p->dict); free(p->dict); }
     delete p;
   }
@@ -335,6 +348,8 @@ static Status ExportOne(Session* ss, const ArrayData& a, const DataType* t, Arro
   int64_t nbits = a.offset + a.length;
   int64_t vbytes = (nbits + 7) / 8;
   int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
+  const bool is_binary = IsBaseBinary(t->id);
+  if (is_binary) dbytes = (nbits + 1) * (t->bit_width / 8);
   if (a.buffers[0] && a.null_count != 0) {
     p->bufs[0] = calloc(1, (size_t)vbytes + 64);
     AHC_RETURN_NOT_OK(ss->FromStatus(ah_download_async(ss->ctx(), p->bufs[0], a.buffers[0]->dptr, (size_t)vbytes)));
@@ -343,12 +358,21 @@ static Status ExportOne(Session* ss, const ArrayData& a, const DataType* t, Arro
   if (a.buffers[1] && dbytes > 0)
     AHC_RETURN_NOT_OK(ss->FromStatus(ah_download_async(ss->ctx(), p->bufs[1], a.buffers[1]->dptr, (size_t)dbytes)));
   AHC_RETURN_NOT_OK(ss->FromStatus(ah_sync(ss->ctx())));
+  if (is_binary) {  // the data buffer's extent is the last offset, now on the host
+    int64_t data_bytes = t->bit_width == 32 ? (int64_t)((const int32_t*)p->bufs[1])[nbits] : ((const int64_t*)p->bufs[1])[nbits];
+    p->bufs[2] = calloc(1, (size_t)data_bytes + 64);
+    if (a.buffers[2] && data_bytes > 0) {
+      AHC_RETURN_NOT_OK(ss->FromStatus(ah_download_async(ss->ctx(), p->bufs[2], a.buffers[2]->dptr, (size_t)data_bytes)));
+      AHC_RETURN_NOT_OK(ss->FromStatus(ah_sync(ss->ctx())));
+    }
+  }
   p->buffer_ptrs[0] = p->bufs[0];
   p->buffer_ptrs[1] = p->bufs[1];
+  p->buffer_ptrs[2] = p->bufs[2];
   arr->length = a.length;
   arr->null_count = p->bufs[0] ? a.null_count : 0;
   arr->offset = a.offset;
-  arr->n_buffers = 2;
+  arr->n_buffers = is_binary ? 3 : 2;
   arr->buffers = p->buffer_ptrs;
   arr->release = ReleaseArray;
   arr->private_data = p;

@@ -19,9 +19,15 @@ static const DataType kTypes[] = {
     {Type::INT64, 64, "int64", "l"},   {Type::FLOAT16, 16, "float16", "e"}, {Type::FLOAT32, 32, "float32", "f"},
     {Type::FLOAT64, 64, "float64", "g"}};
 static const DataType kDictType = {Type::DICTIONARY, 32, "dictionary", "i"};
+static const DataType kBinaryTypes[] = {{Type::STRING, 32, "utf8", "u"}, {Type::BINARY, 32, "binary", "z"},
+                                        {Type::LARGE_STRING, 64, "large_utf8", "U"}, {Type::LARGE_BINARY, 64, "large_binary", "Z"}};
+
+bool IsBaseBinary(Type id) { return id == Type::STRING || id == Type::BINARY || id == Type::LARGE_STRING || id == Type::LARGE_BINARY; }
 
 const DataType* GetDataType(Type id) {
   if (id == Type::DICTIONARY) return &kDictType;
+  for (auto& t : kBinaryTypes)
+    if (t.id == id) return &t;
   int i = (int)id;
   if (i < 0 || i > (int)Type::FLOAT64 || id == Type::FLOAT16) return nullptr;
   return &kTypes[i];
@@ -85,7 +91,7 @@ void ArraySpan::SetMembers(const ArrayData& d) {
   len = d.length;
   nulls = d.null_count;
   offset = d.offset;
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 3; i++) {
     buffers[i].owner = d.buffers[i];
     buffers[i].buf = d.buffers[i] ? (uint8_t*)d.buffers[i]->dptr : nullptr;
     buffers[i].len = d.buffers[i] ? d.buffers[i]->size : 0;
@@ -117,6 +123,7 @@ ArrayDataPtr ArraySpan::MakeData() const {
   d->offset = offset;
   d->buffers[0] = buffers[0].owner;
   d->buffers[1] = buffers[1].owner;
+  d->buffers[2] = buffers[2].owner;
   // span.go:243-247: a known-zero null count drops the validity buffer
   if (nulls == 0) d->buffers[0] = nullptr;
   return d;

@@ -36,7 +36,7 @@ def test_registry_has_the_path_functions():
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
-    assert ac.function_num_kernels("array_take") == 80      # 10 value types × 8 index types
+    assert ac.function_num_kernels("array_take") == 112     # (10 numeric + 4 binary-like value types) × 8 index types
     assert ac.function_num_kernels("filter") == 0           # MetaFunction
     assert ac.function_num_kernels("cast_int64") == 10       # 9 other numeric types + bool
     assert ac.function_num_kernels("cumulative_sum") == 10 and ac.function_num_kernels("cumulative_sum_checked") == 10
@@ -607,6 +607,50 @@ def test_sort_indices_random_vs_arrow_cpp(sess, typ):
             got = sess.call_function("sort_indices", [a], "order=%s;null_placement=%s" % (order, npl))
             exp = pc.sort_indices(a, sort_keys=[("x", order)], null_placement=npl) if False else pc.array_sort_indices(a, order=order, null_placement=npl)
             assert got.to_pylist() == exp.to_pylist(), (typ, order, npl)
+
+
+# ---- var-length take / filter (vector_selection_test.go:698-704, 1193-1210) -----------------------------------
+_BIN = [pa.string(), pa.binary(), pa.large_string(), pa.large_binary()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", _BIN, ids=str)
+def test_take_filter_binary(sess, typ):
+    from arrow_go_amd import compute as ac
+    conv = (lambda v: v) if pa.types.is_string(typ) or pa.types.is_large_string(typ) else (lambda v: None if v is None else v.encode())
+    A = lambda v: pa.array([conv(x) for x in v], type=typ)
+    take = lambda v, i, it=pa.int32(): sess.call_function("take", [A(v), pa.array(i, type=it)])
+    assert take(["a", "b", "c"], [0, 1, 0]).equals(A(["a", "b", "a"]))
+    assert take([None, "b", "c"], [0, 1, 0]).equals(A([None, "b", None]))
+    assert take(["a", "b", "c"], [None, 1, 0]).equals(A([None, "b", "a"]))
+    with pytest.raises(ac.ErrIndex, match="9 out of bounds"):
+        take(["a", "b", "c"], [0, 9, 0], pa.int8())
+    with pytest.raises(ac.ErrIndex, match="5 out of bounds"):
+        take(["a", "b", "c"], [2, 5], pa.int64())
+    out = take(["a", "b", "c"], [0, 1, 0])
+    assert out.type == typ and out.null_count == 0
+    filt = lambda v, f, o="": sess.call_function("filter", [A(v), pa.array(f, type=pa.bool_())], o)
+    assert filt(["a", "b", "c"], [False, True, False]).equals(A(["b"]))
+    assert filt([None, "b", "c"], [False, True, False]).equals(A(["b"]))
+    assert filt(["a", "b", "c"], [None, True, False], "null_selection_behavior=emit_null").equals(A([None, "b"]))
+    assert filt(["a", "b", "c"], [None, True, False]).equals(A(["b"]))
+    assert filt([], []).equals(A([]))
+    # random, sliced, against Arrow C++
+    rng = np.random.default_rng(5)
+    n = 20011
+    words = ["", "x", "hello", "a much longer value that spans many bytes " * 4, "ünïcödé", "zz"]
+    vals = [None if rng.random() < 0.1 else words[int(rng.integers(0, len(words)))] + str(int(rng.integers(0, 1000))) for _ in range(n)]
+    a = A(vals).slice(11, n - 30)
+    idx = pa.array(rng.integers(0, len(a), 30000), mask=rng.random(30000) < 0.05, type=pa.int32())
+    assert sess.call_function("take", [a, idx]).equals(pc.take(a, idx))
+    m = pa.array(rng.random(len(a)) < 0.4, mask=rng.random(len(a)) < 0.1).slice(3)
+    a2 = a.slice(3)
+    assert sess.call_function("filter", [a2, m]).equals(pc.filter(a2, m))
+    assert sess.call_function("filter", [a2, m], "null_selection_behavior=emit_null").equals(pc.filter(a2, m, null_selection_behavior="emit_null"))
+    # sort = take(input, sort_indices(input)) needs a numeric key; a string column rides along through take
+    keys = pa.array(rng.integers(0, 100, len(a)), type=pa.int32())
+    order = sess.call_function("sort_indices", [keys], "order=ascending")
+    assert sess.call_function("take", [a, order]).equals(pc.take(a, pc.array_sort_indices(keys)))
 
 
 # ---- arrow/math + fused -------------------------------------------------------------------------------------
