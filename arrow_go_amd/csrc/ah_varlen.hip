@@ -14,7 +14,8 @@
 //                           ballot, + fused bounds check) → scan (ah_scan.hip's kernels) → output
 //                           offsets, total bytes, null count;
 //   ah_take_binary_data     a wave owns 64 output rows: (source, destination, length) per lane,
-//                           then row after row the 64 lanes copy that row's bytes together.
+//                           compacted through LDS; four 16-lane groups then copy four rows at a
+//                           time, 4 (unaligned) bytes per lane.
 // Filter = ah_filter_to_indices (GetTakeIndices, :102-236) + these two: filter(values, mask) and
 // take(values, indices_of(mask)) select the same slots with the same validity, which is also how
 // the reference filters record batches (compute/selection.go:687).
@@ -78,14 +79,19 @@ __global__ __launch_bounds__(kBlock) void offsets_kernel(const long long* __rest
   }
 }
 
+struct __attribute__((packed)) U32u { unsigned v; };  // 4 bytes at any address (gfx950 global memory runs in unaligned-access mode)
+
 template <typename OffT, typename IdxT>
 __global__ __launch_bounds__(kBlock) void copy_kernel(const OffT* __restrict__ offsets, const uint8_t* __restrict__ data, int64_t voff,
                                                        const IdxT* __restrict__ idx, int64_t n, const OffT* __restrict__ out_offsets,
                                                        uint8_t* __restrict__ out_data) {
-  const int lane = threadIdx.x & 63;
+  struct Row { long long src, dst, len; };
+  __shared__ Row s_rows[kBlock / 64][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int group = lane >> 4, sub = lane & 15;  // four 16-lane groups copy four rows at a time, 4 bytes per lane
   const int64_t nchunks = (n + 63) >> 6;
   const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
-  for (int64_t c = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); c < nchunks; c += wave_stride) {
+  for (int64_t c = (int64_t)blockIdx.x * (kBlock / 64) + wave; c < nchunks; c += wave_stride) {
     const int64_t i = c * 64 + lane;
     long long src = 0, dst = 0, len = 0;
     if (i < n) {
@@ -93,14 +99,25 @@ __global__ __launch_bounds__(kBlock) void copy_kernel(const OffT* __restrict__ o
       len = (long long)out_offsets[i + 1] - dst;
       if (len > 0) src = (long long)offsets[voff + (int64_t)as_unsigned<IdxT>(idx[i])];  // len > 0 ⇒ a valid, in-bounds slot
     }
-    // rows with bytes, one after the other; the 64 lanes copy a row together
-    unsigned long long todo = __ballot(len > 0);
-    while (todo) {
-      const int r = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const long long s = __shfl(src, r, 64), d = __shfl(dst, r, 64), l = __shfl(len, r, 64);
-      for (long long b = lane; b < l; b += 64) out_data[d + b] = data[s + b];
+    // rows that have bytes, compacted into LDS in row order
+    const unsigned long long todo = __ballot(len > 0);
+    const int count = __popcll(todo);
+    if (len > 0) s_rows[wave][__popcll(todo & (lane == 0 ? 0ull : (~0ull >> (64 - lane))))] = Row{src, dst, len};
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS ops of a wave are in order; keep the compiler from reordering
+    __builtin_amdgcn_wave_barrier();
+    for (int k = group; k < count; k += 4) {
+      volatile const Row* rp = &s_rows[wave][k];  // written by other lanes of this wave
+      Row r;
+      r.src = rp->src; r.dst = rp->dst; r.len = rp->len;
+      const uint8_t* sp = data + r.src;
+      uint8_t* dp = out_data + r.dst;
+      long long b = (long long)sub * 4;
+      for (; b + 4 <= r.len; b += 64) ((U32u*)(dp + b))->v = ((const U32u*)(sp + b))->v;
+      const long long tail = r.len & ~3ll;  // the last len mod 4 bytes
+      if (sub < (int)(r.len - tail)) dp[tail + sub] = sp[tail + sub];
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the next chunk overwrites s_rows
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
