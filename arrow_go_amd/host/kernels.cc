@@ -401,8 +401,11 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
 static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool dict_encode) {
   Session* s = k->session;
   ArraySpan keys = b.values[0].array;
-  if (keys.type->bit_width != 64)
-    return Status::Make(StatusCode::NotImplemented, std::string("hash kernels are accelerated for 8-byte keys (int64/uint64/float64), got ") + keys.type->name);
+  // 1/2/4-byte keys: the reference memoises them in Table[uint8/16/32] keyed on the raw bits
+  // (vector_hash.go:596-607); here the bits are zero-extended to 64 on the device, hashed in the same
+  // table, and the dictionary is narrowed back — the ids and the first-seen order are unchanged
+  const int kw = keys.type->bit_width / 8;
+  const int raw_type = kw == 1 ? AH_UINT8 : kw == 2 ? AH_UINT16 : AH_UINT32;
   const DictionaryEncodeOptions* opts = static_cast<const DictionaryEncodeOptions*>(k->state);
   int encode_nulls = dict_encode ? (opts && opts->NullEncoding == NullEncodingEncode) : 1;  // uniqueAction.ShouldEncodeNulls() == true
   AHC_RETURN_NOT_OK(keys.UpdateNullCount(s));
@@ -415,8 +418,15 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
     if (valid && !encode_nulls) AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &ids_valid));
   }
   int64_t ndict = 0; int32_t null_id = -1;
+  const uint64_t* keys64 = (const uint64_t*)Values(keys);
+  BufferPtr widened;
+  if (kw < 8 && n > 0) {
+    AHC_RETURN_NOT_OK(k->Allocate(n * 8, &widened));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_cast_numeric(s->ctx(), raw_type, AH_UINT64, Values(keys), nullptr, 0, n, 1, 1, widened->dptr)));
+    keys64 = (const uint64_t*)widened->dptr;
+  }
   if (n > 0)
-    AHC_RETURN_NOT_OK(s->FromStatus(ah_hash_u64_encode(s->ctx(), (const uint64_t*)Values(keys), valid, keys.offset, n, encode_nulls,
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_hash_u64_encode(s->ctx(), keys64, valid, keys.offset, n, encode_nulls,
                                                        ids ? (int32_t*)ids->dptr : nullptr, ids_valid ? (uint8_t*)ids_valid->dptr : nullptr,
                                                        (uint64_t*)dict->dptr, &ndict, &null_id)));
   // GetDictArrayData (arrow/array/util.go:321-390): values by memo index; if the table holds
@@ -425,8 +435,15 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
   d->type = keys.type;
   d->length = ndict;
   d->null_count = null_id >= 0 ? 1 : 0;
+  if (kw < 8) {
+    BufferPtr narrow;
+    AHC_RETURN_NOT_OK(k->Allocate(ndict * kw, &narrow));
+    if (ndict > 0)
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_cast_numeric(s->ctx(), AH_UINT64, raw_type, dict->dptr, nullptr, 0, ndict, 1, 1, narrow->dptr)));
+    dict = narrow;
+  }
   d->buffers[1] = dict;
-  dict->size = ndict * 8;
+  dict->size = ndict * kw;
   if (null_id >= 0) {
     BufferPtr dv;
     AHC_RETURN_NOT_OK(k->AllocateBitmap(ndict, &dv));
