@@ -124,6 +124,39 @@ int dispatch_idx(ah_ctx* c, int iw, int is_signed, const void* values, const uin
   return ah_fail(c, AH_EINDEX, "invalid indices byte width");  // vector_selection.go:1157
 }
 
+// Boolean values (booleanTakeImpl, vector_selection.go:990-1074): out data bit i = value bit idx[i],
+// validity as for the other widths; a null output keeps data bit 0 (fresh zeroed buffer in the
+// reference).  64 rows per wave step, both output words come from ballots.
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void take_bool_kernel(const uint8_t* __restrict__ data, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                            uint64_t nvalues, const IdxT* __restrict__ idx, const uint8_t* __restrict__ ivalid,
+                                                            int64_t ioff, int64_t nidx, uint8_t* __restrict__ out_data,
+                                                            uint8_t* __restrict__ out_valid, unsigned long long* __restrict__ first_bad) {
+  using UIdx = typename std::make_unsigned<IdxT>::type;
+  const int lane = threadIdx.x & 63;
+  const int64_t nchunks = (nidx + 63) >> 6;
+  const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t c = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); c < nchunks; c += wave_stride) {
+    const int64_t i = c * 64 + lane;
+    bool ok = false, bit = false;
+    if (i < nidx && ah_bit(ivalid, ioff + i)) {
+      const IdxT s = idx[i];
+      const uint64_t u = (uint64_t)(UIdx)s;
+      if ((std::is_signed<IdxT>::value && s < 0) || u >= nvalues) atomicMin(first_bad, (unsigned long long)i);
+      else if (ah_bit(vvalid, voff + (int64_t)u)) { ok = true; bit = ah_bit(data, voff + (int64_t)u); }
+    }
+    const unsigned long long dword = __ballot(ok && bit), vword = __ballot(ok);
+    if (lane == 0) {
+      const int64_t left = nidx - c * 64;
+      const int nbytes = left >= 64 ? 8 : (int)((left + 7) >> 3);
+      for (int b = 0; b < nbytes; b++) {
+        out_data[c * 8 + b] = (uint8_t)(dword >> (8 * b));
+        if (out_valid) out_valid[c * 8 + b] = (uint8_t)(vword >> (8 * b));
+      }
+    }
+  }
+}
+
 }  // namespace
 
 AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
@@ -166,6 +199,55 @@ AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, c
   uint64_t nvalid = *(volatile uint64_t*)&c->pinned[1];
   if (bad_pos != ~0ull) {
     // fetch the offending index value for the message ("%d out of bounds", helpers.go:950)
+    uint64_t raw = 0;
+    AH_HIP(c, hipMemcpy(&raw, (const uint8_t*)idx + bad_pos * (uint64_t)idx_byte_width, (size_t)idx_byte_width, hipMemcpyDeviceToHost));
+    int64_t val;
+    switch (idx_byte_width) {
+      case 1: val = idx_signed ? (int64_t)(int8_t)raw : (int64_t)(uint8_t)raw; break;
+      case 2: val = idx_signed ? (int64_t)(int16_t)raw : (int64_t)(uint16_t)raw; break;
+      case 4: val = idx_signed ? (int64_t)(int32_t)raw : (int64_t)(uint32_t)raw; break;
+      default: val = (int64_t)raw; break;
+    }
+    if (bad_index_host) *bad_index_host = val;
+    if (idx_signed || idx_byte_width < 8) return ah_fail(c, AH_EINDEX, "%lld out of bounds", (long long)val);
+    return ah_fail(c, AH_EINDEX, "%llu out of bounds", (unsigned long long)raw);
+  }
+  if (out_null_count_host) *out_null_count_host = out_valid ? nidx - (int64_t)nvalid : 0;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_take_boolean(ah_ctx* c, const uint8_t* data, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int idx_byte_width,
+                              int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check,
+                              uint8_t* out_data, uint8_t* out_valid, int64_t* out_null_count_host, int64_t* bad_index_host) {
+  AH_ENTER(c);
+  (void)bounds_check;
+  if (nidx < 0 || nvalues < 0 || voff < 0 || ioff < 0) return ah_fail(c, AH_EINVALID, "take: negative length/offset");
+  if (out_null_count_host) *out_null_count_host = 0;
+  if (nidx == 0) return AH_OK;
+  if (!idx || !out_data || (!data && nvalues > 0)) return ah_fail(c, AH_EINVALID, "take: null buffer");
+  if (!out_valid && (vvalid || ivalid)) { vvalid = nullptr; ivalid = nullptr; }
+  unsigned long long* first_bad = (unsigned long long*)&c->dscalars[1];
+  unsigned long long* valid_total = (unsigned long long*)&c->dscalars[2];
+  AH_HIP(c, hipMemsetAsync(first_bad, 0xFF, sizeof(*first_bad), c->stream));
+  AH_HIP(c, hipMemsetAsync(valid_total, 0, sizeof(*valid_total), c->stream));
+  const unsigned grid = ah_stream_grid(c, ah_ceil_div(ah_ceil_div(nidx, 64), kBlock / 64), 8);
+#define AH_TB(IT) take_bool_kernel<IT><<<grid, kBlock, 0, c->stream>>>(data, vvalid, voff, (uint64_t)nvalues, (const IT*)idx, ivalid, ioff, nidx, out_data, out_valid, first_bad); break
+  switch (idx_byte_width * 2 + (idx_signed ? 1 : 0)) {
+    case 2: AH_TB(uint8_t); case 3: AH_TB(int8_t); case 4: AH_TB(uint16_t); case 5: AH_TB(int16_t);
+    case 8: AH_TB(uint32_t); case 9: AH_TB(int32_t); case 16: AH_TB(uint64_t); case 17: AH_TB(int64_t);
+    default: return ah_fail(c, AH_EINDEX, "invalid indices byte width");
+  }
+#undef AH_TB
+  AH_LAUNCH_CHECK(c);
+  if (out_valid && out_null_count_host) {
+    int rc = ah_popcount_async(c, out_valid, 0, nidx, valid_total);
+    if (rc != AH_OK) return rc;
+  }
+  AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[1], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  const uint64_t bad_pos = *(volatile uint64_t*)&c->pinned[0];
+  const uint64_t nvalid = *(volatile uint64_t*)&c->pinned[1];
+  if (bad_pos != ~0ull) {
     uint64_t raw = 0;
     AH_HIP(c, hipMemcpy(&raw, (const uint8_t*)idx + bad_pos * (uint64_t)idx_byte_width, (size_t)idx_byte_width, hipMemcpyDeviceToHost));
     int64_t val;

@@ -290,6 +290,13 @@ class Context:
         nfirst = (C.c_int * k)(*[int(x[5]) for x in keys])
         check(self.handle, lib.ah_sort_indices_multi(self.handle, k, types, vals, valids, offs, n, desc, nfirst, _ptr(out_indices)))
 
+    def take_boolean(self, data, vvalid, voff: int, nvalues: int, idx_byte_width: int, idx_signed: bool, idx, ivalid, ioff: int, nidx: int,
+                     out_data, out_valid) -> int:
+        r, bad = C.c_int64(), C.c_int64()
+        check(self.handle, lib.ah_take_boolean(self.handle, _ptr(data), _ptr(vvalid), voff, nvalues, idx_byte_width, int(idx_signed), _ptr(idx),
+                                               _ptr(ivalid), ioff, nidx, 1, _ptr(out_data), _ptr(out_valid), C.byref(r), C.byref(bad)))
+        return r.value
+
     # ---- var-length take ------------------------------------------------------------------
     def take_binary_offsets(self, offset_width: int, offsets, vvalid, voff: int, nvalues: int, idx_byte_width: int, idx_signed: bool,
                             idx, ivalid, ioff: int, nidx: int, out_offsets, out_valid):

@@ -339,6 +339,55 @@ static Status ExecFilterBinary(KernelCtx* k, const ExecSpan& b, ExecResult* out)
   return TakeBinaryCommon(k, values, 4, false, ib->dptr, idx_nulls ? (const uint8_t*)ivb->dptr : nullptr, 0, n_out, allocate_validity, out);
 }
 
+// booleanTakeImpl (vector_selection.go:990-1074) and, for filter, GetTakeIndices in front of it
+static Status TakeBooleanCommon(KernelCtx* k, const ArraySpan& values, int idx_width, bool idx_signed, const void* idx, const uint8_t* ivalid,
+                                int64_t ioff, int64_t n, bool allocate_validity, ExecResult* out) {
+  Session* s = k->session;
+  out->len = n;
+  BufferPtr vb, db;
+  if (allocate_validity) { AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &vb)); out->buffers[0].WrapBuffer(vb); }
+  AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &db));
+  out->buffers[1].WrapBuffer(db);
+  int64_t nulls = 0, bad = 0;
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_take_boolean(s->ctx(), values.buffers[1].buf, values.MayHaveNulls() ? values.buffers[0].buf : nullptr, values.offset,
+                                                  values.len, idx_width, idx_signed, idx, ivalid, ioff, n, 1, (uint8_t*)db->dptr,
+                                                  allocate_validity ? (uint8_t*)vb->dptr : nullptr, &nulls, &bad)));
+  out->nulls = allocate_validity ? nulls : 0;
+  return Status::OK();
+}
+
+static Status ExecTakeBoolean(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  ArraySpan values = b.values[0].array, indices = b.values[1].array;
+  AHC_RETURN_NOT_OK(values.UpdateNullCount(k->session));
+  AHC_RETURN_NOT_OK(indices.UpdateNullCount(k->session));
+  return TakeBooleanCommon(k, values, indices.type->bit_width / 8, IsSignedInteger(indices.type->id), Values(indices),
+                           indices.MayHaveNulls() ? indices.buffers[0].buf : nullptr, indices.offset, indices.len,
+                           values.nulls != 0 || indices.nulls != 0, out);
+}
+
+static Status ExecFilterBoolean(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  ArraySpan values = b.values[0].array, filter = b.values[1].array;
+  const FilterOptions* opts = static_cast<const FilterOptions*>(k->state);
+  int null_sel = opts ? (int)opts->NullSelection : DropNulls;
+  AHC_RETURN_NOT_OK(values.UpdateNullCount(s));
+  AHC_RETURN_NOT_OK(filter.UpdateNullCount(s));
+  if (values.len >= ((int64_t)1 << 32)) return Status::Make(StatusCode::NotImplemented, "filter of a boolean column with 2^32 rows or more");
+  const uint8_t* fvalid = filter.MayHaveNulls() ? filter.buffers[0].buf : nullptr;
+  int64_t n_out = 0;
+  if (values.len > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_count(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, filter.len, null_sel, &n_out)));
+  BufferPtr ib, ivb;
+  AHC_RETURN_NOT_OK(k->Allocate(n_out * 4, &ib));
+  AHC_RETURN_NOT_OK(k->AllocateBitmap(n_out, &ivb));
+  int64_t idx_nulls = 0;
+  if (n_out > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_to_indices(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, values.len, null_sel, n_out,
+                                                         (uint32_t*)ib->dptr, (uint8_t*)ivb->dptr, &idx_nulls)));
+  return TakeBooleanCommon(k, values, 4, false, ib->dptr, idx_nulls ? (const uint8_t*)ivb->dptr : nullptr, 0, n_out,
+                           values.nulls != 0 || filter.nulls != 0, out);
+}
+
 static const Type kBinaryTypes[] = {Type::STRING, Type::BINARY, Type::LARGE_STRING, Type::LARGE_BINARY};
 
 static const FilterOptions kDefaultFilterOptions;
@@ -359,6 +408,12 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
     k.exec_fn = ExecFilterBinary;
     af->AddKernel(std::move(k));
   }
+  {
+    exec::VectorKernel k;
+    k.sig.in_types = {Type::BOOL, Type::BOOL};
+    k.exec_fn = ExecFilterBoolean;
+    af->AddKernel(std::move(k));
+  }
   reg->AddFunction(af, false);
   auto at = std::make_shared<VectorFunction>("array_take", Arity{2, false}, &kDefaultTakeOptions);
   for (Type t : kNumericTypes)
@@ -369,6 +424,13 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
       k.can_execute_chunkwise = false;  // selection.go:639
       at->AddKernel(std::move(k));
     }
+  for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
+    exec::VectorKernel k;
+    k.sig.in_types = {Type::BOOL, it};
+    k.exec_fn = ExecTakeBoolean;
+    k.can_execute_chunkwise = false;
+    at->AddKernel(std::move(k));
+  }
   for (Type t : kBinaryTypes)
     for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
       exec::VectorKernel k;

@@ -344,6 +344,14 @@ int ah_sort_indices(ah_ctx* ctx, int type, const void* values, const uint8_t* va
 int ah_sort_indices_multi(ah_ctx* ctx, int nkeys, const int* types, const void* const* values, const uint8_t* const* valids,
                           const int64_t* offs, int64_t n, const int* descending, const int* nulls_at_start, uint64_t* out_indices);
 
+/* Boolean VALUES (booleanTakeImpl, kernels/vector_selection.go:990-1074): data and validity are bitmaps
+ * indexed at voff + idx; a null output keeps data bit 0.  Output bitmaps start at bit 0.  Filter of a
+ * boolean column = ah_filter_to_indices + this (the reference's own boolFilterWriter never advances its
+ * output position, :433-436 — SURVEY.md quirk 8 — and is not replicated). */
+int ah_take_boolean(ah_ctx* ctx, const uint8_t* data, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int idx_byte_width,
+                    int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check,
+                    uint8_t* out_data, uint8_t* out_valid, int64_t* out_null_count_host, int64_t* bad_index_host);
+
 /* ---- var-length Take / Filter (row §8(f)-4) ------------------------------------------------------
  * replaces VarBinaryImpl (kernels/vector_selection.go:1925-1992) under takeExec / filterExec
  * (:1460-1598, 1821-1923) for Binary / String (offset_width 4) and LargeBinary / LargeString (8).

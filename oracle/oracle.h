@@ -94,6 +94,9 @@ int orc_take_primitive(int byte_width, const void* values, const uint8_t* vvalid
                        int idx_byte_width, int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff,
                        int64_t nidx, int bounds_check, void* out_values, uint8_t* out_valid,
                        int64_t* out_null_count, int64_t* bad_index);
+int orc_take_boolean(const uint8_t* data, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int idx_byte_width, int idx_signed,
+                     const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check, uint8_t* out_data,
+                     uint8_t* out_valid, int64_t* out_null_count, int64_t* bad_index);
 int orc_filter_to_indices(const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
                           uint32_t* out_idx, uint8_t* out_valid, int64_t* out_len, int64_t* out_null_count);
 

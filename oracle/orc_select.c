@@ -135,3 +135,34 @@ int orc_filter_to_indices(const uint8_t* fdata, const uint8_t* fvalid, int64_t f
   if (out_null_count) *out_null_count = nulls;
   return ORC_OK;
 }
+
+/*
+ * booleanTakeImpl (vector_selection.go:990-1074): out data bit i = value bit at voff + idx[i]; a null
+ * output (null index or null value) keeps data bit 0 and validity bit 0; bounds as checkIndexBounds.
+ */
+int orc_take_boolean(const uint8_t* data, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int idx_byte_width, int idx_signed,
+                     const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check, uint8_t* out_data,
+                     uint8_t* out_valid, int64_t* out_null_count, int64_t* bad_index) {
+  int64_t s = 0; uint64_t u = 0;
+  if (bounds_check) {
+    for (int64_t i = 0; i < nidx; i++) {
+      if (!bget_opt(ivalid, ioff + i)) continue;
+      load_index(idx, idx_byte_width, idx_signed, i, &s, &u);
+      int oob = idx_signed ? (s < 0 || (uint64_t)s >= (uint64_t)nvalues) : (u >= (uint64_t)nvalues);
+      if (oob) { if (bad_index) *bad_index = idx_signed ? s : (int64_t)u; return ORC_EINDEX; }
+    }
+  }
+  if (nidx < 0) return ORC_EINVALID;
+  memset(out_data, 0, (size_t)((nidx + 7) / 8));
+  if (out_valid) memset(out_valid, 0, (size_t)((nidx + 7) / 8));
+  int64_t nulls = 0;
+  for (int64_t i = 0; i < nidx; i++) {
+    if (!bget_opt(ivalid, ioff + i)) { nulls++; continue; }
+    load_index(idx, idx_byte_width, idx_signed, i, &s, &u);
+    if (!bget_opt(vvalid, voff + (int64_t)u)) { nulls++; continue; }
+    if ((data[(voff + (int64_t)u) >> 3] >> ((voff + (int64_t)u) & 7)) & 1) bset(out_data, i);
+    if (out_valid) bset(out_valid, i);
+  }
+  if (out_null_count) *out_null_count = nulls;
+  return ORC_OK;
+}

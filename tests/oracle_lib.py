@@ -75,6 +75,7 @@ class Oracle:
             "orc_sort_indices_multi": (it, [it, vp, vp, vp, vp, i64, vp, vp, vp]),
             "orc_take_binary": (it, [it, vp, vp, vp, i64, i64, it, it, vp, vp, i64, i64, it, vp, vp, vp, vp, vp, vp]),
             "orc_filter_binary": (it, [it, vp, vp, vp, i64, vp, vp, i64, i64, it, vp, vp, vp, vp, vp, vp]),
+            "orc_take_boolean": (it, [vp, vp, i64, i64, it, it, vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
@@ -260,6 +261,15 @@ class Oracle:
         st = self.lib.orc_sort_indices_multi(k, types, vals, valids, offs, n, desc, nfirst, _p(out))
         assert st == 0, st
         return out[:n]
+
+    def take_boolean(self, data, vvalid, voff, nvalues, idx, ivalid, ioff, want_valid):
+        idx = np.ascontiguousarray(idx)
+        n = idx.size
+        od = np.zeros((n + 7) // 8 + 1, np.uint8); ov = np.zeros((n + 7) // 8 + 1, np.uint8) if want_valid else None
+        nulls, bad = np.zeros(1, np.int64), np.zeros(1, np.int64)
+        st = self.lib.orc_take_boolean(_p(data), _p(vvalid), voff, nvalues, idx.dtype.itemsize, int(idx.dtype.kind == "i"), _p(idx), _p(ivalid),
+                                       ioff, n, 1, _p(od), _p(ov), _p(nulls), _p(bad))
+        return st, od[:(n + 7) // 8], (ov[:(n + 7) // 8] if want_valid else None), int(nulls[0]), int(bad[0])
 
     # ---- var-length take / filter -------------------------------------------------------
     def take_binary(self, offsets, data, vvalid, voff, nvalues, idx, ivalid, ioff, want_valid, bounds_check=True):

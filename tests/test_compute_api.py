@@ -36,7 +36,7 @@ def test_registry_has_the_path_functions():
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
-    assert ac.function_num_kernels("array_take") == 112     # (10 numeric + 4 binary-like value types) × 8 index types
+    assert ac.function_num_kernels("array_take") == 120     # (10 numeric + 4 binary-like + bool value types) × 8 index types
     assert ac.function_num_kernels("filter") == 0           # MetaFunction
     assert ac.function_num_kernels("cast_int64") == 10       # 9 other numeric types + bool
     assert ac.function_num_kernels("cumulative_sum") == 10 and ac.function_num_kernels("cumulative_sum_checked") == 10
@@ -651,6 +651,34 @@ def test_take_filter_binary(sess, typ):
     keys = pa.array(rng.integers(0, 100, len(a)), type=pa.int32())
     order = sess.call_function("sort_indices", [keys], "order=ascending")
     assert sess.call_function("take", [a, order]).equals(pc.take(a, pc.array_sort_indices(keys)))
+
+
+# ---- boolean-valued take / filter (vector_selection_test.go:369-377, TestTakeBoolean) ------------------------
+@pytest.mark.gpu
+def test_take_filter_boolean(sess):
+    from arrow_go_amd import compute as ac
+    B = lambda v: pa.array(v, type=pa.bool_())
+    filt = lambda v, f, o="": sess.call_function("filter", [B(v), B(f)], o).to_pylist()
+    assert filt([], []) == []
+    assert filt([True, False, True], [False, True, False]) == [False]
+    assert filt([None, False, True], [False, True, False]) == [False]
+    assert filt([True, False, True], [None, True, False], "null_selection_behavior=emit_null") == [None, False]
+    take = lambda v, i, it=pa.int32(): sess.call_function("take", [B(v), pa.array(i, type=it)]).to_pylist()
+    assert take([True, False, True], [0, 1, 0]) == [True, False, True]
+    assert take([None, False, True], [0, 1, 0]) == [None, False, None]
+    assert take([True, False, True], [None, 1, 0]) == [None, False, True]
+    with pytest.raises(ac.ErrIndex, match="out of bounds"):
+        take([True, False, True], [0, 9, 0])
+    # the case the reference's own boolean filter gets wrong (boolFilterWriter never advances):
+    # several individually selected values in a mixed block — here it is simply right, and equals Arrow C++
+    rng = np.random.default_rng(8)
+    n = 70001
+    v = pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1).slice(5)
+    m = pa.array(rng.random(n - 5) < 0.3, mask=rng.random(n - 5) < 0.1)
+    assert sess.call_function("filter", [v, m]).equals(pc.filter(v, m))
+    assert sess.call_function("filter", [v, m], "null_selection_behavior=emit_null").equals(pc.filter(v, m, null_selection_behavior="emit_null"))
+    idx = pa.array(rng.integers(0, len(v), 50000), mask=rng.random(50000) < 0.05, type=pa.uint32())
+    assert sess.call_function("take", [v, idx]).equals(pc.take(v, idx))
 
 
 # ---- arrow/math + fused -------------------------------------------------------------------------------------

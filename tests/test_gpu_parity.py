@@ -693,6 +693,24 @@ def test_sort_indices_multi_key(hip, orc_be):
             assert g.tobytes() == e.tobytes(), (n, trial, [(c[0].dtype, c[3], c[4]) for c in cols])
 
 
+def test_take_boolean_bit_exact(ctx, orc):
+    rng = np.random.default_rng(9200)
+    for nvals in (1, 70, 5000):
+        voff = int(rng.integers(0, 20))
+        data = OL.pack_bits(list(rng.random(nvals + voff) < 0.5)); vvalid = OL.pack_bits(list(rng.random(nvals + voff) >= 0.2))
+        db = ctx.to_device(np.concatenate([data, np.zeros(8, np.uint8)])); vb = ctx.to_device(np.concatenate([vvalid, np.zeros(8, np.uint8)]))
+        for n, idt in ((1, np.int8), (64, np.uint8), (1000, np.int16), (70001, np.int32), (999, np.uint64)):
+            idx = rng.integers(0, min(nvals, np.iinfo(idt).max + 1), n).astype(idt)
+            ivalid = OL.pack_bits(list(rng.random(n) >= 0.1))
+            ib = ctx.to_device(idx); ivb = ctx.to_device(np.concatenate([ivalid, np.zeros(8, np.uint8)]))
+            od = ctx.alloc((n + 7) // 8 + 64); ov = ctx.alloc((n + 7) // 8 + 64)
+            nulls = ctx.take_boolean(db, vb, voff, nvals, idx.dtype.itemsize, idx.dtype.kind == "i", ib, ivb, 0, n, od, ov)
+            st, ed, ev, en, _ = orc.take_boolean(data, vvalid, voff, nvals, idx, ivalid, 0, True)
+            nb = (n + 7) // 8
+            assert st == 0 and nulls == en
+            assert od.download(np.uint8, nb).tobytes() == ed.tobytes() and ov.download(np.uint8, nb).tobytes() == ev.tobytes(), (nvals, n, idt)
+
+
 # ---- var-length take / filter -----------------------------------------------------------------
 def random_binary(rng, n, odt, mean_len, p_null):
     lens = rng.geometric(1.0 / (mean_len + 1), n) - 1
