@@ -30,6 +30,10 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kItems = 8;                       // rounds of 64 rows per wave per tile
 constexpr int kTile = kBlock * kItems;          // 2048 rows
 constexpr int kRadix = 256;
+constexpr int kMaxTilesPerBlock = 8;             // tiles one workgroup handles = granularity of the histogram / scan
+
+// small inputs keep one tile per workgroup (parallelism), large ones eight (fewer histogram rows)
+static inline int tiles_per_block(int64_t n) { return n >= ((int64_t)1 << 24) ? kMaxTilesPerBlock : 1; }
 
 enum { kCatRest = 0, kCatNaN = 1, kCatNull = 2 };
 
@@ -85,22 +89,26 @@ struct Pairs {
   }
 };
 
-// tile histogram → hist[digit * ntiles + tile]
+// block histogram → hist[digit * nblocks + block]; a block = 1 or 8 consecutive tiles handled by one
+// workgroup (one histogram row per 16 Ki rows: 8× fewer scattered 4-byte writes and an 8× smaller scan)
 template <typename SRC>
-__global__ __launch_bounds__(kBlock) void hist_kernel(SRC src, int64_t n, unsigned* __restrict__ hist, int64_t ntiles) {
+__global__ __launch_bounds__(kBlock) void hist_kernel(SRC src, int64_t n, unsigned* __restrict__ hist, int64_t nblocks, int tpb) {
   __shared__ unsigned s_h[kWaves][kRadix];
   for (int i = threadIdx.x; i < kWaves * kRadix; i += kBlock) (&s_h[0][0])[i] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t tile = blockIdx.x;
-  const int64_t wbase = tile * kTile + (int64_t)wave * (kItems * 64);
+  const int64_t block = blockIdx.x;
+  for (int t = 0; t < tpb; t++) {
+    const int64_t wbase = (block * tpb + t) * kTile + (int64_t)wave * (kItems * 64);
+    if (wbase >= n) break;
 #pragma unroll
-  for (int r = 0; r < kItems; r++) {
-    const int64_t i = wbase + r * 64 + lane;
-    if (i < n) {
-      unsigned long long key; unsigned row, digit;
-      src.load(i, &key, &row, &digit);
-      atomicAdd(&s_h[wave][digit], 1u);
+    for (int r = 0; r < kItems; r++) {
+      const int64_t i = wbase + r * 64 + lane;
+      if (i < n) {
+        unsigned long long key; unsigned row, digit;
+        src.load(i, &key, &row, &digit);
+        atomicAdd(&s_h[wave][digit], 1u);
+      }
     }
   }
   __syncthreads();
@@ -108,20 +116,29 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(SRC src, int64_t n, unsign
     unsigned t = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; w++) t += s_h[w][d];
-    hist[(int64_t)d * ntiles + tile] = t;
+    hist[(int64_t)d * nblocks + block] = t;
   }
 }
 
 // stable scatter: offs = INCLUSIVE scan of hist (digit-major)
 template <typename SRC>
-__global__ __launch_bounds__(kBlock) void scatter_kernel(SRC src, int64_t n, const unsigned* __restrict__ offs, int64_t ntiles,
-                                                          unsigned long long* __restrict__ out_keys, unsigned* __restrict__ out_rows) {
+__global__ __launch_bounds__(kBlock) void scatter_kernel(SRC src, int64_t n, const unsigned* __restrict__ hist, const unsigned* __restrict__ offs,
+                                                          int64_t nblocks, int tpb, unsigned long long* __restrict__ out_keys,
+                                                          unsigned* __restrict__ out_rows) {
   __shared__ unsigned s_cnt[kWaves][kRadix];   // per wave: rows of each digit seen in earlier rounds; later: wave bases
-  __shared__ unsigned s_base[kRadix];          // global position of the tile's first row of each digit
+  __shared__ unsigned s_start[kRadix], s_goff[kRadix], s_wsum[kWaves];
+  __shared__ unsigned long long s_keys[kTile];
+  __shared__ unsigned s_rows[kTile];
+  __shared__ uint8_t s_dig[kTile];
+  static_assert(kBlock == kRadix, "one thread per digit in the prefix step");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // thread d carries the global position of the block's next row of digit d (inclusive scan − own count)
+  unsigned run_d = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x] - hist[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+  for (int tb = 0; tb < tpb; tb++) {
+  const int64_t tile = (int64_t)blockIdx.x * tpb + tb;
+  if (tile * kTile >= n) break;  // workgroup-uniform
   for (int i = threadIdx.x; i < kWaves * kRadix; i += kBlock) (&s_cnt[0][0])[i] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t tile = blockIdx.x;
   const int64_t wbase = tile * kTile + (int64_t)wave * (kItems * 64);
   unsigned long long key[kItems];
   unsigned row[kItems], digit[kItems], rank[kItems];
@@ -158,26 +175,54 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SRC src, int64_t n, con
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  // per digit: exclusive prefix over the waves, and the tile's global base
-  for (int d = threadIdx.x; d < kRadix; d += kBlock) {
-    unsigned run = 0;
+  // per digit: exclusive prefix over the waves, the digit's start inside the tile (exclusive scan over
+  // the 256 digit totals), and the offset that turns a tile-local sorted position into the global one
+  unsigned tot = 0;  // thread d < 256 owns digit d (kBlock == kRadix)
+  {
+    const int d = threadIdx.x;
 #pragma unroll
     for (int w = 0; w < kWaves; w++) {
       const unsigned t = s_cnt[w][d];
-      s_cnt[w][d] = run;
-      run += t;
+      s_cnt[w][d] = tot;
+      tot += t;
     }
-    s_base[d] = offs[(int64_t)d * ntiles + tile] - run;  // inclusive scan − own count
+    unsigned inc = tot;  // inclusive scan of the digit totals: shuffles inside a wave, LDS across waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned wbase = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) if (w < wave) wbase += s_wsum[w];
+    const unsigned start = wbase + inc - tot;                       // first tile-local position of digit d
+    s_start[d] = start;
+    s_goff[d] = run_d - start;     // global = s_goff[d] + local
+    run_d += tot;
   }
   __syncthreads();
+  // stage the tile in digit order in LDS …
 #pragma unroll
   for (int r = 0; r < kItems; r++) {
     if (live[r]) {
-      const unsigned pos = s_base[digit[r]] + s_cnt[wave][digit[r]] + rank[r];
-      out_keys[pos] = key[r];
-      out_rows[pos] = row[r];
+      const unsigned lp = s_start[digit[r]] + s_cnt[wave][digit[r]] + rank[r];
+      s_keys[lp] = key[r];
+      s_rows[lp] = row[r];
+      s_dig[lp] = (uint8_t)digit[r];
     }
   }
+  __syncthreads();
+  // … and write it out: consecutive threads hold consecutive positions of the same digit run, so the
+  // stores to HBM are runs of neighbouring addresses instead of one 8-byte store per bucket
+  const int64_t tile_n = n - tile * kTile >= kTile ? kTile : n - tile * kTile;
+  for (int lp = threadIdx.x; lp < tile_n; lp += kBlock) {
+    const unsigned pos = s_goff[s_dig[lp]] + (unsigned)lp;
+    out_keys[pos] = s_keys[lp];
+    out_rows[pos] = s_rows[lp];
+  }
+  }  // tiles of this block
 }
 
 // which key bits vary at all: res[0] = AND of all keys, res[1] = OR
@@ -219,12 +264,13 @@ struct Temp {  // temporaries of one call (the context's scratch arena is used b
 
 template <typename SRC>
 int radix_pass(ah_ctx* c, SRC src, int64_t n, unsigned* hist, unsigned* offs, unsigned long long* out_keys, unsigned* out_rows) {
-  const int64_t ntiles = ah_ceil_div(n, kTile);
-  hist_kernel<SRC><<<(unsigned)ntiles, kBlock, 0, c->stream>>>(src, n, hist, ntiles);
+  const int tpb = tiles_per_block(n);
+  const int64_t nblocks = ah_ceil_div(n, (int64_t)kTile * tpb);
+  hist_kernel<SRC><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(src, n, hist, nblocks, tpb);
   AH_LAUNCH_CHECK(c);
-  int rc = ah_cumulative_sum(c, AH_UINT32, hist, nullptr, 0, (int64_t)kRadix * ntiles, nullptr, 0, 0, offs, nullptr, nullptr);
+  int rc = ah_cumulative_sum(c, AH_UINT32, hist, nullptr, 0, (int64_t)kRadix * nblocks, nullptr, 0, 0, offs, nullptr, nullptr);
   if (rc != AH_OK) return rc;
-  scatter_kernel<SRC><<<(unsigned)ntiles, kBlock, 0, c->stream>>>(src, n, offs, ntiles, out_keys, out_rows);
+  scatter_kernel<SRC><<<(unsigned)nblocks, kBlock, 0, c->stream>>>(src, n, hist, offs, nblocks, tpb, out_keys, out_rows);
   AH_LAUNCH_CHECK(c);
   return AH_OK;
 }
@@ -240,7 +286,7 @@ struct SortBuffers {  // temporaries shared by all keys of one call
 template <typename T>
 int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t* valid, int64_t off, int64_t n, int descending,
                    int nulls_at_start, const unsigned* rows_in) {
-  const int64_t ntiles = ah_ceil_div(n, kTile);
+  const int64_t ntiles = ah_ceil_div(n, (int64_t)kTile * tiles_per_block(n));  // histogram rows ("blocks")
   int rc;
   // (1) partition by category, keys and row numbers come into being
   Column<T> col{(const T*)values, valid, off, descending, nulls_at_start, rows_in};
