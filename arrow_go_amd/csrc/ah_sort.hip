@@ -89,6 +89,22 @@ struct Pairs {
   }
 };
 
+// group-by helper: (value bits, group id) pairs, digit = a byte of the group id
+struct IdVal {
+  const int32_t* ids;
+  const unsigned long long* vals;
+  const uint8_t* vvalid;
+  int64_t voff;
+  int shift;
+  __device__ __forceinline__ void load(int64_t i, unsigned long long* key, unsigned* row, unsigned* digit) const {
+    const unsigned g = (unsigned)ids[i];
+    const bool ok = ah_bit(vvalid, voff + i);
+    *key = ok ? vals[i] : 0ull;
+    *row = ok ? g : (g | 0x80000000u);
+    *digit = (g >> shift) & 255u;
+  }
+};
+
 // block histogram → hist[digit * nblocks + block]; a block = 1 or 8 consecutive tiles handled by one
 // workgroup (one histogram row per 16 Ki rows: 8× fewer scattered 4-byte writes and an 8× smaller scan)
 template <typename SRC>
@@ -367,6 +383,12 @@ int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values,
 }
 
 }  // namespace
+
+int ah_partition_by_group(ah_ctx* c, const int32_t* ids, const unsigned long long* vals, const uint8_t* vvalid, int64_t voff, int64_t n, int shift,
+                          unsigned* hist, unsigned* offs, unsigned long long* out_vals, unsigned* out_ids) {
+  IdVal src{ids, vals, vvalid, voff, shift};
+  return radix_pass(c, src, n, hist, offs, out_vals, out_ids);
+}
 
 static int check_column(ah_ctx* c, int type, const void* values) {
   const int w = ah_type_width(type);

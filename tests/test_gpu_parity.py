@@ -327,7 +327,7 @@ def test_hash_encode_table_growth(hip, orc_be):
 
 def test_hash_sum(hip, orc_be):
     rng = np.random.default_rng(71)
-    for n, card in [(1, 1), (1000, 3), (70001, 500), (300007, 100000)]:
+    for n, card in [(1, 1), (1000, 3), (70001, 500), (200001, 5000), (1 << 18, 9000), (300007, 100000)]:  # LDS · partitioned (4 Ki < groups ≤ 1 Mi) paths
         keys = rng.integers(0, card, n).astype(np.int64) * 1000003
         kvalid, vvalid = rand_bits(rng, n + 8, 0.95), rand_bits(rng, n + 8, 0.9)
         iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
