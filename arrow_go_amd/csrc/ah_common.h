@@ -78,11 +78,13 @@ static inline int ah_fail(ah_ctx* ctx, int code, const char* fmt, ...) {
 #define AH_LAUNCH_CHECK(ctx) AH_HIP((ctx), hipGetLastError())
 
 void ah_expr_cache_free(ah_ctx* ctx);  // ah_expr.hip
-// internal (ah_sort.hip): one stable 256-way radix partition of (value bits, group id) pairs by
-// (id >> shift) & 255, for the group-by of ah_hash.hip.  A row whose value is null (vvalid bit clear)
-// travels with bit 31 of its id set.  hist / offs: 256 · ceil(n / 2048) unsigned each.
+// internal (ah_sort.hip): stable radix partition of (value bits, group id) pairs for the group-by of
+// ah_hash.hip — by (id >> shift) & 255 (passes = 1) or by (id >> shift) & 65535 (passes = 2, LSD; alt_*
+// is the intermediate buffer).  A row whose value is null (vvalid bit clear) travels with bit 31 of
+// its id set.  hist / offs: 256 · ceil(n / 2048) unsigned each.
 int ah_partition_by_group(ah_ctx* ctx, const int32_t* ids, const unsigned long long* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
-                          int shift, unsigned* hist, unsigned* offs, unsigned long long* out_vals, unsigned* out_ids);
+                          int shift, int passes, unsigned* hist, unsigned* offs, unsigned long long* alt_vals, unsigned* alt_ids,
+                          unsigned long long* out_vals, unsigned* out_ids);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // internal (ah_bitmap.hip): popcount of bits [off, off+nbits) into *total_dev (8 bytes,

@@ -54,46 +54,89 @@ __device__ __forceinline__ uint64_t hash_int(uint64_t v) {  // hash_funcs.go:60-
 // ≈ 0.82^256 ≈ 1e-22 per insert) → flag overflow; the host retries with a larger table.
 constexpr int kProbeLimit = 256;
 
+constexpr int kInsertRows = 4;  // independent rows per lane per step: their first probes are in flight together
+
+struct SlotView {  // one 16-byte load: the fields of a slot as they were at (about) the same time
+  unsigned long long key;
+  unsigned first_row;
+  unsigned id;
+};
+__device__ __forceinline__ SlotView load_slot(const Slot* p) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  return SlotView{((unsigned long long)v.y << 32) | v.x, v.z, v.w};
+}
+
 __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
                                                          int64_t off, int64_t lo, int64_t hi, int encode_nulls, Slot* __restrict__ table,
-                                                         uint64_t cap, unsigned* __restrict__ row_slot,
-                                                         unsigned long long* __restrict__ distinct, unsigned* __restrict__ overflow) {
+                                                         uint64_t cap, unsigned* __restrict__ row_slot, unsigned flag, unsigned direct_below,
+                                                         unsigned long long* __restrict__ distinct, unsigned* __restrict__ overflow,
+                                                         unsigned long long* __restrict__ misses) {
+  // direct_below > 0: the slots whose first_row lies below it have been ranked already (their id is final,
+  // see encode_core) — such a row gets its id right here, every other row a slot number with `flag` set.
   const uint64_t mask = cap - 1;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * kInsertRows;
+  unsigned nmiss = 0;
   unsigned fresh = 0;  // keys this lane inserted (published once, at the end: same-address atomics cost ~12 ns each)
-  for (int64_t i = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < hi; i += stride) {
-    uint64_t s;
-    if (ah_bit(valid, off + i)) {
-      unsigned long long k = keys[i];
-      if (k == kEmpty) {
-        s = cap;
-      } else {
-        uint64_t idx = hash_int(k) & mask;
-        int probes = 0;
-        bool dead = false;
-        for (;;) {
-          unsigned long long cur = table[idx].key;  // plain load: settled slots skip the CAS
-          if (cur != k && cur == kEmpty) {
-            cur = atomicCAS(&table[idx].key, kEmpty, k);
-            if (cur == kEmpty) { fresh++; cur = k; }
-          }
-          if (cur == k) break;
-          idx = (idx + 1) & mask;
-          if (++probes > kProbeLimit) { dead = true; break; }
-        }
-        if (dead) { atomicExch(overflow, 1u); break; }
-        s = idx;
+  for (int64_t base = lo + (int64_t)blockIdx.x * kBlock * kInsertRows + threadIdx.x; base < hi; base += stride) {
+    // kind: 0 = nothing to do, 1 = probe the table, 2 = dedicated slot (all-ones key / null), 3 = masked null
+    int kind[kInsertRows];
+    unsigned long long k[kInsertRows];
+    uint64_t idx[kInsertRows];
+    SlotView sv[kInsertRows];
+#pragma unroll
+    for (int u = 0; u < kInsertRows; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      kind[u] = 0;
+      k[u] = 0;
+      idx[u] = 0;
+      if (i < hi) {
+        if (ah_bit(valid, off + i)) {
+          k[u] = keys[i];
+          if (k[u] == kEmpty) { kind[u] = 2; idx[u] = cap; }
+          else { kind[u] = 1; idx[u] = hash_int(k[u]) & mask; }
+        } else if (encode_nulls) { kind[u] = 2; idx[u] = cap + 1; }
+        else kind[u] = 3;
       }
-    } else if (encode_nulls) {
-      s = cap + 1;
-    } else {
-      if (row_slot) row_slot[i] = kNoRow;
-      continue;
     }
-    if (table[s].first_row > (unsigned)i) atomicMin(&table[s].first_row, (unsigned)i);
-    if (row_slot) row_slot[i] = (unsigned)s;
+#pragma unroll
+    for (int u = 0; u < kInsertRows; u++)
+      if (kind[u] == 1 || kind[u] == 2) sv[u] = load_slot(&table[idx[u]]);
+#pragma unroll
+    for (int u = 0; u < kInsertRows; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (kind[u] == 0) continue;
+      if (kind[u] == 3) { if (row_slot) row_slot[i] = direct_below ? 0u : kNoRow; continue; }  // masked null → index 0, now or in emit_kernel
+      uint64_t s = idx[u];
+      unsigned fr = sv[u].first_row;  // may be stale — only ever LARGER than the truth, so the atomicMin below stays correct
+      unsigned id = sv[u].id;
+      if (kind[u] == 1) {
+        unsigned long long cur = sv[u].key;
+        int probes = 0;
+        for (;;) {
+          if (cur != k[u] && cur == kEmpty) {  // settled slots skip the CAS
+            cur = atomicCAS(&table[s].key, kEmpty, k[u]);
+            if (cur == kEmpty) { fresh++; cur = k[u]; }
+          }
+          if (cur == k[u]) break;
+          s = (s + 1) & mask;
+          if (++probes > kProbeLimit) { atomicExch(overflow, 1u); return; }
+          const SlotView nx = load_slot(&table[s]);
+          cur = nx.key;
+          fr = nx.first_row;
+          id = nx.id;
+        }
+      }
+      if (fr < direct_below) {  // seen in the ranked prefix: nothing to update (i ≥ direct_below > fr)
+        if (row_slot) row_slot[i] = id;
+        continue;
+      }
+      if (fr > (unsigned)i) atomicMin(&table[s].first_row, (unsigned)i);
+      if (row_slot) row_slot[i] = (unsigned)s | flag;  // flag: bit 31 when emit_kernel must tell slots from final ids
+      nmiss++;
+    }
   }
   if (fresh) atomicAdd(distinct, (unsigned long long)fresh);
+  if (direct_below && nmiss) atomicAdd(misses, (unsigned long long)nmiss);
 }
 
 __global__ __launch_bounds__(kBlock) void mark_kernel(const Slot* __restrict__ table, uint64_t nslots,
@@ -181,12 +224,129 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(Slot* __restrict__ table
   }
 }
 
-__global__ __launch_bounds__(kBlock) void emit_kernel(const Slot* __restrict__ table, int32_t* __restrict__ ids, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    unsigned s = (unsigned)ids[i];
-    ids[i] = s == kNoRow ? 0 : (int32_t)table[s].id;  // masked null → index 0 (vector_hash.go:169-172)
+// ids[i] holds what the insert pass left there: a slot number (→ that slot's id), kNoRow (masked null →
+// index 0, vector_hash.go:169-172), or — for rows ≥ direct_from, written by insert_small_kernel — either a
+// final id (kept) or a slot number flagged with bit 31.
+__global__ __launch_bounds__(kBlock) void emit_kernel(const Slot* __restrict__ table, int32_t* __restrict__ ids, int64_t n, int64_t direct_from) {
+  constexpr int U = 4;  // gathers in flight per lane
+  const int64_t stride = (int64_t)gridDim.x * kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < n; base += stride) {
+    unsigned s[U];
+    int32_t id[U];
+    bool put[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      s[u] = i < n ? (unsigned)ids[i] : kNoRow;
+      put[u] = i < n;
+      if (i >= direct_from && s[u] != kNoRow) {
+        if (s[u] & 0x80000000u) s[u] &= 0x7fffffffu; else put[u] = false;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) id[u] = s[u] == kNoRow ? 0 : (put[u] ? (int32_t)table[s[u]].id : 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (put[u]) ids[i] = id[u];
+    }
   }
+}
+
+// ---- low cardinality: the prefix's keys in LDS ---------------------------------------------------
+// When the 2^21-row prefix shows ≤ kSmallKeys distinct keys, their ids are already final (an id is the
+// number of first occurrences before the key's own, and all of those lie in the prefix too).  The
+// (key → id) pairs are copied into a kSmallSlots-entry open-addressing table that every workgroup of
+// the main pass keeps in LDS: a hit costs no global access beyond the key load and the id store, so the
+// pass runs at HBM speed instead of the L2 gather rate.  A miss (key not seen in the prefix) takes the
+// global-table path and leaves a flagged slot number for emit_kernel.
+constexpr int kSmallSlots = 8192;
+constexpr int kSmallKeys = 4096;
+constexpr int kSmallBlock = 1024;
+constexpr int kSmallRows = 8;
+
+__global__ __launch_bounds__(kBlock) void small_build_kernel(const Slot* __restrict__ table, uint64_t cap,
+                                                              unsigned long long* __restrict__ skeys, unsigned* __restrict__ sids) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += stride) {
+    if (table[s].first_row == kNoRow) continue;
+    const unsigned long long k = table[s].key;
+    unsigned j = (unsigned)hash_int(k) & (kSmallSlots - 1);
+    while (atomicCAS(&skeys[j], kEmpty, k) != kEmpty) j = (j + 1) & (kSmallSlots - 1);  // keys are distinct, ≤ half the entries
+    sids[j] = table[s].id;
+  }
+}
+
+__global__ __launch_bounds__(kSmallBlock) void insert_small_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+                                                                    int64_t off, int64_t lo, int64_t hi, int encode_nulls, Slot* __restrict__ table,
+                                                                    uint64_t cap, const unsigned long long* __restrict__ skeys,
+                                                                    const unsigned* __restrict__ sids, unsigned* __restrict__ out_ids,
+                                                                    unsigned long long* __restrict__ distinct, unsigned* __restrict__ overflow,
+                                                                    unsigned long long* __restrict__ misses) {
+  __shared__ unsigned long long l_keys[kSmallSlots];
+  __shared__ unsigned l_ids[kSmallSlots];
+  for (int j = threadIdx.x; j < kSmallSlots; j += kSmallBlock) { l_keys[j] = skeys[j]; l_ids[j] = sids[j]; }
+  __syncthreads();
+  // the two dedicated slots (all-ones key, null): final ids if the prefix saw them
+  const unsigned ones_id = table[cap].first_row != kNoRow ? table[cap].id : kNoRow;
+  const unsigned null_id = table[cap + 1].first_row != kNoRow ? table[cap + 1].id : kNoRow;
+  const uint64_t mask = cap - 1;
+  const int64_t stride = (int64_t)gridDim.x * kSmallBlock * kSmallRows;
+  unsigned fresh = 0, nmiss = 0;
+  for (int64_t base = lo + (int64_t)blockIdx.x * kSmallBlock * kSmallRows + threadIdx.x; base < hi; base += stride) {
+    unsigned long long k[kSmallRows];
+    bool ok[kSmallRows];
+#pragma unroll
+    for (int u = 0; u < kSmallRows; u++) {
+      const int64_t i = base + (int64_t)u * kSmallBlock;
+      ok[u] = i < hi && ah_bit(valid, off + i);
+      k[u] = ok[u] ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < kSmallRows; u++) {
+      const int64_t i = base + (int64_t)u * kSmallBlock;
+      if (i >= hi) break;
+      unsigned r = kNoRow;       // final id, or kNoRow = "take the global path with slot s"
+      uint64_t s = 0;
+      bool probe = false;
+      if (!ok[u]) {
+        if (!encode_nulls) r = 0;  // masked null → index 0
+        else { r = null_id; s = cap + 1; }
+      } else if (k[u] == kEmpty) {
+        r = ones_id; s = cap;
+      } else {
+        unsigned j = (unsigned)hash_int(k[u]) & (kSmallSlots - 1);
+        for (;;) {
+          const unsigned long long lk = l_keys[j];
+          if (lk == k[u]) { r = l_ids[j]; break; }
+          if (lk == kEmpty) { probe = true; break; }
+          j = (j + 1) & (kSmallSlots - 1);
+        }
+      }
+      if (r == kNoRow) {
+        if (probe) {
+          s = hash_int(k[u]) & mask;
+          int probes = 0;
+          for (;;) {
+            unsigned long long cur = table[s].key;
+            if (cur != k[u] && cur == kEmpty) {
+              cur = atomicCAS(&table[s].key, kEmpty, k[u]);
+              if (cur == kEmpty) { fresh++; cur = k[u]; }
+            }
+            if (cur == k[u]) break;
+            s = (s + 1) & mask;
+            if (++probes > kProbeLimit) { atomicExch(overflow, 1u); return; }
+          }
+        }
+        if (table[s].first_row > (unsigned)i) atomicMin(&table[s].first_row, (unsigned)i);
+        r = 0x80000000u | (unsigned)s;
+        nmiss++;
+      }
+      if (out_ids) __builtin_nontemporal_store(r, &out_ids[i]);
+    }
+  }
+  if (fresh) atomicAdd(distinct, (unsigned long long)fresh);
+  if (nmiss) atomicAdd(misses, (unsigned long long)nmiss);
 }
 
 // Per-group accumulation.  ids are dense and in first-seen order, so a low-cardinality
@@ -207,16 +367,28 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __rest
     for (int g = threadIdx.x; g < nl; g += kBlock) { s_sum[g] = (AT)0; s_cnt[g] = 0; }
     __syncthreads();
   }
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    if (!ah_bit(vvalid, voff + i)) continue;
-    int32_t g = ids[i];
-    if (USE_LDS && g < nl) {
-      atomicAdd(&s_sum[g], (AT)vals[i]);
-      atomicAdd(&s_cnt[g], 1u);
-    } else {
-      atomicAdd(&sums[g], (AT)vals[i]);
-      atomicAdd(&counts[g], 1ull);
+  constexpr int U = 8;  // rows per lane per step: 8 id loads + 8 value loads in flight (one row at a time is latency-bound)
+  const int64_t stride = (int64_t)gridDim.x * kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < n; base += stride) {
+    int32_t g[U];
+    VT v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      const bool ok = i < n && ah_bit(vvalid, voff + i);
+      g[u] = ok ? __builtin_nontemporal_load(&ids[i]) : -1;
+      v[u] = ok ? __builtin_nontemporal_load(&vals[i]) : (VT)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (g[u] < 0) continue;
+      if (USE_LDS && g[u] < nl) {
+        atomicAdd(&s_sum[g[u]], (AT)v[u]);
+        atomicAdd(&s_cnt[g[u]], 1u);
+      } else {
+        atomicAdd(&sums[g[u]], (AT)v[u]);
+        atomicAdd(&counts[g[u]], 1ull);
+      }
     }
   }
   if (USE_LDS) {
@@ -231,44 +403,78 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __rest
   }
 }
 
-// Mid cardinality (4 Ki < groups ≤ 1 Mi): LDS cannot hold all groups, and two global atomics per row run
-// at ≈ 25 G atomics/s device-wide (5.4 ms for 2^26 rows, whatever the number of copies of the sums —
-// measured).  So the (value, group id) pairs are first partitioned by id >> 12 — one stable 256-way radix
-// pass, ah_sort.hip's kernels — which makes the groups of any 64 Ki-row chunk fall into one or two
-// 4096-group windows; each workgroup then aggregates its chunk in LDS and flushes only the groups it
-// touched: ≈ 30× fewer global atomics.
-constexpr int kBucketShift = 12;                  // log2(kLdsGroups)
-constexpr int64_t kPartitionMaxGroups = 1 << 20;  // 256 buckets of 4096 groups
+// Above 4 Ki groups LDS cannot hold all groups, and two global atomics per row run at ≈ 25 G atomics/s
+// device-wide (5.4 ms for 2^26 rows, whatever the number of copies of the sums — measured).  So the
+// (value, group id) pairs are first partitioned by id >> 12 with ah_sort.hip's stable radix kernels — one
+// 256-way pass up to 1 Mi groups, two passes (65 536 windows) up to 256 Mi — which makes every 64 Ki-row
+// chunk a short sequence of runs, each inside one 4096-group window.  A workgroup walks the runs of its
+// chunk: aggregate the run in LDS, flush the groups it touched (consecutive addresses), next run.
+constexpr int kBucketShift = 12;                     // log2(kLdsGroups)
+constexpr int64_t kPartitionOnePass = 1 << 20;       // 256 windows of 4096 groups
+constexpr int64_t kPartitionMaxGroups = 1ll << 28;   // 65 536 windows
 constexpr int64_t kChunkRows = 1 << 16;
+constexpr int64_t kShortRun = 1024;                  // runs shorter than this go straight to global atomics
 
 template <typename AT>
 __global__ __launch_bounds__(kBlock) void bucket_sum_kernel(const unsigned long long* __restrict__ vals, const unsigned* __restrict__ ids, int64_t n,
                                                              AT* __restrict__ sums, unsigned long long* __restrict__ counts) {
   __shared__ AT s_sum[kLdsGroups];
   __shared__ unsigned s_cnt[kLdsGroups];
-  for (int g = threadIdx.x; g < kLdsGroups; g += kBlock) { s_sum[g] = (AT)0; s_cnt[g] = 0; }
-  __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * kChunkRows, hi = lo + kChunkRows < n ? lo + kChunkRows : n;
-  const unsigned bucket = (ids[lo] & 0x7fffffffu) >> kBucketShift;  // the window this chunk starts in
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
-    const unsigned id = ids[i];
-    if (id & 0x80000000u) continue;  // null value: neither summed nor counted
-    const AT v = __builtin_bit_cast(AT, vals[i]);
-    if ((id >> kBucketShift) == bucket) {
-      atomicAdd(&s_sum[id & (kLdsGroups - 1)], v);
-      atomicAdd(&s_cnt[id & (kLdsGroups - 1)], 1u);
-    } else {  // the chunk straddles a bucket boundary
-      atomicAdd(&sums[id], v);
-      atomicAdd(&counts[id], 1ull);
+  int64_t pos = lo;
+  while (pos < hi) {
+    const unsigned bucket = (ids[pos] & 0x7fffffffu) >> kBucketShift;
+    // end of this window's run inside the chunk (rows are ordered by window): 256-ary search, every
+    // thread probes one sample per round, the samples still inside the window form a prefix
+    int64_t a = pos, span = hi - pos;
+    while (span > 1) {
+      const int64_t step = (span + kBlock - 1) / kBlock;
+      const int64_t idx = a + (int64_t)threadIdx.x * step;
+      const bool inside = idx < a + span && ((ids[idx] & 0x7fffffffu) >> kBucketShift) == bucket;
+      const int cnt = __syncthreads_count(inside);  // ≥ 1: the sample of thread 0 is row a
+      const int64_t lim = a + span;
+      a += (int64_t)(cnt - 1) * step;
+      span = lim - a < step ? lim - a : step;
     }
-  }
-  __syncthreads();
-  for (int g = threadIdx.x; g < kLdsGroups; g += kBlock) {
-    const unsigned cnt = s_cnt[g];
-    if (cnt) {
-      atomicAdd(&sums[((size_t)bucket << kBucketShift) + g], s_sum[g]);
-      atomicAdd(&counts[((size_t)bucket << kBucketShift) + g], (unsigned long long)cnt);
+    const int64_t end = a + 1;
+    if (end - pos < kShortRun) {
+      for (int64_t i = pos + threadIdx.x; i < end; i += kBlock) {
+        const unsigned id = ids[i];
+        if (id & 0x80000000u) continue;  // null value: neither summed nor counted
+        atomicAdd(&sums[id], __builtin_bit_cast(AT, vals[i]));
+        atomicAdd(&counts[id], 1ull);
+      }
+    } else {
+      for (int g = threadIdx.x; g < kLdsGroups; g += kBlock) { s_sum[g] = (AT)0; s_cnt[g] = 0; }
+      __syncthreads();
+      constexpr int U = 4;
+      for (int64_t b0 = pos + threadIdx.x; b0 < end; b0 += (int64_t)kBlock * U) {
+        unsigned id[U];
+        unsigned long long v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int64_t i = b0 + (int64_t)u * kBlock;
+          id[u] = i < end ? __builtin_nontemporal_load(&ids[i]) : 0x80000000u;
+          v[u] = i < end ? __builtin_nontemporal_load(&vals[i]) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (id[u] & 0x80000000u) continue;  // null value (or past the run)
+          atomicAdd(&s_sum[id[u] & (kLdsGroups - 1)], __builtin_bit_cast(AT, v[u]));
+          atomicAdd(&s_cnt[id[u] & (kLdsGroups - 1)], 1u);
+        }
+      }
+      __syncthreads();
+      for (int g = threadIdx.x; g < kLdsGroups; g += kBlock) {
+        const unsigned cnt = s_cnt[g];
+        if (cnt) {
+          atomicAdd(&sums[((size_t)bucket << kBucketShift) + g], s_sum[g]);
+          atomicAdd(&counts[((size_t)bucket << kBucketShift) + g], (unsigned long long)cnt);
+        }
+      }
+      __syncthreads();
     }
+    pos = end;
   }
 }
 
@@ -276,6 +482,20 @@ static uint64_t next_pow2_u64(uint64_t x) {
   uint64_t p = 1;
   while (p < x) p <<= 1;
   return p;
+}
+
+// distinct keys expected among n rows when a prefix of p rows held d0 (uniform-urn model)
+static double estimate_distinct(double d0, double p, double n) {
+  const double r = d0 / p;
+  if (r >= 0.999) return n;  // (almost) every prefix row was new: cannot tell, assume one key per row
+  double lo = 1e-9, hi = 64.0;  // x = p / C;  g(x) = (1 − e^(−x)) / x falls from 1 to 0
+  for (int it = 0; it < 60; it++) {
+    const double mid = 0.5 * (lo + hi);
+    if ((1.0 - exp(-mid)) / mid > r) lo = mid; else hi = mid;
+  }
+  const double C = p / (0.5 * (lo + hi));
+  const double d = C * (1.0 - exp(-n / C));
+  return d < n ? d : n;
 }
 
 struct EncodeResult {
@@ -298,6 +518,10 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
   unsigned* overflow = (unsigned*)&c->dscalars[5];
   unsigned long long* total = (unsigned long long*)&c->dscalars[6];
   int* null_id = (int*)&c->dscalars[7];
+  unsigned long long* misses = (unsigned long long*)&c->dscalars[8];
+  // tunable, for measurements: 0 = plain (ids in a separate pass), 1 = direct ids, 2 (default) = direct ids + LDS table
+  static const int direct_path = getenv("ARROWHIP_HASH_DIRECT") ? atoi(getenv("ARROWHIP_HASH_DIRECT")) : 2;
+  bool resized = false;  // the table was re-planned: it is large and the prefix holds a minority of its keys
   for (;;) {
     // scratch: table | firsts | wordprefix | tilecnt | tileoff
     size_t table_bytes = (size_t)(cap + 2) * sizeof(Slot);
@@ -306,13 +530,16 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
     size_t tc_bytes = ((size_t)ntiles * 4 + 7) & ~(size_t)7;
     size_t to_bytes = (size_t)ntiles * 8;
     void* scratch;
-    int rc = ah_scratch_reserve(c, table_bytes + firsts_bytes + wp_bytes + tc_bytes + to_bytes + 64, &scratch);
+    const size_t small_bytes = (size_t)kSmallSlots * 12;
+    int rc = ah_scratch_reserve(c, table_bytes + firsts_bytes + wp_bytes + tc_bytes + to_bytes + small_bytes + 64, &scratch);
     if (rc != AH_OK) return rc;
     Slot* table = (Slot*)scratch;
     unsigned long long* firsts = (unsigned long long*)((uint8_t*)scratch + table_bytes);
     unsigned* wordprefix = (unsigned*)((uint8_t*)firsts + firsts_bytes);
     int* tilecnt = (int*)((uint8_t*)wordprefix + wp_bytes);
     int64_t* tileoff = (int64_t*)((uint8_t*)tilecnt + tc_bytes);
+    unsigned long long* skeys = (unsigned long long*)((uint8_t*)tileoff + to_bytes);
+    unsigned* sids = (unsigned*)(skeys + kSmallSlots);
 
     AH_HIP(c, hipMemsetAsync(table, 0xFF, table_bytes, c->stream));
     AH_HIP(c, hipMemsetAsync(&c->dscalars[4], 0, 3 * sizeof(uint64_t), c->stream));
@@ -322,51 +549,123 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
     // on into the same table; a prefix that already fills a quarter of the table means the
     // column needs a table sized from the extrapolated distinct count — restart with that.
     const int64_t prefix = n < ((int64_t)1 << 21) ? n : ((int64_t)1 << 21);
-    unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock));
-    unsigned pgrid = ah_stream_grid(c, ah_ceil_div(prefix, kBlock));
-    insert_kernel<<<pgrid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, 0, prefix, encode_nulls, table, cap,
-                                                   (unsigned*)out_ids, distinct, overflow);
-    AH_LAUNCH_CHECK(c);
-    bool restart = false;
+    unsigned grid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * kInsertRows));  // emit_kernel: 4 rows per lane as well
+    // staged: with every prefix row in flight at once against an empty table, a low-cardinality column turns
+    // into millions of CAS / atomicMin on a few addresses (200 µs for 1024 keys).  A few thousand rows first,
+    // then the rest mostly finds settled slots and issues no atomics at all.
+    {
+      int64_t lo = 0;
+      for (int64_t hi : {(int64_t)1 << 12, (int64_t)1 << 16, prefix}) {
+        if (hi > prefix) hi = prefix;
+        if (hi <= lo) continue;
+        unsigned g = ah_stream_grid(c, ah_ceil_div(hi - lo, (int64_t)kBlock * kInsertRows));
+        insert_kernel<<<g, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, lo, hi, encode_nulls, table, cap,
+                                                   (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
+        AH_LAUNCH_CHECK(c);
+        lo = hi;
+      }
+    }
+    bool restart = false, small = false, direct = false;
     if (prefix < n && cap < cap_max) {
       AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[4], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       AH_HIP(c, hipStreamSynchronize(c->stream));
       uint64_t d0 = *(volatile uint64_t*)&c->pinned[0];
       bool ovf = *(volatile unsigned*)&c->pinned[1] != 0;
       if (ovf || d0 > cap / 4) {
-        // extrapolate: a prefix that is mostly distinct says "about one key per row"
-        double est = d0 * 2 > (uint64_t)prefix ? (double)n : (double)d0 * ((double)n / (double)prefix);
-        uint64_t want = next_pow2_u64((uint64_t)(est * 2.5) + 64);
+        // extrapolate with the urn model (keys drawn uniformly from C values show d0 = C·(1 − e^(−p/C))
+        // distinct ones in a prefix of p rows): solve for C, predict the distinct count of all n rows,
+        // size for load ≤ ⅓.  A skewed column has more distinct keys than this predicts; the probe
+        // limit then trips and the insert is redone with 16× the slots (results never depend on it).
+        uint64_t want = next_pow2_u64((uint64_t)(estimate_distinct((double)d0, (double)prefix, (double)n) * 3.0) + 64);
         if (want < cap * 4) want = cap * 4;
         cap = want < cap_max ? want : cap_max;
         restart = true;
+        resized = true;
       }
+      direct = !restart && !ovf && !resized && direct_path;
+      small = direct && d0 <= (uint64_t)kSmallKeys && direct_path > 1;
     }
     if (restart) continue;
-    if (prefix < n) {
-      insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, prefix, n, encode_nulls, table, cap,
-                                                    (unsigned*)out_ids, distinct, overflow);
+    // first-seen ranks of the used slots over the first `rows` rows: table[].id, dict, first_rows, total, null_id
+    auto rank_slots = [&](int64_t rows) -> int {
+      const int64_t nw = ah_ceil_div(rows, 64), nt = ah_ceil_div(nw, 32);
+      AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nw * 8, c->stream));
+      mark_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(table, cap + 2, firsts);
       AH_LAUNCH_CHECK(c);
+      word_prefix_kernel<<<(unsigned)ah_ceil_div(nw, kBlock), kBlock, 0, c->stream>>>(firsts, nw, wordprefix, tilecnt);
+      AH_LAUNCH_CHECK(c);
+      scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nt, tileoff, total);
+      AH_LAUNCH_CHECK(c);
+      assign_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(
+          table, cap, firsts, wordprefix, tileoff, (unsigned long long*)out_dict, null_id, (long long*)out_first_rows);
+      AH_LAUNCH_CHECK(c);
+      return AH_OK;
+    };
+    // Rows after the prefix: the prefix's keys are ranked first (their ids are final: an id is the number
+    // of first occurrences before the key's own, all of which lie in the prefix too), so the main pass can
+    // write ids directly — out of LDS when the prefix has ≤ kSmallKeys keys, else out of the slot it probes
+    // anyway — and only rows with a key the prefix did not have ("misses") wait for emit_kernel.  Not done
+    // after a restart: that table is large (ranking scans it) and most of its keys are still to come.
+    int64_t direct_from = n;  // rows from here on hold final ids or flagged slot numbers
+    bool ranked = false;      // table[].id, dict, first_rows, total are final
+    if (direct) {
+      if ((rc = rank_slots(prefix)) != AH_OK) return rc;
+      AH_HIP(c, hipMemsetAsync(misses, 0, 8, c->stream));
+      direct_from = prefix;
+      int64_t lo = prefix;
+      if (small) {
+        AH_HIP(c, hipMemsetAsync(skeys, 0xFF, (size_t)kSmallSlots * 8, c->stream));
+        small_build_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap, kBlock)), kBlock, 0, c->stream>>>(table, cap, skeys, sids);
+        AH_LAUNCH_CHECK(c);
+        // a probe segment first: a column whose later rows keep bringing new keys (sorted keys, say)
+        // misses the LDS table all the time and is better served by the plain kernel
+        const int64_t probe_end = n - prefix > ((int64_t)1 << 23) ? prefix + ((int64_t)1 << 22) : n;
+        const unsigned sgrid = (unsigned)c->num_cu;
+        insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, prefix, probe_end, encode_nulls,
+                                                                  table, cap, skeys, sids, (unsigned*)out_ids, distinct, overflow, misses);
+        AH_LAUNCH_CHECK(c);
+        lo = probe_end;
+        if (probe_end < n) {
+          AH_HIP(c, hipMemcpyAsync(c->pinned, misses, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+          AH_HIP(c, hipStreamSynchronize(c->stream));
+          if (*(volatile uint64_t*)c->pinned * 8 < (uint64_t)(probe_end - prefix)) {
+            insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, probe_end, n, encode_nulls,
+                                                                      table, cap, skeys, sids, (unsigned*)out_ids, distinct, overflow, misses);
+            AH_LAUNCH_CHECK(c);
+            lo = n;
+          }
+        }
+      }
+      if (lo < n) {
+        insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, lo, n, encode_nulls, table, cap,
+                                                      (unsigned*)out_ids, 0x80000000u, (unsigned)prefix, distinct, overflow, misses);
+        AH_LAUNCH_CHECK(c);
+      }
+      AH_HIP(c, hipMemcpyAsync(c->pinned, misses, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      AH_HIP(c, hipMemcpyAsync(&c->pinned[1], overflow, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      AH_HIP(c, hipStreamSynchronize(c->stream));
+      ranked = *(volatile uint64_t*)&c->pinned[0] == 0 && *(volatile unsigned*)&c->pinned[1] == 0;
+      *(volatile uint64_t*)c->pinned = *(volatile uint64_t*)&c->pinned[1];  // overflow flag where the check below reads it
+    } else {
+      if (prefix < n) {
+        insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, prefix, n, encode_nulls, table, cap,
+                                                      (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
+        AH_LAUNCH_CHECK(c);
+      }
+      AH_HIP(c, hipMemcpyAsync(c->pinned, overflow, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      AH_HIP(c, hipStreamSynchronize(c->stream));
     }
-    AH_HIP(c, hipMemcpyAsync(c->pinned, overflow, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
     if (*(volatile unsigned*)c->pinned) {
       if (cap >= cap_max) return ah_fail(c, AH_EINVALID, "hash: table overflow at maximum capacity (internal error)");
       cap = cap * 16 < cap_max ? cap * 16 : cap_max;
+      resized = true;
       continue;
     }
-    AH_HIP(c, hipMemsetAsync(firsts, 0, firsts_bytes, c->stream));
-    mark_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(table, cap + 2, firsts);
-    AH_LAUNCH_CHECK(c);
-    word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
-    AH_LAUNCH_CHECK(c);
-    scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, ntiles, tileoff, total);
-    AH_LAUNCH_CHECK(c);
-    assign_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(
-        table, cap, firsts, wordprefix, tileoff, (unsigned long long*)out_dict, null_id, (long long*)out_first_rows);
-    AH_LAUNCH_CHECK(c);
+    if (!ranked && (rc = rank_slots(n)) != AH_OK) return rc;
     if (out_ids) {
-      emit_kernel<<<grid, kBlock, 0, c->stream>>>(table, out_ids, n);
+      // no miss: only the prefix rows still hold slot numbers
+      const int64_t rows = ranked ? prefix : n;
+      emit_kernel<<<ah_stream_grid(c, ah_ceil_div(rows, (int64_t)kBlock * 4)), kBlock, 0, c->stream>>>(table, out_ids, rows, direct_from);
       AH_LAUNCH_CHECK(c);
     }
     AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[6], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -399,20 +698,23 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
   if (rc == AH_OK) {
     static const int partition_path = getenv("ARROWHIP_HASH_PARTITION") ? atoi(getenv("ARROWHIP_HASH_PARTITION")) : 1;
     if (res.ndict <= kLdsGroups) {
-      unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock), /*default_bpc=*/2);
+      unsigned grid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), /*default_bpc=*/2);
       group_sum_kernel<VT, AT, true><<<grid, kBlock, 0, c->stream>>>(ids, vals, vvalid, voff, n, out_sums,
                                                                      (unsigned long long*)out_counts, (int)res.ndict);
     } else if (partition_path && res.ndict <= kPartitionMaxGroups && sizeof(VT) == 8) {
       void* tmp = nullptr;
+      const int passes = res.ndict <= kPartitionOnePass ? 1 : 2;
       const int64_t nb = ah_ceil_div(n, 2048);
       const size_t pv = (size_t)n * 8, pi = (((size_t)n * 4) + 255) & ~(size_t)255, ph = (size_t)256 * nb * 4;
-      if (hipMalloc(&tmp, pv + pi + 2 * ph) != hipSuccess) { (void)hipGetLastError(); rc = ah_fail(c, AH_EHIP, "hash_sum: out of device memory"); }
+      if (hipMalloc(&tmp, (size_t)passes * (pv + pi) + 2 * ph) != hipSuccess) { (void)hipGetLastError(); rc = ah_fail(c, AH_EHIP, "hash_sum: out of device memory"); }
       else {
         unsigned long long* pvals = (unsigned long long*)tmp;
         unsigned* pids = (unsigned*)((uint8_t*)tmp + pv);
         unsigned* hist = (unsigned*)((uint8_t*)tmp + pv + pi);
         unsigned* offs = (unsigned*)((uint8_t*)tmp + pv + pi + ph);
-        rc = ah_partition_by_group(c, ids, (const unsigned long long*)vals, vvalid, voff, n, kBucketShift, hist, offs, pvals, pids);
+        unsigned long long* avals = passes == 2 ? (unsigned long long*)((uint8_t*)tmp + pv + pi + 2 * ph) : nullptr;
+        unsigned* aids = passes == 2 ? (unsigned*)((uint8_t*)avals + pv) : nullptr;
+        rc = ah_partition_by_group(c, ids, (const unsigned long long*)vals, vvalid, voff, n, kBucketShift, passes, hist, offs, avals, aids, pvals, pids);
         if (rc == AH_OK) {
           bucket_sum_kernel<AT><<<(unsigned)ah_ceil_div(n, kChunkRows), kBlock, 0, c->stream>>>(pvals, pids, n, out_sums, (unsigned long long*)out_counts);
           if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
@@ -421,7 +723,7 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
         (void)hipFree(tmp);
       }
     } else {
-      unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock));
+      unsigned grid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8));
       group_sum_kernel<VT, AT, false><<<grid, kBlock, 0, c->stream>>>(ids, vals, vvalid, voff, n, out_sums,
                                                                       (unsigned long long*)out_counts, (int)(res.ndict > 0x7fffffff ? 0x7fffffff : res.ndict));
     }

@@ -105,6 +105,18 @@ struct IdVal {
   }
 };
 
+// second pass of the group-by partition: pairs already carry the null flag in bit 31 of the id
+struct ValId {
+  const unsigned long long* vals;
+  const unsigned* ids;
+  int shift;
+  __device__ __forceinline__ void load(int64_t i, unsigned long long* key, unsigned* row, unsigned* digit) const {
+    *key = vals[i];
+    *row = ids[i];
+    *digit = ((*row & 0x7fffffffu) >> shift) & 255u;
+  }
+};
+
 // block histogram → hist[digit * nblocks + block]; a block = 1 or 8 consecutive tiles handled by one
 // workgroup (one histogram row per 16 Ki rows: 8× fewer scattered 4-byte writes and an 8× smaller scan)
 template <typename SRC>
@@ -385,9 +397,14 @@ int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values,
 }  // namespace
 
 int ah_partition_by_group(ah_ctx* c, const int32_t* ids, const unsigned long long* vals, const uint8_t* vvalid, int64_t voff, int64_t n, int shift,
-                          unsigned* hist, unsigned* offs, unsigned long long* out_vals, unsigned* out_ids) {
+                          int passes, unsigned* hist, unsigned* offs, unsigned long long* alt_vals, unsigned* alt_ids,
+                          unsigned long long* out_vals, unsigned* out_ids) {
   IdVal src{ids, vals, vvalid, voff, shift};
-  return radix_pass(c, src, n, hist, offs, out_vals, out_ids);
+  if (passes == 1) return radix_pass(c, src, n, hist, offs, out_vals, out_ids);
+  int rc = radix_pass(c, src, n, hist, offs, alt_vals, alt_ids);
+  if (rc != AH_OK) return rc;
+  ValId src2{alt_vals, alt_ids, shift + 8};
+  return radix_pass(c, src2, n, hist, offs, out_vals, out_ids);
 }
 
 static int check_column(ah_ctx* c, int type, const void* values) {

@@ -325,9 +325,68 @@ def test_hash_encode_table_growth(hip, orc_be):
     assert g[2].tobytes() == keys.view(np.uint64).tobytes()
 
 
+def test_hash_encode_capacity_estimates(hip, orc_be):
+    # capacity planning extrapolates from a 2^21-row prefix; whatever it guesses, results are the oracle's
+    rng = np.random.default_rng(67)
+    n = (1 << 23) + 77
+    cases = {
+        "uniform 2^22": rng.integers(0, 1 << 22, n),
+        # the prefix looks low-cardinality-ish, the rest is all new keys: under-estimate → overflow → retry
+        "late burst": np.concatenate([rng.integers(0, 3 << 20, 1 << 22), (1 << 40) + np.arange(n - (1 << 22))]),
+        "half unique": np.where(rng.random(n) < 0.5, rng.integers(0, 1000, n), (1 << 40) + np.arange(n)),
+    }
+    for name, k in cases.items():
+        keys = (k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+        g, e = hip.hash_encode(keys, None, 0, False), orc_be.hash_encode(keys, None, 0, False)
+        assert g[0].tobytes() == e[0].tobytes(), name
+        assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3], name
+
+
+def test_hash_encode_low_cardinality_lds_path(hip, orc_be):
+    # more rows than the 2^21-row prefix and ≤ 4096 keys in it: the main pass looks keys up in LDS
+    rng = np.random.default_rng(68)
+    n = (1 << 22) + 1234
+    valid = rand_bits(rng, n + 16, 0.9)
+    for card in (1, 5, 1000, 4096, 5000):
+        pool = rng.integers(-2**63, 2**63, card, dtype=np.int64)
+        if card >= 5:
+            pool[3] = -1  # the all-ones key has its own slot
+        keys = pool[rng.integers(0, card, n)]
+        for off, v in [(0, None), (5, valid)]:
+            for enc in (True, False):
+                g, e = hip.hash_encode(keys, v, off, enc), orc_be.hash_encode(keys, v, off, enc)
+                assert g[0].tobytes() == e[0].tobytes(), (card, off, enc)
+                assert g[1].tobytes() == e[1].tobytes() and g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+    # keys, the all-ones key and nulls that first show up after the prefix: misses go to the global table
+    keys = pool[:100][rng.integers(0, 100, n)]
+    keys[3 << 20:] = rng.integers(0, 300, n - (3 << 20))
+    keys[(3 << 20) + 17] = -1
+    v = np.full((n + 7) // 8, 0xFF, np.uint8)
+    v[(3 << 20) // 8 + 100] = 0
+    for enc in (True, False):
+        g, e = hip.hash_encode(keys, v, 0, enc), orc_be.hash_encode(keys, v, 0, enc)
+        assert g[0].tobytes() == e[0].tobytes() and g[1].tobytes() == e[1].tobytes()
+        assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+    # sorted keys: the probe segment misses all the time → the rest goes through the plain kernel
+    n = (1 << 23) + (1 << 21) + 4321
+    keys = (np.arange(n, dtype=np.int64) // 700) * 1000003
+    g, e = hip.hash_encode(keys, None, 0, False), orc_be.hash_encode(keys, None, 0, False)
+    assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
+    # group-by on top of it
+    n = (1 << 22) + 99
+    keys = rng.integers(0, 777, n).astype(np.int64) * 1000003
+    iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+    vvalid = rand_bits(rng, n + 8, 0.9)
+    g, e = hip.hash_sum("i64", keys, None, 0, iv, vvalid, 5), orc_be.hash_sum("i64", keys, None, 0, iv, vvalid, 5)
+    for a, b in zip(g[:3], e[:3]):
+        assert a.tobytes() == b.tobytes()
+    assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes()
+
+
 def test_hash_sum(hip, orc_be):
     rng = np.random.default_rng(71)
-    for n, card in [(1, 1), (1000, 3), (70001, 500), (200001, 5000), (1 << 18, 9000), (300007, 100000)]:  # LDS · partitioned (4 Ki < groups ≤ 1 Mi) paths
+    for n, card in [(1, 1), (1000, 3), (70001, 500), (200001, 5000), (1 << 18, 9000), (300007, 100000),
+                    (2500003, 1 << 21), ((1 << 22) + 5, 1 << 24)]:  # LDS · one-pass partition (4 Ki < groups ≤ 1 Mi) · two-pass partition
         keys = rng.integers(0, card, n).astype(np.int64) * 1000003
         kvalid, vvalid = rand_bits(rng, n + 8, 0.95), rand_bits(rng, n + 8, 0.9)
         iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
