@@ -48,6 +48,76 @@ __device__ __forceinline__ uint64_t hash_int(uint64_t v) {  // hash_funcs.go:60-
   return __builtin_bswap64(11400714785074694791ull * v);
 }
 
+// ---- what a "key" is -------------------------------------------------------------------------------
+// The table machinery below (insert → rank → emit) only needs, per row: a 64-bit word to CAS into an empty
+// slot, a hash to start probing at, and "does this occupied slot hold my key".
+struct U64Keys {  // Table[uint64] (xxh3_memo_table_types.go): the word is the key itself
+  const unsigned long long* keys;
+  static constexpr bool kLdsTable = true;
+  // false → the all-ones key, which doubles as the EMPTY marker and lives in its own slot
+  __device__ __forceinline__ bool load(int64_t i, unsigned long long* word, uint64_t* h) const {
+    const unsigned long long k = keys[i];
+    *word = k;
+    *h = hash_int(k);
+    return k != kEmpty;
+  }
+  __device__ __forceinline__ bool same(unsigned long long cur, unsigned long long word, int64_t) const { return cur == word; }
+};
+
+struct U64u { unsigned long long v; } __attribute__((packed, aligned(1)));
+__device__ __forceinline__ unsigned long long load8(const uint8_t* p) { return reinterpret_cast<const U64u*>(p)->v; }
+__device__ __forceinline__ unsigned long long load_tail(const uint8_t* p, int nb) {  // 1..7 bytes, little-endian
+  unsigned long long w = 0;
+  for (int t = 0; t < nb; t++) w |= (unsigned long long)p[t] << (8 * t);
+  return w;
+}
+// Any 64-bit hash will do: ids and dictionary order depend only on which rows are EQUAL and on row order,
+// never on hash values (the reference's xxh3 / custom short-string hash, hash_funcs.go:86-124, decides
+// only where its own memo table stores an entry).  Multiply-xorshift over 8-byte words.
+__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int64_t len) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)len * 0xC2B2AE3D27D4EB4Full);
+  int64_t j = 0;
+  for (; j + 8 <= len; j += 8) {
+    h = (h ^ load8(p + j)) * 0xFF51AFD7ED558CCDull;
+    h ^= h >> 32;
+  }
+  if (j < len) {
+    h = (h ^ load_tail(p + j, (int)(len - j))) * 0xC4CEB9FE1A85EC53ull;
+    h ^= h >> 29;
+  }
+  h *= 0x9FB21C651E98DF25ull;
+  return h ^ (h >> 32);
+}
+__device__ __forceinline__ bool equal_bytes(const uint8_t* a, const uint8_t* b, int64_t len) {
+  int64_t j = 0;
+  for (; j + 8 <= len; j += 8)
+    if (load8(a + j) != load8(b + j)) return false;
+  return j == len || load_tail(a + j, (int)(len - j)) == load_tail(b + j, (int)(len - j));
+}
+
+// BinaryMemoTable (internal/hashing/xxh3_memo_table.go): the slot word is {hash bits 63..32 | a row that
+// holds the value}; a slot is "mine" when the tags agree and the bytes of that row equal mine.  Both
+// halves arrive in one CAS, so a reader never sees a tag without its row.
+template <typename OffT>
+struct BinKeys {
+  const OffT* offsets;  // of row 0 of the call (buffer + array offset)
+  const uint8_t* data;
+  static constexpr bool kLdsTable = false;
+  __device__ __forceinline__ bool load(int64_t i, unsigned long long* word, uint64_t* h) const {
+    const int64_t b = (int64_t)offsets[i], e = (int64_t)offsets[i + 1];
+    *h = hash_bytes(data + b, e - b);
+    *word = (*h & 0xFFFFFFFF00000000ull) | (unsigned long long)(unsigned)i;  // never all-ones: i < 2^32 − 1
+    return true;
+  }
+  __device__ __forceinline__ bool same(unsigned long long cur, unsigned long long word, int64_t i) const {
+    if ((cur ^ word) >> 32) return false;
+    const int64_t r = (int64_t)(unsigned)cur;
+    if (r == i) return true;
+    const int64_t b = (int64_t)offsets[i], e = (int64_t)offsets[i + 1], rb = (int64_t)offsets[r], re = (int64_t)offsets[r + 1];
+    return e - b == re - rb && equal_bytes(data + b, data + rb, e - b);
+  }
+};
+
 // status words in dscalars: [4] distinct count, [5] overflow flag, [6] total ids
 // Inserts rows [lo, hi).  Probe chains longer than kProbeLimit mean the table is far beyond
 // the load it was sized for (at load ≤ ½ the chance of a 256-long linear-probing cluster is
@@ -66,7 +136,8 @@ __device__ __forceinline__ SlotView load_slot(const Slot* p) {
   return SlotView{((unsigned long long)v.y << 32) | v.x, v.z, v.w};
 }
 
-__global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+template <typename K>
+__global__ __launch_bounds__(kBlock) void insert_kernel(const K keys, const uint8_t* __restrict__ valid,
                                                          int64_t off, int64_t lo, int64_t hi, int encode_nulls, Slot* __restrict__ table,
                                                          uint64_t cap, unsigned* __restrict__ row_slot, unsigned flag, unsigned direct_below,
                                                          unsigned long long* __restrict__ distinct, unsigned* __restrict__ overflow,
@@ -80,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long
   for (int64_t base = lo + (int64_t)blockIdx.x * kBlock * kInsertRows + threadIdx.x; base < hi; base += stride) {
     // kind: 0 = nothing to do, 1 = probe the table, 2 = dedicated slot (all-ones key / null), 3 = masked null
     int kind[kInsertRows];
-    unsigned long long k[kInsertRows];
+    unsigned long long k[kInsertRows];  // the word this row would CAS into an empty slot
     uint64_t idx[kInsertRows];
     SlotView sv[kInsertRows];
 #pragma unroll
@@ -91,9 +162,9 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long
       idx[u] = 0;
       if (i < hi) {
         if (ah_bit(valid, off + i)) {
-          k[u] = keys[i];
-          if (k[u] == kEmpty) { kind[u] = 2; idx[u] = cap; }
-          else { kind[u] = 1; idx[u] = hash_int(k[u]) & mask; }
+          uint64_t h;
+          if (!keys.load(i, &k[u], &h)) { kind[u] = 2; idx[u] = cap; }
+          else { kind[u] = 1; idx[u] = h & mask; }
         } else if (encode_nulls) { kind[u] = 2; idx[u] = cap + 1; }
         else kind[u] = 3;
       }
@@ -113,11 +184,11 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const unsigned long long
         unsigned long long cur = sv[u].key;
         int probes = 0;
         for (;;) {
-          if (cur != k[u] && cur == kEmpty) {  // settled slots skip the CAS
+          if (cur == kEmpty) {  // settled slots skip the CAS
             cur = atomicCAS(&table[s].key, kEmpty, k[u]);
-            if (cur == kEmpty) { fresh++; cur = k[u]; }
+            if (cur == kEmpty) { fresh++; break; }
           }
-          if (cur == k[u]) break;
+          if (keys.same(cur, k[u], i)) break;
           s = (s + 1) & mask;
           if (++probes > kProbeLimit) { atomicExch(overflow, 1u); return; }
           const SlotView nx = load_slot(&table[s]);
@@ -504,7 +575,8 @@ struct EncodeResult {
 };
 
 // core: ids (optional, n int32), dict (optional), returns sizes.  Device pointers.
-int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
+template <typename K>
+int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
                 int32_t* out_ids, uint64_t* out_dict, EncodeResult* res, int64_t* out_first_rows = nullptr) {
   res->ndict = 0;
   res->null_id = -1;
@@ -559,7 +631,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
         if (hi > prefix) hi = prefix;
         if (hi <= lo) continue;
         unsigned g = ah_stream_grid(c, ah_ceil_div(hi - lo, (int64_t)kBlock * kInsertRows));
-        insert_kernel<<<g, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, lo, hi, encode_nulls, table, cap,
+        insert_kernel<K><<<g, kBlock, 0, c->stream>>>(keys, valid, off, lo, hi, encode_nulls, table, cap,
                                                    (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
         lo = hi;
@@ -583,7 +655,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
         resized = true;
       }
       direct = !restart && !ovf && !resized && direct_path;
-      small = direct && d0 <= (uint64_t)kSmallKeys && direct_path > 1;
+      small = K::kLdsTable && direct && d0 <= (uint64_t)kSmallKeys && direct_path > 1;
     }
     if (restart) continue;
     // first-seen ranks of the used slots over the first `rows` rows: table[].id, dict, first_rows, total, null_id
@@ -613,7 +685,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
       AH_HIP(c, hipMemsetAsync(misses, 0, 8, c->stream));
       direct_from = prefix;
       int64_t lo = prefix;
-      if (small) {
+      if constexpr (K::kLdsTable) if (small) {
         AH_HIP(c, hipMemsetAsync(skeys, 0xFF, (size_t)kSmallSlots * 8, c->stream));
         small_build_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap, kBlock)), kBlock, 0, c->stream>>>(table, cap, skeys, sids);
         AH_LAUNCH_CHECK(c);
@@ -621,7 +693,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
         // misses the LDS table all the time and is better served by the plain kernel
         const int64_t probe_end = n - prefix > ((int64_t)1 << 23) ? prefix + ((int64_t)1 << 22) : n;
         const unsigned sgrid = (unsigned)c->num_cu;
-        insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, prefix, probe_end, encode_nulls,
+        insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>(keys.keys, valid, off, prefix, probe_end, encode_nulls,
                                                                   table, cap, skeys, sids, (unsigned*)out_ids, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
         lo = probe_end;
@@ -629,7 +701,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
           AH_HIP(c, hipMemcpyAsync(c->pinned, misses, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
           AH_HIP(c, hipStreamSynchronize(c->stream));
           if (*(volatile uint64_t*)c->pinned * 8 < (uint64_t)(probe_end - prefix)) {
-            insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, probe_end, n, encode_nulls,
+            insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>(keys.keys, valid, off, probe_end, n, encode_nulls,
                                                                       table, cap, skeys, sids, (unsigned*)out_ids, distinct, overflow, misses);
             AH_LAUNCH_CHECK(c);
             lo = n;
@@ -637,7 +709,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
         }
       }
       if (lo < n) {
-        insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, lo, n, encode_nulls, table, cap,
+        insert_kernel<K><<<grid, kBlock, 0, c->stream>>>(keys, valid, off, lo, n, encode_nulls, table, cap,
                                                       (unsigned*)out_ids, 0x80000000u, (unsigned)prefix, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
       }
@@ -648,7 +720,7 @@ int encode_core(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t o
       *(volatile uint64_t*)c->pinned = *(volatile uint64_t*)&c->pinned[1];  // overflow flag where the check below reads it
     } else {
       if (prefix < n) {
-        insert_kernel<<<grid, kBlock, 0, c->stream>>>((const unsigned long long*)keys, valid, off, prefix, n, encode_nulls, table, cap,
+        insert_kernel<K><<<grid, kBlock, 0, c->stream>>>(keys, valid, off, prefix, n, encode_nulls, table, cap,
                                                       (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
       }
@@ -689,7 +761,7 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
   int32_t* ids = nullptr;
   AH_HIP(c, hipMalloc((void**)&ids, (size_t)n * sizeof(int32_t)));
   EncodeResult res;
-  int rc = encode_core(c, keys, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows);
+  int rc = encode_core(c, U64Keys{(const unsigned long long*)keys}, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows);
   if (rc == AH_OK) {
     hipError_t e1 = hipMemsetAsync(out_sums, 0, (size_t)res.ndict * sizeof(AT), c->stream);
     hipError_t e2 = hipMemsetAsync(out_counts, 0, (size_t)res.ndict * sizeof(int64_t), c->stream);
@@ -739,6 +811,42 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
 
 }  // namespace
 
+static int ids_validity(ah_ctx* c, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, uint8_t* out_ids_valid) {
+  // indices validity: all set when nulls are encoded (or there is no validity);
+  // otherwise the input validity (NullEncodingMask, vector_hash.go:224-230)
+  int rc;
+  if (valid && !encode_nulls) rc = ah_copy_bitmap(c, valid, off, n, out_ids_valid, 0, 0);
+  else {
+    AH_HIP(c, hipMemsetAsync(out_ids_valid, 0, (size_t)((n + 7) / 8), c->stream));
+    rc = ah_set_bits_to(c, out_ids_valid, 0, n, 1);
+  }
+  if (rc != AH_OK) return rc;
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_hash_binary_encode(ah_ctx* c, int offset_width, const void* offsets, const uint8_t* data, const uint8_t* valid, int64_t off,
+                                    int64_t n, int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows,
+                                    int64_t* out_ndict_host, int32_t* out_null_id_host) {
+  AH_ENTER(c);
+  if (n < 0 || off < 0) return ah_fail(c, AH_EINVALID, "hash: negative length/offset");
+  if (offset_width != 4 && offset_width != 8) return ah_fail(c, AH_EINVALID, "hash: offset width must be 4 or 8");
+  if (out_ndict_host) *out_ndict_host = 0;
+  if (out_null_id_host) *out_null_id_host = -1;
+  if (n == 0) return AH_OK;
+  if (!offsets || !out_first_rows) return ah_fail(c, AH_EINVALID, "hash: null buffer");
+  if ((uintptr_t)offsets & (uintptr_t)(offset_width - 1)) return ah_fail(c, AH_EINVALID, "hash: offsets not element-aligned");
+  EncodeResult res;
+  int rc = offset_width == 4
+               ? encode_core(c, BinKeys<int32_t>{(const int32_t*)offsets + off, data}, valid, off, n, encode_nulls, out_ids, nullptr, &res, out_first_rows)
+               : encode_core(c, BinKeys<int64_t>{(const int64_t*)offsets + off, data}, valid, off, n, encode_nulls, out_ids, nullptr, &res, out_first_rows);
+  if (rc != AH_OK) return rc;
+  if (out_ids_valid && (rc = ids_validity(c, valid, off, n, encode_nulls, out_ids_valid)) != AH_OK) return rc;
+  if (out_ndict_host) *out_ndict_host = res.ndict;
+  if (out_null_id_host) *out_null_id_host = res.null_id;
+  return AH_OK;
+}
+
 AH_EXPORT int ah_hash_u64_encode(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n,
                                  int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, uint64_t* out_dict,
                                  int64_t* out_ndict_host, int32_t* out_null_id_host) {
@@ -749,19 +857,9 @@ AH_EXPORT int ah_hash_u64_encode(ah_ctx* c, const uint64_t* keys, const uint8_t*
   if (n == 0) return AH_OK;
   if (!keys) return ah_fail(c, AH_EINVALID, "hash: null keys");
   EncodeResult res;
-  int rc = encode_core(c, keys, valid, off, n, encode_nulls, out_ids, out_dict, &res);
+  int rc = encode_core(c, U64Keys{(const unsigned long long*)keys}, valid, off, n, encode_nulls, out_ids, out_dict, &res);
   if (rc != AH_OK) return rc;
-  if (out_ids_valid) {
-    // indices validity: all set when nulls are encoded (or there is no validity);
-    // otherwise the input validity (NullEncodingMask, vector_hash.go:224-230)
-    if (valid && !encode_nulls) rc = ah_copy_bitmap(c, valid, off, n, out_ids_valid, 0, 0);
-    else {
-      AH_HIP(c, hipMemsetAsync(out_ids_valid, 0, (size_t)((n + 7) / 8), c->stream));
-      rc = ah_set_bits_to(c, out_ids_valid, 0, n, 1);
-    }
-    if (rc != AH_OK) return rc;
-    AH_HIP(c, hipStreamSynchronize(c->stream));
-  }
+  if (out_ids_valid && (rc = ids_validity(c, valid, off, n, encode_nulls, out_ids_valid)) != AH_OK) return rc;
   if (out_ndict_host) *out_ndict_host = res.ndict;
   if (out_null_id_host) *out_null_id_host = res.null_id;
   return AH_OK;

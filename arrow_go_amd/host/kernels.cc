@@ -529,6 +529,63 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
   return Status::OK();
 }
 
+// regularHashState over BinaryMemoTable (vector_hash.go:288-325,612-618): ids on the device, the dictionary
+// = the var-length take of each entry's first row (the memo table's builder holds exactly those bytes)
+static Status ExecHashBinary(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool dict_encode) {
+  Session* s = k->session;
+  ArraySpan keys = b.values[0].array;
+  const DictionaryEncodeOptions* opts = static_cast<const DictionaryEncodeOptions*>(k->state);
+  int encode_nulls = dict_encode ? (opts && opts->NullEncoding == NullEncodingEncode) : 1;
+  AHC_RETURN_NOT_OK(keys.UpdateNullCount(s));
+  const uint8_t* valid = keys.MayHaveNulls() ? keys.buffers[0].buf : nullptr;
+  const int64_t n = keys.len;
+  const int ow = keys.type->bit_width / 8;
+  BufferPtr ids, ids_valid, first_rows;
+  AHC_RETURN_NOT_OK(k->Allocate((n + 1) * 8, &first_rows));
+  if (dict_encode) {
+    AHC_RETURN_NOT_OK(k->Allocate(n * 4, &ids));
+    if (valid && !encode_nulls) AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &ids_valid));
+  }
+  int64_t ndict = 0; int32_t null_id = -1;
+  if (n > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_hash_binary_encode(s->ctx(), ow, keys.buffers[1].buf, keys.buffers[2].buf, valid, keys.offset, n, encode_nulls,
+                                                          ids ? (int32_t*)ids->dptr : nullptr, ids_valid ? (uint8_t*)ids_valid->dptr : nullptr,
+                                                          (int64_t*)first_rows->dptr, &ndict, &null_id)));
+  // GetDictArrayData (arrow/array/util.go:341-366): offsets + values in memo order, a null entry has no
+  // bytes; validity = all ones with the null's bit cleared (:375-384)
+  ExecResult dres;
+  dres.type = keys.type;
+  AHC_RETURN_NOT_OK(TakeBinaryCommon(k, keys, 8, true, first_rows->dptr, nullptr, 0, ndict, false, &dres));
+  auto d = std::make_shared<ArrayData>();
+  d->type = keys.type;
+  d->length = ndict;
+  d->null_count = null_id >= 0 ? 1 : 0;
+  d->buffers[1] = dres.buffers[1].owner;
+  d->buffers[2] = dres.buffers[2].owner;
+  if (null_id >= 0) {
+    BufferPtr dv;
+    AHC_RETURN_NOT_OK(k->AllocateBitmap(ndict, &dv));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), dv->dptr, 0xFF, (size_t)((ndict + 7) / 8))));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_set_bits_to(s->ctx(), (uint8_t*)dv->dptr, null_id, 1, 0)));
+    d->buffers[0] = dv;
+  }
+  if (!dict_encode) {  // uniqueFinalize (vector_hash.go:721-741)
+    out->type = d->type;
+    out->len = d->length;
+    out->nulls = d->null_count;
+    out->buffers[0].WrapBuffer(d->buffers[0]);
+    out->buffers[1].WrapBuffer(d->buffers[1]);
+    out->buffers[2].WrapBuffer(d->buffers[2]);
+    return Status::OK();
+  }
+  out->len = n;
+  out->nulls = ids_valid ? keys.nulls : 0;
+  out->buffers[0].WrapBuffer(ids_valid);
+  out->buffers[1].WrapBuffer(ids);
+  out->dictionary = d;
+  return Status::OK();
+}
+
 void RegisterVectorHash(FunctionRegistry* reg) {
   auto uq = std::make_shared<VectorFunction>("unique", Arity{1, false});
   auto de = std::make_shared<VectorFunction>("dictionary_encode", Arity{1, false}, &kDefaultDictOptions);
@@ -541,6 +598,17 @@ void RegisterVectorHash(FunctionRegistry* reg) {
     kd.sig.in_types = {t};
     kd.output_is_dictionary = true;
     kd.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHash(k, b, o, true); };
+    de->AddKernel(std::move(kd));
+  }
+  for (Type t : {Type::BINARY, Type::STRING, Type::LARGE_BINARY, Type::LARGE_STRING}) {
+    exec::VectorKernel ku;
+    ku.sig.in_types = {t};
+    ku.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHashBinary(k, b, o, false); };
+    uq->AddKernel(std::move(ku));
+    exec::VectorKernel kd;
+    kd.sig.in_types = {t};
+    kd.output_is_dictionary = true;
+    kd.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHashBinary(k, b, o, true); };
     de->AddKernel(std::move(kd));
   }
   reg->AddFunction(uq, false);

@@ -237,6 +237,20 @@ int ah_take_primitive(ah_ctx* ctx, int byte_width, const void* values, const uin
 int ah_hash_u64_encode(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n,
                        int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, uint64_t* out_dict,
                        int64_t* out_ndict_host, int32_t* out_null_id_host);
+/* The same for Binary / String (offset_width 4) and LargeBinary / LargeString (8) values ==
+ * doAppendBinary (kernels/vector_hash.go:288-325) over hashing.BinaryMemoTable
+ * (internal/hashing/xxh3_memo_table.go:248-341: lookup by hash + bytes.Equal, memo index = position
+ * in the builder = order of first occurrence; null via GetOrInsertNull :333-341).  `offsets`: the
+ * values' offsets buffer (elements off + i, off + i + 1 delimit row i; validity bit off + i).
+ * The memo table's hash (hash_funcs.go:86-124, xxh3 for > 16 bytes) only places entries inside the
+ * reference's table and cannot influence ids or dictionary order, so the device uses its own 64-bit
+ * hash and compares bytes on tag match.  The dictionary is not copied here: out_first_rows[id]
+ * (int64, relative to off, n + 1 entries of room) is the row that first held dictionary entry id —
+ * dictionary = ah_take_binary_offsets / _data with those rows as indices (the null entry, if any,
+ * points at a null row: zero length, as BinaryBuilder.AppendNull leaves it).  < 2^32 − 1 rows. */
+int ah_hash_binary_encode(ah_ctx* ctx, int offset_width, const void* offsets, const uint8_t* data, const uint8_t* valid, int64_t off,
+                          int64_t n, int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows,
+                          int64_t* out_ndict_host, int32_t* out_null_id_host);
 /* group-by sum (NEW — arrow-go has no hash aggregate; definition in DESIGN.md): groups
  * = dictionary_encode(keys, encode_nulls=1) ids; out_sums[g] = Σ valid vals of group
  * g, out_counts[g] = number of valid vals.  i64 sums wrap and are exact; f64 sums

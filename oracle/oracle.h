@@ -118,6 +118,11 @@ uint64_t orc_hash_int(uint64_t v, uint64_t alg);
 int orc_hash_u64_encode(const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
                         int32_t* out_ids, uint8_t* out_ids_valid, uint64_t* out_dict,
                         int64_t* out_ndict, int32_t* out_null_id);
+/* the same over Binary / String (offset_width 4) and LargeBinary / LargeString (8) values; the
+ * dictionary is take(values, out_first_rows[0..ndict)) (a null entry points at the first null row) */
+int orc_hash_binary_encode(int offset_width, const void* offsets, const uint8_t* data, const uint8_t* valid, int64_t off, int64_t n,
+                           int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows,
+                           int64_t* out_ndict, int32_t* out_null_id);
 /* group-by (new functionality, oracle = sequential row-order accumulation) */
 int orc_hash_sum_f64(const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
                      const double* vals, const uint8_t* vvalid, int64_t voff, int64_t n,

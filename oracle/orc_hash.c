@@ -114,6 +114,81 @@ int orc_hash_u64_encode(const uint64_t* keys, const uint8_t* valid, int64_t off,
   return ORC_OK;
 }
 
+/* ---- binary / string keys ---------------------------------------------------------------------
+ * doAppendBinary (kernels/vector_hash.go:288-325) over BinaryMemoTable
+ * (internal/hashing/xxh3_memo_table.go:248-341): InsertOrGet = lookup by (hash, bytes.Equal against
+ * the builder's value), else append to the builder — the memo index is the builder position, i.e. the
+ * order of FIRST OCCURRENCE; GetOrInsertNull appends a null (zero length) at Size().
+ * Hash (hash_funcs.go:86-124) only decides where an entry sits in the open-addressing table: for
+ * ≤ 16 bytes it is restated below; for longer values the reference calls github.com/zeebo/xxh3 v1.1.0
+ * (go.mod:47), whose source is NOT in the snapshot — FNV-1a stands in, which cannot change any memo
+ * index (equality is decided by the bytes).  The dictionary is not materialised here: out_first_rows[id]
+ * = the row whose bytes the builder holds at position id, so dictionary = take(values, first_rows). */
+static uint64_t hash_bytes_ref(const uint8_t* b, uint32_t n) {
+  if (n <= 16) {
+    if (n > 8) {
+      uint64_t x, y; memcpy(&x, b + n - 8, 8); memcpy(&y, b, 8);
+      return (uint64_t)n ^ orc_hash_int(x, 0) ^ orc_hash_int(y, 1);
+    }
+    if (n >= 4) {
+      uint32_t x, y; memcpy(&x, b + n - 4, 4); memcpy(&y, b, 4);
+      return (uint64_t)n ^ orc_hash_int(x, 0) ^ orc_hash_int(y, 1);
+    }
+    if (n > 0) {
+      uint32_t x = (n << 24) ^ ((uint32_t)b[0] << 16) ^ ((uint32_t)b[n / 2] << 8) ^ (uint32_t)b[n - 1];
+      return orc_hash_int(x, 0);
+    }
+    return 1;
+  }
+  uint64_t h = 14695981039346656037ull;  /* stand-in for xxh3.Hash(b) */
+  for (uint32_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h + 1609587929392839161ull;     /* + exprimes[0] (:87) */
+}
+
+#define BIN_ENCODE_BODY(OT)                                                                               \
+  const OT* o = (const OT*)offsets + off;                                                                 \
+  table_t t; table_init(&t, 0);                                                                           \
+  int64_t* rows = out_first_rows; /* memo index → row (the "builder") */                                  \
+  if (out_ids_valid) memset(out_ids_valid, 0, (size_t)((n + 7) / 8));                                     \
+  for (int64_t i = 0; i < n; i++) {                                                                       \
+    if (bget_opt(valid, off + i)) {                                                                       \
+      const uint8_t* v = data + o[i]; const int64_t len = (int64_t)(o[i + 1] - o[i]);                     \
+      uint64_t h = fix_hash(hash_bytes_ref(v, (uint32_t)len));                                            \
+      uint64_t idx = h & t.mask, perturb = (h >> 5) + 1; int id = -1;                                     \
+      for (;;) {                                                                                          \
+        entry_t* s = &t.e[idx];                                                                           \
+        if (s->h == h) {                                                                                  \
+          const int64_t r = rows[s->memo_idx];                                                            \
+          if ((int64_t)(o[r + 1] - o[r]) == len && memcmp(data + o[r], v, (size_t)len) == 0) { id = s->memo_idx; break; } \
+        }                                                                                                 \
+        if (s->h == 0) break;                                                                             \
+        idx = (idx + perturb) & t.mask; perturb = (perturb >> 5) + 1;                                     \
+      }                                                                                                   \
+      if (id < 0) {                                                                                       \
+        id = table_size(&t); rows[id] = i;                                                                \
+        t.e[idx].h = h; t.e[idx].val = 0; t.e[idx].memo_idx = id; t.size++;                               \
+        if (t.size * 2 >= t.cap) table_upsize(&t, t.cap * 4);                                             \
+      }                                                                                                   \
+      if (out_ids) out_ids[i] = id;                                                                       \
+      if (out_ids_valid) bset(out_ids_valid, i);                                                          \
+    } else if (encode_nulls) {                                                                            \
+      if (t.null_idx < 0) { t.null_idx = table_size(&t); rows[t.null_idx] = i; }                          \
+      if (out_ids) out_ids[i] = t.null_idx;                                                               \
+      if (out_ids_valid) bset(out_ids_valid, i);                                                          \
+    } else if (out_ids) out_ids[i] = 0;                                                                   \
+  }                                                                                                       \
+  if (out_ndict) *out_ndict = table_size(&t);                                                             \
+  if (out_null_id) *out_null_id = t.null_idx;                                                             \
+  free(t.e);                                                                                              \
+  return ORC_OK;
+
+int orc_hash_binary_encode(int offset_width, const void* offsets, const uint8_t* data, const uint8_t* valid, int64_t off, int64_t n,
+                           int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows,
+                           int64_t* out_ndict, int32_t* out_null_id) {
+  if (offset_width == 4) { BIN_ENCODE_BODY(int32_t) }
+  BIN_ENCODE_BODY(int64_t)
+}
+
 #define HASH_SUM_BODY(VT, ACC_T)                                                                  \
   table_t t; table_init(&t, 0);                                                                   \
   int64_t ng = 0;                                                                                 \

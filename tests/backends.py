@@ -101,6 +101,9 @@ class OracleBackend:
     def hash_encode(self, keys, valid, off, encode_nulls):
         return self.o.hash_u64_encode(keys, valid, off, encode_nulls)
 
+    def hash_binary_encode(self, offsets, data, valid, off, n, encode_nulls):
+        return self.o.hash_binary_encode(offsets, data, valid, off, n, encode_nulls)
+
     def hash_sum(self, kind, keys, kvalid, koff, vals, vvalid, voff):
         return self.o.hash_sum(kind, keys, kvalid, koff, vals, vvalid, voff)
 
@@ -397,6 +400,13 @@ class HipBackend:
         idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); db = self.c.alloc((n + 1) * 8 + 64)
         nd, nid = self.c.hash_u64_encode(kp, vp, off, n, encode_nulls, idb, idvb, db)
         return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), db.download(np.uint64, nd), nid
+
+    def hash_binary_encode(self, offsets, data, valid, off, n, encode_nulls):
+        offsets = np.ascontiguousarray(offsets); data = np.ascontiguousarray(data, dtype=np.uint8)
+        ofb, ofp = self._up(offsets); db, dp = self._up(data) if data.size else (None, None); vb, vp = self._upbits(valid)
+        idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); frb = self.c.alloc((n + 1) * 8 + 64)
+        nd, nid = self.c.hash_binary_encode(offsets.dtype.itemsize, ofp, dp, vp, off, n, encode_nulls, idb, idvb, frb)
+        return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), frb.download(np.int64, nd), nid
 
     def hash_sum(self, kind, keys, kvalid, koff, vals, vvalid, voff):
         keys = np.ascontiguousarray(keys).view(np.uint64); vals = np.ascontiguousarray(vals)

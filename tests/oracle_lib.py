@@ -78,6 +78,7 @@ class Oracle:
             "orc_take_boolean": (it, [vp, vp, i64, i64, it, it, vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_hash_int": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "orc_hash_u64_encode": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
+            "orc_hash_binary_encode": (it, [it, vp, vp, vp, i64, i64, it, vp, vp, vp, vp, vp]),
             "orc_hash_sum_f64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
             "orc_hash_sum_i64": (it, [vp, vp, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
             "orc_cmp_filter_sum_i64": (it, [it, vp, vp, i64, i64, i64, vp, vp]),
@@ -309,6 +310,16 @@ class Oracle:
         st = self.lib.orc_hash_u64_encode(_p(keys), _p(valid), off, n, int(encode_nulls), _p(ids), _p(idv), _p(d), _p(nd), _p(nid))
         assert st == 0, st
         return ids[:n], idv[:(n + 7) // 8], d[:int(nd[0])], int(nid[0])
+
+    def hash_binary_encode(self, offsets, data, valid, off, n, encode_nulls):
+        """→ ids, ids validity, first rows (one per dictionary entry), null id"""
+        offsets = np.ascontiguousarray(offsets); data = np.ascontiguousarray(data, dtype=np.uint8)
+        ids = np.zeros(max(n, 1), np.int32); idv = np.zeros((n + 7) // 8 + 1, np.uint8)
+        fr = np.zeros(n + 1, np.int64); nd = np.zeros(1, np.int64); nid = np.zeros(1, np.int32)
+        st = self.lib.orc_hash_binary_encode(offsets.dtype.itemsize, _p(offsets), _p(data) if data.size else None, _p(valid), off, n,
+                                             int(encode_nulls), _p(ids), _p(idv), _p(fr), _p(nd), _p(nid))
+        assert st == 0, st
+        return ids[:n], idv[:(n + 7) // 8], fr[:int(nd[0])], int(nid[0])
 
     def hash_sum(self, kind, keys, kvalid, koff, vals, vvalid, voff):
         keys = np.ascontiguousarray(keys).view(np.uint64); vals = np.ascontiguousarray(vals)

@@ -302,6 +302,37 @@ def test_unique_and_dictionary_encode(sess, typ):
     assert got.indices.equals(exp.indices) and got.dictionary.equals(exp.dictionary)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", [pa.string(), pa.large_string(), pa.binary(), pa.large_binary()], ids=str)
+def test_unique_and_dictionary_encode_binary(sess, typ):
+    isbin = pa.types.is_binary(typ) or pa.types.is_large_binary(typ)
+    conv = (lambda x: x.encode() if isinstance(x, str) and isbin else x)
+    A = lambda v: pa.array([conv(x) for x in v], type=typ)
+    L = lambda v: [conv(x) for x in v]
+    uq = lambda v: sess.call_function("unique", [v])
+    assert uq(A(["test", None, "test2", "test"])).to_pylist() == L(["test", None, "test2"])          # vector_hash_test.go:272-279
+    assert uq(A(["foo", "bar", "foo", "bar", "baz", "quuux", "foo"])).to_pylist() == L(["foo", "bar", "baz", "quuux"])  # :420-449
+    assert uq(A(["test", None, "test2", "test"])).type == typ
+    d = sess.call_function("dictionary_encode", [A(["foo", "bar", "foo", None, "bar", None])])      # :541-594
+    assert d.type == pa.dictionary(pa.int32(), typ)
+    assert d.indices.to_pylist() == [0, 1, 0, None, 1, None] and d.dictionary.to_pylist() == L(["foo", "bar"])
+    d = sess.call_function("dictionary_encode", [A(["foo", "bar", "foo", None, "bar", None])], "null_encoding_behavior=encode")
+    assert d.indices.to_pylist() == [0, 1, 0, 2, 1, 2] and d.dictionary.to_pylist() == L(["foo", "bar", None])
+    assert d.dictionary.null_count == 1 and d.indices.null_count == 0
+    d = sess.call_function("dictionary_encode", [A(["ignored", "foo", None, "bar", "foo", "ignored"]).slice(1, 4)])  # :802-825
+    assert d.indices.to_pylist() == [0, None, 1, 0] and d.dictionary.to_pylist() == L(["foo", "bar"])
+    assert uq(A([])).to_pylist() == []
+    # random vs Arrow C++ (same first-seen-order contract)
+    rng = np.random.default_rng(5)
+    words = ["w%d" % i * int(1 + i % 5) for i in range(300)] + ["", "a" * 40]
+    v = pa.array([conv(words[j]) for j in rng.integers(0, len(words), 50001)], mask=rng.random(50001) < 0.05, type=typ)
+    assert uq(v).equals(pc.unique(v))
+    got, exp = sess.call_function("dictionary_encode", [v]), pc.dictionary_encode(v)
+    assert got.indices.equals(exp.indices) and got.dictionary.equals(exp.dictionary)
+    got, exp = sess.call_function("dictionary_encode", [v], "null_encoding_behavior=encode"), pc.dictionary_encode(v, null_encoding="encode")
+    assert got.indices.equals(exp.indices) and got.dictionary.equals(exp.dictionary)
+
+
 # ---- cumulative_sum (arrow/compute/vector_cumulative_test.go) -----------------------------------------------
 @pytest.mark.gpu
 def test_cumulative_sum_reference_tables(sess):

@@ -1018,3 +1018,49 @@ def test_filter_string(be, odt):
     assert run([a, b, c], [None, True, False], DROP) == [b]
     assert run([a, None, c * 40, b""], [True, True, True, True], DROP) == [a, None, c * 40, b""]
     assert run([], [], DROP) == []
+
+
+# ---- unique / dictionary_encode over String / Binary ------------------------------------------------
+def bin_dictionary(be, offsets, data, valid, off, n, first_rows, null_id):
+    """dictionary = take(values, first rows) — what GetDictArrayData (arrow/array/util.go:341-366) reads out of
+    the memo table's builder; the null entry comes out as None"""
+    st, oo, od, ov, nulls, _ = be.take_binary(offsets, data, valid, off, n, first_rows, None, 0, valid is not None)
+    assert st == 0
+    return un_binary(oo, od, ov, len(first_rows))
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64], ids=["string", "large_string"])
+def test_unique_binary_vectors(be, odt):
+    # vector_hash_test.go:272-279 (BinaryTypeHashKernelSuite.TestUnique, String / LargeString / Binary / LargeBinary)
+    offsets, data, valid = mk_binary([b"test", None, b"test2", b"test"], odt, pad=b"")
+    ids, idv, fr, null_id = be.hash_binary_encode(offsets, data, valid, 0, 4, True)
+    assert bin_dictionary(be, offsets, data, valid, 0, 4, fr, null_id) == [b"test", None, b"test2"] and null_id == 1
+    # :420-449 TestUniqueChunkedArrayInvoke, the two chunks laid end to end
+    offsets, data, valid = mk_binary([b"foo", b"bar", b"foo", b"bar", b"baz", b"quuux", b"foo"], odt)
+    ids, idv, fr, null_id = be.hash_binary_encode(offsets, data, valid, 0, 7, True)
+    assert bin_dictionary(be, offsets, data, valid, 0, 7, fr, null_id) == [b"foo", b"bar", b"baz", b"quuux"] and null_id == -1
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64], ids=["string", "large_string"])
+def test_dictionary_encode_binary_vectors(be, odt):
+    # vector_hash_test.go:541-594 TestDictionaryEncode
+    offsets, data, valid = mk_binary([b"foo", b"bar", b"foo", None, b"bar", None], odt, pad=b"zz")
+    ids, idv, fr, null_id = be.hash_binary_encode(offsets, data, valid, 0, 6, False)
+    assert ids.tolist() == [0, 1, 0, 0, 1, 0] and null_id == -1
+    assert OL.unpack_bits(idv, 0, 6).tolist() == [True, True, True, False, True, False]
+    assert bin_dictionary(be, offsets, data, valid, 0, 6, fr, null_id) == [b"foo", b"bar"]
+    ids, idv, fr, null_id = be.hash_binary_encode(offsets, data, valid, 0, 6, True)
+    assert ids.tolist() == [0, 1, 0, 2, 1, 2] and null_id == 2 and OL.unpack_bits(idv, 0, 6).all()
+    assert bin_dictionary(be, offsets, data, valid, 0, 6, fr, null_id) == [b"foo", b"bar", None]
+    # :802-825 TestDictionaryEncodeArraySlicedInput: ["ignored","foo",null,"bar","foo","ignored"][1:5]
+    offsets, data, valid = mk_binary([b"ignored", b"foo", None, b"bar", b"foo", b"ignored"], odt)
+    ids, idv, fr, null_id = be.hash_binary_encode(offsets, data, valid, 1, 4, False)
+    assert ids.tolist() == [0, 0, 1, 0] and OL.unpack_bits(idv, 0, 4).tolist() == [True, False, True, True]
+    assert bin_dictionary(be, offsets, data, valid, 1, 4, fr, null_id) == [b"foo", b"bar"]
+    # a null whose slot still holds bytes equal to a real value is not that value
+    offsets, data, valid = mk_binary([b"ab", None, b"ab"], odt, pad=b"ab")
+    ids, idv, fr, null_id = be.hash_binary_encode(offsets, data, valid, 0, 3, True)
+    assert ids.tolist() == [0, 1, 0] and null_id == 1
+    # empty input
+    ids, idv, fr, null_id = be.hash_binary_encode(np.zeros(1, odt), np.zeros(0, np.uint8), None, 0, 0, True)
+    assert len(ids) == 0 and len(fr) == 0 and null_id == -1

@@ -917,3 +917,54 @@ def test_beyond_2_31_rows(ctx):
     assert ctx.count_set_bits(od, 0, n) == int(np.isin(tail, [99, 98]).sum()) and ctx.count_set_bits(ov, 0, n) == n
     for buf in (a, b, out, mask, od, ov):
         buf.free()
+
+
+# ---- unique / dictionary_encode over binary keys -------------------------------------------------
+def binary_from_pool(rng, n, odt, pool):
+    """rows drawn from a pool of byte strings; Arrow offsets + data"""
+    pick = rng.integers(0, len(pool), n)
+    lens = np.array([len(pool[j]) for j in pick], np.int64)
+    offsets = np.zeros(n + 1, odt)
+    offsets[1:] = np.cumsum(lens)
+    data = np.frombuffer(b"".join(pool[j] for j in pick), np.uint8) if offsets[-1] else np.zeros(0, np.uint8)
+    return offsets, data
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64], ids=["binary", "large_binary"])
+def test_hash_binary_encode_first_seen_order(hip, orc_be, odt):
+    """ids, index validity, the first row of every dictionary entry and the null id: all identical to the
+    sequential memo table — short keys, keys longer than 16 bytes, empty strings, shared prefixes and
+    equal lengths (so the byte comparison decides), nulls encoded or masked, sliced input"""
+    rng = np.random.default_rng(9100 + np.dtype(odt).itemsize)
+    for card, maxlen in ((1, 4), (6, 0), (40, 3), (500, 12), (3000, 40), (20000, 9)):
+        pool = [bytes(rng.integers(97, 100, int(rng.integers(0, maxlen + 1)), dtype=np.uint8)) for _ in range(card)]
+        pool += [p + b"x" for p in pool[: card // 4]] + [b"", b"a" * 17, b"a" * 16 + b"b", b"a" * 24, b"a" * 23 + b"c"]
+        for n in (1, 65, 3001, 150001):
+            offsets, data = binary_from_pool(rng, n + 9, odt, pool)
+            valid = rand_bits(rng, n + 16, 0.9)
+            for off, v in ((0, None), (0, valid), (9, valid)):
+                for enc in (True, False):
+                    g = hip.hash_binary_encode(offsets, data, v, off, n, enc)
+                    e = orc_be.hash_binary_encode(offsets, data, v, off, n, enc)
+                    assert g[0].tobytes() == e[0].tobytes(), (card, n, off, enc)
+                    assert g[1].tobytes() == e[1].tobytes()
+                    assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+
+
+def test_hash_binary_encode_large(hip, orc_be):
+    # beyond the 2^21-row prefix: direct ids for keys the prefix knew, late keys, table growth
+    rng = np.random.default_rng(9200)
+    n = (1 << 22) + 321
+    pool = [b"k%07d" % i for i in range(5000)]
+    offsets, data = binary_from_pool(rng, n, np.int32, pool)
+    valid = rand_bits(rng, n + 8, 0.95)
+    for enc in (True, False):
+        g, e = hip.hash_binary_encode(offsets, data, valid, 0, n, enc), orc_be.hash_binary_encode(offsets, data, valid, 0, n, enc)
+        assert g[0].tobytes() == e[0].tobytes() and g[1].tobytes() == e[1].tobytes()
+        assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+    # mostly distinct 8-byte values: the table is re-planned
+    n = (1 << 22) + 5
+    data = rng.integers(0, 256, n * 8, dtype=np.uint8)
+    offsets = (np.arange(n + 1, dtype=np.int64) * 8)
+    g, e = hip.hash_binary_encode(offsets, data, None, 0, n, True), orc_be.hash_binary_encode(offsets, data, None, 0, n, True)
+    assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
