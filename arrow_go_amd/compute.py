@@ -46,6 +46,15 @@ lib.ahc_registry_add_alias.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_int]
 lib.ahc_import_device.argtypes = [_vp, _vp, _vp, C.POINTER(_vp)]
 lib.ahc_export_device.argtypes = [_vp, _vp, _vp, _vp]
 lib.ahc_datum_buffers.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]
+lib.ahc_ipc_open.argtypes = [_vp, _vp, C.c_int64, C.POINTER(_vp)]
+lib.ahc_ipc_close.argtypes = [_vp]
+lib.ahc_ipc_close.restype = None
+lib.ahc_ipc_num_fields.argtypes = [_vp]
+lib.ahc_ipc_field.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.ahc_ipc_next.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)]
+lib.ahc_ipc_bytes_uploaded.argtypes = [_vp]
+lib.ahc_ipc_bytes_uploaded.restype = C.c_int64
+lib.ahc_ipc_inspect.argtypes = [_vp, C.c_int64, C.c_char_p, C.c_int64]
 lib.ahc_expr_eval.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]
 
 
@@ -146,6 +155,35 @@ _ERRS = {1: ErrInvalid, 2: ErrIndex, 3: ErrNotImplemented, 4: ErrType, 5: ErrKey
 _TYPE_IDS = {"string": 13, "binary": 14, "large_string": 34, "large_binary": 35, "bool": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7, "uint64": 8, "int64": 9,
              "float": 11, "double": 12}
 _PACK = {1: "<?", 2: "<B", 3: "<b", 4: "<H", 5: "<h", 6: "<I", 7: "<i", 8: "<Q", 9: "<q", 11: "<f", 12: "<d"}
+
+
+def _as_bytes_ptr(buf):
+    """(keep-alive object, address, length) of a bytes-like / pyarrow.Buffer without copying when possible"""
+    mv = memoryview(buf)
+    if mv.readonly:
+        keep = (C.c_char * mv.nbytes).from_buffer_copy(mv) if not isinstance(buf, bytes) else buf
+        addr = C.cast(C.c_char_p(keep), _vp).value if isinstance(keep, bytes) else C.addressof(keep)
+        return keep, addr, mv.nbytes
+    keep = (C.c_char * mv.nbytes).from_buffer(mv)
+    return keep, C.addressof(keep), mv.nbytes
+
+
+def ipc_inspect(buf):
+    """Walk an Arrow IPC stream on the host only (no GPU needed): → ([(name, type name, nullable)], [rows per batch]).
+    Raises the same errors read_ipc would."""
+    keep, addr, n = _as_bytes_ptr(buf)
+    out = C.create_string_buffer(1 << 20)
+    rc = lib.ahc_ipc_inspect(addr, n, out, len(out))
+    text = out.value.decode()
+    if rc != 0:
+        raise _ERRS.get(rc, ArrowError)(text)
+    names = {v: k for k, v in _TYPE_IDS.items()}
+    fields, rows = text.split("|")
+    fl = []
+    for f in filter(None, fields.split(",")):
+        nm, tid, nullable = f.rsplit(":", 2)
+        fl.append((bytes.fromhex(nm).decode("utf-8", "replace"), names[int(tid)], nullable == "1"))
+    return fl, [int(r) for r in rows.split(",") if r]
 
 
 def has_function(name: str) -> bool:
@@ -303,6 +341,32 @@ class Session:
                 if d.value not in borrowed_handles:  # DeviceArray arguments stay owned by their wrappers
                     lib.ahc_datum_release(d)
 
+    # -- ipc.NewReader / Reader.Next, with the record-batch bodies landing in HBM
+    def read_ipc(self, buf):
+        """Iterate the record batches of an Arrow IPC *stream* (bytes / pyarrow.Buffer / mmap): yields
+        (field names, [DeviceArray per column], rows).  Each body goes to the device in one copy; the columns
+        are slices of it."""
+        keep, addr, n = _as_bytes_ptr(buf)
+        r = _vp()
+        self._check(lib.ahc_ipc_open(self.h, addr, n, C.byref(r)))
+        try:
+            nf = lib.ahc_ipc_num_fields(r)
+            names = []
+            for i in range(nf):
+                nm = C.c_char_p()
+                self._check(lib.ahc_ipc_field(r, i, C.byref(nm), None, None))
+                names.append(nm.value.decode())
+            while True:
+                cols = (_vp * max(nf, 1))()
+                rows = C.c_int64()
+                self._check(lib.ahc_ipc_next(r, cols, C.byref(rows)))
+                if rows.value < 0:
+                    return
+                yield names, [DeviceArray(self, _vp(cols[i])) for i in range(nf)], rows.value
+        finally:
+            lib.ahc_ipc_close(r)
+            del keep
+
     # -- compute.Expression / exprs.ExecuteScalarExpression
     def eval_expression(self, text: str, columns, literals=(), fuse: bool = True, raw: bool = False):
         """Evaluate an expression tree over a batch.  `text` is prefix notation with `$i` for
@@ -327,14 +391,22 @@ class Session:
 
     # -- arrow/math
     def math_sum(self, arr):
-        d = self._import(arr)
+        """math.Float64.Sum / Int64.Sum / Uint64.Sum of a pyarrow array or a DeviceArray"""
+        resident = isinstance(arr, DeviceArray)
+        d = arr.h if resident else self._import(arr)
         try:
             f, i, u = C.c_double(), C.c_int64(), C.c_uint64()
             self._check(lib.ahc_math_sum(self.h, d, C.byref(f), C.byref(i), C.byref(u)))
-            t = str(arr.type)
+            if resident:
+                kind, tid, length, nulls, sv = C.c_int(), C.c_int(), C.c_int64(), C.c_int64(), C.c_int()
+                lib.ahc_datum_info(d, C.byref(kind), C.byref(tid), C.byref(length), C.byref(nulls), C.byref(sv), None)
+                t = {v: k for k, v in _TYPE_IDS.items()}[tid.value]
+            else:
+                t = str(arr.type)
             return f.value if t == "double" else (i.value if t == "int64" else u.value)
         finally:
-            lib.ahc_datum_release(d)
+            if not resident:
+                lib.ahc_datum_release(d)
 
     def add_alias(self, alias: str, existing: str, allow_overwrite: bool = False):
         self._check(lib.ahc_registry_add_alias(self.h, alias.encode(), existing.encode(), int(allow_overwrite)))

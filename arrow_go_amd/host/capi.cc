@@ -13,6 +13,7 @@
 #include <string>
 
 #include "arrowhip_compute.h"
+#include "ipc.h"
 
 extern "C" {
 struct ArrowSchema {
@@ -584,5 +585,74 @@ AHC_EXPORT int ahc_expr_eval(ahc_session* s, const char* text, int ncols, ahc_da
   if (!st.ok()) return Fail(s, st);
   if (fused_out) *fused_out = fused;
   *out = new ahc_datum{res};
+  return 0;
+}
+
+// ---- Arrow IPC stream → HBM-resident record batches (ipc.NewReader / Reader.Next, arrow/ipc/reader.go:97,202) ----
+struct ahc_ipc_reader {
+  ahc_session* s;
+  std::unique_ptr<ipc::StreamReader> r;
+};
+
+// `bytes` must outlive the reader (the body of each batch is copied to the device when it is read)
+AHC_EXPORT int ahc_ipc_open(ahc_session* s, const uint8_t* bytes, int64_t len, ahc_ipc_reader** out) {
+  *out = nullptr;
+  std::unique_ptr<ipc::StreamReader> r;
+  Status st = ipc::StreamReader::Open(s->session.get(), bytes, len, &r);
+  if (!st.ok()) return Fail(s, st);
+  *out = new ahc_ipc_reader{s, std::move(r)};
+  return 0;
+}
+AHC_EXPORT void ahc_ipc_close(ahc_ipc_reader* r) { delete r; }
+AHC_EXPORT int ahc_ipc_num_fields(ahc_ipc_reader* r) { return (int)r->r->fields().size(); }
+AHC_EXPORT int ahc_ipc_field(ahc_ipc_reader* r, int i, const char** name, int* type_id, int* nullable) {
+  if (i < 0 || i >= (int)r->r->fields().size()) return Fail(r->s, Status::Make(StatusCode::Invalid, "field index out of range"));
+  const ipc::FieldInfo& f = r->r->fields()[i];
+  if (name) *name = f.name.c_str();
+  if (type_id) *type_id = (int)f.type->id;
+  if (nullable) *nullable = f.nullable;
+  return 0;
+}
+// next batch: columns[0..num_fields) receive array datums (caller releases each), *rows its length;
+// *rows = -1 at the end of the stream
+AHC_EXPORT int ahc_ipc_next(ahc_ipc_reader* r, ahc_datum** columns, int64_t* rows) {
+  bool have = false;
+  std::vector<ArrayDataPtr> cols;
+  int64_t n = 0;
+  Status st = r->r->Next(&have, &cols, &n);
+  if (!st.ok()) return Fail(r->s, st);
+  if (!have) { *rows = -1; return 0; }
+  for (size_t i = 0; i < cols.size(); i++) columns[i] = new ahc_datum{Datum::Of(cols[i])};
+  *rows = n;
+  return 0;
+}
+AHC_EXPORT int64_t ahc_ipc_bytes_uploaded(ahc_ipc_reader* r) { return r->r->body_bytes_uploaded(); }
+
+// Walks a stream without a device: "hex(name):type_id:nullable,…|rows,rows,…" into out (NUL-terminated), or
+// the error text with the status code returned — the parser's own test entry (runs where there is no GPU).
+AHC_EXPORT int ahc_ipc_inspect(const uint8_t* bytes, int64_t len, char* out, int64_t cap) {
+  auto put = [&](const std::string& t) { if (cap > 0) { snprintf(out, (size_t)cap, "%s", t.c_str()); } };
+  std::unique_ptr<ipc::StreamReader> r;
+  Status st = ipc::StreamReader::Open(nullptr, bytes, len, &r);
+  std::string text;
+  if (st.ok()) {
+    for (size_t i = 0; i < r->fields().size(); i++) {
+      const ipc::FieldInfo& f = r->fields()[i];
+      std::string hex;  // names are arbitrary bytes: hex keeps the separators unambiguous
+      for (unsigned char ch : f.name) { char b[3]; snprintf(b, sizeof b, "%02x", ch); hex += b; }
+      text += (i ? "," : "") + hex + ":" + std::to_string((int)f.type->id) + ":" + (f.nullable ? "1" : "0");
+    }
+    text += "|";
+    bool have = true, first = true;
+    while (st.ok()) {
+      int64_t rows = 0;
+      st = r->Next(&have, nullptr, &rows);
+      if (!st.ok() || !have) break;
+      text += (first ? "" : ",") + std::to_string(rows);
+      first = false;
+    }
+  }
+  if (!st.ok()) { put(st.ToString()); return (int)st.code; }
+  put(text);
   return 0;
 }

@@ -1,0 +1,292 @@
+// Arrow IPC stream reader that lands record-batch bodies in HBM — see ipc.h.
+#include "ipc.h"
+
+#include <cstring>
+
+#include "../../include/arrowhip.h"
+
+namespace arrowhip {
+namespace ipc {
+namespace {
+
+// ---- a bounds-checked FlatBuffer accessor ------------------------------------------------------
+// Layout (flatbuffers internals): a table starts with an int32 pointing BACK to its vtable; the vtable
+// is [u16 vtable bytes, u16 table bytes, u16 offset of field 0, …] (0 = field absent → default).
+// Strings / vectors / sub-tables are reached through a u32 forward offset stored in the field.
+// Every read goes through `at`, which flags the buffer as bad instead of reading outside it.
+struct Fb {
+  const uint8_t* p;
+  int64_t n;
+  bool bad = false;
+
+  const uint8_t* at(int64_t off, int64_t len) {
+    if (off < 0 || len < 0 || off > n || len > n - off) { bad = true; return nullptr; }
+    return p + off;
+  }
+  template <typename T>
+  T rd(int64_t off) {
+    const uint8_t* q = at(off, (int64_t)sizeof(T));
+    T v{};
+    if (q) std::memcpy(&v, q, sizeof(T));
+    return v;
+  }
+  int64_t root() { return (int64_t)rd<uint32_t>(0); }
+  // position of field `id` inside table `t`, 0 if absent
+  int64_t field(int64_t t, int id) {
+    const int64_t vt = t - (int64_t)rd<int32_t>(t);
+    const int vt_len = rd<uint16_t>(vt);
+    const int slot = 4 + 2 * id;
+    if (bad || slot + 2 > vt_len) return 0;
+    const int off = rd<uint16_t>(vt + slot);
+    return off ? t + off : 0;
+  }
+  template <typename T>
+  T scalar(int64_t t, int id, T dflt) {
+    const int64_t f = field(t, id);
+    return f ? rd<T>(f) : dflt;
+  }
+  // target of an offset field (table / string / vector), 0 if absent
+  int64_t indirect(int64_t t, int id) {
+    const int64_t f = field(t, id);
+    return f ? f + (int64_t)rd<uint32_t>(f) : 0;
+  }
+  int64_t vec_len(int64_t v) { return v ? (int64_t)rd<uint32_t>(v) : 0; }
+  std::string str(int64_t s) {
+    if (!s) return std::string();
+    const int64_t len = (int64_t)rd<uint32_t>(s);
+    const uint8_t* q = at(s + 4, len);
+    return q ? std::string((const char*)q, (size_t)len) : std::string();
+  }
+};
+
+// format/Message.fbs
+enum { kHeaderSchema = 1, kHeaderDictionaryBatch = 2, kHeaderRecordBatch = 3 };
+// format/Schema.fbs: union Type
+enum { kTypeInt = 2, kTypeFloatingPoint = 3, kTypeBinary = 4, kTypeUtf8 = 5, kTypeBool = 6, kTypeLargeBinary = 19, kTypeLargeUtf8 = 20 };
+
+Status Invalid(const std::string& m) { return Status::Make(StatusCode::Invalid, "arrow/ipc: " + m); }
+Status NotImpl(const std::string& m) { return Status::Make(StatusCode::NotImplemented, "arrow/ipc: " + m); }
+
+// one Field table → DataType (metadata.go: typeFromFB / intFromFB / floatFromFB)
+Status DecodeField(Fb& fb, int64_t f, FieldInfo* out) {
+  out->name = fb.str(fb.indirect(f, 0));
+  out->nullable = fb.scalar<uint8_t>(f, 1, 0) != 0;
+  const int type_type = fb.scalar<uint8_t>(f, 2, 0);
+  const int64_t tt = fb.indirect(f, 3);
+  if (fb.field(f, 4)) return NotImpl("field '" + out->name + "' is dictionary-encoded");
+  if (fb.vec_len(fb.indirect(f, 5)) != 0) return NotImpl("field '" + out->name + "' is nested");
+  Type id = Type::NA;
+  switch (type_type) {
+    case kTypeInt: {
+      const int bits = tt ? fb.scalar<int32_t>(tt, 0, 0) : 0;
+      const bool sgn = tt && fb.scalar<uint8_t>(tt, 1, 0) != 0;
+      switch (bits) {
+        case 8: id = sgn ? Type::INT8 : Type::UINT8; break;
+        case 16: id = sgn ? Type::INT16 : Type::UINT16; break;
+        case 32: id = sgn ? Type::INT32 : Type::UINT32; break;
+        case 64: id = sgn ? Type::INT64 : Type::UINT64; break;
+        default: return Invalid("field '" + out->name + "': integer of " + std::to_string(bits) + " bits");
+      }
+      break;
+    }
+    case kTypeFloatingPoint: {
+      const int prec = tt ? fb.scalar<int16_t>(tt, 0, 0) : 0;  // HALF 0, SINGLE 1, DOUBLE 2
+      if (prec == 1) id = Type::FLOAT32;
+      else if (prec == 2) id = Type::FLOAT64;
+      else return NotImpl("field '" + out->name + "': float16");
+      break;
+    }
+    case kTypeBool: id = Type::BOOL; break;
+    case kTypeUtf8: id = Type::STRING; break;
+    case kTypeBinary: id = Type::BINARY; break;
+    case kTypeLargeUtf8: id = Type::LARGE_STRING; break;
+    case kTypeLargeBinary: id = Type::LARGE_BINARY; break;
+    default: return NotImpl("field '" + out->name + "' has flatbuf type " + std::to_string(type_type));
+  }
+  out->type = GetDataType(id);
+  return Status::OK();
+}
+
+}  // namespace
+
+// message.go:207-287: [continuation 0xFFFFFFFF] [int32 metadata bytes] [metadata, padded] [body];
+// a length of 0 (with or without the continuation word) or the end of the bytes ends the stream;
+// a first word that is not the continuation token is the pre-0.15 framing (the length itself).
+Status StreamReader::NextMessage(bool* have, const uint8_t** meta, int64_t* meta_len, const uint8_t** body, int64_t* body_len) {
+  *have = false;
+  if (pos_ == n_) return Status::OK();
+  if (n_ - pos_ < 4) return Invalid("could not read continuation indicator");
+  uint32_t word;
+  std::memcpy(&word, p_ + pos_, 4);
+  pos_ += 4;
+  int32_t mlen;
+  if (word == 0) return Status::OK();
+  if (word == 0xFFFFFFFFu) {
+    if (n_ - pos_ < 4) return Invalid("could not read message length");
+    std::memcpy(&mlen, p_ + pos_, 4);
+    pos_ += 4;
+    if (mlen == 0) return Status::OK();
+  } else {
+    mlen = (int32_t)word;
+  }
+  if (mlen < 4) return Invalid("invalid message metadata length " + std::to_string(mlen));
+  if (mlen > n_ - pos_) return Invalid("could not read message metadata");
+  *meta = p_ + pos_;
+  *meta_len = mlen;
+  pos_ += mlen;
+  Fb fb{*meta, *meta_len};
+  const int64_t msg = fb.root();
+  const int64_t blen = fb.scalar<int64_t>(msg, 3, 0);
+  if (fb.bad) return Invalid("invalid message metadata");
+  if (blen < 0) return Invalid("invalid message body length " + std::to_string(blen));
+  if (blen > n_ - pos_) return Invalid("could not read message body");
+  *body = p_ + pos_;
+  *body_len = blen;
+  pos_ += blen;
+  *have = true;
+  return Status::OK();
+}
+
+Status StreamReader::Open(Session* s, const uint8_t* bytes, int64_t len, std::unique_ptr<StreamReader>* out) {
+  std::unique_ptr<StreamReader> r(new StreamReader());
+  r->s_ = s;
+  r->p_ = bytes;
+  r->n_ = len;
+  bool have;
+  const uint8_t *meta, *body;
+  int64_t mlen, blen;
+  AHC_RETURN_NOT_OK(r->NextMessage(&have, &meta, &mlen, &body, &blen));
+  if (!have) return Invalid("stream holds no schema message");  // reader.go:148-160 getSchema
+  Fb fb{meta, mlen};
+  const int64_t msg = fb.root();
+  if (fb.scalar<uint8_t>(msg, 1, 0) != kHeaderSchema) return Invalid("invalid message type (got=" + std::to_string(fb.scalar<uint8_t>(msg, 1, 0)) + ", want=Schema)");
+  const int64_t sch = fb.indirect(msg, 2);
+  if (!sch || fb.bad) return Invalid("invalid message metadata");
+  if (fb.scalar<int16_t>(sch, 0, 0) != 0) return NotImpl("big-endian stream");
+  const int64_t fv = fb.indirect(sch, 1);
+  const int64_t nf = fb.vec_len(fv);
+  for (int64_t i = 0; i < nf && !fb.bad; i++) {
+    const int64_t slot = fv + 4 + 4 * i;
+    const int64_t f = slot + (int64_t)fb.rd<uint32_t>(slot);
+    FieldInfo fi;
+    AHC_RETURN_NOT_OK(DecodeField(fb, f, &fi));
+    r->fields_.push_back(std::move(fi));
+  }
+  if (fb.bad) return Invalid("invalid message metadata");
+  *out = std::move(r);
+  return Status::OK();
+}
+
+// reader.go:249-300 (next) + file_reader.go:523-575 (newRecordBatch) + arrayLoaderContext (:660-…):
+// nodes and buffers are consumed in field order — validity, then data (fixed width / bool) or
+// offsets + data (binary).
+Status StreamReader::Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_t* rows) {
+  const bool dry = columns == nullptr;  // validate the metadata against the body, move nothing
+  if (!dry) columns->clear();
+  *rows = 0;
+  const uint8_t *meta, *body;
+  int64_t mlen, blen;
+  for (;;) {
+    AHC_RETURN_NOT_OK(NextMessage(have, &meta, &mlen, &body, &blen));
+    if (!*have) return Status::OK();
+    Fb probe{meta, mlen};
+    const int ht = probe.scalar<uint8_t>(probe.root(), 1, 0);
+    if (probe.bad) return Invalid("invalid message metadata");
+    if (ht == kHeaderRecordBatch) break;
+    if (ht == kHeaderDictionaryBatch) return NotImpl("dictionary batch");
+    return Invalid("invalid message type (got=" + std::to_string(ht) + ", want=RecordBatch)");
+  }
+  Fb fb{meta, mlen};
+  const int64_t rb = fb.indirect(fb.root(), 2);
+  if (!rb || fb.bad) return Invalid("invalid message metadata");
+  const int64_t nrows = fb.scalar<int64_t>(rb, 0, 0);
+  const int64_t nodes = fb.indirect(rb, 1), bufs = fb.indirect(rb, 2);
+  const int64_t n_nodes = fb.vec_len(nodes), n_bufs = fb.vec_len(bufs);
+  if (fb.field(rb, 3)) return NotImpl("compressed record batch body");
+  if (nrows < 0 || fb.bad) return Invalid("invalid message metadata");
+  if (n_nodes != (int64_t)fields_.size()) return Invalid("record batch has " + std::to_string(n_nodes) + " field nodes, the schema " + std::to_string(fields_.size()) + " fields");
+
+  // the whole body in one transfer; columns are slices of it
+  BufferPtr dev;
+  if (!dry) AHC_RETURN_NOT_OK(s_->Allocate(blen, &dev));
+  if (!dry && blen > 0) {
+    AHC_RETURN_NOT_OK(s_->FromStatus(ah_upload_async(s_->ctx(), dev->dptr, body, (size_t)blen)));
+    AHC_RETURN_NOT_OK(s_->FromStatus(ah_sync(s_->ctx())));
+    uploaded_ += blen;
+  }
+  int64_t ib = 0;
+  auto next_buffer = [&](int64_t* off, int64_t* len) -> Status {
+    if (ib >= n_bufs) return Invalid("buffer index out of bound");
+    const int64_t e = bufs + 4 + 16 * ib++;  // struct Buffer { offset: long; length: long }
+    *off = fb.rd<int64_t>(e);
+    *len = fb.rd<int64_t>(e + 8);
+    if (fb.bad) return Invalid("invalid message metadata");
+    if (*off < 0 || *len < 0 || *off > blen || *len > blen - *off) return Invalid("buffer [" + std::to_string(*off) + ", +" + std::to_string(*len) + ") lies outside the " + std::to_string(blen) + "-byte body");
+    if (*len > 0 && (*off & 7)) return Invalid("buffer offset " + std::to_string(*off) + " is not 8-byte aligned");
+    return Status::OK();
+  };
+  auto slice = [&](int64_t off, int64_t len) -> BufferPtr {
+    if (dry) return nullptr;
+    auto b = std::make_shared<Buffer>();
+    b->session = s_;
+    b->dptr = (uint8_t*)dev->dptr + off;
+    b->size = len;
+    b->owned = false;
+    b->owner = dev;
+    return b;
+  };
+  for (size_t i = 0; i < fields_.size(); i++) {
+    const FieldInfo& fi = fields_[i];
+    const int64_t ne = nodes + 4 + 16 * (int64_t)i;  // struct FieldNode { length: long; null_count: long }
+    const int64_t flen = fb.rd<int64_t>(ne), fnulls = fb.rd<int64_t>(ne + 8);
+    if (fb.bad) return Invalid("invalid message metadata");
+    if (flen != nrows) return Invalid("field '" + fi.name + "' has " + std::to_string(flen) + " rows, the batch " + std::to_string(nrows));
+    if (fnulls < 0 || fnulls > flen) return Invalid("field '" + fi.name + "': null count " + std::to_string(fnulls));
+    auto d = std::make_shared<ArrayData>();
+    d->type = fi.type;
+    d->length = flen;
+    d->offset = 0;
+    int64_t off, len;
+    AHC_RETURN_NOT_OK(next_buffer(&off, &len));
+    if (fnulls > 0) {
+      if (len < (flen + 7) / 8) return Invalid("field '" + fi.name + "': validity bitmap of " + std::to_string(len) + " bytes for " + std::to_string(flen) + " rows");
+      d->buffers[0] = slice(off, len);
+      d->null_count = fnulls;
+    } else {
+      d->null_count = 0;  // a bitmap that is present but all set is dropped, like loadCommon (file_reader.go:700-712)
+    }
+    const int w = fi.type->bit_width / 8;
+    if (IsBaseBinary(fi.type->id)) {
+      AHC_RETURN_NOT_OK(next_buffer(&off, &len));
+      if (flen > 0 && len < (flen + 1) * w) return Invalid("field '" + fi.name + "': offsets buffer of " + std::to_string(len) + " bytes for " + std::to_string(flen) + " rows");
+      if (len == 0 && !dry) {  // an empty array may carry no offsets at all: give it the single zero Arrow asks for
+        BufferPtr z;
+        AHC_RETURN_NOT_OK(s_->Allocate(w, &z));
+        AHC_RETURN_NOT_OK(s_->FromStatus(ah_memset_async(s_->ctx(), z->dptr, 0, (size_t)w)));
+        d->buffers[1] = z;
+      } else {
+        d->buffers[1] = slice(off, len);
+      }
+      const int64_t ooff = off, olen = len;
+      AHC_RETURN_NOT_OK(next_buffer(&off, &len));
+      d->buffers[2] = slice(off, len);
+      if (olen > 0) {  // the body is still on the host: the first and last offset bound every device read of the data
+        int64_t first, last;
+        if (w == 4) { int32_t a, b; std::memcpy(&a, body + ooff, 4); std::memcpy(&b, body + ooff + flen * 4, 4); first = a; last = b; }
+        else { std::memcpy(&first, body + ooff, 8); std::memcpy(&last, body + ooff + flen * 8, 8); }
+        if (first < 0 || last < first || last > len) return Invalid("field '" + fi.name + "': offsets [" + std::to_string(first) + ", " + std::to_string(last) + "] do not fit the " + std::to_string(len) + "-byte data buffer");
+      }
+    } else {
+      AHC_RETURN_NOT_OK(next_buffer(&off, &len));
+      const int64_t need = fi.type->bit_width == 1 ? (flen + 7) / 8 : flen * w;
+      if (len < need) return Invalid("field '" + fi.name + "': data buffer of " + std::to_string(len) + " bytes for " + std::to_string(flen) + " rows");
+      d->buffers[1] = slice(off, len);
+    }
+    if (!dry) columns->push_back(d);
+  }
+  *rows = nrows;
+  return Status::OK();
+}
+
+}  // namespace ipc
+}  // namespace arrowhip

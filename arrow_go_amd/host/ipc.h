@@ -1,0 +1,50 @@
+// Arrow IPC *stream* → record batches resident in HBM.
+//
+// What ipc.NewReader / Reader.Next do on the host (arrow/ipc/reader.go:97-120,202-300;
+// message framing message.go:207-287; batch assembly file_reader.go:523-575, buffers :583-616,
+// type decoding metadata.go) with one difference in where the bytes land: the body of a RecordBatch
+// message is sent to the device with ONE copy and every column buffer becomes a slice of that one
+// allocation — the IPC body is already laid out as Arrow buffers (8-byte aligned, validity / offsets /
+// data in field order), so nothing is unpacked on the host.
+//
+// Scope: flat columns of the types the kernels take — Int8..Uint64, Float32/64, Bool, Utf8 / Binary and
+// their Large variants; little-endian; uncompressed; no dictionary batches.  Anything else is
+// ErrNotImplemented with the field named.  The metadata is a FlatBuffer (format/Message.fbs,
+// Schema.fbs); it is read with the small bounds-checked accessor in ipc.cc — the bytes come from a
+// file or a socket and are not trusted.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "arrowhip_compute.h"
+
+namespace arrowhip {
+namespace ipc {
+
+struct FieldInfo {
+  std::string name;
+  const DataType* type = nullptr;
+  bool nullable = true;
+};
+
+class StreamReader {
+ public:
+  // Parses the Schema message.  `bytes` must stay alive and unchanged while the reader is used.
+  static Status Open(Session* s, const uint8_t* bytes, int64_t len, std::unique_ptr<StreamReader>* out);
+  const std::vector<FieldInfo>& fields() const { return fields_; }
+  // Next record batch: *have = false at the end of the stream (EOS marker or end of bytes).
+  // columns == nullptr: only check the batch's metadata against its body (no session needed).
+  Status Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_t* rows);
+  int64_t body_bytes_uploaded() const { return uploaded_; }
+
+ private:
+  Status NextMessage(bool* have, const uint8_t** meta, int64_t* meta_len, const uint8_t** body, int64_t* body_len);
+  Session* s_ = nullptr;
+  const uint8_t* p_ = nullptr;
+  int64_t n_ = 0, pos_ = 0, uploaded_ = 0;
+  std::vector<FieldInfo> fields_;
+};
+
+}  // namespace ipc
+}  // namespace arrowhip

@@ -1,0 +1,144 @@
+"""Arrow IPC stream → HBM: the host-side FlatBuffer / framing reader is checked
+against streams written by pyarrow without a GPU; the upload path on the GPU box.
+Reference behaviour: arrow/ipc/reader.go:97-300, message.go:207-287, file_reader.go:523-616."""
+import struct
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from arrow_go_amd import compute as ac
+
+TYPES = [pa.int8(), pa.uint8(), pa.int16(), pa.uint16(), pa.int32(), pa.uint32(), pa.int64(), pa.uint64(), pa.float32(), pa.float64(),
+         pa.bool_(), pa.string(), pa.binary(), pa.large_string(), pa.large_binary()]
+NAMES = {"float": "float", "double": "double"}
+
+
+def random_column(rng, typ, n, p_null):
+    mask = rng.random(n) < p_null if p_null else None
+    if pa.types.is_boolean(typ):
+        return pa.array(rng.random(n) < 0.5, mask=mask, type=typ)
+    if pa.types.is_floating(typ):
+        return pa.array(rng.normal(size=n), mask=mask, type=typ)
+    if pa.types.is_integer(typ):
+        info = np.iinfo(typ.to_pandas_dtype())
+        return pa.array(rng.integers(info.min, info.max, n, dtype=typ.to_pandas_dtype(), endpoint=True), mask=mask, type=typ)
+    words = [("w%d" % i) * (i % 7) for i in range(50)]
+    vals = [words[j] for j in rng.integers(0, len(words), n)]
+    if pa.types.is_binary(typ) or pa.types.is_large_binary(typ):
+        vals = [v.encode() for v in vals]
+    return pa.array(vals, mask=mask, type=typ)
+
+
+def make_stream(batches, schema):
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, schema) as w:
+        for b in batches:
+            w.write_batch(b)
+    return sink.getvalue()
+
+
+def sample_stream(seed=0, sizes=(1000, 0, 7, 4097)):
+    rng = np.random.default_rng(seed)
+    schema = pa.schema([pa.field("c%d_%s" % (i, t), t, nullable=(i % 3 != 0)) for i, t in enumerate(TYPES)])
+    batches = [pa.record_batch([random_column(rng, t, n, 0.2 if i % 3 else 0.0) for i, t in enumerate(TYPES)], schema=schema) for n in sizes]
+    return schema, batches, make_stream(batches, schema)
+
+
+def test_inspect_schema_and_batches():
+    schema, batches, buf = sample_stream()
+    fields, rows = ac.ipc_inspect(buf)
+    assert [f[0] for f in fields] == schema.names
+    assert [f[1] for f in fields] == [{"float": "float", "double": "double"}.get(str(t), str(t)) for t in schema.types]
+    assert [f[2] for f in fields] == [f.nullable for f in schema]
+    assert rows == [b.num_rows for b in batches]
+    # plain bytes and a schema-only stream
+    assert ac.ipc_inspect(buf.to_pybytes())[1] == rows
+    assert ac.ipc_inspect(make_stream([], schema)) == (fields, [])
+
+
+def test_inspect_rejects_what_it_does_not_read():
+    d = pa.array(["a", "b", "a"]).dictionary_encode()
+    with pytest.raises(ac.ErrNotImplemented, match="dictionary"):
+        ac.ipc_inspect(make_stream([pa.record_batch([d], names=["d"])], pa.schema([("d", d.type)])))
+    l = pa.array([[1, 2], [3]])
+    with pytest.raises(ac.ErrNotImplemented, match="nested|flatbuf type"):
+        ac.ipc_inspect(make_stream([pa.record_batch([l], names=["l"])], pa.schema([("l", l.type)])))
+    t = pa.array([1, 2], type=pa.timestamp("s"))
+    with pytest.raises(ac.ErrNotImplemented, match="flatbuf type"):
+        ac.ipc_inspect(make_stream([pa.record_batch([t], names=["t"])], pa.schema([("t", t.type)])))
+    sink = pa.BufferOutputStream()
+    schema = pa.schema([("x", pa.int64())])
+    with pa.ipc.new_stream(sink, schema, options=pa.ipc.IpcWriteOptions(compression="lz4")) as w:
+        w.write_batch(pa.record_batch([pa.array(range(1000))], schema=schema))
+    with pytest.raises(ac.ErrNotImplemented, match="compressed"):
+        ac.ipc_inspect(sink.getvalue())
+
+
+def test_inspect_survives_damaged_streams():
+    """truncations and bit flips anywhere in the metadata end in an error (or a shorter stream), never a crash"""
+    _, _, buf = sample_stream(1, sizes=(100, 33))
+    raw = buf.to_pybytes()
+    with pytest.raises(ac.ErrInvalid):
+        ac.ipc_inspect(b"")
+    with pytest.raises(ac.ErrInvalid):
+        ac.ipc_inspect(raw[:3])
+    ok = bad = 0
+    for cut in list(range(4, 600, 7)) + list(range(600, len(raw), 997)):
+        try:
+            ac.ipc_inspect(raw[:cut]); ok += 1
+        except ac.ArrowError:
+            bad += 1
+    assert bad > 0
+    rng = np.random.default_rng(2)
+    meta_end = 8 + struct.unpack("<i", raw[4:8])[0]
+    for _ in range(400):
+        b = bytearray(raw)
+        pos = int(rng.integers(0, min(len(raw), meta_end + 2000)))
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            ac.ipc_inspect(bytes(b))
+        except ac.ArrowError:
+            pass
+    # a body shorter than the metadata says
+    with pytest.raises(ac.ErrInvalid, match="body"):
+        ac.ipc_inspect(raw[:-64])
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = ac.Session(0)
+    yield s
+    s.close()
+
+
+@pytest.mark.gpu
+def test_read_ipc_round_trip(sess):
+    schema, batches, buf = sample_stream(3)
+    got = list(sess.read_ipc(buf))
+    assert len(got) == len(batches)
+    for (names, cols, rows), b in zip(got, batches):
+        assert names == schema.names and rows == b.num_rows
+        for c, exp in zip(cols, b.columns):
+            assert c.to_arrow().equals(exp)
+    # the columns are ordinary device arrays: compute on them without leaving HBM
+    names, cols, rows = got[0]
+    i64 = cols[names.index("c6_int64")]
+    out = sess.call_function("add_unchecked", [i64, i64])
+    import pyarrow.compute as pc
+    assert out.equals(pc.add(batches[0].column(6), batches[0].column(6)))
+    s = cols[names.index("c11_string")]
+    assert sess.call_function("unique", [s]).equals(pc.unique(batches[0].column(11)))
+
+
+@pytest.mark.gpu
+def test_read_ipc_large_batch(sess):
+    rng = np.random.default_rng(4)
+    n = 1 << 22
+    schema = pa.schema([("k", pa.int64()), ("v", pa.float64())])
+    b = pa.record_batch([pa.array(rng.integers(0, 1000, n)), pa.array(rng.normal(size=n))], schema=schema)
+    buf = make_stream([b, b.slice(5, 1000)], schema)
+    got = list(sess.read_ipc(buf))
+    assert [g[2] for g in got] == [n, 1000]
+    assert sess.math_sum(got[0][1][0]) == int(np.asarray(b.column(0)).sum())
+    assert got[1][1][1].to_arrow().equals(b.column(1).slice(5, 1000))
