@@ -101,6 +101,7 @@ _SIGS = {
     "ah_upload_async": [_vp, _vp, _vp, _sz],
     "ah_download_async": [_vp, _vp, _vp, _sz],
     "ah_memset_async": [_vp, _vp, _int, _sz],
+    "ah_copy_async": [_vp, _vp, _vp, _sz],
     "ah_sync": [_vp],
     "ah_timer_start": [_vp],
     "ah_timer_stop": [_vp, _pf],

@@ -46,6 +46,9 @@ lib.ahc_registry_add_alias.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_int]
 lib.ahc_import_device.argtypes = [_vp, _vp, _vp, C.POINTER(_vp)]
 lib.ahc_export_device.argtypes = [_vp, _vp, _vp, _vp]
 lib.ahc_datum_buffers.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]
+lib.ahc_chunked_from_arrays.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]
+lib.ahc_datum_num_chunks.argtypes = [_vp]
+lib.ahc_datum_chunk.argtypes = [_vp, _vp, C.c_int, C.POINTER(_vp)]
 lib.ahc_ipc_open.argtypes = [_vp, _vp, C.c_int64, C.POINTER(_vp)]
 lib.ahc_ipc_close.argtypes = [_vp]
 lib.ahc_ipc_close.restype = None
@@ -227,8 +230,19 @@ class Session:
     # -- datum plumbing
     def _import(self, arr):
         import pyarrow as pa
-        if isinstance(arr, pa.ChunkedArray):
-            arr = arr.combine_chunks()
+        if isinstance(arr, pa.ChunkedArray):  # compute.ChunkedDatum: every chunk uploaded, chunk boundaries kept
+            tname = str(arr.type)
+            if tname not in _TYPE_IDS:
+                raise ErrNotImplemented(f"unsupported chunked type {tname}")
+            parts = [self._import(c) for c in arr.chunks]
+            try:
+                d = _vp()
+                handles = (_vp * max(len(parts), 1))(*parts)
+                self._check(lib.ahc_chunked_from_arrays(self.h, _TYPE_IDS[tname], len(parts), handles, C.byref(d)))
+                return d
+            finally:
+                for p in parts:
+                    lib.ahc_datum_release(p)
         a = (C.c_uint8 * 80)()
         s = (C.c_uint8 * 72)()
         arr._export_to_c(C.addressof(a), C.addressof(s))
@@ -308,6 +322,20 @@ class Session:
                 return pa.scalar(None, type=typ)
             fmt = _PACK[tid.value]
             return pa.scalar(struct.unpack(fmt, bytes(val)[:struct.calcsize(fmt)])[0], type=typ)
+        if kind.value == 3:  # chunked
+            parts = []
+            for i in range(lib.ahc_datum_num_chunks(d)):
+                c = _vp()
+                self._check(lib.ahc_datum_chunk(self.h, d, i, C.byref(c)))
+                try:
+                    parts.append(self._export(c))
+                finally:
+                    lib.ahc_datum_release(c)
+            if parts:
+                return pa.chunked_array(parts)
+            name = {v: k for k, v in _TYPE_IDS.items()}[tid.value]
+            typ = {"float": pa.float32(), "double": pa.float64(), "bool": pa.bool_()}.get(name) or getattr(pa, name)()
+            return pa.chunked_array([], type=typ)
         a = (C.c_uint8 * 80)()
         s = (C.c_uint8 * 72)()
         self._check(lib.ahc_export(self.h, d, C.addressof(a), C.addressof(s)))

@@ -162,6 +162,14 @@ AH_EXPORT int ah_memset_async(ah_ctx* c, void* dptr, int byte_value, size_t nbyt
   return AH_OK;
 }
 
+AH_EXPORT int ah_copy_async(ah_ctx* c, void* dst, const void* src, size_t nbytes) {
+  AH_ENTER(c);
+  if (nbytes == 0) return AH_OK;
+  if (!dst || !src) return ah_fail(c, AH_EINVALID, "copy: null buffer");
+  AH_HIP(c, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, c->stream));
+  return AH_OK;
+}
+
 AH_EXPORT int ah_sync(ah_ctx* c) {
   AH_ENTER(c);
   AH_HIP(c, hipStreamSynchronize(c->copy_stream));

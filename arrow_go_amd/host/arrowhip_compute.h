@@ -237,16 +237,34 @@ struct CumulativeOptions : FunctionOptions { ScalarPtr Start; bool SkipNulls = f
 struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
 
 // compute.Datum (datum.go:35-40): array or scalar
-enum class DatumKind { None, Scalar, Array };
+enum class DatumKind { None, Scalar, Array, Chunked };
 struct Datum {
   DatumKind kind = DatumKind::None;
   ArrayDataPtr array;
   ScalarPtr scalar;
+  std::vector<ArrayDataPtr> chunks;       // ChunkedDatum (datum.go:186-230): arrow.Chunked = type + chunk list
+  const DataType* chunked_type = nullptr;
   static Datum Of(ArrayDataPtr a) { Datum d; d.kind = DatumKind::Array; d.array = std::move(a); return d; }
   static Datum Of(ScalarPtr s) { Datum d; d.kind = DatumKind::Scalar; d.scalar = std::move(s); return d; }
-  const DataType* type() const { return kind == DatumKind::Array ? array->type : (kind == DatumKind::Scalar ? scalar->type : nullptr); }
-  int64_t Len() const { return kind == DatumKind::Array ? array->length : 1; }
+  static Datum OfChunks(const DataType* t, std::vector<ArrayDataPtr> c) {
+    Datum d; d.kind = DatumKind::Chunked; d.chunked_type = t; d.chunks = std::move(c); return d;
+  }
+  const DataType* type() const {
+    return kind == DatumKind::Array ? array->type : kind == DatumKind::Scalar ? scalar->type : kind == DatumKind::Chunked ? chunked_type : nullptr;
+  }
+  int64_t Len() const {
+    if (kind == DatumKind::Chunked) { int64_t n = 0; for (auto& c : chunks) n += c->length; return n; }
+    return kind == DatumKind::Array ? array->length : 1;
+  }
+  bool IsArrayLike() const { return kind == DatumKind::Array || kind == DatumKind::Chunked; }
 };
+
+// array.Concatenate (arrow/array/concat.go:41-110) for the layouts of this path, done in HBM: validity and
+// boolean data through the bit-offset bitmap copy, fixed-width values with one device copy per chunk,
+// var-length offsets rebased with the arr∘scalar Add kernel.  A single chunk is returned as is.
+Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const DataType* type, ArrayDataPtr* out);
+// array.NewSliceData: zero-copy view
+ArrayDataPtr SliceData(const ArrayDataPtr& a, int64_t off, int64_t len);
 
 class FunctionRegistry;
 // compute.ExecCtx (executor.go:46-64) — the registry travels with the context, so a child
@@ -305,6 +323,16 @@ class VectorFunction : public Function {  // functions.go:290-360
   int NumKernels() const override { return (int)kernels_.size(); }
   Status DispatchExact(const std::vector<const DataType*>& types, const exec::VectorKernel** out) const;
   Status Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) override;
+  // What the function returns for chunked input — the visible outcome of VectorKernel.CanExecuteChunkWise /
+  // ExecChunked / OutputChunked / Finalize in the reference (exec/kernel.go:697-725, executor.go:896-1080):
+  enum class Chunked {
+    SameLength,   // one output row per input row, re-chunked like the input (dictionary_encode: vector_hash.go:905)
+    SingleArray,  // state accumulated over the chunks, one array out (unique: vector_hash.go:890, Finalize; sort_indices)
+    SingleChunk,  // ExecChunked returning one result (cumulative_sum: vector_cumulative.go:368-391)
+    Filter,       // chunk-wise with data-dependent lengths (array_filter)
+    Take,         // the take meta function's rules (selection.go:195-330)
+  };
+  Chunked chunked = Chunked::SameLength;
  private:
   std::vector<exec::VectorKernel> kernels_;
 };

@@ -588,6 +588,30 @@ AHC_EXPORT int ahc_expr_eval(ahc_session* s, const char* text, int ncols, ahc_da
   return 0;
 }
 
+// ---- chunked datums (compute.ChunkedDatum, datum.go:186-230) ----------------------------------------------------
+// A chunked datum is assembled from array datums already on the device (the arrays stay owned by the caller).
+AHC_EXPORT int ahc_chunked_from_arrays(ahc_session* s, int type_id, int n, ahc_datum** arrays, ahc_datum** out) {
+  *out = nullptr;
+  const DataType* t = GetDataType((Type)type_id);
+  if (!t) return Fail(s, Status::Make(StatusCode::Invalid, "unknown type id " + std::to_string(type_id)));
+  std::vector<ArrayDataPtr> chunks;
+  for (int i = 0; i < n; i++) {
+    if (arrays[i]->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "chunks must be arrays"));
+    if (arrays[i]->d.array->type->id != t->id)
+      return Fail(s, Status::Make(StatusCode::Invalid, std::string("arrow/array: mismatch data type ") + arrays[i]->d.array->type->name + " vs " + t->name));  // arrow/table.go NewChunked
+    chunks.push_back(arrays[i]->d.array);
+  }
+  *out = new ahc_datum{Datum::OfChunks(t, std::move(chunks))};
+  return 0;
+}
+AHC_EXPORT int ahc_datum_num_chunks(ahc_datum* d) { return d->d.kind == DatumKind::Chunked ? (int)d->d.chunks.size() : -1; }
+AHC_EXPORT int ahc_datum_chunk(ahc_session* s, ahc_datum* d, int i, ahc_datum** out) {
+  *out = nullptr;
+  if (d->d.kind != DatumKind::Chunked || i < 0 || i >= (int)d->d.chunks.size()) return Fail(s, Status::Make(StatusCode::Invalid, "chunk index out of range"));
+  *out = new ahc_datum{Datum::Of(d->d.chunks[i])};
+  return 0;
+}
+
 // ---- Arrow IPC stream → HBM-resident record batches (ipc.NewReader / Reader.Next, arrow/ipc/reader.go:97,202) ----
 struct ahc_ipc_reader {
   ahc_session* s;

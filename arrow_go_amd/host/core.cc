@@ -5,6 +5,7 @@
 #include <algorithm>
 #include "arrowhip_compute.h"
 
+#include <climits>
 #include <cstring>
 #include <mutex>
 #include <sstream>
@@ -516,10 +517,220 @@ std::unique_ptr<FunctionRegistry> NewChildRegistry(FunctionRegistry* parent) {
   return std::unique_ptr<FunctionRegistry>(new FunctionRegistry(parent));
 }
 
+// ---- chunked arguments -------------------------------------------------------------------------
+// The reference walks chunked inputs span by span on the host (iterateExecSpans, executor.go:750-870:
+// spans end wherever any argument's chunk ends) and calls the kernel once per span.  A launch per small
+// chunk is the wrong shape for this device, so the chunks of every chunked argument are laid end to end
+// in HBM (Concatenate: device-to-device copies), the kernel runs ONCE, and the result is cut back into
+// zero-copy slices at exactly the boundaries the reference's spans would have produced.  Row for row
+// the results are the same: every kernel on this path is either element-wise or defined on the
+// logical concatenation (unique, dictionary_encode, cumulative_sum, sort_indices carry state across
+// chunks in the reference too).
+ArrayDataPtr SliceData(const ArrayDataPtr& a, int64_t off, int64_t len) {
+  auto d = std::make_shared<ArrayData>(*a);
+  d->offset = a->offset + off;
+  d->length = len;
+  d->null_count = (a->null_count == 0 || !a->buffers[0]) ? 0 : (off == 0 && len == a->length ? a->null_count : kUnknownNullCount);
+  return d;
+}
+
+Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const DataType* type, ArrayDataPtr* out) {
+  if (chunks.size() == 1) { *out = chunks[0]; return Status::OK(); }
+  auto d = std::make_shared<ArrayData>();
+  d->type = type;
+  int64_t total = 0;
+  bool nulls = false;
+  for (auto& c : chunks) {
+    if (c->type->id != type->id) return Status::Make(StatusCode::Invalid, "arrays to be concatenated must be identically typed, but " + std::string(type->name) + " and " + c->type->name + " were encountered.");  // concat.go:53-56
+    total += c->length;
+    nulls = nulls || (c->buffers[0] && c->null_count != 0);
+  }
+  d->length = total;
+  d->null_count = nulls ? kUnknownNullCount : 0;
+  auto bitmap = [&](int which, BufferPtr* dst) -> Status {  // validity (which = 0) or boolean data (which = 1), bit by bit offset
+    AHC_RETURN_NOT_OK(s->AllocateBitmap(total, dst));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), (*dst)->dptr, 0, (size_t)((total + 7) / 8))));
+    int64_t pos = 0;
+    for (auto& c : chunks) {
+      if (c->length == 0) continue;
+      if (c->buffers[which] && !(which == 0 && c->null_count == 0))
+        AHC_RETURN_NOT_OK(s->FromStatus(ah_copy_bitmap(s->ctx(), (const uint8_t*)c->buffers[which]->dptr, c->offset, c->length, (uint8_t*)(*dst)->dptr, pos, 0)));
+      else
+        AHC_RETURN_NOT_OK(s->FromStatus(ah_set_bits_to(s->ctx(), (uint8_t*)(*dst)->dptr, pos, c->length, 1)));
+      pos += c->length;
+    }
+    return Status::OK();
+  };
+  if (nulls) AHC_RETURN_NOT_OK(bitmap(0, &d->buffers[0]));
+  const int w = type->bit_width / 8;
+  if (type->bit_width == 1) {
+    AHC_RETURN_NOT_OK(bitmap(1, &d->buffers[1]));
+  } else if (IsBaseBinary(type->id)) {
+    // value ranges: first and last offset of every chunk (concat.go:182-200 / 300-322 concatOffsets)
+    std::vector<int64_t> first(chunks.size(), 0), last(chunks.size(), 0);
+    std::vector<uint8_t> host(chunks.size() * 16, 0);
+    for (size_t i = 0; i < chunks.size(); i++) {
+      auto& c = chunks[i];
+      if (c->length == 0 || !c->buffers[1]) continue;
+      const uint8_t* o = (const uint8_t*)c->buffers[1]->dptr;
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), &host[i * 16], o + c->offset * w, (size_t)w)));
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), &host[i * 16 + 8], o + (c->offset + c->length) * w, (size_t)w)));
+    }
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+    int64_t bytes = 0;
+    for (size_t i = 0; i < chunks.size(); i++) {
+      if (w == 4) { int32_t a, b; memcpy(&a, &host[i * 16], 4); memcpy(&b, &host[i * 16 + 8], 4); first[i] = a; last[i] = b; }
+      else { memcpy(&first[i], &host[i * 16], 8); memcpy(&last[i], &host[i * 16 + 8], 8); }
+      bytes += last[i] - first[i];
+    }
+    if (w == 4 && bytes > INT32_MAX) return Status::Make(StatusCode::Invalid, "offset overflow while concatenating arrays");  // concat.go:197
+    AHC_RETURN_NOT_OK(s->Allocate((total + 1) * w, &d->buffers[1]));
+    AHC_RETURN_NOT_OK(s->Allocate(bytes, &d->buffers[2]));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), d->buffers[1]->dptr, 0, (size_t)w)));
+    int64_t pos = 0, base = 0;
+    for (size_t i = 0; i < chunks.size(); i++) {
+      auto& c = chunks[i];
+      if (c->length == 0) continue;
+      const int64_t delta = base - first[i];  // out_offsets[pos + 1 + j] = in_offsets[offset + 1 + j] + delta
+      const int32_t delta32 = (int32_t)delta;
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_arithmetic_arr_scalar(s->ctx(), w == 4 ? AH_INT32 : AH_INT64, AH_OP_ADD,
+                                                               (const uint8_t*)c->buffers[1]->dptr + (c->offset + 1) * w,
+                                                               w == 4 ? (const void*)&delta32 : (const void*)&delta,
+                                                               (uint8_t*)d->buffers[1]->dptr + (pos + 1) * w, c->length)));
+      if (last[i] > first[i])
+        AHC_RETURN_NOT_OK(s->FromStatus(ah_copy_async(s->ctx(), (uint8_t*)d->buffers[2]->dptr + base, (const uint8_t*)c->buffers[2]->dptr + first[i],
+                                                      (size_t)(last[i] - first[i]))));
+      pos += c->length;
+      base += last[i] - first[i];
+    }
+  } else {
+    AHC_RETURN_NOT_OK(s->Allocate(total * w, &d->buffers[1]));
+    int64_t pos = 0;
+    for (auto& c : chunks) {
+      if (c->length == 0) continue;
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_copy_async(s->ctx(), (uint8_t*)d->buffers[1]->dptr + pos * w, (const uint8_t*)c->buffers[1]->dptr + c->offset * w,
+                                                    (size_t)(c->length * w))));
+      pos += c->length;
+    }
+  }
+  *out = d;
+  return Status::OK();
+}
+
+namespace {
+
+// cut `a` at the given row counts; empty pieces are dropped (WrapResults, executor.go:521-582 / 1000-1080)
+Datum Rechunk(const ArrayDataPtr& a, const std::vector<int64_t>& lens, bool keep_one_if_empty) {
+  std::vector<ArrayDataPtr> pieces;
+  int64_t pos = 0;
+  for (int64_t n : lens) {
+    if (n > 0) pieces.push_back(SliceData(a, pos, n));
+    pos += n;
+  }
+  if (pieces.empty() && keep_one_if_empty) pieces.push_back(SliceData(a, 0, 0));
+  Datum d = Datum::OfChunks(a->type, std::move(pieces));
+  return d;
+}
+
+// span lengths of iterateExecSpans: the union of the chunk boundaries of all chunked arguments
+Status SpanLengths(const std::vector<Datum>& args, std::vector<int64_t>* lens, int64_t* length) {
+  *length = -1;
+  for (auto& a : args) {
+    if (!a.IsArrayLike()) continue;
+    if (*length < 0) *length = a.Len();
+    else if (*length != a.Len()) return Status::Make(StatusCode::Invalid, "array arguments must all be the same length");  // executor.go:352-390
+  }
+  std::vector<int64_t> cuts;
+  for (auto& a : args) {
+    if (a.kind != DatumKind::Chunked) continue;
+    int64_t pos = 0;
+    for (auto& c : a.chunks) { pos += c->length; cuts.push_back(pos); }
+  }
+  std::sort(cuts.begin(), cuts.end());
+  cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+  lens->clear();
+  int64_t prev = 0;
+  for (int64_t c : cuts) { lens->push_back(c - prev); prev = c; }
+  return Status::OK();
+}
+
+Status ExecuteChunked(ExecCtx* ctx, Function* fn, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) {
+  Session* s = ctx ? ctx->session : nullptr;
+  if (!s) return Status::Make(StatusCode::Invalid, "ExecCtx has no device session");
+  if (fn->Kind() == FuncKind::Meta) return fn->Execute(ctx, opts, args, out);  // filter / take / cast / sort forward to their array_* twins
+  std::vector<Datum> flat = args;
+  for (auto& a : flat) {
+    if (a.kind != DatumKind::Chunked) continue;
+    ArrayDataPtr whole;
+    if (a.chunks.empty()) {  // no chunks at all: a zero-length array of the type (MakeArrayOfNull(…, 0), selection.go:270)
+      whole = std::make_shared<ArrayData>();
+      whole->type = a.chunked_type;
+      whole->null_count = 0;
+      AHC_RETURN_NOT_OK(s->Allocate(IsBaseBinary(a.chunked_type->id) ? a.chunked_type->bit_width / 8 : 0, &whole->buffers[1]));
+      if (IsBaseBinary(a.chunked_type->id)) {
+        AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), whole->buffers[1]->dptr, 0, (size_t)(a.chunked_type->bit_width / 8))));
+        AHC_RETURN_NOT_OK(s->Allocate(0, &whole->buffers[2]));
+      }
+    } else {
+      AHC_RETURN_NOT_OK(Concatenate(s, a.chunks, a.chunked_type, &whole));
+    }
+    a = Datum::Of(whole);
+  }
+  auto mode = VectorFunction::Chunked::SameLength;
+  if (fn->Kind() == FuncKind::Vector) mode = static_cast<VectorFunction*>(fn)->chunked;
+  std::vector<int64_t> lens;
+  int64_t length = 0;
+  if (mode == VectorFunction::Chunked::Take) {
+    // selection.go:195-330: a chunked `indices` gives one output chunk per indices chunk; chunked values with
+    // array indices give a one-chunk result
+    Datum res;
+    AHC_RETURN_NOT_OK(fn->Execute(ctx, opts, flat, &res));
+    if (args[1].kind == DatumKind::Chunked) {
+      for (auto& c : args[1].chunks) lens.push_back(c->length);
+      *out = Rechunk(res.array, lens, false);
+    } else {
+      *out = Datum::OfChunks(res.array->type, {res.array});
+    }
+    return Status::OK();
+  }
+  AHC_RETURN_NOT_OK(SpanLengths(args, &lens, &length));
+  Datum res;
+  AHC_RETURN_NOT_OK(fn->Execute(ctx, opts, flat, &res));
+  if (res.kind != DatumKind::Array) { *out = res; return Status::OK(); }
+  switch (mode) {
+    case VectorFunction::Chunked::SingleArray: *out = res; break;
+    case VectorFunction::Chunked::SingleChunk: *out = Datum::OfChunks(res.array->type, {res.array}); break;
+    case VectorFunction::Chunked::Filter: {
+      // one output chunk per span, as long as that span's selection (getFilterOutputSize, vector_selection.go:57-81)
+      const FilterOptions* fo = static_cast<const FilterOptions*>(opts ? opts : fn->DefaultOptions());
+      const int null_sel = fo ? (int)fo->NullSelection : 0;
+      const ArrayData& f = *flat[1].array;
+      const uint8_t* fvalid = (f.buffers[0] && f.null_count != 0) ? (const uint8_t*)f.buffers[0]->dptr : nullptr;
+      std::vector<int64_t> outs;
+      int64_t pos = 0;
+      for (int64_t n : lens) {
+        int64_t cnt = 0;
+        if (n > 0) AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_count(s->ctx(), (const uint8_t*)f.buffers[1]->dptr, fvalid, f.offset + pos, n, null_sel, &cnt)));
+        outs.push_back(cnt);
+        pos += n;
+      }
+      *out = Rechunk(res.array, outs, false);
+      break;
+    }
+    default:
+      *out = Rechunk(res.array, lens, fn->Kind() == FuncKind::Scalar);
+  }
+  return Status::OK();
+}
+
+}  // namespace
+
 Status CallFunction(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) {
   FunctionRegistry* reg = ctx && ctx->Registry ? ctx->Registry : GetFunctionRegistry();
   Function* fn = reg->GetFunction(name);
   if (!fn) return Status::Make(StatusCode::KeyError, "function '" + name + "' not found");  // exec.go:191-199
+  for (auto& a : args)
+    if (a.kind == DatumKind::Chunked) return ExecuteChunked(ctx, fn, opts, args, out);
   return fn->Execute(ctx, opts, args, out);
 }
 

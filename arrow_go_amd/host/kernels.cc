@@ -396,6 +396,7 @@ static const DictionaryEncodeOptions kDefaultDictOptions;
 
 void RegisterVectorSelection(FunctionRegistry* reg) {
   auto af = std::make_shared<VectorFunction>("array_filter", Arity{2, false}, &kDefaultFilterOptions);
+  af->chunked = VectorFunction::Chunked::Filter;
   for (Type t : kNumericTypes) {
     exec::VectorKernel k;
     k.sig.in_types = {t, Type::BOOL};
@@ -416,6 +417,7 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
   }
   reg->AddFunction(af, false);
   auto at = std::make_shared<VectorFunction>("array_take", Arity{2, false}, &kDefaultTakeOptions);
+  at->chunked = VectorFunction::Chunked::Take;
   for (Type t : kNumericTypes)
     for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
       exec::VectorKernel k;
@@ -588,6 +590,7 @@ static Status ExecHashBinary(KernelCtx* k, const ExecSpan& b, ExecResult* out, b
 
 void RegisterVectorHash(FunctionRegistry* reg) {
   auto uq = std::make_shared<VectorFunction>("unique", Arity{1, false});
+  uq->chunked = VectorFunction::Chunked::SingleArray;
   auto de = std::make_shared<VectorFunction>("dictionary_encode", Arity{1, false}, &kDefaultDictOptions);
   for (Type t : kNumericTypes) {
     exec::VectorKernel ku;
@@ -754,10 +757,20 @@ void RegisterScalarSetLookup(FunctionRegistry* reg) {
 // ---- sort_indices / sort ------------------------------------------------------------------------------
 // sortIndicesMetaFunc → sortIndicesImpl (compute/vector_sort.go:42-52, 117-190) → kernels.SortIndices
 // (kernels/vector_sort.go:388-481), array input: one key, ColumnIndex ignored; uint64 indices, no nulls
-static Status SortIndicesImpl(ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
+static Status SortIndicesImpl(ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args_in, Datum* out) {
   const SortOptions* opts = dynamic_cast<const SortOptions*>(o);
   if (!opts || opts->Keys.empty()) return Status::Make(StatusCode::Invalid, "must provide at least one sort key");  // :119-121
   Session* s = ctx->session;
+  // a chunked column is sorted as its logical concatenation: the indices address the whole column
+  // (compute/vector_sort.go:144-148, SortIndicesChunked :226)
+  std::vector<Datum> args = args_in;
+  for (auto& a : args) {
+    if (a.kind != DatumKind::Chunked) continue;
+    if (a.chunks.empty()) return Status::Make(StatusCode::NotImplemented, "sort_indices of a chunked array without chunks");
+    ArrayDataPtr whole;
+    AHC_RETURN_NOT_OK(Concatenate(s, a.chunks, a.chunked_type, &whole));
+    a = Datum::Of(whole);
+  }
   // one array: the first key, ColumnIndex ignored (:130-141); several arrays = the columns of a record batch,
   // every key names its column (:153-166)
   std::vector<SortKey> keys = opts->Keys;
@@ -917,6 +930,7 @@ static const CumulativeOptions kDefaultCumulativeOptions;
 void RegisterVectorCumulative(FunctionRegistry* reg) {
   for (bool checked : {false, true}) {
     auto fn = std::make_shared<VectorFunction>(checked ? "cumulative_sum_checked" : "cumulative_sum", Arity{1, false}, &kDefaultCumulativeOptions);
+    fn->chunked = VectorFunction::Chunked::SingleChunk;
     for (Type t : kNumericTypes) {
       exec::VectorKernel k;
       k.sig.in_types = {t};

@@ -173,7 +173,19 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     timed("min_max_int64", 8 * rows, lambda: ctx.min_max(N.INT64, a, rows, np.int64))
     timed("bitmap_and", 0.375 * rows, lambda: ctx.bitmap_op(N.BIT_AND, mask, 0, vvalid, 0, ovalid, 0, rows))
     timed("count_set_bits", 0.125 * rows, lambda: ctx.count_set_bits(mask, 0, rows))
-    for bfr in (res, mask, vvalid, ovalid, idx):
+    # C5 per GPU: 2^26 Int64 keys (512 MiB; 4 GiB over 8 GPUs) + Float64 values — dictionary_encode and hash + sum.
+    # Algorithmic bytes: 8 (key) + 4 (id) per row for encode, 8 + 8 for the group-by (outputs are per group).
+    hrows = min(rows, 1 << 26)
+    hids = ctx.alloc(hrows * 4 + 64)
+    hdic, hsum, hcnt = (ctx.alloc((hrows + 1) * 8 + 64) for _ in range(3))
+    for lg in (10, 16, 20):
+        kchunk = (rng.integers(0, 1 << lg, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+        for off in range(0, hrows, 1 << 22):
+            c.upload(kchunk[:min(1 << 22, hrows - off)], off * 8)
+        timed("dictionary_encode_int64_2^%d_keys" % lg, 12 * hrows, lambda: ctx.hash_u64_encode(c, None, 0, hrows, False, hids, None, hdic), reps=3)
+        timed("hash_sum_float64_2^%d_groups" % lg, 16 * hrows, lambda: ctx.hash_sum("f64", c, None, 0, x, None, 0, hrows, hdic, hsum, hcnt), reps=3)
+        out["hash_sum_float64_2^%d_groups" % lg]["Grows/s"] = round(hrows / out["hash_sum_float64_2^%d_groups" % lg]["ms"] / 1e6, 2)
+    for bfr in (res, mask, vvalid, ovalid, idx, hids, hdic, hsum, hcnt):
         bfr.free()
     return out
 

@@ -116,6 +116,9 @@ int ah_host_free_pinned(ah_ctx* ctx, void* hptr);
 int ah_upload_async(ah_ctx* ctx, void* dptr, const void* hptr, size_t nbytes);
 int ah_download_async(ah_ctx* ctx, void* hptr, const void* dptr, size_t nbytes);
 int ah_memset_async(ah_ctx* ctx, void* dptr, int byte_value, size_t nbytes); /* arrow/memory/_lib/memory.c:20-27 */
+/* device → device, ordered on the compute stream: the value-range copies of array.Concatenate
+ * (arrow/array/concat.go:159-180 concatBuffers) when chunked inputs are laid end to end in HBM */
+int ah_copy_async(ah_ctx* ctx, void* dst, const void* src, size_t nbytes);
 int ah_sync(ah_ctx* ctx);
 /* hipEvent pair on the compute stream (what bench.py times kernels with). */
 int ah_timer_start(ah_ctx* ctx);

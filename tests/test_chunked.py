@@ -1,0 +1,151 @@
+"""Chunked arguments through CallFunction (compute.ChunkedDatum).  Values are checked against Arrow C++ on the
+logical arrays; the CHUNK LAYOUT of every result against the reference's rules — spans end where any
+argument's chunk ends (iterateExecSpans, arrow/compute/executor.go:750-870), empty outputs are dropped
+(WrapResults :521-582, :1000-1080), `take` follows selection.go:195-330, unique / sort_indices return one
+array, cumulative_sum one chunk (vector_cumulative.go:368-391)."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+from arrow_go_amd import compute as ac
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    s = ac.Session(0)
+    yield s
+    s.close()
+
+
+def chunked(arr, cuts):
+    """split `arr` at the given positions (may repeat → empty chunks)"""
+    edges = [0] + list(cuts) + [len(arr)]
+    return pa.chunked_array([arr.slice(a, b - a) for a, b in zip(edges[:-1], edges[1:])], type=arr.type)
+
+
+def span_lengths(n, *cut_lists):
+    edges = sorted(set([0, n] + [c for cl in cut_lists for c in cl]))
+    return [b - a for a, b in zip(edges[:-1], edges[1:]) if b > a]
+
+
+def layout(c):
+    return [len(x) for x in c.chunks]
+
+
+def rand(rng, typ, n, p_null=0.1):
+    mask = rng.random(n) < p_null
+    if pa.types.is_boolean(typ):
+        return pa.array(rng.random(n) < 0.5, mask=mask, type=typ)
+    if pa.types.is_string(typ) or pa.types.is_large_string(typ):
+        words = ["", "a", "bc", "hello world", "x" * 30] + ["w%d" % i for i in range(40)]
+        return pa.array([words[j] for j in rng.integers(0, len(words), n)], mask=mask, type=typ)
+    if pa.types.is_floating(typ):
+        return pa.array(rng.integers(-1000, 1000, n).astype(np.float64), mask=mask, type=typ)
+    lo = 0 if pa.types.is_unsigned_integer(typ) else -100
+    return pa.array(rng.integers(lo, 100, n), mask=mask, type=typ)
+
+
+def test_scalar_functions_follow_span_boundaries(sess):
+    rng = np.random.default_rng(1)
+    n = 10007
+    a, b = rand(rng, pa.int64(), n), rand(rng, pa.int64(), n)
+    ca, cb = chunked(a, [100, 100, 5000, 9000]), chunked(b, [64, 5000, 7777])
+    out = sess.call_function("add", [ca, cb])
+    assert isinstance(out, pa.ChunkedArray) and layout(out) == span_lengths(n, [100, 5000, 9000], [64, 5000, 7777])
+    assert out.combine_chunks().equals(pc.add_checked(a, b))
+    out = sess.call_function("greater", [ca, b])           # chunked ∘ array
+    assert layout(out) == span_lengths(n, [100, 5000, 9000]) and out.combine_chunks().equals(pc.greater(a, b))
+    out = sess.call_function("multiply_unchecked", [cb, pa.scalar(3, pa.int64())])   # chunked ∘ scalar
+    assert layout(out) == span_lengths(n, [64, 5000, 7777]) and out.combine_chunks().equals(pc.multiply(b, 3))
+    out = sess.call_function("cast", [ca], "to_type=double")
+    assert layout(out) == span_lengths(n, [100, 5000, 9000]) and out.combine_chunks().equals(a.cast(pa.float64()))
+    out = sess.call_function("is_in", [ca], value_set=pa.array([1, 2, 3, None], type=pa.int64()))
+    assert out.combine_chunks().equals(pc.is_in(a, value_set=pa.array([1, 2, 3, None], type=pa.int64())))
+    x, y = rand(rng, pa.bool_(), n), rand(rng, pa.bool_(), n)
+    out = sess.call_function("and_kleene", [chunked(x, [13, 4096]), chunked(y, [8191])])
+    assert layout(out) == span_lengths(n, [13, 4096], [8191]) and out.combine_chunks().equals(pc.and_kleene(x, y))
+    # mismatched total lengths
+    with pytest.raises(ac.ErrInvalid, match="same length"):
+        sess.call_function("add", [ca, chunked(b.slice(0, n - 1), [10])])
+    # no chunks at all / only empty chunks: one empty chunk comes back (the first output is kept)
+    out = sess.call_function("add", [pa.chunked_array([], type=pa.int64()), pa.chunked_array([], type=pa.int64())])
+    assert isinstance(out, pa.ChunkedArray) and len(out) == 0 and out.type == pa.int64()
+
+
+@pytest.mark.parametrize("typ", [pa.int64(), pa.int16(), pa.float64(), pa.bool_(), pa.string(), pa.large_string()], ids=str)
+def test_filter_and_take_chunked(sess, typ):
+    rng = np.random.default_rng(2)
+    n = 6001
+    v, m = rand(rng, typ, n), rand(rng, pa.bool_(), n)
+    vc, mc = [50, 3000, 3000], [2048, 4096]
+    for opt, null_sel in (("", "drop"), ("null_selection_behavior=emit_null", "emit_null")):
+        out = sess.call_function("filter", [chunked(v, vc), chunked(m, mc)], opt)
+        exp = pc.filter(v, m, null_selection_behavior=null_sel)
+        assert out.combine_chunks().equals(exp)
+        edges = sorted(set([0, n] + vc + mc))
+        sel = [len(pc.filter(v.slice(a, b - a), m.slice(a, b - a), null_selection_behavior=null_sel)) for a, b in zip(edges[:-1], edges[1:])]
+        assert layout(out) == [k for k in sel if k > 0]
+    out = sess.call_function("filter", [v, chunked(m, mc)])      # array values, chunked mask
+    assert out.combine_chunks().equals(pc.filter(v, m)) and isinstance(out, pa.ChunkedArray)
+    idx = pa.array(rng.integers(0, n, 2500), mask=rng.random(2500) < 0.1, type=pa.int32())
+    out = sess.call_function("take", [chunked(v, vc), idx])      # chunked values, array indices → one chunk
+    assert layout(out) == [2500] and out.combine_chunks().equals(pc.take(v, idx))
+    out = sess.call_function("take", [v, chunked(idx, [700, 700, 1999])])   # array values, chunked indices → chunk per indices chunk
+    assert layout(out) == [700, 1299, 501] and out.combine_chunks().equals(pc.take(v, idx))
+    out = sess.call_function("take", [chunked(v, vc), chunked(idx, [1, 2000])])
+    assert layout(out) == [1, 1999, 500] and out.combine_chunks().equals(pc.take(v, idx))
+    with pytest.raises(ac.ErrIndex):
+        sess.call_function("take", [chunked(v, vc), pa.array([0, n], type=pa.int64())])   # bounds are those of the whole column
+
+
+@pytest.mark.parametrize("typ", [pa.int64(), pa.uint8(), pa.float64(), pa.string()], ids=str)
+def test_hash_kernels_chunked(sess, typ):
+    rng = np.random.default_rng(3)
+    n = 9000
+    v = rand(rng, typ, n)
+    c = chunked(v, [1, 1, 4500, 8999])
+    out = sess.call_function("unique", [c])                      # vector_hash_test.go:420-449 TestUniqueChunkedArrayInvoke
+    assert isinstance(out, pa.Array) and out.equals(pc.unique(v))
+    for opt, enc in (("", "mask"), ("null_encoding_behavior=encode", "encode")):
+        out = sess.call_function("dictionary_encode", [c], opt)  # :925-… TestDictionaryEncodeChunked*: one dictionary for all chunks
+        exp = pc.dictionary_encode(v, null_encoding=enc)
+        assert layout(out) == [1, 4499, 4499, 1]
+        for ch in out.chunks:
+            assert ch.dictionary.equals(exp.dictionary)
+        assert pa.concat_arrays([ch.indices for ch in out.chunks]).equals(exp.indices)
+    if pa.types.is_string(typ):
+        a1, a2 = pa.array(["foo", "bar", "foo"]), pa.array(["bar", "baz", "quuux", "foo"])
+        assert sess.call_function("unique", [pa.chunked_array([a1, a2])]).to_pylist() == ["foo", "bar", "baz", "quuux"]
+
+
+def test_cumulative_sum_and_sort_chunked(sess):
+    rng = np.random.default_rng(4)
+    n = 20011
+    v = rand(rng, pa.int64(), n)
+    c = chunked(v, [3, 10000, 10000, 15000])
+    out = sess.call_function("cumulative_sum", [c])
+    assert layout(out) == [n] and out.combine_chunks().equals(pc.cumulative_sum(v))
+    out = sess.call_function("cumulative_sum", [c], "skip_nulls=1;start=int64:5")
+    assert out.combine_chunks().equals(pc.cumulative_sum(v, start=5, skip_nulls=True))
+    idx = sess.call_function("sort_indices", [c], "order=descending;null_placement=at_start")
+    assert isinstance(idx, pa.Array) and idx.equals(pc.sort_indices(v, sort_keys=[("", "descending")], null_placement="at_start"))
+    out = sess.call_function("sort", [c], "order=ascending")
+    assert isinstance(out, pa.ChunkedArray) and layout(out) == [n]
+    assert out.combine_chunks().equals(pc.take(v, pc.sort_indices(v)))
+    f = rand(rng, pa.float64(), n)
+    out = sess.call_function("cumulative_sum", [chunked(f, [7777])])
+    assert out.combine_chunks().equals(pc.cumulative_sum(f))     # integer-valued doubles: exact in any order
+
+
+def test_chunked_results_feed_the_next_call(sess):
+    rng = np.random.default_rng(5)
+    a = rand(rng, pa.int64(), 5000, 0.0)
+    c = chunked(a, [1234, 4000])
+    s1 = sess.call_function("add", [c, c], keep_on_device=True)
+    s2 = sess.call_function("greater", [s1, pa.scalar(0, pa.int64())], keep_on_device=True)
+    out = sess.call_function("filter", [s1, s2])
+    exp = pc.filter(pc.add(a, a), pc.greater(pc.add(a, a), 0))
+    assert out.combine_chunks().equals(exp)
