@@ -49,6 +49,9 @@ lib.ahc_datum_buffers.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]
 lib.ahc_chunked_from_arrays.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]
 lib.ahc_datum_num_chunks.argtypes = [_vp]
 lib.ahc_datum_chunk.argtypes = [_vp, _vp, C.c_int, C.POINTER(_vp)]
+lib.ahc_record_from_arrays.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_vp)]
+lib.ahc_record_num_columns.argtypes = [_vp]
+lib.ahc_record_column.argtypes = [_vp, _vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_vp)]
 lib.ahc_ipc_open.argtypes = [_vp, _vp, C.c_int64, C.POINTER(_vp)]
 lib.ahc_ipc_close.argtypes = [_vp]
 lib.ahc_ipc_close.restype = None
@@ -306,9 +309,20 @@ class Session:
             return x.h
         if isinstance(x, (pa.Array, pa.ChunkedArray)):
             return self._import(x)
+        if isinstance(x, pa.RecordBatch):  # compute.RecordDatum
+            parts = [self._import(c) for c in x.columns]
+            try:
+                d = _vp()
+                names = (C.c_char_p * max(len(parts), 1))(*[n.encode() for n in x.schema.names])
+                handles = (_vp * max(len(parts), 1))(*parts)
+                self._check(lib.ahc_record_from_arrays(self.h, len(parts), names, handles, C.byref(d)))
+                return d
+            finally:
+                for p in parts:
+                    lib.ahc_datum_release(p)
         if isinstance(x, pa.Scalar):
             return self._scalar(x)
-        raise TypeError(f"unsupported argument {type(x)}: pass a pyarrow Array or Scalar")
+        raise TypeError(f"unsupported argument {type(x)}: pass a pyarrow Array, ChunkedArray, RecordBatch or Scalar")
 
     def _export(self, d):
         import pyarrow as pa
@@ -322,6 +336,17 @@ class Session:
                 return pa.scalar(None, type=typ)
             fmt = _PACK[tid.value]
             return pa.scalar(struct.unpack(fmt, bytes(val)[:struct.calcsize(fmt)])[0], type=typ)
+        if kind.value == 4:  # record batch
+            cols, names = [], []
+            for i in range(lib.ahc_record_num_columns(d)):
+                c, nm = _vp(), C.c_char_p()
+                self._check(lib.ahc_record_column(self.h, d, i, C.byref(nm), C.byref(c)))
+                names.append(nm.value.decode())
+                try:
+                    cols.append(self._export(c))
+                finally:
+                    lib.ahc_datum_release(c)
+            return pa.RecordBatch.from_arrays(cols, names=names)
         if kind.value == 3:  # chunked
             parts = []
             for i in range(lib.ahc_datum_num_chunks(d)):

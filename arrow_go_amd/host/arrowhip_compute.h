@@ -237,7 +237,7 @@ struct CumulativeOptions : FunctionOptions { ScalarPtr Start; bool SkipNulls = f
 struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
 
 // compute.Datum (datum.go:35-40): array or scalar
-enum class DatumKind { None, Scalar, Array, Chunked };
+enum class DatumKind { None, Scalar, Array, Chunked, Record };
 struct Datum {
   DatumKind kind = DatumKind::None;
   ArrayDataPtr array;
@@ -246,6 +246,12 @@ struct Datum {
   const DataType* chunked_type = nullptr;
   static Datum Of(ArrayDataPtr a) { Datum d; d.kind = DatumKind::Array; d.array = std::move(a); return d; }
   static Datum Of(ScalarPtr s) { Datum d; d.kind = DatumKind::Scalar; d.scalar = std::move(s); return d; }
+  // RecordDatum (datum.go:232-260): equal-length named columns; `chunks` holds the columns
+  std::vector<std::string> names;
+  int64_t num_rows = 0;
+  static Datum OfRecord(std::vector<std::string> n, std::vector<ArrayDataPtr> cols, int64_t rows) {
+    Datum d; d.kind = DatumKind::Record; d.names = std::move(n); d.chunks = std::move(cols); d.num_rows = rows; return d;
+  }
   static Datum OfChunks(const DataType* t, std::vector<ArrayDataPtr> c) {
     Datum d; d.kind = DatumKind::Chunked; d.chunked_type = t; d.chunks = std::move(c); return d;
   }
@@ -254,6 +260,7 @@ struct Datum {
   }
   int64_t Len() const {
     if (kind == DatumKind::Chunked) { int64_t n = 0; for (auto& c : chunks) n += c->length; return n; }
+    if (kind == DatumKind::Record) return num_rows;
     return kind == DatumKind::Array ? array->length : 1;
   }
   bool IsArrayLike() const { return kind == DatumKind::Array || kind == DatumKind::Chunked; }

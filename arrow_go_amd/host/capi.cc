@@ -612,6 +612,33 @@ AHC_EXPORT int ahc_datum_chunk(ahc_session* s, ahc_datum* d, int i, ahc_datum** 
   return 0;
 }
 
+// ---- record batches (compute.RecordDatum, datum.go:232-260): named equal-length columns -------------------------
+AHC_EXPORT int ahc_record_from_arrays(ahc_session* s, int n, const char* const* names, ahc_datum** arrays, ahc_datum** out) {
+  *out = nullptr;
+  std::vector<ArrayDataPtr> cols;
+  std::vector<std::string> nm;
+  int64_t rows = 0;
+  for (int i = 0; i < n; i++) {
+    if (arrays[i]->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "record batch columns must be arrays"));
+    if (i == 0) rows = arrays[i]->d.array->length;
+    else if (arrays[i]->d.array->length != rows)  // array.NewRecordBatch validate(): arrow/array/record.go
+      return Fail(s, Status::Make(StatusCode::Invalid, std::string("arrow/array: mismatch number of rows in column \"") + names[i] + "\": got=" +
+                                                           std::to_string(arrays[i]->d.array->length) + ", want=" + std::to_string(rows)));
+    cols.push_back(arrays[i]->d.array);
+    nm.push_back(names[i]);
+  }
+  *out = new ahc_datum{Datum::OfRecord(std::move(nm), std::move(cols), rows)};
+  return 0;
+}
+AHC_EXPORT int ahc_record_num_columns(ahc_datum* d) { return d->d.kind == DatumKind::Record ? (int)d->d.chunks.size() : -1; }
+AHC_EXPORT int ahc_record_column(ahc_session* s, ahc_datum* d, int i, const char** name, ahc_datum** out) {
+  *out = nullptr;
+  if (d->d.kind != DatumKind::Record || i < 0 || i >= (int)d->d.chunks.size()) return Fail(s, Status::Make(StatusCode::Invalid, "column index out of range"));
+  if (name) *name = d->d.names[i].c_str();
+  *out = new ahc_datum{Datum::Of(d->d.chunks[i])};
+  return 0;
+}
+
 // ---- Arrow IPC stream → HBM-resident record batches (ipc.NewReader / Reader.Next, arrow/ipc/reader.go:97,202) ----
 struct ahc_ipc_reader {
   ahc_session* s;

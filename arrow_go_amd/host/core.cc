@@ -162,6 +162,7 @@ static std::string TypesToString(const std::vector<const DataType*>& types) {
 static Status ArgTypes(const std::vector<Datum>& args, std::vector<const DataType*>* types) {
   for (auto& a : args) {
     if (a.kind == DatumKind::None) return Status::Make(StatusCode::Invalid, "invalid datum");
+    if (a.kind == DatumKind::Record) return Status::Make(StatusCode::NotImplemented, "record batch arguments are only understood by filter, take, sort_indices and sort");
     types->push_back(a.type());
   }
   return Status::OK();

@@ -394,6 +394,44 @@ static const FilterOptions kDefaultFilterOptions;
 static const TakeOptions kDefaultTakeOptions;
 static const DictionaryEncodeOptions kDefaultDictOptions;
 
+// FilterRecordBatch (compute/selection.go:679-722): the mask becomes ONE index vector (GetTakeIndices,
+// kernels/vector_selection.go:102-236) and every column is gathered with it, bounds check off
+static Status FilterRecordBatch(ExecCtx* ctx, const Datum& batch, const ArrayData& filter_in, const FilterOptions* opts, Datum* out) {
+  Session* s = ctx->session;
+  if (batch.num_rows != filter_in.length) return Status::Make(StatusCode::Invalid, "filter inputs must all be the same length");
+  if (filter_in.length >= ((int64_t)1 << 32) - 1)
+    return Status::Make(StatusCode::NotImplemented, "filter length exceeds UINT32_MAX, consider a different strategy for selecting elements");  // :229-235
+  exec::ArraySpan filter;
+  filter.SetMembers(filter_in);
+  AHC_RETURN_NOT_OK(filter.UpdateNullCount(s));
+  const int null_sel = opts ? (int)opts->NullSelection : DropNulls;
+  const uint8_t* fvalid = filter.MayHaveNulls() ? filter.buffers[0].buf : nullptr;
+  int64_t n_out = 0;
+  if (filter.len > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_count(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, filter.len, null_sel, &n_out)));
+  auto idx = std::make_shared<ArrayData>();
+  idx->type = GetDataType(Type::UINT32);
+  idx->length = n_out;
+  AHC_RETURN_NOT_OK(s->Allocate(n_out * 4, &idx->buffers[1]));
+  BufferPtr ivb;
+  AHC_RETURN_NOT_OK(s->AllocateBitmap(n_out, &ivb));
+  int64_t idx_nulls = 0;
+  if (n_out > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_to_indices(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, filter.len, null_sel, n_out,
+                                                         (uint32_t*)idx->buffers[1]->dptr, (uint8_t*)ivb->dptr, &idx_nulls)));
+  idx->null_count = idx_nulls;
+  if (idx_nulls) idx->buffers[0] = ivb;
+  static const TakeOptions kNoBoundsCheck = [] { TakeOptions t; t.BoundsCheck = false; return t; }();
+  std::vector<ArrayDataPtr> cols;
+  for (auto& c : batch.chunks) {
+    Datum col;
+    AHC_RETURN_NOT_OK(CallFunction(ctx, "array_take", &kNoBoundsCheck, {Datum::Of(c), Datum::Of(idx)}, &col));
+    cols.push_back(col.array);
+  }
+  *out = Datum::OfRecord(batch.names, std::move(cols), n_out);
+  return Status::OK();
+}
+
 void RegisterVectorSelection(FunctionRegistry* reg) {
   auto af = std::make_shared<VectorFunction>("array_filter", Arity{2, false}, &kDefaultFilterOptions);
   af->chunked = VectorFunction::Chunked::Filter;
@@ -445,8 +483,13 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
   // filterMetaFunc (selection.go:42-85): validates, then dispatches on the values kind
   reg->AddFunction(std::make_shared<MetaFunction>("filter", Arity{2, false}, &kDefaultFilterOptions,
       [](ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
-        if (args[1].type()->id != Type::BOOL)
+        if (!args[1].type() || args[1].type()->id != Type::BOOL)
           return Status::Make(StatusCode::NotImplemented, "filter argument must be boolean type");  // :45-48
+        if (args[0].kind == DatumKind::Record) {
+          if (args[1].kind != DatumKind::Array)
+            return Status::Make(StatusCode::NotImplemented, "record batch filtering only implemented for Array filter");  // :69
+          return FilterRecordBatch(ctx, args[0], *args[1].array, static_cast<const FilterOptions*>(o), out);
+        }
         if (args[0].kind == DatumKind::Array && args[1].kind == DatumKind::Array && args[0].Len() != args[1].Len())
           return Status::Make(StatusCode::Invalid, "filter inputs must all be the same length");  // FilterArray check
         return CallFunction(ctx, "array_filter", o, args, out);
@@ -454,8 +497,25 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
   // takeMetaFunc (selection.go:93-114)
   reg->AddFunction(std::make_shared<MetaFunction>("take", Arity{2, false}, &kDefaultTakeOptions,
       [](ExecCtx* ctx, const FunctionOptions* o, const std::vector<Datum>& args, Datum* out) {
-        if (!IsInteger(args[1].type()->id))
+        if (!args[1].type() || !IsInteger(args[1].type()->id))
           return Status::Make(StatusCode::NotImplemented, "take indices must be an integer type");
+        if (args[0].kind == DatumKind::Record) {  // takeRecordImpl (selection.go:160-204): every column through array_take with the same indices
+          Datum indices = args[1];
+          if (indices.kind == DatumKind::Chunked) {
+            if (indices.chunks.empty()) return Status::Make(StatusCode::Invalid, "Must pass at least one array");  // concat.go:43-45
+            ArrayDataPtr whole;
+            AHC_RETURN_NOT_OK(Concatenate(ctx->session, indices.chunks, indices.chunked_type, &whole));
+            indices = Datum::Of(whole);
+          }
+          std::vector<ArrayDataPtr> cols;
+          for (auto& c : args[0].chunks) {
+            Datum col;
+            AHC_RETURN_NOT_OK(CallFunction(ctx, "array_take", o, {Datum::Of(c), indices}, &col));
+            cols.push_back(col.array);
+          }
+          *out = Datum::OfRecord(args[0].names, std::move(cols), indices.Len());
+          return Status::OK();
+        }
         return CallFunction(ctx, "array_take", o, args, out);
       }), false);
 }
@@ -764,6 +824,12 @@ static Status SortIndicesImpl(ExecCtx* ctx, const FunctionOptions* o, const std:
   // a chunked column is sorted as its logical concatenation: the indices address the whole column
   // (compute/vector_sort.go:144-148, SortIndicesChunked :226)
   std::vector<Datum> args = args_in;
+  if (args.size() == 1 && args[0].kind == DatumKind::Record) {  // KindRecord (:150-166): the keys name columns of the batch
+    std::vector<Datum> cols;
+    for (auto& c : args_in[0].chunks) cols.push_back(Datum::Of(c));
+    if (cols.empty()) return Status::Make(StatusCode::Invalid, "sort_indices: record batch without columns");
+    args = cols;
+  }
   for (auto& a : args) {
     if (a.kind != DatumKind::Chunked) continue;
     if (a.chunks.empty()) return Status::Make(StatusCode::NotImplemented, "sort_indices of a chunked array without chunks");

@@ -149,3 +149,32 @@ def test_chunked_results_feed_the_next_call(sess):
     out = sess.call_function("filter", [s1, s2])
     exp = pc.filter(pc.add(a, a), pc.greater(pc.add(a, a), 0))
     assert out.combine_chunks().equals(exp)
+
+
+# ---- record batches (compute.RecordDatum): FilterRecordBatch selection.go:679-722, takeRecordImpl :160-204 ----------
+def test_record_batch_filter_take_sort(sess):
+    rng = np.random.default_rng(6)
+    n = 7001
+    rb = pa.RecordBatch.from_arrays([rand(rng, pa.int64(), n), rand(rng, pa.float64(), n), rand(rng, pa.string(), n), rand(rng, pa.bool_(), n),
+                                     rand(rng, pa.int8(), n, 0.0)], names=["a", "b", "s", "t", "z"])
+    m = rand(rng, pa.bool_(), n)
+    for opt, null_sel in (("", "drop"), ("null_selection_behavior=emit_null", "emit_null")):
+        out = sess.call_function("filter", [rb, m], opt)
+        assert isinstance(out, pa.RecordBatch) and out.schema.names == rb.schema.names
+        assert out.equals(rb.filter(m, null_selection_behavior=null_sel))
+    with pytest.raises(ac.ErrInvalid, match="same length"):
+        sess.call_function("filter", [rb, m.slice(1)])
+    with pytest.raises(ac.ErrNotImplemented, match="only implemented for Array filter"):
+        sess.call_function("filter", [rb, chunked(m, [10])])
+    idx = pa.array(rng.integers(0, n, 3000), mask=rng.random(3000) < 0.1, type=pa.int32())
+    assert sess.call_function("take", [rb, idx]).equals(rb.take(idx))
+    assert sess.call_function("take", [rb, chunked(idx, [5, 1000])]).equals(rb.take(idx))
+    with pytest.raises(ac.ErrIndex):
+        sess.call_function("take", [rb, pa.array([n], type=pa.int64())])
+    keys = "sort_keys=4:asc:at_end,0:desc:at_start"
+    exp = pc.sort_indices(rb, sort_keys=[("z", "ascending"), ("a", "descending")], null_placement="at_start")
+    got = sess.call_function("sort_indices", [rb], keys)
+    # z has no nulls, so only key a's placement (at_start) matters — same reading in both libraries
+    assert got.equals(exp)
+    with pytest.raises(ac.ErrNotImplemented, match="record batch"):
+        sess.call_function("add", [rb, rb])
