@@ -33,6 +33,7 @@ X_ADD, X_SUB, X_MUL, X_ADD_CHECKED, X_SUB_CHECKED, X_MUL_CHECKED = 10, 11, 12, 1
 X_NEGATE, X_ABS, X_SIGN = 20, 21, 22
 X_EQ, X_NE, X_GT, X_GE, X_LT, X_LE = 30, 31, 32, 33, 34, 35
 X_AND, X_OR, X_XOR, X_AND_NOT, X_INVERT = 40, 41, 42, 43, 44
+X_CAST = 50
 
 
 class ArrowHipError(Exception):

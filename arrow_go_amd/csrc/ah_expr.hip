@@ -81,6 +81,15 @@ bool IsInt(int t) { return t >= AH_UINT8 && t <= AH_INT64; }
 bool IsSigned(int t) { return t == AH_INT8 || t == AH_INT16 || t == AH_INT32 || t == AH_INT64; }
 bool IsFloat(int t) { return t == AH_FLOAT32 || t == AH_FLOAT64; }
 bool IsNum(int t) { return IsInt(t) || IsFloat(t); }
+// conversions that keep every value (so the safe cast DispatchBest would insert cannot fail)
+bool ValuePreserving(int from, int to) {
+  if (!IsNum(from) || !IsNum(to)) return false;
+  if (from == to) return true;
+  const int fb = ah_type_width(from) * 8, tb = ah_type_width(to) * 8;
+  if (IsInt(from) && IsInt(to)) return IsSigned(from) == IsSigned(to) ? tb >= fb : (!IsSigned(from) && IsSigned(to) && tb > fb);
+  if (IsInt(from)) return to == AH_FLOAT64 ? fb <= 32 : fb <= 16;
+  return from == AH_FLOAT32 && to == AH_FLOAT64;
+}
 
 const char* kPrelude = R"SRC(
 typedef unsigned long long u64;
@@ -178,6 +187,12 @@ int Generate(ah_ctx* c, const ah_expr_node* nodes, int n_nodes, const int* col_t
         else ex = "(" + T + ")(" + a.v + " > 0 ? 1 : (" + a.v + " ? -1 : 0))";
       }
       push(a.type, ex, a.ok);
+    } else if (op == AH_X_CAST) {
+      if (stack.empty()) return ah_fail(c, AH_EINVALID, "expr: stack underflow");
+      NodeVal a = stack.back(); stack.pop_back();
+      if (!ValuePreserving(a.type, arg))
+        return ah_fail(c, AH_ENOTIMPL, "expr: cast %s → type %d is not value-preserving: it needs the checked cast kernel", CType(a.type) ? CType(a.type) : "?", arg);
+      push(arg, "(" + std::string(CType(arg)) + ")" + a.v, a.ok);
     } else if (op == AH_X_INVERT) {
       if (stack.empty()) return ah_fail(c, AH_EINVALID, "expr: stack underflow");
       NodeVal a = stack.back(); stack.pop_back();
@@ -188,7 +203,7 @@ int Generate(ah_ctx* c, const ah_expr_node* nodes, int n_nodes, const int* col_t
       NodeVal b = stack.back(); stack.pop_back();
       NodeVal a = stack.back(); stack.pop_back();
       if (a.type != b.type)
-        return ah_fail(c, AH_ENOTIMPL, "expr: operand types differ (%s, %s): implicit casts are out of scope", CType(a.type), CType(b.type));
+        return ah_fail(c, AH_ENOTIMPL, "expr: operand types differ (%s, %s): the caller inserts AH_X_CAST where DispatchBest would cast", CType(a.type), CType(b.type));
       std::string ok = a.ok + " && " + b.ok, T = CType(a.type);
       if (op >= AH_X_ADD && op <= AH_X_MUL_CHECKED) {
         if (!IsNum(a.type)) return ah_fail(c, AH_ENOTIMPL, "expr: arithmetic needs numeric operands");

@@ -98,15 +98,29 @@ struct Flat {
   std::vector<ah_expr_node> nodes;
   std::vector<int> col_index;   // program column → batch column
   std::vector<const Scalar*> lits;
+  std::vector<ScalarPtr> owned;  // literals re-typed on the host (safe cast) for the program
 };
 
-// returns false (without error) when the tree has something the fused kernel does not cover
-static bool Flatten(const Expression& e, const ExecBatch& batch, Flat* f, Status* st) {
+// conversions that keep every value: the implicit casts of DispatchBest that can never fail their safe-cast
+// check, hence may run inside the fused kernel (ah_expr.hip applies the same rule to AH_X_CAST)
+static bool ValuePreserving(const DataType* from, const DataType* to) {
+  if (from->id == to->id) return true;
+  const bool fi = IsInteger(from->id), ti = IsInteger(to->id);
+  if (fi && ti) return IsSignedInteger(from->id) == IsSignedInteger(to->id) ? to->bit_width >= from->bit_width
+                                                                            : (!IsSignedInteger(from->id) && to->bit_width > from->bit_width);
+  if (fi) return to->id == Type::FLOAT64 ? from->bit_width <= 32 : (to->id == Type::FLOAT32 && from->bit_width <= 16);
+  return from->id == Type::FLOAT32 && to->id == Type::FLOAT64;
+}
+
+// Flattens to the postfix program; *type = the type the subtree evaluates to.  Returns false (without error)
+// when the tree has something the fused kernel does not cover.
+static bool Flatten(ExecCtx* ctx, const Expression& e, const ExecBatch& batch, Flat* f, Status* st, const DataType** type) {
   switch (e.kind) {
     case Expression::LITERAL:
       if (e.literal.kind != DatumKind::Scalar || (int)f->lits.size() >= 16) return false;
       f->nodes.push_back({AH_X_LITERAL, (int32_t)f->lits.size()});
       f->lits.push_back(e.literal.scalar.get());
+      *type = e.literal.scalar->type;
       return true;
     case Expression::FIELD_REF: {
       int idx;
@@ -117,8 +131,10 @@ static bool Flatten(const Expression& e, const ExecBatch& batch, Flat* f, Status
         if ((int)f->lits.size() >= 16) return false;
         f->nodes.push_back({AH_X_LITERAL, (int32_t)f->lits.size()});
         f->lits.push_back(d.scalar.get());
+        *type = d.scalar->type;
         return true;
       }
+      if (d.kind != DatumKind::Array) return false;
       int pos = -1;
       for (size_t i = 0; i < f->col_index.size(); i++) if (f->col_index[i] == idx) pos = (int)i;
       if (pos < 0) {
@@ -127,14 +143,46 @@ static bool Flatten(const Expression& e, const ExecBatch& batch, Flat* f, Status
         f->col_index.push_back(idx);
       }
       f->nodes.push_back({AH_X_FIELD, pos});
+      *type = d.array->type;
       return true;
     }
     default: {
       auto it = FusibleOps().find(e.function);
       if (it == FusibleOps().end()) return false;
-      for (auto& a : e.args) if (!Flatten(*a, batch, f, st)) return false;
-      f->nodes.push_back({it->second, 0});
-      return true;
+      const int op = it->second;
+      std::vector<const DataType*> types(e.args.size(), nullptr);
+      std::vector<size_t> starts, ends;  // program range of each argument; a cast, if any, goes at its end
+      for (size_t i = 0; i < e.args.size(); i++) {
+        starts.push_back(f->nodes.size());
+        if (!Flatten(ctx, *e.args[i], batch, f, st, &types[i])) return false;
+        ends.push_back(f->nodes.size());
+      }
+      const bool arith_or_cmp = op < AH_X_AND && !(op >= AH_X_NEGATE && op <= AH_X_SIGN);
+      if (arith_or_cmp && types.size() == 2 && types[0]->id != types[1]->id) {
+        // arithmeticFunction / compareFunction.DispatchBest (arithmetic.go:112-142, scalar_compare.go:37-63):
+        // both sides to the common numeric type; only casts that cannot fail are fused
+        const DataType* common = CommonNumeric(types);
+        if (!common) return false;
+        for (int i = 1; i >= 0; i--) {
+          if (types[i]->id == common->id) continue;
+          if (ends[i] - starts[i] == 1 && f->nodes[starts[i]].op == AH_X_LITERAL) {
+            // a scalar operand: the safe cast happens once, on the host side of the call (same CastDatum, same error)
+            const int slot = f->nodes[ends[i] - 1].arg;
+            Datum casted;
+            *st = CastDatum(ctx, Datum::Of(std::make_shared<Scalar>(*f->lits[slot])), CastOptions::Safe(common), &casted);
+            if (!st->ok() || casted.kind != DatumKind::Scalar) return false;
+            f->owned.push_back(casted.scalar);
+            f->lits[slot] = casted.scalar.get();
+            continue;
+          }
+          if (!ValuePreserving(types[i], common)) return false;
+          f->nodes.insert(f->nodes.begin() + (long)ends[i], ah_expr_node{AH_X_CAST, (int32_t)common->id});
+        }
+        types[0] = types[1] = common;
+      }
+      f->nodes.push_back({op, 0});
+      *type = (op >= AH_X_EQ && op <= AH_X_INVERT) ? GetDataType(Type::BOOL) : (types.empty() ? nullptr : types[0]);
+      return *type != nullptr;
     }
   }
 }
@@ -148,7 +196,8 @@ Status ExecuteScalarExpression(ExecCtx* ctx, const ExprPtr& expr, const ExecBatc
   Session* s = ctx->session;
   Flat f;
   Status st;
-  if (fuse && expr->kind == Expression::CALL && Flatten(*expr, batch, &f, &st) && !f.col_index.empty()) {
+  const DataType* root_type = nullptr;
+  if (fuse && expr->kind == Expression::CALL && Flatten(ctx, *expr, batch, &f, &st, &root_type) && !f.col_index.empty()) {
     std::vector<int> col_types, lit_types;
     for (int ci : f.col_index) col_types.push_back((int)batch.values[ci].array->type->id);
     for (auto* l : f.lits) lit_types.push_back((int)l->type->id);

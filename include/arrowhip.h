@@ -395,7 +395,8 @@ int ah_take_binary_data(ah_ctx* ctx, int offset_width, const void* offsets, cons
  * computed in ONE kernel generated for the tree and JIT-compiled with hiprtc.  The tree is a
  * postfix program; results are bit-identical to executing the calls one by one through the
  * entry points above (same wraparound / IEEE / checked-overflow / null-intersection rules;
- * no implicit casts: operand types of a call must match → AH_ENOTIMPL). */
+ * operand types of a call must match — the caller inserts AH_X_CAST nodes where the reference's
+ * DispatchBest would cast — else AH_ENOTIMPL). */
 typedef struct { int32_t op; int32_t arg; } ah_expr_node;
 typedef struct ah_expr ah_expr;
 #define AH_X_FIELD 1        /* push input column `arg` */
@@ -420,6 +421,10 @@ typedef struct ah_expr ah_expr;
 #define AH_X_XOR 42
 #define AH_X_AND_NOT 43
 #define AH_X_INVERT 44
+#define AH_X_CAST 50        /* value-preserving numeric conversion of the top of the stack to type `arg`: integer → wider integer
+                             * (unsigned → signed only when wider), ≤ 32-bit integer → double, ≤ 16-bit integer → float, float →
+                             * double — the implicit casts DispatchBest inserts (commonNumeric, compute/internal/kernels/
+                             * helpers.go) that can never fail a safe-cast check; any other pair is AH_ENOTIMPL */
 /* column / literal types are arrow.Type ids (1 = BOOL: bitmap column).  Compiled programs are
  * cached per context by (program, types); the returned handle is owned by the context. */
 int ah_expr_compile(ah_ctx* ctx, const ah_expr_node* nodes, int n_nodes, const int* col_types, int n_cols,

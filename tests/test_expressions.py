@@ -32,8 +32,21 @@ def test_codegen_compiles_offline():
     assert "v2 = v0 * v1" in src
 
 
+def test_codegen_cast_nodes():
+    # the value-preserving casts DispatchBest may insert compile into the kernel …
+    for frm, to in [(N.INT8, N.INT64), (N.UINT16, N.INT32), (N.UINT32, N.UINT64), (N.INT32, N.FLOAT64), (N.INT16, N.FLOAT32),
+                    (N.UINT8, N.FLOAT32), (N.FLOAT32, N.FLOAT64), (N.INT64, N.INT64)]:
+        src, out_type = ah.expr_codegen([(N.X_FIELD, 0), (N.X_CAST, to), (N.X_FIELD, 1), (N.X_ADD, 0)], [frm, to], [])
+        assert out_type == to
+    # … the ones that need the checked cast kernel do not
+    for frm, to in [(N.INT64, N.INT32), (N.INT32, N.UINT32), (N.UINT32, N.INT32), (N.INT64, N.FLOAT64), (N.INT32, N.FLOAT32),
+                    (N.FLOAT64, N.FLOAT32), (N.FLOAT64, N.INT64), (N.BOOL, N.INT8)]:
+        with pytest.raises(ah.ErrNotImplemented):
+            ah.expr_codegen([(N.X_FIELD, 0), (N.X_CAST, to)], [frm], [])
+
+
 def test_codegen_rejects_what_the_reference_would_cast():
-    with pytest.raises(ah.ErrNotImplemented, match="implicit casts"):
+    with pytest.raises(ah.ErrNotImplemented, match="AH_X_CAST"):
         ah.expr_codegen([(N.X_FIELD, 0), (N.X_FIELD, 1), (N.X_ADD, 0)], [N.INT64, N.INT32], [])
     with pytest.raises(ah.ErrNotImplemented):
         ah.expr_codegen([(N.X_FIELD, 0), (N.X_FIELD, 1), (N.X_AND, 0)], [N.INT64, N.INT64], [])
@@ -139,16 +152,55 @@ def test_fused_checked_overflow_and_null_literal(sess):
 
 
 @pytest.mark.gpu
+def test_fused_implicit_promotion(sess):
+    """DispatchBest's implicit casts (arithmetic.go:112-142, scalar_compare.go:37-63) inside the fused kernel: column
+    casts that cannot fail run as AH_X_CAST nodes, scalar operands are safe-cast once on the host; fused ==
+    per-call, byte for byte, and equal to Arrow C++"""
+    from arrow_go_amd import compute as ac
+    rng = np.random.default_rng(9)
+    n = 30011
+    i8 = pa.array(rng.integers(-100, 100, n), mask=rng.random(n) < 0.1, type=pa.int8())
+    u16 = pa.array(rng.integers(0, 60000, n), mask=rng.random(n) < 0.1, type=pa.uint16())
+    i32 = pa.array(rng.integers(-10**6, 10**6, n), type=pa.int32())
+    i64 = pa.array(rng.integers(-10**9, 10**9, n), mask=rng.random(n) < 0.1, type=pa.int64())
+    f32 = pa.array(rng.uniform(-1, 1, n).astype(np.float32), type=pa.float32())
+    f64 = pa.array(rng.uniform(-1, 1, n), mask=rng.random(n) < 0.1, type=pa.float64())
+    cases = [
+        ("add($0,$1)", [i8, i64], [], pc.add_checked(i8.cast(pa.int64()), i64)),                       # int8 + int64 → int64
+        ("multiply_unchecked($0,$1)", [u16, i32], [], pc.multiply(u16.cast(pa.int32()), i32)),        # uint16 · int32 → int32
+        ("add($0,$1)", [i8, u16], [], pc.add_checked(i8.cast(pa.int32()), u16.cast(pa.int32()))),    # int8 + uint16 → int32
+        ("greater($0,$1)", [i32, f64], [], pc.greater(i32.cast(pa.float64()), f64)),                  # int32 vs double → double
+        ("add($0,$1)", [f32, f64], [], pc.add(f32.cast(pa.float64()), f64)),                          # float + double
+        ("subtract($0,$1)", [i8, f32], [], pc.subtract(i8.cast(pa.float32()), f32)),                  # int8 − float → float
+        ("greater(add($0,$1),#0)", [i8, i64], [pa.scalar(7, pa.int32())], pc.greater(pc.add_checked(i8.cast(pa.int64()), i64), 7)),
+        ("multiply($0,#0)", [f64], [pa.scalar(3, pa.int64())], pc.multiply(f64, 3.0)),                # scalar int64 → double on the host
+        ("less($0,#0)", [i32], [pa.scalar(12345678901, pa.int64())], pc.less(i32.cast(pa.int64()), 12345678901)),
+    ]
+    for text, cols, lits, exp in cases:
+        got, fused = sess.eval_expression(text, cols, lits)
+        ref, ref_fused = sess.eval_expression(text, cols, lits, fuse=False)
+        assert fused and not ref_fused, text
+        assert got.type == exp.type and got.equals(exp), text
+        assert got.equals(ref) and got.buffers()[1].equals(ref.buffers()[1]), text   # same bytes, null slots included
+    # a scalar whose safe cast fails gives the per-call error, fused or not
+    for fuse in (True, False):
+        with pytest.raises(ac.ErrInvalid):
+            sess.eval_expression("add($0,#0)", [f64], [pa.scalar(2**53 + 1, pa.int64())], fuse=fuse)
+
+
+@pytest.mark.gpu
 def test_unfusible_trees_fall_back(sess):
     # a Kleene node is not in the fused op set: the tree runs per call and still works
     a = pa.array([True, None, False]); b = pa.array([None, True, False])
     got, fused = sess.eval_expression("and_kleene($0,invert($1))", [a, b])
     assert not fused and got.equals(pc.and_kleene(a, pc.invert(b)))
     from arrow_go_amd import compute as ac
-    # mixed operand types: not fusible (the generator has no casts) → per-call execution, where DispatchBest
-    # promotes both sides to the common numeric type exactly like the reference
-    mixed, fused = sess.eval_expression("add($0,$1)", [pa.array([1, None], pa.int32()), pa.array([1, 2], pa.int64())])
-    assert not fused and mixed.type == pa.int64() and mixed.to_pylist() == [2, None]
+    # mixed operand types whose promotion could fail its safe-cast check (int64 → double is exact only below
+    # 2^53) are not fused → per-call execution, where DispatchBest casts both sides exactly like the reference
+    mixed, fused = sess.eval_expression("add($0,$1)", [pa.array([1, None], pa.int64()), pa.array([1.5, 2.0], pa.float64())])
+    assert not fused and mixed.type == pa.float64() and mixed.to_pylist() == [2.5, None]
+    with pytest.raises(ac.ErrInvalid):
+        sess.eval_expression("add($0,$1)", [pa.array([2**53 + 1], pa.int64()), pa.array([1.5], pa.float64())])
     with pytest.raises(ac.ErrKey, match="not found"):
         sess.eval_expression("frobnicate($0)", [pa.array([1])])
     with pytest.raises(ac.ErrInvalid, match="out of range"):
