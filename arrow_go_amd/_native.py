@@ -34,6 +34,8 @@ X_NEGATE, X_ABS, X_SIGN = 20, 21, 22
 X_EQ, X_NE, X_GT, X_GE, X_LT, X_LE = 30, 31, 32, 33, 34, 35
 X_AND, X_OR, X_XOR, X_AND_NOT, X_INVERT = 40, 41, 42, 43, 44
 X_CAST = 50
+OP_DIV, OP_SQRT, OP_DIV_CHECKED, OP_ABS_CHECKED, OP_NEGATE_CHECKED, OP_SQRT_CHECKED = 3, 6, 24, 25, 26, 27
+OP_SHIFT_LEFT, OP_SHIFT_LEFT_CHECKED, OP_SHIFT_RIGHT, OP_SHIFT_RIGHT_CHECKED, OP_BIT_AND, OP_BIT_OR, OP_BIT_XOR, OP_BIT_NOT = 64, 65, 66, 67, 68, 69, 70, 71
 
 
 class ArrowHipError(Exception):
@@ -118,6 +120,7 @@ _SIGS = {
     "ah_arithmetic_scalar_arr": [_vp, _int, _i8, _vp, _vp, _vp, _i64],
     "ah_arithmetic_unary": [_vp, _int, _i8, _vp, _vp, _i64],
     "ah_arithmetic_checked": [_vp, _int, _i8, _int, _vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64],
+    "ah_arithmetic_ext": [_vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64],
     "ah_comparison": [_vp, _int, _int, _int, _vp, _vp, _vp, _i64, _int],
     "ah_bitmap_op": [_vp, _int, _vp, _i64, _vp, _i64, _vp, _i64, _i64],
     "ah_count_set_bits": [_vp, _vp, _i64, _i64, _pi64],

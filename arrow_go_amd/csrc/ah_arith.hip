@@ -265,10 +265,33 @@ __device__ __forceinline__ ST checked_one(ST a, ST b, bool valid, bool& ovf) {
 
 // One 16-byte vector per lane per operand, validity as V bits per lane out of the bitmaps
 // (two aligned 8-byte loads at most), result zeroed under nulls, 16-byte store.
+// 16-byte aligned operands stream through nontemporal vector accesses; `aligned` is wave-uniform
+template <typename ST>
+__device__ __forceinline__ ah_vec16<ST> load16(const ST* base, int64_t i, bool aligned) {
+  ah_vec16<ST> v;
+  if (aligned) {
+    const Vec16<ST> t = __builtin_nontemporal_load((const Vec16<ST>*)base + i);
+    __builtin_memcpy(&v, &t, 16);
+  } else {
+    v = ((const ah_vec16<ST>*)base)[i];
+  }
+  return v;
+}
+template <typename ST>
+__device__ __forceinline__ void store16(ST* base, int64_t i, const ah_vec16<ST>& v, bool aligned) {
+  if (aligned) {
+    Vec16<ST> t;
+    __builtin_memcpy(&t, &v, 16);
+    __builtin_nontemporal_store(t, (Vec16<ST>*)base + i);
+  } else {
+    ((ah_vec16<ST>*)base)[i] = v;
+  }
+}
+
 template <typename ST, int OP /*OP_ADD, OP_SUB, OP_MUL*/, int SHAPE>
 __global__ __launch_bounds__(kBlock) void checked_kernel(const ST* __restrict__ l, const uint8_t* __restrict__ lv, int64_t loff,
                                                           const ST* __restrict__ r, const uint8_t* __restrict__ rv, int64_t roff,
-                                                          ST scalar, ST* __restrict__ out, int64_t len, unsigned* __restrict__ flag) {
+                                                          ST scalar, ST* __restrict__ out, int64_t len, unsigned* __restrict__ flag, int aligned) {
   constexpr int V = 16 / sizeof(ST);
   using VT = ah_vec16<ST>;
   bool ovf = false;
@@ -276,8 +299,8 @@ __global__ __launch_bounds__(kBlock) void checked_kernel(const ST* __restrict__ 
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
     VT a, b, o;
-    if (SHAPE != 2) a = ((const VT*)l)[i];
-    if (SHAPE != 1) b = ((const VT*)r)[i];
+    if (SHAPE != 2) a = load16<ST>(l, i, aligned);
+    if (SHAPE != 1) b = load16<ST>(r, i, aligned);
     unsigned vbits = (1u << V) - 1;
     if (OP != OP_MUL) {
       if (SHAPE != 2 && lv) vbits &= (unsigned)ah_load_bits64(lv, loff + i * V, V);
@@ -286,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void checked_kernel(const ST* __restrict__ 
 #pragma unroll
     for (int e = 0; e < V; e++)
       o.v[e] = checked_one<ST, OP>(SHAPE == 2 ? scalar : a.v[e], SHAPE == 1 ? scalar : b.v[e], (vbits >> e) & 1, ovf);
-    ((VT*)out)[i] = o;
+    store16<ST>(out, i, o, aligned);
   }
   if (blockIdx.x == 0) {  // < V trailing elements
     int64_t j = nvec * V + threadIdx.x;
@@ -306,11 +329,12 @@ int dispatch_checked(ah_ctx* c, int op, int shape, const void* l, const uint8_t*
   if (shape == AH_SHAPE_SA) memcpy(&scalar, l, sizeof(ST));
   unsigned grid = ah_stream_grid(c, ah_ceil_div(len / (16 / (int64_t)sizeof(ST)) + 1, kBlock), /*default_bpc=*/0);
   const ST* pl = (const ST*)l; const ST* pr = (const ST*)r; ST* po = (ST*)out;
+  const int aligned = c->tune_nt && ((((uintptr_t)out) | (shape != AH_SHAPE_SA ? (uintptr_t)l : 0) | (shape != AH_SHAPE_AS ? (uintptr_t)r : 0)) & 15) == 0;
 #define AH_CHK(OPC)                                                                                                       \
   switch (shape) {                                                                                                        \
-    case AH_SHAPE_AA: checked_kernel<ST, OPC, 0><<<grid, kBlock, 0, c->stream>>>(pl, lv, loff, pr, rv, roff, scalar, po, len, flag); break; \
-    case AH_SHAPE_AS: checked_kernel<ST, OPC, 1><<<grid, kBlock, 0, c->stream>>>(pl, lv, loff, nullptr, nullptr, 0, scalar, po, len, flag); break; \
-    case AH_SHAPE_SA: checked_kernel<ST, OPC, 2><<<grid, kBlock, 0, c->stream>>>(nullptr, nullptr, 0, pr, rv, roff, scalar, po, len, flag); break; \
+    case AH_SHAPE_AA: checked_kernel<ST, OPC, 0><<<grid, kBlock, 0, c->stream>>>(pl, lv, loff, pr, rv, roff, scalar, po, len, flag, aligned); break; \
+    case AH_SHAPE_AS: checked_kernel<ST, OPC, 1><<<grid, kBlock, 0, c->stream>>>(pl, lv, loff, nullptr, nullptr, 0, scalar, po, len, flag, aligned); break; \
+    case AH_SHAPE_SA: checked_kernel<ST, OPC, 2><<<grid, kBlock, 0, c->stream>>>(nullptr, nullptr, 0, pr, rv, roff, scalar, po, len, flag, aligned); break; \
   }
   switch (op) {
     case AH_OP_ADD_CHECKED: AH_CHK(OP_ADD) break;

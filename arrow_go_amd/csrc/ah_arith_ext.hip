@@ -1,0 +1,275 @@
+// ah_arith_ext.hip — the exact part of the arithmetic registry beyond + − ×: divide, abs / negate with
+// overflow check, bit-wise and / or / xor / not, shifts, sqrt.
+//
+// Reference (arrow/compute/internal/kernels):
+//   divide, divide_unchecked   base_arithmetic.go:154-160, 287-294 (integers: BOTH names refuse a zero divisor in
+//                              a valid slot, "divide by zero"; Go's truncated quotient, MinInt / −1 wraps);
+//                              :386-396 (floats: unchecked = IEEE a / b, checked refuses b == 0)
+//                              — all through ScalarBinaryNotNull (helpers.go:284-380): null slots hold 0
+//   abs, negate                :295-340 (signed integers: MinInt → "overflow", tested in EVERY slot — ScalarUnary
+//                              walks the value buffer, helpers.go:56-90 — unsigned abs is a copy), floats :398-411
+//   bit_wise_and / or / xor    scalar_arithmetic.go:170-245: bitmap ops over the raw value buffers, every slot
+//   bit_wise_not               :253-268 ScalarUnaryNotNull: null slots hold 0
+//   shift_left / shift_right   :293-378: a shift count outside [0, bits − 2] (signed) / [0, bits − 1] (unsigned)
+//                              returns the left operand, and is "shift amount must be >= 0 and less than precision
+//                              of type" for the checked names; ScalarBinaryNotNull
+//   sqrt, sqrt_unchecked       base_arithmetic.go:412-426: unchecked in every slot (ScalarUnary), checked NotNull
+//                              with "square root of negative number"
+// None of these has an assembly leaf in the reference (base_arithmetic_amd64.go:67-105: "no SIMD for POWER or
+// SQRT", NotNull ops stay in Go), so the C signature below is derived from the Go closures.
+//
+// One kernel shape for all of them: 16 bytes per lane per operand, validity as V bits per lane, one flag word
+// of error bits, 16-byte stores.  HBM-bound like ah_arith.hip except 64-bit integer division (≈ 100 VALU
+// instructions per element).
+#include <type_traits>
+
+#include "ah_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <typename T>
+using Vec16 = T __attribute__((ext_vector_type(16 / sizeof(T))));
+
+// 16-byte aligned operands stream through nontemporal vector accesses (+10–15 % on this chip);
+// element-aligned Arrow slices fall back to the 16-byte struct access.  `aligned` is wave-uniform.
+template <typename ST>
+__device__ __forceinline__ ah_vec16<ST> load16(const ST* base, int64_t i, bool aligned) {
+  ah_vec16<ST> v;
+  if (aligned) {
+    const Vec16<ST> t = __builtin_nontemporal_load((const Vec16<ST>*)base + i);
+    __builtin_memcpy(&v, &t, 16);
+  } else {
+    v = ((const ah_vec16<ST>*)base)[i];
+  }
+  return v;
+}
+template <typename ST>
+__device__ __forceinline__ void store16(ST* base, int64_t i, const ah_vec16<ST>& v, bool aligned) {
+  if (aligned) {
+    Vec16<ST> t;
+    __builtin_memcpy(&t, &v, 16);
+    __builtin_nontemporal_store(t, (Vec16<ST>*)base + i);
+  } else {
+    ((ah_vec16<ST>*)base)[i] = v;
+  }
+}
+
+enum { ERR_OVERFLOW = 1, ERR_DIV_ZERO = 2, ERR_SHIFT = 4, ERR_NEG_SQRT = 8 };
+enum { X_DIV, X_DIV_CHECKED, X_SHL, X_SHL_CHECKED, X_SHR, X_SHR_CHECKED, X_BIT_NOT, X_SQRT_CHECKED,  // NotNull
+       X_ABS_CHECKED, X_NEG_CHECKED, X_BIT_AND, X_BIT_OR, X_BIT_XOR, X_SQRT };                       // every slot
+
+constexpr bool NotNull(int x) { return x <= X_SQRT_CHECKED; }
+constexpr bool Unary(int x) { return x == X_BIT_NOT || x == X_SQRT_CHECKED || x == X_ABS_CHECKED || x == X_NEG_CHECKED || x == X_SQRT; }
+
+template <typename ST, int X>
+__device__ __forceinline__ ST apply(ST a, ST b, unsigned& err) {
+  constexpr bool kFloat = std::is_floating_point<ST>::value;
+  constexpr bool kSigned = !kFloat && ((ST)-1 < (ST)0);
+  constexpr int bits = sizeof(ST) * 8;
+  if constexpr (X == X_DIV || X == X_DIV_CHECKED) {
+    if constexpr (kFloat) {
+      if (X == X_DIV_CHECKED && b == 0) { err |= ERR_DIV_ZERO; return (ST)0; }
+      return a / b;
+    } else {
+      using U = typename std::make_unsigned<ST>::type;
+      if (b == 0) { err |= ERR_DIV_ZERO; return (ST)0; }
+      if constexpr (kSigned) { if (b == (ST)-1) return (ST)((U)0 - (U)a); }  // MinInt / −1 wraps (Go spec, "Integer overflow")
+      return (ST)(a / b);
+    }
+  } else if constexpr (X == X_SHL || X == X_SHL_CHECKED || X == X_SHR || X == X_SHR_CHECKED) {
+    using U = typename std::make_unsigned<ST>::type;
+    constexpr ST maxshift = kSigned ? (ST)(bits - 1) : (ST)bits;  // unsigned 8-bit: bits = 8 fits
+    const bool bad = kSigned ? (b < 0 || b >= maxshift) : ((unsigned long long)b >= (unsigned long long)bits);
+    if (bad) { if (X == X_SHL_CHECKED || X == X_SHR_CHECKED) err |= ERR_SHIFT; return a; }
+    if (X == X_SHL || X == X_SHL_CHECKED) return (ST)((U)a << (int)b);
+    return (ST)(a >> (int)b);  // arithmetic for signed, logical for unsigned
+  } else if constexpr (X == X_BIT_NOT) {
+    return (ST)~a;
+  } else if constexpr (X == X_BIT_AND) {
+    return (ST)(a & b);
+  } else if constexpr (X == X_BIT_OR) {
+    return (ST)(a | b);
+  } else if constexpr (X == X_BIT_XOR) {
+    return (ST)(a ^ b);
+  } else if constexpr (X == X_ABS_CHECKED || X == X_NEG_CHECKED) {
+    if constexpr (kFloat) {
+      return X == X_ABS_CHECKED ? (ST)__builtin_fabs(a) : -a;
+    } else if constexpr (!kSigned) {
+      return a;  // abs of an unsigned value; negate has no unsigned kernel
+    } else {
+      using U = typename std::make_unsigned<ST>::type;
+      constexpr ST tmin = (ST)((U)1 << (bits - 1));
+      if (a == tmin) { err |= ERR_OVERFLOW; return (ST)0; }
+      return X == X_ABS_CHECKED ? (ST)(a < 0 ? -a : a) : (ST)-a;
+    }
+  } else {  // X_SQRT, X_SQRT_CHECKED
+    if constexpr (kFloat) {
+      if (X == X_SQRT_CHECKED && a < 0) { err |= ERR_NEG_SQRT; return (ST)__builtin_nan(""); }
+      return sizeof(ST) == 4 ? (ST)__builtin_sqrtf((float)a) : (ST)__builtin_sqrt((double)a);
+    } else {
+      return a;
+    }
+  }
+}
+
+// SHAPE: 0 = l[i] ∘ r[i], 1 = l[i] ∘ scalar (and all unary ops), 2 = scalar ∘ r[i]
+template <typename ST, int X, int SHAPE>
+__global__ __launch_bounds__(kBlock) void ext_kernel(const ST* __restrict__ l, const uint8_t* __restrict__ lv, int64_t loff,
+                                                      const ST* __restrict__ r, const uint8_t* __restrict__ rv, int64_t roff,
+                                                      ST scalar, ST* __restrict__ out, int64_t len, unsigned* __restrict__ flag, int aligned) {
+  constexpr int V = 16 / sizeof(ST);
+  using VT = ah_vec16<ST>;
+  unsigned err = 0;
+  const int64_t nvec = len / V;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    VT a, b, o;
+    if (SHAPE != 2) a = load16<ST>(l, i, aligned);
+    if (SHAPE != 1) b = load16<ST>(r, i, aligned);
+    unsigned vbits = (1u << V) - 1;
+    if (NotNull(X)) {
+      if (SHAPE != 2 && lv) vbits &= (unsigned)ah_load_bits64(lv, loff + i * V, V);
+      if (SHAPE != 1 && rv) vbits &= (unsigned)ah_load_bits64(rv, roff + i * V, V);
+    }
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      unsigned e1 = 0;
+      const ST v = apply<ST, X>(SHAPE == 2 ? scalar : a.v[e], SHAPE == 1 ? scalar : b.v[e], e1);
+      const bool valid = (vbits >> e) & 1;
+      o.v[e] = valid ? v : (ST)0;   // helpers.go:303-306: null slots hold the zero value
+      if (valid) err |= e1;
+    }
+    store16<ST>(out, i, o, aligned);
+  }
+  if (blockIdx.x == 0) {  // < V trailing elements
+    const int64_t j = nvec * V + threadIdx.x;
+    if (j < len) {
+      const bool valid = !NotNull(X) || ((SHAPE == 2 || ah_bit(lv, loff + j)) && (SHAPE == 1 || ah_bit(rv, roff + j)));
+      unsigned e1 = 0;
+      const ST v = apply<ST, X>(SHAPE == 2 ? scalar : l[j], SHAPE == 1 ? scalar : r[j], e1);
+      out[j] = valid ? v : (ST)0;
+      if (valid) err |= e1;
+    }
+  }
+  // one atomic per wave that saw an error, none otherwise
+  for (unsigned bit = 1; bit <= ERR_NEG_SQRT; bit <<= 1)
+    if (__any((err & bit) != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
+}
+
+template <typename ST, int X>
+int launch(ah_ctx* c, int shape, const void* l, const uint8_t* lv, int64_t loff, const void* r, const uint8_t* rv, int64_t roff, void* out,
+           int64_t len, unsigned* flag) {
+  ST scalar = 0;
+  if (!Unary(X)) {
+    if (shape == AH_SHAPE_AS) memcpy(&scalar, r, sizeof(ST));
+    if (shape == AH_SHAPE_SA) memcpy(&scalar, l, sizeof(ST));
+  }
+  // exact grid, one vector per lane: same finding as ah_arith.hip (no grid-stride tail, maximum loads in flight)
+  const unsigned grid = ah_stream_grid(c, ah_ceil_div(len / (16 / (int64_t)sizeof(ST)) + 1, kBlock), /*default_bpc=*/0);
+  const ST* pl = (const ST*)l; const ST* pr = (const ST*)r; ST* po = (ST*)out;
+  const bool arr_l = !(shape == AH_SHAPE_SA && !Unary(X)), arr_r = !Unary(X) && shape != AH_SHAPE_AS;
+  const int aligned = c->tune_nt && ((((uintptr_t)out) | (arr_l ? (uintptr_t)l : 0) | (arr_r ? (uintptr_t)r : 0)) & 15) == 0;
+  if (Unary(X) || shape == AH_SHAPE_AS) ext_kernel<ST, X, 1><<<grid, kBlock, 0, c->stream>>>(pl, lv, loff, nullptr, nullptr, 0, scalar, po, len, flag, aligned);
+  else if (shape == AH_SHAPE_AA) ext_kernel<ST, X, 0><<<grid, kBlock, 0, c->stream>>>(pl, lv, loff, pr, rv, roff, scalar, po, len, flag, aligned);
+  else ext_kernel<ST, X, 2><<<grid, kBlock, 0, c->stream>>>(nullptr, nullptr, 0, pr, rv, roff, scalar, po, len, flag, aligned);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
+
+template <typename ST>
+int dispatch_int(ah_ctx* c, int op, int shape, const void* l, const uint8_t* lv, int64_t loff, const void* r, const uint8_t* rv, int64_t roff,
+                 void* out, int64_t len, unsigned* flag) {
+#define AH_X(X) return launch<ST, X>(c, shape, l, lv, loff, r, rv, roff, out, len, flag)
+  switch (op) {
+    case AH_OP_DIV: AH_X(X_DIV);
+    case AH_OP_DIV_CHECKED: AH_X(X_DIV_CHECKED);
+    case AH_OP_SHIFT_LEFT: AH_X(X_SHL);
+    case AH_OP_SHIFT_LEFT_CHECKED: AH_X(X_SHL_CHECKED);
+    case AH_OP_SHIFT_RIGHT: AH_X(X_SHR);
+    case AH_OP_SHIFT_RIGHT_CHECKED: AH_X(X_SHR_CHECKED);
+    case AH_OP_BIT_NOT: AH_X(X_BIT_NOT);
+    case AH_OP_BIT_AND: AH_X(X_BIT_AND);
+    case AH_OP_BIT_OR: AH_X(X_BIT_OR);
+    case AH_OP_BIT_XOR: AH_X(X_BIT_XOR);
+    case AH_OP_ABS_CHECKED: AH_X(X_ABS_CHECKED);
+    case AH_OP_NEGATE_CHECKED:
+      if ((ST)-1 > (ST)0) break;  // GetArithmeticUnarySignedKernels: no unsigned negate
+      AH_X(X_NEG_CHECKED);
+  }
+  return ah_fail(c, AH_ENOTIMPL, "arithmetic: op %d is not defined for this integer type", op);
+}
+
+template <typename ST>
+int dispatch_float(ah_ctx* c, int op, int shape, const void* l, const uint8_t* lv, int64_t loff, const void* r, const uint8_t* rv, int64_t roff,
+                   void* out, int64_t len, unsigned* flag) {
+  switch (op) {
+    case AH_OP_DIV: AH_X(X_DIV);
+    case AH_OP_DIV_CHECKED: AH_X(X_DIV_CHECKED);
+    case AH_OP_ABS_CHECKED: AH_X(X_ABS_CHECKED);
+    case AH_OP_NEGATE_CHECKED: AH_X(X_NEG_CHECKED);
+    case AH_OP_SQRT: AH_X(X_SQRT);
+    case AH_OP_SQRT_CHECKED: AH_X(X_SQRT_CHECKED);
+  }
+#undef AH_X
+  return ah_fail(c, AH_ENOTIMPL, "arithmetic: op %d is not defined for floating point", op);
+}
+
+bool is_unary_op(int op) {
+  return op == AH_OP_BIT_NOT || op == AH_OP_ABS_CHECKED || op == AH_OP_NEGATE_CHECKED || op == AH_OP_SQRT || op == AH_OP_SQRT_CHECKED;
+}
+
+}  // namespace
+
+AH_EXPORT int ah_arithmetic_ext(ah_ctx* c, int type, int op, int shape, const void* l, const uint8_t* lvalid, int64_t loff, const void* r,
+                                const uint8_t* rvalid, int64_t roff, int scalar_valid, void* out, int64_t len) {
+  AH_ENTER(c);
+  if (len < 0 || loff < 0 || roff < 0) return ah_fail(c, AH_EINVALID, "arithmetic: negative length/offset");
+  if (len == 0) return AH_OK;
+  const bool unary = is_unary_op(op);
+  if (unary) shape = AH_SHAPE_AS;
+  if (shape < AH_SHAPE_AA || shape > AH_SHAPE_SA) return ah_fail(c, AH_EINVALID, "arithmetic: bad shape %d", shape);
+  const int w = ah_type_width(type);
+  if (!w) return ah_fail(c, AH_ENOTIMPL, "arithmetic: unsupported type id %d", type);
+  if (!out || (shape != AH_SHAPE_SA && !l) || (!unary && !r) || (shape == AH_SHAPE_SA && !l)) return ah_fail(c, AH_EINVALID, "arithmetic: null buffer");
+  const void* arr0 = shape == AH_SHAPE_SA ? r : l;
+  if ((((uintptr_t)arr0 | (uintptr_t)out | (shape == AH_SHAPE_AA ? (uintptr_t)r : 0)) & (uintptr_t)(w - 1)) != 0)
+    return ah_fail(c, AH_EINVALID, "arithmetic: buffer not element-aligned");
+  const bool every_slot = op == AH_OP_BIT_AND || op == AH_OP_BIT_OR || op == AH_OP_BIT_XOR || op == AH_OP_ABS_CHECKED || op == AH_OP_NEGATE_CHECKED ||
+                          op == AH_OP_SQRT;
+  if (!every_slot && !unary && shape != AH_SHAPE_AA && !scalar_valid) {
+    // null scalar: the output stays as allocated = zero (helpers.go:312-314, 341-343)
+    AH_HIP(c, hipMemsetAsync(out, 0, (size_t)len * w, c->stream));
+    return AH_OK;
+  }
+  unsigned* flag = (unsigned*)c->dscalars;
+  AH_HIP(c, hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+  int rc;
+  switch (type) {
+    case AH_UINT8: rc = dispatch_int<uint8_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_INT8: rc = dispatch_int<int8_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_UINT16: rc = dispatch_int<uint16_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_INT16: rc = dispatch_int<int16_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_UINT32: rc = dispatch_int<uint32_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_INT32: rc = dispatch_int<int32_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_UINT64: rc = dispatch_int<uint64_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_INT64: rc = dispatch_int<int64_t>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_FLOAT32: rc = dispatch_float<float>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    case AH_FLOAT64: rc = dispatch_float<double>(c, op, shape, l, lvalid, loff, r, rvalid, roff, out, len, flag); break;
+    default: return ah_fail(c, AH_ENOTIMPL, "arithmetic: unsupported type id %d", type);
+  }
+  if (rc != AH_OK) return rc;
+  if (op == AH_OP_DIV && (type == AH_FLOAT32 || type == AH_FLOAT64)) return AH_OK;  // cannot fail: no readback
+  if (op == AH_OP_BIT_AND || op == AH_OP_BIT_OR || op == AH_OP_BIT_XOR || op == AH_OP_BIT_NOT || op == AH_OP_SQRT || op == AH_OP_SHIFT_LEFT ||
+      op == AH_OP_SHIFT_RIGHT)
+    return AH_OK;
+  AH_HIP(c, hipMemcpyAsync(c->pinned, flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  const unsigned f = *(volatile unsigned*)c->pinned;
+  if (f & ERR_OVERFLOW) return ah_fail(c, AH_EOVERFLOW, "overflow");
+  if (f & ERR_DIV_ZERO) return ah_fail(c, AH_EINVALID, "divide by zero");
+  if (f & ERR_SHIFT) return ah_fail(c, AH_EINVALID, "shift amount must be >= 0 and less than precision of type");
+  if (f & ERR_NEG_SQRT) return ah_fail(c, AH_EINVALID, "square root of negative number");
+  return AH_OK;
+}

@@ -175,6 +175,23 @@ class Context:
                                        side(r, shape == N.SHAPE_AS), _ptr(rvalid), roff, int(scalar_valid), _ptr(out), n)
         check(self.handle, st)
 
+    def arithmetic_ext(self, type_id: int, op: int, shape: int, l, lvalid, loff, r, rvalid, roff, scalar_valid, out, n: int) -> None:
+        """divide / abs / negate (checked) / bit-wise / shifts / sqrt — see ah_arithmetic_ext; unary ops: r = None"""
+        keep = []
+
+        def side(x, is_scalar):
+            if x is None:
+                return None
+            if is_scalar:
+                s = np.ascontiguousarray(x)
+                keep.append(s)
+                return s.ctypes.data
+            return _ptr(x)
+
+        st = lib.ah_arithmetic_ext(self.handle, type_id, op, shape, side(l, shape == N.SHAPE_SA), _ptr(lvalid), loff,
+                                   side(r, shape == N.SHAPE_AS), _ptr(rvalid), roff, int(scalar_valid), _ptr(out), n)
+        check(self.handle, st)
+
     # ---- compare ------------------------------------------------------------------------
     def comparison(self, cmpop: int, shape: int, type_id: int, l, r, out_bits, n: int, out_bit_offset: int = 0) -> None:
         keep = []

@@ -318,6 +318,7 @@ class ScalarFunction : public Function {  // functions.go:239-290
   // (scalar_compare.go:37-63): when no kernel matches exactly, both arguments are promoted to
   // commonNumeric (utils.go:178-240) and implicitly SAFE-cast (exec.go:105-114)
   bool promote_numeric = false;
+  bool promote_to_float = false;  // unary floating-point functions: integer arguments are cast to float64
   Status DispatchBest(std::vector<const DataType*>* types, const exec::ScalarKernel** out) const;
  private:
   std::vector<exec::ScalarKernel> kernels_;

@@ -389,6 +389,11 @@ const DataType* CommonNumeric(const std::vector<const DataType*>& types) {
 
 Status ScalarFunction::DispatchBest(std::vector<const DataType*>* types, const exec::ScalarKernel** out) const {
   Status st = DispatchExact(*types, out);
+  if (!st.ok() && promote_to_float && types->size() == 1 && IsInteger((*types)[0]->id)) {
+    std::vector<const DataType*> promoted{GetDataType(Type::FLOAT64)};
+    Status st2 = DispatchExact(promoted, out);
+    if (st2.ok()) { *types = promoted; return st2; }
+  }
   if (st.ok() || !promote_numeric || types->size() != 2) return st;
   if (const DataType* common = CommonNumeric(*types)) {
     std::vector<const DataType*> promoted(types->size(), common);

@@ -68,6 +68,39 @@ static Status ExecArithChecked(KernelCtx* k, const ExecSpan& b, ExecResult* out,
   return s->FromStatus(ah_arithmetic_checked(s->ctx(), type, (int8_t)op, shape, l, lv, lo, r, rv, ro, scalar_valid, Values(out), out->len));
 }
 
+// ScalarBinaryNotNull / ScalarUnaryNotNull / whole-buffer closures of the pure-Go arithmetic kernels: divide, abs, negate,
+// bit-wise, shifts, sqrt (base_arithmetic.go:154-160,287-340,386-426; scalar_arithmetic.go:170-378)
+static Status ExecArithExt(KernelCtx* k, const ExecSpan& b, ExecResult* out, int op) {
+  Session* s = k->session;
+  if (out->len == 0) return Status::OK();
+  const int type = (int)out->type->id;
+  const void *l = nullptr, *r = nullptr;
+  const uint8_t *lv = nullptr, *rv = nullptr;
+  int64_t lo = 0, ro = 0;
+  int scalar_valid = 1, shape = AH_SHAPE_AS;
+  if (b.values.size() == 2) shape = ShapeOf(b);
+  if (b.values[0].IsArray()) { l = Values(b.values[0].array); lv = b.values[0].array.MayHaveNulls() ? b.values[0].array.buffers[0].buf : nullptr; lo = b.values[0].array.offset; }
+  else { l = b.values[0].scalar->value; scalar_valid = b.values[0].scalar->valid; }
+  if (b.values.size() == 2) {
+    if (b.values[1].IsArray()) { r = Values(b.values[1].array); rv = b.values[1].array.MayHaveNulls() ? b.values[1].array.buffers[0].buf : nullptr; ro = b.values[1].array.offset; }
+    else { r = b.values[1].scalar->value; scalar_valid = b.values[1].scalar->valid; }
+  }
+  return s->FromStatus(ah_arithmetic_ext(s->ctx(), type, op, shape, l, lv, lo, r, rv, ro, scalar_valid, Values(out), out->len));
+}
+
+static std::shared_ptr<ScalarFunction> MakeArithExt(const std::string& name, int op, int nargs, std::initializer_list<Type> types) {
+  auto fn = std::make_shared<ScalarFunction>(name, Arity{nargs, false});
+  for (Type t : types) {
+    exec::ScalarKernel k;
+    k.sig.in_types = nargs == 2 ? std::vector<Type>{t, t} : std::vector<Type>{t};
+    k.sig.out_is_first_input = true;
+    k.exec_fn = [op](KernelCtx* c, const ExecSpan& b, ExecResult* o) { return ExecArithExt(c, b, o, op); };
+    fn->AddKernel(std::move(k));
+  }
+  fn->promote_numeric = true;  // arithmeticFunction.DispatchBest (arithmetic.go:112-142)
+  return fn;
+}
+
 static Status ExecUnary(KernelCtx* k, const ExecSpan& b, ExecResult* out, int op) {
   Session* s = k->session;
   if (out->len == 0) return Status::OK();
@@ -97,6 +130,28 @@ void RegisterScalarArithmetic(FunctionRegistry* reg) {
   reg->AddFunction(MakeArith("subtract_unchecked", AH_OP_SUB, false), false);
   reg->AddFunction(MakeArith("multiply", AH_OP_MUL_CHECKED, true), false);
   reg->AddFunction(MakeArith("multiply_unchecked", AH_OP_MUL, false), false);
+  // the pure-Go rest of the registry that is exact (arithmetic.go:784-785, 822-840, 855-856, 944-995)
+  const auto ints = {Type::UINT8, Type::INT8, Type::UINT16, Type::INT16, Type::UINT32, Type::INT32, Type::UINT64, Type::INT64};
+  const auto nums = {Type::UINT8, Type::INT8, Type::UINT16, Type::INT16, Type::UINT32, Type::INT32, Type::UINT64, Type::INT64, Type::FLOAT32, Type::FLOAT64};
+  const auto sgn = {Type::INT8, Type::INT16, Type::INT32, Type::INT64, Type::FLOAT32, Type::FLOAT64};
+  const auto flt = {Type::FLOAT32, Type::FLOAT64};
+  reg->AddFunction(MakeArithExt("divide", AH_OP_DIV_CHECKED, 2, nums), false);
+  reg->AddFunction(MakeArithExt("divide_unchecked", AH_OP_DIV, 2, nums), false);
+  reg->AddFunction(MakeArithExt("abs", AH_OP_ABS_CHECKED, 1, nums), false);
+  reg->AddFunction(MakeArithExt("negate", AH_OP_NEGATE_CHECKED, 1, sgn), false);  // GetArithmeticUnarySignedKernels: no unsigned kernel
+  reg->AddFunction(MakeArithExt("bit_wise_and", AH_OP_BIT_AND, 2, ints), false);
+  reg->AddFunction(MakeArithExt("bit_wise_or", AH_OP_BIT_OR, 2, ints), false);
+  reg->AddFunction(MakeArithExt("bit_wise_xor", AH_OP_BIT_XOR, 2, ints), false);
+  reg->AddFunction(MakeArithExt("bit_wise_not", AH_OP_BIT_NOT, 1, ints), false);
+  reg->AddFunction(MakeArithExt("shift_left", AH_OP_SHIFT_LEFT_CHECKED, 2, ints), false);
+  reg->AddFunction(MakeArithExt("shift_left_unchecked", AH_OP_SHIFT_LEFT, 2, ints), false);
+  reg->AddFunction(MakeArithExt("shift_right", AH_OP_SHIFT_RIGHT_CHECKED, 2, ints), false);
+  reg->AddFunction(MakeArithExt("shift_right_unchecked", AH_OP_SHIFT_RIGHT, 2, ints), false);
+  for (auto p : {std::make_pair("sqrt", AH_OP_SQRT_CHECKED), std::make_pair("sqrt_unchecked", AH_OP_SQRT)}) {
+    auto fn = MakeArithExt(p.first, p.second, 1, flt);
+    fn->promote_to_float = true;  // arithmeticFloatingPointFunc.DispatchBest (arithmetic.go:144-170): integers go to float64
+    reg->AddFunction(fn, false);
+  }
   struct U { const char* name; int op; };
   for (U u : {U{"abs_unchecked", AH_OP_ABS}, U{"negate_unchecked", AH_OP_NEGATE}, U{"sign", AH_OP_SIGN}}) {
     auto fn = std::make_shared<ScalarFunction>(u.name, Arity{1, false});

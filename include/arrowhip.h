@@ -64,6 +64,20 @@ extern "C" {
 #define AH_OP_ABS 4
 #define AH_OP_NEGATE 5
 #define AH_OP_SIGN 20
+#define AH_OP_DIV 3               /* ah_arithmetic_ext ops: the reference's ArithmeticOp numbering where it has one … */
+#define AH_OP_SQRT 6
+#define AH_OP_DIV_CHECKED 24
+#define AH_OP_ABS_CHECKED 25
+#define AH_OP_NEGATE_CHECKED 26
+#define AH_OP_SQRT_CHECKED 27
+#define AH_OP_SHIFT_LEFT 64       /* … and private numbers for the shift / bit-wise kernels (scalar_arithmetic.go) */
+#define AH_OP_SHIFT_LEFT_CHECKED 65
+#define AH_OP_SHIFT_RIGHT 66
+#define AH_OP_SHIFT_RIGHT_CHECKED 67
+#define AH_OP_BIT_AND 68
+#define AH_OP_BIT_OR 69
+#define AH_OP_BIT_XOR 70
+#define AH_OP_BIT_NOT 71
 #define AH_OP_ADD_CHECKED 21
 #define AH_OP_SUB_CHECKED 22
 #define AH_OP_MUL_CHECKED 23
@@ -166,6 +180,23 @@ int ah_arithmetic_checked(ah_ctx* ctx, int type, int8_t op, int shape,
                           const void* l, const uint8_t* lvalid, int64_t loff,
                           const void* r, const uint8_t* rvalid, int64_t roff,
                           int scalar_valid, void* out, int64_t len);
+
+/* The exact rest of the arithmetic registry — no assembly leaf in the reference (base_arithmetic_amd64.go:67-105
+ * keeps these in Go), signature derived from the Go closures.  Same argument meaning as ah_arithmetic_checked;
+ * unary ops ignore r / shape.
+ *   DIV, DIV_CHECKED (divide_unchecked, divide; base_arithmetic.go:154-160,287-294,386-396): integers refuse a zero
+ *       divisor in a valid slot under BOTH names (AH_EINVALID "divide by zero"), truncated quotient, MinInt / −1
+ *       wraps; floats: IEEE a / b, the checked name refuses b == 0.  Null slots hold 0 (ScalarBinaryNotNull).
+ *   ABS_CHECKED, NEGATE_CHECKED (abs, negate; :295-340,398-411): MinInt in ANY slot, null or not, is
+ *       AH_EOVERFLOW "overflow" (ScalarUnary walks the whole value buffer); unsigned abs copies; no unsigned negate.
+ *   BIT_AND / OR / XOR (bit_wise_*; scalar_arithmetic.go:170-245): every slot.  BIT_NOT (:253-268): null slots hold 0.
+ *   SHIFT_LEFT / RIGHT [_CHECKED] (:293-378): a count outside [0, bits − 2] (signed) / [0, bits − 1] (unsigned)
+ *       returns the left operand; the checked names make it AH_EINVALID "shift amount must be >= 0 and less than
+ *       precision of type".  Null slots hold 0.
+ *   SQRT (every slot), SQRT_CHECKED (null slots 0; a negative valid value is AH_EINVALID "square root of negative
+ *       number"; :412-426): correctly rounded IEEE sqrt, floats only. */
+int ah_arithmetic_ext(ah_ctx* ctx, int type, int op, int shape, const void* l, const uint8_t* lvalid, int64_t loff, const void* r,
+                      const uint8_t* rvalid, int64_t roff, int scalar_valid, void* out, int64_t len);
 
 /* ---- comparisons → packed bitmap ----------------------------------------------
  * replaces the 12 _comparison_<op>_<shape>_avx2 symbols

@@ -70,6 +70,12 @@ int orc_arithmetic_checked(int type, int8_t op, int shape,
                            const void* r, const uint8_t* rv, int64_t roff,
                            int scalar_valid, void* out, int64_t len);
 
+/* divide / abs / negate (checked) / bit-wise / shifts / sqrt: ops numbered as in include/arrowhip.h
+ * (DIV 3, SQRT 6, DIV_CHECKED 24, ABS_CHECKED 25, NEGATE_CHECKED 26, SQRT_CHECKED 27, SHIFT_LEFT 64 … BIT_NOT 71).
+ * ORC_EOVERFLOW / ORC_EINVALID with the reference's text in msg (>= 128 bytes, may be NULL). */
+int orc_arithmetic_ext(int type, int op, int shape, const void* l, const uint8_t* lvalid, int64_t loff, const void* r,
+                       const uint8_t* rvalid, int64_t roff, int scalar_valid, void* out, int64_t len, char* msg);
+
 /* ---- comparisons → packed bitmap ------------------------------------ */
 int orc_comparison(int cmpop, int shape, int type, const void* l, const void* r,
                    uint8_t* out_bits, int64_t length, int out_bit_offset);

@@ -205,3 +205,119 @@ int orc_arithmetic_checked(int type, int8_t op, int shape,
   }
   return ORC_EINVALID;
 }
+
+/* ---- the exact rest of the arithmetic registry (no SIMD leaf in the reference: pure Go) ----------------
+ * divide / divide_unchecked   base_arithmetic.go:154-160,287-294 (ints: zero divisor in a valid slot → errDivByZero
+ *                             under both names; Go's truncated quotient; MinInt / −1 wraps), :386-396 (floats:
+ *                             unchecked a / b, checked refuses b == 0) — ScalarBinaryNotNull (helpers.go:284-380):
+ *                             out = 0 in null slots, the closure runs only on valid ones
+ * abs / negate                :295-340: ScalarUnary over the WHOLE value buffer (helpers.go:56-90) → MinInt under a
+ *                             null is an overflow too; unsigned abs = copy; floats :398-411
+ * bit_wise_and / or / xor     scalar_arithmetic.go:170-245 (bitmap op on the value bytes: every slot)
+ * bit_wise_not                :253-268 ScalarUnaryNotNull
+ * shift_left / shift_right    :293-378: count outside [0, bits − 2] (signed) / [0, bits − 1] (unsigned) → lhs, and
+ *                             errShift for the checked names; ScalarBinaryNotNull
+ * sqrt_unchecked / sqrt       base_arithmetic.go:412-426
+ * msg (≥ 128 bytes, may be NULL) receives the reference's error text. */
+#include <math.h>
+#include <stdio.h>
+enum { X_OK = 0, X_OVERFLOW = 1, X_DIVZERO = 2, X_SHIFT = 3, X_NEGSQRT = 4 };
+
+static int ext_is_unary(int op) { return op == 71 || op == 25 || op == 26 || op == 6 || op == 27; }
+static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || op == 25 || op == 26 || op == 6; }
+
+#define EXT_INT_BODY(T, U, SIGNED)                                                                                 \
+  {                                                                                                                \
+    const T* l = (const T*)lvp; const T* r = (const T*)rvp; T* o = (T*)ov;                                         \
+    const int bits = (int)sizeof(T) * 8;                                                                           \
+    for (int64_t i = 0; i < len && err == X_OK; i++) {                                                             \
+      const T a = shape == ORC_SHAPE_SA ? l[0] : l[i];                                                             \
+      const T b = unary ? (T)0 : (shape == ORC_SHAPE_AS ? r[0] : r[i]);                                            \
+      int valid = 1;                                                                                               \
+      if (!every) {                                                                                                \
+        if (shape != ORC_SHAPE_SA && lvalid && !((lvalid[(loff + i) >> 3] >> ((loff + i) & 7)) & 1)) valid = 0;    \
+        if (!unary && shape != ORC_SHAPE_AS && rvalid && !((rvalid[(roff + i) >> 3] >> ((roff + i) & 7)) & 1)) valid = 0; \
+      }                                                                                                            \
+      if (!valid) { o[i] = 0; continue; }                                                                          \
+      switch (op) {                                                                                                \
+        case 3: case 24:                                                                                           \
+          if (b == 0) { err = X_DIVZERO; o[i] = 0; break; }                                                        \
+          if (SIGNED && b == (T)-1) { o[i] = (T)((U)0 - (U)a); break; }                                            \
+          o[i] = (T)(a / b); break;                                                                                \
+        case 64: case 65: case 66: case 67: {                                                                      \
+          int bad = SIGNED ? ((long long)b < 0 || (long long)b >= bits - 1) : ((unsigned long long)b >= (unsigned long long)bits); \
+          if (bad) { if (op == 65 || op == 67) err = X_SHIFT; o[i] = a; break; }                                   \
+          if (op == 64 || op == 65) o[i] = (T)((U)a << (int)b);                                                    \
+          else o[i] = SIGNED ? (T)((long long)a >> (int)b) : (T)((U)a >> (int)b);                                  \
+          break;                                                                                                   \
+        }                                                                                                          \
+        case 71: o[i] = (T)~a; break;                                                                              \
+        case 68: o[i] = (T)(a & b); break;                                                                         \
+        case 69: o[i] = (T)(a | b); break;                                                                         \
+        case 70: o[i] = (T)(a ^ b); break;                                                                         \
+        case 25: case 26:                                                                                          \
+          if (!SIGNED) { if (op == 26) return ORC_EINVALID; o[i] = a; break; }                                     \
+          if ((U)a == (U)1 << (bits - 1)) { err = X_OVERFLOW; break; }                                             \
+          o[i] = op == 25 ? (T)((long long)a < 0 ? (T)((U)0 - (U)a) : a) : (T)((U)0 - (U)a);                       \
+          break;                                                                                                   \
+        default: return ORC_EINVALID;                                                                              \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+
+#define EXT_FLOAT_BODY(T, SQRTF, FABSF)                                                                            \
+  {                                                                                                                \
+    const T* l = (const T*)lvp; const T* r = (const T*)rvp; T* o = (T*)ov;                                         \
+    for (int64_t i = 0; i < len && err == X_OK; i++) {                                                             \
+      const T a = shape == ORC_SHAPE_SA ? l[0] : l[i];                                                             \
+      const T b = unary ? (T)0 : (shape == ORC_SHAPE_AS ? r[0] : r[i]);                                            \
+      int valid = 1;                                                                                               \
+      if (!every) {                                                                                                \
+        if (shape != ORC_SHAPE_SA && lvalid && !((lvalid[(loff + i) >> 3] >> ((loff + i) & 7)) & 1)) valid = 0;    \
+        if (!unary && shape != ORC_SHAPE_AS && rvalid && !((rvalid[(roff + i) >> 3] >> ((roff + i) & 7)) & 1)) valid = 0; \
+      }                                                                                                            \
+      if (!valid) { o[i] = 0; continue; }                                                                          \
+      switch (op) {                                                                                                \
+        case 3: o[i] = a / b; break;                                                                               \
+        case 24: if (b == 0) { err = X_DIVZERO; o[i] = 0; } else o[i] = a / b; break;                              \
+        case 25: o[i] = FABSF(a); break;                                                                           \
+        case 26: o[i] = -a; break;                                                                                 \
+        case 6: o[i] = SQRTF(a); break;                                                                            \
+        case 27: if (a < 0) { err = X_NEGSQRT; o[i] = (T)NAN; } else o[i] = SQRTF(a); break;                       \
+        default: return ORC_EINVALID;                                                                              \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+
+int orc_arithmetic_ext(int type, int op, int shape, const void* lvp, const uint8_t* lvalid, int64_t loff, const void* rvp,
+                       const uint8_t* rvalid, int64_t roff, int scalar_valid, void* ov, int64_t len, char* msg) {
+  const int unary = ext_is_unary(op), every = ext_every_slot(op);
+  int err = X_OK;
+  if (unary) shape = ORC_SHAPE_AS;
+  if (!every && !unary && shape != ORC_SHAPE_AA && !scalar_valid) {
+    const int w = type == ORC_UINT8 || type == ORC_INT8 ? 1 : type == ORC_UINT16 || type == ORC_INT16 ? 2
+                : type == ORC_UINT32 || type == ORC_INT32 || type == ORC_FLOAT32 ? 4 : 8;
+    memset(ov, 0, (size_t)len * w);  /* helpers.go:312-314,341-343 */
+    return ORC_OK;
+  }
+  switch (type) {
+    case ORC_UINT8: EXT_INT_BODY(uint8_t, uint8_t, 0) break;
+    case ORC_INT8: EXT_INT_BODY(int8_t, uint8_t, 1) break;
+    case ORC_UINT16: EXT_INT_BODY(uint16_t, uint16_t, 0) break;
+    case ORC_INT16: EXT_INT_BODY(int16_t, uint16_t, 1) break;
+    case ORC_UINT32: EXT_INT_BODY(uint32_t, uint32_t, 0) break;
+    case ORC_INT32: EXT_INT_BODY(int32_t, uint32_t, 1) break;
+    case ORC_UINT64: EXT_INT_BODY(uint64_t, uint64_t, 0) break;
+    case ORC_INT64: EXT_INT_BODY(int64_t, uint64_t, 1) break;
+    case ORC_FLOAT32: EXT_FLOAT_BODY(float, sqrtf, fabsf) break;
+    case ORC_FLOAT64: EXT_FLOAT_BODY(double, sqrt, fabs) break;
+    default: return ORC_EINVALID;
+  }
+  static const char* text[] = {"", "overflow", "divide by zero", "shift amount must be >= 0 and less than precision of type",
+                               "square root of negative number"};
+  if (err != X_OK) {
+    if (msg) snprintf(msg, 128, "%s", text[err]);
+    return err == X_OVERFLOW ? ORC_EOVERFLOW : ORC_EINVALID;
+  }
+  return ORC_OK;
+}

@@ -39,6 +39,10 @@ class OracleBackend:
     def arithmetic_checked(self, op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid=True):
         return self.o.arithmetic_checked(op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid)
 
+    def arithmetic_ext(self, op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid=True):
+        """→ (status, out, error text)"""
+        return self.o.arithmetic_ext(op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid)
+
     def comparison(self, cmpop, shape, l, r, out_init, out_bit_offset=0, misalign=0):
         out = np.array(out_init, dtype=np.uint8, copy=True)
         return self.o.comparison(cmpop, shape, l, r, out, out_bit_offset)
@@ -184,6 +188,25 @@ class HipBackend:
             assert "overflow" in str(e)
             st = STATUS_EOVERFLOW
         return st, ob.download(arr.dtype, arr.size)
+
+    def arithmetic_ext(self, op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid=True):
+        import arrow_go_amd as ah
+        l = np.ascontiguousarray(l); r = None if r is None else np.ascontiguousarray(r)
+        arr = r if shape == 2 else l
+        lb, lp = (None, l) if shape == 2 else self._up(l)
+        rb, rp = (None, r) if (shape == 1 or r is None) else self._up(r)
+        lvb, lvp = self._upbits(lvalid)
+        rvb, rvp = self._upbits(rvalid)
+        ob = self.c.alloc(arr.nbytes + 64)
+        ob.memset(0xCD)
+        st, msg = STATUS_OK, ""
+        try:
+            self.c.arithmetic_ext(OL.TYPE_IDS[arr.dtype], op, shape, lp, lvp, loff, rp, rvp, roff, scalar_valid, ob, arr.size)
+        except ah.ErrOverflow as e:
+            st, msg = STATUS_EOVERFLOW, str(e)
+        except ah.ErrInvalid as e:
+            st, msg = STATUS_EINVALID, str(e)
+        return st, ob.download(arr.dtype, arr.size), msg
 
     def comparison(self, cmpop, shape, l, r, out_init, out_bit_offset=0, misalign=0):
         l = np.ascontiguousarray(l); r = np.ascontiguousarray(r)

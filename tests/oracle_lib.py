@@ -56,6 +56,7 @@ class Oracle:
             "orc_arithmetic_scalar_arr": (it, [it, i8, vp, vp, vp, i64]),
             "orc_arithmetic_unary": (it, [it, i8, vp, vp, i64]),
             "orc_arithmetic_checked": (it, [it, i8, it, vp, vp, i64, vp, vp, i64, it, vp, i64]),
+            "orc_arithmetic_ext": (it, [it, it, it, vp, vp, i64, vp, vp, i64, it, vp, i64, vp]),
             "orc_comparison": (it, [it, it, it, vp, vp, vp, i64, it]),
             "orc_count_set_bits": (i64, [vp, i64, i64]),
             "orc_bitmap_op": (None, [it, vp, i64, vp, i64, vp, i64, i64]),
@@ -126,6 +127,16 @@ class Oracle:
         st = self.lib.orc_arithmetic_checked(TYPE_IDS[arr.dtype], op, shape, _p(l), _p(lvalid), loff, _p(r), _p(rvalid), roff,
                                              int(scalar_valid), _p(out), arr.size)
         return st, out
+
+    def arithmetic_ext(self, op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid=True):
+        """→ (status, out, message)"""
+        l = np.ascontiguousarray(l); r = None if r is None else np.ascontiguousarray(r)
+        arr = r if shape == 2 else l
+        out = np.zeros(arr.size, dtype=arr.dtype)
+        msg = C.create_string_buffer(256)
+        st = self.lib.orc_arithmetic_ext(TYPE_IDS[arr.dtype], op, shape, _p(l), _p(lvalid), loff, _p(r), _p(rvalid), roff,
+                                         int(scalar_valid), _p(out), arr.size, msg)
+        return st, out, msg.value.decode()
 
     # ---- compare ------------------------------------------------------------------------
     def comparison(self, cmpop, shape, l, r, out_bits, out_bit_offset=0):

@@ -733,3 +733,59 @@ def test_fused_equals_three_calls(sess):
     kept = sess.call_function("filter", [x, mask])
     assert kept.null_count == 0
     assert sess.call_function("greater_filter_sum", [x, thr]).as_py() == sess.math_sum(kept) == pc.sum(kept).as_py()
+
+
+# ---- divide / abs / negate / bit-wise / shifts / sqrt through the registry ------------------------------------
+@pytest.mark.gpu
+def test_extended_arithmetic_functions(sess):
+    from arrow_go_amd import compute as ac
+    rng = np.random.default_rng(77)
+    n = 20011
+    for typ in NUMERIC:
+        np_t = typ.to_pandas_dtype()
+        isint = pa.types.is_integer(typ)
+        if isint:
+            info = np.iinfo(np_t)
+            a = pa.array(rng.integers(info.min + 1, info.max, n, dtype=np_t, endpoint=True), mask=rng.random(n) < 0.1, type=typ)
+            bnp = rng.integers(info.min + 1, info.max, n, dtype=np_t, endpoint=True); bnp[bnp == 0] = 1
+            b = pa.array(bnp, mask=rng.random(n) < 0.1, type=typ)
+        else:
+            a = pa.array(rng.standard_normal(n).astype(np_t), mask=rng.random(n) < 0.1, type=typ)
+            b = pa.array((rng.standard_normal(n) + 3).astype(np_t), mask=rng.random(n) < 0.1, type=typ)
+        for name, ref in (("divide", pc.divide_checked), ("divide_unchecked", pc.divide)):
+            assert sess.call_function(name, [a, b]).equals(ref(a, b)), (name, typ)
+            assert sess.call_function(name, [a, pa.scalar(3, typ)]).equals(ref(a, pa.scalar(3, typ)))
+        assert sess.call_function("abs", [a]).equals(pc.abs_checked(a))
+        if isint:
+            with pytest.raises(ac.ErrInvalid, match="divide by zero"):
+                sess.call_function("divide_unchecked", [a, pa.array(np.zeros(n, np_t), type=typ)])
+            for name, ref in (("bit_wise_and", pc.bit_wise_and), ("bit_wise_or", pc.bit_wise_or), ("bit_wise_xor", pc.bit_wise_xor)):
+                assert sess.call_function(name, [a, b]).equals(ref(a, b)), (name, typ)
+            assert sess.call_function("bit_wise_not", [a]).equals(pc.bit_wise_not(a))
+            cnt = pa.array(rng.integers(0, info.bits - 1, n).astype(np_t), mask=rng.random(n) < 0.1, type=typ)
+            for name, ref in (("shift_left", pc.shift_left_checked), ("shift_right", pc.shift_right_checked),
+                              ("shift_left_unchecked", pc.shift_left), ("shift_right_unchecked", pc.shift_right)):
+                assert sess.call_function(name, [a, cnt]).equals(ref(a, cnt)), (name, typ)
+            with pytest.raises(ac.ErrInvalid, match="shift amount"):
+                sess.call_function("shift_left", [a, pa.scalar(info.bits, typ)])
+            if info.min < 0:
+                assert sess.call_function("negate", [a]).equals(pc.negate_checked(a))
+                with pytest.raises(ac.ErrInvalid, match="overflow"):
+                    sess.call_function("abs", [pa.array([1, info.min], type=typ)])
+            else:
+                with pytest.raises(ac.ErrNotImplemented, match="no kernel matching"):
+                    sess.call_function("negate", [a])
+        else:
+            assert sess.call_function("negate", [a]).equals(pc.negate_checked(a))
+            p = pc.abs(a)
+            assert sess.call_function("sqrt", [p]).equals(pc.sqrt_checked(p))
+            got, exp = sess.call_function("sqrt_unchecked", [a]), pc.sqrt(a)
+            assert got.is_valid().equals(exp.is_valid())
+            assert np.array_equal(got.to_numpy(zero_copy_only=False), exp.to_numpy(zero_copy_only=False), equal_nan=True)
+            with pytest.raises(ac.ErrInvalid, match="square root of negative"):
+                sess.call_function("sqrt", [pa.array([4, -1], type=typ)])
+            with pytest.raises(ac.ErrInvalid, match="divide by zero"):
+                sess.call_function("divide", [a, pa.scalar(0, typ)])
+    # implicit promotion, as for the other arithmetic functions
+    assert sess.call_function("divide", [pa.array([7, 9], pa.int8()), pa.array([2, 3], pa.int32())]).equals(pa.array([3, 3], pa.int32()))
+    assert sess.call_function("sqrt", [pa.array([4, 9, None], pa.int32())]).equals(pa.array([2.0, 3.0, None]))

@@ -1064,3 +1064,163 @@ def test_dictionary_encode_binary_vectors(be, odt):
     # empty input
     ids, idv, fr, null_id = be.hash_binary_encode(np.zeros(1, odt), np.zeros(0, np.uint8), None, 0, 0, True)
     assert len(ids) == 0 and len(fr) == 0 and null_id == -1
+
+
+# ---- divide / shifts / bit-wise / abs / negate / sqrt (arrow/compute/arithmetic_test.go) -------------------------
+X = dict(DIV=3, SQRT=6, DIV_CHECKED=24, ABS_CHECKED=25, NEGATE_CHECKED=26, SQRT_CHECKED=27, SHL=64, SHL_CHECKED=65, SHR=66,
+         SHR_CHECKED=67, AND=68, OR=69, XOR=70, NOT=71)
+_INTS = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64]
+_SIGNED = [np.int8, np.int16, np.int32, np.int64]
+_FLOATS = [np.float32, np.float64]
+
+
+def ext_binop(be, op, l, r, dtype, fill=7):
+    """both sides python lists with None → (status, logical result with the null-intersection validity, message, raw)"""
+    la, lv = mk(l, dtype, fill); ra, rv = mk(r, dtype, fill)
+    st, out, msg = be.arithmetic_ext(op, 0, la, lv, 0, ra, rv, 0)
+    valid = [(a is not None) and (b is not None) for a, b in zip(l, r)]
+    return st, [x if ok else None for x, ok in zip(out.tolist(), valid)], msg, out
+
+
+@pytest.mark.parametrize("dtype", _INTS + _FLOATS, ids=str)
+def test_divide_vectors(be, dtype):
+    # arithmetic_test.go:427-459 TestDiv, for divide (checked) and divide_unchecked alike
+    for op in (X["DIV"], X["DIV_CHECKED"]):
+        assert ext_binop(be, op, [3, 2, 6], [1, 1, 2], dtype)[:2] == (0, [3, 2, 3])
+        st, res, _, raw = ext_binop(be, op, [None, 10, 30, None, 20], [1, 5, 2, 5, 10], dtype)
+        assert st == 0 and res == [None, 2, 15, None, 2]
+        assert raw[0] == 0 and raw[3] == 0                                   # ScalarBinaryNotNull: null slots hold 0
+        arr, v = mk([None, 1, 3, None, 2] if np.dtype(dtype).kind != "f" else [None, 1, 2.5, None, 2], dtype, 9)
+        s = np.array([33 if np.dtype(dtype).kind != "f" else 10], dtype)
+        st, out, _ = be.arithmetic_ext(op, 2, s, None, 0, arr, v, 0)       # scalar ÷ array
+        assert st == 0 and out.tolist() == ([0, 33, 11, 0, 16] if np.dtype(dtype).kind != "f" else [0, 10, 4, 0, 5])
+        arr, v = mk([None, 10, 30, None, 2], dtype, 9)
+        st, out, _ = be.arithmetic_ext(op, 1, arr, v, 0, np.array([3 if np.dtype(dtype).kind != "f" else 10], dtype), None, 0)   # array ÷ scalar
+        assert st == 0 and out.tolist()[1:3] == ([3, 10] if np.dtype(dtype).kind != "f" else [1, 3])
+    # :462-481 TestDivideByZero
+    if np.dtype(dtype).kind != "f":
+        for op in (X["DIV"], X["DIV_CHECKED"]):
+            st, _, msg, _ = ext_binop(be, op, [3, 2, 6], [1, 1, 0], dtype)
+            assert st == 1 and "divide by zero" in msg
+        assert ext_binop(be, X["DIV"], [3, None, 6], [1, 0, 2], dtype)[:2] == (0, [3, None, 3])   # a zero divisor under a null is not looked at
+    else:
+        for l in ([3, 2, 6], [3, 2, 0], [3, 2, -6]):
+            st, _, msg, _ = ext_binop(be, X["DIV_CHECKED"], l, [1, 1, 0], dtype)
+            assert st == 1 and "divide by zero" in msg
+        with np.errstate(all="ignore"):
+            assert ext_binop(be, X["DIV"], [3, 2, 6], [1, 1, 0], dtype)[1] == [3, 2, float("inf")]
+            assert ext_binop(be, X["DIV"], [3, 2, -6], [1, 1, 0], dtype)[1] == [3, 2, float("-inf")]
+            assert np.isnan(ext_binop(be, X["DIV"], [3, 2, 0], [1, 1, 0], dtype)[1][2])
+    if dtype in _SIGNED:   # Go: the quotient of MinInt / −1 wraps, and division truncates toward zero
+        mn = np.iinfo(dtype).min
+        assert ext_binop(be, X["DIV"], [mn, -7, 7], [-1, 2, -2], dtype)[1] == [mn, -3, -3]
+
+
+@pytest.mark.parametrize("dtype", _INTS, ids=str)
+def test_shift_vectors(be, dtype):
+    # :571-611 TestShiftLeft / TestShiftRight
+    for op in (X["SHL"], X["SHL_CHECKED"]):
+        assert ext_binop(be, op, [0, 1, 2, 3], [2, 3, 4, 5], dtype)[:2] == (0, [0, 8, 32, 96])
+        assert ext_binop(be, op, [0, None, 2, 3], [2, 3, None, 5], dtype)[:2] == (0, [0, None, None, 96])
+        st, out, _ = be.arithmetic_ext(op, 2, np.array([2], dtype), None, 0, *mk([None, 5], dtype, 1), 0)
+        assert st == 0 and out.tolist() == [0, 64]
+        st, out, _ = be.arithmetic_ext(op, 1, *mk([None, 5], dtype, 1), 0, np.array([3], dtype), None, 0)
+        assert st == 0 and out.tolist() == [0, 40]
+        st, out, _ = be.arithmetic_ext(op, 1, *mk([None, 5], dtype, 1), 0, np.array([3], dtype), None, 0, scalar_valid=False)
+        assert st == 0 and out.tolist() == [0, 0]                           # null scalar: everything null, output zero
+    for op in (X["SHR"], X["SHR_CHECKED"]):
+        assert ext_binop(be, op, [0, 1, 4, 8], [1, 1, 1, 4], dtype)[:2] == (0, [0, 0, 2, 0])
+        assert ext_binop(be, op, [0, None, 4, 8], [1, 1, None, 4], dtype)[:2] == (0, [0, None, None, 0])
+        st, out, _ = be.arithmetic_ext(op, 2, np.array([64], dtype), None, 0, *mk([None, 2, 6], dtype, 1), 0)
+        assert st == 0 and out.tolist() == [0, 16, 1]
+    # :613-671 the overflow tables
+    info = np.iinfo(dtype)
+    signed = info.min < 0
+    bw = info.bits - (1 if signed else 0)
+    err = "shift amount must be >= 0 and less than precision of type"
+    assert ext_binop(be, X["SHL_CHECKED"], [1], [bw - 1], dtype)[1] == [int(dtype(1) << dtype(bw - 1))]
+    assert ext_binop(be, X["SHL_CHECKED"], [2], [bw - 2], dtype)[1] == [int(dtype(1) << dtype(bw - 1))]
+    assert ext_binop(be, X["SHR_CHECKED"], [info.max], [bw - 1], dtype)[1] == [1]
+    if not signed:
+        assert ext_binop(be, X["SHL_CHECKED"], [2, 4], [bw - 1, bw - 1], dtype)[1] == [0, 0]
+        for op in (X["SHL_CHECKED"], X["SHR_CHECKED"]):
+            st, _, msg, _ = ext_binop(be, op, [1], [bw], dtype)
+            assert st == 1 and err in msg
+    else:
+        assert ext_binop(be, X["SHL_CHECKED"], [2, 4, info.min], [bw - 1, bw - 1, 1], dtype)[1] == [info.min, 0, 0]
+        assert ext_binop(be, X["SHR_CHECKED"], [-1, -1, info.min], [1, 5, 1], dtype)[1] == [-1, -1, info.min // 2]
+        for op, un in ((X["SHL_CHECKED"], X["SHL"]), (X["SHR_CHECKED"], X["SHR"])):
+            st, _, msg, _ = ext_binop(be, op, [1, 2], [1, -1], dtype)
+            assert st == 1 and err in msg
+            st, _, msg, _ = ext_binop(be, op, [1], [bw], dtype)
+            assert st == 1 and err in msg
+            assert ext_binop(be, un, [1, 1], [-1, bw], dtype)[:2] == (0, [1, 1])     # unchecked: the left operand comes back
+
+
+@pytest.mark.parametrize("dtype", _INTS, ids=str)
+def test_bitwise_vectors(be, dtype):
+    # :3045-3063 TestBitWiseAnd / Or / Xor (the byte patterns, in every integer width); bit_wise_not :253-268
+    w = np.dtype(dtype).itemsize
+    pat = lambda bs: np.frombuffer(bytes(b for b in bs for _ in range(w)), dtype)
+    a, b = pat([0x00, 0xFF, 0x00, 0xFF]), pat([0x00, 0x00, 0xFF, 0xFF])
+    for op, exp in ((X["AND"], [0x00, 0x00, 0x00, 0xFF]), (X["OR"], [0x00, 0xFF, 0xFF, 0xFF]), (X["XOR"], [0x00, 0xFF, 0xFF, 0x00])):
+        st, out, _ = be.arithmetic_ext(op, 0, a, None, 0, b, None, 0)
+        assert st == 0 and out.tobytes() == pat(exp).tobytes()
+        # the value buffers are combined in every slot: validity does not change the bytes
+        st, out2, _ = be.arithmetic_ext(op, 0, a, OL.pack_bits([True, False, True, False]), 0, b, None, 0)
+        assert out2.tobytes() == out.tobytes()
+    arr, v = mk([0, None, 5, -1 if np.iinfo(dtype).min < 0 else np.iinfo(dtype).max], dtype, 3)
+    st, out, _ = be.arithmetic_ext(X["NOT"], 1, arr, v, 0, None, None, 0)
+    assert st == 0 and out.tolist() == [int(dtype(~dtype(0))), 0, int(dtype(~dtype(5))), 0 if np.iinfo(dtype).min < 0 else 0]
+
+
+@pytest.mark.parametrize("dtype", _INTS + _FLOATS, ids=str)
+def test_abs_negate_checked_vectors(be, dtype):
+    # :2631-2760: abs over signed / unsigned / floating, negate over signed / floating
+    kind = np.dtype(dtype).kind
+    un = lambda op, vals, fill=3: be.arithmetic_ext(op, 1, *mk(vals, dtype, fill), 0, None, None, 0)
+    if kind == "u":
+        st, out, _ = un(X["ABS_CHECKED"], [0, 1, 10, 127, np.iinfo(dtype).max])
+        assert st == 0 and out.tolist() == [0, 1, 10, 127, np.iinfo(dtype).max]
+        return
+    st, out, _ = un(X["ABS_CHECKED"], [1, None, -10, -1, -127, 0])
+    assert st == 0 and out.tolist()[0] == 1 and out.tolist()[2:] == [10, 1, 127, 0]
+    st, out, _ = un(X["NEGATE_CHECKED"], [1, None, -10, 127, -127])
+    assert st == 0 and out.tolist()[0] == -1 and out.tolist()[2:] == [10, -127, 127]
+    if kind == "i":
+        mn, mx = np.iinfo(dtype).min, np.iinfo(dtype).max
+        assert un(X["ABS_CHECKED"], [mx])[1].tolist() == [mx]
+        assert un(X["NEGATE_CHECKED"], [mn + 1, mx])[1].tolist() == [mx, mn + 1]
+        for op in (X["ABS_CHECKED"], X["NEGATE_CHECKED"]):
+            st, _, msg = un(op, [1, mn])
+            assert st == 3 and "overflow" in msg
+            # ScalarUnary walks the whole value buffer: MinInt under a NULL slot overflows as well (helpers.go:56-90)
+            st, _, msg = un(op, [1, None], fill=mn)
+            assert st == 3 and "overflow" in msg
+    else:
+        st, out, _ = un(X["ABS_CHECKED"], [-0.0, float("-inf"), 1.5])
+        assert st == 0 and out.tolist() == [0.0, float("inf"), 1.5] and not np.signbit(out[0])
+        st, out, _ = un(X["NEGATE_CHECKED"], [0.0, float("inf")])
+        assert np.signbit(out[0]) and out[1] == float("-inf")
+
+
+@pytest.mark.parametrize("dtype", _FLOATS, ids=str)
+def test_sqrt_vectors(be, dtype):
+    # base_arithmetic.go:412-426; arithmetic_test.go TestSqrt
+    un = lambda op, vals, fill=4: be.arithmetic_ext(op, 1, *mk(vals, dtype, fill), 0, None, None, 0)
+    for op in (X["SQRT"], X["SQRT_CHECKED"]):
+        st, out, _ = un(op, [0, 1, 4, 2.25, float("inf")])
+        assert st == 0 and out.tolist() == [0, 1, 2, 1.5, float("inf")]
+        st, out, _ = un(op, [9, -0.0])
+        assert st == 0 and out[0] == 3 and np.signbit(out[1])
+    with np.errstate(all="ignore"):
+        st, out, _ = un(X["SQRT"], [4, -1, None], fill=-4)
+        assert st == 0 and out[0] == 2 and np.isnan(out[1]) and np.isnan(out[2])   # unchecked: every slot, null payloads too
+    st, _, msg = un(X["SQRT_CHECKED"], [4, -1])
+    assert st == 1 and "square root of negative number" in msg
+    st, out, _ = un(X["SQRT_CHECKED"], [4, None], fill=-4)
+    assert st == 0 and out.tolist() == [2, 0]
+    # correctly rounded: equals numpy's IEEE sqrt on random inputs
+    x = np.random.default_rng(1).uniform(0, 1e6, 4099).astype(dtype)
+    st, out, _ = be.arithmetic_ext(X["SQRT"], 1, x, None, 0, None, None, 0)
+    assert out.tobytes() == np.sqrt(x).tobytes()

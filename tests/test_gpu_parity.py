@@ -968,3 +968,80 @@ def test_hash_binary_encode_large(hip, orc_be):
     offsets = (np.arange(n + 1, dtype=np.int64) * 8)
     g, e = hip.hash_binary_encode(offsets, data, None, 0, n, True), orc_be.hash_binary_encode(offsets, data, None, 0, n, True)
     assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
+
+
+# ---- divide / shifts / bit-wise / abs / negate / sqrt ------------------------------------------------
+_XOPS = dict(DIV=3, SQRT=6, DIV_CHECKED=24, ABS_CHECKED=25, NEGATE_CHECKED=26, SQRT_CHECKED=27, SHL=64, SHL_CHECKED=65, SHR=66,
+             SHR_CHECKED=67, AND=68, OR=69, XOR=70, NOT=71)
+
+
+def _ext_same(g, e, what):
+    assert g[0] == e[0], (what, g[2], e[2])
+    if e[0] == 0:
+        assert g[1].tobytes() == e[1].tobytes(), what      # every byte, null slots included
+    else:
+        assert g[2].endswith(e[2]) or e[2] in g[2], (what, g[2], e[2])
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64], ids=str)
+def test_arithmetic_ext_integers_bit_exact(hip, orc_be, dtype):
+    rng = np.random.default_rng(1200 + np.dtype(dtype).itemsize * 2 + (np.iinfo(dtype).min < 0))
+    info = np.iinfo(dtype)
+    for n in (1, 15, 16, 17, 1000, 70001):
+        a = rng.integers(info.min, info.max, n + 9, dtype=dtype, endpoint=True)
+        b = rng.integers(info.min, info.max, n + 9, dtype=dtype, endpoint=True)
+        b[b == 0] = 1
+        small = rng.integers(-2 if info.min < 0 else 0, info.bits + 2, n + 9).astype(dtype)   # shift counts around the legal range
+        lv, rv = rand_bits(rng, n + 16, 0.85), rand_bits(rng, n + 16, 0.85)
+        for sl in (0, 3):   # element-aligned but not 16-byte aligned slices
+            A, B, S = a[sl:sl + n], b[sl:sl + n], small[sl:sl + n]
+            for op in ("DIV", "DIV_CHECKED"):
+                for shape, l, r in ((0, A, B), (1, A, B[:1]), (2, A[:1], B)):
+                    _ext_same(hip.arithmetic_ext(_XOPS[op], shape, l, lv, sl, r, rv, 5), orc_be.arithmetic_ext(_XOPS[op], shape, l, lv, sl, r, rv, 5), (op, n, shape))
+            # a zero divisor: an error when its slot is valid, ignored under a null
+            Bz = B.copy(); Bz[n // 2] = 0
+            for v in (None, rv):
+                _ext_same(hip.arithmetic_ext(_XOPS["DIV"], 0, A, None, 0, Bz, v, 5), orc_be.arithmetic_ext(_XOPS["DIV"], 0, A, None, 0, Bz, v, 5), ("div0", n))
+            legal = (S.astype(np.int64) % (info.bits - 1)).astype(dtype)
+            for op in ("SHL", "SHR", "SHL_CHECKED", "SHR_CHECKED"):
+                counts = legal if op.endswith("CHECKED") else S
+                for shape, l, r in ((0, A, counts), (1, A, counts[:1]), (2, A[:1], counts)):
+                    _ext_same(hip.arithmetic_ext(_XOPS[op], shape, l, lv, sl, r, rv, 5), orc_be.arithmetic_ext(_XOPS[op], shape, l, lv, sl, r, rv, 5), (op, n, shape))
+                _ext_same(hip.arithmetic_ext(_XOPS[op], 0, A, None, 0, S, rv, 5), orc_be.arithmetic_ext(_XOPS[op], 0, A, None, 0, S, rv, 5), (op, "illegal counts", n))
+            for op in ("AND", "OR", "XOR"):
+                for shape, l, r in ((0, A, B), (1, A, B[:1]), (2, A[:1], B)):
+                    _ext_same(hip.arithmetic_ext(_XOPS[op], shape, l, lv, sl, r, rv, 5), orc_be.arithmetic_ext(_XOPS[op], shape, l, lv, sl, r, rv, 5), (op, n, shape))
+            _ext_same(hip.arithmetic_ext(_XOPS["NOT"], 1, A, lv, sl, None, None, 0), orc_be.arithmetic_ext(_XOPS["NOT"], 1, A, lv, sl, None, None, 0), ("not", n))
+            ops = ("ABS_CHECKED", "NEGATE_CHECKED") if info.min < 0 else ("ABS_CHECKED",)
+            for op in ops:
+                An = A.copy(); An[An == info.min] = 0
+                _ext_same(hip.arithmetic_ext(_XOPS[op], 1, An, lv, sl, None, None, 0), orc_be.arithmetic_ext(_XOPS[op], 1, An, lv, sl, None, None, 0), (op, n))
+                if info.min < 0:
+                    Am = An.copy(); Am[n - 1] = info.min
+                    _ext_same(hip.arithmetic_ext(_XOPS[op], 1, Am, lv, sl, None, None, 0), orc_be.arithmetic_ext(_XOPS[op], 1, Am, lv, sl, None, None, 0), (op, "min", n))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=str)
+def test_arithmetic_ext_floats_bit_exact(hip, orc_be, dtype):
+    """one correctly rounded IEEE operation per element: bit-exact, NaN / Inf / signed zeros / denormals included"""
+    rng = np.random.default_rng(1300 + np.dtype(dtype).itemsize)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, np.finfo(dtype).tiny, np.finfo(dtype).tiny / 8, np.finfo(dtype).max], dtype)
+    for n in (1, 7, 1000, 70001):
+        a = (rng.standard_normal(n + 5) * 10.0 ** rng.integers(-30, 30, n + 5)).astype(dtype)
+        b = (rng.standard_normal(n + 5) * 10.0 ** rng.integers(-30, 30, n + 5)).astype(dtype)
+        k = min(len(special), n)
+        a[:k] = special[:k]; b[:k] = special[::-1][:k]
+        lv, rv = rand_bits(rng, n + 16, 0.85), rand_bits(rng, n + 16, 0.85)
+        with np.errstate(all="ignore"):
+            for sl in (0, 1):
+                A, B = a[sl:sl + n], b[sl:sl + n]
+                for shape, l, r in ((0, A, B), (1, A, B[:1]), (2, A[:1], B)):
+                    _ext_same(hip.arithmetic_ext(_XOPS["DIV"], shape, l, lv, sl, r, rv, 5), orc_be.arithmetic_ext(_XOPS["DIV"], shape, l, lv, sl, r, rv, 5), ("div", n, shape))
+                Bn = B.copy(); Bn[Bn == 0] = 2
+                _ext_same(hip.arithmetic_ext(_XOPS["DIV_CHECKED"], 0, A, lv, sl, Bn, rv, 5), orc_be.arithmetic_ext(_XOPS["DIV_CHECKED"], 0, A, lv, sl, Bn, rv, 5), ("divc", n))
+                _ext_same(hip.arithmetic_ext(_XOPS["DIV_CHECKED"], 0, A, None, 0, B, None, 0), orc_be.arithmetic_ext(_XOPS["DIV_CHECKED"], 0, A, None, 0, B, None, 0), ("divc zero", n))
+                for op in ("ABS_CHECKED", "NEGATE_CHECKED", "SQRT"):
+                    _ext_same(hip.arithmetic_ext(_XOPS[op], 1, A, lv, sl, None, None, 0), orc_be.arithmetic_ext(_XOPS[op], 1, A, lv, sl, None, None, 0), (op, n))
+                P = np.abs(A)
+                _ext_same(hip.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, P, lv, sl, None, None, 0), orc_be.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, P, lv, sl, None, None, 0), ("sqrtc", n))
+                _ext_same(hip.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, A, None, 0, None, None, 0), orc_be.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, A, None, 0, None, None, 0), ("sqrtc neg", n))
