@@ -88,11 +88,36 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(const T* __restrict__ a
   const int64_t n_iters = (nvec + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);
   const int lane = threadIdx.x & 63;
 
+  auto mask_of = [&](const VT& xv, const VT& yv) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      T xe, ye;
+      if constexpr (ALIGNED) { xe = xv[e]; ye = yv[e]; } else { xe = xv.v[e]; ye = yv.v[e]; }
+      m |= (uint32_t)pred(xe, ye) << e;
+    }
+    return m;
+  };
+  // merge the V-bit lane masks into dwords (lane L gets the bits of lanes L .. L+LPW−1) and store
+  auto emit = [&](int64_t j, uint32_t m) {
+#pragma unroll
+    for (int s = 1; s < LPW; s <<= 1) m |= (uint32_t)__shfl_down((int)m, s, 64) << (V * s);
+    if ((lane % LPW) == 0) {
+      const int64_t bit0 = j * V;  // first body bit of this dword (multiple of 32)
+      if (bit0 < nb) {
+        const int64_t left = nb - bit0;
+        store_bits(ob + (bit0 >> 3), m, left >= 32 ? 32 : (int)left);
+      }
+    }
+  };
+
   for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
     const int64_t base = it * kBlock * kUnroll + threadIdx.x;
-    VT x[kUnroll], y[kUnroll] = {};
-    bool full_iter = (it + 1) * (int64_t)kBlock * kUnroll <= nvec_full;
-    if (full_iter) {
+    if ((it + 1) * (int64_t)kBlock * kUnroll <= nvec_full) {
+      // the whole tile is full vectors: all loads first, then straight-line code (two separate paths on purpose —
+      // one loop with a per-vector "is it loaded already" choice made the compiler index the register arrays
+      // dynamically and spill them to scratch: 3.8 TB/s instead of 6+ on 1- and 2-byte types)
+      VT x[kUnroll], y[kUnroll] = {};
 #pragma unroll
       for (int k = 0; k < kUnroll; k++) {
         if constexpr (ALIGNED && NT) {
@@ -103,34 +128,21 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(const T* __restrict__ a
           if (SHAPE == 0) y[k] = bv[base + (int64_t)k * kBlock];
         }
       }
-    }
 #pragma unroll
-    for (int k = 0; k < kUnroll; k++) {
-      const int64_t j = base + (int64_t)k * kBlock;
-      uint32_t m = 0;
-      if (full_iter || j < nvec_full) {
-        VT xv, yv = {};
-        if (full_iter) { xv = x[k]; yv = y[k]; }
-        else { xv = av[j]; if (SHAPE == 0) yv = bv[j]; }
-#pragma unroll
-        for (int e = 0; e < V; e++) {
-          T xe, ye;
-          if constexpr (ALIGNED) { xe = xv[e]; ye = yv[e]; } else { xe = xv.v[e]; ye = yv.v[e]; }
-          m |= (uint32_t)pred(xe, ye) << e;
+      for (int k = 0; k < kUnroll; k++) emit(base + (int64_t)k * kBlock, mask_of(x[k], y[k]));
+    } else {
+      for (int k = 0; k < kUnroll; k++) {
+        const int64_t j = base + (int64_t)k * kBlock;
+        uint32_t m = 0;
+        if (j < nvec_full) {
+          VT xv = av[j], yv = xv;
+          if (SHAPE == 0) yv = bv[j];
+          m = mask_of(xv, yv);
+        } else if (j == nvec_full) {  // ragged last vector: element-wise, in bounds
+          const int rem = (int)(nb - nvec_full * V);
+          for (int e = 0; e < rem; e++) m |= (uint32_t)pred(ab[j * V + e], SHAPE == 0 ? bb[j * V + e] : scalar) << e;
         }
-      } else if (j == nvec_full) {  // ragged last vector: element-wise, in bounds
-        int rem = (int)(nb - nvec_full * V);
-        for (int e = 0; e < rem; e++) m |= (uint32_t)pred(ab[j * V + e], SHAPE == 0 ? bb[j * V + e] : scalar) << e;
-      }
-      // merge V-bit lane masks into dwords: lane L gets bits of lanes L .. L+LPW-1
-#pragma unroll
-      for (int s = 1; s < LPW; s <<= 1) m |= (uint32_t)__shfl_down((int)m, s, 64) << (V * s);
-      if ((lane % LPW) == 0) {
-        int64_t bit0 = j * V;  // first body bit of this dword (multiple of 32)
-        if (bit0 < nb) {
-          int64_t left = nb - bit0;
-          store_bits(ob + (bit0 >> 3), m, left >= 32 ? 32 : (int)left);
-        }
+        emit(j, m);
       }
     }
   }
