@@ -13,6 +13,7 @@
 //   shift_left / shift_right   :293-378: a shift count outside [0, bits − 2] (signed) / [0, bits − 1] (unsigned)
 //                              returns the left operand, and is "shift amount must be >= 0 and less than precision
 //                              of type" for the checked names; ScalarBinaryNotNull
+//   floor, ceil, trunc         rounding.go:180-187, 748-775: math.Floor / Ceil / Trunc in every slot (ScalarUnary), floats
 //   sqrt, sqrt_unchecked       base_arithmetic.go:412-426: unchecked in every slot (ScalarUnary), checked NotNull
 //                              with "square root of negative number"
 // None of these has an assembly leaf in the reference (base_arithmetic_amd64.go:67-105: "no SIMD for POWER or
@@ -58,10 +59,10 @@ __device__ __forceinline__ void store16(ST* base, int64_t i, const ah_vec16<ST>&
 
 enum { ERR_OVERFLOW = 1, ERR_DIV_ZERO = 2, ERR_SHIFT = 4, ERR_NEG_SQRT = 8 };
 enum { X_DIV, X_DIV_CHECKED, X_SHL, X_SHL_CHECKED, X_SHR, X_SHR_CHECKED, X_BIT_NOT, X_SQRT_CHECKED,  // NotNull
-       X_ABS_CHECKED, X_NEG_CHECKED, X_BIT_AND, X_BIT_OR, X_BIT_XOR, X_SQRT };                       // every slot
+       X_ABS_CHECKED, X_NEG_CHECKED, X_BIT_AND, X_BIT_OR, X_BIT_XOR, X_SQRT, X_FLOOR, X_CEIL, X_TRUNC };  // every slot
 
 constexpr bool NotNull(int x) { return x <= X_SQRT_CHECKED; }
-constexpr bool Unary(int x) { return x == X_BIT_NOT || x == X_SQRT_CHECKED || x == X_ABS_CHECKED || x == X_NEG_CHECKED || x == X_SQRT; }
+constexpr bool Unary(int x) { return x == X_BIT_NOT || x == X_SQRT_CHECKED || x == X_ABS_CHECKED || x == X_NEG_CHECKED || x >= X_SQRT; }
 
 template <typename ST, int X>
 __device__ __forceinline__ ST apply(ST a, ST b, unsigned& err) {
@@ -103,6 +104,15 @@ __device__ __forceinline__ ST apply(ST a, ST b, unsigned& err) {
       constexpr ST tmin = (ST)((U)1 << (bits - 1));
       if (a == tmin) { err |= ERR_OVERFLOW; return (ST)0; }
       return X == X_ABS_CHECKED ? (ST)(a < 0 ? -a : a) : (ST)-a;
+    }
+  } else if constexpr (X == X_FLOOR || X == X_CEIL || X == X_TRUNC) {
+    // getFloatRoundImpl (rounding.go:180-187): math.Floor / Ceil / Trunc of the value widened to float64 and narrowed
+    // back — exact in the narrow type as well
+    if constexpr (kFloat) {
+      const double v = (double)a;
+      return (ST)(X == X_FLOOR ? __builtin_floor(v) : X == X_CEIL ? __builtin_ceil(v) : __builtin_trunc(v));
+    } else {
+      return a;
     }
   } else {  // X_SQRT, X_SQRT_CHECKED
     if constexpr (kFloat) {
@@ -211,13 +221,17 @@ int dispatch_float(ah_ctx* c, int op, int shape, const void* l, const uint8_t* l
     case AH_OP_NEGATE_CHECKED: AH_X(X_NEG_CHECKED);
     case AH_OP_SQRT: AH_X(X_SQRT);
     case AH_OP_SQRT_CHECKED: AH_X(X_SQRT_CHECKED);
+    case AH_OP_FLOOR: AH_X(X_FLOOR);
+    case AH_OP_CEIL: AH_X(X_CEIL);
+    case AH_OP_TRUNC: AH_X(X_TRUNC);
   }
 #undef AH_X
   return ah_fail(c, AH_ENOTIMPL, "arithmetic: op %d is not defined for floating point", op);
 }
 
 bool is_unary_op(int op) {
-  return op == AH_OP_BIT_NOT || op == AH_OP_ABS_CHECKED || op == AH_OP_NEGATE_CHECKED || op == AH_OP_SQRT || op == AH_OP_SQRT_CHECKED;
+  return op == AH_OP_BIT_NOT || op == AH_OP_ABS_CHECKED || op == AH_OP_NEGATE_CHECKED || op == AH_OP_SQRT || op == AH_OP_SQRT_CHECKED ||
+         op == AH_OP_FLOOR || op == AH_OP_CEIL || op == AH_OP_TRUNC;
 }
 
 }  // namespace
@@ -237,7 +251,7 @@ AH_EXPORT int ah_arithmetic_ext(ah_ctx* c, int type, int op, int shape, const vo
   if ((((uintptr_t)arr0 | (uintptr_t)out | (shape == AH_SHAPE_AA ? (uintptr_t)r : 0)) & (uintptr_t)(w - 1)) != 0)
     return ah_fail(c, AH_EINVALID, "arithmetic: buffer not element-aligned");
   const bool every_slot = op == AH_OP_BIT_AND || op == AH_OP_BIT_OR || op == AH_OP_BIT_XOR || op == AH_OP_ABS_CHECKED || op == AH_OP_NEGATE_CHECKED ||
-                          op == AH_OP_SQRT;
+                          op == AH_OP_SQRT || op == AH_OP_FLOOR || op == AH_OP_CEIL || op == AH_OP_TRUNC;
   if (!every_slot && !unary && shape != AH_SHAPE_AA && !scalar_valid) {
     // null scalar: the output stays as allocated = zero (helpers.go:312-314, 341-343)
     AH_HIP(c, hipMemsetAsync(out, 0, (size_t)len * w, c->stream));
@@ -262,7 +276,7 @@ AH_EXPORT int ah_arithmetic_ext(ah_ctx* c, int type, int op, int shape, const vo
   if (rc != AH_OK) return rc;
   if (op == AH_OP_DIV && (type == AH_FLOAT32 || type == AH_FLOAT64)) return AH_OK;  // cannot fail: no readback
   if (op == AH_OP_BIT_AND || op == AH_OP_BIT_OR || op == AH_OP_BIT_XOR || op == AH_OP_BIT_NOT || op == AH_OP_SQRT || op == AH_OP_SHIFT_LEFT ||
-      op == AH_OP_SHIFT_RIGHT)
+      op == AH_OP_SHIFT_RIGHT || op == AH_OP_FLOOR || op == AH_OP_CEIL || op == AH_OP_TRUNC)
     return AH_OK;
   AH_HIP(c, hipMemcpyAsync(c->pinned, flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));

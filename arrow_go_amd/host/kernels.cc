@@ -152,6 +152,11 @@ void RegisterScalarArithmetic(FunctionRegistry* reg) {
     fn->promote_to_float = true;  // arithmeticFloatingPointFunc.DispatchBest (arithmetic.go:144-170): integers go to float64
     reg->AddFunction(fn, false);
   }
+  for (auto p : {std::make_pair("floor", AH_OP_FLOOR), std::make_pair("ceil", AH_OP_CEIL), std::make_pair("trunc", AH_OP_TRUNC)}) {
+    auto fn = MakeArithExt(p.first, p.second, 1, flt);  // GetSimpleRoundKernels (rounding.go:748-775)
+    fn->promote_to_float = true;                         // arithmeticIntegerToFloatingPointFunc (arithmetic.go:172-200)
+    reg->AddFunction(fn, false);
+  }
   struct U { const char* name; int op; };
   for (U u : {U{"abs_unchecked", AH_OP_ABS}, U{"negate_unchecked", AH_OP_NEGATE}, U{"sign", AH_OP_SIGN}}) {
     auto fn = std::make_shared<ScalarFunction>(u.name, Arity{1, false});
@@ -202,6 +207,62 @@ void RegisterScalarComparisons(FunctionRegistry* reg) {
   auto le = std::make_shared<ScalarFunction>("less_equal", Arity{2, false});
   le->flipped_of = "greater_equal";
   reg->AddFunction(le, false);
+  // is_null / is_not_null / is_nan (scalar_compare.go:138-160; kernels/scalar_comparisons.go:718-813)
+  const std::vector<Type> any_types = {Type::BOOL, Type::UINT8, Type::INT8, Type::UINT16, Type::INT16, Type::UINT32, Type::INT32, Type::UINT64,
+                                       Type::INT64, Type::FLOAT32, Type::FLOAT64, Type::STRING, Type::BINARY, Type::LARGE_STRING, Type::LARGE_BINARY};
+  auto validity_fn = [&](const char* name, bool want_null) {
+    auto fn = std::make_shared<ScalarFunction>(name, Arity{1, false});
+    for (Type t : any_types) {
+      exec::ScalarKernel k;
+      k.sig.in_types = {t};
+      k.sig.out_is_first_input = false;
+      k.sig.out_type = Type::BOOL;
+      k.null_handling = exec::NullHandling::NullComputedNoPrealloc;  // :753-758: the result is never null
+      k.mem_alloc = exec::MemAlloc::MemNoPrealloc;
+      k.exec_fn = [want_null](KernelCtx* c, const ExecSpan& b, ExecResult* out) -> Status {
+        // isNullExec: the inverted validity, or zeros when there is none (:718-730).  isNotNullExec: the validity itself
+        // (:732-745) — the reference shares the buffer WITHOUT carrying the input offset, which mis-reads sliced arrays;
+        // here the bits are copied from the offset (equal wherever the reference is right)
+        Session* s = c->session;
+        const ArraySpan& in = b.values[0].array;
+        BufferPtr bits;
+        AHC_RETURN_NOT_OK(c->AllocateBitmap(in.len, &bits));
+        out->nulls = 0;
+        out->buffers[1].WrapBuffer(bits);
+        if (in.len == 0) return Status::OK();
+        AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), bits->dptr, 0, (size_t)((in.len + 7) / 8))));
+        if (in.buffers[0].buf)
+          return s->FromStatus(ah_copy_bitmap(s->ctx(), in.buffers[0].buf, in.offset, in.len, (uint8_t*)bits->dptr, 0, want_null ? 1 : 0));
+        return want_null ? Status::OK() : s->FromStatus(ah_set_bits_to(s->ctx(), (uint8_t*)bits->dptr, 0, in.len, 1));
+      };
+      fn->AddKernel(std::move(k));
+    }
+    reg->AddFunction(fn, false);
+  };
+  validity_fn("is_null", true);
+  validity_fn("is_not_null", false);
+  {
+    auto fn = std::make_shared<ScalarFunction>("is_nan", Arity{1, false});
+    for (Type t : kNumericTypes) {
+      exec::ScalarKernel k;
+      k.sig.in_types = {t};
+      k.sig.out_is_first_input = false;
+      k.sig.out_type = Type::BOOL;
+      k.null_handling = exec::NullHandling::NullNoOutput;  // :788,792,800
+      k.exec_fn = [](KernelCtx* c, const ExecSpan& b, ExecResult* out) -> Status {
+        Session* s = c->session;
+        if (out->len == 0) return Status::OK();
+        const ArraySpan& in = b.values[0].array;
+        uint8_t* ob = out->buffers[1].buf + out->offset / 8;
+        if (IsFloating(in.type->id))  // isNanKernelExec: x != x over every slot (:770-780)
+          return s->FromStatus(ah_comparison(s->ctx(), AH_CMP_NE, AH_SHAPE_AA, (int)in.type->id, Values(in), Values(in), ob, out->len, (int)(out->offset % 8)));
+        return s->FromStatus(ah_set_bits_to(s->ctx(), out->buffers[1].buf, out->offset, out->len, 0));  // ConstBoolExec(false) :763-768
+      };
+      fn->AddKernel(std::move(k));
+    }
+    reg->AddFunction(fn, false);
+  }
+
 }
 
 // ---- boolean --------------------------------------------------------------------------------

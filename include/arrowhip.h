@@ -78,6 +78,9 @@ extern "C" {
 #define AH_OP_BIT_OR 69
 #define AH_OP_BIT_XOR 70
 #define AH_OP_BIT_NOT 71
+#define AH_OP_FLOOR 72             /* floor / ceil / trunc (kernels/rounding.go:180-187, 748-775) */
+#define AH_OP_CEIL 73
+#define AH_OP_TRUNC 74
 #define AH_OP_ADD_CHECKED 21
 #define AH_OP_SUB_CHECKED 22
 #define AH_OP_MUL_CHECKED 23
@@ -194,7 +197,8 @@ int ah_arithmetic_checked(ah_ctx* ctx, int type, int8_t op, int shape,
  *       returns the left operand; the checked names make it AH_EINVALID "shift amount must be >= 0 and less than
  *       precision of type".  Null slots hold 0.
  *   SQRT (every slot), SQRT_CHECKED (null slots 0; a negative valid value is AH_EINVALID "square root of negative
- *       number"; :412-426): correctly rounded IEEE sqrt, floats only. */
+ *       number"; :412-426): correctly rounded IEEE sqrt, floats only.
+ *   FLOOR, CEIL, TRUNC (floor, ceil, trunc; rounding.go:180-187,748-775): every slot, floats only. */
 int ah_arithmetic_ext(ah_ctx* ctx, int type, int op, int shape, const void* l, const uint8_t* lvalid, int64_t loff, const void* r,
                       const uint8_t* rvalid, int64_t roff, int scalar_valid, void* out, int64_t len);
 

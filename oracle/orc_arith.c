@@ -217,14 +217,15 @@ int orc_arithmetic_checked(int type, int8_t op, int shape,
  * bit_wise_not                :253-268 ScalarUnaryNotNull
  * shift_left / shift_right    :293-378: count outside [0, bits − 2] (signed) / [0, bits − 1] (unsigned) → lhs, and
  *                             errShift for the checked names; ScalarBinaryNotNull
+ * floor / ceil / trunc        rounding.go:180-187,748-775 (ScalarUnary: every slot)
  * sqrt_unchecked / sqrt       base_arithmetic.go:412-426
  * msg (≥ 128 bytes, may be NULL) receives the reference's error text. */
 #include <math.h>
 #include <stdio.h>
 enum { X_OK = 0, X_OVERFLOW = 1, X_DIVZERO = 2, X_SHIFT = 3, X_NEGSQRT = 4 };
 
-static int ext_is_unary(int op) { return op == 71 || op == 25 || op == 26 || op == 6 || op == 27; }
-static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || op == 25 || op == 26 || op == 6; }
+static int ext_is_unary(int op) { return op == 71 || op == 25 || op == 26 || op == 6 || op == 27 || (op >= 72 && op <= 74); }
+static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || op == 25 || op == 26 || op == 6 || (op >= 72 && op <= 74); }
 
 #define EXT_INT_BODY(T, U, SIGNED)                                                                                 \
   {                                                                                                                \
@@ -284,6 +285,9 @@ static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || o
         case 26: o[i] = -a; break;                                                                                 \
         case 6: o[i] = SQRTF(a); break;                                                                            \
         case 27: if (a < 0) { err = X_NEGSQRT; o[i] = (T)NAN; } else o[i] = SQRTF(a); break;                       \
+        case 72: o[i] = (T)floor((double)a); break;   /* rounding.go:183 */                                          \
+        case 73: o[i] = (T)ceil((double)a); break;    /* :185 */                                                     \
+        case 74: o[i] = (T)trunc((double)a); break;   /* :187 */                                                     \
         default: return ORC_EINVALID;                                                                              \
       }                                                                                                            \
     }                                                                                                              \

@@ -789,3 +789,31 @@ def test_extended_arithmetic_functions(sess):
     # implicit promotion, as for the other arithmetic functions
     assert sess.call_function("divide", [pa.array([7, 9], pa.int8()), pa.array([2, 3], pa.int32())]).equals(pa.array([3, 3], pa.int32()))
     assert sess.call_function("sqrt", [pa.array([4, 9, None], pa.int32())]).equals(pa.array([2.0, 3.0, None]))
+
+
+@pytest.mark.gpu
+def test_validity_and_rounding_functions(sess):
+    """is_null / is_not_null / is_nan (scalar_compare.go:138-160) and floor / ceil / trunc (rounding.go:748-775)"""
+    rng = np.random.default_rng(78)
+    n = 10007
+    cols = [pa.array(rng.integers(-5, 5, n), mask=rng.random(n) < 0.3, type=pa.int32()),
+            pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.3, type=pa.float64()),
+            pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.3),
+            pa.array(["a", "bb", None, ""] * (n // 4) + ["x"] * (n % 4)),
+            pa.array(rng.integers(0, 9, n), type=pa.uint8())]          # no validity buffer at all
+    for c in cols:
+        for v in (c, c.slice(13, 999), c.slice(0, 0)):                  # sliced inputs: bits are taken from the offset
+            assert sess.call_function("is_null", [v]).equals(pc.is_null(v))
+            assert sess.call_function("is_not_null", [v]).equals(pc.is_valid(v))
+    f = pa.array([1.0, float("nan"), None, float("inf"), -0.0], type=pa.float64())
+    assert sess.call_function("is_nan", [f]).to_pylist() == [False, True, False, False, False]     # NullNoOutput: no nulls in the result
+    assert sess.call_function("is_nan", [f]).null_count == 0
+    f32 = pa.array(np.array([np.nan, 1, np.nan], np.float32))
+    assert sess.call_function("is_nan", [f32]).to_pylist() == [True, False, True]
+    assert sess.call_function("is_nan", [cols[0]]).to_pylist() == [False] * n
+    x = pa.array(rng.standard_normal(n) * 100, mask=rng.random(n) < 0.1, type=pa.float64())
+    x32 = x.cast(pa.float32())
+    for name, ref in (("floor", pc.floor), ("ceil", pc.ceil), ("trunc", pc.trunc)):
+        assert sess.call_function(name, [x]).equals(ref(x))
+        assert sess.call_function(name, [x32]).equals(ref(x32))
+        assert sess.call_function(name, [cols[0]]).equals(ref(cols[0].cast(pa.float64())))        # integers go to float64

@@ -1224,3 +1224,21 @@ def test_sqrt_vectors(be, dtype):
     x = np.random.default_rng(1).uniform(0, 1e6, 4099).astype(dtype)
     st, out, _ = be.arithmetic_ext(X["SQRT"], 1, x, None, 0, None, None, 0)
     assert out.tobytes() == np.sqrt(x).tobytes()
+
+
+@pytest.mark.parametrize("dtype", _FLOATS, ids=str)
+def test_floor_ceil_trunc_vectors(be, dtype):
+    # arithmetic_test.go TestRounding*: floor / ceil / trunc tables (rounding.go:180-187)
+    vals = [3.2, 3.5, 3.7, 4.5, -3.2, -3.5, -3.7, 0.0, -0.0, float("inf"), float("-inf")]
+    exp = {72: [3, 3, 3, 4, -4, -4, -4, 0, -0.0, float("inf"), float("-inf")],
+           73: [4, 4, 4, 5, -3, -3, -3, 0, -0.0, float("inf"), float("-inf")],
+           74: [3, 3, 3, 4, -3, -3, -3, 0, -0.0, float("inf"), float("-inf")]}
+    arr = np.array(vals, dtype)
+    for op, e in exp.items():
+        st, out, _ = be.arithmetic_ext(op, 1, arr, None, 0, None, None, 0)
+        assert st == 0 and out.tolist() == e and np.signbit(out[8])
+        st, out, _ = be.arithmetic_ext(op, 1, np.array([np.nan, 2.5], dtype), OL.pack_bits([True, False]), 0, None, None, 0)
+        assert np.isnan(out[0]) and out[1] == {72: 2, 73: 3, 74: 2}[op]       # every slot, nulls included
+    x = (np.random.default_rng(2).standard_normal(5003) * 1e3).astype(dtype)
+    for op, f in ((72, np.floor), (73, np.ceil), (74, np.trunc)):
+        assert be.arithmetic_ext(op, 1, x, None, 0, None, None, 0)[1].tobytes() == f(x).tobytes()
