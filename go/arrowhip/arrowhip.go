@@ -213,6 +213,40 @@ func (x *Context) CastNumeric(in, out arrow.Type, values, valid unsafe.Pointer, 
 		boolInt(opts.AllowIntOverflow), boolInt(opts.AllowFloatTruncate), dst))
 }
 
+// ArithmeticExt covers the pure-Go arithmetic kernels that have no assembly leaf: divide, abs, negate,
+// bit-wise ops, shifts, sqrt, floor / ceil / trunc (base_arithmetic.go:154-160,287-340,386-426;
+// scalar_arithmetic.go:170-378; rounding.go:180-187).  op: AH_OP_* of include/arrowhip.h.  Errors carry
+// the reference's text ("divide by zero", "overflow", …) as arrow.ErrInvalid.
+func (x *Context) ArithmeticExt(typ arrow.Type, op, shape int, l, lvalid unsafe.Pointer, loff int64, r, rvalid unsafe.Pointer, roff int64,
+	scalarValid bool, out unsafe.Pointer, n int64) error {
+	return x.err(C.ah_arithmetic_ext(x.c, C.int(typ), C.int(op), C.int(shape), l, (*C.uint8_t)(lvalid), C.int64_t(loff),
+		r, (*C.uint8_t)(rvalid), C.int64_t(roff), boolInt(scalarValid), out, C.int64_t(n)))
+}
+
+// HashBinaryEncode mirrors doAppendBinary over BinaryMemoTable (vector_hash.go:288-325): ids in first-seen
+// order and, per dictionary entry, the row that first held it; the dictionary itself is
+// TakeBinary(values, firstRows[:ndict]).
+func (x *Context) HashBinaryEncode(offsetWidth int, offsets, data, valid unsafe.Pointer, off, n int64, encodeNulls bool,
+	outIDs, outIDsValid, outFirstRows unsafe.Pointer) (ndict int64, nullID int32, err error) {
+	var nd C.int64_t
+	var nid C.int32_t
+	st := C.ah_hash_binary_encode(x.c, C.int(offsetWidth), offsets, (*C.uint8_t)(data), (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n),
+		boolInt(encodeNulls), (*C.int32_t)(outIDs), (*C.uint8_t)(outIDsValid), (*C.int64_t)(outFirstRows), &nd, &nid)
+	return int64(nd), int32(nid), x.err(st)
+}
+
+// SortIndices mirrors the single-column path of sortIndicesMetaFunc (compute/vector_sort.go:110-215):
+// a stable order, uint64 indices.
+func (x *Context) SortIndices(typ arrow.Type, values, valid unsafe.Pointer, off, n int64, descending, nullsAtStart bool, outIndices unsafe.Pointer) error {
+	return x.err(C.ah_sort_indices(x.c, C.int(typ), values, (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n), boolInt(descending),
+		boolInt(nullsAtStart), (*C.uint64_t)(outIndices)))
+}
+
+// CopyDevice is the device-to-device copy array.Concatenate needs when chunked inputs are laid end to end in HBM.
+func (x *Context) CopyDevice(dst, src unsafe.Pointer, nbytes int) error {
+	return x.err(C.ah_copy_async(x.c, dst, src, C.size_t(nbytes)))
+}
+
 func boolInt(b bool) C.int {
 	if b {
 		return 1
