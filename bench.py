@@ -266,6 +266,41 @@ def main():
     add_ms = [ctx.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(args.steps)]
     add_avg_ms = float(np.mean(add_ms)) if add_ms else float("nan")
 
+    # Secondary line (config C4, the 1/2/4/8-GPU curve of the record-batch-sharded filter + aggregate): every rank runs the
+    # fused Compare(>) → Filter → Sum over its 2^27-row Int64 shard, the 16-byte (sum, count) partial is all-reduced.
+    # Same protocol as above — barrier, K steps, barrier, MAX over ranks — reported next to the headline, never as `value`.
+    c4 = None
+    try:
+        if use_dist:
+            pair = torch.zeros(2, dtype=torch.int64, device=f"cuda:{local_rank}")
+            pair_ptr = pair.data_ptr()
+        else:
+            pair_buf = ctx.alloc(64)
+            pair_ptr = pair_buf.ptr
+
+        def c4_step():
+            ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, pair_ptr)
+            if use_dist:
+                dist.all_reduce(pair)
+
+        for _ in range(max(args.warmup, 1)):
+            c4_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            c4_step()
+        barrier()
+        c4_dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([c4_dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c4_dt = float(t.item())
+        c4_ms = c4_dt * 1e3 / max(args.steps, 1)
+        c4 = {"workload": "C4: fused Compare(>) -> Filter -> Sum over an Int64 record-batch shard per GPU + 16-byte all-reduce",
+              "ms_per_step": round(c4_ms, 5), "GB/s": round(8.0 * rows * args.gpus / (c4_ms * 1e-3) / 1e9, 1), "rows_per_gpu": rows, "n_gpus": args.gpus}
+    except Exception as e:  # informative only
+        c4 = {"error": repr(e)}
+
     if rank == 0:
         bytes_per_step = 32.0 * rows * args.gpus
         value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
@@ -285,6 +320,7 @@ def main():
                          "traffic": args.traffic if args.traffic is not None else pmc_traffic(rows),
                          "avg_launch_ms": round(add_avg_ms, 5), "algorithmic_bytes_per_launch": int(24 * rows)},
         }
+        result["c4_filter_aggregate"] = c4
         if world == 1 and not args.no_kernels:
             try:
                 result["kernels"] = per_kernel_table(ctx, rows, a, b, c, x)
