@@ -58,6 +58,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--rows", type=int, default=1 << 27, help="rows per GPU (default 2^27 = 1 GiB columns)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--c5-merge", action="store_true",
+                   help="C5 secondary line: also merge the per-GPU aggregates by key-hash owner (ragged all-to-all); off by default so "
+                        "that the headline never depends on a collective that world size 1 cannot exercise")
     p.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table")
     p.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch of the Add kernel from a rocprofv3 --pmc pass")
     return p.parse_args()
@@ -301,6 +304,54 @@ def main():
     except Exception as e:  # informative only
         c4 = {"error": repr(e)}
 
+    # Secondary line (config C5): hash + sum group-by, 2^26 Int64 keys (2^16 distinct) + Float64 values per GPU; under
+    # torch.distributed the local aggregates are merged by key-hash owner (all-to-all of O(groups) tuples, distributed.py).
+    c5 = None
+    try:
+        hrows = min(rows, 1 << 26)
+        krng = np.random.default_rng(77 + rank)
+        kchunk = (krng.integers(0, 1 << 16, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+        for off in range(0, hrows, 1 << 22):
+            c.upload(kchunk[:min(1 << 22, hrows - off)], off * 8)
+        merge = use_dist and args.c5_merge
+        if merge:
+            from arrow_go_amd.distributed import HipLocal, ShardedCompute
+            local = HipLocal.__new__(HipLocal); local.ctx = ctx; local.N = N        # share this rank's context / stream
+            sc = ShardedCompute(dist, torch.device("cuda", local_rank), local)
+            outs = [torch.empty(hrows + 1, dtype=torch.int64, device=f"cuda:{local_rank}") for _ in range(4)]
+            optr = [t.data_ptr() for t in outs]
+        else:
+            obufs = [ctx.alloc((hrows + 1) * 8 + 64) for _ in range(4)]
+            optr = [b_.ptr for b_ in obufs]
+        ngroups = [0]
+
+        def c5_step():
+            ng, _ = ctx.hash_sum("f64", c, None, 0, x, None, 0, hrows, optr[0], optr[1], optr[2], optr[3])
+            if merge:
+                cols = torch.stack([outs[0][:ng], outs[1][:ng], outs[2][:ng], outs[3][:ng] + rank * hrows])
+                ng = sc.merge_groups_t(torch, cols, True).shape[1]
+            ngroups[0] = int(ng)
+
+        c5_step()
+        barrier()
+        t0 = time.perf_counter()
+        c5_steps = max(1, min(args.steps, 5))
+        for _ in range(c5_steps):
+            c5_step()
+        barrier()
+        c5_dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([c5_dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c5_dt = float(t.item())
+        c5_ms = c5_dt * 1e3 / c5_steps
+        c5 = {"workload": "C5: hash + sum group-by over Int64 keys / Float64 values per GPU" + (", merged by key-hash owner (all-to-all of group tuples)" if merge else
+                                                                                                        " (local aggregates; --c5-merge adds the owner merge)"),
+              "ms_per_step": round(c5_ms, 4), "Grows/s": round(hrows * args.gpus / (c5_ms * 1e-3) / 1e9, 2), "rows_per_gpu": hrows,
+              "groups": ngroups[0], "n_gpus": args.gpus, "steps": c5_steps}
+    except Exception as e:  # informative only
+        c5 = {"error": repr(e)}
+
     if rank == 0:
         bytes_per_step = 32.0 * rows * args.gpus
         value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
@@ -321,6 +372,7 @@ def main():
                          "avg_launch_ms": round(add_avg_ms, 5), "algorithmic_bytes_per_launch": int(24 * rows)},
         }
         result["c4_filter_aggregate"] = c4
+        result["c5_group_by"] = c5
         if world == 1 and not args.no_kernels:
             try:
                 result["kernels"] = per_kernel_table(ctx, rows, a, b, c, x)
