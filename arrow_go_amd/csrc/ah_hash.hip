@@ -581,7 +581,8 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
   res->ndict = 0;
   res->null_id = -1;
   if (n == 0) return AH_OK;
-  if (n >= 0xFFFFFFFFll) return ah_fail(c, AH_ENOTIMPL, "hash: more than 2^32-2 rows per call");
+  // slot numbers travel through the int32 id column: the largest table (2n slots + 2) must stay below 2^32 − 1
+  if (n > ((int64_t)1 << 30)) return ah_fail(c, AH_ENOTIMPL, "hash: more than 2^30 rows per call");
   const int64_t nwords = ah_ceil_div(n, 64);
   const int64_t ntiles = ah_ceil_div(nwords, 32);
   const uint64_t cap_max = next_pow2_u64((uint64_t)n * 2 < 64 ? 64 : (uint64_t)n * 2);

@@ -271,7 +271,8 @@ int ah_take_primitive(ah_ctx* ctx, int byte_width, const void* values, const uin
  * (unique, NullEncodingEncode): null owns the id at which it was first seen;
  * = 0 (NullEncodingMask): null → id 0 + cleared validity bit.  out_dict must hold
  * min(n, distinct)+1 keys — call with out_dict = NULL first to learn the size if
- * unknown, or size it n+1.  out_ids / out_ids_valid may be NULL.  Synchronises. */
+ * unknown, or size it n+1.  out_ids / out_ids_valid may be NULL.  Synchronises.  ≤ 2^30 rows per call
+ * (slot numbers travel through the int32 id column; every reference config is ≤ 2^30 rows). */
 int ah_hash_u64_encode(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n,
                        int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, uint64_t* out_dict,
                        int64_t* out_ndict_host, int32_t* out_null_id_host);
@@ -285,7 +286,7 @@ int ah_hash_u64_encode(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, 
  * hash and compares bytes on tag match.  The dictionary is not copied here: out_first_rows[id]
  * (int64, relative to off, n + 1 entries of room) is the row that first held dictionary entry id —
  * dictionary = ah_take_binary_offsets / _data with those rows as indices (the null entry, if any,
- * points at a null row: zero length, as BinaryBuilder.AppendNull leaves it).  < 2^32 − 1 rows. */
+ * points at a null row: zero length, as BinaryBuilder.AppendNull leaves it).  ≤ 2^30 rows per call. */
 int ah_hash_binary_encode(ah_ctx* ctx, int offset_width, const void* offsets, const uint8_t* data, const uint8_t* valid, int64_t off,
                           int64_t n, int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows,
                           int64_t* out_ndict_host, int32_t* out_null_id_host);
