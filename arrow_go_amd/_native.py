@@ -121,6 +121,7 @@ _SIGS = {
     "ah_arithmetic_scalar_arr": [_vp, _int, _i8, _vp, _vp, _vp, _i64],
     "ah_arithmetic_unary": [_vp, _int, _i8, _vp, _vp, _i64],
     "ah_arithmetic_checked": [_vp, _int, _i8, _int, _vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64],
+    "ah_round": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _vp, C.c_double, _vp],
     "ah_arithmetic_ext": [_vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _i64],
     "ah_comparison": [_vp, _int, _int, _int, _vp, _vp, _vp, _i64, _int],
     "ah_bitmap_op": [_vp, _int, _vp, _i64, _vp, _i64, _vp, _i64, _i64],

@@ -229,6 +229,52 @@ int dispatch_float(ah_ctx* c, int op, int shape, const void* l, const uint8_t* l
   return ah_fail(c, AH_ENOTIMPL, "arithmetic: op %d is not defined for floating point", op);
 }
 
+// ---- round / round_to_multiple (kernels/rounding.go:321-370, 562-598) --------------------------------------------
+// MODE: RoundMode (rounding.go:40-59).  MULTIPLE: round_to_multiple (scale = the multiple: divide, round, multiply);
+// otherwise scale = 10^|ndigits| (multiply first when ndigits ≥ 0, divide first when negative).  Arithmetic in T, the
+// rounding primitives in double — as the Go code has it.  Inf / NaN and values that are integral after scaling pass
+// through; a non-finite result in a valid slot is "overflow".  ScalarUnaryNotNull: null slots hold 0.
+template <typename T>
+__device__ __forceinline__ T round_impl(T v, int mode) {
+  const double d = (double)v;
+  switch (mode) {
+    case 0: case 4: return (T)__builtin_floor(d);                                   // RoundDown, HalfDown (tie)
+    case 1: case 5: return (T)__builtin_ceil(d);                                    // RoundUp, HalfUp (tie)
+    case 2: case 6: return (T)__builtin_trunc(d);                                   // TowardsZero, HalfTowardsZero (tie)
+    case 3: case 7: return (T)(__builtin_signbit(d) ? __builtin_floor(d) : __builtin_ceil(d));  // AwayFromZero, HalfAwayFromZero (tie)
+    case 8: return (T)__builtin_rint(d);                                            // HalfToEven: math.RoundToEven
+    default: return (T)(__builtin_floor(d * 0.5) + __builtin_ceil(d * 0.5));        // HalfToOdd
+  }
+}
+
+template <typename T, bool MULTIPLE>
+__global__ __launch_bounds__(kBlock) void round_kernel(const T* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+                                                        T scale, int ndigits_sign, int mode, T* __restrict__ out, unsigned* __restrict__ flag) {
+  unsigned err = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const T arg = in[i];
+    T res = arg;
+    if (!ah_bit(valid, off + i)) {
+      res = (T)0;
+    } else if (!(__builtin_isinf((double)arg) || __builtin_isnan((double)arg))) {
+      T rv = (MULTIPLE || ndigits_sign < 0) ? arg / scale : arg * scale;
+      const T frac = rv - (T)__builtin_floor((double)rv);
+      if (frac != (T)0) {
+        if (mode >= 4 && frac != (T)0.5) rv = (T)__builtin_round((double)rv);  // math.Round: half away from zero (not a tie here)
+        else rv = round_impl<T>(rv, mode);
+        if (MULTIPLE) rv *= scale;
+        else if (ndigits_sign > 0) rv /= scale;
+        else rv *= scale;
+        if (__builtin_isinf((double)rv) || __builtin_isnan((double)rv)) err |= ERR_OVERFLOW;
+        else res = rv;
+      }
+    }
+    out[i] = res;
+  }
+  if (__any(err != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, (unsigned)ERR_OVERFLOW);
+}
+
 bool is_unary_op(int op) {
   return op == AH_OP_BIT_NOT || op == AH_OP_ABS_CHECKED || op == AH_OP_NEGATE_CHECKED || op == AH_OP_SQRT || op == AH_OP_SQRT_CHECKED ||
          op == AH_OP_FLOOR || op == AH_OP_CEIL || op == AH_OP_TRUNC;
@@ -285,5 +331,33 @@ AH_EXPORT int ah_arithmetic_ext(ah_ctx* c, int type, int op, int shape, const vo
   if (f & ERR_DIV_ZERO) return ah_fail(c, AH_EINVALID, "divide by zero");
   if (f & ERR_SHIFT) return ah_fail(c, AH_EINVALID, "shift amount must be >= 0 and less than precision of type");
   if (f & ERR_NEG_SQRT) return ah_fail(c, AH_EINVALID, "square root of negative number");
+  return AH_OK;
+}
+
+AH_EXPORT int ah_round(ah_ctx* c, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t ndigits, int mode,
+                       const void* multiple_host, double pow10, void* out) {
+  AH_ENTER(c);
+  if (n < 0 || off < 0) return ah_fail(c, AH_EINVALID, "round: negative length/offset");
+  if (mode < 0 || mode > 9) return ah_fail(c, AH_EINVALID, "round: invalid rounding mode %d", mode);
+  if (type != AH_FLOAT32 && type != AH_FLOAT64) return ah_fail(c, AH_ENOTIMPL, "round: unsupported type id %d", type);
+  if (n == 0) return AH_OK;
+  if (!values || !out) return ah_fail(c, AH_EINVALID, "round: null buffer");
+  unsigned* flag = (unsigned*)c->dscalars;
+  AH_HIP(c, hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream));
+  const unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock), /*default_bpc=*/8);
+  const int sgn = ndigits > 0 ? 1 : (ndigits < 0 ? -1 : 0);
+  if (type == AH_FLOAT32) {
+    float scale = (float)pow10;
+    if (multiple_host) { memcpy(&scale, multiple_host, 4); round_kernel<float, true><<<grid, kBlock, 0, c->stream>>>((const float*)values, valid, off, n, scale, 0, mode, (float*)out, flag); }
+    else round_kernel<float, false><<<grid, kBlock, 0, c->stream>>>((const float*)values, valid, off, n, scale, sgn, mode, (float*)out, flag);
+  } else {
+    double scale = pow10;
+    if (multiple_host) { memcpy(&scale, multiple_host, 8); round_kernel<double, true><<<grid, kBlock, 0, c->stream>>>((const double*)values, valid, off, n, scale, 0, mode, (double*)out, flag); }
+    else round_kernel<double, false><<<grid, kBlock, 0, c->stream>>>((const double*)values, valid, off, n, scale, sgn, mode, (double*)out, flag);
+  }
+  AH_LAUNCH_CHECK(c);
+  AH_HIP(c, hipMemcpyAsync(c->pinned, flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(volatile unsigned*)c->pinned & ERR_OVERFLOW) return ah_fail(c, AH_EOVERFLOW, "overflow");
   return AH_OK;
 }

@@ -192,6 +192,12 @@ class Context:
                                    side(r, shape == N.SHAPE_AS), _ptr(rvalid), roff, int(scalar_valid), _ptr(out), n)
         check(self.handle, st)
 
+    def round(self, type_id: int, values, valid, off: int, n: int, ndigits: int, mode: int, multiple, pow10: float, out) -> None:
+        """round (multiple=None; pow10 = math.Pow10(|ndigits|)) / round_to_multiple (multiple: numpy scalar array of the type)"""
+        m = None if multiple is None else np.ascontiguousarray(multiple)
+        check(self.handle, lib.ah_round(self.handle, type_id, _ptr(values), _ptr(valid), off, n, ndigits, mode,
+                                        None if m is None else m.ctypes.data, float(pow10), _ptr(out)))
+
     # ---- compare ------------------------------------------------------------------------
     def comparison(self, cmpop: int, shape: int, type_id: int, l, r, out_bits, n: int, out_bit_offset: int = 0) -> None:
         keep = []

@@ -234,6 +234,11 @@ struct SortOptions : FunctionOptions {
 };
 // kernels.CumulativeOptions (vector_cumulative.go:30-39): nil Start = zero of the input type
 struct CumulativeOptions : FunctionOptions { ScalarPtr Start; bool SkipNulls = false; const char* TypeName() const override { return "CumulativeOptions"; } };
+// kernels.RoundMode / RoundOptions / RoundToMultipleOptions (rounding.go:37-66, 93-104; defaults arithmetic.go:78-80)
+enum RoundMode { RoundDown = 0, RoundUp, RoundTowardsZero, RoundTowardsInfinity, RoundHalfDown, RoundHalfUp, RoundHalfTowardsZero,
+                 RoundHalfTowardsInfinity, RoundHalfToEven, RoundHalfToOdd };
+struct RoundOptions : FunctionOptions { int64_t NDigits = 0; RoundMode Mode = RoundHalfToEven; const char* TypeName() const override { return "RoundOptions"; } };
+struct RoundToMultipleOptions : FunctionOptions { ScalarPtr Multiple; RoundMode Mode = RoundHalfToEven; const char* TypeName() const override { return "RoundToMultipleOptions"; } };
 struct CompareFilterSumOptions : FunctionOptions { int cmpop = AH_CMP_GT; const char* TypeName() const override { return "CompareFilterSumOptions"; } };
 
 // compute.Datum (datum.go:35-40): array or scalar
@@ -293,6 +298,7 @@ class Function {  // functions.go:30-41
   FuncKind Kind() const { return kind_; }
   Arity GetArity() const { return arity_; }
   const FunctionOptions* DefaultOptions() const { return default_opts_; }
+  void SetDefaultOptions(const FunctionOptions* o) { default_opts_ = o; }
   virtual int NumKernels() const = 0;
   virtual Status Execute(ExecCtx* ctx, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) = 0;
   Status CheckArity(size_t nargs) const;  // functions.go:130-146 checkArity

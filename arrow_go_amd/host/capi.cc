@@ -177,6 +177,8 @@ AHC_EXPORT int ahc_datum_info(ahc_datum* d, int* kind, int* type_id, int64_t* le
 //   value_set=@<ahc_datum* in hex>   null_matching_behavior=match|skip|emit_null|inconclusive      (SetOptions)
 //   order=ascending|descending   null_placement=at_end|at_start                                   (SortOptions, one key)
 //   sort_keys=<col>:<asc|desc>:<at_end|at_start>,…                                                (SortOptions, several keys)
+//   ndigits=<n>   round_mode=down|up|towards_zero|towards_infinity|half_down|half_up|half_towards_zero|half_towards_infinity|
+//   half_to_even|half_to_odd   multiple=<type>:<value>                                            (RoundOptions / RoundToMultipleOptions)
 //   skip_nulls=0|1   start=<type>:<value>|null:<type>   (e.g. start=int64:10, start=double:1.5, start=null:int32)
 struct ParsedOptions {
   compute::FilterOptions filter;
@@ -186,6 +188,8 @@ struct ParsedOptions {
   compute::CastOptions cast;
   compute::SetOptions set;
   compute::SortOptions sort;
+  compute::RoundOptions round;
+  compute::RoundToMultipleOptions round_multiple;
   const compute::FunctionOptions* pick = nullptr;
 };
 static const struct { const char* name; Type id; } kTypeNames[] = {
@@ -270,6 +274,15 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
         if (k == "order") p->sort.Keys[0].Order = v == "descending" ? compute::SortOrderDescending : compute::SortOrderAscending;
         else p->sort.Keys[0].Placement = v == "at_start" ? compute::SortNullsAtStart : compute::SortNullsAtEnd;
         p->pick = &p->sort;
+      }
+      if (k == "ndigits") { p->round.NDigits = strtoll(v.c_str(), nullptr, 10); p->pick = &p->round; }
+      if (k == "multiple") { p->round_multiple.Multiple = ParseScalarText(v); p->pick = &p->round_multiple; }
+      if (k == "round_mode") {
+        static const char* names[] = {"down", "up", "towards_zero", "towards_infinity", "half_down", "half_up", "half_towards_zero",
+                                      "half_towards_infinity", "half_to_even", "half_to_odd"};
+        for (int m = 0; m < 10; m++)
+          if (v == names[m]) { p->round.Mode = (compute::RoundMode)m; p->round_multiple.Mode = (compute::RoundMode)m; }
+        if (!p->pick) p->pick = &p->round;
       }
       if (k == "skip_nulls") { p->cumulative.SkipNulls = v != "0"; p->pick = &p->cumulative; }
       if (k == "start") { p->cumulative.Start = ParseScalarText(v); p->pick = &p->cumulative; }

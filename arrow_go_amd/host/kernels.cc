@@ -68,6 +68,18 @@ static Status ExecArithChecked(KernelCtx* k, const ExecSpan& b, ExecResult* out,
   return s->FromStatus(ah_arithmetic_checked(s->ctx(), type, (int8_t)op, shape, l, lv, lo, r, rv, ro, scalar_valid, Values(out), out->len));
 }
 
+// Go's math.Pow10 (src/math/pow10.go): a product of two table entries — pow10tab[n % 32] · pow10postab32[n / 32] — which
+// is what InitRoundState hands the round kernel (rounding.go:86-90); beyond 1e31 it is NOT always the correctly rounded
+// literal, so it is restated rather than replaced by pow()
+static double GoPow10(int64_t n) {
+  static const double tab[32] = {1e00, 1e01, 1e02, 1e03, 1e04, 1e05, 1e06, 1e07, 1e08, 1e09, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22, 1e23, 1e24, 1e25, 1e26, 1e27, 1e28, 1e29, 1e30, 1e31};
+  static const double pos32[10] = {1e00, 1e32, 1e64, 1e96, 1e128, 1e160, 1e192, 1e224, 1e256, 1e288};
+  if (n < 0) return 0;
+  if (n > 308) return HUGE_VAL;
+  return pos32[n / 32] * tab[n % 32];
+}
+
 // ScalarBinaryNotNull / ScalarUnaryNotNull / whole-buffer closures of the pure-Go arithmetic kernels: divide, abs, negate,
 // bit-wise, shifts, sqrt (base_arithmetic.go:154-160,287-340,386-426; scalar_arithmetic.go:170-378)
 static Status ExecArithExt(KernelCtx* k, const ExecSpan& b, ExecResult* out, int op) {
@@ -156,6 +168,61 @@ void RegisterScalarArithmetic(FunctionRegistry* reg) {
     auto fn = MakeArithExt(p.first, p.second, 1, flt);  // GetSimpleRoundKernels (rounding.go:748-775)
     fn->promote_to_float = true;                         // arithmeticIntegerToFloatingPointFunc (arithmetic.go:172-200)
     reg->AddFunction(fn, false);
+  }
+  // round / round_to_multiple (arithmetic.go:1036-1056; kernels/rounding.go:321-370, 562-598)
+  {
+    static const RoundOptions kDefaultRound;                  // {NDigits: 0, Mode: RoundHalfToEven} (arithmetic.go:78)
+    static const RoundToMultipleOptions kDefaultRoundMultiple = [] {  // Multiple: float64 1 (:79-80)
+      RoundToMultipleOptions o;
+      auto one = std::make_shared<Scalar>();
+      one->type = GetDataType(Type::FLOAT64); one->valid = true;
+      const double v = 1.0; memcpy(one->value, &v, 8);
+      o.Multiple = one;
+      return o;
+    }();
+    for (bool multiple : {false, true}) {
+      auto fn = std::make_shared<ScalarFunction>(multiple ? "round_to_multiple" : "round", Arity{1, false});
+      fn->SetDefaultOptions(multiple ? (const FunctionOptions*)&kDefaultRoundMultiple : (const FunctionOptions*)&kDefaultRound);
+      for (Type t : flt) {
+        exec::ScalarKernel k;
+        k.sig.in_types = {t};
+        k.sig.out_is_first_input = true;
+        k.exec_fn = [multiple](KernelCtx* c, const ExecSpan& b, ExecResult* out) -> Status {
+          Session* s = c->session;
+          const ArraySpan& in = b.values[0].array;
+          const uint8_t* valid = in.MayHaveNulls() ? in.buffers[0].buf : nullptr;
+          const int type = (int)out->type->id;
+          if (!multiple) {
+            const RoundOptions* o = dynamic_cast<const RoundOptions*>(static_cast<const FunctionOptions*>(c->state));
+            if (!o) return Status::Make(StatusCode::Invalid, "attempted to initialize kernel state from invalid function options");  // InitRoundState
+            if (out->len == 0) return Status::OK();
+            const int64_t ad = o->NDigits < 0 ? -o->NDigits : o->NDigits;
+            return s->FromStatus(ah_round(s->ctx(), type, Values(in), valid, in.offset, out->len, o->NDigits, (int)o->Mode, nullptr, GoPow10(ad), Values(out)));
+          }
+          const RoundToMultipleOptions* o = dynamic_cast<const RoundToMultipleOptions*>(static_cast<const FunctionOptions*>(c->state));
+          if (!o) return Status::Make(StatusCode::Invalid, "attempted to initialize kernel state from invalid function options");
+          // InitRoundToMultipleState (rounding.go:127-177)
+          if (!o->Multiple || !o->Multiple->valid) return Status::Make(StatusCode::Invalid, "rounding multiple must be non-null and valid");
+          const Scalar& m = *o->Multiple;
+          double mv = 0;
+          bool positive = false;
+          if (m.type->id == Type::FLOAT64) { memcpy(&mv, m.value, 8); positive = mv > 0; }
+          else if (m.type->id == Type::FLOAT32) { float f; memcpy(&f, m.value, 4); mv = f; positive = f > 0; }
+          else if (IsSignedInteger(m.type->id)) { long long x = 0; memcpy(&x, m.value, m.type->bit_width / 8); if (m.type->bit_width < 64) x = (x << (64 - m.type->bit_width)) >> (64 - m.type->bit_width); mv = (double)x; positive = x > 0; }
+          else if (IsInteger(m.type->id)) { unsigned long long x = 0; memcpy(&x, m.value, m.type->bit_width / 8); mv = (double)x; positive = true; }  // isPositive: unsigned is always "positive"
+          else return Status::Make(StatusCode::Invalid, "rounding multiple must be positive");
+          if (!positive) return Status::Make(StatusCode::Invalid, "rounding multiple must be positive");
+          // an integer multiple is cast to float64, a floating one to the input type (:157-175)
+          uint8_t mbuf[8];
+          if (type == AH_FLOAT32) { const float f = (float)mv; memcpy(mbuf, &f, 4); } else memcpy(mbuf, &mv, 8);
+          if (out->len == 0) return Status::OK();
+          return s->FromStatus(ah_round(s->ctx(), type, Values(in), valid, in.offset, out->len, 0, (int)o->Mode, mbuf, 1.0, Values(out)));
+        };
+        fn->AddKernel(std::move(k));
+      }
+      fn->promote_to_float = true;  // arithmeticIntegerToFloatingPointFunc
+      reg->AddFunction(fn, false);
+    }
   }
   struct U { const char* name; int op; };
   for (U u : {U{"abs_unchecked", AH_OP_ABS}, U{"negate_unchecked", AH_OP_NEGATE}, U{"sign", AH_OP_SIGN}}) {

@@ -202,6 +202,15 @@ int ah_arithmetic_checked(ah_ctx* ctx, int type, int8_t op, int shape,
 int ah_arithmetic_ext(ah_ctx* ctx, int type, int op, int shape, const void* l, const uint8_t* lvalid, int64_t loff, const void* r,
                       const uint8_t* rvalid, int64_t roff, int scalar_valid, void* out, int64_t len);
 
+/* round / round_to_multiple on Float32 / Float64 (kernels/rounding.go:321-370 round[T].call, :562-598
+ * roundToMultiple[T].call; ScalarUnaryNotNull → null slots hold 0).  mode = RoundMode (rounding.go:40-59: 0 Down, 1 Up,
+ * 2 TowardsZero, 3 AwayFromZero, 4 HalfDown, 5 HalfUp, 6 HalfTowardsZero, 7 HalfAwayFromZero, 8 HalfToEven, 9 HalfToOdd).
+ * multiple_host == NULL: round to ndigits, pow10 = math.Pow10(|ndigits|) computed by the caller exactly as
+ * InitRoundState does (:72-91); else *multiple_host (one element of `type`, positive) is the rounding multiple and
+ * ndigits / pow10 are ignored.  A non-finite result in a valid slot is AH_EOVERFLOW "overflow". */
+int ah_round(ah_ctx* ctx, int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t ndigits, int mode,
+             const void* multiple_host, double pow10, void* out);
+
 /* ---- comparisons → packed bitmap ----------------------------------------------
  * replaces the 12 _comparison_<op>_<shape>_avx2 symbols
  * (kernels/scalar_comparison_avx2_amd64.go; C truth

@@ -76,6 +76,10 @@ int orc_arithmetic_checked(int type, int8_t op, int shape,
 int orc_arithmetic_ext(int type, int op, int shape, const void* l, const uint8_t* lvalid, int64_t loff, const void* r,
                        const uint8_t* rvalid, int64_t roff, int scalar_valid, void* out, int64_t len, char* msg);
 
+/* round (multiple == NULL) / round_to_multiple on float32 / float64; mode = RoundMode 0..9 (rounding.go:40-59) */
+int orc_round(int type, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t ndigits, int mode, const void* multiple, void* out);
+double orc_pow10(int n); /* Go's math.Pow10 for 0 <= n <= 308 */
+
 /* ---- comparisons → packed bitmap ------------------------------------ */
 int orc_comparison(int cmpop, int shape, int type, const void* l, const void* r,
                    uint8_t* out_bits, int64_t length, int out_bit_offset);

@@ -325,3 +325,54 @@ int orc_arithmetic_ext(int type, int op, int shape, const void* lvp, const uint8
   }
   return ORC_OK;
 }
+
+/* ---- round / round_to_multiple (kernels/rounding.go) --------------------------------------------------------------
+ * round[T].call :329-370, roundToMultiple[T].call :570-598, getFloatRoundImpl :180-221; ScalarUnaryNotNull.
+ * pow10 is math.Pow10(|ndigits|) (InitRoundState :72-91) — orc_pow10 restates Go's table-driven math.Pow10
+ * (src/math/pow10.go: pow10tab[n % 32] · pow10postab32[n / 32]), which is what the reference multiplies by. */
+double orc_pow10(int n) {
+  static const double tab[32] = {1e00, 1e01, 1e02, 1e03, 1e04, 1e05, 1e06, 1e07, 1e08, 1e09, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22, 1e23, 1e24, 1e25, 1e26, 1e27, 1e28, 1e29, 1e30, 1e31};
+  static const double pos32[10] = {1e00, 1e32, 1e64, 1e96, 1e128, 1e160, 1e192, 1e224, 1e256, 1e288};
+  if (n < 0) return 0;           /* the callers pass |ndigits| */
+  if (n > 308) return INFINITY;
+  return pos32[n / 32] * tab[n % 32];
+}
+
+static double round_mode_impl(double d, int mode) {
+  switch (mode) {
+    case 0: case 4: return floor(d);
+    case 1: case 5: return ceil(d);
+    case 2: case 6: return trunc(d);
+    case 3: case 7: return signbit(d) ? floor(d) : ceil(d);
+    case 8: return nearbyint(d);   /* math.RoundToEven; the default FE_TONEAREST mode */
+    default: return floor(d * 0.5) + ceil(d * 0.5);
+  }
+}
+
+#define ROUND_BODY(T)                                                                                            \
+  {                                                                                                              \
+    const T* in = (const T*)vp; T* o = (T*)ov;                                                                   \
+    const T scale = multiple ? *(const T*)multiple : (T)orc_pow10((int)(ndigits < 0 ? -ndigits : ndigits));      \
+    for (int64_t i = 0; i < n; i++) {                                                                            \
+      if (valid && !((valid[(off + i) >> 3] >> ((off + i) & 7)) & 1)) { o[i] = 0; continue; }                    \
+      const T arg = in[i];                                                                                       \
+      o[i] = arg;                                                                                                \
+      if (isinf((double)arg) || isnan((double)arg)) continue;                                                    \
+      T rv = (multiple || ndigits < 0) ? arg / scale : arg * scale;                                              \
+      const T frac = rv - (T)floor((double)rv);                                                                  \
+      if (frac == 0) continue;                                                                                   \
+      if (mode >= 4 && frac != (T)0.5) rv = (T)round((double)rv);                                                \
+      else rv = (T)round_mode_impl((double)rv, mode);                                                            \
+      if (multiple) rv *= scale; else if (ndigits > 0) rv /= scale; else rv *= scale;                            \
+      if (isinf((double)rv) || isnan((double)rv)) return ORC_EOVERFLOW;                                          \
+      o[i] = rv;                                                                                                 \
+    }                                                                                                            \
+    return ORC_OK;                                                                                               \
+  }
+
+int orc_round(int type, const void* vp, const uint8_t* valid, int64_t off, int64_t n, int64_t ndigits, int mode, const void* multiple, void* ov) {
+  if (type == ORC_FLOAT32) ROUND_BODY(float)
+  if (type == ORC_FLOAT64) ROUND_BODY(double)
+  return ORC_EINVALID;
+}

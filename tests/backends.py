@@ -43,6 +43,9 @@ class OracleBackend:
         """→ (status, out, error text)"""
         return self.o.arithmetic_ext(op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid)
 
+    def round(self, values, valid, off, ndigits, mode, multiple=None):
+        return self.o.round(values, valid, off, ndigits, mode, multiple)
+
     def comparison(self, cmpop, shape, l, r, out_init, out_bit_offset=0, misalign=0):
         out = np.array(out_init, dtype=np.uint8, copy=True)
         return self.o.comparison(cmpop, shape, l, r, out, out_bit_offset)
@@ -188,6 +191,19 @@ class HipBackend:
             assert "overflow" in str(e)
             st = STATUS_EOVERFLOW
         return st, ob.download(arr.dtype, arr.size)
+
+    def round(self, values, valid, off, ndigits, mode, multiple=None):
+        import arrow_go_amd as ah
+        values = np.ascontiguousarray(values)
+        vb, vp = self._up(values); vvb, vvp = self._upbits(valid)
+        ob = self.c.alloc(values.nbytes + 64); ob.memset(0xCD)
+        m = None if multiple is None else np.array([multiple], values.dtype)
+        try:
+            self.c.round(OL.TYPE_IDS[values.dtype], vp, vvp, off, values.size, ndigits, mode, m, OL.load_oracle().pow10(abs(ndigits)), ob)
+            st = STATUS_OK
+        except ah.ErrOverflow:
+            st = STATUS_EOVERFLOW
+        return st, ob.download(values.dtype, values.size)
 
     def arithmetic_ext(self, op, shape, l, lvalid, loff, r, rvalid, roff, scalar_valid=True):
         import arrow_go_amd as ah

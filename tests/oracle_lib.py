@@ -56,6 +56,8 @@ class Oracle:
             "orc_arithmetic_scalar_arr": (it, [it, i8, vp, vp, vp, i64]),
             "orc_arithmetic_unary": (it, [it, i8, vp, vp, i64]),
             "orc_arithmetic_checked": (it, [it, i8, it, vp, vp, i64, vp, vp, i64, it, vp, i64]),
+            "orc_round": (it, [it, vp, vp, i64, i64, i64, it, vp, vp]),
+            "orc_pow10": (C.c_double, [it]),
             "orc_arithmetic_ext": (it, [it, it, it, vp, vp, i64, vp, vp, i64, it, vp, i64, vp]),
             "orc_comparison": (it, [it, it, it, vp, vp, vp, i64, it]),
             "orc_count_set_bits": (i64, [vp, i64, i64]),
@@ -137,6 +139,15 @@ class Oracle:
         st = self.lib.orc_arithmetic_ext(TYPE_IDS[arr.dtype], op, shape, _p(l), _p(lvalid), loff, _p(r), _p(rvalid), roff,
                                          int(scalar_valid), _p(out), arr.size, msg)
         return st, out, msg.value.decode()
+
+    def pow10(self, n): return float(self.lib.orc_pow10(int(n)))
+
+    def round(self, values, valid, off, ndigits, mode, multiple=None):
+        values = np.ascontiguousarray(values)
+        out = np.zeros(values.size, values.dtype)
+        m = None if multiple is None else np.array([multiple], values.dtype)
+        st = self.lib.orc_round(TYPE_IDS[values.dtype], _p(values), _p(valid), off, values.size, ndigits, mode, _p(m), _p(out))
+        return st, out
 
     # ---- compare ------------------------------------------------------------------------
     def comparison(self, cmpop, shape, l, r, out_bits, out_bit_offset=0):

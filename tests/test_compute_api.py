@@ -817,3 +817,34 @@ def test_validity_and_rounding_functions(sess):
         assert sess.call_function(name, [x]).equals(ref(x))
         assert sess.call_function(name, [x32]).equals(ref(x32))
         assert sess.call_function(name, [cols[0]]).equals(ref(cols[0].cast(pa.float64())))        # integers go to float64
+
+
+@pytest.mark.gpu
+def test_round_functions(sess):
+    """round / round_to_multiple (arithmetic.go:1036-1056) against Arrow C++ — the Go kernels are its transliteration"""
+    from arrow_go_amd import compute as ac
+    rng = np.random.default_rng(79)
+    n = 20011
+    x = pa.array(np.round(rng.standard_normal(n) * 100, 3), mask=rng.random(n) < 0.1, type=pa.float64())
+    x32 = pa.array(np.round(rng.standard_normal(n) * 100, 2).astype(np.float32), mask=rng.random(n) < 0.1, type=pa.float32())
+    modes = ["down", "up", "towards_zero", "towards_infinity", "half_down", "half_up", "half_towards_zero", "half_towards_infinity",
+             "half_to_even", "half_to_odd"]
+    assert sess.call_function("round", [x]).equals(pc.round(x))                               # defaults: ndigits 0, half to even
+    assert sess.call_function("round_to_multiple", [x]).equals(pc.round_to_multiple(x))       # multiple 1.0
+    for mode in modes:
+        for nd in (-2, 0, 1, 2):
+            for v in (x, x32):
+                got = sess.call_function("round", [v], f"ndigits={nd};round_mode={mode}")
+                assert got.equals(pc.round(v, ndigits=nd, round_mode=mode)), (mode, nd, v.type)
+        for mult in ("double:0.25", "double:2", "int64:5"):
+            m = float(mult.split(":")[1])
+            got = sess.call_function("round_to_multiple", [x], f"multiple={mult};round_mode={mode}")
+            assert got.equals(pc.round_to_multiple(x, multiple=m, round_mode=mode)), (mode, mult)
+    ints = pa.array([1, 25, None, -15], type=pa.int32())                                     # integers are rounded as float64
+    assert sess.call_function("round", [ints], "ndigits=-1;round_mode=half_up").equals(pa.array([0.0, 30.0, None, -10.0]))
+    with pytest.raises(ac.ErrInvalid, match="must be positive"):
+        sess.call_function("round_to_multiple", [x], "multiple=double:-1")
+    with pytest.raises(ac.ErrInvalid, match="non-null"):
+        sess.call_function("round_to_multiple", [x], "multiple=null:double")
+    with pytest.raises(ac.ErrInvalid, match="overflow"):
+        sess.call_function("round", [pa.array([1.7e308])], "ndigits=-308;round_mode=up")

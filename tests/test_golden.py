@@ -1242,3 +1242,43 @@ def test_floor_ceil_trunc_vectors(be, dtype):
     x = (np.random.default_rng(2).standard_normal(5003) * 1e3).astype(dtype)
     for op, f in ((72, np.floor), (73, np.ceil), (74, np.trunc)):
         assert be.arithmetic_ext(op, 1, x, None, 0, None, None, 0)[1].tobytes() == f(x).tobytes()
+
+
+# ---- round / round_to_multiple (arithmetic_test.go:3268-3366) -------------------------------------------------------
+_RMODE = dict(DOWN=0, UP=1, TOWARDS_ZERO=2, TOWARDS_INFINITY=3, HALF_DOWN=4, HALF_UP=5, HALF_TOWARDS_ZERO=6, HALF_TOWARDS_INFINITY=7,
+              HALF_TO_EVEN=8, HALF_TO_ODD=9)
+_ROUND_TABLE = [("DOWN", [3, 3, 3, 4, -4, -4, -4]), ("UP", [4, 4, 4, 5, -3, -3, -3]), ("TOWARDS_ZERO", [3, 3, 3, 4, -3, -3, -3]),
+                ("TOWARDS_INFINITY", [4, 4, 4, 5, -4, -4, -4]), ("HALF_DOWN", [3, 3, 4, 4, -3, -4, -4]), ("HALF_UP", [3, 4, 4, 5, -3, -3, -4]),
+                ("HALF_TOWARDS_ZERO", [3, 3, 4, 4, -3, -3, -4]), ("HALF_TO_EVEN", [3, 4, 4, 4, -3, -4, -4]), ("HALF_TO_ODD", [3, 3, 4, 5, -3, -3, -4])]
+
+
+@pytest.mark.parametrize("dtype", _FLOATS, ids=str)
+def test_round_vectors(be, dtype):
+    vals = np.array([3.2, 3.5, 3.7, 4.5, -3.2, -3.5, -3.7], dtype)
+    for mode, exp in _ROUND_TABLE:
+        for kw in ({}, {"multiple": 1}):                       # TestRound and TestRoundToMultiple share the table
+            st, out = be.round(vals, None, 0, 0, _RMODE[mode], **kw)
+            assert st == 0 and out.tolist() == exp, (mode, kw)
+            sp, v = mk([None, 0, float("inf"), float("-inf"), float("nan")], dtype, 7.5)
+            st, out = be.round(sp, v, 0, 0, _RMODE[mode], **kw)
+            assert st == 0 and out[0] == 0 and out[1] == 0 and out[2] == np.inf and out[3] == -np.inf and np.isnan(out[4])
+    vals = np.array([320, 3.5, 3.075, 4.5, -3.212, -35.1234, -3.045], dtype)
+    close = lambda a, b: np.allclose(a, np.array(b, dtype), rtol=1e-6 if dtype == np.float32 else 1e-12, atol=0)
+    for nd, exp in ((-2, [300, 0.0, 0.0, 0.0, -0.0, -0.0, -0.0]), (-1, [320, 0.0, 0.0, 0.0, -0.0, -40, -0.0]), (0, [320, 4, 3, 5, -3, -35, -3]),
+                    (1, [320, 3.5, 3.1, 4.5, -3.2, -35.1, -3]), (2, [320, 3.5, 3.08, 4.5, -3.21, -35.12, -3.05])):
+        st, out = be.round(vals, None, 0, nd, _RMODE["HALF_TOWARDS_INFINITY"])
+        assert st == 0 and close(out, exp), (nd, out)
+    for mult, exp in ((0.05, [320, 3.5, 3.1, 4.5, -3.2, -35.1, -3.05]), (0.1, [320, 3.5, 3.1, 4.5, -3.2, -35.1, -3]), (2, [320, 4, 4, 4, -4, -36, -4]),
+                      (10, [320, 0.0, 0.0, 0.0, -0.0, -40, -0.0]), (100, [300, 0.0, 0.0, 0.0, -0.0, -0.0, -0.0])):
+        st, out = be.round(vals, None, 0, 0, _RMODE["HALF_TOWARDS_INFINITY"], multiple=mult)
+        assert st == 0 and close(out, exp), (mult, out)
+    # overflow: the rescaled result leaves the type's range
+    big = np.array([np.finfo(dtype).max], dtype)
+    assert be.round(big, None, 0, -int(np.log10(np.finfo(dtype).max)), _RMODE["UP"])[0] == 3
+    assert be.round(big, OL.pack_bits([False]), 0, -int(np.log10(np.finfo(dtype).max)), _RMODE["UP"])[0] == 0   # not under a null
+
+
+def test_pow10_is_gos_table(orc):
+    # math.Pow10: pow10tab[n % 32] · pow10postab32[n / 32] — the product, not the correctly rounded literal, beyond 1e31
+    assert orc.pow10(0) == 1.0 and orc.pow10(22) == 1e22 and orc.pow10(31) == 1e31
+    assert orc.pow10(40) == 1e32 * 1e8 and orc.pow10(308) == 1e288 * 1e20 and orc.pow10(309) == float("inf")

@@ -1045,3 +1045,21 @@ def test_arithmetic_ext_floats_bit_exact(hip, orc_be, dtype):
                 P = np.abs(A)
                 _ext_same(hip.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, P, lv, sl, None, None, 0), orc_be.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, P, lv, sl, None, None, 0), ("sqrtc", n))
                 _ext_same(hip.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, A, None, 0, None, None, 0), orc_be.arithmetic_ext(_XOPS["SQRT_CHECKED"], 1, A, None, 0, None, None, 0), ("sqrtc neg", n))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=str)
+def test_round_bit_exact(hip, orc_be, dtype):
+    rng = np.random.default_rng(1400 + np.dtype(dtype).itemsize)
+    n = 50021
+    x = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)).astype(dtype)
+    x[:8] = [0.5, 1.5, 2.5, -0.5, -1.5, np.inf, -np.inf, np.nan]
+    x[8:16] = np.array([0.125, 0.375, 2.675, -2.675, 1e15, -1e15, 0.0, -0.0], dtype)
+    valid = rand_bits(rng, n + 8, 0.9)
+    for mode in range(10):
+        for nd in (-3, -1, 0, 1, 2, 5):
+            for v, off in ((None, 0), (valid, 3)):
+                g, e = hip.round(x, v, off, nd, mode), orc_be.round(x, v, off, nd, mode)
+                assert g[0] == e[0] == 0 and g[1].tobytes() == e[1].tobytes(), (mode, nd)
+        for mult in (0.05, 0.1, 0.25, 2, 7, 1000):
+            g, e = hip.round(x, valid, 3, 0, mode, multiple=mult), orc_be.round(x, valid, 3, 0, mode, multiple=mult)
+            assert g[0] == e[0] == 0 and g[1].tobytes() == e[1].tobytes(), (mode, mult)
