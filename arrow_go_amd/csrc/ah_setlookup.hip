@@ -100,25 +100,30 @@ __device__ __forceinline__ void put_bits(uint8_t* __restrict__ bm, int64_t pos, 
 }
 
 // ---- probe -----------------------------------------------------------------------------------
-// MODE 0: bitmap in LDS (W ≤ 2) · 1: hash table in LDS · 2: hash table in HBM.
+// MODE 0: bitmap in LDS (W ≤ 2) · 1: hash table in LDS (≤ 4096 slots, 32 KiB) · 2: hash table in HBM · 3: hash table in
+// LDS, 16 384 slots = 128 KiB of gfx950's 160 KiB, one 1024-thread workgroup per CU (sets of up to 4096 keys: 2–4× faster
+// than probing the table through L2).
 // One row per lane is instruction-bound unless the per-row work is tiny (a wave64 VALU instruction
 // costs 4 cycles on a 16-lane SIMD: ≈ 50 instructions per 64-row chunk is the HBM-bound budget for
 // 8-byte rows), so: ONE ballot per chunk, the null-behaviour table folded into three wave-uniform
 // flags and scalar mask arithmetic, results of a group of chunks gathered with v_writelane and
 // stored by one instruction (ALIGNED: output word-aligned; otherwise lane 0 merges bits).
-template <int W, int MODE, bool HAS_VALID, bool ALIGNED>
-__global__ __launch_bounds__(kBlock) void is_in_kernel(const void* __restrict__ values, const uint8_t* __restrict__ valid, int64_t off,
+constexpr int kLdsSlotsBig = 16384;
+constexpr int kBlockBig = 1024;
+
+template <int W, int MODE, bool HAS_VALID, bool ALIGNED, int BLOCK = (MODE == 3 ? kBlockBig : kBlock)>
+__global__ __launch_bounds__(BLOCK) void is_in_kernel(const void* __restrict__ values, const uint8_t* __restrict__ valid, int64_t off,
                                                         int64_t n, const unsigned long long* __restrict__ table, unsigned mask, int shift,
                                                         const unsigned* __restrict__ bits, const unsigned* __restrict__ flags,
                                                         int null_behavior, uint8_t* __restrict__ out_data, uint8_t* __restrict__ out_valid,
                                                         int64_t out_off) {
-  __shared__ unsigned long long s_tab[MODE == 1 ? kLdsSlots : 1];
+  __shared__ unsigned long long s_tab[MODE == 1 ? kLdsSlots : (MODE == 3 ? kLdsSlotsBig : 1)];
   __shared__ unsigned s_bits[MODE == 0 ? (W == 1 ? 8 : 2048) : 1];
   if (MODE == 0) {
-    for (int i = threadIdx.x; i < (W == 1 ? 8 : 2048); i += kBlock) s_bits[i] = bits[i];
+    for (int i = threadIdx.x; i < (W == 1 ? 8 : 2048); i += BLOCK) s_bits[i] = bits[i];
     __syncthreads();
-  } else if (MODE == 1) {
-    for (unsigned i = threadIdx.x; i <= mask; i += kBlock) s_tab[i] = table[i];
+  } else if (MODE == 1 || MODE == 3) {
+    for (unsigned i = threadIdx.x; i <= mask; i += BLOCK) s_tab[i] = table[i];
     __syncthreads();
   }
   const unsigned fl = flags[0];
@@ -131,10 +136,10 @@ __global__ __launch_bounds__(kBlock) void is_in_kernel(const void* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int64_t nchunks = (n + 63) >> 6;
   const int64_t ngroups = (nchunks + kChunks - 1) / kChunks;
-  const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t wave_stride = (int64_t)gridDim.x * (BLOCK / 64);
   unsigned long long* __restrict__ od64 = (unsigned long long*)out_data + (out_off >> 6);   // used when ALIGNED
   unsigned long long* __restrict__ ov64 = (unsigned long long*)out_valid + (out_off >> 6);
-  for (int64_t g = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); g < ngroups; g += wave_stride) {
+  for (int64_t g = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < ngroups; g += wave_stride) {
     const int64_t c0 = g * kChunks;
     unsigned long long k[kChunks], vin[kChunks];
 #pragma unroll
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void is_in_kernel(const void* __restrict__ 
         } else {
           unsigned idx = slot_of(key, mask, shift);
           for (;;) {  // load ≤ ¼: a miss ends after 1.4 slots on average
-            const unsigned long long sl = MODE == 1 ? s_tab[idx] : table[idx];
+            const unsigned long long sl = (MODE == 1 || MODE == 3) ? s_tab[idx] : table[idx];
             if (sl == key) { found = true; break; }
             if (sl == kEmpty) break;
             idx = (idx + 1) & mask;
@@ -200,7 +205,7 @@ void launch_probe(ah_ctx* c, unsigned grid, const void* values, const uint8_t* v
                   unsigned mask, int shift, const unsigned* bits, const unsigned* flags, int nb, uint8_t* out_data, uint8_t* out_valid,
                   int64_t out_off) {
   const bool aligned = (out_off & 63) == 0 && (((uintptr_t)out_data | (uintptr_t)out_valid) & 7) == 0;
-#define AH_PROBE(HV, AL) is_in_kernel<W, MODE, HV, AL><<<grid, kBlock, 0, c->stream>>>(values, valid, off, n, table, mask, shift, bits, flags, nb, \
+#define AH_PROBE(HV, AL) is_in_kernel<W, MODE, HV, AL><<<grid, (MODE == 3 ? kBlockBig : kBlock), 0, c->stream>>>(values, valid, off, n, table, mask, shift, bits, flags, nb, \
                                                                                   out_data, out_valid, out_off)
   if (valid) { if (aligned) AH_PROBE(true, true); else AH_PROBE(true, false); }
   else { if (aligned) AH_PROBE(false, true); else AH_PROBE(false, false); }
@@ -232,11 +237,18 @@ int run_is_in(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, 
   }
   const int64_t nchunks = ah_ceil_div(n, 64);
   const unsigned grid = ah_stream_grid(c, ah_ceil_div(ah_ceil_div(nchunks, kChunks), kBlock / 64), 8);
+  // tunable, for measurements: 0 keeps mid-size sets (1025 … 4096 keys) on the HBM table
+  static const bool big_lds = !(getenv("ARROWHIP_ISIN_BIG_LDS") && atoi(getenv("ARROWHIP_ISIN_BIG_LDS")) == 0);
   if constexpr (W <= 2) {
     launch_probe<W, 0>(c, grid, values, valid, off, n, nullptr, 0, 0, (const unsigned*)tab, flags, null_behavior, out_data, out_valid, out_off);
   } else if (cap <= (unsigned long long)kLdsSlots) {
     launch_probe<W, 1>(c, grid, values, valid, off, n, (const unsigned long long*)tab, (unsigned)(cap - 1), shift, nullptr, flags, null_behavior,
                        out_data, out_valid, out_off);
+  } else if (cap <= (unsigned long long)kLdsSlotsBig && big_lds) {
+    const unsigned per_cu = (unsigned)c->num_cu;  // 128 KiB of LDS each: one workgroup per CU
+    const unsigned need = (unsigned)ah_ceil_div(ah_ceil_div(nchunks, kChunks), kBlockBig / 64);
+    launch_probe<W, 3>(c, need < per_cu ? need : per_cu, values, valid, off, n, (const unsigned long long*)tab, (unsigned)(cap - 1), shift, nullptr, flags,
+                       null_behavior, out_data, out_valid, out_off);
   } else {
     launch_probe<W, 2>(c, grid, values, valid, off, n, (const unsigned long long*)tab, (unsigned)(cap - 1), shift, nullptr, flags, null_behavior,
                        out_data, out_valid, out_off);

@@ -11,7 +11,7 @@ def timed(fn, reps=5):
     for _ in range(reps): fn()
     ctx.event_record(11); return ctx.event_elapsed_ms(10, 11) / reps
 res = {}
-for set_n in (16, 2048, 1 << 16, 1 << 20, 1 << 24):
+for set_n in (16, 1024, 2048, 4096, 1 << 16, 1 << 20, 1 << 24):
     universe = 4 * set_n
     chunk = rng.integers(0, universe, 1 << 22, dtype=np.int64)
     for off in range(0, rows, 1 << 22): a.upload(chunk, off * 8)

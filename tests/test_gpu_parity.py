@@ -658,7 +658,7 @@ def test_is_in_random(hip, orc_be, dtype):
     rng = np.random.default_rng(7000 + OL.TYPE_IDS[np.dtype(dtype)])
     dt = np.dtype(dtype)
     for n in (1, 63, 64, 65, 1000, 4097, 70001):
-        for set_n in (0, 1, 7, 300, 5000):
+        for set_n in (0, 1, 7, 300, 2500, 5000):   # LDS table · 128 KiB LDS table (1025 … 4096 keys) · HBM table
             universe = max(4, 3 * set_n)
             def draw(m):
                 if dt.kind == "f":
