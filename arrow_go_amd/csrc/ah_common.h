@@ -24,6 +24,8 @@ struct ah_ctx {
   // scratch arena (device): partial sums, tile counts, hash tables ...
   void* scratch;
   size_t scratch_bytes;
+  void* temp;              // second grow-only arena: the temporaries of sort / group-by / var-length take (see ah_temp_reserve)
+  size_t temp_bytes;
   // small pinned staging block for *_host results (64 x 8 bytes)
   uint64_t* pinned;
   // small device block for scalar results / flags (64 x 8 bytes) followed by a
@@ -87,6 +89,10 @@ int ah_partition_by_group(ah_ctx* ctx, const int32_t* ids, const unsigned long l
                           unsigned long long* out_vals, unsigned* out_ids);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
+// A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are
+// live: sort, group-by, var-length take.  One reservation per top-level call, carved by the caller; the block is
+// reused by the next call in stream order (no hipMalloc / hipFree — each maps and unmaps the whole range — per call).
+int ah_temp_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // internal (ah_bitmap.hip): popcount of bits [off, off+nbits) into *total_dev (8 bytes,
 // device), enqueued on the compute stream; uses dscalars[16..] as partials — no scratch.
 int ah_popcount_async(ah_ctx* ctx, const uint8_t* bits, int64_t off, int64_t nbits, unsigned long long* total_dev);

@@ -71,6 +71,7 @@ AH_EXPORT void ah_ctx_destroy(ah_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->dscalars) (void)hipFree(c->dscalars);
+  if (c->temp) (void)hipFree(c->temp);
   (void)hipEventDestroy(c->ev_copy);
   (void)hipEventDestroy(c->ev_compute);
   (void)hipEventDestroy(c->t0);
@@ -96,6 +97,20 @@ int ah_scratch_reserve(ah_ctx* c, size_t nbytes, void** out) {
     c->scratch_bytes = want;
   }
   *out = c->scratch;
+  return AH_OK;
+}
+
+int ah_temp_reserve(ah_ctx* c, size_t nbytes, void** out) {
+  if (nbytes > c->temp_bytes) {
+    AH_HIP(c, hipStreamSynchronize(c->stream));  // the old block may still be in use by enqueued kernels
+    if (c->temp) AH_HIP(c, hipFree(c->temp));
+    c->temp = nullptr;
+    c->temp_bytes = 0;
+    size_t want = (nbytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (hipMalloc(&c->temp, want) != hipSuccess) { (void)hipGetLastError(); return ah_fail(c, AH_EHIP, "out of device memory (%zu bytes of temporaries)", want); }
+    c->temp_bytes = want;
+  }
+  *out = c->temp;
   return AH_OK;
 }
 

@@ -758,11 +758,17 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
   if (out_null_group_host) *out_null_group_host = -1;
   if (n == 0) return AH_OK;
   if (!keys || !vals || !out_keys || !out_sums || !out_counts) return ah_fail(c, AH_EINVALID, "hash_sum: null buffer");
-  // dense group ids need a temporary int32 per row
-  int32_t* ids = nullptr;
-  AH_HIP(c, hipMalloc((void**)&ids, (size_t)n * sizeof(int32_t)));
+  // temporaries: a dense group id per row and, above 4096 groups, the partitioned (value, id) pairs with their
+  // histograms — one reservation in the context's temp arena, sized for the two-pass partition, reused by the next call
+  const int64_t nb = ah_ceil_div(n, 2048);
+  const size_t pv = (size_t)n * 8, pi = (((size_t)n * 4) + 255) & ~(size_t)255, ph = (size_t)256 * nb * 4;
+  void* arena = nullptr;
+  int rc = ah_temp_reserve(c, pi + 2 * (pv + pi) + 2 * ph + 256, &arena);
+  if (rc != AH_OK) return rc;
+  int32_t* ids = (int32_t*)arena;
+  uint8_t* part = (uint8_t*)arena + pi;
   EncodeResult res;
-  int rc = encode_core(c, U64Keys{(const unsigned long long*)keys}, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows);
+  rc = encode_core(c, U64Keys{(const unsigned long long*)keys}, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows);
   if (rc == AH_OK) {
     hipError_t e1 = hipMemsetAsync(out_sums, 0, (size_t)res.ndict * sizeof(AT), c->stream);
     hipError_t e2 = hipMemsetAsync(out_counts, 0, (size_t)res.ndict * sizeof(int64_t), c->stream);
@@ -775,25 +781,17 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
       group_sum_kernel<VT, AT, true><<<grid, kBlock, 0, c->stream>>>(ids, vals, vvalid, voff, n, out_sums,
                                                                      (unsigned long long*)out_counts, (int)res.ndict);
     } else if (partition_path && res.ndict <= kPartitionMaxGroups && sizeof(VT) == 8) {
-      void* tmp = nullptr;
       const int passes = res.ndict <= kPartitionOnePass ? 1 : 2;
-      const int64_t nb = ah_ceil_div(n, 2048);
-      const size_t pv = (size_t)n * 8, pi = (((size_t)n * 4) + 255) & ~(size_t)255, ph = (size_t)256 * nb * 4;
-      if (hipMalloc(&tmp, (size_t)passes * (pv + pi) + 2 * ph) != hipSuccess) { (void)hipGetLastError(); rc = ah_fail(c, AH_EHIP, "hash_sum: out of device memory"); }
-      else {
-        unsigned long long* pvals = (unsigned long long*)tmp;
-        unsigned* pids = (unsigned*)((uint8_t*)tmp + pv);
-        unsigned* hist = (unsigned*)((uint8_t*)tmp + pv + pi);
-        unsigned* offs = (unsigned*)((uint8_t*)tmp + pv + pi + ph);
-        unsigned long long* avals = passes == 2 ? (unsigned long long*)((uint8_t*)tmp + pv + pi + 2 * ph) : nullptr;
-        unsigned* aids = passes == 2 ? (unsigned*)((uint8_t*)avals + pv) : nullptr;
-        rc = ah_partition_by_group(c, ids, (const unsigned long long*)vals, vvalid, voff, n, kBucketShift, passes, hist, offs, avals, aids, pvals, pids);
-        if (rc == AH_OK) {
-          bucket_sum_kernel<AT><<<(unsigned)ah_ceil_div(n, kChunkRows), kBlock, 0, c->stream>>>(pvals, pids, n, out_sums, (unsigned long long*)out_counts);
-          if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
-        }
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(tmp);
+      unsigned long long* pvals = (unsigned long long*)part;
+      unsigned* pids = (unsigned*)(part + pv);
+      unsigned* hist = (unsigned*)(part + pv + pi);
+      unsigned* offs = (unsigned*)(part + pv + pi + ph);
+      unsigned long long* avals = passes == 2 ? (unsigned long long*)(part + pv + pi + 2 * ph) : nullptr;
+      unsigned* aids = passes == 2 ? (unsigned*)((uint8_t*)avals + pv) : nullptr;
+      rc = ah_partition_by_group(c, ids, (const unsigned long long*)vals, vvalid, voff, n, kBucketShift, passes, hist, offs, avals, aids, pvals, pids);
+      if (rc == AH_OK) {
+        bucket_sum_kernel<AT><<<(unsigned)ah_ceil_div(n, kChunkRows), kBlock, 0, c->stream>>>(pvals, pids, n, out_sums, (unsigned long long*)out_counts);
+        if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
       }
     } else {
       unsigned grid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8));
@@ -802,8 +800,6 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
     }
     if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
   }
-  (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(ids);
   if (rc != AH_OK) return rc;
   if (out_ngroups_host) *out_ngroups_host = res.ndict;
   if (out_null_group_host) *out_null_group_host = res.null_id;

@@ -274,20 +274,13 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const unsigned* __restrict
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = rows[i];
 }
 
-struct Temp {  // temporaries of one call (the context's scratch arena is used by the scan this calls)
-  ah_ctx* c;
-  void* p[8];
-  int n = 0;
-  explicit Temp(ah_ctx* ctx) : c(ctx) {}
-  int get(size_t bytes, void** out) {
-    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return ah_fail(c, AH_EHIP, "sort: out of device memory (%zu bytes)", bytes); }
-    p[n++] = *out;
-    return AH_OK;
-  }
-  ~Temp() {
-    (void)hipStreamSynchronize(c->stream);  // kernels of this call may still be reading them
-    for (int i = 0; i < n; i++) (void)hipFree(p[i]);
-  }
+// temporaries of one call, carved out of the context's temp arena (the scratch arena is used by the scan this calls)
+struct Carver {
+  uint8_t* base;
+  size_t used = 0;
+  static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+  template <typename P>
+  void take(size_t bytes, P** out) { *out = (P*)(base + used); used += pad(bytes); }
 };
 
 template <typename SRC>
@@ -367,19 +360,23 @@ int sort_dispatch(ah_ctx* c, SortBuffers& b, int type, const void* values, const
 
 int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values, const uint8_t* const* valids, const int64_t* offs, int64_t n,
               const int* descending, const int* nulls_at_start, uint64_t* out) {
-  Temp tmp(c);
   SortBuffers b;
   const int64_t ntiles = ah_ceil_div(n, kTile);
   int rc;
-  if ((rc = tmp.get((size_t)n * 8, (void**)&b.ka)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)n * 8, (void**)&b.kb)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)n * 4, (void**)&b.ra)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)n * 4, (void**)&b.rb)) != AH_OK) return rc;
+  const size_t hist_bytes = (size_t)kRadix * ntiles * 4;
+  const size_t total = 2 * Carver::pad((size_t)n * 8) + (nkeys > 1 ? 3 : 2) * Carver::pad((size_t)n * 4) + 2 * Carver::pad(hist_bytes) + 256;
+  void* arena;
+  if ((rc = ah_temp_reserve(c, total, &arena)) != AH_OK) return rc;
+  Carver tmp{(uint8_t*)arena};
+  tmp.take((size_t)n * 8, &b.ka);
+  tmp.take((size_t)n * 8, &b.kb);
+  tmp.take((size_t)n * 4, &b.ra);
+  tmp.take((size_t)n * 4, &b.rb);
   b.rc = nullptr;
-  if (nkeys > 1 && (rc = tmp.get((size_t)n * 4, (void**)&b.rc)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&b.hist)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)kRadix * ntiles * 4, (void**)&b.offs)) != AH_OK) return rc;
-  if ((rc = tmp.get(64, (void**)&b.andor)) != AH_OK) return rc;
+  if (nkeys > 1) tmp.take((size_t)n * 4, &b.rc);
+  tmp.take(hist_bytes, &b.hist);
+  tmp.take(hist_bytes, &b.offs);
+  tmp.take(64, &b.andor);
   // lexicographic order by keys 0..k−1 = stable sorts by key k−1, …, key 0 in turn (every pass is stable)
   const unsigned* rows_in = nullptr;
   for (int k = nkeys - 1; k >= 0; k--) {

@@ -121,21 +121,6 @@ __global__ __launch_bounds__(kBlock) void copy_kernel(const OffT* __restrict__ o
   }
 }
 
-struct Temp {
-  ah_ctx* c;
-  void* p[4];
-  int n = 0;
-  explicit Temp(ah_ctx* ctx) : c(ctx) {}
-  int get(size_t bytes, void** out) {
-    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return ah_fail(c, AH_EHIP, "take: out of device memory (%zu bytes)", bytes); }
-    p[n++] = *out;
-    return AH_OK;
-  }
-  ~Temp() {
-    (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < n; i++) (void)hipFree(p[i]);
-  }
-};
 
 template <typename OffT, typename IdxT>
 int run_offsets(ah_ctx* c, const void* offsets, const uint8_t* vvalid, int64_t voff, int64_t nvalues, const void* idx, const uint8_t* ivalid,
@@ -202,11 +187,13 @@ AH_EXPORT int ah_take_binary_offsets(ah_ctx* c, int offset_width, const void* of
   }
   if (!idx) return ah_fail(c, AH_EINVALID, "take: null buffer");
   if (!out_valid && (vvalid || ivalid)) { vvalid = nullptr; ivalid = nullptr; }  // the caller's null counts say: no nulls (:1176)
-  Temp tmp(c);
-  long long *lens, *incl;
-  int rc;
-  if ((rc = tmp.get((size_t)nidx * 8, (void**)&lens)) != AH_OK) return rc;
-  if ((rc = tmp.get((size_t)nidx * 8, (void**)&incl)) != AH_OK) return rc;
+  // temporaries in the context's temp arena (the scan called below uses the scratch arena)
+  const size_t col = (((size_t)nidx * 8) + 255) & ~(size_t)255;
+  void* arena;
+  int rc = ah_temp_reserve(c, 2 * col, &arena);
+  if (rc != AH_OK) return rc;
+  long long* lens = (long long*)arena;
+  long long* incl = (long long*)((uint8_t*)arena + col);
   AH_HIP(c, hipMemsetAsync(&c->dscalars[1], 0xFF, sizeof(uint64_t), c->stream));  // first bad position
   AH_HIP(c, hipMemsetAsync(&c->dscalars[2], 0, 2 * sizeof(uint64_t), c->stream)); // valid count, overflow flag
   rc = offset_width == 4 ? offsets_idx<int32_t>(c, idx_byte_width, idx_signed, offsets, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_offsets, out_valid, lens, incl)
