@@ -78,6 +78,7 @@ struct Buffer {
   // producer's ArrowArray alive and calls its release callback when the last buffer goes away
   bool owned = true;
   std::shared_ptr<void> owner;
+  size_t alloc_bytes = 0;  // size class of the block behind dptr when it came from Session::Allocate (0: not pooled)
   ~Buffer();
 };
 using BufferPtr = std::shared_ptr<Buffer>;
@@ -88,11 +89,21 @@ class Session {
   ~Session();
   ah_ctx* ctx() const { return ctx_; }
   // zero-filled like GoAllocator / Mallocator (quirk 4 in SURVEY.md §8a): kernels rely on it
-  Status Allocate(int64_t nbytes, BufferPtr* out);
+  // zero_all = false: only the padding behind the last whole 64-byte block is cleared — for outputs whose every slot the
+  // kernel writes anyway (the zero-fill of a 1 GiB output costs a third of the Add that fills it)
+  Status Allocate(int64_t nbytes, BufferPtr* out, bool zero_all = true);
   Status AllocateBitmap(int64_t nbits, BufferPtr* out);
   Status FromStatus(int ah_status) const;  // AH_* → Status with ah_last_error()
+  // Freed output buffers are kept in size classes and handed out again — what a pooling memory.Allocator does for the
+  // Go executor.  hipMalloc / hipFree map and unmap the whole range (≈ 0.35 ms per GiB round trip, two thirds of an
+  // Int64 Add kernel); reuse is safe because every consumer is ordered on the session's compute stream and both copy
+  // directions wait for it (ah_upload_async / ah_download_async).  ARROWHIP_POOL_BYTES caps the cache (default 16 GiB; 0 = off).
+  void Release(void* dptr, size_t alloc_bytes);
+  void TrimPool();
  private:
   ah_ctx* ctx_ = nullptr;
+  std::multimap<size_t, void*> pool_;
+  size_t pooled_bytes_ = 0, pool_cap_ = (size_t)16 << 30;
 };
 
 // ---- arrow.ArrayData (arrow/array.go:54-86) / scalar.Scalar ----------------------------
@@ -158,7 +169,7 @@ struct KernelCtx {
   Session* session = nullptr;
   const void* state = nullptr;   // KernelState: the FunctionOptions for vector kernels
   const void* kernel_data = nullptr;  // Kernel.Data
-  Status Allocate(int64_t nbytes, BufferPtr* out) { return session->Allocate(nbytes, out); }
+  Status Allocate(int64_t nbytes, BufferPtr* out, bool zero_all = true) { return session->Allocate(nbytes, out, zero_all); }
   Status AllocateBitmap(int64_t nbits, BufferPtr* out) { return session->AllocateBitmap(nbits, out); }
 };
 

@@ -46,7 +46,7 @@ std::string Status::ToString() const {
 
 // ---- session / buffers ------------------------------------------------------------------
 Buffer::~Buffer() {
-  if (owned && dptr && session && session->ctx()) ah_buf_free(session->ctx(), dptr);
+  if (owned && dptr && session && session->ctx()) session->Release(dptr, alloc_bytes);
 }
 
 Status Session::Create(int device_id, std::unique_ptr<Session>* out) {
@@ -57,7 +57,24 @@ Status Session::Create(int device_id, std::unique_ptr<Session>* out) {
   return Status::OK();
 }
 Session::~Session() {
+  TrimPool();
   if (ctx_) ah_ctx_destroy(ctx_);
+}
+void Session::TrimPool() {
+  for (auto& kv : pool_) ah_buf_free(ctx_, kv.second);
+  pool_.clear();
+  pooled_bytes_ = 0;
+}
+void Session::Release(void* dptr, size_t alloc_bytes) {
+  if (alloc_bytes == 0 || pooled_bytes_ + alloc_bytes > pool_cap_) { ah_buf_free(ctx_, dptr); return; }
+  pool_.emplace(alloc_bytes, dptr);
+  pooled_bytes_ += alloc_bytes;
+}
+// size classes: powers of two up to 1 MiB, then multiples of 1 MiB — repeated calls on same-shaped batches hit exactly
+static size_t SizeClass(size_t nbytes) {
+  if (nbytes <= 256) return 256;
+  if (nbytes <= ((size_t)1 << 20)) { size_t c = 256; while (c < nbytes) c <<= 1; return c; }
+  return (nbytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
 }
 Status Session::FromStatus(int st) const {
   if (st == AH_OK) return Status::OK();
@@ -70,15 +87,32 @@ Status Session::FromStatus(int st) const {
   }
   return Status::Make(c, ah_last_error(ctx_));
 }
-Status Session::Allocate(int64_t nbytes, BufferPtr* out) {
+Status Session::Allocate(int64_t nbytes, BufferPtr* out, bool zero_all) {
   auto b = std::make_shared<Buffer>();
   b->session = this;
   b->size = nbytes;
-  AHC_RETURN_NOT_OK(FromStatus(ah_buf_alloc(ctx_, (size_t)(nbytes > 0 ? nbytes : 1), &b->dptr)));
+  static const long long cap_env = getenv("ARROWHIP_POOL_BYTES") ? atoll(getenv("ARROWHIP_POOL_BYTES")) : -1;
+  if (cap_env >= 0) pool_cap_ = (size_t)cap_env;
+  const size_t cls = SizeClass(((size_t)(nbytes > 0 ? nbytes : 1) + 63) & ~(size_t)63);
+  auto hit = pool_cap_ ? pool_.find(cls) : pool_.end();
+  if (hit != pool_.end()) {
+    b->dptr = hit->second;
+    pooled_bytes_ -= cls;
+    pool_.erase(hit);
+  } else {
+    int rc = ah_buf_alloc(ctx_, cls, &b->dptr);
+    if (rc != AH_OK && !pool_.empty()) {  // out of memory with blocks parked in the pool: give them back and retry
+      TrimPool();
+      rc = ah_buf_alloc(ctx_, cls, &b->dptr);
+    }
+    AHC_RETURN_NOT_OK(FromStatus(rc));
+  }
+  b->alloc_bytes = pool_cap_ ? cls : 0;
   // ctx.Allocate → memory.NewResizableBuffer is zero-filled (executor.go:600 prepareOutput;
   // SURVEY §8a quirk 4): null slots "hold 0" because of this
   size_t padded = ((size_t)(nbytes > 0 ? nbytes : 1) + 63) & ~(size_t)63;
-  AHC_RETURN_NOT_OK(FromStatus(ah_memset_async(ctx_, b->dptr, 0, padded)));
+  const size_t keep = zero_all ? 0 : ((size_t)(nbytes > 0 ? nbytes : 0) & ~(size_t)63);
+  AHC_RETURN_NOT_OK(FromStatus(ah_memset_async(ctx_, (uint8_t*)b->dptr + keep, 0, padded - keep)));
   *out = std::move(b);
   return Status::OK();
 }
@@ -332,7 +366,10 @@ Status ScalarFunction::Execute(ExecCtx* ctx, const FunctionOptions* opts, const 
   if (kernel->mem_alloc == exec::MemAlloc::MemPrealloc) {
     BufferPtr b;
     int64_t nbytes = res.type->bit_width == 1 ? (length + 7) / 8 : length * (res.type->bit_width / 8);
-    AHC_RETURN_NOT_OK(s->Allocate(nbytes, &b));
+    // every scalar kernel with a byte-addressed output writes all `length` slots (null slots included: the NotNull
+    // ops store their zero, a null scalar operand memsets); bitmap outputs keep the full zero-fill, their kernels
+    // read-modify-write boundary words
+    AHC_RETURN_NOT_OK(s->Allocate(nbytes, &b, /*zero_all=*/res.type->bit_width == 1));
     res.buffers[1].WrapBuffer(b);
   }
   // executeSingleSpan (executor.go:644-656)

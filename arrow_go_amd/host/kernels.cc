@@ -428,7 +428,7 @@ static Status ExecFilter(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
   out->len = n_out;  // preallocateData :83-93
   BufferPtr vb, db;
   if (allocate_validity) { AHC_RETURN_NOT_OK(k->AllocateBitmap(n_out, &vb)); out->buffers[0].WrapBuffer(vb); }
-  AHC_RETURN_NOT_OK(k->Allocate(n_out * w, &db));
+  AHC_RETURN_NOT_OK(k->Allocate(n_out * w, &db, /*zero_all=*/false));
   out->buffers[1].WrapBuffer(db);
   if (values.len == 0) return Status::OK();
   int64_t nulls = 0;
@@ -454,7 +454,7 @@ static Status ExecTake(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
   out->len = indices.len;
   BufferPtr vb, db;
   if (allocate_validity) { AHC_RETURN_NOT_OK(k->AllocateBitmap(indices.len, &vb)); out->buffers[0].WrapBuffer(vb); }
-  AHC_RETURN_NOT_OK(k->Allocate(indices.len * w, &db));
+  AHC_RETURN_NOT_OK(k->Allocate(indices.len * w, &db, /*zero_all=*/false));
   out->buffers[1].WrapBuffer(db);
   if (indices.len == 0) { out->nulls = 0; return Status::OK(); }
   int64_t nulls = 0, bad = 0;
@@ -480,7 +480,7 @@ static Status TakeBinaryCommon(KernelCtx* k, const ArraySpan& values, int idx_wi
   AHC_RETURN_NOT_OK(s->FromStatus(ah_take_binary_offsets(s->ctx(), ow, values.buffers[1].buf, values.MayHaveNulls() ? values.buffers[0].buf : nullptr,
                                                          values.offset, values.len, idx_width, idx_signed, idx, ivalid, ioff, n, 1, ob->dptr,
                                                          allocate_validity ? (uint8_t*)vb->dptr : nullptr, &nulls, &total, &bad)));
-  AHC_RETURN_NOT_OK(k->Allocate(total, &db));
+  AHC_RETURN_NOT_OK(k->Allocate(total, &db, /*zero_all=*/false));
   out->buffers[2].WrapBuffer(db);
   if (n > 0)
     AHC_RETURN_NOT_OK(s->FromStatus(ah_take_binary_data(s->ctx(), ow, values.buffers[1].buf, values.buffers[2].buf, values.offset, idx_width, idx, n,
@@ -721,14 +721,14 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
   BufferPtr ids, ids_valid, dict;
   AHC_RETURN_NOT_OK(k->Allocate((n + 1) * 8, &dict));
   if (dict_encode) {
-    AHC_RETURN_NOT_OK(k->Allocate(n * 4, &ids));
+    AHC_RETURN_NOT_OK(k->Allocate(n * 4, &ids, /*zero_all=*/false));
     if (valid && !encode_nulls) AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &ids_valid));
   }
   int64_t ndict = 0; int32_t null_id = -1;
   const uint64_t* keys64 = (const uint64_t*)Values(keys);
   BufferPtr widened;
   if (kw < 8 && n > 0) {
-    AHC_RETURN_NOT_OK(k->Allocate(n * 8, &widened));
+    AHC_RETURN_NOT_OK(k->Allocate(n * 8, &widened, /*zero_all=*/false));
     AHC_RETURN_NOT_OK(s->FromStatus(ah_cast_numeric(s->ctx(), raw_type, AH_UINT64, Values(keys), nullptr, 0, n, 1, 1, widened->dptr)));
     keys64 = (const uint64_t*)widened->dptr;
   }
@@ -744,7 +744,7 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
   d->null_count = null_id >= 0 ? 1 : 0;
   if (kw < 8) {
     BufferPtr narrow;
-    AHC_RETURN_NOT_OK(k->Allocate(ndict * kw, &narrow));
+    AHC_RETURN_NOT_OK(k->Allocate(ndict * kw, &narrow, /*zero_all=*/false));
     if (ndict > 0)
       AHC_RETURN_NOT_OK(s->FromStatus(ah_cast_numeric(s->ctx(), AH_UINT64, raw_type, dict->dptr, nullptr, 0, ndict, 1, 1, narrow->dptr)));
     dict = narrow;
@@ -788,7 +788,7 @@ static Status ExecHashBinary(KernelCtx* k, const ExecSpan& b, ExecResult* out, b
   BufferPtr ids, ids_valid, first_rows;
   AHC_RETURN_NOT_OK(k->Allocate((n + 1) * 8, &first_rows));
   if (dict_encode) {
-    AHC_RETURN_NOT_OK(k->Allocate(n * 4, &ids));
+    AHC_RETURN_NOT_OK(k->Allocate(n * 4, &ids, /*zero_all=*/false));
     if (valid && !encode_nulls) AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &ids_valid));
   }
   int64_t ndict = 0; int32_t null_id = -1;
@@ -1056,7 +1056,7 @@ static Status SortIndicesImpl(ExecCtx* ctx, const FunctionOptions* o, const std:
   res->type = GetDataType(Type::UINT64);
   res->length = length;
   res->null_count = 0;
-  AHC_RETURN_NOT_OK(s->Allocate(length * 8, &res->buffers[1]));
+  AHC_RETURN_NOT_OK(s->Allocate(length * 8, &res->buffers[1], /*zero_all=*/false));
   if (length > 0)
     AHC_RETURN_NOT_OK(s->FromStatus(ah_sort_indices_multi(s->ctx(), (int)keys.size(), types.data(), values.data(), valids.data(), offs.data(), length,
                                                           desc.data(), nfirst.data(), (uint64_t*)res->buffers[1]->dptr)));
@@ -1158,7 +1158,7 @@ static Status ExecCumulativeSum(KernelCtx* k, const ExecSpan& b, ExecResult* out
   bool needs_validity = in.MayHaveNulls();  // :354
   int w = in.type->bit_width / 8;
   BufferPtr vb, db;
-  AHC_RETURN_NOT_OK(k->Allocate(in.len * w, &db));  // prepareCumulativeOutput :211-226
+  AHC_RETURN_NOT_OK(k->Allocate(in.len * w, &db, /*zero_all=*/false));  // prepareCumulativeOutput :211-226
   out->buffers[1].WrapBuffer(db);
   if (needs_validity) {
     AHC_RETURN_NOT_OK(k->AllocateBitmap(in.len, &vb));
