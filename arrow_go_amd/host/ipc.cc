@@ -152,6 +152,9 @@ Status StreamReader::Open(Session* s, const uint8_t* bytes, int64_t len, std::un
   r->s_ = s;
   r->p_ = bytes;
   r->n_ = len;
+  // the FILE format (ipc.NewFileReader, arrow/ipc/file_reader.go:60-160) is the same message sequence between an
+  // "ARROW1\0\0" magic and a footer: after the magic it reads as a stream and ends at the EOS marker in front of the footer
+  if (len >= 8 && std::memcmp(bytes, "ARROW1\0\0", 8) == 0) r->pos_ = 8;
   bool have;
   const uint8_t *meta, *body;
   int64_t mlen, blen;

@@ -7,6 +7,8 @@
 // allocation — the IPC body is already laid out as Arrow buffers (8-byte aligned, validity / offsets /
 // data in field order), so nothing is unpacked on the host.
 //
+// Both the stream format and the file format ("ARROW1" magic … footer) are read; the footer's block index is not
+// needed for a sequential pass.
 // Scope: flat columns of the types the kernels take — Int8..Uint64, Float32/64, Bool, Utf8 / Binary and
 // their Large variants; little-endian; uncompressed; no dictionary batches.  Anything else is
 // ErrNotImplemented with the field named.  The metadata is a FlatBuffer (format/Message.fbs,

@@ -57,6 +57,17 @@ def test_inspect_schema_and_batches():
     assert ac.ipc_inspect(make_stream([], schema)) == (fields, [])
 
 
+def test_inspect_file_format():
+    # ipc.NewFileReader's input: magic, the same messages, EOS, footer, magic
+    schema, batches, _ = sample_stream(5, sizes=(10, 0, 300))
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_file(sink, schema) as w:
+        for b in batches:
+            w.write_batch(b)
+    fields, rows = ac.ipc_inspect(sink.getvalue())
+    assert [f[0] for f in fields] == schema.names and rows == [10, 0, 300]
+
+
 def test_inspect_rejects_what_it_does_not_read():
     d = pa.array(["a", "b", "a"]).dictionary_encode()
     with pytest.raises(ac.ErrNotImplemented, match="dictionary"):
@@ -129,6 +140,19 @@ def test_read_ipc_round_trip(sess):
     assert out.equals(pc.add(batches[0].column(6), batches[0].column(6)))
     s = cols[names.index("c11_string")]
     assert sess.call_function("unique", [s]).equals(pc.unique(batches[0].column(11)))
+
+
+@pytest.mark.gpu
+def test_read_ipc_file_format(sess):
+    schema, batches, _ = sample_stream(6, sizes=(500, 64))
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_file(sink, schema) as w:
+        for b in batches:
+            w.write_batch(b)
+    got = list(sess.read_ipc(sink.getvalue()))
+    assert len(got) == 2
+    for (names, cols, rows), b in zip(got, batches):
+        assert rows == b.num_rows and all(c.to_arrow().equals(e) for c, e in zip(cols, b.columns))
 
 
 @pytest.mark.gpu
