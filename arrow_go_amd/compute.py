@@ -235,13 +235,17 @@ class Session:
         import pyarrow as pa
         if isinstance(arr, pa.ChunkedArray):  # compute.ChunkedDatum: every chunk uploaded, chunk boundaries kept
             tname = str(arr.type)
-            if tname not in _TYPE_IDS:
+            if pa.types.is_dictionary(arr.type):
+                tid = 36  # arrow.DICTIONARY
+            elif tname in _TYPE_IDS:
+                tid = _TYPE_IDS[tname]
+            else:
                 raise ErrNotImplemented(f"unsupported chunked type {tname}")
             parts = [self._import(c) for c in arr.chunks]
             try:
                 d = _vp()
                 handles = (_vp * max(len(parts), 1))(*parts)
-                self._check(lib.ahc_chunked_from_arrays(self.h, _TYPE_IDS[tname], len(parts), handles, C.byref(d)))
+                self._check(lib.ahc_chunked_from_arrays(self.h, tid, len(parts), handles, C.byref(d)))
                 return d
             finally:
                 for p in parts:

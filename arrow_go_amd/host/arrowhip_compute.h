@@ -114,8 +114,9 @@ struct ArrayData {
   int64_t null_count = kUnknownNullCount;
   int64_t offset = 0;
   BufferPtr buffers[3];                    // [0] validity, [1] values / boolean data / offsets, [2] var-length data
-  std::shared_ptr<ArrayData> dictionary;   // for DICTIONARY results (dictionary_encode)
+  std::shared_ptr<ArrayData> dictionary;   // DICTIONARY arrays: buffers = the indices, `dictionary` = the values
   const DataType* dict_value_type = nullptr;
+  const DataType* dict_index_type = nullptr;  // nullptr = int32 (what dictionary_encode produces)
 };
 using ArrayDataPtr = std::shared_ptr<ArrayData>;
 
@@ -140,7 +141,9 @@ struct ArraySpan {
   const DataType* type = nullptr;
   int64_t len = 0, nulls = kUnknownNullCount, offset = 0;
   BufferSpan buffers[3];
-  ArrayDataPtr dictionary;  // DICTIONARY outputs (exec.ArraySpan.Dictionary, span.go:159-168)
+  ArrayDataPtr dictionary;  // DICTIONARY arrays (exec.ArraySpan.Dictionary, span.go:159-168)
+  const DataType* dict_value_type = nullptr;
+  const DataType* dict_index_type = nullptr;
   void SetMembers(const ArrayData& d);
   bool MayHaveNulls() const { return nulls != 0 && buffers[0].buf != nullptr; }  // span.go:127-129
   // ArraySpan.UpdateNullCount (span.go:112-125): popcount of the validity on the device

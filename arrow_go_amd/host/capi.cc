@@ -104,43 +104,66 @@ static const DataType* TypeFromFormat(const char* f) {
   return nullptr;
 }
 
-// ImportCArray-like (arrow/cdata/interface.go:153): host buffers → device; releases the source
+// ImportCArray-like (arrow/cdata/interface.go:153): host buffers → device.  Does not release the source.
+static Status ImportOne(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, ArrayDataPtr* out) {
+  const DataType* t = TypeFromFormat(schema->format);
+  if (!t) return Status::Make(StatusCode::NotImplemented, std::string("unsupported Arrow format '") + (schema->format ? schema->format : "") + "'");
+  Status st;
+  auto d = std::make_shared<ArrayData>();
+  d->type = t;
+  d->length = arr->length;
+  d->null_count = arr->null_count;
+  d->offset = arr->offset;
+  Session* ss = s->session.get();
+  int64_t nbits = arr->offset + arr->length;
+  int64_t vbytes = (nbits + 7) / 8;
+  int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
+  int64_t data_bytes = 0;
+  if (IsBaseBinary(t->id)) {  // [validity, offsets (offset + length + 1 entries), data (up to the last offset)]
+    dbytes = (nbits + 1) * (t->bit_width / 8);
+    if (arr->n_buffers >= 3 && arr->buffers[1] != nullptr)
+      data_bytes = t->bit_width == 32 ? (int64_t)((const int32_t*)arr->buffers[1])[nbits] : ((const int64_t*)arr->buffers[1])[nbits];
+    AHC_RETURN_NOT_OK(ss->Allocate(data_bytes, &d->buffers[2]));
+    if (data_bytes > 0 && arr->buffers[2] != nullptr)
+      AHC_RETURN_NOT_OK(ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[2]->dptr, arr->buffers[2], (size_t)data_bytes)));
+  }
+  if (arr->n_buffers >= 1 && arr->buffers[0] != nullptr && arr->null_count != 0) {
+    AHC_RETURN_NOT_OK(ss->Allocate(vbytes, &d->buffers[0]));
+    AHC_RETURN_NOT_OK(ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[0]->dptr, arr->buffers[0], (size_t)vbytes)));
+  } else {
+    d->null_count = 0;
+  }
+  AHC_RETURN_NOT_OK(ss->Allocate(dbytes, &d->buffers[1]));
+  if (dbytes > 0 && arr->n_buffers >= 2 && arr->buffers[1] != nullptr)
+    AHC_RETURN_NOT_OK(ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[1]->dptr, arr->buffers[1], (size_t)dbytes)));
+  AHC_RETURN_NOT_OK(ss->FromStatus(ah_sync(ss->ctx())));
+  if (schema->dictionary && arr->dictionary) {
+    // a dictionary array (arrow/cdata/cdata.go importDictionary): the struct describes the INDICES, `dictionary` the values.
+    // On the device the indices are always int32 (what dictionary_encode produces); the producer's index type is
+    // remembered and restored on export.
+    if (!IsInteger(t->id)) return Status::Make(StatusCode::Invalid, "dictionary indices must be integers");
+    ArrayDataPtr values;
+    AHC_RETURN_NOT_OK(ImportOne(s, arr->dictionary, schema->dictionary, &values));
+    if (t->id != Type::INT32) {
+      Datum casted;
+      AHC_RETURN_NOT_OK(compute::CastDatum(&s->ectx, Datum::Of(d), compute::CastOptions::Safe(GetDataType(Type::INT32)), &casted));
+      d = casted.array;
+    }
+    auto dict = std::make_shared<ArrayData>(*d);
+    dict->type = GetDataType(Type::DICTIONARY);
+    dict->dict_index_type = t;
+    dict->dict_value_type = values->type;
+    dict->dictionary = values;
+    d = dict;
+  }
+  *out = d;
+  return Status::OK();
+}
+
 AHC_EXPORT int ahc_import(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, ahc_datum** out) {
   *out = nullptr;
-  const DataType* t = TypeFromFormat(schema->format);
-  Status st;
-  if (!t) st = Status::Make(StatusCode::NotImplemented, std::string("unsupported Arrow format '") + (schema->format ? schema->format : "") + "'");
-  auto d = std::make_shared<ArrayData>();
-  if (st.ok()) {
-    d->type = t;
-    d->length = arr->length;
-    d->null_count = arr->null_count;
-    d->offset = arr->offset;
-    Session* ss = s->session.get();
-    int64_t nbits = arr->offset + arr->length;
-    int64_t vbytes = (nbits + 7) / 8;
-    int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
-    int64_t data_bytes = 0;
-    if (IsBaseBinary(t->id)) {  // [validity, offsets (offset + length + 1 entries), data (up to the last offset)]
-      dbytes = (nbits + 1) * (t->bit_width / 8);
-      if (arr->n_buffers >= 3 && arr->buffers[1] != nullptr)
-        data_bytes = t->bit_width == 32 ? (int64_t)((const int32_t*)arr->buffers[1])[nbits] : ((const int64_t*)arr->buffers[1])[nbits];
-      st = ss->Allocate(data_bytes, &d->buffers[2]);
-      if (st.ok() && data_bytes > 0 && arr->buffers[2] != nullptr)
-        st = ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[2]->dptr, arr->buffers[2], (size_t)data_bytes));
-    }
-    if (!st.ok()) {
-    } else if (arr->n_buffers >= 1 && arr->buffers[0] != nullptr && arr->null_count != 0) {
-      st = ss->Allocate(vbytes, &d->buffers[0]);
-      if (st.ok()) st = ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[0]->dptr, arr->buffers[0], (size_t)vbytes));
-    } else {
-      d->null_count = 0;
-    }
-    if (st.ok()) st = ss->Allocate(dbytes, &d->buffers[1]);
-    if (st.ok() && dbytes > 0 && arr->n_buffers >= 2 && arr->buffers[1] != nullptr)
-      st = ss->FromStatus(ah_upload_async(ss->ctx(), d->buffers[1]->dptr, arr->buffers[1], (size_t)dbytes));
-    if (st.ok()) st = ss->FromStatus(ah_sync(ss->ctx()));
-  }
+  ArrayDataPtr d;
+  Status st = ImportOne(s, arr, schema, &d);
   if (arr->release) arr->release(arr);
   if (schema->release) schema->release(schema);
   if (!st.ok()) return Fail(s, st);
@@ -403,7 +426,18 @@ AHC_EXPORT int ahc_export(ahc_session* s, ahc_datum* d, ArrowArray* arr, ArrowSc
   const ArrayData& a = *d->d.array;
   Session* ss = s->session.get();
   if (a.type->id == Type::DICTIONARY) {
-    Status st = ExportOne(ss, a, GetDataType(Type::INT32), arr, schema);
+    const DataType* it = a.dict_index_type ? a.dict_index_type : GetDataType(Type::INT32);
+    Status st;
+    if (it->id != Type::INT32) {  // back to the producer's index type (the values fit: they came from it or are a selection of it)
+      auto idx = std::make_shared<ArrayData>(a);
+      idx->type = GetDataType(Type::INT32);
+      idx->dictionary = nullptr;
+      Datum casted;
+      st = compute::CastDatum(&s->ectx, Datum::Of(idx), compute::CastOptions::Unsafe(it), &casted);
+      if (st.ok()) st = ExportOne(ss, *casted.array, it, arr, schema);
+    } else {
+      st = ExportOne(ss, a, it, arr, schema);
+    }
     if (!st.ok()) return Fail(s, st);
     auto* da = (ArrowArray*)calloc(1, sizeof(ArrowArray));
     auto* ds = (ArrowSchema*)calloc(1, sizeof(ArrowSchema));

@@ -134,6 +134,9 @@ void ArraySpan::SetMembers(const ArrayData& d) {
   }
   // span.go:322-333: no validity buffer ⇒ null count is 0
   if (buffers[0].buf == nullptr) nulls = 0;
+  dictionary = d.dictionary;
+  dict_value_type = d.dict_value_type;
+  dict_index_type = d.dict_index_type;
 }
 
 Status ArraySpan::UpdateNullCount(Session* s, int64_t* out) {
@@ -161,6 +164,11 @@ ArrayDataPtr ArraySpan::MakeData() const {
   d->buffers[2] = buffers[2].owner;
   // span.go:243-247: a known-zero null count drops the validity buffer
   if (nulls == 0) d->buffers[0] = nullptr;
+  if (type && type->id == Type::DICTIONARY) {
+    d->dictionary = dictionary;
+    d->dict_value_type = dict_value_type;
+    d->dict_index_type = dict_index_type;
+  }
   return d;
 }
 
@@ -577,6 +585,56 @@ ArrayDataPtr SliceData(const ArrayDataPtr& a, int64_t off, int64_t len) {
   return d;
 }
 
+// array.Equal for two dictionaries on the device (what dictionaryHashState.Append asks before it unifies, vector_hash.go:527-531):
+// same type and length, equal validity, equal values (fixed width) or equal offsets and bytes (binary).  Compares through the
+// compare + popcount kernels; only unsliced arrays (offset 0), anything else reports "not equal".
+static Status DeviceArrayEqual(Session* s, const ArrayData& a, const ArrayData& b, bool* eq) {
+  *eq = false;
+  if (a.type->id != b.type->id || a.length != b.length || a.offset != 0 || b.offset != 0) return Status::OK();
+  const int64_t n = a.length;
+  if (n == 0) { *eq = true; return Status::OK(); }
+  const bool av = a.buffers[0] && a.null_count != 0, bv = b.buffers[0] && b.null_count != 0;
+  if (av != bv) return Status::OK();
+  BufferPtr bits;
+  auto same_bytes = [&](int type, const void* x, const void* y, int64_t count, bool* same) -> Status {
+    if (count == 0) { *same = true; return Status::OK(); }
+    AHC_RETURN_NOT_OK(s->AllocateBitmap(count, &bits));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_comparison(s->ctx(), AH_CMP_NE, AH_SHAPE_AA, type, x, y, (uint8_t*)bits->dptr, count, 0)));
+    int64_t diff = 0;
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_count_set_bits(s->ctx(), (const uint8_t*)bits->dptr, 0, count, &diff)));
+    *same = diff == 0;
+    return Status::OK();
+  };
+  bool same = true;
+  if (av) {
+    BufferPtr x;
+    AHC_RETURN_NOT_OK(s->AllocateBitmap(n, &x));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_bitmap_op(s->ctx(), AH_BIT_XOR, (const uint8_t*)a.buffers[0]->dptr, 0, (const uint8_t*)b.buffers[0]->dptr, 0, (uint8_t*)x->dptr, 0, n)));
+    int64_t diff = 0;
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_count_set_bits(s->ctx(), (const uint8_t*)x->dptr, 0, n, &diff)));
+    if (diff) return Status::OK();
+  }
+  const int w = a.type->bit_width / 8;
+  if (IsBaseBinary(a.type->id)) {
+    AHC_RETURN_NOT_OK(same_bytes(w == 4 ? AH_INT32 : AH_INT64, a.buffers[1]->dptr, b.buffers[1]->dptr, n + 1, &same));
+    if (!same) return Status::OK();
+    uint8_t last[8] = {0};
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), last, (const uint8_t*)a.buffers[1]->dptr + n * w, (size_t)w)));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+    int64_t bytes = 0;
+    if (w == 4) { int32_t v; memcpy(&v, last, 4); bytes = v; } else memcpy(&bytes, last, 8);
+    AHC_RETURN_NOT_OK(same_bytes(AH_UINT8, a.buffers[2]->dptr, b.buffers[2]->dptr, bytes, &same));
+  } else if (a.type->bit_width == 1) {
+    return Status::OK();  // boolean dictionaries: not compared
+  } else {
+    // raw bit patterns: compare as unsigned integers of the element width (NaN payloads and ±0 distinguish, as bytes.Equal would)
+    const int t = w == 1 ? AH_UINT8 : w == 2 ? AH_UINT16 : w == 4 ? AH_UINT32 : AH_UINT64;
+    AHC_RETURN_NOT_OK(same_bytes(t, a.buffers[1]->dptr, b.buffers[1]->dptr, n, &same));
+  }
+  *eq = same;   // values under nulls may differ between producers; validity already matched
+  return Status::OK();
+}
+
 Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const DataType* type, ArrayDataPtr* out) {
   if (chunks.size() == 1) { *out = chunks[0]; return Status::OK(); }
   auto d = std::make_shared<ArrayData>();
@@ -590,6 +648,19 @@ Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const Da
   }
   d->length = total;
   d->null_count = nulls ? kUnknownNullCount : 0;
+  if (type->id == Type::DICTIONARY) {
+    // chunks of one dictionary array share their dictionary (what dictionary_encode and the selections above produce);
+    // differing dictionaries would need the unifier (array.NewDictionaryUnifier, arrow/array/dictionary.go) — not built
+    for (auto& c : chunks) {
+      if (c->dictionary == chunks[0]->dictionary) continue;
+      bool eq = false;
+      if (c->dictionary && chunks[0]->dictionary) AHC_RETURN_NOT_OK(DeviceArrayEqual(s, *c->dictionary, *chunks[0]->dictionary, &eq));
+      if (!eq) return Status::Make(StatusCode::NotImplemented, "concatenating dictionary arrays with different dictionaries");
+    }
+    d->dictionary = chunks[0]->dictionary;
+    d->dict_value_type = chunks[0]->dict_value_type;
+    d->dict_index_type = chunks[0]->dict_index_type;
+  }
   auto bitmap = [&](int which, BufferPtr* dst) -> Status {  // validity (which = 0) or boolean data (which = 1), bit by bit offset
     AHC_RETURN_NOT_OK(s->AllocateBitmap(total, dst));
     AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), (*dst)->dptr, 0, (size_t)((total + 7) / 8))));

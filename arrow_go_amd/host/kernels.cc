@@ -466,6 +466,24 @@ static Status ExecTake(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
   return Status::OK();
 }
 
+// dictionaryTake / dictionaryFilter (compute/selection.go:497-586): select the INDICES (int32 on the device), keep a pointer
+// to the same dictionary
+static void CarryDictionary(const ArraySpan& in, ExecResult* out) {
+  out->dictionary = in.dictionary;
+  out->dict_value_type = in.dict_value_type;
+  out->dict_index_type = in.dict_index_type;
+}
+static Status ExecTakeDictionary(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  AHC_RETURN_NOT_OK(ExecTake(k, b, out));
+  CarryDictionary(b.values[0].array, out);
+  return Status::OK();
+}
+static Status ExecFilterDictionary(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  AHC_RETURN_NOT_OK(ExecFilter(k, b, out));
+  CarryDictionary(b.values[0].array, out);
+  return Status::OK();
+}
+
 // VarBinaryImpl (vector_selection.go:1925-1992) under takeExec: offsets + validity + byte count, then the bytes
 static Status TakeBinaryCommon(KernelCtx* k, const ArraySpan& values, int idx_width, bool idx_signed, const void* idx, const uint8_t* ivalid,
                                int64_t ioff, int64_t n, bool allocate_validity, ExecResult* out) {
@@ -624,6 +642,12 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
     k.exec_fn = ExecFilter;
     af->AddKernel(std::move(k));
   }
+  {
+    exec::VectorKernel k;
+    k.sig.in_types = {Type::DICTIONARY, Type::BOOL};
+    k.exec_fn = ExecFilterDictionary;
+    af->AddKernel(std::move(k));
+  }
   for (Type t : kBinaryTypes) {
     exec::VectorKernel k;
     k.sig.in_types = {t, Type::BOOL};
@@ -647,6 +671,13 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
       k.can_execute_chunkwise = false;  // selection.go:639
       at->AddKernel(std::move(k));
     }
+  for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
+    exec::VectorKernel k;
+    k.sig.in_types = {Type::DICTIONARY, it};
+    k.exec_fn = ExecTakeDictionary;
+    k.can_execute_chunkwise = false;
+    at->AddKernel(std::move(k));
+  }
   for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
     exec::VectorKernel k;
     k.sig.in_types = {Type::BOOL, it};
@@ -855,6 +886,25 @@ void RegisterVectorHash(FunctionRegistry* reg) {
     kd.sig.in_types = {t};
     kd.output_is_dictionary = true;
     kd.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHashBinary(k, b, o, true); };
+    de->AddKernel(std::move(kd));
+  }
+  {
+    // dictionaryHashState (vector_hash.go:505-576, uniqueFinalizeDictionary :757-775): the distinct INDICES in first-seen
+    // order, as a dictionary array over the same dictionary; dictionary_encode of a dictionary array is the identity (:473-478)
+    exec::VectorKernel ku;
+    ku.sig.in_types = {Type::DICTIONARY};
+    ku.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) {
+      AHC_RETURN_NOT_OK(ExecHash(k, b, o, false));
+      CarryDictionary(b.values[0].array, o);
+      return Status::OK();
+    };
+    uq->AddKernel(std::move(ku));
+    exec::VectorKernel kd;
+    kd.sig.in_types = {Type::DICTIONARY};
+    kd.exec_fn = [](KernelCtx*, const ExecSpan& b, ExecResult* o) {
+      *o = b.values[0].array;
+      return Status::OK();
+    };
     de->AddKernel(std::move(kd));
   }
   reg->AddFunction(uq, false);

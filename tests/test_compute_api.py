@@ -848,3 +848,34 @@ def test_round_functions(sess):
         sess.call_function("round_to_multiple", [x], "multiple=null:double")
     with pytest.raises(ac.ErrInvalid, match="overflow"):
         sess.call_function("round", [pa.array([1.7e308])], "ndigits=-308;round_mode=up")
+
+
+# ---- dictionary arrays: dictionaryTake / dictionaryFilter (compute/selection.go:497-586), dictionaryHashState (vector_hash.go:505-576) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("index_type", [pa.int8(), pa.uint16(), pa.int32(), pa.int64()], ids=str)
+def test_dictionary_arrays(sess, index_type):
+    rng = np.random.default_rng(80)
+    n = 20001
+    for dictionary in (pa.array([10, 20, 30, 40], pa.int64()), pa.array(["foo", "bar", None, "quuux", ""])):
+        idx = pa.array(rng.integers(0, len(dictionary), n), mask=rng.random(n) < 0.1, type=index_type)
+        d = pa.DictionaryArray.from_arrays(idx, dictionary)
+        back = sess.call_function("dictionary_encode", [d])                       # identity (vector_hash.go:473-478), and a C Data round trip
+        assert back.type == d.type and back.equals(d)
+        sel = pa.array(rng.integers(0, n, 5000), mask=rng.random(5000) < 0.1, type=pa.int32())
+        got = sess.call_function("take", [d, sel])
+        assert got.type == d.type and got.equals(d.take(sel)) and got.dictionary.equals(dictionary)
+        mask = pa.array(rng.random(n) < 0.3, mask=rng.random(n) < 0.1)
+        for opt, ns in (("", "drop"), ("null_selection_behavior=emit_null", "emit_null")):
+            got = sess.call_function("filter", [d, mask], opt)
+            assert got.equals(d.filter(mask, null_selection_behavior=ns)) and got.dictionary.equals(dictionary)
+        uq = sess.call_function("unique", [d])                                      # vector_hash_test.go:452-500 TestDictionaryUnique
+        exp = pc.unique(d)
+        assert uq.type == d.type and uq.indices.equals(exp.indices) and uq.dictionary.equals(dictionary)
+        # chunks of one dictionary array keep their dictionary
+        parts = pa.chunked_array([d.slice(0, 700), d.slice(700)])
+        got = sess.call_function("take", [parts, sel])
+        assert got.combine_chunks().equals(d.take(sel))
+    # vector_hash_test.go:452-500: indices [3,0,0,0,1,1,3,0,1,3,0,1] over [10,20,30,40] → [3,0,1] over the same dictionary
+    d = pa.DictionaryArray.from_arrays(pa.array([3, 0, 0, 0, 1, 1, 3, 0, 1, 3, 0, 1], index_type), pa.array([10, 20, 30, 40], pa.int64()))
+    uq = sess.call_function("unique", [d])
+    assert uq.indices.to_pylist() == [3, 0, 1] and uq.dictionary.to_pylist() == [10, 20, 30, 40]
