@@ -36,7 +36,7 @@ def test_registry_has_the_path_functions():
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
-    assert ac.function_num_kernels("array_take") == 120     # (10 numeric + 4 binary-like + bool value types) × 8 index types
+    assert ac.function_num_kernels("array_take") == 128     # (10 numeric + 4 binary-like + bool + dictionary value types) × 8 index types
     assert ac.function_num_kernels("filter") == 0           # MetaFunction
     assert ac.function_num_kernels("cast_int64") == 10       # 9 other numeric types + bool
     assert ac.function_num_kernels("cumulative_sum") == 10 and ac.function_num_kernels("cumulative_sum_checked") == 10
