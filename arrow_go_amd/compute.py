@@ -158,7 +158,7 @@ class ErrHip(ArrowError):
 _ERRS = {1: ErrInvalid, 2: ErrIndex, 3: ErrNotImplemented, 4: ErrType, 5: ErrKey, 6: ErrHip}
 
 # arrow.Type ids
-_TYPE_IDS = {"string": 13, "binary": 14, "large_string": 34, "large_binary": 35, "bool": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7, "uint64": 8, "int64": 9,
+_TYPE_IDS = {"dictionary": 36, "string": 13, "binary": 14, "large_string": 34, "large_binary": 35, "bool": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7, "uint64": 8, "int64": 9,
              "float": 11, "double": 12}
 _PACK = {1: "<?", 2: "<B", 3: "<b", 4: "<H", 5: "<h", 6: "<I", 7: "<i", 8: "<Q", 9: "<q", 11: "<f", 12: "<d"}
 

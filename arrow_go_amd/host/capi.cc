@@ -707,7 +707,7 @@ AHC_EXPORT int ahc_ipc_field(ahc_ipc_reader* r, int i, const char** name, int* t
   if (i < 0 || i >= (int)r->r->fields().size()) return Fail(r->s, Status::Make(StatusCode::Invalid, "field index out of range"));
   const ipc::FieldInfo& f = r->r->fields()[i];
   if (name) *name = f.name.c_str();
-  if (type_id) *type_id = (int)f.type->id;
+  if (type_id) *type_id = f.dict_id >= 0 ? (int)Type::DICTIONARY : (int)f.type->id;
   if (nullable) *nullable = f.nullable;
   return 0;
 }
@@ -738,7 +738,7 @@ AHC_EXPORT int ahc_ipc_inspect(const uint8_t* bytes, int64_t len, char* out, int
       const ipc::FieldInfo& f = r->fields()[i];
       std::string hex;  // names are arbitrary bytes: hex keeps the separators unambiguous
       for (unsigned char ch : f.name) { char b[3]; snprintf(b, sizeof b, "%02x", ch); hex += b; }
-      text += (i ? "," : "") + hex + ":" + std::to_string((int)f.type->id) + ":" + (f.nullable ? "1" : "0");
+      text += (i ? "," : "") + hex + ":" + std::to_string(f.dict_id >= 0 ? (int)Type::DICTIONARY : (int)f.type->id) + ":" + (f.nullable ? "1" : "0");
     }
     text += "|";
     bool have = true, first = true;

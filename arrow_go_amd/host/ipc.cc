@@ -73,7 +73,22 @@ Status DecodeField(Fb& fb, int64_t f, FieldInfo* out) {
   out->nullable = fb.scalar<uint8_t>(f, 1, 0) != 0;
   const int type_type = fb.scalar<uint8_t>(f, 2, 0);
   const int64_t tt = fb.indirect(f, 3);
-  if (fb.field(f, 4)) return NotImpl("field '" + out->name + "' is dictionary-encoded");
+  if (const int64_t de = fb.indirect(f, 4)) {  // DictionaryEncoding { id: long; indexType: Int; isOrdered: bool; dictionaryKind }
+    out->dict_id = fb.scalar<int64_t>(de, 0, 0);
+    const int64_t it = fb.indirect(de, 1);
+    const int bits = it ? fb.scalar<int32_t>(it, 0, 0) : 32;   // absent → signed 32-bit (Schema.fbs)
+    const bool sgn = it ? fb.scalar<uint8_t>(it, 1, 0) != 0 : true;
+    Type iid = Type::NA;
+    switch (bits) {
+      case 8: iid = sgn ? Type::INT8 : Type::UINT8; break;
+      case 16: iid = sgn ? Type::INT16 : Type::UINT16; break;
+      case 32: iid = sgn ? Type::INT32 : Type::UINT32; break;
+      case 64: iid = sgn ? Type::INT64 : Type::UINT64; break;
+      default: return Invalid("field '" + out->name + "': dictionary index of " + std::to_string(bits) + " bits");
+    }
+    out->index_type = GetDataType(iid);
+    if (out->dict_id < 0) return Invalid("field '" + out->name + "': negative dictionary id");
+  }
   if (fb.vec_len(fb.indirect(f, 5)) != 0) return NotImpl("field '" + out->name + "' is nested");
   Type id = Type::NA;
   switch (type_type) {
@@ -184,24 +199,42 @@ Status StreamReader::Open(Session* s, const uint8_t* bytes, int64_t len, std::un
 // nodes and buffers are consumed in field order — validity, then data (fixed width / bool) or
 // offsets + data (binary).
 Status StreamReader::Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_t* rows) {
-  const bool dry = columns == nullptr;  // validate the metadata against the body, move nothing
-  if (!dry) columns->clear();
+  if (columns) columns->clear();
   *rows = 0;
   const uint8_t *meta, *body;
   int64_t mlen, blen;
   for (;;) {
     AHC_RETURN_NOT_OK(NextMessage(have, &meta, &mlen, &body, &blen));
     if (!*have) return Status::OK();
-    Fb probe{meta, mlen};
-    const int ht = probe.scalar<uint8_t>(probe.root(), 1, 0);
-    if (probe.bad) return Invalid("invalid message metadata");
-    if (ht == kHeaderRecordBatch) break;
-    if (ht == kHeaderDictionaryBatch) return NotImpl("dictionary batch");
-    return Invalid("invalid message type (got=" + std::to_string(ht) + ", want=RecordBatch)");
+    Fb fb{meta, mlen};
+    const int64_t msg = fb.root();
+    const int ht = fb.scalar<uint8_t>(msg, 1, 0);
+    const int64_t hdr = fb.indirect(msg, 2);
+    if (fb.bad || !hdr) return Invalid("invalid message metadata");
+    if (ht == kHeaderRecordBatch) return LoadColumns(meta, mlen, hdr, body, blen, fields_, false, columns, rows);
+    if (ht != kHeaderDictionaryBatch) return Invalid("invalid message type (got=" + std::to_string(ht) + ", want=RecordBatch)");
+    // DictionaryBatch { id: long; data: RecordBatch; isDelta: bool } (reader.go:167-200 readDictionary): one column of the
+    // field's value type, kept by id for the record batches that follow
+    const int64_t id = fb.scalar<int64_t>(hdr, 0, 0);
+    const int64_t data = fb.indirect(hdr, 1);
+    if (fb.bad || !data) return Invalid("invalid message metadata");
+    if (fb.scalar<uint8_t>(hdr, 2, 0)) return NotImpl("delta dictionary batch");
+    const FieldInfo* owner = nullptr;
+    for (auto& f : fields_) if (f.dict_id == id) owner = &f;
+    if (!owner) return Invalid("dictionary batch for unknown dictionary id " + std::to_string(id));
+    std::vector<FieldInfo> one{*owner};
+    std::vector<ArrayDataPtr> vals;
+    int64_t nvals = 0;
+    AHC_RETURN_NOT_OK(LoadColumns(meta, mlen, data, body, blen, one, true, columns ? &vals : nullptr, &nvals));
+    if (columns) dicts_[id] = vals[0];
+    seen_dict_[id] = true;
   }
+}
+
+Status StreamReader::LoadColumns(const uint8_t* meta, int64_t mlen, int64_t rb, const uint8_t* body, int64_t blen,
+                                 const std::vector<FieldInfo>& fields_, bool as_values, std::vector<ArrayDataPtr>* columns, int64_t* rows) {
+  const bool dry = columns == nullptr;  // validate the metadata against the body, move nothing
   Fb fb{meta, mlen};
-  const int64_t rb = fb.indirect(fb.root(), 2);
-  if (!rb || fb.bad) return Invalid("invalid message metadata");
   const int64_t nrows = fb.scalar<int64_t>(rb, 0, 0);
   const int64_t nodes = fb.indirect(rb, 1), bufs = fb.indirect(rb, 2);
   const int64_t n_nodes = fb.vec_len(nodes), n_bufs = fb.vec_len(bufs);
@@ -245,8 +278,11 @@ Status StreamReader::Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_
     if (fb.bad) return Invalid("invalid message metadata");
     if (flen != nrows) return Invalid("field '" + fi.name + "' has " + std::to_string(flen) + " rows, the batch " + std::to_string(nrows));
     if (fnulls < 0 || fnulls > flen) return Invalid("field '" + fi.name + "': null count " + std::to_string(fnulls));
+    const bool encoded = fi.dict_id >= 0 && !as_values;   // the column holds indices into dictionary fi.dict_id
+    if (encoded && !seen_dict_.count(fi.dict_id)) return Invalid("field '" + fi.name + "': no dictionary batch with id " + std::to_string(fi.dict_id) + " before the record batch");
+    const DataType* storage = encoded ? fi.index_type : fi.type;
     auto d = std::make_shared<ArrayData>();
-    d->type = fi.type;
+    d->type = storage;
     d->length = flen;
     d->offset = 0;
     int64_t off, len;
@@ -258,8 +294,8 @@ Status StreamReader::Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_
     } else {
       d->null_count = 0;  // a bitmap that is present but all set is dropped, like loadCommon (file_reader.go:700-712)
     }
-    const int w = fi.type->bit_width / 8;
-    if (IsBaseBinary(fi.type->id)) {
+    const int w = storage->bit_width / 8;
+    if (IsBaseBinary(storage->id)) {
       AHC_RETURN_NOT_OK(next_buffer(&off, &len));
       if (flen > 0 && len < (flen + 1) * w) return Invalid("field '" + fi.name + "': offsets buffer of " + std::to_string(len) + " bytes for " + std::to_string(flen) + " rows");
       if (len == 0 && !dry) {  // an empty array may carry no offsets at all: give it the single zero Arrow asks for
@@ -281,9 +317,22 @@ Status StreamReader::Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_
       }
     } else {
       AHC_RETURN_NOT_OK(next_buffer(&off, &len));
-      const int64_t need = fi.type->bit_width == 1 ? (flen + 7) / 8 : flen * w;
+      const int64_t need = storage->bit_width == 1 ? (flen + 7) / 8 : flen * w;
       if (len < need) return Invalid("field '" + fi.name + "': data buffer of " + std::to_string(len) + " bytes for " + std::to_string(flen) + " rows");
       d->buffers[1] = slice(off, len);
+    }
+    if (encoded && !dry) {
+      // on the device dictionary indices are int32 (arrowhip_compute.h); the wire type is kept for export
+      if (storage->id != Type::INT32 && flen > 0) {
+        BufferPtr idx32;
+        AHC_RETURN_NOT_OK(s_->Allocate(flen * 4, &idx32, /*zero_all=*/false));
+        AHC_RETURN_NOT_OK(s_->FromStatus(ah_cast_numeric(s_->ctx(), (int)storage->id, AH_INT32, d->buffers[1]->dptr, nullptr, 0, flen, 1, 1, idx32->dptr)));
+        d->buffers[1] = idx32;
+      }
+      d->type = GetDataType(Type::DICTIONARY);
+      d->dict_index_type = storage;
+      d->dict_value_type = fi.type;
+      d->dictionary = dicts_[fi.dict_id];
     }
     if (!dry) columns->push_back(d);
   }

@@ -10,11 +10,13 @@
 // Both the stream format and the file format ("ARROW1" magic … footer) are read; the footer's block index is not
 // needed for a sequential pass.
 // Scope: flat columns of the types the kernels take — Int8..Uint64, Float32/64, Bool, Utf8 / Binary and
-// their Large variants; little-endian; uncompressed; no dictionary batches.  Anything else is
+// their Large variants, plain or dictionary-encoded (DictionaryBatch messages; delta dictionaries excepted);
+// little-endian; uncompressed.  Anything else is
 // ErrNotImplemented with the field named.  The metadata is a FlatBuffer (format/Message.fbs,
 // Schema.fbs); it is read with the small bounds-checked accessor in ipc.cc — the bytes come from a
 // file or a socket and are not trusted.
 #pragma once
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -26,8 +28,10 @@ namespace ipc {
 
 struct FieldInfo {
   std::string name;
-  const DataType* type = nullptr;
+  const DataType* type = nullptr;        // the column's type; for a dictionary-encoded field the VALUE type
   bool nullable = true;
+  int64_t dict_id = -1;                  // ≥ 0: dictionary-encoded (Schema.fbs DictionaryEncoding.id)
+  const DataType* index_type = nullptr;  // … with these indices on the wire
 };
 
 class StreamReader {
@@ -42,6 +46,11 @@ class StreamReader {
 
  private:
   Status NextMessage(bool* have, const uint8_t** meta, int64_t* meta_len, const uint8_t** body, int64_t* body_len);
+  // one RecordBatch table (a record batch message, or the `data` of a dictionary batch) against its body
+  Status LoadColumns(const uint8_t* meta, int64_t meta_len, int64_t rb, const uint8_t* body, int64_t body_len,
+                     const std::vector<FieldInfo>& fields, bool as_values, std::vector<ArrayDataPtr>* columns, int64_t* rows);
+  std::map<int64_t, ArrayDataPtr> dicts_;   // dictionary id → values (dictutils.Memo)
+  std::map<int64_t, bool> seen_dict_;
   Session* s_ = nullptr;
   const uint8_t* p_ = nullptr;
   int64_t n_ = 0, pos_ = 0, uploaded_ = 0;

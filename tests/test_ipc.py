@@ -68,10 +68,26 @@ def test_inspect_file_format():
     assert [f[0] for f in fields] == schema.names and rows == [10, 0, 300]
 
 
+def test_inspect_dictionary_batches():
+    # DictionaryBatch messages (reader.go:167-200): the field reports as a dictionary, the batches keep their lengths;
+    # a replaced dictionary (same id, second non-delta batch) is accepted like the reference does
+    d1 = pa.DictionaryArray.from_arrays(pa.array([0, 1, None, 0], pa.int8()), pa.array(["x", "yy"]))
+    d2 = pa.DictionaryArray.from_arrays(pa.array([1, 0], pa.int8()), pa.array(["p", "q", "r"]))
+    schema = pa.schema([("k", d1.type), ("v", pa.int32())])
+    buf = make_stream([pa.record_batch([d1, pa.array([1, 2, 3, 4], pa.int32())], schema=schema),
+                       pa.record_batch([d2, pa.array([5, 6], pa.int32())], schema=schema)], schema)
+    fields, rows = ac.ipc_inspect(buf)
+    assert fields == [("k", "dictionary", True), ("v", "int32", True)] and rows == [4, 2]
+
+
 def test_inspect_rejects_what_it_does_not_read():
-    d = pa.array(["a", "b", "a"]).dictionary_encode()
-    with pytest.raises(ac.ErrNotImplemented, match="dictionary"):
-        ac.ipc_inspect(make_stream([pa.record_batch([d], names=["d"])], pa.schema([("d", d.type)])))
+    d1, d2 = pa.array(["a", "b", "a"]).dictionary_encode(), pa.array(["a", "b", "c"]).dictionary_encode()
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, pa.schema([("d", d1.type)]), options=pa.ipc.IpcWriteOptions(emit_dictionary_deltas=True)) as w:
+        w.write_batch(pa.record_batch([d1], names=["d"]))
+        w.write_batch(pa.record_batch([d2], names=["d"]))
+    with pytest.raises(ac.ErrNotImplemented, match="delta"):
+        ac.ipc_inspect(sink.getvalue())
     l = pa.array([[1, 2], [3]])
     with pytest.raises(ac.ErrNotImplemented, match="nested|flatbuf type"):
         ac.ipc_inspect(make_stream([pa.record_batch([l], names=["l"])], pa.schema([("l", l.type)])))
@@ -140,6 +156,31 @@ def test_read_ipc_round_trip(sess):
     assert out.equals(pc.add(batches[0].column(6), batches[0].column(6)))
     s = cols[names.index("c11_string")]
     assert sess.call_function("unique", [s]).equals(pc.unique(batches[0].column(11)))
+
+
+@pytest.mark.gpu
+def test_read_ipc_dictionary_columns(sess):
+    rng = np.random.default_rng(8)
+    n = 5000
+    words = pa.array(["w%d" % i for i in range(37)] + [None])
+    nums = pa.array(np.arange(100, 120), pa.int64())
+    for index_type in (pa.int8(), pa.uint16(), pa.int32(), pa.int64()):
+        k1 = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 38, n), mask=rng.random(n) < 0.1, type=index_type), words)
+        k2 = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 20, n), type=index_type), nums)
+        schema = pa.schema([("s", k1.type), ("x", pa.float64()), ("i", k2.type)])
+        b = pa.record_batch([k1, pa.array(rng.standard_normal(n)), k2], schema=schema)
+        got = list(sess.read_ipc(make_stream([b, b.slice(10, 100)], schema)))
+        assert [g[2] for g in got] == [n, 100]
+        for (names, cols, rows), exp in zip(got, (b, b.slice(10, 100))):
+            for c, e in zip(cols, exp.columns):
+                a = c.to_arrow()
+                assert a.type == e.type and a.equals(e), (index_type, a.type)
+        # the columns are ordinary dictionary arrays on the device
+        s_col = got[0][1][0]
+        sel = pa.array(rng.integers(0, n, 777), type=pa.int32())
+        assert sess.call_function("take", [s_col, sel]).equals(k1.take(sel))
+        import pyarrow.compute as pc
+        assert sess.call_function("unique", [s_col]).indices.equals(pc.unique(k1).indices)
 
 
 @pytest.mark.gpu
