@@ -648,24 +648,65 @@ Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const Da
   }
   d->length = total;
   d->null_count = nulls ? kUnknownNullCount : 0;
+  std::vector<ArrayDataPtr> unified;  // chunks re-indexed against one dictionary, when theirs differ
+  const std::vector<ArrayDataPtr>* src = &chunks;
   if (type->id == Type::DICTIONARY) {
-    // chunks of one dictionary array share their dictionary (what dictionary_encode and the selections above produce);
-    // differing dictionaries would need the unifier (array.NewDictionaryUnifier, arrow/array/dictionary.go) — not built
+    bool same = true;
     for (auto& c : chunks) {
       if (c->dictionary == chunks[0]->dictionary) continue;
       bool eq = false;
       if (c->dictionary && chunks[0]->dictionary) AHC_RETURN_NOT_OK(DeviceArrayEqual(s, *c->dictionary, *chunks[0]->dictionary, &eq));
-      if (!eq) return Status::Make(StatusCode::NotImplemented, "concatenating dictionary arrays with different dictionaries");
+      same = same && eq;
     }
-    d->dictionary = chunks[0]->dictionary;
+    ArrayDataPtr dict = chunks[0]->dictionary;
+    if (!same) {
+      // array.NewDictionaryUnifier + TransposeDictIndices (arrow/array/dictionary.go:1380-1500, concat.go:600-640), on the
+      // device: the dictionaries laid end to end and dictionary-encoded with nulls encoded ARE the unifier's memo table —
+      // ids = the transposition maps, its dictionary = the unified values in first-seen order; each chunk's indices are
+      // then gathered through its slice of the map
+      std::vector<ArrayDataPtr> dvals;
+      for (auto& c : chunks) {
+        if (!c->dictionary || c->dictionary->type->id != chunks[0]->dictionary->type->id)
+          return Status::Make(StatusCode::Invalid, "dictionary type different from unifier");  // dictionary.go:1416-1418
+        dvals.push_back(c->dictionary);
+      }
+      ArrayDataPtr all;
+      AHC_RETURN_NOT_OK(Concatenate(s, dvals, dvals[0]->type, &all));
+      ExecCtx ectx{GetFunctionRegistry(), s};
+      DictionaryEncodeOptions eo;
+      eo.NullEncoding = NullEncodingEncode;
+      Datum enc;
+      AHC_RETURN_NOT_OK(CallFunction(&ectx, "dictionary_encode", &eo, {Datum::Of(all)}, &enc));
+      dict = enc.array->dictionary;
+      auto map_all = std::make_shared<ArrayData>(*enc.array);
+      map_all->type = GetDataType(Type::INT32);
+      map_all->dictionary = nullptr;
+      TakeOptions no_check;
+      no_check.BoundsCheck = false;
+      int64_t o = 0;
+      for (auto& c : chunks) {
+        auto idx = std::make_shared<ArrayData>(*c);   // the chunk's indices as a plain int32 array
+        idx->type = GetDataType(Type::INT32);
+        idx->dictionary = nullptr;
+        Datum moved;
+        AHC_RETURN_NOT_OK(CallFunction(&ectx, "array_take", &no_check, {Datum::Of(SliceData(map_all, o, c->dictionary->length)), Datum::Of(idx)}, &moved));
+        auto nc = std::make_shared<ArrayData>(*moved.array);
+        nc->type = type;
+        unified.push_back(nc);
+        o += c->dictionary->length;
+      }
+      src = &unified;
+    }
+    d->dictionary = dict;
     d->dict_value_type = chunks[0]->dict_value_type;
     d->dict_index_type = chunks[0]->dict_index_type;
   }
+  const std::vector<ArrayDataPtr>& chunks_ = *src;
   auto bitmap = [&](int which, BufferPtr* dst) -> Status {  // validity (which = 0) or boolean data (which = 1), bit by bit offset
     AHC_RETURN_NOT_OK(s->AllocateBitmap(total, dst));
     AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), (*dst)->dptr, 0, (size_t)((total + 7) / 8))));
     int64_t pos = 0;
-    for (auto& c : chunks) {
+    for (auto& c : chunks_) {
       if (c->length == 0) continue;
       if (c->buffers[which] && !(which == 0 && c->null_count == 0))
         AHC_RETURN_NOT_OK(s->FromStatus(ah_copy_bitmap(s->ctx(), (const uint8_t*)c->buffers[which]->dptr, c->offset, c->length, (uint8_t*)(*dst)->dptr, pos, 0)));
@@ -681,10 +722,10 @@ Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const Da
     AHC_RETURN_NOT_OK(bitmap(1, &d->buffers[1]));
   } else if (IsBaseBinary(type->id)) {
     // value ranges: first and last offset of every chunk (concat.go:182-200 / 300-322 concatOffsets)
-    std::vector<int64_t> first(chunks.size(), 0), last(chunks.size(), 0);
-    std::vector<uint8_t> host(chunks.size() * 16, 0);
-    for (size_t i = 0; i < chunks.size(); i++) {
-      auto& c = chunks[i];
+    std::vector<int64_t> first(chunks_.size(), 0), last(chunks_.size(), 0);
+    std::vector<uint8_t> host(chunks_.size() * 16, 0);
+    for (size_t i = 0; i < chunks_.size(); i++) {
+      auto& c = chunks_[i];
       if (c->length == 0 || !c->buffers[1]) continue;
       const uint8_t* o = (const uint8_t*)c->buffers[1]->dptr;
       AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), &host[i * 16], o + c->offset * w, (size_t)w)));
@@ -692,7 +733,7 @@ Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const Da
     }
     AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
     int64_t bytes = 0;
-    for (size_t i = 0; i < chunks.size(); i++) {
+    for (size_t i = 0; i < chunks_.size(); i++) {
       if (w == 4) { int32_t a, b; memcpy(&a, &host[i * 16], 4); memcpy(&b, &host[i * 16 + 8], 4); first[i] = a; last[i] = b; }
       else { memcpy(&first[i], &host[i * 16], 8); memcpy(&last[i], &host[i * 16 + 8], 8); }
       bytes += last[i] - first[i];
@@ -702,8 +743,8 @@ Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const Da
     AHC_RETURN_NOT_OK(s->Allocate(bytes, &d->buffers[2]));
     AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), d->buffers[1]->dptr, 0, (size_t)w)));
     int64_t pos = 0, base = 0;
-    for (size_t i = 0; i < chunks.size(); i++) {
-      auto& c = chunks[i];
+    for (size_t i = 0; i < chunks_.size(); i++) {
+      auto& c = chunks_[i];
       if (c->length == 0) continue;
       const int64_t delta = base - first[i];  // out_offsets[pos + 1 + j] = in_offsets[offset + 1 + j] + delta
       const int32_t delta32 = (int32_t)delta;
@@ -720,7 +761,7 @@ Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const Da
   } else {
     AHC_RETURN_NOT_OK(s->Allocate(total * w, &d->buffers[1]));
     int64_t pos = 0;
-    for (auto& c : chunks) {
+    for (auto& c : chunks_) {
       if (c->length == 0) continue;
       AHC_RETURN_NOT_OK(s->FromStatus(ah_copy_async(s->ctx(), (uint8_t*)d->buffers[1]->dptr + pos * w, (const uint8_t*)c->buffers[1]->dptr + c->offset * w,
                                                     (size_t)(c->length * w))));

@@ -178,3 +178,38 @@ def test_record_batch_filter_take_sort(sess):
     assert got.equals(exp)
     with pytest.raises(ac.ErrNotImplemented, match="record batch"):
         sess.call_function("add", [rb, rb])
+
+
+def test_chunked_dictionary_arrays_with_different_dictionaries(sess):
+    """array.Concatenate over dictionary chunks unifies the dictionaries and transposes the indices
+    (arrow/array/concat.go:600-640, dictionary.go:1380-1500) — here on the device; values against Arrow C++"""
+    rng = np.random.default_rng(9)
+    d1 = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 4, 900), mask=rng.random(900) < 0.1, type=pa.int32()), pa.array(["a", "b", "c", "d"]))
+    d2 = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 5, 1100), mask=rng.random(1100) < 0.1, type=pa.int32()), pa.array(["c", "x", None, "a", "y"]))
+    d3 = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 2, 300), type=pa.int32()), pa.array(["y", "a"]))
+    c = pa.chunked_array([d1, d2, d3])
+    ref = pa.concat_arrays([x.cast(pa.string()) for x in (d1, d2, d3)])   # the logical column (Arrow C++ cannot unify dictionaries holding nulls)
+    logical = lambda arr: (arr if isinstance(arr, pa.Array) else arr.combine_chunks()).cast(pa.string()).to_pylist()
+    sel = pa.array(rng.integers(0, len(c), 500), mask=rng.random(500) < 0.1, type=pa.int64())
+    got = sess.call_function("take", [c, sel])
+    assert logical(got) == logical(pc.take(ref, sel))
+    # the unified dictionary is the unifier's: values in first-seen order over the chunk dictionaries, null included
+    assert got.chunk(0).dictionary.to_pylist() == ["a", "b", "c", "d", "x", None, "y"]
+    mask = pa.array(rng.random(len(c)) < 0.4)
+    assert logical(sess.call_function("filter", [c, mask])) == logical(pc.filter(ref, mask))
+    # unique hashes the (transposed) INDICES (dictionaryHashState, vector_hash.go:505-576): a null index and an index of
+    # the dictionary's null entry are two different results
+    uq = sess.call_function("unique", [c])
+    unified = ["a", "b", "c", "d", "x", None, "y"]
+    moved = []
+    for ch in (d1, d2, d3):
+        vals = ch.dictionary.to_pylist()
+        moved += [None if i is None else unified.index(vals[i]) for i in ch.indices.to_pylist()]
+    first_seen = list(dict.fromkeys(moved))
+    assert uq.indices.to_pylist() == first_seen and uq.dictionary.to_pylist() == unified
+    # numeric values
+    n1 = pa.DictionaryArray.from_arrays(pa.array([0, 1, 1, None], pa.int32()), pa.array([10, 20], pa.int64()))
+    n2 = pa.DictionaryArray.from_arrays(pa.array([1, 0, 2], pa.int32()), pa.array([20, 30, 10], pa.int64()))
+    got = sess.call_function("take", [pa.chunked_array([n1, n2]), pa.array([6, 0, 3, 4], pa.int32())])
+    assert got.combine_chunks().cast(pa.int64()).to_pylist() == [10, 10, None, 30]
+    assert got.chunk(0).dictionary.to_pylist() == [10, 20, 30]
