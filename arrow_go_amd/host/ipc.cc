@@ -218,7 +218,8 @@ Status StreamReader::Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_
     const int64_t id = fb.scalar<int64_t>(hdr, 0, 0);
     const int64_t data = fb.indirect(hdr, 1);
     if (fb.bad || !data) return Invalid("invalid message metadata");
-    if (fb.scalar<uint8_t>(hdr, 2, 0)) return NotImpl("delta dictionary batch");
+    const bool is_delta = fb.scalar<uint8_t>(hdr, 2, 0) != 0;
+    if (is_delta && !seen_dict_.count(id)) return Invalid("delta dictionary batch for id " + std::to_string(id) + " without a dictionary to extend");
     const FieldInfo* owner = nullptr;
     for (auto& f : fields_) if (f.dict_id == id) owner = &f;
     if (!owner) return Invalid("dictionary batch for unknown dictionary id " + std::to_string(id));
@@ -226,7 +227,15 @@ Status StreamReader::Next(bool* have, std::vector<ArrayDataPtr>* columns, int64_
     std::vector<ArrayDataPtr> vals;
     int64_t nvals = 0;
     AHC_RETURN_NOT_OK(LoadColumns(meta, mlen, data, body, blen, one, true, columns ? &vals : nullptr, &nvals));
-    if (columns) dicts_[id] = vals[0];
+    if (columns) {
+      if (is_delta) {  // readDictionary (reader.go:186-196): the new values are appended to the existing dictionary
+        ArrayDataPtr merged;
+        AHC_RETURN_NOT_OK(compute::Concatenate(s_, {dicts_[id], vals[0]}, owner->type, &merged));
+        dicts_[id] = merged;
+      } else {
+        dicts_[id] = vals[0];
+      }
+    }
     seen_dict_[id] = true;
   }
 }

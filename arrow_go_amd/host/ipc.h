@@ -10,7 +10,7 @@
 // Both the stream format and the file format ("ARROW1" magic … footer) are read; the footer's block index is not
 // needed for a sequential pass.
 // Scope: flat columns of the types the kernels take — Int8..Uint64, Float32/64, Bool, Utf8 / Binary and
-// their Large variants, plain or dictionary-encoded (DictionaryBatch messages; delta dictionaries excepted);
+// their Large variants, plain or dictionary-encoded (DictionaryBatch messages, replacement and delta);
 // little-endian; uncompressed.  Anything else is
 // ErrNotImplemented with the field named.  The metadata is a FlatBuffer (format/Message.fbs,
 // Schema.fbs); it is read with the small bounds-checked accessor in ipc.cc — the bytes come from a

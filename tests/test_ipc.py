@@ -81,13 +81,6 @@ def test_inspect_dictionary_batches():
 
 
 def test_inspect_rejects_what_it_does_not_read():
-    d1, d2 = pa.array(["a", "b", "a"]).dictionary_encode(), pa.array(["a", "b", "c"]).dictionary_encode()
-    sink = pa.BufferOutputStream()
-    with pa.ipc.new_stream(sink, pa.schema([("d", d1.type)]), options=pa.ipc.IpcWriteOptions(emit_dictionary_deltas=True)) as w:
-        w.write_batch(pa.record_batch([d1], names=["d"]))
-        w.write_batch(pa.record_batch([d2], names=["d"]))
-    with pytest.raises(ac.ErrNotImplemented, match="delta"):
-        ac.ipc_inspect(sink.getvalue())
     l = pa.array([[1, 2], [3]])
     with pytest.raises(ac.ErrNotImplemented, match="nested|flatbuf type"):
         ac.ipc_inspect(make_stream([pa.record_batch([l], names=["l"])], pa.schema([("l", l.type)])))
@@ -181,6 +174,20 @@ def test_read_ipc_dictionary_columns(sess):
         assert sess.call_function("take", [s_col, sel]).equals(k1.take(sel))
         import pyarrow.compute as pc
         assert sess.call_function("unique", [s_col]).indices.equals(pc.unique(k1).indices)
+
+
+@pytest.mark.gpu
+def test_read_ipc_delta_dictionaries(sess):
+    # reader.go:186-196: a delta batch appends to the dictionary the earlier batches were read with
+    d1, d2, d3 = (pa.array(v).dictionary_encode() for v in (["a", "b", "a"], ["a", "b", "c", "c"], ["a", "b", "c", "d", None]))
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, pa.schema([("d", d1.type)]), options=pa.ipc.IpcWriteOptions(emit_dictionary_deltas=True)) as w:
+        for d in (d1, d2, d3):
+            w.write_batch(pa.record_batch([d], names=["d"]))
+    assert ac.ipc_inspect(sink.getvalue())[1] == [3, 4, 5]
+    got = [cols[0].to_arrow() for _, cols, _ in sess.read_ipc(sink.getvalue())]
+    assert [g.to_pylist() for g in got] == [["a", "b", "a"], ["a", "b", "c", "c"], ["a", "b", "c", "d", None]]
+    assert got[1].dictionary.to_pylist() == ["a", "b", "c"] and got[2].dictionary.to_pylist() == ["a", "b", "c", "d"]
 
 
 @pytest.mark.gpu
