@@ -58,6 +58,9 @@ lib.ahc_ipc_close.restype = None
 lib.ahc_ipc_num_fields.argtypes = [_vp]
 lib.ahc_ipc_field.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 lib.ahc_ipc_next.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int64)]
+lib.ahc_datum_logical.argtypes = [_vp]
+lib.ahc_datum_logical.restype = C.c_char_p
+lib.ahc_scalar_set_logical.argtypes = [_vp, _vp, C.c_char_p]
 lib.ahc_ipc_bytes_uploaded.argtypes = [_vp]
 lib.ahc_ipc_bytes_uploaded.restype = C.c_int64
 lib.ahc_ipc_inspect.argtypes = [_vp, C.c_int64, C.c_char_p, C.c_int64]
@@ -163,6 +166,43 @@ _TYPE_IDS = {"dictionary": 36, "string": 13, "binary": 14, "large_string": 34, "
 _PACK = {1: "<?", 2: "<B", 3: "<b", 4: "<H", 5: "<h", 6: "<I", 7: "<i", 8: "<Q", 9: "<q", 11: "<f", 12: "<d"}
 
 
+_UNITS = {"s": "s", "m": "ms", "u": "us", "n": "ns"}
+
+
+def _temporal_format(t):
+    """pyarrow temporal type → its Arrow C Data format ("tsu:UTC", "tdD", "ttm", "tDn"), None for any other type"""
+    import pyarrow as pa
+    short = {v: k for k, v in _UNITS.items()}
+    if pa.types.is_timestamp(t):
+        return "ts%s:%s" % (short[t.unit], t.tz or "")
+    if pa.types.is_duration(t):
+        return "tD" + short[t.unit]
+    if pa.types.is_date32(t):
+        return "tdD"
+    if pa.types.is_date64(t):
+        return "tdm"
+    if pa.types.is_time32(t) or pa.types.is_time64(t):
+        return "tt" + short[t.unit]
+    return None
+
+
+def _temporal_type(fmt):
+    """the inverse: C Data format → pyarrow type"""
+    import pyarrow as pa
+    if fmt == "tdD":
+        return pa.date32()
+    if fmt == "tdm":
+        return pa.date64()
+    unit = _UNITS[fmt[2]]
+    if fmt[1] == "t":
+        return pa.time32(unit) if unit in ("s", "ms") else pa.time64(unit)
+    if fmt[1] == "D":
+        return pa.duration(unit)
+    if fmt[1] == "s":
+        return pa.timestamp(unit, tz=fmt[4:] or None)
+    raise ErrNotImplemented(f"temporal format {fmt!r}")
+
+
 def _as_bytes_ptr(buf):
     """(keep-alive object, address, length) of a bytes-like / pyarrow.Buffer without copying when possible"""
     mv = memoryview(buf)
@@ -187,8 +227,9 @@ def ipc_inspect(buf):
     fields, rows = text.split("|")
     fl = []
     for f in filter(None, fields.split(",")):
-        nm, tid, nullable = f.rsplit(":", 2)
-        fl.append((bytes.fromhex(nm).decode("utf-8", "replace"), names[int(tid)], nullable == "1"))
+        nm, tid, nullable, logical = f.rsplit(":", 3)
+        tname = str(_temporal_type(bytes.fromhex(logical).decode())) if logical and int(tid) != 36 else names[int(tid)]
+        fl.append((bytes.fromhex(nm).decode("utf-8", "replace"), tname, nullable == "1"))
     return fl, [int(r) for r in rows.split(",") if r]
 
 
@@ -237,6 +278,8 @@ class Session:
             tname = str(arr.type)
             if pa.types.is_dictionary(arr.type):
                 tid = 36  # arrow.DICTIONARY
+            elif _temporal_format(arr.type):  # stored as integers of the type's width, labelled chunk by chunk
+                tid = _TYPE_IDS["int32" if arr.type.bit_width == 32 else "int64"]
             elif tname in _TYPE_IDS:
                 tid = _TYPE_IDS[tname]
             else:
@@ -259,14 +302,17 @@ class Session:
 
     def _scalar(self, sc):
         import pyarrow as pa
-        tid = _TYPE_IDS[str(sc.type)]
+        logical = _temporal_format(sc.type)
+        tid = _TYPE_IDS[("int32" if sc.type.bit_width == 32 else "int64") if logical else str(sc.type)]
         valid = sc.is_valid
         buf = (C.c_uint8 * 8)()
         if valid:
-            raw = struct.pack(_PACK[tid], sc.as_py())
+            raw = struct.pack(_PACK[tid], sc.value if logical else sc.as_py())
             C.memmove(buf, raw, len(raw))
         d = _vp()
         self._check(lib.ahc_scalar(self.h, tid, int(valid), buf, C.byref(d)))
+        if logical:
+            self._check(lib.ahc_scalar_set_logical(self.h, d, logical.encode()))
         return d
 
     def import_device(self, type_name: str, length: int, data_ptr, validity_ptr=None, null_count: int = 0, offset: int = 0,
@@ -336,10 +382,12 @@ class Session:
         if kind.value == 1:  # scalar
             name = {v: k for k, v in _TYPE_IDS.items()}[tid.value]
             typ = {"float": pa.float32(), "double": pa.float64(), "bool": pa.bool_()}.get(name) or getattr(pa, name)()
+            logical = lib.ahc_datum_logical(d).decode()
             if not sv.value:
-                return pa.scalar(None, type=typ)
+                return pa.scalar(None, type=_temporal_type(logical) if logical else typ)
             fmt = _PACK[tid.value]
-            return pa.scalar(struct.unpack(fmt, bytes(val)[:struct.calcsize(fmt)])[0], type=typ)
+            plain = pa.scalar(struct.unpack(fmt, bytes(val)[:struct.calcsize(fmt)])[0], type=typ)
+            return plain.cast(_temporal_type(logical)) if logical else plain
         if kind.value == 4:  # record batch
             cols, names = [], []
             for i in range(lib.ahc_record_num_columns(d)):

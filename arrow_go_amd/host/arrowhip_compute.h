@@ -53,6 +53,8 @@ bool IsInteger(Type id);
 bool IsSignedInteger(Type id);
 bool IsFloating(Type id);
 bool IsNumeric(Type id);
+// Temporal types by their C Data format: the integer type that stores them (nullptr: not a temporal format this layer takes)
+const DataType* TemporalStorage(const std::string& format);
 bool IsBaseBinary(Type id);  // String, Binary, LargeString, LargeBinary: buffers = [validity, offsets, data]
 
 // ---- errors (arrow/errors.go) ---------------------------------------------------------
@@ -117,6 +119,11 @@ struct ArrayData {
   std::shared_ptr<ArrayData> dictionary;   // DICTIONARY arrays: buffers = the indices, `dictionary` = the values
   const DataType* dict_value_type = nullptr;
   const DataType* dict_index_type = nullptr;  // nullptr = int32 (what dictionary_encode produces)
+  // Temporal columns (arrow.TimestampType / Date32 / Date64 / Time32 / Time64 / DurationType, datatype_fixedwidth.go):
+  // `type` is the PHYSICAL integer type the kernels run on, `logical` the Arrow C Data format of the
+  // temporal type ("tsu:UTC", "tdD", "ttm", "tDn" …; empty = a plain column).  CallFunction checks the
+  // reference's type rules on it, runs the integer kernel, and labels the result (core.cc, "temporal front end").
+  std::string logical;
 };
 using ArrayDataPtr = std::shared_ptr<ArrayData>;
 
@@ -124,6 +131,7 @@ struct Scalar {
   const DataType* type = nullptr;
   bool valid = false;
   alignas(8) uint8_t value[8] = {0};  // little-endian payload of width type->bit_width (bool: value[0])
+  std::string logical;                // as ArrayData::logical
 };
 using ScalarPtr = std::shared_ptr<Scalar>;
 
@@ -220,6 +228,7 @@ struct DictionaryEncodeOptions : FunctionOptions { NullEncodingBehavior NullEnco
 // kernels.CastOptions (kernels/cast.go:27-35); NewCastOptions(dt, safe) / SafeCastOptions / UnsafeCastOptions (compute/cast.go)
 struct CastOptions : FunctionOptions {
   const DataType* ToType = nullptr;
+  std::string ToLogical;  // a temporal target by its C Data format ("tsu:", "tdD" …): see core.cc, temporal front end
   bool AllowIntOverflow = false, AllowTimeTruncate = false, AllowTimeOverflow = false, AllowDecimalTruncate = false,
        AllowFloatTruncate = false, AllowInvalidUtf8 = false;
   const char* TypeName() const override { return "CastOptions"; }

@@ -94,6 +94,7 @@ AHC_EXPORT int ahc_function_num_kernels(const char* name) {
 }
 
 static const DataType* TypeFromFormat(const char* f) {
+  if (f && f[0] == 't') return TemporalStorage(f);  // timestamps, dates, times, durations: integers with a label
   if (!f || !f[0] || f[1]) return nullptr;
   for (Type bt : {Type::STRING, Type::BINARY, Type::LARGE_STRING, Type::LARGE_BINARY})
     if (GetDataType(bt)->format[0] == f[0]) return GetDataType(bt);
@@ -111,6 +112,7 @@ static Status ImportOne(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, Ar
   Status st;
   auto d = std::make_shared<ArrayData>();
   d->type = t;
+  if (schema->format[0] == 't') d->logical = schema->format;
   d->length = arr->length;
   d->null_count = arr->null_count;
   d->offset = arr->offset;
@@ -151,6 +153,7 @@ static Status ImportOne(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, Ar
     }
     auto dict = std::make_shared<ArrayData>(*d);
     dict->type = GetDataType(Type::DICTIONARY);
+    dict->logical.clear();
     dict->dict_index_type = t;
     dict->dict_value_type = values->type;
     dict->dictionary = values;
@@ -179,6 +182,24 @@ AHC_EXPORT int ahc_scalar(ahc_session* s, int type_id, int valid, const void* va
   sc->valid = valid != 0;
   if (value8) memcpy(sc->value, value8, 8);
   *out = new ahc_datum{Datum::Of(sc)};
+  return 0;
+}
+
+// the temporal label of a datum ("" for a plain one), and setting it on a scalar built with ahc_scalar
+AHC_EXPORT const char* ahc_datum_logical(ahc_datum* d) {
+  static thread_local std::string keep;
+  keep.clear();
+  if (d->d.kind == DatumKind::Array) keep = d->d.array->logical;
+  if (d->d.kind == DatumKind::Scalar) keep = d->d.scalar->logical;
+  if (d->d.kind == DatumKind::Chunked && !d->d.chunks.empty()) keep = d->d.chunks[0]->logical;
+  return keep.c_str();
+}
+AHC_EXPORT int ahc_scalar_set_logical(ahc_session* s, ahc_datum* d, const char* format) {
+  if (d->d.kind != DatumKind::Scalar) return Fail(s, Status::Make(StatusCode::Invalid, "not a scalar datum"));
+  const DataType* storage = TemporalStorage(format ? format : "");
+  if (!storage || storage->id != d->d.scalar->type->id)
+    return Fail(s, Status::Make(StatusCode::TypeError, std::string("'") + (format ? format : "") + "' is not a temporal type stored as " + d->d.scalar->type->name));
+  d->d.scalar->logical = format;
   return 0;
 }
 
@@ -260,7 +281,8 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
         for (auto& tn : kTypeNames) if (v == tn.name) p->cast.ToType = GetDataType(tn.id);
         p->pick = &p->cast;
       }
-      if (k == "safe" && v == "0") { const DataType* t = p->cast.ToType; p->cast = compute::CastOptions::Unsafe(t); p->pick = &p->cast; }
+      if (k == "to_logical") { p->cast.ToLogical = v; p->pick = &p->cast; }
+      if (k == "safe" && v == "0") { const DataType* t = p->cast.ToType; std::string l = p->cast.ToLogical; p->cast = compute::CastOptions::Unsafe(t); p->cast.ToLogical = l; p->pick = &p->cast; }
       if (k == "allow_int_overflow") { p->cast.AllowIntOverflow = v != "0"; p->pick = &p->cast; }
       if (k == "allow_float_truncate") { p->cast.AllowFloatTruncate = v != "0"; p->pick = &p->cast; }
       if (k == "value_set" && v.size() > 1 && v[0] == '@') {
@@ -332,6 +354,7 @@ AHC_EXPORT int ahc_math_sum(ahc_session* s, ahc_datum* d, double* f64, int64_t* 
   if (d->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "math.Sum needs an array"));
   const ArrayData& a = *d->d.array;
   Status st;
+  if (!a.logical.empty()) return Fail(s, Status::Make(StatusCode::TypeError, "arrow/math has Float64, Int64 and Uint64 Sum only, not " + a.logical));
   switch (a.type->id) {
     case Type::FLOAT64: st = math::Float64.Sum(s->session.get(), a, f64); break;
     case Type::INT64: st = math::Int64.Sum(s->session.get(), a, i64); break;
@@ -375,6 +398,8 @@ static void ReleaseArray(ArrowArray* a) {
 }
 static void ReleaseSchema(ArrowSchema* sc) {
   if (sc->dictionary) { if (sc->dictionary->release) sc->dictionary->release(sc->dictionary); free(sc->dictionary); }
+  free(sc->private_data);
+  sc->private_data = nullptr;
   sc->release = nullptr;
 }
 
@@ -414,6 +439,11 @@ static Status ExportOne(Session* ss, const ArrayData& a, const DataType* t, Arro
   arr->release = ReleaseArray;
   arr->private_data = p;
   schema->format = t->format;
+  schema->private_data = nullptr;
+  if (!a.logical.empty()) {  // the temporal type the column came in as; the copy lives until the schema is released
+    schema->private_data = strdup(a.logical.c_str());
+    schema->format = (const char*)schema->private_data;
+  }
   schema->name = "";
   schema->flags = 2;  // ARROW_FLAG_NULLABLE
   schema->release = ReleaseSchema;
@@ -493,6 +523,7 @@ AHC_EXPORT int ahc_import_device(ahc_session* s, ArrowDeviceArray* darr, ArrowSc
   const ArrowArray& a = holder->arr;
   auto d = std::make_shared<ArrayData>();
   d->type = t;
+  if (schema->format[0] == 't') d->logical = schema->format;
   d->length = a.length;
   d->null_count = a.null_count;
   d->offset = a.offset;
@@ -557,6 +588,11 @@ AHC_EXPORT int ahc_export_device(ahc_session* s, ahc_datum* d, ArrowDeviceArray*
   out->device_type = ARROW_DEVICE_ROCM;
   out->sync_event = nullptr;
   schema->format = a->type->format;
+  schema->private_data = nullptr;
+  if (!a->logical.empty()) {
+    schema->private_data = strdup(a->logical.c_str());
+    schema->format = (const char*)schema->private_data;
+  }
   schema->name = "";
   schema->flags = 2;  // ARROW_FLAG_NULLABLE
   schema->release = ReleaseSchema;
@@ -646,6 +682,8 @@ AHC_EXPORT int ahc_chunked_from_arrays(ahc_session* s, int type_id, int n, ahc_d
     if (arrays[i]->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "chunks must be arrays"));
     if (arrays[i]->d.array->type->id != t->id)
       return Fail(s, Status::Make(StatusCode::Invalid, std::string("arrow/array: mismatch data type ") + arrays[i]->d.array->type->name + " vs " + t->name));  // arrow/table.go NewChunked
+    if (!chunks.empty() && arrays[i]->d.array->logical != chunks[0]->logical)
+      return Fail(s, Status::Make(StatusCode::Invalid, "arrow/array: mismatch data type " + arrays[i]->d.array->logical + " vs " + chunks[0]->logical));
     chunks.push_back(arrays[i]->d.array);
   }
   *out = new ahc_datum{Datum::OfChunks(t, std::move(chunks))};
@@ -739,6 +777,9 @@ AHC_EXPORT int ahc_ipc_inspect(const uint8_t* bytes, int64_t len, char* out, int
       std::string hex;  // names are arbitrary bytes: hex keeps the separators unambiguous
       for (unsigned char ch : f.name) { char b[3]; snprintf(b, sizeof b, "%02x", ch); hex += b; }
       text += (i ? "," : "") + hex + ":" + std::to_string(f.dict_id >= 0 ? (int)Type::DICTIONARY : (int)f.type->id) + ":" + (f.nullable ? "1" : "0");
+      std::string lhex;  // the temporal type of the column (or of the dictionary's values), "" for a plain one
+      for (unsigned char ch : f.logical) { char b[3]; snprintf(b, sizeof b, "%02x", ch); lhex += b; }
+      text += ":" + lhex;
     }
     text += "|";
     bool have = true, first = true;

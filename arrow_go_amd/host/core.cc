@@ -23,6 +23,17 @@ static const DataType kDictType = {Type::DICTIONARY, 32, "dictionary", "i"};
 static const DataType kBinaryTypes[] = {{Type::STRING, 32, "utf8", "u"}, {Type::BINARY, 32, "binary", "z"},
                                         {Type::LARGE_STRING, 64, "large_utf8", "U"}, {Type::LARGE_BINARY, 64, "large_binary", "Z"}};
 
+const DataType* TemporalStorage(const std::string& f) {
+  if (f.size() < 3 || f[0] != 't') return nullptr;
+  auto unit = [&](char c) { return c == 's' || c == 'm' || c == 'u' || c == 'n'; };
+  if (f == "tdD") return GetDataType(Type::INT32);                                 // Date32: days
+  if (f == "tdm") return GetDataType(Type::INT64);                                 // Date64: milliseconds
+  if (f == "tts" || f == "ttm") return GetDataType(Type::INT32);                   // Time32
+  if (f == "ttu" || f == "ttn") return GetDataType(Type::INT64);                   // Time64
+  if (f[1] == 'D' && f.size() == 3 && unit(f[2])) return GetDataType(Type::INT64);  // Duration
+  if (f[1] == 's' && f.size() >= 4 && unit(f[2]) && f[3] == ':') return GetDataType(Type::INT64);  // Timestamp, "tsu:<tz>"
+  return nullptr;
+}
 bool IsBaseBinary(Type id) { return id == Type::STRING || id == Type::BINARY || id == Type::LARGE_STRING || id == Type::LARGE_BINARY; }
 
 const DataType* GetDataType(Type id) {
@@ -639,9 +650,11 @@ Status Concatenate(Session* s, const std::vector<ArrayDataPtr>& chunks, const Da
   if (chunks.size() == 1) { *out = chunks[0]; return Status::OK(); }
   auto d = std::make_shared<ArrayData>();
   d->type = type;
+  d->logical = chunks.empty() ? std::string() : chunks[0]->logical;
   int64_t total = 0;
   bool nulls = false;
   for (auto& c : chunks) {
+    if (c->logical != d->logical) return Status::Make(StatusCode::Invalid, "arrays to be concatenated must be identically typed, but " + d->logical + " and " + c->logical + " were encountered.");
     if (c->type->id != type->id) return Status::Make(StatusCode::Invalid, "arrays to be concatenated must be identically typed, but " + std::string(type->name) + " and " + c->type->name + " were encountered.");  // concat.go:53-56
     total += c->length;
     nulls = nulls || (c->buffers[0] && c->null_count != 0);
@@ -880,10 +893,208 @@ Status ExecuteChunked(ExecCtx* ctx, Function* fn, const FunctionOptions* opts, c
 
 }  // namespace
 
+// ---- temporal front end -------------------------------------------------------------------------------------
+// Timestamp / Date / Time / Duration columns are integers with a label (ArrayData::logical).  The reference registers
+// the SAME integer kernels for them under temporal input matchers (selection: vector_selection.go:1845-1870 "any
+// fixed width"; hashing: vector_hash.go:545-560 by physical type; compare: scalar_comparisons.go:640-690; add /
+// subtract: arithmetic.go:630-770), so the work here is the type rule, not a kernel: check the labels the way those
+// matchers would, run the call on the bare integers, label the result.  What the reference reaches through implicit
+// unit casts (commonTemporalResolution, arithmetic.go:130-131) is refused with the two types named — cast first.
+namespace {
+
+struct TemporalType { char kind = 0, unit = 0; bool zoned = false; };  // kind: 's' timestamp, 'D' duration, 'd' date, 't' time
+TemporalType ParseTemporal(const std::string& f) {
+  TemporalType t;
+  if (f.empty()) return t;
+  t.kind = f[1];
+  t.unit = f[2];
+  t.zoned = t.kind == 's' && f.size() > 4;
+  return t;
+}
+std::string DatumLogical(const Datum& d, Status* st) {
+  switch (d.kind) {
+    case DatumKind::Array: return d.array->logical;
+    case DatumKind::Scalar: return d.scalar->logical;
+    case DatumKind::Chunked: {
+      std::string l = d.chunks.empty() ? std::string() : d.chunks[0]->logical;
+      for (auto& c : d.chunks)
+        if (c->logical != l) *st = Status::Make(StatusCode::Invalid, "chunks of one column must be identically typed, but " + l + " and " + c->logical + " were encountered");
+      return l;
+    }
+    default: return std::string();
+  }
+}
+Datum WithLogical(const Datum& d, const std::string& l) {  // a relabelled view; buffers are shared
+  Datum r = d;
+  if (d.kind == DatumKind::Array) { r.array = std::make_shared<ArrayData>(*d.array); r.array->logical = l; }
+  if (d.kind == DatumKind::Scalar) { r.scalar = std::make_shared<Scalar>(*d.scalar); r.scalar->logical = l; }
+  if (d.kind == DatumKind::Chunked)
+    for (auto& c : r.chunks) { c = std::make_shared<ArrayData>(*c); c->logical = l; }
+  return r;
+}
+// equal types for the temporal matchers: identical, or two timestamps of one unit that both carry a zone
+// (both are instants on the UTC line; a zoned and a naive timestamp do not compare — arrow.TypeEqual + exec.TimestampTypeUnit)
+bool SameTemporal(const std::string& a, const std::string& b) {
+  if (a == b) return true;
+  TemporalType x = ParseTemporal(a), y = ParseTemporal(b);
+  return x.kind == 's' && y.kind == 's' && x.unit == y.unit && x.zoned && y.zoned;
+}
+std::string Describe(const std::string& l, const Datum& d) { return l.empty() ? std::string(d.type() ? d.type()->name : "?") : l; }
+
+enum class TemporalRule { Preserve, Plain, Same, Add, Sub, Cast };
+const std::map<std::string, TemporalRule>& TemporalRules() {
+  static const std::map<std::string, TemporalRule> r = {
+      {"take", TemporalRule::Preserve}, {"array_take", TemporalRule::Preserve}, {"filter", TemporalRule::Preserve},
+      {"array_filter", TemporalRule::Preserve}, {"unique", TemporalRule::Preserve}, {"sort", TemporalRule::Preserve},
+      {"dictionary_encode", TemporalRule::Preserve},
+      {"is_null", TemporalRule::Plain}, {"is_not_null", TemporalRule::Plain}, {"sort_indices", TemporalRule::Plain},
+      {"equal", TemporalRule::Same}, {"not_equal", TemporalRule::Same}, {"greater", TemporalRule::Same}, {"greater_equal", TemporalRule::Same},
+      {"less", TemporalRule::Same}, {"less_equal", TemporalRule::Same}, {"is_in", TemporalRule::Same},
+      {"add", TemporalRule::Add}, {"add_unchecked", TemporalRule::Add},
+      {"subtract", TemporalRule::Sub}, {"subtract_unchecked", TemporalRule::Sub},
+      {"cast", TemporalRule::Cast}};
+  return r;
+}
+
+Status CallTemporal(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args,
+                    const std::vector<std::string>& lg, Datum* out) {
+  auto refuse = [&]() {
+    std::string types;
+    for (size_t i = 0; i < args.size(); i++) types += (i ? ", " : "") + Describe(lg[i], args[i]);
+    return Status::Make(StatusCode::NotImplemented, "function '" + name + "' has no kernel matching input types (" + types + ")");
+  };
+  auto it = TemporalRules().find(name);
+  if (it == TemporalRules().end()) return refuse();
+  std::vector<Datum> bare;
+  for (size_t i = 0; i < args.size(); i++) bare.push_back(lg[i].empty() ? args[i] : WithLogical(args[i], ""));
+  std::string out_logical;
+  const bool checked = name.find("_unchecked") == std::string::npos;
+  switch (it->second) {
+    case TemporalRule::Preserve:  // the values move, their meaning does not; indices / masks are plain columns
+      for (size_t i = 1; i < args.size(); i++) if (!lg[i].empty()) return refuse();
+      out_logical = lg[0];
+      break;
+    case TemporalRule::Plain:
+      for (size_t i = 1; i < args.size(); i++) if (!lg[i].empty()) return refuse();
+      break;
+    case TemporalRule::Same: {
+      for (size_t i = 1; i < args.size(); i++) if (!SameTemporal(lg[0], lg[i])) return refuse();
+      if (name == "is_in") {
+        auto* so = dynamic_cast<const SetOptions*>(opts);
+        if (!so || !so->ValueSet || !SameTemporal(lg[0], so->ValueSet->logical))
+          return Status::Make(StatusCode::TypeError, "is_in: the value set (" + (so && so->ValueSet ? Describe(so->ValueSet->logical, Datum::Of(so->ValueSet)) : "none") + ") is not of the column's type " + lg[0]);
+        SetOptions plain = *so;
+        plain.ValueSet = std::make_shared<ArrayData>(*so->ValueSet);
+        plain.ValueSet->logical.clear();
+        return CallFunction(ctx, name, &plain, bare, out);
+      }
+      break;
+    }
+    case TemporalRule::Add: {  // arithmetic.go:648-668
+      if (args.size() != 2) return refuse();
+      TemporalType a = ParseTemporal(lg[0]), b = ParseTemporal(lg[1]);
+      if (a.kind == 's' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];        // timestamp + duration → timestamp
+      else if (a.kind == 'D' && b.kind == 's' && a.unit == b.unit) out_logical = lg[1];   // duration + timestamp → timestamp
+      else if (a.kind == 'D' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];   // duration + duration → duration
+      else return refuse();
+      break;
+    }
+    case TemporalRule::Sub: {  // arithmetic.go:694-762
+      if (args.size() != 2) return refuse();
+      TemporalType a = ParseTemporal(lg[0]), b = ParseTemporal(lg[1]);
+      const std::string dur = std::string("tD") + a.unit;
+      if (a.kind == 's' && b.kind == 's' && SameTemporal(lg[0], lg[1])) out_logical = dur;     // timestamp − timestamp → duration
+      else if (a.kind == 's' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];          // timestamp − duration → timestamp
+      else if (a.kind == 'D' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];
+      else if (a.kind == 't' && lg[0] == lg[1] && (a.unit == 'u' || a.unit == 'n')) out_logical = dur;  // time64 − time64 → duration
+      else if (a.kind == 't' && lg[0] == lg[1]) {
+        // time32 − time32 → duration: the int32 kernel, widened afterwards (arithmetic.go:721-741)
+        Datum narrow;
+        AHC_RETURN_NOT_OK(CallFunction(ctx, name, opts, bare, &narrow));
+        AHC_RETURN_NOT_OK(CastDatum(ctx, narrow, CastOptions::Safe(GetDataType(Type::INT64)), out));
+        *out = WithLogical(*out, dur);
+        return Status::OK();
+      } else if (lg[0] == "tdm" && lg[1] == "tdm") out_logical = "tDm";                        // date64 − date64 → duration[ms]
+      else if (lg[0] == "tdD" && lg[1] == "tdD") {
+        // date32 − date32 → duration[s] (SubtractDate32, base_arithmetic.go:702-720).  Unchecked: the difference AND the ×86400 are
+        // int32 arithmetic that wraps, then widened; checked: both in int64 (where neither step can overflow).
+        auto day = std::make_shared<Scalar>();
+        day->valid = true;
+        Datum diff, secs;
+        if (checked) {
+          Datum w0, w1;
+          AHC_RETURN_NOT_OK(CastDatum(ctx, bare[0], CastOptions::Safe(GetDataType(Type::INT64)), &w0));
+          AHC_RETURN_NOT_OK(CastDatum(ctx, bare[1], CastOptions::Safe(GetDataType(Type::INT64)), &w1));
+          AHC_RETURN_NOT_OK(CallFunction(ctx, "subtract", opts, {w0, w1}, &diff));
+          day->type = GetDataType(Type::INT64);
+          int64_t v = 86400; memcpy(day->value, &v, 8);
+          AHC_RETURN_NOT_OK(CallFunction(ctx, "multiply", opts, {diff, Datum::Of(day)}, &secs));
+        } else {
+          AHC_RETURN_NOT_OK(CallFunction(ctx, "subtract_unchecked", opts, bare, &diff));
+          day->type = GetDataType(Type::INT32);
+          int32_t v = 86400; memcpy(day->value, &v, 4);
+          Datum narrow;
+          AHC_RETURN_NOT_OK(CallFunction(ctx, "multiply_unchecked", opts, {diff, Datum::Of(day)}, &narrow));
+          AHC_RETURN_NOT_OK(CastDatum(ctx, narrow, CastOptions::Safe(GetDataType(Type::INT64)), &secs));
+        }
+        *out = WithLogical(secs, "tDs");
+        return Status::OK();
+      } else return refuse();
+      break;
+    }
+    case TemporalRule::Cast: {
+      // temporal ↔ its storage integer is a relabelling (cast_temporal.go / cast.go "zero copy" casts); unit changes are not built
+      auto* co = dynamic_cast<const CastOptions*>(opts);
+      if (!co || args.size() != 1) return refuse();
+      const DataType* storage = TemporalStorage(lg[0]);
+      if (!co->ToLogical.empty()) {
+        if (co->ToLogical == lg[0]) { *out = args[0]; return Status::OK(); }
+        return Status::Make(StatusCode::NotImplemented, "cast from " + lg[0] + " to " + co->ToLogical + " is not built; cast through the storage integer with the conversion spelled out");
+      }
+      if (co->ToType && storage && co->ToType->id == storage->id) { *out = bare[0]; return Status::OK(); }
+      return Status::Make(StatusCode::NotImplemented, std::string("cast from ") + lg[0] + " to " + (co->ToType ? co->ToType->name : "?") + " is not built");
+    }
+  }
+  AHC_RETURN_NOT_OK(CallFunction(ctx, name, opts, bare, out));
+  if (!out_logical.empty()) {
+    if (name == "dictionary_encode") {  // the label belongs to the dictionary's values
+      auto relabel = [&](ArrayDataPtr& a) {
+        a = std::make_shared<ArrayData>(*a);
+        if (a->dictionary) { a->dictionary = std::make_shared<ArrayData>(*a->dictionary); a->dictionary->logical = out_logical; }
+      };
+      if (out->kind == DatumKind::Array) relabel(out->array);
+      if (out->kind == DatumKind::Chunked) for (auto& c : out->chunks) relabel(c);
+    } else {
+      *out = WithLogical(*out, out_logical);
+    }
+  }
+  return Status::OK();
+}
+
+}  // namespace
+
 Status CallFunction(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out) {
   FunctionRegistry* reg = ctx && ctx->Registry ? ctx->Registry : GetFunctionRegistry();
   Function* fn = reg->GetFunction(name);
   if (!fn) return Status::Make(StatusCode::KeyError, "function '" + name + "' not found");  // exec.go:191-199
+  {
+    std::vector<std::string> lg;
+    bool any = false;
+    Status st;
+    for (auto& a : args) { lg.push_back(DatumLogical(a, &st)); any = any || !lg.back().empty(); }
+    AHC_RETURN_NOT_OK(st);
+    if (!any)
+      if (auto* co = dynamic_cast<const CastOptions*>(opts))
+        if (name == "cast" && !co->ToLogical.empty() && args.size() == 1) {  // integer → temporal of that storage: a relabelling
+          const DataType* storage = TemporalStorage(co->ToLogical);
+          if (!storage) return Status::Make(StatusCode::NotImplemented, "cast to " + co->ToLogical + ": not a temporal type this layer takes");
+          if (!args[0].type() || args[0].type()->id != storage->id)
+            return Status::Make(StatusCode::NotImplemented, std::string("cast from ") + (args[0].type() ? args[0].type()->name : "?") + " to " + co->ToLogical + " is not built; cast to " + storage->name + " first");
+          *out = WithLogical(args[0], co->ToLogical);
+          return Status::OK();
+        }
+    if (any) return CallTemporal(ctx, name, opts, args, lg, out);
+  }
   for (auto& a : args)
     if (a.kind == DatumKind::Chunked) return ExecuteChunked(ctx, fn, opts, args, out);
   return fn->Execute(ctx, opts, args, out);

@@ -187,9 +187,21 @@ static bool Flatten(ExecCtx* ctx, const Expression& e, const ExecBatch& batch, F
   }
 }
 
+// a temporal literal anywhere in the tree
+static bool HasTemporalLiteral(const Expression& e) {
+  if (e.kind == Expression::LITERAL) return e.literal.kind == DatumKind::Scalar && !e.literal.scalar->logical.empty();
+  for (auto& a : e.args) if (a && HasTemporalLiteral(*a)) return true;
+  return false;
+}
+
 Status ExecuteScalarExpression(ExecCtx* ctx, const ExprPtr& expr, const ExecBatch& batch, Datum* out, bool fuse, bool* fused_out) {
   if (fused_out) *fused_out = false;
   if (!expr) return Status::Make(StatusCode::Invalid, "nil expression");  // exec.go:441-443
+  // temporal operands: the type rules live in CallFunction, so every node goes through it (the fused kernel would
+  // compute on the integers without checking that a timestamp meets a duration of its own unit)
+  for (auto& v : batch.values)
+    if (v.kind == DatumKind::Array && !v.array->logical.empty()) fuse = false;
+  if (fuse && HasTemporalLiteral(*expr)) fuse = false;
   for (auto& v : batch.values)
     if (v.kind == DatumKind::Array && v.array->length != batch.len)
       return Status::Make(StatusCode::Invalid, "all columns of the batch must have the batch length");

@@ -62,7 +62,8 @@ struct Fb {
 // format/Message.fbs
 enum { kHeaderSchema = 1, kHeaderDictionaryBatch = 2, kHeaderRecordBatch = 3 };
 // format/Schema.fbs: union Type
-enum { kTypeInt = 2, kTypeFloatingPoint = 3, kTypeBinary = 4, kTypeUtf8 = 5, kTypeBool = 6, kTypeLargeBinary = 19, kTypeLargeUtf8 = 20 };
+enum { kTypeInt = 2, kTypeFloatingPoint = 3, kTypeBinary = 4, kTypeUtf8 = 5, kTypeBool = 6, kTypeDate = 8, kTypeTime = 9, kTypeTimestamp = 10,
+       kTypeDuration = 18, kTypeLargeBinary = 19, kTypeLargeUtf8 = 20 };
 
 Status Invalid(const std::string& m) { return Status::Make(StatusCode::Invalid, "arrow/ipc: " + m); }
 Status NotImpl(const std::string& m) { return Status::Make(StatusCode::NotImplemented, "arrow/ipc: " + m); }
@@ -116,9 +117,38 @@ Status DecodeField(Fb& fb, int64_t f, FieldInfo* out) {
     case kTypeBinary: id = Type::BINARY; break;
     case kTypeLargeUtf8: id = Type::LARGE_STRING; break;
     case kTypeLargeBinary: id = Type::LARGE_BINARY; break;
+    // temporal columns (metadata.go: dateFromFB / timeFromFB / timestampFromFB / durationFromFB): integers with a label,
+    // written as the C Data format of the type (TimeUnit: SECOND 0, MILLISECOND 1, MICROSECOND 2, NANOSECOND 3)
+    case kTypeDate: {
+      const int unit = tt ? fb.scalar<int16_t>(tt, 0, 1) : 1;  // DateUnit: DAY 0, MILLISECOND 1 (default)
+      if (unit != 0 && unit != 1) return Invalid("field '" + out->name + "': date unit " + std::to_string(unit));
+      out->logical = unit == 0 ? "tdD" : "tdm";
+      break;
+    }
+    case kTypeTime: {
+      const int unit = tt ? fb.scalar<int16_t>(tt, 0, 1) : 1;
+      const int bits = tt ? fb.scalar<int32_t>(tt, 1, 32) : 32;
+      if (unit < 0 || unit > 3 || bits != (unit < 2 ? 32 : 64))
+        return Invalid("field '" + out->name + "': time of unit " + std::to_string(unit) + " in " + std::to_string(bits) + " bits");
+      out->logical = std::string("tt") + "smun"[unit];
+      break;
+    }
+    case kTypeTimestamp: {
+      const int unit = tt ? fb.scalar<int16_t>(tt, 0, 0) : 0;
+      if (unit < 0 || unit > 3) return Invalid("field '" + out->name + "': timestamp unit " + std::to_string(unit));
+      out->logical = std::string("ts") + "smun"[unit] + ":" + (tt ? fb.str(fb.indirect(tt, 1)) : std::string());
+      break;
+    }
+    case kTypeDuration: {
+      const int unit = tt ? fb.scalar<int16_t>(tt, 0, 1) : 1;
+      if (unit < 0 || unit > 3) return Invalid("field '" + out->name + "': duration unit " + std::to_string(unit));
+      out->logical = std::string("tD") + "smun"[unit];
+      break;
+    }
     default: return NotImpl("field '" + out->name + "' has flatbuf type " + std::to_string(type_type));
   }
-  out->type = GetDataType(id);
+  out->type = out->logical.empty() ? GetDataType(id) : TemporalStorage(out->logical);
+  if (!out->type) return NotImpl("field '" + out->name + "': type " + out->logical);
   return Status::OK();
 }
 
@@ -292,6 +322,7 @@ Status StreamReader::LoadColumns(const uint8_t* meta, int64_t mlen, int64_t rb, 
     const DataType* storage = encoded ? fi.index_type : fi.type;
     auto d = std::make_shared<ArrayData>();
     d->type = storage;
+    if (!encoded) d->logical = fi.logical;   // a dictionary-encoded temporal column: the label sits on the dictionary's values
     d->length = flen;
     d->offset = 0;
     int64_t off, len;

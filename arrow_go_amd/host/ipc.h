@@ -9,8 +9,8 @@
 //
 // Both the stream format and the file format ("ARROW1" magic … footer) are read; the footer's block index is not
 // needed for a sequential pass.
-// Scope: flat columns of the types the kernels take — Int8..Uint64, Float32/64, Bool, Utf8 / Binary and
-// their Large variants, plain or dictionary-encoded (DictionaryBatch messages, replacement and delta);
+// Scope: flat columns of the types the kernels take — Int8..Uint64, Float32/64, Bool, Date32/64, Time32/64, Timestamp,
+// Duration, Utf8 / Binary and their Large variants, plain or dictionary-encoded (DictionaryBatch messages, replacement and delta);
 // little-endian; uncompressed.  Anything else is
 // ErrNotImplemented with the field named.  The metadata is a FlatBuffer (format/Message.fbs,
 // Schema.fbs); it is read with the small bounds-checked accessor in ipc.cc — the bytes come from a
@@ -29,6 +29,7 @@ namespace ipc {
 struct FieldInfo {
   std::string name;
   const DataType* type = nullptr;        // the column's type; for a dictionary-encoded field the VALUE type
+  std::string logical;                   // temporal columns: C Data format of the type, `type` is then the storage integer
   bool nullable = true;
   int64_t dict_id = -1;                  // ≥ 0: dictionary-encoded (Schema.fbs DictionaryEncoding.id)
   const DataType* index_type = nullptr;  // … with these indices on the wire
