@@ -135,6 +135,7 @@ _SIGS = {
     "ah_take_primitive": [_vp, _int, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _i64, _i64, _int, _vp, _vp, _pi64, _pi64],
     "ah_cumulative_sum": [_vp, _int, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _pi64],
     "ah_cast_numeric": [_vp, _int, _int, _vp, _vp, _i64, _i64, _int, _int, _vp],
+    "ah_shift_time": [_vp, _int, _int, _int, _i64, _int, _vp, _vp, _i64, _i64, _vp, _vp],
     "ah_cast_bool_to_numeric": [_vp, _int, _vp, _i64, _i64, _vp],
     "ah_is_in": [_vp, _int, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _int, _vp, _vp, _i64],
     "ah_sort_indices": [_vp, _int, _vp, _vp, _i64, _i64, _int, _int, _vp],

@@ -282,6 +282,16 @@ class Context:
         check(self.handle, lib.ah_cast_numeric(self.handle, in_type, out_type, _ptr(values), _ptr(valid), off, n,
                                                int(allow_int_overflow), int(allow_float_truncate), _ptr(out_values)))
 
+    def shift_time(self, in_bits: int, out_bits: int, op: int, factor: int, checked: bool, values, valid, off: int, n: int, out_values) -> None:
+        """ShiftTime (cast_temporal.go:35-104); op 0 multiply, 1 divide.  A failed check raises ErrInvalid carrying .bad_value"""
+        bad = C.c_int64(0)
+        try:
+            check(self.handle, lib.ah_shift_time(self.handle, in_bits, out_bits, op, factor, int(checked), _ptr(values), _ptr(valid), off, n,
+                                                        _ptr(out_values), C.byref(bad)))
+        except N.ErrInvalid as e:
+            e.bad_value = bad.value
+            raise
+
     def cast_bool_to_numeric(self, out_type: int, bits, off: int, n: int, out_values) -> None:
         check(self.handle, lib.ah_cast_bool_to_numeric(self.handle, out_type, _ptr(bits), off, n, _ptr(out_values)))
 

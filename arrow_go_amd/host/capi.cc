@@ -284,6 +284,8 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
       if (k == "to_logical") { p->cast.ToLogical = v; p->pick = &p->cast; }
       if (k == "safe" && v == "0") { const DataType* t = p->cast.ToType; std::string l = p->cast.ToLogical; p->cast = compute::CastOptions::Unsafe(t); p->cast.ToLogical = l; p->pick = &p->cast; }
       if (k == "allow_int_overflow") { p->cast.AllowIntOverflow = v != "0"; p->pick = &p->cast; }
+      if (k == "allow_time_truncate") { p->cast.AllowTimeTruncate = v != "0"; p->pick = &p->cast; }
+      if (k == "allow_time_overflow") { p->cast.AllowTimeOverflow = v != "0"; p->pick = &p->cast; }
       if (k == "allow_float_truncate") { p->cast.AllowFloatTruncate = v != "0"; p->pick = &p->cast; }
       if (k == "value_set" && v.size() > 1 && v[0] == '@') {
         ahc_datum* d = (ahc_datum*)(uintptr_t)strtoull(v.c_str() + 1, nullptr, 16);

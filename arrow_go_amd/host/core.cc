@@ -932,12 +932,118 @@ Datum WithLogical(const Datum& d, const std::string& l) {  // a relabelled view;
     for (auto& c : r.chunks) { c = std::make_shared<ArrayData>(*c); c->logical = l; }
   return r;
 }
-// equal types for the temporal matchers: identical, or two timestamps of one unit that both carry a zone
-// (both are instants on the UTC line; a zoned and a naive timestamp do not compare — arrow.TypeEqual + exec.TimestampTypeUnit)
+// equal types for the temporal matchers: identical, or two timestamps of one unit — exec.TimestampTypeUnit (kernel.go) matches
+// on the unit alone, so the reference compares and subtracts timestamps of different zones (and zoned with naive ones)
 bool SameTemporal(const std::string& a, const std::string& b) {
   if (a == b) return true;
   TemporalType x = ParseTemporal(a), y = ParseTemporal(b);
-  return x.kind == 's' && y.kind == 's' && x.unit == y.unit && x.zoned && y.zoned;
+  return x.kind == 's' && y.kind == 's' && x.unit == y.unit;
+}
+int UnitRank(char u) { return u == 's' ? 0 : u == 'm' ? 1 : u == 'u' ? 2 : 3; }
+std::string WithUnit(const std::string& l, char u) {
+  TemporalType t = ParseTemporal(l);
+  if (t.kind == 's') { std::string r = l; r[2] = u; return r; }
+  if (t.kind == 'D') return std::string("tD") + u;
+  if (t.kind == 't') return std::string("tt") + u;
+  return l;
+}
+// arrow.DataType.String() of a temporal type, for messages
+std::string TemporalName(const std::string& l) {
+  TemporalType t = ParseTemporal(l);
+  const std::string unit = t.unit == 's' ? "s" : t.unit == 'm' ? "ms" : t.unit == 'u' ? "us" : "ns";
+  if (l == "tdD") return "date32";
+  if (l == "tdm") return "date64";
+  if (t.kind == 't') return std::string(UnitRank(t.unit) < 2 ? "time32[" : "time64[") + unit + "]";
+  if (t.kind == 'D') return "duration[" + unit + "]";
+  if (t.kind == 's') return "timestamp[" + unit + (l.size() > 4 ? ", tz=" + l.substr(4) : std::string()) + "]";
+  return l;
+}
+
+// The temporal → temporal casts that are a unit change (cast_temporal.go:240-420 → ShiftTime :35-104): timestamp → timestamp,
+// duration → duration, time32 / time64 among themselves, date32 ↔ date64.  One ah_shift_time pass; the result keeps the
+// input's validity buffer and offset.  A scalar is converted on the host by the same rule.
+Status CastTemporalUnits(ExecCtx* ctx, const Datum& in, const std::string& from, const std::string& to, const CastOptions& opts, Datum* out) {
+  if (from == to) { *out = in; return Status::OK(); }
+  TemporalType a = ParseTemporal(from), b = ParseTemporal(to);
+  const DataType* st_in = TemporalStorage(from);
+  const DataType* st_out = TemporalStorage(to);
+  if (!st_in || !st_out || a.kind != b.kind)
+    return Status::Make(StatusCode::NotImplemented, "cast from " + TemporalName(from) + " to " + TemporalName(to) + " is not built");
+  int64_t factor = 1;
+  int op = AH_SHIFT_MULTIPLY;
+  if (a.kind == 'd') {
+    factor = 86400000;  // days ↔ milliseconds
+    op = from == "tdD" ? AH_SHIFT_MULTIPLY : AH_SHIFT_DIVIDE;
+  } else {
+    const int d = UnitRank(b.unit) - UnitRank(a.unit);
+    for (int i = 0; i < (d < 0 ? -d : d); i++) factor *= 1000;
+    op = d >= 0 ? AH_SHIFT_MULTIPLY : AH_SHIFT_DIVIDE;
+  }
+  const bool check = op == AH_SHIFT_MULTIPLY ? !opts.AllowTimeOverflow : !opts.AllowTimeTruncate;
+  auto fail = [&](int64_t v) {
+    return Status::Make(StatusCode::Invalid, "casting from " + TemporalName(from) + " to " + TemporalName(to) +
+                                                 (op == AH_SHIFT_MULTIPLY ? " would result in out of bounds timestamp: " : " would lose data: ") + std::to_string(v));
+  };
+  const int wi = st_in->bit_width / 8, wo = st_out->bit_width / 8;
+  Session* s = ctx->session;
+  auto one = [&](const ArrayData& src, ArrayDataPtr* dst) -> Status {
+    auto d = std::make_shared<ArrayData>(src);
+    d->type = st_out;
+    d->logical = to;
+    d->buffers[1] = nullptr;
+    AHC_RETURN_NOT_OK(s->Allocate((src.offset + src.length) * wo, &d->buffers[1], /*zero_all=*/src.offset != 0));
+    if (src.length > 0) {
+      const bool nulls = src.buffers[0] && src.null_count != 0;
+      int64_t bad = 0;
+      int rc = ah_shift_time(s->ctx(), wi * 8, wo * 8, op, factor, check, (const uint8_t*)src.buffers[1]->dptr + src.offset * wi,
+                             nulls ? (const uint8_t*)src.buffers[0]->dptr : nullptr, src.offset, src.length,
+                             (uint8_t*)d->buffers[1]->dptr + src.offset * wo, &bad);
+      if (rc == AH_EINVALID && check) return fail(bad);
+      AHC_RETURN_NOT_OK(s->FromStatus(rc));
+    }
+    *dst = d;
+    return Status::OK();
+  };
+  switch (in.kind) {
+    case DatumKind::Array: {
+      ArrayDataPtr d;
+      AHC_RETURN_NOT_OK(one(*in.array, &d));
+      *out = Datum::Of(d);
+      return Status::OK();
+    }
+    case DatumKind::Chunked: {
+      std::vector<ArrayDataPtr> chunks;
+      for (auto& c : in.chunks) {
+        ArrayDataPtr d;
+        AHC_RETURN_NOT_OK(one(*c, &d));
+        chunks.push_back(d);
+      }
+      *out = Datum::OfChunks(st_out, std::move(chunks));
+      return Status::OK();
+    }
+    case DatumKind::Scalar: {
+      auto sc = std::make_shared<Scalar>(*in.scalar);
+      sc->type = st_out;
+      sc->logical = to;
+      int64_t v = 0;
+      if (wi == 4) { int32_t x; memcpy(&x, in.scalar->value, 4); v = x; } else memcpy(&v, in.scalar->value, 8);
+      int64_t r;
+      if (op == AH_SHIFT_MULTIPLY) {
+        if (check && in.scalar->valid && (v < INT64_MIN / factor || v > INT64_MAX / factor)) return fail(v);
+        r = wo == 4 ? (int64_t)(int32_t)((uint32_t)(int32_t)v * (uint32_t)(int32_t)factor) : (int64_t)((uint64_t)v * (uint64_t)factor);
+      } else {
+        r = v / factor;
+        if (wo == 4) r = (int32_t)r;
+        const int64_t again = wi == 4 ? (int64_t)(int32_t)((uint32_t)(int32_t)r * (uint32_t)(int32_t)factor) : (int64_t)((uint64_t)r * (uint64_t)factor);
+        if (check && in.scalar->valid && again != v) return fail(v);
+      }
+      memset(sc->value, 0, 8);
+      if (wo == 4) { int32_t x = (int32_t)r; memcpy(sc->value, &x, 4); } else memcpy(sc->value, &r, 8);
+      *out = Datum::Of(sc);
+      return Status::OK();
+    }
+    default: return Status::Make(StatusCode::Invalid, "cast: not an array or scalar");
+  }
 }
 std::string Describe(const std::string& l, const Datum& d) { return l.empty() ? std::string(d.type() ? d.type()->name : "?") : l; }
 
@@ -956,15 +1062,40 @@ const std::map<std::string, TemporalRule>& TemporalRules() {
   return r;
 }
 
-Status CallTemporal(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args,
-                    const std::vector<std::string>& lg, Datum* out) {
+Status CallTemporal(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args_in,
+                    const std::vector<std::string>& lg_in, Datum* out) {
   auto refuse = [&]() {
     std::string types;
-    for (size_t i = 0; i < args.size(); i++) types += (i ? ", " : "") + Describe(lg[i], args[i]);
+    for (size_t i = 0; i < args_in.size(); i++) types += (i ? ", " : "") + Describe(lg_in[i], args_in[i]);
     return Status::Make(StatusCode::NotImplemented, "function '" + name + "' has no kernel matching input types (" + types + ")");
   };
   auto it = TemporalRules().find(name);
   if (it == TemporalRules().end()) return refuse();
+  // DispatchBest for two temporal operands whose units differ: both go to the finer unit (commonTemporalResolution +
+  // replaceTemporalTypes for add / subtract, arithmetic.go:130-131, utils.go:130-170; commonTemporal for the comparisons,
+  // utils.go:329-399) through the safe unit cast.  Dates are promoted only among themselves, for comparisons.
+  std::vector<Datum> args = args_in;
+  std::vector<std::string> lg = lg_in;
+  if (args.size() == 2 && !lg[0].empty() && !lg[1].empty() && it->second != TemporalRule::Preserve && it->second != TemporalRule::Plain &&
+      it->second != TemporalRule::Cast && name != "is_in") {
+    TemporalType a = ParseTemporal(lg[0]), b = ParseTemporal(lg[1]);
+    auto unit_kind = [](char k) { return k == 's' || k == 'D' || k == 't'; };
+    std::string to[2] = {lg[0], lg[1]};
+    if (unit_kind(a.kind) && unit_kind(b.kind) && a.unit != b.unit && (it->second != TemporalRule::Same || a.kind == b.kind)) {
+      const char finest = UnitRank(a.unit) > UnitRank(b.unit) ? a.unit : b.unit;
+      to[0] = WithUnit(lg[0], finest);
+      to[1] = WithUnit(lg[1], finest);
+    } else if (it->second == TemporalRule::Same && a.kind == 'd' && b.kind == 'd' && lg[0] != lg[1]) {
+      to[0] = to[1] = "tdm";
+    }
+    for (int i = 0; i < 2; i++)
+      if (to[i] != lg[i]) {
+        Datum moved;
+        AHC_RETURN_NOT_OK(CastTemporalUnits(ctx, args[i], lg[i], to[i], CastOptions::Safe(nullptr), &moved));
+        args[i] = moved;
+        lg[i] = to[i];
+      }
+  }
   std::vector<Datum> bare;
   for (size_t i = 0; i < args.size(); i++) bare.push_back(lg[i].empty() ? args[i] : WithLogical(args[i], ""));
   std::string out_logical;
@@ -1043,13 +1174,13 @@ Status CallTemporal(ExecCtx* ctx, const std::string& name, const FunctionOptions
       break;
     }
     case TemporalRule::Cast: {
-      // temporal ↔ its storage integer is a relabelling (cast_temporal.go / cast.go "zero copy" casts); unit changes are not built
+      // temporal ↔ its storage integer is a relabelling (cast.go "zero copy" casts); temporal → temporal of the same family is a unit change
       auto* co = dynamic_cast<const CastOptions*>(opts);
       if (!co || args.size() != 1) return refuse();
       const DataType* storage = TemporalStorage(lg[0]);
       if (!co->ToLogical.empty()) {
-        if (co->ToLogical == lg[0]) { *out = args[0]; return Status::OK(); }
-        return Status::Make(StatusCode::NotImplemented, "cast from " + lg[0] + " to " + co->ToLogical + " is not built; cast through the storage integer with the conversion spelled out");
+        if (!TemporalStorage(co->ToLogical)) return Status::Make(StatusCode::NotImplemented, "cast to " + co->ToLogical + ": not a temporal type this layer takes");
+        return CastTemporalUnits(ctx, args[0], lg[0], co->ToLogical, *co, out);
       }
       if (co->ToType && storage && co->ToType->id == storage->id) { *out = bare[0]; return Status::OK(); }
       return Status::Make(StatusCode::NotImplemented, std::string("cast from ") + lg[0] + " to " + (co->ToType ? co->ToType->name : "?") + " is not built");

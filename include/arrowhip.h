@@ -374,6 +374,20 @@ int ah_hash_partition_u64(ah_ctx* ctx, const uint64_t* keys, int64_t n, int npar
  * Synchronises only when a check is active.  in_type == out_type is a device copy. */
 int ah_cast_numeric(ah_ctx* ctx, int in_type, int out_type, const void* values, const uint8_t* valid, int64_t off, int64_t n,
                     int allow_int_overflow, int allow_float_truncate, void* out_values);
+/* ---- temporal unit change (the casts either side of the temporal kernels) ----------------------------
+ * replaces ShiftTime[InT, OutT](ctx, op, factor, input, output) (kernels/cast_temporal.go:35-104), the leaf of the
+ * timestamp / duration / time32↔time64 / date32↔date64 casts (cast_temporal.go:240-420) and of the implicit unit
+ * casts DispatchBest inserts between temporal operands (arithmetic.go:130-131).  in_bits / out_bits: 32 or 64
+ * (the storage integers).  op: AH_SHIFT_MULTIPLY out = OutT(v)·OutT(factor) (wrapping), AH_SHIFT_DIVIDE
+ * out = OutT(v / InT(factor)) (truncating); factor == 1 only converts the width.  Every slot is converted.
+ * check != 0 (CastOptions.AllowTimeOverflow / AllowTimeTruncate false): a VALID value (valid = NULL: all) outside
+ * [MinInt64/factor, MaxInt64/factor] (multiply) or not a multiple of factor (divide) → AH_EINVALID, *bad_value =
+ * that value of the FIRST such row ("would result in out of bounds timestamp: %d" / "would lose data: %d");
+ * the type names of the reference's message are the host's to add.  Synchronises only when checking. */
+#define AH_SHIFT_MULTIPLY 0
+#define AH_SHIFT_DIVIDE 1
+int ah_shift_time(ah_ctx* ctx, int in_bits, int out_bits, int op, int64_t factor, int check, const void* values, const uint8_t* valid,
+                  int64_t off, int64_t n, void* out_values, int64_t* bad_value);
 /* boolToNum (numeric_cast.go:555-569): out[i] = bit(off + i) ? 1 : 0.  (numeric → bool is
  * isNonZero, boolean_cast.go:30-36 = ah_comparison(AH_CMP_NE, AH_SHAPE_AS, type, values, &zero).) */
 int ah_cast_bool_to_numeric(ah_ctx* ctx, int out_type, const uint8_t* bits, int64_t off, int64_t n, void* out_values);

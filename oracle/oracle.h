@@ -153,6 +153,9 @@ int orc_cumulative_sum(int type, const void* values, const uint8_t* valid, int64
 int orc_cast_numeric(int in_type, int out_type, const void* in, const uint8_t* valid, int64_t off, int64_t n,
                      int allow_int_overflow, int allow_float_truncate, void* out, int64_t* bad_index, char* msg);
 int orc_cast_bool_to_numeric(int out_type, const uint8_t* bits, int64_t off, int64_t n, void* out);
+/* ShiftTime (kernels/cast_temporal.go:35-104): op 0 multiply, 1 divide; ORC_EINVALID + *bad_value = the first failing row's input */
+int orc_shift_time(int in_bits, int out_bits, int op, int64_t factor, int check, const void* in, const uint8_t* valid, int64_t off,
+                   int64_t n, void* out, int64_t* bad_value);
 
 /* ---- is_in (kernels/scalar_set_lookup.go:192-244,374-413): keys are the raw bits of the fixed-width
  * value; out_data / out_valid bits [out_off, out_off + n) are written, every other bit is preserved */

@@ -181,3 +181,56 @@ int orc_cast_bool_to_numeric(int out_type, const uint8_t* bits, int64_t off, int
   }
   return ORC_OK;
 }
+
+/* ---- ShiftTime (kernels/cast_temporal.go:35-104) --------------------------------------------------
+ * The reference's loops restated for the four (InT, OutT) pairs: factor == 1 converts (:41-45); multiply checks the
+ * int64 bounds MaxInt64/factor, MinInt64/factor on VALID slots before writing OutT(v)*OutT(factor) (:47-74); divide
+ * writes OutT(v / InT(factor)) and then checks InT(out)*InT(factor) != v on VALID slots (:75-102).  The reference
+ * returns at the first failing row in index order; *bad_value is that row's input. */
+#define SHIFT_LOOP(InT, OutT, UIn, UOut)                                                            \
+  do {                                                                                              \
+    const InT* src = (const InT*)in;                                                                \
+    OutT* dst = (OutT*)out;                                                                         \
+    if (factor == 1) {                                                                              \
+      for (int64_t i = 0; i < n; i++) dst[i] = (OutT)src[i];                                        \
+      return ORC_OK;                                                                                \
+    }                                                                                               \
+    if (op == 0) {                                                                                  \
+      const int64_t max_val = INT64_MAX / factor, min_val = INT64_MIN / factor;                     \
+      for (int64_t i = 0; i < n; i++) {                                                             \
+        const InT v = src[i];                                                                       \
+        const int is_valid = !valid || ((valid[(off + i) >> 3] >> ((off + i) & 7)) & 1);            \
+        if (check && is_valid && ((int64_t)v < min_val || (int64_t)v > max_val)) {                  \
+          if (bad_value) *bad_value = (int64_t)v;                                                   \
+          return ORC_EINVALID;                                                                      \
+        }                                                                                           \
+        dst[i] = (OutT)((UOut)(OutT)v * (UOut)(OutT)factor);                                        \
+      }                                                                                             \
+      return ORC_OK;                                                                                \
+    }                                                                                               \
+    {                                                                                               \
+      const InT f = (InT)factor;                                                                    \
+      if (f == 0) return ORC_EINVALID;                                                              \
+      for (int64_t i = 0; i < n; i++) {                                                             \
+        const InT v = src[i];                                                                       \
+        const int is_valid = !valid || ((valid[(off + i) >> 3] >> ((off + i) & 7)) & 1);            \
+        dst[i] = (OutT)(v / f);                                                                     \
+        if (check && is_valid && (InT)((UIn)(InT)dst[i] * (UIn)f) != v) {                           \
+          if (bad_value) *bad_value = (int64_t)v;                                                   \
+          return ORC_EINVALID;                                                                      \
+        }                                                                                           \
+      }                                                                                             \
+      return ORC_OK;                                                                                \
+    }                                                                                               \
+  } while (0)
+
+int orc_shift_time(int in_bits, int out_bits, int op, int64_t factor, int check, const void* in, const uint8_t* valid, int64_t off,
+                   int64_t n, void* out, int64_t* bad_value) {
+  if (factor < 1 || (op != 0 && op != 1)) return ORC_EINVALID;
+  if (bad_value) *bad_value = 0;
+  if (in_bits == 32 && out_bits == 32) SHIFT_LOOP(int32_t, int32_t, uint32_t, uint32_t);
+  else if (in_bits == 32 && out_bits == 64) SHIFT_LOOP(int32_t, int64_t, uint32_t, uint64_t);
+  else if (in_bits == 64 && out_bits == 32) SHIFT_LOOP(int64_t, int32_t, uint64_t, uint32_t);
+  else if (in_bits == 64 && out_bits == 64) SHIFT_LOOP(int64_t, int64_t, uint64_t, uint64_t);
+  return ORC_EINVALID;
+}

@@ -87,6 +87,9 @@ class OracleBackend:
     def cast_bool_to_numeric(self, bits, off, n, out_dtype):
         return self.o.cast_bool_to_numeric(bits, off, n, out_dtype)
 
+    def shift_time(self, values, out_dtype, op, factor, check, valid=None, off=0, misalign=0):
+        return self.o.shift_time(values, out_dtype, op, factor, check, valid, off)
+
     def is_in(self, values, valid, off, set_values, set_valid, set_off, null_behavior, out_off=0, fill=0, misalign=0):
         return self.o.is_in(values, valid, off, set_values, set_valid, set_off, null_behavior, out_off, fill)
 
@@ -350,6 +353,19 @@ class HipBackend:
         except ah.ErrInvalid as e:
             return STATUS_EINVALID, None, str(e)
         return STATUS_OK, ob.download(od, values.size, misalign * od.itemsize), ""
+
+    def shift_time(self, values, out_dtype, op, factor, check, valid=None, off=0, misalign=0):
+        import arrow_go_amd as ah
+        values = np.ascontiguousarray(values)
+        od = np.dtype(out_dtype)
+        vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
+        ob = self.c.alloc(values.size * od.itemsize + 128)
+        ob.memset(0xCD)
+        try:
+            self.c.shift_time(values.dtype.itemsize * 8, od.itemsize * 8, op, factor, check, vp, vvp, off, values.size, ob.ptr + misalign * od.itemsize)
+        except ah.ErrInvalid as e:
+            return STATUS_EINVALID, None, e.bad_value
+        return STATUS_OK, ob.download(od, values.size, misalign * od.itemsize), 0
 
     def cast_bool_to_numeric(self, bits, off, n, out_dtype):
         od = np.dtype(out_dtype)

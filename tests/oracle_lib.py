@@ -71,6 +71,7 @@ class Oracle:
             "orc_filter_to_indices": (it, [vp, vp, i64, i64, it, vp, vp, vp, vp]),
             "orc_cumulative_sum": (it, [it, vp, vp, i64, i64, vp, it, it, vp, vp, vp]),
             "orc_cast_numeric": (it, [it, it, vp, vp, i64, i64, it, it, vp, vp, vp]),
+            "orc_shift_time": (it, [it, it, it, i64, it, vp, vp, i64, i64, vp, vp]),
             "orc_cast_bool_to_numeric": (it, [it, vp, i64, i64, vp]),
             "orc_is_in": (it, [it, vp, vp, i64, i64, vp, vp, i64, i64, it, vp, vp, i64]),
             "orc_sort_indices": (it, [it, vp, vp, i64, i64, it, it, vp]),
@@ -235,6 +236,15 @@ class Oracle:
         st = self.lib.orc_cast_numeric(TYPE_IDS[values.dtype], TYPE_IDS[np.dtype(out_dtype)], _p(values), _p(valid), off, values.size,
                                        int(allow_int_overflow), int(allow_float_truncate), _p(out), _p(bad), msg)
         return st, out[:values.size], msg.value.decode()
+
+    def shift_time(self, values, out_dtype, op, factor, check, valid=None, off=0):
+        """→ (status, out, bad value)"""
+        values = np.ascontiguousarray(values)
+        out = np.zeros(max(values.size, 1), dtype=out_dtype)
+        bad = np.zeros(1, np.int64)
+        st = self.lib.orc_shift_time(values.dtype.itemsize * 8, np.dtype(out_dtype).itemsize * 8, op, factor, int(check), _p(values), _p(valid),
+                                     off, values.size, _p(out), _p(bad))
+        return st, out[:values.size], int(bad[0])
 
     def cast_bool_to_numeric(self, bits, off, n, out_dtype):
         out = np.zeros(max(n, 1), dtype=out_dtype)

@@ -1282,3 +1282,56 @@ def test_pow10_is_gos_table(orc):
     # math.Pow10: pow10tab[n % 32] · pow10postab32[n / 32] — the product, not the correctly rounded literal, beyond 1e31
     assert orc.pow10(0) == 1.0 and orc.pow10(22) == 1e22 and orc.pow10(31) == 1e31
     assert orc.pow10(40) == 1e32 * 1e8 and orc.pow10(308) == 1e288 * 1e20 and orc.pow10(309) == float("inf")
+
+
+# ---- ShiftTime: unit changes of temporal columns (arrow/compute/cast_test.go) ----------------------------------
+SHIFT_MUL, SHIFT_DIV = 0, 1
+_SHIFT_CASES = [  # (coarse dtype, fine dtype, factor): TestTimestampToTimestamp :2650-2693, TestTimeToTime :2964-3038, TestDurationToDuration
+    (np.int64, np.int64, 1000), (np.int64, np.int64, 1000000000), (np.int32, np.int32, 1000), (np.int32, np.int64, 1000),
+    (np.int32, np.int64, 1000000), (np.int32, np.int64, 1000000000)]
+
+
+@pytest.mark.parametrize("coarse_t,fine_t,factor", _SHIFT_CASES, ids=lambda v: getattr(v, "__name__", str(v)))
+def test_shift_time_reference_vectors(be, coarse_t, fine_t, factor):
+    coarse, cv = mk([0, None, 200, 1, 2], coarse_t)
+    st, out, _ = be.shift_time(coarse, fine_t, SHIFT_MUL, factor, True, cv)
+    assert st == STATUS_OK and logical(out, cv, 0, 5) == [0, None, 200 * factor, factor, 2 * factor]
+    lossy, lv = mk([0, None, 200 * factor + 456 * (factor // 1000), factor + 123 * (factor // 1000), 2 * factor + 456 * (factor // 1000)], fine_t)
+    st, _, bad = be.shift_time(lossy, coarse_t, SHIFT_DIV, factor, True, lv)      # AllowTimeTruncate = false: "would lose data"
+    assert st == STATUS_EINVALID and bad == 200 * factor + 456 * (factor // 1000)
+    st, out, _ = be.shift_time(lossy, coarse_t, SHIFT_DIV, factor, False, lv)     # AllowTimeTruncate = true: divide / truncate
+    assert st == STATUS_OK and logical(out, lv, 0, 5) == [0, None, 200, 1, 2]
+
+
+def test_shift_time_dates_and_overflow(be):
+    # TestDateToDate :3052-3069
+    d32, dv = mk([0, None, 100, 1, 10], np.int32)
+    st, out, _ = be.shift_time(d32, np.int64, SHIFT_MUL, 86400000, True, dv)
+    assert st == STATUS_OK and logical(out, dv, 0, 5) == [0, None, 8640000000, 86400000, 864000000]
+    st, back, _ = be.shift_time(out, np.int32, SHIFT_DIV, 86400000, True, dv)
+    assert st == STATUS_OK and logical(back, dv, 0, 5) == [0, None, 100, 1, 10]
+    lossy, lv = mk([0, None, 8640000123, 86400456, 864000789], np.int64)
+    st, _, bad = be.shift_time(lossy, np.int32, SHIFT_DIV, 86400000, True, lv)
+    assert st == STATUS_EINVALID and bad == 8640000123
+    st, out, _ = be.shift_time(lossy, np.int32, SHIFT_DIV, 86400000, False, lv)
+    assert st == STATUS_OK and logical(out, lv, 0, 5) == [0, None, 100, 1, 10]
+    # TestTimestampToTimestampMultiplyOverflow :2703-2707 (years 1000 … 3000 in seconds → ns), TestDurationToDurationMultiplyOverflow :3166-3169
+    far = np.array([-30610224000, -5364662400, 946684800, 10413792000, 32503680000], np.int64)
+    st, _, bad = be.shift_time(far, np.int64, SHIFT_MUL, 1000000000, True)
+    assert st == STATUS_EINVALID and bad == -30610224000
+    st, _, bad = be.shift_time(np.array([10000000000, 1, 2, 3, 10000000000], np.int64), np.int64, SHIFT_MUL, 1000000000, True)
+    assert st == STATUS_EINVALID and bad == 10000000000
+    # AllowTimeOverflow: the product wraps
+    st, out, _ = be.shift_time(far, np.int64, SHIFT_MUL, 1000000000, False)
+    assert st == STATUS_OK and out.tolist() == (far.astype(np.uint64) * np.uint64(1000000000)).astype(np.int64).tolist()
+    # a failing value in a NULL slot does not fail the cast; the first VALID offender is the one reported
+    vals, vv = mk([None, 5, 10413792000, 32503680000], np.int64)
+    vals[0] = 32503680000
+    st, _, bad = be.shift_time(vals, np.int64, SHIFT_MUL, 1000000000, True, vv)
+    assert st == STATUS_EINVALID and bad == 10413792000
+    # factor 1 converts the width and never fails (cast_temporal.go:41-45)
+    st, out, _ = be.shift_time(np.array([1, -2, 3], np.int32), np.int64, SHIFT_MUL, 1, True)
+    assert st == STATUS_OK and out.tolist() == [1, -2, 3]
+    # a quotient that does not fit the 32-bit output is "lost data" too (:85)
+    st, _, bad = be.shift_time(np.array([0, 2**40 * 1000], np.int64), np.int32, SHIFT_DIV, 1000, True)
+    assert st == STATUS_EINVALID and bad == 2**40 * 1000

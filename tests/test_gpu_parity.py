@@ -1063,3 +1063,48 @@ def test_round_bit_exact(hip, orc_be, dtype):
         for mult in (0.05, 0.1, 0.25, 2, 7, 1000):
             g, e = hip.round(x, valid, 3, 0, mode, multiple=mult), orc_be.round(x, valid, 3, 0, mode, multiple=mult)
             assert g[0] == e[0] == 0 and g[1].tobytes() == e[1].tobytes(), (mode, mult)
+
+
+# ---- ShiftTime (temporal unit casts) -------------------------------------------------------------------------------
+@pytest.mark.parametrize("in_t,out_t", [(np.int32, np.int32), (np.int32, np.int64), (np.int64, np.int32), (np.int64, np.int64)],
+                         ids=["32to32", "32to64", "64to32", "64to64"])
+def test_shift_time_bit_exact(hip, orc_be, in_t, out_t):
+    """multiply / divide, checked and not, all four width pairs: same integers in every slot (null slots included), the same
+    first offending value when a check fires, offenders under null slots ignored; sizes cross the 4-row lane tile, buffers
+    are misaligned to force the scalar path."""
+    rng = np.random.default_rng(8100 + np.dtype(in_t).itemsize * 10 + np.dtype(out_t).itemsize)
+    info = np.iinfo(in_t)
+    for k, n in enumerate([1, 3, 4, 5, 1023, 1024, 1025, 65537, 1 << 20]):
+        for factor in [1, 1000, 86400000]:
+            wide = rng.integers(info.min, info.max, n, dtype=in_t, endpoint=True)
+            small = (rng.integers(-1000, 1000, n) * min(factor, 1000)).astype(in_t)   # passes both checks
+            valid = OL.pack_bits(rng.random(n + 5) < 0.8)
+            for op in (0, 1):
+                # unchecked: every slot computed, wrapping / truncating
+                st_e, e, _ = orc_be.shift_time(wide, out_t, op, factor, False, valid, 5)
+                st_g, g, _ = hip.shift_time(wide, out_t, op, factor, False, valid, 5, misalign=k % 3)
+                assert st_e == st_g == STATUS_OK and np.array_equal(e, g), (n, factor, op)
+                # checked on values that may or may not pass: same verdict, same first offender
+                for vals in (small, wide):
+                    st_e, e, bad_e = orc_be.shift_time(vals, out_t, op, factor, True, valid, 5)
+                    st_g, g, bad_g = hip.shift_time(vals, out_t, op, factor, True, valid, 5, misalign=(k + 1) % 3)
+                    assert st_e == st_g, (n, factor, op)
+                    if st_e == STATUS_OK:
+                        assert np.array_equal(e, g), (n, factor, op)
+                    else:
+                        assert bad_e == bad_g, (n, factor, op)
+                # all valid
+                st_e, e, bad_e = orc_be.shift_time(small, out_t, op, factor, True)
+                st_g, g, bad_g = hip.shift_time(small, out_t, op, factor, True)
+                assert st_e == st_g and bad_e == bad_g and (st_e != STATUS_OK or np.array_equal(e, g)), (n, factor, op)
+
+
+def test_shift_time_full_size_round_trip(hip):
+    """at a bench-sized column: s → ns → s is the identity, and the ns values are the seconds times 10^9 (linearity checked by sum)"""
+    rng = np.random.default_rng(8200)
+    n = 1 << 24
+    secs = rng.integers(-2**31, 2**31, n).astype(np.int64)
+    st, ns, _ = hip.shift_time(secs, np.int64, 0, 1000000000, True)
+    assert st == STATUS_OK and (int(ns.sum()) - int(secs.sum()) * 1000000000) % 2**64 == 0   # numpy's int64 sum wraps
+    st, back, _ = hip.shift_time(ns, np.int64, 1, 1000000000, True)
+    assert st == STATUS_OK and np.array_equal(back, secs)

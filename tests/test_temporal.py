@@ -113,14 +113,30 @@ def test_comparisons_need_equal_types(sess, typ):
 @pytest.mark.gpu
 def test_timestamp_units_and_zones(sess):
     a = pa.array([1, 5, None, 7], pa.timestamp("us", "UTC"))
-    other_zone = pa.array([1, 4, 3, 9], pa.timestamp("us", "Europe/Paris"))
-    assert sess.call_function("less", [a, other_zone]).to_pylist() == [False, False, None, True]  # both are instants
-    d = sess.call_function("subtract", [a, other_zone])
-    assert d.type == pa.duration("us") and d.cast(pa.int64()).to_pylist() == [0, 1, None, -2]
-    for wrong in [pa.array([1, 4, 3, 9], pa.timestamp("us")), pa.array([1, 4, 3, 9], pa.timestamp("ms", "UTC"))]:
-        for fn in ["equal", "subtract"]:
-            with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
-                sess.call_function(fn, [a, wrong])
+    # exec.TimestampTypeUnit matches on the unit alone: other zones, and naive timestamps, meet a zoned one
+    for other in [pa.array([1, 4, 3, 9], pa.timestamp("us", "Europe/Paris")), pa.array([1, 4, 3, 9], pa.timestamp("us"))]:
+        assert sess.call_function("less", [a, other]).to_pylist() == [False, False, None, True]
+        d = sess.call_function("subtract", [a, other])
+        assert d.type == pa.duration("us") and d.cast(pa.int64()).to_pylist() == [0, 1, None, -2]
+    # different units: DispatchBest takes both sides to the finer one (utils.go:130-170, :329-399)
+    ms = pa.array([0, 1, 3, -9], pa.timestamp("ms", "UTC"))
+    assert sess.call_function("greater", [a, ms]).to_pylist() == [True, False, None, True]
+    assert sess.call_function("greater", [ms, a]).to_pylist() == [False, True, None, False]
+    d = sess.call_function("subtract", [ms, a])
+    assert d.type == pa.duration("us") and d.cast(pa.int64()).to_pylist() == [-1, 995, None, -9007]
+    got = sess.call_function("add", [pa.array([10, None], pa.timestamp("s")), pa.array([5, 5], pa.duration("ns"))])
+    assert got.type == pa.timestamp("ns") and got.cast(pa.int64()).to_pylist() == [10_000_000_005, None]
+    got = sess.call_function("subtract", [pa.array([10, 20], pa.time32("s")), pa.array([5, 7], pa.time64("us"))])
+    assert got.type == pa.duration("us") and got.cast(pa.int64()).to_pylist() == [9_999_995, 19_999_993]
+    assert sess.call_function("equal", [pa.array([1, 2, None], pa.date32()), pa.array([86400000, 5, 7], pa.date64())]).to_pylist() == [True, False, None]
+    assert sess.call_function("less", [pa.array([1, 2000], pa.duration("s")), pa.scalar(1500, pa.int64()).cast(pa.duration("ms"))]).to_pylist() == [True, False]
+    # the implicit cast is the safe one: a second count that has no nanosecond representation stops the call
+    with pytest.raises(ac.ErrInvalid, match=r"casting from timestamp\[s\] to timestamp\[ns\] would result in out of bounds timestamp: 32503680000"):
+        sess.call_function("less", [pa.array([1, 32503680000], pa.timestamp("s")), pa.array([1, 2], pa.timestamp("ns"))])
+    # no common type: a point in time and a span, a date and a timestamp
+    for args in [[a, pa.array([1, 2, 3, 4], pa.duration("us"))], [a, pa.array([1, 2, 3, 4], pa.date32())]]:
+        with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
+            sess.call_function("equal", args)
 
 
 # arrow/compute/arithmetic_test.go:2234-2268
@@ -193,8 +209,13 @@ def test_timestamp_duration_arithmetic(sess, unit):
         sess.call_function("add", [edge, step])
     assert sess.call_function("add_unchecked", [edge, step]).cast(pa.int64()).to_pylist() == [-2**63, 6, None]
     # pairs the reference has no kernel for (arithmetic.go:630-770)
+    # a duration of another unit: both sides go to the finer one first
     other = {"s": "ms", "ms": "us", "us": "ns", "ns": "s"}[unit]
-    for fn, args in [("add", [ts, ts2]), ("multiply", [du, du2]), ("add", [ts, rand(rng, pa.duration(other), n)]),
+    finer = "ns" if "ns" in (unit, other) else other
+    small_ts, du_o = rand(rng, pa.timestamp(unit, "UTC"), n), rand(rng, pa.duration(other), n)
+    got = sess.call_function("add", [small_ts, du_o])
+    assert got.equals(pc.add_checked(small_ts.cast(pa.timestamp(finer, "UTC")), du_o.cast(pa.duration(finer))))
+    for fn, args in [("add", [ts, ts2]), ("multiply", [du, du2]),
                      ("subtract", [du, ts]), ("add", [ts, storage(du)]), ("negate", [du]), ("cumulative_sum", [du])]:
         with pytest.raises(ac.ErrNotImplemented, match="no kernel matching input types"):
             sess.call_function(fn, args)
@@ -210,10 +231,65 @@ def test_casts_between_a_temporal_type_and_its_storage(sess):
     assert sess.call_function("cast", [ts], "to_logical=tsu:UTC").equals(ts)
     d = sess.call_function("cast", [pa.array([1, 2], pa.int32())], "to_logical=tdD")
     assert d.equals(pa.array([1, 2], pa.date32()))
-    for args, opts in [([ts], "to_logical=tsn:UTC"), ([ts], "to_type=int32"), ([pa.array([1], pa.int32())], "to_logical=tsu:"),
-                       ([pa.array([1], pa.int64())], "to_logical=txx")]:
+    for args, opts in [([ts], "to_type=int32"), ([pa.array([1], pa.int32())], "to_logical=tsu:"), ([pa.array([1], pa.int64())], "to_logical=txx"),
+                       ([ts], "to_logical=tDu"), ([ts], "to_logical=tdD")]:
         with pytest.raises(ac.ErrNotImplemented):
             sess.call_function("cast", args, opts)
+
+
+# arrow/compute/cast_test.go: TestTimestampToTimestamp :2650-2693, TestTimeToTime :2964-3038, TestDurationToDuration :3083-3157
+_UNIT_CASTS = [(pa.timestamp("s"), pa.timestamp("ms"), 10**3), (pa.timestamp("ms"), pa.timestamp("us"), 10**3), (pa.timestamp("us"), pa.timestamp("ns"), 10**3),
+               (pa.timestamp("s"), pa.timestamp("ns"), 10**9), (pa.duration("s"), pa.duration("ms"), 10**3), (pa.duration("ms"), pa.duration("us"), 10**3),
+               (pa.duration("us"), pa.duration("ns"), 10**3), (pa.duration("s"), pa.duration("ns"), 10**9),
+               (pa.time32("s"), pa.time32("ms"), 10**3), (pa.time32("ms"), pa.time64("us"), 10**3), (pa.time64("us"), pa.time64("ns"), 10**3),
+               (pa.time32("s"), pa.time64("us"), 10**6), (pa.time32("ms"), pa.time64("ns"), 10**6), (pa.time32("s"), pa.time64("ns"), 10**9)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coarse,fine,factor", _UNIT_CASTS, ids=lambda v: str(v))
+def test_unit_casts_reference_vectors(sess, coarse, fine, factor):
+    store = lambda t: pa.int32() if t.bit_width == 32 else pa.int64()
+    arr = lambda vals, t: pa.array(vals, store(t)).cast(t)
+    to = lambda t: "to_logical=" + ac._temporal_format(t)
+    got = sess.call_function("cast", [arr([0, None, 200, 1, 2], coarse)], to(fine))
+    assert got.type == fine and got.equals(arr([0, None, 200 * factor, factor, 2 * factor], fine))
+    k = factor // 1000
+    lossy = arr([0, None, 200 * factor + 456 * k, factor + 123 * k, 2 * factor + 456 * k], fine)
+    with pytest.raises(ac.ErrInvalid, match="would lose data: %d" % (200 * factor + 456 * k)):
+        sess.call_function("cast", [lossy], to(coarse))
+    got = sess.call_function("cast", [lossy], to(coarse) + ";allow_time_truncate=1")
+    assert got.type == coarse and got.equals(arr([0, None, 200, 1, 2], coarse))
+    # a slice keeps its offset; chunked columns go chunk by chunk
+    big = arr(list(range(1000)), coarse)
+    assert sess.call_function("cast", [big.slice(13, 900)], to(fine)).equals(arr([v * factor for v in range(13, 913)], fine))
+    ch = sess.call_function("cast", [pa.chunked_array([big.slice(0, 10), big.slice(10, 990)])], to(fine))
+    assert isinstance(ch, pa.ChunkedArray) and ch.type == fine and ch.combine_chunks().equals(arr([v * factor for v in range(1000)], fine))
+
+
+@pytest.mark.gpu
+def test_unit_cast_overflow_and_dates(sess):
+    # TestTimestampToTimestampMultiplyOverflow :2703-2707, TestDurationToDurationMultiplyOverflow :3166-3169, TestDateToDate :3052-3069
+    far = pa.array([-30610224000, -5364662400, 946684800, 10413792000, 32503680000], pa.timestamp("s"))
+    with pytest.raises(ac.ErrInvalid, match=r"casting from timestamp\[s\] to timestamp\[ns\] would result in out of bounds timestamp: -30610224000"):
+        sess.call_function("cast", [far], "to_logical=tsn:")
+    wrapped = sess.call_function("cast", [far], "to_logical=tsn:;allow_time_overflow=1")
+    assert wrapped.cast(pa.int64()).to_pylist() == (np.array(far.cast(pa.int64())).astype(np.uint64) * np.uint64(10**9)).astype(np.int64).tolist()
+    with pytest.raises(ac.ErrInvalid, match=r"casting from duration\[s\] to duration\[ns\] would result in out of bounds timestamp: 10000000000"):
+        sess.call_function("cast", [pa.array([10000000000, 1, 2, 3, 10000000000], pa.duration("s"))], "to_logical=tDn")
+    d32 = pa.array([0, None, 100, 1, 10], pa.date32())
+    d64 = sess.call_function("cast", [d32], "to_logical=tdm")
+    assert d64.equals(pa.array([0, None, 8640000000, 86400000, 864000000], pa.date64()))
+    assert sess.call_function("cast", [d64], "to_logical=tdD").equals(d32)
+    lossy = pa.array([0, None, 8640000123, 86400456, 864000789], pa.int64())
+    lossy = sess.call_function("cast", [lossy], "to_logical=tdm", keep_on_device=True)   # pyarrow would refuse to build this date64
+    with pytest.raises(ac.ErrInvalid, match="casting from date64 to date32 would lose data: 8640000123"):
+        sess.call_function("cast", [lossy], "to_logical=tdD")
+    assert sess.call_function("cast", [lossy], "to_logical=tdD;allow_time_truncate=1").equals(d32)
+    # zones are labels: a cast between them leaves the instants alone (TestTimestampToTimestampSimpleTimezone :2643-2648)
+    z = pa.array([1672601100123456, None], pa.timestamp("us", "Etc/UTC"))
+    assert sess.call_function("cast", [z], "to_logical=tsu:").equals(z.cast(pa.int64()).cast(pa.timestamp("us")))
+    # scalars follow the same rule on the host
+    assert sess.call_function("cast", [pa.scalar(7, pa.int64()).cast(pa.duration("s"))], "to_logical=tDm").value == 7000
 
 
 @pytest.mark.gpu
