@@ -173,6 +173,12 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     timed("cast_int64_to_int32_unsafe", 12 * rows, lambda: ctx.cast_numeric(N.INT64, N.INT32, a, None, 0, rows, True, True, c))
     timed("cast_int32_to_int64", 12 * rows, lambda: ctx.cast_numeric(N.INT32, N.INT64, a, None, 0, rows, False, False, c))
     timed("cast_float64_to_float32", 12 * rows, lambda: ctx.cast_numeric(N.FLOAT64, N.FLOAT32, x, None, 0, rows, False, False, c))
+    # temporal unit change (ShiftTime): ns → us truncating, then us → ns with the overflow check on (16 B/row)
+    t_us = ctx.alloc(rows * 8)
+    timed("shift_time_div1000_int64", 16 * rows, lambda: ctx.shift_time(64, 64, 1, 1000, False, a, None, 0, rows, t_us))
+    timed("shift_time_mul1000_int64_checked", 16 * rows, lambda: ctx.shift_time(64, 64, 0, 1000, True, t_us, None, 0, rows, c))
+    timed("shift_time_mul1000_int64_checked_nulls10", 16.125 * rows, lambda: ctx.shift_time(64, 64, 0, 1000, True, t_us, vvalid, 0, rows, c))
+    del t_us
     timed("min_max_int64", 8 * rows, lambda: ctx.min_max(N.INT64, a, rows, np.int64))
     timed("bitmap_and", 0.375 * rows, lambda: ctx.bitmap_op(N.BIT_AND, mask, 0, vvalid, 0, ovalid, 0, rows))
     timed("count_set_bits", 0.125 * rows, lambda: ctx.count_set_bits(mask, 0, rows))
