@@ -20,14 +20,13 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kRows = 4;  // rows per lane: 16 bytes of int32, 32 bytes of int64
 
 enum { SHIFT_CONVERT = 0, SHIFT_MULTIPLY = 1, SHIFT_DIVIDE = 2 };
 
-template <typename T>
-using Vec4 = T __attribute__((ext_vector_type(4)));
-
-template <typename InT, typename OutT, int OP>
+// F: the divisor as a compile-time constant for the factors the unit table produces (10^3, 10^6, 10^9, 86 400 000) — a
+// multiply-high instead of the generic 64-bit division sequence, which made the int64 divide ALU-bound (4.6 TB/s);
+// 0 = take it from the argument.
+template <typename InT, typename OutT, int OP, int64_t F>
 __device__ __forceinline__ OutT shift_one(InT v, int64_t factor, int64_t lo, int64_t hi, bool& bad) {
   using UOut = typename std::make_unsigned<OutT>::type;
   using UIn = typename std::make_unsigned<InT>::type;
@@ -38,69 +37,94 @@ __device__ __forceinline__ OutT shift_one(InT v, int64_t factor, int64_t lo, int
     bad = (int64_t)v < lo || (int64_t)v > hi;
     return (OutT)((UOut)(OutT)v * (UOut)(OutT)factor);  // OutT(v) * OutT(factor), wrapping like Go
   } else {
-    const InT f = (InT)factor;
+    const InT f = F ? (InT)F : (InT)factor;
     const OutT q = (OutT)(v / f);                        // truncated quotient, then narrowed
     bad = (InT)((UIn)(InT)q * (UIn)f) != v;
     return q;
   }
 }
 
-template <typename InT, typename OutT, int OP, bool CHECK>
+// Lane shape: K rows per access so that the WIDER of the two sides moves 16 bytes per lane (the narrow side then moves 8 —
+// still one contiguous run per wave), U such accesses per lane a workgroup-tile apart, both loads issued before any
+// arithmetic.  (A first version gave each lane 4 consecutive int64 = two 16-byte accesses 32 bytes apart: every wave
+// instruction touched each cache line half — 5.4 TB/s where the 16-byte shape of the other streaming kernels gets 6+.)
+template <typename InT, typename OutT>
+struct ShiftShape {
+  static constexpr int K = 16 / (int)(sizeof(InT) > sizeof(OutT) ? sizeof(InT) : sizeof(OutT));
+  static constexpr int U = 2;
+  typedef InT VIn __attribute__((ext_vector_type(K)));
+  typedef OutT VOut __attribute__((ext_vector_type(K)));
+};
+
+template <typename InT, typename OutT, int OP, bool CHECK, int64_t F = 0>
 __global__ __launch_bounds__(kBlock) void shift_time_kernel(const InT* __restrict__ in, const uint8_t* __restrict__ valid, int64_t voff, int64_t n,
                                                             int64_t factor, int64_t lo, int64_t hi, OutT* __restrict__ out,
                                                             unsigned long long* __restrict__ first_bad, int aligned) {
-  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kRows;
-  if (base >= n) return;
-  InT v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-  const bool full = base + kRows <= n;
-  if (full && aligned) {
-    const Vec4<InT> x = __builtin_nontemporal_load((const Vec4<InT>*)(in + base));
-    v0 = x.x; v1 = x.y; v2 = x.z; v3 = x.w;
-  } else {
-    v0 = in[base];
-    if (base + 1 < n) v1 = in[base + 1];
-    if (base + 2 < n) v2 = in[base + 2];
-    if (base + 3 < n) v3 = in[base + 3];
-  }
-  bool b0, b1, b2, b3;
-  const OutT o0 = shift_one<InT, OutT, OP>(v0, factor, lo, hi, b0);
-  const OutT o1 = shift_one<InT, OutT, OP>(v1, factor, lo, hi, b1);
-  const OutT o2 = shift_one<InT, OutT, OP>(v2, factor, lo, hi, b2);
-  const OutT o3 = shift_one<InT, OutT, OP>(v3, factor, lo, hi, b3);
-  if constexpr (CHECK) {
-    if (b0 | b1 | b2 | b3) {  // rare: look at validity only now
-      auto live = [&](int k) {
-        const int64_t r = base + k;
-        if (r >= n) return false;
-        if (!valid) return true;
-        const int64_t bit = voff + r;
-        return ((valid[bit >> 3] >> (bit & 7)) & 1) != 0;
-      };
-      int first = -1;
-      if (b3 && live(3)) first = 3;
-      if (b2 && live(2)) first = 2;
-      if (b1 && live(1)) first = 1;
-      if (b0 && live(0)) first = 0;
-      if (first >= 0) atomicMin(first_bad, (unsigned long long)(base + first));
+  using S = ShiftShape<InT, OutT>;
+  constexpr int K = S::K;
+  typedef typename S::VIn VIn;
+  typedef typename S::VOut VOut;
+  const int64_t base0 = (int64_t)blockIdx.x * (kBlock * K * S::U) + (int64_t)threadIdx.x * K;
+  const int64_t base1 = base0 + kBlock * K;
+  if (base0 >= n) return;
+  auto load = [&](int64_t base) {
+    VIn x;
+    if (base + K <= n && aligned) {
+      x = __builtin_nontemporal_load((const VIn*)(in + base));
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) x[k] = base + k < n ? in[base + k] : (InT)0;
     }
-  }
-  if (full && aligned) {
-    Vec4<OutT> y;
-    y.x = o0; y.y = o1; y.z = o2; y.w = o3;
-    __builtin_nontemporal_store(y, (Vec4<OutT>*)(out + base));
+    return x;
+  };
+  auto finish = [&](int64_t base, VIn x) {
+    VOut y;
+    unsigned bad = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      bool b;
+      y[k] = shift_one<InT, OutT, OP, F>(x[k], factor, lo, hi, b);
+      bad |= (unsigned)b << k;
+    }
+    if constexpr (CHECK) {
+      if (bad) {  // rare: look at validity only now; the lowest failing VALID row of this lane competes for "first"
+#pragma unroll
+        for (int k = K - 1; k >= 0; k--) {
+          const int64_t r = base + k;
+          bool live = ((bad >> k) & 1) && r < n;
+          if (live && valid) {
+            const int64_t bit = voff + r;
+            live = ((valid[bit >> 3] >> (bit & 7)) & 1) != 0;
+          }
+          if (live) atomicMin(first_bad, (unsigned long long)r);
+        }
+      }
+    }
+    if (base + K <= n && aligned) {
+      __builtin_nontemporal_store(y, (VOut*)(out + base));
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if (base + k < n) out[base + k] = y[k];
+    }
+  };
+  const VIn x0 = load(base0);
+  if (base1 < n) {
+    const VIn x1 = load(base1);
+    finish(base0, x0);
+    finish(base1, x1);
   } else {
-    out[base] = o0;
-    if (base + 1 < n) out[base + 1] = o1;
-    if (base + 2 < n) out[base + 2] = o2;
-    if (base + 3 < n) out[base + 3] = o3;
+    finish(base0, x0);
   }
 }
 
 template <typename InT, typename OutT>
 void launch_shift(ah_ctx* c, int op, bool check, const void* in, const uint8_t* valid, int64_t voff, int64_t n, int64_t factor, int64_t lo,
                   int64_t hi, void* out, unsigned long long* first_bad) {
-  const unsigned grid = (unsigned)((n + (int64_t)kBlock * kRows - 1) / ((int64_t)kBlock * kRows));
-  const int aligned = ((uintptr_t)in % (kRows * sizeof(InT)) == 0) && ((uintptr_t)out % (kRows * sizeof(OutT)) == 0);
+  using S = ShiftShape<InT, OutT>;
+  const int64_t tile = (int64_t)kBlock * S::K * S::U;
+  const unsigned grid = (unsigned)((n + tile - 1) / tile);
+  const int aligned = ((uintptr_t)in % (S::K * sizeof(InT)) == 0) && ((uintptr_t)out % (S::K * sizeof(OutT)) == 0);
   const InT* pi = (const InT*)in;
   OutT* po = (OutT*)out;
 #define AH_SHIFT(OP)                                                                                                                   \
@@ -108,9 +132,19 @@ void launch_shift(ah_ctx* c, int op, bool check, const void* in, const uint8_t* 
     if (check) shift_time_kernel<InT, OutT, OP, true><<<grid, kBlock, 0, c->stream>>>(pi, valid, voff, n, factor, lo, hi, po, first_bad, aligned); \
     else shift_time_kernel<InT, OutT, OP, false><<<grid, kBlock, 0, c->stream>>>(pi, valid, voff, n, factor, lo, hi, po, first_bad, aligned);      \
   } while (0)
+#define AH_SHIFT_DIV(F)                                                                                                                       \
+  do {                                                                                                                                         \
+    if (check) shift_time_kernel<InT, OutT, SHIFT_DIVIDE, true, F><<<grid, kBlock, 0, c->stream>>>(pi, valid, voff, n, factor, lo, hi, po, first_bad, aligned); \
+    else shift_time_kernel<InT, OutT, SHIFT_DIVIDE, false, F><<<grid, kBlock, 0, c->stream>>>(pi, valid, voff, n, factor, lo, hi, po, first_bad, aligned);      \
+  } while (0)
   if (op == SHIFT_CONVERT) AH_SHIFT(SHIFT_CONVERT);
   else if (op == SHIFT_MULTIPLY) AH_SHIFT(SHIFT_MULTIPLY);
+  else if (factor == 1000) AH_SHIFT_DIV(1000);
+  else if (factor == 1000000) AH_SHIFT_DIV(1000000);
+  else if (factor == 1000000000) AH_SHIFT_DIV(1000000000);
+  else if (factor == 86400000) AH_SHIFT_DIV(86400000);
   else AH_SHIFT(SHIFT_DIVIDE);
+#undef AH_SHIFT_DIV
 #undef AH_SHIFT
 }
 
