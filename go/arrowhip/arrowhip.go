@@ -213,6 +213,29 @@ func (x *Context) CastNumeric(in, out arrow.Type, values, valid unsafe.Pointer, 
 		boolInt(opts.AllowIntOverflow), boolInt(opts.AllowFloatTruncate), dst))
 }
 
+// ShiftTime mirrors kernels.ShiftTime[InT, OutT] (cast_temporal.go:35-104), the leaf of the timestamp / duration /
+// time32↔time64 / date32↔date64 unit casts: inBits / outBits are the storage widths, op arrow.ConvMULTIPLY or
+// arrow.ConvDIVIDE.  The checks follow opts.AllowTimeOverflow / AllowTimeTruncate; a failure comes back as
+// arrow.ErrInvalid with the reference's text built around the first offending value.
+func (x *Context) ShiftTime(inBits, outBits int, op arrow.TimestampConvertOp, factor int64, opts compute.CastOptions,
+	inType, outType arrow.DataType, values, valid unsafe.Pointer, off, n int64, dst unsafe.Pointer) error {
+	cop, check := C.int(C.AH_SHIFT_MULTIPLY), !opts.AllowTimeOverflow
+	if op == arrow.ConvDIVIDE {
+		cop, check = C.int(C.AH_SHIFT_DIVIDE), !opts.AllowTimeTruncate
+	}
+	var bad C.int64_t
+	rc := C.ah_shift_time(x.c, C.int(inBits), C.int(outBits), cop, C.int64_t(factor), boolInt(check), values, (*C.uint8_t)(valid),
+		C.int64_t(off), C.int64_t(n), dst, &bad)
+	if rc == C.AH_EINVALID && check {
+		what := "would result in out of bounds timestamp"
+		if op == arrow.ConvDIVIDE {
+			what = "would lose data"
+		}
+		return fmt.Errorf("%w: casting from %s to %s %s: %v", arrow.ErrInvalid, inType, outType, what, int64(bad))
+	}
+	return x.err(rc)
+}
+
 // ArithmeticExt covers the pure-Go arithmetic kernels that have no assembly leaf: divide, abs, negate,
 // bit-wise ops, shifts, sqrt, floor / ceil / trunc (base_arithmetic.go:154-160,287-340,386-426;
 // scalar_arithmetic.go:170-378; rounding.go:180-187).  op: AH_OP_* of include/arrowhip.h.  Errors carry
