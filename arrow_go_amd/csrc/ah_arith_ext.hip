@@ -57,9 +57,9 @@ __device__ __forceinline__ void store16(ST* base, int64_t i, const ah_vec16<ST>&
   }
 }
 
-enum { ERR_OVERFLOW = 1, ERR_DIV_ZERO = 2, ERR_SHIFT = 4, ERR_NEG_SQRT = 8 };
-enum { X_DIV, X_DIV_CHECKED, X_SHL, X_SHL_CHECKED, X_SHR, X_SHR_CHECKED, X_BIT_NOT, X_SQRT_CHECKED,  // NotNull
-       X_ABS_CHECKED, X_NEG_CHECKED, X_BIT_AND, X_BIT_OR, X_BIT_XOR, X_SQRT, X_FLOOR, X_CEIL, X_TRUNC };  // every slot
+enum { ERR_OVERFLOW = 1, ERR_DIV_ZERO = 2, ERR_SHIFT = 4, ERR_NEG_SQRT = 8, ERR_NEG_POWER = 16 };
+enum { X_DIV, X_DIV_CHECKED, X_SHL, X_SHL_CHECKED, X_SHR, X_SHR_CHECKED, X_POW_CHECKED, X_BIT_NOT, X_SQRT_CHECKED,  // NotNull
+       X_ABS_CHECKED, X_NEG_CHECKED, X_BIT_AND, X_BIT_OR, X_BIT_XOR, X_POW, X_SQRT, X_FLOOR, X_CEIL, X_TRUNC };  // every slot
 
 constexpr bool NotNull(int x) { return x <= X_SQRT_CHECKED; }
 constexpr bool Unary(int x) { return x == X_BIT_NOT || x == X_SQRT_CHECKED || x == X_ABS_CHECKED || x == X_NEG_CHECKED || x >= X_SQRT; }
@@ -104,6 +104,42 @@ __device__ __forceinline__ ST apply(ST a, ST b, unsigned& err) {
       constexpr ST tmin = (ST)((U)1 << (bits - 1));
       if (a == tmin) { err |= ERR_OVERFLOW; return (ST)0; }
       return X == X_ABS_CHECKED ? (ST)(a < 0 ? -a : a) : (ST)-a;
+    }
+  } else if constexpr (X == X_POW || X == X_POW_CHECKED) {
+    // power_unchecked / power (base_arithmetic.go:226-248, 342-373, 443-446)
+    if constexpr (kFloat) {
+      return (ST)::pow((double)a, (double)b);      // OutT(math.Pow(float64(a), float64(b))) under both names
+    } else {
+      if constexpr (kSigned) {
+        if (b < 0) { err |= ERR_NEG_POWER; return (ST)0; }
+      }
+      if constexpr (X == X_POW) {  // right to left in uint64, narrowed at the end: wraps
+        unsigned long long base = (unsigned long long)a, e = (unsigned long long)b, p = 1;
+        while (e != 0) {
+          if (e & 1) p *= base;
+          base *= base;
+          e >>= 1;
+        }
+        return (ST)p;
+      } else {  // left to right with mulWithOverflow (:84-108: an overflowing product is 0 and the flag sticks)
+        if (b == 0) return (ST)1;
+        const unsigned long long ue = (unsigned long long)b;
+        unsigned long long mask = 1ull << (63 - __builtin_clzll(ue));
+        ST p = (ST)1;
+        bool of = false;
+        while (mask != 0) {
+          ST t;
+          if (__builtin_mul_overflow(p, p, &t)) { of = true; t = (ST)0; }
+          p = t;
+          if (ue & mask) {
+            if (__builtin_mul_overflow(p, a, &t)) { of = true; t = (ST)0; }
+            p = t;
+          }
+          mask >>= 1;
+        }
+        if (of) err |= ERR_OVERFLOW;
+        return p;
+      }
     }
   } else if constexpr (X == X_FLOOR || X == X_CEIL || X == X_TRUNC) {
     // getFloatRoundImpl (rounding.go:180-187): math.Floor / Ceil / Trunc of the value widened to float64 and narrowed
@@ -164,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void ext_kernel(const ST* __restrict__ l, c
     }
   }
   // one atomic per wave that saw an error, none otherwise
-  for (unsigned bit = 1; bit <= ERR_NEG_SQRT; bit <<= 1)
+  for (unsigned bit = 1; bit <= ERR_NEG_POWER; bit <<= 1)
     if (__any((err & bit) != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
 }
 
@@ -199,6 +235,8 @@ int dispatch_int(ah_ctx* c, int op, int shape, const void* l, const uint8_t* lv,
     case AH_OP_SHIFT_LEFT_CHECKED: AH_X(X_SHL_CHECKED);
     case AH_OP_SHIFT_RIGHT: AH_X(X_SHR);
     case AH_OP_SHIFT_RIGHT_CHECKED: AH_X(X_SHR_CHECKED);
+    case AH_OP_POWER: AH_X(X_POW);
+    case AH_OP_POWER_CHECKED: AH_X(X_POW_CHECKED);
     case AH_OP_BIT_NOT: AH_X(X_BIT_NOT);
     case AH_OP_BIT_AND: AH_X(X_BIT_AND);
     case AH_OP_BIT_OR: AH_X(X_BIT_OR);
@@ -219,6 +257,7 @@ int dispatch_float(ah_ctx* c, int op, int shape, const void* l, const uint8_t* l
     case AH_OP_DIV_CHECKED: AH_X(X_DIV_CHECKED);
     case AH_OP_ABS_CHECKED: AH_X(X_ABS_CHECKED);
     case AH_OP_NEGATE_CHECKED: AH_X(X_NEG_CHECKED);
+    case AH_OP_POWER: case AH_OP_POWER_CHECKED: AH_X(X_POW);
     case AH_OP_SQRT: AH_X(X_SQRT);
     case AH_OP_SQRT_CHECKED: AH_X(X_SQRT_CHECKED);
     case AH_OP_FLOOR: AH_X(X_FLOOR);
@@ -297,7 +336,8 @@ AH_EXPORT int ah_arithmetic_ext(ah_ctx* c, int type, int op, int shape, const vo
   if ((((uintptr_t)arr0 | (uintptr_t)out | (shape == AH_SHAPE_AA ? (uintptr_t)r : 0)) & (uintptr_t)(w - 1)) != 0)
     return ah_fail(c, AH_EINVALID, "arithmetic: buffer not element-aligned");
   const bool every_slot = op == AH_OP_BIT_AND || op == AH_OP_BIT_OR || op == AH_OP_BIT_XOR || op == AH_OP_ABS_CHECKED || op == AH_OP_NEGATE_CHECKED ||
-                          op == AH_OP_SQRT || op == AH_OP_FLOOR || op == AH_OP_CEIL || op == AH_OP_TRUNC;
+                          op == AH_OP_SQRT || op == AH_OP_FLOOR || op == AH_OP_CEIL || op == AH_OP_TRUNC || op == AH_OP_POWER ||
+                          (op == AH_OP_POWER_CHECKED && (type == AH_FLOAT32 || type == AH_FLOAT64));
   if (!every_slot && !unary && shape != AH_SHAPE_AA && !scalar_valid) {
     // null scalar: the output stays as allocated = zero (helpers.go:312-314, 341-343)
     AH_HIP(c, hipMemsetAsync(out, 0, (size_t)len * w, c->stream));
@@ -331,6 +371,7 @@ AH_EXPORT int ah_arithmetic_ext(ah_ctx* c, int type, int op, int shape, const vo
   if (f & ERR_DIV_ZERO) return ah_fail(c, AH_EINVALID, "divide by zero");
   if (f & ERR_SHIFT) return ah_fail(c, AH_EINVALID, "shift amount must be >= 0 and less than precision of type");
   if (f & ERR_NEG_SQRT) return ah_fail(c, AH_EINVALID, "square root of negative number");
+  if (f & ERR_NEG_POWER) return ah_fail(c, AH_EINVALID, "integers to negative integer powers are not allowed");
   return AH_OK;
 }
 

@@ -149,6 +149,8 @@ void RegisterScalarArithmetic(FunctionRegistry* reg) {
   const auto flt = {Type::FLOAT32, Type::FLOAT64};
   reg->AddFunction(MakeArithExt("divide", AH_OP_DIV_CHECKED, 2, nums), false);
   reg->AddFunction(MakeArithExt("divide_unchecked", AH_OP_DIV, 2, nums), false);
+  reg->AddFunction(MakeArithExt("power", AH_OP_POWER_CHECKED, 2, nums), false);             // arithmetic.go:929-930
+  reg->AddFunction(MakeArithExt("power_unchecked", AH_OP_POWER, 2, nums), false);
   reg->AddFunction(MakeArithExt("abs", AH_OP_ABS_CHECKED, 1, nums), false);
   reg->AddFunction(MakeArithExt("negate", AH_OP_NEGATE_CHECKED, 1, sgn), false);  // GetArithmeticUnarySignedKernels: no unsigned kernel
   reg->AddFunction(MakeArithExt("bit_wise_and", AH_OP_BIT_AND, 2, ints), false);

@@ -70,6 +70,8 @@ extern "C" {
 #define AH_OP_ABS_CHECKED 25
 #define AH_OP_NEGATE_CHECKED 26
 #define AH_OP_SQRT_CHECKED 27
+#define AH_OP_POWER 7             /* OpPower / OpPowerChecked (base_arithmetic.go:46,71) */
+#define AH_OP_POWER_CHECKED 28
 #define AH_OP_SHIFT_LEFT 64       /* … and private numbers for the shift / bit-wise kernels (scalar_arithmetic.go) */
 #define AH_OP_SHIFT_LEFT_CHECKED 65
 #define AH_OP_SHIFT_RIGHT 66

@@ -222,10 +222,10 @@ int orc_arithmetic_checked(int type, int8_t op, int shape,
  * msg (≥ 128 bytes, may be NULL) receives the reference's error text. */
 #include <math.h>
 #include <stdio.h>
-enum { X_OK = 0, X_OVERFLOW = 1, X_DIVZERO = 2, X_SHIFT = 3, X_NEGSQRT = 4 };
+enum { X_OK = 0, X_OVERFLOW = 1, X_DIVZERO = 2, X_SHIFT = 3, X_NEGSQRT = 4, X_NEGPOWER = 5 };
 
 static int ext_is_unary(int op) { return op == 71 || op == 25 || op == 26 || op == 6 || op == 27 || (op >= 72 && op <= 74); }
-static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || op == 25 || op == 26 || op == 6 || (op >= 72 && op <= 74); }
+static int ext_every_slot(int op) { return op == 7 || op == 68 || op == 69 || op == 70 || op == 25 || op == 26 || op == 6 || (op >= 72 && op <= 74); }
 
 #define EXT_INT_BODY(T, U, SIGNED)                                                                                 \
   {                                                                                                                \
@@ -256,6 +256,24 @@ static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || o
         case 68: o[i] = (T)(a & b); break;                                                                         \
         case 69: o[i] = (T)(a | b); break;                                                                         \
         case 70: o[i] = (T)(a ^ b); break;                                                                         \
+        case 7: { /* power_unchecked, base_arithmetic.go:226-248: uint64 right-to-left, narrowed */              \
+          if (SIGNED && (long long)b < 0) { err = X_NEGPOWER; break; }                                             \
+          unsigned long long base = (unsigned long long)a, e = (unsigned long long)b, pw = 1;                      \
+          while (e != 0) { if (e & 1) pw *= base; base *= base; e >>= 1; }                                         \
+          o[i] = (T)pw; break; }                                                                                   \
+        case 28: { /* power, :342-373: left-to-right with mulWithOverflow (:84-108) */                             \
+          if (SIGNED && (long long)b < 0) { err = X_NEGPOWER; break; }                                             \
+          if (b == 0) { o[i] = 1; break; }                                                                         \
+          unsigned long long ue = (unsigned long long)b, mask = 1ull << (63 - __builtin_clzll(ue));                \
+          T pw = 1, t; int of = 0;                                                                                 \
+          while (mask != 0) {                                                                                      \
+            if (__builtin_mul_overflow(pw, pw, &t)) { of = 1; t = 0; }                                             \
+            pw = t;                                                                                                \
+            if (ue & mask) { if (__builtin_mul_overflow(pw, a, &t)) { of = 1; t = 0; } pw = t; }                   \
+            mask >>= 1;                                                                                            \
+          }                                                                                                        \
+          if (of) { err = X_OVERFLOW; break; }                                                                     \
+          o[i] = pw; break; }                                                                                      \
         case 25: case 26:                                                                                          \
           if (!SIGNED) { if (op == 26) return ORC_EINVALID; o[i] = a; break; }                                     \
           if ((U)a == (U)1 << (bits - 1)) { err = X_OVERFLOW; break; }                                             \
@@ -280,6 +298,7 @@ static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || o
       if (!valid) { o[i] = 0; continue; }                                                                          \
       switch (op) {                                                                                                \
         case 3: o[i] = a / b; break;                                                                               \
+        case 7: case 28: o[i] = (T)pow((double)a, (double)b); break;   /* :443-446 */                              \
         case 24: if (b == 0) { err = X_DIVZERO; o[i] = 0; } else o[i] = a / b; break;                              \
         case 25: o[i] = FABSF(a); break;                                                                           \
         case 26: o[i] = -a; break;                                                                                 \
@@ -295,7 +314,8 @@ static int ext_every_slot(int op) { return op == 68 || op == 69 || op == 70 || o
 
 int orc_arithmetic_ext(int type, int op, int shape, const void* lvp, const uint8_t* lvalid, int64_t loff, const void* rvp,
                        const uint8_t* rvalid, int64_t roff, int scalar_valid, void* ov, int64_t len, char* msg) {
-  const int unary = ext_is_unary(op), every = ext_every_slot(op);
+  const int unary = ext_is_unary(op);
+  const int every = ext_every_slot(op) || (op == 28 && (type == ORC_FLOAT32 || type == ORC_FLOAT64));  /* float power: ScalarBinary under both names */
   int err = X_OK;
   if (unary) shape = ORC_SHAPE_AS;
   if (!every && !unary && shape != ORC_SHAPE_AA && !scalar_valid) {
@@ -318,7 +338,7 @@ int orc_arithmetic_ext(int type, int op, int shape, const void* lvp, const uint8
     default: return ORC_EINVALID;
   }
   static const char* text[] = {"", "overflow", "divide by zero", "shift amount must be >= 0 and less than precision of type",
-                               "square root of negative number"};
+                               "square root of negative number", "integers to negative integer powers are not allowed"};
   if (err != X_OK) {
     if (msg) snprintf(msg, 128, "%s", text[err]);
     return err == X_OVERFLOW ? ORC_EOVERFLOW : ORC_EINVALID;

@@ -1335,3 +1335,54 @@ def test_shift_time_dates_and_overflow(be):
     # a quotient that does not fit the 32-bit output is "lost data" too (:85)
     st, _, bad = be.shift_time(np.array([0, 2**40 * 1000], np.int64), np.int32, SHIFT_DIV, 1000, True)
     assert st == STATUS_EINVALID and bad == 2**40 * 1000
+
+
+# ---- power / power_unchecked (arithmetic_test.go:482-510 TestPower; base_arithmetic.go:226-248, 342-373, 443-446) --
+X.update(POW=7, POW_CHECKED=28)
+
+
+@pytest.mark.parametrize("dtype", _INTS, ids=str)
+def test_power_integer_vectors(be, dtype):
+    for op in (X["POW"], X["POW_CHECKED"]):
+        assert ext_binop(be, op, [3, 2, 6, 2], [1, 1, 2, 0], dtype)[:2] == (0, [3, 2, 36, 1])
+        assert ext_binop(be, op, [None, 2, 3, None, 20], [1, 6, 2, 5, 1], dtype, fill=1)[:2] == (0, [None, 64, 9, None, 20])
+        st, out, _ = be.arithmetic_ext(op, 2, np.array([3], dtype), None, 0, *mk([None, 3, 4, None, 2], dtype, 1), 0)   # scalar ^ array
+        assert st == 0 and out.tolist()[1:3] + out.tolist()[4:] == [27, 81, 9]
+        st, out, _ = be.arithmetic_ext(op, 1, *mk([None, 10, 3, None, 2], dtype, 1), 0, np.array([2], dtype), None, 0)  # array ^ scalar
+        assert st == 0 and out.tolist()[1:3] + out.tolist()[4:] == [100, 9, 4]
+        assert ext_binop(be, op, [4], [3], dtype)[1] == [64]
+        assert ext_binop(be, op, [0, 1, 0], [0, 0, 42], dtype)[:2] == (0, [1, 1, 0])
+    mx = int(np.iinfo(dtype).max)
+    st, _, msg, _ = ext_binop(be, X["POW_CHECKED"], [mx], [10], dtype)
+    assert st == STATUS_EOVERFLOW and "overflow" in msg
+    assert ext_binop(be, X["POW"], [mx], [10], dtype)[:2] == (0, [1])                 # wraps: max^10 ≡ 1
+    if dtype in _SIGNED:
+        err = "integers to negative integer powers are not allowed"
+        for op in (X["POW"], X["POW_CHECKED"]):
+            st, _, msg, _ = ext_binop(be, op, [2, 3], [1, -1], dtype)
+            assert st == STATUS_EINVALID and err in msg
+        # ScalarBinaryNotNull (checked) skips null slots, ScalarBinary (unchecked) runs the closure on them too
+        assert ext_binop(be, X["POW_CHECKED"], [2, None], [3, -1], dtype)[:2] == (0, [8, None])
+        st, _, msg, _ = ext_binop(be, X["POW"], [2, None], [3, -1], dtype)
+        assert st == STATUS_EINVALID and err in msg
+        mn = int(np.iinfo(dtype).min)
+        bits = np.iinfo(dtype).bits
+        assert ext_binop(be, X["POW_CHECKED"], [-2, -1, -1], [bits - 1, 7, 8], dtype)[:2] == (0, [mn, -1, 1])   # (−2)^(bits−1) = MinInt fits
+        st, _, msg, _ = ext_binop(be, X["POW_CHECKED"], [2], [bits - 1], dtype)
+        assert st == STATUS_EOVERFLOW
+
+
+@pytest.mark.parametrize("dtype", _FLOATS, ids=str)
+def test_power_float_vectors(be, dtype):
+    # the reference checks these with array.ApproxEqual; the same values here to 4 ulp of the type
+    tol = 4 * np.finfo(dtype).eps
+    close = lambda got, want: all((g is None and w is None) or (g == w) or (g is not None and w is not None and abs(g - w) <= tol * abs(w)) for g, w in zip(got, want))
+    with np.errstate(all="ignore"):
+        for op in (X["POW"], X["POW_CHECKED"]):
+            assert close(ext_binop(be, op, [3.4, 16, 0.64, 1.2, 0], [1, 0.5, 2, 4, 0], dtype)[1], [float(dtype(3.4)), 4, float(dtype(0.64)) ** 2, float(dtype(1.2)) ** 4, 1])
+            assert close(ext_binop(be, op, [None, 1, 3.3, None, 2], [1, 4, 2, 5, 0.1], dtype)[1], [None, 1, float(dtype(3.3)) ** 2, None, 2 ** float(dtype(0.1))])
+            inf = float("inf")
+            assert ext_binop(be, op, [3.4, inf, -inf, 1.1, 10000], [1, 2, 3, inf, 100000], dtype)[1][1:] == [inf, -inf, inf, inf]
+            assert ext_binop(be, op, [0.0, 0.0], [-1.0, -3.0], dtype)[1] == [inf, inf]
+            got = ext_binop(be, op, [3.4, float("nan"), 2.0], [1, 2, 2.0], dtype)[1]
+            assert np.isnan(got[1]) and got[2] == 4.0

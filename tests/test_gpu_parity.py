@@ -1108,3 +1108,55 @@ def test_shift_time_full_size_round_trip(hip):
     assert st == STATUS_OK and (int(ns.sum()) - int(secs.sum()) * 1000000000) % 2**64 == 0   # numpy's int64 sum wraps
     st, back, _ = hip.shift_time(ns, np.int64, 1, 1000000000, True)
     assert st == STATUS_OK and np.array_equal(back, secs)
+
+
+# ---- power -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64], ids=str)
+def test_power_integers_bit_exact(hip, orc_be, dtype):
+    """power_unchecked wraps like the uint64 square-and-multiply of the reference in every slot; power reports exactly the
+    overflows mulWithOverflow would and skips null slots; negative exponents are refused by both (by the unchecked form even
+    under a null)."""
+    info = np.iinfo(dtype)
+    rng = np.random.default_rng(9100 + info.bits + (info.min < 0))
+    for n in (1, 15, 16, 17, 1000, 70001):
+        base = rng.integers(info.min, info.max, n + 4, dtype=dtype, endpoint=True)
+        base[rng.random(n + 4) < 0.5] = rng.integers(max(info.min, -3), 4)          # small bases: results that fit
+        exp = rng.integers(0, min(info.max, 70), n + 4).astype(dtype)
+        lv, rv = rand_bits(rng, n + 16, 0.85), rand_bits(rng, n + 16, 0.85)
+        for sl in (0, 3):
+            A, E = base[sl:sl + n], exp[sl:sl + n]
+            for shape, l, r in ((0, A, E), (1, A, E[:1]), (2, A[:1], E)):
+                _ext_same(hip.arithmetic_ext(7, shape, l, lv, sl, r, rv, 5), orc_be.arithmetic_ext(7, shape, l, lv, sl, r, rv, 5), ("pow", n, shape))
+            # checked: exponents small enough that nothing overflows, then the general case (usually "overflow")
+            tiny = (E.astype(np.int64) % 3).astype(dtype)
+            fits = np.clip(A.astype(np.float64), -11, 11).astype(dtype) if info.bits >= 16 else np.clip(A.astype(np.float64), -5, 5).astype(dtype)
+            _ext_same(hip.arithmetic_ext(28, 0, fits, lv, sl, tiny, rv, 5), orc_be.arithmetic_ext(28, 0, fits, lv, sl, tiny, rv, 5), ("powc fits", n))
+            _ext_same(hip.arithmetic_ext(28, 0, A, lv, sl, E, rv, 5), orc_be.arithmetic_ext(28, 0, A, lv, sl, E, rv, 5), ("powc", n))
+            _ext_same(hip.arithmetic_ext(28, 1, fits, lv, sl, tiny[:1], None, 0), orc_be.arithmetic_ext(28, 1, fits, lv, sl, tiny[:1], None, 0), ("powc AS", n))
+            if info.min < 0:
+                En = E.copy(); En[n // 2] = -1
+                for op in (7, 28):
+                    for v in (None, rv):
+                        _ext_same(hip.arithmetic_ext(op, 0, fits, None, 0, En, v, 5), orc_be.arithmetic_ext(op, 0, fits, None, 0, En, v, 5), ("neg exp", op, n))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=str)
+def test_power_floats_close(hip, orc_be, dtype):
+    """math.Pow is not correctly rounded and neither is the device's pow; the reference's own test is ApproxEqual.
+    Tolerance: 4 ulp of the type against the host libm, special values (NaN, ±Inf, ±0, 1) exactly."""
+    rng = np.random.default_rng(9200 + np.dtype(dtype).itemsize)
+    n = 50001
+    a = np.abs(rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)).astype(dtype)
+    b = (rng.standard_normal(n) * 4).astype(dtype)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 2.0, 0.5, -2.0], dtype)
+    a[:10] = special; b[:10] = special[::-1]
+    a[10:20] = special; b[10:20] = np.array([0, 1, 2, -1, 0.5, np.inf, -np.inf, np.nan, 3, 3], dtype)
+    with np.errstate(all="ignore"):
+        for op in (7, 28):
+            g, e = hip.arithmetic_ext(op, 0, a, None, 0, b, None, 0), orc_be.arithmetic_ext(op, 0, a, None, 0, b, None, 0)
+            assert g[0] == e[0] == 0
+            G, E = g[1].astype(np.float64), e[1].astype(np.float64)
+            assert np.array_equal(np.isnan(G), np.isnan(E))
+            fin = np.isfinite(E)
+            assert np.array_equal(G[~fin & ~np.isnan(E)], E[~fin & ~np.isnan(E)])
+            assert np.all(np.abs(G[fin] - E[fin]) <= 4 * np.finfo(dtype).eps * np.abs(E[fin]) + np.finfo(dtype).tiny), np.max(np.abs(G[fin] - E[fin]) / np.maximum(np.abs(E[fin]), 1e-300))
