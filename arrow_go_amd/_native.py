@@ -35,6 +35,7 @@ X_EQ, X_NE, X_GT, X_GE, X_LT, X_LE = 30, 31, 32, 33, 34, 35
 X_AND, X_OR, X_XOR, X_AND_NOT, X_INVERT = 40, 41, 42, 43, 44
 X_CAST = 50
 OP_DIV, OP_SQRT, OP_DIV_CHECKED, OP_ABS_CHECKED, OP_NEGATE_CHECKED, OP_SQRT_CHECKED = 3, 6, 24, 25, 26, 27
+OP_POWER, OP_POWER_CHECKED = 7, 28
 OP_SHIFT_LEFT, OP_SHIFT_LEFT_CHECKED, OP_SHIFT_RIGHT, OP_SHIFT_RIGHT_CHECKED, OP_BIT_AND, OP_BIT_OR, OP_BIT_XOR, OP_BIT_NOT = 64, 65, 66, 67, 68, 69, 70, 71
 OP_FLOOR, OP_CEIL, OP_TRUNC = 72, 73, 74
 

@@ -200,7 +200,11 @@ int ah_arithmetic_checked(ah_ctx* ctx, int type, int8_t op, int shape,
  *       precision of type".  Null slots hold 0.
  *   SQRT (every slot), SQRT_CHECKED (null slots 0; a negative valid value is AH_EINVALID "square root of negative
  *       number"; :412-426): correctly rounded IEEE sqrt, floats only.
- *   FLOOR, CEIL, TRUNC (floor, ceil, trunc; rounding.go:180-187,748-775): every slot, floats only. */
+ *   FLOOR, CEIL, TRUNC (floor, ceil, trunc; rounding.go:180-187,748-775): every slot, floats only.
+ *   POWER (power_unchecked; base_arithmetic.go:226-248): integers right-to-left in uint64, narrowed (wraps), EVERY slot;
+ *       POWER_CHECKED (power; :342-373): left-to-right with mulWithOverflow → AH_EOVERFLOW "overflow", valid slots only,
+ *       null slots 0.  A negative integer exponent is AH_EINVALID "integers to negative integer powers are not allowed"
+ *       under both.  Floats (:443-446): pow in double under both names, every slot, never fails. */
 int ah_arithmetic_ext(ah_ctx* ctx, int type, int op, int shape, const void* l, const uint8_t* lvalid, int64_t loff, const void* r,
                       const uint8_t* rvalid, int64_t roff, int scalar_valid, void* out, int64_t len);
 
