@@ -93,7 +93,7 @@ class CArrowDeviceArray(C.Structure):
 
 ARROW_DEVICE_CPU, ARROW_DEVICE_ROCM, ARROW_DEVICE_ROCM_HOST = 1, 10, 11
 _FORMATS = {"bool": b"b", "int8": b"c", "uint8": b"C", "int16": b"s", "uint16": b"S", "int32": b"i", "uint32": b"I", "int64": b"l",
-            "uint64": b"L", "float": b"f", "double": b"g"}
+            "uint64": b"L", "float": b"f", "double": b"g", "string": b"u", "binary": b"z", "large_string": b"U", "large_binary": b"Z"}
 
 
 class DeviceArray:
@@ -316,12 +316,15 @@ class Session:
         return d
 
     def import_device(self, type_name: str, length: int, data_ptr, validity_ptr=None, null_count: int = 0, offset: int = 0,
-                      sync_event=None, on_release=None, device_type: int = ARROW_DEVICE_ROCM, device_id=None) -> "DeviceArray":
+                      sync_event=None, on_release=None, device_type: int = ARROW_DEVICE_ROCM, device_id=None, var_data_ptr=None,
+                      n_buffers=None) -> "DeviceArray":
         """Consumer side of the Arrow C Device Data Interface (arrow/cdata/abi.h:66-128): wrap device
         buffers produced elsewhere WITHOUT copying them.  `on_release` is called when the library lets
-        go of the producer's array (its release callback)."""
-        bufs = (_vp * 2)(validity_ptr, data_ptr)
+        go of the producer's array (its release callback).  String / binary types: `data_ptr` is the offsets
+        buffer, `var_data_ptr` the bytes (three buffers)."""
         fmt = _FORMATS[type_name]
+        nb = n_buffers if n_buffers is not None else (3 if fmt in (b"u", b"z", b"U", b"Z") else 2)
+        bufs = (_vp * 3)(validity_ptr, data_ptr, var_data_ptr)
         keep = {"bufs": bufs, "fmt": fmt}
 
         def _release_array(ptr):
@@ -340,7 +343,7 @@ class Session:
         self._device_imports.append(keep)  # callbacks must outlive the C side's use of them
         darr = CArrowDeviceArray()
         darr.array.length, darr.array.null_count, darr.array.offset = length, null_count, offset
-        darr.array.n_buffers, darr.array.n_children = 2, 0
+        darr.array.n_buffers, darr.array.n_children = nb, 0
         darr.array.buffers = C.cast(bufs, C.POINTER(_vp))
         darr.array.release = rel_a
         darr.device_id = self.device_id if device_id is None else device_id

@@ -74,6 +74,10 @@ struct Status {
 class Session;  // owns the ah_ctx
 struct Buffer {
   Session* session = nullptr;
+  // Keeps the session (its ah_ctx and the block pool ~Buffer returns memory to) alive for as long as any buffer of it
+  // is: a datum or an exported ArrowDeviceArray may outlive ahc_session_destroy.  Set by Session::Keep() wherever
+  // `session` is set.
+  std::shared_ptr<Session> keep;
   void* dptr = nullptr;
   int64_t size = 0;
   // foreign device memory (Arrow C Device Data Interface import): not freed here; `owner` keeps the
@@ -85,10 +89,12 @@ struct Buffer {
 };
 using BufferPtr = std::shared_ptr<Buffer>;
 
-class Session {
+class Session : public std::enable_shared_from_this<Session> {
  public:
-  static Status Create(int device_id, std::unique_ptr<Session>* out);
+  static Status Create(int device_id, std::shared_ptr<Session>* out);
   ~Session();
+  // buffers call this so that the session outlives them (Buffer::keep)
+  void Keep(Buffer* b) { b->session = this; b->keep = shared_from_this(); }
   ah_ctx* ctx() const { return ctx_; }
   // zero-filled like GoAllocator / Mallocator (quirk 4 in SURVEY.md §8a): kernels rely on it
   // zero_all = false: only the padding behind the last whole 64-byte block is cleared — for outputs whose every slot the

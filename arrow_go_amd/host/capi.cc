@@ -15,49 +15,16 @@
 #include "arrowhip_compute.h"
 #include "ipc.h"
 
-extern "C" {
-struct ArrowSchema {
-  const char* format;
-  const char* name;
-  const char* metadata;
-  int64_t flags;
-  int64_t n_children;
-  struct ArrowSchema** children;
-  struct ArrowSchema* dictionary;
-  void (*release)(struct ArrowSchema*);
-  void* private_data;
-};
-struct ArrowArray {
-  int64_t length;
-  int64_t null_count;
-  int64_t offset;
-  int64_t n_buffers;
-  int64_t n_children;
-  const void** buffers;
-  struct ArrowArray** children;
-  struct ArrowArray* dictionary;
-  void (*release)(struct ArrowArray*);
-  void* private_data;
-};
-// Arrow C Device Data Interface (arrow/cdata/abi.h:66-128)
-#define ARROW_DEVICE_CPU 1
-#define ARROW_DEVICE_ROCM 10
-#define ARROW_DEVICE_ROCM_HOST 11
-struct ArrowDeviceArray {
-  struct ArrowArray array;
-  int64_t device_id;
-  int32_t device_type;
-  void* sync_event;
-  int64_t reserved[3];
-};
-}
+// the public C header: the Arrow C Data / C Device Data structs and every ahc_* prototype — including it here makes the
+// compiler check each definition below against its declaration
+#include "../../include/arrowhip_compute.h"
 
 using namespace arrowhip;
 using compute::Datum;
 using compute::DatumKind;
 
 struct ahc_session {
-  std::unique_ptr<Session> session;
+  std::shared_ptr<Session> session;  // shared with every live buffer (Buffer::keep): destroying the handle never frees a pool a datum still returns memory to
   std::unique_ptr<compute::FunctionRegistry> child_registry;  // per-session registry, like SetExecCtx
   compute::ExecCtx ectx;
   std::string err;
@@ -511,8 +478,13 @@ AHC_EXPORT int ahc_import_device(ahc_session* s, ArrowDeviceArray* darr, ArrowSc
                                                std::to_string(ah_device_id(ss->ctx())));
   else if (!t)
     st = Status::Make(StatusCode::NotImplemented, std::string("unsupported Arrow format '") + (schema->format ? schema->format : "") + "'");
-  else if (darr->array.n_buffers < 2 || darr->array.n_children != 0 || darr->array.dictionary)
-    st = Status::Make(StatusCode::NotImplemented, "ArrowDeviceArray: fixed-width primitive layout only");
+  else if (darr->array.n_children != 0 || darr->array.dictionary)
+    st = Status::Make(StatusCode::NotImplemented, "ArrowDeviceArray: flat primitive / binary layouts only (no children, no dictionary)");
+  else if (darr->array.n_buffers != (IsBaseBinary(t->id) ? 3 : 2))
+    st = Status::Make(StatusCode::Invalid, std::string("ArrowDeviceArray: format '") + schema->format + "' needs " + (IsBaseBinary(t->id) ? "3" : "2") +
+                                               " buffers, the array has " + std::to_string(darr->array.n_buffers));
+  else if (darr->array.length < 0 || darr->array.offset < 0)
+    st = Status::Make(StatusCode::Invalid, "ArrowDeviceArray: negative length / offset");
   if (st.ok()) st = ss->FromStatus(ah_wait_event(ss->ctx(), darr->sync_event));
   if (!st.ok()) {
     if (darr->array.release) darr->array.release(&darr->array);
@@ -534,7 +506,7 @@ AHC_EXPORT int ahc_import_device(ahc_session* s, ArrowDeviceArray* darr, ArrowSc
   const int64_t dbytes = t->bit_width == 1 ? vbytes : nbits * (t->bit_width / 8);
   auto wrap = [&](const void* p, int64_t size) {
     auto b = std::make_shared<Buffer>();
-    b->session = ss;
+    ss->Keep(b.get());
     b->dptr = const_cast<void*>(p);
     b->size = size;
     b->owned = false;
@@ -543,8 +515,32 @@ AHC_EXPORT int ahc_import_device(ahc_session* s, ArrowDeviceArray* darr, ArrowSc
   };
   if (a.buffers[0] != nullptr && a.null_count != 0) d->buffers[0] = wrap(a.buffers[0], vbytes);
   else d->null_count = 0;
-  if (a.buffers[1] != nullptr) d->buffers[1] = wrap(a.buffers[1], dbytes);
-  else st = ss->Allocate(dbytes, &d->buffers[1]);  // zero-length arrays may carry no data buffer
+  if (IsBaseBinary(t->id)) {
+    // [validity, offsets (offset + length + 1 entries), data]: the data buffer's extent is the last offset, which lives on
+    // the device — one small read-back (the stream already waits for sync_event), as ImportCArray sizes it from the
+    // offsets on the host (arrow/cdata/cdata.go importStringLike)
+    const int w = t->bit_width / 8;
+    int64_t last = 0;
+    if (a.buffers[1] != nullptr) {
+      d->buffers[1] = wrap(a.buffers[1], (nbits + 1) * w);
+      if (w == 4) { int32_t v = 0; st = ss->FromStatus(ah_download_async(ss->ctx(), &v, (const uint8_t*)a.buffers[1] + nbits * 4, 4)); if (st.ok()) st = ss->FromStatus(ah_sync(ss->ctx())); last = v; }
+      else { st = ss->FromStatus(ah_download_async(ss->ctx(), &last, (const uint8_t*)a.buffers[1] + nbits * 8, 8)); if (st.ok()) st = ss->FromStatus(ah_sync(ss->ctx())); }
+      if (st.ok() && last < 0) st = Status::Make(StatusCode::Invalid, "ArrowDeviceArray: negative last offset");
+      if (st.ok() && last > 0 && a.buffers[2] == nullptr) st = Status::Make(StatusCode::Invalid, "ArrowDeviceArray: offsets reach " + std::to_string(last) + " bytes but there is no data buffer");
+    } else if (a.length + a.offset != 0) {
+      st = Status::Make(StatusCode::Invalid, "ArrowDeviceArray: binary array without an offsets buffer");
+    } else {  // an empty array may carry no offsets: give it the single zero Arrow asks for
+      st = ss->Allocate(w, &d->buffers[1]);
+    }
+    if (st.ok()) {
+      if (a.buffers[2] != nullptr) d->buffers[2] = wrap(a.buffers[2], last);
+      else st = ss->Allocate(0, &d->buffers[2]);
+    }
+  } else if (a.buffers[1] != nullptr) {
+    d->buffers[1] = wrap(a.buffers[1], dbytes);
+  } else {
+    st = ss->Allocate(dbytes, &d->buffers[1]);  // zero-length arrays may carry no data buffer
+  }
   if (schema->release) schema->release(schema);
   if (!st.ok()) return Fail(s, st);
   *out = new ahc_datum{Datum::Of(d)};
@@ -557,7 +553,7 @@ AHC_EXPORT int ahc_import_device(ahc_session* s, ArrowDeviceArray* darr, ArrowSc
 namespace {
 struct DeviceExportPriv {
   ArrayDataPtr keep;
-  const void* buffer_ptrs[2] = {nullptr, nullptr};
+  const void* buffer_ptrs[3] = {nullptr, nullptr, nullptr};
 };
 void ReleaseDeviceArray(ArrowArray* a) {
   delete (DeviceExportPriv*)a->private_data;
@@ -579,10 +575,12 @@ AHC_EXPORT int ahc_export_device(ahc_session* s, ahc_datum* d, ArrowDeviceArray*
   const bool has_nulls = a->buffers[0] && a->null_count != 0;
   p->buffer_ptrs[0] = has_nulls ? a->buffers[0]->dptr : nullptr;
   p->buffer_ptrs[1] = a->buffers[1] ? a->buffers[1]->dptr : nullptr;
+  const bool is_binary = IsBaseBinary(a->type->id);  // [validity, offsets, data] (arrow/cdata/cdata.go exportArray: one slot per layout buffer)
+  if (is_binary) p->buffer_ptrs[2] = a->buffers[2] ? a->buffers[2]->dptr : nullptr;
   out->array.length = a->length;
   out->array.null_count = has_nulls ? a->null_count : 0;
   out->array.offset = a->offset;
-  out->array.n_buffers = 2;
+  out->array.n_buffers = is_binary ? 3 : 2;
   out->array.buffers = p->buffer_ptrs;
   out->array.release = ReleaseDeviceArray;
   out->array.private_data = p;

@@ -60,8 +60,8 @@ Buffer::~Buffer() {
   if (owned && dptr && session && session->ctx()) session->Release(dptr, alloc_bytes);
 }
 
-Status Session::Create(int device_id, std::unique_ptr<Session>* out) {
-  std::unique_ptr<Session> s(new Session());
+Status Session::Create(int device_id, std::shared_ptr<Session>* out) {
+  std::shared_ptr<Session> s(new Session());
   int rc = ah_ctx_create(device_id, &s->ctx_);
   if (rc != AH_OK) return Status::Make(StatusCode::Hip, "ah_ctx_create failed (no GPU visible?) — there is no CPU fallback");
   *out = std::move(s);
@@ -100,7 +100,7 @@ Status Session::FromStatus(int st) const {
 }
 Status Session::Allocate(int64_t nbytes, BufferPtr* out, bool zero_all) {
   auto b = std::make_shared<Buffer>();
-  b->session = this;
+  Keep(b.get());
   b->size = nbytes;
   static const long long cap_env = getenv("ARROWHIP_POOL_BYTES") ? atoll(getenv("ARROWHIP_POOL_BYTES")) : -1;
   if (cap_env >= 0) pool_cap_ = (size_t)cap_env;

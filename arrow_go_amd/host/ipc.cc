@@ -303,7 +303,7 @@ Status StreamReader::LoadColumns(const uint8_t* meta, int64_t mlen, int64_t rb, 
   auto slice = [&](int64_t off, int64_t len) -> BufferPtr {
     if (dry) return nullptr;
     auto b = std::make_shared<Buffer>();
-    b->session = s_;
+    s_->Keep(b.get());
     b->dptr = (uint8_t*)dev->dptr + off;
     b->size = len;
     b->owned = false;
@@ -316,6 +316,9 @@ Status StreamReader::LoadColumns(const uint8_t* meta, int64_t mlen, int64_t rb, 
     const int64_t flen = fb.rd<int64_t>(ne), fnulls = fb.rd<int64_t>(ne + 8);
     if (fb.bad) return Invalid("invalid message metadata");
     if (flen != nrows) return Invalid("field '" + fi.name + "' has " + std::to_string(flen) + " rows, the batch " + std::to_string(nrows));
+    // every size below is flen × (≤ 8 bytes) or (flen + 1) × 8: a crafted length ≥ 2^60 would wrap those products to something
+    // small and pass the "buffer holds enough bytes" tests.  A row needs at least one bit of body, so bound it by that first.
+    if (flen < 0 || flen > blen * 8) return Invalid("field '" + fi.name + "': " + std::to_string(flen) + " rows cannot fit a " + std::to_string(blen) + "-byte body");
     if (fnulls < 0 || fnulls > flen) return Invalid("field '" + fi.name + "': null count " + std::to_string(fnulls));
     const bool encoded = fi.dict_id >= 0 && !as_values;   // the column holds indices into dictionary fi.dict_id
     if (encoded && !seen_dict_.count(fi.dict_id)) return Invalid("field '" + fi.name + "': no dictionary batch with id " + std::to_string(fi.dict_id) + " before the record batch");

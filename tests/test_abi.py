@@ -26,6 +26,33 @@ def test_exported_symbols_are_exactly_the_header():
     assert exported == N.declared_symbols()
 
 
+def _c_prototypes(header):
+    """function names a C header declares (comments stripped so that prose such as "foo(bar)" does not count)"""
+    text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ahc?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_compute_library_exports_exactly_its_header():
+    """libarrowhip_compute.so (the array-level C API: sessions, datums, ahc_call, IPC) == include/arrowhip_compute.h"""
+    lib_path = os.path.join(ROOT, "arrow_go_amd", "libarrowhip_compute.so")
+    header = os.path.join(ROOT, "include", "arrowhip_compute.h")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and not l.split()[-1].startswith("_Z"))
+    declared = _c_prototypes(header)
+    assert len(declared) >= 30
+    assert exported == declared
+    # ... and no C++ symbol leaks out of the library (everything else is hidden)
+    assert not [l for l in out.splitlines() if " T _Z" in l]
+
+
+def test_headers_are_plain_c():
+    """both boundary headers compile as C11 with nothing but the C library (what cgo does with them)"""
+    for h in ("arrowhip.h", "arrowhip_compute.h"):
+        src = '#include "%s"\nint main(void) { return 0; }\n' % h
+        subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                       input=src, text=True, check=True)
+
+
 def test_product_never_references_the_oracle():
     """A product path that routes through the oracle voids every parity claim."""
     pkg = os.path.join(ROOT, "arrow_go_amd")

@@ -111,3 +111,56 @@ def test_import_cpu_device_array_from_pyarrow(sess):
     da = ac.DeviceArray(sess, d)
     assert sess.call_function("add", [da, da]).to_pylist() == [2, None, 6, 8]
     da.release()
+
+
+def test_string_device_round_trip(sess, producer):
+    """String / binary layouts are [validity, offsets, data] (three buffers) on both sides of the device interface:
+    import wraps all three without a copy (the data extent comes from the last offset), export hands all three out."""
+    from arrow_go_amd import compute as ac
+    import arrow_go_amd as ah
+    rng = np.random.default_rng(3)
+    words = [("w%d" % i) * (i % 5) for i in range(40)]
+    for typ, name, odt in ((pa.string(), "string", np.int32), (pa.large_binary(), "large_binary", np.int64)):
+        vals = [words[j] for j in rng.integers(0, len(words), 1000)]
+        if name == "large_binary":
+            vals = [v.encode() for v in vals]
+        mask = rng.random(1000) < 0.2
+        arr = pa.array(vals, mask=mask, type=typ)
+        vbuf, obuf, dbuf = arr.buffers()
+        ob = producer.to_device(np.frombuffer(obuf, odt, 1001))
+        db = producer.to_device(np.frombuffer(dbuf, np.uint8))
+        vb = producer.to_device(np.frombuffer(vbuf, np.uint8))
+        producer.sync()
+        rel = []
+        a = sess.import_device(name, 900, ob.ptr, vb.ptr, null_count=-1, offset=50, var_data_ptr=db.ptr, on_release=lambda: rel.append(1))
+        assert a.to_arrow().equals(arr.slice(50, 900))
+        idx = pa.array(rng.integers(0, 900, 300), pa.int32())
+        assert sess.call_function("take", [a, idx]).equals(pc.take(arr.slice(50, 900), idx))
+        darr, sch = a.export_device()
+        assert darr.array.n_buffers == 3 and sch.format == {"string": b"u", "large_binary": b"Z"}[name]
+        assert (darr.array.buffers[1], darr.array.buffers[2]) == (ob.ptr, db.ptr)    # zero copy both ways
+        assert darr.array.offset == 50 and darr.array.length == 900
+        darr.array.release(C.byref(darr.array))
+        a.release()
+        assert rel == [1]
+        # a fixed-width array with 3 buffers / a string array with 2: rejected, the producer's array released
+        with pytest.raises(ac.ErrInvalid, match="needs 3 buffers"):
+            sess.import_device(name, 10, ob.ptr, n_buffers=2, on_release=lambda: rel.append(2))
+        with pytest.raises(ac.ErrInvalid, match="needs 2 buffers"):
+            sess.import_device("int64", 10, ob.ptr, n_buffers=3, on_release=lambda: rel.append(3))
+        assert rel == [1, 2, 3]
+
+
+def test_datum_outlives_session(producer):
+    """a datum (and the pooled blocks behind it) released after its session was destroyed must not touch freed memory:
+    buffers keep the session's context and pool alive (Buffer::keep)"""
+    from arrow_go_amd import compute as ac
+    with ac.Session(0) as s:
+        d = s.call_function("add", [pa.array(np.arange(100000)), pa.scalar(1)], keep_on_device=True)
+        kept_ptr = d.buffers()[1]
+    host = np.zeros(100000, np.int64)
+    import arrow_go_amd as ah
+    ah._native.check(producer.handle, ah._native.lib.ah_download_async(producer.handle, host.ctypes.data, kept_ptr, host.nbytes))
+    producer.sync()
+    assert host[-1] == 100000                     # the memory is still the datum's
+    d.release()                                   # last reference: block goes back to the (still alive) pool, then the pool is freed

@@ -214,3 +214,20 @@ def test_read_ipc_large_batch(sess):
     assert [g[2] for g in got] == [n, 1000]
     assert sess.math_sum(got[0][1][0]) == int(np.asarray(b.column(0)).sum())
     assert got[1][1][1].to_arrow().equals(b.column(1).slice(5, 1000))
+
+
+def test_inspect_rejects_row_counts_that_would_wrap_the_size_checks():
+    """a crafted RecordBatch.length / FieldNode.length ≥ 2^60 would wrap `rows × width` to a small number and pass the
+    "buffer holds enough bytes" tests; the reader bounds the row count by the body size first (Go would panic on the slice)"""
+    schema = pa.schema([("x", pa.int64())])
+    n = 12345
+    raw = bytearray(make_stream([pa.record_batch([pa.array(np.arange(n))], schema=schema)], schema).to_pybytes())
+    pat = struct.pack("<q", n)
+    hits = [i for i in range(len(raw) - 8) if raw[i:i + 8] == pat and i < len(raw) - 8 * n]   # metadata only, not the body
+    assert len(hits) >= 2                       # RecordBatch.length and the FieldNode's length
+    for big in (1 << 61, (1 << 61) + 1, 1 << 62):
+        b = bytearray(raw)
+        for i in hits:
+            b[i:i + 8] = struct.pack("<q", big)
+        with pytest.raises(ac.ErrInvalid, match="cannot fit|rows"):
+            ac.ipc_inspect(bytes(b))
