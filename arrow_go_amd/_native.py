@@ -99,6 +99,7 @@ _SIGS = {
     "ah_ctx_create": [_int, _pvp],
     "ah_ctx_create_on_stream": [_int, _vp, _pvp],
     "ah_device_count": [_pint],
+    "ah_ctx_set_option": [_vp, C.c_char_p, _i64],
     "ah_buf_alloc": [_vp, _sz, _pvp],
     "ah_buf_free": [_vp, _vp],
     "ah_host_alloc_pinned": [_vp, _sz, _pvp],

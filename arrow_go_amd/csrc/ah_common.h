@@ -35,6 +35,9 @@ struct ah_ctx {
   // tunables (env ARROWHIP_NT / ARROWHIP_BLOCKS_PER_CU, read at ctx creation)
   int tune_nt;             // 1: nontemporal loads/stores on streaming kernels
   int tune_blocks_per_cu;  // grid cap for grid-stride streaming kernels
+  // take (ah_take_binned.hip): ARROWHIP_TAKE_BINNED 0 never / 1 auto / 2 whenever legal; _WINDOW_LOG2 bytes of `values` per
+  // bin; _GATHER_WG_PER_CU occupancy cap of the gather pass.  Also settable per context: ah_ctx_set_option.
+  int opt_take_binned, opt_take_window_log2, opt_take_gather_wg, opt_take_gather_load;
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   char err[512];
 };
@@ -87,6 +90,10 @@ void ah_expr_cache_free(ah_ctx* ctx);  // ah_expr.hip
 int ah_partition_by_group(ah_ctx* ctx, const int32_t* ids, const unsigned long long* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
                           int shift, int passes, unsigned* hist, unsigned* offs, unsigned long long* alt_vals, unsigned* alt_ids,
                           unsigned long long* out_vals, unsigned* out_ids);
+// internal (ah_take_binned.hip): Take for random indices into a column the caches cannot hold; *used says whether it ran
+int ah_take_binned_try(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int iw,
+                       int is_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values,
+                       uint8_t* out_valid, unsigned long long* first_bad, int* used);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are

@@ -32,6 +32,11 @@ static int ctx_init_common(ah_ctx* c) {
   c->tune_nt = e_nt ? atoi(e_nt) : 1;
   const char* e_bpc = getenv("ARROWHIP_BLOCKS_PER_CU");
   c->tune_blocks_per_cu = e_bpc ? atoi(e_bpc) : 0;  // 0 = each kernel's own default
+  auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  c->opt_take_binned = env_int("ARROWHIP_TAKE_BINNED", 1);
+  c->opt_take_window_log2 = env_int("ARROWHIP_TAKE_WINDOW_LOG2", 22);
+  c->opt_take_gather_wg = env_int("ARROWHIP_TAKE_GATHER_WG_PER_CU", 8);
+  c->opt_take_gather_load = env_int("ARROWHIP_TAKE_GATHER_LOAD", 0);   // 0 plain, 1 nontemporal, 2 L1-bypassing (sc1)
   return AH_OK;
 }
 
@@ -81,6 +86,20 @@ AH_EXPORT void ah_ctx_destroy(ah_ctx* c) {
   (void)hipStreamDestroy(c->copy_stream);
   if (c->owns_stream) (void)hipStreamDestroy(c->stream);
   free(c);
+}
+
+// measurement / test switches of one context (none of them changes a result; DESIGN.md §6 lists them)
+AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
+  AH_ENTER(c);
+  if (!name) return ah_fail(c, AH_EINVALID, "set_option: null name");
+  if (!strcmp(name, "nt")) c->tune_nt = (int)value;
+  else if (!strcmp(name, "blocks_per_cu")) c->tune_blocks_per_cu = (int)value;
+  else if (!strcmp(name, "take_binned")) c->opt_take_binned = (int)value;
+  else if (!strcmp(name, "take_window_log2")) c->opt_take_window_log2 = (int)value;
+  else if (!strcmp(name, "take_gather_wg_per_cu")) c->opt_take_gather_wg = (int)value;
+  else if (!strcmp(name, "take_gather_load")) c->opt_take_gather_load = (int)value;
+  else return ah_fail(c, AH_EINVALID, "set_option: unknown option '%s'", name);
+  return AH_OK;
 }
 
 AH_EXPORT const char* ah_last_error(ah_ctx* c) { return c ? c->err : "null context"; }

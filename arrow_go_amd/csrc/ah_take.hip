@@ -47,15 +47,29 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
   const int64_t n_iters = (nidx + (int64_t)kBlock * kUnroll - 1) / ((int64_t)kBlock * kUnroll);
   for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
     const int64_t base = it * kBlock * kUnroll + threadIdx.x;
+    // two memory round trips, not four: {index, index-validity byte} go out together, then {value, value-validity byte}
+    // (each pair used to be a dependent chain: with 10 % nulls the identity take ran at 2.2 TB/s against 5.2 without)
     uint64_t u[kUnroll];
     bool ok[kUnroll];
+    IdxT raw[kUnroll];
+    uint8_t ib[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; k++) {
+      const int64_t i = base + (int64_t)k * kBlock;
+      raw[k] = 0;
+      ib[k] = 0xff;
+      if (i < nidx) {
+        raw[k] = idx[i];
+        if (ivalid != nullptr) ib[k] = ivalid[(ioff + i) >> 3];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       const int64_t i = base + (int64_t)k * kBlock;
       ok[k] = false;
       u[k] = 0;
-      if (i < nidx && ah_bit(ivalid, ioff + i)) {
-        IdxT s = idx[i];
+      if (i < nidx && ((ib[k] >> ((ioff + i) & 7)) & 1)) {
+        const IdxT s = raw[k];
         u[k] = (uint64_t)(UIdx)s;  // reinterpret as unsigned of the same width
         bool oob = (std::is_signed<IdxT>::value && s < 0) || u[k] >= nvalues;  // helpers.go:937-939
         if (oob) atomicMin(first_bad, (unsigned long long)i);
@@ -63,13 +77,20 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
       }
     }
     T v[kUnroll];
+    uint8_t vb[kUnroll];
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       v[k] = 0;
+      vb[k] = 0xff;
       if (ok[k]) {
-        if (HAS_VALID && vvalid != nullptr && !ah_bit(vvalid, voff + (int64_t)u[k])) ok[k] = false;
-        else v[k] = values[u[k]];
+        v[k] = values[u[k]];
+        if (HAS_VALID && vvalid != nullptr) vb[k] = vvalid[(voff + (int64_t)u[k]) >> 3];
       }
+    }
+    if (HAS_VALID) {
+#pragma unroll
+      for (int k = 0; k < kUnroll; k++)
+        if (!((vb[k] >> ((voff + (int64_t)u[k]) & 7)) & 1)) { ok[k] = false; v[k] = 0; }
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
@@ -82,8 +103,9 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
           int64_t left = nidx - i0;
           uint8_t* p = out_valid + (i0 >> 3);
           if (left >= 64) {
-#pragma unroll
-            for (int bb = 0; bb < 8; bb++) p[bb] = (uint8_t)(word >> (8 * bb));
+            // i0 is a multiple of 64, so p is as aligned as out_valid itself: one 8-byte store (unaligned global access is
+            // legal on gfx950) instead of eight 1-byte stores — with nulls the identity take ran at 2.2 TB/s against 5.2 without
+            *(uint64_t*)p = word;
           } else {
             int nbytes = (int)((left + 7) >> 3);
             for (int bb = 0; bb < nbytes; bb++) p[bb] = (uint8_t)(word >> (8 * bb));
@@ -180,8 +202,12 @@ AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, c
   unsigned long long* valid_total = (unsigned long long*)&c->dscalars[2];
   AH_HIP(c, hipMemsetAsync(first_bad, 0xFF, sizeof(*first_bad), c->stream));
   AH_HIP(c, hipMemsetAsync(valid_total, 0, sizeof(*valid_total), c->stream));
-  int rc;
-  switch (byte_width) {
+  int rc, binned = 0;
+  // random indices into a column beyond the caches: bin → gather in L2-sized windows → unpermute (ah_take_binned.hip)
+  rc = ah_take_binned_try(c, byte_width, values, vvalid, voff, nvalues, idx_byte_width, idx_signed, idx, ivalid, ioff, nidx, out_values, out_valid,
+                          first_bad, &binned);
+  if (rc != AH_OK) return rc;
+  if (!binned) switch (byte_width) {
     case 1: rc = dispatch_idx<1>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 2: rc = dispatch_idx<2>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 4: rc = dispatch_idx<4>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;

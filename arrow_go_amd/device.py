@@ -99,6 +99,10 @@ class Context:
     def sync(self) -> None:
         check(self.handle, lib.ah_sync(self.handle))
 
+    def set_option(self, name: str, value: int) -> None:
+        """measurement / test switch of this context (ah_ctx_set_option); never changes a result"""
+        check(self.handle, lib.ah_ctx_set_option(self.handle, name.encode(), int(value)))
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 

@@ -299,6 +299,48 @@ def test_take_first_bad_index_random(hip, orc_be):
         assert g[0] == e[0] == STATUS_EINDEX and g[4] == e[4]
 
 
+@pytest.mark.parametrize("vdtype", [np.uint8, np.int16, np.float32, np.int64])
+def test_take_binned_path_bit_exact(ctx, hip, orc_be, vdtype):
+    """the binned path (ah_take_binned.hip: bin → L2-window gather → unpermute), forced on at sizes the oracle does in
+    milliseconds: every index type, nulls on either side, bit offsets, ragged last tile, skewed and empty bins, tiny windows"""
+    rng = np.random.default_rng(53)
+    ctx.set_option("take_binned", 2)
+    try:
+        for window_log2, nvalues, nidx in [(21, 300_000, 8192), (12, 70_001, 100_003), (10, 5_000, 40_000), (14, 1_000_000, 250_007)]:
+            ctx.set_option("take_window_log2", window_log2)
+            vals = rand(rng, vdtype, nvalues)
+            for idtype in (np.int32, np.uint32, np.int64, np.uint64, np.int16, np.uint8):
+                hi = min(nvalues, np.iinfo(idtype).max + 1)
+                idx = rng.integers(0, hi, nidx).astype(idtype)
+                if idtype == np.int32:   # skew: half the indices in one window, a stretch of empty windows
+                    idx[::2] = rng.integers(0, min(hi, 300), (nidx + 1) // 2).astype(idtype)
+                for voff, ioff in [(0, 0), (5, 3)]:
+                    nv = nvalues - voff
+                    ix = np.minimum(idx.astype(np.int64), nv - 1).astype(idtype)
+                    for vvalid, ivalid in [(None, None), (rand_bits(rng, nvalues + 8, 0.9), None), (None, rand_bits(rng, ioff + nidx + 8, 0.9)),
+                                           (rand_bits(rng, nvalues + 8, 0.5), rand_bits(rng, ioff + nidx + 8, 0.5))]:
+                        want_valid = vvalid is not None or ivalid is not None
+                        g = hip.take(vals[voff:], vvalid, voff, ix, ivalid, ioff, True, want_valid)
+                        e = orc_be.take(vals[voff:], vvalid, voff, ix, ivalid, ioff, True, want_valid)
+                        assert g[0] == e[0] == STATUS_OK
+                        assert g[1].tobytes() == e[1].tobytes(), (vdtype, idtype, nvalues, nidx, voff, window_log2)
+                        if want_valid:
+                            assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+        # bounds: the first offender in index order, null slots not checked
+        vals = rand(rng, vdtype, 50_000)
+        idx = rng.integers(0, 50_000, 60_000).astype(np.int32)
+        bad = rng.integers(0, 60_000, 20)
+        idx[bad] = rng.integers(50_000, 1 << 30, 20)
+        idx[bad[::2]] *= -1
+        for iv in (None, rand_bits(rng, 60_000, 0.7)):
+            g = hip.take(vals, None, 0, idx, iv, 0, True, iv is not None)
+            e = orc_be.take(vals, None, 0, idx, iv, 0, True, iv is not None)
+            assert g[0] == e[0] == STATUS_EINDEX and g[4] == e[4]
+    finally:
+        ctx.set_option("take_binned", 1)
+        ctx.set_option("take_window_log2", 22)
+
+
 # ---- hashing ------------------------------------------------------------------------------
 @pytest.mark.parametrize("card", [1, 7, 1000, 40000])
 def test_hash_encode_first_seen_order(hip, orc_be, card):
