@@ -58,9 +58,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--rows", type=int, default=1 << 27, help="rows per GPU (default 2^27 = 1 GiB columns)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--c5-merge", action="store_true",
-                   help="C5 secondary line: also merge the per-GPU aggregates by key-hash owner (ragged all-to-all); off by default so "
-                        "that the headline never depends on a collective that world size 1 cannot exercise")
+    p.add_argument("--no-c5-merge", action="store_true",
+                   help="C5 secondary line: skip the merge of the per-GPU aggregates by key-hash owner (all-to-all of group tuples over "
+                        "RCCL), which is ON whenever more than one rank runs — the config is 'partitioned by key-hash over xGMI'")
     p.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table")
     p.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch of the Add kernel from a rocprofv3 --pmc pass")
     return p.parse_args()
@@ -86,33 +86,63 @@ def fill_random(ctx, buf, rows, dtype, seed):
 
 
 def cpu_baseline(sample_rows, reps):
-    """Reference AVX2 kernels (or, if oracle/_ref was never built, our C port) on one core."""
+    """Reference AVX2 kernels (or, if oracle/_ref was never built, our C port) on one core.  The Add writes into a
+    PREALLOCATED, already-touched output (the rate of the kernel itself); the rate with a fresh zero-filled output per call —
+    what the Go executor pays through memory.Allocator, page faults included — is reported beside it in `sample`."""
+    import ctypes as C
     from tests import oracle_lib as OL
     ref = OL.load_reference()
     rng = np.random.default_rng(1)
     a = rng.integers(-2**62, 2**62, sample_rows, dtype=np.int64)
     b = rng.integers(-2**62, 2**62, sample_rows, dtype=np.int64)
     x = rng.uniform(-1e6, 1e6, sample_rows)
+    out = np.ones(sample_rows, np.int64)
     if ref is not None:
         kind = "reference"
-        add = lambda: ref.arithmetic(0, 0, a, b)
+        f = ref.avx2.arithmetic_binary_avx2
+        f.restype = None
+        f.argtypes = [C.c_int, C.c_int8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        add = lambda: f(OL.TYPE_IDS[a.dtype], 0, a.ctypes.data, b.ctypes.data, out.ctypes.data, sample_rows)
+        add_alloc = lambda: ref.arithmetic(0, 0, a, b)
         ssum = lambda: ref.sum("avx2", x)
     else:
         kind = "port"
         o = OL.load_oracle()
-        add = lambda: o.arithmetic(0, 0, a, b)
+        add = add_alloc = lambda: o.arithmetic(0, 0, a, b)
         ssum = lambda: o.sum_float64_seq(x)
-    add(); ssum()  # warm
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        add()
-        ssum()
-    dt = time.perf_counter() - t0
-    gbs = 32.0 * sample_rows * reps / dt / 1e9
+
+    def rate(add_fn):
+        add_fn(); ssum()  # warm
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            add_fn()
+            ssum()
+        return 32.0 * sample_rows * reps / (time.perf_counter() - t0) / 1e9
+
+    gbs, gbs_alloc = rate(add), rate(add_alloc)
+    assert out.tobytes() == (a + b).tobytes(), "cpu baseline: reference Add produced wrong values"
     return {"value": round(gbs, 3), "unit": "GB/s", "cores": 1, "kind": kind,
             "sample": f"{reps} steps of Int64 Add + Float64 Sum over {sample_rows} rows "
                       f"({'reference AVX2 machine code, oracle/_ref/libref_avx2.so' if kind == 'reference' else 'oracle C port'}; "
-                      f"includes the output allocation the Go executor also pays), host has {os.cpu_count()} logical cores"}
+                      f"output preallocated and touched; {gbs_alloc:.1f} GB/s with a fresh zero-filled output per call = first touch "
+                      f"included, as the Go executor pays), host has {os.cpu_count()} logical cores"}
+
+
+def random_bits(rng, n, p, pad=64):
+    """n Bernoulli(p) bits packed LSB-first"""
+    out = np.zeros(n // 8 + pad, np.uint8)
+    for i in range(0, n, 1 << 24):
+        m = min(1 << 24, n - i)
+        out[i // 8:i // 8 + (m + 7) // 8] = np.packbits(rng.random(m) < p, bitorder="little")
+    return out
+
+
+def zipf_ranks(rng, n, card, s=1.1):
+    """ranks of a Zipf(s) distribution truncated to `card` values (inverse CDF)"""
+    w = 1.0 / np.arange(1, card + 1) ** s
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    return np.searchsorted(cdf, rng.random(n)).astype(np.uint64)
 
 
 def per_kernel_table(ctx, rows, a, b, c, x):
@@ -140,31 +170,66 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     mask = ctx.alloc(rows // 8 + 64)
     thr = np.array([0], np.int64)
     timed("greater_int64_scalar", 8.125 * rows, lambda: ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT64, a, thr, mask, rows, 0))
-    # C3: Filter on a 1 GiB Int64 column with 10 % nulls, ~50 % selectivity (mask = a > 0)
+    # ---- C3: Filter on a 1 GiB Int64 column with 10 % value nulls: Bernoulli masks at four selectivities, Drop;
+    # Drop / Emit with 10 % mask nulls; a mask of geometric runs (mean 256).  Per line: "GB/s" = the full algorithmic traffic
+    # 8 + 1/8 (mask) + 1/8 (value validity) [+ 1/8 mask validity] per input row + (8 + 1/8) per output row; "input_GB/s" = 8·n / t,
+    # the "GB/s processed" headline of BASELINE.md.
     rng = np.random.default_rng(5)
-    vbits = np.packbits(rng.random(1 << 22) < 0.9, bitorder="little")
-    vvalid = ctx.alloc(rows // 8 + 64)
-    for off in range(0, rows // 8, vbits.size):
-        vvalid.upload(vbits[:min(vbits.size, rows // 8 - off)], off)
-    n_out = ctx.filter_count(mask, None, 0, rows, 0)
-    s = n_out / rows
+    vvalid = ctx.to_device(random_bits(rng, rows, 0.9))
     ovalid = ctx.alloc(rows // 8 + 64)
-    timed("filter_int64_nulls10_sel%.2f" % s, (8 + 0.125 + 0.125) * rows + (8 + 0.125) * n_out,
-          lambda: ctx.filter_primitive(8, a, vvalid, 0, mask, None, 0, rows, 0, n_out, c, ovalid, want_null_count=False))
-    out["filter_input_GB/s"] = round(8 * rows / out["filter_int64_nulls10_sel%.2f" % s]["ms"] / 1e6, 1)
-    timed("filter_count", 0.125 * rows, lambda: ctx.filter_count(mask, None, 0, rows, 0))
-    # C3: Take, int32 indices (random / sorted-identity) into the 1 GiB column
-    idx = ctx.alloc(rows * 4)
-    ichunk = rng.integers(0, rows, 1 << 22, dtype=np.int64).astype(np.int32)
-    for off in range(0, rows, 1 << 22):
-        idx.upload(ichunk[:min(1 << 22, rows - off)], off * 4)
-    timed("take_int64_random_i32", 20 * rows,
-          lambda: ctx.take_primitive(8, a, None, 0, rows, 4, True, idx, None, 0, rows, True, c, None), reps=3)
-    for off in range(0, rows, 1 << 22):
-        m = min(1 << 22, rows - off)
-        idx.upload(np.arange(off, off + m, dtype=np.int32), off * 4)
-    timed("take_int64_identity_i32", 20 * rows,
-          lambda: ctx.take_primitive(8, a, None, 0, rows, 4, True, idx, None, 0, rows, True, c, None), reps=3)
+    fmask = ctx.alloc(rows // 8 + 64)
+    fvalid = ctx.to_device(random_bits(rng, rows, 0.9))
+
+    def filter_case(name, fv, null_sel):
+        n_out = ctx.filter_count(fmask, fv, 0, rows, null_sel)
+        traffic = (8 + 0.125 + 0.125 + (0.125 if fv is not None else 0)) * rows + (8 + 0.125) * n_out
+        timed(name, traffic, lambda: ctx.filter_primitive(8, a, vvalid, 0, fmask, fv, 0, rows, null_sel, n_out, c, ovalid, want_null_count=False))
+        out[name]["input_GB/s"] = round(8 * rows / out[name]["ms"] / 1e6, 1)
+        out[name]["selected"] = round(n_out / rows, 4)
+
+    for sel in (0.01, 0.1, 0.5, 0.9):
+        fmask.upload(random_bits(rng, rows, sel))
+        filter_case("filter_int64_nulls10_sel%.2f" % sel, None, 0)
+        if sel == 0.5:
+            filter_case("filter_int64_nulls10_sel0.50_masknulls10_drop", fvalid, 0)
+            filter_case("filter_int64_nulls10_sel0.50_masknulls10_emit", fvalid, 1)
+    runs = rng.geometric(1 / 256, rows // 200)
+    on = np.repeat(np.arange(runs.size) % 2 == 0, runs)[:rows]
+    fmask.upload(np.packbits(np.concatenate([on, np.zeros(rows - on.size, bool)]), bitorder="little"))
+    del runs, on
+    filter_case("filter_int64_nulls10_runs256", None, 0)
+    out["filter_input_GB/s"] = out["filter_int64_nulls10_sel0.50"]["input_GB/s"]
+    timed("filter_count", 0.125 * rows, lambda: ctx.filter_count(fmask, None, 0, rows, 0))
+    # mask for the later lines (bitmap_and, count_set_bits): a > 0
+    ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT64, a, thr, mask, rows, 0)
+    # ---- C3: Take, 2^27 int32 indices into the 1 GiB column.  "random" = 2^27 INDEPENDENT uniform draws over [0, rows) —
+    # every line of the column is a target; with 10 % nulls on both sides (the stated config) and without; then sorted-random,
+    # identity, reverse.  20 algorithmic bytes per output row (+ 3/8 with validity: two bitmaps read, one written).
+    idx = ctx.alloc(rows * 4 + 64)
+    ivalid = ctx.to_device(random_bits(rng, rows, 0.9))
+    ridx = rng.integers(0, rows, rows, dtype=np.int32)
+
+    def take_case(name, nulls, reps=3):
+        timed(name, (20 + (0.375 if nulls else 0)) * rows,
+              lambda: ctx.take_primitive(8, a, vvalid if nulls else None, 0, rows, 4, True, idx, ivalid if nulls else None, 0, rows, True, c,
+                                         ovalid if nulls else None), reps=reps)
+
+    idx.upload(ridx)
+    take_case("take_int64_random_i32_nulls10", True)
+    take_case("take_int64_random_i32", False)
+    ctx.set_option("take_binned", 0)
+    take_case("take_int64_random_i32_nulls10_direct_kernel", True)
+    ctx.set_option("take_binned", 1)
+    ridx.sort()
+    idx.upload(ridx)
+    take_case("take_int64_sorted_random_i32_nulls10", True)
+    del ridx
+    idx.upload(np.arange(rows, dtype=np.int32))
+    take_case("take_int64_identity_i32", False)
+    take_case("take_int64_identity_i32_nulls10", True)
+    idx.upload(np.arange(rows - 1, -1, -1, dtype=np.int32))
+    take_case("take_int64_reverse_i32_nulls10", True)
+    fmask.free(); fvalid.free(); ivalid.free()
     timed("fused_gt_filter_sum_int64", 8 * rows, lambda: ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, res))
     timed("fused_gt_filter_sum_int64_nulls10", 8.125 * rows, lambda: ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, vvalid, 0, rows, 0, res))
     # (f) rows: cumulative_sum (16 B/row algorithmic; 24 moved: reduce-then-scan) and numeric cast (w_in + w_out)
@@ -182,18 +247,21 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     timed("min_max_int64", 8 * rows, lambda: ctx.min_max(N.INT64, a, rows, np.int64))
     timed("bitmap_and", 0.375 * rows, lambda: ctx.bitmap_op(N.BIT_AND, mask, 0, vvalid, 0, ovalid, 0, rows))
     timed("count_set_bits", 0.125 * rows, lambda: ctx.count_set_bits(mask, 0, rows))
-    # C5 per GPU: 2^26 Int64 keys (512 MiB; 4 GiB over 8 GPUs) + Float64 values — dictionary_encode and hash + sum.
+    # ---- C5 per GPU: 2^26 Int64 keys (512 MiB; 4 GiB over 8 GPUs) + Float64 values — dictionary_encode and hash + sum at the
+    # cardinalities of SURVEY §8d, uniform keys, plus one Zipf(1.1) column over 2^20 keys.  Keys are 2^26 independent draws.
     # Algorithmic bytes: 8 (key) + 4 (id) per row for encode, 8 + 8 for the group-by (outputs are per group).
     hrows = min(rows, 1 << 26)
     hids = ctx.alloc(hrows * 4 + 64)
     hdic, hsum, hcnt = (ctx.alloc((hrows + 1) * 8 + 64) for _ in range(3))
-    for lg in (10, 16, 20):
-        kchunk = (rng.integers(0, 1 << lg, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
-        for off in range(0, hrows, 1 << 22):
-            c.upload(kchunk[:min(1 << 22, hrows - off)], off * 8)
-        timed("dictionary_encode_int64_2^%d_keys" % lg, 12 * hrows, lambda: ctx.hash_u64_encode(c, None, 0, hrows, False, hids, None, hdic), reps=3)
-        timed("hash_sum_float64_2^%d_groups" % lg, 16 * hrows, lambda: ctx.hash_sum("f64", c, None, 0, x, None, 0, hrows, hdic, hsum, hcnt), reps=3)
-        out["hash_sum_float64_2^%d_groups" % lg]["Grows/s"] = round(hrows / out["hash_sum_float64_2^%d_groups" % lg]["ms"] / 1e6, 2)
+    mult = np.uint64(0x9E3779B97F4A7C15)
+    for lg, dist in ((10, "uniform"), (16, "uniform"), (20, "uniform"), (24, "uniform"), (20, "zipf1.1")):
+        ranks = zipf_ranks(rng, hrows, 1 << lg) if dist != "uniform" else rng.integers(0, 1 << lg, hrows, dtype=np.uint64)
+        c.upload((ranks * mult).view(np.int64))
+        del ranks
+        tag = "2^%d_%s" % (lg, dist) if dist != "uniform" else "2^%d" % lg
+        timed("dictionary_encode_int64_%s_keys" % tag, 12 * hrows, lambda: ctx.hash_u64_encode(c, None, 0, hrows, False, hids, None, hdic), reps=3)
+        timed("hash_sum_float64_%s_groups" % tag, 16 * hrows, lambda: ctx.hash_sum("f64", c, None, 0, x, None, 0, hrows, hdic, hsum, hcnt), reps=3)
+        out["hash_sum_float64_%s_groups" % tag]["Grows/s"] = round(hrows / out["hash_sum_float64_%s_groups" % tag]["ms"] / 1e6, 2)
     for bfr in (res, mask, vvalid, ovalid, idx, hids, hdic, hsum, hcnt):
         bfr.free()
     return out
@@ -319,7 +387,7 @@ def main():
         kchunk = (krng.integers(0, 1 << 16, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
         for off in range(0, hrows, 1 << 22):
             c.upload(kchunk[:min(1 << 22, hrows - off)], off * 8)
-        merge = use_dist and args.c5_merge
+        merge = use_dist and world > 1 and not args.no_c5_merge
         if merge:
             from arrow_go_amd.distributed import HipLocal, ShardedCompute
             local = HipLocal.__new__(HipLocal); local.ctx = ctx; local.N = N        # share this rank's context / stream
@@ -352,7 +420,7 @@ def main():
             c5_dt = float(t.item())
         c5_ms = c5_dt * 1e3 / c5_steps
         c5 = {"workload": "C5: hash + sum group-by over Int64 keys / Float64 values per GPU" + (", merged by key-hash owner (all-to-all of group tuples)" if merge else
-                                                                                                        " (local aggregates; --c5-merge adds the owner merge)"),
+                                                                                                        " (local aggregate; the owner merge over RCCL runs when world > 1)"),
               "ms_per_step": round(c5_ms, 4), "Grows/s": round(hrows * args.gpus / (c5_ms * 1e-3) / 1e9, 2), "rows_per_gpu": hrows,
               "groups": ngroups[0], "n_gpus": args.gpus, "steps": c5_steps}
     except Exception as e:  # informative only
