@@ -38,6 +38,7 @@ struct ah_ctx {
   // take (ah_take_binned.hip): ARROWHIP_TAKE_BINNED 0 never / 1 auto / 2 whenever legal; _WINDOW_LOG2 bytes of `values` per
   // bin; _GATHER_WG_PER_CU occupancy cap of the gather pass.  Also settable per context: ah_ctx_set_option.
   int opt_take_binned, opt_take_window_log2, opt_take_gather_wg, opt_take_gather_load;
+  int opt_scan_segment_log2;   // cumulative_sum: bytes of input per segment (ARROWHIP_SCAN_SEGMENT_LOG2; 0 = one segment)
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   char err[512];
 };

@@ -30,6 +30,7 @@
 //
 // HBM: 8 B/row of keys + random 16-byte slot traffic (atomics-bound at high
 // cardinality, cache-resident at low cardinality).
+#include <type_traits>
 #include "ah_common.h"
 
 namespace {
@@ -420,6 +421,83 @@ __global__ __launch_bounds__(kSmallBlock) void insert_small_kernel(const unsigne
   if (nmiss) atomicAdd(misses, (unsigned long long)nmiss);
 }
 
+// ---- deterministic Float64 group sums: fixed point --------------------------------------------------------------
+// fp64 atomic adds make a group's sum depend on the order the hardware happens to perform them in.  Integer addition
+// is associative, so every value is converted to a 128-bit fixed-point number  q = trunc(x · 2^sh),  sh = 94 − emax,
+// emax = exponent of the largest finite |x| of the call (|q| < 2^95; 2^30 rows cannot overflow 2^127), accumulated with
+// 64-bit integer atomics (low word with carry into the high word — each addend derives its own carry from the value
+// its atomic returned, so any interleaving gives the same 128 bits), and rounded to double ONCE at the end.
+// Result: identical bytes run to run, on any launch geometry; error ≤ ½ulp(Σ) + n_g·2^(emax−94) — inside the
+// n_g·ε·Σ|x| of the sequential definition (oracle/orc_hash.c).  ±inf / NaN addends are tallied as three flag bits per
+// group and give the IEEE result of any order: NaN if a NaN or both infinities were seen, else the infinity.
+struct FxAcc {  // global accumulators of one call (device pointers); null for integer sums
+  unsigned long long* lo;
+  unsigned long long* hi;
+  unsigned* flags;
+  const unsigned long long* absmax;  // bit pattern of the largest finite |x|
+};
+__device__ __forceinline__ int fx_shift(unsigned long long absmax_bits) {
+  const int e = (int)((absmax_bits >> 52) & 0x7ff);
+  return 94 - ((e ? e : 1) - 1023);
+}
+__device__ __forceinline__ bool fx_finite(double x) { return ((__builtin_bit_cast(unsigned long long, x) >> 52) & 0x7ff) != 0x7ff; }
+__device__ __forceinline__ unsigned fx_flag(double x) { return x != x ? 1u : (x > 0 ? 2u : 4u); }   // NaN, +inf, −inf
+__device__ __forceinline__ void fx_split(double x, int sh, unsigned long long* lo, unsigned long long* hi) {
+  const double t = trunc(ldexp(fabs(x), sh));           // integer-valued, < 2^95
+  const double h = floor(t * 0x1p-64);                  // exact: a power-of-two scaling; < 2^31
+  const double r = t - h * 0x1p64;                      // exact: the bits of t below 2^64 (a subset of its 53)
+  unsigned long long l = (unsigned long long)r, u = (unsigned long long)h;
+  if (x < 0) { l = ~l + 1; u = ~u + (l == 0 ? 1 : 0); }  // two's complement of the 128-bit magnitude
+  *lo = l;
+  *hi = u;
+}
+template <typename P>   // P = pointer into LDS or global memory
+__device__ __forceinline__ void fx_add(P lo_arr, P hi_arr, size_t g, unsigned long long lo, unsigned long long hi) {
+  const unsigned long long old = atomicAdd(&lo_arr[g], lo);
+  const unsigned long long carry = old + lo < old ? 1ull : 0ull;
+  if (hi + carry) atomicAdd(&hi_arr[g], hi + carry);
+}
+__device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned long long hi, int sh) {
+  const bool neg = (long long)hi < 0;
+  if (neg) { lo = ~lo + 1; hi = ~hi + (lo == 0 ? 1 : 0); }
+  double d;
+  if (hi == 0) {
+    d = (double)lo;                                    // u64 → f64 is correctly rounded
+  } else {
+    const int lz = __clzll((long long)hi);             // hi != 0: 0..63
+    unsigned long long top = lz ? (hi << lz) | (lo >> (64 - lz)) : hi;
+    const unsigned long long rest = lz ? lo << lz : lo;
+    top |= rest ? 1ull : 0ull;                         // sticky bit: below the 53 bits the conversion keeps
+    d = ldexp((double)top, 64 - lz);
+  }
+  d = ldexp(d, -sh);
+  return neg ? -d : d;
+}
+__global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                         int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long m = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const unsigned long long b = __builtin_nontemporal_load(&vals[i]) & 0x7fffffffffffffffull;
+    if ((b >> 52) != 0x7ff && b > m && ah_bit(vvalid, voff + i)) m = b;   // |x| of finite values order like their bit patterns
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_down(m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ __launch_bounds__(kBlock) void fx_finalize_kernel(FxAcc acc, int64_t ngroups, double* __restrict__ out_sums) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= ngroups) return;
+  const unsigned f = acc.flags[g];
+  double r;
+  if (f) r = (f & 1u) || (f & 6u) == 6u ? __builtin_nan("") : ((f & 2u) ? __builtin_inf() : -__builtin_inf());
+  else r = fx_to_double(acc.lo[g], acc.hi[g], fx_shift(*acc.absmax));
+  out_sums[g] = r;
+}
+
 // Per-group accumulation.  ids are dense and in first-seen order, so a low-cardinality
 // column keeps ALL its groups in a per-workgroup LDS table (kLdsGroups × {sum, count}):
 // rows hit LDS atomics, and each workgroup flushes every touched group to HBM once —
@@ -430,14 +508,18 @@ constexpr int kLdsGroups = 4096;
 template <typename VT, typename AT, bool USE_LDS>
 __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __restrict__ ids, const VT* __restrict__ vals,
                                                             const uint8_t* __restrict__ vvalid, int64_t voff, int64_t n,
-                                                            AT* __restrict__ sums, unsigned long long* __restrict__ counts, int ngroups) {
-  __shared__ AT s_sum[USE_LDS ? kLdsGroups : 1];
+                                                            AT* __restrict__ sums, unsigned long long* __restrict__ counts, int ngroups, FxAcc fx) {
+  constexpr bool kFx = std::is_same<VT, double>::value;   // doubles: 128-bit fixed point (s_sum = low words, s_hi = high words)
+  __shared__ unsigned long long s_sum[USE_LDS ? kLdsGroups : 1];
+  __shared__ unsigned long long s_hi[USE_LDS && kFx ? kLdsGroups : 1];
   __shared__ unsigned s_cnt[USE_LDS ? kLdsGroups : 1];
   const int nl = ngroups < kLdsGroups ? ngroups : kLdsGroups;
   if (USE_LDS) {
-    for (int g = threadIdx.x; g < nl; g += kBlock) { s_sum[g] = (AT)0; s_cnt[g] = 0; }
+    for (int g = threadIdx.x; g < nl; g += kBlock) { s_sum[g] = 0; s_cnt[g] = 0; if (kFx) s_hi[g] = 0; }
     __syncthreads();
   }
+  int sh = 0;
+  if constexpr (kFx) sh = fx_shift(*fx.absmax);
   constexpr int U = 8;  // rows per lane per step: 8 id loads + 8 value loads in flight (one row at a time is latency-bound)
   const int64_t stride = (int64_t)gridDim.x * kBlock * U;
   for (int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < n; base += stride) {
@@ -453,13 +535,22 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __rest
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (g[u] < 0) continue;
-      if (USE_LDS && g[u] < nl) {
-        atomicAdd(&s_sum[g[u]], (AT)v[u]);
-        atomicAdd(&s_cnt[g[u]], 1u);
+      const bool lds = USE_LDS && g[u] < nl;
+      if constexpr (kFx) {
+        if (fx_finite(v[u])) {
+          unsigned long long lo, hi;
+          fx_split(v[u], sh, &lo, &hi);
+          if (lds) fx_add(s_sum, s_hi, (size_t)g[u], lo, hi);
+          else fx_add(fx.lo, fx.hi, (size_t)g[u], lo, hi);
+        } else {
+          atomicOr(&fx.flags[g[u]], fx_flag(v[u]));
+        }
       } else {
-        atomicAdd(&sums[g[u]], (AT)v[u]);
-        atomicAdd(&counts[g[u]], 1ull);
+        if (lds) atomicAdd(&s_sum[g[u]], (unsigned long long)v[u]);
+        else atomicAdd(&sums[g[u]], (AT)v[u]);
       }
+      if (lds) atomicAdd(&s_cnt[g[u]], 1u);
+      else atomicAdd(&counts[g[u]], 1ull);
     }
   }
   if (USE_LDS) {
@@ -467,7 +558,8 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __rest
     for (int g = threadIdx.x; g < nl; g += kBlock) {
       unsigned cnt = s_cnt[g];
       if (cnt) {
-        atomicAdd(&sums[g], s_sum[g]);
+        if constexpr (kFx) fx_add(fx.lo, fx.hi, (size_t)g, s_sum[g], s_hi[g]);
+        else atomicAdd(&sums[g], (AT)s_sum[g]);
         atomicAdd(&counts[g], (unsigned long long)cnt);
       }
     }
@@ -488,9 +580,33 @@ constexpr int64_t kShortRun = 1024;                  // runs shorter than this g
 
 template <typename AT>
 __global__ __launch_bounds__(kBlock) void bucket_sum_kernel(const unsigned long long* __restrict__ vals, const unsigned* __restrict__ ids, int64_t n,
-                                                             AT* __restrict__ sums, unsigned long long* __restrict__ counts) {
-  __shared__ AT s_sum[kLdsGroups];
+                                                             AT* __restrict__ sums, unsigned long long* __restrict__ counts, FxAcc fx) {
+  constexpr bool kFx = std::is_same<AT, double>::value;
+  __shared__ unsigned long long s_sum[kLdsGroups];
+  __shared__ unsigned long long s_hi[kFx ? kLdsGroups : 1];
   __shared__ unsigned s_cnt[kLdsGroups];
+  int sh = 0;
+  if constexpr (kFx) sh = fx_shift(*fx.absmax);
+  // one row into the LDS window (base = nullptr) or straight into the global accumulators
+  auto add_row = [&](unsigned id, unsigned long long bits, bool lds) {
+    const size_t g = lds ? (size_t)(id & (kLdsGroups - 1)) : (size_t)id;
+    if constexpr (kFx) {
+      const double x = __builtin_bit_cast(double, bits);
+      if (fx_finite(x)) {
+        unsigned long long lo, hi;
+        fx_split(x, sh, &lo, &hi);
+        if (lds) fx_add(s_sum, s_hi, g, lo, hi);
+        else fx_add(fx.lo, fx.hi, g, lo, hi);
+      } else {
+        atomicOr(&fx.flags[id], fx_flag(x));
+      }
+    } else {
+      if (lds) atomicAdd(&s_sum[g], bits);
+      else atomicAdd(&sums[g], (AT)bits);
+    }
+    if (lds) atomicAdd(&s_cnt[g], 1u);
+    else atomicAdd(&counts[g], 1ull);
+  };
   const int64_t lo = (int64_t)blockIdx.x * kChunkRows, hi = lo + kChunkRows < n ? lo + kChunkRows : n;
   int64_t pos = lo;
   while (pos < hi) {
@@ -512,11 +628,10 @@ __global__ __launch_bounds__(kBlock) void bucket_sum_kernel(const unsigned long 
       for (int64_t i = pos + threadIdx.x; i < end; i += kBlock) {
         const unsigned id = ids[i];
         if (id & 0x80000000u) continue;  // null value: neither summed nor counted
-        atomicAdd(&sums[id], __builtin_bit_cast(AT, vals[i]));
-        atomicAdd(&counts[id], 1ull);
+        add_row(id, vals[i], false);
       }
     } else {
-      for (int g = threadIdx.x; g < kLdsGroups; g += kBlock) { s_sum[g] = (AT)0; s_cnt[g] = 0; }
+      for (int g = threadIdx.x; g < kLdsGroups; g += kBlock) { s_sum[g] = 0; s_cnt[g] = 0; if (kFx) s_hi[g] = 0; }
       __syncthreads();
       constexpr int U = 4;
       for (int64_t b0 = pos + threadIdx.x; b0 < end; b0 += (int64_t)kBlock * U) {
@@ -531,16 +646,17 @@ __global__ __launch_bounds__(kBlock) void bucket_sum_kernel(const unsigned long 
 #pragma unroll
         for (int u = 0; u < U; u++) {
           if (id[u] & 0x80000000u) continue;  // null value (or past the run)
-          atomicAdd(&s_sum[id[u] & (kLdsGroups - 1)], __builtin_bit_cast(AT, v[u]));
-          atomicAdd(&s_cnt[id[u] & (kLdsGroups - 1)], 1u);
+          add_row(id[u], v[u], true);
         }
       }
       __syncthreads();
       for (int g = threadIdx.x; g < kLdsGroups; g += kBlock) {
         const unsigned cnt = s_cnt[g];
         if (cnt) {
-          atomicAdd(&sums[((size_t)bucket << kBucketShift) + g], s_sum[g]);
-          atomicAdd(&counts[((size_t)bucket << kBucketShift) + g], (unsigned long long)cnt);
+          const size_t gg = ((size_t)bucket << kBucketShift) + g;
+          if constexpr (kFx) fx_add(fx.lo, fx.hi, gg, s_sum[g], s_hi[g]);
+          else atomicAdd(&sums[gg], (AT)s_sum[g]);
+          atomicAdd(&counts[gg], (unsigned long long)cnt);
         }
       }
       __syncthreads();
@@ -762,16 +878,32 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
   // histograms — one reservation in the context's temp arena, sized for the two-pass partition, reused by the next call
   const int64_t nb = ah_ceil_div(n, 2048);
   const size_t pv = (size_t)n * 8, pi = (((size_t)n * 4) + 255) & ~(size_t)255, ph = (size_t)256 * nb * 4;
+  constexpr bool kFx = std::is_same<VT, double>::value;
+  // doubles: 128-bit fixed-point accumulators + flag word per group (≤ n + 1 groups) and the absmax word
+  const size_t fxw = kFx ? (((size_t)(n + 1) * 8) + 255) & ~(size_t)255 : 0, fxf = kFx ? (((size_t)(n + 1) * 4) + 255) & ~(size_t)255 : 0;
   void* arena = nullptr;
-  int rc = ah_temp_reserve(c, pi + 2 * (pv + pi) + 2 * ph + 256, &arena);
+  int rc = ah_temp_reserve(c, pi + 2 * (pv + pi) + 2 * ph + 256 + 2 * fxw + fxf + 256, &arena);
   if (rc != AH_OK) return rc;
   int32_t* ids = (int32_t*)arena;
   uint8_t* part = (uint8_t*)arena + pi;
+  uint8_t* fxbase = part + 2 * (pv + pi) + 2 * ph + 256;
+  FxAcc fx{nullptr, nullptr, nullptr, nullptr};
+  if (kFx) {
+    fx = FxAcc{(unsigned long long*)fxbase, (unsigned long long*)(fxbase + fxw), (unsigned*)(fxbase + 2 * fxw),
+               (const unsigned long long*)(fxbase + 2 * fxw + fxf)};
+    AH_HIP(c, hipMemsetAsync((void*)fx.absmax, 0, 8, c->stream));
+    absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 8), kBlock, 0, c->stream>>>((const unsigned long long*)vals, vvalid, voff, n,
+                                                                                                        (unsigned long long*)fx.absmax);
+    AH_LAUNCH_CHECK(c);
+  }
   EncodeResult res;
   rc = encode_core(c, U64Keys{(const unsigned long long*)keys}, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows);
   if (rc == AH_OK) {
     hipError_t e1 = hipMemsetAsync(out_sums, 0, (size_t)res.ndict * sizeof(AT), c->stream);
     hipError_t e2 = hipMemsetAsync(out_counts, 0, (size_t)res.ndict * sizeof(int64_t), c->stream);
+    if (kFx && e1 == hipSuccess) e1 = hipMemsetAsync(fx.lo, 0, (size_t)res.ndict * 8, c->stream);
+    if (kFx && e1 == hipSuccess) e1 = hipMemsetAsync(fx.hi, 0, (size_t)res.ndict * 8, c->stream);
+    if (kFx && e1 == hipSuccess) e1 = hipMemsetAsync(fx.flags, 0, (size_t)res.ndict * 4, c->stream);
     if (e1 != hipSuccess || e2 != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: memset failed");
   }
   if (rc == AH_OK) {
@@ -779,7 +911,7 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
     if (res.ndict <= kLdsGroups) {
       unsigned grid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), /*default_bpc=*/2);
       group_sum_kernel<VT, AT, true><<<grid, kBlock, 0, c->stream>>>(ids, vals, vvalid, voff, n, out_sums,
-                                                                     (unsigned long long*)out_counts, (int)res.ndict);
+                                                                     (unsigned long long*)out_counts, (int)res.ndict, fx);
     } else if (partition_path && res.ndict <= kPartitionMaxGroups && sizeof(VT) == 8) {
       const int passes = res.ndict <= kPartitionOnePass ? 1 : 2;
       unsigned long long* pvals = (unsigned long long*)part;
@@ -790,15 +922,21 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
       unsigned* aids = passes == 2 ? (unsigned*)((uint8_t*)avals + pv) : nullptr;
       rc = ah_partition_by_group(c, ids, (const unsigned long long*)vals, vvalid, voff, n, kBucketShift, passes, hist, offs, avals, aids, pvals, pids);
       if (rc == AH_OK) {
-        bucket_sum_kernel<AT><<<(unsigned)ah_ceil_div(n, kChunkRows), kBlock, 0, c->stream>>>(pvals, pids, n, out_sums, (unsigned long long*)out_counts);
+        bucket_sum_kernel<AT><<<(unsigned)ah_ceil_div(n, kChunkRows), kBlock, 0, c->stream>>>(pvals, pids, n, out_sums, (unsigned long long*)out_counts, fx);
         if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
       }
     } else {
       unsigned grid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8));
       group_sum_kernel<VT, AT, false><<<grid, kBlock, 0, c->stream>>>(ids, vals, vvalid, voff, n, out_sums,
-                                                                      (unsigned long long*)out_counts, (int)(res.ndict > 0x7fffffff ? 0x7fffffff : res.ndict));
+                                                                      (unsigned long long*)out_counts, (int)(res.ndict > 0x7fffffff ? 0x7fffffff : res.ndict), fx);
     }
     if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
+    if constexpr (kFx) {
+      if (rc == AH_OK && res.ndict > 0) {
+        fx_finalize_kernel<<<(unsigned)ah_ceil_div(res.ndict, kBlock), kBlock, 0, c->stream>>>(fx, res.ndict, (double*)out_sums);
+        if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
+      }
+    }
   }
   if (rc != AH_OK) return rc;
   if (out_ngroups_host) *out_ngroups_host = res.ndict;

@@ -146,9 +146,12 @@ __global__ __launch_bounds__(kBlock) void tile_sums_kernel(const T* __restrict__
 // (Scanning all tile sums here cost 56 µs for 32768 tiles — 8-byte accesses at a 256-byte lane
 // stride; the scan pass instead adds the ≤ 7 tile sums in front of its tile with scalar loads.)
 constexpr int kPrefixBlock = 1024;
+// carry_in (nullable): the running total of the segments in front of this one (device memory) replaces `start`;
+// carry_out (nullable) receives carry + this segment's total, for the next segment.
 template <typename A>
 __global__ __launch_bounds__(kPrefixBlock) void super_prefix_kernel(const A* __restrict__ super_sum, A* __restrict__ super_excl, int64_t nsuper,
-                                                                     A start) {
+                                                                     A start, const A* __restrict__ carry_in, A* __restrict__ carry_out) {
+  if (carry_in) start = *carry_in;
   __shared__ A s_w[kPrefixBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t per = (nsuper + kPrefixBlock - 1) / kPrefixBlock;
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(kPrefixBlock) void super_prefix_kernel(const A* __r
     super_excl[q] = run;
     run += t;
   }
+  if (carry_out && threadIdx.x == kPrefixBlock - 1) *carry_out = run;  // the last thread's run ends at nsuper (empty runs pass it through)
 }
 
 // 3. in-tile scan + tile prefix (= super prefix + the tile sums in front of this tile within its
@@ -184,7 +188,7 @@ template <typename T, typename A, bool CHECKED, int VPT, bool ALN>
 __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const T* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off,
                                                             int64_t n, int64_t limit, A start, const A* __restrict__ super_excl,
                                                             const A* __restrict__ tile_sum, T* __restrict__ out,
-                                                            unsigned* __restrict__ overflow) {
+                                                            unsigned* __restrict__ overflow, int64_t row0, unsigned long long* __restrict__ first_nf) {
   using G = Geom<T, VPT>;
   constexpr int V = G::V;
   constexpr bool kIsInt = std::is_integral<T>::value;
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const T* __restrict__
     if (w < wave) pre += s_w[w];
 
   bool ovf = false;
+  unsigned long long nf = ~0ull;  // floats: first row (of the whole column: row0 = this segment's first row) whose running sum is not finite
 #pragma unroll
   for (int k = 0; k < VPT; k++) {
     const int64_t e0 = wb + ((int64_t)k * 64 + lane) * V;
@@ -251,6 +256,10 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const T* __restrict__
           if (run > (A)L::max() || run < (A)L::min()) ovf = true;
         }
         o.v[j] = (T)run;
+        if (!kIsInt) {
+          const T ov = o.v[j];
+          if (!(ov - ov == (T)0) && nf == ~0ull) nf = (unsigned long long)(row0 + e0 + j);   // inf − inf and NaN − NaN are NaN
+        }
       } else {
         o.v[j] = (T)0;  // null rows keep the zero of the fresh buffer
       }
@@ -264,6 +273,56 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const T* __restrict__
     }
   }
   if (CHECKED && __any(ovf) && lane == 0) atomicOr(overflow, 1u);
+  if (!kIsInt && __any(nf != ~0ull)) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_down(nf, o, 64);
+      nf = t < nf ? t : nf;
+    }
+    if (lane == 0) atomicMin(first_nf, nf);
+  }
+}
+
+// ---- floats: a running sum that has become ±inf / NaN stays there -----------------------------------------------
+// The reference adds row after row in T (vector_cumulative.go:228-318): once `current` is ±inf it can only stay ±inf or
+// turn NaN (an addend of the opposite infinity, or a NaN), and NaN is final — whatever finite values follow.  The tree
+// above would come back to finite values.  So: r = first row with a non-finite running sum (found by the scan itself);
+// r2 = first valid row after r whose addend turns state s0 = out[r] into NaN (r2 = r if s0 is NaN); rows (r, r2) ← s0,
+// rows ≥ r2 ← NaN.  Both kernels return at once in the normal case (no non-finite sum anywhere).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sticky_find_kernel(const T* __restrict__ in, const uint8_t* __restrict__ valid, int64_t off,
+                                                              int64_t limit, const T* __restrict__ out, const unsigned long long* __restrict__ first_nf,
+                                                              unsigned long long* __restrict__ nan_from) {
+  const unsigned long long r = *first_nf;
+  if (r == ~0ull) return;
+  const T s0 = out[r];
+  if (s0 != s0) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(nan_from, r); return; }
+  unsigned long long best = ~0ull;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)r + 1 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < limit; i += stride) {
+    if (!ah_bit(valid, off + i)) continue;
+    const T x = in[i];
+    if (x != x || x == -s0) { best = (unsigned long long)i; break; }   // NaN, or the opposite infinity (s0 is ±inf here)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_down(best, o, 64);
+    best = t < best ? t : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(nan_from, best);
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sticky_fill_kernel(const uint8_t* __restrict__ valid, int64_t off, int64_t limit, T* __restrict__ out,
+                                                              const unsigned long long* __restrict__ first_nf,
+                                                              const unsigned long long* __restrict__ nan_from) {
+  const unsigned long long r = *first_nf;
+  if (r == ~0ull) return;
+  const unsigned long long r2 = *nan_from;
+  const T s0 = out[r];   // row r itself is never rewritten
+  const T qnan = s0 - s0;  // inf − inf: the NaN this device's adder produces
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)r + 1 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < limit; i += stride)
+    if (ah_bit(valid, off + i)) out[i] = (unsigned long long)i < r2 ? s0 : qnan;
 }
 
 // first zero bit of a validity bitmap (or n): where encounteredNull turns on
@@ -295,33 +354,67 @@ __global__ __launch_bounds__(kBlock) void first_null_kernel(const uint8_t* __res
   }
 }
 
+// Segments (OFF by default: c->opt_scan_segment_log2 = 0).  The scan pass re-reads what the sums pass has just read — 24 B/row
+// moved for 16 algorithmic.  The idea that segments of ≤ 64–128 MiB would let the 256 MiB Infinity Cache serve the re-read was
+// built and measured (scripts/bench_scan_seg.py, profiles/r02_bench_scan_seg.json): 2^27 Int64 rows 0.55 ms in one piece,
+// 0.61 / 0.75 / 0.99 ms in 128 / 64 / 32 MiB segments — and a Sum re-reading the SAME 32 … 256 MiB range twenty times runs at
+// 5.3 … 6.7 TB/s, below the 7.1 TB/s of a cold 1 GiB stream: on this chip a streamed range that fits the memory-side cache is
+// not read back any faster than HBM, so the segments only add 3 launches (and their drain) each.  The running total crosses
+// segments through device memory (super_prefix_kernel's carry); kept as a measurement switch and for the tests.
 template <typename T, typename A, bool CHECKED, int VPT, bool ALN>
 int run_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t limit, A start, void* out) {
   using G = Geom<T, VPT>;
-  const int64_t ntiles = ah_ceil_div(n, G::TILE);
   unsigned* overflow = (unsigned*)&c->dscalars[13];
+  unsigned long long* first_nf = (unsigned long long*)&c->dscalars[9];
+  unsigned long long* nan_from = (unsigned long long*)&c->dscalars[10];
+  constexpr bool kFloat = std::is_floating_point<T>::value;
   if (CHECKED) AH_HIP(c, hipMemsetAsync(overflow, 0, sizeof(uint64_t), c->stream));
-  const A *super_excl = nullptr, *tile_sum = nullptr;
-  if (ntiles > 1) {
-    const int64_t nsuper = ah_ceil_div(ntiles, kSuper);
-    size_t tbytes = (((size_t)ntiles * sizeof(A)) + 127) & ~(size_t)127;
-    size_t sbytes = (((size_t)nsuper * sizeof(A)) + 127) & ~(size_t)127;
-    void* scratch;
-    int rc = ah_scratch_reserve(c, tbytes + 2 * sbytes, &scratch);
+  if (kFloat) AH_HIP(c, hipMemsetAsync(first_nf, 0xFF, 2 * sizeof(uint64_t), c->stream));
+  const int64_t group = (int64_t)G::TILE * kSuper;
+  int64_t seg_rows = c->opt_scan_segment_log2 > 0 ? (((int64_t)1 << c->opt_scan_segment_log2) / (int64_t)sizeof(T)) / group * group : 0;
+  if (seg_rows <= 0 || n <= seg_rows + seg_rows / 2) seg_rows = n;   // one segment (also: no short tail segment)
+  const int64_t nseg = ah_ceil_div(n, seg_rows);
+  const int64_t max_tiles = ah_ceil_div(seg_rows < n ? seg_rows : n, G::TILE), max_super = ah_ceil_div(max_tiles, kSuper);
+  const size_t tbytes = (((size_t)max_tiles * sizeof(A)) + 127) & ~(size_t)127;
+  const size_t sbytes = (((size_t)max_super * sizeof(A)) + 127) & ~(size_t)127;
+  uint8_t* scratch = nullptr;
+  if (max_tiles > 1 || nseg > 1) {
+    int rc = ah_scratch_reserve(c, 2 * (tbytes + 2 * sbytes) + 256, (void**)&scratch);   // two sets: segment k + 1's sums do not wait for k's scan to drain
     if (rc != AH_OK) return rc;
-    A* sums = (A*)scratch;
-    A* ssum = (A*)((uint8_t*)scratch + tbytes);
-    A* sexcl = (A*)((uint8_t*)scratch + tbytes + sbytes);
-    tile_sums_kernel<T, A, VPT, ALN><<<(unsigned)nsuper, kBlock, 0, c->stream>>>((const T*)values, valid, off, n, limit, sums, ssum, ntiles);
-    AH_LAUNCH_CHECK(c);
-    super_prefix_kernel<A><<<1, kPrefixBlock, 0, c->stream>>>(ssum, sexcl, nsuper, start);
-    AH_LAUNCH_CHECK(c);
-    super_excl = sexcl;
-    tile_sum = sums;
   }
-  tile_scan_kernel<T, A, CHECKED, VPT, ALN><<<(unsigned)ntiles, kBlock, 0, c->stream>>>((const T*)values, valid, off, n, limit, start,
-                                                                                        super_excl, tile_sum, (T*)out, overflow);
-  AH_LAUNCH_CHECK(c);
+  A* carry = (A*)(scratch + 2 * (tbytes + 2 * sbytes));   // [2]: ping-pong
+  for (int64_t sg = 0; sg < nseg; sg++) {
+    const int64_t r0 = sg * seg_rows, rn = n - r0 < seg_rows ? n - r0 : seg_rows;
+    const int64_t lim = limit <= r0 ? 0 : (limit - r0 < rn ? limit - r0 : rn);
+    const T* vin = (const T*)values + r0;
+    T* vout = (T*)out + r0;
+    const int64_t ntiles = ah_ceil_div(rn, G::TILE);
+    const A *super_excl = nullptr, *tile_sum = nullptr;
+    if (ntiles > 1 || nseg > 1) {
+      const int64_t nsuper = ah_ceil_div(ntiles, kSuper);
+      uint8_t* set = scratch + (sg & 1) * (tbytes + 2 * sbytes);
+      A* sums = (A*)set;
+      A* ssum = (A*)(set + tbytes);
+      A* sexcl = (A*)(set + tbytes + sbytes);
+      tile_sums_kernel<T, A, VPT, ALN><<<(unsigned)nsuper, kBlock, 0, c->stream>>>(vin, valid, off + r0, rn, lim, sums, ssum, ntiles);
+      AH_LAUNCH_CHECK(c);
+      super_prefix_kernel<A><<<1, kPrefixBlock, 0, c->stream>>>(ssum, sexcl, nsuper, start, sg > 0 ? &carry[(sg - 1) & 1] : nullptr,
+                                                                 nseg > 1 ? &carry[sg & 1] : nullptr);
+      AH_LAUNCH_CHECK(c);
+      super_excl = sexcl;
+      tile_sum = sums;
+    }
+    tile_scan_kernel<T, A, CHECKED, VPT, ALN><<<(unsigned)ntiles, kBlock, 0, c->stream>>>(vin, valid, off + r0, rn, lim, start, super_excl, tile_sum,
+                                                                                          vout, overflow, r0, first_nf);
+    AH_LAUNCH_CHECK(c);
+  }
+  if constexpr (kFloat) {
+    const unsigned grid = ah_stream_grid(c, ah_ceil_div(n, kBlock), 8);
+    sticky_find_kernel<T><<<grid, kBlock, 0, c->stream>>>((const T*)values, valid, off, limit, (const T*)out, first_nf, nan_from);
+    AH_LAUNCH_CHECK(c);
+    sticky_fill_kernel<T><<<grid, kBlock, 0, c->stream>>>(valid, off, limit, (T*)out, first_nf, nan_from);
+    AH_LAUNCH_CHECK(c);
+  }
   return AH_OK;
 }
 

@@ -441,12 +441,52 @@ def test_hash_sum(hip, orc_be):
         g, e = hip.hash_sum("f64", keys, kvalid, 3, fv, vvalid, 5), orc_be.hash_sum("f64", keys, kvalid, 3, fv, vvalid, 5)
         for a, b in zip(g[:3], e[:3]):
             assert a.tobytes() == b.tobytes()
-        # general data: tolerance n_g·ε·Σ|x| per group (atomic order is not deterministic)
+        # general data: tolerance n_g·ε·Σ|x| per group — the bound of the oracle's own sequential order (ours is tighter:
+        # test_hash_sum_f64_is_deterministic_and_tight)
         fv = rng.uniform(-1, 1, n)
         g, e = hip.hash_sum("f64", keys, kvalid, 3, fv, vvalid, 5), orc_be.hash_sum("f64", keys, kvalid, 3, fv, vvalid, 5)
         assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
         tol = np.maximum(e[2], 1) * 2.3e-16 * np.maximum(e[2], 1)  # n_g·ε·(Σ|x| ≤ n_g)
         assert (np.abs(g[1] - e[1]) <= tol).all()
+
+
+def test_hash_sum_f64_is_deterministic_and_tight(hip, orc_be):
+    """Float64 group sums are accumulated in 128-bit fixed point with integer atomics (associative), rounded once:
+    the bytes do not change from run to run, and they are far closer to the exact sums than the sequential definition's
+    own bound.  ±inf / NaN addends give the IEEE class any order would give."""
+    import math
+    from fractions import Fraction
+    rng = np.random.default_rng(72)
+    for n, card in [(70001, 500), (300007, 100000), (2500003, 1 << 21)]:   # LDS path · one-pass partition · two-pass partition
+        keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+        vvalid = rand_bits(rng, n + 8, 0.9)
+        fv = rng.standard_normal(n) * np.exp(rng.uniform(-30, 30, n))       # 26 orders of magnitude
+        runs = [hip.hash_sum("f64", keys, None, 0, fv, vvalid, 0) for _ in range(3)]
+        for r in runs[1:]:
+            assert r[1].tobytes() == runs[0][1].tobytes() and r[2].tobytes() == runs[0][2].tobytes()
+        e = orc_be.hash_sum("f64", keys, None, 0, fv, vvalid, 0)
+        g = runs[0]
+        assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
+        # exact per-group sums (math.fsum) for the groups of the first 2000 keys
+        ok = np.unpackbits(vvalid, bitorder="little")[:n].astype(bool)
+        order = np.argsort(keys, kind="stable")
+        ks, vs, oks = keys[order], fv[order], ok[order]
+        bounds = np.flatnonzero(np.diff(ks)) + 1
+        starts, ends = np.concatenate([[0], bounds])[:2000], np.concatenate([bounds, [n]])[:2000]
+        pos = {int(k): i for i, k in enumerate(g[0].view(np.int64))}
+        m = float(np.abs(fv).max())
+        for a, b in zip(starts, ends):
+            vals = vs[a:b][oks[a:b]]
+            exact = sum((Fraction(float(v)) for v in vals), Fraction(0))      # the real-number sum
+            got = float(g[1][pos[int(ks[a])]])
+            assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(len(vals) * m * 2.0**-93), (n, card, got, float(exact))
+    # non-finite addends
+    keys = np.array([1, 1, 2, 2, 3, 3, 4, 4, 5], np.int64)
+    fv = np.array([np.inf, 1.0, -np.inf, 5.0, np.inf, -np.inf, np.nan, 1.0, 2.5])
+    g, e = hip.hash_sum("f64", keys, None, 0, fv, None, 0), orc_be.hash_sum("f64", keys, None, 0, fv, None, 0)
+    assert g[0].tobytes() == e[0].tobytes()
+    assert g[1][0] == np.inf and g[1][1] == -np.inf and np.isnan(g[1][2]) and np.isnan(g[1][3]) and g[1][4] == 2.5
+    assert np.array_equal(np.isnan(g[1]), np.isnan(e[1])) and np.array_equal(g[1][~np.isnan(g[1])], e[1][~np.isnan(e[1])])
 
 
 # ---- fused ---------------------------------------------------------------------------------
@@ -578,6 +618,64 @@ def test_cumulative_sum_float(hip, orc_be, dtype):
     g = hip.cumulative_sum(x, None, 0, None, False, False)[1]
     e = orc_be.cumulative_sum(x, None, 0, None, False, False)[1]
     assert np.array_equal(g[:4500], e[:4500]) and np.all(np.isnan(g[4500:])) and np.all(np.isnan(e[4500:]))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cumulative_sum_float_overflow_sticks(ctx, hip, orc_be, dtype):
+    """a running sum that reaches ±inf STAYS there in the reference's sequential loop (vector_cumulative.go:228-318), whatever
+    finite values follow; the opposite infinity or a NaN turns it into NaN for good.  The tree scan alone would come back to
+    finite values — the first non-finite row is found by the scan and the sequential state is forced from there on.
+    Values are powers of two so that every finite prefix is exact in any order: the comparison with the oracle is bit for
+    bit on the finite rows and class for class (±inf / NaN) on the rest."""
+    big = dtype(2.0 ** (127 if dtype == np.float32 else 1023))
+    rng = np.random.default_rng(7)
+
+    def check(x, bits=None, skip=True):
+        st_e, e, ev, en = orc_be.cumulative_sum(x, bits, 0, None, skip, False)
+        st_g, g, gv, gn = hip.cumulative_sum(x, bits, 0, None, skip, False)
+        assert st_e == st_g == STATUS_OK
+        fin = np.isfinite(e)
+        assert np.array_equal(fin, np.isfinite(g))
+        assert g[fin].tobytes() == e[fin].tobytes()
+        assert np.array_equal(np.isnan(e), np.isnan(g)) and np.array_equal(e[np.isinf(e)], g[np.isinf(g)])
+        if bits is not None:
+            assert cumsum_valid_equal(gv, ev, x.size) and gn == en
+        return e
+
+    for n in (10, 5000, 70001, (1 << 21) + 17):
+        x = rng.integers(-4, 5, n).astype(dtype)
+        r = n // 3
+        x[r], x[r + 1] = big, big                       # overflow to +inf at r + 1 …
+        x[r + 2], x[r + 3] = -big, -big                 # … the true sum is back in range right after
+        e = check(x)
+        assert np.isfinite(e[r]) and np.all(e[r + 1:] == np.inf)
+        y = x.copy(); y[n - 2] = -np.inf                # the opposite infinity: NaN from there on
+        e = check(y)
+        assert np.all(e[r + 1:n - 2] == np.inf) and np.all(np.isnan(e[n - 2:]))
+        y = -x; y[(r + n) // 2] = np.nan                # −inf, then a NaN addend
+        e = check(y)
+        assert np.all(e[r + 1:(r + n) // 2] == -np.inf) and np.all(np.isnan(e[(r + n) // 2:]))
+        keep = rng.random(n) >= 0.2
+        keep[r:r + 4] = True                             # (with x[r] or x[r + 1] null no prefix overflows, but −big − big would overflow
+        bits = OL.pack_bits(list(keep))                  #  inside one 16-byte vector of the tree: the corner DESIGN.md §4 documents)
+        # nulls: skipped rows keep payload 0 and do not disturb the state
+        check(x, bits, True)
+        check(y, bits, True)
+        check(x, bits, False)
+    # several segments (the running total crosses them through device memory): forced small here
+    ctx.set_option("scan_segment_log2", 16)
+    try:
+        n = 300_007
+        x = rng.integers(-4, 5, n).astype(dtype); x[1000], x[1001] = big, big; x[250_000] = -np.inf
+        check(x)
+        xi = rng.integers(-1000, 1000, n).astype(np.int64)
+        assert hip.cumulative_sum(xi, None, 0)[1].tobytes() == orc_be.cumulative_sum(xi, None, 0)[1].tobytes()
+        bits = OL.pack_bits(list(rng.random(n) >= 0.1))
+        for skip in (True, False):
+            g, e = hip.cumulative_sum(xi, bits, 0, None, skip, True), orc_be.cumulative_sum(xi, bits, 0, None, skip, True)
+            assert g[0] == e[0] == STATUS_OK and g[1].tobytes() == e[1].tobytes() and g[3] == e[3]
+    finally:
+        ctx.set_option("scan_segment_log2", 0)
 
 
 def test_cumulative_sum_many_tiles(hip, orc_be):
