@@ -159,6 +159,14 @@ _SIGS = {
     "ah_cmp_filter_sum_f64_dev": [_vp, _int, _vp, _vp, _i64, _i64, C.c_double, _vp, _vp],
 }
 _SIGS.update({
+    "ah_comm_unique_id": [_vp],
+    "ah_comm_init": [_vp, _int, _int, _vp, _pvp],
+    "ah_comm_destroy": [_vp],
+    "ah_comm_rank": [_vp],
+    "ah_comm_world": [_vp],
+    "ah_comm_allreduce_sum": [_vp, _int, _vp, _vp, _i64],
+    "ah_comm_allgather": [_vp, _vp, _vp, _i64],
+    "ah_comm_alltoallv": [_vp, _vp, _pi64, _pi64, _vp, _pi64, _pi64],
     "ah_expr_compile": [_vp, _vp, _int, _vp, _int, _vp, _int, _pvp, _pint],
     "ah_expr_execute": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "ah_expr_codegen": [_vp, _int, _vp, _int, _vp, _int, _int, C.c_char_p, _sz, C.c_char_p, _sz, _pint],

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kSmallBlock) void insert_small_kernel(const unsigne
 // 64-bit integer atomics (low word with carry into the high word — each addend derives its own carry from the value
 // its atomic returned, so any interleaving gives the same 128 bits), and rounded to double ONCE at the end.
 // Result: identical bytes run to run, on any launch geometry; error ≤ ½ulp(Σ) + n_g·2^(emax−94) — inside the
-// n_g·ε·Σ|x| of the sequential definition (oracle/orc_hash.c).  ±inf / NaN addends are tallied as three flag bits per
+// n_g·ε·Σ|x| of the sequential row-order definition.  ±inf / NaN addends are tallied as three flag bits per
 // group and give the IEEE result of any order: NaN if a NaN or both infinities were seen, else the infinity.
 struct FxAcc {  // global accumulators of one call (device pointers); null for integer sums
   unsigned long long* lo;

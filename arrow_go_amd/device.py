@@ -70,6 +70,41 @@ class DeviceBuffer:
             pass
 
 
+class Comm:
+    """ah_comm: this rank's RCCL communicator on an ah_ctx's compute stream (include/arrowhip.h, "multi-GPU exchange").
+    Buffers are device pointers (ints, DeviceBuffers, or anything with .data_ptr())."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        st = lib.ah_comm_unique_id(C.addressof(buf))
+        if st != N.AH_OK:
+            raise N.ErrHip("ah_comm_unique_id failed: is librccl.so loadable?")
+        return bytes(buf)
+
+    def __init__(self, ctx: "Context", rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        h = C.c_void_p()
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(ctx.handle, lib.ah_comm_init(ctx.handle, rank, world, C.addressof(idb), C.byref(h)))
+        self.ctx, self.handle, self.rank, self.world = ctx, h, rank, world
+
+    def close(self) -> None:
+        if self.handle:
+            lib.ah_comm_destroy(self.handle)
+            self.handle = None
+
+    def allreduce_sum(self, type_id: int, send, recv, count: int) -> None:
+        check(self.ctx.handle, lib.ah_comm_allreduce_sum(self.handle, type_id, _ptr(send), _ptr(recv), count))
+
+    def allgather(self, send, recv, nbytes_per_rank: int) -> None:
+        check(self.ctx.handle, lib.ah_comm_allgather(self.handle, _ptr(send), _ptr(recv), nbytes_per_rank))
+
+    def alltoallv(self, send, send_bytes, send_offs, recv, recv_bytes, recv_offs) -> None:
+        arr = lambda v: (C.c_int64 * self.world)(*[int(x) for x in v])
+        check(self.ctx.handle, lib.ah_comm_alltoallv(self.handle, _ptr(send), arr(send_bytes), arr(send_offs), _ptr(recv), arr(recv_bytes), arr(recv_offs)))
+
+
 class Context:
     """ah_ctx: one GPU, a compute stream and a copy stream."""
 

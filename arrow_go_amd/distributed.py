@@ -15,10 +15,10 @@ collective for them.  Exactly one exchange step exists, for reductions:
     steps: on the GPU for HipLocal (hash partition + compactions, two group-by passes + a
     gather, radix sort + gathers) — the tuples never visit host memory.
 
-One process per GPU (`torchrun`), `torch.distributed` with backend "nccl" (= RCCL over
-xGMI) in production, "gloo" in the CPU tests.  torch is plumbing here: process group,
-device tensors for the collectives, and its current stream is shared with the ah_ctx so
-kernels and collectives order without host synchronisation.
+One process per GPU.  The exchanges go through the C ABI — ah_comm_* of libarrowhip.so, RCCL over
+xGMI on the ah_ctx's compute stream (AhCommCollectives) — so a Go host can run the same steps
+without Python; `torch.distributed` is the injected alternative (TorchCollectives: "gloo" for the
+world-2 / 3 CPU tests).  torch is plumbing here: launcher rendezvous and device memory.
 
 The per-shard compute is a `local` object with the leaf methods used below; in production
 it is `HipLocal` (libarrowhip.so on this rank's GPU; construction fails loudly without a
@@ -129,12 +129,119 @@ class HipLocal:
         return out
 
 
-class ShardedCompute:
-    """Collective layer over a `local` leaf provider."""
-
-    def __init__(self, dist, device, local):
-        self.dist, self.device, self.local = dist, device, local
+# ---- collective providers ------------------------------------------------------------------------------------------
+# ShardedCompute needs four exchanges; who performs them is injected:
+#   AhCommCollectives  — production: ah_comm_* of libarrowhip.so (RCCL over xGMI on the ah_ctx's stream, include/arrowhip.h);
+#                        torch only lends the device memory
+#   TorchCollectives   — torch.distributed: "gloo" in the CPU tests (world 2 and 3), "nccl" as a cross-check
+class TorchCollectives:
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def all_reduce_sum(self, torch, t):
+        self.dist.all_reduce(t)
+        return t
+
+    def all_gather_rows(self, torch, t):
+        """t: 1-d tensor, same length on every rank → [world, len]"""
+        parts = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return torch.stack(parts)
+
+    def exchange(self, torch, send):
+        """ragged all-to-all of [4, g_r] int64 blocks (send[r] goes to rank r) → what arrived, concatenated in source-rank order"""
+        world = self.world
+        sizes = torch.tensor([t.shape[1] for t in send], dtype=torch.int64, device=self.device)
+        rsizes = torch.zeros(world, dtype=torch.int64, device=self.device)
+        self.dist.all_to_all_single(rsizes, sizes)
+        recv = [torch.zeros((4, int(k)), dtype=torch.int64, device=self.device) for k in rsizes.tolist()]
+        send = [t.contiguous() for t in send]
+        try:
+            self.dist.all_to_all(recv, send)
+        except Exception:  # gloo has no all_to_all for CPU tensors in every build: point-to-point pairs, same bytes on the wire
+            reqs = []
+            for r in range(world):
+                if r == self.rank:
+                    recv[r].copy_(send[r])
+                    continue
+                if send[r].numel():
+                    reqs.append(self.dist.isend(send[r], r))
+                if recv[r].numel():
+                    reqs.append(self.dist.irecv(recv[r], r))
+            for q in reqs:
+                q.wait()
+        return torch.cat(recv, dim=1).contiguous()
+
+    def gather_groups(self, torch, mine):
+        """ragged all-gather of [4, g] blocks → [4, G], rank order"""
+        world = self.world
+        counts = [int(v) for v in self.all_gather_rows(torch, torch.tensor([mine.shape[1]], dtype=torch.int64, device=self.device))[:, 0].tolist()]
+        mx = max(counts) if counts else 0
+        pad = torch.zeros((4, mx), dtype=torch.int64, device=self.device)
+        pad[:, : mine.shape[1]] = mine
+        gathered = [torch.zeros((4, mx), dtype=torch.int64, device=self.device) for _ in range(world)]
+        self.dist.all_gather(gathered, pad)
+        return torch.cat([gathered[r][:, : counts[r]] for r in range(world)], dim=1).contiguous()
+
+
+class AhCommCollectives:
+    """The same four exchanges through the C ABI (ah_comm_*).  Sizes cross the host once per exchange (an all-gather of
+    world × 8 bytes followed by a stream sync): the blocks themselves never leave the devices."""
+
+    def __init__(self, comm, device):
+        self.comm, self.device = comm, device
+        self.rank, self.world = comm.rank, comm.world
+        import arrow_go_amd as ah
+        self.N = ah._native
+
+    def all_reduce_sum(self, torch, t):
+        tid = {torch.int64: self.N.INT64, torch.float64: self.N.FLOAT64, torch.int32: self.N.INT32, torch.float32: self.N.FLOAT32}[t.dtype]
+        self.comm.allreduce_sum(tid, t.data_ptr(), t.data_ptr(), t.numel())
+        return t
+
+    def all_gather_rows(self, torch, t):
+        t = t.contiguous()
+        out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=self.device)
+        self.comm.allgather(t.data_ptr(), out.data_ptr(), t.numel() * t.element_size())
+        return out
+
+    def _sizes(self, torch, mine):
+        """every rank's size vector: [world, len(mine)] on the host"""
+        m = self.all_gather_rows(torch, torch.tensor(mine, dtype=torch.int64, device=self.device))
+        self.comm.ctx.sync()
+        return m.cpu().numpy()
+
+    def exchange(self, torch, send):
+        world, rank = self.world, self.rank
+        cnt = [int(t.shape[1]) for t in send]
+        table = self._sizes(torch, cnt)                       # table[s][r] = tuples rank s sends to rank r
+        rcnt = [int(table[s][rank]) for s in range(world)]
+        sbuf = torch.cat([t.t().contiguous() for t in send], dim=0).contiguous() if sum(cnt) else torch.zeros((0, 4), dtype=torch.int64, device=self.device)
+        rbuf = torch.empty((sum(rcnt), 4), dtype=torch.int64, device=self.device)   # tuple-major: one contiguous block per peer
+        offs = lambda c: [32 * int(v) for v in np.concatenate([[0], np.cumsum(c)[:-1]])]
+        self.comm.alltoallv(sbuf.data_ptr(), [32 * c for c in cnt], offs(cnt), rbuf.data_ptr(), [32 * c for c in rcnt], offs(rcnt))
+        return rbuf.t().contiguous()
+
+    def gather_groups(self, torch, mine):
+        world = self.world
+        counts = [int(v) for v in self._sizes(torch, [int(mine.shape[1])])[:, 0]]
+        mx = max(counts) if counts else 0
+        pad = torch.zeros((mx, 4), dtype=torch.int64, device=self.device)
+        pad[: mine.shape[1]] = mine.t()
+        out = torch.empty((world, mx, 4), dtype=torch.int64, device=self.device)
+        self.comm.allgather(pad.data_ptr(), out.data_ptr(), mx * 32)
+        return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0).t().contiguous()
+
+
+class ShardedCompute:
+    """Collective layer over a `local` leaf provider and a collective provider (`dist_or_coll`: a provider object,
+    or torch.distributed itself → TorchCollectives)."""
+
+    def __init__(self, dist_or_coll, device, local):
+        self.coll = dist_or_coll if hasattr(dist_or_coll, "exchange") else TorchCollectives(dist_or_coll, device)
+        self.device, self.local = device, local
+        self.rank, self.world = self.coll.rank, self.coll.world
 
     # ---- C4: Compare(op scalar) → Filter(DropNulls) → Sum --------------------------------
     def cmp_filter_sum(self, torch, cmpop: int, x_ptr, valid_ptr, off: int, n_local: int, thr, dtype):
@@ -144,19 +251,18 @@ class ShardedCompute:
             part = torch.zeros(2, dtype=torch.int64, device=self.device)  # [sum, count]
             self.local.cmp_filter_sum_partial(cmpop, x_ptr, valid_ptr, off, n_local, thr, dtype,
                                               part.data_ptr(), part.data_ptr() + 8)
-            self.dist.all_reduce(part)  # wrapping int64 sum: exact in any order
+            self.coll.all_reduce_sum(torch, part)  # wrapping int64 sum: exact in any order — 16 bytes on the wire
             return int(part[0].item()), int(part[1].item())
         s = torch.zeros(1, dtype=torch.float64, device=self.device)
         c = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.local.cmp_filter_sum_partial(cmpop, x_ptr, valid_ptr, off, n_local, thr, dtype, s.data_ptr(), c.data_ptr())
         # float64: all-gather the partials and add them in RANK order on every rank, so the
         # result is bit-identical across ranks and runs (an all-reduce's order is not)
-        parts = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(self.world)]
-        self.dist.all_gather(parts, s)
-        self.dist.all_reduce(c)
+        parts = self.coll.all_gather_rows(torch, s)
+        self.coll.all_reduce_sum(torch, c)
         total = 0.0
-        for p in parts:
-            total += float(p.item())
+        for p in parts[:, 0].tolist():
+            total += float(p)
         return total, int(c.item())
 
     # ---- C5: hash group-by sum ----------------------------------------------------------------
@@ -178,48 +284,13 @@ class ShardedCompute:
         gets all groups, ordered by global first occurrence).  Bytes exchanged are O(groups), never
         O(rows); every compute step (owner bucketing, owner-side re-aggregation, final ordering)
         runs through the `local` provider — on the GPU for HipLocal."""
-        world = self.world
         # 1. bucket this rank's groups by owner rank
-        send = self.local.partition_by_owner(torch, cols, world)          # list of [4, g_r]
-        # 2. sizes, then payloads (ragged all-to-all)
-        sizes = torch.tensor([t.shape[1] for t in send], dtype=torch.int64, device=self.device)
-        rsizes = torch.zeros(world, dtype=torch.int64, device=self.device)
-        self.dist.all_to_all_single(rsizes, sizes)
-        recv = [torch.zeros((4, int(k)), dtype=torch.int64, device=self.device) for k in rsizes.tolist()]
-        self._all_to_all(recv, [t.contiguous() for t in send])
-        got = torch.cat(recv, dim=1).contiguous()                         # source ranks in ascending order
+        send = self.local.partition_by_owner(torch, cols, self.world)     # list of [4, g_r]
+        # 2. ragged all-to-all: every owner receives the tuples of its keys, source ranks in ascending order
+        got = self.coll.exchange(torch, send)
         # 3. the owner re-aggregates its keys (sum of partial sums, sum of counts, first of the firsts)
         mine = self.local.merge_tuples(torch, got, is_float)              # [4, g_owned]
         # 4. every rank gets every owner's groups …
-        n_mine = torch.tensor([mine.shape[1]], dtype=torch.int64, device=self.device)
-        all_n = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(world)]
-        self.dist.all_gather(all_n, n_mine)
-        counts = [int(t.item()) for t in all_n]
-        mx = max(counts) if counts else 0
-        pad = torch.zeros((4, mx), dtype=torch.int64, device=self.device)
-        pad[:, : mine.shape[1]] = mine
-        gathered = [torch.zeros((4, mx), dtype=torch.int64, device=self.device) for _ in range(world)]
-        self.dist.all_gather(gathered, pad)
-        rows = torch.cat([gathered[r][:, : counts[r]] for r in range(world)], dim=1).contiguous()
+        rows = self.coll.gather_groups(torch, mine)
         # 5. … ordered by global first occurrence (what a single-process `unique` would produce)
         return self.local.order_by_first(torch, rows)
-
-    def _all_to_all(self, recv, send):
-        """ragged all-to-all; gloo has no all_to_all for CPU tensors in every build, so fall
-        back to point-to-point send/recv pairs there (same bytes on the wire)."""
-        try:
-            self.dist.all_to_all(recv, send)
-            return
-        except Exception:
-            pass
-        reqs = []
-        for r in range(self.world):
-            if r == self.rank:
-                recv[r].copy_(send[r])
-                continue
-            if send[r].numel():
-                reqs.append(self.dist.isend(send[r], r))
-            if recv[r].numel():
-                reqs.append(self.dist.irecv(recv[r], r))
-        for q in reqs:
-            q.wait()

@@ -61,6 +61,9 @@ def parse():
     p.add_argument("--no-c5-merge", action="store_true",
                    help="C5 secondary line: skip the merge of the per-GPU aggregates by key-hash owner (all-to-all of group tuples over "
                         "RCCL), which is ON whenever more than one rank runs — the config is 'partitioned by key-hash over xGMI'")
+    p.add_argument("--collectives", choices=["ah", "torch"], default="ah",
+                   help="who performs the data-path collectives under torch.distributed.run: 'ah' = ah_comm_* of libarrowhip.so (RCCL through "
+                        "the C ABI, on the library's stream — what a Go host would call), 'torch' = torch.distributed's nccl group")
     p.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table")
     p.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch of the Add kernel from a rocprofv3 --pmc pass")
     return p.parse_args()
@@ -289,8 +292,19 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import arrow_go_amd as ah
     N = ah._native
+    comm = None
     if use_dist:
         ctx = ah.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        if args.collectives == "ah":
+            # rank 0's RCCL unique id reaches the others over the launcher's process group; from here on the data-path
+            # collectives are C-ABI calls on the library's own stream
+            try:
+                uid = [ah.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = ah.Comm(ctx, rank, world, uid[0])
+            except Exception as e:  # stay measurable: fall back to torch's group and say so
+                sys.stderr.write(f"bench: ah_comm unavailable ({e!r}); using torch.distributed collectives\n")
+                comm = None
     else:
         ctx = ah.Context(0)
 
@@ -319,8 +333,10 @@ def main():
         if mark:
             ctx.event_record(2 * i + 1)
         ctx.sum_float64_dev(x, rows, part_ptr)
-        if use_dist:
-            dist.all_reduce(part)  # 8-byte RCCL all-reduce: the path's only exchange step
+        if comm is not None:
+            comm.allreduce_sum(N.FLOAT64, part_ptr, part_ptr, 1)  # 8-byte RCCL all-reduce through the C ABI: the path's only exchange step
+        elif use_dist:
+            dist.all_reduce(part)
 
     for i in range(args.warmup):
         step(i, False)
@@ -357,7 +373,9 @@ def main():
 
         def c4_step():
             ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, pair_ptr)
-            if use_dist:
+            if comm is not None:
+                comm.allreduce_sum(N.INT64, pair_ptr, pair_ptr, 2)
+            elif use_dist:
                 dist.all_reduce(pair)
 
         for _ in range(max(args.warmup, 1)):
@@ -389,9 +407,10 @@ def main():
             c.upload(kchunk[:min(1 << 22, hrows - off)], off * 8)
         merge = use_dist and world > 1 and not args.no_c5_merge
         if merge:
-            from arrow_go_amd.distributed import HipLocal, ShardedCompute
+            from arrow_go_amd.distributed import AhCommCollectives, HipLocal, ShardedCompute
             local = HipLocal.__new__(HipLocal); local.ctx = ctx; local.N = N        # share this rank's context / stream
-            sc = ShardedCompute(dist, torch.device("cuda", local_rank), local)
+            dev = torch.device("cuda", local_rank)
+            sc = ShardedCompute(AhCommCollectives(comm, dev) if comm is not None else dist, dev, local)
             outs = [torch.empty(hrows + 1, dtype=torch.int64, device=f"cuda:{local_rank}") for _ in range(4)]
             optr = [t.data_ptr() for t in outs]
         else:
@@ -436,7 +455,8 @@ def main():
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": "C2: Int64 Add (array+array) + Float64 Sum over contiguous Arrow value buffers resident in HBM"
-                                   + (" + 8-byte RCCL all-reduce of the partial sums" if use_dist else ""),
+                                   + (" + 8-byte RCCL all-reduce of the partial sums" + (" (ah_comm_allreduce_sum)" if comm is not None else " (torch.distributed)")
+                                      if use_dist else ""),
                        "rows_per_gpu": rows, "bytes_per_row_per_step": 32,
                        "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "binary_kernel<uint64, ADD, array∘array> (Int64 Add)",
@@ -458,6 +478,8 @@ def main():
             except Exception as e:
                 result["cpu_baseline"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -373,6 +373,32 @@ int ah_min_max(ah_ctx* ctx, int type, const void* values, int64_t n, void* out_m
  * hashInt = internal/hashing/hash_funcs.go:60-67.  No reference analogue (the reference is single-process). */
 int ah_hash_partition_u64(ah_ctx* ctx, const uint64_t* keys, int64_t n, int nparts, int32_t* out_part);
 
+/* ---- multi-GPU exchange — RCCL over xGMI on the context's compute stream -------------------------------
+ * No reference analogue (arrow-go is single-process).  One process per GPU.  Rank 0 calls ah_comm_unique_id and the
+ * host distributes the 128 bytes (file, socket, launcher); every rank then calls ah_comm_init on its own ah_ctx.
+ * Collectives are enqueued behind the kernels already on the compute stream and return without waiting (ah_sync to
+ * wait); buffers are device pointers, counts / offsets host arrays of `world` entries.  The path needs exactly these:
+ *   C4  ah_comm_allreduce_sum(AH_INT64, partial, partial, 2) after ah_cmp_filter_sum_i64_dev — 16 bytes;
+ *       float64: ah_comm_allgather of the 8-byte partials, added in rank order by the caller (bit-reproducible)
+ *   C5  owner merge of group tuples: ah_comm_alltoallv (direct send / recv pairs — all xGMI links at once) of
+ *       O(groups) bytes, then ah_comm_allgather of the owners' results
+ * RCCL is bound with dlopen at first use (the copy already in the process, e.g. torch's, else the system's;
+ * ARROWHIP_RCCL overrides); a machine without it gets AH_EHIP from these calls and loses nothing else. */
+typedef struct ah_comm ah_comm;
+int ah_comm_unique_id(void* id_host128);
+int ah_comm_init(ah_ctx* ctx, int rank, int world, const void* unique_id_host128, ah_comm** out);
+int ah_comm_destroy(ah_comm* comm);
+int ah_comm_rank(ah_comm* comm);
+int ah_comm_world(ah_comm* comm);
+/* type: AH_INT32 / UINT32 / INT64 / UINT64 / FLOAT32 / FLOAT64; send may equal recv (in place) */
+int ah_comm_allreduce_sum(ah_comm* comm, int type, const void* send, void* recv, int64_t count);
+/* recv holds world × nbytes_per_rank bytes, rank r's block at r × nbytes_per_rank */
+int ah_comm_allgather(ah_comm* comm, const void* send, void* recv, int64_t nbytes_per_rank);
+/* block for rank r: send + send_offs_host[r], send_bytes_host[r] bytes; arrives at recv + recv_offs_host[r] of rank r;
+ * recv_bytes_host[r] must be what rank r sends here (exchange the sizes first: an allgather of 8·world bytes) */
+int ah_comm_alltoallv(ah_comm* comm, const void* send, const int64_t* send_bytes_host, const int64_t* send_offs_host, void* recv,
+                      const int64_t* recv_bytes_host, const int64_t* recv_offs_host);
+
 /* ---- numeric cast (row §8(f)-2) ----------------------------------------------------------------
  * replaces castNumberToNumberUnsafe → castNumericUnsafe (kernels/cast_numeric.go:28-131; AVX2 leaf
  * cast_type_numeric_avx2(itype, otype, in, out, len), kernels/_lib/cast_numeric.cc:62) together with

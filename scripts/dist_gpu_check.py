@@ -22,13 +22,18 @@ torch.cuda.set_device(local_rank)
 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
 import arrow_go_amd as ah  # noqa: E402  (after torch, on purpose)
-from arrow_go_amd.distributed import HipLocal, ShardedCompute, shard_bounds  # noqa: E402
+from arrow_go_amd.distributed import AhCommCollectives, HipLocal, ShardedCompute, shard_bounds  # noqa: E402
 from tests import oracle_lib as OL  # noqa: E402
 
 o = OL.load_oracle()
 local = HipLocal(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-sc = ShardedCompute(dist, torch.device("cuda", local_rank), local)
 ctx = local.ctx
+# the exchanges go through the C ABI (ah_comm_*: RCCL on the ah_ctx's stream); torch.distributed only carries the 128-byte id
+uid = [ah.Comm.unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, src=0)
+comm = ah.Comm(ctx, rank, world, uid[0])
+sc = ShardedCompute(AhCommCollectives(comm, torch.device("cuda", local_rank)), torch.device("cuda", local_rank), local)
+sc_torch = ShardedCompute(dist, torch.device("cuda", local_rank), local)     # cross-check: the same steps over torch's "nccl" group
 rng = np.random.default_rng(1234)
 n = 1_000_003
 x = rng.integers(-10**9, 10**9, n, dtype=np.int64)
@@ -39,6 +44,7 @@ vt = torch.from_numpy(np.packbits(valid_bits[lo:hi], bitorder="little")).cuda()
 got = sc.cmp_filter_sum(torch, 2, xt.data_ptr(), vt.data_ptr(), 0, hi - lo, 0, np.int64)
 exp = o.cmp_filter_sum_i64(2, x, np.packbits(valid_bits, bitorder="little"), 0, 0)
 assert got == exp, (got, exp)
+assert sc_torch.cmp_filter_sum(torch, 2, xt.data_ptr(), vt.data_ptr(), 0, hi - lo, 0, np.int64) == exp
 xf = rng.uniform(-1, 1, n)
 xft = torch.from_numpy(xf[lo:hi].copy()).cuda()
 gotf = sc.cmp_filter_sum(torch, 2, xft.data_ptr(), vt.data_ptr(), 0, hi - lo, 0.25, np.float64)
@@ -56,6 +62,19 @@ lk = ok[:ng].cpu().numpy().view(np.uint64); ls = osum[:ng].cpu().numpy(); lc = o
 mk, ms, mc, mf = sc.merge_groups(torch, lk, ls, lc, lf, lo)
 ek, es, ec, _nid, ef = o.hash_sum("i64", keys, None, 0, vals, None, 0)
 assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes()
+tk, ts, tc, tf = sc_torch.merge_groups(torch, lk, ls, lc, lf, lo)
+assert tk.tobytes() == ek.tobytes() and ts.tobytes() == es.tobytes() and tc.tobytes() == ec.tobytes() and tf.tobytes() == ef.tobytes()
+# raw entry points: in-place all-reduce, all-gather, ragged all-to-all (at world 1 the own block is a device copy)
+t = torch.arange(5, dtype=torch.float64, device="cuda")
+comm.allreduce_sum(ah._native.FLOAT64, t.data_ptr(), t.data_ptr(), 5)
+gat = torch.empty(world * 5, dtype=torch.float64, device="cuda")
+comm.allgather(t.data_ptr(), gat.data_ptr(), 40)
+src = torch.arange(world * 3, dtype=torch.int64, device="cuda") + 100 * rank
+dst = torch.zeros(world * 3, dtype=torch.int64, device="cuda")
+comm.alltoallv(src.data_ptr(), [24] * world, [24 * r for r in range(world)], dst.data_ptr(), [24] * world, [24 * r for r in range(world)])
+ctx.sync()
+assert t.tolist() == [float(world * i) for i in range(5)] and gat.tolist() == [float(world * i) for i in range(5)] * world
+assert dst.tolist() == [100 * r + 3 * rank + j for r in range(world) for j in range(3)]
 # the three merge steps of the collective layer on the GPU, against their numpy restatement: bucket a
 # group list for a 3-rank world, re-aggregate tuples with duplicate keys, order by first row
 from arrow_go_amd.distributed import owner_of  # noqa: E402
@@ -78,7 +97,8 @@ for j, key in enumerate(merged[0][:200].tolist()):
 shuf = ct[:, torch.randperm(g, device="cuda")].contiguous()
 ordered = local.order_by_first(torch, shuf).cpu().numpy()
 assert ordered.tobytes() == cols.tobytes()       # first rows are distinct and ascending in `cols`
+comm.close()
 dist.barrier()
 dist.destroy_process_group()
 if rank == 0:
-    print("dist_gpu_check ok: RCCL all-reduce + fused kernel on torch's stream + group-by merge, world =", world)
+    print("dist_gpu_check ok: ah_comm_* (RCCL through the C ABI) all-reduce / all-gather / all-to-all + fused kernel + group-by merge, world =", world)

@@ -89,6 +89,52 @@ class OracleLocal:
         return torch.from_numpy(np.ascontiguousarray(r[:, np.argsort(r[3], kind="stable")]))
 
 
+class GlooByteComm:
+    """stand-in for arrow_go_amd.Comm with the SAME byte-level interface as ah_comm_* (pointers, byte counts, byte offsets),
+    carried by gloo point-to-point messages between CPU buffers: what runs under test is AhCommCollectives' packing —
+    tuple-major blocks, size table, offsets — for world > 1, which a 1-GPU box cannot exercise over RCCL."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.ctx = self
+
+    def sync(self):
+        pass
+
+    def _view(self, ptr, nbytes):
+        return self.torch.frombuffer((ctypes.c_uint8 * max(nbytes, 1)).from_address(ptr if nbytes else ctypes.addressof(ctypes.c_uint8())), dtype=self.torch.uint8)[:nbytes]
+
+    def allreduce_sum(self, type_id, send, recv, count):
+        import arrow_go_amd as ah
+        dt = {ah._native.INT64: self.torch.int64, ah._native.FLOAT64: self.torch.float64}[type_id]
+        t = self._view(recv, count * 8).view(dt)
+        if send != recv:
+            t.copy_(self._view(send, count * 8).view(dt))
+        self.dist.all_reduce(t)
+
+    def allgather(self, send, recv, nbytes):
+        parts = [self.torch.zeros(nbytes, dtype=self.torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, self._view(send, nbytes).clone())
+        self._view(recv, nbytes * self.world).copy_(self.torch.cat(parts))
+
+    def alltoallv(self, send, send_bytes, send_offs, recv, recv_bytes, recv_offs):
+        reqs, keep = [], []
+        for r in range(self.world):
+            if r == self.rank:
+                assert send_bytes[r] == recv_bytes[r]
+                if send_bytes[r]:
+                    self._view(recv + recv_offs[r], recv_bytes[r]).copy_(self._view(send + send_offs[r], send_bytes[r]).clone())
+                continue
+            if send_bytes[r]:
+                t = self._view(send + send_offs[r], send_bytes[r]).clone(); keep.append(t)
+                reqs.append(self.dist.isend(t, r))
+            if recv_bytes[r]:
+                reqs.append(self.dist.irecv(self._view(recv + recv_offs[r], recv_bytes[r]), r))
+        for q in reqs:
+            q.wait()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -142,6 +188,25 @@ def _worker(rank, world, port, q):
         mk, ms, mc, mf = sc.merge_groups(torch, lk, ls, lc, lf, lo)
         ek, es, ec, _nid, ef = o.hash_sum("f64", keys, None, 0, fv, None, 0)
         assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes()
+        # the same steps through the C-ABI-shaped provider (AhCommCollectives over a byte-level comm): block packing and
+        # offsets for world > 1; ragged on purpose (rank 0 contributes no groups at all in the second round)
+        from arrow_go_amd.distributed import AhCommCollectives
+        sc2 = ShardedCompute(AhCommCollectives(GlooByteComm(dist, torch), torch.device("cpu")), torch.device("cpu"), OracleLocal())
+        assert sc2.cmp_filter_sum(torch, GT, x[lo:hi], vshard, 0, hi - lo, 0, np.int64) == exp
+        assert sc2.cmp_filter_sum(torch, GT, xf[lo:hi], vshard, 0, hi - lo, 0.25, np.float64) == gotf
+        lk, ls, lc, _nid, lf = o.hash_sum("i64", keys[lo:hi], None, 0, vals[lo:hi], None, 0)
+        mk, ms, mc, mf = sc2.merge_groups(torch, lk, ls, lc, lf, lo)
+        ek, es, ec, _nid, ef = o.hash_sum("i64", keys, None, 0, vals, None, 0)
+        assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes()
+        l0, h0 = shard_bounds(n, 0, world)
+        k2, v2 = keys[h0:], vals[h0:]                     # rows of rank 0 removed: it has nothing to send
+        if rank == 0:
+            lk, ls, lc, lf = np.zeros(0, np.uint64), np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64)
+        else:
+            lk, ls, lc, _nid, lf = o.hash_sum("i64", keys[lo:hi], None, 0, vals[lo:hi], None, 0)
+        mk, ms, mc, mf = sc2.merge_groups(torch, lk, ls, lc, lf, lo - h0)
+        ek, es, ec, _nid, ef = o.hash_sum("i64", k2, None, 0, v2, None, 0)
+        assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes()
         q.put((rank, "ok"))
     except Exception as e:  # surface the failure in the parent
         import traceback
