@@ -142,6 +142,11 @@ func (x *Context) ArithmeticArrScalar(typ arrow.Type, op int8, l, rHost, out uns
 	return x.err(C.ah_arithmetic_arr_scalar(x.c, C.int(typ), C.int8_t(op), l, rHost, out, C.int64_t(n)))
 }
 
+// ArithmeticScalarArr: scalar ∘ array (scalar in HOST memory).
+func (x *Context) ArithmeticScalarArr(typ arrow.Type, op int8, lHost, r, out unsafe.Pointer, n int64) error {
+	return x.err(C.ah_arithmetic_scalar_arr(x.c, C.int(typ), C.int8_t(op), lHost, r, out, C.int64_t(n)))
+}
+
 // Comparison replaces the 12 _comparison_*_avx2 leaves (kernels/scalar_comparison_avx2_amd64.go).
 func (x *Context) Comparison(cmpop, shape int, typ arrow.Type, l, r, outBits unsafe.Pointer, n int64, outBitOffset int) error {
 	return x.err(C.ah_comparison(x.c, C.int(cmpop), C.int(shape), C.int(typ), l, r, (*C.uint8_t)(outBits), C.int64_t(n), C.int(outBitOffset)))
@@ -150,6 +155,17 @@ func (x *Context) Comparison(cmpop, shape int, typ arrow.Type, l, r, outBits uns
 // BitmapAnd replaces bitutil.BitmapAnd (arrow/bitutil/bitmaps.go:601) on device bitmaps.
 func (x *Context) BitmapAnd(l unsafe.Pointer, lOff int64, r unsafe.Pointer, rOff int64, out unsafe.Pointer, oOff, n int64) error {
 	return x.err(C.ah_bitmap_op(x.c, C.AH_BIT_AND, (*C.uint8_t)(l), C.int64_t(lOff), (*C.uint8_t)(r), C.int64_t(rOff), (*C.uint8_t)(out), C.int64_t(oOff), C.int64_t(n)))
+}
+
+// BitmapOp is bitutil.BitmapOp (arrow/bitutil/bitmaps.go:494-521): op = AH_BIT_AND / OR / XOR / AND_NOT / XNOR.
+func (x *Context) BitmapOp(op int, l unsafe.Pointer, lOff int64, r unsafe.Pointer, rOff int64, out unsafe.Pointer, oOff, n int64) error {
+	return x.err(C.ah_bitmap_op(x.c, C.int(op), (*C.uint8_t)(l), C.int64_t(lOff), (*C.uint8_t)(r), C.int64_t(rOff), (*C.uint8_t)(out), C.int64_t(oOff), C.int64_t(n)))
+}
+
+// Kleene is computeKleene (kernels/scalar_boolean.go:29-65): op = AH_KLEENE_AND / OR / AND_NOT; writes validity AND data.
+func (x *Context) Kleene(op int, lvalid, ldata unsafe.Pointer, lOff int64, rvalid, rdata unsafe.Pointer, rOff int64, ovalid, odata unsafe.Pointer, oOff, n int64) error {
+	return x.err(C.ah_kleene(x.c, C.int(op), (*C.uint8_t)(lvalid), (*C.uint8_t)(ldata), C.int64_t(lOff), (*C.uint8_t)(rvalid), (*C.uint8_t)(rdata),
+		C.int64_t(rOff), (*C.uint8_t)(ovalid), (*C.uint8_t)(odata), C.int64_t(oOff), C.int64_t(n)))
 }
 
 func (x *Context) CountSetBits(bits unsafe.Pointer, off, n int64) (int64, error) {
@@ -173,6 +189,15 @@ func (x *Context) FilterPrimitive(byteWidth int, values, vvalid unsafe.Pointer, 
 	var r C.int64_t
 	err = x.err(C.ah_filter_primitive(x.c, C.int(byteWidth), values, (*C.uint8_t)(vvalid), C.int64_t(voff), (*C.uint8_t)(fdata),
 		(*C.uint8_t)(fvalid), C.int64_t(foff), C.int64_t(n), C.int(nullSel), C.int64_t(nOut), outValues, (*C.uint8_t)(outValid), &r))
+	return int64(r), err
+}
+
+// FilterToIndices == GetTakeIndices (vector_selection.go:102-236), uint32 flavour: one index vector gathers every column of
+// a record batch (FilterRecordBatch, compute/selection.go:679-722).
+func (x *Context) FilterToIndices(fdata, fvalid unsafe.Pointer, foff, n int64, nullSel int, nOut int64, outIdx, outValid unsafe.Pointer) (nulls int64, err error) {
+	var r C.int64_t
+	err = x.err(C.ah_filter_to_indices(x.c, (*C.uint8_t)(fdata), (*C.uint8_t)(fvalid), C.int64_t(foff), C.int64_t(n), C.int(nullSel), C.int64_t(nOut),
+		(*C.uint32_t)(outIdx), (*C.uint8_t)(outValid), &r))
 	return int64(r), err
 }
 
@@ -244,6 +269,73 @@ func (x *Context) ArithmeticExt(typ arrow.Type, op, shape int, l, lvalid unsafe.
 	scalarValid bool, out unsafe.Pointer, n int64) error {
 	return x.err(C.ah_arithmetic_ext(x.c, C.int(typ), C.int(op), C.int(shape), l, (*C.uint8_t)(lvalid), C.int64_t(loff),
 		r, (*C.uint8_t)(rvalid), C.int64_t(roff), boolInt(scalarValid), out, C.int64_t(n)))
+}
+
+// HashU64Encode mirrors doAppendNumeric[uint64] over hashing.Table[uint64] (vector_hash.go:359-385): int32 ids in FIRST-SEEN
+// order + the dictionary; nullID = the id null received (-1: none).  outIDsValid / outDict may be nil.
+func (x *Context) HashU64Encode(keys, valid unsafe.Pointer, off, n int64, encodeNulls bool, outIDs, outIDsValid, outDict unsafe.Pointer) (ndict int64, nullID int32, err error) {
+	var nd C.int64_t
+	var nid C.int32_t
+	st := C.ah_hash_u64_encode(x.c, (*C.uint64_t)(keys), (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n), boolInt(encodeNulls), (*C.int32_t)(outIDs),
+		(*C.uint8_t)(outIDsValid), (*C.uint64_t)(outDict), &nd, &nid)
+	return int64(nd), int32(nid), x.err(st)
+}
+
+// HashSumFloat64 is the group-by sum (no reference analogue; definition in DESIGN.md §4): groups in first-seen order of the
+// keys, per group the sum of the valid values (bit-reproducible: 128-bit fixed point), their count and the first row.
+func (x *Context) HashSumFloat64(keys, kvalid unsafe.Pointer, koff int64, vals, vvalid unsafe.Pointer, voff, n int64,
+	outKeys, outSums, outCounts, outFirstRows unsafe.Pointer) (ngroups int64, nullGroup int32, err error) {
+	var ng C.int64_t
+	var nid C.int32_t
+	st := C.ah_hash_sum_f64(x.c, (*C.uint64_t)(keys), (*C.uint8_t)(kvalid), C.int64_t(koff), (*C.double)(vals), (*C.uint8_t)(vvalid), C.int64_t(voff), C.int64_t(n),
+		(*C.uint64_t)(outKeys), (*C.double)(outSums), (*C.int64_t)(outCounts), (*C.int64_t)(outFirstRows), &ng, &nid)
+	return int64(ng), int32(nid), x.err(st)
+}
+
+// IsIn mirrors isInKernelExec (kernels/scalar_set_lookup.go:374-413): nullBehavior = AH_NULL_MATCH / SKIP / EMIT_NULL / INCONCLUSIVE.
+func (x *Context) IsIn(byteWidth int, values, valid unsafe.Pointer, off, n int64, setValues, setValid unsafe.Pointer, setOff, setN int64, nullBehavior int,
+	outData, outValid unsafe.Pointer, outBitOffset int64) error {
+	return x.err(C.ah_is_in(x.c, C.int(byteWidth), values, (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(n), setValues, (*C.uint8_t)(setValid), C.int64_t(setOff),
+		C.int64_t(setN), C.int(nullBehavior), (*C.uint8_t)(outData), (*C.uint8_t)(outValid), C.int64_t(outBitOffset)))
+}
+
+// Comm is this rank's RCCL communicator on the Context's compute stream (one process per GPU; SURVEY.md §8e).  Rank 0 makes
+// the id with CommUniqueID and the launcher ships the 128 bytes to the other ranks.
+type Comm struct {
+	x *Context
+	c *C.ah_comm
+}
+
+func CommUniqueID() (id [128]byte, err error) {
+	if st := C.ah_comm_unique_id(unsafe.Pointer(&id[0])); st != C.AH_OK {
+		err = fmt.Errorf("arrowhip: ah_comm_unique_id failed (status %d): is librccl.so loadable?", int(st))
+	}
+	return
+}
+
+func (x *Context) NewComm(rank, world int, id [128]byte) (*Comm, error) {
+	var c *C.ah_comm
+	if err := x.err(C.ah_comm_init(x.c, C.int(rank), C.int(world), unsafe.Pointer(&id[0]), &c)); err != nil {
+		return nil, err
+	}
+	return &Comm{x: x, c: c}, nil
+}
+
+func (m *Comm) Close() { C.ah_comm_destroy(m.c) }
+
+// AllReduceSum: C4's only exchange step — the 16-byte {sum, count} of CmpFilterSumInt64Dev, in place.
+func (m *Comm) AllReduceSum(typ arrow.Type, send, recv unsafe.Pointer, count int64) error {
+	return m.x.err(C.ah_comm_allreduce_sum(m.c, C.int(typ), send, recv, C.int64_t(count)))
+}
+
+func (m *Comm) AllGather(send, recv unsafe.Pointer, nbytesPerRank int64) error {
+	return m.x.err(C.ah_comm_allgather(m.c, send, recv, C.int64_t(nbytesPerRank)))
+}
+
+// AllToAllV: the ragged exchange of group tuples for C5's key-hash-owner merge; sizes and offsets in bytes, one per rank.
+func (m *Comm) AllToAllV(send unsafe.Pointer, sendBytes, sendOffs []int64, recv unsafe.Pointer, recvBytes, recvOffs []int64) error {
+	p := func(v []int64) *C.int64_t { return (*C.int64_t)(unsafe.Pointer(&v[0])) }
+	return m.x.err(C.ah_comm_alltoallv(m.c, send, p(sendBytes), p(sendOffs), recv, p(recvBytes), p(recvOffs)))
 }
 
 // HashBinaryEncode mirrors doAppendBinary over BinaryMemoTable (vector_hash.go:288-325): ids in first-seen
