@@ -38,6 +38,8 @@ struct ah_ctx {
   // take (ah_take_binned.hip): ARROWHIP_TAKE_BINNED 0 never / 1 auto / 2 whenever legal; _WINDOW_LOG2 bytes of `values` per
   // bin; _GATHER_WG_PER_CU occupancy cap of the gather pass.  Also settable per context: ah_ctx_set_option.
   int opt_take_binned, opt_take_window_log2, opt_take_gather_wg, opt_take_gather_load;
+  int opt_groupby_partition;   // hash + sum (ah_groupby.hip): 0 never, 1 auto, k ≥ 2 always with 2^(k−2) partitions (ARROWHIP_GROUPBY_PARTITION)
+  int opt_hash_direct;         // unique / dictionary_encode (ah_hash.hip): 0 ids in a separate pass, 1 direct ids, 2 + LDS / re-packed table (default), 3 no re-packed table (ARROWHIP_HASH_DIRECT)
   int opt_scan_segment_log2;   // cumulative_sum: bytes of input per segment (ARROWHIP_SCAN_SEGMENT_LOG2; 0 = one segment)
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   char err[512];
@@ -95,6 +97,10 @@ int ah_partition_by_group(ah_ctx* ctx, const int32_t* ids, const unsigned long l
 int ah_take_binned_try(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int iw,
                        int is_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values,
                        uint8_t* out_valid, unsigned long long* first_bad, int* used);
+// internal (ah_groupby.hip): partition-first group-by; *used says whether it produced the result (else: the id-based path)
+int ah_groupby_partitioned_try(ah_ctx* ctx, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals,
+                               const uint8_t* vvalid, int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts,
+                               int64_t* out_first_rows, int64_t* out_ngroups, int32_t* out_null_group, int* used);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are

@@ -1,0 +1,639 @@
+// ah_groupby.hip — partition-first group-by (hash + sum) for 8-byte keys: config C5 of the baseline.
+//
+// There is no group-by in the reference: the definition is "dictionary-encode the keys with
+// hashing.Table[uint64] (internal/hashing/xxh3_memo_table_types.go:283-294; first-seen order, the null key takes the
+// id at which it is first seen, :231-238), then accumulate value[i] into group id[i] in row order".  The id-based path
+// of ah_hash.hip follows that literally — ids for every row (one probe of a table that lives in L2 / the Infinity
+// Cache / HBM per row), then a partition of (value, id) by id window and an LDS aggregation.  The ids in ROW order are
+// the expensive part, and a group-by does not need them: it needs, per distinct key, {sum, count, first row}.
+//
+// So the rows are first cut by a hash of the key into P partitions small enough that ALL keys of a partition fit a
+// table in LDS, and everything after the cut happens at LDS speed:
+//
+//   0 sample      2^21 rows spread over the column → linear-counting bitmap, read at half and at full sample → distinct
+//                 estimate (even-draw extrapolation, × 4 when the two points say "heavy tail") → P = 8 … 1024
+//   1 hist        per (tile, partition) counts
+//   - offsets     count table → position of every tile's first record of every partition        (ah_bins.h)
+//   2 scatter     {key, value bits, row | null flags} staged in partition order in LDS, written as runs; the largest
+//                 finite |value| rides along (the fixed-point scale of ah_hashing.h)
+//   3 aggregate   a workgroup takes ≤ 2^18 consecutive records of ONE partition: open-addressing table in LDS
+//                 {key, sum lo, sum hi, count | inf/nan flags, first row}, LDS atomics per row; the table leaves
+//                 as one coalesced copy (a partition handled by one workgroup) or is merged into the partition's
+//                 global table with atomics (partitions cut into several chunks: skewed keys)
+//   4 rank, emit  first rows → n-bit bitmap → prefix popcount = the sequential memo index of each group
+//                 (same argument as ah_hash.hip), groups written to out_*[id]
+//
+// Up to ≈ 4300 expected groups the id-based path keeps all groups in one LDS table and is as fast; beyond ≈ 1.3 M groups
+// 1024 partitions are not enough — both are left to it.
+// Nothing here depends on timing: integer sums and the 128-bit fixed-point float sums are associative, first row is
+// a minimum, ids are a function of the first rows — two runs give identical bytes, and the same bytes as the id-based
+// path (tests/test_gpu_parity.py::test_hash_sum_paths_agree).
+// Algorithmic bytes: 16 B/row (key + value).  Moved: 8 (hist) + 16 + 20 (scatter) + 20 (aggregate) = 64 B/row, all
+// streaming or ≥ 32-byte runs, against ≈ 90–200 B/row of random lines on the id-based path at 2^16–2^24 groups.
+#include <type_traits>
+#include "ah_common.h"
+#include "ah_hashing.h"
+#include "ah_bins.h"
+
+namespace {
+
+constexpr int kGbTile = 4096;                       // rows per tile of the hist / scatter passes
+constexpr int kGbRows = kGbTile / kThreads;          // 4 per thread in the scatter
+constexpr int kGbHistThreads = 256, kGbHistRows = kGbTile / kGbHistThreads;
+constexpr int kSlots = 4096;                         // LDS table: open addressing, linear probing
+constexpr int kSoftLimit = 3584;                     // keys admitted to the LDS table; later keys go to the global table
+constexpr int kLSlots = kSlots + 2;                  // + the all-ones key (kSlots) and the null key (kSlots + 1)
+constexpr int kGSlots = 8192;                        // global table of ONE partition
+constexpr int kGStride = kGSlots + 8;                // + the same two special slots at kGSlots, kGSlots + 1
+constexpr int kChunkLog2 = 18;                       // records per aggregate workgroup
+constexpr unsigned kKeyNull = 0x80000000u, kValNull = 0x40000000u, kRowMask = 0x1fffffffu;
+constexpr unsigned kCntMask = 0x1fffffffu;           // count word: bits 29..31 = NaN / +inf / −inf seen
+constexpr int64_t kMaxRows = (int64_t)1 << 29;
+
+// Any well-mixed hash will do: results depend on key EQUALITY and row order only.  (hashInt's low bits are fine, but
+// its bits above 12 depend on ever fewer key bits, and the partition number must not.)
+__device__ __forceinline__ uint64_t gb_mix(uint64_t k) {
+  uint64_t x = k * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  return x ^ (x >> 32);
+}
+__device__ __forceinline__ unsigned gb_part(uint64_t m, int lp) { return (unsigned)(m >> (64 - lp)); }   // lp = 3 … 10
+
+// ---- 0: distinct estimate by linear counting over a strided sample ---------------------------------------------------
+// Sample group g = 64 consecutive rows at g · stride; the launch covers groups g0, g0 + 2, g0 + 4, … (the host runs the even
+// groups, reads the bitmap's popcount, then the odd ones: two points of the distinct-count curve).  A 1024-entry filter
+// in LDS drops the keys this workgroup has just seen: without it a hot key sends every sampled row to ONE bitmap word —
+// 2^21 same-address atomics = 0.65 ms, and still 0.49 ms with a look-before-set on a Zipf column.
+__global__ __launch_bounds__(1024) void gb_sample_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
+                                                          int64_t n, int64_t ngroups, int64_t stride, int g0, unsigned* __restrict__ bm, unsigned mmask) {
+  __shared__ unsigned long long s_seen[1024];
+  s_seen[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t g = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + g0;
+  const int64_t i = g * stride + (threadIdx.x & 63);
+  if (g >= ngroups || i >= n || !ah_bit(kvalid, koff + i)) return;
+  const uint64_t m = gb_mix(keys[i]) | 1ull;
+  const unsigned f = (unsigned)(m >> 44) & 1023u;
+  if (atomicExch(&s_seen[f], m) == m) return;   // an LDS atomic, so that of the lanes holding a hot key at this instant only one goes on
+  const unsigned b = (unsigned)(m >> 20) & mmask;
+  if (!((__hip_atomic_load(&bm[b >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b & 31)) & 1u)) atomicOr(&bm[b >> 5], 1u << (b & 31));
+}
+
+// ---- 1: per (tile, partition) counts ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kGbHistThreads) void gb_hist_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
+                                                                  int64_t n, int lp, int nb, int64_t ntiles, unsigned* __restrict__ cnt_tm) {
+  __shared__ unsigned s_cnt[kMaxBins];
+  const int64_t tile = xcd_contiguous_tile(ntiles);
+  if (tile < 0) return;
+  for (int b = threadIdx.x; b < nb; b += kGbHistThreads) s_cnt[b] = 0;
+  __syncthreads();
+  const int64_t base = tile * kGbTile;
+  unsigned long long k[kGbHistRows];
+#pragma unroll
+  for (int u = 0; u < kGbHistRows; u++) {
+    const int64_t i = base + u * kGbHistThreads + threadIdx.x;
+    k[u] = i < n ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+  }
+#pragma unroll
+  for (int u = 0; u < kGbHistRows; u++) {
+    const int64_t i = base + u * kGbHistThreads + threadIdx.x;
+    if (i >= n) continue;
+    const unsigned p = ah_bit(kvalid, koff + i) ? gb_part(gb_mix(k[u]), lp) : 0u;
+    atomicAdd(&s_cnt[p], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += kGbHistThreads) cnt_tm[tile * nb + b] = s_cnt[b];
+}
+
+// largest finite |value| of the call from the per-tile maxima the scatter pass leaves (one plain store per tile: 65 536
+// atomicMax on one address cost 0.8 ms — 12 ns each, serialised)
+__global__ __launch_bounds__(1024) void gb_max_kernel(const unsigned long long* __restrict__ tile_max, int64_t ntiles, unsigned long long* __restrict__ absmax) {
+  __shared__ unsigned long long s_max[16];
+  unsigned long long m = 0;
+  for (int64_t i = threadIdx.x; i < ntiles; i += 1024) { const unsigned long long t = tile_max[i]; m = t > m ? t : m; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_down(m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) m = s_max[w] > m ? s_max[w] : m;
+    *absmax = m;
+  }
+}
+
+// ---- 2: records in partition order ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
+                                                               const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                               int64_t n, int lp, int nb, int64_t ntiles, const unsigned* __restrict__ toffs,
+                                                               unsigned long long* __restrict__ pkeys, unsigned long long* __restrict__ pvals,
+                                                               unsigned* __restrict__ prows, unsigned long long* __restrict__ tile_max) {
+  __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_goff[kMaxBins], s_wsum[kThreads / 64];
+  __shared__ unsigned long long s_stage[kGbTile];
+  __shared__ uint16_t s_bin[kGbTile];
+  __shared__ unsigned long long s_max[kThreads / 64];
+  // consecutive tiles on ONE XCD: the runs they append to a partition meet in that XCD's L2 and leave as whole lines
+  const int64_t tile = xcd_contiguous_tile(ntiles);
+  if (tile < 0) return;
+  s_cnt[threadIdx.x] = 0;
+  const int64_t base = tile * kGbTile;
+  unsigned long long k[kGbRows], v[kGbRows];
+  unsigned rw[kGbRows], bin[kGbRows], rank[kGbRows];
+  bool live[kGbRows];
+  unsigned long long vmax = 0;
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++) {
+    const int64_t i = base + u * kThreads + threadIdx.x;
+    live[u] = i < n;
+    k[u] = live[u] ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+    v[u] = live[u] ? __builtin_nontemporal_load(&vals[i]) : 0ull;
+  }
+  unsigned goff_excl = 0;
+  if ((int)threadIdx.x < nb) goff_excl = toffs[tile * nb + threadIdx.x];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++) {
+    const int64_t i = base + u * kThreads + threadIdx.x;
+    rw[u] = 0; bin[u] = 0; rank[u] = 0;
+    if (live[u]) {
+      const bool kv = ah_bit(kvalid, koff + i), vv = ah_bit(vvalid, voff + i);
+      bin[u] = kv ? gb_part(gb_mix(k[u]), lp) : 0u;
+      rw[u] = (unsigned)i | (kv ? 0u : kKeyNull) | (vv ? 0u : kValNull);
+      rank[u] = atomicAdd(&s_cnt[bin[u]], 1u);
+      const unsigned long long a = v[u] & 0x7fffffffffffffffull;   // |x| of finite doubles order like their bit patterns
+      if (tile_max && vv && (a >> 52) != 0x7ff && a > vmax) vmax = a;
+    }
+  }
+  if (tile_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long x = __shfl_down(vmax, o, 64);
+      vmax = x > vmax ? x : vmax;
+    }
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = vmax;
+  }
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  if ((int)threadIdx.x < nb) s_goff[threadIdx.x] = goff_excl - s_start[threadIdx.x];
+  if (tile_max && threadIdx.x == 0) {
+    unsigned long long x = s_max[0];
+    for (int w = 1; w < kThreads / 64; w++) x = s_max[w] > x ? s_max[w] : x;
+    tile_max[tile] = x;
+  }
+  const int tile_n = n - base >= kGbTile ? kGbTile : (int)(n - base);
+  // three rounds through one staging buffer: keys, value bits, row words
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++)
+    if (live[u]) { const unsigned q = s_start[bin[u]] + rank[u]; s_stage[q] = k[u]; s_bin[q] = (uint16_t)bin[u]; }
+  __syncthreads();
+  int64_t dst[kGbRows];
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++) {
+    const int q = u * kThreads + threadIdx.x;
+    dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
+    if (dst[u] >= 0) pkeys[dst[u]] = s_stage[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++)
+    if (live[u]) s_stage[s_start[bin[u]] + rank[u]] = v[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++)
+    if (dst[u] >= 0) pvals[dst[u]] = s_stage[u * kThreads + threadIdx.x];
+  __syncthreads();
+  unsigned* s_stage32 = reinterpret_cast<unsigned*>(s_stage);
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++)
+    if (live[u]) s_stage32[s_start[bin[u]] + rank[u]] = rw[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kGbRows; u++)
+    if (dst[u] >= 0) prows[dst[u]] = s_stage32[u * kThreads + threadIdx.x];
+}
+
+// ---- 3: aggregate -----------------------------------------------------------------------------------------------------
+// workgroups a partition of `rows` records is cut into: rows / 2^18 ROUNDED (and ≥ 1 when there are rows), so that evenly
+// spread keys with n / P = 2^18 give one chunk per partition — not one full chunk plus a sliver, which doubled the
+// number of workgroup rounds and turned every table copy into an atomic merge
+__host__ __device__ __forceinline__ unsigned gb_chunks(unsigned rows) {
+  const unsigned c = (rows + (1u << (kChunkLog2 - 1))) >> kChunkLog2;
+  return rows ? (c ? c : 1u) : 0u;
+}
+struct GbTable {   // global tables of all partitions, structure of arrays; partition p owns [p·kGStride, (p+1)·kGStride)
+  unsigned long long* key;
+  unsigned long long* lo;
+  unsigned long long* hi;    // floats only
+  unsigned* cnt;
+  unsigned* first;
+};
+
+// The table hashes are 32-bit (two quarter-rate multiplies instead of the eight of gb_mix): inside a partition the keys
+// agree in the top bits of gb_mix, so a different function is wanted here anyway.
+__device__ __forceinline__ unsigned gb_hash32(unsigned long long k) {
+  unsigned h = ((unsigned)k ^ ((unsigned)(k >> 32) * 0x9E3779B1u)) * 0x85EBCA6Bu;
+  return h ^ (h >> 15);
+}
+__device__ __forceinline__ unsigned gb_lslot(unsigned h) { return (h * 0xC2B2AE35u) >> (32 - 12); }
+__device__ __forceinline__ unsigned gb_gslot(unsigned h) { return (h * 0x27D4EB2Fu) >> (32 - 13); }
+static_assert(kSlots == 1 << 12 && kGSlots == 1 << 13, "slot hashes take the top 12 / 13 bits");
+
+// slot of `key` in partition table `base` (find or claim); −1 = table full → overflow flag, row dropped (the host falls back)
+__device__ __noinline__ long long gb_global_slot(unsigned long long* __restrict__ gkey, long long base, unsigned long long key, unsigned* __restrict__ overflow) {
+  unsigned j = gb_gslot(gb_hash32(key));
+  for (int probes = 0; probes < kGSlots; probes++) {
+    unsigned long long cur = gkey[base + j];
+    if (cur == kEmpty) cur = atomicCAS(&gkey[base + j], kEmpty, key);
+    if (cur == kEmpty || cur == key) return base + j;
+    j = (j + 1) & (kGSlots - 1);
+  }
+  atomicExch(overflow, 1u);
+  return -1;
+}
+
+template <bool FX>
+__device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsigned long long lo, unsigned long long hi, unsigned cntflags, unsigned first) {
+  if (FX) { if (lo | hi) fx_add(gt.lo, gt.hi, (size_t)s, lo, hi); }
+  else if (lo) atomicAdd(&gt.lo[s], lo);
+  if (cntflags & kCntMask) atomicAdd(&gt.cnt[s], cntflags & kCntMask);
+  if (cntflags & ~kCntMask) atomicOr(&gt.cnt[s], cntflags & ~kCntMask);
+  if (gt.first[s] > first) atomicMin(&gt.first[s], first);
+}
+
+// FX: Float64 values summed in 128-bit fixed point; else 64-bit wrapping integer sums.
+//
+// The kernel is bound by instruction issue, not by LDS or HBM (PMC at 2^26 rows: 121 VALU + 109 SALU + 10 LDS instructions
+// per 64 rows in the first version, the SALU all exec-mask bookkeeping of per-row branches; waves parked 52 % of the time
+// on LDS round trips with only 4 waves per SIMD — the table takes 136 KiB).  Hence: addends are formed without branches,
+// count / first row / high word go out as fire-and-forget LDS atomics (adding 0 or re-stating a minimum costs an LDS
+// slot, not a wait), and only two things make a wave wait: the key probe and the returning add that yields the carry.
+template <bool FX>
+__global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
+                                                                 const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
+                                                                 const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow) {
+  __shared__ __attribute__((aligned(16))) unsigned long long l_key[kLSlots];
+  __shared__ unsigned long long l_lo[kLSlots];
+  __shared__ unsigned long long l_hi[FX ? kLSlots : 1];
+  __shared__ unsigned l_cnt[kLSlots];
+  __shared__ unsigned l_first[kLSlots];
+  __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_wsum[kThreads / 64];
+  __shared__ unsigned s_used, s_direct;
+  __shared__ int s_part, s_chunk, s_multi;
+  const int t = threadIdx.x;
+  // which records?  workgroup → (partition, chunk): prefix sum over the partitions' chunk counts
+  unsigned rows = 0, ch = 0;
+  if (t < nb) { rows = binstart[t + 1] - binstart[t]; ch = gb_chunks(rows); }
+  s_cnt[t] = ch;
+  if (t == 0) s_part = -1;
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  if (t < nb && ch && s_start[t] <= blockIdx.x && blockIdx.x < s_start[t] + ch) { s_part = t; s_chunk = (int)(blockIdx.x - s_start[t]); s_multi = ch > 1; }
+  __syncthreads();
+  if (s_part < 0) return;
+  const int part = s_part;
+  const bool multi = s_multi != 0;
+  int64_t r0, r1;
+  {
+    const int64_t b0 = binstart[part], b1 = binstart[part + 1];
+    const int64_t nch = gb_chunks((unsigned)(b1 - b0)), per = (b1 - b0 + nch - 1) / nch;   // equal shares
+    r0 = b0 + (int64_t)s_chunk * per;
+    r1 = r0 + per < b1 ? r0 + per : b1;
+  }
+  for (int j = t; j < kLSlots; j += kThreads) { l_key[j] = kEmpty; l_lo[j] = 0; if (FX) l_hi[j] = 0; l_cnt[j] = 0; l_first[j] = kNoRow; }
+  if (t == 0) { s_used = 0; s_direct = 0; }
+  __syncthreads();
+  int sh = 0;
+  if (FX) sh = fx_shift(*absmax);
+  const int64_t gbase = (int64_t)part * kGStride;
+  bool went_direct = false;
+  // one pending group per lane: {key, 128-bit sum, count | flags, first row}.  A row with the key of the lane's previous row
+  // is added in registers: a key that owns most of a chunk (skewed columns) would otherwise put every lane of every wave
+  // on ONE LDS address, and same-address LDS atomics are served one lane at a time.
+  bool p_live = false;
+  unsigned long long p_key = 0, p_lo = 0, p_hi = 0;
+  unsigned p_kw = 0, p_cf = 0, p_first = kNoRow;
+  auto flush_row = [&](unsigned long long key, unsigned kw, unsigned long long lo, unsigned long long hi, unsigned cf, unsigned row) {
+    int j;
+    if (__builtin_expect(kw != 0 || key == kEmpty, 0)) {
+      j = kw ? kSlots + 1 : kSlots;
+    } else {
+      // Linear probing over aligned groups of 4 slots, a group per step (two 16-byte LDS reads, one wait): a wave walks as
+      // far as its unluckiest lane, and at load ¼ one slot per step meant 3–4 dependent round trips per row for the wave.
+      // The first slot of the probe order that holds the key or is empty decides (no deletions: a key never sits behind
+      // an empty slot of its own probe order).
+      unsigned g = gb_lslot(gb_hash32(key)) & ~3u;
+      for (;;) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&l_key[g]), c = *reinterpret_cast<const ulonglong2*>(&l_key[g + 2]);
+        const unsigned hit = (a.x == key ? 1u : 0u) | (a.y == key ? 2u : 0u) | (c.x == key ? 4u : 0u) | (c.y == key ? 8u : 0u);
+        const unsigned emp = (a.x == kEmpty ? 1u : 0u) | (a.y == kEmpty ? 2u : 0u) | (c.x == kEmpty ? 4u : 0u) | (c.y == kEmpty ? 8u : 0u);
+        const unsigned any = hit | emp;
+        if (any == 0) { g = (g + 4) & (kSlots - 1); continue; }
+        const int f = __builtin_ctz(any);
+        j = (int)g + f;
+        if ((hit >> f) & 1u) break;
+        // first empty slot of the probe order: claim it
+        if (atomicAdd(&s_used, 1u) >= (unsigned)kSoftLimit) { j = -1; break; }   // tickets are never returned: "full" sticks
+        const unsigned long long cur = atomicCAS(&l_key[j], kEmpty, key);
+        if (cur == kEmpty || cur == key) break;
+        // another key took it meanwhile: look at the group again
+      }
+    }
+    if (__builtin_expect(j >= 0, 1)) {
+      if (FX) {
+        const unsigned long long old = atomicAdd(&l_lo[j], lo);
+        atomicAdd(&l_hi[j], hi + (old + lo < old ? 1ull : 0ull));
+      } else {
+        atomicAdd(&l_lo[j], lo);
+      }
+      atomicAdd(&l_cnt[j], cf & kCntMask);
+      if (__builtin_expect(cf & ~kCntMask, 0)) atomicOr(&l_cnt[j], cf & ~kCntMask);
+      atomicMin(&l_first[j], row);
+    } else {
+      went_direct = true;
+      const long long gs = gb_global_slot(gt.key, gbase, key, overflow);
+      if (gs >= 0) gb_global_add<FX>(gt, gs, lo, hi, cf, row);
+    }
+  };
+  // software pipeline: the next step's 12 loads per lane are in flight while this step's rows go through LDS
+  constexpr int U = 4;
+  unsigned long long nk[U], nv[U];
+  unsigned nrw[U];
+  auto load_step = [&](int64_t b) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      nk[u] = 0; nv[u] = 0; nrw[u] = 0;
+      if (i < r1) {
+        nk[u] = __builtin_nontemporal_load(&keys[i]);
+        nv[u] = __builtin_nontemporal_load(&vals[i]);
+        nrw[u] = __builtin_nontemporal_load(&prows[i]);
+      }
+    }
+  };
+  load_step(r0);
+  for (int64_t b = r0; b < r1; b += (int64_t)kThreads * U) {
+    unsigned long long k[U], v[U];
+    unsigned rw[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { k[u] = nk[u]; v[u] = nv[u]; rw[u] = nrw[u]; }
+    if (b + (int64_t)kThreads * U < r1) load_step(b + (int64_t)kThreads * U);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool live = b + u * kThreads + t < r1;   // a slot past the end adds nothing to whatever is pending
+      const unsigned row = live ? rw[u] & kRowMask : kNoRow;
+      // the addend, without branches: a null value adds nothing and is not counted; ±inf / NaN are counted and flagged
+      const bool has = live && !(rw[u] & kValNull);
+      unsigned long long lo, hi = 0;
+      unsigned cf = has ? 1u : 0u;
+      if (FX) {
+        const double x = __builtin_bit_cast(double, v[u]);
+        const bool fin = fx_finite(x);
+        fx_split(x, sh, &lo, &hi);
+        lo = has && fin ? lo : 0ull;
+        hi = has && fin ? hi : 0ull;
+        cf |= has && !fin ? fx_flag(x) << 29 : 0u;
+      } else {
+        lo = has ? v[u] : 0ull;
+      }
+      const unsigned kw = rw[u] & kKeyNull;
+      const bool same = !live || (p_live && p_key == k[u] && p_kw == kw);
+      if (!same) {
+        if (p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
+        p_key = k[u]; p_kw = kw; p_lo = 0; p_hi = 0; p_cf = 0; p_first = kNoRow;
+        p_live = true;
+      }
+      const unsigned long long nl = p_lo + lo;
+      p_hi += hi + (nl < p_lo ? 1ull : 0ull);
+      p_lo = nl;
+      p_cf = (p_cf + (cf & kCntMask)) | (cf & ~kCntMask);   // < 2^19 rows per chunk: the count cannot reach the flag bits
+      p_first = row < p_first ? row : p_first;
+    }
+  }
+  if (p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
+  if (went_direct) s_direct = 1;
+  __syncthreads();
+  if (!multi && !s_direct) {
+    // the only workgroup of this partition and everything is in LDS: the table leaves as it is
+    for (int j = t; j < kSlots; j += kThreads) {
+      gt.key[gbase + j] = l_key[j];
+      gt.lo[gbase + j] = l_lo[j];
+      if (FX) gt.hi[gbase + j] = l_hi[j];
+      gt.cnt[gbase + j] = l_cnt[j];
+      gt.first[gbase + j] = l_first[j];
+    }
+    if (t < 2) {
+      const int j = kSlots + t;
+      const int64_t g = gbase + kGSlots + t;
+      gt.key[g] = l_key[j]; gt.lo[g] = l_lo[j]; if (FX) gt.hi[g] = l_hi[j]; gt.cnt[g] = l_cnt[j]; gt.first[g] = l_first[j];
+    }
+  } else {
+    for (int j = t; j < kLSlots; j += kThreads) {
+      const unsigned fr = l_first[j];
+      if (fr == kNoRow) continue;
+      long long gs;
+      if (j >= kSlots) gs = gbase + kGSlots + (j - kSlots);
+      else gs = gb_global_slot(gt.key, gbase, l_key[j], overflow);
+      if (gs >= 0) gb_global_add<FX>(gt, gs, l_lo[j], FX ? l_hi[j] : 0ull, l_cnt[j], fr);
+    }
+  }
+}
+
+// ---- 4: first-seen ranks and the output ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gb_mark_kernel(const unsigned* __restrict__ first, int64_t nslots, unsigned long long* __restrict__ firsts) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
+    const unsigned fr = first[s];
+    if (fr != kNoRow) atomicOr(&firsts[fr >> 6], 1ull << (fr & 63));
+  }
+}
+
+template <bool FX>
+__global__ __launch_bounds__(kBlock) void gb_emit_kernel(GbTable gt, int64_t nslots, const unsigned long long* __restrict__ firsts,
+                                                          const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff,
+                                                          const unsigned long long* __restrict__ absmax, unsigned long long* __restrict__ out_keys,
+                                                          unsigned long long* __restrict__ out_sums, long long* __restrict__ out_counts,
+                                                          long long* __restrict__ out_first_rows, int* __restrict__ null_id) {
+  int sh = 0;
+  if (FX) sh = fx_shift(*absmax);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
+    const unsigned fr = gt.first[s];
+    if (fr == kNoRow) continue;
+    const unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
+    const int in_part = (int)(s % kGStride);
+    unsigned long long key = gt.key[s];
+    if (in_part == kGSlots) key = kEmpty;
+    if (in_part == kGSlots + 1) { key = 0; *null_id = (int)id; }   // the null group's key slot keeps the fresh buffer's zero
+    out_keys[id] = key;
+    const unsigned cf = gt.cnt[s];
+    out_counts[id] = (long long)(cf & kCntMask);
+    if (FX) {
+      const unsigned f = cf >> 29;
+      double r;
+      if (f) r = (f & 1u) || (f & 6u) == 6u ? __builtin_nan("") : ((f & 2u) ? __builtin_inf() : -__builtin_inf());
+      else r = fx_to_double(gt.lo[s], gt.hi[s], sh);
+      out_sums[id] = __builtin_bit_cast(unsigned long long, r);
+    } else {
+      out_sums[id] = gt.lo[s];
+    }
+    if (out_first_rows) out_first_rows[id] = (long long)fr;
+  }
+}
+
+// distinct keys expected among n rows when a sample of p rows held d (uniform-urn model; as in ah_hash.hip)
+static double gb_extrapolate(double d, double p, double n) {
+  const double r = d / p;
+  if (r >= 0.999) return n;
+  if (r < 1.0 / 32) return d;   // every key was sampled dozens of times: nothing more to come
+  double lo = 1e-9, hi = 64.0;
+  for (int it = 0; it < 60; it++) {
+    const double mid = 0.5 * (lo + hi);
+    if ((1.0 - exp(-mid)) / mid > r) lo = mid; else hi = mid;
+  }
+  const double C = p / (0.5 * (lo + hi));
+  const double e = C * (1.0 - exp(-n / C));
+  return e < n ? e : n;
+}
+
+}  // namespace
+
+// Called by ah_hash_sum_* before the id-based path.  *used = 1: out_* hold the result; 0: not applicable (small input,
+// too many expected groups, or the estimate was so far off that a partition's table overflowed) — the caller runs the
+// id-based path, which accepts anything.
+int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals,
+                               const uint8_t* vvalid, int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts,
+                               int64_t* out_first_rows, int64_t* out_ngroups, int32_t* out_null_group, int* used) {
+  *used = 0;
+  const int mode = c->opt_groupby_partition;   // 0 never, 1 auto, k ≥ 5: always, with 2^(k − 2) partitions (tests, measurements)
+  if (mode == 0 || n >= kMaxRows || n < 1 || (mode == 1 && n < ((int64_t)1 << 21))) return AH_OK;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned* overflow = (unsigned*)&c->dscalars[21];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[22];
+  int* null_id = (int*)&c->dscalars[23];
+  unsigned long long* ones = (unsigned long long*)&c->dscalars[24];   // [24], [25]: the two sample points
+  // ---- 0: how many partitions?
+  int lp;
+  if (mode > 1) {
+    lp = mode - 2 < 3 ? 3 : (mode - 2 > 10 ? 10 : mode - 2);
+  } else {
+    constexpr int kSampleGroups = 1 << 15;            // × 64 consecutive rows = 2^21 sampled rows
+    constexpr unsigned kBits = 1u << 24;
+    const int64_t groups = (n / 64 < kSampleGroups ? n / 64 : kSampleGroups) & ~(int64_t)1;
+    const int64_t stride = ((n / groups) & ~(int64_t)63) ? ((n / groups) & ~(int64_t)63) : 64;
+    unsigned* bm;
+    int rc = ah_temp_reserve(c, kBits / 8, (void**)&bm);
+    if (rc != AH_OK) return rc;
+    AH_HIP(c, hipMemsetAsync(bm, 0, kBits / 8, c->stream));
+    for (int half = 0; half < 2; half++) {
+      gb_sample_kernel<<<(unsigned)ah_ceil_div(groups / 2, 16), 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, n, groups, stride, half, bm, kBits - 1);
+      AH_LAUNCH_CHECK(c);
+      if ((rc = ah_popcount_async(c, (const uint8_t*)bm, 0, kBits, ones + half)) != AH_OK) return rc;
+    }
+    AH_HIP(c, hipMemcpyAsync(&c->pinned[8], ones, 16, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    auto distinct = [&](uint64_t set, double rows) {   // linear counting: M·ln(M / zeros)
+      const double z = (double)kBits - (double)set;
+      const double d = z < 1.0 ? rows : -(double)kBits * log(z / (double)kBits);
+      return d > rows ? rows : d;
+    };
+    const double sampled = (double)groups * 64.0;
+    const double dh = distinct(*(volatile uint64_t*)&c->pinned[8], sampled / 2), ds = distinct(*(volatile uint64_t*)&c->pinned[9], sampled);
+    double est = gb_extrapolate(ds, sampled, (double)n);
+    if (est <= 4300.0) return AH_OK;                   // all groups fit the id-based path's LDS table: 0.55–1.0 ms there, no better here
+    // Keys drawn evenly from C values give a curve that the second half of the sample must follow; a heavy-tailed column
+    // (Zipf) keeps bringing new keys long after that curve has flattened, and its full distinct count is several times the
+    // even-draw extrapolation — give those columns 4× the partitions rather than let the LDS tables overflow into the
+    // global ones (measured: 0.45 → 0.89 ms in the aggregate pass of a Zipf(1.1) column over 2^20 keys)
+    const double dh_even = gb_extrapolate(ds, sampled, sampled / 2);
+    if (dh < 0.93 * dh_even) est *= 4.0;
+    if (est > 1.3e6 * 4.0 || gb_extrapolate(ds, sampled, (double)n) > 1.3e6) return AH_OK;   // beyond 1024 partitions of ≤ 1280 keys: the id-based path
+    lp = 3;                                            // ≤ 1280 expected keys per partition (LDS table: 3584), a few partitions at least
+    while (lp < 10 && est / (double)(1 << lp) > 1280.0) lp++;
+  }
+  const int P = 1 << lp;
+  const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
+  const int64_t nslots = (int64_t)P * kGStride;
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  // ---- temporaries (one reservation)
+  const size_t table = (size_t)P * (size_t)ntiles * 4;
+  const size_t need = pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2 + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
+                      pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) +
+                      pad((size_t)n * 8) * 2 + pad((size_t)n * 4) + pad((size_t)ntiles * 8);
+  uint8_t* base;
+  int rc = ah_temp_reserve(c, need, (void**)&base);
+  if (rc != AH_OK) return rc;
+  size_t used_b = 0;
+  auto take = [&](size_t b) { uint8_t* q = base + used_b; used_b += pad(b); return q; };
+  GbTable gt;
+  gt.key = (unsigned long long*)take((size_t)nslots * 8);
+  gt.lo = (unsigned long long*)take((size_t)nslots * 8);
+  gt.hi = (unsigned long long*)take((size_t)nslots * 8);
+  gt.cnt = (unsigned*)take((size_t)nslots * 4);
+  gt.first = (unsigned*)take((size_t)nslots * 4);
+  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
+  int* tilecnt = (int*)take((size_t)nrt * 4);
+  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
+  unsigned* cnt_tm = (unsigned*)take(table);
+  unsigned* toffs = (unsigned*)take(table);
+  unsigned* gsum = (unsigned*)take((size_t)ngrp * P * 4);
+  unsigned* binstart = (unsigned*)take((size_t)(P + 1) * 4);
+  unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
+  unsigned* prows = (unsigned*)take((size_t)n * 4);
+  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 8);
+  AH_HIP(c, hipMemsetAsync(gt.key, 0xFF, (size_t)nslots * 8, c->stream));
+  AH_HIP(c, hipMemsetAsync(gt.lo, 0, pad((size_t)nslots * 8) * 2 + (size_t)nslots * 4, c->stream));   // lo, hi, cnt are adjacent
+  AH_HIP(c, hipMemsetAsync(gt.first, 0xFF, (size_t)nslots * 4, c->stream));
+  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));   // absmax, overflow, total
+  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+  const unsigned long long* k64 = (const unsigned long long*)keys;
+  const unsigned long long* v64 = (const unsigned long long*)vals;
+  // ---- 1, 2: cut
+  const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
+  gb_hist_kernel<<<tgrid, kGbHistThreads, 0, c->stream>>>(k64, kvalid, koff, n, lp, P, ntiles, cnt_tm);
+  AH_LAUNCH_CHECK(c);
+  colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, P, ntiles, gsum);
+  AH_LAUNCH_CHECK(c);
+  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, P, ngrp, n, binstart);
+  AH_LAUNCH_CHECK(c);
+  tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, gsum, P, ntiles, toffs);
+  AH_LAUNCH_CHECK(c);
+  gb_scatter_kernel<<<tgrid, kThreads, 0, c->stream>>>(k64, kvalid, koff, v64, vvalid, voff, n, lp, P, ntiles, toffs, pkeys, pvals, prows,
+                                                       is_f64 ? tile_max : nullptr);
+  AH_LAUNCH_CHECK(c);
+  if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
+    gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+  }
+  // ---- 3: aggregate
+  const unsigned grid = (unsigned)(P + (n >> kChunkLog2));   // ≥ Σ max(1, round(rows_p / chunk))
+  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow);
+  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow);
+  AH_LAUNCH_CHECK(c);
+  // ---- 4: rank the groups by first row, write them out
+  gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
+  AH_LAUNCH_CHECK(c);
+  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  AH_LAUNCH_CHECK(c);
+  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
+  AH_LAUNCH_CHECK(c);
+  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
+  if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id);
+  else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id);
+  AH_LAUNCH_CHECK(c);
+  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition held far more keys than estimated: the caller's path redoes the call
+  if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
+  if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
+  *used = 1;
+  return AH_OK;
+}

@@ -32,12 +32,10 @@
 // cardinality, cache-resident at low cardinality).
 #include <type_traits>
 #include "ah_common.h"
+#include "ah_hashing.h"
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr unsigned long long kEmpty = ~0ull;
-constexpr unsigned kNoRow = ~0u;
 
 struct Slot {
   unsigned long long key;
@@ -45,9 +43,6 @@ struct Slot {
   unsigned id;
 };
 
-__device__ __forceinline__ uint64_t hash_int(uint64_t v) {  // hash_funcs.go:60-67, alg 0
-  return __builtin_bswap64(11400714785074694791ull * v);
-}
 
 // ---- what a "key" is -------------------------------------------------------------------------------
 // The table machinery below (insert → rank → emit) only needs, per row: a 64-bit word to CAS into an empty
@@ -220,60 +215,6 @@ __global__ __launch_bounds__(kBlock) void mark_kernel(const Slot* __restrict__ t
   }
 }
 
-// per word: exclusive popcount prefix INSIDE its 32-word tile; per tile: total
-__global__ __launch_bounds__(kBlock) void word_prefix_kernel(const unsigned long long* __restrict__ firsts, int64_t nwords,
-                                                              unsigned* __restrict__ wordprefix, int* __restrict__ tilecnt) {
-  int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  int lane32 = threadIdx.x & 31;
-  int v = w < nwords ? __popcll(firsts[w]) : 0;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    int t = __shfl_up(inc, o, 64);
-    if (lane32 >= o) inc += t;
-  }
-  if (w < nwords) wordprefix[w] = (unsigned)(inc - v);
-  if (lane32 == 31 || w == nwords - 1) {
-    if (w < nwords) tilecnt[w >> 5] = inc;
-  }
-}
-
-__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ counts, int64_t ntiles,
-                                                     int64_t* __restrict__ offsets, unsigned long long* __restrict__ total) {
-  __shared__ int64_t wave_tot[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t chunk = (ntiles + 1023) / 1024;
-  const int64_t lo = (int64_t)tid * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
-  int64_t s = 0;
-  for (int64_t i = lo; i < hi; i++) s += counts[i];
-  int64_t inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int64_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) wave_tot[wave] = inc;
-  __syncthreads();
-  int64_t base = 0, tot = 0;
-  for (int k = 0; k < 16; k++) {
-    int64_t t = wave_tot[k];
-    if (k < wave) base += t;
-    tot += t;
-  }
-  int64_t run = base + inc - s;
-  for (int64_t i = lo; i < hi; i++) {
-    offsets[i] = run;
-    run += counts[i];
-  }
-  if (tid == 0) *total = (unsigned long long)tot;
-}
-
-__device__ __forceinline__ unsigned rank_of_row(unsigned fr, const unsigned long long* __restrict__ firsts,
-                                                const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff) {
-  unsigned w = fr >> 6;
-  unsigned long long below = firsts[w] & ((1ull << (fr & 63)) - 1);
-  return (unsigned)(tileoff[w >> 5] + wordprefix[w] + __popcll(below));
-}
 
 __global__ __launch_bounds__(kBlock) void assign_kernel(Slot* __restrict__ table, uint64_t cap, const unsigned long long* __restrict__ firsts,
                                                          const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff,
@@ -421,81 +362,99 @@ __global__ __launch_bounds__(kSmallBlock) void insert_small_kernel(const unsigne
   if (nmiss) atomicAdd(misses, (unsigned long long)nmiss);
 }
 
-// ---- deterministic Float64 group sums: fixed point --------------------------------------------------------------
-// fp64 atomic adds make a group's sum depend on the order the hardware happens to perform them in.  Integer addition
-// is associative, so every value is converted to a 128-bit fixed-point number  q = trunc(x · 2^sh),  sh = 94 − emax,
-// emax = exponent of the largest finite |x| of the call (|q| < 2^95; 2^30 rows cannot overflow 2^127), accumulated with
-// 64-bit integer atomics (low word with carry into the high word — each addend derives its own carry from the value
-// its atomic returned, so any interleaving gives the same 128 bits), and rounded to double ONCE at the end.
-// Result: identical bytes run to run, on any launch geometry; error ≤ ½ulp(Σ) + n_g·2^(emax−94) — inside the
-// n_g·ε·Σ|x| of the sequential row-order definition.  ±inf / NaN addends are tallied as three flag bits per
-// group and give the IEEE result of any order: NaN if a NaN or both infinities were seen, else the infinity.
-struct FxAcc {  // global accumulators of one call (device pointers); null for integer sums
-  unsigned long long* lo;
-  unsigned long long* hi;
-  unsigned* flags;
-  const unsigned long long* absmax;  // bit pattern of the largest finite |x|
+// ---- medium cardinality: the prefix's keys in a table sized for an XCD's L2 ---------------------------------
+// The insert table is sized before anything is known about the column (2^22 slots = 64 MiB): 2^16 distinct keys sit
+// there one per 64-byte line, 4 MiB of hot lines scattered over 64 MiB — PMC showed the main pass fetching a line
+// from the fabric for every probe (35 B/row at 2^16 keys).  Once the prefix is ranked its (key → id) pairs are
+// final, so they are re-packed into a read-only table at load ≤ ½ (2^16 keys: 2 MiB, 2^17: 4 MiB — one XCD's L2;
+// beyond that still half the footprint in the Infinity Cache) and the main pass probes THAT: a hit costs one
+// 16-byte load that stays in L2.  Misses take the insert table like in insert_small_kernel.
+struct CSlot {
+  unsigned long long key;
+  unsigned id;
+  unsigned pad;
 };
-__device__ __forceinline__ int fx_shift(unsigned long long absmax_bits) {
-  const int e = (int)((absmax_bits >> 52) & 0x7ff);
-  return 94 - ((e ? e : 1) - 1023);
-}
-__device__ __forceinline__ bool fx_finite(double x) { return ((__builtin_bit_cast(unsigned long long, x) >> 52) & 0x7ff) != 0x7ff; }
-__device__ __forceinline__ unsigned fx_flag(double x) { return x != x ? 1u : (x > 0 ? 2u : 4u); }   // NaN, +inf, −inf
-__device__ __forceinline__ void fx_split(double x, int sh, unsigned long long* lo, unsigned long long* hi) {
-  const double t = trunc(ldexp(fabs(x), sh));           // integer-valued, < 2^95
-  const double h = floor(t * 0x1p-64);                  // exact: a power-of-two scaling; < 2^31
-  const double r = t - h * 0x1p64;                      // exact: the bits of t below 2^64 (a subset of its 53)
-  unsigned long long l = (unsigned long long)r, u = (unsigned long long)h;
-  if (x < 0) { l = ~l + 1; u = ~u + (l == 0 ? 1 : 0); }  // two's complement of the 128-bit magnitude
-  *lo = l;
-  *hi = u;
-}
-template <typename P>   // P = pointer into LDS or global memory
-__device__ __forceinline__ void fx_add(P lo_arr, P hi_arr, size_t g, unsigned long long lo, unsigned long long hi) {
-  const unsigned long long old = atomicAdd(&lo_arr[g], lo);
-  const unsigned long long carry = old + lo < old ? 1ull : 0ull;
-  if (hi + carry) atomicAdd(&hi_arr[g], hi + carry);
-}
-__device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned long long hi, int sh) {
-  const bool neg = (long long)hi < 0;
-  if (neg) { lo = ~lo + 1; hi = ~hi + (lo == 0 ? 1 : 0); }
-  double d;
-  if (hi == 0) {
-    d = (double)lo;                                    // u64 → f64 is correctly rounded
-  } else {
-    const int lz = __clzll((long long)hi);             // hi != 0: 0..63
-    unsigned long long top = lz ? (hi << lz) | (lo >> (64 - lz)) : hi;
-    const unsigned long long rest = lz ? lo << lz : lo;
-    top |= rest ? 1ull : 0ull;                         // sticky bit: below the 53 bits the conversion keeps
-    d = ldexp((double)top, 64 - lz);
-  }
-  d = ldexp(d, -sh);
-  return neg ? -d : d;
-}
-__global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
-                                                         int64_t n, unsigned long long* __restrict__ out) {
-  unsigned long long m = 0;
+__global__ __launch_bounds__(kBlock) void compact_build_kernel(const Slot* __restrict__ table, uint64_t cap, CSlot* __restrict__ ctab, uint64_t cmask) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const unsigned long long b = __builtin_nontemporal_load(&vals[i]) & 0x7fffffffffffffffull;
-    if ((b >> 52) != 0x7ff && b > m && ah_bit(vvalid, voff + i)) m = b;   // |x| of finite values order like their bit patterns
+  for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += stride) {
+    const SlotView v = load_slot(&table[s]);
+    if (v.first_row == kNoRow) continue;
+    uint64_t j = hash_int(v.key) & cmask;
+    while (atomicCAS(&ctab[j].key, kEmpty, v.key) != kEmpty) j = (j + 1) & cmask;  // keys are distinct, load ≤ ½
+    ctab[j].id = v.id;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long t = __shfl_down(m, o, 64);
-    m = t > m ? t : m;
-  }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
-__global__ __launch_bounds__(kBlock) void fx_finalize_kernel(FxAcc acc, int64_t ngroups, double* __restrict__ out_sums) {
-  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (g >= ngroups) return;
-  const unsigned f = acc.flags[g];
-  double r;
-  if (f) r = (f & 1u) || (f & 6u) == 6u ? __builtin_nan("") : ((f & 2u) ? __builtin_inf() : -__builtin_inf());
-  else r = fx_to_double(acc.lo[g], acc.hi[g], fx_shift(*acc.absmax));
-  out_sums[g] = r;
+
+constexpr int kCompactRows = 8;  // rows per lane per step: eight independent probes in flight
+__global__ __launch_bounds__(kBlock) void insert_compact_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+                                                                 int64_t off, int64_t lo, int64_t hi, int encode_nulls, Slot* __restrict__ table,
+                                                                 uint64_t cap, const CSlot* __restrict__ ctab, uint64_t cmask,
+                                                                 unsigned* __restrict__ out_ids, unsigned long long* __restrict__ distinct,
+                                                                 unsigned* __restrict__ overflow, unsigned long long* __restrict__ misses) {
+  const unsigned ones_id = table[cap].first_row != kNoRow ? table[cap].id : kNoRow;
+  const unsigned null_id = table[cap + 1].first_row != kNoRow ? table[cap + 1].id : kNoRow;
+  const uint64_t mask = cap - 1;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * kCompactRows;
+  unsigned fresh = 0, nmiss = 0;
+  for (int64_t base = lo + (int64_t)blockIdx.x * kBlock * kCompactRows + threadIdx.x; base < hi; base += stride) {
+    unsigned long long k[kCompactRows];
+    bool ok[kCompactRows];
+    uint4 cs[kCompactRows];
+#pragma unroll
+    for (int u = 0; u < kCompactRows; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      ok[u] = i < hi && ah_bit(valid, off + i);
+      k[u] = ok[u] ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < kCompactRows; u++) cs[u] = *reinterpret_cast<const uint4*>(&ctab[hash_int(k[u]) & cmask]);
+#pragma unroll
+    for (int u = 0; u < kCompactRows; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (i >= hi) break;
+      unsigned r = kNoRow;  // final id, or kNoRow = "take the insert table with slot s"
+      uint64_t s = 0;
+      bool probe = false;
+      if (!ok[u]) {
+        if (!encode_nulls) r = 0;  // masked null → index 0
+        else { r = null_id; s = cap + 1; }
+      } else if (k[u] == kEmpty) {
+        r = ones_id; s = cap;
+      } else {
+        uint64_t j = hash_int(k[u]) & cmask;
+        uint4 c = cs[u];
+        for (;;) {
+          const unsigned long long ck = ((unsigned long long)c.y << 32) | c.x;
+          if (ck == k[u]) { r = c.z; break; }
+          if (ck == kEmpty) { probe = true; break; }
+          j = (j + 1) & cmask;
+          c = *reinterpret_cast<const uint4*>(&ctab[j]);
+        }
+      }
+      if (r == kNoRow) {
+        if (probe) {
+          s = hash_int(k[u]) & mask;
+          int probes = 0;
+          for (;;) {
+            unsigned long long cur = table[s].key;
+            if (cur != k[u] && cur == kEmpty) {
+              cur = atomicCAS(&table[s].key, kEmpty, k[u]);
+              if (cur == kEmpty) { fresh++; cur = k[u]; }
+            }
+            if (cur == k[u]) break;
+            s = (s + 1) & mask;
+            if (++probes > kProbeLimit) { atomicExch(overflow, 1u); return; }
+          }
+        }
+        if (table[s].first_row > (unsigned)i) atomicMin(&table[s].first_row, (unsigned)i);
+        r = 0x80000000u | (unsigned)s;
+        nmiss++;
+      }
+      if (out_ids) __builtin_nontemporal_store(r, &out_ids[i]);
+    }
+  }
+  if (fresh) atomicAdd(distinct, (unsigned long long)fresh);
+  if (nmiss) atomicAdd(misses, (unsigned long long)nmiss);
 }
 
 // Per-group accumulation.  ids are dense and in first-seen order, so a low-cardinality
@@ -709,7 +668,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
   int* null_id = (int*)&c->dscalars[7];
   unsigned long long* misses = (unsigned long long*)&c->dscalars[8];
   // tunable, for measurements: 0 = plain (ids in a separate pass), 1 = direct ids, 2 (default) = direct ids + LDS table
-  static const int direct_path = getenv("ARROWHIP_HASH_DIRECT") ? atoi(getenv("ARROWHIP_HASH_DIRECT")) : 2;
+  const int direct_path = c->opt_hash_direct;
   bool resized = false;  // the table was re-planned: it is large and the prefix holds a minority of its keys
   for (;;) {
     // scratch: table | firsts | wordprefix | tilecnt | tileoff
@@ -720,7 +679,8 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
     size_t to_bytes = (size_t)ntiles * 8;
     void* scratch;
     const size_t small_bytes = (size_t)kSmallSlots * 12;
-    int rc = ah_scratch_reserve(c, table_bytes + firsts_bytes + wp_bytes + tc_bytes + to_bytes + small_bytes + 64, &scratch);
+    const size_t compact_bytes = K::kLdsTable ? (size_t)(cap / 2) * sizeof(CSlot) : 0;  // ≤ cap/4 prefix keys at load ≤ ½
+    int rc = ah_scratch_reserve(c, table_bytes + firsts_bytes + wp_bytes + tc_bytes + to_bytes + small_bytes + compact_bytes + 64, &scratch);
     if (rc != AH_OK) return rc;
     Slot* table = (Slot*)scratch;
     unsigned long long* firsts = (unsigned long long*)((uint8_t*)scratch + table_bytes);
@@ -729,6 +689,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
     int64_t* tileoff = (int64_t*)((uint8_t*)tilecnt + tc_bytes);
     unsigned long long* skeys = (unsigned long long*)((uint8_t*)tileoff + to_bytes);
     unsigned* sids = (unsigned*)(skeys + kSmallSlots);
+    CSlot* ctab = (CSlot*)(((uintptr_t)(sids + kSmallSlots) + 63) & ~(uintptr_t)63);
 
     AH_HIP(c, hipMemsetAsync(table, 0xFF, table_bytes, c->stream));
     AH_HIP(c, hipMemsetAsync(&c->dscalars[4], 0, 3 * sizeof(uint64_t), c->stream));
@@ -754,11 +715,12 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
         lo = hi;
       }
     }
-    bool restart = false, small = false, direct = false;
+    bool restart = false, small = false, direct = false, compact = false;
+    uint64_t d0 = 0;
     if (prefix < n && cap < cap_max) {
       AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[4], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       AH_HIP(c, hipStreamSynchronize(c->stream));
-      uint64_t d0 = *(volatile uint64_t*)&c->pinned[0];
+      d0 = *(volatile uint64_t*)&c->pinned[0];
       bool ovf = *(volatile unsigned*)&c->pinned[1] != 0;
       if (ovf || d0 > cap / 4) {
         // extrapolate with the urn model (keys drawn uniformly from C values show d0 = C·(1 − e^(−p/C))
@@ -773,6 +735,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
       }
       direct = !restart && !ovf && !resized && direct_path;
       small = K::kLdsTable && direct && d0 <= (uint64_t)kSmallKeys && direct_path > 1;
+      compact = K::kLdsTable && direct && !small && direct_path > 1 && direct_path != 3;   // 3: measurement switch, no re-packed table
     }
     if (restart) continue;
     // first-seen ranks of the used slots over the first `rows` rows: table[].id, dict, first_rows, total, null_id
@@ -820,6 +783,30 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
           if (*(volatile uint64_t*)c->pinned * 8 < (uint64_t)(probe_end - prefix)) {
             insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>(keys.keys, valid, off, probe_end, n, encode_nulls,
                                                                       table, cap, skeys, sids, (unsigned*)out_ids, distinct, overflow, misses);
+            AH_LAUNCH_CHECK(c);
+            lo = n;
+          }
+        }
+      }
+      if constexpr (K::kLdsTable) if (compact && lo < n) {
+        const uint64_t ccap = next_pow2_u64(d0 * 2 < 64 ? 64 : d0 * 2);
+        AH_HIP(c, hipMemsetAsync(ctab, 0xFF, (size_t)ccap * sizeof(CSlot), c->stream));
+        compact_build_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap, kBlock)), kBlock, 0, c->stream>>>(table, cap, ctab, ccap - 1);
+        AH_LAUNCH_CHECK(c);
+        // a probe segment first, as above: a miss costs a second, dependent walk (re-packed table, then the insert table), so a
+        // column that keeps bringing keys the prefix did not hold (2^20 uniform keys: 14 % of the rows; Zipf tails) is
+        // better served by the plain kernel, whose first probes are all in flight together — measured 1.4 → 2.1 ms otherwise
+        const int64_t seg_lo = lo, probe_end = n - lo > ((int64_t)1 << 23) ? lo + ((int64_t)1 << 22) : n;
+        insert_compact_kernel<<<ah_stream_grid(c, ah_ceil_div(probe_end - lo, (int64_t)kBlock * kCompactRows)), kBlock, 0, c->stream>>>(
+            keys.keys, valid, off, lo, probe_end, encode_nulls, table, cap, ctab, ccap - 1, (unsigned*)out_ids, distinct, overflow, misses);
+        AH_LAUNCH_CHECK(c);
+        lo = probe_end;
+        if (probe_end < n) {
+          AH_HIP(c, hipMemcpyAsync(c->pinned, misses, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+          AH_HIP(c, hipStreamSynchronize(c->stream));
+          if (*(volatile uint64_t*)c->pinned * 64 < (uint64_t)(probe_end - seg_lo)) {
+            insert_compact_kernel<<<ah_stream_grid(c, ah_ceil_div(n - lo, (int64_t)kBlock * kCompactRows)), kBlock, 0, c->stream>>>(
+                keys.keys, valid, off, lo, n, encode_nulls, table, cap, ctab, ccap - 1, (unsigned*)out_ids, distinct, overflow, misses);
             AH_LAUNCH_CHECK(c);
             lo = n;
           }
@@ -874,6 +861,20 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
   if (out_null_group_host) *out_null_group_host = -1;
   if (n == 0) return AH_OK;
   if (!keys || !vals || !out_keys || !out_sums || !out_counts) return ah_fail(c, AH_EINVALID, "hash_sum: null buffer");
+  if (sizeof(VT) == 8) {
+    // large inputs with up to ~10^6 groups: cut the rows by key hash first, aggregate each partition in LDS (ah_groupby.hip)
+    int used = 0;
+    int64_t ng = 0;
+    int32_t nullg = -1;
+    int prc = ah_groupby_partitioned_try(c, std::is_same<VT, double>::value ? 1 : 0, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums,
+                                         out_counts, out_first_rows, &ng, &nullg, &used);
+    if (prc != AH_OK) return prc;
+    if (used) {
+      if (out_ngroups_host) *out_ngroups_host = ng;
+      if (out_null_group_host) *out_null_group_host = nullg;
+      return AH_OK;
+    }
+  }
   // temporaries: a dense group id per row and, above 4096 groups, the partitioned (value, id) pairs with their
   // histograms — one reservation in the context's temp arena, sized for the two-pass partition, reused by the next call
   const int64_t nb = ah_ceil_div(n, 2048);

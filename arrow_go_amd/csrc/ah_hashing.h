@@ -1,0 +1,156 @@
+// ah_hashing.h — pieces shared by ah_hash.hip (unique / dictionary_encode / the id-based group-by) and
+// ah_groupby.hip (the partition-first group-by): the reference's integer hash, first-seen ranking over an n-bit
+// "first occurrence" bitmap, and the 128-bit fixed-point accumulation that makes Float64 group sums reproducible.
+#pragma once
+#include "ah_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr unsigned long long kEmpty = ~0ull;
+constexpr unsigned kNoRow = ~0u;
+
+__device__ __forceinline__ uint64_t hash_int(uint64_t v) {  // hash_funcs.go:60-67, alg 0
+  return __builtin_bswap64(11400714785074694791ull * v);
+}
+
+// per word: exclusive popcount prefix INSIDE its 32-word tile; per tile: total
+__global__ __launch_bounds__(kBlock) void word_prefix_kernel(const unsigned long long* __restrict__ firsts, int64_t nwords,
+                                                              unsigned* __restrict__ wordprefix, int* __restrict__ tilecnt) {
+  int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int lane32 = threadIdx.x & 31;
+  int v = w < nwords ? __popcll(firsts[w]) : 0;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane32 >= o) inc += t;
+  }
+  if (w < nwords) wordprefix[w] = (unsigned)(inc - v);
+  if (lane32 == 31 || w == nwords - 1) {
+    if (w < nwords) tilecnt[w >> 5] = inc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ counts, int64_t ntiles,
+                                                     int64_t* __restrict__ offsets, unsigned long long* __restrict__ total) {
+  __shared__ int64_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t chunk = (ntiles + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; i++) s += counts[i];
+  int64_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int64_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int64_t base = 0, tot = 0;
+  for (int k = 0; k < 16; k++) {
+    int64_t t = wave_tot[k];
+    if (k < wave) base += t;
+    tot += t;
+  }
+  int64_t run = base + inc - s;
+  for (int64_t i = lo; i < hi; i++) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+  if (tid == 0) *total = (unsigned long long)tot;
+}
+
+__device__ __forceinline__ unsigned rank_of_row(unsigned fr, const unsigned long long* __restrict__ firsts,
+                                                const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff) {
+  unsigned w = fr >> 6;
+  unsigned long long below = firsts[w] & ((1ull << (fr & 63)) - 1);
+  return (unsigned)(tileoff[w >> 5] + wordprefix[w] + __popcll(below));
+}
+
+// ---- deterministic Float64 group sums: fixed point --------------------------------------------------------------
+// fp64 atomic adds make a group's sum depend on the order the hardware happens to perform them in.  Integer addition
+// is associative, so every value is converted to a 128-bit fixed-point number  q = trunc(x · 2^sh),  sh = 94 − emax,
+// emax = exponent of the largest finite |x| of the call (|q| < 2^95; 2^30 rows cannot overflow 2^127), accumulated with
+// 64-bit integer atomics (low word with carry into the high word — each addend derives its own carry from the value
+// its atomic returned, so any interleaving gives the same 128 bits), and rounded to double ONCE at the end.
+// Result: identical bytes run to run, on any launch geometry; error ≤ ½ulp(Σ) + n_g·2^(emax−94) — inside the
+// n_g·ε·Σ|x| of the sequential row-order definition.  ±inf / NaN addends are tallied as three flag bits per
+// group and give the IEEE result of any order: NaN if a NaN or both infinities were seen, else the infinity.
+struct FxAcc {  // global accumulators of one call (device pointers); null for integer sums
+  unsigned long long* lo;
+  unsigned long long* hi;
+  unsigned* flags;
+  const unsigned long long* absmax;  // bit pattern of the largest finite |x|
+};
+__device__ __forceinline__ int fx_shift(unsigned long long absmax_bits) {
+  const int e = (int)((absmax_bits >> 52) & 0x7ff);
+  return 94 - ((e ? e : 1) - 1023);
+}
+__device__ __forceinline__ bool fx_finite(double x) { return ((__builtin_bit_cast(unsigned long long, x) >> 52) & 0x7ff) != 0x7ff; }
+__device__ __forceinline__ unsigned fx_flag(double x) { return x != x ? 1u : (x > 0 ? 2u : 4u); }   // NaN, +inf, −inf
+// q = trunc(|x| · 2^sh) as a 128-bit integer, negated for x < 0.  Done on the bits of x: |x| = m · 2^(e − 1075) with the
+// 53-bit significand m, so q = m shifted by s = e − 1075 + sh (≤ 42 for |x| ≤ absmax: q < 2^95; right shifts truncate).
+// (The first version went through ldexp / trunc / floor and two double → uint64 conversions: ≈ 4× the instructions,
+// and the group-by kernels are instruction-bound.)
+__device__ __forceinline__ void fx_split(double x, int sh, unsigned long long* lo, unsigned long long* hi) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const int e = (int)((b >> 52) & 0x7ff);
+  const unsigned long long m = (b & 0xfffffffffffffull) | (e ? 1ull << 52 : 0ull);
+  const int s = (e ? e : 1) - 1075 + sh;
+  unsigned long long l, u;
+  if (s >= 0) { l = m << s; u = s > 11 ? m >> (64 - s) : 0ull; }
+  else { l = s > -64 ? m >> -s : 0ull; u = 0ull; }
+  if ((long long)b < 0) { l = ~l + 1; u = ~u + (l == 0 ? 1 : 0); }  // two's complement of the 128-bit magnitude
+  *lo = l;
+  *hi = u;
+}
+template <typename P>   // P = pointer into LDS or global memory
+__device__ __forceinline__ void fx_add(P lo_arr, P hi_arr, size_t g, unsigned long long lo, unsigned long long hi) {
+  const unsigned long long old = atomicAdd(&lo_arr[g], lo);
+  const unsigned long long carry = old + lo < old ? 1ull : 0ull;
+  if (hi + carry) atomicAdd(&hi_arr[g], hi + carry);
+}
+__device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned long long hi, int sh) {
+  const bool neg = (long long)hi < 0;
+  if (neg) { lo = ~lo + 1; hi = ~hi + (lo == 0 ? 1 : 0); }
+  double d;
+  if (hi == 0) {
+    d = (double)lo;                                    // u64 → f64 is correctly rounded
+  } else {
+    const int lz = __clzll((long long)hi);             // hi != 0: 0..63
+    unsigned long long top = lz ? (hi << lz) | (lo >> (64 - lz)) : hi;
+    const unsigned long long rest = lz ? lo << lz : lo;
+    top |= rest ? 1ull : 0ull;                         // sticky bit: below the 53 bits the conversion keeps
+    d = ldexp((double)top, 64 - lz);
+  }
+  d = ldexp(d, -sh);
+  return neg ? -d : d;
+}
+__global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                         int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long m = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const unsigned long long b = __builtin_nontemporal_load(&vals[i]) & 0x7fffffffffffffffull;
+    if ((b >> 52) != 0x7ff && b > m && ah_bit(vvalid, voff + i)) m = b;   // |x| of finite values order like their bit patterns
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_down(m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ __launch_bounds__(kBlock) void fx_finalize_kernel(FxAcc acc, int64_t ngroups, double* __restrict__ out_sums) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= ngroups) return;
+  const unsigned f = acc.flags[g];
+  double r;
+  if (f) r = (f & 1u) || (f & 6u) == 6u ? __builtin_nan("") : ((f & 2u) ? __builtin_inf() : -__builtin_inf());
+  else r = fx_to_double(acc.lo[g], acc.hi[g], fx_shift(*acc.absmax));
+  out_sums[g] = r;
+}
+
+}  // namespace

@@ -24,15 +24,13 @@
 // The in-run order of records depends on LDS atomic timing; the OUTPUT does not (each record carries its row).
 #include <type_traits>
 #include "ah_common.h"
+#include "ah_bins.h"
 
 namespace {
 
 constexpr int kTileBits = 13;
 constexpr int kTile = 1 << kTileBits;   // rows per tile: row-in-tile fits 13 bits of the record
-constexpr int kThreads = 1024;                     // 2 workgroups per CU = all 32 wave slots; LDS 2 × ≤ 77 KiB
 constexpr int kRowsPerThread = kTile / kThreads;  // 8 = two runs of 4 consecutive rows (one 16-byte index load each)
-constexpr int kMaxBins = 1024;
-static_assert(kMaxBins == 1024, "");
 constexpr int kGatherBlock = 256;
 constexpr int kGatherPerThread = 8;
 constexpr int kGatherChunk = kGatherBlock * kGatherPerThread;  // 2048 records per workgroup
@@ -42,32 +40,6 @@ template <> struct UIntW<1> { using type = uint8_t; };
 template <> struct UIntW<2> { using type = uint16_t; };
 template <> struct UIntW<4> { using type = uint32_t; };
 template <> struct UIntW<8> { using type = uint64_t; };
-
-// consecutive tiles on one XCD: block b runs on XCD b & 7 (observed), so XCD x gets tiles [x·tpx, (x+1)·tpx)
-__device__ __forceinline__ int64_t xcd_contiguous_tile(int64_t ntiles) {
-  const int64_t tpx = (ntiles + 7) >> 3;
-  const int64_t t = (int64_t)(blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
-  return ((int64_t)(blockIdx.x >> 3) < tpx && t < ntiles) ? t : -1;
-}
-
-// exclusive scan of cnt[0..nb) (nb ≤ 1024 = kThreads): thread t owns bin t.  Result in s_start.
-__device__ __forceinline__ void block_excl_scan(const unsigned* s_cnt, unsigned* s_start, unsigned* s_wsum, int nb) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const unsigned a = t < nb ? s_cnt[t] : 0u;
-  unsigned inc = a;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned v = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += v;
-  }
-  if (lane == 63) s_wsum[wave] = inc;
-  __syncthreads();
-  unsigned base = 0;
-#pragma unroll
-  for (int w = 0; w < kThreads / 64; w++) if (w < wave) base += s_wsum[w];
-  if (t < nb) s_start[t] = base + inc - a;
-  __syncthreads();
-}
 
 // the tile's index slots of one thread: kGroups runs of 4 consecutive rows, each run ONE vector load (16 bytes for int32
 // indices) — all of them issued before anything is used, so a workgroup has its whole 32 KiB of indices in flight at once.
@@ -180,60 +152,6 @@ __global__ __launch_bounds__(kHistThreads) void bin_hist_kernel(const IdxT* __re
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nb; b += kHistThreads) cnt_tm[tile * nb + b] = s_cnt[b];   // one contiguous row per tile
-}
-
-// ---- the offsets table.  toffs[tile][bin] = global position of the tile's first record of that bin = (records of
-// smaller bins) + (records of this bin in earlier tiles): a prefix sum DOWN the columns of the tile-major count table,
-// done in three small launches with coalesced row accesses only (groups of kGroupTiles tiles):
-constexpr int kGroupTiles = 128;
-// (a) column sums of each group of tiles
-__global__ __launch_bounds__(kMaxBins) void colsum_kernel(const unsigned* __restrict__ cnt_tm, int nb, int64_t ntiles, unsigned* __restrict__ gsum) {
-  const int b = threadIdx.x;
-  if (b >= nb) return;
-  const int64_t t0 = (int64_t)blockIdx.x * kGroupTiles, t1 = t0 + kGroupTiles < ntiles ? t0 + kGroupTiles : ntiles;
-  unsigned s = 0;
-#pragma unroll 8
-  for (int64_t t = t0; t < t1; t++) s += cnt_tm[t * nb + b];
-  gsum[(int64_t)blockIdx.x * nb + b] = s;
-}
-// (b) one workgroup: per bin the exclusive prefix over the groups, then the exclusive prefix over the bins' totals
-//     (= binstart; binstart[nb] = nidx); gsum is overwritten with binstart[b] + prefix of the groups before
-__global__ __launch_bounds__(kMaxBins) void bin_prefix_kernel(unsigned* __restrict__ gsum, int nb, int64_t ngroups, int64_t nidx,
-                                                               unsigned* __restrict__ binstart) {
-  __shared__ unsigned s_tot[kMaxBins], s_start[kMaxBins], s_wsum[kThreads / 64];
-  const int b = threadIdx.x;
-  unsigned run = 0;
-  if (b < nb) {
-#pragma unroll 8
-    for (int64_t g = 0; g < ngroups; g++) run += gsum[g * nb + b];
-  }
-  s_tot[b] = b < nb ? run : 0u;
-  __syncthreads();
-  block_excl_scan(s_tot, s_start, s_wsum, nb);
-  if (b < nb) {
-    const unsigned start = s_start[b];
-    binstart[b] = start;
-    unsigned acc = start;
-    for (int64_t g = 0; g < ngroups; g++) {
-      const unsigned c = gsum[g * nb + b];
-      gsum[g * nb + b] = acc;
-      acc += c;
-    }
-  }
-  if (b == 0) binstart[nb] = (unsigned)nidx;
-}
-// (c) inside each group: running offsets tile after tile
-__global__ __launch_bounds__(kMaxBins) void tile_offs_kernel(const unsigned* __restrict__ cnt_tm, const unsigned* __restrict__ gbase, int nb,
-                                                              int64_t ntiles, unsigned* __restrict__ toffs) {
-  const int b = threadIdx.x;
-  if (b >= nb) return;
-  const int64_t t0 = (int64_t)blockIdx.x * kGroupTiles, t1 = t0 + kGroupTiles < ntiles ? t0 + kGroupTiles : ntiles;
-  unsigned run = gbase[(int64_t)blockIdx.x * nb + b];
-#pragma unroll 8
-  for (int64_t t = t0; t < t1; t++) {
-    toffs[t * nb + b] = run;
-    run += cnt_tm[t * nb + b];
-  }
 }
 
 // ---- 2: records in bin order

@@ -450,6 +450,103 @@ def test_hash_sum(hip, orc_be):
         assert (np.abs(g[1] - e[1]) <= tol).all()
 
 
+def _hash_sum_cases(rng, n, card, hot=0.0):
+    keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+    if hot:
+        keys[rng.random(n) < hot] = 7 * 1000003          # one key owns a large share of the rows (chunks of one partition)
+    keys[rng.integers(0, n, 5)] = -1                       # the all-ones key: the tables' EMPTY marker
+    kvalid, vvalid = rand_bits(rng, n + 8, 0.95), rand_bits(rng, n + 8, 0.9)
+    return keys, kvalid, vvalid
+
+
+@pytest.mark.parametrize("n,card,mode,hot", [
+    (70001, 500, 5, 0.0),          # 8 partitions of one chunk each: the LDS table leaves as a copy
+    (300007, 20000, 5, 0.0),
+    (6000017, 9000, 5, 0.6),       # a hot key: its partition is cut into chunks, merged into the global table; runs combined per lane
+    (1 << 21, 48000, 5, 0.0),      # 6000 keys per partition: beyond the LDS table's 3584 → later keys go to the global table
+    (1 << 21, 160000, 5, 0.0),     # 20000 keys per partition: the global table overflows → the id-based path answers
+    (2500003, 700000, 12, 0.0),    # 1024 partitions
+])
+def test_hash_sum_partition_first(hip, orc_be, ctx, n, card, mode, hot):
+    """ah_groupby.hip: rows cut by key hash, each partition aggregated in LDS.  Same bytes as the id-based path and as the
+    oracle (ids = first-seen order, int sums wrap, integer-valued float sums exact, counts, first rows, null group)."""
+    rng = np.random.default_rng(n + card)
+    keys, kvalid, vvalid = _hash_sum_cases(rng, n, card, hot)
+    iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+    fi = rng.integers(-1000, 1000, n).astype(np.float64)
+    fv = rng.standard_normal(n) * np.exp(rng.uniform(-20, 20, n))
+    fv[rng.integers(0, n, 3)] = np.inf
+    fv[rng.integers(0, n, 2)] = -np.inf
+    fv[rng.integers(0, n, 2)] = np.nan
+    try:
+        ctx.set_option("groupby_partition", 0)
+        base = {k: hip.hash_sum(k[0:3], keys, kvalid, 3, v, vvalid, 5) for k, v in (("i64", iv), ("f64i", fi), ("f64v", fv))}
+        ctx.set_option("groupby_partition", mode)
+        got = {k: hip.hash_sum(k[0:3], keys, kvalid, 3, v, vvalid, 5) for k, v in (("i64", iv), ("f64i", fi), ("f64v", fv))}
+        again = hip.hash_sum("f64", keys, kvalid, 3, fv, vvalid, 5)
+    finally:
+        ctx.set_option("groupby_partition", 1)
+    for k in got:
+        g, b = got[k], base[k]
+        assert g[0].tobytes() == b[0].tobytes() and g[1].tobytes() == b[1].tobytes() and g[2].tobytes() == b[2].tobytes(), k
+        assert g[3] == b[3] and g[4].tobytes() == b[4].tobytes(), k
+    assert again[1].tobytes() == got["f64v"][1].tobytes()
+    for k, v in (("i64", iv), ("f64i", fi)):
+        e = orc_be.hash_sum(k[0:3], keys, kvalid, 3, v, vvalid, 5)
+        g = got[k]
+        for a, b in zip(g[:3], e[:3]):
+            assert a.tobytes() == b.tobytes(), k
+        assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes(), k
+
+
+def test_hash_sum_partition_first_auto(hip, orc_be):
+    """the automatic choice (≥ 2^21 rows; partitions from a sampled distinct estimate), skewed keys included"""
+    rng = np.random.default_rng(77)
+    n = (1 << 22) + 77
+    for card, zipf in [(300, False), (50000, False), (1 << 20, True)]:
+        if zipf:
+            keys = (rng.zipf(1.1, n) % card).astype(np.int64) * 1000003
+        else:
+            keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+        kvalid, vvalid = rand_bits(rng, n + 8, 0.95), rand_bits(rng, n + 8, 0.9)
+        iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+        g, e = hip.hash_sum("i64", keys, kvalid, 3, iv, vvalid, 5), orc_be.hash_sum("i64", keys, kvalid, 3, iv, vvalid, 5)
+        for a, b in zip(g[:3], e[:3]):
+            assert a.tobytes() == b.tobytes()
+        assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes()
+        fi = rng.integers(-1000, 1000, n).astype(np.float64)
+        g, e = hip.hash_sum("f64", keys, kvalid, 3, fi, vvalid, 5), orc_be.hash_sum("f64", keys, kvalid, 3, fi, vvalid, 5)
+        for a, b in zip(g[:3], e[:3]):
+            assert a.tobytes() == b.tobytes()
+
+
+def test_hash_encode_repacked_table(hip, orc_be, ctx):
+    """dictionary_encode beyond the 2^21-row prefix with 4 Ki < keys ≤ 1 Mi: the main pass probes the re-packed
+    (key → id) table; keys the prefix did not hold still get their first-seen ids"""
+    rng = np.random.default_rng(78)
+    n = (1 << 22) + 1001
+    for card in (6000, 70000, 400000):
+        keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+        keys[(1 << 21) + 5:(1 << 21) + 5000] = np.arange(4995) + (1 << 40)     # new keys after the prefix
+        keys[n - 3] = -1
+        valid = rand_bits(rng, n + 8, 0.97)
+        for enc in (False, True):
+            g, e = hip.hash_encode(keys, valid, 3, enc), orc_be.hash_encode(keys, valid, 3, enc)
+            assert g[2].size == e[2].size and g[3] == e[3], (card, enc, g[2].size, e[2].size, g[3], e[3])
+            bad = np.flatnonzero(g[0] != e[0])
+            assert bad.size == 0, (card, enc, bad.size, bad[:5], g[0][bad[:5]], e[0][bad[:5]])
+            bits = lambda a: np.unpackbits(a, bitorder="little")[:n]    # the bits past n belong to the caller's buffer
+            assert (bits(g[1]) == bits(e[1])).all() and g[2].tobytes() == e[2].tobytes(), (card, enc)
+        try:
+            ctx.set_option("hash_direct", 3)
+            g3 = hip.hash_encode(keys, valid, 3, True)
+        finally:
+            ctx.set_option("hash_direct", 2)
+        g2 = hip.hash_encode(keys, valid, 3, True)
+        assert g3[0].tobytes() == g2[0].tobytes() and g3[2].tobytes() == g2[2].tobytes()
+
+
+
 def test_hash_sum_f64_is_deterministic_and_tight(hip, orc_be):
     """Float64 group sums are accumulated in 128-bit fixed point with integer atomics (associative), rounded once:
     the bytes do not change from run to run, and they are far closer to the exact sums than the sequential definition's
