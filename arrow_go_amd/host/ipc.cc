@@ -1,7 +1,11 @@
 // Arrow IPC stream reader that lands record-batch bodies in HBM — see ipc.h.
 #include "ipc.h"
 
+#include <dlfcn.h>
+
 #include <cstring>
+#include <mutex>
+#include <new>
 
 #include "../../include/arrowhip.h"
 
@@ -67,6 +71,66 @@ enum { kTypeInt = 2, kTypeFloatingPoint = 3, kTypeBinary = 4, kTypeUtf8 = 5, kTy
 
 Status Invalid(const std::string& m) { return Status::Make(StatusCode::Invalid, "arrow/ipc: " + m); }
 Status NotImpl(const std::string& m) { return Status::Make(StatusCode::NotImplemented, "arrow/ipc: " + m); }
+
+// ---- compressed bodies (format/Message.fbs: BodyCompression { codec: LZ4_FRAME | ZSTD; method: BUFFER }) -----------
+// ipc/compression.go:25-40 + file_reader.go:585-612: every buffer of a compressed body is [int64 uncompressed length |
+// frame]; −1 means "stored as it is".  The reference decompresses with pierrec/lz4 and klauspost/zstd on the host; here
+// the system's liblz4.so.1 / libzstd.so.1 do it (bound at first use — the library has no link-time dependency on them),
+// into ONE host buffer laid out like an uncompressed body, which then takes the usual single transfer.
+struct Codecs {
+  // lz4frame.h
+  size_t (*lz4f_create)(void**, unsigned) = nullptr;
+  size_t (*lz4f_free)(void*) = nullptr;
+  size_t (*lz4f_decompress)(void*, void*, size_t*, const void*, size_t*, const void*) = nullptr;
+  unsigned (*lz4f_is_error)(size_t) = nullptr;
+  // zstd.h
+  size_t (*zstd_decompress)(void*, size_t, const void*, size_t) = nullptr;
+  unsigned (*zstd_is_error)(size_t) = nullptr;
+};
+const Codecs& GetCodecs() {
+  static Codecs c;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_LOCAL)) {
+      c.lz4f_create = (decltype(c.lz4f_create))dlsym(h, "LZ4F_createDecompressionContext");
+      c.lz4f_free = (decltype(c.lz4f_free))dlsym(h, "LZ4F_freeDecompressionContext");
+      c.lz4f_decompress = (decltype(c.lz4f_decompress))dlsym(h, "LZ4F_decompress");
+      c.lz4f_is_error = (decltype(c.lz4f_is_error))dlsym(h, "LZ4F_isError");
+    }
+    if (void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL)) {
+      c.zstd_decompress = (decltype(c.zstd_decompress))dlsym(h, "ZSTD_decompress");
+      c.zstd_is_error = (decltype(c.zstd_is_error))dlsym(h, "ZSTD_isError");
+    }
+  });
+  return c;
+}
+enum { kCodecLz4Frame = 0, kCodecZstd = 1 };
+
+Status DecompressBuffer(int codec, const uint8_t* src, int64_t srclen, uint8_t* dst, int64_t dstlen) {
+  const Codecs& c = GetCodecs();
+  if (codec == kCodecZstd) {
+    if (!c.zstd_decompress || !c.zstd_is_error) return NotImpl("ZSTD-compressed body: libzstd.so.1 not available");
+    const size_t r = c.zstd_decompress(dst, (size_t)dstlen, src, (size_t)srclen);
+    if (c.zstd_is_error(r) || (int64_t)r != dstlen) return Invalid("ZSTD buffer does not decompress to the " + std::to_string(dstlen) + " bytes it announces");
+    return Status::OK();
+  }
+  if (!c.lz4f_create || !c.lz4f_free || !c.lz4f_decompress || !c.lz4f_is_error) return NotImpl("LZ4-compressed body: liblz4.so.1 not available");
+  void* dctx = nullptr;
+  if (c.lz4f_is_error(c.lz4f_create(&dctx, 100 /* LZ4F_VERSION */))) return Invalid("LZ4 decompression context");
+  int64_t in = 0, out = 0;
+  Status st = Status::OK();
+  for (;;) {
+    size_t dn = (size_t)(dstlen - out), sn = (size_t)(srclen - in);
+    const size_t r = c.lz4f_decompress(dctx, dst + out, &dn, src + in, &sn, nullptr);
+    if (c.lz4f_is_error(r)) { st = Invalid("corrupt LZ4 frame"); break; }
+    in += (int64_t)sn; out += (int64_t)dn;
+    if (r == 0) break;                                   // frame complete
+    if (sn == 0 && dn == 0) { st = Invalid("LZ4 frame is truncated or larger than the " + std::to_string(dstlen) + " bytes it announces"); break; }
+  }
+  c.lz4f_free(dctx);
+  if (st.ok() && out != dstlen) st = Invalid("LZ4 buffer decompresses to " + std::to_string(out) + " bytes, announced " + std::to_string(dstlen));
+  return st;
+}
 
 // one Field table → DataType (metadata.go: typeFromFB / intFromFB / floatFromFB)
 Status DecodeField(Fb& fb, int64_t f, FieldInfo* out) {
@@ -277,9 +341,47 @@ Status StreamReader::LoadColumns(const uint8_t* meta, int64_t mlen, int64_t rb, 
   const int64_t nrows = fb.scalar<int64_t>(rb, 0, 0);
   const int64_t nodes = fb.indirect(rb, 1), bufs = fb.indirect(rb, 2);
   const int64_t n_nodes = fb.vec_len(nodes), n_bufs = fb.vec_len(bufs);
-  if (fb.field(rb, 3)) return NotImpl("compressed record batch body");
   if (nrows < 0 || fb.bad) return Invalid("invalid message metadata");
   if (n_nodes != (int64_t)fields_.size()) return Invalid("record batch has " + std::to_string(n_nodes) + " field nodes, the schema " + std::to_string(fields_.size()) + " fields");
+  // a compressed body is inflated on the host into the layout an uncompressed body has; (offset, length) pairs follow it
+  std::vector<uint8_t> plain;
+  std::vector<std::pair<int64_t, int64_t>> plain_bufs;
+  const int64_t comp = fb.indirect(rb, 3);
+  if (comp) {
+    const int codec = fb.scalar<int8_t>(comp, 0, 0), method = fb.scalar<int8_t>(comp, 1, 0);
+    if (fb.bad) return Invalid("invalid message metadata");
+    if (codec != kCodecLz4Frame && codec != kCodecZstd) return NotImpl("body compression codec " + std::to_string(codec));
+    if (method != 0) return NotImpl("body compression method " + std::to_string(method));
+    struct Piece { int64_t src, srclen, dst, dstlen; bool stored; };
+    std::vector<Piece> pieces;
+    int64_t total = 0;
+    for (int64_t i = 0; i < n_bufs; i++) {
+      const int64_t e = bufs + 4 + 16 * i;
+      const int64_t off = fb.rd<int64_t>(e), len = fb.rd<int64_t>(e + 8);
+      if (fb.bad) return Invalid("invalid message metadata");
+      if (off < 0 || len < 0 || off > blen || len > blen - off) return Invalid("buffer [" + std::to_string(off) + ", +" + std::to_string(len) + ") lies outside the " + std::to_string(blen) + "-byte body");
+      if (len == 0) { pieces.push_back({0, 0, total, 0, true}); continue; }
+      if (len < 8) return Invalid("compressed buffer of " + std::to_string(len) + " bytes has no length prefix");
+      int64_t ulen;
+      std::memcpy(&ulen, body + off, 8);
+      const bool stored = ulen == -1;
+      if (stored) ulen = len - 8;
+      // a frame cannot announce more than the formats' best ratios allow from its own size: (zeros compress ≈ 30 000 : 1 under ZSTD): no allocation bombs from 20 bytes
+      if (ulen < 0 || (!stored && ulen / 131072 > len + 1024)) return Invalid("compressed buffer announces " + std::to_string(ulen) + " bytes from " + std::to_string(len));
+      pieces.push_back({off + 8, len - 8, total, ulen, stored});
+      total += (ulen + 63) & ~(int64_t)63;
+      if (total > ((int64_t)1 << 40)) return Invalid("decompressed body beyond 1 TiB");
+    }
+    try { plain.resize((size_t)total); } catch (const std::bad_alloc&) { return Invalid("cannot hold a decompressed body of " + std::to_string(total) + " bytes"); }
+    for (const Piece& p : pieces) {
+      if (p.dstlen == 0) { /* nothing */ }
+      else if (p.stored) std::memcpy(plain.data() + p.dst, body + p.src, (size_t)p.dstlen);
+      else AHC_RETURN_NOT_OK(DecompressBuffer(codec, body + p.src, p.srclen, plain.data() + p.dst, p.dstlen));
+      plain_bufs.push_back({p.dst, p.dstlen});
+    }
+    body = plain.data();
+    blen = total;
+  }
 
   // the whole body in one transfer; columns are slices of it
   BufferPtr dev;
@@ -292,9 +394,15 @@ Status StreamReader::LoadColumns(const uint8_t* meta, int64_t mlen, int64_t rb, 
   int64_t ib = 0;
   auto next_buffer = [&](int64_t* off, int64_t* len) -> Status {
     if (ib >= n_bufs) return Invalid("buffer index out of bound");
-    const int64_t e = bufs + 4 + 16 * ib++;  // struct Buffer { offset: long; length: long }
-    *off = fb.rd<int64_t>(e);
-    *len = fb.rd<int64_t>(e + 8);
+    if (comp) {
+      *off = plain_bufs[(size_t)ib].first;
+      *len = plain_bufs[(size_t)ib].second;
+      ib++;
+    } else {
+      const int64_t e = bufs + 4 + 16 * ib++;  // struct Buffer { offset: long; length: long }
+      *off = fb.rd<int64_t>(e);
+      *len = fb.rd<int64_t>(e + 8);
+    }
     if (fb.bad) return Invalid("invalid message metadata");
     if (*off < 0 || *len < 0 || *off > blen || *len > blen - *off) return Invalid("buffer [" + std::to_string(*off) + ", +" + std::to_string(*len) + ") lies outside the " + std::to_string(blen) + "-byte body");
     if (*len > 0 && (*off & 7)) return Invalid("buffer offset " + std::to_string(*off) + " is not 8-byte aligned");

@@ -11,7 +11,8 @@
 // needed for a sequential pass.
 // Scope: flat columns of the types the kernels take — Int8..Uint64, Float32/64, Bool, Date32/64, Time32/64, Timestamp,
 // Duration, Utf8 / Binary and their Large variants, plain or dictionary-encoded (DictionaryBatch messages, replacement and delta);
-// little-endian; uncompressed.  Anything else is
+// little-endian; bodies uncompressed or compressed per buffer with LZ4_FRAME / ZSTD (ipc/compression.go: inflated on the host
+// by the system's liblz4 / libzstd into the layout of an uncompressed body, then the same single transfer).  Anything else is
 // ErrNotImplemented with the field named.  The metadata is a FlatBuffer (format/Message.fbs,
 // Schema.fbs); it is read with the small bounds-checked accessor in ipc.cc — the bytes come from a
 // file or a socket and are not trusted.
