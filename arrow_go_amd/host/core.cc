@@ -1062,6 +1062,56 @@ const std::map<std::string, TemporalRule>& TemporalRules() {
   return r;
 }
 
+
+// time32 / time64 ± duration of the same unit → the time type (GetArithmeticFunctionTimeDuration, scalar_arithmetic.go:47-65;
+// timeDurationOp, base_arithmetic.go:642-700): the duration is narrowed to the time's storage (`OutT(b)`: for time32 the int64
+// duration is TRUNCATED to int32, as the generic instantiation does), the integer kernel adds / subtracts (the checked names
+// report "overflow" from its carry test), and every result — ScalarBinary walks all slots — must lie in [0, one day):
+// otherwise the call fails with the LAST offending value, as the Go loop that keeps overwriting its error does.
+Status TimePlusDuration(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const Datum& time, const std::string& time_lg,
+                        const Datum& dur, Datum* out) {
+  const DataType* st = TemporalStorage(time_lg);
+  TemporalType t = ParseTemporal(time_lg);
+  int64_t day = 86400;
+  for (int i = 0; i < UnitRank(t.unit); i++) day *= 1000;
+  Datum d = dur;
+  if (st->id == Type::INT32) {
+    CastOptions narrow = CastOptions::Unsafe(GetDataType(Type::INT32));
+    AHC_RETURN_NOT_OK(CastDatum(ctx, dur, narrow, &d));
+  }
+  Datum r;
+  AHC_RETURN_NOT_OK(CallFunction(ctx, name, opts, {time, d}, &r));
+  Session* s = ctx->session;
+  auto check = [&](const ArrayData& a) -> Status {
+    if (a.length == 0) return Status::OK();
+    const int w = st->bit_width / 8;
+    const uint8_t* vals = (const uint8_t*)a.buffers[1]->dptr + a.offset * w;
+    int64_t lo = 0, hi = 0;
+    if (w == 4) { int32_t mn, mx; AHC_RETURN_NOT_OK(s->FromStatus(ah_min_max(s->ctx(), AH_INT32, vals, a.length, &mn, &mx))); lo = mn; hi = mx; }
+    else AHC_RETURN_NOT_OK(s->FromStatus(ah_min_max(s->ctx(), AH_INT64, vals, a.length, &lo, &hi)));
+    if (lo >= 0 && hi < day) return Status::OK();
+    std::vector<uint8_t> host((size_t)a.length * w);   // the error path: name the value the sequential loop would report
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), host.data(), vals, host.size())));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+    int64_t bad = 0;
+    for (int64_t i = a.length - 1; i >= 0; i--) {
+      int64_t v;
+      if (w == 4) { int32_t x; memcpy(&x, host.data() + i * 4, 4); v = x; } else memcpy(&v, host.data() + i * 8, 8);
+      if (v < 0 || v >= day) { bad = v; break; }
+    }
+    return Status::Make(StatusCode::Invalid, std::to_string(bad) + " is not within acceptable range of [0, " + std::to_string(day) + ") s");
+  };
+  if (r.kind == DatumKind::Array) AHC_RETURN_NOT_OK(check(*r.array));
+  else if (r.kind == DatumKind::Chunked) { for (auto& c : r.chunks) AHC_RETURN_NOT_OK(check(*c)); }
+  else if (r.kind == DatumKind::Scalar && r.scalar->valid) {
+    int64_t v;
+    if (st->id == Type::INT32) { int32_t x; memcpy(&x, r.scalar->value, 4); v = x; } else memcpy(&v, r.scalar->value, 8);
+    if (v < 0 || v >= day) return Status::Make(StatusCode::Invalid, std::to_string(v) + " is not within acceptable range of [0, " + std::to_string(day) + ") s");
+  }
+  *out = WithLogical(r, time_lg);
+  return Status::OK();
+}
+
 Status CallTemporal(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args_in,
                     const std::vector<std::string>& lg_in, Datum* out) {
   auto refuse = [&]() {
@@ -1127,6 +1177,7 @@ Status CallTemporal(ExecCtx* ctx, const std::string& name, const FunctionOptions
       if (a.kind == 's' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];        // timestamp + duration → timestamp
       else if (a.kind == 'D' && b.kind == 's' && a.unit == b.unit) out_logical = lg[1];   // duration + timestamp → timestamp
       else if (a.kind == 'D' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];   // duration + duration → duration
+      else if (a.kind == 't' && b.kind == 'D' && a.unit == b.unit) return TimePlusDuration(ctx, name, opts, bare[0], lg[0], bare[1], out);   // time + duration → time
       else return refuse();
       break;
     }
@@ -1137,6 +1188,7 @@ Status CallTemporal(ExecCtx* ctx, const std::string& name, const FunctionOptions
       if (a.kind == 's' && b.kind == 's' && SameTemporal(lg[0], lg[1])) out_logical = dur;     // timestamp − timestamp → duration
       else if (a.kind == 's' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];          // timestamp − duration → timestamp
       else if (a.kind == 'D' && b.kind == 'D' && a.unit == b.unit) out_logical = lg[0];
+      else if (a.kind == 't' && b.kind == 'D' && a.unit == b.unit) return TimePlusDuration(ctx, name, opts, bare[0], lg[0], bare[1], out);   // time − duration → time
       else if (a.kind == 't' && lg[0] == lg[1] && (a.unit == 'u' || a.unit == 'n')) out_logical = dur;  // time64 − time64 → duration
       else if (a.kind == 't' && lg[0] == lg[1]) {
         // time32 − time32 → duration: the int32 kernel, widened afterwards (arithmetic.go:721-741)

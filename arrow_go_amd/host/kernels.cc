@@ -744,7 +744,10 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
   // 1/2/4-byte keys: the reference memoises them in Table[uint8/16/32] keyed on the raw bits
   // (vector_hash.go:596-607); here the bits are zero-extended to 64 on the device, hashed in the same
   // table, and the dictionary is narrowed back — the ids and the first-seen order are unchanged
-  const int kw = keys.type->bit_width / 8;
+  // Boolean keys (doAppendBoolean, vector_hash.go:387-415: the bit becomes the uint8 key 0 / 1 of the same memo table): the bits
+  // are widened on the device like the narrow integers, and the ≤ 3 dictionary entries go back to a bitmap through `!= 0`
+  const bool is_bool = keys.type->id == Type::BOOL;
+  const int kw = is_bool ? 1 : keys.type->bit_width / 8;
   const int raw_type = kw == 1 ? AH_UINT8 : kw == 2 ? AH_UINT16 : AH_UINT32;
   const DictionaryEncodeOptions* opts = static_cast<const DictionaryEncodeOptions*>(k->state);
   int encode_nulls = dict_encode ? (opts && opts->NullEncoding == NullEncodingEncode) : 1;  // uniqueAction.ShouldEncodeNulls() == true
@@ -758,11 +761,12 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
     if (valid && !encode_nulls) AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &ids_valid));
   }
   int64_t ndict = 0; int32_t null_id = -1;
-  const uint64_t* keys64 = (const uint64_t*)Values(keys);
+  const uint64_t* keys64 = is_bool ? nullptr : (const uint64_t*)Values(keys);
   BufferPtr widened;
   if (kw < 8 && n > 0) {
     AHC_RETURN_NOT_OK(k->Allocate(n * 8, &widened, /*zero_all=*/false));
-    AHC_RETURN_NOT_OK(s->FromStatus(ah_cast_numeric(s->ctx(), raw_type, AH_UINT64, Values(keys), nullptr, 0, n, 1, 1, widened->dptr)));
+    if (is_bool) AHC_RETURN_NOT_OK(s->FromStatus(ah_cast_bool_to_numeric(s->ctx(), AH_UINT64, keys.buffers[1].buf, keys.offset, n, widened->dptr)));
+    else AHC_RETURN_NOT_OK(s->FromStatus(ah_cast_numeric(s->ctx(), raw_type, AH_UINT64, Values(keys), nullptr, 0, n, 1, 1, widened->dptr)));
     keys64 = (const uint64_t*)widened->dptr;
   }
   if (n > 0)
@@ -775,7 +779,13 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
   d->type = keys.type;
   d->length = ndict;
   d->null_count = null_id >= 0 ? 1 : 0;
-  if (kw < 8) {
+  if (is_bool) {
+    BufferPtr bits;
+    AHC_RETURN_NOT_OK(k->AllocateBitmap(ndict, &bits));
+    alignas(8) uint8_t zero[8] = {0};
+    if (ndict > 0) AHC_RETURN_NOT_OK(s->FromStatus(ah_comparison(s->ctx(), AH_CMP_NE, AH_SHAPE_AS, AH_UINT64, dict->dptr, zero, (uint8_t*)bits->dptr, ndict, 0)));
+    dict = bits;
+  } else if (kw < 8) {
     BufferPtr narrow;
     AHC_RETURN_NOT_OK(k->Allocate(ndict * kw, &narrow, /*zero_all=*/false));
     if (ndict > 0)
@@ -783,7 +793,7 @@ static Status ExecHash(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool di
     dict = narrow;
   }
   d->buffers[1] = dict;
-  dict->size = ndict * kw;
+  dict->size = is_bool ? (ndict + 7) / 8 : ndict * kw;
   if (null_id >= 0) {
     BufferPtr dv;
     AHC_RETURN_NOT_OK(k->AllocateBitmap(ndict, &dv));
@@ -868,7 +878,9 @@ void RegisterVectorHash(FunctionRegistry* reg) {
   auto uq = std::make_shared<VectorFunction>("unique", Arity{1, false});
   uq->chunked = VectorFunction::Chunked::SingleArray;
   auto de = std::make_shared<VectorFunction>("dictionary_encode", Arity{1, false}, &kDefaultDictOptions);
-  for (Type t : kNumericTypes) {
+  std::vector<Type> fixed(std::begin(kNumericTypes), std::end(kNumericTypes));
+  fixed.push_back(Type::BOOL);
+  for (Type t : fixed) {
     exec::VectorKernel ku;
     ku.sig.in_types = {t};
     ku.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHash(k, b, o, false); };

@@ -303,6 +303,33 @@ def test_unique_and_dictionary_encode(sess, typ):
 
 
 @pytest.mark.gpu
+def test_unique_and_dictionary_encode_boolean(sess):
+    """doAppendBoolean (kernels/vector_hash.go:387-415): the bit is the uint8 key of the same memo table"""
+    A = lambda v: pa.array(v, type=pa.bool_())
+    uq = lambda v: sess.call_function("unique", [v])
+    assert uq(A([False, None, True, False, None, True])).to_pylist() == [False, None, True]   # TestUniqueBoolean, vector_hash_test.go:300-319
+    assert uq(A([True, True, False, True])).to_pylist() == [True, False]
+    d = sess.call_function("dictionary_encode", [A([False, True, False, None, True])])           # TestDictionaryEncodeBoolean :637-698
+    assert d.indices.to_pylist() == [0, 1, 0, None, 1] and d.dictionary.to_pylist() == [False, True]
+    d = sess.call_function("dictionary_encode", [A([True, False, True, None, True, False, True]).slice(1, 5)], "null_encoding_behavior=encode")  # :700-760
+    assert d.indices.to_pylist() == [0, 1, 2, 1, 0] and d.dictionary.to_pylist() == [False, True, None]
+    assert uq(A([True, None, True, None, False])).to_pylist() == [True, None, False]
+    assert uq(A([None, None])).to_pylist() == [None]
+    assert uq(A([True, False, None, True]).slice(1, 3)).to_pylist() == [False, None, True]
+    assert uq(A([])).to_pylist() == [] and uq(A([True])).type == pa.bool_()
+    d = sess.call_function("dictionary_encode", [A([True, False, True, None, False, None])])
+    assert d.type == pa.dictionary(pa.int32(), pa.bool_())
+    assert d.indices.to_pylist() == [0, 1, 0, None, 1, None] and d.dictionary.to_pylist() == [True, False]
+    d = sess.call_function("dictionary_encode", [A([True, False, True, None, False, None])], "null_encoding_behavior=encode")
+    assert d.indices.to_pylist() == [0, 1, 0, 2, 1, 2] and d.dictionary.to_pylist() == [True, False, None]
+    rng = np.random.default_rng(6)
+    v = pa.array(rng.random(70003) < 0.3, mask=rng.random(70003) < 0.05, type=pa.bool_()).slice(3)
+    assert uq(v).equals(pc.unique(v))
+    got, exp = sess.call_function("dictionary_encode", [v]), pc.dictionary_encode(v)
+    assert got.indices.equals(exp.indices) and got.dictionary.equals(exp.dictionary)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("typ", [pa.string(), pa.large_string(), pa.binary(), pa.large_binary()], ids=str)
 def test_unique_and_dictionary_encode_binary(sess, typ):
     isbin = pa.types.is_binary(typ) or pa.types.is_large_binary(typ)

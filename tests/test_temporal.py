@@ -188,6 +188,44 @@ def test_date32_difference_overflow_rules(sess):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("typ,unit,day", [(pa.time32("s"), "s", 86400), (pa.time32("ms"), "ms", 86400 * 10**3),
+                                          (pa.time64("us"), "us", 86400 * 10**6), (pa.time64("ns"), "ns", 86400 * 10**9)], ids=str)
+def test_time_plus_minus_duration(sess, typ, unit, day):
+    """GetArithmeticFunctionTimeDuration (scalar_arithmetic.go:47-65) / timeDurationOp (base_arithmetic.go:642-700): time ± duration of
+    the same unit → the time type; every result must lie in [0, one day), the error names the last offender"""
+    rng = np.random.default_rng(13)
+    n = 3001
+    store = pa.int32() if pa.types.is_time32(typ) else pa.int64()
+    t0 = rng.integers(0, day // 2, n)
+    d0 = rng.integers(0, day // 2, n)
+    t = pa.array(t0, mask=rng.random(n) < 0.1, type=store).cast(typ)
+    d = pa.array(d0, mask=rng.random(n) < 0.1, type=pa.int64()).cast(pa.duration(unit))
+    for name in ("add", "add_unchecked"):
+        got = sess.call_function(name, [t, d])
+        assert got.type == typ
+        want = pc.add(t.cast(store).cast(pa.int64()), d.cast(pa.int64())).cast(store).cast(typ)
+        assert got.equals(want), name
+    big = pa.array(t0 + day // 2, mask=rng.random(n) < 0.1, type=store).cast(typ)
+    for name in ("subtract", "subtract_unchecked"):
+        got = sess.call_function(name, [big, d])
+        want = pc.subtract(big.cast(store).cast(pa.int64()), d.cast(pa.int64())).cast(store).cast(typ)
+        assert got.type == typ and got.equals(want), name
+    # arr ∘ scalar
+    one = pa.scalar(5, pa.int64()).cast(pa.duration(unit))
+    assert sess.call_function("add", [t, one]).equals(pc.add(t.cast(store).cast(pa.int64()), 5).cast(store).cast(typ))
+    # out of [0, day): the last offending value is reported (the Go loop keeps overwriting its error)
+    late = pa.array([10, day - 1, day - 2, 7], type=store).cast(typ)
+    step = pa.array([1, 1, 5, 1], type=pa.int64()).cast(pa.duration(unit))
+    with pytest.raises(ac.ErrInvalid, match=r"%d is not within acceptable range of \[0, %d\) s" % (day + 3, day)):
+        sess.call_function("add", [late, step])
+    with pytest.raises(ac.ErrInvalid, match=r"-4 is not within acceptable range"):
+        sess.call_function("subtract_unchecked", [pa.array([1, 50], type=store).cast(typ), pa.array([5, 1], type=pa.int64()).cast(pa.duration(unit))])
+    # a duration of another unit is refused unless it can be brought to the time's family unit
+    with pytest.raises((ac.ErrNotImplemented, ac.ErrInvalid)):
+        sess.call_function("multiply", [t, d])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("unit", ["s", "ms", "us", "ns"])
 def test_timestamp_duration_arithmetic(sess, unit):
     rng = np.random.default_rng(3)
