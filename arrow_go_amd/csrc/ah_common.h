@@ -40,6 +40,7 @@ struct ah_ctx {
   int opt_take_binned, opt_take_window_log2, opt_take_gather_wg, opt_take_gather_load;
   int opt_groupby_partition;   // hash + sum (ah_groupby.hip): 0 never, 1 auto, k ≥ 2 always with 2^(k−2) partitions (ARROWHIP_GROUPBY_PARTITION)
   int opt_hash_direct;         // unique / dictionary_encode (ah_hash.hip): 0 ids in a separate pass, 1 direct ids, 2 + LDS / re-packed table (default), 3 no re-packed table (ARROWHIP_HASH_DIRECT)
+  int opt_sort_msd;            // sort_indices: 0 LSD passes only, 1 auto (ARROWHIP_SORT_MSD)
   int opt_scan_segment_log2;   // cumulative_sum: bytes of input per segment (ARROWHIP_SCAN_SEGMENT_LOG2; 0 = one segment)
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   char err[512];
@@ -93,6 +94,15 @@ void ah_expr_cache_free(ah_ctx* ctx);  // ah_expr.hip
 int ah_partition_by_group(ah_ctx* ctx, const int32_t* ids, const unsigned long long* vals, const uint8_t* vvalid, int64_t voff, int64_t n,
                           int shift, int passes, unsigned* hist, unsigned* offs, unsigned long long* alt_vals, unsigned* alt_ids,
                           unsigned long long* out_vals, unsigned* out_ids);
+// internal (ah_sort_msd.hip): the `rest` range of sort_indices by two MSD partition passes + one wave per bucket; *used = 0: not
+// applicable or a bucket came out too large — the pairs are clobbered and the caller regenerates them for the LSD passes
+int ah_sort_rest_msd(ah_ctx* ctx, unsigned long long* keys, unsigned* rows, unsigned long long* alt_keys, unsigned* alt_rows, int64_t n,
+                     unsigned long long varying, unsigned long long kmin, unsigned long long kmax, int float_bytes, int descending, void* tmp,
+                     int* used);
+size_t ah_sort_msd_temp_bytes(int64_t n);   // size of `tmp`; 0: the path does not apply to n pairs
+// internal (ah_sort.hip): (key, row) pairs sorted by the full 64-bit key with the stable LSD passes; *sorted_keys = where the keys ended up
+int ah_sort_pairs_lsd(ah_ctx* ctx, unsigned long long* keys, unsigned* rows, unsigned long long* alt_keys, unsigned* alt_rows, int64_t n,
+                      unsigned* hist, unsigned* offs, unsigned long long** sorted_keys);
 // internal (ah_take_binned.hip): Take for random indices into a column the caches cannot hold; *used says whether it ran
 int ah_take_binned_try(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int iw,
                        int is_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values,

@@ -38,6 +38,7 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_take_gather_wg = env_int("ARROWHIP_TAKE_GATHER_WG_PER_CU", 8);
   c->opt_groupby_partition = env_int("ARROWHIP_GROUPBY_PARTITION", 1);
   c->opt_hash_direct = env_int("ARROWHIP_HASH_DIRECT", 2);
+  c->opt_sort_msd = env_int("ARROWHIP_SORT_MSD", 1);
   c->opt_scan_segment_log2 = env_int("ARROWHIP_SCAN_SEGMENT_LOG2", 0);   // 0 = one segment: segments measured slower
   c->opt_take_gather_load = env_int("ARROWHIP_TAKE_GATHER_LOAD", 0);   // 0 plain, 1 nontemporal, 2 L1-bypassing (sc1)
   return AH_OK;
@@ -103,6 +104,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "take_gather_load")) c->opt_take_gather_load = (int)value;
   else if (!strcmp(name, "groupby_partition")) c->opt_groupby_partition = (int)value;
   else if (!strcmp(name, "hash_direct")) c->opt_hash_direct = (int)value;
+  else if (!strcmp(name, "sort_msd")) c->opt_sort_msd = (int)value;
   else if (!strcmp(name, "scan_segment_log2")) c->opt_scan_segment_log2 = (int)value;
   else return ah_fail(c, AH_EINVALID, "set_option: unknown option '%s'", name);
   return AH_OK;

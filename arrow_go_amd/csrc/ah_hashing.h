@@ -32,34 +32,49 @@ __global__ __launch_bounds__(kBlock) void word_prefix_kernel(const unsigned long
   }
 }
 
+// exclusive scan of the tile totals, one workgroup: 4096 entries per round (one 16-byte load per thread, a wave scan, 16 wave
+// totals through LDS).  (The first version gave each thread ntiles / 1024 consecutive entries to walk: 64 dependent
+// 4-byte loads per thread at 2^26 rows = 62 µs of pure latency; this one takes ≈ 10 µs.)
 __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ counts, int64_t ntiles,
                                                      int64_t* __restrict__ offsets, unsigned long long* __restrict__ total) {
   __shared__ int64_t wave_tot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t chunk = (ntiles + 1023) / 1024;
-  const int64_t lo = (int64_t)tid * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
-  int64_t s = 0;
-  for (int64_t i = lo; i < hi; i++) s += counts[i];
-  int64_t inc = s;
+  int64_t carry = 0;
+  for (int64_t base = 0; base < ntiles; base += 4096) {
+    const int64_t i0 = base + (int64_t)tid * 4;
+    int c[4] = {0, 0, 0, 0};
+    if (i0 + 4 <= ntiles) {
+      const ah_vec16<int> v = *reinterpret_cast<const ah_vec16<int>*>(counts + i0);   // element-aligned 16-byte load
+      c[0] = v.v[0]; c[1] = v.v[1]; c[2] = v.v[2]; c[3] = v.v[3];
+    } else {
+      for (int k = 0; k < 4; k++) if (i0 + k < ntiles) c[k] = counts[i0 + k];
+    }
+    const int64_t s = (int64_t)c[0] + c[1] + c[2] + c[3];
+    int64_t inc = s;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int64_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int64_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int64_t t = wave_tot[k];
+      if (k < wave) wbase += t;
+      tot += t;
+    }
+    int64_t run = carry + wbase + inc - s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (i0 + k < ntiles) offsets[i0 + k] = run;
+      run += c[k];
+    }
+    carry += tot;
+    __syncthreads();   // wave_tot is rewritten in the next round
   }
-  if (lane == 63) wave_tot[wave] = inc;
-  __syncthreads();
-  int64_t base = 0, tot = 0;
-  for (int k = 0; k < 16; k++) {
-    int64_t t = wave_tot[k];
-    if (k < wave) base += t;
-    tot += t;
-  }
-  int64_t run = base + inc - s;
-  for (int64_t i = lo; i < hi; i++) {
-    offsets[i] = run;
-    run += counts[i];
-  }
-  if (tid == 0) *total = (unsigned long long)tot;
+  if (tid == 0) *total = (unsigned long long)carry;
 }
 
 __device__ __forceinline__ unsigned rank_of_row(unsigned fr, const unsigned long long* __restrict__ firsts,
@@ -131,17 +146,34 @@ __device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned l
 __global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
                                                          int64_t n, unsigned long long* __restrict__ out) {
   unsigned long long m = 0;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const unsigned long long b = __builtin_nontemporal_load(&vals[i]) & 0x7fffffffffffffffull;
-    if ((b >> 52) != 0x7ff && b > m && ah_bit(vvalid, voff + i)) m = b;   // |x| of finite values order like their bit patterns
+  // 8 values per lane per step (four of them loaded before the first is used): a one-value grid-stride loop ran at 3.1 TB/s
+  constexpr int U = 8;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < n; base += stride) {
+    unsigned long long b[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      b[u] = i < n ? __builtin_nontemporal_load(&vals[i]) & 0x7fffffffffffffffull : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (i < n && (b[u] >> 52) != 0x7ff && b[u] > m && ah_bit(vvalid, voff + i)) m = b[u];   // |x| of finite values order like their bit patterns
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long t = __shfl_down(m, o, 64);
     m = t > m ? t : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  __shared__ unsigned long long s_m[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per workgroup: same-address atomics cost ≈ 12 ns each, serialised
+    for (int w = 1; w < kBlock / 64; w++) m = s_m[w] > m ? s_m[w] : m;
+    if (m) atomicMax(out, m);
+  }
 }
 __global__ __launch_bounds__(kBlock) void fx_finalize_kernel(FxAcc acc, int64_t ngroups, double* __restrict__ out_sums) {
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;

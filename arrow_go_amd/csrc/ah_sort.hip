@@ -21,6 +21,7 @@
 // Traffic: 8 (+1/8) B/row for (1) and (2), ≈ 32 B/row per LSD pass ((key, row) read twice, written
 // once), 12 B/row for (4): an Int64 column with all 8 bytes varying moves ≈ 290 B/row.
 #include <type_traits>
+#include <vector>
 #include "ah_common.h"
 
 namespace {
@@ -253,20 +254,87 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SRC src, int64_t n, con
   }  // tiles of this block
 }
 
-// which key bits vary at all: res[0] = AND of all keys, res[1] = OR
+// which key bits vary at all, and the extreme keys: per workgroup {AND, OR, min, max} of its keys (the host folds the ≤ 1024
+// partial results — four same-address atomics per wave would cost more than the pass)
 __global__ __launch_bounds__(kBlock) void and_or_kernel(const unsigned long long* __restrict__ keys, int64_t n, unsigned long long* __restrict__ res) {
-  unsigned long long a = ~0ull, o = 0ull;
+  __shared__ unsigned long long s_r[kWaves][4];
+  unsigned long long a = ~0ull, o = 0ull, mn = ~0ull, mx = 0ull;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     const unsigned long long k = keys[i];
     a &= k; o |= k;
+    mn = k < mn ? k : mn;
+    mx = k > mx ? k : mx;
   }
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) {
     a &= __shfl_down(a, s, 64);
     o |= __shfl_down(o, s, 64);
+    const unsigned long long m1 = __shfl_down(mn, s, 64), m2 = __shfl_down(mx, s, 64);
+    mn = m1 < mn ? m1 : mn;
+    mx = m2 > mx ? m2 : mx;
   }
-  if ((threadIdx.x & 63) == 0) { atomicAnd(&res[0], a); atomicOr(&res[1], o); }
+  if ((threadIdx.x & 63) == 0) { s_r[threadIdx.x >> 6][0] = a; s_r[threadIdx.x >> 6][1] = o; s_r[threadIdx.x >> 6][2] = mn; s_r[threadIdx.x >> 6][3] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kWaves; w++) {
+      a &= s_r[w][0]; o |= s_r[w][1];
+      mn = s_r[w][2] < mn ? s_r[w][2] : mn;
+      mx = s_r[w][3] > mx ? s_r[w][3] : mx;
+    }
+    res[blockIdx.x * 4 + 0] = a; res[blockIdx.x * 4 + 1] = o; res[blockIdx.x * 4 + 2] = mn; res[blockIdx.x * 4 + 3] = mx;
+  }
+}
+
+// Pass (1) without the partition, for a column with no validity bitmap in input order: keys and row numbers in one streaming
+// pass, the AND / OR / min / max of the keys on the way (per workgroup: res[5 b …] = {AND, OR, min, max, NaN count}).  Valid
+// only if the NaN count comes back zero — then every row is `rest` and pass (2) has been done too; otherwise the caller
+// runs the partition pass as usual.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pairs_kernel(const T* __restrict__ values, int64_t n, int descending, unsigned long long* __restrict__ keys,
+                                                        unsigned* __restrict__ rows, unsigned long long* __restrict__ res) {
+  __shared__ unsigned long long s_r[kWaves][5];
+  unsigned long long a = ~0ull, o = 0ull, mn = ~0ull, mx = 0ull, nans = 0;
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < n; base += stride) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int64_t i = base + (int64_t)u * kBlock; v[u] = i < n ? __builtin_nontemporal_load(&values[i]) : (T)0; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (i >= n) continue;
+      if (std::is_floating_point<T>::value && v[u] != v[u]) { nans++; continue; }
+      const unsigned long long k = make_key<T>(v[u], descending);
+      __builtin_nontemporal_store(k, &keys[i]);
+      __builtin_nontemporal_store((unsigned)i, &rows[i]);
+      a &= k; o |= k;
+      mn = k < mn ? k : mn;
+      mx = k > mx ? k : mx;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    a &= __shfl_down(a, s, 64);
+    o |= __shfl_down(o, s, 64);
+    const unsigned long long m1 = __shfl_down(mn, s, 64), m2 = __shfl_down(mx, s, 64);
+    mn = m1 < mn ? m1 : mn;
+    mx = m2 > mx ? m2 : mx;
+    nans += __shfl_down(nans, s, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { unsigned long long* r = s_r[threadIdx.x >> 6]; r[0] = a; r[1] = o; r[2] = mn; r[3] = mx; r[4] = nans; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kWaves; w++) {
+      a &= s_r[w][0]; o |= s_r[w][1];
+      mn = s_r[w][2] < mn ? s_r[w][2] : mn;
+      mx = s_r[w][3] > mx ? s_r[w][3] : mx;
+      nans += s_r[w][4];
+    }
+    unsigned long long* r = res + (size_t)blockIdx.x * 5;
+    r[0] = a; r[1] = o; r[2] = mn; r[3] = mx; r[4] = nans;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void emit_kernel(const unsigned* __restrict__ rows, int64_t n, uint64_t* __restrict__ out) {
@@ -297,6 +365,7 @@ int radix_pass(ah_ctx* c, SRC src, int64_t n, unsigned* hist, unsigned* offs, un
 }
 
 struct SortBuffers {  // temporaries shared by all keys of one call
+  void* msd_tmp = nullptr;  // ah_sort_msd.hip's tables (nullptr: that path is off for this call)
   unsigned long long *ka, *kb, *andor;
   unsigned *ra, *rb, *rc;  // ra / rb: ping-pong of a key's passes; rc: the previous key's result
   unsigned *hist, *offs;
@@ -311,29 +380,73 @@ int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t*
   int rc;
   // (1) partition by category, keys and row numbers come into being
   Column<T> col{(const T*)values, valid, off, descending, nulls_at_start, rows_in};
-  if ((rc = radix_pass(c, col, n, b.hist, b.offs, b.ka, b.ra)) != AH_OK) return rc;
-  // how many rows of each category?  offs (inclusive scan, digit-major): the last tile's entry of digit d
-  unsigned ends[3];
-  for (int d = 0; d < 3; d++)
-    AH_HIP(c, hipMemcpyAsync(&c->pinned[d], b.offs + ((int64_t)d + 1) * ntiles - 1, 4, hipMemcpyDeviceToHost, c->stream));
-  AH_HIP(c, hipStreamSynchronize(c->stream));
-  for (int d = 0; d < 3; d++) ends[d] = *(volatile unsigned*)&c->pinned[d];
-  // the `rest` category is digit 0 (nulls at end) or digit 2 (nulls at start)
-  const int64_t rest_lo = nulls_at_start ? ends[1] : 0;
-  const int64_t rest_n = nulls_at_start ? (int64_t)ends[2] - ends[1] : ends[0];
+  int64_t rest_lo = 0, rest_n = 0;
+  unsigned long long k_and = ~0ull, k_or = 0, kmin = ~0ull, kmax = 0;
+  bool have_stats = false;
+  if (valid == nullptr && rows_in == nullptr && n >= ((int64_t)1 << 20)) {
+    // no validity bitmap, input order: nothing to partition unless a float column holds NaNs — one streaming pass, checked after
+    const unsigned pgrid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 4), 8);
+    pairs_kernel<T><<<pgrid, kBlock, 0, c->stream>>>((const T*)values, n, descending, b.ka, b.ra, b.andor);
+    AH_LAUNCH_CHECK(c);
+    std::vector<unsigned long long> parts((size_t)pgrid * 5);
+    AH_HIP(c, hipMemcpyAsync(parts.data(), b.andor, parts.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned long long nans = 0;
+    for (unsigned g = 0; g < pgrid; g++) {
+      k_and &= parts[g * 5]; k_or |= parts[g * 5 + 1];
+      kmin = parts[g * 5 + 2] < kmin ? parts[g * 5 + 2] : kmin;
+      kmax = parts[g * 5 + 3] > kmax ? parts[g * 5 + 3] : kmax;
+      nans += parts[g * 5 + 4];
+    }
+    if (nans == 0) { have_stats = true; rest_lo = 0; rest_n = n; }
+  }
+  if (!have_stats) {
+    if ((rc = radix_pass(c, col, n, b.hist, b.offs, b.ka, b.ra)) != AH_OK) return rc;
+    // how many rows of each category?  offs (inclusive scan, digit-major): the last tile's entry of digit d
+    unsigned ends[3];
+    for (int d = 0; d < 3; d++)
+      AH_HIP(c, hipMemcpyAsync(&c->pinned[d], b.offs + ((int64_t)d + 1) * ntiles - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    for (int d = 0; d < 3; d++) ends[d] = *(volatile unsigned*)&c->pinned[d];
+    // the `rest` category is digit 0 (nulls at end) or digit 2 (nulls at start)
+    rest_lo = nulls_at_start ? ends[1] : 0;
+    rest_n = nulls_at_start ? (int64_t)ends[2] - ends[1] : ends[0];
+  }
   unsigned long long *kcur = b.ka + rest_lo, *kalt = b.kb + rest_lo;
   unsigned *rcur = b.ra + rest_lo, *ralt = b.rb + rest_lo;
   if (rest_n > 1) {
-    // (2) which key bytes vary
-    AH_HIP(c, hipMemsetAsync(b.andor, 0xFF, 8, c->stream));
-    AH_HIP(c, hipMemsetAsync(b.andor + 1, 0, 8, c->stream));
-    and_or_kernel<<<ah_stream_grid(c, ah_ceil_div(rest_n, kBlock), 4), kBlock, 0, c->stream>>>(kcur, rest_n, b.andor);
-    AH_LAUNCH_CHECK(c);
-    AH_HIP(c, hipMemcpyAsync(c->pinned, b.andor, 16, hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
-    const unsigned long long varying = ((volatile unsigned long long*)c->pinned)[0] ^ ((volatile unsigned long long*)c->pinned)[1];
+    if (!have_stats) {
+      // (2) which key bytes vary; smallest and largest key
+      const unsigned agrid = ah_stream_grid(c, ah_ceil_div(rest_n, kBlock), 4);
+      and_or_kernel<<<agrid, kBlock, 0, c->stream>>>(kcur, rest_n, b.andor);
+      AH_LAUNCH_CHECK(c);
+      std::vector<unsigned long long> parts((size_t)agrid * 4);
+      AH_HIP(c, hipMemcpyAsync(parts.data(), b.andor, parts.size() * 8, hipMemcpyDeviceToHost, c->stream));
+      AH_HIP(c, hipStreamSynchronize(c->stream));
+      for (unsigned g = 0; g < agrid; g++) {
+        k_and &= parts[g * 4]; k_or |= parts[g * 4 + 1];
+        kmin = parts[g * 4 + 2] < kmin ? parts[g * 4 + 2] : kmin;
+        kmax = parts[g * 4 + 3] > kmax ? parts[g * 4 + 3] : kmax;
+      }
+    }
+    const unsigned long long varying = k_and ^ k_or;
+    int nvar = 0;
+    for (int by = 0; by < (int)sizeof(T); by++) nvar += ((varying >> (8 * by)) & 0xFFull) != 0;
+    // (3') large inputs with ≥ 4 varying bytes, in input order (the first key processed): two unstable MSD partition passes
+    // + one wave per bucket comparing (key, row) — ah_sort_msd.hip.  Equal keys end up in row order = input order.
+    bool done = false;
+    if (rows_in == nullptr && nvar >= 4 && c->opt_sort_msd) {
+      int used = 0;
+      if ((rc = ah_sort_rest_msd(c, kcur, rcur, kalt, ralt, rest_n, varying, kmin, kmax, std::is_floating_point<T>::value ? (int)sizeof(T) : 0, descending, b.msd_tmp, &used)) != AH_OK) return rc;
+      if (used) {
+        done = true;   // sorted rows are in rcur (each bucket is rewritten in place)
+      } else if (b.msd_tmp && ah_sort_msd_temp_bytes(rest_n) != 0) {
+        // it ran and gave up (a bucket too large): the pairs are gone — pass (1) again, then the LSD passes
+        if ((rc = radix_pass(c, col, n, b.hist, b.offs, b.ka, b.ra)) != AH_OK) return rc;
+      }
+    }
     // (3) one stable pass per varying byte, least significant first
-    for (int by = 0; by < (int)sizeof(T); by++) {
+    for (int by = 0; !done && by < (int)sizeof(T); by++) {
       if (((varying >> (8 * by)) & 0xFFull) == 0) continue;
       Pairs src{kcur, rcur, 8 * by};
       if ((rc = radix_pass(c, src, rest_n, b.hist, b.offs, kalt, ralt)) != AH_OK) return rc;
@@ -364,7 +477,8 @@ int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values,
   const int64_t ntiles = ah_ceil_div(n, kTile);
   int rc;
   const size_t hist_bytes = (size_t)kRadix * ntiles * 4;
-  const size_t total = 2 * Carver::pad((size_t)n * 8) + (nkeys > 1 ? 3 : 2) * Carver::pad((size_t)n * 4) + 2 * Carver::pad(hist_bytes) + 256;
+  const size_t msd_bytes = c->opt_sort_msd ? ah_sort_msd_temp_bytes(n) : 0;   // sized for rest_n = n
+  const size_t total = 2 * Carver::pad((size_t)n * 8) + (nkeys > 1 ? 3 : 2) * Carver::pad((size_t)n * 4) + 2 * Carver::pad(hist_bytes) + Carver::pad(4096 * 8 * 8) + Carver::pad(msd_bytes);
   void* arena;
   if ((rc = ah_temp_reserve(c, total, &arena)) != AH_OK) return rc;
   Carver tmp{(uint8_t*)arena};
@@ -376,7 +490,8 @@ int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values,
   if (nkeys > 1) tmp.take((size_t)n * 4, &b.rc);
   tmp.take(hist_bytes, &b.hist);
   tmp.take(hist_bytes, &b.offs);
-  tmp.take(64, &b.andor);
+  tmp.take(4096 * 8 * 8, &b.andor);   // ≤ 8 workgroups per CU × {AND, OR, min, max, NaNs}
+  if (msd_bytes) { uint8_t* m; tmp.take(msd_bytes, &m); b.msd_tmp = m; }
   // lexicographic order by keys 0..k−1 = stable sorts by key k−1, …, key 0 in turn (every pass is stable)
   const unsigned* rows_in = nullptr;
   for (int k = nkeys - 1; k >= 0; k--) {
@@ -402,6 +517,19 @@ int ah_partition_by_group(ah_ctx* c, const int32_t* ids, const unsigned long lon
   if (rc != AH_OK) return rc;
   ValId src2{alt_vals, alt_ids, shift + 8};
   return radix_pass(c, src2, n, hist, offs, out_vals, out_ids);
+}
+
+int ah_sort_pairs_lsd(ah_ctx* c, unsigned long long* keys, unsigned* rows, unsigned long long* alt_keys, unsigned* alt_rows, int64_t n,
+                      unsigned* hist, unsigned* offs, unsigned long long** sorted_keys) {
+  for (int by = 0; by < 8; by++) {
+    Pairs src{keys, rows, 8 * by};
+    int rc = radix_pass(c, src, n, hist, offs, alt_keys, alt_rows);
+    if (rc != AH_OK) return rc;
+    unsigned long long* tk = keys; keys = alt_keys; alt_keys = tk;
+    unsigned* tr = rows; rows = alt_rows; alt_rows = tr;
+  }
+  *sorted_keys = keys;
+  return AH_OK;
 }
 
 static int check_column(ah_ctx* c, int type, const void* values) {

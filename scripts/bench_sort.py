@@ -18,6 +18,18 @@ for lg in (20, 24, 27):
     for off in range(0, rows, chunk.size): a.upload(chunk + off, off * 8)
     ms = timed(lambda: ctx.sort_indices(N.INT64, a, None, 0, rows, False, False, out))
     res[f"int64 random 2^{lg}"] = {"ms": round(ms, 3), "Mrows_per_s": round(rows / ms / 1e3)}
+    ctx.set_option("sort_msd", 0)
+    res[f"int64 random 2^{lg}"]["ms_lsd_only"] = round(timed(lambda: ctx.sort_indices(N.INT64, a, None, 0, rows, False, False, out)), 3)
+    ctx.set_option("sort_msd", 1)
+    if lg >= 24:
+        f = rng.standard_normal(min(rows, 1 << 22))
+        for off in range(0, rows, f.size): a.upload(f + off * 1e-9, off * 8)
+        ms = timed(lambda: ctx.sort_indices(N.FLOAT64, a, None, 0, rows, False, False, out))
+        res[f"float64 normal 2^{lg}"] = {"ms": round(ms, 3), "Mrows_per_s": round(rows / ms / 1e3)}
+        ctx.set_option("sort_msd", 0)
+        res[f"float64 normal 2^{lg}"]["ms_lsd_only"] = round(timed(lambda: ctx.sort_indices(N.FLOAT64, a, None, 0, rows, False, False, out)), 3)
+        ctx.set_option("sort_msd", 1)
+        for off in range(0, rows, chunk.size): a.upload(chunk + off, off * 8)
     if lg == 27:
         ms = timed(lambda: ctx.sort_indices(N.FLOAT64, a, None, 0, rows, True, False, out))
         res["float64(bits) desc 2^27"] = {"ms": round(ms, 3), "Mrows_per_s": round(rows / ms / 1e3)}

@@ -968,6 +968,42 @@ def test_sort_indices_many_tiles(hip, orc_be):
         assert hip.sort_indices(a, None, 0, True, False).tobytes() == orc_be.sort_indices(a, None, 0, True, False).tobytes()
 
 
+def test_sort_indices_msd_path(ctx, hip, orc_be):
+    """≥ 2^22 rows with ≥ 4 varying key bytes take ah_sort_msd.hip (bucket map from a sample → two MSD partition passes → one
+    wave per bucket on (key, row)); columns it cannot balance fall back to the LSD passes.  Either way the permutation is the
+    oracle's, and the same as with the path switched off."""
+    rng = np.random.default_rng(8300)
+    n = (1 << 22) + 12345
+    cases = {
+        "int64 full range": rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64),
+        "uint64": rng.integers(0, 2**64 - 1, n, dtype=np.uint64),
+        "float64 normal": rng.standard_normal(n),
+        "float64 lognormal": np.exp(rng.standard_normal(n) * 8),
+        "float64 uniform(-1, 1)": rng.uniform(-1, 1, n),
+        "int64 clustered": 10**15 + rng.integers(0, 10**11, n),
+        "int64 two clusters": np.where(rng.random(n) < 0.3, rng.integers(0, 10**6, n), 2**60 + rng.integers(0, 2**40, n)),
+        "int64 ties among wide keys": rng.integers(0, 2**40, n // 4, dtype=np.int64)[rng.integers(0, n // 4, n)] * 1000003,
+        "float32": (rng.standard_normal(n) * 1e3).astype(np.float32),
+        "int64 heavy duplicates (falls back)": rng.integers(0, 2**50, 3000, dtype=np.int64)[rng.integers(0, 3000, n)],
+        "int64 one hot key (falls back)": np.where(rng.random(n) < 0.2, np.int64(123456789012345), rng.integers(-2**62, 2**62, n, dtype=np.int64)),
+    }
+    for name, a in cases.items():
+        a = np.ascontiguousarray(a)
+        if a.dtype.kind == "f":
+            a[rng.integers(0, n, 6)] = [np.nan, -np.nan, np.inf, -np.inf, -0.0, 0.0]
+        valid = OL.pack_bits(list(rng.random(n + 9) >= 0.03))
+        for desc, at_start, v, off in [(False, False, valid, 9), (True, True, None, 0)]:
+            e = orc_be.sort_indices(a, v, off, desc, at_start)
+            g = hip.sort_indices(a, v, off, desc, at_start)
+            assert g.tobytes() == e.tobytes(), (name, desc)
+        try:
+            ctx.set_option("sort_msd", 0)
+            g0 = hip.sort_indices(a, None, 0, False, False)
+        finally:
+            ctx.set_option("sort_msd", 1)
+        assert g0.tobytes() == hip.sort_indices(a, None, 0, False, False).tobytes(), name
+
+
 def test_sort_indices_multi_key(hip, orc_be):
     """record-batch sort: 1–4 keys of mixed types, orders and null placements, few distinct values per key
     so that later keys decide most positions; the permutation must equal the oracle's exactly"""
