@@ -98,7 +98,7 @@ int ah_partition_by_group(ah_ctx* ctx, const int32_t* ids, const unsigned long l
 // applicable or a bucket came out too large — the pairs are clobbered and the caller regenerates them for the LSD passes
 int ah_sort_rest_msd(ah_ctx* ctx, unsigned long long* keys, unsigned* rows, unsigned long long* alt_keys, unsigned* alt_rows, int64_t n,
                      unsigned long long varying, unsigned long long kmin, unsigned long long kmax, int float_bytes, int descending, void* tmp,
-                     int* used);
+                     unsigned long long* out64, int* used);
 size_t ah_sort_msd_temp_bytes(int64_t n);   // size of `tmp`; 0: the path does not apply to n pairs
 // internal (ah_sort.hip): (key, row) pairs sorted by the full 64-bit key with the stable LSD passes; *sorted_keys = where the keys ended up
 int ah_sort_pairs_lsd(ah_ctx* ctx, unsigned long long* keys, unsigned* rows, unsigned long long* alt_keys, unsigned* alt_rows, int64_t n,

@@ -366,6 +366,8 @@ int radix_pass(ah_ctx* c, SRC src, int64_t n, unsigned* hist, unsigned* offs, un
 
 struct SortBuffers {  // temporaries shared by all keys of one call
   void* msd_tmp = nullptr;  // ah_sort_msd.hip's tables (nullptr: that path is off for this call)
+  uint64_t* final_out = nullptr;  // single-key call: where the widened result goes; the MSD path writes it directly when every row is `rest`
+  bool emitted = false;
   unsigned long long *ka, *kb, *andor;
   unsigned *ra, *rb, *rc;  // ra / rb: ping-pong of a key's passes; rc: the previous key's result
   unsigned *hist, *offs;
@@ -437,9 +439,11 @@ int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t*
     bool done = false;
     if (rows_in == nullptr && nvar >= 4 && c->opt_sort_msd) {
       int used = 0;
-      if ((rc = ah_sort_rest_msd(c, kcur, rcur, kalt, ralt, rest_n, varying, kmin, kmax, std::is_floating_point<T>::value ? (int)sizeof(T) : 0, descending, b.msd_tmp, &used)) != AH_OK) return rc;
+      if ((rc = ah_sort_rest_msd(c, kcur, rcur, kalt, ralt, rest_n, varying, kmin, kmax, std::is_floating_point<T>::value ? (int)sizeof(T) : 0, descending, b.msd_tmp,
+                                 (unsigned long long*)(rest_n == n ? b.final_out : nullptr), &used)) != AH_OK) return rc;
       if (used) {
-        done = true;   // sorted rows are in rcur (each bucket is rewritten in place)
+        done = true;   // sorted rows are in rcur (each bucket is rewritten in place) — or already widened in the output
+        b.emitted = rest_n == n && b.final_out != nullptr;
       } else if (b.msd_tmp && ah_sort_msd_temp_bytes(rest_n) != 0) {
         // it ran and gave up (a bucket too large): the pairs are gone — pass (1) again, then the LSD passes
         if ((rc = radix_pass(c, col, n, b.hist, b.offs, b.ka, b.ra)) != AH_OK) return rc;
@@ -454,7 +458,7 @@ int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t*
       unsigned* tr = rcur; rcur = ralt; ralt = tr;
     }
     // the rest range must end up in ra, next to the NaN / null groups pass (1) left there
-    if (rcur != b.ra + rest_lo) AH_HIP(c, hipMemcpyAsync(b.ra + rest_lo, rcur, (size_t)rest_n * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (!b.emitted && rcur != b.ra + rest_lo) AH_HIP(c, hipMemcpyAsync(b.ra + rest_lo, rcur, (size_t)rest_n * 4, hipMemcpyDeviceToDevice, c->stream));
   }
   return AH_OK;
 }
@@ -494,6 +498,7 @@ int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values,
   if (msd_bytes) { uint8_t* m; tmp.take(msd_bytes, &m); b.msd_tmp = m; }
   // lexicographic order by keys 0..k−1 = stable sorts by key k−1, …, key 0 in turn (every pass is stable)
   const unsigned* rows_in = nullptr;
+  if (nkeys == 1) b.final_out = out;
   for (int k = nkeys - 1; k >= 0; k--) {
     if ((rc = sort_dispatch(c, b, types[k], values[k], valids[k], offs[k], n, descending[k], nulls_at_start[k], rows_in)) != AH_OK) return rc;
     if (k > 0) {
@@ -501,8 +506,10 @@ int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values,
       rows_in = b.rc;
     }
   }
-  emit_kernel<<<ah_stream_grid(c, ah_ceil_div(n, kBlock), 8), kBlock, 0, c->stream>>>(b.ra, n, out);
-  AH_LAUNCH_CHECK(c);
+  if (!b.emitted) {
+    emit_kernel<<<ah_stream_grid(c, ah_ceil_div(n, kBlock), 8), kBlock, 0, c->stream>>>(b.ra, n, out);
+    AH_LAUNCH_CHECK(c);
+  }
   return AH_OK;
 }
 

@@ -115,26 +115,28 @@ __global__ __launch_bounds__(256) void ms_guide_kernel(const unsigned long long*
 }
 
 // ---- 1: bucket ids ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ms_bucket_kernel(const unsigned long long* __restrict__ keys, int64_t n, MsMap m, MsPoints p,
+// 1024 threads: the 41 KB of tables are shared by 16 waves, two workgroups fill a CU (with 256 threads three of them did: 12 waves
+// on dependent LDS reads — 0.83 ms for 2^27 rows)
+__global__ __launch_bounds__(kThreads) void ms_bucket_kernel(const unsigned long long* __restrict__ keys, int64_t n, MsMap m, MsPoints p,
                                                          const unsigned long long* __restrict__ split, const unsigned* __restrict__ flags,
                                                          const unsigned short* __restrict__ guide, unsigned per, unsigned* __restrict__ bucket) {
   __shared__ unsigned long long s_s[kSplit + 1];
   __shared__ unsigned s_f[kFlagWords];
   __shared__ unsigned short s_g[4097];
-  for (int i = threadIdx.x; i <= kSplit; i += 256) { s_s[i] = split[i]; s_g[i] = guide[i]; }
-  for (int i = threadIdx.x; i < kFlagWords; i += 256) s_f[i] = flags[i];
+  for (int i = threadIdx.x; i <= kSplit; i += kThreads) { s_s[i] = split[i]; s_g[i] = guide[i]; }
+  for (int i = threadIdx.x; i < kFlagWords; i += kThreads) s_f[i] = flags[i];
   __syncthreads();
-  constexpr int U = 8;
-  const int64_t stride = (int64_t)gridDim.x * 256 * U;
-  for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < n; base += stride) {
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * kThreads * U;
+  for (int64_t base = (int64_t)blockIdx.x * kThreads * U + threadIdx.x; base < n; base += stride) {
     unsigned long long u[U];
     unsigned lo[U], hi[U];
 #pragma unroll
     for (int q = 0; q < U; q++) {
-      const int64_t i = base + q * 256;
+      const int64_t i = base + q * kThreads;
       u[q] = i < n ? (__builtin_nontemporal_load(&keys[i]) & m.mask) << m.lshift : s_s[0];
     }
-    // largest k with split[k] ≤ u, between the guide's two candidates; the eight searches of a lane side by side
+    // largest k with split[k] ≤ u, between the guide's two candidates; the four searches of a lane side by side
 #pragma unroll
     for (int q = 0; q < U; q++) { lo[q] = s_g[u[q] >> 52]; hi[q] = s_g[(u[q] >> 52) + 1]; }
     bool more = true;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void ms_bucket_kernel(const unsigned long long
     }
 #pragma unroll
     for (int q = 0; q < U; q++) {
-      const int64_t i = base + q * 256;
+      const int64_t i = base + q * kThreads;
       if (i >= n) continue;
       double f;   // position inside the interval in units of its probability mass, 0 ≤ f ≤ 1
       if ((s_f[lo[q] >> 5] >> (lo[q] & 31)) & 1u) {
@@ -173,8 +175,10 @@ __global__ __launch_bounds__(256) void ms_bucket_kernel(const unsigned long long
         }
         f = ((double)(a - a0) + ms_frac(u[q], pa, pb, m) * (double)(b - a)) / g;
       } else {
+        // (u − x) · 1/(y − x): the hardware reciprocal is a few ulp off, but a CONSTANT factor per interval keeps the map monotone,
+        // which is all the sort needs; the correctly rounded division was a third of this kernel's instructions
         const unsigned long long x = s_s[lo[q]], y = s_s[lo[q] + 1];
-        f = y > x ? (double)(u[q] - x) / (double)(y - x) : 0.0;
+        f = y > x ? (double)(u[q] - x) * __builtin_amdgcn_rcp((double)(y - x)) : 0.0;
       }
       f = f >= 0.0 ? f : 0.0;   // (also catches a NaN)
       unsigned in = (unsigned)(f * (double)per);
@@ -381,10 +385,24 @@ __global__ __launch_bounds__(kThreads) void ms_scatter_kernel(const unsigned lon
 // ---- 4: one wave sorts one bucket ----------------------------------------------------------------------------------------
 struct KR { unsigned long long k; unsigned r; };
 __device__ __forceinline__ bool kr_less(const KR& a, const KR& b) { return a.k < b.k || (a.k == b.k && a.r < b.r); }
-__device__ __forceinline__ KR kr_shfl_xor(const KR& a, int j) {
+// the value lane ^ j holds, without the LDS crossbar (ds_bpermute): DPP within rows of 16 lanes, the gfx950 permlane swaps
+// across rows and halves (scripts/micro/dpp_xor_test.hip checks all six forms against __shfl_xor)
+template <int CTRL>
+__device__ __forceinline__ unsigned ms_dpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ unsigned ms_xor_lane(unsigned v, int j, int lane) {   // j is a constant after unrolling
+  switch (j) {
+    case 1: return ms_dpp<0xB1>(v);                         // quad_perm [1,0,3,2]
+    case 2: return ms_dpp<0x4E>(v);                         // quad_perm [2,3,0,1]
+    case 4: { const unsigned a = ms_dpp<0x124>(v), b = ms_dpp<0x12C>(v); return (lane & 4) ? a : b; }   // row_ror:4 / row_ror:12
+    case 8: return ms_dpp<0x128>(v);                        // row_ror:8
+    case 16: { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
+    default: { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
+  }
+}
+__device__ __forceinline__ KR kr_xor(const KR& a, int j, int lane) {
   KR o;
-  o.k = __shfl_xor(a.k, j, 64);
-  o.r = __shfl_xor(a.r, j, 64);
+  o.k = ((unsigned long long)ms_xor_lane((unsigned)(a.k >> 32), j, lane) << 32) | ms_xor_lane((unsigned)a.k, j, lane);
+  o.r = ms_xor_lane(a.r, j, lane);
   return o;
 }
 // keep the smaller (keep_min) or the larger of (mine, other)
@@ -417,7 +435,7 @@ __device__ __forceinline__ void ms_bitonic(KR (&x)[SLOTS], int lane) {
 #pragma unroll
         for (int sl = 0; sl < SLOTS; sl++) {
           const bool asc = k < 64 ? (lane & k) == 0 : (sl & (k >> 6)) == 0;
-          x[sl] = kr_pick(x[sl], kr_shfl_xor(x[sl], j), low == asc);
+          x[sl] = kr_pick(x[sl], kr_xor(x[sl], j, lane), low == asc);
         }
       }
     }
@@ -425,7 +443,7 @@ __device__ __forceinline__ void ms_bitonic(KR (&x)[SLOTS], int lane) {
 }
 template <int SLOTS>
 __device__ __forceinline__ void ms_sort_bucket(const unsigned long long* __restrict__ keys, const unsigned* rows, unsigned s, int m,
-                                               int lane, unsigned* out_rows) {
+                                               int lane, unsigned* out_rows, unsigned long long* __restrict__ out64) {
   KR x[SLOTS];
 #pragma unroll
   for (int sl = 0; sl < SLOTS; sl++) {   // slots past the bucket hold the largest pair
@@ -435,12 +453,16 @@ __device__ __forceinline__ void ms_sort_bucket(const unsigned long long* __restr
   }
   ms_bitonic<SLOTS>(x, lane);
 #pragma unroll
-  for (int sl = 0; sl < SLOTS; sl++) { const int i = sl * 64 + lane; if (i < m) out_rows[s + i] = x[sl].r; }
+  for (int sl = 0; sl < SLOTS; sl++) {
+    const int i = sl * 64 + lane;
+    if (i < m) { if (out64) out64[s + i] = x[sl].r; else out_rows[s + i] = x[sl].r; }
+  }
 }
 
 __global__ __launch_bounds__(256) void ms_local_kernel(const unsigned long long* __restrict__ keys, const unsigned* rows,
                                                         const unsigned* __restrict__ bstart, int64_t nbuckets, unsigned* out_rows,
-                                                        unsigned* __restrict__ oversize, unsigned* __restrict__ big_list) {
+                                                        unsigned long long* __restrict__ out64, unsigned* __restrict__ oversize,
+                                                        unsigned* __restrict__ big_list) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= nbuckets) return;
@@ -454,18 +476,19 @@ __global__ __launch_bounds__(256) void ms_local_kernel(const unsigned long long*
     }
     return;
   }
-  if (m == 1) { if (lane == 0) out_rows[s] = rows[s]; return; }
-  if (m <= 64) ms_sort_bucket<1>(keys, rows, s, m, lane, out_rows);
-  else if (m <= 128) ms_sort_bucket<2>(keys, rows, s, m, lane, out_rows);
-  else if (m <= 256) ms_sort_bucket<4>(keys, rows, s, m, lane, out_rows);   // the tail of the size distribution: a few buckets in a million
-  else ms_sort_bucket<8>(keys, rows, s, m, lane, out_rows);
+  if (m == 1) { if (lane == 0) { if (out64) out64[s] = rows[s]; else out_rows[s] = rows[s]; } return; }
+  if (m <= 64) ms_sort_bucket<1>(keys, rows, s, m, lane, out_rows, out64);
+  else if (m <= 128) ms_sort_bucket<2>(keys, rows, s, m, lane, out_rows, out64);
+  else if (m <= 256) ms_sort_bucket<4>(keys, rows, s, m, lane, out_rows, out64);   // the tail of the size distribution: a few buckets in a million
+  else ms_sort_bucket<8>(keys, rows, s, m, lane, out_rows, out64);
 }
 
 // A bucket of 513 … 8192 rows (the rows beyond the sample's extremes, a run of equal keys): one workgroup, bitonic network in LDS.
 // A handful per call at most; the list holds 1024.
 __global__ __launch_bounds__(kThreads) void ms_big_kernel(const unsigned long long* __restrict__ keys, const unsigned* rows,
                                                            const unsigned* __restrict__ bstart, const unsigned* __restrict__ oversize,
-                                                           const unsigned* __restrict__ big_list, unsigned* out_rows) {
+                                                           const unsigned* __restrict__ big_list, unsigned* out_rows,
+                                                           unsigned long long* __restrict__ out64) {
   __shared__ unsigned long long s_k[kBigMax];
   __shared__ unsigned s_r[kBigMax];
   if (blockIdx.x >= oversize[1] || blockIdx.x >= (unsigned)kBigList) return;
@@ -488,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void ms_big_kernel(const unsigned long lo
       __syncthreads();
     }
   }
-  for (int i = threadIdx.x; i < m; i += kThreads) out_rows[s + i] = s_r[i];
+  for (int i = threadIdx.x; i < m; i += kThreads) { if (out64) out64[s + i] = s_r[i]; else out_rows[s + i] = s_r[i]; }
 }
 
 }  // namespace
@@ -516,10 +539,11 @@ size_t ah_sort_msd_temp_bytes(int64_t n) {
 }
 
 // keys / rows: the `rest` range (n pairs, row order).  alt_keys / alt_rows: same-sized scratch.  tmp: ah_sort_msd_temp_bytes(n) bytes.
-// On success (*used = 1) `rows` holds the rows in sorted order; keys / alt_* are clobbered either way.
+// On success (*used = 1) the rows are in sorted order in `rows` — or, if out64 is given, widened in out64[0 .. n) and NOT in
+// `rows`; keys / alt_* are clobbered either way.
 int ah_sort_rest_msd(ah_ctx* c, unsigned long long* keys, unsigned* rows, unsigned long long* alt_keys, unsigned* alt_rows, int64_t n,
                      unsigned long long varying, unsigned long long kmin, unsigned long long kmax, int float_bytes, int descending, void* tmp,
-                     int* used) {
+                     unsigned long long* out64, int* used) {
   *used = 0;
   if (!tmp || varying == 0 || ah_sort_msd_temp_bytes(n) == 0) return AH_OK;
   unsigned* out_rows = rows;   // the last step rewrites every bucket in place
@@ -568,7 +592,7 @@ int ah_sort_rest_msd(ah_ctx* c, unsigned long long* keys, unsigned* rows, unsign
   // 1: bucket ids
   ms_guide_kernel<<<17, 256, 0, c->stream>>>(split, guide);
   AH_LAUNCH_CHECK(c);
-  ms_bucket_kernel<<<ah_stream_grid(c, ah_ceil_div(n, 256 * 8), 8), 256, 0, c->stream>>>(keys, n, map, pts, split, flags, guide, nbuckets / kSplit, bucket);
+  ms_bucket_kernel<<<ah_stream_grid(c, ah_ceil_div(n, kThreads * 4), 2), kThreads, 0, c->stream>>>(keys, n, map, pts, split, flags, guide, nbuckets / kSplit, bucket);
   AH_LAUNCH_CHECK(c);
   // 2: level 1
   ms_hist_kernel<<<grid1, kThreads, 0, c->stream>>>(bucket, n, nullptr, 1, lb2, (unsigned)(nb1 - 1), nb1, cnt1);
@@ -591,9 +615,9 @@ int ah_sort_rest_msd(ah_ctx* c, unsigned long long* keys, unsigned* rows, unsign
                                                                       rows, nullptr);
   AH_LAUNCH_CHECK(c);
   // 4: buckets
-  ms_local_kernel<<<(unsigned)ah_ceil_div((int64_t)nbuckets, 4), 256, 0, c->stream>>>(keys, rows, bstart, (int64_t)nbuckets, out_rows, oversize, big_list);
+  ms_local_kernel<<<(unsigned)ah_ceil_div((int64_t)nbuckets, 4), 256, 0, c->stream>>>(keys, rows, bstart, (int64_t)nbuckets, out_rows, out64, oversize, big_list);
   AH_LAUNCH_CHECK(c);
-  ms_big_kernel<<<kBigList, kThreads, 0, c->stream>>>(keys, rows, bstart, oversize, big_list, out_rows);
+  ms_big_kernel<<<kBigList, kThreads, 0, c->stream>>>(keys, rows, bstart, oversize, big_list, out_rows, out64);
   AH_LAUNCH_CHECK(c);
   AH_HIP(c, hipMemcpyAsync(&c->pinned[12], oversize, 8, hipMemcpyDeviceToHost, c->stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
