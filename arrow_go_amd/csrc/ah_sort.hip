@@ -438,13 +438,13 @@ int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t*
     // + one wave per bucket comparing (key, row) — ah_sort_msd.hip.  Equal keys end up in row order = input order.
     bool done = false;
     if (rows_in == nullptr && nvar >= 4 && c->opt_sort_msd) {
-      int used = 0;
+      int used = -1;
       if ((rc = ah_sort_rest_msd(c, kcur, rcur, kalt, ralt, rest_n, varying, kmin, kmax, std::is_floating_point<T>::value ? (int)sizeof(T) : 0, descending, b.msd_tmp,
                                  (unsigned long long*)(rest_n == n ? b.final_out : nullptr), &used)) != AH_OK) return rc;
-      if (used) {
+      if (used > 0) {
         done = true;   // sorted rows are in rcur (each bucket is rewritten in place) — or already widened in the output
         b.emitted = rest_n == n && b.final_out != nullptr;
-      } else if (b.msd_tmp && ah_sort_msd_temp_bytes(rest_n) != 0) {
+      } else if (used == 0 && b.msd_tmp && ah_sort_msd_temp_bytes(rest_n) != 0) {
         // it ran and gave up (a bucket too large): the pairs are gone — pass (1) again, then the LSD passes
         if ((rc = radix_pass(c, col, n, b.hist, b.offs, b.ka, b.ra)) != AH_OK) return rc;
       }

@@ -102,6 +102,14 @@ __global__ __launch_bounds__(256) void ms_split_kernel(MsPoints p, unsigned long
   if (flag) atomicOr(&flags[k >> 5], 1u << (k & 31));
 }
 
+// A key repeated so often that its bucket would outgrow a workgroup's LDS shows in the sorted sample as a run of equal values:
+// `run` consecutive sample points ≈ run · n / S rows.  Found before the expensive passes, so that a low-cardinality column costs
+// the attempt 0.3 ms instead of 3.
+__global__ __launch_bounds__(256) void ms_dupes_kernel(const unsigned long long* __restrict__ sorted, int64_t count, int64_t run, unsigned* __restrict__ found) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i + run < count && sorted[i] == sorted[i + run]) *found = 1u;
+}
+
 // guide[c] = largest k with split[k] ≤ c · 2^52 (0 if none): a key whose top 12 bits are c has its interval in
 // [guide[c], guide[c + 1]] — one or two candidates for evenly spread keys instead of twelve halving steps
 __global__ __launch_bounds__(256) void ms_guide_kernel(const unsigned long long* __restrict__ split, unsigned short* __restrict__ guide) {
@@ -539,12 +547,12 @@ size_t ah_sort_msd_temp_bytes(int64_t n) {
 }
 
 // keys / rows: the `rest` range (n pairs, row order).  alt_keys / alt_rows: same-sized scratch.  tmp: ah_sort_msd_temp_bytes(n) bytes.
-// On success (*used = 1) the rows are in sorted order in `rows` — or, if out64 is given, widened in out64[0 .. n) and NOT in
-// `rows`; keys / alt_* are clobbered either way.
+// *used = 1: the rows are in sorted order in `rows` — or, if out64 is given, widened in out64[0 .. n) and NOT in `rows`.
+// *used = 0: gave up half-way, keys / rows / alt_* are clobbered.  *used = −1: not attempted, nothing touched.
 int ah_sort_rest_msd(ah_ctx* c, unsigned long long* keys, unsigned* rows, unsigned long long* alt_keys, unsigned* alt_rows, int64_t n,
                      unsigned long long varying, unsigned long long kmin, unsigned long long kmax, int float_bytes, int descending, void* tmp,
                      unsigned long long* out64, int* used) {
-  *used = 0;
+  *used = -1;
   if (!tmp || varying == 0 || ah_sort_msd_temp_bytes(n) == 0) return AH_OK;
   unsigned* out_rows = rows;   // the last step rewrites every bucket in place
   auto pad = ms_pad;
@@ -585,6 +593,20 @@ int ah_sort_rest_msd(ah_ctx* c, unsigned long long* keys, unsigned* rows, unsign
   AH_LAUNCH_CHECK(c);
   unsigned long long* sorted = nullptr;
   if ((rc = ah_sort_pairs_lsd(c, sample, sample_rows, sample_alt, sample_rows_alt, sample_n, (unsigned*)cnt2, (unsigned*)toffs2, &sorted)) != AH_OK) return rc;
+  {
+    // equal keys filling more than half of what a workgroup can sort (kBigMax rows): give up now
+    const int64_t run = (int64_t)(kBigMax / 2) * sample_n / n;
+    ms_dupes_kernel<<<(unsigned)ah_ceil_div(sample_n, 256), 256, 0, c->stream>>>(sorted, sample_n, run < 1 ? 1 : run, oversize);
+    AH_LAUNCH_CHECK(c);
+    AH_HIP(c, hipMemcpyAsync(&c->pinned[12], oversize, 8, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (((volatile unsigned*)&c->pinned[12])[0] != 0) {
+      if (getenv("ARROWHIP_DEBUG_MSD")) fprintf(stderr, "msd: n=%lld: the sample shows a key with more than %d rows, not attempted\n", (long long)n, kBigMax / 2);
+      *used = -1;   // nothing was clobbered yet
+      return AH_OK;
+    }
+  }
+  *used = 0;   // from here on the pairs are being moved
   MsPoints pts{sorted, sample_n, (kmin & map.mask) << map.lshift, (kmax & map.mask) << map.lshift};
   AH_HIP(c, hipMemsetAsync(flags, 0, kFlagWords * 4, c->stream));
   ms_split_kernel<<<(kSplit + 256) / 256, 256, 0, c->stream>>>(pts, split, flags);

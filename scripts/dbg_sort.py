@@ -10,6 +10,9 @@ for name, lg, gen in [("int uniform", 22, lambda n: rng.integers(-2**62, 2**62, 
                       ("normal", 24, lambda n: rng.standard_normal(n)), ("lognormal", 24, lambda n: np.exp(rng.standard_normal(n) * 8)),
                       ("uniform(-1,1)", 24, lambda n: rng.uniform(-1, 1, n)), ("cauchy", 24, lambda n: rng.standard_cauchy(n)),
                       ("int uniform", 26, lambda n: rng.integers(-2**62, 2**62, n, dtype=np.int64)), ("normal", 26, lambda n: rng.standard_normal(n)),
+                      ("3000 distinct", 24, lambda n: rng.integers(0, 2**50, 3000, dtype=np.int64)[rng.integers(0, 3000, n)]),
+                      ("hot key 20%", 24, lambda n: np.where(rng.random(n) < 0.2, np.int64(123456789012345), rng.integers(-2**62, 2**62, n, dtype=np.int64))),
+                      ("each key 4x", 24, lambda n: np.repeat(rng.integers(-2**62, 2**62, n // 4, dtype=np.int64), 4)[rng.permutation(n)]),
                       ("exp", 24, lambda n: rng.exponential(1.0, n)), ("clustered", 24, lambda n: 10**15 + rng.integers(0, 10**11, n)),
                       ("two clusters", 24, lambda n: np.where(rng.random(n) < 0.3, rng.integers(0, 10**6, n), 2**60 + rng.integers(0, 2**40, n)))]:
     n = 1 << lg
