@@ -40,6 +40,7 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_hash_direct = env_int("ARROWHIP_HASH_DIRECT", 2);
   c->opt_sort_msd = env_int("ARROWHIP_SORT_MSD", 1);
   c->opt_scan_segment_log2 = env_int("ARROWHIP_SCAN_SEGMENT_LOG2", 0);   // 0 = one segment: segments measured slower
+  c->opt_take_gather_lds = env_int("ARROWHIP_TAKE_GATHER_LDS", 1);   // 1: the window's validity bits in LDS (ah_take_binned.hip)
   c->opt_take_gather_load = env_int("ARROWHIP_TAKE_GATHER_LOAD", 0);   // 0 plain, 1 nontemporal, 2 L1-bypassing (sc1)
   return AH_OK;
 }
@@ -101,6 +102,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "take_binned")) c->opt_take_binned = (int)value;
   else if (!strcmp(name, "take_window_log2")) c->opt_take_window_log2 = (int)value;
   else if (!strcmp(name, "take_gather_wg_per_cu")) c->opt_take_gather_wg = (int)value;
+  else if (!strcmp(name, "take_gather_lds")) c->opt_take_gather_lds = (int)value;
   else if (!strcmp(name, "take_gather_load")) c->opt_take_gather_load = (int)value;
   else if (!strcmp(name, "groupby_partition")) c->opt_groupby_partition = (int)value;
   else if (!strcmp(name, "hash_direct")) c->opt_hash_direct = (int)value;
