@@ -247,6 +247,19 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     timed("shift_time_mul1000_int64_checked", 16 * rows, lambda: ctx.shift_time(64, 64, 0, 1000, True, t_us, None, 0, rows, c))
     timed("shift_time_mul1000_int64_checked_nulls10", 16.125 * rows, lambda: ctx.shift_time(64, 64, 0, 1000, True, t_us, vvalid, 0, rows, c))
     del t_us
+    # sort_indices (row (f)-2): stable argsort of the 2^27-row columns; 16 B/row algorithmic (8 read + the uint64 index written).
+    # Keys are independent draws (the tiled columns above repeat every key 32 times): full-range Int64, then Float64 from a normal
+    # distribution — the MSD path — and the Int64 column again through the LSD passes alone.
+    step = min(rows, 1 << 22)
+    for off in range(0, rows, step):
+        b.upload(rng.integers(-2**63, 2**63 - 1, step, dtype=np.int64), off * 8)
+    timed("sort_indices_int64_random", 16 * rows, lambda: ctx.sort_indices(N.INT64, b, None, 0, rows, False, False, c), reps=3)
+    ctx.set_option("sort_msd", 0)
+    timed("sort_indices_int64_random_lsd_passes_only", 16 * rows, lambda: ctx.sort_indices(N.INT64, b, None, 0, rows, False, False, c), reps=2)
+    ctx.set_option("sort_msd", 1)
+    for off in range(0, rows, step):
+        b.upload(rng.standard_normal(step), off * 8)
+    timed("sort_indices_float64_normal", 16 * rows, lambda: ctx.sort_indices(N.FLOAT64, b, None, 0, rows, False, False, c), reps=3)
     timed("min_max_int64", 8 * rows, lambda: ctx.min_max(N.INT64, a, rows, np.int64))
     timed("bitmap_and", 0.375 * rows, lambda: ctx.bitmap_op(N.BIT_AND, mask, 0, vvalid, 0, ovalid, 0, rows))
     timed("count_set_bits", 0.125 * rows, lambda: ctx.count_set_bits(mask, 0, rows))
