@@ -34,6 +34,7 @@
 #include "ah_common.h"
 #include "ah_hashing.h"
 #include "ah_bins.h"
+#include "ah_msd.h"
 
 namespace {
 
@@ -45,6 +46,7 @@ constexpr int kSoftLimit = 3584;                     // keys admitted to the LDS
 constexpr int kLSlots = kSlots + 2;                  // + the all-ones key (kSlots) and the null key (kSlots + 1)
 constexpr int kGSlots = 8192;                        // global table of ONE partition
 constexpr int kGStride = kGSlots + 8;                // + the same two special slots at kGSlots, kGSlots + 1
+constexpr int kFlatStride = kSlots + 8;              // flat mode (two-level cut): the LDS table as it is + the two special slots at kSlots
 constexpr int kChunkLog2 = 18;                       // records per aggregate workgroup
 constexpr unsigned kKeyNull = 0x80000000u, kValNull = 0x40000000u, kRowMask = 0x1fffffffu;
 constexpr unsigned kCntMask = 0x1fffffffu;           // count word: bits 29..31 = NaN / +inf / −inf seen
@@ -273,7 +275,9 @@ __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsi
 template <bool FX>
 __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                                  const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
-                                                                 const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow) {
+                                                                 const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat) {
+  // flat: one workgroup per partition (blockIdx = partition; thousands of partitions from the two-level cut), tables of
+  // kSlots + 8 entries side by side, no merging: a partition that outgrows its LDS table voids the attempt
   __shared__ __attribute__((aligned(16))) unsigned long long l_key[kLSlots];
   __shared__ unsigned long long l_lo[kLSlots];
   __shared__ unsigned long long l_hi[FX ? kLSlots : 1];
@@ -283,20 +287,27 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   __shared__ unsigned s_used, s_direct;
   __shared__ int s_part, s_chunk, s_multi;
   const int t = threadIdx.x;
-  // which records?  workgroup → (partition, chunk): prefix sum over the partitions' chunk counts
-  unsigned rows = 0, ch = 0;
-  if (t < nb) { rows = binstart[t + 1] - binstart[t]; ch = gb_chunks(rows); }
-  s_cnt[t] = ch;
-  if (t == 0) s_part = -1;
-  __syncthreads();
-  block_excl_scan(s_cnt, s_start, s_wsum, nb);
-  if (t < nb && ch && s_start[t] <= blockIdx.x && blockIdx.x < s_start[t] + ch) { s_part = t; s_chunk = (int)(blockIdx.x - s_start[t]); s_multi = ch > 1; }
-  __syncthreads();
-  if (s_part < 0) return;
-  const int part = s_part;
-  const bool multi = s_multi != 0;
+  int part;
+  bool multi;
   int64_t r0, r1;
-  {
+  if (flat) {
+    part = (int)blockIdx.x;
+    multi = false;
+    r0 = binstart[part];
+    r1 = binstart[part + 1];
+  } else {
+    // which records?  workgroup → (partition, chunk): prefix sum over the partitions' chunk counts
+    unsigned rows = 0, ch = 0;
+    if (t < nb) { rows = binstart[t + 1] - binstart[t]; ch = gb_chunks(rows); }
+    s_cnt[t] = ch;
+    if (t == 0) s_part = -1;
+    __syncthreads();
+    block_excl_scan(s_cnt, s_start, s_wsum, nb);
+    if (t < nb && ch && s_start[t] <= blockIdx.x && blockIdx.x < s_start[t] + ch) { s_part = t; s_chunk = (int)(blockIdx.x - s_start[t]); s_multi = ch > 1; }
+    __syncthreads();
+    if (s_part < 0) return;
+    part = s_part;
+    multi = s_multi != 0;
     const int64_t b0 = binstart[part], b1 = binstart[part + 1];
     const int64_t nch = gb_chunks((unsigned)(b1 - b0)), per = (b1 - b0 + nch - 1) / nch;   // equal shares
     r0 = b0 + (int64_t)s_chunk * per;
@@ -307,7 +318,8 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   __syncthreads();
   int sh = 0;
   if (FX) sh = fx_shift(*absmax);
-  const int64_t gbase = (int64_t)part * kGStride;
+  const int64_t gbase = (int64_t)part * (flat ? kFlatStride : kGStride);
+  const int gspecial = flat ? kSlots : kGSlots;   // where the two special slots sit in the partition's global table
   bool went_direct = false;
   // one pending group per lane: {key, 128-bit sum, count | flags, first row}.  A row with the key of the lane's previous row
   // is added in registers: a key that owns most of a chunk (skewed columns) would otherwise put every lane of every wave
@@ -351,6 +363,8 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       atomicAdd(&l_cnt[j], cf & kCntMask);
       if (__builtin_expect(cf & ~kCntMask, 0)) atomicOr(&l_cnt[j], cf & ~kCntMask);
       atomicMin(&l_first[j], row);
+    } else if (flat) {
+      atomicExch(overflow, 1u);   // no global table behind a flat partition
     } else {
       went_direct = true;
       const long long gs = gb_global_slot(gt.key, gbase, key, overflow);
@@ -426,8 +440,10 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     }
     if (t < 2) {
       const int j = kSlots + t;
-      const int64_t g = gbase + kGSlots + t;
+      const int64_t g = gbase + gspecial + t;
       gt.key[g] = l_key[j]; gt.lo[g] = l_lo[j]; if (FX) gt.hi[g] = l_hi[j]; gt.cnt[g] = l_cnt[j]; gt.first[g] = l_first[j];
+    } else if (flat && t < kFlatStride - kSlots) {
+      gt.first[gbase + kSlots + t] = kNoRow;   // the stride's padding: nothing was memset in flat mode
     }
   } else {
     for (int j = t; j < kLSlots; j += kThreads) {
@@ -455,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void gb_emit_kernel(GbTable gt, int64_t nsl
                                                           const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff,
                                                           const unsigned long long* __restrict__ absmax, unsigned long long* __restrict__ out_keys,
                                                           unsigned long long* __restrict__ out_sums, long long* __restrict__ out_counts,
-                                                          long long* __restrict__ out_first_rows, int* __restrict__ null_id) {
+                                                          long long* __restrict__ out_first_rows, int* __restrict__ null_id, int gstride, int gspecial) {
   int sh = 0;
   if (FX) sh = fx_shift(*absmax);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -463,10 +479,10 @@ __global__ __launch_bounds__(kBlock) void gb_emit_kernel(GbTable gt, int64_t nsl
     const unsigned fr = gt.first[s];
     if (fr == kNoRow) continue;
     const unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
-    const int in_part = (int)(s % kGStride);
+    const int in_part = (int)(s % gstride);
     unsigned long long key = gt.key[s];
-    if (in_part == kGSlots) key = kEmpty;
-    if (in_part == kGSlots + 1) { key = 0; *null_id = (int)id; }   // the null group's key slot keeps the fresh buffer's zero
+    if (in_part == gspecial) key = kEmpty;
+    if (in_part == gspecial + 1) { key = 0; *null_id = (int)id; }   // the null group's key slot keeps the fresh buffer's zero
     out_keys[id] = key;
     const unsigned cf = gt.cnt[s];
     out_counts[id] = (long long)(cf & kCntMask);
@@ -480,6 +496,272 @@ __global__ __launch_bounds__(kBlock) void gb_emit_kernel(GbTable gt, int64_t nsl
       out_sums[id] = gt.lo[s];
     }
     if (out_first_rows) out_first_rows[id] = (long long)fr;
+  }
+}
+
+// ---- very many groups (beyond 1024 partitions of LDS-table size): sort instead of hash ---------------------------------------
+// With millions of groups a partition small enough for an LDS table holds only a few thousand rows — initialising and writing
+// out the table would cost more than the rows.  The rows are cut into buckets of ≈ 64 by the top bits of gb_mix(key) instead (the
+// two partition levels of ah_msd.h: equal keys share a bucket), and one wave per bucket SORTS its rows by (key, row) in
+// registers and walks the runs of equal keys: sum, count, first row = the run's first element.  No table, no probing, no
+// atomics on the sums; all rows of a key meet in one bucket, so the group records are final when the wave is done — only
+// their order (ids = rank of the first row) is global, and that is the bitmap + prefix popcount of the other paths.
+constexpr int kGsLocalMax = 256;   // rows one wave takes; a larger bucket (a key with hundreds of rows among millions of groups) voids the attempt
+__device__ __forceinline__ unsigned gs_bucket(unsigned long long key, bool knull, int lb) { return knull ? 0u : (unsigned)(gb_mix(key) >> (64 - lb)); }
+
+struct GsColumns {   // level 1 reads the columns
+  const unsigned long long* keys; const uint8_t* kvalid; int64_t koff;
+  const unsigned long long* vals; const uint8_t* vvalid; int64_t voff;
+  __device__ __forceinline__ void load(int64_t i, unsigned long long* k, unsigned long long* v, unsigned* rw) const {
+    const bool kv = ah_bit(kvalid, koff + i), vv = ah_bit(vvalid, voff + i);
+    *k = kv ? __builtin_nontemporal_load(&keys[i]) : 0ull;     // a null key travels as 0 + the flag
+    *v = __builtin_nontemporal_load(&vals[i]);
+    *rw = (unsigned)i | (kv ? 0u : kKeyNull) | (vv ? 0u : kValNull);
+  }
+};
+struct GsRecords {   // level 2 reads level 1's output
+  const unsigned long long* keys; const unsigned long long* vals; const unsigned* rows;
+  __device__ __forceinline__ void load(int64_t i, unsigned long long* k, unsigned long long* v, unsigned* rw) const {
+    *k = __builtin_nontemporal_load(&keys[i]);
+    *v = __builtin_nontemporal_load(&vals[i]);
+    *rw = __builtin_nontemporal_load(&rows[i]);
+  }
+};
+
+template <typename SRC>
+__global__ __launch_bounds__(kThreads) void gs_hist_kernel(SRC src, int64_t n, const unsigned* __restrict__ pstart, int nparents, int lb, int shift,
+                                                            unsigned mask, int nb, unsigned* __restrict__ cnt) {
+  __shared__ unsigned s_h[kMaxNb2];
+  __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_wsum[kThreads / 64];
+  __shared__ int s_pick;
+  const TileRange r = ms_tile(pstart, nparents, n, s_cnt, s_start, s_wsum, &s_pick);
+  if (r.parent < 0) return;
+  for (int b = threadIdx.x; b < nb; b += kThreads) s_h[b] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    const int64_t i = r.lo + u * kThreads + threadIdx.x;
+    if (i < r.hi) {
+      unsigned long long k, v; unsigned rw;
+      src.load(i, &k, &v, &rw);
+      atomicAdd(&s_h[(gs_bucket(k, rw & kKeyNull, lb) >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += kThreads) cnt[r.id * nb + b] = s_h[b];
+}
+
+template <typename SRC>
+__global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n, const unsigned* __restrict__ pstart, int nparents, int lb, int shift,
+                                                               unsigned mask, int nb, const unsigned* __restrict__ toffs,
+                                                               unsigned long long* __restrict__ out_keys, unsigned long long* __restrict__ out_vals,
+                                                               unsigned* __restrict__ out_rows, unsigned long long* __restrict__ tile_max) {
+  __shared__ unsigned s_cnt[kMaxNb2], s_start[kMaxNb2], s_goff[kMaxNb2], s_wsum[kThreads / 64];
+  __shared__ unsigned s_a[kThreads], s_b[kThreads];
+  __shared__ unsigned long long s_stage[kMsTile];
+  __shared__ uint16_t s_bin[kMsTile];
+  __shared__ unsigned long long s_max[kThreads / 64];
+  __shared__ int s_pick;
+  __shared__ unsigned s_carry;
+  const TileRange r = ms_tile(pstart, nparents, n, s_a, s_b, s_wsum, &s_pick);
+  if (r.parent < 0) return;
+  const int t = threadIdx.x;
+  for (int b = t; b < nb; b += kThreads) s_cnt[b] = 0;
+  unsigned long long k[kMsRows], v[kMsRows], vmax = 0;
+  unsigned rw[kMsRows], dg[kMsRows], rank[kMsRows];
+  bool live[kMsRows];
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    const int64_t i = r.lo + u * kThreads + t;
+    live[u] = i < r.hi;
+    k[u] = 0; v[u] = 0; rw[u] = 0;
+    if (live[u]) src.load(i, &k[u], &v[u], &rw[u]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    dg[u] = (gs_bucket(k[u], rw[u] & kKeyNull, lb) >> shift) & mask;
+    rank[u] = live[u] ? atomicAdd(&s_cnt[dg[u]], 1u) : 0u;
+    const unsigned long long a = v[u] & 0x7fffffffffffffffull;
+    if (tile_max && live[u] && !(rw[u] & kValNull) && (a >> 52) != 0x7ff && a > vmax) vmax = a;
+  }
+  if (tile_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_down(vmax, o, 64); vmax = x > vmax ? x : vmax; }
+    if ((t & 63) == 0) s_max[t >> 6] = vmax;
+  }
+  __syncthreads();
+  unsigned carry = 0;
+  for (int h = 0; h * kThreads < nb; h++) {   // exclusive scan over nb ≤ 2048 digit counts, 1024 at a time
+    s_a[t] = t + h * kThreads < nb ? s_cnt[t + h * kThreads] : 0u;
+    __syncthreads();
+    block_excl_scan(s_a, s_b, s_wsum, kThreads);
+    if (t + h * kThreads < nb) {
+      const unsigned st = carry + s_b[t];
+      s_start[t + h * kThreads] = st;
+      s_goff[t + h * kThreads] = toffs[r.id * nb + t + h * kThreads] - st;
+    }
+    if (t == kThreads - 1) s_carry = s_b[t] + s_a[t];
+    __syncthreads();
+    carry += s_carry;
+    __syncthreads();
+  }
+  if (tile_max && t == 0) {
+    unsigned long long x = s_max[0];
+    for (int w = 1; w < kThreads / 64; w++) x = s_max[w] > x ? s_max[w] : x;
+    tile_max[r.id] = x;
+  }
+  const int tile_n = (int)(r.hi - r.lo);
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (live[u]) { const unsigned q = s_start[dg[u]] + rank[u]; s_stage[q] = k[u]; s_bin[q] = (uint16_t)dg[u]; }
+  __syncthreads();
+  int64_t dst[kMsRows];
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    const int q = u * kThreads + t;
+    dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
+    if (dst[u] >= 0) out_keys[dst[u]] = s_stage[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (live[u]) s_stage[s_start[dg[u]] + rank[u]] = v[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (dst[u] >= 0) out_vals[dst[u]] = s_stage[u * kThreads + t];
+  __syncthreads();
+  unsigned* s_stage32 = reinterpret_cast<unsigned*>(s_stage);
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (live[u]) s_stage32[s_start[dg[u]] + rank[u]] = rw[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (dst[u] >= 0) out_rows[dst[u]] = s_stage32[u * kThreads + t];
+}
+
+// sort element: (key, null-key flag | row) decides; li = position in the bucket before the sort (| null-value flag) finds the value
+struct GsEl {
+  unsigned long long k;
+  unsigned r, li;
+  static __device__ __forceinline__ bool less(const GsEl& a, const GsEl& b) { return a.k < b.k || (a.k == b.k && a.r < b.r); }
+  static __device__ __forceinline__ GsEl xchg(const GsEl& a, int j, int lane) {
+    GsEl o;
+    o.k = ((unsigned long long)ms_xor_lane((unsigned)(a.k >> 32), j, lane) << 32) | ms_xor_lane((unsigned)a.k, j, lane);
+    o.r = ms_xor_lane(a.r, j, lane);
+    o.li = ms_xor_lane(a.li, j, lane);
+    return o;
+  }
+};
+
+template <bool FX, int SLOTS>
+__device__ __forceinline__ void gs_bucket_groups(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
+                                                 const unsigned* __restrict__ rows, unsigned s, int m, int lane, int sh, unsigned long long* s_val,
+                                                 unsigned long long* s_k, unsigned* s_r, unsigned* s_li, unsigned long long* __restrict__ g_key,
+                                                 unsigned long long* __restrict__ g_sum, unsigned* __restrict__ g_cnt, unsigned* __restrict__ g_first,
+                                                 unsigned long long* __restrict__ firsts) {
+  GsEl x[SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; sl++) {
+    const int i = sl * 64 + lane;
+    x[sl].k = ~0ull; x[sl].r = ~0u; x[sl].li = 0;   // slots past the bucket hold the largest element
+    if (i < m) {
+      const unsigned rw = rows[s + i];
+      x[sl].k = keys[s + i];
+      x[sl].r = (rw & kKeyNull) | (rw & kRowMask);
+      x[sl].li = (unsigned)i | ((rw & kValNull) ? 0x80000000u : 0u);
+      s_val[i] = vals[s + i];
+    }
+  }
+  ms_bitonic<GsEl, SLOTS>(x, lane);
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; sl++) { const int i = sl * 64 + lane; s_k[i] = x[sl].k; s_r[i] = x[sl].r; s_li[i] = x[sl].li; }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the wave's own LDS writes before its reads of other lanes' slots
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < m; i += 64) {
+    const unsigned long long k = s_k[i];
+    const unsigned ri = s_r[i], nullbit = ri & kKeyNull;
+    if (i > 0 && s_k[i - 1] == k && (s_r[i - 1] & kKeyNull) == nullbit) continue;   // not the first row of its key
+    unsigned long long lo = 0, hi = 0;
+    unsigned cnt = 0, flags = 0;
+    for (int j = i; j < m && s_k[j] == k && (s_r[j] & kKeyNull) == nullbit; j++) {
+      const unsigned li = s_li[j];
+      if (li & 0x80000000u) continue;   // null value: neither summed nor counted
+      const unsigned long long vb = s_val[li & 0x7fffffffu];
+      cnt++;
+      if (FX) {
+        const double d = __builtin_bit_cast(double, vb);
+        if (fx_finite(d)) {
+          unsigned long long l, h;
+          fx_split(d, sh, &l, &h);
+          const unsigned long long nl = lo + l;
+          hi += h + (nl < lo ? 1ull : 0ull);
+          lo = nl;
+        } else flags |= fx_flag(d);
+      } else lo += vb;
+    }
+    unsigned long long sum = lo;
+    if (FX) {
+      double rr;
+      if (flags) rr = (flags & 1u) || (flags & 6u) == 6u ? __builtin_nan("") : ((flags & 2u) ? __builtin_inf() : -__builtin_inf());
+      else rr = fx_to_double(lo, hi, sh);
+      sum = __builtin_bit_cast(unsigned long long, rr);
+    }
+    const unsigned first = ri & kRowMask;
+    const int64_t pos = (int64_t)s + i;
+    g_key[pos] = nullbit ? 0ull : k;
+    g_sum[pos] = sum;
+    g_cnt[pos] = cnt | nullbit;
+    g_first[pos] = first;
+    atomicOr(&firsts[first >> 6], 1ull << (first & 63));
+  }
+}
+
+template <bool FX>
+__global__ __launch_bounds__(256) void gs_local_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
+                                                        const unsigned* __restrict__ rows, const unsigned* __restrict__ bstart, int64_t nbuckets,
+                                                        const unsigned long long* __restrict__ absmax, unsigned long long* __restrict__ g_key,
+                                                        unsigned long long* __restrict__ g_sum, unsigned* __restrict__ g_cnt,
+                                                        unsigned* __restrict__ g_first, unsigned long long* __restrict__ firsts,
+                                                        unsigned* __restrict__ oversize) {
+  __shared__ unsigned long long s_val[4][kGsLocalMax], s_k[4][kGsLocalMax];
+  __shared__ unsigned s_r[4][kGsLocalMax], s_li[4][kGsLocalMax];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  if (b >= nbuckets) return;
+  const unsigned s = bstart[b], e = bstart[b + 1];
+  const int m = (int)(e - s);
+  if (m <= 0) return;
+  if (m > kGsLocalMax) { if (lane == 0) atomicMax(oversize, (unsigned)m); return; }
+  int sh = 0;
+  if (FX) sh = fx_shift(*absmax);
+#define AH_GS(SL) gs_bucket_groups<FX, SL>(keys, vals, rows, s, m, lane, sh, s_val[w], s_k[w], s_r[w], s_li[w], g_key, g_sum, g_cnt, g_first, firsts)
+  if (m <= 64) AH_GS(1);
+  else if (m <= 128) AH_GS(2);
+  else AH_GS(4);
+#undef AH_GS
+}
+
+template <bool FX>
+__global__ __launch_bounds__(kBlock) void gs_emit_kernel(const unsigned long long* __restrict__ g_key, const unsigned long long* __restrict__ g_sum,
+                                                          const unsigned* __restrict__ g_cnt, const unsigned* __restrict__ g_first, int64_t n,
+                                                          const unsigned long long* __restrict__ firsts, const unsigned* __restrict__ wordprefix,
+                                                          const int64_t* __restrict__ tileoff, unsigned long long* __restrict__ out_keys,
+                                                          unsigned long long* __restrict__ out_sums, long long* __restrict__ out_counts,
+                                                          long long* __restrict__ out_first_rows, int* __restrict__ null_id) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += stride) {
+    const unsigned fr = __builtin_nontemporal_load(&g_first[p]);
+    if (fr == kNoRow) continue;
+    const unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
+    const unsigned c = g_cnt[p];
+    out_keys[id] = g_key[p];
+    out_sums[id] = g_sum[p];
+    out_counts[id] = (long long)(c & 0x7fffffffu);
+    if (out_first_rows) out_first_rows[id] = (long long)fr;
+    if (c & kKeyNull) *null_id = (int)id;
   }
 }
 
@@ -500,6 +782,209 @@ static double gb_extrapolate(double d, double p, double n) {
 
 }  // namespace
 
+// the sort-based path (gs_* kernels).  *used = 1: out_* hold the result.
+static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
+                      int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
+                      int32_t* out_null_group, int* used) {
+  *used = 0;
+  if (n < ((int64_t)1 << 22) || n > ((int64_t)1 << 27)) return AH_OK;   // 2^27 rows = 2^21 buckets of 64 = 1024 parents × 2048
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  int lb = 0;
+  while (((int64_t)64 << lb) < n) lb++;
+  const int lb2 = lb >= 20 ? lb - 10 : lb - lb / 2;
+  const int nb2 = 1 << lb2, nb1 = 1 << (lb - lb2);
+  const int64_t nbuckets = (int64_t)1 << lb;
+  const int64_t ntiles = ah_ceil_div(n, kMsTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
+  const unsigned grid1 = (unsigned)(((ntiles + 7) / 8) * 8);
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const size_t need = pad((size_t)n * 8) * 4 + pad((size_t)n * 4) * 3 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
+                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)nbuckets + 1) * 4) + pad((size_t)ntiles * 8) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
+                      pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
+  uint8_t* base;
+  int rc = ah_temp_reserve(c, need, (void**)&base);
+  if (rc != AH_OK) return rc;
+  size_t off = 0;
+  auto take = [&](size_t b) { uint8_t* q = base + off; off += pad(b); return q; };
+  unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* qkeys = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* qvals = (unsigned long long*)take((size_t)n * 8);
+  unsigned* prows = (unsigned*)take((size_t)n * 4);
+  unsigned* qrows = (unsigned*)take((size_t)n * 4);
+  unsigned* g_cnt = (unsigned*)take((size_t)n * 4);
+  unsigned* cnt1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
+  unsigned* toffs1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
+  unsigned* gsum = (unsigned*)take((size_t)ngrp * nb1 * 4);
+  unsigned* pstart = (unsigned*)take((size_t)(nb1 + 1) * 4);
+  unsigned* cnt2 = (unsigned*)take((size_t)nvt * nb2 * 4);
+  unsigned* toffs2 = (unsigned*)take((size_t)nvt * nb2 * 4);
+  unsigned* bstart = (unsigned*)take(((size_t)nbuckets + 1) * 4);
+  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 8);
+  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
+  int* tilecnt = (int*)take((size_t)nrt * 4);
+  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned* oversize = (unsigned*)&c->dscalars[21];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[22];
+  int* null_id = (int*)&c->dscalars[23];
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
+  // level 1
+  gs_hist_kernel<GsColumns><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lb, lb2, (unsigned)(nb1 - 1), nb1, cnt1);
+  AH_LAUNCH_CHECK(c);
+  colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt1, nb1, ntiles, gsum);
+  AH_LAUNCH_CHECK(c);
+  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, nb1, ngrp, n, pstart);
+  AH_LAUNCH_CHECK(c);
+  tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt1, gsum, nb1, ntiles, toffs1);
+  AH_LAUNCH_CHECK(c);
+  gs_scatter_kernel<GsColumns><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lb, lb2, (unsigned)(nb1 - 1), nb1, toffs1, pkeys, pvals, prows,
+                                                                  is_f64 ? tile_max : nullptr);
+  AH_LAUNCH_CHECK(c);
+  if (is_f64) {
+    gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+  }
+  // level 2, parent by parent
+  GsRecords rec{pkeys, pvals, prows};
+  gs_hist_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lb, 0, (unsigned)(nb2 - 1), nb2, cnt2);
+  AH_LAUNCH_CHECK(c);
+  ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
+  AH_LAUNCH_CHECK(c);
+  gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lb, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
+  AH_LAUNCH_CHECK(c);
+  // buckets → group records at the position of each group's first row (p* are free again: they take the records)
+  unsigned long long *g_key = pkeys, *g_sum = pvals;
+  unsigned* g_first = prows;
+  AH_HIP(c, hipMemsetAsync(g_first, 0xFF, (size_t)n * 4, c->stream));
+  const unsigned lgrid = (unsigned)ah_ceil_div(nbuckets, 4);
+  if (is_f64) gs_local_kernel<true><<<lgrid, 256, 0, c->stream>>>(qkeys, qvals, qrows, bstart, nbuckets, absmax, g_key, g_sum, g_cnt, g_first, firsts, oversize);
+  else gs_local_kernel<false><<<lgrid, 256, 0, c->stream>>>(qkeys, qvals, qrows, bstart, nbuckets, absmax, g_key, g_sum, g_cnt, g_first, firsts, oversize);
+  AH_LAUNCH_CHECK(c);
+  // ids = rank of the first rows
+  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  AH_LAUNCH_CHECK(c);
+  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
+  AH_LAUNCH_CHECK(c);
+  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(n, kBlock));
+  if (is_f64) gs_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(g_key, g_sum, g_cnt, g_first, n, firsts, wordprefix, tileoff, (unsigned long long*)out_keys,
+                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id);
+  else gs_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(g_key, g_sum, g_cnt, g_first, n, firsts, wordprefix, tileoff, (unsigned long long*)out_keys,
+                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id);
+  AH_LAUNCH_CHECK(c);
+  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // oversize, total, null id
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a bucket beyond one wave (a key with hundreds of rows): the id-based path redoes the call
+  if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
+  if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
+  *used = 1;
+  return AH_OK;
+}
+
+// 1.3 M … 10 M expected groups: the LDS-table aggregation needs 2048 … 8192 partitions — cut in two levels (the gs_* scatter
+// kernels: 64 × 64 partitions, runs as long as in the one-level cut of 64), then ONE workgroup per partition, tables dumped
+// side by side.  *used = 1: out_* hold the result.
+static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
+                       int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
+                       int32_t* out_null_group, int* used) {
+  *used = 0;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const int lb2 = lp - lp / 2;
+  const int nb2 = 1 << lb2, nb1 = 1 << (lp - lb2);
+  const int64_t P = (int64_t)1 << lp;
+  const int64_t ntiles = ah_ceil_div(n, kMsTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
+  const unsigned grid1 = (unsigned)(((ntiles + 7) / 8) * 8);
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const int64_t nslots = P * kFlatStride;
+  const size_t need = pad((size_t)n * 8) * 4 + pad((size_t)n * 4) * 2 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
+                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 8) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
+                      pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2;
+  uint8_t* base;
+  int rc = ah_temp_reserve(c, need, (void**)&base);
+  if (rc != AH_OK) return rc;
+  size_t off = 0;
+  auto take = [&](size_t b) { uint8_t* q = base + off; off += pad(b); return q; };
+  unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* qkeys = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* qvals = (unsigned long long*)take((size_t)n * 8);
+  unsigned* prows = (unsigned*)take((size_t)n * 4);
+  unsigned* qrows = (unsigned*)take((size_t)n * 4);
+  unsigned* cnt1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
+  unsigned* toffs1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
+  unsigned* gsum = (unsigned*)take((size_t)ngrp * nb1 * 4);
+  unsigned* pstart = (unsigned*)take((size_t)(nb1 + 1) * 4);
+  unsigned* cnt2 = (unsigned*)take((size_t)nvt * nb2 * 4);
+  unsigned* toffs2 = (unsigned*)take((size_t)nvt * nb2 * 4);
+  unsigned* bstart = (unsigned*)take(((size_t)P + 1) * 4);
+  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 8);
+  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
+  int* tilecnt = (int*)take((size_t)nrt * 4);
+  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
+  GbTable gt;
+  gt.key = (unsigned long long*)take((size_t)nslots * 8);
+  gt.lo = (unsigned long long*)take((size_t)nslots * 8);
+  gt.hi = (unsigned long long*)take((size_t)nslots * 8);
+  gt.cnt = (unsigned*)take((size_t)nslots * 4);
+  gt.first = (unsigned*)take((size_t)nslots * 4);
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned* overflow = (unsigned*)&c->dscalars[21];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[22];
+  int* null_id = (int*)&c->dscalars[23];
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
+  gs_hist_kernel<GsColumns><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lp, lb2, (unsigned)(nb1 - 1), nb1, cnt1);
+  AH_LAUNCH_CHECK(c);
+  colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt1, nb1, ntiles, gsum);
+  AH_LAUNCH_CHECK(c);
+  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, nb1, ngrp, n, pstart);
+  AH_LAUNCH_CHECK(c);
+  tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt1, gsum, nb1, ntiles, toffs1);
+  AH_LAUNCH_CHECK(c);
+  gs_scatter_kernel<GsColumns><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lp, lb2, (unsigned)(nb1 - 1), nb1, toffs1, pkeys, pvals, prows,
+                                                                  is_f64 ? tile_max : nullptr);
+  AH_LAUNCH_CHECK(c);
+  if (is_f64) {
+    gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+  }
+  GsRecords rec{pkeys, pvals, prows};
+  gs_hist_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, cnt2);
+  AH_LAUNCH_CHECK(c);
+  ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
+  AH_LAUNCH_CHECK(c);
+  gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
+  AH_LAUNCH_CHECK(c);
+  if (is_f64) gb_aggregate_kernel<true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1);
+  else gb_aggregate_kernel<false><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1);
+  AH_LAUNCH_CHECK(c);
+  gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
+  AH_LAUNCH_CHECK(c);
+  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  AH_LAUNCH_CHECK(c);
+  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
+  AH_LAUNCH_CHECK(c);
+  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
+  if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kFlatStride, kSlots);
+  else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kFlatStride, kSlots);
+  AH_LAUNCH_CHECK(c);
+  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition outgrew its LDS table: the id-based path redoes the call
+  if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
+  if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
+  *used = 1;
+  return AH_OK;
+}
+
 // Called by ah_hash_sum_* before the id-based path.  *used = 1: out_* hold the result; 0: not applicable (small input,
 // too many expected groups, or the estimate was so far off that a partition's table overflowed) — the caller runs the
 // id-based path, which accepts anything.
@@ -507,7 +992,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
                                const uint8_t* vvalid, int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts,
                                int64_t* out_first_rows, int64_t* out_ngroups, int32_t* out_null_group, int* used) {
   *used = 0;
-  const int mode = c->opt_groupby_partition;   // 0 never, 1 auto, k ≥ 5: always, with 2^(k − 2) partitions (tests, measurements)
+  const int mode = c->opt_groupby_partition;   // 0 never, 1 auto, 2: always sort-based, 3 / 4: always the two-level cut with 2^11 / 2^13 partitions, k ≥ 5: always LDS tables in 2^(k − 2) partitions (tests, measurements)
   if (mode == 0 || n >= kMaxRows || n < 1 || (mode == 1 && n < ((int64_t)1 << 21))) return AH_OK;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
@@ -517,6 +1002,8 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   unsigned long long* ones = (unsigned long long*)&c->dscalars[24];   // [24], [25]: the two sample points
   // ---- 0: how many partitions?
   int lp;
+  if (mode == 3 || mode == 4) return gb2_groupby(c, is_f64, mode == 3 ? 11 : 13, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
+  if (mode == 2) return gs_groupby(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
   if (mode > 1) {
     lp = mode - 2 < 3 ? 3 : (mode - 2 > 10 ? 10 : mode - 2);
   } else {
@@ -549,8 +1036,20 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
     // even-draw extrapolation — give those columns 4× the partitions rather than let the LDS tables overflow into the
     // global ones (measured: 0.45 → 0.89 ms in the aggregate pass of a Zipf(1.1) column over 2^20 keys)
     const double dh_even = gb_extrapolate(ds, sampled, sampled / 2);
-    if (dh < 0.93 * dh_even) est *= 4.0;
-    if (est > 1.3e6 * 4.0 || gb_extrapolate(ds, sampled, (double)n) > 1.3e6) return AH_OK;   // beyond 1024 partitions of ≤ 1280 keys: the id-based path
+    const bool heavy_tail = dh < 0.93 * dh_even;
+    if (est > 1.3e6) {
+      // beyond 1024 partitions of ≤ 1280 keys.  Evenly spread keys: up to 8192 partitions through the two-level cut, one workgroup
+      // each; beyond that (fewer than ≈ 8 rows per group) sort-based buckets.  A heavy tail at this size means keys with thousands
+      // of rows — one workgroup per partition or a bucket of 64 cannot take those: the id-based path
+      if (heavy_tail || n < ((int64_t)1 << 22) || n > ((int64_t)1 << 27)) return AH_OK;
+      if (est <= 10.0e6) {
+        int lp2 = 11;
+        while (lp2 < 13 && est / (double)(1 << lp2) > 1280.0) lp2++;
+        return gb2_groupby(c, is_f64, lp2, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
+      }
+      return gs_groupby(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
+    }
+    if (heavy_tail) est *= 4.0;   // up to 1024 partitions (the loop below stops there)
     lp = 3;                                            // ≤ 1280 expected keys per partition (LDS table: 3584), a few partitions at least
     while (lp < 10 && est / (double)(1 << lp) > 1280.0) lp++;
   }
@@ -613,8 +1112,8 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   }
   // ---- 3: aggregate
   const unsigned grid = (unsigned)(P + (n >> kChunkLog2));   // ≥ Σ max(1, round(rows_p / chunk))
-  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow);
-  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow);
+  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0);
+  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0);
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank the groups by first row, write them out
   gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
@@ -625,9 +1124,9 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   AH_LAUNCH_CHECK(c);
   const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
   if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id);
+                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
   else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id);
+                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
   AH_LAUNCH_CHECK(c);
   AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
   AH_HIP(c, hipStreamSynchronize(c->stream));

@@ -466,6 +466,12 @@ def _hash_sum_cases(rng, n, card, hot=0.0):
     (1 << 21, 48000, 5, 0.0),      # 6000 keys per partition: beyond the LDS table's 3584 → later keys go to the global table
     (1 << 21, 160000, 5, 0.0),     # 20000 keys per partition: the global table overflows → the id-based path answers
     (2500003, 700000, 12, 0.0),    # 1024 partitions
+    ((1 << 22) + 77, 1 << 21, 3, 0.0),     # 2048 partitions through the two-level cut, one workgroup per partition
+    ((1 << 22) + 77, 1 << 22, 4, 0.0),     # 8192 partitions
+    ((1 << 22) + 77, 1 << 24, 3, 0.0),     # far more keys per partition than an LDS table holds → the id-based path answers
+    ((1 << 22) + 77, 3 << 20, 2, 0.0),     # very many groups: sort-based buckets (ah_groupby.hip gs_*), one wave per bucket
+    ((1 << 22) + 77, 1 << 24, 2, 0.0),     # nearly every row its own group
+    ((1 << 22) + 77, 1 << 21, 2, 0.01),    # a key with 40 000 rows among two million groups: its bucket is beyond a wave → the id-based path answers
 ])
 def test_hash_sum_partition_first(hip, orc_be, ctx, n, card, mode, hot):
     """ah_groupby.hip: rows cut by key hash, each partition aggregated in LDS.  Same bytes as the id-based path and as the
@@ -503,7 +509,7 @@ def test_hash_sum_partition_first_auto(hip, orc_be):
     """the automatic choice (≥ 2^21 rows; partitions from a sampled distinct estimate), skewed keys included"""
     rng = np.random.default_rng(77)
     n = (1 << 22) + 77
-    for card, zipf in [(300, False), (50000, False), (1 << 20, True)]:
+    for card, zipf in [(300, False), (50000, False), (1 << 20, True), (1 << 23, False)]:
         if zipf:
             keys = (rng.zipf(1.1, n) % card).astype(np.int64) * 1000003
         else:
