@@ -151,7 +151,7 @@ def zipf_keys(rng, n, card, s=1.1):
     return pool[ranks]
 
 
-@pytest.mark.parametrize("lg,dist", [(10, "uniform"), (16, "uniform"), (20, "uniform"), (24, "uniform"), (20, "zipf")])
+@pytest.mark.parametrize("lg,dist", [(10, "uniform"), (16, "uniform"), (20, "uniform"), (22, "uniform"), (24, "uniform"), (20, "zipf")])
 def test_c5_hash_2_26(hip, orc_be, lg, dist):
     rng = np.random.default_rng(40 + lg + (dist == "zipf"))
     if dist == "zipf":
@@ -160,7 +160,7 @@ def test_c5_hash_2_26(hip, orc_be, lg, dist):
         pool = rng.integers(-2**63, 2**63 - 1, 1 << lg, dtype=np.int64)
         keys = pool[rng.integers(0, 1 << lg, N26)]
     kvalid = bits(rng, N26, 0.98)
-    for enc in ((False, True) if lg < 24 else (False,)):   # (2^24 keys: ≈ 10 s of oracle per call)
+    for enc in ((False, True) if lg < 22 else (False,)):   # (2^24 keys: ≈ 10 s of oracle per call)
         g = hip.hash_encode(keys, kvalid, 0, enc)
         e = orc_be.hash_encode(keys, kvalid, 0, enc)
         same(g[0], e[0], f"ids enc={enc}")
@@ -197,3 +197,23 @@ def test_c2_sum_and_cumulative_sum_2_27(hip, orc_be, column):
     assert g[0] == e[0] == STATUS_OK and g[3] == e[3]
     same(g[1], e[1], "cumulative_sum skip_nulls payload")
     same(g[2], e[2], "cumulative_sum skip_nulls validity")
+
+
+@pytest.mark.parametrize("kind", ["int64", "float64"])
+def test_sort_indices_2_27(hip, kind):
+    """sort_indices at the size of the C2 / C3 columns through the MSD path: the permutation must be THE stable one
+    (numpy's stable argsort of the same keys; a stable sort has exactly one answer), nulls last"""
+    rng = np.random.default_rng(90)
+    a = rng.integers(-2**63, 2**63 - 1, N27, dtype=np.int64) if kind == "int64" else rng.standard_normal(N27)
+    a[rng.integers(0, N27, 1000)] = a[0]          # some ties
+    g = hip.sort_indices(a, None, 0, False, False)
+    e = np.argsort(a, kind="stable").astype(np.uint64)
+    same(g, e, f"sort_indices {kind}")
+    valid = bits(rng, N27, 0.9)
+    g = hip.sort_indices(a, valid, 0, True, True)   # descending, nulls first: the partition pass in front of the MSD path
+    ok = np.unpackbits(valid, bitorder="little")[:N27].astype(bool)
+    nulls = np.flatnonzero(~ok).astype(np.uint64)
+    rest = np.flatnonzero(ok)
+    key = a[rest]
+    order = rest[np.argsort(-key if kind == "float64" else ~key, kind="stable")].astype(np.uint64)
+    same(g, np.concatenate([nulls, order]), f"sort_indices {kind} descending, nulls first")
