@@ -275,8 +275,12 @@ __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsi
 template <bool FX>
 __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                                  const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
-                                                                 const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat) {
-  // flat: one workgroup per partition (blockIdx = partition; thousands of partitions from the two-level cut), tables of
+                                                                 const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat,
+                                                                 const uint8_t* __restrict__ kvalid, int64_t koff, const uint8_t* __restrict__ vvalid,
+                                                                 int64_t voff, int64_t nrows) {
+  // flat = 2 ("direct", ≤ 2048 expected groups): no cut at all — keys / vals ARE the columns, a workgroup takes 2^18 consecutive rows
+  // and the chunks are merged into ONE global table with atomics.
+  // flat = 1: one workgroup per partition (blockIdx = partition; thousands of partitions from the two-level cut), tables of
   // kSlots + 8 entries side by side, no merging: a partition that outgrows its LDS table voids the attempt
   __shared__ __attribute__((aligned(16))) unsigned long long l_key[kLSlots];
   __shared__ unsigned long long l_lo[kLSlots];
@@ -290,7 +294,13 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   int part;
   bool multi;
   int64_t r0, r1;
-  if (flat) {
+  if (flat == 2) {
+    part = 0;
+    multi = true;
+    r0 = (int64_t)blockIdx.x << kChunkLog2;
+    r1 = r0 + ((int64_t)1 << kChunkLog2) < nrows ? r0 + ((int64_t)1 << kChunkLog2) : nrows;
+    if (r0 >= nrows) return;
+  } else if (flat) {
     part = (int)blockIdx.x;
     multi = false;
     r0 = binstart[part];
@@ -318,8 +328,8 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   __syncthreads();
   int sh = 0;
   if (FX) sh = fx_shift(*absmax);
-  const int64_t gbase = (int64_t)part * (flat ? kFlatStride : kGStride);
-  const int gspecial = flat ? kSlots : kGSlots;   // where the two special slots sit in the partition's global table
+  const int64_t gbase = (int64_t)part * (flat == 1 ? kFlatStride : kGStride);
+  const int gspecial = flat == 1 ? kSlots : kGSlots;   // where the two special slots sit in the partition's global table
   bool went_direct = false;
   // one pending group per lane: {key, 128-bit sum, count | flags, first row}.  A row with the key of the lane's previous row
   // is added in registers: a key that owns most of a chunk (skewed columns) would otherwise put every lane of every wave
@@ -362,8 +372,8 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       }
       atomicAdd(&l_cnt[j], cf & kCntMask);
       if (__builtin_expect(cf & ~kCntMask, 0)) atomicOr(&l_cnt[j], cf & ~kCntMask);
-      atomicMin(&l_first[j], row);
-    } else if (flat) {
+      if (l_first[j] > row) atomicMin(&l_first[j], row);   // an LDS read costs about half an LDS atomic, and rows of a key arrive mostly in ascending order
+    } else if (flat == 1) {
       atomicExch(overflow, 1u);   // no global table behind a flat partition
     } else {
       went_direct = true;
@@ -383,7 +393,8 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       if (i < r1) {
         nk[u] = __builtin_nontemporal_load(&keys[i]);
         nv[u] = __builtin_nontemporal_load(&vals[i]);
-        nrw[u] = __builtin_nontemporal_load(&prows[i]);
+        if (prows) nrw[u] = __builtin_nontemporal_load(&prows[i]);
+        else nrw[u] = (unsigned)i | (ah_bit(kvalid, koff + i) ? 0u : kKeyNull) | (ah_bit(vvalid, voff + i) ? 0u : kValNull);
       }
     }
   };
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       const int j = kSlots + t;
       const int64_t g = gbase + gspecial + t;
       gt.key[g] = l_key[j]; gt.lo[g] = l_lo[j]; if (FX) gt.hi[g] = l_hi[j]; gt.cnt[g] = l_cnt[j]; gt.first[g] = l_first[j];
-    } else if (flat && t < kFlatStride - kSlots) {
+    } else if (flat == 1 && t < kFlatStride - kSlots) {
       gt.first[gbase + kSlots + t] = kNoRow;   // the stride's padding: nothing was memset in flat mode
     }
   } else {
@@ -961,8 +972,8 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   AH_LAUNCH_CHECK(c);
   gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
   AH_LAUNCH_CHECK(c);
-  if (is_f64) gb_aggregate_kernel<true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1);
-  else gb_aggregate_kernel<false><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1);
+  if (is_f64) gb_aggregate_kernel<true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0);
+  else gb_aggregate_kernel<false><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0);
   AH_LAUNCH_CHECK(c);
   gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
   AH_LAUNCH_CHECK(c);
@@ -979,6 +990,72 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
   AH_HIP(c, hipStreamSynchronize(c->stream));
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition outgrew its LDS table: the id-based path redoes the call
+  if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
+  if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
+  *used = 1;
+  return AH_OK;
+}
+
+// ≤ 2048 expected groups: no cut — every workgroup aggregates 2^18 consecutive rows of the columns in its LDS table and merges it
+// into one global table (the id-based path spends a pass on row-order ids it does not need, and a second one reading them back).
+static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
+                     int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
+                     int32_t* out_null_group, int* used) {
+  *used = 0;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const int64_t nslots = kGStride;
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const size_t need = pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2 + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
+  uint8_t* base;
+  int rc = ah_temp_reserve(c, need, (void**)&base);
+  if (rc != AH_OK) return rc;
+  size_t off = 0;
+  auto take = [&](size_t b) { uint8_t* q = base + off; off += pad(b); return q; };
+  GbTable gt;
+  gt.key = (unsigned long long*)take((size_t)nslots * 8);
+  gt.lo = (unsigned long long*)take((size_t)nslots * 8);
+  gt.hi = (unsigned long long*)take((size_t)nslots * 8);
+  gt.cnt = (unsigned*)take((size_t)nslots * 4);
+  gt.first = (unsigned*)take((size_t)nslots * 4);
+  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
+  int* tilecnt = (int*)take((size_t)nrt * 4);
+  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned* overflow = (unsigned*)&c->dscalars[21];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[22];
+  int* null_id = (int*)&c->dscalars[23];
+  AH_HIP(c, hipMemsetAsync(gt.key, 0xFF, (size_t)nslots * 8, c->stream));
+  AH_HIP(c, hipMemsetAsync(gt.lo, 0, pad((size_t)nslots * 8) * 2 + (size_t)nslots * 4, c->stream));   // lo, hi, cnt are adjacent
+  AH_HIP(c, hipMemsetAsync(gt.first, 0xFF, (size_t)nslots * 4, c->stream));
+  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+  const unsigned long long* k64 = (const unsigned long long*)keys;
+  const unsigned long long* v64 = (const unsigned long long*)vals;
+  if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
+    absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 8), kBlock, 0, c->stream>>>(v64, vvalid, voff, n, absmax);
+    AH_LAUNCH_CHECK(c);
+  }
+  const unsigned grid = (unsigned)ah_ceil_div(n, (int64_t)1 << kChunkLog2);
+  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
+  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
+  AH_LAUNCH_CHECK(c);
+  gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
+  AH_LAUNCH_CHECK(c);
+  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  AH_LAUNCH_CHECK(c);
+  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
+  AH_LAUNCH_CHECK(c);
+  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
+  if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
+  else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
+  AH_LAUNCH_CHECK(c);
+  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;
   if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
   *used = 1;
@@ -1002,6 +1079,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   unsigned long long* ones = (unsigned long long*)&c->dscalars[24];   // [24], [25]: the two sample points
   // ---- 0: how many partitions?
   int lp;
+  if (mode == -2) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
   if (mode == 3 || mode == 4) return gb2_groupby(c, is_f64, mode == 3 ? 11 : 13, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
   if (mode == 2) return gs_groupby(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
   if (mode > 1) {
@@ -1030,7 +1108,8 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
     const double sampled = (double)groups * 64.0;
     const double dh = distinct(*(volatile uint64_t*)&c->pinned[8], sampled / 2), ds = distinct(*(volatile uint64_t*)&c->pinned[9], sampled);
     double est = gb_extrapolate(ds, sampled, (double)n);
-    if (est <= 4300.0) return AH_OK;                   // all groups fit the id-based path's LDS table: 0.55–1.0 ms there, no better here
+    if (est <= 2048.0) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
+    if (est <= 4300.0) return AH_OK;                   // all groups still fit the id-based path's LDS table: ≈ 1 ms there, no better here
     // Keys drawn evenly from C values give a curve that the second half of the sample must follow; a heavy-tailed column
     // (Zipf) keeps bringing new keys long after that curve has flattened, and its full distinct count is several times the
     // even-draw extrapolation — give those columns 4× the partitions rather than let the LDS tables overflow into the
@@ -1112,8 +1191,8 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   }
   // ---- 3: aggregate
   const unsigned grid = (unsigned)(P + (n >> kChunkLog2));   // ≥ Σ max(1, round(rows_p / chunk))
-  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0);
-  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0);
+  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0);
+  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0);
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank the groups by first row, write them out
   gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);

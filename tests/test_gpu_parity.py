@@ -460,6 +460,9 @@ def _hash_sum_cases(rng, n, card, hot=0.0):
 
 
 @pytest.mark.parametrize("n,card,mode,hot", [
+    (70001, 500, -2, 0.0),         # no cut: chunks of the columns aggregated in LDS, merged into one global table
+    (3000017, 1500, -2, 0.6),      # … with a hot key and a dozen chunks
+    (3000017, 9000, -2, 0.0),      # … and more keys than the LDS table admits: the rest goes straight to the global table
     (70001, 500, 5, 0.0),          # 8 partitions of one chunk each: the LDS table leaves as a copy
     (300007, 20000, 5, 0.0),
     (6000017, 9000, 5, 0.6),       # a hot key: its partition is cut into chunks, merged into the global table; runs combined per lane
