@@ -335,10 +335,17 @@ int run_counts(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t f
   return AH_OK;
 }
 
+// *_dev flavour: {rows selected, output null count} stay in device memory
+__global__ void filter_status_kernel(const int64_t* __restrict__ total, const unsigned long long* __restrict__ nvalid, int has_valid,
+                                     int64_t* __restrict__ status) {
+  status[0] = *total;
+  status[1] = has_valid ? *total - (int64_t)*nvalid : 0;
+}
+
 template <int W, bool INDICES>
 int run_filter(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t voff, const uint8_t* fdata,
                const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel, int64_t n_out, void* out_values,
-               uint8_t* out_valid, int64_t* out_null_count_host) {
+               uint8_t* out_valid, int64_t* out_null_count_host, int64_t* status_dev = nullptr) {
   int* tile_local; int64_t* super_off; int64_t* total; int64_t ntiles;
   int rc = run_counts<W>(c, fdata, fvalid, foff, n, null_sel, &tile_local, &super_off, &total, &ntiles);
   if (rc != AH_OK) return rc;
@@ -353,6 +360,13 @@ int run_filter(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t vof
                                                                                   super_off, tile_local, out_values, nullptr, valid_total);
   }
   AH_LAUNCH_CHECK(c);
+  if (status_dev) {
+    // the output was sized for n rows and its validity bytes zeroed up to there: bits past the selection count add nothing
+    if (out_valid && (rc = ah_popcount_async(c, out_valid, 0, n_out, valid_total)) != AH_OK) return rc;
+    filter_status_kernel<<<1, 1, 0, c->stream>>>(total, valid_total, out_valid != nullptr, status_dev);
+    AH_LAUNCH_CHECK(c);
+    return AH_OK;
+  }
   if (out_null_count_host) {
     // null count = n_out − popcount(out_valid[0, n_out)) — a 2-launch reduction over n_out/8
     // bytes instead of one same-address atomic per tile (~12 ns each, serialised at L2)
@@ -407,6 +421,28 @@ AH_EXPORT int ah_filter_primitive(ah_ctx* c, int byte_width, const void* values,
     case 8: return run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
   }
   return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);  // vector_selection.go:515
+}
+
+AH_EXPORT int ah_filter_primitive_dev(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                                      const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                                      void* out_values, uint8_t* out_valid, int64_t* status_dev) {
+  AH_ENTER(c);
+  if (n < 0 || foff < 0 || voff < 0) return ah_fail(c, AH_EINVALID, "filter: negative length/offset");
+  if (!status_dev) return ah_fail(c, AH_EINVALID, "filter: null status pointer");
+  if (n == 0) {
+    AH_HIP(c, hipMemsetAsync(status_dev, 0, 2 * sizeof(int64_t), c->stream));
+    return AH_OK;
+  }
+  if (!fdata || !values) return ah_fail(c, AH_EINVALID, "filter: null input buffer");
+  if (((uintptr_t)values | (uintptr_t)out_values) & (uintptr_t)(byte_width - 1))
+    return ah_fail(c, AH_EINVALID, "filter: buffer not element-aligned");
+  switch (byte_width) {   // n_out = n: the capacity the caller sized the output for
+    case 1: return run_filter<1, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status_dev);
+    case 2: return run_filter<2, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status_dev);
+    case 4: return run_filter<4, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status_dev);
+    case 8: return run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status_dev);
+  }
+  return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);
 }
 
 AH_EXPORT int ah_filter_to_indices(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,

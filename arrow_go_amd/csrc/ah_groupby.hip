@@ -267,12 +267,22 @@ __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsi
 
 // FX: Float64 values summed in 128-bit fixed point; else 64-bit wrapping integer sums.
 //
-// The kernel is bound by instruction issue, not by LDS or HBM (PMC at 2^26 rows: 121 VALU + 109 SALU + 10 LDS instructions
-// per 64 rows in the first version, the SALU all exec-mask bookkeeping of per-row branches; waves parked 52 % of the time
-// on LDS round trips with only 4 waves per SIMD — the table takes 136 KiB).  Hence: addends are formed without branches,
-// count / first row / high word go out as fire-and-forget LDS atomics (adding 0 or re-stating a minimum costs an LDS
-// slot, not a wait), and only two things make a wave wait: the key probe and the returning add that yields the carry.
-template <bool FX>
+// What bounds this kernel: the vector unit's instruction stream — not LDS, not HBM, and not latency.  PMC at 2^26 rows: 140 VALU +
+// 61 SALU + 7 LDS instructions per 64 rows, of the VALU ones ≈ 40 on 64-bit integers (half rate) and 3 quarter-rate multiplies;
+// SQ_ACTIVE_INST_ANY = 94 % of the SIMD issue time although every wave is parked half of ITS time (4 waves per SIMD: the table
+// takes 136 KiB).  An LDS micro-benchmark retires the row's four LDS operations at 2 rows / clock / CU, eight times the rate
+// seen here.  What was tried, read off the ISA and measured (2^16 groups, 2^26 rows):
+//   · branch-free addends (fx_split without the shift-direction branch), lane masks kept as booleans for the 4-slot probe,
+//     two multiplies for the slot hash instead of three: 160 → 126 vector instructions per row, 441 → 406 µs;
+//   · the software pipeline of the record loads never overlapped anything before: entering the loop with the first step's
+//     loads pending, the compiler's wait-count pass put "≤ 3 loads outstanding" in front of the row processing, i.e. a wait
+//     for the prefetch just issued.  Fixed with an explicit wait before the loop (below) — the time did not move, so the
+//     loads were never what the waves waited for;
+//   · two pending groups per lane flushed together (both probes read in one go, both returning adds in flight together,
+//     wave-uniform loops): half the dependent LDS round trips per row, same instruction count — 6 % SLOWER.  Latency is not it.
+// What is left is fewer instructions per row, and the ones that remain are the algorithm: eight 64-bit compares per probe
+// step, a 128-bit fixed-point split, two 128-bit adds, five LDS operations.
+template <bool FX, bool DIRECT = false>
 __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                                  const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
                                                                  const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat,
@@ -342,20 +352,21 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     if (__builtin_expect(kw != 0 || key == kEmpty, 0)) {
       j = kw ? kSlots + 1 : kSlots;
     } else {
-      // Linear probing over aligned groups of 4 slots, a group per step (two 16-byte LDS reads, one wait): a wave walks as
+      // Linear probing over aligned groups of 4 slots, a group per step (32 bytes of LDS, one wait): a wave walks as
       // far as its unluckiest lane, and at load ¼ one slot per step meant 3–4 dependent round trips per row for the wave.
       // The first slot of the probe order that holds the key or is empty decides (no deletions: a key never sits behind
-      // an empty slot of its own probe order).
-      unsigned g = gb_lslot(gb_hash32(key)) & ~3u;
+      // an empty slot of its own probe order).  The eight comparisons stay booleans (lane masks in scalar registers,
+      // combined by the scalar unit); per-lane integer masks cost three vector instructions per comparison.
+      // Two multiplies: inside a partition the keys agree in the top bits of gb_mix, so a different function is wanted anyway.
+      unsigned g = ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 20) & (unsigned)(kSlots - 4);
       for (;;) {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&l_key[g]), c = *reinterpret_cast<const ulonglong2*>(&l_key[g + 2]);
-        const unsigned hit = (a.x == key ? 1u : 0u) | (a.y == key ? 2u : 0u) | (c.x == key ? 4u : 0u) | (c.y == key ? 8u : 0u);
-        const unsigned emp = (a.x == kEmpty ? 1u : 0u) | (a.y == kEmpty ? 2u : 0u) | (c.x == kEmpty ? 4u : 0u) | (c.y == kEmpty ? 8u : 0u);
-        const unsigned any = hit | emp;
-        if (any == 0) { g = (g + 4) & (kSlots - 1); continue; }
-        const int f = __builtin_ctz(any);
-        j = (int)g + f;
-        if ((hit >> f) & 1u) break;
+        const bool h0 = a.x == key, h1 = a.y == key, h2 = c.x == key, h3 = c.y == key;
+        const bool e0 = a.x == kEmpty, e1 = a.y == kEmpty, e2 = c.x == kEmpty, e3 = c.y == kEmpty;
+        const bool y0 = h0 || e0, y1 = h1 || e1, y2 = h2 || e2, y3 = h3 || e3;
+        if (!(y0 || y1 || y2 || y3)) { g = (g + 4) & (kSlots - 1); continue; }
+        j = (int)g + (y0 ? 0 : y1 ? 1 : y2 ? 2 : 3);
+        if (h0 || (!e0 && (h1 || (!e1 && (h2 || (!e2 && h3)))))) break;   // the key sits in front of the first empty slot (a key is in the table once)
         // first empty slot of the probe order: claim it
         if (atomicAdd(&s_used, 1u) >= (unsigned)kSoftLimit) { j = -1; break; }   // tickets are never returned: "full" sticks
         const unsigned long long cur = atomicCAS(&l_key[j], kEmpty, key);
@@ -365,14 +376,19 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     }
     if (__builtin_expect(j >= 0, 1)) {
       if (FX) {
+        // the returning add (its old value yields the carry) and the read of the group's first row travel together: one wait.
+        // Rows of a key arrive mostly in ascending order, so the minimum is rarely lowered — and a plain read costs half an atomic.
         const unsigned long long old = atomicAdd(&l_lo[j], lo);
+        const unsigned fr = l_first[j];
         atomicAdd(&l_hi[j], hi + (old + lo < old ? 1ull : 0ull));
+        atomicAdd(&l_cnt[j], cf & kCntMask);
+        if (fr > row) atomicMin(&l_first[j], row);
       } else {
         atomicAdd(&l_lo[j], lo);
+        atomicAdd(&l_cnt[j], cf & kCntMask);
+        atomicMin(&l_first[j], row);   // nothing here waits for LDS: fire and forget beats look-before-you-lower
       }
-      atomicAdd(&l_cnt[j], cf & kCntMask);
       if (__builtin_expect(cf & ~kCntMask, 0)) atomicOr(&l_cnt[j], cf & ~kCntMask);
-      if (l_first[j] > row) atomicMin(&l_first[j], row);   // an LDS read costs about half an LDS atomic, and rows of a key arrive mostly in ascending order
     } else if (flat == 1) {
       atomicExch(overflow, 1u);   // no global table behind a flat partition
     } else {
@@ -381,49 +397,85 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       if (gs >= 0) gb_global_add<FX>(gt, gs, lo, hi, cf, row);
     }
   };
-  // software pipeline: the next step's 12 loads per lane are in flight while this step's rows go through LDS
+  // software pipeline: the next step's loads (12 per lane) are in flight while this step's rows go through LDS.  The load step
+  // only LOADS: anything that consumes a loaded value (the validity bits of the direct mode) would make it wait for memory
+  // between the rows of one step, and a step that lies wholly inside the range runs without per-lane guards.
   constexpr int U = 4;
+  constexpr int64_t kStep = (int64_t)kThreads * U;
   unsigned long long nk[U], nv[U];
-  unsigned nrw[U];
-  auto load_step = [&](int64_t b) {
+  unsigned nrw[U];                         // the row word — direct mode: the row's two validity BYTES, decoded when the row is processed
+  auto load_step = [&](int64_t b, auto full) {
+    constexpr bool kFull = decltype(full)::value;
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t i = b + u * kThreads + t;
-      nk[u] = 0; nv[u] = 0; nrw[u] = 0;
-      if (i < r1) {
-        nk[u] = __builtin_nontemporal_load(&keys[i]);
-        nv[u] = __builtin_nontemporal_load(&vals[i]);
-        if (prows) nrw[u] = __builtin_nontemporal_load(&prows[i]);
-        else nrw[u] = (unsigned)i | (ah_bit(kvalid, koff + i) ? 0u : kKeyNull) | (ah_bit(vvalid, voff + i) ? 0u : kValNull);
+      const bool in = kFull || i < r1;
+      nk[u] = in ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+      nv[u] = in ? __builtin_nontemporal_load(&vals[i]) : 0ull;
+    }
+    if (!DIRECT) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int64_t i = b + u * kThreads + t;
+        nrw[u] = (kFull || i < r1) ? __builtin_nontemporal_load(&prows[i]) : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) nrw[u] = 0xFFFFu;
+      if (kvalid) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int64_t i = b + u * kThreads + t;
+          if (kFull || i < r1) nrw[u] = (nrw[u] & 0xFF00u) | kvalid[(koff + i) >> 3];
+        }
+      }
+      if (vvalid) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int64_t i = b + u * kThreads + t;
+          if (kFull || i < r1) nrw[u] = (nrw[u] & 0x00FFu) | ((unsigned)vvalid[(voff + i) >> 3] << 8);
+        }
       }
     }
   };
-  load_step(r0);
-  for (int64_t b = r0; b < r1; b += (int64_t)kThreads * U) {
+  auto load_any = [&](int64_t b) {
+    if (b + kStep <= r1) load_step(b, std::true_type{});
+    else if (b < r1) load_step(b, std::false_type{});
+  };
+  load_any(r0);
+  // The first step's loads are waited for HERE.  Entering the loop with them pending, the compiler's wait-count pass merges that
+  // state with the back edge's and puts "at most 3 loads outstanding" in front of the row processing — which in the steady state
+  // means waiting for the prefetch just issued: the pipeline below never overlapped anything (seen in the ISA, not in a profile).
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int64_t b = r0; b < r1; b += kStep) {
     unsigned long long k[U], v[U];
     unsigned rw[U];
 #pragma unroll
     for (int u = 0; u < U; u++) { k[u] = nk[u]; v[u] = nv[u]; rw[u] = nrw[u]; }
-    if (b + (int64_t)kThreads * U < r1) load_step(b + (int64_t)kThreads * U);
+    load_any(b + kStep);
+    const unsigned left = r1 - b < kStep ? (unsigned)(r1 - b) : (unsigned)kStep;   // rows of this step (uniform)
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const bool live = b + u * kThreads + t < r1;   // a slot past the end adds nothing to whatever is pending
-      const unsigned row = live ? rw[u] & kRowMask : kNoRow;
+      const bool live = (unsigned)(u * kThreads + t) < left;   // a slot past the end adds nothing to whatever is pending
+      unsigned rwu = rw[u];
+      if (DIRECT) {
+        const int64_t i = b + u * kThreads + t;
+        rwu = (unsigned)i | (((rwu >> ((koff + i) & 7)) & 1u) ? 0u : kKeyNull) | (((rwu >> (8 + ((voff + i) & 7))) & 1u) ? 0u : kValNull);
+      }
+      const unsigned row = live ? rwu & kRowMask : kNoRow;
       // the addend, without branches: a null value adds nothing and is not counted; ±inf / NaN are counted and flagged
-      const bool has = live && !(rw[u] & kValNull);
+      const bool has = live && !(rwu & kValNull);
       unsigned long long lo, hi = 0;
       unsigned cf = has ? 1u : 0u;
       if (FX) {
         const double x = __builtin_bit_cast(double, v[u]);
         const bool fin = fx_finite(x);
-        fx_split(x, sh, &lo, &hi);
-        lo = has && fin ? lo : 0ull;
-        hi = has && fin ? hi : 0ull;
+        fx_split(has && fin ? x : 0.0, sh, &lo, &hi);
         cf |= has && !fin ? fx_flag(x) << 29 : 0u;
       } else {
         lo = has ? v[u] : 0ull;
       }
-      const unsigned kw = rw[u] & kKeyNull;
+      const unsigned kw = rwu & kKeyNull;
       const bool same = !live || (p_live && p_key == k[u] && p_kw == kw);
       if (!same) {
         if (p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
@@ -1038,8 +1090,8 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
     AH_LAUNCH_CHECK(c);
   }
   const unsigned grid = (unsigned)ah_ceil_div(n, (int64_t)1 << kChunkLog2);
-  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
-  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
+  if (is_f64) gb_aggregate_kernel<true, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
+  else gb_aggregate_kernel<false, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
   AH_LAUNCH_CHECK(c);
   gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
   AH_LAUNCH_CHECK(c);

@@ -306,14 +306,34 @@ __global__ __launch_bounds__(kSmallBlock) void insert_small_kernel(const unsigne
   const uint64_t mask = cap - 1;
   const int64_t stride = (int64_t)gridDim.x * kSmallBlock * kSmallRows;
   unsigned fresh = 0, nmiss = 0;
-  for (int64_t base = lo + (int64_t)blockIdx.x * kSmallBlock * kSmallRows + threadIdx.x; base < hi; base += stride) {
+  // the next step's keys are requested before this step's are looked up: a lane has 2 × kSmallRows loads in flight and the
+  // LDS work of one step hides behind the HBM latency of the next (one workgroup per CU: there is nobody else to hide it)
+  unsigned long long kn[kSmallRows];
+  bool okn[kSmallRows];
+  auto fetch = [&](int64_t b) {
+#pragma unroll
+    for (int u = 0; u < kSmallRows; u++) {
+      const int64_t i = b + (int64_t)u * kSmallBlock;
+      okn[u] = i < hi && ah_bit(valid, off + i);
+      kn[u] = okn[u] ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+    }
+  };
+  int64_t base = lo + (int64_t)blockIdx.x * kSmallBlock * kSmallRows + threadIdx.x;
+  if (base < hi) fetch(base);
+  for (; base < hi; base += stride) {
     unsigned long long k[kSmallRows];
     bool ok[kSmallRows];
 #pragma unroll
+    for (int u = 0; u < kSmallRows; u++) { k[u] = kn[u]; ok[u] = okn[u]; }
+    if (base + stride < hi) fetch(base + stride);
+    // first probes of all rows together (and the id that goes with a hit): eight independent LDS round trips, not a chain
+    unsigned j0[kSmallRows], id0[kSmallRows];
+    unsigned long long lk0[kSmallRows];
+#pragma unroll
     for (int u = 0; u < kSmallRows; u++) {
-      const int64_t i = base + (int64_t)u * kSmallBlock;
-      ok[u] = i < hi && ah_bit(valid, off + i);
-      k[u] = ok[u] ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+      j0[u] = (unsigned)hash_int(k[u]) & (kSmallSlots - 1);
+      lk0[u] = l_keys[j0[u]];
+      id0[u] = l_ids[j0[u]];
     }
 #pragma unroll
     for (int u = 0; u < kSmallRows; u++) {
@@ -327,8 +347,12 @@ __global__ __launch_bounds__(kSmallBlock) void insert_small_kernel(const unsigne
         else { r = null_id; s = cap + 1; }
       } else if (k[u] == kEmpty) {
         r = ones_id; s = cap;
+      } else if (lk0[u] == k[u]) {
+        r = id0[u];
+      } else if (lk0[u] == kEmpty) {
+        probe = true;
       } else {
-        unsigned j = (unsigned)hash_int(k[u]) & (kSmallSlots - 1);
+        unsigned j = (j0[u] + 1) & (kSmallSlots - 1);
         for (;;) {
           const unsigned long long lk = l_keys[j];
           if (lk == k[u]) { r = l_ids[j]; break; }

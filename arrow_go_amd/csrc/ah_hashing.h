@@ -110,16 +110,23 @@ __device__ __forceinline__ unsigned fx_flag(double x) { return x != x ? 1u : (x 
 // (The first version went through ldexp / trunc / floor and two double → uint64 conversions: ≈ 4× the instructions,
 // and the group-by kernels are instruction-bound.)
 __device__ __forceinline__ void fx_split(double x, int sh, unsigned long long* lo, unsigned long long* hi) {
+  // without branches (a divergent if / else costs the wave both sides plus the exec-mask bookkeeping): exactly one of the
+  // two shift counts is non-zero; m < 2^53, so a right shift by 63 stands for every right shift ≥ 53, and the high word
+  // (m >> (64 − sl), nothing for sl ≤ 11) is (m >> 1) >> (63 − sl) for every sl in [0, 42]
   const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
   const int e = (int)((b >> 52) & 0x7ff);
   const unsigned long long m = (b & 0xfffffffffffffull) | (e ? 1ull << 52 : 0ull);
   const int s = (e ? e : 1) - 1075 + sh;
-  unsigned long long l, u;
-  if (s >= 0) { l = m << s; u = s > 11 ? m >> (64 - s) : 0ull; }
-  else { l = s > -64 ? m >> -s : 0ull; u = 0ull; }
-  if ((long long)b < 0) { l = ~l + 1; u = ~u + (l == 0 ? 1 : 0); }  // two's complement of the 128-bit magnitude
-  *lo = l;
-  *hi = u;
+  const int sl = s > 0 ? s : 0;
+  int sr = s < 0 ? -s : 0;
+  sr = sr < 63 ? sr : 63;
+  unsigned long long l = (m << sl) >> sr;
+  unsigned long long u = (m >> 1) >> (63 - sl);
+  // two's complement of the 128-bit magnitude for x < 0: q = (q ^ S) − S with S = the sign, extended to 128 bits
+  const unsigned __int128 S = (unsigned __int128)(__int128)((long long)b >> 63);
+  const unsigned __int128 q = ((((unsigned __int128)u << 64) | l) ^ S) - S;
+  *lo = (unsigned long long)q;
+  *hi = (unsigned long long)(q >> 64);
 }
 template <typename P>   // P = pointer into LDS or global memory
 __device__ __forceinline__ void fx_add(P lo_arr, P hi_arr, size_t g, unsigned long long lo, unsigned long long hi) {

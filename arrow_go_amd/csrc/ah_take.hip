@@ -179,6 +179,17 @@ __global__ __launch_bounds__(kBlock) void take_bool_kernel(const uint8_t* __rest
   }
 }
 
+// *_dev flavour: {position of the first offending index or UINT64_MAX, output null count} stay in device memory
+__global__ void take_status_kernel(const unsigned long long* __restrict__ first_bad, const unsigned long long* __restrict__ nvalid, int has_valid,
+                                   int64_t nidx, unsigned long long* __restrict__ status) {
+  status[0] = *first_bad;
+  status[1] = has_valid ? (unsigned long long)nidx - *nvalid : 0ull;
+}
+
+int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int idx_byte_width,
+                        int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values, uint8_t* out_valid,
+                        int64_t* out_null_count_host, int64_t* bad_index_host, uint64_t* status_dev);
+
 }  // namespace
 
 AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
@@ -188,9 +199,34 @@ AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, c
                                 int64_t* bad_index_host) {
   AH_ENTER(c);
   (void)bounds_check;  // the check is fused into the gather and always on (header)
+  return take_primitive_core(c, byte_width, values, vvalid, voff, nvalues, idx_byte_width, idx_signed, idx, ivalid, ioff, nidx, out_values, out_valid,
+                             out_null_count_host, bad_index_host, nullptr);
+}
+
+AH_EXPORT int ah_take_primitive_dev(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                                    int64_t nvalues, int idx_byte_width, int idx_signed, const void* idx,
+                                    const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values, uint8_t* out_valid,
+                                    uint64_t* status_dev) {
+  AH_ENTER(c);
+  if (!status_dev) return ah_fail(c, AH_EINVALID, "take: null status pointer");
+  return take_primitive_core(c, byte_width, values, vvalid, voff, nvalues, idx_byte_width, idx_signed, idx, ivalid, ioff, nidx, out_values, out_valid,
+                             nullptr, nullptr, status_dev);
+}
+
+namespace {
+
+int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int idx_byte_width,
+                        int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values, uint8_t* out_valid,
+                        int64_t* out_null_count_host, int64_t* bad_index_host, uint64_t* status_dev) {
   if (nidx < 0 || nvalues < 0 || voff < 0 || ioff < 0) return ah_fail(c, AH_EINVALID, "take: negative length/offset");
   if (out_null_count_host) *out_null_count_host = 0;
-  if (nidx == 0) return AH_OK;
+  if (nidx == 0) {
+    if (status_dev) {
+      AH_HIP(c, hipMemsetAsync(status_dev, 0xFF, 8, c->stream));
+      AH_HIP(c, hipMemsetAsync(status_dev + 1, 0, 8, c->stream));
+    }
+    return AH_OK;
+  }
   if (!idx || !out_values || (!values && nvalues > 0)) return ah_fail(c, AH_EINVALID, "take: null buffer");
   if (!out_valid && (vvalid || ivalid)) {
     // the caller decided there are no nulls (PrimitiveTake :1176 uses the null COUNTS);
@@ -215,9 +251,14 @@ AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, c
     default: return ah_fail(c, AH_EINVALID, "invalid values byte width for take");  // :1189
   }
   if (rc != AH_OK) return rc;
-  if (out_valid && out_null_count_host) {
+  if (out_valid && (out_null_count_host || status_dev)) {
     rc = ah_popcount_async(c, out_valid, 0, nidx, valid_total);
     if (rc != AH_OK) return rc;
+  }
+  if (status_dev) {   // no round trip: the caller looks at the two words when (and if) it wants to
+    take_status_kernel<<<1, 1, 0, c->stream>>>(first_bad, valid_total, out_valid != nullptr, nidx, (unsigned long long*)status_dev);
+    AH_LAUNCH_CHECK(c);
+    return AH_OK;
   }
   AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[1], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
@@ -241,6 +282,8 @@ AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, c
   if (out_null_count_host) *out_null_count_host = out_valid ? nidx - (int64_t)nvalid : 0;
   return AH_OK;
 }
+
+}  // namespace
 
 AH_EXPORT int ah_take_boolean(ah_ctx* c, const uint8_t* data, const uint8_t* vvalid, int64_t voff, int64_t nvalues, int idx_byte_width,
                               int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check,

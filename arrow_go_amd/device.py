@@ -285,6 +285,19 @@ class Context:
                                                    C.byref(r) if want_null_count else None))
         return r.value
 
+    def filter_primitive_dev(self, byte_width: int, values, vvalid, voff: int, fdata, fvalid, foff: int, n: int, null_sel: int,
+                             out_values, out_valid, status_dev) -> None:
+        """No count call, no host round trip: outputs sized for n rows, {selected, null count} left in `status_dev` (16 bytes)."""
+        check(self.handle, lib.ah_filter_primitive_dev(self.handle, byte_width, _ptr(values), _ptr(vvalid), voff, _ptr(fdata),
+                                                       _ptr(fvalid), foff, n, null_sel, _ptr(out_values), _ptr(out_valid), _ptr(status_dev)))
+
+    def take_primitive_dev(self, byte_width: int, values, vvalid, voff: int, nvalues: int, idx_byte_width: int, idx_signed: bool,
+                           idx, ivalid, ioff: int, nidx: int, out_values, out_valid, status_dev) -> None:
+        """No host round trip: {position of the first out-of-range index or 2^64 − 1, null count} left in `status_dev` (16 bytes)."""
+        check(self.handle, lib.ah_take_primitive_dev(self.handle, byte_width, _ptr(values), _ptr(vvalid), voff, nvalues,
+                                                     idx_byte_width, int(idx_signed), _ptr(idx), _ptr(ivalid), ioff, nidx,
+                                                     _ptr(out_values), _ptr(out_valid), _ptr(status_dev)))
+
     def filter_to_indices(self, fdata, fvalid, foff: int, n: int, null_sel: int, n_out: int, out_idx, out_valid) -> int:
         r = C.c_int64()
         check(self.handle, lib.ah_filter_to_indices(self.handle, _ptr(fdata), _ptr(fvalid), foff, n, null_sel, n_out,

@@ -214,6 +214,24 @@ func (x *Context) TakePrimitive(byteWidth int, values, vvalid unsafe.Pointer, vo
 	return int64(r), err
 }
 
+// FilterPrimitiveDev / TakePrimitiveDev: the same kernels without the host round trip — outputs sized for the worst case,
+// {selected rows, nulls} resp. {position of the first out-of-range index or MaxUint64, nulls} left in 16 bytes of device memory.
+func (x *Context) FilterPrimitiveDev(byteWidth int, values, vvalid unsafe.Pointer, voff int64, fdata, fvalid unsafe.Pointer,
+	foff, n int64, nullSel int, outValues, outValid, statusDev unsafe.Pointer) error {
+	return x.err(C.ah_filter_primitive_dev(x.c, C.int(byteWidth), values, (*C.uint8_t)(vvalid), C.int64_t(voff), (*C.uint8_t)(fdata),
+		(*C.uint8_t)(fvalid), C.int64_t(foff), C.int64_t(n), C.int(nullSel), outValues, (*C.uint8_t)(outValid), (*C.int64_t)(statusDev)))
+}
+
+func (x *Context) TakePrimitiveDev(byteWidth int, values, vvalid unsafe.Pointer, voff, nvalues int64, idxWidth int, idxSigned bool,
+	idx, ivalid unsafe.Pointer, ioff, nidx int64, outValues, outValid, statusDev unsafe.Pointer) error {
+	s := C.int(0)
+	if idxSigned {
+		s = 1
+	}
+	return x.err(C.ah_take_primitive_dev(x.c, C.int(byteWidth), values, (*C.uint8_t)(vvalid), C.int64_t(voff), C.int64_t(nvalues),
+		C.int(idxWidth), s, idx, (*C.uint8_t)(ivalid), C.int64_t(ioff), C.int64_t(nidx), outValues, (*C.uint8_t)(outValid), (*C.uint64_t)(statusDev)))
+}
+
 // CmpFilterSumInt64 is the fused Compare→Filter→Sum (no reference analogue).
 func (x *Context) CmpFilterSumInt64(cmpop int, values, valid unsafe.Pointer, off, n, threshold int64) (sum, count int64, err error) {
 	var s, c C.int64_t

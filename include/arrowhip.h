@@ -266,6 +266,13 @@ int ah_filter_count(ah_ctx* ctx, const uint8_t* fdata, const uint8_t* fvalid, in
 int ah_filter_primitive(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
                         const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
                         int64_t n_out, void* out_values, uint8_t* out_valid, int64_t* out_null_count_host);
+/* The same compaction without the count call and without a host round trip, for pipelines that
+ * keep going on the stream: out_values holds n·byte_width bytes and out_valid (iff either input has
+ * nulls) ceil(n/8) — the worst case — and status_dev[0] = rows selected, status_dev[1] = output
+ * null count are left in DEVICE memory (16 bytes, readable after ah_sync or by the next kernel). */
+int ah_filter_primitive_dev(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                            const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                            void* out_values, uint8_t* out_valid, int64_t* status_dev /* [2] */);
 /* GetTakeIndices (kernels/vector_selection.go:102-236), uint32 flavour: the mask as
  * an index vector so FilterRecordBatch can gather N columns with one scan. */
 int ah_filter_to_indices(ah_ctx* ctx, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,
@@ -284,6 +291,15 @@ int ah_take_primitive(ah_ctx* ctx, int byte_width, const void* values, const uin
                       const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check,
                       void* out_values, uint8_t* out_valid, int64_t* out_null_count_host,
                       int64_t* bad_index_host);
+/* Take without the host round trip: status_dev[0] = POSITION (not value) of the first valid index
+ * that is out of range, UINT64_MAX when there is none — the output is then unspecified at the
+ * offending rows (payload 0, validity 0) and the caller raises checkIndexBounds' error itself;
+ * status_dev[1] = output null count (0 without out_valid).  Device memory, 16 bytes.  The one wait
+ * left is the path choice for columns ≥ 64 MiB gathered by ≥ 2^20 indices (a 64 × 255-neighbour sample). */
+int ah_take_primitive_dev(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                          int64_t nvalues, int idx_byte_width, int idx_signed, const void* idx,
+                          const uint8_t* ivalid, int64_t ioff, int64_t nidx,
+                          void* out_values, uint8_t* out_valid, uint64_t* status_dev /* [2] */);
 
 /* ---- hashing ------------------------------------------------------------------------
  * unique / dictionary_encode over 8-byte keys == doAppendNumeric[uint64] over

@@ -34,7 +34,7 @@ for lg, zipf in cases:
         ctx.set_option("groupby_partition", 0); r[f"{kind}_idbased_ms"] = timed(hs)
         ctx.set_option("groupby_partition", 1); r[f"{kind}_auto_ms"] = timed(hs)
         r[f"{kind}_groups"] = int(hs()[0])
-    if not quick and not zipf and lg <= 12:
+    if not zipf and lg <= 12:
         ctx.set_option("groupby_partition", -2); r["f64_direct_ms"] = timed(lambda: ctx.hash_sum("f64", keys, None, 0, vals, None, 0, hrows, dic, sums, cnts))
         ctx.set_option("groupby_partition", 1)
     if not quick and not zipf and lg >= 21:

@@ -318,6 +318,39 @@ class HipBackend:
         ov = ovb.download(np.uint8, (idx.size + 7) // 8) if want_valid else None
         return STATUS_OK, out, ov, nulls, 0
 
+    # -- the *_dev flavours: worst-case outputs, status words fetched after the fact
+    def filter_dev(self, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid, misalign=0):
+        values = np.ascontiguousarray(values)
+        w = values.dtype.itemsize
+        vb, vp = self._up(values, misalign)
+        vvb, vvp = self._upbits(vvalid)
+        fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
+        ob = self.c.alloc(n * w + 128); ob.memset(0xCD)
+        ovb = self.c.alloc((n + 7) // 8 + 64) if want_valid else None
+        if ovb is not None:
+            ovb.memset(0xCD)
+        st = self.c.alloc(64); st.memset(0xCD)
+        self.c.filter_primitive_dev(w, vp, vvp, voff, fp, fvp, foff, n, null_sel, ob, ovb, st)
+        n_out, nulls = (int(v) for v in st.download(np.int64, 2))
+        out = ob.download(values.dtype, n_out)
+        ov = ovb.download(np.uint8, (n_out + 7) // 8) if want_valid else None
+        return out, ov, nulls
+
+    def take_dev(self, values, vvalid, voff, idx, ivalid, ioff, want_valid):
+        """→ (values, validity bytes, null count, position of the first out-of-range index or None)"""
+        values = np.ascontiguousarray(values); idx = np.ascontiguousarray(idx)
+        vb, vp = self._up(values); vvb, vvp = self._upbits(vvalid)
+        ib, ip = self._up(idx); ivb, ivp = self._upbits(ivalid)
+        ob = self.c.alloc(idx.size * values.dtype.itemsize + 64); ob.memset(0xCD)
+        ovb = self.c.alloc((idx.size + 7) // 8 + 64) if want_valid else None
+        st = self.c.alloc(64); st.memset(0xCD)
+        self.c.take_primitive_dev(values.dtype.itemsize, vp, vvp, voff, values.size, idx.dtype.itemsize, idx.dtype.kind == "i",
+                                  ip, ivp, ioff, idx.size, ob, ovb, st)
+        bad, nulls = (int(v) for v in st.download(np.uint64, 2))
+        out = ob.download(values.dtype, idx.size)
+        ov = ovb.download(np.uint8, (idx.size + 7) // 8) if want_valid else None
+        return out, ov, nulls, (None if bad == 2**64 - 1 else bad)
+
     def cumulative_sum(self, values, valid, off, start=None, skip_nulls=False, checked=False, misalign=0):
         import arrow_go_amd as ah
         values = np.ascontiguousarray(values)

@@ -232,6 +232,48 @@ def test_filter_bit_exact(hip, orc_be, dtype):
                         assert hip.filter_count(fdata, fvalid, foff, n, null_sel) == len(e[0])
 
 
+def test_filter_dev_flavour(hip, orc_be):
+    """ah_filter_primitive_dev: no count call, worst-case outputs, {selected, nulls} left on the device — same bytes"""
+    rng = np.random.default_rng(44)
+    for dtype, n in [(np.int64, 1), (np.int64, 70001), (np.uint8, 40000), (np.float32, 4096 * 3 + 5)]:
+        vals = rand(rng, dtype, n)
+        for sel_p in (0.0, 0.3, 1.0):
+            fdata = rand_bits(rng, n + 80, sel_p)
+            for vvalid, fvalid, voff, foff in [(None, None, 0, 0), (rand_bits(rng, n + 80, 0.9), rand_bits(rng, n + 80, 0.9), 3, 9)]:
+                want_valid = vvalid is not None
+                for null_sel in (DROP, EMIT):
+                    g = hip.filter_dev(vals, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid)
+                    e = orc_be.filter(vals, vvalid, voff, fdata, fvalid, foff, n, null_sel, want_valid)
+                    assert g[0].tobytes() == e[0].tobytes(), (dtype, n, sel_p, null_sel)
+                    if want_valid:
+                        assert g[1].tobytes() == e[1].tobytes(), (dtype, n, sel_p, null_sel)
+                    assert g[2] == e[2]
+
+
+def test_take_dev_flavour(hip, orc_be):
+    """ah_take_primitive_dev: same bytes, {first offending position, nulls} left on the device"""
+    rng = np.random.default_rng(54)
+    for vdtype, idtype, nvalues, nidx in [(np.int64, np.int32, 5000, 70001), (np.uint8, np.uint16, 300, 4099), (np.float32, np.int64, 1, 1)]:
+        vals = rand(rng, vdtype, nvalues)
+        idx = rng.integers(0, nvalues, nidx).astype(idtype)
+        for vvalid, ivalid in [(None, None), (rand_bits(rng, nvalues + 8, 0.9), rand_bits(rng, nidx + 8, 0.9))]:
+            want_valid = vvalid is not None
+            g = hip.take_dev(vals, vvalid, 0, idx, ivalid, 0, want_valid)
+            e = orc_be.take(vals, vvalid, 0, idx, ivalid, 0, True, want_valid)
+            assert g[3] is None and g[0].tobytes() == e[1].tobytes()
+            if want_valid:
+                assert g[1].tobytes() == e[2].tobytes() and g[2] == e[3]
+    # an out-of-range index: its position (the first one in index order, null index slots skipped) instead of an error
+    vals = np.arange(1000, dtype=np.int64)
+    idx = rng.integers(0, 1000, 50000).astype(np.int32)
+    bad = np.sort(rng.choice(50000, 20, replace=False))
+    idx[bad] = 1000 + np.arange(20)
+    ivalid = rand_bits(rng, 50000, 0.7)
+    assert hip.take_dev(vals, None, 0, idx, None, 0, False)[3] == bad[0]
+    ok = np.unpackbits(ivalid, bitorder="little")[:50000].astype(bool)
+    assert hip.take_dev(vals, None, 0, idx, ivalid, 0, True)[3] == bad[ok[bad]][0]
+
+
 def test_filter_all_and_none(hip, orc_be):
     n = 40000
     vals = np.arange(n, dtype=np.int64)
