@@ -344,6 +344,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   // one pending group per lane: {key, 128-bit sum, count | flags, first row}.  A row with the key of the lane's previous row
   // is added in registers: a key that owns most of a chunk (skewed columns) would otherwise put every lane of every wave
   // on ONE LDS address, and same-address LDS atomics are served one lane at a time.
+  const unsigned lkey_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)l_key;   // LDS byte address of the key table
   bool p_live = false;
   unsigned long long p_key = 0, p_lo = 0, p_hi = 0;
   unsigned p_kw = 0, p_cf = 0, p_first = kNoRow;
@@ -360,7 +361,13 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       // Two multiplies: inside a partition the keys agree in the top bits of gb_mix, so a different function is wanted anyway.
       unsigned g = ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 20) & (unsigned)(kSlots - 4);
       for (;;) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(&l_key[g]), c = *reinterpret_cast<const ulonglong2*>(&l_key[g + 2]);
+        // Two ds_read_b128, spelled out: the compiler splits either 16-byte half into a ds_read2_b64 (it does not see the
+        // alignment through the loop-carried slot number), which serves 16 lanes per LDS cycle over 32 banks where
+        // ds_read_b128 serves 16 lanes over 64 — and bank conflicts are ¾ of this kernel's LDS time (SQ_LDS_BANK_CONFLICT).
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 a, c;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a), "=&v"(c) : "v"(lkey_base + g * 8u) : "memory");
         const bool h0 = a.x == key, h1 = a.y == key, h2 = c.x == key, h3 = c.y == key;
         const bool e0 = a.x == kEmpty, e1 = a.y == kEmpty, e2 = c.x == kEmpty, e3 = c.y == kEmpty;
         const bool y0 = h0 || e0, y1 = h1 || e1, y2 = h2 || e2, y3 = h3 || e3;

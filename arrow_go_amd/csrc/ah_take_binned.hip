@@ -73,6 +73,10 @@ __device__ __forceinline__ void load_tile_indices(const IdxT* __restrict__ idx, 
     vbits[g] = HAS_IV ? (unsigned)ah_load_bits64(ivalid, ioff + i0, left) : (left >= 4 ? 0xfu : ((1u << left) - 1u));
   }
   bool any_oob = false;
+  // A null index slot gathers nothing that is kept (the un-permute pass clears its row), but it must not be binned through
+  // index 0: with 10 % nulls a tenth of every tile's rows would land on ONE bin counter — same-address LDS atomics, served one
+  // lane at a time (the histogram pass went 97 → 189 µs).  Null slots get a scattered in-range index instead.
+  const int lgv = 63 - __builtin_clzll(nvalues < 0xffffffffull ? (nvalues ? nvalues : 1) : 0xffffffffull);   // 2^lgv ≤ nvalues
 #pragma unroll
   for (int g = 0; g < GROUPS; g++) {
 #pragma unroll
@@ -82,8 +86,9 @@ __device__ __forceinline__ void load_tile_indices(const IdxT* __restrict__ idx, 
       const uint64_t w = (uint64_t)(UIdx)s;
       const bool valid = (vbits[g] >> j) & 1u;     // in range of the column AND a non-null index slot
       const bool oob = (std::is_signed<IdxT>::value && s < 0) || w >= nvalues;  // helpers.go:937-939
-      live[k] = FULL ? true : (base + (int64_t)g * 4 * THREADS + 4 * (int64_t)threadIdx.x + j < nidx);
-      u[k] = (valid && !oob) ? (unsigned)w : 0u;
+      const int64_t row = base + (int64_t)g * 4 * THREADS + 4 * (int64_t)threadIdx.x + j;
+      live[k] = FULL ? true : (row < nidx);
+      u[k] = valid ? (oob ? 0u : (unsigned)w) : (HAS_IV ? (((unsigned)row * 2654435761u) >> 1) >> (31 - lgv) : 0u);
       any_oob |= valid && oob;
     }
   }
