@@ -304,6 +304,23 @@ struct KR {
   }
 };
 __device__ __forceinline__ bool kr_less(const KR& a, const KR& b) { return KR::less(a, b); }
+// One 64-bit word per element where the bucket allows it.  The network is all vector instructions (SQ counters: the vector
+// unit is saturated, LDS and memory idle), and a (key, row) pair costs three exchanged words, a two-level comparison and
+// three selects per stage.  The keys of a bucket lie close together — it is 1 / 2^21 of the column's quantile range — so:
+//   tier 1: all keys within 2^36 of lane 0's → (key − key₀ + 2^36) << 27 | row, unique, sorted as plain integers;
+//   tier 2: within 2^56 → … << 7 | position in the bucket, and the rows are fetched by position afterwards (ds_bpermute);
+//           two equal keys would come out in bucket order instead of row order — seen by comparing neighbours, and then,
+//           as for everything wider, the pairs go through the network (equal keys mean a dense bucket: tier 1 took those).
+struct C64 {
+  unsigned long long c;
+  static __device__ __forceinline__ bool less(const C64& a, const C64& b) { return a.c < b.c; }
+  static __device__ __forceinline__ C64 xchg(const C64& a, int j, int lane) {
+    C64 o;
+    o.c = ((unsigned long long)ms_xor_lane((unsigned)(a.c >> 32), j, lane) << 32) | ms_xor_lane((unsigned)a.c, j, lane);
+    return o;
+  }
+};
+constexpr int kMsRowBits = 27;   // the MSD path takes ≤ 2^27 rows (ah_sort_msd_temp_bytes)
 template <int SLOTS>
 __device__ __forceinline__ void ms_sort_bucket(const unsigned long long* __restrict__ keys, const unsigned* rows, unsigned s, int m,
                                                int lane, unsigned* out_rows, unsigned long long* __restrict__ out64) {
@@ -314,12 +331,61 @@ __device__ __forceinline__ void ms_sort_bucket(const unsigned long long* __restr
     x[sl].k = i < m ? keys[s + i] : ~0ull;
     x[sl].r = i < m ? rows[s + i] : ~0u;
   }
+  auto emit = [&](int i, unsigned row) { if (i < m) { if (out64) out64[s + i] = row; else out_rows[s + i] = row; } };
+  if (SLOTS <= 2) {
+    const unsigned long long k0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(x[0].k >> 32)) << 32) |
+                                  __builtin_amdgcn_readfirstlane((unsigned)x[0].k);   // lane 0 of slot 0 is inside the bucket (m ≥ 1)
+    bool fits1 = true, fits2 = true;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; sl++) {
+      const bool in = sl * 64 + lane < m;
+      fits1 = fits1 && (!in || x[sl].k - k0 + (1ull << 36) < (1ull << 37));
+      fits2 = fits2 && (!in || x[sl].k - k0 + (1ull << 56) < (1ull << 57));
+    }
+    if (__all(fits1)) {
+      C64 y[SLOTS];
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; sl++)
+        y[sl].c = sl * 64 + lane < m ? ((x[sl].k - k0 + (1ull << 36)) << kMsRowBits) | x[sl].r : ~0ull;
+      ms_bitonic<C64, SLOTS>(y, lane);
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; sl++) emit(sl * 64 + lane, (unsigned)y[sl].c & ((1u << kMsRowBits) - 1u));
+      return;
+    }
+    if (__all(fits2)) {
+      C64 y[SLOTS];
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; sl++)
+        y[sl].c = sl * 64 + lane < m ? ((x[sl].k - k0 + (1ull << 56)) << 7) | (unsigned)(sl * 64 + lane) : ~0ull;
+      ms_bitonic<C64, SLOTS>(y, lane);
+      bool tie = false;
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; sl++) {
+        unsigned long long nxt = __shfl_down(y[sl].c, 1, 64);
+        if (sl + 1 < SLOTS) {
+          const unsigned long long head = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(y[sl + 1 < SLOTS ? sl + 1 : sl].c >> 32)) << 32) |
+                                          __builtin_amdgcn_readfirstlane((unsigned)y[sl + 1 < SLOTS ? sl + 1 : sl].c);
+          nxt = lane == 63 ? head : nxt;
+        } else if (lane == 63) {
+          nxt = ~0ull;
+        }
+        tie = tie || (sl * 64 + lane + 1 < m && (y[sl].c >> 7) == (nxt >> 7));
+      }
+      if (!__any(tie)) {
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) {
+          const unsigned at = (unsigned)y[sl].c & 127u;
+          unsigned row = __shfl(x[0].r, (int)(at & 63u), 64);
+          if (SLOTS > 1) { const unsigned row1 = __shfl(x[SLOTS > 1 ? 1 : 0].r, (int)(at & 63u), 64); row = (at >> 6) ? row1 : row; }
+          emit(sl * 64 + lane, row);
+        }
+        return;
+      }
+    }
+  }
   ms_bitonic<KR, SLOTS>(x, lane);
 #pragma unroll
-  for (int sl = 0; sl < SLOTS; sl++) {
-    const int i = sl * 64 + lane;
-    if (i < m) { if (out64) out64[s + i] = x[sl].r; else out_rows[s + i] = x[sl].r; }
-  }
+  for (int sl = 0; sl < SLOTS; sl++) emit(sl * 64 + lane, x[sl].r);
 }
 
 __global__ __launch_bounds__(256) void ms_local_kernel(const unsigned long long* __restrict__ keys, const unsigned* rows,

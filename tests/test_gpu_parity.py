@@ -1035,6 +1035,8 @@ def test_sort_indices_msd_path(ctx, hip, orc_be):
         "int64 two clusters": np.where(rng.random(n) < 0.3, rng.integers(0, 10**6, n), 2**60 + rng.integers(0, 2**40, n)),
         "int64 ties among wide keys": rng.integers(0, 2**40, n // 4, dtype=np.int64)[rng.integers(0, n // 4, n)] * 1000003,
         "float32": (rng.standard_normal(n) * 1e3).astype(np.float32),
+        "int64 dense, ties inside the buckets": rng.integers(0, 2**27, n, dtype=np.int64),          # one-word elements carrying the row
+        "int64 wide, a few equal pairs": np.concatenate([w := rng.integers(-2**62, 2**62, n - 5000, dtype=np.int64), w[:5000]])[rng.permutation(n)],
         "int64 heavy duplicates (falls back)": rng.integers(0, 2**50, 3000, dtype=np.int64)[rng.integers(0, 3000, n)],
         "int64 one hot key (falls back)": np.where(rng.random(n) < 0.2, np.int64(123456789012345), rng.integers(-2**62, 2**62, n, dtype=np.int64)),
     }
