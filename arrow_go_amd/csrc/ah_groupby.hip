@@ -68,11 +68,11 @@ __device__ __forceinline__ unsigned gb_part(uint64_t m, int lp) { return (unsign
 // in LDS drops the keys this workgroup has just seen: without it a hot key sends every sampled row to ONE bitmap word —
 // 2^21 same-address atomics = 0.65 ms, and still 0.49 ms with a look-before-set on a Zipf column.
 __global__ __launch_bounds__(1024) void gb_sample_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
-                                                          int64_t n, int64_t ngroups, int64_t stride, int g0, unsigned* __restrict__ bm, unsigned mmask) {
+                                                          int64_t n, int64_t ngroups, int64_t stride, int g0, int gstep, unsigned* __restrict__ bm, unsigned mmask) {
   __shared__ unsigned long long s_seen[1024];
   s_seen[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t g = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + g0;
+  const int64_t g = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * gstep + g0;
   const int64_t i = g * stride + (threadIdx.x & 63);
   if (g >= ngroups || i >= n || !ah_bit(kvalid, koff + i)) return;
   const uint64_t m = gb_mix(keys[i]) | 1ull;
@@ -1152,22 +1152,22 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
     int rc = ah_temp_reserve(c, kBits / 8, (void**)&bm);
     if (rc != AH_OK) return rc;
     AH_HIP(c, hipMemsetAsync(bm, 0, kBits / 8, c->stream));
-    for (int half = 0; half < 2; half++) {
-      gb_sample_kernel<<<(unsigned)ah_ceil_div(groups / 2, 16), 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, n, groups, stride, half, bm, kBits - 1);
-      AH_LAUNCH_CHECK(c);
-      if ((rc = ah_popcount_async(c, (const uint8_t*)bm, 0, kBits, ones + half)) != AH_OK) return rc;
-    }
-    AH_HIP(c, hipMemcpyAsync(&c->pinned[8], ones, 16, hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
     auto distinct = [&](uint64_t set, double rows) {   // linear counting: M·ln(M / zeros)
       const double z = (double)kBits - (double)set;
       const double d = z < 1.0 ? rows : -(double)kBits * log(z / (double)kBits);
       return d > rows ? rows : d;
     };
+    for (int half = 0; half < 2; half++) {
+      gb_sample_kernel<<<(unsigned)ah_ceil_div(groups / 2, 16), 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, n, groups, stride, half, 2, bm, kBits - 1);
+      AH_LAUNCH_CHECK(c);
+      if ((rc = ah_popcount_async(c, (const uint8_t*)bm, 0, kBits, ones + half)) != AH_OK) return rc;
+    }
+    AH_HIP(c, hipMemcpyAsync(&c->pinned[8], ones, 16, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
     const double sampled = (double)groups * 64.0;
     const double dh = distinct(*(volatile uint64_t*)&c->pinned[8], sampled / 2), ds = distinct(*(volatile uint64_t*)&c->pinned[9], sampled);
     double est = gb_extrapolate(ds, sampled, (double)n);
-    if (est <= 2048.0) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
+    if (est <= 2048.0 && is_f64) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
     if (est <= 4300.0) return AH_OK;                   // all groups still fit the id-based path's LDS table: ≈ 1 ms there, no better here
     // Keys drawn evenly from C values give a curve that the second half of the sample must follow; a heavy-tailed column
     // (Zipf) keeps bringing new keys long after that curve has flattened, and its full distinct count is several times the
