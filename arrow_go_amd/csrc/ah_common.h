@@ -163,6 +163,15 @@ __device__ __forceinline__ int ah_bit(const uint8_t* __restrict__ bm, int64_t i)
 // one bit in [pos, pos + nvalid) — never touches a word outside the caller's
 // range, so it cannot fault on the last page of an allocation.  Bits past nvalid
 // are returned as 0.  NULL bitmap → all ones (masked to nvalid).
+__device__ __forceinline__ uint64_t ah_load_bits64(const uint8_t* __restrict__ bm, int64_t pos, int nvalid);
+// The validity word of the 64 consecutive rows a wave is looking at (row `pos0` = the wave's lane 0, the same in every lane):
+// the position is moved to scalar registers, so the two 8-byte loads are scalar loads — one per wave instead of a byte load
+// (a vector memory instruction with its address arithmetic) per lane and row.
+__device__ __forceinline__ uint64_t ah_wave_bits64(const uint8_t* __restrict__ bm, int64_t pos0, int64_t nrows_left) {
+  const int64_t p = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pos0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pos0);
+  const int64_t left = ((int64_t)__builtin_amdgcn_readfirstlane((int)(nrows_left >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)nrows_left);
+  return ah_load_bits64(bm, p, left >= 64 ? 64 : (int)(left < 0 ? 0 : left));
+}
 __device__ __forceinline__ uint64_t ah_load_bits64(const uint8_t* __restrict__ bm, int64_t pos, int nvalid) {
   uint64_t mask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1);
   if (nvalid <= 0) return 0;

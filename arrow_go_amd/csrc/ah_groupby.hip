@@ -100,9 +100,15 @@ __global__ __launch_bounds__(kGbHistThreads) void gb_hist_kernel(const unsigned 
 #pragma unroll
   for (int u = 0; u < kGbHistRows; u++) {
     const int64_t i = base + u * kGbHistThreads + threadIdx.x;
+    const int64_t w0 = base + u * kGbHistThreads + (threadIdx.x & ~63);   // the wave's first row of this step
+    // the wave's 64 validity bits in one scalar load; null keys all belong to partition 0 and are counted once per wave —
+    // a tenth of a tile's rows on one LDS counter would be served a lane at a time
+    const unsigned long long vw = ah_wave_bits64(kvalid, koff + w0, n - w0);   // 0 past the end
+    const unsigned long long in = n - w0 >= 64 ? ~0ull : (n > w0 ? (1ull << (n - w0)) - 1ull : 0ull);
+    const unsigned long long nulls = in & ~vw;
     if (i >= n) continue;
-    const unsigned p = ah_bit(kvalid, koff + i) ? gb_part(gb_mix(k[u]), lp) : 0u;
-    atomicAdd(&s_cnt[p], 1u);
+    if ((vw >> (threadIdx.x & 63)) & 1ull) atomicAdd(&s_cnt[gb_part(gb_mix(k[u]), lp)], 1u);
+    else if ((nulls & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0) atomicAdd(&s_cnt[0], (unsigned)__popcll(nulls));
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nb; b += kGbHistThreads) cnt_tm[tile * nb + b] = s_cnt[b];
@@ -160,13 +166,26 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
   for (int u = 0; u < kGbRows; u++) {
     const int64_t i = base + u * kThreads + threadIdx.x;
     rw[u] = 0; bin[u] = 0; rank[u] = 0;
+    // the wave's validity words by scalar loads (0 past the end)
+    const int64_t w0 = base + u * kThreads + (threadIdx.x & ~63);
+    const unsigned long long kw64 = ah_wave_bits64(kvalid, koff + w0, n - w0), vw64 = ah_wave_bits64(vvalid, voff + w0, n - w0);
+    const bool kv = (kw64 >> (threadIdx.x & 63)) & 1ull, vv = (vw64 >> (threadIdx.x & 63)) & 1ull;
+    // null keys (partition 0) take their ranks from ONE counter update per wave: same-address LDS atomics are served a lane at a time
+    const unsigned long long nulls = __ballot(live[u] && !kv);
     if (live[u]) {
-      const bool kv = ah_bit(kvalid, koff + i), vv = ah_bit(vvalid, voff + i);
+      k[u] = kv ? k[u] : 0ull;   // one key for all null rows: the aggregate pass adds consecutive rows of one key in registers
       bin[u] = kv ? gb_part(gb_mix(k[u]), lp) : 0u;
       rw[u] = (unsigned)i | (kv ? 0u : kKeyNull) | (vv ? 0u : kValNull);
-      rank[u] = atomicAdd(&s_cnt[bin[u]], 1u);
+      if (kv) rank[u] = atomicAdd(&s_cnt[bin[u]], 1u);
       const unsigned long long a = v[u] & 0x7fffffffffffffffull;   // |x| of finite doubles order like their bit patterns
       if (tile_max && vv && (a >> 52) != 0x7ff && a > vmax) vmax = a;
+    }
+    if (nulls) {   // wave-uniform
+      const int leader = __builtin_ctzll(nulls);
+      unsigned first = 0;
+      if ((int)(threadIdx.x & 63) == leader) first = atomicAdd(&s_cnt[0], (unsigned)__popcll(nulls));
+      first = __shfl(first, leader, 64);
+      if (live[u] && !kv) rank[u] = first + (unsigned)__popcll(nulls & ((1ull << (threadIdx.x & 63)) - 1ull));
     }
   }
   if (tile_max) {
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
                                                                  const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
                                                                  const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat,
                                                                  const uint8_t* __restrict__ kvalid, int64_t koff, const uint8_t* __restrict__ vvalid,
-                                                                 int64_t voff, int64_t nrows) {
+                                                                 int64_t voff, int64_t nrows, int64_t seg_rows) {
   // flat = 2 ("direct", ≤ 2048 expected groups): no cut at all — keys / vals ARE the columns, a workgroup takes 2^18 consecutive rows
   // and the chunks are merged into ONE global table with atomics.
   // flat = 1: one workgroup per partition (blockIdx = partition; thousands of partitions from the two-level cut), tables of
@@ -297,13 +316,13 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   __shared__ unsigned long long l_hi[FX ? kLSlots : 1];
   __shared__ unsigned l_cnt[kLSlots];
   __shared__ unsigned l_first[kLSlots];
-  __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_wsum[kThreads / 64];
   __shared__ unsigned s_used, s_direct;
-  __shared__ int s_part, s_chunk, s_multi;
+  __shared__ int s_part;
+  __shared__ unsigned long long s_snap[2];
   const int t = threadIdx.x;
   int part;
   bool multi;
-  int64_t r0, r1;
+  int64_t r0, r1, seg_lo = 0, seg_hi = 0;
   if (flat == 2) {
     part = 0;
     multi = true;
@@ -316,29 +335,36 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     r0 = binstart[part];
     r1 = binstart[part + 1];
   } else {
-    // which records?  workgroup → (partition, chunk): prefix sum over the partitions' chunk counts
-    unsigned rows = 0, ch = 0;
-    if (t < nb) { rows = binstart[t + 1] - binstart[t]; ch = gb_chunks(rows); }
-    s_cnt[t] = ch;
+    // which records?  Equal shares of the partition-ordered records, whatever partitions a share spans: workgroup w takes
+    // [w·R, (w + 1)·R) and walks the partition segments inside it, one table per segment.  (One workgroup per CU fits, so a
+    // launch is ONE round of equal length — cut per partition into 2^18-row chunks, a partition that is larger than the
+    // others (null keys all go to partition 0; skewed keys) added a second round for a few workgroups: 10 % null keys cost 35 %.)
+    // A share's end that lies within a quarter share of a partition boundary moves there (both neighbours compute the same
+    // point): partitions much smaller than a share are then taken whole — their tables leave as copies, not through the
+    // atomic merge — and a large partition's end does not leave a sliver to the next workgroup.
+    const int64_t total = (int64_t)binstart[nb], x0 = (int64_t)blockIdx.x * seg_rows, x1 = x0 + seg_rows, tol = seg_rows >> 2;
+    if (x0 >= total) return;
+    if (t < 2) s_snap[t] = ~0ull;
     if (t == 0) s_part = -1;
     __syncthreads();
-    block_excl_scan(s_cnt, s_start, s_wsum, nb);
-    if (t < nb && ch && s_start[t] <= blockIdx.x && blockIdx.x < s_start[t] + ch) { s_part = t; s_chunk = (int)(blockIdx.x - s_start[t]); s_multi = ch > 1; }
+    if (t < nb) {
+      const int64_t b = (int64_t)binstart[t], d0 = b > x0 ? b - x0 : x0 - b, d1 = b > x1 ? b - x1 : x1 - b;
+      if (d0 <= tol) atomicMin(&s_snap[0], ((unsigned long long)d0 << 32) | (unsigned long long)b);
+      if (d1 <= tol) atomicMin(&s_snap[1], ((unsigned long long)d1 << 32) | (unsigned long long)b);
+    }
     __syncthreads();
-    if (s_part < 0) return;
+    seg_lo = s_snap[0] == ~0ull ? x0 : (int64_t)(s_snap[0] & 0xffffffffull);
+    seg_hi = x1 >= total ? total : (s_snap[1] == ~0ull ? x1 : (int64_t)(s_snap[1] & 0xffffffffull));
+    if (seg_lo >= seg_hi) return;
+    if (t < nb && (int64_t)binstart[t] <= seg_lo && seg_lo < (int64_t)binstart[t + 1]) s_part = t;
+    __syncthreads();
     part = s_part;
-    multi = s_multi != 0;
-    const int64_t b0 = binstart[part], b1 = binstart[part + 1];
-    const int64_t nch = gb_chunks((unsigned)(b1 - b0)), per = (b1 - b0 + nch - 1) / nch;   // equal shares
-    r0 = b0 + (int64_t)s_chunk * per;
-    r1 = r0 + per < b1 ? r0 + per : b1;
+    multi = true;
+    r0 = r1 = 0;
   }
-  for (int j = t; j < kLSlots; j += kThreads) { l_key[j] = kEmpty; l_lo[j] = 0; if (FX) l_hi[j] = 0; l_cnt[j] = 0; l_first[j] = kNoRow; }
-  if (t == 0) { s_used = 0; s_direct = 0; }
-  __syncthreads();
   int sh = 0;
   if (FX) sh = fx_shift(*absmax);
-  const int64_t gbase = (int64_t)part * (flat == 1 ? kFlatStride : kGStride);
+  int64_t gbase = (int64_t)part * (flat == 1 ? kFlatStride : kGStride);
   const int gspecial = flat == 1 ? kSlots : kGSlots;   // where the two special slots sit in the partition's global table
   bool went_direct = false;
   // one pending group per lane: {key, 128-bit sum, count | flags, first row}.  A row with the key of the lane's previous row
@@ -449,6 +475,20 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     if (b + kStep <= r1) load_step(b, std::true_type{});
     else if (b < r1) load_step(b, std::false_type{});
   };
+  for (;;) {   // one pass per partition segment of this workgroup's share (flat modes: exactly one)
+  if (flat == 0) {
+    const int64_t b0 = binstart[part], b1 = binstart[part + 1];
+    r0 = seg_lo > b0 ? seg_lo : b0;
+    r1 = seg_hi < b1 ? seg_hi : b1;
+    multi = !(r0 == b0 && r1 == b1);   // the whole partition is ours: its table leaves as a copy
+    gbase = (int64_t)part * kGStride;
+  }
+  if (r0 < r1) {
+  for (int j = t; j < kLSlots; j += kThreads) { l_key[j] = kEmpty; l_lo[j] = 0; if (FX) l_hi[j] = 0; l_cnt[j] = 0; l_first[j] = kNoRow; }
+  if (t == 0) { s_used = 0; s_direct = 0; }
+  __syncthreads();
+  went_direct = false;
+  p_live = false;
   load_any(r0);
   // The first step's loads are waited for HERE.  Entering the loop with them pending, the compiler's wait-count pass merges that
   // state with the back edge's and puts "at most 3 loads outstanding" in front of the row processing — which in the steady state
@@ -483,6 +523,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
         lo = has ? v[u] : 0ull;
       }
       const unsigned kw = rwu & kKeyNull;
+      if (DIRECT) k[u] = kw ? 0ull : k[u];   // one key for all null rows (the partition pass has done this for the other modes)
       const bool same = !live || (p_live && p_key == k[u] && p_kw == kw);
       if (!same) {
         if (p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
@@ -524,6 +565,11 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       else gs = gb_global_slot(gt.key, gbase, l_key[j], overflow);
       if (gs >= 0) gb_global_add<FX>(gt, gs, l_lo[j], FX ? l_hi[j] : 0ull, l_cnt[j], fr);
     }
+  }
+  __syncthreads();   // the next segment re-initialises the table
+  }
+  if (flat != 0 || (int64_t)binstart[part + 1] >= seg_hi) break;
+  part++;
   }
 }
 
@@ -1031,8 +1077,8 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   AH_LAUNCH_CHECK(c);
   gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
   AH_LAUNCH_CHECK(c);
-  if (is_f64) gb_aggregate_kernel<true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0);
-  else gb_aggregate_kernel<false><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0);
+  if (is_f64) gb_aggregate_kernel<true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0);
+  else gb_aggregate_kernel<false><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0);
   AH_LAUNCH_CHECK(c);
   gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
   AH_LAUNCH_CHECK(c);
@@ -1097,8 +1143,8 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
     AH_LAUNCH_CHECK(c);
   }
   const unsigned grid = (unsigned)ah_ceil_div(n, (int64_t)1 << kChunkLog2);
-  if (is_f64) gb_aggregate_kernel<true, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
-  else gb_aggregate_kernel<false, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n);
+  if (is_f64) gb_aggregate_kernel<true, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n, 0);
+  else gb_aggregate_kernel<false, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n, 0);
   AH_LAUNCH_CHECK(c);
   gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
   AH_LAUNCH_CHECK(c);
@@ -1249,9 +1295,13 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
     AH_LAUNCH_CHECK(c);
   }
   // ---- 3: aggregate
-  const unsigned grid = (unsigned)(P + (n >> kChunkLog2));   // ≥ Σ max(1, round(rows_p / chunk))
-  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0);
-  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0);
+  // one workgroup fits a CU: one round of equal shares (≥ 2^17 records each: a table costs its 136 KiB to set up and to write out)
+  int64_t nwg = n >> 17;
+  nwg = nwg < 1 ? 1 : (nwg > c->num_cu ? c->num_cu : nwg);
+  const int64_t seg_rows = ah_ceil_div(n, nwg);
+  const unsigned grid = (unsigned)nwg;
+  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
+  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank the groups by first row, write them out
   gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
