@@ -1,12 +1,11 @@
+# what is run at the end of a round: full GPU suite, smoke, bench line, per-workload PMC, group-by sweep, kernel stats of the
+# sort / group-by paths.  Outputs under gpurun_out/ (copied to profiles/ by hand, named per round).
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-bash scripts/gpu_prof_workloads.sh r02 2>&1 | tail -60
+bash scripts/gpu_final_check.sh
+bash scripts/gpu_prof_workloads.sh r02 2>&1 | tail -30
 cd $R
 timeout 600 python scripts/bench_groupby.py > gpurun_out/bench_groupby.json 2> gpurun_out/bench_groupby.err; tail -2 gpurun_out/bench_groupby.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_groupby.json'))
-for k,v in d['results'].items(): print(k, v)
-PY
+timeout 300 python scripts/bench_nullkeys.py > gpurun_out/bench_nullkeys.json 2> gpurun_out/bench_nullkeys.err
 cd /tmp
 for c in "27 int" "27 normal"; do
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o run -- python $R/scripts/bench_sort_one.py $c 1 > /tmp/prof_s.out 2> /tmp/prof_s.err
