@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   // software pipeline: the next step's loads (12 per lane) are in flight while this step's rows go through LDS.  The load step
   // only LOADS: anything that consumes a loaded value (the validity bits of the direct mode) would make it wait for memory
   // between the rows of one step, and a step that lies wholly inside the range runs without per-lane guards.
-  constexpr int U = 4;
+  constexpr int U = 4;   // (direct mode spills 8 registers at 4 rows per step; at 2 it does not and is 5 % slower)
   constexpr int64_t kStep = (int64_t)kThreads * U;
   unsigned long long nk[U], nv[U];
   unsigned nrw[U];                         // the row word — direct mode: the row's two validity BYTES, decoded when the row is processed
@@ -505,9 +505,9 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     for (int u = 0; u < U; u++) {
       const bool live = (unsigned)(u * kThreads + t) < left;   // a slot past the end adds nothing to whatever is pending
       unsigned rwu = rw[u];
-      if (DIRECT) {
-        const int64_t i = b + u * kThreads + t;
-        rwu = (unsigned)i | (((rwu >> ((koff + i) & 7)) & 1u) ? 0u : kKeyNull) | (((rwu >> (8 + ((voff + i) & 7))) & 1u) ? 0u : kValNull);
+      if (DIRECT) {   // in 32 bits: rows are below 2^29 here, and only the low three bits of the bit positions matter
+        const unsigned il = (unsigned)b + (unsigned)(u * kThreads + t);
+        rwu = il | (((rwu >> (((unsigned)koff + il) & 7u)) & 1u) ? 0u : kKeyNull) | (((rwu >> (8u + (((unsigned)voff + il) & 7u))) & 1u) ? 0u : kValNull);
       }
       const unsigned row = live ? rwu & kRowMask : kNoRow;
       // the addend, without branches: a null value adds nothing and is not counted; ±inf / NaN are counted and flagged

@@ -45,8 +45,7 @@ for lg, zipf in cases:
             ctx.set_option("groupby_partition", lp + 2); r[f"f64_P2^{lp}_ms"] = timed(lambda: ctx.hash_sum("f64", keys, None, 0, vals, None, 0, hrows, dic, sums, cnts))
         ctx.set_option("groupby_partition", 1)
     if only:
-        continue
-    if only:
+        res[f"2^{lg}" + ("_zipf1.1" if zipf else "")] = r
         continue
     enc = lambda: ctx.hash_u64_encode(keys, None, 0, hrows, False, ids, None, dic)
     ctx.set_option("hash_direct", 3); r["encode_sparse_table_ms"] = timed(enc)
