@@ -165,6 +165,9 @@ def per_kernel_table(ctx, rows, a, b, c, x):
         out[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "bytes": int(nbytes)}
 
     res = ctx.alloc(64)
+    # the chip's streaming ceiling in this very session: a device-to-device copy of 1 GiB, 2 bytes moved per byte copied
+    from arrow_go_amd._native import check as _check, lib as _lib
+    timed("ceiling_hipMemcpyDtoD", 16 * rows, lambda: _check(ctx.handle, _lib.ah_copy_async(ctx.handle, c.ptr, a.ptr, 8 * rows)))
     timed("sum_float64", 8 * rows, lambda: ctx.sum_float64_dev(x, rows, res))
     timed("sum_int64", 8 * rows, lambda: ctx.sum_int64_dev(a, rows, res))
     timed("add_int64", 24 * rows, lambda: ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, a, b, c, rows))
@@ -485,6 +488,8 @@ def main():
                 result["kernels"] = per_kernel_table(ctx, rows, a, b, c, x)
             except Exception as e:  # the table is informative; never lose the headline over it
                 result["kernels"] = {"error": repr(e)}
+            if isinstance(result["kernels"].get("ceiling_hipMemcpyDtoD"), dict):
+                result["roofline"]["measured_copy_GB/s"] = result["kernels"]["ceiling_hipMemcpyDtoD"]["GB/s"]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(min(rows, 1 << 26), 8)
