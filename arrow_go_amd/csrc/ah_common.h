@@ -38,6 +38,7 @@ struct ah_ctx {
   // take (ah_take_binned.hip): ARROWHIP_TAKE_BINNED 0 never / 1 auto / 2 whenever legal; _WINDOW_LOG2 bytes of `values` per
   // bin; _GATHER_WG_PER_CU occupancy cap of the gather pass.  Also settable per context: ah_ctx_set_option.
   int opt_take_binned, opt_take_window_log2, opt_take_gather_wg, opt_take_gather_load, opt_take_gather_lds;
+  int opt_groupby_keys;        // hash + sum: expected keys per partition the cut aims at (ARROWHIP_GROUPBY_KEYS; the LDS table admits 3584)
   int opt_groupby_partition;   // hash + sum (ah_groupby.hip): 0 never, 1 auto, k ≥ 2 always with 2^(k−2) partitions (ARROWHIP_GROUPBY_PARTITION)
   int opt_hash_direct;         // unique / dictionary_encode (ah_hash.hip): 0 ids in a separate pass, 1 direct ids, 2 + LDS / re-packed table (default), 3 no re-packed table (ARROWHIP_HASH_DIRECT)
   int opt_sort_msd;            // sort_indices: 0 LSD passes only, 1 auto (ARROWHIP_SORT_MSD)

@@ -23,7 +23,7 @@
 //   4 rank, emit  first rows → n-bit bitmap → prefix popcount = the sequential memo index of each group
 //                 (same argument as ah_hash.hip), groups written to out_*[id]
 //
-// Up to ≈ 4300 expected groups the id-based path keeps all groups in one LDS table and is as fast; beyond ≈ 1.3 M groups
+// Up to ≈ 4300 expected groups the id-based path keeps all groups in one LDS table and is as fast; beyond ≈ 2.1 M groups
 // 1024 partitions are not enough — both are left to it.
 // Nothing here depends on timing: integer sums and the 128-bit fixed-point float sums are associative, first row is
 // a minimum, ids are a function of the first rows — two runs give identical bytes, and the same bytes as the id-based
@@ -1000,7 +1000,7 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
   return AH_OK;
 }
 
-// 1.3 M … 10 M expected groups: the LDS-table aggregation needs 2048 … 8192 partitions — cut in two levels (the gs_* scatter
+// 2.1 M … 10 M expected groups: the LDS-table aggregation needs 2048 … 8192 partitions — cut in two levels (the gs_* scatter
 // kernels: 64 × 64 partitions, runs as long as in the one-level cut of 64), then ONE workgroup per partition, tables dumped
 // side by side.  *used = 1: out_* hold the result.
 static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
@@ -1221,7 +1221,13 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
     // global ones (measured: 0.45 → 0.89 ms in the aggregate pass of a Zipf(1.1) column over 2^20 keys)
     const double dh_even = gb_extrapolate(ds, sampled, sampled / 2);
     const bool heavy_tail = dh < 0.93 * dh_even;
-    if (est > 1.3e6) {
+    // Expected keys per partition: ≈ 1024–1280 (a quarter of the LDS table) while that needs ≤ 256 partitions; beyond, the
+    // scatter's runs get short (4096-row tiles / 1024 partitions = 4 rows) and costs more than fuller tables do — up to 2100
+    // keys per partition then (the table admits 3584).  Measured at 2^26 rows (`scripts/bench_gb_keys.py`): 2^19 groups 1.62 →
+    // 1.46 ms, 2^20 1.90 → 1.69 ms, 2^21 (one level of 1024 instead of two levels) 2.9 → 2.1 ms; 2^14 … 2^18 are best at ≈ 1024.
+    const double kpp = (double)(c->opt_groupby_keys < 256 ? 256 : (c->opt_groupby_keys > 3000 ? 3000 : c->opt_groupby_keys));
+    const double kpp_many = kpp > 2100.0 ? kpp : 2100.0;
+    if (est > 1024.0 * kpp_many) {
       // beyond 1024 partitions of ≤ 1280 keys.  Evenly spread keys: up to 8192 partitions through the two-level cut, one workgroup
       // each; beyond that (fewer than ≈ 8 rows per group) sort-based buckets.  A heavy tail at this size means keys with thousands
       // of rows — one workgroup per partition or a bucket of 64 cannot take those: the id-based path
@@ -1235,7 +1241,11 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
     }
     if (heavy_tail) est *= 4.0;   // up to 1024 partitions (the loop below stops there)
     lp = 3;                                            // ≤ 1280 expected keys per partition (LDS table: 3584), a few partitions at least
-    while (lp < 10 && est / (double)(1 << lp) > 1280.0) lp++;
+    while (lp < 10 && est / (double)(1 << lp) > kpp) lp++;
+    if (lp > 8) {
+      lp = 8;
+      while (lp < 10 && est / (double)(1 << lp) > kpp_many) lp++;
+    }
   }
   const int P = 1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);

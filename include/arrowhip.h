@@ -125,7 +125,8 @@ const char* ah_last_error(ah_ctx* ctx); /* never NULL; owned by ctx */
  * "blocks_per_cu" (grid cap of grid-stride kernels, 0 = each kernel's default), "take_binned" (0 never, 1 auto, 2 whenever
  * legal), "take_window_log2" (bytes of values per bin), "take_gather_wg_per_cu", "take_gather_load", "scan_segment_log2",
  * "hash_direct" (unique / dictionary_encode: 0 ids in a separate pass … 2 default, 3 without the re-packed table),
- * "groupby_partition" (hash + sum: 0 id-based path only, 1 auto, k >= 5 always 2^(k-2) partitions), "sort_msd" (sort_indices:
+ * "groupby_partition" (hash + sum: 0 id-based path only, 1 auto, k >= 5 always 2^(k-2) partitions, 2 sort-based, 3 / 4 two levels,
+ * -2 no cut), "groupby_keys" (expected keys per partition the auto choice aims at, default 1280), "sort_msd" (sort_indices:
  * 0 LSD passes only, 1 auto).  Defaults come from the ARROWHIP_* environment variables of the same names at context
  * creation. */
 int ah_ctx_set_option(ah_ctx* ctx, const char* name, int64_t value);
