@@ -235,16 +235,23 @@ __global__ __launch_bounds__(kGatherBlock) void bin_gather_kernel(const void* __
   T v[kGatherPerThread];
   bool ok[kGatherPerThread];
   unsigned u[kGatherPerThread];
+  // all the records first, then their bins: with the bin walk (a data-dependent LDS loop) between two loads the compiler waited
+  // for each record before requesting the next — eight memory round trips in a row in front of every workgroup's gathers
+  unsigned r[kGatherPerThread];
+#pragma unroll
+  for (int k = 0; k < kGatherPerThread; k++) {
+    const int64_t e = e0 + k * kGatherBlock + threadIdx.x;
+    ok[k] = e < nidx;
+    r[k] = ok[k] ? __builtin_nontemporal_load(&rec[e]) : 0u;
+  }
 #pragma unroll
   for (int k = 0; k < kGatherPerThread; k++) {
     const int64_t e = e0 + k * kGatherBlock + threadIdx.x;
     u[k] = 0;
-    ok[k] = e < nidx;
     if (ok[k]) {
-      const unsigned r = __builtin_nontemporal_load(&rec[e]);
       int bin = bin0;
       while (bin + 1 < nb && s_bs[bin + 1] <= (unsigned)e) bin++;
-      u[k] = ((unsigned)bin << shift) | (r & low_mask);
+      u[k] = ((unsigned)bin << shift) | (r[k] & low_mask);
     }
   }
   // value and validity bit are fetched side by side (u is in range for every live record; dead lanes read element 0)
@@ -329,16 +336,21 @@ __global__ __launch_bounds__(kThreads) void bin_gather_lds_kernel(const void* __
     T v[kGatherPerThread];
     bool ok[kGatherPerThread];
     unsigned u[kGatherPerThread];
+    unsigned r[kGatherPerThread];   // all the records first, then their bins (see bin_gather_kernel)
+#pragma unroll
+    for (int k = 0; k < kGatherPerThread; k++) {
+      const int64_t e = e0 + k * kThreads + threadIdx.x;
+      ok[k] = e < nidx;
+      r[k] = ok[k] ? __builtin_nontemporal_load(&rec[e]) : 0u;
+    }
 #pragma unroll
     for (int k = 0; k < kGatherPerThread; k++) {
       const int64_t e = e0 + k * kThreads + threadIdx.x;
       u[k] = 0;
-      ok[k] = e < nidx;
       if (ok[k]) {
-        const unsigned r = __builtin_nontemporal_load(&rec[e]);
         int bin = b_first;
         if (!pure) while (bin + 1 < nb && s_bs[bin + 1] <= (unsigned)e) bin++;
-        u[k] = ((unsigned)bin << shift) | (r & low_mask);
+        u[k] = ((unsigned)bin << shift) | (r[k] & low_mask);
       }
     }
 #pragma unroll
