@@ -10,6 +10,7 @@
 // RCCL is bound at first use with dlopen — librccl.so.1 as already loaded by the process if there is one (torch ships
 // its own), else the system's — so libarrowhip.so itself carries no link-time dependency on it.
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 #include "ah_common.h"
 
@@ -36,8 +37,14 @@ struct Rccl {
 };
 Rccl g_rccl;
 
-const char* load_rccl() {  // nullptr = ok, else why not
-  if (g_rccl.lib) return nullptr;
+const char* load_rccl_once();
+const char* load_rccl() {  // nullptr = ok, else why not; safe from any number of threads (Go runs ExecFns on whatever OS thread it likes)
+  static std::once_flag once;
+  static const char* why = nullptr;
+  std::call_once(once, [] { why = load_rccl_once(); });
+  return why;
+}
+const char* load_rccl_once() {
   const char* override_path = getenv("ARROWHIP_RCCL");
   const char* names[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;

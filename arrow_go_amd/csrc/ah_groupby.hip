@@ -114,22 +114,28 @@ __global__ __launch_bounds__(kGbHistThreads) void gb_hist_kernel(const unsigned 
   for (int b = threadIdx.x; b < nb; b += kGbHistThreads) cnt_tm[tile * nb + b] = s_cnt[b];
 }
 
-// largest finite |value| of the call from the per-tile maxima the scatter pass leaves (one plain store per tile: 65 536
-// atomicMax on one address cost 0.8 ms — 12 ns each, serialised)
-__global__ __launch_bounds__(1024) void gb_max_kernel(const unsigned long long* __restrict__ tile_max, int64_t ntiles, unsigned long long* __restrict__ absmax) {
-  __shared__ unsigned long long s_max[16];
-  unsigned long long m = 0;
-  for (int64_t i = threadIdx.x; i < ntiles; i += 1024) { const unsigned long long t = tile_max[i]; m = t > m ? t : m; }
+// largest finite |value| — and smallest non-zero one, inverted (ah_hashing.h) — of the call from the per-tile pairs the scatter
+// pass leaves (plain stores per tile: 65 536 atomicMax on one address cost 0.8 ms — 12 ns each, serialised)
+__global__ __launch_bounds__(1024) void gb_max_kernel(const unsigned long long* __restrict__ tile_rng, int64_t ntiles, unsigned long long* __restrict__ range) {
+  __shared__ unsigned long long s_max[16], s_imin[16];
+  unsigned long long m = 0, im = 0;
+  for (int64_t i = threadIdx.x; i < ntiles; i += 1024) {
+    const unsigned long long t = tile_rng[2 * i], ti = tile_rng[2 * i + 1];
+    m = t > m ? t : m;
+    im = ti > im ? ti : im;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long t = __shfl_down(m, o, 64);
+    const unsigned long long t = __shfl_down(m, o, 64), ti = __shfl_down(im, o, 64);
     m = t > m ? t : m;
+    im = ti > im ? ti : im;
   }
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = m; s_imin[threadIdx.x >> 6] = im; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; w++) m = s_max[w] > m ? s_max[w] : m;
-    *absmax = m;
+    for (int w = 1; w < 16; w++) { m = s_max[w] > m ? s_max[w] : m; im = s_imin[w] > im ? s_imin[w] : im; }
+    range[0] = m;
+    range[1] = im;
   }
 }
 
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
   __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_goff[kMaxBins], s_wsum[kThreads / 64];
   __shared__ unsigned long long s_stage[kGbTile];
   __shared__ uint16_t s_bin[kGbTile];
-  __shared__ unsigned long long s_max[kThreads / 64];
+  __shared__ unsigned long long s_max[kThreads / 64], s_imin[kThreads / 64];
   // consecutive tiles on ONE XCD: the runs they append to a partition meet in that XCD's L2 and leave as whole lines
   const int64_t tile = xcd_contiguous_tile(ntiles);
   if (tile < 0) return;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
   unsigned long long k[kGbRows], v[kGbRows];
   unsigned rw[kGbRows], bin[kGbRows], rank[kGbRows];
   bool live[kGbRows];
-  unsigned long long vmax = 0;
+  unsigned long long vmax = 0, vimin = 0;
 #pragma unroll
   for (int u = 0; u < kGbRows; u++) {
     const int64_t i = base + u * kThreads + threadIdx.x;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
       rw[u] = (unsigned)i | (kv ? 0u : kKeyNull) | (vv ? 0u : kValNull);
       if (kv) rank[u] = atomicAdd(&s_cnt[bin[u]], 1u);
       const unsigned long long a = v[u] & 0x7fffffffffffffffull;   // |x| of finite doubles order like their bit patterns
-      if (tile_max && vv && (a >> 52) != 0x7ff && a > vmax) vmax = a;
+      if (tile_max && vv && (a >> 52) != 0x7ff && a != 0) { vmax = a > vmax ? a : vmax; vimin = ~a > vimin ? ~a : vimin; }
     }
     if (nulls) {   // wave-uniform
       const int leader = __builtin_ctzll(nulls);
@@ -191,18 +197,20 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
   if (tile_max) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long x = __shfl_down(vmax, o, 64);
+      const unsigned long long x = __shfl_down(vmax, o, 64), xi = __shfl_down(vimin, o, 64);
       vmax = x > vmax ? x : vmax;
+      vimin = xi > vimin ? xi : vimin;
     }
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = vmax;
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = vmax; s_imin[threadIdx.x >> 6] = vimin; }
   }
   __syncthreads();
   block_excl_scan(s_cnt, s_start, s_wsum, nb);
   if ((int)threadIdx.x < nb) s_goff[threadIdx.x] = goff_excl - s_start[threadIdx.x];
   if (tile_max && threadIdx.x == 0) {
-    unsigned long long x = s_max[0];
-    for (int w = 1; w < kThreads / 64; w++) x = s_max[w] > x ? s_max[w] : x;
-    tile_max[tile] = x;
+    unsigned long long x = s_max[0], xi = s_imin[0];
+    for (int w = 1; w < kThreads / 64; w++) { x = s_max[w] > x ? s_max[w] : x; xi = s_imin[w] > xi ? s_imin[w] : xi; }
+    tile_max[2 * tile] = x;
+    tile_max[2 * tile + 1] = xi;
   }
   const int tile_n = n - base >= kGbTile ? kGbTile : (int)(n - base);
   // three rounds through one staging buffer: keys, value bits, row words
@@ -676,14 +684,14 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
   __shared__ unsigned s_a[kThreads], s_b[kThreads];
   __shared__ unsigned long long s_stage[kMsTile];
   __shared__ uint16_t s_bin[kMsTile];
-  __shared__ unsigned long long s_max[kThreads / 64];
+  __shared__ unsigned long long s_max[kThreads / 64], s_imin[kThreads / 64];
   __shared__ int s_pick;
   __shared__ unsigned s_carry;
   const TileRange r = ms_tile(pstart, nparents, n, s_a, s_b, s_wsum, &s_pick);
   if (r.parent < 0) return;
   const int t = threadIdx.x;
   for (int b = t; b < nb; b += kThreads) s_cnt[b] = 0;
-  unsigned long long k[kMsRows], v[kMsRows], vmax = 0;
+  unsigned long long k[kMsRows], v[kMsRows], vmax = 0, vimin = 0;
   unsigned rw[kMsRows], dg[kMsRows], rank[kMsRows];
   bool live[kMsRows];
 #pragma unroll
@@ -699,12 +707,16 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
     dg[u] = (gs_bucket(k[u], rw[u] & kKeyNull, lb) >> shift) & mask;
     rank[u] = live[u] ? atomicAdd(&s_cnt[dg[u]], 1u) : 0u;
     const unsigned long long a = v[u] & 0x7fffffffffffffffull;
-    if (tile_max && live[u] && !(rw[u] & kValNull) && (a >> 52) != 0x7ff && a > vmax) vmax = a;
+    if (tile_max && live[u] && !(rw[u] & kValNull) && (a >> 52) != 0x7ff && a != 0) { vmax = a > vmax ? a : vmax; vimin = ~a > vimin ? ~a : vimin; }
   }
   if (tile_max) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_down(vmax, o, 64); vmax = x > vmax ? x : vmax; }
-    if ((t & 63) == 0) s_max[t >> 6] = vmax;
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long x = __shfl_down(vmax, o, 64), xi = __shfl_down(vimin, o, 64);
+      vmax = x > vmax ? x : vmax;
+      vimin = xi > vimin ? xi : vimin;
+    }
+    if ((t & 63) == 0) { s_max[t >> 6] = vmax; s_imin[t >> 6] = vimin; }
   }
   __syncthreads();
   unsigned carry = 0;
@@ -723,9 +735,10 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
     __syncthreads();
   }
   if (tile_max && t == 0) {
-    unsigned long long x = s_max[0];
-    for (int w = 1; w < kThreads / 64; w++) x = s_max[w] > x ? s_max[w] : x;
-    tile_max[r.id] = x;
+    unsigned long long x = s_max[0], xi = s_imin[0];
+    for (int w = 1; w < kThreads / 64; w++) { x = s_max[w] > x ? s_max[w] : x; xi = s_imin[w] > xi ? s_imin[w] : xi; }
+    tile_max[2 * r.id] = x;
+    tile_max[2 * r.id + 1] = xi;
   }
   const int tile_n = (int)(r.hi - r.lo);
 #pragma unroll
@@ -914,7 +927,7 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
   const unsigned grid1 = (unsigned)(((ntiles + 7) / 8) * 8);
   const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
   const size_t need = pad((size_t)n * 8) * 4 + pad((size_t)n * 4) * 3 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
-                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)nbuckets + 1) * 4) + pad((size_t)ntiles * 8) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
+                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)nbuckets + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
                       pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
@@ -935,16 +948,17 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
   unsigned* cnt2 = (unsigned*)take((size_t)nvt * nb2 * 4);
   unsigned* toffs2 = (unsigned*)take((size_t)nvt * nb2 * 4);
   unsigned* bstart = (unsigned*)take(((size_t)nbuckets + 1) * 4);
-  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 8);
+  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 16);
   unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
   unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
   int* tilecnt = (int*)take((size_t)nrt * 4);
   int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
-  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* oversize = (unsigned*)&c->dscalars[21];
   unsigned long long* total = (unsigned long long*)&c->dscalars[22];
   int* null_id = (int*)&c->dscalars[23];
   AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
   AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
   AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
   GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
@@ -962,6 +976,8 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
   AH_LAUNCH_CHECK(c);
   if (is_f64) {
     gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+    fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, oversize);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);
   }
   // level 2, parent by parent
@@ -1016,7 +1032,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
   const int64_t nslots = P * kFlatStride;
   const size_t need = pad((size_t)n * 8) * 4 + pad((size_t)n * 4) * 2 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
-                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 8) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
+                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
                       pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2;
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
@@ -1036,7 +1052,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   unsigned* cnt2 = (unsigned*)take((size_t)nvt * nb2 * 4);
   unsigned* toffs2 = (unsigned*)take((size_t)nvt * nb2 * 4);
   unsigned* bstart = (unsigned*)take(((size_t)P + 1) * 4);
-  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 8);
+  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 16);
   unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
   unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
   int* tilecnt = (int*)take((size_t)nrt * 4);
@@ -1047,11 +1063,12 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   gt.hi = (unsigned long long*)take((size_t)nslots * 8);
   gt.cnt = (unsigned*)take((size_t)nslots * 4);
   gt.first = (unsigned*)take((size_t)nslots * 4);
-  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
   unsigned long long* total = (unsigned long long*)&c->dscalars[22];
   int* null_id = (int*)&c->dscalars[23];
   AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
   AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
   AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
   GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
@@ -1068,6 +1085,8 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   AH_LAUNCH_CHECK(c);
   if (is_f64) {
     gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+    fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);
   }
   GsRecords rec{pkeys, pvals, prows};
@@ -1126,7 +1145,7 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
   unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
   int* tilecnt = (int*)take((size_t)nrt * 4);
   int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
-  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
   unsigned long long* total = (unsigned long long*)&c->dscalars[22];
   int* null_id = (int*)&c->dscalars[23];
@@ -1135,11 +1154,14 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
   AH_HIP(c, hipMemsetAsync(gt.first, 0xFF, (size_t)nslots * 4, c->stream));
   AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
   AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
   AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
   const unsigned long long* k64 = (const unsigned long long*)keys;
   const unsigned long long* v64 = (const unsigned long long*)vals;
   if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
     absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 8), kBlock, 0, c->stream>>>(v64, vvalid, voff, n, absmax);
+    AH_LAUNCH_CHECK(c);
+    fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);
   }
   const unsigned grid = (unsigned)ah_ceil_div(n, (int64_t)1 << kChunkLog2);
@@ -1177,7 +1199,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   const int mode = c->opt_groupby_partition;   // 0 never, 1 auto, 2: always sort-based, 3 / 4: always the two-level cut with 2^11 / 2^13 partitions, k ≥ 5: always LDS tables in 2^(k − 2) partitions (tests, measurements)
   if (mode == 0 || n >= kMaxRows || n < 1 || (mode == 1 && n < ((int64_t)1 << 21))) return AH_OK;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  unsigned long long* absmax = (unsigned long long*)&c->dscalars[20];
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
   unsigned long long* total = (unsigned long long*)&c->dscalars[22];
   int* null_id = (int*)&c->dscalars[23];
@@ -1255,7 +1277,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   const size_t table = (size_t)P * (size_t)ntiles * 4;
   const size_t need = pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2 + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
                       pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) +
-                      pad((size_t)n * 8) * 2 + pad((size_t)n * 4) + pad((size_t)ntiles * 8);
+                      pad((size_t)n * 8) * 2 + pad((size_t)n * 4) + pad((size_t)ntiles * 16);
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -1278,12 +1300,13 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
   unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
   unsigned* prows = (unsigned*)take((size_t)n * 4);
-  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 8);
+  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 16);
   AH_HIP(c, hipMemsetAsync(gt.key, 0xFF, (size_t)nslots * 8, c->stream));
   AH_HIP(c, hipMemsetAsync(gt.lo, 0, pad((size_t)nslots * 8) * 2 + (size_t)nslots * 4, c->stream));   // lo, hi, cnt are adjacent
   AH_HIP(c, hipMemsetAsync(gt.first, 0xFF, (size_t)nslots * 4, c->stream));
   AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
   AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));   // absmax, overflow, total
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
   AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
   const unsigned long long* k64 = (const unsigned long long*)keys;
   const unsigned long long* v64 = (const unsigned long long*)vals;
@@ -1302,6 +1325,8 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   AH_LAUNCH_CHECK(c);
   if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
     gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+    fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);
   }
   // ---- 3: aggregate

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __rest
     __syncthreads();
   }
   int sh = 0;
-  if constexpr (kFx) sh = fx_shift(*fx.absmax);
+  if constexpr (kFx) sh = fx_shift(*fx.absmax);   // wide columns (fx.gmax): the group's own scale, looked up per row below
   constexpr int U = 8;  // rows per lane per step: 8 id loads + 8 value loads in flight (one row at a time is latency-bound)
   const int64_t stride = (int64_t)gridDim.x * kBlock * U;
   for (int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < n; base += stride) {
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __rest
       if constexpr (kFx) {
         if (fx_finite(v[u])) {
           unsigned long long lo, hi;
-          fx_split(v[u], sh, &lo, &hi);
+          fx_split(v[u], fx.gmax ? fx_shift(fx.gmax[g[u]]) : sh, &lo, &hi);
           if (lds) fx_add(s_sum, s_hi, (size_t)g[u], lo, hi);
           else fx_add(fx.lo, fx.hi, (size_t)g[u], lo, hi);
         } else {
@@ -545,6 +545,31 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const int32_t* __rest
         else atomicAdd(&sums[g], (AT)s_sum[g]);
         atomicAdd(&counts[g], (unsigned long long)cnt);
       }
+    }
+  }
+}
+
+// wide columns (ah_hashing.h): largest finite |x| per group = the group's fixed-point scale.  A look before the atomic: once a
+// group's maximum has been seen (early, on average) its rows issue none.
+__global__ __launch_bounds__(kBlock) void group_max_kernel(const int32_t* __restrict__ ids, const unsigned long long* __restrict__ vals,
+                                                            const uint8_t* __restrict__ vvalid, int64_t voff, int64_t n,
+                                                            unsigned long long* __restrict__ gmax) {
+  constexpr int U = 8;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * U;
+  for (int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; base < n; base += stride) {
+    int32_t g[U];
+    unsigned long long a[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      const bool ok = i < n && ah_bit(vvalid, voff + i);
+      g[u] = ok ? __builtin_nontemporal_load(&ids[i]) : -1;
+      a[u] = ok ? __builtin_nontemporal_load(&vals[i]) & 0x7fffffffffffffffull : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (g[u] < 0 || (a[u] >> 52) == 0x7ff || a[u] == 0) continue;
+      if (__hip_atomic_load(&gmax[g[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a[u]) atomicMax(&gmax[g[u]], a[u]);
     }
   }
 }
@@ -912,11 +937,11 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
   int32_t* ids = (int32_t*)arena;
   uint8_t* part = (uint8_t*)arena + pi;
   uint8_t* fxbase = part + 2 * (pv + pi) + 2 * ph + 256;
-  FxAcc fx{nullptr, nullptr, nullptr, nullptr};
+  FxAcc fx{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (kFx) {
     fx = FxAcc{(unsigned long long*)fxbase, (unsigned long long*)(fxbase + fxw), (unsigned*)(fxbase + 2 * fxw),
-               (const unsigned long long*)(fxbase + 2 * fxw + fxf)};
-    AH_HIP(c, hipMemsetAsync((void*)fx.absmax, 0, 8, c->stream));
+               (const unsigned long long*)(fxbase + 2 * fxw + fxf), nullptr};
+    AH_HIP(c, hipMemsetAsync((void*)fx.absmax, 0, 16, c->stream));
     absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 8), kBlock, 0, c->stream>>>((const unsigned long long*)vals, vvalid, voff, n,
                                                                                                         (unsigned long long*)fx.absmax);
     AH_LAUNCH_CHECK(c);
@@ -931,13 +956,30 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
     if (kFx && e1 == hipSuccess) e1 = hipMemsetAsync(fx.flags, 0, (size_t)res.ndict * 4, c->stream);
     if (e1 != hipSuccess || e2 != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: memset failed");
   }
+  bool wide = false;
+  if (kFx && rc == AH_OK) {
+    // one scale for the call, or one per group?  (ah_hashing.h: a column spanning more than 42 binades)
+    hipError_t e = hipMemcpyAsync(&c->pinned[2], fx.absmax, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: range read-back failed");
+    else wide = fx_wide(*(volatile uint64_t*)&c->pinned[2], *(volatile uint64_t*)&c->pinned[3]);
+    if (rc == AH_OK && wide) {
+      unsigned long long* gmax = (unsigned long long*)part;   // the partition temporaries are idle on this route
+      if (hipMemsetAsync(gmax, 0, (size_t)res.ndict * 8, c->stream) != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: memset failed");
+      if (rc == AH_OK) {
+        group_max_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8)), kBlock, 0, c->stream>>>(ids, (const unsigned long long*)vals, vvalid, voff, n, gmax);
+        if (hipGetLastError() != hipSuccess) rc = ah_fail(c, AH_EHIP, "hash_sum: launch failed");
+      }
+      fx.gmax = gmax;
+    }
+  }
   if (rc == AH_OK) {
     static const int partition_path = getenv("ARROWHIP_HASH_PARTITION") ? atoi(getenv("ARROWHIP_HASH_PARTITION")) : 1;
     if (res.ndict <= kLdsGroups) {
       unsigned grid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), /*default_bpc=*/2);
       group_sum_kernel<VT, AT, true><<<grid, kBlock, 0, c->stream>>>(ids, vals, vvalid, voff, n, out_sums,
                                                                      (unsigned long long*)out_counts, (int)res.ndict, fx);
-    } else if (partition_path && res.ndict <= kPartitionMaxGroups && sizeof(VT) == 8) {
+    } else if (partition_path && !wide && res.ndict <= kPartitionMaxGroups && sizeof(VT) == 8) {
       const int passes = res.ndict <= kPartitionOnePass ? 1 : 2;
       unsigned long long* pvals = (unsigned long long*)part;
       unsigned* pids = (unsigned*)(part + pv);

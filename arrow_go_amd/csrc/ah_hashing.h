@@ -87,21 +87,41 @@ __device__ __forceinline__ unsigned rank_of_row(unsigned fr, const unsigned long
 // ---- deterministic Float64 group sums: fixed point --------------------------------------------------------------
 // fp64 atomic adds make a group's sum depend on the order the hardware happens to perform them in.  Integer addition
 // is associative, so every value is converted to a 128-bit fixed-point number  q = trunc(x · 2^sh),  sh = 94 − emax,
-// emax = exponent of the largest finite |x| of the call (|q| < 2^95; 2^30 rows cannot overflow 2^127), accumulated with
+// emax = exponent of the largest finite |x| (|q| < 2^95; 2^30 rows cannot overflow 2^127), accumulated with
 // 64-bit integer atomics (low word with carry into the high word — each addend derives its own carry from the value
 // its atomic returned, so any interleaving gives the same 128 bits), and rounded to double ONCE at the end.
-// Result: identical bytes run to run, on any launch geometry; error ≤ ½ulp(Σ) + n_g·2^(emax−94) — inside the
-// n_g·ε·Σ|x| of the sequential row-order definition.  ±inf / NaN addends are tallied as three flag bits per
+// Result: identical bytes run to run, on any launch geometry.  ±inf / NaN addends are tallied as three flag bits per
 // group and give the IEEE result of any order: NaN if a NaN or both infinities were seen, else the infinity.
+//
+// WHICH emax.  A 53-bit significand shifted left by e − emax + 42 bits loses nothing while e ≥ emax − 42.  So every
+// call also finds the SMALLEST non-zero finite |x| (range[1], stored inverted so that both words are atomicMax targets):
+//   · the column spans ≤ 42 binades ("narrow", the usual case): ONE scale for the call, no addend is truncated, the
+//     128-bit sum is the exact sum and the result is its correctly rounded double — for every group, whatever its magnitude;
+//   · wider ("wide": an outlier or sentinel such as 1e300 next to ordinary values): one scale would truncate every
+//     addend below 2^(emax − 94) to zero, i.e. one group's outlier would wipe out all other groups' sums.  The scale is
+//     then PER GROUP (gmax[g] = largest finite |x| of group g, found by a pass of its own on the id-based path — the
+//     partition-first paths hand the call over): error ≤ ½ulp(Σ_g) + n_g·2^(emax_g − 94) ≤ n_g·2^−94·Σ_g|x| — inside the
+//     n_g·ε·Σ_g|x| of the sequential row-order definition, now with the GROUP's own Σ|x|.
 struct FxAcc {  // global accumulators of one call (device pointers); null for integer sums
   unsigned long long* lo;
   unsigned long long* hi;
   unsigned* flags;
-  const unsigned long long* absmax;  // bit pattern of the largest finite |x|
+  const unsigned long long* absmax;  // range[0] = bit pattern of the largest finite |x|, range[1] = ~(bit pattern of the smallest non-zero one)
+  const unsigned long long* gmax;    // per-group largest finite |x| (wide columns); null: the call's one scale
 };
 __device__ __forceinline__ int fx_shift(unsigned long long absmax_bits) {
   const int e = (int)((absmax_bits >> 52) & 0x7ff);
   return 94 - ((e ? e : 1) - 1023);
+}
+// does one scale for the whole call truncate an addend?  (range as in FxAcc::absmax)
+__host__ __device__ __forceinline__ bool fx_wide(unsigned long long max_bits, unsigned long long inv_min_bits) {
+  if (!inv_min_bits) return false;   // no non-zero finite value at all
+  const int emax = (int)((max_bits >> 52) & 0x7ff), emin = (int)((~inv_min_bits >> 52) & 0x7ff);
+  return (emax ? emax : 1) - (emin ? emin : 1) > 42;
+}
+// sets bit 1 of *flag (the partition-first paths' "redo the call on the id-based path" word) for a wide column
+__global__ void fx_range_check_kernel(const unsigned long long* __restrict__ range, unsigned* __restrict__ flag) {
+  if (fx_wide(range[0], range[1])) atomicOr(flag, 2u);
 }
 __device__ __forceinline__ bool fx_finite(double x) { return ((__builtin_bit_cast(unsigned long long, x) >> 52) & 0x7ff) != 0x7ff; }
 __device__ __forceinline__ unsigned fx_flag(double x) { return x != x ? 1u : (x > 0 ? 2u : 4u); }   // NaN, +inf, −inf
@@ -150,9 +170,10 @@ __device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned l
   d = ldexp(d, -sh);
   return neg ? -d : d;
 }
+// out[0] = max, out[1] = max of the inverted bit patterns of the non-zero values (= ~min); both zeroed by the caller
 __global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
                                                          int64_t n, unsigned long long* __restrict__ out) {
-  unsigned long long m = 0;
+  unsigned long long m = 0, im = 0;
   // 8 values per lane per step (four of them loaded before the first is used): a one-value grid-stride loop ran at 3.1 TB/s
   constexpr int U = 8;
   const int64_t stride = (int64_t)gridDim.x * kBlock * U;
@@ -166,20 +187,26 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t i = base + (int64_t)u * kBlock;
-      if (i < n && (b[u] >> 52) != 0x7ff && b[u] > m && ah_bit(vvalid, voff + i)) m = b[u];   // |x| of finite values order like their bit patterns
+      // |x| of finite values order like their bit patterns; a value inside the current [min, max] changes nothing and skips the validity read
+      if (i < n && (b[u] >> 52) != 0x7ff && b[u] != 0 && (b[u] > m || ~b[u] > im) && ah_bit(vvalid, voff + i)) {
+        m = b[u] > m ? b[u] : m;
+        im = ~b[u] > im ? ~b[u] : im;
+      }
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long t = __shfl_down(m, o, 64);
+    const unsigned long long t = __shfl_down(m, o, 64), ti = __shfl_down(im, o, 64);
     m = t > m ? t : m;
+    im = ti > im ? ti : im;
   }
-  __shared__ unsigned long long s_m[kBlock / 64];
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __shared__ unsigned long long s_m[kBlock / 64], s_im[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_im[threadIdx.x >> 6] = im; }
   __syncthreads();
-  if (threadIdx.x == 0) {   // one atomic per workgroup: same-address atomics cost ≈ 12 ns each, serialised
-    for (int w = 1; w < kBlock / 64; w++) m = s_m[w] > m ? s_m[w] : m;
-    if (m) atomicMax(out, m);
+  if (threadIdx.x == 0) {   // one atomic pair per workgroup: same-address atomics cost ≈ 12 ns each, serialised
+    for (int w = 1; w < kBlock / 64; w++) { m = s_m[w] > m ? s_m[w] : m; im = s_im[w] > im ? s_im[w] : im; }
+    if (m) atomicMax(&out[0], m);
+    if (im) atomicMax(&out[1], im);
   }
 }
 __global__ __launch_bounds__(kBlock) void fx_finalize_kernel(FxAcc acc, int64_t ngroups, double* __restrict__ out_sums) {
@@ -188,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void fx_finalize_kernel(FxAcc acc, int64_t 
   const unsigned f = acc.flags[g];
   double r;
   if (f) r = (f & 1u) || (f & 6u) == 6u ? __builtin_nan("") : ((f & 2u) ? __builtin_inf() : -__builtin_inf());
-  else r = fx_to_double(acc.lo[g], acc.hi[g], fx_shift(*acc.absmax));
+  else r = fx_to_double(acc.lo[g], acc.hi[g], fx_shift(acc.gmax ? acc.gmax[g] : *acc.absmax));
   out_sums[g] = r;
 }
 

@@ -20,6 +20,7 @@
 // groups keep their input order because only pass (1) ever moves them.
 // Traffic: 8 (+1/8) B/row for (1) and (2), ≈ 32 B/row per LSD pass ((key, row) read twice, written
 // once), 12 B/row for (4): an Int64 column with all 8 bytes varying moves ≈ 290 B/row.
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 #include "ah_common.h"
@@ -31,6 +32,7 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kItems = 8;                       // rounds of 64 rows per wave per tile
 constexpr int kTile = kBlock * kItems;          // 2048 rows
 constexpr int kRadix = 256;
+constexpr int kAndOrGrid = 4096;                 // most workgroups the two key-reduction kernels are launched with (their partials live in SortBuffers::andor)
 constexpr int kMaxTilesPerBlock = 8;             // tiles one workgroup handles = granularity of the histogram / scan
 
 // small inputs keep one tile per workgroup (parallelism), large ones eight (fewer histogram rows)
@@ -387,7 +389,8 @@ int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t*
   bool have_stats = false;
   if (valid == nullptr && rows_in == nullptr && n >= ((int64_t)1 << 20)) {
     // no validity bitmap, input order: nothing to partition unless a float column holds NaNs — one streaming pass, checked after
-    const unsigned pgrid = ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 4), 8);
+    // b.andor holds kAndOrGrid × 8 words (sort_buffers): the grid is clamped to that whatever ARROWHIP_BLOCKS_PER_CU asks for
+    const unsigned pgrid = std::min(ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 4), 8), (unsigned)kAndOrGrid);
     pairs_kernel<T><<<pgrid, kBlock, 0, c->stream>>>((const T*)values, n, descending, b.ka, b.ra, b.andor);
     AH_LAUNCH_CHECK(c);
     std::vector<unsigned long long> parts((size_t)pgrid * 5);
@@ -419,7 +422,7 @@ int sort_by_column(ah_ctx* c, SortBuffers& b, const void* values, const uint8_t*
   if (rest_n > 1) {
     if (!have_stats) {
       // (2) which key bytes vary; smallest and largest key
-      const unsigned agrid = ah_stream_grid(c, ah_ceil_div(rest_n, kBlock), 4);
+      const unsigned agrid = std::min(ah_stream_grid(c, ah_ceil_div(rest_n, kBlock), 4), (unsigned)kAndOrGrid);
       and_or_kernel<<<agrid, kBlock, 0, c->stream>>>(kcur, rest_n, b.andor);
       AH_LAUNCH_CHECK(c);
       std::vector<unsigned long long> parts((size_t)agrid * 4);
@@ -494,7 +497,7 @@ int sort_keys(ah_ctx* c, int nkeys, const int* types, const void* const* values,
   if (nkeys > 1) tmp.take((size_t)n * 4, &b.rc);
   tmp.take(hist_bytes, &b.hist);
   tmp.take(hist_bytes, &b.offs);
-  tmp.take(4096 * 8 * 8, &b.andor);   // ≤ 8 workgroups per CU × {AND, OR, min, max, NaNs}
+  tmp.take((size_t)kAndOrGrid * 8 * 8, &b.andor);   // ≤ kAndOrGrid workgroups × {AND, OR, min, max, NaNs} (8 words reserved each)
   if (msd_bytes) { uint8_t* m; tmp.take(msd_bytes, &m); b.msd_tmp = m; }
   // lexicographic order by keys 0..k−1 = stable sorts by key k−1, …, key 0 in turn (every pass is stable)
   const unsigned* rows_in = nullptr;

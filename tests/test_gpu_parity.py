@@ -525,7 +525,9 @@ def test_hash_sum_partition_first(hip, orc_be, ctx, n, card, mode, hot):
     keys, kvalid, vvalid = _hash_sum_cases(rng, n, card, hot)
     iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
     fi = rng.integers(-1000, 1000, n).astype(np.float64)
-    fv = rng.standard_normal(n) * np.exp(rng.uniform(-20, 20, n))
+    # 35 binades: inside the 42 one fixed-point scale holds exactly, so the partition-first passes keep the call (a wider column is
+    # handed to the id-based path and its per-group scales: test_hash_sum_f64_wide_range)
+    fv = (1.0 + rng.random(n)) * np.exp(rng.uniform(-12, 12, n)) * rng.choice([-1.0, 1.0], n)
     fv[rng.integers(0, n, 3)] = np.inf
     fv[rng.integers(0, n, 2)] = -np.inf
     fv[rng.integers(0, n, 2)] = np.nan
@@ -598,36 +600,49 @@ def test_hash_encode_repacked_table(hip, orc_be, ctx):
 
 
 
+def _exact_group_sums(keys, fv, ok, limit):
+    """{key: (Fraction exact sum of the valid values, count, max |x|)} for the first `limit` keys in sorted-key order"""
+    from fractions import Fraction
+    order = np.argsort(keys, kind="stable")
+    ks, vs, oks = keys[order], fv[order], ok[order]
+    bounds = np.flatnonzero(np.diff(ks)) + 1
+    starts, ends = np.concatenate([[0], bounds])[:limit], np.concatenate([bounds, [keys.size]])[:limit]
+    out = {}
+    for a, b in zip(starts, ends):
+        vals = vs[a:b][oks[a:b]]
+        fin = vals[np.isfinite(vals)]
+        out[int(ks[a])] = (sum((Fraction(float(v)) for v in fin), Fraction(0)), len(vals), float(np.abs(fin).max()) if fin.size else 0.0)
+    return out
+
+
 def test_hash_sum_f64_is_deterministic_and_tight(hip, orc_be):
-    """Float64 group sums are accumulated in 128-bit fixed point with integer atomics (associative), rounded once:
-    the bytes do not change from run to run, and they are far closer to the exact sums than the sequential definition's
-    own bound.  ±inf / NaN addends give the IEEE class any order would give."""
+    """Float64 group sums are accumulated in 128-bit fixed point with integer atomics (associative), rounded once: the bytes
+    do not change from run to run.  A column spanning ≤ 42 binades keeps every addend whole, so each group's sum is the
+    CORRECTLY ROUNDED exact sum; a wider column gets one scale per group and stays within ½ulp + n_g·2^-93·max_g|x| — the
+    group's OWN maximum — of the exact sum, far inside the sequential definition's n_g·ε·Σ_g|x|.  ±inf / NaN addends give the
+    IEEE class any order would give."""
     import math
     from fractions import Fraction
     rng = np.random.default_rng(72)
     for n, card in [(70001, 500), (300007, 100000), (2500003, 1 << 21)]:   # LDS path · one-pass partition · two-pass partition
         keys = rng.integers(0, card, n).astype(np.int64) * 1000003
         vvalid = rand_bits(rng, n + 8, 0.9)
-        fv = rng.standard_normal(n) * np.exp(rng.uniform(-30, 30, n))       # 26 orders of magnitude
-        runs = [hip.hash_sum("f64", keys, None, 0, fv, vvalid, 0) for _ in range(3)]
-        for r in runs[1:]:
-            assert r[1].tobytes() == runs[0][1].tobytes() and r[2].tobytes() == runs[0][2].tobytes()
-        e = orc_be.hash_sum("f64", keys, None, 0, fv, vvalid, 0)
-        g = runs[0]
-        assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
-        # exact per-group sums (math.fsum) for the groups of the first 2000 keys
         ok = np.unpackbits(vvalid, bitorder="little")[:n].astype(bool)
-        order = np.argsort(keys, kind="stable")
-        ks, vs, oks = keys[order], fv[order], ok[order]
-        bounds = np.flatnonzero(np.diff(ks)) + 1
-        starts, ends = np.concatenate([[0], bounds])[:2000], np.concatenate([bounds, [n]])[:2000]
-        pos = {int(k): i for i, k in enumerate(g[0].view(np.int64))}
-        m = float(np.abs(fv).max())
-        for a, b in zip(starts, ends):
-            vals = vs[a:b][oks[a:b]]
-            exact = sum((Fraction(float(v)) for v in vals), Fraction(0))      # the real-number sum
-            got = float(g[1][pos[int(ks[a])]])
-            assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(len(vals) * m * 2.0**-93), (n, card, got, float(exact))
+        for spread, exact_bytes in ((12, True), (30, False)):               # 35 binades (one scale, exact) · 87 binades (per-group scales)
+            fv = (1.0 + rng.random(n)) * np.exp(rng.uniform(-spread, spread, n)) * rng.choice([-1.0, 1.0], n)
+            runs = [hip.hash_sum("f64", keys, None, 0, fv, vvalid, 0) for _ in range(3)]
+            for r in runs[1:]:
+                assert r[1].tobytes() == runs[0][1].tobytes() and r[2].tobytes() == runs[0][2].tobytes()
+            e = orc_be.hash_sum("f64", keys, None, 0, fv, vvalid, 0)
+            g = runs[0]
+            assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
+            pos = {int(k): i for i, k in enumerate(g[0].view(np.int64))}
+            for k, (exact, cnt, gmax) in _exact_group_sums(keys, fv, ok, 2000).items():
+                got = float(g[1][pos[k]])
+                if exact_bytes:
+                    assert got == float(exact), (n, card, k, got, float(exact))       # float(Fraction) rounds to nearest even
+                else:
+                    assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(cnt * gmax * 2.0**-93), (n, card, got, float(exact))
     # non-finite addends
     keys = np.array([1, 1, 2, 2, 3, 3, 4, 4, 5], np.int64)
     fv = np.array([np.inf, 1.0, -np.inf, 5.0, np.inf, -np.inf, np.nan, 1.0, 2.5])
@@ -635,6 +650,43 @@ def test_hash_sum_f64_is_deterministic_and_tight(hip, orc_be):
     assert g[0].tobytes() == e[0].tobytes()
     assert g[1][0] == np.inf and g[1][1] == -np.inf and np.isnan(g[1][2]) and np.isnan(g[1][3]) and g[1][4] == 2.5
     assert np.array_equal(np.isnan(g[1]), np.isnan(e[1])) and np.array_equal(g[1][~np.isnan(g[1])], e[1][~np.isnan(e[1])])
+
+
+@pytest.mark.parametrize("mode", [0, 1, -2, 6, 10])
+def test_hash_sum_f64_wide_range(hip, orc_be, ctx, mode):
+    """One outlier must not cost the other groups their sums (round-2 review, ah_hashing.h): a 1e300 sentinel in ONE group next to
+    groups of ordinary values.  With one fixed-point scale for the call every addend below 2^(emax − 94) would truncate to zero;
+    the call is answered with per-group scales instead.  Per-group tolerance against the exact sums, on every route
+    (id-based, automatic, no-cut, 16 and 256 partitions)."""
+    import math
+    from fractions import Fraction
+    rng = np.random.default_rng(91 + mode)
+    n = (1 << 21) + 1234
+    for card in (7, 3000, 100000):
+        keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+        fv = rng.uniform(-1.0, 1.0, n)
+        fv[rng.integers(0, n, 40)] = 0.0
+        hot = rng.integers(0, n, 3)
+        fv[hot] = [1e300, -3e299, 1.5e307]
+        keys[hot] = keys[hot[0]]                       # the outliers share one group
+        tiny = rng.integers(0, n, 5)
+        fv[tiny] = 4.9e-324                            # denormals in other groups
+        vvalid = rand_bits(rng, n + 8, 0.9)
+        ok = np.unpackbits(vvalid, bitorder="little")[5:5 + n].astype(bool)
+        try:
+            ctx.set_option("groupby_partition", mode)
+            g = hip.hash_sum("f64", keys, None, 0, fv, vvalid, 5)
+            again = hip.hash_sum("f64", keys, None, 0, fv, vvalid, 5)
+        finally:
+            ctx.set_option("groupby_partition", 1)
+        e = orc_be.hash_sum("f64", keys, None, 0, fv, vvalid, 5)
+        assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes() and g[1].tobytes() == again[1].tobytes()
+        pos = {int(k): i for i, k in enumerate(g[0].view(np.int64))}
+        for k, (exact, cnt, gmax) in _exact_group_sums(keys, fv, ok, 3000).items():
+            got = float(g[1][pos[k]])
+            assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(cnt * gmax) * Fraction(1, 2**93), (mode, card, k, got, float(exact))
+            if gmax <= 1.0 and cnt > 3:
+                assert got != 0.0 or exact == 0, (mode, card, k)   # what the one-scale version returned for every ordinary group
 
 
 # ---- fused ---------------------------------------------------------------------------------
