@@ -1,6 +1,7 @@
 // ah_common.h — shared host/device helpers for libarrowhip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <initializer_list>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -10,6 +11,22 @@
 #include "../../include/arrowhip.h"
 
 #define AH_EXPORT extern "C" __attribute__((visibility("default")))
+
+// What ah_filter_count leaves for the ah_filter_primitive that follows it (the two-phase protocol of
+// vector_selection.go:459/475: count, allocate, fill): the per-tile survivor prefixes of THAT mask, so the fill does not
+// count the selection vector a second time.  Dropped by every entry point that may change device memory (AH_ENTER);
+// allocation, synchronisation, timers and a memset / upload / copy that stays clear of the mask's bytes keep it (AH_ENTER_KEEP).
+struct ah_filter_cache {
+  bool valid;
+  const uint8_t *fdata, *fvalid;
+  int64_t foff, n, ntiles;
+  int null_sel, tile_rows;
+  void* buf;          // device: super_off[nsuper] (int64) | tile_local[ntiles] (int) | super_total[nsuper] (int) | total (int64)
+  size_t bytes;
+  int64_t* super_off;
+  int* tile_local;
+  int64_t* total;
+};
 
 struct ah_ctx {
   int device;
@@ -44,6 +61,13 @@ struct ah_ctx {
   int opt_sort_msd;            // sort_indices: 0 LSD passes only, 1 auto (ARROWHIP_SORT_MSD)
   int opt_scan_segment_log2;   // cumulative_sum: bytes of input per segment (ARROWHIP_SCAN_SEGMENT_LOG2; 0 = one segment)
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
+  ah_filter_cache fcache;  // ah_filter.hip
+  int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
+  int opt_take_vec;
+  // two words of coherent (fine-grained) pinned host memory a kernel can store to: {value, sequence number}.  A count the host
+  // must see before it can go on (ah_filter_count) is polled here instead of paying a stream synchronisation's wake-up.
+  unsigned long long* mailbox;
+  unsigned long long mailbox_seq;
   char err[512];
 };
 
@@ -78,12 +102,28 @@ static inline int ah_fail(ah_ctx* ctx, int code, const char* fmt, ...) {
                      __FILE__, __LINE__);                                              \
   } while (0)
 
-#define AH_ENTER(ctx)                                                  \
+#define AH_ENTER_KEEP(ctx)                                             \
   do {                                                                 \
     if (!(ctx)) return AH_EINVALID;                                    \
     (ctx)->err[0] = 0;                                                 \
     AH_HIP((ctx), hipSetDevice((ctx)->device));                        \
   } while (0)
+
+#define AH_ENTER(ctx)                                                  \
+  do {                                                                 \
+    AH_ENTER_KEEP(ctx);                                                \
+    (ctx)->fcache.valid = false;                                       \
+  } while (0)
+
+// does a write to [p, p + nbytes) touch the mask the filter cache was computed from?
+static inline bool ah_fcache_overlaps(const ah_ctx* c, const void* p, size_t nbytes) {
+  if (!c->fcache.valid) return false;
+  const uintptr_t a = (uintptr_t)p, b = a + nbytes;
+  const uintptr_t lo = (uintptr_t)(c->fcache.foff >> 3), hi = (uintptr_t)((c->fcache.foff + c->fcache.n + 7) >> 3);
+  for (const uint8_t* bm : {c->fcache.fdata, c->fcache.fvalid})
+    if (bm && a < (uintptr_t)bm + hi && (uintptr_t)bm + lo < b) return true;
+  return false;
+}
 
 #define AH_LAUNCH_CHECK(ctx) AH_HIP((ctx), hipGetLastError())
 

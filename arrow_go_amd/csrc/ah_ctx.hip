@@ -25,6 +25,8 @@ static int ctx_init_common(ah_ctx* c) {
   AH_HIP(c, hipEventCreate(&c->t1));
   AH_HIP(c, hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
   AH_HIP(c, hipMalloc((void**)&c->dscalars, (64 + 4096) * sizeof(uint64_t)));
+  AH_HIP(c, hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(c->mailbox, 0, 64);
   hipDeviceProp_t prop;
   AH_HIP(c, hipGetDeviceProperties(&prop, c->device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -42,6 +44,7 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_sort_msd = env_int("ARROWHIP_SORT_MSD", 1);
   c->opt_scan_segment_log2 = env_int("ARROWHIP_SCAN_SEGMENT_LOG2", 0);   // 0 = one segment: segments measured slower
   c->opt_take_gather_lds = env_int("ARROWHIP_TAKE_GATHER_LDS", 1);   // 1: the window's validity bits in LDS (ah_take_binned.hip)
+  c->opt_take_vec = env_int("ARROWHIP_TAKE_VEC", 1);   // 0: one row per lane always, 1: V rows per lane when the sample says clustered, 2: always
   c->opt_take_gather_load = env_int("ARROWHIP_TAKE_GATHER_LOAD", 0);   // 0 plain, 1 nontemporal, 2 L1-bypassing (sc1)
   return AH_OK;
 }
@@ -82,6 +85,8 @@ AH_EXPORT void ah_ctx_destroy(ah_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->dscalars) (void)hipFree(c->dscalars);
+  if (c->mailbox) (void)hipHostFree(c->mailbox);
+  if (c->fcache.buf) (void)hipFree(c->fcache.buf);
   if (c->temp) (void)hipFree(c->temp);
   (void)hipEventDestroy(c->ev_copy);
   (void)hipEventDestroy(c->ev_compute);
@@ -104,6 +109,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "take_window_log2")) c->opt_take_window_log2 = (int)value;
   else if (!strcmp(name, "take_gather_wg_per_cu")) c->opt_take_gather_wg = (int)value;
   else if (!strcmp(name, "take_gather_lds")) c->opt_take_gather_lds = (int)value;
+  else if (!strcmp(name, "take_vec")) c->opt_take_vec = (int)value;
   else if (!strcmp(name, "take_gather_load")) c->opt_take_gather_load = (int)value;
   else if (!strcmp(name, "groupby_partition")) c->opt_groupby_partition = (int)value;
   else if (!strcmp(name, "groupby_keys")) c->opt_groupby_keys = (int)value;
@@ -146,7 +152,7 @@ int ah_temp_reserve(ah_ctx* c, size_t nbytes, void** out) {
 }
 
 AH_EXPORT int ah_buf_alloc(ah_ctx* c, size_t nbytes, void** dptr_host) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   if (!dptr_host) return ah_fail(c, AH_EINVALID, "ah_buf_alloc: null out pointer");
   *dptr_host = nullptr;
   if (nbytes == 0) nbytes = 1;
@@ -164,7 +170,7 @@ AH_EXPORT int ah_buf_free(ah_ctx* c, void* dptr) {
 }
 
 AH_EXPORT int ah_host_alloc_pinned(ah_ctx* c, size_t nbytes, void** hptr_host) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   if (!hptr_host) return ah_fail(c, AH_EINVALID, "ah_host_alloc_pinned: null out pointer");
   if (nbytes == 0) nbytes = 1;
   nbytes = (nbytes + 63) & ~(size_t)63;
@@ -173,13 +179,14 @@ AH_EXPORT int ah_host_alloc_pinned(ah_ctx* c, size_t nbytes, void** hptr_host) {
 }
 
 AH_EXPORT int ah_host_free_pinned(ah_ctx* c, void* hptr) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   if (hptr) AH_HIP(c, hipHostFree(hptr));
   return AH_OK;
 }
 
 AH_EXPORT int ah_upload_async(ah_ctx* c, void* dptr, const void* hptr, size_t nbytes) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
+  if (ah_fcache_overlaps(c, dptr, nbytes)) c->fcache.valid = false;
   if (nbytes == 0) return AH_OK;
   // the copy must not overtake compute work that still reads/writes dptr
   AH_HIP(c, hipEventRecord(c->ev_compute, c->stream));
@@ -191,7 +198,7 @@ AH_EXPORT int ah_upload_async(ah_ctx* c, void* dptr, const void* hptr, size_t nb
 }
 
 AH_EXPORT int ah_download_async(ah_ctx* c, void* hptr, const void* dptr, size_t nbytes) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   if (nbytes == 0) return AH_OK;
   AH_HIP(c, hipEventRecord(c->ev_compute, c->stream));
   AH_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute, 0));
@@ -202,35 +209,72 @@ AH_EXPORT int ah_download_async(ah_ctx* c, void* hptr, const void* dptr, size_t 
 }
 
 AH_EXPORT int ah_memset_async(ah_ctx* c, void* dptr, int byte_value, size_t nbytes) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
+  if (ah_fcache_overlaps(c, dptr, nbytes)) c->fcache.valid = false;
   if (nbytes == 0) return AH_OK;
   AH_HIP(c, hipMemsetAsync(dptr, byte_value, nbytes, c->stream));
   return AH_OK;
 }
 
+namespace {
+// Device-to-device copy written like the streaming kernels of this library (16 bytes per lane and access, nontemporal, four
+// accesses in flight per lane, exact grid): hipMemcpyDtoD reaches 4.8–5.1 TB/s of read + write on this part, this loop the
+// same ≈ 6.3 TB/s plateau as the Add — so it is both what Concatenate moves chunks with and the measured streaming ceiling
+// bench.py reports beside the 8 TB/s specification (`roofline.measured_copy_GB/s`).
+constexpr int kCopyBlock = 256, kCopyUnroll = 4;
+typedef unsigned copy_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kCopyBlock) void copy16_kernel(const copy_v4* __restrict__ src, copy_v4* __restrict__ dst, int64_t nvec) {
+  const int64_t i = (int64_t)blockIdx.x * kCopyBlock * kCopyUnroll + threadIdx.x;
+  if (i + (int64_t)(kCopyUnroll - 1) * kCopyBlock < nvec) {
+    copy_v4 x[kCopyUnroll];
+#pragma unroll
+    for (int k = 0; k < kCopyUnroll; k++) x[k] = __builtin_nontemporal_load(&src[i + (int64_t)k * kCopyBlock]);
+#pragma unroll
+    for (int k = 0; k < kCopyUnroll; k++) __builtin_nontemporal_store(x[k], &dst[i + (int64_t)k * kCopyBlock]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kCopyUnroll; k++) {
+      const int64_t j = i + (int64_t)k * kCopyBlock;
+      if (j < nvec) dst[j] = src[j];
+    }
+  }
+}
+}  // namespace
+
 AH_EXPORT int ah_copy_async(ah_ctx* c, void* dst, const void* src, size_t nbytes) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
+  if (ah_fcache_overlaps(c, dst, nbytes)) c->fcache.valid = false;
   if (nbytes == 0) return AH_OK;
   if (!dst || !src) return ah_fail(c, AH_EINVALID, "copy: null buffer");
+  const uintptr_t d = (uintptr_t)dst, s = (uintptr_t)src;
+  const bool disjoint = d + nbytes <= s || s + nbytes <= d;
+  if (nbytes >= ((size_t)1 << 20) && ((d | s) & 15) == 0 && disjoint) {
+    const int64_t nvec = (int64_t)(nbytes / 16);
+    copy16_kernel<<<(unsigned)ah_ceil_div(nvec, (int64_t)kCopyBlock * kCopyUnroll), kCopyBlock, 0, c->stream>>>((const copy_v4*)src, (copy_v4*)dst, nvec);
+    AH_LAUNCH_CHECK(c);
+    const size_t done = (size_t)nvec * 16;
+    if (done < nbytes) AH_HIP(c, hipMemcpyAsync((uint8_t*)dst + done, (const uint8_t*)src + done, nbytes - done, hipMemcpyDeviceToDevice, c->stream));
+    return AH_OK;
+  }
   AH_HIP(c, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, c->stream));
   return AH_OK;
 }
 
 AH_EXPORT int ah_sync(ah_ctx* c) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   AH_HIP(c, hipStreamSynchronize(c->copy_stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
   return AH_OK;
 }
 
 AH_EXPORT int ah_timer_start(ah_ctx* c) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   AH_HIP(c, hipEventRecord(c->t0, c->stream));
   return AH_OK;
 }
 
 AH_EXPORT int ah_timer_stop(ah_ctx* c, float* ms_host) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   AH_HIP(c, hipEventRecord(c->t1, c->stream));
   AH_HIP(c, hipEventSynchronize(c->t1));
   float ms = 0.f;
@@ -242,7 +286,7 @@ AH_EXPORT int ah_timer_stop(ah_ctx* c, float* ms_host) {
 // numbered event slots on the compute stream: lets a harness bracket individual
 // kernels inside a longer timed region without synchronising in between
 AH_EXPORT int ah_event_record(ah_ctx* c, int slot) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   if (slot < 0 || slot >= (1 << 16)) return ah_fail(c, AH_EINVALID, "event_record: slot out of range");
   if (slot >= c->n_marks) {
     int n = c->n_marks ? c->n_marks : 64;
@@ -259,7 +303,7 @@ AH_EXPORT int ah_event_record(ah_ctx* c, int slot) {
 }
 
 AH_EXPORT int ah_event_elapsed_ms(ah_ctx* c, int slot_a, int slot_b, float* ms_host) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   if (slot_a < 0 || slot_b < 0 || slot_a >= c->n_marks || slot_b >= c->n_marks || !c->marks[slot_a] || !c->marks[slot_b])
     return ah_fail(c, AH_EINVALID, "event_elapsed_ms: slot never recorded");
   AH_HIP(c, hipEventSynchronize(c->marks[slot_b]));
@@ -271,7 +315,7 @@ AH_EXPORT int ah_event_elapsed_ms(ah_ctx* c, int slot_a, int slot_b, float* ms_h
 
 // ArrowDeviceArray.sync_event for ARROW_DEVICE_ROCM is a hipEvent_t* (arrow/cdata/abi.h:104-128)
 AH_EXPORT int ah_wait_event(ah_ctx* c, void* hip_event_ptr) {
-  AH_ENTER(c);
+  AH_ENTER_KEEP(c);
   if (!hip_event_ptr) return AH_OK;
   AH_HIP(c, hipStreamWaitEvent(c->stream, *(hipEvent_t*)hip_event_ptr, 0));
   return AH_OK;

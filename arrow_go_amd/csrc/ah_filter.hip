@@ -28,6 +28,7 @@
 //      value-validity word by the selection word, OR-ed into place.
 // Algorithmic bytes per input row (w = 8): 8 + 1/8 (+1/8 with value validity) read,
 // 8·s (+ s/8) written for selectivity s.
+#include <chrono>
 #include "ah_common.h"
 
 namespace {
@@ -147,8 +148,11 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __res
 }
 
 // ---- 2. exclusive scan of the super-tile totals (one block; ≤ a few thousand entries) -
+// mailbox (optional): coherent pinned HOST memory — {total, seq} stored with system scope, so the host that needs the count to go
+// on (ah_filter_count) can poll for it instead of waiting for the stream
 __global__ __launch_bounds__(1024) void super_scan_kernel(const int* __restrict__ super_total, int64_t nsuper,
-                                                           int64_t* __restrict__ super_off, int64_t* __restrict__ total) {
+                                                           int64_t* __restrict__ super_off, int64_t* __restrict__ total,
+                                                           unsigned long long* mailbox, unsigned long long seq) {
   __shared__ int64_t wave_tot[16];
   __shared__ int64_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,7 +180,13 @@ __global__ __launch_bounds__(1024) void super_scan_kernel(const int* __restrict_
     if (tid == 0) carry_s += tot;
     __syncthreads();
   }
-  if (tid == 0) *total = carry_s;
+  if (tid == 0) {
+    *total = carry_s;
+    if (mailbox) {
+      __hip_atomic_store(&mailbox[0], (unsigned long long)carry_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&mailbox[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---- 3. compaction -------------------------------------------------------------------
@@ -311,25 +321,42 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const void* __restrict_
   }
 }
 
+// to_cache: the tables go to the context's filter cache (ah_common.h) instead of the scratch arena, and the total is also posted
+// to the host mailbox with sequence number `seq`
 template <int W>
 int run_counts(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
-               int** tile_local_out, int64_t** super_off_out, int64_t** total_out, int64_t* ntiles_out) {
+               int** tile_local_out, int64_t** super_off_out, int64_t** total_out, int64_t* ntiles_out, bool to_cache = false,
+               unsigned long long seq = 0) {
   constexpr int TILE = TileBytes<W>() / W;
   constexpr int WPT = TILE / 64;
   int64_t ntiles = ah_ceil_div(n, TILE);
   int64_t nsuper = ah_ceil_div(ntiles, kSuper);
-  // scratch layout: super_off[nsuper] (int64) | tile_local[ntiles] (int) | super_total[nsuper] (int)
-  size_t bytes = (size_t)nsuper * sizeof(int64_t) + (size_t)ntiles * sizeof(int) + (size_t)nsuper * sizeof(int) + 64;
+  // layout: super_off[nsuper] (int64) | tile_local[ntiles] (int) | super_total[nsuper] (int) | total (int64, cache only)
+  const size_t tables = (size_t)nsuper * sizeof(int64_t) + (size_t)ntiles * sizeof(int) + (size_t)nsuper * sizeof(int);
+  size_t bytes = ((tables + 7) & ~(size_t)7) + 64;
   void* scratch;
-  int rc = ah_scratch_reserve(c, bytes, &scratch);
-  if (rc != AH_OK) return rc;
+  if (to_cache) {
+    ah_filter_cache& fc = c->fcache;
+    if (bytes > fc.bytes) {
+      AH_HIP(c, hipStreamSynchronize(c->stream));   // a fill may still be reading the old block
+      if (fc.buf) AH_HIP(c, hipFree(fc.buf));
+      fc.buf = nullptr; fc.bytes = 0;
+      const size_t want = (bytes + 65535) & ~(size_t)65535;
+      AH_HIP(c, hipMalloc(&fc.buf, want));
+      fc.bytes = want;
+    }
+    scratch = fc.buf;
+  } else {
+    int rc = ah_scratch_reserve(c, bytes, &scratch);
+    if (rc != AH_OK) return rc;
+  }
   int64_t* super_off = (int64_t*)scratch;
   int* tile_local = (int*)(super_off + nsuper);
   int* super_total = tile_local + ntiles;
-  int64_t* total = (int64_t*)&c->dscalars[1];
+  int64_t* total = to_cache ? (int64_t*)((uint8_t*)scratch + ((tables + 7) & ~(size_t)7)) : (int64_t*)&c->dscalars[1];
   tile_count_kernel<WPT><<<(unsigned)nsuper, kBlock, 0, c->stream>>>(fdata, fvalid, foff, n, null_sel, tile_local, super_total, ntiles);
   AH_LAUNCH_CHECK(c);
-  super_scan_kernel<<<1, 1024, 0, c->stream>>>(super_total, nsuper, super_off, total);
+  super_scan_kernel<<<1, 1024, 0, c->stream>>>(super_total, nsuper, super_off, total, to_cache ? c->mailbox : nullptr, seq);
   AH_LAUNCH_CHECK(c);
   *tile_local_out = tile_local; *super_off_out = super_off; *total_out = total; *ntiles_out = ntiles;
   return AH_OK;
@@ -345,9 +372,17 @@ __global__ void filter_status_kernel(const int64_t* __restrict__ total, const un
 template <int W, bool INDICES>
 int run_filter(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t voff, const uint8_t* fdata,
                const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel, int64_t n_out, void* out_values,
-               uint8_t* out_valid, int64_t* out_null_count_host, int64_t* status_dev = nullptr) {
+               uint8_t* out_valid, int64_t* out_null_count_host, int64_t* status_dev = nullptr, bool cached = false) {
   int* tile_local; int64_t* super_off; int64_t* total; int64_t ntiles;
-  int rc = run_counts<W>(c, fdata, fvalid, foff, n, null_sel, &tile_local, &super_off, &total, &ntiles);
+  int rc = AH_OK;
+  const ah_filter_cache& fc = c->fcache;
+  if (cached && fc.fdata == fdata && fc.fvalid == fvalid && fc.foff == foff && fc.n == n && fc.null_sel == null_sel &&
+      fc.tile_rows == TileBytes<W>() / W) {
+    // the count call that preceded this fill left the tile prefixes of this very mask: nothing to recount
+    tile_local = fc.tile_local; super_off = fc.super_off; total = fc.total; ntiles = fc.ntiles;
+  } else {
+    rc = run_counts<W>(c, fdata, fvalid, foff, n, null_sel, &tile_local, &super_off, &total, &ntiles);
+  }
   if (rc != AH_OK) return rc;
   unsigned long long* valid_total = (unsigned long long*)&c->dscalars[2];
   if (out_valid) {
@@ -374,7 +409,8 @@ int run_filter(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t vof
       rc = ah_popcount_async(c, out_valid, 0, n_out, valid_total);
       if (rc != AH_OK) return rc;
     }
-    AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[1], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipMemcpyAsync(&c->pinned[0], total, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipMemcpyAsync(&c->pinned[1], valid_total, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     AH_HIP(c, hipStreamSynchronize(c->stream));
     int64_t tot = (int64_t) * (volatile uint64_t*)&c->pinned[0];
     int64_t nvalid = (int64_t) * (volatile uint64_t*)&c->pinned[1];
@@ -396,17 +432,35 @@ AH_EXPORT int ah_filter_count(ah_ctx* c, const uint8_t* fdata, const uint8_t* fv
   if (n == 0) return AH_OK;
   if (!fdata) return ah_fail(c, AH_EINVALID, "filter_count: null filter data");
   int* tile_local; int64_t* super_off; int64_t* total; int64_t ntiles;
-  int rc = run_counts<8>(c, fdata, fvalid, foff, n, null_sel, &tile_local, &super_off, &total, &ntiles);
+  const unsigned long long seq = ++c->mailbox_seq;
+  int rc = run_counts<8>(c, fdata, fvalid, foff, n, null_sel, &tile_local, &super_off, &total, &ntiles, /*to_cache=*/true, seq);
   if (rc != AH_OK) return rc;
-  AH_HIP(c, hipMemcpyAsync(c->pinned, total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-  AH_HIP(c, hipStreamSynchronize(c->stream));
-  *n_out_host = (int64_t) * (volatile uint64_t*)c->pinned;
+  // The host cannot go on without the count (it sizes the output: vector_selection.go:459-475), so it polls the two words the scan
+  // kernel posts to coherent pinned memory — a stream synchronisation's wake-up costs more than the two kernels together.  A
+  // kernel that never posts (a fault) is found by the synchronisation the poll falls back to.
+  bool seen = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0; !seen; spin++) {
+    if (__atomic_load_n(&c->mailbox[1], __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+    __builtin_ia32_pause();
+    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+  }
+  if (!seen) {
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(&c->mailbox[1], __ATOMIC_ACQUIRE) != seq) return ah_fail(c, AH_EHIP, "filter_count: the count kernel did not report");
+  }
+  *n_out_host = (int64_t)__atomic_load_n(&c->mailbox[0], __ATOMIC_RELAXED);
+  ah_filter_cache& fc = c->fcache;
+  fc.fdata = fdata; fc.fvalid = fvalid; fc.foff = foff; fc.n = n; fc.null_sel = null_sel; fc.tile_rows = TileBytes<8>() / 8;
+  fc.ntiles = ntiles; fc.super_off = super_off; fc.tile_local = tile_local; fc.total = total;
+  fc.valid = true;
   return AH_OK;
 }
 
 AH_EXPORT int ah_filter_primitive(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
                                   const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
                                   int64_t n_out, void* out_values, uint8_t* out_valid, int64_t* out_null_count_host) {
+  const bool cached = c && c->fcache.valid;   // read before AH_ENTER drops it: this fill is the call the cache was left for
   AH_ENTER(c);
   if (n < 0 || foff < 0 || voff < 0) return ah_fail(c, AH_EINVALID, "filter: negative length/offset");
   if (out_null_count_host) *out_null_count_host = 0;
@@ -414,13 +468,22 @@ AH_EXPORT int ah_filter_primitive(ah_ctx* c, int byte_width, const void* values,
   if (!fdata || !values) return ah_fail(c, AH_EINVALID, "filter: null input buffer");
   if (((uintptr_t)values | (uintptr_t)out_values) & (uintptr_t)(byte_width - 1))
     return ah_fail(c, AH_EINVALID, "filter: buffer not element-aligned");
+  int rc;
   switch (byte_width) {
-    case 1: return run_filter<1, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
-    case 2: return run_filter<2, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
-    case 4: return run_filter<4, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
-    case 8: return run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host);
+    case 1: rc = run_filter<1, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host, nullptr, cached); break;
+    case 2: rc = run_filter<2, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host, nullptr, cached); break;
+    case 4: rc = run_filter<4, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host, nullptr, cached); break;
+    case 8: rc = run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n_out, out_values, out_valid, out_null_count_host, nullptr, cached); break;
+    default: return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);  // vector_selection.go:515
   }
-  return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);  // vector_selection.go:515
+  // the same mask may filter the next column: the tables stay valid unless this call's outputs lie on the mask's bytes
+  if (rc == AH_OK && cached) {
+    c->fcache.valid = true;
+    const size_t rows_out = (size_t)(n_out >= 0 ? n_out : n);
+    if (ah_fcache_overlaps(c, out_values, rows_out * (size_t)byte_width) || (out_valid && ah_fcache_overlaps(c, out_valid, (rows_out + 7) / 8)))
+      c->fcache.valid = false;
+  }
+  return rc;
 }
 
 AH_EXPORT int ah_filter_primitive_dev(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,

@@ -572,7 +572,10 @@ int ah_take_binned_try(ah_ctx* c, int byte_width, const void* values, const uint
     AH_HIP(c, hipMemcpyAsync(&c->pinned[8], hits, sizeof(*hits), hipMemcpyDeviceToHost, c->stream));
     AH_HIP(c, hipStreamSynchronize(c->stream));
     const uint64_t h = *(volatile uint64_t*)&c->pinned[8];
-    if (h * 4 > 64 * 255) return AH_OK;  // more than a quarter of the sampled neighbours sit within one 128-byte line
+    if (h * 4 > 64 * 255) {  // more than a quarter of the sampled neighbours sit within one 128-byte line
+      if (c->opt_take_vec) c->take_clustered_hint = 1;   // … and the direct path takes V rows per lane with merged 16-byte accesses (ah_take.hip)
+      return AH_OK;
+    }
   }
   // temporaries
   const size_t table = (size_t)p.nb * (size_t)p.ntiles * sizeof(unsigned);

@@ -35,20 +35,27 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ≈ 6.3 TB/s
 
 
+PMC_PROFILE = "r03_pmc_by_workload.json"   # THIS round's counters (scripts/prof_workloads.py + pmc_by_workload.py on the GPU box)
+
+
 def pmc_traffic(rows):
-    """HBM bytes per launch of the Int64 Add kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE),
-    or None if the profile is for a different size."""
+    """(HBM bytes per launch of the Int64 Add kernel, where the figure comes from): the current round's committed rocprofv3
+    PMC passes (profiles/r03_pmc_by_workload.json — FETCH_SIZE with the calibrated gfx950 streaming factor + WRITE_SIZE), or
+    (None, why) when that file is absent or was taken at another size — never an older round's file."""
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if d.get("rows") != rows:
-            return None
-        for k, v in d["kernels"].items():
-            if "binary_kernel<unsigned long, 0, 0, true" in k:
-                return int(v["hbm_bytes_per_launch"])
+        d = json.load(open(path))
     except Exception:
-        pass
-    return None
+        return None, f"profiles/{PMC_PROFILE} not present (counters are collected in a separate rocprofv3 --pmc run)"
+    if d.get("rows") != rows:
+        return None, f"profiles/{PMC_PROFILE} was taken at {d.get('rows')} rows, this run has {rows}"
+    for w in d.get("workloads", {}).values():
+        for k, v in w.get("kernels", {}).items():
+            if "binary_kernel<unsigned long, 0, 0, true" in k and "fetch_kib_raw" in v:
+                # streaming 16-byte lane loads are tallied at half their bytes (128-byte requests counted as 64: the file's own
+                # calibration rows show it), writes at face value
+                return int(v["fetch_kib_raw"] * 1024 * 2 + v["write_kib"] * 1024), f"profiles/{PMC_PROFILE}: FETCH_SIZE x2 (calibrated) + WRITE_SIZE"
+    return None, f"profiles/{PMC_PROFILE} holds no row for the Int64 Add kernel"
 
 
 def parse():
@@ -131,6 +138,28 @@ def cpu_baseline(sample_rows, reps):
                       f"included, as the Go executor pays), host has {os.cpu_count()} logical cores"}
 
 
+def cpu_baseline_mt():
+    """the same reference AVX2 kernels on ALL host cores (oracle/_ref/bench_ref_mt: N threads over contiguous 1/N shards with a
+    final combine — what a Go user gets from chunking + ExecCtx.NumParallel), 2^27-row columns"""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "bench_ref_mt")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/bench_ref_mt not built"}
+    nproc = os.cpu_count() or 1
+    cand = sorted({nproc, max(1, nproc // 2), max(1, nproc // 4)}, reverse=True)[:3]
+    t0 = time.perf_counter()
+    r = json.loads(subprocess.run([exe, os.path.join(ROOT, "oracle", "_ref")] + [str(t) for t in cand], capture_output=True, text=True, timeout=240, check=True).stdout)
+    best = None
+    for t in cand:
+        ms = r[f"Int64_Add_1GiB_threads{t}"]["ms"] + r[f"Float64_Sum_1GiB_threads{t}"]["ms"]
+        gbs = 32.0 * (1 << 27) / (ms * 1e-3) / 1e9
+        if best is None or gbs > best[0]:
+            best = (gbs, t, ms)
+    return {"value": round(best[0], 1), "unit": "GB/s", "cores": best[1], "kind": "reference",
+            "sample": f"best of {cand} threads: Int64 Add + Float64 Sum over 2^27-row columns, each thread a contiguous shard, best of 3 timed "
+                      f"repetitions ({best[2]:.1f} ms per step; whole measurement {time.perf_counter() - t0:.0f} s)", "all": r}
+
+
 def random_bits(rng, n, p, pad=64):
     """n Bernoulli(p) bits packed LSB-first"""
     out = np.zeros(n // 8 + pad, np.uint8)
@@ -167,7 +196,8 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     res = ctx.alloc(64)
     # the chip's streaming ceiling in this very session: a device-to-device copy of 1 GiB, 2 bytes moved per byte copied
     from arrow_go_amd._native import check as _check, lib as _lib
-    timed("ceiling_hipMemcpyDtoD", 16 * rows, lambda: _check(ctx.handle, _lib.ah_copy_async(ctx.handle, c.ptr, a.ptr, 8 * rows)))
+    # (ah_copy_async = the library's own 16-byte-per-lane copy kernel; hipMemcpyDtoD, which rounds 1-2 reported here, stops at ≈ 5 TB/s)
+    timed("ceiling_copy_kernel", 16 * rows, lambda: _check(ctx.handle, _lib.ah_copy_async(ctx.handle, c.ptr, a.ptr, 8 * rows)))
     timed("sum_float64", 8 * rows, lambda: ctx.sum_float64_dev(x, rows, res))
     timed("sum_int64", 8 * rows, lambda: ctx.sum_int64_dev(a, rows, res))
     timed("add_int64", 24 * rows, lambda: ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, a, b, c, rows))
@@ -187,9 +217,20 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     fvalid = ctx.to_device(random_bits(rng, rows, 0.9))
 
     def filter_case(name, fv, null_sel):
+        # the whole two-phase call the protocol needs (vector_selection.go:459 then :475): ah_filter_count (the host gets n_out and
+        # sizes the output; its tile prefixes stay in the context for the fill) + ah_filter_primitive.  The fill alone — what this
+        # line timed in rounds 1–2 — is kept beside it as "fill_only_ms".
         n_out = ctx.filter_count(fmask, fv, 0, rows, null_sel)
         traffic = (8 + 0.125 + 0.125 + (0.125 if fv is not None else 0)) * rows + (8 + 0.125) * n_out
-        timed(name, traffic, lambda: ctx.filter_primitive(8, a, vvalid, 0, fmask, fv, 0, rows, null_sel, n_out, c, ovalid, want_null_count=False))
+
+        def call():
+            k = ctx.filter_count(fmask, fv, 0, rows, null_sel)
+            ctx.filter_primitive(8, a, vvalid, 0, fmask, fv, 0, rows, null_sel, k, c, ovalid, want_null_count=False)
+
+        timed(name + "_fill_only", traffic, lambda: ctx.filter_primitive(8, a, vvalid, 0, fmask, fv, 0, rows, null_sel, n_out, c, ovalid, want_null_count=False))
+        fill_only = out.pop(name + "_fill_only")["ms"]
+        timed(name, traffic, call)
+        out[name]["fill_only_ms"] = fill_only
         out[name]["input_GB/s"] = round(8 * rows / out[name]["ms"] / 1e6, 1)
         out[name]["selected"] = round(n_out / rows, 4)
 
@@ -314,13 +355,11 @@ def main():
         if args.collectives == "ah":
             # rank 0's RCCL unique id reaches the others over the launcher's process group; from here on the data-path
             # collectives are C-ABI calls on the library's own stream
-            try:
-                uid = [ah.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                comm = ah.Comm(ctx, rank, world, uid[0])
-            except Exception as e:  # stay measurable: fall back to torch's group and say so
-                sys.stderr.write(f"bench: ah_comm unavailable ({e!r}); using torch.distributed collectives\n")
-                comm = None
+            # no fallback: `--collectives ah` either measures ah_comm_* or fails (a silent switch to torch's collectives would put
+            # another library's numbers under this one's name); `--collectives torch` is the explicit alternative
+            uid = [ah.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = ah.Comm(ctx, rank, world, uid[0])
     else:
         ctx = ah.Context(0)
 
@@ -474,11 +513,13 @@ def main():
                                    + (" + 8-byte RCCL all-reduce of the partial sums" + (" (ah_comm_allreduce_sum)" if comm is not None else " (torch.distributed)")
                                       if use_dist else ""),
                        "rows_per_gpu": rows, "bytes_per_row_per_step": 32,
-                       "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective"},
+                       "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective",
+                       "collectives": ("ah_comm (RCCL through the C ABI)" if comm is not None else "torch.distributed") if use_dist else "none (single process)"},
             "roofline": {"bound": "hbm", "kernel": "binary_kernel<uint64, ADD, array∘array> (Int64 Add)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": args.traffic if args.traffic is not None else pmc_traffic(rows),
+                         "traffic": args.traffic if args.traffic is not None else pmc_traffic(rows)[0],
+                         "traffic_source": "--traffic" if args.traffic is not None else pmc_traffic(rows)[1],
                          "avg_launch_ms": round(add_avg_ms, 5), "algorithmic_bytes_per_launch": int(24 * rows)},
         }
         result["c4_filter_aggregate"] = c4
@@ -488,13 +529,17 @@ def main():
                 result["kernels"] = per_kernel_table(ctx, rows, a, b, c, x)
             except Exception as e:  # the table is informative; never lose the headline over it
                 result["kernels"] = {"error": repr(e)}
-            if isinstance(result["kernels"].get("ceiling_hipMemcpyDtoD"), dict):
-                result["roofline"]["measured_copy_GB/s"] = result["kernels"]["ceiling_hipMemcpyDtoD"]["GB/s"]
+            if isinstance(result["kernels"].get("ceiling_copy_kernel"), dict):
+                result["roofline"]["measured_copy_GB/s"] = result["kernels"]["ceiling_copy_kernel"]["GB/s"]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(min(rows, 1 << 26), 8)
             except Exception as e:
                 result["cpu_baseline"] = {"error": repr(e)}
+            try:
+                result["cpu_baseline_mt"] = cpu_baseline_mt()
+            except Exception as e:
+                result["cpu_baseline_mt"] = {"error": repr(e)}
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if comm is not None:
         comm.close()

@@ -232,6 +232,57 @@ def test_filter_bit_exact(hip, orc_be, dtype):
                         assert hip.filter_count(fdata, fvalid, foff, n, null_sel) == len(e[0])
 
 
+def test_filter_count_cache(ctx, orc_be):
+    """ah_filter_count leaves the tile prefixes of its mask for the fill that follows (no second count).  The fill must still see
+    the mask as it IS: anything that can change device memory between the two calls — an upload or a kernel writing the mask's
+    bytes — drops the tables; allocation / memset of other buffers and a second fill with the same mask keep them."""
+    import arrow_go_amd as ah
+    N = ah._native
+    rng = np.random.default_rng(45)
+    n = 5 * 2048 + 77
+    vals = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+    vals2 = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+    dv, dv2 = ctx.to_device(vals), ctx.to_device(vals2)
+    bits_a = rng.random(n + 64) < 0.4
+    bits_b = np.roll(bits_a[:n], 1234)                       # same number of survivors, other rows
+    mask_a = np.packbits(bits_a, bitorder="little")
+    mask_b = np.packbits(np.concatenate([bits_b, bits_a[n:]]), bitorder="little")
+    dm = ctx.to_device(mask_a)
+
+    def fill(values_dev, k):
+        ob = ctx.alloc(k * 8 + 128)                           # alloc + memset between count and fill, as the Go executor does
+        ob.memset(0xCD)
+        ctx.filter_primitive(8, values_dev, None, 0, dm, None, 0, n, DROP, k, ob, None)
+        r = ob.download(np.int64, k)
+        ob.free()
+        return r
+
+    k = ctx.filter_count(dm, None, 0, n, DROP)
+    assert k == int(bits_a[:n].sum())
+    assert fill(dv, k).tobytes() == vals[bits_a[:n]].tobytes()
+    assert fill(dv2, k).tobytes() == vals2[bits_a[:n]].tobytes()      # second column, same tables
+    # the mask changes under the same pointer after the count: upload
+    k = ctx.filter_count(dm, None, 0, n, DROP)
+    dm.upload(mask_b)
+    assert fill(dv, k).tobytes() == vals[bits_b].tobytes()
+    # ... and by a kernel: greater(vals, 0) written over the mask
+    ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT64, dv, np.array([0], np.int64), dm, n, 0)
+    gt = vals > 0
+    k = ctx.filter_count(dm, None, 0, n, DROP)
+    assert k == int(gt.sum())
+    ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT64, dv2, np.array([0], np.int64), dm, n, 0)   # same pointer, new content, stale tables
+    gt2 = vals2 > 0
+    assert fill(dv, int(gt2.sum())).tobytes() == vals[gt2].tobytes()
+    # other range of the same buffer: recounted
+    k = ctx.filter_count(dm, None, 0, n, DROP)
+    sub = gt2[3:3 + n - 100]
+    ob = ctx.alloc(n * 8 + 128)
+    ctx.filter_primitive(8, dv, None, 0, dm, None, 3, n - 100, DROP, int(sub.sum()), ob, None)
+    assert ob.download(np.int64, int(sub.sum())).tobytes() == vals[:n - 100][sub].tobytes()
+    for b in (dv, dv2, dm, ob):
+        b.free()
+
+
 def test_filter_dev_flavour(hip, orc_be):
     """ah_filter_primitive_dev: no count call, worst-case outputs, {selected, nulls} left on the device — same bytes"""
     rng = np.random.default_rng(44)
@@ -325,6 +376,55 @@ def test_take_bit_exact(hip, orc_be, vdtype, idtype):
                 assert g[1].tobytes() == e[1].tobytes(), (vdtype, idtype, nvalues, nidx)
                 if want_valid:
                     assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+
+
+@pytest.mark.parametrize("vdtype", [np.float32, np.int64, np.uint32, np.float64])
+def test_take_vec_path_bit_exact(ctx, hip, orc_be, vdtype):
+    """take_vec_kernel (16 / W adjacent rows per lane; one merged 16-byte load when their indices are consecutive, ascending or
+    descending), forced on for every call: identity, reversed, sorted-with-repeats, runs broken by jumps, random; nulls on either
+    side with bit offsets; every index type; ragged ends; the first out-of-range index."""
+    rng = np.random.default_rng(55)
+    ctx.set_option("take_vec", 2)
+    try:
+        for nvalues, nidx in [(1, 1), (3, 2), (100, 63), (100, 1025), (5000, 4099), (70001, 70001), (300007, 131075)]:
+            vals = rand(rng, vdtype, nvalues)
+            base = np.arange(nidx, dtype=np.int64) % nvalues
+            pats = {"identity": base, "reverse": (nvalues - 1 - base), "sorted": np.sort(rng.integers(0, nvalues, nidx)),
+                    "random": rng.integers(0, nvalues, nidx)}
+            runs = base.copy()
+            cuts = rng.integers(0, nidx, max(1, nidx // 37))
+            runs[cuts] = rng.integers(0, nvalues, cuts.size)      # consecutive runs broken at odd and even rows
+            pats["broken_runs"] = runs
+            pats["rev_sorted"] = np.sort(rng.integers(0, nvalues, nidx))[::-1]
+            for name, ix64 in pats.items():
+                for idtype in ((np.int32, np.uint64, np.int16, np.uint8) if name in ("identity", "broken_runs") else (np.int32,)):
+                    hi = np.iinfo(idtype).max
+                    ix = np.minimum(ix64, min(hi, nvalues - 1)).astype(idtype)
+                    for voff, ioff in [(0, 0), (5, 3)]:
+                        nv = nvalues - voff
+                        if nv < 1:
+                            continue
+                        ixx = np.minimum(ix.astype(np.int64), nv - 1).astype(idtype)
+                        for vvalid, ivalid in [(None, None), (rand_bits(rng, nvalues + 8, 0.9), None), (None, rand_bits(rng, ioff + nidx + 8, 0.9)),
+                                               (rand_bits(rng, nvalues + 8, 0.5), rand_bits(rng, ioff + nidx + 8, 0.5))]:
+                            want_valid = vvalid is not None or ivalid is not None
+                            g = hip.take(vals[voff:], vvalid, voff, ixx, ivalid, ioff, True, want_valid)
+                            e = orc_be.take(vals[voff:], vvalid, voff, ixx, ivalid, ioff, True, want_valid)
+                            assert g[0] == e[0] == STATUS_OK
+                            assert g[1].tobytes() == e[1].tobytes(), (vdtype, name, idtype, nvalues, nidx, voff)
+                            if want_valid:
+                                assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3], (vdtype, name, idtype, nvalues, nidx, voff)
+        vals = rand(rng, vdtype, 50_000)
+        idx = np.arange(60_000, dtype=np.int32) % 50_000
+        bad = rng.integers(0, 60_000, 20)
+        idx[bad] = rng.integers(50_000, 1 << 30, 20)
+        idx[bad[::2]] *= -1
+        for iv in (None, rand_bits(rng, 60_000, 0.7)):
+            g = hip.take(vals, None, 0, idx, iv, 0, True, iv is not None)
+            e = orc_be.take(vals, None, 0, idx, iv, 0, True, iv is not None)
+            assert g[0] == e[0] == STATUS_EINDEX and g[4] == e[4]
+    finally:
+        ctx.set_option("take_vec", 1)
 
 
 def test_take_first_bad_index_random(hip, orc_be):
