@@ -7,6 +7,6 @@ it fails loudly if the HIP library is missing: there is no CPU fallback.
 """
 from . import _native  # noqa: F401  (raises ImportError if libarrowhip.so is absent)
 from ._native import (ArrowHipError, ErrInvalid, ErrIndex, ErrOverflow, ErrHip, ErrNotImplemented)  # noqa: F401
-from .device import Comm, Context, DeviceBuffer, device_count, expr_codegen  # noqa: F401
+from .device import Comm, Context, DeviceBuffer, Ingest, PinnedBuffer, device_count, expr_codegen  # noqa: F401
 
 __version__ = "0.1.0"

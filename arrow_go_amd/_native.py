@@ -173,6 +173,23 @@ _SIGS.update({
     "ah_expr_execute": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "ah_expr_codegen": [_vp, _int, _vp, _int, _vp, _int, _int, C.c_char_p, _sz, C.c_char_p, _sz, _pint],
 })
+_SIGS.update({
+    "ah_host_register": [_vp, _vp, _sz],
+    "ah_host_unregister": [_vp, _vp],
+    "ah_ingest_create": [_vp, _sz, _int, _pvp],
+    "ah_ingest_destroy": [_vp],
+    "ah_ingest_sum_float64": [_vp, _vp, _sz, _pd],
+    "ah_ingest_sum_int64": [_vp, _vp, _sz, _pi64],
+    "ah_ingest_arithmetic_binary": [_vp, _int, _i8, _vp, _vp, _vp, _i64],
+    "ah_ingest_filter_count": [_vp, _vp, _vp, _i64, _i64, _int, _pi64],
+    "ah_ingest_filter_primitive": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _pi64],
+    "ah_ingest_depth": [_vp],
+    "ah_ingest_slot_upload": [_vp, _int, _int, _sz, _vp, _sz, _int],
+    "ah_ingest_slot_ready": [_vp, _int, _int],
+    "ah_ingest_slot_release": [_vp, _int],
+    "ah_ingest_slot_download": [_vp, _int, _int, _sz, _vp, _sz],
+    "ah_ingest_wait": [_vp],
+})
 for _name, _args in _SIGS.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
@@ -183,6 +200,10 @@ lib.ah_last_error.argtypes = [_vp]
 lib.ah_last_error.restype = C.c_char_p
 lib.ah_expr_source.argtypes = [_vp]
 lib.ah_expr_source.restype = C.c_char_p
+lib.ah_ingest_chunk_bytes.argtypes = [_vp]
+lib.ah_ingest_chunk_bytes.restype = _sz
+lib.ah_ingest_slot_buffer.argtypes = [_vp, _int, _int]
+lib.ah_ingest_slot_buffer.restype = _vp
 lib.ah_version.argtypes = []
 lib.ah_version.restype = C.c_char_p
 

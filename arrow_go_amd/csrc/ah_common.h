@@ -152,6 +152,10 @@ int ah_take_binned_try(ah_ctx* ctx, int byte_width, const void* values, const ui
 int ah_groupby_partitioned_try(ah_ctx* ctx, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals,
                                const uint8_t* vvalid, int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts,
                                int64_t* out_first_rows, int64_t* out_ngroups, int32_t* out_null_group, int* used);
+// internal (ah_sum.hip): the workgroup partials of one chunk written to a caller-owned array (16 bytes reserved per partial; *n_written
+// counts 8-byte partials for the integer sums, 16-byte ones for Float64), and the one final reduction over all of them
+int ah_sum_chunk_partials(ah_ctx* ctx, int is_f64, const void* buf, size_t len, void* partials16, int max_partials, int* n_written);
+int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials16, int n, void* res_dev);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are

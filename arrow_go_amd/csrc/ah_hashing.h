@@ -94,7 +94,8 @@ __device__ __forceinline__ unsigned rank_of_row(unsigned fr, const unsigned long
 // group and give the IEEE result of any order: NaN if a NaN or both infinities were seen, else the infinity.
 //
 // WHICH emax.  A 53-bit significand shifted left by e − emax + 42 bits loses nothing while e ≥ emax − 42.  So every
-// call also finds the SMALLEST non-zero finite |x| (range[1], stored inverted so that both words are atomicMax targets):
+// call also finds the smallest biased exponent among its non-zero finite values (range[1] = 0x7ff − that exponent, 0 = none
+// seen: inverted so that both words are atomicMax targets, and one 32-bit register per lane in the passes that carry it):
 //   · the column spans ≤ 42 binades ("narrow", the usual case): ONE scale for the call, no addend is truncated, the
 //     128-bit sum is the exact sum and the result is its correctly rounded double — for every group, whatever its magnitude;
 //   · wider ("wide": an outlier or sentinel such as 1e300 next to ordinary values): one scale would truncate every
@@ -106,7 +107,7 @@ struct FxAcc {  // global accumulators of one call (device pointers); null for i
   unsigned long long* lo;
   unsigned long long* hi;
   unsigned* flags;
-  const unsigned long long* absmax;  // range[0] = bit pattern of the largest finite |x|, range[1] = ~(bit pattern of the smallest non-zero one)
+  const unsigned long long* absmax;  // range[0] = bit pattern of the largest finite |x|, range[1] = 0x7ff − smallest biased exponent of a non-zero finite |x| (denormals: 1)
   const unsigned long long* gmax;    // per-group largest finite |x| (wide columns); null: the call's one scale
 };
 __device__ __forceinline__ int fx_shift(unsigned long long absmax_bits) {
@@ -114,10 +115,15 @@ __device__ __forceinline__ int fx_shift(unsigned long long absmax_bits) {
   return 94 - ((e ? e : 1) - 1023);
 }
 // does one scale for the whole call truncate an addend?  (range as in FxAcc::absmax)
-__host__ __device__ __forceinline__ bool fx_wide(unsigned long long max_bits, unsigned long long inv_min_bits) {
-  if (!inv_min_bits) return false;   // no non-zero finite value at all
-  const int emax = (int)((max_bits >> 52) & 0x7ff), emin = (int)((~inv_min_bits >> 52) & 0x7ff);
-  return (emax ? emax : 1) - (emin ? emin : 1) > 42;
+__host__ __device__ __forceinline__ bool fx_wide(unsigned long long max_bits, unsigned long long inv_min_exp) {
+  if (!inv_min_exp) return false;   // no non-zero finite value at all
+  const int emax = (int)((max_bits >> 52) & 0x7ff), emin = 0x7ff - (int)inv_min_exp;
+  return (emax ? emax : 1) - emin > 42;
+}
+// 0x7ff − biased exponent of a non-zero finite |x| given as its bit pattern (a denormal counts as exponent 1, like fx_split)
+__device__ __forceinline__ unsigned fx_inv_exp(unsigned long long abs_bits) {
+  const unsigned e = (unsigned)(abs_bits >> 52);
+  return 0x7ffu - (e ? e : 1u);
 }
 // sets bit 1 of *flag (the partition-first paths' "redo the call on the id-based path" word) for a wide column
 __global__ void fx_range_check_kernel(const unsigned long long* __restrict__ range, unsigned* __restrict__ flag) {
@@ -170,10 +176,11 @@ __device__ __forceinline__ double fx_to_double(unsigned long long lo, unsigned l
   d = ldexp(d, -sh);
   return neg ? -d : d;
 }
-// out[0] = max, out[1] = max of the inverted bit patterns of the non-zero values (= ~min); both zeroed by the caller
+// out[0] = largest finite |x| (bits), out[1] = largest fx_inv_exp of the non-zero finite values; both zeroed by the caller
 __global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
                                                          int64_t n, unsigned long long* __restrict__ out) {
-  unsigned long long m = 0, im = 0;
+  unsigned long long m = 0;
+  unsigned im = 0;
   // 8 values per lane per step (four of them loaded before the first is used): a one-value grid-stride loop ran at 3.1 TB/s
   constexpr int U = 8;
   const int64_t stride = (int64_t)gridDim.x * kBlock * U;
@@ -188,25 +195,27 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long
     for (int u = 0; u < U; u++) {
       const int64_t i = base + (int64_t)u * kBlock;
       // |x| of finite values order like their bit patterns; a value inside the current [min, max] changes nothing and skips the validity read
-      if (i < n && (b[u] >> 52) != 0x7ff && b[u] != 0 && (b[u] > m || ~b[u] > im) && ah_bit(vvalid, voff + i)) {
+      if (i < n && (b[u] >> 52) != 0x7ff && b[u] != 0 && (b[u] > m || fx_inv_exp(b[u]) > im) && ah_bit(vvalid, voff + i)) {
         m = b[u] > m ? b[u] : m;
-        im = ~b[u] > im ? ~b[u] : im;
+        im = fx_inv_exp(b[u]) > im ? fx_inv_exp(b[u]) : im;
       }
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long t = __shfl_down(m, o, 64), ti = __shfl_down(im, o, 64);
+    const unsigned long long t = __shfl_down(m, o, 64);
+    const unsigned ti = __shfl_down(im, o, 64);
     m = t > m ? t : m;
     im = ti > im ? ti : im;
   }
-  __shared__ unsigned long long s_m[kBlock / 64], s_im[kBlock / 64];
+  __shared__ unsigned long long s_m[kBlock / 64];
+  __shared__ unsigned s_im[kBlock / 64];
   if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_im[threadIdx.x >> 6] = im; }
   __syncthreads();
   if (threadIdx.x == 0) {   // one atomic pair per workgroup: same-address atomics cost ≈ 12 ns each, serialised
     for (int w = 1; w < kBlock / 64; w++) { m = s_m[w] > m ? s_m[w] : m; im = s_im[w] > im ? s_im[w] : im; }
     if (m) atomicMax(&out[0], m);
-    if (im) atomicMax(&out[1], im);
+    if (im) atomicMax(&out[1], (unsigned long long)im);
   }
 }
 __global__ __launch_bounds__(kBlock) void fx_finalize_kernel(FxAcc acc, int64_t ngroups, double* __restrict__ out_sums) {

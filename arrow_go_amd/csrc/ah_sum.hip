@@ -169,6 +169,30 @@ int sum_dev(ah_ctx* c, const T* buf, size_t len, T* res_dev) {
   return AH_OK;
 }
 
+// the partials of one chunk, appended to a caller-owned array (the chunked ingest: every chunk's double-double partials meet in ONE
+// final reduction, so a sum that arrives in pieces is rounded once, like a sum over the whole column)
+template <typename T, typename Acc>
+int sum_chunk(ah_ctx* c, const T* buf, size_t len, Acc* partials, int max_partials, int* n_written) {
+  *n_written = 0;
+  if (len == 0) return AH_OK;
+  if (((uintptr_t)buf & (sizeof(T) - 1)) != 0) return ah_fail(c, AH_EINVALID, "sum: buffer not element-aligned");
+  int nhead = (int)((((uintptr_t)buf & 15) != 0) ? 1 : 0);
+  if ((size_t)nhead > len) nhead = (int)len;
+  const T* body = buf + nhead;
+  const int64_t nvec = (int64_t)((len - nhead) / 2);
+  const T* tail = body + nvec * 2;
+  const int ntail = (int)(len - nhead - (size_t)nvec * 2);
+  unsigned grid = ah_stream_grid(c, ah_ceil_div(nvec, (int64_t)kBlock * kUnroll), /*default_bpc=*/2);
+  if ((int)grid > max_partials) grid = (unsigned)max_partials;
+  if (c->tune_nt)
+    sum_partials_kernel<T, Acc, true><<<grid, kBlock, 0, c->stream>>>((const Vec2<T>*)body, nvec, buf, nhead, tail, ntail, partials);
+  else
+    sum_partials_kernel<T, Acc, false><<<grid, kBlock, 0, c->stream>>>((const Vec2<T>*)body, nvec, buf, nhead, tail, ntail, partials);
+  AH_LAUNCH_CHECK(c);
+  *n_written = (int)grid;
+  return AH_OK;
+}
+
 template <typename T, typename Acc>
 int sum_host(ah_ctx* c, const T* buf, size_t len, T* res_host) {
   if (!res_host) return ah_fail(c, AH_EINVALID, "sum: null result pointer");
@@ -183,6 +207,19 @@ int sum_host(ah_ctx* c, const T* buf, size_t len, T* res_host) {
 }
 
 }  // namespace
+
+// internal (ah_ingest.hip): 16 bytes per partial whatever the type
+int ah_sum_chunk_partials(ah_ctx* c, int is_f64, const void* buf, size_t len, void* partials16, int max_partials, int* n_written) {
+  if (is_f64) return sum_chunk<double, AccDD>(c, (const double*)buf, len, (AccDD*)partials16, max_partials, n_written);
+  return sum_chunk<uint64_t, AccU64>(c, (const uint64_t*)buf, len, (AccU64*)partials16, max_partials * 2, n_written);
+}
+int ah_sum_finish_partials(ah_ctx* c, int is_f64, const void* partials16, int n, void* res_dev) {
+  if (n <= 0) { AH_HIP(c, hipMemsetAsync(res_dev, 0, 8, c->stream)); return AH_OK; }
+  if (is_f64) sum_final_kernel<double, AccDD><<<1, kBlock, 0, c->stream>>>((const AccDD*)partials16, n, (double*)res_dev);
+  else sum_final_kernel<uint64_t, AccU64><<<1, kBlock, 0, c->stream>>>((const AccU64*)partials16, n, (uint64_t*)res_dev);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
 
 AH_EXPORT int ah_sum_float64(ah_ctx* c, const double* buf, size_t len, double* res_host) {
   AH_ENTER(c);

@@ -121,30 +121,16 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
 // The kernel above moves W bytes per lane and instruction; for 8-byte values that is half of what the memory pipeline takes per
 // request, and sorted / identity / reversed index vectors stopped at 4.3–4.9 TB/s where 16-byte accesses stream at 6.3.  Here a lane
 // owns V consecutive output rows: their indices arrive in one load, the V results leave in ONE 16-byte store, and when the V
-// indices are themselves consecutive (ascending: identity, sorted runs, slices; or descending: a reversed column) the V values
-// arrive in ONE 16-byte load — element-aligned, which gfx950 allows.  Anything else falls back to V separate gathers, so results
-// never depend on the choice (the reference's isSorted / primitiveTakeImplSorted split, vector_selection.go:734-876, is the
-// same kind of decision: loop shape only).  Chosen when the 64 × 255 neighbour sample of ah_take_binned.hip says "clustered".
+// indices all name values inside one 16-byte window [base, base + V) — consecutive ascending (identity, sorted runs, slices) or
+// descending (a reversed column), repeats of a sorted column included — the V values arrive in ONE 16-byte load (element-aligned,
+// which gfx950 allows) and each row picks its element.  Anything else falls back to V separate gathers, so results never depend
+// on the choice (the reference's isSorted / primitiveTakeImplSorted split, vector_selection.go:734-876, is the same kind of
+// decision: loop shape only).  Chosen when the 64 × 255 neighbour sample of ah_take_binned.hip says "clustered".
 template <typename IdxT, int V>
 struct alignas(sizeof(IdxT)) IdxVec { IdxT v[V]; };
 
-// bit t of x → bit V·t (the V ballots of a wave step interleave into V validity words)
-template <int V> __device__ __forceinline__ uint64_t spread_bits(uint64_t x);
-template <> __device__ __forceinline__ uint64_t spread_bits<2>(uint64_t x) {   // 32 bits in
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-template <> __device__ __forceinline__ uint64_t spread_bits<4>(uint64_t x) {   // 16 bits in
-  x = (x | (x << 24)) & 0x000000FF000000FFull;
-  x = (x | (x << 12)) & 0x000F000F000F000Full;
-  x = (x | (x << 6)) & 0x0303030303030303ull;
-  x = (x | (x << 3)) & 0x1111111111111111ull;
-  return x;
-}
+template <int CTRL>
+__device__ __forceinline__ unsigned take_dpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
 
 template <int W, typename IdxT, bool HAS_VALID>
 __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict__ values_v, const uint8_t* __restrict__ vvalid, int64_t voff,
@@ -153,8 +139,9 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
                                                            unsigned long long* __restrict__ first_bad) {
   using T = typename UIntOf<W>::type;
   using UIdx = typename std::make_unsigned<IdxT>::type;
-  constexpr int V = 16 / W;          // rows per lane
+  constexpr int V = 16 / W;          // rows per lane (2 or 4)
   constexpr int K = 4;               // groups per lane per step: 4 index loads, then 4 value loads in flight
+  constexpr unsigned kAll = (1u << V) - 1u;
   const T* __restrict__ values = (const T*)values_v;
   T* __restrict__ out = (T*)out_v;
   const int lane = threadIdx.x & 63;
@@ -173,53 +160,67 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
 #pragma unroll
         for (int j = 0; j < V; j++) iv[k].v[j] = r + j < nidx ? idx[r + j] : (IdxT)0;
       }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
       // the wave's 64·V rows start at a multiple of 64·V: V scalar-loaded words, the lane's V bits sit in word (lane·V) >> 6
-      const int64_t r0 = (g - lane) * V;
+      const int64_t r0 = (gbase + (int64_t)k * kBlock - lane) * V;
       uint64_t mine = 0;
 #pragma unroll
       for (int w = 0; w < V; w++) {
         const uint64_t word = ah_wave_bits64(ivalid, ioff + r0 + 64 * w, nidx - (r0 + 64 * w));   // 0 past the end, ones without a bitmap
         if (((lane * V) >> 6) == w) mine = word;
       }
-      ibits[k] = (unsigned)(mine >> ((lane * V) & 63)) & ((1u << V) - 1u);
+      ibits[k] = (unsigned)(mine >> ((lane * V) & 63)) & kAll;
     }
-    uint64_t u[K][V];
+    uint64_t u[K][V], lo[K];
     unsigned okb[K];     // rows with a valid, in-range index
-    bool asc[K], desc[K];
+    bool merged[K];      // all V raw indices lie in [lo, lo + V) and that window is inside the column
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int64_t r = (gbase + (int64_t)k * kBlock) * V;
       okb[k] = 0;
+      uint64_t mn = ~0ull, mx = 0;
+      bool neg = false;
 #pragma unroll
       for (int j = 0; j < V; j++) {
         const IdxT s = iv[k].v[j];
         u[k][j] = (uint64_t)(UIdx)s;   // reinterpret as unsigned of the same width
+        neg = neg || (std::is_signed<IdxT>::value && s < 0);
+        mn = u[k][j] < mn ? u[k][j] : mn;
+        mx = u[k][j] > mx ? u[k][j] : mx;
         if ((ibits[k] >> j) & 1u) {
           const bool oob = (std::is_signed<IdxT>::value && s < 0) || u[k][j] >= nvalues;   // helpers.go:937-939
           if (oob) atomicMin(first_bad, (unsigned long long)(r + j));
           else okb[k] |= 1u << j;
         }
       }
-      asc[k] = desc[k] = okb[k] == (1u << V) - 1u;
-#pragma unroll
-      for (int j = 1; j < V; j++) {
-        asc[k] = asc[k] && u[k][j] == u[k][0] + (uint64_t)j;
-        desc[k] = desc[k] && u[k][j] + (uint64_t)j == u[k][0];
-      }
+      // (the slots under a null index take part with whatever they hold — an identity vector stays one window per lane whatever its
+      // validity; their rows are cleared below)
+      lo[k] = mn;
+      merged[k] = !neg && mx - mn < (uint64_t)V && mn + V <= nvalues && r < nidx;
     }
     ah_vec16<T> x[K];
     unsigned vbits[K];   // value validity of the V rows
 #pragma unroll
     for (int k = 0; k < K; k++) {
-      vbits[k] = (1u << V) - 1u;
-      if (asc[k] || desc[k]) {
-        const uint64_t lo = asc[k] ? u[k][0] : u[k][V - 1];
-        x[k] = *reinterpret_cast<const ah_vec16<T>*>(values + lo);
-        if (HAS_VALID && vvalid != nullptr) {
-          const int64_t p = voff + (int64_t)lo;   // bits p … p + V − 1: one byte, or two neighbours
-          const unsigned b = (unsigned)vvalid[p >> 3] | ((unsigned)vvalid[(p + V - 1) >> 3] << 8);
-          vbits[k] = (b >> (p & 7)) & ((1u << V) - 1u);
+      vbits[k] = kAll;
+      if (merged[k]) {
+        const ah_vec16<T> t = *reinterpret_cast<const ah_vec16<T>*>(values + lo[k]);
+        unsigned b = 0xffffu;
+        const int64_t p = voff + (int64_t)lo[k];   // validity bits p … p + V − 1: one byte, or two neighbours
+        if (HAS_VALID && vvalid != nullptr) b = (unsigned)vvalid[p >> 3] | ((unsigned)vvalid[(p + V - 1) >> 3] << 8);
+        unsigned vb = 0;
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+          const unsigned d = (unsigned)(u[k][j] - lo[k]);   // 0 … V − 1
+          T e = t.v[0];
+#pragma unroll
+          for (int q = 1; q < V; q++) e = d == (unsigned)q ? t.v[q] : e;
+          x[k].v[j] = e;
+          vb |= ((b >> ((unsigned)(p & 7) + d)) & 1u) << j;
         }
+        if (HAS_VALID) vbits[k] = vb;
       } else {
 #pragma unroll
         for (int j = 0; j < V; j++) {
@@ -237,13 +238,6 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const int64_t g = gbase + (int64_t)k * kBlock, r = g * V;
-      if (desc[k] && !asc[k]) {   // loaded lowest address first: reverse values and validity bits into row order
-        ah_vec16<T> t = x[k];
-        unsigned vb = 0;
-#pragma unroll
-        for (int j = 0; j < V; j++) { x[k].v[j] = t.v[V - 1 - j]; vb |= ((vbits[k] >> (V - 1 - j)) & 1u) << j; }
-        vbits[k] = vb;
-      }
       const unsigned good = HAS_VALID ? (okb[k] & vbits[k]) : okb[k];
 #pragma unroll
       for (int j = 0; j < V; j++)
@@ -255,27 +249,12 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
         for (int j = 0; j < V; j++) if (r + j < nidx) out[r + j] = x[k].v[j];
       }
       if (HAS_VALID) {
-        // ballot j = the wave's rows r0 + V·lane + j; word w of the output = the lanes [64 w / V, 64 (w + 1) / V), V bits each
-        uint64_t bal[V];
-#pragma unroll
-        for (int j = 0; j < V; j++) bal[j] = __ballot((good >> j) & 1u);
-        const int64_t r0 = (g - lane) * V;
-        if (lane == 0 && r0 < nidx) {
-          uint8_t* pbytes = out_valid + (r0 >> 3);
-#pragma unroll
-          for (int w = 0; w < V; w++) {
-            uint64_t word = 0;
-#pragma unroll
-            for (int j = 0; j < V; j++) word |= spread_bits<V>((bal[j] >> (w * (64 / V))) & ((V == 2) ? 0xFFFFFFFFull : 0xFFFFull)) << j;
-            const int64_t left = nidx - (r0 + 64 * w);
-            if (left >= 64) {
-              *(uint64_t*)(pbytes + 8 * w) = word;   // r0 is a multiple of 64·V: as aligned as out_valid itself
-            } else if (left > 0) {
-              const int nbytes = (int)((left + 7) >> 3);
-              for (int bb = 0; bb < nbytes; bb++) pbytes[8 * w + bb] = (uint8_t)(word >> (8 * bb));
-            }
-          }
-        }
+        // a validity BYTE = the V bits of 8 / V neighbouring lanes: OR them together inside the quad (DPP, no LDS, no ballots), the
+        // first lane of each group stores the byte — consecutive bytes from consecutive lane groups, one store instruction per step
+        unsigned m = good << (V * (lane & (8 / V - 1)));
+        m |= take_dpp<0xB1>(m);                    // quad_perm [1,0,3,2]
+        if (V == 2) m |= take_dpp<0x4E>(m);        // quad_perm [2,3,0,1]
+        if ((lane & (8 / V - 1)) == 0 && r < nidx) out_valid[r >> 3] = (uint8_t)m;
       }
     }
   }

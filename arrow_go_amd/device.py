@@ -70,6 +70,88 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """Pinned host memory from ah_host_alloc_pinned (what a Go memory.Allocator backed by go/arrowhip/allocator.go hands out),
+    seen as a numpy array: the source / destination of overlapped transfers."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.handle, lib.ah_host_alloc_pinned(ctx.handle, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value or 0
+        self._raw = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+
+    def view(self, dtype, count: Optional[int] = None, byte_offset: int = 0) -> np.ndarray:
+        dt = np.dtype(dtype)
+        n = (self.nbytes - byte_offset) // dt.itemsize if count is None else int(count)
+        return np.frombuffer(self._raw, dtype=dt, count=n, offset=byte_offset)
+
+    def free(self) -> None:
+        if self.ptr:
+            self._raw = None
+            lib.ah_host_free_pinned(self.ctx.handle, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
+
+def _hptr(x) -> Optional[int]:
+    """host pointer of a numpy array / PinnedBuffer / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, PinnedBuffer):
+        return x.ptr
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+    return int(x)
+
+
+class Ingest:
+    """ah_ingest: chunked host → HBM pipeline with per-slot events (include/arrowhip.h, "overlapped host -> HBM ingest").
+    Host arguments are numpy arrays (ideally views of a PinnedBuffer), PinnedBuffers or raw host addresses."""
+
+    def __init__(self, ctx: "Context", chunk_bytes: int = 0, depth: int = 0):
+        h = C.c_void_p()
+        check(ctx.handle, lib.ah_ingest_create(ctx.handle, chunk_bytes, depth, C.byref(h)))
+        self.ctx, self.handle = ctx, h
+
+    def close(self) -> None:
+        if self.handle:
+            lib.ah_ingest_destroy(self.handle)
+            self.handle = None
+
+    def sum_float64(self, host, n: int) -> float:
+        r = C.c_double()
+        check(self.ctx.handle, lib.ah_ingest_sum_float64(self.handle, _hptr(host), n, C.byref(r)))
+        return r.value
+
+    def sum_int64(self, host, n: int) -> int:
+        r = C.c_int64()
+        check(self.ctx.handle, lib.ah_ingest_sum_int64(self.handle, _hptr(host), n, C.byref(r)))
+        return r.value
+
+    def arithmetic_binary(self, type_id: int, op: int, l_host, r_host, out_host, n: int) -> None:
+        check(self.ctx.handle, lib.ah_ingest_arithmetic_binary(self.handle, type_id, op, _hptr(l_host), _hptr(r_host), _hptr(out_host), n))
+
+    def filter_count(self, fdata_host, fvalid_host, foff: int, n: int, null_sel: int) -> int:
+        r = C.c_int64()
+        check(self.ctx.handle, lib.ah_ingest_filter_count(self.handle, _hptr(fdata_host), _hptr(fvalid_host), foff, n, null_sel, C.byref(r)))
+        return r.value
+
+    def filter_primitive(self, byte_width: int, values_host, vvalid_host, voff: int, n: int, n_out: int, out_values_host, out_valid_host) -> int:
+        r = C.c_int64()
+        check(self.ctx.handle, lib.ah_ingest_filter_primitive(self.handle, byte_width, _hptr(values_host), _hptr(vvalid_host), voff, n, n_out,
+                                                              _hptr(out_values_host), _hptr(out_valid_host), C.byref(r)))
+        return r.value
+
+
 class Comm:
     """ah_comm: this rank's RCCL communicator on an ah_ctx's compute stream (include/arrowhip.h, "multi-GPU exchange").
     Buffers are device pointers (ints, DeviceBuffers, or anything with .data_ptr())."""
@@ -137,6 +219,9 @@ class Context:
     def set_option(self, name: str, value: int) -> None:
         """measurement / test switch of this context (ah_ctx_set_option); never changes a result"""
         check(self.handle, lib.ah_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def alloc_pinned(self, nbytes: int) -> PinnedBuffer:
+        return PinnedBuffer(self, nbytes)
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

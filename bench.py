@@ -22,6 +22,7 @@ timed region.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -327,6 +328,103 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     return out
 
 
+def host_ingest_legs(ctx, rows):
+    """The same kernels when the Arrow buffers start (and end) in PINNED HOST memory: ah_ingest_* cuts them into 32 MiB chunks and
+    overlaps upload k + 1 / kernel k / download k − 1 on three streams with per-slot events (csrc/ah_ingest.hip).  Wall-clock of
+    the synchronous calls; `h2d_GB/s` = bytes that crossed PCIe towards the device ÷ time, to be read against `h2d_pinned_1GiB`
+    (one plain pinned hipMemcpyAsync of the same size, the rate of the link) — an ingest that overlaps runs at the link's rate."""
+    import arrow_go_amd as ah
+    N = ah._native
+    out = {}
+    rng = np.random.default_rng(99)
+    nbytes = rows * 8
+    pa, pb, po = ctx.alloc_pinned(nbytes + 64), ctx.alloc_pinned(nbytes + 64), ctx.alloc_pinned(nbytes + 64)
+    va, vb, vo = pa.view(np.int64, rows), pb.view(np.int64, rows), po.view(np.int64, rows)
+    chunk = rng.integers(-2**62, 2**62, 1 << 22, dtype=np.int64)
+    for off in range(0, rows, 1 << 22):
+        m = min(1 << 22, rows - off)
+        va[off:off + m] = chunk[:m]
+        vb[off:off + m] = chunk[:m][::-1]
+    vx = pb.view(np.float64, rows)   # the same bytes read as doubles would hold NaNs: a separate fill for the Sum leg below
+    dev = ctx.alloc(nbytes + 64)
+
+    def wall(name, fn, h2d_bytes, d2h_bytes, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        out[name] = {"ms": round(t * 1e3, 3), "h2d_GB/s": round(h2d_bytes / t / 1e9, 2), "pcie_both_ways_GB/s": round((h2d_bytes + d2h_bytes) / t / 1e9, 2),
+                     "ms_mean": round(float(np.mean(ts)) * 1e3, 3)}
+
+    def plain_upload():
+        ah._native.check(ctx.handle, ah._native.lib.ah_upload_async(ctx.handle, dev.ptr, pa.ptr, nbytes))
+        ctx.sync()
+
+    def plain_download():
+        ah._native.check(ctx.handle, ah._native.lib.ah_download_async(ctx.handle, po.ptr, dev.ptr, nbytes))
+        ctx.sync()
+
+    wall("h2d_pinned_1GiB", plain_upload, nbytes, 0)
+    wall("d2h_pinned_1GiB", plain_download, 0, nbytes)
+    out["d2h_pinned_1GiB"]["d2h_GB/s"] = round(nbytes / (out["d2h_pinned_1GiB"]["ms"] * 1e-3) / 1e9, 2)
+    link = out["h2d_pinned_1GiB"]["h2d_GB/s"]
+    ing = ah.Ingest(ctx)   # 32 MiB chunks, 3 slots
+    try:
+        # Int64 Add: 2 GiB up, 1 GiB down
+        wall("add_int64_from_pinned_host", lambda: ing.arithmetic_binary(N.INT64, N.OP_ADD, va, vb, vo, rows), 2 * nbytes, nbytes)
+        assert vo[:4096].tobytes() == (va[:4096] + vb[:4096]).tobytes() and vo[-4096:].tobytes() == (va[-4096:] + vb[-4096:]).tobytes(), "ingest Add: wrong values"
+        # the unpipelined way (what rounds 1-2 had): upload both, compute, download, each behind the other
+        b2 = ctx.alloc(nbytes + 64); c2 = ctx.alloc(nbytes + 64)
+
+        def serial_add():
+            ah._native.check(ctx.handle, ah._native.lib.ah_upload_async(ctx.handle, dev.ptr, pa.ptr, nbytes))
+            ah._native.check(ctx.handle, ah._native.lib.ah_upload_async(ctx.handle, b2.ptr, pb.ptr, nbytes))
+            ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, dev, b2, c2, rows)
+            ah._native.check(ctx.handle, ah._native.lib.ah_download_async(ctx.handle, po.ptr, c2.ptr, nbytes))
+            ctx.sync()
+
+        wall("add_int64_from_pinned_host_unpipelined", serial_add, 2 * nbytes, nbytes)
+        b2.free(); c2.free()
+        # Filter: s = 0.5, 10 % value nulls; mask + validity up (32 MiB), values up (1 GiB), survivors down
+        fmask, vvalid = random_bits(rng, rows, 0.5), random_bits(rng, rows, 0.9)
+        pov = ctx.alloc_pinned(rows // 8 + 64)
+        kk = [0]
+
+        def filt():
+            kk[0] = ing.filter_count(fmask, None, 0, rows, 0)
+            ing.filter_primitive(8, va, vvalid, 0, rows, kk[0], vo, pov)
+
+        wall("filter_int64_sel0.50_nulls10_from_pinned_host", filt, nbytes + rows // 4, 0)
+        k = kk[0]
+        out["filter_int64_sel0.50_nulls10_from_pinned_host"]["pcie_both_ways_GB/s"] = round((nbytes + rows // 4 + k * 8 + k // 8) / (out["filter_int64_sel0.50_nulls10_from_pinned_host"]["ms"] * 1e-3) / 1e9, 2)
+        out["filter_int64_sel0.50_nulls10_from_pinned_host"]["selected"] = round(k / rows, 4)
+        sel = np.unpackbits(fmask[:512], bitorder="little")[:4096].astype(bool)
+        assert vo[:int(sel.sum())].tobytes() == va[:4096][sel].tobytes(), "ingest Filter: wrong values"
+        pov.free()
+        # Float64 Sum: 1 GiB up, 8 bytes down
+        xchunk = rng.uniform(-1e6, 1e6, 1 << 22)
+        for off in range(0, rows, 1 << 22):
+            vx[off:off + min(1 << 22, rows - off)] = xchunk[:min(1 << 22, rows - off)]
+        res = [0.0]
+
+        def ssum():
+            res[0] = ing.sum_float64(vx, rows)
+
+        wall("sum_float64_from_pinned_host", ssum, nbytes, 0)
+        exact = math.fsum(xchunk.tolist()) * (rows // (1 << 22)) if rows % (1 << 22) == 0 else None
+        if exact is not None:
+            assert abs(res[0] - exact) <= 2 * abs(np.spacing(exact)) * (rows // (1 << 22)), "ingest Sum: wrong value"
+    finally:
+        ing.close()
+    for name, v in out.items():
+        if name.endswith("_from_pinned_host"):
+            v["frac_of_h2d_link"] = round(v["h2d_GB/s"] / link, 3)
+    for b_ in (pa, pb, po, dev):
+        b_.free()
+    return out
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL's version
@@ -529,6 +627,10 @@ def main():
                 result["kernels"] = per_kernel_table(ctx, rows, a, b, c, x)
             except Exception as e:  # the table is informative; never lose the headline over it
                 result["kernels"] = {"error": repr(e)}
+            try:
+                result["host_ingest"] = host_ingest_legs(ctx, rows)
+            except Exception as e:
+                result["host_ingest"] = {"error": repr(e)}
             if isinstance(result["kernels"].get("ceiling_copy_kernel"), dict):
                 result["roofline"]["measured_copy_GB/s"] = result["kernels"]["ceiling_copy_kernel"]["GB/s"]
         if world == 1 and not args.no_cpu_baseline:

@@ -148,6 +148,52 @@ int ah_memset_async(ah_ctx* ctx, void* dptr, int byte_value, size_t nbytes); /* 
  * (arrow/array/concat.go:159-180 concatBuffers) when chunked inputs are laid end to end in HBM */
 int ah_copy_async(ah_ctx* ctx, void* dst, const void* src, size_t nbytes);
 int ah_sync(ah_ctx* ctx);
+/* pin / unpin memory the host already owns (hipHostRegister) — e.g. a Go []byte for the duration of one cgo call; copies from
+ * pageable memory are staged by the runtime and overlap nothing */
+int ah_host_register(ah_ctx* ctx, void* hptr, size_t nbytes);
+int ah_host_unregister(ah_ctx* ctx, void* hptr);
+
+/* ---- overlapped host -> HBM ingest (csrc/ah_ingest.hip) ----------------------------------------------------------------------
+ * Replaces, for host-resident inputs, the executor's span loop: ExecCtx.ChunkSize / NumParallel (arrow/compute/executor.go:46-64)
+ * and the per-span kernel call (:658-702), over buffers from a memory.Allocator (arrow/memory/allocator.go:20-27 — here
+ * ah_host_alloc_pinned).  An ah_ingest owns `depth` slots of three `chunk_bytes` device buffers, an upload stream and a download
+ * stream; chunk k + 1 uploads while chunk k computes and chunk k - 1 downloads, ordered by per-slot events (not by the
+ * stream-wide fences of ah_upload_async).  chunk_bytes = 0 -> 32 MiB, depth = 0 -> 3.  Host buffers must be pinned
+ * (ah_host_alloc_pinned / ah_host_register) for the copies to overlap; pageable memory still gives correct results.
+ * One call at a time per ah_ingest; it shares its context's compute stream. */
+typedef struct ah_ingest ah_ingest;
+int ah_ingest_create(ah_ctx* ctx, size_t chunk_bytes, int depth, ah_ingest** out);
+int ah_ingest_destroy(ah_ingest* ing);
+/* arrow/math Sum of a HOST column (float64.go:34-47 / int64.go:34-47; validity ignored): every chunk's double-double workgroup
+ * partials are kept and reduced ONCE, so the result has the rounding of ah_sum_float64 over the whole column */
+int ah_ingest_sum_float64(ah_ingest* ing, const double* buf_host, size_t len, double* res_host);
+int ah_ingest_sum_int64(ah_ingest* ing, const int64_t* buf_host, size_t len, int64_t* res_host);
+/* ah_arithmetic_binary with all three buffers on the host (base_arithmetic.cc:441-475) */
+int ah_ingest_arithmetic_binary(ah_ingest* ing, int type, int8_t op, const void* l_host, const void* r_host, void* out_host, int64_t len);
+/* PrimitiveFilter (vector_selection.go:449-520) on host buffers, two-phase like ah_filter_count / ah_filter_primitive: the count
+ * call uploads the selection vector (n/8 bytes) and KEEPS it on the device; the host allocates the outputs; the fill call
+ * streams the values through (chunks with no survivor never cross PCIe) and returns values, validity (out_valid_host nullable:
+ * pass NULL when no input has nulls) and null count.  Same payload rules as ah_filter_primitive. */
+int ah_ingest_filter_count(ah_ingest* ing, const uint8_t* fdata_host, const uint8_t* fvalid_host, int64_t foff, int64_t n, int null_sel,
+                           int64_t* n_out_host);
+int ah_ingest_filter_primitive(ah_ingest* ing, int byte_width, const void* values_host, const uint8_t* vvalid_host, int64_t voff, int64_t n,
+                               int64_t n_out, void* out_values_host, uint8_t* out_valid_host, int64_t* out_null_count_host);
+/* The slot protocol itself, for a host that runs other kernels over its own chunking (go/arrowhip/register.go stage()):
+ *   upload(slot, which, …, first_of_chunk=1 for the chunk's first copy)   h2d stream; waits only for the slot's last release
+ *   ready(slot, writes_output)                                            compute stream waits for the slot's uploads
+ *                                                                          (and, if the kernel writes buffer 2, for its last download)
+ *   … any ah_* kernels on ah_ingest_slot_buffer(slot, 0..2) …
+ *   release(slot)                                                          marks the kernels done
+ *   download(slot, which, …)                                               d2h stream; waits for the release
+ *   wait()                                                                 host waits for all three streams */
+int ah_ingest_depth(ah_ingest* ing);
+size_t ah_ingest_chunk_bytes(ah_ingest* ing);
+void* ah_ingest_slot_buffer(ah_ingest* ing, int slot, int which);
+int ah_ingest_slot_upload(ah_ingest* ing, int slot, int which, size_t dst_offset, const void* hptr, size_t nbytes, int first_of_chunk);
+int ah_ingest_slot_ready(ah_ingest* ing, int slot, int writes_output);
+int ah_ingest_slot_release(ah_ingest* ing, int slot);
+int ah_ingest_slot_download(ah_ingest* ing, int slot, int which, size_t src_offset, void* hptr, size_t nbytes);
+int ah_ingest_wait(ah_ingest* ing);
 /* hipEvent pair on the compute stream (what bench.py times kernels with). */
 int ah_timer_start(ah_ctx* ctx);
 int ah_timer_stop(ah_ctx* ctx, float* ms_host); /* synchronises */

@@ -742,7 +742,7 @@ def test_hash_sum_f64_is_deterministic_and_tight(hip, orc_be):
                 if exact_bytes:
                     assert got == float(exact), (n, card, k, got, float(exact))       # float(Fraction) rounds to nearest even
                 else:
-                    assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(cnt * gmax * 2.0**-93), (n, card, got, float(exact))
+                    assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(gmax) * cnt / 2**93, (n, card, got, float(exact))
     # non-finite addends
     keys = np.array([1, 1, 2, 2, 3, 3, 4, 4, 5], np.int64)
     fv = np.array([np.inf, 1.0, -np.inf, 5.0, np.inf, -np.inf, np.nan, 1.0, 2.5])
@@ -784,7 +784,7 @@ def test_hash_sum_f64_wide_range(hip, orc_be, ctx, mode):
         pos = {int(k): i for i, k in enumerate(g[0].view(np.int64))}
         for k, (exact, cnt, gmax) in _exact_group_sums(keys, fv, ok, 3000).items():
             got = float(g[1][pos[k]])
-            assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(cnt * gmax) * Fraction(1, 2**93), (mode, card, k, got, float(exact))
+            assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(gmax) * cnt / 2**93, (mode, card, k, got, float(exact))
             if gmax <= 1.0 and cnt > 3:
                 assert got != 0.0 or exact == 0, (mode, card, k)   # what the one-scale version returned for every ordinary group
 
