@@ -173,7 +173,20 @@ _SIGS.update({
     "ah_expr_execute": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "ah_expr_codegen": [_vp, _int, _vp, _int, _vp, _int, _int, C.c_char_p, _sz, C.c_char_p, _sz, _pint],
 })
+TRANSPORT_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+TRANSPORT_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+
+
+class AhTransport(C.Structure):   # struct ah_transport (include/arrowhip.h)
+    _fields_ = [("user", C.c_void_p), ("allgather", TRANSPORT_ALLGATHER), ("alltoallv", TRANSPORT_ALLTOALLV)]
+
+
 _SIGS.update({
+    "ah_comm_init_transport": [_vp, _int, _int, C.POINTER(AhTransport), _pvp],
+    "ah_comm_cmp_filter_sum_i64": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _pi64, _pi64],
+    "ah_comm_cmp_filter_sum_f64": [_vp, _int, _vp, _vp, _i64, _i64, C.c_double, _pd, _pi64],
+    "ah_comm_merge_groups": [_vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _pi64],
     "ah_host_register": [_vp, _vp, _sz],
     "ah_host_unregister": [_vp, _vp],
     "ah_ingest_create": [_vp, _sz, _int, _pvp],

@@ -11,13 +11,19 @@
 // its own), else the system's — so libarrowhip.so itself carries no link-time dependency on it.
 #include <dlfcn.h>
 #include <mutex>
+#include <vector>
 #include <rccl/rccl.h>
 #include "ah_common.h"
 
 struct ah_comm {
   ah_ctx* ctx;
-  ncclComm_t comm;
+  ncclComm_t comm;          // RCCL communicator, or nullptr for a host-transport communicator
   int rank, world;
+  ah_transport transport;   // host-transport flavour (ah_comm_init_transport): the two exchanges over host memory
+  bool has_transport;
+  // grow-only blocks owned by the communicator: device temporaries of the C4 / C5 entry points, and pinned host staging
+  uint8_t* arena; size_t arena_bytes;
+  uint8_t* stage; size_t stage_bytes;
 };
 
 namespace {
@@ -87,6 +93,108 @@ bool nccl_type(int type, ncclDataType_t* t) {
 }
 }  // namespace
 
+// ---- host-transport flavour: the same three collectives with the bytes carried by callbacks the host supplies (its launcher's
+// sockets, MPI, a gloo group in the tests) instead of RCCL.  Device blocks are staged through pinned host memory; this is the
+// flavour for hosts without RCCL between their processes — and for running N ranks on ONE GPU, which RCCL refuses.
+namespace {
+int stage_reserve(ah_comm* m, size_t nbytes, uint8_t** out) {
+  ah_ctx* c = m->ctx;
+  if (nbytes > m->stage_bytes) {
+    if (m->stage) AH_HIP(c, hipHostFree(m->stage));
+    m->stage = nullptr; m->stage_bytes = 0;
+    const size_t want = (nbytes + 65535) & ~(size_t)65535;
+    AH_HIP(c, hipHostMalloc((void**)&m->stage, want, hipHostMallocDefault));
+    m->stage_bytes = want;
+  }
+  *out = m->stage;
+  return AH_OK;
+}
+int arena_reserve(ah_comm* m, size_t nbytes, uint8_t** out) {
+  ah_ctx* c = m->ctx;
+  if (nbytes > m->arena_bytes) {
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (m->arena) AH_HIP(c, hipFree(m->arena));
+    m->arena = nullptr; m->arena_bytes = 0;
+    const size_t want = (nbytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    AH_HIP(c, hipMalloc((void**)&m->arena, want));
+    m->arena_bytes = want;
+  }
+  *out = m->arena;
+  return AH_OK;
+}
+int transport_fail(ah_ctx* c, const char* what, int rc) { return ah_fail(c, AH_EHIP, "%s: the host transport returned %d", what, rc); }
+
+int transport_allgather(ah_comm* m, const void* send, void* recv, int64_t nbytes) {
+  ah_ctx* c = m->ctx;
+  uint8_t* h;
+  int rc = stage_reserve(m, (size_t)nbytes * (size_t)(m->world + 1), &h);
+  if (rc != AH_OK) return rc;
+  AH_HIP(c, hipMemcpyAsync(h, send, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  const int trc = m->transport.allgather(m->transport.user, h, h + nbytes, nbytes);
+  if (trc) return transport_fail(c, "allgather", trc);
+  AH_HIP(c, hipMemcpyAsync(recv, h + nbytes, (size_t)nbytes * (size_t)m->world, hipMemcpyHostToDevice, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));   // the staging block is reused by the next call
+  return AH_OK;
+}
+// every rank's vector, added in RANK order on every rank: the same bytes everywhere, run after run — also for Float64
+int transport_allreduce(ah_comm* m, int type, const void* send, void* recv, int64_t count) {
+  ah_ctx* c = m->ctx;
+  const int w = ah_type_width(type);
+  const int64_t nbytes = count * w;
+  uint8_t* h;
+  int rc = stage_reserve(m, (size_t)nbytes * (size_t)(m->world + 1), &h);
+  if (rc != AH_OK) return rc;
+  AH_HIP(c, hipMemcpyAsync(h, send, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  const int trc = m->transport.allgather(m->transport.user, h, h + nbytes, nbytes);
+  if (trc) return transport_fail(c, "allreduce", trc);
+  uint8_t* all = h + nbytes;
+  for (int64_t i = 0; i < count; i++) {
+    switch (type) {
+      case AH_FLOAT64: { double a = 0; for (int r = 0; r < m->world; r++) a += ((const double*)(all + (size_t)r * nbytes))[i]; ((double*)h)[i] = a; break; }
+      case AH_FLOAT32: { float a = 0; for (int r = 0; r < m->world; r++) a += ((const float*)(all + (size_t)r * nbytes))[i]; ((float*)h)[i] = a; break; }
+      case AH_INT64: case AH_UINT64: { uint64_t a = 0; for (int r = 0; r < m->world; r++) a += ((const uint64_t*)(all + (size_t)r * nbytes))[i]; ((uint64_t*)h)[i] = a; break; }
+      default: { uint32_t a = 0; for (int r = 0; r < m->world; r++) a += ((const uint32_t*)(all + (size_t)r * nbytes))[i]; ((uint32_t*)h)[i] = a; break; }
+    }
+  }
+  AH_HIP(c, hipMemcpyAsync(recv, h, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  return AH_OK;
+}
+int transport_alltoallv(ah_comm* m, const void* send, const int64_t* sb, const int64_t* so, void* recv, const int64_t* rb, const int64_t* ro) {
+  ah_ctx* c = m->ctx;
+  std::vector<int64_t> hso(m->world), hro(m->world);
+  int64_t stot = 0, rtot = 0;
+  for (int r = 0; r < m->world; r++) { hso[r] = stot; stot += sb[r]; }
+  for (int r = 0; r < m->world; r++) { hro[r] = rtot; rtot += rb[r]; }
+  uint8_t* h;
+  int rc = stage_reserve(m, (size_t)(stot + rtot) + 64, &h);
+  if (rc != AH_OK) return rc;
+  for (int r = 0; r < m->world; r++)
+    if (sb[r] > 0) AH_HIP(c, hipMemcpyAsync(h + hso[r], (const uint8_t*)send + so[r], (size_t)sb[r], hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  const int trc = m->transport.alltoallv(m->transport.user, h, sb, hso.data(), h + stot, rb, hro.data());
+  if (trc) return transport_fail(c, "alltoallv", trc);
+  for (int r = 0; r < m->world; r++)
+    if (rb[r] > 0 && r != m->rank) AH_HIP(c, hipMemcpyAsync((uint8_t*)recv + ro[r], h + stot + hro[r], (size_t)rb[r], hipMemcpyHostToDevice, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  return AH_OK;
+}
+}  // namespace
+
+AH_EXPORT int ah_comm_init_transport(ah_ctx* c, int rank, int world, const ah_transport* t, ah_comm** out) {
+  AH_ENTER(c);
+  if (!out) return ah_fail(c, AH_EINVALID, "comm_init_transport: null out pointer");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world || !t || !t->allgather || !t->alltoallv) return ah_fail(c, AH_EINVALID, "comm_init_transport: bad rank / world / callbacks");
+  ah_comm* m = (ah_comm*)calloc(1, sizeof(ah_comm));
+  if (!m) return ah_fail(c, AH_EINVALID, "comm_init_transport: out of memory");
+  m->ctx = c; m->comm = nullptr; m->rank = rank; m->world = world; m->transport = *t; m->has_transport = true;
+  *out = m;
+  return AH_OK;
+}
+
 AH_EXPORT int ah_comm_unique_id(void* id_host128) {
   if (!id_host128) return AH_EINVALID;
   if (load_rccl()) return AH_EHIP;
@@ -118,7 +226,9 @@ AH_EXPORT int ah_comm_destroy(ah_comm* m) {
   if (!m) return AH_OK;
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
-  if (g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+  if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+  if (m->arena) (void)hipFree(m->arena);
+  if (m->stage) (void)hipHostFree(m->stage);
   free(m);
   return AH_OK;
 }
@@ -134,6 +244,7 @@ AH_EXPORT int ah_comm_allreduce_sum(ah_comm* m, int type, const void* send, void
   if (!nccl_type(type, &t)) return ah_fail(c, AH_EINVALID, "allreduce: unsupported element type %d", type);
   if (count < 0 || (count > 0 && (!send || !recv))) return ah_fail(c, AH_EINVALID, "allreduce: bad buffer / count");
   if (count == 0) return AH_OK;
+  if (m->has_transport) return transport_allreduce(m, type, send, recv, count);
   AH_NCCL(c, g_rccl.AllReduce(send, recv, (size_t)count, t, ncclSum, m->comm, c->stream));
   return AH_OK;
 }
@@ -144,6 +255,7 @@ AH_EXPORT int ah_comm_allgather(ah_comm* m, const void* send, void* recv, int64_
   AH_ENTER(c);
   if (nbytes_per_rank < 0 || (nbytes_per_rank > 0 && (!send || !recv))) return ah_fail(c, AH_EINVALID, "allgather: bad buffer / size");
   if (nbytes_per_rank == 0) return AH_OK;
+  if (m->has_transport) return transport_allgather(m, send, recv, nbytes_per_rank);
   AH_NCCL(c, g_rccl.AllGather(send, recv, (size_t)nbytes_per_rank, ncclUint8, m->comm, c->stream));
   return AH_OK;
 }
@@ -164,6 +276,7 @@ AH_EXPORT int ah_comm_alltoallv(ah_comm* m, const void* send, const int64_t* sen
     AH_HIP(c, hipMemcpyAsync((uint8_t*)recv + recv_offs_host[m->rank], (const uint8_t*)send + send_offs_host[m->rank],
                              (size_t)send_bytes_host[m->rank], hipMemcpyDeviceToDevice, c->stream));
   if (m->world == 1) return AH_OK;
+  if (m->has_transport) return transport_alltoallv(m, send, send_bytes_host, send_offs_host, recv, recv_bytes_host, recv_offs_host);
   // direct exchange: all 7 xGMI links of a GPU carry a block at the same time (a ring would be per-link bound)
   AH_NCCL(c, g_rccl.GroupStart());
   for (int r = 0; r < m->world; r++) {
@@ -178,5 +291,250 @@ AH_EXPORT int ah_comm_alltoallv(ah_comm* m, const void* send, const int64_t* sen
     }
   }
   AH_NCCL(c, g_rccl.GroupEnd());
+  return AH_OK;
+}
+
+// ---- C4 / C5 as single calls: what a Go host runs per record-batch shard — no Python in between -----------------
+// small host vector ↔ every rank (sizes): through the device for RCCL, directly for a host transport
+static int comm_allgather_host(ah_comm* m, const int64_t* mine, int count, int64_t* all /* world × count */) {
+  ah_ctx* c = m->ctx;
+  const size_t nb = (size_t)count * 8;
+  if (m->has_transport) {
+    const int trc = m->transport.allgather(m->transport.user, mine, all, (int64_t)nb);
+    return trc ? transport_fail(c, "allgather", trc) : AH_OK;
+  }
+  if ((size_t)(m->world + 1) * nb > 4096 * 8) return ah_fail(c, AH_EINVALID, "comm: size vector too long");
+  uint8_t* d = (uint8_t*)&c->dscalars[64];   // the popcount partials area: idle between kernels
+  AH_HIP(c, hipMemcpyAsync(d, mine, nb, hipMemcpyHostToDevice, c->stream));
+  AH_NCCL(c, g_rccl.AllGather(d, d + nb, nb, ncclUint8, m->comm, c->stream));
+  AH_HIP(c, hipMemcpyAsync(all, d + nb, nb * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_comm_cmp_filter_sum_i64(ah_comm* m, int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n_local,
+                                         int64_t threshold, int64_t* out_sum_host, int64_t* out_count_host) {
+  if (!m) return AH_EINVALID;
+  ah_ctx* c = m->ctx;
+  AH_ENTER(c);
+  if (!out_sum_host || !out_count_host) return ah_fail(c, AH_EINVALID, "comm_cmp_filter_sum: null result pointer");
+  int64_t* pair = (int64_t*)&c->dscalars[40];   // {sum, count}
+  int rc = ah_cmp_filter_sum_i64_dev(c, cmpop, x, valid, off, n_local, threshold, pair);
+  if (rc != AH_OK) return rc;
+  // wrapping int64 sums are exact in any order: ONE all-reduce of 16 bytes is the path's whole exchange
+  if ((rc = ah_comm_allreduce_sum(m, AH_INT64, pair, pair, 2)) != AH_OK) return rc;
+  AH_HIP(c, hipMemcpyAsync(&c->pinned[16], pair, 16, hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  *out_sum_host = (int64_t) * (volatile uint64_t*)&c->pinned[16];
+  *out_count_host = (int64_t) * (volatile uint64_t*)&c->pinned[17];
+  return AH_OK;
+}
+
+AH_EXPORT int ah_comm_cmp_filter_sum_f64(ah_comm* m, int cmpop, const double* x, const uint8_t* valid, int64_t off, int64_t n_local,
+                                         double threshold, double* out_sum_host, int64_t* out_count_host) {
+  if (!m) return AH_EINVALID;
+  ah_ctx* c = m->ctx;
+  AH_ENTER(c);
+  if (!out_sum_host || !out_count_host) return ah_fail(c, AH_EINVALID, "comm_cmp_filter_sum: null result pointer");
+  if (m->world > 1024) return ah_fail(c, AH_EINVALID, "comm_cmp_filter_sum: world too large");
+  double* part = (double*)&c->dscalars[40];     // [40] sum, [41] count
+  int64_t* cnt = (int64_t*)&c->dscalars[41];
+  int rc = ah_cmp_filter_sum_f64_dev(c, cmpop, x, valid, off, n_local, threshold, part, cnt);
+  if (rc != AH_OK) return rc;
+  // Float64: an all-reduce adds in whatever order the ring runs; every rank gets every partial instead (16 bytes each) and
+  // adds them in RANK order — the same bytes on every rank and in every run of a given world size
+  uint8_t* all = (uint8_t*)&c->dscalars[64];
+  if ((rc = ah_comm_allgather(m, part, all, 16)) != AH_OK) return rc;
+  std::vector<uint64_t> h((size_t)m->world * 2);
+  AH_HIP(c, hipMemcpyAsync(h.data(), all, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  double s = 0.0;
+  int64_t n = 0;
+  for (int r = 0; r < m->world; r++) {
+    double p;
+    memcpy(&p, &h[2 * (size_t)r], 8);
+    s += p;
+    n += (int64_t)h[2 * (size_t)r + 1];
+  }
+  *out_sum_host = s;
+  *out_count_host = n;
+  return AH_OK;
+}
+
+// C5, plan A of SURVEY.md §8e: every rank has aggregated its own row shard (ah_hash_sum_*); this merges the per-rank groups:
+//   1 bucket the local groups by OWNER = (hashInt(key) >> 40) mod world   (ah_hash_partition_u64 + one compare and four stream
+//     compactions per destination — on the device)
+//   2 ragged all-to-all of {key, sum, count, global first row} tuples: O(groups) bytes on the wire, never O(rows)
+//   3 the owner re-aggregates the tuples of its keys: sum of the partial sums (Float64: the reproducible fixed-point sums of
+//     ah_hash_sum_f64), sum of the counts, the first row of the FIRST tuple (source ranks arrive in ascending order and lower
+//     ranks hold lower row ranges, so that is the smallest global row)
+//   4 ragged all-gather of the owners' groups
+//   5 ordered by global first row = what unique / dictionary_encode over the undivided column would give
+//     (kernels/vector_hash.go:359-385, 721-741: first-seen order)
+// All device buffers; out_* hold up to `capacity` groups.  *out_ngroups_host = number of global groups; AH_EINVALID with that
+// number set when `capacity` is too small (nothing written).
+AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys, const void* sums, const int64_t* counts, const int64_t* first_rows,
+                                   int64_t ngroups_local, int64_t row_offset, int64_t capacity, uint64_t* out_keys, void* out_sums,
+                                   int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups_host) {
+  if (!m) return AH_EINVALID;
+  ah_ctx* c = m->ctx;
+  AH_ENTER(c);
+  if (!out_ngroups_host) return ah_fail(c, AH_EINVALID, "merge_groups: null result pointer");
+  *out_ngroups_host = 0;
+  const int W = m->world;
+  const int64_t g = ngroups_local;
+  if (g < 0 || capacity < 0) return ah_fail(c, AH_EINVALID, "merge_groups: negative count");
+  if (g > 0 && (!keys || !sums || !counts || !first_rows)) return ah_fail(c, AH_EINVALID, "merge_groups: null input");
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  int rc;
+  // ---- 1: owners and the send blocks (block r = four columns of g_r values, back to back)
+  uint8_t* a0;
+  if ((rc = arena_reserve(m, pad((size_t)g * 8) * 6 + pad((size_t)g * 4) + pad((size_t)g / 8 + 128) + 4096, &a0)) != AH_OK) return rc;
+  size_t o = 0;
+  auto take = [&](size_t b) { uint8_t* q = a0 + o; o += pad(b); return q; };
+  int64_t* gfirst = (int64_t*)take((size_t)g * 8);
+  int32_t* owner = (int32_t*)take((size_t)g * 4);
+  uint8_t* mask = take((size_t)g / 8 + 128);
+  uint8_t* sendbuf = take((size_t)g * 32);
+  const size_t phase1 = o;
+  std::vector<int64_t> scnt(W, 0);
+  if (g > 0) {
+    if ((rc = ah_arithmetic_arr_scalar(c, AH_INT64, 0 /*ADD*/, first_rows, &row_offset, gfirst, g)) != AH_OK) return rc;
+    if (W == 1) {
+      scnt[0] = g;
+      const void* cols[4] = {keys, sums, counts, gfirst};
+      for (int k = 0; k < 4; k++) if ((rc = ah_copy_async(c, sendbuf + (size_t)k * (size_t)g * 8, cols[k], (size_t)g * 8)) != AH_OK) return rc;
+    } else {
+      if ((rc = ah_hash_partition_u64(c, keys, g, W, owner)) != AH_OK) return rc;
+      int64_t done = 0;
+      for (int r = 0; r < W; r++) {
+        const int32_t rr = r;
+        if ((rc = ah_comparison(c, AH_CMP_EQ, AH_SHAPE_AS, AH_INT32, owner, &rr, mask, g, 0)) != AH_OK) return rc;
+        int64_t n_r = 0;
+        if ((rc = ah_filter_count(c, mask, nullptr, 0, g, AH_DROP_NULLS, &n_r)) != AH_OK) return rc;
+        scnt[r] = n_r;
+        const void* cols[4] = {keys, sums, counts, gfirst};
+        for (int k = 0; k < 4 && n_r > 0; k++)
+          if ((rc = ah_filter_primitive(c, 8, cols[k], nullptr, 0, mask, nullptr, 0, g, AH_DROP_NULLS, n_r, sendbuf + (size_t)done * 32 + (size_t)k * (size_t)n_r * 8,
+                                        nullptr, nullptr)) != AH_OK) return rc;
+        done += n_r;
+      }
+    }
+  }
+  // ---- 2: sizes, then the tuples
+  std::vector<int64_t> table((size_t)W * W);
+  if (W == 1) table[0] = scnt[0];
+  else if ((rc = comm_allgather_host(m, scnt.data(), W, table.data())) != AH_OK) return rc;
+  std::vector<int64_t> rcnt(W), sb(W), so(W), rb(W), ro(W);
+  int64_t mrecv = 0, acc = 0;
+  for (int s = 0; s < W; s++) { rcnt[s] = table[(size_t)s * W + m->rank]; ro[s] = mrecv * 32; rb[s] = rcnt[s] * 32; mrecv += rcnt[s]; }
+  for (int r = 0; r < W; r++) { so[r] = acc * 32; sb[r] = scnt[r] * 32; acc += scnt[r]; }
+  // the arena grows without keeping its contents: everything after the send blocks is placed in a second reservation that
+  // includes them (same base unless it grew — so re-derive the pointers, and copy the send blocks if it moved)
+  const size_t need2 = phase1 + pad((size_t)mrecv * 32) + pad((size_t)mrecv * 8) * 4 + pad(((size_t)mrecv + 1) * 8) * 7 + 4096;
+  if (need2 > m->arena_bytes) {
+    uint8_t* keep = nullptr;
+    if (g > 0) {
+      AH_HIP(c, hipMalloc((void**)&keep, (size_t)g * 32));
+      AH_HIP(c, hipMemcpyAsync(keep, sendbuf, (size_t)g * 32, hipMemcpyDeviceToDevice, c->stream));
+    }
+    rc = arena_reserve(m, need2, &a0);
+    if (rc == AH_OK && g > 0) {
+      sendbuf = a0 + (sendbuf - (uint8_t*)gfirst) + 0;   // same offsets in the new block
+      if (hipMemcpyAsync(sendbuf, keep, (size_t)g * 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+        rc = ah_fail(c, AH_EHIP, "merge_groups: copy failed");
+    }
+    if (keep) (void)hipFree(keep);
+    if (rc != AH_OK) return rc;
+  }
+  o = phase1;
+  uint8_t* recvbuf = take((size_t)mrecv * 32);
+  if ((rc = ah_comm_alltoallv(m, sendbuf, sb.data(), so.data(), recvbuf, rb.data(), ro.data())) != AH_OK) return rc;
+  // ---- 3: the owner's re-aggregation over its mrecv tuples (columns laid end to end, source ranks ascending)
+  uint64_t* rk = (uint64_t*)take((size_t)mrecv * 8);
+  uint8_t* rs = take((size_t)mrecv * 8);
+  int64_t* rc_ = (int64_t*)take((size_t)mrecv * 8);
+  int64_t* rf = (int64_t*)take((size_t)mrecv * 8);
+  {
+    int64_t at = 0;
+    for (int s = 0; s < W; s++) {
+      const size_t nb = (size_t)rcnt[s] * 8;
+      const uint8_t* blk = recvbuf + ro[s];
+      if (nb) {
+        if ((rc = ah_copy_async(c, (uint8_t*)rk + (size_t)at * 8, blk, nb)) != AH_OK) return rc;
+        if ((rc = ah_copy_async(c, rs + (size_t)at * 8, blk + nb, nb)) != AH_OK) return rc;
+        if ((rc = ah_copy_async(c, (uint8_t*)rc_ + (size_t)at * 8, blk + 2 * nb, nb)) != AH_OK) return rc;
+        if ((rc = ah_copy_async(c, (uint8_t*)rf + (size_t)at * 8, blk + 3 * nb, nb)) != AH_OK) return rc;
+      }
+      at += rcnt[s];
+    }
+  }
+  uint64_t* ok = (uint64_t*)take(((size_t)mrecv + 1) * 8);
+  uint8_t* osum = take(((size_t)mrecv + 1) * 8);
+  int64_t* ocnt = (int64_t*)take(((size_t)mrecv + 1) * 8);
+  int64_t* ofirst = (int64_t*)take(((size_t)mrecv + 1) * 8);
+  uint64_t* ok2 = (uint64_t*)take(((size_t)mrecv + 1) * 8);
+  int64_t* csum = (int64_t*)take(((size_t)mrecv + 1) * 8);
+  int64_t* ofirst_rows = (int64_t*)take(((size_t)mrecv + 1) * 8);
+  int64_t ng = 0, ng2 = 0;
+  if (mrecv > 0) {
+    if (is_f64) rc = ah_hash_sum_f64(c, rk, nullptr, 0, (const double*)rs, nullptr, 0, mrecv, ok, (double*)osum, ocnt, ofirst, &ng, nullptr);
+    else rc = ah_hash_sum_i64(c, rk, nullptr, 0, (const int64_t*)rs, nullptr, 0, mrecv, ok, (int64_t*)osum, ocnt, ofirst, &ng, nullptr);
+    if (rc != AH_OK) return rc;
+    if ((rc = ah_hash_sum_i64(c, rk, nullptr, 0, rc_, nullptr, 0, mrecv, ok2, csum, ocnt, nullptr, &ng2, nullptr)) != AH_OK) return rc;
+    if (ng2 != ng) return ah_fail(c, AH_EINVALID, "merge_groups: internal error (group counts differ)");
+    if ((rc = ah_take_primitive(c, 8, rf, nullptr, 0, mrecv, 8, 1, ofirst, nullptr, 0, ng, 1, ofirst_rows, nullptr, nullptr, nullptr)) != AH_OK) return rc;
+  }
+  // ---- 4: every rank gets every owner's groups
+  std::vector<int64_t> gcnt(W);
+  const int64_t ng_local = ng;
+  if (W == 1) gcnt[0] = ng;
+  else if ((rc = comm_allgather_host(m, &ng_local, 1, gcnt.data())) != AH_OK) return rc;
+  int64_t G = 0, mx = 0;
+  for (int r = 0; r < W; r++) { G += gcnt[r]; mx = gcnt[r] > mx ? gcnt[r] : mx; }
+  *out_ngroups_host = G;
+  if (G > capacity) return ah_fail(c, AH_EINVALID, "merge_groups: %lld groups, the outputs hold %lld", (long long)G, (long long)capacity);
+  if (G == 0) return AH_OK;
+  if (!out_keys || !out_sums || !out_counts || !out_first_rows) return ah_fail(c, AH_EINVALID, "merge_groups: null output");
+  // blocks of 4 columns × mx (padded) per rank; then the columns are laid end to end, rank order
+  uint8_t* b0;
+  {
+    // a third reservation: the re-aggregation's temporaries are dead except ok / osum / csum / ofirst_rows (copied into the block first)
+    uint8_t* blk_local = nullptr;
+    AH_HIP(c, hipMalloc((void**)&blk_local, (size_t)mx * 32 + 64));
+    const void* cols[4] = {ok, osum, csum, ofirst_rows};
+    for (int k = 0; k < 4; k++)
+      if (ng > 0 && hipMemcpyAsync(blk_local + (size_t)k * (size_t)mx * 8, cols[k], (size_t)ng * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+        (void)hipFree(blk_local);
+        return ah_fail(c, AH_EHIP, "merge_groups: copy failed");
+      }
+    rc = arena_reserve(m, pad((size_t)mx * 32 * (size_t)W) + pad((size_t)G * 8) * 5 + 4096, &b0);
+    if (rc == AH_OK) {
+      if (W == 1) rc = ah_copy_async(c, b0, blk_local, (size_t)mx * 32);
+      else rc = ah_comm_allgather(m, blk_local, b0, mx * 32);
+    }
+    if (rc == AH_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = ah_fail(c, AH_EHIP, "merge_groups: sync failed");
+    (void)hipFree(blk_local);
+    if (rc != AH_OK) return rc;
+  }
+  uint8_t* colbase = b0 + pad((size_t)mx * 32 * (size_t)W);
+  uint8_t* col[4];
+  for (int k = 0; k < 4; k++) col[k] = colbase + (size_t)k * pad((size_t)G * 8);
+  uint64_t* order = (uint64_t*)(colbase + 4 * pad((size_t)G * 8));
+  {
+    int64_t at = 0;
+    for (int r = 0; r < W; r++) {
+      const size_t nb = (size_t)gcnt[r] * 8;
+      for (int k = 0; k < 4 && nb; k++)
+        if ((rc = ah_copy_async(c, col[k] + (size_t)at * 8, b0 + (size_t)r * (size_t)mx * 32 + (size_t)k * (size_t)mx * 8, nb)) != AH_OK) return rc;
+      at += gcnt[r];
+    }
+  }
+  // ---- 5: global first-seen order
+  if ((rc = ah_sort_indices(c, AH_INT64, col[3], nullptr, 0, G, 0, 0, order)) != AH_OK) return rc;
+  void* outs[4] = {out_keys, out_sums, out_counts, out_first_rows};
+  for (int k = 0; k < 4; k++)
+    if ((rc = ah_take_primitive(c, 8, col[k], nullptr, 0, G, 8, 0, order, nullptr, 0, G, 0, outs[k], nullptr, nullptr, nullptr)) != AH_OK) return rc;
+  AH_HIP(c, hipStreamSynchronize(c->stream));
   return AH_OK;
 }

@@ -57,6 +57,8 @@ struct ah_ctx {
   int opt_take_binned, opt_take_window_log2, opt_take_gather_wg, opt_take_gather_load, opt_take_gather_lds;
   int opt_groupby_keys;        // hash + sum: expected keys per partition the cut aims at (ARROWHIP_GROUPBY_KEYS; the LDS table admits 3584)
   int opt_groupby_partition;   // hash + sum (ah_groupby.hip): 0 never, 1 auto, k ≥ 2 always with 2^(k−2) partitions (ARROWHIP_GROUPBY_PARTITION)
+  int opt_encode_partition;    // unique / dictionary_encode (ah_hash_part.hip): 0 never, 1 auto (by the prefix's distinct count), k ≥ 3: always, 2^k partitions (ARROWHIP_ENCODE_PARTITION)
+  int opt_encode_part_min;     // auto: smallest expected distinct count that takes the partition-first path (ARROWHIP_ENCODE_PART_MIN)
   int opt_hash_direct;         // unique / dictionary_encode (ah_hash.hip): 0 ids in a separate pass, 1 direct ids, 2 + LDS / re-packed table (default), 3 no re-packed table (ARROWHIP_HASH_DIRECT)
   int opt_sort_msd;            // sort_indices: 0 LSD passes only, 1 auto (ARROWHIP_SORT_MSD)
   int opt_scan_segment_log2;   // cumulative_sum: bytes of input per segment (ARROWHIP_SCAN_SEGMENT_LOG2; 0 = one segment)
@@ -156,6 +158,10 @@ int ah_groupby_partitioned_try(ah_ctx* ctx, int is_f64, const uint64_t* keys, co
 // counts 8-byte partials for the integer sums, 16-byte ones for Float64), and the one final reduction over all of them
 int ah_sum_chunk_partials(ah_ctx* ctx, int is_f64, const void* buf, size_t len, void* partials16, int max_partials, int* n_written);
 int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials16, int n, void* res_dev);
+// internal (ah_hash_part.hip): unique / dictionary_encode of 8-byte keys by partitions of the key hash, 2^lp of them (8 … 10);
+// temporaries in the temp arena; *used says whether out_* hold the result
+int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+                              int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are

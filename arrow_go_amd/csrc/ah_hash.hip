@@ -701,10 +701,29 @@ struct EncodeResult {
 // core: ids (optional, n int32), dict (optional), returns sizes.  Device pointers.
 template <typename K>
 int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
-                int32_t* out_ids, uint64_t* out_dict, EncodeResult* res, int64_t* out_first_rows = nullptr) {
+                int32_t* out_ids, uint64_t* out_dict, EncodeResult* res, int64_t* out_first_rows = nullptr, bool allow_partitioned = true) {
   res->ndict = 0;
   res->null_id = -1;
   if (n == 0) return AH_OK;
+  // partition-first (ah_hash_part.hip) — forced by the option (tests, measurements); the automatic choice comes after the prefix below.
+  // allow_partitioned = false: the caller's own temporaries live in the arena that path would take (the id-based group-by)
+  auto try_partitioned = [&](int lp, bool* done) -> int {
+    *done = false;
+    if constexpr (K::kLdsTable) {
+      int used = 0;
+      int64_t nd = 0;
+      int32_t nid = -1;
+      int prc = ah_encode_partitioned_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, out_ids, out_dict, out_first_rows, &nd, &nid, &used);
+      if (prc != AH_OK) return prc;
+      if (used) { res->ndict = nd; res->null_id = nid; *done = true; }
+    }
+    return AH_OK;
+  };
+  if (K::kLdsTable && allow_partitioned && c->opt_encode_partition >= 3) {
+    bool done;
+    int prc = try_partitioned(c->opt_encode_partition > 10 ? 10 : c->opt_encode_partition, &done);
+    if (prc != AH_OK || done) return prc;
+  }
   // slot numbers travel through the int32 id column: the largest table (2n slots + 2) must stay below 2^32 − 1
   if (n > ((int64_t)1 << 30)) return ah_fail(c, AH_ENOTIMPL, "hash: more than 2^30 rows per call");
   const int64_t nwords = ah_ceil_div(n, 64);
@@ -762,6 +781,23 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
                                                    (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
         lo = hi;
+        if (K::kLdsTable && allow_partitioned && c->opt_encode_partition == 1 && !resized && hi == ((int64_t)1 << 16) && n >= ((int64_t)1 << 22)) {
+          // A first look after 2^16 rows: ≈ 3·10^5 … 4.5·10^6 expected keys are more than the LDS / re-packed tables and the caches
+          // hold — cut the rows by key hash and give every partition a table in LDS (ah_hash_part.hip; ≤ 4400 expected keys per
+          // partition of 256 … 1024).  2^16 rows show 2^19 evenly drawn keys with ≈ 3900 repeats (± 62): the urn model's estimate
+          // is good to a few per cent up to 2^22 keys; a column whose head misleads (sorted keys) is caught by the partition
+          // pass itself (a table that overflows voids the attempt) or simply stays on this path.
+          AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[4], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+          AH_HIP(c, hipStreamSynchronize(c->stream));
+          const double est = estimate_distinct((double)*(volatile uint64_t*)&c->pinned[0], (double)hi, (double)n);
+          if (*(volatile unsigned*)&c->pinned[1] == 0 && est >= (double)c->opt_encode_part_min && est <= 1024.0 * 4400.0) {
+            int lp = 8;
+            while (lp < 10 && est / (double)(1 << lp) > 4400.0) lp++;
+            bool done;
+            int prc = try_partitioned(lp, &done);
+            if (prc != AH_OK || done) return prc;
+          }
+        }
       }
     }
     bool restart = false, small = false, direct = false, compact = false;
@@ -947,7 +983,7 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
     AH_LAUNCH_CHECK(c);
   }
   EncodeResult res;
-  rc = encode_core(c, U64Keys{(const unsigned long long*)keys}, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows);
+  rc = encode_core(c, U64Keys{(const unsigned long long*)keys}, kvalid, koff, n, /*encode_nulls=*/1, ids, out_keys, &res, out_first_rows, /*allow_partitioned=*/false);
   if (rc == AH_OK) {
     hipError_t e1 = hipMemsetAsync(out_sums, 0, (size_t)res.ndict * sizeof(AT), c->stream);
     hipError_t e2 = hipMemsetAsync(out_counts, 0, (size_t)res.ndict * sizeof(int64_t), c->stream);

@@ -1,0 +1,329 @@
+// ah_hash_part.hip — partition-first unique / dictionary_encode for 8-byte keys: the path for the cardinalities where the one
+// global table of ah_hash.hip is neither in LDS nor in L2 (≈ 4·10^5 … 5·10^6 distinct keys).
+//
+// Replaces (same results, other order of work): doAppendNumeric[uint64] over hashing.Table[uint64].InsertOrGet
+// (kernels/vector_hash.go:359-385, internal/hashing/xxh3_memo_table_types.go:283-294), dictionaryEncodeAction
+// (vector_hash.go:145-241) and uniqueFinalize (:721-741): ids = order of first occurrence, the null key (if encoded) takes the
+// id at which it is first seen (:231-238), a masked null row gets index 0 (vector_hash.go:169-172).
+//
+// Why.  With 2^20 keys the global table is 32 MiB: every row's probe is a random 64-byte line from the Infinity Cache or HBM,
+// and the ids come from a second walk of the same table — PMC showed 92 B/row at 2^20 keys and 237 at 2^24 for 12 algorithmic
+// (profiles/r02_pmc_by_workload.json), all of it random lines at the ≈ 50 G/s this chip serves them.  The group-by of
+// ah_groupby.hip already avoids that by cutting the rows by key hash first; this file does the same for the encode, whose
+// extra difficulty is that it owes an id to every ROW, in row order:
+//
+//   1 hist, offsets     per (4096-row tile, partition) counts → where every tile's run of every partition starts   (ah_partition.h, ah_bins.h)
+//   2 scatter           {key, row | null flag} staged in partition order in LDS, written as runs (20 B/row moved)
+//   3 table             ONE workgroup per partition: its keys in an 8192-slot open-addressing table in LDS {key, first row};
+//                       every record learns its SLOT (2 bytes, partition order); the table and the first-row bits leave
+//   4 rank              first rows → n-bit bitmap → prefix popcount = the sequential memo index (the argument of ah_hash.hip);
+//                       every used slot gets its id, dict[id] = key
+//   5 resolve           one workgroup per partition again, the partition's slot → id table in LDS: slot numbers → ids, still
+//                       in partition order (6 B/row)
+//   6 unpermute         per tile: its runs are read back (id + row), placed at row-in-tile in LDS, 4096 ids leave coalesced
+//                       (the way the binned Take sends gathered values home, ah_take_binned.hip)
+// `unique` (no ids wanted) stops after step 4.  Everything is streaming or ≥ 64-byte runs: 8 + 20 + 14 + 6 + 12 = 60 B/row.
+// Nothing depends on timing: a slot number is arbitrary, an id is a function of first rows only — the bytes are those of the
+// global-table path (tests/test_gpu_parity.py::test_hash_encode_partitioned).
+//
+// One workgroup per partition needs partitions of similar size: a key that owns a large share of the rows (Zipf) makes one
+// partition many times the others — seen on the host right after the offsets pass, and such columns stay on the other path.
+#include <vector>
+#include "ah_common.h"
+#include "ah_hashing.h"
+#include "ah_bins.h"
+#include "ah_partition.h"
+
+namespace {
+
+constexpr int kESlots = 8192;              // LDS table of one partition: open addressing, aligned groups of 4
+constexpr int kESoft = 6144;               // keys admitted; beyond that the attempt is void (the estimate was far off)
+constexpr int kELSlots = kESlots + 2;      // + the all-ones key (kESlots) and the null key (kESlots + 1)
+constexpr int kEStride = kESlots + 8;      // a partition's slice of the global copies
+constexpr unsigned short kMaskedSlot = 0xFFFFu;   // a null row whose nulls are not encoded: index 0, no dictionary entry
+
+__device__ __forceinline__ unsigned enc_group(unsigned long long key) {   // first slot group; inside a partition the keys agree in the top bits of gb_mix
+  return ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 19) & (unsigned)(kESlots - 4);
+}
+
+// ---- 3: one workgroup per partition ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long long* __restrict__ pkeys, const unsigned* __restrict__ prows,
+                                                              const unsigned* __restrict__ binstart, int encode_nulls,
+                                                              unsigned long long* __restrict__ tab_key, unsigned* __restrict__ tab_first,
+                                                              unsigned short* __restrict__ rec_slot, unsigned long long* __restrict__ firsts,
+                                                              unsigned* __restrict__ overflow) {
+  __shared__ __attribute__((aligned(16))) unsigned long long l_key[kELSlots];
+  __shared__ unsigned l_first[kELSlots];
+  __shared__ unsigned s_used;
+  const int t = threadIdx.x, part = blockIdx.x;
+  const int64_t r0 = binstart[part], r1 = binstart[part + 1];
+  for (int j = t; j < kELSlots; j += kThreads) { l_key[j] = kEmpty; l_first[j] = kNoRow; }
+  if (t == 0) s_used = 0;
+  __syncthreads();
+  const unsigned lkey_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)l_key;   // LDS byte address of the key table
+  // find or claim the slot of `key` (−1: the table is full)
+  auto slot_of = [&](unsigned long long key) -> int {
+    unsigned g = enc_group(key);
+    for (;;) {
+      // two ds_read_b128, spelled out (the compiler would split them into ds_read2_b64: half the banks per access, ah_groupby.hip)
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 a, c;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(a), "=&v"(c) : "v"(lkey_base + g * 8u) : "memory");
+      const bool h0 = a.x == key, h1 = a.y == key, h2 = c.x == key, h3 = c.y == key;
+      const bool e0 = a.x == kEmpty, e1 = a.y == kEmpty, e2 = c.x == kEmpty, e3 = c.y == kEmpty;
+      const bool y0 = h0 || e0, y1 = h1 || e1, y2 = h2 || e2, y3 = h3 || e3;
+      if (!(y0 || y1 || y2 || y3)) { g = (g + 4) & (kESlots - 1); continue; }
+      const int j = (int)g + (y0 ? 0 : y1 ? 1 : y2 ? 2 : 3);
+      if (h0 || (!e0 && (h1 || (!e1 && (h2 || (!e2 && h3)))))) return j;   // the key sits in front of the first empty slot
+      if (atomicAdd(&s_used, 1u) >= (unsigned)kESoft) return -1;             // tickets are never returned: "full" sticks
+      const unsigned long long cur = atomicCAS(&l_key[j], kEmpty, key);
+      if (cur == kEmpty || cur == key) return j;
+      // another key took it meanwhile: look at the group again
+    }
+  };
+  constexpr int U = 4;
+  constexpr int64_t kStep = (int64_t)kThreads * U;
+  unsigned long long nk[U];
+  unsigned nrw[U];
+  auto load_step = [&](int64_t b) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      const bool in = i < r1;
+      nk[u] = in ? __builtin_nontemporal_load(&pkeys[i]) : 0ull;
+      nrw[u] = in ? __builtin_nontemporal_load(&prows[i]) : 0u;
+    }
+  };
+  bool full = false;
+  // the lane's previous row: a key that owns much of the partition would put every lane on one slot group
+  unsigned long long p_key = 0;
+  int p_slot = -2;
+  if (r0 < r1) load_step(r0);
+  __builtin_amdgcn_s_waitcnt(0);   // enter the loop with nothing pending: see gb_aggregate_kernel on the compiler's wait counts
+  for (int64_t b = r0; b < r1; b += kStep) {
+    unsigned long long k[U];
+    unsigned rw[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { k[u] = nk[u]; rw[u] = nrw[u]; }
+    if (b + kStep < r1) load_step(b + kStep);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      if (i >= r1) continue;
+      const unsigned row = rw[u] & kRowMask;
+      int j;
+      if (rw[u] & kKeyNull) j = encode_nulls ? kESlots + 1 : -2;
+      else if (k[u] == kEmpty) j = kESlots;
+      else if (p_slot >= 0 && p_key == k[u]) j = p_slot;
+      else { j = slot_of(k[u]); p_key = k[u]; p_slot = j; }
+      if (j >= 0) {
+        if (l_first[j] > row) atomicMin(&l_first[j], row);   // rows of a key arrive mostly in ascending order: a read is half an atomic
+      } else if (j == -1) {
+        full = true;
+      }
+      if (rec_slot) rec_slot[i] = j >= 0 ? (unsigned short)j : kMaskedSlot;
+    }
+  }
+  if (full) atomicExch(overflow, 1u);
+  __syncthreads();
+  const int64_t gbase = (int64_t)part * kEStride;
+  for (int j = t; j < kEStride; j += kThreads) {
+    const unsigned fr = j < kELSlots ? l_first[j] : kNoRow;
+    if (j < kELSlots) tab_key[gbase + j] = l_key[j];
+    tab_first[gbase + j] = fr;
+    if (fr != kNoRow) atomicOr(&firsts[fr >> 6], 1ull << (fr & 63));
+  }
+}
+
+// ---- 4: ids of the used slots (tab_first is overwritten with them), the dictionary -----------------------------------------------
+__global__ __launch_bounds__(kBlock) void enc_assign_kernel(const unsigned long long* __restrict__ tab_key, unsigned* __restrict__ tab_first, int64_t nslots,
+                                                             const unsigned long long* __restrict__ firsts, const unsigned* __restrict__ wordprefix,
+                                                             const int64_t* __restrict__ tileoff, unsigned long long* __restrict__ dict,
+                                                             long long* __restrict__ first_rows, int* __restrict__ null_id) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
+    const unsigned fr = tab_first[s];
+    if (fr == kNoRow) continue;
+    const unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
+    tab_first[s] = id;
+    const int in_part = (int)(s % kEStride);
+    unsigned long long key = tab_key[s];
+    if (in_part == kESlots) key = kEmpty;
+    if (in_part == kESlots + 1) { key = 0; *null_id = (int)id; }   // GetDictArrayData: the null slot keeps the fresh buffer's zero
+    if (dict) dict[id] = key;
+    if (first_rows) first_rows[id] = (long long)fr;
+  }
+}
+
+// ---- 5: slot numbers → ids, in partition order ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void enc_resolve_kernel(const unsigned short* __restrict__ rec_slot, const unsigned* __restrict__ tab_id,
+                                                                const unsigned* __restrict__ binstart, int* __restrict__ rec_id) {
+  __shared__ unsigned l_id[kELSlots];
+  const int t = threadIdx.x, part = blockIdx.x;
+  const int64_t r0 = binstart[part], r1 = binstart[part + 1];
+  for (int j = t; j < kELSlots; j += kThreads) l_id[j] = tab_id[(int64_t)part * kEStride + j];
+  __syncthreads();
+  constexpr int U = 8;
+  for (int64_t b = r0; b < r1; b += (int64_t)kThreads * U) {
+    unsigned short s[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      s[u] = i < r1 ? __builtin_nontemporal_load(&rec_slot[i]) : kMaskedSlot;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      if (i < r1) __builtin_nontemporal_store(s[u] == kMaskedSlot ? 0 : (int)l_id[s[u]], &rec_id[i]);
+    }
+  }
+}
+
+// ---- 6: ids back to row order, tile by tile -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void enc_unpermute_kernel(const int* __restrict__ rec_id, const unsigned* __restrict__ prows,
+                                                                  const unsigned* __restrict__ cnt_tm, const unsigned* __restrict__ toffs, int nb,
+                                                                  int64_t ntiles, int64_t n, int32_t* __restrict__ out_ids) {
+  __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_goff[kMaxBins], s_wsum[kThreads / 64];
+  __shared__ int s_out[kGbTile];
+  const int64_t tile = xcd_contiguous_tile(ntiles);
+  if (tile < 0) return;
+  unsigned excl = 0;
+  s_cnt[threadIdx.x] = 0;
+  if ((int)threadIdx.x < nb) {
+    s_cnt[threadIdx.x] = cnt_tm[tile * nb + threadIdx.x];
+    excl = toffs[tile * nb + threadIdx.x];
+  }
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  if ((int)threadIdx.x < nb) s_goff[threadIdx.x] = excl - s_start[threadIdx.x];
+  __syncthreads();
+  const int64_t base = tile * kGbTile;
+  const int tile_n = n - base >= kGbTile ? kGbTile : (int)(n - base);
+  // staged position lp → its partition = the LAST b with s_start[b] ≤ lp (empty partitions share their start with the next one)
+  int lo[kGbRows], hi[kGbRows];
+#pragma unroll
+  for (int k = 0; k < kGbRows; k++) { lo[k] = 0; hi[k] = nb - 1; }
+#pragma unroll 1
+  for (int step = 0; step < 10; step++) {   // 2^10 = kMaxBins
+#pragma unroll
+    for (int k = 0; k < kGbRows; k++) {
+      const int mid = (lo[k] + hi[k] + 1) >> 1;
+      const bool le = s_start[mid] <= (unsigned)(k * kThreads + threadIdx.x);
+      lo[k] = le ? mid : lo[k];
+      hi[k] = le ? hi[k] : mid - 1;
+    }
+  }
+  int id[kGbRows];
+  unsigned rw[kGbRows];
+#pragma unroll
+  for (int k = 0; k < kGbRows; k++) {
+    const int lp = k * kThreads + threadIdx.x;
+    id[k] = 0; rw[k] = 0;
+    if (lp < tile_n) {
+      const int64_t e = (int64_t)s_goff[lo[k]] + lp;
+      id[k] = __builtin_nontemporal_load(&rec_id[e]);
+      rw[k] = __builtin_nontemporal_load(&prows[e]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kGbRows; k++)
+    if (k * kThreads + (int)threadIdx.x < tile_n) s_out[(int64_t)(rw[k] & kRowMask) - base] = id[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kGbRows; k++) {
+    const int i = k * kThreads + threadIdx.x;
+    if (i < tile_n) __builtin_nontemporal_store(s_out[i], &out_ids[base + i]);
+  }
+}
+
+}  // namespace
+
+// Called by encode_core (ah_hash.hip) for 8-byte keys.  lp = log2 of the number of partitions (8 … 10).  *used = 1: out_* hold the
+// result; 0: not applicable or the attempt was void (a partition outgrew its table, or one partition holds several times its
+// share of the rows) — nothing the caller owns was touched except out_ids / out_dict / out_first_rows, which it rewrites.
+int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+                              int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used) {
+  *used = 0;
+  if (n < 1 || n >= kMaxRows || lp < 3 || lp > 10) return AH_OK;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const int P = 1 << lp;
+  const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
+  const int64_t nslots = (int64_t)P * kEStride;
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const size_t table = (size_t)P * (size_t)ntiles * 4;
+  const size_t need = pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) + pad((size_t)n * 8) + pad((size_t)n * 4) + pad((size_t)n * 2) +
+                      pad((size_t)nslots * 8) + pad((size_t)nslots * 4) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
+  uint8_t* base;
+  int rc = ah_temp_reserve(c, need, (void**)&base);
+  if (rc != AH_OK) return rc;
+  size_t used_b = 0;
+  auto take = [&](size_t b) { uint8_t* q = base + used_b; used_b += pad(b); return q; };
+  unsigned* cnt_tm = (unsigned*)take(table);
+  unsigned* toffs = (unsigned*)take(table);
+  unsigned* gsum = (unsigned*)take((size_t)ngrp * P * 4);
+  unsigned* binstart = (unsigned*)take((size_t)(P + 1) * 4);
+  unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
+  unsigned* prows = (unsigned*)take((size_t)n * 4);
+  unsigned short* rec_slot = (unsigned short*)take((size_t)n * 2);
+  unsigned long long* tab_key = (unsigned long long*)take((size_t)nslots * 8);
+  unsigned* tab_first = (unsigned*)take((size_t)nslots * 4);
+  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
+  int* tilecnt = (int*)take((size_t)nrt * 4);
+  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
+  int* rec_id = (int*)pkeys;   // the keys are not needed once every record knows its slot
+  unsigned* overflow = (unsigned*)&c->dscalars[30];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[31];
+  int* null_id = (int*)&c->dscalars[32];
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[30], 0, 2 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  const unsigned long long* k64 = (const unsigned long long*)keys;
+  // ---- 1, 2: cut
+  const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
+  gb_hist_kernel<<<tgrid, kGbHistThreads, 0, c->stream>>>(k64, valid, off, n, lp, P, ntiles, cnt_tm);
+  AH_LAUNCH_CHECK(c);
+  colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, P, ntiles, gsum);
+  AH_LAUNCH_CHECK(c);
+  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, P, ngrp, n, binstart);
+  AH_LAUNCH_CHECK(c);
+  tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, gsum, P, ntiles, toffs);
+  AH_LAUNCH_CHECK(c);
+  {
+    // one workgroup per partition is only as fast as the largest partition: look at the sizes before anything else is spent
+    std::vector<unsigned> bs((size_t)P + 1);
+    AH_HIP(c, hipMemcpyAsync(bs.data(), binstart, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned mx = 0;
+    for (int p = 0; p < P; p++) mx = bs[p + 1] - bs[p] > mx ? bs[p + 1] - bs[p] : mx;
+    if ((int64_t)mx * P > 3 * n && mx > (1u << 16)) return AH_OK;
+  }
+  gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lp, P, ntiles, toffs, pkeys, nullptr, prows, nullptr);
+  AH_LAUNCH_CHECK(c);
+  // ---- 3: tables
+  enc_table_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  AH_LAUNCH_CHECK(c);
+  // ---- 4: rank
+  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  AH_LAUNCH_CHECK(c);
+  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
+  AH_LAUNCH_CHECK(c);
+  enc_assign_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff,
+                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id);
+  AH_LAUNCH_CHECK(c);
+  if (out_ids) {
+    // ---- 5, 6: ids per record, then per row
+    enc_resolve_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
+    AH_LAUNCH_CHECK(c);
+    enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, P, ntiles, n, out_ids);
+    AH_LAUNCH_CHECK(c);
+  }
+  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[30], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition held more keys than its table admits: the global-table path redoes the call
+  if (out_ndict) *out_ndict = (int64_t) * (volatile uint64_t*)&c->pinned[9];
+  if (out_null_id) *out_null_id = *(volatile int32_t*)&c->pinned[10];
+  *used = 1;
+  return AH_OK;
+}

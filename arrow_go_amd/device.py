@@ -171,10 +171,39 @@ class Comm:
         check(ctx.handle, lib.ah_comm_init(ctx.handle, rank, world, C.addressof(idb), C.byref(h)))
         self.ctx, self.handle, self.rank, self.world = ctx, h, rank, world
 
+    @classmethod
+    def from_transport(cls, ctx: "Context", rank: int, world: int, transport) -> "Comm":
+        """a communicator over a host-supplied transport (ah_comm_init_transport): `transport` has a `.struct` (AhTransport)
+        whose callbacks stay alive with it — e.g. arrow_go_amd.distributed.GlooTransport"""
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        check(ctx.handle, lib.ah_comm_init_transport(ctx.handle, rank, world, C.byref(transport.struct), C.byref(h)))
+        self.ctx, self.handle, self.rank, self.world, self._transport = ctx, h, rank, world, transport
+        return self
+
     def close(self) -> None:
         if self.handle:
             lib.ah_comm_destroy(self.handle)
             self.handle = None
+
+    # ---- configs C4 / C5 as single calls -------------------------------------------------------------------------------
+    def cmp_filter_sum_i64(self, cmpop: int, x, valid, off: int, n_local: int, threshold: int):
+        s, n = C.c_int64(), C.c_int64()
+        check(self.ctx.handle, lib.ah_comm_cmp_filter_sum_i64(self.handle, cmpop, _ptr(x), _ptr(valid), off, n_local, threshold, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def cmp_filter_sum_f64(self, cmpop: int, x, valid, off: int, n_local: int, threshold: float):
+        s, n = C.c_double(), C.c_int64()
+        check(self.ctx.handle, lib.ah_comm_cmp_filter_sum_f64(self.handle, cmpop, _ptr(x), _ptr(valid), off, n_local, threshold, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def merge_groups(self, is_f64: bool, keys, sums, counts, first_rows, ngroups_local: int, row_offset: int, capacity: int,
+                     out_keys, out_sums, out_counts, out_first_rows) -> int:
+        g = C.c_int64()
+        check(self.ctx.handle, lib.ah_comm_merge_groups(self.handle, int(is_f64), _ptr(keys), _ptr(sums), _ptr(counts), _ptr(first_rows),
+                                                        ngroups_local, row_offset, capacity, _ptr(out_keys), _ptr(out_sums), _ptr(out_counts),
+                                                        _ptr(out_first_rows), C.byref(g)))
+        return g.value
 
     def allreduce_sum(self, type_id: int, send, recv, count: int) -> None:
         check(self.ctx.handle, lib.ah_comm_allreduce_sum(self.handle, type_id, _ptr(send), _ptr(recv), count))

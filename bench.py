@@ -525,10 +525,11 @@ def main():
             pair_ptr = pair_buf.ptr
 
         def c4_step():
-            ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, pair_ptr)
             if comm is not None:
-                comm.allreduce_sum(N.INT64, pair_ptr, pair_ptr, 2)
-            elif use_dist:
+                comm.cmp_filter_sum_i64(N.CMP_GT, a, None, 0, rows, 0)   # ONE C-ABI call: fused kernel + 16-byte all-reduce + the result on the host
+                return
+            ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, pair_ptr)
+            if use_dist:
                 dist.all_reduce(pair)
 
         for _ in range(max(args.warmup, 1)):
@@ -558,24 +559,18 @@ def main():
         kchunk = (krng.integers(0, 1 << 16, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
         for off in range(0, hrows, 1 << 22):
             c.upload(kchunk[:min(1 << 22, hrows - off)], off * 8)
-        merge = use_dist and world > 1 and not args.no_c5_merge
-        if merge:
-            from arrow_go_amd.distributed import AhCommCollectives, HipLocal, ShardedCompute
-            local = HipLocal.__new__(HipLocal); local.ctx = ctx; local.N = N        # share this rank's context / stream
-            dev = torch.device("cuda", local_rank)
-            sc = ShardedCompute(AhCommCollectives(comm, dev) if comm is not None else dist, dev, local)
-            outs = [torch.empty(hrows + 1, dtype=torch.int64, device=f"cuda:{local_rank}") for _ in range(4)]
-            optr = [t.data_ptr() for t in outs]
-        else:
-            obufs = [ctx.alloc((hrows + 1) * 8 + 64) for _ in range(4)]
-            optr = [b_.ptr for b_ in obufs]
+        # the owner merge is ONE C-ABI call (ah_comm_merge_groups); it runs whenever the ah_comm communicator exists and world > 1
+        merge = comm is not None and world > 1 and not args.no_c5_merge
+        obufs = [ctx.alloc((hrows + 1) * 8 + 64) for _ in range(4)]
+        optr = [b_.ptr for b_ in obufs]
+        mcap = (1 << 16) * 2 + 64
+        mbufs = [ctx.alloc(mcap * 8 + 64) for _ in range(4)] if merge else []
         ngroups = [0]
 
         def c5_step():
             ng, _ = ctx.hash_sum("f64", c, None, 0, x, None, 0, hrows, optr[0], optr[1], optr[2], optr[3])
             if merge:
-                cols = torch.stack([outs[0][:ng], outs[1][:ng], outs[2][:ng], outs[3][:ng] + rank * hrows])
-                ng = sc.merge_groups_t(torch, cols, True).shape[1]
+                ng = comm.merge_groups(True, optr[0], optr[1], optr[2], optr[3], ng, rank * hrows, mcap, *mbufs)
             ngroups[0] = int(ng)
 
         c5_step()
@@ -591,8 +586,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c5_dt = float(t.item())
         c5_ms = c5_dt * 1e3 / c5_steps
-        c5 = {"workload": "C5: hash + sum group-by over Int64 keys / Float64 values per GPU" + (", merged by key-hash owner (all-to-all of group tuples)" if merge else
-                                                                                                        " (local aggregate; the owner merge over RCCL runs when world > 1)"),
+        c5 = {"workload": "C5: hash + sum group-by over Int64 keys / Float64 values per GPU" + (", merged by key-hash owner (ah_comm_merge_groups: all-to-all of group tuples)" if merge else
+                                                                                                        " (local aggregate; the owner merge over RCCL runs when world > 1 with --collectives ah)"),
               "ms_per_step": round(c5_ms, 4), "Grows/s": round(hrows * args.gpus / (c5_ms * 1e-3) / 1e9, 2), "rows_per_gpu": hrows,
               "groups": ngroups[0], "n_gpus": args.gpus, "steps": c5_steps}
     except Exception as e:  # informative only

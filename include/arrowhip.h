@@ -378,10 +378,12 @@ int ah_hash_binary_encode(ah_ctx* ctx, int offset_width, const void* offsets, co
                           int64_t* out_ndict_host, int32_t* out_null_id_host);
 /* group-by sum (NEW — arrow-go has no hash aggregate; definition in DESIGN.md): groups
  * = dictionary_encode(keys, encode_nulls=1) ids; out_sums[g] = Σ valid vals of group
- * g, out_counts[g] = number of valid vals.  i64 sums wrap and are exact; f64 sums
- * use hardware fp64 atomic adds, so the accumulation ORDER is not deterministic:
- * |err| ≤ n_g·ε·Σ|x| per group, exact whenever all partial sums are representable
- * (e.g. integer-valued data < 2^53).  out_first_rows (nullable) receives each group's first
+ * g, out_counts[g] = number of valid vals.  i64 sums wrap and are exact; f64 sums are
+ * accumulated in 128-bit fixed point with integer atomics (csrc/ah_hashing.h): the same bytes
+ * run after run; a column spanning <= 42 binades gives every group its CORRECTLY ROUNDED exact
+ * sum, a wider one (an outlier such as 1e300 next to ordinary values) one scale per group and
+ * |err| <= ulp/2 + n_g·2^-94·max_g|x| — inside the sequential definition's n_g·ε·Σ_g|x|.
+ * out_first_rows (nullable) receives each group's first
  * row index — what a cross-GPU merge needs to restore the global first-seen order.
  * Outputs sized like out_dict above. */
 int ah_hash_sum_f64(ah_ctx* ctx, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
@@ -464,6 +466,38 @@ int ah_comm_allgather(ah_comm* comm, const void* send, void* recv, int64_t nbyte
  * recv_bytes_host[r] must be what rank r sends here (exchange the sizes first: an allgather of 8·world bytes) */
 int ah_comm_alltoallv(ah_comm* comm, const void* send, const int64_t* send_bytes_host, const int64_t* send_offs_host, void* recv,
                       const int64_t* recv_bytes_host, const int64_t* recv_offs_host);
+/* A communicator whose bytes are carried by the HOST's own transport (its launcher's sockets, MPI, a gloo group in the tests)
+ * instead of RCCL: the two callbacks work on host memory, return 0 on success, and are called by every rank in the same order.
+ * Device blocks are staged through pinned memory.  For hosts without RCCL between their processes — and for several ranks on
+ * ONE GPU, which RCCL refuses.  All ah_comm_* entry points work on either flavour. */
+typedef struct ah_transport {
+  void* user;
+  /* every rank contributes nbytes_per_rank bytes; recv_host gets world x nbytes_per_rank, rank order */
+  int (*allgather)(void* user, const void* send_host, void* recv_host, int64_t nbytes_per_rank);
+  /* block for rank r: send_host + send_offs[r], send_bytes[r] bytes -> recv_host + recv_offs[r] on rank r (the own block included) */
+  int (*alltoallv)(void* user, const void* send_host, const int64_t* send_bytes, const int64_t* send_offs, void* recv_host,
+                   const int64_t* recv_bytes, const int64_t* recv_offs);
+} ah_transport;
+int ah_comm_init_transport(ah_ctx* ctx, int rank, int world, const ah_transport* transport, ah_comm** out);
+/* ---- configs C4 / C5 as single calls — what a host runs per record-batch shard, nothing in between -------------
+ * C4: the fused Compare(op, scalar) -> Filter(DropNulls) -> Sum over THIS rank's shard (ah_cmp_filter_sum_*) and the one exchange
+ * step of the path: Int64 — an all-reduce of the 16-byte {sum, count} (wrapping sums are exact in any order); Float64 — an
+ * all-gather of the partials, added in RANK order on every rank (the same bytes on every rank and in every run of a given world
+ * size; an all-reduce's order is the ring's).  Every rank receives the global result.  Synchronises. */
+int ah_comm_cmp_filter_sum_i64(ah_comm* comm, int cmpop, const int64_t* x, const uint8_t* valid, int64_t off, int64_t n_local,
+                               int64_t threshold, int64_t* out_sum_host, int64_t* out_count_host);
+int ah_comm_cmp_filter_sum_f64(ah_comm* comm, int cmpop, const double* x, const uint8_t* valid, int64_t off, int64_t n_local,
+                               double threshold, double* out_sum_host, int64_t* out_count_host);
+/* C5: merge of the ranks' LOCAL aggregates (the outputs of ah_hash_sum_* over each rank's row shard; first_rows local, row_offset =
+ * the shard's first global row) by key-hash owner: groups bucketed by (hashInt(key) >> 40) mod world on the device -> ragged
+ * all-to-all of {key, sum, count, global first row} tuples (O(groups) bytes, never O(rows)) -> the owner re-aggregates (Float64:
+ * the reproducible sums of ah_hash_sum_f64) -> ragged all-gather -> ordered by global first row: the groups, in the order, that
+ * unique / dictionary_encode over the undivided column gives (kernels/vector_hash.go:359-385, 721-741).  Every rank receives all
+ * groups.  Device buffers; out_* hold `capacity` groups; *out_ngroups_host = the global group count — AH_EINVALID with that
+ * count set (and nothing written) when capacity is too small.  Synchronises. */
+int ah_comm_merge_groups(ah_comm* comm, int is_f64, const uint64_t* keys, const void* sums, const int64_t* counts, const int64_t* first_rows,
+                         int64_t ngroups_local, int64_t row_offset, int64_t capacity, uint64_t* out_keys, void* out_sums,
+                         int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups_host);
 
 /* ---- numeric cast (row §8(f)-2) ----------------------------------------------------------------
  * replaces castNumberToNumberUnsafe → castNumericUnsafe (kernels/cast_numeric.go:28-131; AVX2 leaf

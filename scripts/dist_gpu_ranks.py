@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Configs C4 / C5 through the C ABI with SEVERAL ranks on one GPU: every rank is a process with its own ah_ctx on device 0, the
+communicator is the host-transport flavour (ah_comm_init_transport) carried by a gloo group — RCCL refuses two ranks on one
+device, and a 1-GPU box has no second one.  Launched by tests/test_distributed_gpu.py under torch.distributed.run; every rank
+checks the global results of ah_comm_cmp_filter_sum_{i64,f64} and ah_comm_merge_groups against the CPU oracle over the
+UNDIVIDED data, byte for byte, and against each other through the protocol model of tests/dist_model.py."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+
+import arrow_go_amd as ah  # noqa: E402
+from arrow_go_amd.distributed import GlooTransport, ShardedGpu, shard_bounds  # noqa: E402
+from tests import oracle_lib as OL  # noqa: E402
+
+o = OL.load_oracle()
+ctx = ah.Context(0)
+tr = GlooTransport(dist)
+comm = ah.Comm.from_transport(ctx, rank, world, tr)
+sg = ShardedGpu(comm)
+rng = np.random.default_rng(4321)   # the same "table" on every rank; each takes its shard
+n = 400_003
+x = rng.integers(-10**9, 10**9, n, dtype=np.int64)
+valid_bits = rng.random(n) < 0.9
+xf = rng.standard_normal(n)
+lo, hi = shard_bounds(n, rank, world)
+vall = np.packbits(valid_bits, bitorder="little")
+dx = ctx.to_device(x[lo:hi]); dxf = ctx.to_device(xf[lo:hi]); dv = ctx.to_device(np.packbits(valid_bits[lo:hi], bitorder="little"), pad=64)
+# ---- C4
+for thr in (-5 * 10**8, 0, 7 * 10**8):
+    assert sg.cmp_filter_sum(2, dx, dv, 0, hi - lo, thr, np.int64) == o.cmp_filter_sum_i64(2, x, vall, 0, thr), thr
+gotf = sg.cmp_filter_sum(2, dxf, dv, 0, hi - lo, 0.25, np.float64)
+parts = []
+for r in range(world):
+    l2, h2 = shard_bounds(n, r, world)
+    _, s_exact, _c = o.cmp_filter_sum_f64(2, xf[l2:h2], np.packbits(valid_bits[l2:h2], bitorder="little"), 0, 0.25)
+    parts.append(s_exact)
+tot = 0.0
+for p in parts:   # rank order: what every rank must have, bit for bit
+    tot += p
+assert gotf[1] == int(((xf > 0.25) & valid_bits).sum())
+assert abs(gotf[0] - tot) <= 4 * np.spacing(abs(tot)) * world, (gotf[0], tot)    # each partial is within 1 ULP of its exact sum
+allf = [None] * world
+dist.all_gather_object(allf, float(gotf[0]).hex())
+assert len(set(allf)) == 1, allf                                                    # the same bytes on every rank
+
+
+def local_aggregate(kind, keys, vals):
+    m = keys.size
+    dk = ctx.to_device(keys); dvv = ctx.to_device(vals)
+    outs = [ctx.alloc((m + 1) * 8 + 64) for _ in range(4)]
+    ng, _ = ctx.hash_sum(kind, dk, None, 0, dvv, None, 0, m, outs[0], outs[1], outs[2], outs[3]) if m else (0, -1)
+    return ng, outs
+
+
+def merged(kind, keys, vals, row_offset, capacity):
+    ng, outs = local_aggregate(kind, keys, vals)
+    res = [ctx.alloc(capacity * 8 + 64) for _ in range(4)]
+    G = sg.merge_groups(kind == "f64", outs[0], outs[1], outs[2], outs[3], ng, row_offset, capacity, *res)
+    sdt = np.float64 if kind == "f64" else np.int64
+    return G, res[0].download(np.uint64, G), res[1].download(sdt, G), res[2].download(np.int64, G), res[3].download(np.int64, G)
+
+
+# ---- C5: few groups, many groups, every key its own group
+for card in (777, 50_000, 10**9):
+    keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+    vals = rng.integers(-2**40, 2**40, n, dtype=np.int64)
+    G, mk, ms, mc, mf = merged("i64", keys[lo:hi], vals[lo:hi], lo, n + 1)
+    ek, es, ec, _nid, ef = o.hash_sum("i64", keys, None, 0, vals, None, 0)
+    assert G == ek.size and mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes(), card
+    fv = rng.integers(-1000, 1000, n).astype(np.float64)          # integer-valued: exact in any merge order
+    G, mk, ms, mc, mf = merged("f64", keys[lo:hi], fv[lo:hi], lo, n + 1)
+    ek, es, ec, _nid, ef = o.hash_sum("f64", keys, None, 0, fv, None, 0)
+    assert G == ek.size and mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes(), card
+# general doubles: every rank the same bytes, each group within 2 ULP·world of the exact sum
+keys = rng.integers(0, 5000, n).astype(np.int64) * 1000003
+gv = rng.standard_normal(n)
+G, mk, ms, mc, mf = merged("f64", keys[lo:hi], gv[lo:hi], lo, n + 1)
+ek, es, ec, _nid, ef = o.hash_sum("f64", keys, None, 0, gv, None, 0)
+assert mk.tobytes() == ek.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes()
+assert np.all(np.abs(ms - es) <= 1e-9 * np.maximum(1.0, np.abs(es)))
+digests = [None] * world
+dist.all_gather_object(digests, ms.tobytes().hex()[:64] + str(hash(ms.tobytes())))
+assert len({d[:64] for d in digests}) == 1
+# ragged: rank 0 contributes no group at all; too small a capacity is an error that names the count
+l0, h0 = shard_bounds(n, 0, world)
+k2, v2 = keys[h0:], rng.integers(-2**40, 2**40, n, dtype=np.int64)[h0:]
+if rank == 0:
+    mine_k, mine_v = np.zeros(0, np.int64), np.zeros(0, np.int64)
+else:
+    mine_k, mine_v = keys[lo:hi], v2[lo - h0:hi - h0]
+G, mk, ms, mc, mf = merged("i64", mine_k, mine_v, max(lo - h0, 0), n + 1)
+ek, es, ec, _nid, ef = o.hash_sum("i64", k2, None, 0, v2, None, 0)
+assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes()
+try:
+    merged("i64", mine_k, mine_v, max(lo - h0, 0), 10)
+    raise SystemExit("a capacity of 10 groups was accepted")
+except ah.ErrInvalid as e:
+    assert str(ek.size) in str(e), str(e)
+assert not tr.errors, tr.errors
+comm.close()
+dist.barrier()
+if rank == 0:
+    print(f"dist_gpu_ranks ok: world {world} on one GPU, C4 and C5 through ah_comm_* == oracle over the undivided data")
+dist.destroy_process_group()

@@ -1,11 +1,10 @@
-"""world_size-2 gloo tests (CPU) of the record-batch sharding layer
-(arrow_go_amd/distributed.py): shard bounds, the 16-byte all-reduce of the fused
-Compare→Filter→Sum partials, the rank-ordered float64 combine, and the key-hash-owner
-all-to-all merge of the hash group-by.
-
-The per-shard leaf compute is injected: here it is a stand-in backed by the CPU oracle
-(test infrastructure), so what runs under test is the product's SHARDING / COLLECTIVE /
-MERGE code.  On GPUs the same class is driven by HipLocal (libarrowhip.so) over RCCL.
+"""world_size-2 / 3 gloo tests (CPU) of the record-batch sharding protocol: shard bounds and the owner function
+(arrow_go_amd/distributed.py), and — through the executable model of tests/dist_model.py, with a stand-in backed by the CPU
+oracle for the per-shard compute — the 16-byte all-reduce of the fused Compare→Filter→Sum partials, the rank-ordered float64
+combine, and the key-hash-owner all-to-all merge of the hash group-by, incl. the byte-level block packing of the ah_comm_*
+interface.  The product's implementation of the same protocol is C (csrc/ah_comm.hip: ah_comm_cmp_filter_sum_*,
+ah_comm_merge_groups) and needs a GPU: tests/test_distributed_gpu.py runs it with 2 and 3 ranks on one device and compares
+it with the oracle — and this model is the second opinion on what the bytes must be.
 """
 import ctypes
 import os
@@ -145,7 +144,7 @@ def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     from tests import oracle_lib as OL
-    from arrow_go_amd.distributed import ShardedCompute
+    from tests.dist_model import ShardedCompute
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -190,7 +189,7 @@ def _worker(rank, world, port, q):
         assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes()
         # the same steps through the C-ABI-shaped provider (AhCommCollectives over a byte-level comm): block packing and
         # offsets for world > 1; ragged on purpose (rank 0 contributes no groups at all in the second round)
-        from arrow_go_amd.distributed import AhCommCollectives
+        from tests.dist_model import AhCommCollectives
         sc2 = ShardedCompute(AhCommCollectives(GlooByteComm(dist, torch), torch.device("cpu")), torch.device("cpu"), OracleLocal())
         assert sc2.cmp_filter_sum(torch, GT, x[lo:hi], vshard, 0, hi - lo, 0, np.int64) == exp
         assert sc2.cmp_filter_sum(torch, GT, xf[lo:hi], vshard, 0, hi - lo, 0.25, np.float64) == gotf

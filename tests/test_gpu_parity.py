@@ -715,6 +715,56 @@ def _exact_group_sums(keys, fv, ok, limit):
     return out
 
 
+@pytest.mark.parametrize("lp", [3, 8, 10])
+def test_hash_encode_partitioned(hip, orc_be, ctx, lp):
+    """ah_hash_part.hip (rows cut by key hash, one LDS table per partition, ids sent back to row order), forced on at sizes the
+    oracle does in a second: ids, index validity, dictionary and null id byte-equal to the sequential memo table — nulls encoded
+    and masked, the all-ones key, bit offsets, ragged last tile, partitions with no rows, more keys than a partition's table
+    admits (the attempt is void, the global-table path answers), one key owning half the rows (not attempted)."""
+    rng = np.random.default_rng(700 + lp)
+    try:
+        ctx.set_option("encode_partition", lp)
+        for n, card, hot in [(1, 1, 0), (4096, 7, 0), (4097, 3000, 0), (70001, 500, 0), (300007, 40000, 0), ((1 << 20) + 3, 1 << 19, 0),
+                             ((1 << 21) + 77, (1 << 21) + 77, 0), (500009, 20000, 0.5)]:
+            keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+            if hot:
+                keys[rng.random(n) < hot] = 12345
+            if n > 10:
+                keys[rng.integers(0, n, 3)] = -1          # the all-ones key
+            for valid, off in ((None, 0), (rand_bits(rng, n + 16, 0.9), 5)):
+                for enc in (False, True):
+                    g, e = hip.hash_encode(keys, valid, off, enc), orc_be.hash_encode(keys, valid, off, enc)
+                    assert g[2].size == e[2].size and g[3] == e[3], (n, card, enc, g[2].size, e[2].size, g[3], e[3])
+                    bad = np.flatnonzero(g[0] != e[0])
+                    assert bad.size == 0, (n, card, enc, bad.size, bad[:5], g[0][bad[:5]], e[0][bad[:5]])
+                    bits = lambda a: np.unpackbits(a, bitorder="little")[:n]
+                    assert (bits(g[1]) == bits(e[1])).all() and g[2].tobytes() == e[2].tobytes(), (n, card, enc)
+            # unique: no ids wanted — the dictionary alone
+            kb = ctx.to_device(keys.view(np.uint64)); db = ctx.alloc((n + 1) * 8 + 64)
+            nd, nid = ctx.hash_u64_encode(kb, None, 0, n, True, None, None, db)
+            e = orc_be.hash_encode(keys, None, 0, True)
+            assert nd == e[2].size and db.download(np.uint64, nd).tobytes() == e[2].tobytes()
+            kb.free(); db.free()
+    finally:
+        ctx.set_option("encode_partition", 1)
+
+
+def test_hash_encode_partitioned_auto(hip, orc_be, ctx):
+    """the automatic choice: ≥ 2^22 rows and a prefix that promises between encode_part_min and 4.5 M keys"""
+    rng = np.random.default_rng(79)
+    n = (1 << 22) + 1001
+    try:
+        ctx.set_option("encode_part_min", 50000)
+        for card in (70000, 1 << 20):
+            keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+            valid = rand_bits(rng, n + 8, 0.97)
+            for enc in (False, True):
+                g, e = hip.hash_encode(keys, valid, 3, enc), orc_be.hash_encode(keys, valid, 3, enc)
+                assert g[2].size == e[2].size and g[3] == e[3] and g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes(), (card, enc)
+    finally:
+        ctx.set_option("encode_part_min", 300000)
+
+
 def test_hash_sum_f64_is_deterministic_and_tight(hip, orc_be):
     """Float64 group sums are accumulated in 128-bit fixed point with integer atomics (associative), rounded once: the bytes
     do not change from run to run.  A column spanning ≤ 42 binades keeps every addend whole, so each group's sum is the
