@@ -162,6 +162,9 @@ int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials16, int 
 // temporaries in the temp arena; *used says whether out_* hold the result
 int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
+// … and by two cuts, 64 parents × 2^(lp − 6) partitions (lp = 11 … 13)
+int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are

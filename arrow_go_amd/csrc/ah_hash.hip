@@ -713,7 +713,8 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
       int used = 0;
       int64_t nd = 0;
       int32_t nid = -1;
-      int prc = ah_encode_partitioned_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, out_ids, out_dict, out_first_rows, &nd, &nid, &used);
+      int prc = lp <= 10 ? ah_encode_partitioned_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, out_ids, out_dict, out_first_rows, &nd, &nid, &used)
+                         : ah_encode_partitioned2_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, out_ids, out_dict, out_first_rows, &nd, &nid, &used);
       if (prc != AH_OK) return prc;
       if (used) { res->ndict = nd; res->null_id = nid; *done = true; }
     }
@@ -721,7 +722,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
   };
   if (K::kLdsTable && allow_partitioned && c->opt_encode_partition >= 3) {
     bool done;
-    int prc = try_partitioned(c->opt_encode_partition > 10 ? 10 : c->opt_encode_partition, &done);
+    int prc = try_partitioned(c->opt_encode_partition > 13 ? 13 : c->opt_encode_partition, &done);
     if (prc != AH_OK || done) return prc;
   }
   // slot numbers travel through the int32 id column: the largest table (2n slots + 2) must stay below 2^32 − 1
@@ -790,9 +791,9 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
           AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[4], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
           AH_HIP(c, hipStreamSynchronize(c->stream));
           const double est = estimate_distinct((double)*(volatile uint64_t*)&c->pinned[0], (double)hi, (double)n);
-          if (*(volatile unsigned*)&c->pinned[1] == 0 && est >= (double)c->opt_encode_part_min && est <= 1024.0 * 4400.0) {
-            int lp = 8;
-            while (lp < 10 && est / (double)(1 << lp) > 4400.0) lp++;
+          if (*(volatile unsigned*)&c->pinned[1] == 0 && est >= (double)c->opt_encode_part_min && est <= 8192.0 * 4400.0) {
+            int lp = 8;   // 256 … 1024 partitions in one cut, 2048 … 8192 in two (ah_encode_partitioned2_try)
+            while (lp < 13 && est / (double)(1 << lp) > 4400.0) lp++;
             bool done;
             int prc = try_partitioned(lp, &done);
             if (prc != AH_OK || done) return prc;

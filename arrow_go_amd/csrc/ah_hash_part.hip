@@ -33,6 +33,7 @@
 #include "ah_hashing.h"
 #include "ah_bins.h"
 #include "ah_partition.h"
+#include "ah_msd.h"
 
 namespace {
 
@@ -237,6 +238,152 @@ __global__ __launch_bounds__(kThreads) void enc_unpermute_kernel(const int* __re
   }
 }
 
+
+// ---- more than 1024 partitions: a second cut ---------------------------------------------------------------------------------------
+// Beyond ≈ 4.5 M keys 1024 LDS tables are not enough, and one scatter into thousands of partitions would write runs of one or two
+// rows.  So the cut is made twice, as in the MSD sort and the large group-by (ah_msd.h): level 1 = the pass above with 64
+// partitions ("parents"); level 2 cuts every parent into 2^lb2 ≤ 128 partitions — its tiles are "virtual tiles" that never cross
+// a parent boundary and all run on one XCD.  A level-2 record is {key, row | flag} plus its position in the virtual tile (2 bytes):
+// the ids go home in two steps, virtual tile by virtual tile back into level-1 order, then tile by tile into row order.
+__device__ __forceinline__ unsigned e2_digit(unsigned long long key, unsigned rw, int lp, unsigned mask) {
+  return (rw & kKeyNull) ? 0u : ((unsigned)(gb_mix(key) >> (64 - lp)) & mask);   // level 1 took the top 6 of these lp bits (null keys: partition 0 of parent 0)
+}
+
+__global__ __launch_bounds__(kThreads) void e2_hist_kernel(const unsigned long long* __restrict__ pkeys, const unsigned* __restrict__ prows, int64_t n,
+                                                            const unsigned* __restrict__ pstart, int nparents, int lp, unsigned mask, int nb,
+                                                            unsigned* __restrict__ cnt) {
+  __shared__ unsigned s_h[kThreads];
+  __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_wsum[kThreads / 64];
+  __shared__ int s_pick;
+  const TileRange r = ms_tile(pstart, nparents, n, s_cnt, s_start, s_wsum, &s_pick);
+  if (r.parent < 0) return;
+  for (int b = threadIdx.x; b < nb; b += kThreads) s_h[b] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    const int64_t i = r.lo + u * kThreads + threadIdx.x;
+    if (i < r.hi) atomicAdd(&s_h[e2_digit(__builtin_nontemporal_load(&pkeys[i]), __builtin_nontemporal_load(&prows[i]), lp, mask)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += kThreads) cnt[r.id * nb + b] = s_h[b];
+}
+
+__global__ __launch_bounds__(kThreads) void e2_scatter_kernel(const unsigned long long* __restrict__ pkeys, const unsigned* __restrict__ prows, int64_t n,
+                                                               const unsigned* __restrict__ pstart, int nparents, int lp, unsigned mask, int nb,
+                                                               const unsigned* __restrict__ toffs, unsigned long long* __restrict__ out_keys,
+                                                               unsigned* __restrict__ out_rows, unsigned short* __restrict__ out_j) {
+  __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_goff[kThreads], s_wsum[kThreads / 64];
+  __shared__ unsigned s_a[kThreads], s_b[kThreads];
+  __shared__ unsigned long long s_stage[kMsTile];
+  __shared__ uint16_t s_bin[kMsTile];
+  __shared__ int s_pick;
+  const TileRange r = ms_tile(pstart, nparents, n, s_a, s_b, s_wsum, &s_pick);
+  if (r.parent < 0) return;
+  const int t = threadIdx.x;
+  s_cnt[t] = 0;
+  unsigned long long k[kMsRows];
+  unsigned rw[kMsRows], dg[kMsRows], rank[kMsRows];
+  bool live[kMsRows];
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    const int64_t i = r.lo + u * kThreads + t;
+    live[u] = i < r.hi;
+    k[u] = live[u] ? __builtin_nontemporal_load(&pkeys[i]) : 0ull;
+    rw[u] = live[u] ? __builtin_nontemporal_load(&prows[i]) : 0u;
+  }
+  unsigned goff_excl = 0;
+  if (t < nb) goff_excl = toffs[r.id * nb + t];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    dg[u] = e2_digit(k[u], rw[u], lp, mask);
+    rank[u] = live[u] ? atomicAdd(&s_cnt[dg[u]], 1u) : 0u;
+  }
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);   // nb ≤ 128
+  if (t < nb) s_goff[t] = goff_excl - s_start[t];
+  const int tile_n = (int)(r.hi - r.lo);
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (live[u]) { const unsigned q = s_start[dg[u]] + rank[u]; s_stage[q] = k[u]; s_bin[q] = (uint16_t)dg[u]; }
+  __syncthreads();
+  int64_t dst[kMsRows];
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++) {
+    const int q = u * kThreads + t;
+    dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
+    if (dst[u] >= 0) out_keys[dst[u]] = s_stage[q];
+  }
+  __syncthreads();
+  // second round: {row word, position in the virtual tile} as one 8-byte staged element
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (live[u]) s_stage[s_start[dg[u]] + rank[u]] = ((unsigned long long)(unsigned)(u * kThreads + t) << 32) | rw[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kMsRows; u++)
+    if (dst[u] >= 0) {
+      const unsigned long long x = s_stage[u * kThreads + t];
+      out_rows[dst[u]] = (unsigned)x;
+      out_j[dst[u]] = (unsigned short)(x >> 32);
+    }
+}
+
+// ids of a virtual tile's records (scattered over the parent's partitions) → back at their level-1 positions
+__global__ __launch_bounds__(kThreads) void e2_unpermute_kernel(const int* __restrict__ rec_id, const unsigned short* __restrict__ rec_j,
+                                                                 const unsigned* __restrict__ cnt, const unsigned* __restrict__ toffs, int64_t n,
+                                                                 const unsigned* __restrict__ pstart, int nparents, int nb, int* __restrict__ rec_id1) {
+  __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_goff[kThreads], s_wsum[kThreads / 64];
+  __shared__ unsigned s_a[kThreads], s_b[kThreads];
+  __shared__ int s_out[kMsTile];
+  __shared__ int s_pick;
+  const TileRange r = ms_tile(pstart, nparents, n, s_a, s_b, s_wsum, &s_pick);
+  if (r.parent < 0) return;
+  const int t = threadIdx.x;
+  unsigned excl = 0;
+  s_cnt[t] = 0;
+  if (t < nb) { s_cnt[t] = cnt[r.id * nb + t]; excl = toffs[r.id * nb + t]; }
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  if (t < nb) s_goff[t] = excl - s_start[t];
+  __syncthreads();
+  const int tile_n = (int)(r.hi - r.lo);
+  int lo[kMsRows], hi[kMsRows];
+#pragma unroll
+  for (int k = 0; k < kMsRows; k++) { lo[k] = 0; hi[k] = nb - 1; }
+#pragma unroll 1
+  for (int step = 0; step < 8; step++) {   // 2^7 ≥ nb
+#pragma unroll
+    for (int k = 0; k < kMsRows; k++) {
+      const int mid = (lo[k] + hi[k] + 1) >> 1;
+      const bool le = s_start[mid] <= (unsigned)(k * kThreads + t);
+      lo[k] = le ? mid : lo[k];
+      hi[k] = le ? hi[k] : mid - 1;
+    }
+  }
+  int id[kMsRows];
+  unsigned short j[kMsRows];
+#pragma unroll
+  for (int k = 0; k < kMsRows; k++) {
+    const int lp = k * kThreads + t;
+    id[k] = 0; j[k] = 0;
+    if (lp < tile_n) {
+      const int64_t e = (int64_t)s_goff[lo[k]] + lp;
+      id[k] = __builtin_nontemporal_load(&rec_id[e]);
+      j[k] = __builtin_nontemporal_load(&rec_j[e]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kMsRows; k++)
+    if (k * kThreads + t < tile_n) s_out[j[k]] = id[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kMsRows; k++) {
+    const int i = k * kThreads + t;
+    if (i < tile_n) __builtin_nontemporal_store(s_out[i], &rec_id1[r.lo + i]);
+  }
+}
+
 }  // namespace
 
 // Called by encode_core (ah_hash.hip) for 8-byte keys.  lp = log2 of the number of partitions (8 … 10).  *used = 1: out_* hold the
@@ -322,6 +469,109 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[30], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
   AH_HIP(c, hipStreamSynchronize(c->stream));
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition held more keys than its table admits: the global-table path redoes the call
+  if (out_ndict) *out_ndict = (int64_t) * (volatile uint64_t*)&c->pinned[9];
+  if (out_null_id) *out_null_id = *(volatile int32_t*)&c->pinned[10];
+  *used = 1;
+  return AH_OK;
+}
+
+
+// Two cuts: 64 parents × 2^(lp − 6) partitions (lp = 11 … 13), for ≈ 4.5 … 36 M expected keys.  Same contract as above.
+int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used) {
+  *used = 0;
+  if (n < ((int64_t)1 << 20) || n >= kMaxRows || lp < 7 || lp > 13) return AH_OK;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  constexpr int lb1 = 6, nb1 = 1 << lb1;
+  const int lb2 = lp - lb1, nb2 = 1 << lb2;
+  const int64_t P = (int64_t)1 << lp;
+  const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
+  const int64_t nslots = P * kEStride;
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const size_t need = pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) + pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) +
+                      pad((size_t)n * 8) * 2 + pad((size_t)n * 4) * 2 + pad((size_t)n * 2) * 2 + pad((size_t)nslots * 8) + pad((size_t)nslots * 4) +
+                      pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
+  uint8_t* base;
+  int rc = ah_temp_reserve(c, need, (void**)&base);
+  if (rc != AH_OK) return rc;
+  size_t used_b = 0;
+  auto take = [&](size_t b) { uint8_t* q = base + used_b; used_b += pad(b); return q; };
+  unsigned* cnt1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
+  unsigned* toffs1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
+  unsigned* gsum = (unsigned*)take((size_t)ngrp * nb1 * 4);
+  unsigned* pstart = (unsigned*)take((size_t)(nb1 + 1) * 4);
+  unsigned* cnt2 = (unsigned*)take((size_t)nvt * nb2 * 4);
+  unsigned* toffs2 = (unsigned*)take((size_t)nvt * nb2 * 4);
+  unsigned* bstart = (unsigned*)take(((size_t)P + 1) * 4);
+  unsigned long long* pkeys1 = (unsigned long long*)take((size_t)n * 8);
+  unsigned long long* pkeys2 = (unsigned long long*)take((size_t)n * 8);
+  unsigned* prows1 = (unsigned*)take((size_t)n * 4);
+  unsigned* prows2 = (unsigned*)take((size_t)n * 4);
+  unsigned short* pj2 = (unsigned short*)take((size_t)n * 2);
+  unsigned short* rec_slot = (unsigned short*)take((size_t)n * 2);
+  unsigned long long* tab_key = (unsigned long long*)take((size_t)nslots * 8);
+  unsigned* tab_first = (unsigned*)take((size_t)nslots * 4);
+  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
+  int* tilecnt = (int*)take((size_t)nrt * 4);
+  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
+  int* rec_id2 = (int*)pkeys2;   // level-2 keys are dead once every record knows its slot
+  int* rec_id1 = (int*)pkeys1;   // level-1 keys are dead after the level-2 scatter
+  unsigned* overflow = (unsigned*)&c->dscalars[30];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[31];
+  int* null_id = (int*)&c->dscalars[32];
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[30], 0, 2 * sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
+  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  const unsigned long long* k64 = (const unsigned long long*)keys;
+  // ---- level 1: 64 parents by the top 6 bits of the key hash
+  const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
+  gb_hist_kernel<<<tgrid, kGbHistThreads, 0, c->stream>>>(k64, valid, off, n, lb1, nb1, ntiles, cnt1);
+  AH_LAUNCH_CHECK(c);
+  colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt1, nb1, ntiles, gsum);
+  AH_LAUNCH_CHECK(c);
+  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, nb1, ngrp, n, pstart);
+  AH_LAUNCH_CHECK(c);
+  tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt1, gsum, nb1, ntiles, toffs1);
+  AH_LAUNCH_CHECK(c);
+  gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lb1, nb1, ntiles, toffs1, pkeys1, nullptr, prows1, nullptr);
+  AH_LAUNCH_CHECK(c);
+  // ---- level 2: every parent into 2^lb2 partitions
+  e2_hist_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, cnt2);
+  AH_LAUNCH_CHECK(c);
+  ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
+  AH_LAUNCH_CHECK(c);
+  {
+    std::vector<unsigned> bs((size_t)P + 1);
+    AH_HIP(c, hipMemcpyAsync(bs.data(), bstart, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned mx = 0;
+    for (int64_t p = 0; p < P; p++) mx = bs[p + 1] - bs[p] > mx ? bs[p + 1] - bs[p] : mx;
+    if ((int64_t)mx * P > 3 * n && mx > (1u << 16)) return AH_OK;   // a key that owns a large share of the rows: the other path
+  }
+  e2_scatter_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, toffs2, pkeys2, prows2, pj2);
+  AH_LAUNCH_CHECK(c);
+  // ---- tables, ranks, ids: as in the one-level path, one workgroup per final partition
+  enc_table_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  AH_LAUNCH_CHECK(c);
+  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  AH_LAUNCH_CHECK(c);
+  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
+  AH_LAUNCH_CHECK(c);
+  enc_assign_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff,
+                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id);
+  AH_LAUNCH_CHECK(c);
+  if (out_ids) {
+    enc_resolve_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2);
+    AH_LAUNCH_CHECK(c);
+    e2_unpermute_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec_id2, pj2, cnt2, toffs2, n, pstart, nb1, nb2, rec_id1);
+    AH_LAUNCH_CHECK(c);
+    enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id1, prows1, cnt1, toffs1, nb1, ntiles, n, out_ids);
+    AH_LAUNCH_CHECK(c);
+  }
+  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[30], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
+  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;
   if (out_ndict) *out_ndict = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_id) *out_null_id = *(volatile int32_t*)&c->pinned[10];
   *used = 1;

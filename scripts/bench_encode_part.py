@@ -18,7 +18,7 @@ def timed(fn, reps=3):
     return round(ctx.event_elapsed_ms(1, 2) / reps, 3)
 def run(tag):
     r = {}
-    for name, mode in (("global_table", 0), ("auto", 1), ("forced_256", 8), ("forced_512", 9), ("forced_1024", 10)):
+    for name, mode in (("global_table", 0), ("auto", 1), ("forced_256", 8), ("forced_1024", 10), ("forced_2048", 11), ("forced_4096", 12), ("forced_8192", 13)):
         ctx.set_option("encode_partition", mode)
         r[name + "_encode_ms"] = timed(lambda: ctx.hash_u64_encode(keys, None, 0, hrows, False, ids, None, dic))
         if mode in (0, 1):

@@ -17,9 +17,9 @@ REPS = 3
 N = ah._native
 rows = 1 << args.rows_log2
 hrows = min(rows, 1 << 26)
-WORKLOADS = ["add_int64", "sum_float64", "filter_sel0.01", "filter_sel0.50", "filter_sel0.90", "filter_sel0.50_masknulls_emit",
-             "take_random_nulls10", "take_random", "take_random_nulls10_direct", "take_identity_nulls10", "take_stride8_calib", "take_stride16_calib",
-             "cumulative_sum_int64", "dict_encode_2^10", "dict_encode_2^16", "dict_encode_2^20", "dict_encode_2^24", "dict_encode_2^20_zipf",
+WORKLOADS = ["add_int64", "sum_float64", "copy_kernel", "filter_sel0.01", "filter_sel0.50", "filter_sel0.90", "filter_sel0.50_masknulls_emit", "filter_sel0.50_count_and_fill",
+             "take_random_nulls10", "take_random", "take_random_nulls10_direct", "take_identity_nulls10", "take_identity", "take_reverse_nulls10", "take_stride8_calib", "take_stride16_calib",
+             "cumulative_sum_int64", "dict_encode_2^10", "dict_encode_2^16", "dict_encode_2^20", "dict_encode_2^22", "dict_encode_2^24", "dict_encode_2^20_zipf", "unique_2^20",
              "hash_sum_2^10", "hash_sum_2^16", "hash_sum_2^20", "hash_sum_2^24", "hash_sum_2^20_zipf", "sort_indices_int64_2^27"]
 if args.list:
     print("\n".join(WORKLOADS)); sys.exit(0)
@@ -67,15 +67,28 @@ def build(name):
     global sort_out
     if name == "add_int64": return lambda: ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, a, b, c, rows)
     if name == "sum_float64": return lambda: ctx.sum_float64_dev(x, rows, res)
+    if name == "copy_kernel":
+        return lambda: N.check(ctx.handle, N.lib.ah_copy_async(ctx.handle, c.ptr, a.ptr, rows * 8))
+    if name == "filter_sel0.50_count_and_fill":   # the two-phase call as a host makes it: count (tile prefixes stay in the context), then fill
+        fmask.upload(random_bits(rng, rows, 0.5))
+        def both():
+            k = ctx.filter_count(fmask, None, 0, rows, 0)
+            ctx.filter_primitive(8, a, vvalid, 0, fmask, None, 0, rows, 0, k, c, ovalid, want_null_count=False)
+        return both
     if name.startswith("filter_sel"):
         sel = float(name[10:14])
         return setup_filter(sel, fvalid if "masknulls" in name else None, 1 if name.endswith("emit") else 0)
     if name.startswith("take_random"): return setup_take(lambda: rng.integers(0, rows, rows, dtype=np.int32), "nulls" in name, 0 if name.endswith("direct") else 1)
     if name == "take_identity_nulls10": return setup_take(lambda: np.arange(rows, dtype=np.int32), True)
+    if name == "take_identity": return setup_take(lambda: np.arange(rows, dtype=np.int32), False)
+    if name == "take_reverse_nulls10": return setup_take(lambda: np.arange(rows - 1, -1, -1, dtype=np.int32), True)
     if name.startswith("take_stride"):  # calibration: every gather its own 64-byte (stride 8) / 128-byte (stride 16) piece of the column, direct kernel
         st = int(name[11:].split("_")[0])
         return setup_take(lambda: ((np.arange(rows, dtype=np.int64) * st) % rows).astype(np.int32), False, 0)
     if name == "cumulative_sum_int64": return lambda: ctx.cumulative_sum(N.INT64, a, None, 0, rows, None, False, False, c, None)
+    if name.startswith("unique"):
+        setup_keys(int(name.split("^")[1]), False)
+        return lambda: ctx.hash_u64_encode(keys, None, 0, hrows, False, None, None, hdic)
     if name.startswith("dict_encode") or name.startswith("hash_sum"):
         lg = int(name.split("^")[1].split("_")[0])
         setup_keys(lg, name.endswith("zipf"))

@@ -217,3 +217,72 @@ def test_sort_indices_2_27(hip, kind):
     key = a[rest]
     order = rest[np.argsort(-key if kind == "float64" else ~key, kind="stable")].astype(np.uint64)
     same(g, np.concatenate([nulls, order]), f"sort_indices {kind} descending, nulls first")
+
+
+@pytest.mark.parametrize("pct", [10, 50, 90])
+def test_c4_fused_2_27_vs_oracle(hip, orc_be, column, pct):
+    """Config C4 per GPU — Compare(>) → Filter(DropNulls) → Sum over a 2^27-row shard with 10 % nulls — against orc_fused.c (the
+    unfused reference chain collapsed per element), thresholds at the 10th / 50th / 90th percentile: Int64 sum and
+    count bit-exact; Float64 count exact and the sum within 1 ULP of the exact sum of the survivors (the Sum rule of DESIGN §4)."""
+    a, av = column
+    thr = int(np.percentile(a[:1 << 20], pct))
+    g, e = hip.cmp_filter_sum_i64(2, a, av, 0, thr), orc_be.cmp_filter_sum_i64(2, a, av, 0, thr)
+    assert g == e, (pct, g, e)
+    g, e = hip.cmp_filter_sum_i64(2, a[:N27 - 11], av, 11, thr), orc_be.cmp_filter_sum_i64(2, a[:N27 - 11], av, 11, thr)   # validity at a bit offset
+    assert g == e, (pct, g, e)
+    rng = np.random.default_rng(300 + pct)
+    x = rng.standard_normal(N27) * 1e3
+    tf = float(np.percentile(x[:1 << 20], pct))
+    gs, gc = hip.cmp_filter_sum_f64(2, x, av, 0, tf)
+    es, ec = orc_be.cmp_filter_sum_f64(2, x, av, 0, tf)     # (exact sum of the survivors, count)
+    assert gc == ec
+    assert abs(gs - es) <= np.spacing(abs(es)), (pct, gs, es)
+    gs2, gc2 = hip.cmp_filter_sum_f64(2, x, av, 0, tf)
+    assert gs2 == gs and gc2 == gc                            # the double-double tree does not depend on timing
+
+
+@pytest.mark.parametrize("lg", [10, 16, 20])
+def test_c5_hash_sum_f64_general_doubles_2_26(hip, orc_be, lg):
+    """hash + sum of 2^26 rows with GENERAL doubles (round-2 review: only integer-valued addends had been checked at this size).
+    The column spans < 42 binades, so the 128-bit fixed point holds every addend whole: each group's sum must be the correctly
+    rounded exact sum (math.fsum) — checked on the groups of 4096 sampled keys — and two runs must give the same bytes."""
+    import math
+    rng = np.random.default_rng(500 + lg)
+    pool = rng.integers(-2**63, 2**63 - 1, 1 << lg, dtype=np.int64)
+    keys = pool[rng.integers(0, 1 << lg, N26)]
+    vals = (1.0 + rng.random(N26)) * np.exp(rng.uniform(-10, 10, N26)) * rng.choice([-1.0, 1.0], N26)
+    vvalid = bits(rng, N26, 0.9)
+    g = hip.hash_sum("f64", keys, None, 0, vals, vvalid, 0)
+    g2 = hip.hash_sum("f64", keys, None, 0, vals, vvalid, 0)
+    same(g[1].view(np.uint64), g2[1].view(np.uint64), "hash_sum f64 run to run")
+    ok = np.unpackbits(vvalid, bitorder="little")[:N26].astype(bool)
+    first = {int(k): i for i, k in enumerate(g[0].view(np.int64))}
+    assert len(first) == g[0].size
+    sample = pool[rng.integers(0, 1 << lg, 4096 if lg > 10 else 64)]
+    # one pass: rows of the sampled keys only
+    want = np.isin(keys, sample)
+    ks, vs = keys[want & ok], vals[want & ok]
+    order = np.argsort(ks, kind="stable")
+    ks, vs = ks[order], vs[order]
+    bounds = np.flatnonzero(np.diff(ks)) + 1
+    for lo, hi in zip(np.concatenate([[0], bounds]), np.concatenate([bounds, [ks.size]])):
+        exact = math.fsum(vs[lo:hi].tolist())             # correctly rounded exact sum
+        got = float(g[1][first[int(ks[lo])]])
+        assert got == exact, (lg, int(ks[lo]), got, exact, hi - lo)
+        assert int(g[2][first[int(ks[lo])]]) == hi - lo
+
+
+def test_c3_take_2_27_clustered_vec_path(hip, orc_be, column):
+    """the 16 / W rows-per-lane Take (ah_take.hip take_vec_kernel) at the size of config C3, chosen by the neighbour sample:
+    identity, reversed and a shifted slice with 10 % nulls on both sides, byte for byte"""
+    a, av = column
+    rng = np.random.default_rng(61)
+    iv = bits(rng, N27, 0.9)
+    for name, idx in (("identity", np.arange(N27, dtype=np.int32)), ("reverse", np.arange(N27 - 1, -1, -1, dtype=np.int32)),
+                      ("slice", np.minimum(np.arange(N27, dtype=np.int64) + 777, N27 - 1).astype(np.int32))):
+        g = hip.take(a, av, 0, idx, iv, 0, True, True)
+        e = orc_be.take(a, av, 0, idx, iv, 0, True, True)
+        assert g[0] == e[0] == STATUS_OK
+        same(g[1], e[1], f"take {name} values")
+        same(g[2], e[2], f"take {name} validity")
+        assert g[3] == e[3]

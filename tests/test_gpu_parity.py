@@ -715,7 +715,7 @@ def _exact_group_sums(keys, fv, ok, limit):
     return out
 
 
-@pytest.mark.parametrize("lp", [3, 8, 10])
+@pytest.mark.parametrize("lp", [3, 8, 10, 11, 13])   # 11, 13: two cuts (64 parents × 32 / 128), for inputs of ≥ 2^20 rows
 def test_hash_encode_partitioned(hip, orc_be, ctx, lp):
     """ah_hash_part.hip (rows cut by key hash, one LDS table per partition, ids sent back to row order), forced on at sizes the
     oracle does in a second: ids, index validity, dictionary and null id byte-equal to the sequential memo table — nulls encoded
