@@ -66,7 +66,7 @@ struct ah_ctx {
   ah_filter_cache fcache;  // ah_filter.hip
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;
-  // two words of coherent (fine-grained) pinned host memory a kernel can store to: {value, sequence number}.  A count the host
+  // 2 × 8 words of coherent (fine-grained) pinned host memory kernels can store to: {value, sequence number} for ah_filter_count, {≤ 7 words, sequence number} for ah_mailbox_read.  A count the host
   // must see before it can go on (ah_filter_count) is polled here instead of paying a stream synchronisation's wake-up.
   unsigned long long* mailbox;
   unsigned long long mailbox_seq;
@@ -165,6 +165,10 @@ int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* 
 // … and by two cuts, 64 parents × 2^(lp − 6) partitions (lp = 11 … 13)
 int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
                                int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
+// internal (ah_ctx.hip): 1..7 device words (8 bytes each, written by work already on the compute stream) → host, through the polled
+// mailbox — a cheaper "I need this number before I go on" than a copy + stream synchronisation.  Everything enqueued before it has
+// completed when it returns, like a synchronisation of the stream up to that point.
+int ah_mailbox_read(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, unsigned long long* out_host);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are

@@ -4,6 +4,7 @@
 // are memory.Allocator (arrow/memory/allocator.go:23-27, 64-byte alignment :20) and
 // memory.Set (arrow/memory/_lib/memory.c:20-27).  A Go `memory.Allocator` backed by
 // ah_host_alloc_pinned gives Arrow buffers that hipMemcpyAsync can DMA directly.
+#include <chrono>
 #include "ah_common.h"
 
 static const char* kVersion = "arrowhip 0.1 (gfx950)";
@@ -25,8 +26,8 @@ static int ctx_init_common(ah_ctx* c) {
   AH_HIP(c, hipEventCreate(&c->t1));
   AH_HIP(c, hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
   AH_HIP(c, hipMalloc((void**)&c->dscalars, (64 + 4096) * sizeof(uint64_t)));
-  AH_HIP(c, hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocCoherent | hipHostMallocMapped));
-  memset(c->mailbox, 0, 64);
+  AH_HIP(c, hipHostMalloc((void**)&c->mailbox, 128, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(c->mailbox, 0, 128);
   hipDeviceProp_t prop;
   AH_HIP(c, hipGetDeviceProperties(&prop, c->device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -125,6 +126,35 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
 }
 
 AH_EXPORT const char* ah_last_error(ah_ctx* c) { return c ? c->err : "null context"; }
+
+// ---- a few device words the host must see before it can go on: posted to coherent pinned memory by a one-thread kernel and polled,
+// instead of hipMemcpyAsync + hipStreamSynchronize (whose wake-up costs ≈ 15 µs: more than many of the passes it sits between)
+namespace {
+__global__ void mailbox_post_kernel(const unsigned long long* __restrict__ src, int nwords, unsigned long long* mailbox, unsigned long long seq) {
+  for (int i = 0; i < nwords; i++) __hip_atomic_store(&mailbox[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&mailbox[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+int ah_mailbox_read(ah_ctx* c, const unsigned long long* dev_words, int nwords, unsigned long long* out_host) {
+  if (nwords < 1 || nwords > 7) return ah_fail(c, AH_EINVALID, "mailbox_read: 1..7 words");
+  unsigned long long* mb = c->mailbox + 8;   // the second half: the first belongs to ah_filter_count
+  const unsigned long long seq = ++c->mailbox_seq;
+  mailbox_post_kernel<<<1, 1, 0, c->stream>>>(dev_words, nwords, mb, seq);
+  AH_LAUNCH_CHECK(c);
+  bool seen = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; spin++) {
+    if (__atomic_load_n(&mb[7], __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+    __builtin_ia32_pause();
+    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+  }
+  if (!seen) {   // a long queue in front of the post, or a fault: the synchronisation tells which
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(&mb[7], __ATOMIC_ACQUIRE) != seq) return ah_fail(c, AH_EHIP, "mailbox_read: the post kernel did not report");
+  }
+  for (int i = 0; i < nwords; i++) out_host[i] = __atomic_load_n(&mb[i], __ATOMIC_RELAXED);
+  return AH_OK;
+}
 
 int ah_scratch_reserve(ah_ctx* c, size_t nbytes, void** out) {
   if (nbytes > c->scratch_bytes) {

@@ -772,6 +772,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
     // staged: with every prefix row in flight at once against an empty table, a low-cardinality column turns
     // into millions of CAS / atomicMin on a few addresses (200 µs for 1024 keys).  A few thousand rows first,
     // then the rest mostly finds settled slots and issues no atomics at all.
+    bool part_undecided = false;
     {
       int64_t lo = 0;
       for (int64_t hi : {(int64_t)1 << 12, (int64_t)1 << 16, prefix}) {
@@ -788,9 +789,13 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
           // partition of 256 … 1024).  2^16 rows show 2^19 evenly drawn keys with ≈ 3900 repeats (± 62): the urn model's estimate
           // is good to a few per cent up to 2^22 keys; a column whose head misleads (sorted keys) is caught by the partition
           // pass itself (a table that overflows voids the attempt) or simply stays on this path.
-          AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[4], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-          AH_HIP(c, hipStreamSynchronize(c->stream));
-          const double est = estimate_distinct((double)*(volatile uint64_t*)&c->pinned[0], (double)hi, (double)n);
+          unsigned long long look[2];   // {distinct so far, overflow flag}: polled, not synchronised — this look is on every large call's path
+          if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[4], 2, look)) != AH_OK) return rc;
+          c->pinned[0] = look[0]; c->pinned[1] = look[1];
+          const double d16 = (double)*(volatile uint64_t*)&c->pinned[0];
+          const double est = estimate_distinct(d16, (double)hi, (double)n);
+          // (almost) every one of the 2^16 rows was new: ≥ 2^25 keys or so, too few repeats to say how many — the prefix below will tell
+          part_undecided = *(volatile unsigned*)&c->pinned[1] == 0 && d16 >= 0.999 * (double)hi;
           if (*(volatile unsigned*)&c->pinned[1] == 0 && est >= (double)c->opt_encode_part_min && est <= 8192.0 * 4400.0) {
             int lp = 8;   // 256 … 1024 partitions in one cut, 2048 … 8192 in two (ah_encode_partitioned2_try)
             while (lp < 13 && est / (double)(1 << lp) > 4400.0) lp++;
@@ -808,6 +813,14 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
       AH_HIP(c, hipStreamSynchronize(c->stream));
       d0 = *(volatile uint64_t*)&c->pinned[0];
       bool ovf = *(volatile unsigned*)&c->pinned[1] != 0;
+      if (part_undecided && !ovf) {   // 2^21 rows hold enough repeats to tell 2^25 keys from 2^26: up to ≈ 36 M expected keys take the two-cut path
+        const double est = estimate_distinct((double)d0, (double)prefix, (double)n);
+        if (est <= 8192.0 * 4400.0) {
+          bool done;
+          int prc = try_partitioned(13, &done);
+          if (prc != AH_OK || done) return prc;
+        }
+      }
       if (ovf || d0 > cap / 4) {
         // extrapolate with the urn model (keys drawn uniformly from C values show d0 = C·(1 − e^(−p/C))
         // distinct ones in a prefix of p rows): solve for C, predict the distinct count of all n rows,

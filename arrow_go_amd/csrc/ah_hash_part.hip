@@ -268,6 +268,45 @@ __global__ __launch_bounds__(kThreads) void e2_hist_kernel(const unsigned long l
   for (int b = threadIdx.x; b < nb; b += kThreads) cnt[r.id * nb + b] = s_h[b];
 }
 
+// level-2 offsets for FEW digits (nb ≤ 128): ms_offs2_kernel (ah_msd.h) gives every digit one thread that walks all of the parent's
+// virtual tiles — right for the sort's 2048 digits, but here 64 of 1024 threads would walk ≈ 260 tiles twice, one dependent load
+// after the other (343 µs at 2^26 rows).  Here thread (slice s, digit d) takes a contiguous slice of the parent's tiles,
+// S = 1024 / nb slices per digit; slice totals meet in LDS, one scan, then every thread walks its own slice once more.
+__global__ __launch_bounds__(kThreads) void e2_offs2_kernel(const unsigned* __restrict__ cnt, const unsigned* __restrict__ pstart, int nparents, int nb,
+                                                             unsigned* __restrict__ toffs, unsigned* __restrict__ bstart, int64_t n) {
+  __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_wsum[kThreads / 64];
+  __shared__ unsigned s_part[kThreads];   // [slice][digit] totals
+  const int t = threadIdx.x, p = blockIdx.x;
+  unsigned tiles = 0;
+  if (t < nparents) { const int q = ms_parent_of(t, nparents); tiles = (pstart[q + 1] - pstart[q] + kMsTile - 1) / kMsTile; }
+  s_cnt[t] = tiles;
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nparents);
+  const int j = (p & 7) * (nparents >> 3) + (p >> 3);   // this parent's place in the class-major tile numbering (ms_tile)
+  const int64_t vt0 = s_start[j], nvt = s_cnt[j];
+  __syncthreads();
+  const int S = kThreads / nb, d = t % nb, sl = t / nb;
+  const int64_t per = (nvt + S - 1) / S, a = vt0 + sl * per, b = a + per < vt0 + nvt ? a + per : vt0 + nvt;
+  unsigned tot = 0;
+  for (int64_t vt = a; vt < b; vt++) tot += cnt[vt * nb + d];
+  s_part[sl * nb + d] = sl < S ? tot : 0u;
+  __syncthreads();
+  // digit totals → exclusive scan over the digits
+  unsigned dtot = 0;
+  if (t < nb) for (int q = 0; q < S; q++) dtot += s_part[q * nb + t];
+  s_cnt[t] = t < nb ? dtot : 0u;
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  const unsigned base = pstart[p];
+  if (t < nb) bstart[(int64_t)p * nb + t] = base + s_start[t];
+  // this thread's running offset = parent start + smaller digits + this digit in earlier slices
+  unsigned run = base + s_start[d];
+  for (int q = 0; q < sl; q++) run += s_part[q * nb + d];
+  if (sl < S)
+    for (int64_t vt = a; vt < b; vt++) { toffs[vt * nb + d] = run; run += cnt[vt * nb + d]; }
+  if (p == nparents - 1 && t == 0) bstart[(int64_t)nparents * nb] = (unsigned)n;
+}
+
 __global__ __launch_bounds__(kThreads) void e2_scatter_kernel(const unsigned long long* __restrict__ pkeys, const unsigned* __restrict__ prows, int64_t n,
                                                                const unsigned* __restrict__ pstart, int nparents, int lp, unsigned mask, int nb,
                                                                const unsigned* __restrict__ toffs, unsigned long long* __restrict__ out_keys,
@@ -539,7 +578,7 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   // ---- level 2: every parent into 2^lb2 partitions
   e2_hist_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, cnt2);
   AH_LAUNCH_CHECK(c);
-  ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
+  e2_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
   AH_LAUNCH_CHECK(c);
   {
     std::vector<unsigned> bs((size_t)P + 1);

@@ -370,7 +370,10 @@ Status StreamReader::LoadColumns(const uint8_t* meta, int64_t mlen, int64_t rb, 
       if (ulen < 0 || (!stored && ulen / 131072 > len + 1024)) return Invalid("compressed buffer announces " + std::to_string(ulen) + " bytes from " + std::to_string(len));
       pieces.push_back({off + 8, len - 8, total, ulen, stored});
       total += (ulen + 63) & ~(int64_t)63;
-      if (total > ((int64_t)1 << 40)) return Invalid("decompressed body beyond 1 TiB");
+      // the sum is bounded as well — an ≈ 8 MB message of maximal ratios could otherwise ask for hundreds of GiB, which an
+      // overcommitting host grants and then kills the process for: ARROWHIP_IPC_MAX_INFLATED_BYTES (default 16 GiB per message)
+      static const int64_t kMaxInflated = [] { const char* e = getenv("ARROWHIP_IPC_MAX_INFLATED_BYTES"); const long long v = e ? atoll(e) : 0; return v > 0 ? (int64_t)v : ((int64_t)16 << 30); }();
+      if (total > kMaxInflated) return Invalid("decompressed body beyond " + std::to_string(kMaxInflated) + " bytes (ARROWHIP_IPC_MAX_INFLATED_BYTES)");
     }
     try { plain.resize((size_t)total); } catch (const std::bad_alloc&) { return Invalid("cannot hold a decompressed body of " + std::to_string(total) + " bytes"); }
     for (const Piece& p : pieces) {

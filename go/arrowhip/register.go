@@ -62,10 +62,21 @@ func (d *dev) validPtr() unsafe.Pointer {
 	return d.valid.Ptr
 }
 
+// PinUploads: buffers that did NOT come from a PinnedAllocator are pinned (hipHostRegister) for the duration of their upload, so
+// the copy is a DMA from the Arrow buffer itself instead of the runtime's staged copy.  Arrays built with
+// memory.Allocator = &PinnedAllocator{Ctx: x} need nothing: their buffers are pinned from birth.  Columns too large to wait for
+// go through Ingest (ingest.go): chunk k + 1 uploads while chunk k computes.
+var PinUploads = false
+
 func (x *Context) upload(b []byte) (*DeviceBuffer, error) {
 	d, err := x.Alloc(len(b) + 64)
 	if err != nil {
 		return nil, err
+	}
+	if PinUploads && len(b) >= 1<<20 {
+		if perr := x.Pin(b); perr == nil {
+			defer x.Unpin(b)
+		}
 	}
 	if err := d.Upload(b); err != nil {
 		d.Free()
