@@ -153,6 +153,7 @@ _SIGS = {
     "ah_take_boolean": [_vp, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _i64, _i64, _int, _vp, _vp, _pi64, _pi64],
     "ah_hash_u64_encode": [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _pi64, _pi32],
     "ah_hash_binary_encode": [_vp, _int, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _pi64, _pi32],
+    "ah_hash_fixed_encode": [_vp, _int, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _pi64, _pi32],
     "ah_hash_sum_f64": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _pi64, _pi32],
     "ah_hash_sum_i64": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _pi64, _pi32],
     "ah_cmp_filter_sum_i64": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _pi64, _pi64],

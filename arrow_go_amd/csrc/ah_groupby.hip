@@ -976,7 +976,7 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
   const unsigned long long* k64 = (const unsigned long long*)keys;
   const unsigned long long* v64 = (const unsigned long long*)vals;
   if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
-    absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 8), kBlock, 0, c->stream>>>(v64, vvalid, voff, n, absmax);
+    absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 2), kBlock, 0, c->stream>>>(v64, vvalid, voff, n, absmax);
     AH_LAUNCH_CHECK(c);
     fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);

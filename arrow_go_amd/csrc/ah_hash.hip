@@ -114,6 +114,35 @@ struct BinKeys {
   }
 };
 
+// FixedSizeBinary / Decimal128 / Decimal256 keys (kernels/vector_hash.go:608-609, 698: the same BinaryMemoTable, every value
+// `w` bytes): the BinKeys scheme with the offsets implied — value i lives at data + i·w.
+struct FixKeys {
+  const uint8_t* data;  // of row 0 of the call
+  int w;
+  static constexpr bool kLdsTable = false;
+  __device__ __forceinline__ bool load(int64_t i, unsigned long long* word, uint64_t* h) const {
+    *h = hash_bytes(data + i * w, w);
+    *word = (*h & 0xFFFFFFFF00000000ull) | (unsigned long long)(unsigned)i;
+    return true;
+  }
+  __device__ __forceinline__ bool same(unsigned long long cur, unsigned long long word, int64_t i) const {
+    if ((cur ^ word) >> 32) return false;
+    const int64_t r = (int64_t)(unsigned)cur;
+    return r == i || equal_bytes(data + i * w, data + r * w, w);
+  }
+};
+
+// dictionary of fixed-width keys: entry id = the value at its first row (the null entry: zeros, like a fresh builder slot)
+__global__ __launch_bounds__(kBlock) void fixed_dict_kernel(const uint8_t* __restrict__ data, int w, const long long* __restrict__ first_rows, int64_t ndict,
+                                                             int null_id, uint8_t* __restrict__ dict) {
+  const int64_t total = ndict * w;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < total; b += stride) {
+    const int64_t id = b / w;
+    dict[b] = id == null_id ? (uint8_t)0 : data[first_rows[id] * w + (b - id * w)];
+  }
+}
+
 // status words in dscalars: [4] distinct count, [5] overflow flag, [6] total ids
 // Inserts rows [lo, hi).  Probe chains longer than kProbeLimit mean the table is far beyond
 // the load it was sized for (at load ≤ ½ the chance of a 256-long linear-probing cluster is
@@ -992,7 +1021,7 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
     fx = FxAcc{(unsigned long long*)fxbase, (unsigned long long*)(fxbase + fxw), (unsigned*)(fxbase + 2 * fxw),
                (const unsigned long long*)(fxbase + 2 * fxw + fxf), nullptr};
     AH_HIP(c, hipMemsetAsync((void*)fx.absmax, 0, 16, c->stream));
-    absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 8), kBlock, 0, c->stream>>>((const unsigned long long*)vals, vvalid, voff, n,
+    absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 2), kBlock, 0, c->stream>>>((const unsigned long long*)vals, vvalid, voff, n,
                                                                                                         (unsigned long long*)fx.absmax);
     AH_LAUNCH_CHECK(c);
   }
@@ -1093,6 +1122,31 @@ AH_EXPORT int ah_hash_binary_encode(ah_ctx* c, int offset_width, const void* off
                ? encode_core(c, BinKeys<int32_t>{(const int32_t*)offsets + off, data}, valid, off, n, encode_nulls, out_ids, nullptr, &res, out_first_rows)
                : encode_core(c, BinKeys<int64_t>{(const int64_t*)offsets + off, data}, valid, off, n, encode_nulls, out_ids, nullptr, &res, out_first_rows);
   if (rc != AH_OK) return rc;
+  if (out_ids_valid && (rc = ids_validity(c, valid, off, n, encode_nulls, out_ids_valid)) != AH_OK) return rc;
+  if (out_ndict_host) *out_ndict_host = res.ndict;
+  if (out_null_id_host) *out_null_id_host = res.null_id;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_hash_fixed_encode(ah_ctx* c, int byte_width, const uint8_t* data, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
+                                   int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows, uint8_t* out_dict, int64_t* out_ndict_host,
+                                   int32_t* out_null_id_host) {
+  AH_ENTER(c);
+  if (n < 0 || off < 0) return ah_fail(c, AH_EINVALID, "hash: negative length/offset");
+  if (byte_width < 1 || byte_width > 4096) return ah_fail(c, AH_EINVALID, "hash: fixed width must be 1..4096 bytes");
+  if (out_ndict_host) *out_ndict_host = 0;
+  if (out_null_id_host) *out_null_id_host = -1;
+  if (n == 0) return AH_OK;
+  if (!data || !out_first_rows) return ah_fail(c, AH_EINVALID, "hash: null buffer");
+  EncodeResult res;
+  int rc = encode_core(c, FixKeys{data + off * (int64_t)byte_width, byte_width}, valid, off, n, encode_nulls, out_ids, nullptr, &res, out_first_rows);
+  if (rc != AH_OK) return rc;
+  if (out_dict && res.ndict > 0) {
+    fixed_dict_kernel<<<ah_stream_grid(c, ah_ceil_div(res.ndict * byte_width, kBlock), 8), kBlock, 0, c->stream>>>(data + off * (int64_t)byte_width, byte_width,
+                                                                                                                    (const long long*)out_first_rows, res.ndict, res.null_id, out_dict);
+    AH_LAUNCH_CHECK(c);
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+  }
   if (out_ids_valid && (rc = ids_validity(c, valid, off, n, encode_nulls, out_ids_valid)) != AH_OK) return rc;
   if (out_ndict_host) *out_ndict_host = res.ndict;
   if (out_null_id_host) *out_null_id_host = res.null_id;

@@ -527,6 +527,13 @@ class Context:
                                                      C.byref(nd), C.byref(nid)))
         return nd.value, nid.value
 
+    def hash_fixed_encode(self, byte_width: int, data, valid, off: int, n: int, encode_nulls: bool, out_ids, out_ids_valid, out_first_rows, out_dict):
+        nd = C.c_int64()
+        nid = C.c_int32()
+        check(self.handle, lib.ah_hash_fixed_encode(self.handle, byte_width, _ptr(data), _ptr(valid), off, n, int(encode_nulls), _ptr(out_ids),
+                                                    _ptr(out_ids_valid), _ptr(out_first_rows), _ptr(out_dict), C.byref(nd), C.byref(nid)))
+        return nd.value, nid.value
+
     def hash_sum(self, kind: str, keys, kvalid, koff: int, vals, vvalid, voff: int, n: int, out_keys, out_sums, out_counts,
                  out_first_rows=None):
         ng = C.c_int64()

@@ -30,7 +30,10 @@ import (
 // Every C entry point selects the device itself, so a Context may be used from whatever OS
 // thread the executor goroutine lands on (arrow/compute/exec.go:165); it serves one call at a
 // time — pool Contexts for concurrency, like scalarExecPool does (executor.go:867-873).
-type Context struct{ c *C.ah_ctx }
+type Context struct {
+	c   *C.ah_ctx
+	ing *Ingest // lazily created by register.go's ExecFns for host-resident operands (ingest.go)
+}
 
 func NewContext(device int) (*Context, error) {
 	var c *C.ah_ctx
@@ -43,6 +46,10 @@ func NewContext(device int) (*Context, error) {
 }
 
 func (x *Context) Close() {
+	if x.ing != nil {
+		x.ing.Close()
+		x.ing = nil
+	}
 	if x.c != nil {
 		C.ah_ctx_destroy(x.c)
 		x.c = nil

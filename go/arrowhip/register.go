@@ -68,6 +68,21 @@ func (d *dev) validPtr() unsafe.Pointer {
 // go through Ingest (ingest.go): chunk k + 1 uploads while chunk k computes.
 var PinUploads = false
 
+// IngestThresholdBytes: operands at least this large go through the chunked, overlapped ingest instead of one whole upload.
+var IngestThresholdBytes = 64 << 20
+
+// ingest returns the context's pipeline (32 MiB chunks, 3 slots), created on first use.
+func (x *Context) ingest() (*Ingest, error) {
+	if x.ing == nil {
+		g, err := x.NewIngest(0, 0)
+		if err != nil {
+			return nil, err
+		}
+		x.ing = g
+	}
+	return x.ing, nil
+}
+
 func (x *Context) upload(b []byte) (*DeviceBuffer, error) {
 	d, err := x.Alloc(len(b) + 64)
 	if err != nil {
@@ -116,6 +131,26 @@ func binaryExec(x *Context, typ arrow.Type, w int, op int8) exec.ArrayKernelExec
 		}
 		defer do.Free()
 		l, r := &batch.Values[0], &batch.Values[1]
+		// A large span of two arrays never sits in HBM whole: the chunked ingest (ingest.go → ah_ingest_arithmetic_binary) uploads
+		// chunk k + 1 while chunk k computes and chunk k − 1 downloads — 0.95 of the PCIe link instead of 0.66 for
+		// upload-all / compute / download-all (INTEGRATION.md §2a).  Buffers from a PinnedAllocator overlap as they are; others are
+		// pinned for the call when PinUploads is set.
+		if l.IsArray() && r.IsArray() && int(n)*w >= IngestThresholdBytes {
+			ing, err := x.ingest()
+			if err != nil {
+				return err
+			}
+			lb := l.Array.Buffers[1].Buf[int(l.Array.Offset)*w : (int(l.Array.Offset)+int(n))*w]
+			rb := r.Array.Buffers[1].Buf[int(r.Array.Offset)*w : (int(r.Array.Offset)+int(n))*w]
+			if PinUploads {
+				for _, b := range [][]byte{lb, rb, ob} {
+					if perr := x.Pin(b); perr == nil {
+						defer x.Unpin(b)
+					}
+				}
+			}
+			return ing.ArithmeticBinary(typ, op, lb, rb, ob, n)
+		}
 		var kerr error
 		switch {
 		case l.IsArray() && r.IsArray():

@@ -307,7 +307,13 @@ int ah_kleene(ah_ctx* ctx, int op, const uint8_t* lvalid, const uint8_t* ldata, 
  * (:267-395).  n_out is the value ah_filter_count returned (the library zero-fills
  * the ceil(n_out/8) bytes of out_valid itself and cross-checks n_out when it
  * synchronises; pass -1 only when out_valid is NULL).  Payload rules in DESIGN.md.
- * byte_width ∈ {1,2,4,8}.  out_null_count_host may be NULL (then no sync). */
+ * byte_width ∈ {1,2,4,8}.  out_null_count_host may be NULL (then no sync).
+ * The count call leaves the per-tile survivor prefixes of ITS mask in the context, and an ah_filter_primitive with the same
+ * (fdata, fvalid, foff, n, null_sel) uses them instead of counting again — as long as nothing that can change device memory was
+ * called on this context in between: allocation, synchronisation, timers, and a memset / upload / copy whose destination
+ * does not overlap the mask's bytes keep them; every other entry point drops them.  Writing the mask from OUTSIDE this
+ * context between the two calls (another context, another library on another stream) breaks the two-phase contract itself —
+ * n_out would no longer be the mask's count either. */
 int ah_filter_count(ah_ctx* ctx, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,
                     int null_sel, int64_t* n_out_host);
 int ah_filter_primitive(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
@@ -376,6 +382,13 @@ int ah_hash_u64_encode(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, 
 int ah_hash_binary_encode(ah_ctx* ctx, int offset_width, const void* offsets, const uint8_t* data, const uint8_t* valid, int64_t off,
                           int64_t n, int encode_nulls, int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows,
                           int64_t* out_ndict_host, int32_t* out_null_id_host);
+/* FixedSizeBinary / Decimal128 / Decimal256 keys of unique / dictionary_encode (kernels/vector_hash.go:608-609, 698: the same
+ * BinaryMemoTable, every value byte_width bytes; row i of the call = data + (off + i)·byte_width, validity bit off + i).  ids, index
+ * validity, first rows, null id as ah_hash_binary_encode; out_dict (nullable, ndict·byte_width bytes) receives the dictionary —
+ * the value at each entry's first row, zeros for the null entry.  Synchronises. */
+int ah_hash_fixed_encode(ah_ctx* ctx, int byte_width, const uint8_t* data, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls,
+                         int32_t* out_ids, uint8_t* out_ids_valid, int64_t* out_first_rows, uint8_t* out_dict, int64_t* out_ndict_host,
+                         int32_t* out_null_id_host);
 /* group-by sum (NEW — arrow-go has no hash aggregate; definition in DESIGN.md): groups
  * = dictionary_encode(keys, encode_nulls=1) ids; out_sums[g] = Σ valid vals of group
  * g, out_counts[g] = number of valid vals.  i64 sums wrap and are exact; f64 sums are

@@ -114,6 +114,18 @@ class OracleBackend:
     def hash_binary_encode(self, offsets, data, valid, off, n, encode_nulls):
         return self.o.hash_binary_encode(offsets, data, valid, off, n, encode_nulls)
 
+    def hash_fixed_encode(self, data, w, valid, off, n, encode_nulls):
+        """fixed-width keys = binary keys whose offsets are implied (i·w): the oracle's binary memo table over explicit offsets"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = (np.arange(data.size // w + 1, dtype=np.int64) * w)
+        ids, idv, first, nid = self.o.hash_binary_encode(offsets, data, valid, off, n, encode_nulls)
+        base = data[off * w:].reshape(-1, w)
+        dic = np.zeros((first.size, w), np.uint8)
+        for i, r in enumerate(first):
+            if i != nid:
+                dic[i] = base[r]
+        return ids, idv, first, nid, dic.reshape(-1)
+
     def hash_sum(self, kind, keys, kvalid, koff, vals, vvalid, voff):
         return self.o.hash_sum(kind, keys, kvalid, koff, vals, vvalid, voff)
 
@@ -495,6 +507,13 @@ class HipBackend:
         idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); frb = self.c.alloc((n + 1) * 8 + 64)
         nd, nid = self.c.hash_binary_encode(offsets.dtype.itemsize, ofp, dp, vp, off, n, encode_nulls, idb, idvb, frb)
         return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), frb.download(np.int64, nd), nid
+
+    def hash_fixed_encode(self, data, w, valid, off, n, encode_nulls):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        db, dp = self._up(data); vb, vp = self._upbits(valid)
+        idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); frb = self.c.alloc((n + 1) * 8 + 64); dcb = self.c.alloc((n + 1) * w + 64)
+        nd, nid = self.c.hash_fixed_encode(w, dp, vp, off, n, encode_nulls, idb, idvb, frb, dcb)
+        return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), frb.download(np.int64, nd), nid, dcb.download(np.uint8, nd * w)
 
     def hash_sum(self, kind, keys, kvalid, koff, vals, vvalid, voff):
         keys = np.ascontiguousarray(keys).view(np.uint64); vals = np.ascontiguousarray(vals)

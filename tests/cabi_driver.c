@@ -199,8 +199,55 @@ typedef struct { int device; ah_ctx* ctx; } create_st;
 static void step_create(void* p) { create_st* s = (create_st*)p; CHECK((ah_ctx*)NULL, ah_ctx_create(s->device, &s->ctx)); }
 static void step_destroy(void* p) { ah_ctx_destroy((ah_ctx*)p); }
 
+/* ---- `<exe> bench <log2 rows>`: the two-phase Filter call (count, then fill) timed from C — what a compiled host pays between the
+ * two dependent launches, without an interpreter in the loop (bench.py drives the same two calls through Python's ctypes) */
+static int bench_filter(int lg) {
+  const int64_t n = (int64_t)1 << lg;
+  ah_ctx* ctx;
+  CHECK((ah_ctx*)NULL, ah_ctx_create(0, &ctx));
+  uint64_t seed = 12345;
+  int64_t* a = (int64_t*)go_allocate((size_t)n * 8);
+  uint8_t* fd = (uint8_t*)go_allocate(bytes_for_bits(n) + 64); uint8_t* vv = (uint8_t*)go_allocate(bytes_for_bits(n) + 64);
+  for (int64_t i = 0; i < n; i++) a[i] = (int64_t)lcg(&seed);
+  for (size_t i = 0; i < bytes_for_bits(n); i++) { fd[i] = (uint8_t)lcg(&seed); vv[i] = (uint8_t)(lcg(&seed) | lcg(&seed) | lcg(&seed)); }   /* s = 0.5, 87 % valid */
+  void *dv, *dfd, *dvv, *dout, *dov;
+  CHECK(ctx, ah_buf_alloc(ctx, (size_t)n * 8 + 64, &dv)); CHECK(ctx, ah_buf_alloc(ctx, bytes_for_bits(n) + 64, &dfd));
+  CHECK(ctx, ah_buf_alloc(ctx, bytes_for_bits(n) + 64, &dvv)); CHECK(ctx, ah_buf_alloc(ctx, (size_t)n * 8 + 64, &dout));
+  CHECK(ctx, ah_buf_alloc(ctx, bytes_for_bits(n) + 64, &dov));
+  CHECK(ctx, ah_upload_async(ctx, dv, a, (size_t)n * 8)); CHECK(ctx, ah_upload_async(ctx, dfd, fd, bytes_for_bits(n)));
+  CHECK(ctx, ah_upload_async(ctx, dvv, vv, bytes_for_bits(n))); CHECK(ctx, ah_sync(ctx));
+  int64_t n_out = 0;
+  const int reps = 20;
+  float ms_both = 0, ms_fill = 0, ms_count = 0;
+  for (int pass = 0; pass < 2; pass++) {   /* pass 0 warms up */
+    CHECK(ctx, ah_event_record(ctx, 1));
+    for (int r = 0; r < reps; r++) {
+      CHECK(ctx, ah_filter_count(ctx, (uint8_t*)dfd, NULL, 0, n, AH_DROP_NULLS, &n_out));
+      CHECK(ctx, ah_filter_primitive(ctx, 8, dv, (uint8_t*)dvv, 0, (uint8_t*)dfd, NULL, 0, n, AH_DROP_NULLS, n_out, dout, (uint8_t*)dov, NULL));
+    }
+    CHECK(ctx, ah_event_record(ctx, 2));
+    CHECK(ctx, ah_event_elapsed_ms(ctx, 1, 2, &ms_both));
+    CHECK(ctx, ah_event_record(ctx, 3));
+    for (int r = 0; r < reps; r++)
+      CHECK(ctx, ah_filter_primitive(ctx, 8, dv, (uint8_t*)dvv, 0, (uint8_t*)dfd, NULL, 0, n, AH_DROP_NULLS, n_out, dout, (uint8_t*)dov, NULL));
+    CHECK(ctx, ah_event_record(ctx, 4));
+    CHECK(ctx, ah_event_elapsed_ms(ctx, 3, 4, &ms_fill));
+    CHECK(ctx, ah_event_record(ctx, 5));
+    for (int r = 0; r < reps; r++) CHECK(ctx, ah_filter_count(ctx, (uint8_t*)dfd, NULL, 0, n, AH_DROP_NULLS, &n_out));
+    CHECK(ctx, ah_event_record(ctx, 6));
+    CHECK(ctx, ah_event_elapsed_ms(ctx, 5, 6, &ms_count));
+  }
+  const double traffic = (8 + 0.125 + 0.125) * (double)n + (8 + 0.125) * (double)n_out;
+  printf("{\"caller\": \"C (tests/cabi_driver.c)\", \"rows\": %lld, \"selected\": %.4f, \"count_and_fill_ms\": %.4f, \"fill_only_ms\": %.4f, \"count_only_ms\": %.4f, "
+         "\"traffic_GB/s\": %.1f, \"frac_of_8TB/s\": %.4f}\n",
+         (long long)n, (double)n_out / (double)n, ms_both / reps, ms_fill / reps, ms_count / reps, traffic / (ms_both / reps) / 1e6, traffic / (ms_both / reps) / 1e6 / 8000.0);
+  ah_ctx_destroy(ctx);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s <outdir> <rows>\n", argv[0]); return 2; }
+  if (argc >= 3 && strcmp(argv[1], "bench") == 0) return bench_filter(atoi(argv[2]));
+  if (argc < 3) { fprintf(stderr, "usage: %s <outdir> <rows> | bench <log2 rows>\n", argv[0]); return 2; }
   g_out = argv[1];
   g_n = atoll(argv[2]);
   const int64_t n = g_n;

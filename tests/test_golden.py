@@ -1386,3 +1386,21 @@ def test_power_float_vectors(be, dtype):
             assert ext_binop(be, op, [0.0, 0.0], [-1.0, -3.0], dtype)[1] == [inf, inf]
             got = ext_binop(be, op, [3.4, float("nan"), 2.0], [1, 2, 2.0], dtype)[1]
             assert np.isnan(got[1]) and got[2] == 4.0
+
+
+def test_unique_fixed_width_keys_reference_vectors():
+    """TestUniqueFixedSizeBinary / TestUniqueDecimal (vector_hash_test.go:342-389) on the oracle: fixed-width keys go through the
+    binary memo table (kernels/vector_hash.go:608-609, 698) — ["aaa", null, "bbb", "aaa"] → ["aaa", null, "bbb"]; decimal128 / 256
+    [12, null, 11, 12] → [12, null, 11].  (The same vectors run on the device in test_gpu_parity.py::test_hash_fixed_width_keys.)"""
+    from tests.backends import OracleBackend
+    o = OracleBackend()
+    valid = np.array([0b1101], np.uint8)
+    ids, idv, first, nid, dic = o.hash_fixed_encode(np.frombuffer(b"aaa" + b"zzz" + b"bbb" + b"aaa", np.uint8), 3, valid, 0, 4, True)
+    assert ids.tolist() == [0, 1, 2, 0] and nid == 1 and first.tolist() == [0, 1, 2] and bytes(dic) == b"aaa\0\0\0bbb"
+    for w in (16, 32):
+        num = lambda v: np.frombuffer(int(v).to_bytes(w, "little", signed=True), np.uint8)
+        ids, idv, first, nid, dic = o.hash_fixed_encode(np.concatenate([num(12), num(12), num(11), num(12)]), w, valid, 0, 4, True)
+        assert ids.tolist() == [0, 1, 2, 0] and nid == 1 and bytes(dic) == bytes(num(12)) + bytes(w) + bytes(num(11))
+    # nulls masked instead of encoded: the null row gets index 0 and no dictionary entry (dictionaryEncodeAction, vector_hash.go:169-172)
+    ids, idv, first, nid, dic = o.hash_fixed_encode(np.frombuffer(b"aaa" + b"zzz" + b"bbb" + b"aaa", np.uint8), 3, valid, 0, 4, False)
+    assert ids.tolist() == [0, 0, 1, 0] and nid == -1 and bytes(dic) == b"aaabbb" and idv[0] & 0xF == 0b1101

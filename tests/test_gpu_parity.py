@@ -1479,6 +1479,39 @@ def test_hash_binary_encode_first_seen_order(hip, orc_be, odt):
                     assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
 
 
+@pytest.mark.parametrize("w", [3, 16, 32, 7])
+def test_hash_fixed_width_keys(hip, orc_be, w):
+    """unique / dictionary_encode of FixedSizeBinary (w = 3, 7), Decimal128 (16) and Decimal256 (32) keys — the reference hashes
+    them through the same BinaryMemoTable as strings (kernels/vector_hash.go:608-609, 698).  First the reference's own vectors
+    (vector_hash_test.go:342-389: ["aaa", null, "bbb", "aaa"] → ["aaa", null, "bbb"]; decimals [12, null, 11, 12] → [12, null, 11]),
+    then random columns against the oracle's memo table: ids, index validity, first rows, null id and the dictionary bytes."""
+    if w == 3:
+        data = np.frombuffer(b"aaa" + b"zzz" + b"bbb" + b"aaa", np.uint8)
+        valid = np.array([0b1101], np.uint8)
+        for be in (hip, orc_be):
+            ids, idv, first, nid, dic = be.hash_fixed_encode(data, 3, valid, 0, 4, True)
+            assert ids.tolist() == [0, 1, 2, 0] and nid == 1 and first.tolist() == [0, 1, 2] and bytes(dic) == b"aaa\0\0\0bbb"
+    if w in (16, 32):
+        num = lambda v: np.frombuffer(int(v).to_bytes(w, "little", signed=True), np.uint8)
+        data = np.concatenate([num(12), num(12), num(11), num(12)])       # slot 1 is null: its bytes must not matter
+        valid = np.array([0b1101], np.uint8)
+        for be in (hip, orc_be):
+            ids, idv, first, nid, dic = be.hash_fixed_encode(data, w, valid, 0, 4, True)
+            assert ids.tolist() == [0, 1, 2, 0] and nid == 1
+            assert bytes(dic) == bytes(num(12)) + bytes(w) + bytes(num(11))
+    rng = np.random.default_rng(9300 + w)
+    for card, n in ((1, 1), (5, 70), (300, 3001), (20000, 150001)):
+        pool = rng.integers(0, 4, (card, w), dtype=np.uint8)       # few symbols: many shared prefixes, the byte comparison decides
+        data = pool[rng.integers(0, card, n + 9)].reshape(-1)
+        valid = rand_bits(rng, n + 16, 0.9)
+        for off, v in ((0, None), (0, valid), (9, valid)):
+            for enc in (True, False):
+                g, e = hip.hash_fixed_encode(data, w, v, off, n, enc), orc_be.hash_fixed_encode(data, w, v, off, n, enc)
+                assert g[0].tobytes() == e[0].tobytes(), (w, card, n, off, enc)
+                assert g[1].tobytes() == e[1].tobytes() and g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+                assert g[4].tobytes() == e[4].tobytes()
+
+
 def test_hash_binary_encode_large(hip, orc_be):
     # beyond the 2^21-row prefix: direct ids for keys the prefix knew, late keys, table growth
     rng = np.random.default_rng(9200)
