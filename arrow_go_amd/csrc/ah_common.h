@@ -162,8 +162,8 @@ int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials16, int 
 // temporaries in the temp arena; *used says whether out_* hold the result
 int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
-// … and by two cuts, 64 parents × 2^(lp − 6) partitions (lp = 11 … 13)
-int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+// … and by two cuts, 64 parents × 2^(lp − 6) partitions (lp = 11 … 13) with LDS tables of `slots` = 4096 or 8192 entries
+int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,
                                int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
 // internal (ah_ctx.hip): 1..7 device words (8 bytes each, written by work already on the compute stream) → host, through the polled
 // mailbox — a cheaper "I need this number before I go on" than a copy + stream synchronisation.  Everything enqueued before it has

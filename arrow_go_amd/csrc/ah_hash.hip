@@ -736,14 +736,14 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
   if (n == 0) return AH_OK;
   // partition-first (ah_hash_part.hip) — forced by the option (tests, measurements); the automatic choice comes after the prefix below.
   // allow_partitioned = false: the caller's own temporaries live in the arena that path would take (the id-based group-by)
-  auto try_partitioned = [&](int lp, bool* done) -> int {
+  auto try_partitioned = [&](int lp, bool* done, int slots2 = 4096) -> int {
     *done = false;
     if constexpr (K::kLdsTable) {
       int used = 0;
       int64_t nd = 0;
       int32_t nid = -1;
       int prc = lp <= 10 ? ah_encode_partitioned_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, out_ids, out_dict, out_first_rows, &nd, &nid, &used)
-                         : ah_encode_partitioned2_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, out_ids, out_dict, out_first_rows, &nd, &nid, &used);
+                         : ah_encode_partitioned2_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, slots2, out_ids, out_dict, out_first_rows, &nd, &nid, &used);
       if (prc != AH_OK) return prc;
       if (used) { res->ndict = nd; res->null_id = nid; *done = true; }
     }
@@ -826,10 +826,16 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
           // (almost) every one of the 2^16 rows was new: ≥ 2^25 keys or so, too few repeats to say how many — the prefix below will tell
           part_undecided = *(volatile unsigned*)&c->pinned[1] == 0 && d16 >= 0.999 * (double)hi;
           if (*(volatile unsigned*)&c->pinned[1] == 0 && est >= (double)c->opt_encode_part_min && est <= 8192.0 * 4400.0) {
-            int lp = 8;   // 256 … 1024 partitions in one cut, 2048 … 8192 in two (ah_encode_partitioned2_try)
-            while (lp < 13 && est / (double)(1 << lp) > 4400.0) lp++;
+            int lp = 8;   // 256 … 1024 partitions of ≤ 4400 expected keys in one cut (8192-slot tables); beyond, two cuts into 2048 … 8192 of ≤ 2200 (4096-slot tables)
+            while (lp < 10 && est / (double)(1 << lp) > 4400.0) lp++;
+            int slots2 = 4096;
+            if (est / (double)(1 << lp) > 4400.0) {
+              lp = 11;
+              while (lp < 13 && est / (double)(1 << lp) > 2200.0) lp++;
+              if (est / (double)(1 << lp) > 2200.0) slots2 = 8192;   // 18 … 36 M keys: 8192 partitions with the large tables
+            }
             bool done;
-            int prc = try_partitioned(lp, &done);
+            int prc = try_partitioned(lp, &done, slots2);
             if (prc != AH_OK || done) return prc;
           }
         }
@@ -846,7 +852,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
         const double est = estimate_distinct((double)d0, (double)prefix, (double)n);
         if (est <= 8192.0 * 4400.0) {
           bool done;
-          int prc = try_partitioned(13, &done);
+          int prc = try_partitioned(13, &done, est / 8192.0 > 2200.0 ? 8192 : 4096);
           if (prc != AH_OK || done) return prc;
         }
       }

@@ -37,34 +37,38 @@
 
 namespace {
 
-constexpr int kESlots = 8192;              // LDS table of one partition: open addressing, aligned groups of 4
-constexpr int kESoft = 6144;               // keys admitted; beyond that the attempt is void (the estimate was far off)
-constexpr int kELSlots = kESlots + 2;      // + the all-ones key (kESlots) and the null key (kESlots + 1)
-constexpr int kEStride = kESlots + 8;      // a partition's slice of the global copies
+// LDS table of one partition: S slots (open addressing, aligned groups of 4) + the all-ones key (slot S) and the null key (S + 1);
+// ¾ S keys admitted — beyond that the attempt is void (the estimate was far off); a partition's slice of the global copies is
+// S + 8 entries.  S = 8192 (96 KiB: one workgroup per CU) for the one-cut path; S = 4096 for the two-cut path, whose partitions
+// hold only ≈ 8 Ki rows: three workgroups per CU hide each other's LDS round trips, and a table costs half as much to set up and dump.
+constexpr int kESlots = 8192, kESlots2 = 4096;
 constexpr unsigned short kMaskedSlot = 0xFFFFu;   // a null row whose nulls are not encoded: index 0, no dictionary entry
 
+template <int S>
 __device__ __forceinline__ unsigned enc_group(unsigned long long key) {   // first slot group; inside a partition the keys agree in the top bits of gb_mix
-  return ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 19) & (unsigned)(kESlots - 4);
+  return ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 18) & (unsigned)(S - 4);
 }
 
 // ---- 3: one workgroup per partition ------------------------------------------------------------------------------------------
+template <int S>
 __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long long* __restrict__ pkeys, const unsigned* __restrict__ prows,
                                                               const unsigned* __restrict__ binstart, int encode_nulls,
                                                               unsigned long long* __restrict__ tab_key, unsigned* __restrict__ tab_first,
                                                               unsigned short* __restrict__ rec_slot, unsigned long long* __restrict__ firsts,
                                                               unsigned* __restrict__ overflow) {
-  __shared__ __attribute__((aligned(16))) unsigned long long l_key[kELSlots];
-  __shared__ unsigned l_first[kELSlots];
+  constexpr int kLS = S + 2, kStride = S + 8, kSoft = S / 4 * 3;
+  __shared__ __attribute__((aligned(16))) unsigned long long l_key[kLS];
+  __shared__ unsigned l_first[kLS];
   __shared__ unsigned s_used;
   const int t = threadIdx.x, part = blockIdx.x;
   const int64_t r0 = binstart[part], r1 = binstart[part + 1];
-  for (int j = t; j < kELSlots; j += kThreads) { l_key[j] = kEmpty; l_first[j] = kNoRow; }
+  for (int j = t; j < kLS; j += kThreads) { l_key[j] = kEmpty; l_first[j] = kNoRow; }
   if (t == 0) s_used = 0;
   __syncthreads();
   const unsigned lkey_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)l_key;   // LDS byte address of the key table
   // find or claim the slot of `key` (−1: the table is full)
   auto slot_of = [&](unsigned long long key) -> int {
-    unsigned g = enc_group(key);
+    unsigned g = enc_group<S>(key);
     for (;;) {
       // two ds_read_b128, spelled out (the compiler would split them into ds_read2_b64: half the banks per access, ah_groupby.hip)
       typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -74,10 +78,10 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
       const bool h0 = a.x == key, h1 = a.y == key, h2 = c.x == key, h3 = c.y == key;
       const bool e0 = a.x == kEmpty, e1 = a.y == kEmpty, e2 = c.x == kEmpty, e3 = c.y == kEmpty;
       const bool y0 = h0 || e0, y1 = h1 || e1, y2 = h2 || e2, y3 = h3 || e3;
-      if (!(y0 || y1 || y2 || y3)) { g = (g + 4) & (kESlots - 1); continue; }
+      if (!(y0 || y1 || y2 || y3)) { g = (g + 4) & (S - 1); continue; }
       const int j = (int)g + (y0 ? 0 : y1 ? 1 : y2 ? 2 : 3);
       if (h0 || (!e0 && (h1 || (!e1 && (h2 || (!e2 && h3)))))) return j;   // the key sits in front of the first empty slot
-      if (atomicAdd(&s_used, 1u) >= (unsigned)kESoft) return -1;             // tickets are never returned: "full" sticks
+      if (atomicAdd(&s_used, 1u) >= (unsigned)kSoft) return -1;             // tickets are never returned: "full" sticks
       const unsigned long long cur = atomicCAS(&l_key[j], kEmpty, key);
       if (cur == kEmpty || cur == key) return j;
       // another key took it meanwhile: look at the group again
@@ -114,8 +118,8 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
       if (i >= r1) continue;
       const unsigned row = rw[u] & kRowMask;
       int j;
-      if (rw[u] & kKeyNull) j = encode_nulls ? kESlots + 1 : -2;
-      else if (k[u] == kEmpty) j = kESlots;
+      if (rw[u] & kKeyNull) j = encode_nulls ? S + 1 : -2;
+      else if (k[u] == kEmpty) j = S;
       else if (p_slot >= 0 && p_key == k[u]) j = p_slot;
       else { j = slot_of(k[u]); p_key = k[u]; p_slot = j; }
       if (j >= 0) {
@@ -128,10 +132,10 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
   }
   if (full) atomicExch(overflow, 1u);
   __syncthreads();
-  const int64_t gbase = (int64_t)part * kEStride;
-  for (int j = t; j < kEStride; j += kThreads) {
-    const unsigned fr = j < kELSlots ? l_first[j] : kNoRow;
-    if (j < kELSlots) tab_key[gbase + j] = l_key[j];
+  const int64_t gbase = (int64_t)part * kStride;
+  for (int j = t; j < kStride; j += kThreads) {
+    const unsigned fr = j < kLS ? l_first[j] : kNoRow;
+    if (j < kLS) tab_key[gbase + j] = l_key[j];
     tab_first[gbase + j] = fr;
     if (fr != kNoRow) atomicOr(&firsts[fr >> 6], 1ull << (fr & 63));
   }
@@ -141,29 +145,31 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
 __global__ __launch_bounds__(kBlock) void enc_assign_kernel(const unsigned long long* __restrict__ tab_key, unsigned* __restrict__ tab_first, int64_t nslots,
                                                              const unsigned long long* __restrict__ firsts, const unsigned* __restrict__ wordprefix,
                                                              const int64_t* __restrict__ tileoff, unsigned long long* __restrict__ dict,
-                                                             long long* __restrict__ first_rows, int* __restrict__ null_id) {
+                                                             long long* __restrict__ first_rows, int* __restrict__ null_id, int slots) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
     const unsigned fr = tab_first[s];
     if (fr == kNoRow) continue;
     const unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
     tab_first[s] = id;
-    const int in_part = (int)(s % kEStride);
+    const int in_part = (int)(s % (slots + 8));
     unsigned long long key = tab_key[s];
-    if (in_part == kESlots) key = kEmpty;
-    if (in_part == kESlots + 1) { key = 0; *null_id = (int)id; }   // GetDictArrayData: the null slot keeps the fresh buffer's zero
+    if (in_part == slots) key = kEmpty;
+    if (in_part == slots + 1) { key = 0; *null_id = (int)id; }   // GetDictArrayData: the null slot keeps the fresh buffer's zero
     if (dict) dict[id] = key;
     if (first_rows) first_rows[id] = (long long)fr;
   }
 }
 
 // ---- 5: slot numbers → ids, in partition order ---------------------------------------------------------------------------------
+template <int S>
 __global__ __launch_bounds__(kThreads) void enc_resolve_kernel(const unsigned short* __restrict__ rec_slot, const unsigned* __restrict__ tab_id,
                                                                 const unsigned* __restrict__ binstart, int* __restrict__ rec_id) {
-  __shared__ unsigned l_id[kELSlots];
+  constexpr int kLS = S + 2, kStride = S + 8;
+  __shared__ unsigned l_id[kLS];
   const int t = threadIdx.x, part = blockIdx.x;
   const int64_t r0 = binstart[part], r1 = binstart[part + 1];
-  for (int j = t; j < kELSlots; j += kThreads) l_id[j] = tab_id[(int64_t)part * kEStride + j];
+  for (int j = t; j < kLS; j += kThreads) l_id[j] = tab_id[(int64_t)part * kStride + j];
   __syncthreads();
   constexpr int U = 8;
   for (int64_t b = r0; b < r1; b += (int64_t)kThreads * U) {
@@ -435,7 +441,7 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int P = 1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
-  const int64_t nslots = (int64_t)P * kEStride;
+  const int64_t nslots = (int64_t)P * (kESlots + 8);
   const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
   const size_t table = (size_t)P * (size_t)ntiles * 4;
   const size_t need = pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) + pad((size_t)n * 8) + pad((size_t)n * 4) + pad((size_t)n * 2) +
@@ -488,7 +494,7 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lp, P, ntiles, toffs, pkeys, nullptr, prows, nullptr);
   AH_LAUNCH_CHECK(c);
   // ---- 3: tables
-  enc_table_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  enc_table_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
@@ -496,11 +502,11 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
   AH_LAUNCH_CHECK(c);
   enc_assign_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff,
-                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id);
+                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id, kESlots);
   AH_LAUNCH_CHECK(c);
   if (out_ids) {
     // ---- 5, 6: ids per record, then per row
-    enc_resolve_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
+    enc_resolve_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
     AH_LAUNCH_CHECK(c);
     enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, P, ntiles, n, out_ids);
     AH_LAUNCH_CHECK(c);
@@ -516,16 +522,16 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
 
 
 // Two cuts: 64 parents × 2^(lp − 6) partitions (lp = 11 … 13), for ≈ 4.5 … 36 M expected keys.  Same contract as above.
-int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,
                                int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used) {
   *used = 0;
-  if (n < ((int64_t)1 << 20) || n >= kMaxRows || lp < 7 || lp > 13) return AH_OK;
+  if (n < ((int64_t)1 << 20) || n >= kMaxRows || lp < 7 || lp > 13 || (slots != kESlots && slots != kESlots2)) return AH_OK;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   constexpr int lb1 = 6, nb1 = 1 << lb1;
   const int lb2 = lp - lb1, nb2 = 1 << lb2;
   const int64_t P = (int64_t)1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
-  const int64_t nslots = P * kEStride;
+  const int64_t nslots = P * (slots + 8);
   const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
   const size_t need = pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) + pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) +
                       pad((size_t)n * 8) * 2 + pad((size_t)n * 4) * 2 + pad((size_t)n * 2) * 2 + pad((size_t)nslots * 8) + pad((size_t)nslots * 4) +
@@ -591,17 +597,19 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   e2_scatter_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, toffs2, pkeys2, prows2, pj2);
   AH_LAUNCH_CHECK(c);
   // ---- tables, ranks, ids: as in the one-level path, one workgroup per final partition
-  enc_table_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  if (slots == kESlots2) enc_table_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  else enc_table_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
   AH_LAUNCH_CHECK(c);
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
   AH_LAUNCH_CHECK(c);
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
   AH_LAUNCH_CHECK(c);
   enc_assign_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff,
-                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id);
+                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id, slots);
   AH_LAUNCH_CHECK(c);
   if (out_ids) {
-    enc_resolve_kernel<<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2);
+    if (slots == kESlots2) enc_resolve_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2);
+    else enc_resolve_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2);
     AH_LAUNCH_CHECK(c);
     e2_unpermute_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec_id2, pj2, cnt2, toffs2, n, pstart, nb1, nb2, rec_id1);
     AH_LAUNCH_CHECK(c);
