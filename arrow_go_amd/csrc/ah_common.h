@@ -58,6 +58,7 @@ struct ah_ctx {
   int opt_groupby_keys;        // hash + sum: expected keys per partition the cut aims at (ARROWHIP_GROUPBY_KEYS; the LDS table admits 3584)
   int opt_groupby_partition;   // hash + sum (ah_groupby.hip): 0 never, 1 auto, k ≥ 2 always with 2^(k−2) partitions (ARROWHIP_GROUPBY_PARTITION)
   int opt_encode_partition;    // unique / dictionary_encode (ah_hash_part.hip): 0 never, 1 auto (by the prefix's distinct count), k ≥ 3: always, 2^k partitions (ARROWHIP_ENCODE_PARTITION)
+  int opt_encode_part_slots;   // measurement: LDS table size of the one-cut path (8192 default, 4096)
   int opt_encode_part_min;     // auto: smallest expected distinct count that takes the partition-first path (ARROWHIP_ENCODE_PART_MIN)
   int opt_hash_direct;         // unique / dictionary_encode (ah_hash.hip): 0 ids in a separate pass, 1 direct ids, 2 + LDS / re-packed table (default), 3 no re-packed table (ARROWHIP_HASH_DIRECT)
   int opt_sort_msd;            // sort_indices: 0 LSD passes only, 1 auto (ARROWHIP_SORT_MSD)
@@ -160,7 +161,7 @@ int ah_sum_chunk_partials(ah_ctx* ctx, int is_f64, const void* buf, size_t len, 
 int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials16, int n, void* res_dev);
 // internal (ah_hash_part.hip): unique / dictionary_encode of 8-byte keys by partitions of the key hash, 2^lp of them (8 … 10);
 // temporaries in the temp arena; *used says whether out_* hold the result
-int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,
                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
 // … and by two cuts, 64 parents × 2^(lp − 6) partitions (lp = 11 … 13) with LDS tables of `slots` = 4096 or 8192 entries
 int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,

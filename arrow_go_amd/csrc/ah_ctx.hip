@@ -44,6 +44,7 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_hash_direct = env_int("ARROWHIP_HASH_DIRECT", 2);
   c->opt_encode_partition = env_int("ARROWHIP_ENCODE_PARTITION", 1);
   c->opt_encode_part_min = env_int("ARROWHIP_ENCODE_PART_MIN", 300000);
+  c->opt_encode_part_slots = env_int("ARROWHIP_ENCODE_PART_SLOTS", 8192);
   c->opt_sort_msd = env_int("ARROWHIP_SORT_MSD", 1);
   c->opt_scan_segment_log2 = env_int("ARROWHIP_SCAN_SEGMENT_LOG2", 0);   // 0 = one segment: segments measured slower
   c->opt_take_gather_lds = env_int("ARROWHIP_TAKE_GATHER_LDS", 1);   // 1: the window's validity bits in LDS (ah_take_binned.hip)
@@ -119,6 +120,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "hash_direct")) c->opt_hash_direct = (int)value;
   else if (!strcmp(name, "encode_partition")) c->opt_encode_partition = (int)value;
   else if (!strcmp(name, "encode_part_min")) c->opt_encode_part_min = (int)value;
+  else if (!strcmp(name, "encode_part_slots")) c->opt_encode_part_slots = (int)value;
   else if (!strcmp(name, "sort_msd")) c->opt_sort_msd = (int)value;
   else if (!strcmp(name, "scan_segment_log2")) c->opt_scan_segment_log2 = (int)value;
   else return ah_fail(c, AH_EINVALID, "set_option: unknown option '%s'", name);

@@ -742,7 +742,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
       int used = 0;
       int64_t nd = 0;
       int32_t nid = -1;
-      int prc = lp <= 10 ? ah_encode_partitioned_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, out_ids, out_dict, out_first_rows, &nd, &nid, &used)
+      int prc = lp <= 10 ? ah_encode_partitioned_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, c->opt_encode_part_slots == 4096 ? 4096 : 8192, out_ids, out_dict, out_first_rows, &nd, &nid, &used)
                          : ah_encode_partitioned2_try(c, (const uint64_t*)keys.keys, valid, off, n, encode_nulls, lp, slots2, out_ids, out_dict, out_first_rows, &nd, &nid, &used);
       if (prc != AH_OK) return prc;
       if (used) { res->ndict = nd; res->null_id = nid; *done = true; }
@@ -827,9 +827,10 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
           part_undecided = *(volatile unsigned*)&c->pinned[1] == 0 && d16 >= 0.999 * (double)hi;
           if (*(volatile unsigned*)&c->pinned[1] == 0 && est >= (double)c->opt_encode_part_min && est <= 8192.0 * 4400.0) {
             int lp = 8;   // 256 … 1024 partitions of ≤ 4400 expected keys in one cut (8192-slot tables); beyond, two cuts into 2048 … 8192 of ≤ 2200 (4096-slot tables)
-            while (lp < 10 && est / (double)(1 << lp) > 4400.0) lp++;
+            const double kpp1 = c->opt_encode_part_slots == 4096 ? 2200.0 : 4400.0;
+            while (lp < 10 && est / (double)(1 << lp) > kpp1) lp++;
             int slots2 = 4096;
-            if (est / (double)(1 << lp) > 4400.0) {
+            if (est / (double)(1 << lp) > kpp1) {
               lp = 11;
               while (lp < 13 && est / (double)(1 << lp) > 2200.0) lp++;
               if (est / (double)(1 << lp) > 2200.0) slots2 = 8192;   // 18 … 36 M keys: 8192 partitions with the large tables

@@ -434,14 +434,14 @@ __global__ __launch_bounds__(kThreads) void e2_unpermute_kernel(const int* __res
 // Called by encode_core (ah_hash.hip) for 8-byte keys.  lp = log2 of the number of partitions (8 … 10).  *used = 1: out_* hold the
 // result; 0: not applicable or the attempt was void (a partition outgrew its table, or one partition holds several times its
 // share of the rows) — nothing the caller owns was touched except out_ids / out_dict / out_first_rows, which it rewrites.
-int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp,
+int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,
                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used) {
   *used = 0;
-  if (n < 1 || n >= kMaxRows || lp < 3 || lp > 10) return AH_OK;
+  if (n < 1 || n >= kMaxRows || lp < 3 || lp > 10 || (slots != kESlots && slots != kESlots2)) return AH_OK;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int P = 1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
-  const int64_t nslots = (int64_t)P * (kESlots + 8);
+  const int64_t nslots = (int64_t)P * (slots + 8);
   const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
   const size_t table = (size_t)P * (size_t)ntiles * 4;
   const size_t need = pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) + pad((size_t)n * 8) + pad((size_t)n * 4) + pad((size_t)n * 2) +
@@ -494,7 +494,8 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lp, P, ntiles, toffs, pkeys, nullptr, prows, nullptr);
   AH_LAUNCH_CHECK(c);
   // ---- 3: tables
-  enc_table_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  if (slots == kESlots2) enc_table_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  else enc_table_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
@@ -502,11 +503,12 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
   AH_LAUNCH_CHECK(c);
   enc_assign_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff,
-                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id, kESlots);
+                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id, slots);
   AH_LAUNCH_CHECK(c);
   if (out_ids) {
     // ---- 5, 6: ids per record, then per row
-    enc_resolve_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
+    if (slots == kESlots2) enc_resolve_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
+    else enc_resolve_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
     AH_LAUNCH_CHECK(c);
     enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, P, ntiles, n, out_ids);
     AH_LAUNCH_CHECK(c);

@@ -24,6 +24,9 @@ def run(tag):
         if mode in (0, 1):
             r[name + "_unique_ms"] = timed(lambda: ctx.hash_u64_encode(keys, None, 0, hrows, False, None, None, dic))
     ctx.set_option("encode_partition", 1)
+    ctx.set_option("encode_part_slots", 4096)
+    r["auto_slots4096_encode_ms"] = timed(lambda: ctx.hash_u64_encode(keys, None, 0, hrows, False, ids, None, dic))
+    ctx.set_option("encode_part_slots", 8192)
     res[tag] = r
 for lg in lgs:
     card = 1 << lg
