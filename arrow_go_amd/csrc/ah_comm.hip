@@ -22,7 +22,8 @@ struct ah_comm {
   ah_transport transport;   // host-transport flavour (ah_comm_init_transport): the two exchanges over host memory
   bool has_transport;
   // grow-only blocks owned by the communicator: device temporaries of the C4 / C5 entry points, and pinned host staging
-  uint8_t* arena; size_t arena_bytes;
+  uint8_t* arena; size_t arena_bytes;     // merge_groups: bucketing, exchange and re-aggregation
+  uint8_t* arena2; size_t arena2_bytes;   // merge_groups: the gathered groups (reserved while the first still holds live data)
   uint8_t* stage; size_t stage_bytes;
 };
 
@@ -109,19 +110,21 @@ int stage_reserve(ah_comm* m, size_t nbytes, uint8_t** out) {
   *out = m->stage;
   return AH_OK;
 }
-int arena_reserve(ah_comm* m, size_t nbytes, uint8_t** out) {
+int arena_reserve_in(ah_comm* m, uint8_t** arena, size_t* have, size_t nbytes, uint8_t** out) {
   ah_ctx* c = m->ctx;
-  if (nbytes > m->arena_bytes) {
+  if (nbytes > *have) {
     AH_HIP(c, hipStreamSynchronize(c->stream));
-    if (m->arena) AH_HIP(c, hipFree(m->arena));
-    m->arena = nullptr; m->arena_bytes = 0;
+    if (*arena) AH_HIP(c, hipFree(*arena));
+    *arena = nullptr; *have = 0;
     const size_t want = (nbytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    AH_HIP(c, hipMalloc((void**)&m->arena, want));
-    m->arena_bytes = want;
+    AH_HIP(c, hipMalloc((void**)arena, want));
+    *have = want;
   }
-  *out = m->arena;
+  *out = *arena;
   return AH_OK;
 }
+int arena_reserve(ah_comm* m, size_t nbytes, uint8_t** out) { return arena_reserve_in(m, &m->arena, &m->arena_bytes, nbytes, out); }
+int arena2_reserve(ah_comm* m, size_t nbytes, uint8_t** out) { return arena_reserve_in(m, &m->arena2, &m->arena2_bytes, nbytes, out); }
 int transport_fail(ah_ctx* c, const char* what, int rc) { return ah_fail(c, AH_EHIP, "%s: the host transport returned %d", what, rc); }
 
 int transport_allgather(ah_comm* m, const void* send, void* recv, int64_t nbytes) {
@@ -228,6 +231,7 @@ AH_EXPORT int ah_comm_destroy(ah_comm* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   if (m->arena) (void)hipFree(m->arena);
+  if (m->arena2) (void)hipFree(m->arena2);
   if (m->stage) (void)hipHostFree(m->stage);
   free(m);
   return AH_OK;
@@ -293,6 +297,64 @@ AH_EXPORT int ah_comm_alltoallv(ah_comm* m, const void* send, const int64_t* sen
   AH_NCCL(c, g_rccl.GroupEnd());
   return AH_OK;
 }
+
+// ---- owner bucketing of a rank's local groups (C5): two small launches and ONE read-back, whatever the world size --------------------
+// (round 3's first version ran a compare, a count and four stream compactions per destination: 6·W launches and W host syncs.)
+// The order of the tuples INSIDE a destination's block is whatever the atomics make it — harmless: a rank's keys are distinct,
+// the owner's re-aggregation is order-free except for "first tuple of a key", which depends on the order of the source RANKS
+// only, and the result is sorted by first row at the end.
+namespace {
+constexpr int kOwnBlock = 256, kOwnMaxWorld = 1024;
+__device__ __forceinline__ unsigned owner_of_key(unsigned long long key, unsigned world) {   // = ah_hash_partition_u64: (hashInt(key) >> 40) mod world
+  return (unsigned)((__builtin_bswap64(11400714785074694791ull * key) >> 40) % world);
+}
+__global__ __launch_bounds__(kOwnBlock) void owner_hist_kernel(const unsigned long long* __restrict__ keys, int64_t g, unsigned world,
+                                                                unsigned long long* __restrict__ counts) {
+  __shared__ unsigned s_c[kOwnMaxWorld];
+  for (unsigned r = threadIdx.x; r < world; r += kOwnBlock) s_c[r] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kOwnBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kOwnBlock + threadIdx.x; i < g; i += stride) atomicAdd(&s_c[owner_of_key(keys[i], world)], 1u);
+  __syncthreads();
+  for (unsigned r = threadIdx.x; r < world; r += kOwnBlock) if (s_c[r]) atomicAdd(&counts[r], (unsigned long long)s_c[r]);
+}
+// block r = four columns of size[r] values back to back, starting at tuple base[r]
+__global__ __launch_bounds__(kOwnBlock) void owner_scatter_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ sums,
+                                                                   const long long* __restrict__ cnts, const long long* __restrict__ firsts, long long row_offset,
+                                                                   int64_t g, unsigned world, const long long* __restrict__ base, const long long* __restrict__ size,
+                                                                   unsigned long long* __restrict__ cursor, unsigned long long* __restrict__ sendbuf) {
+  __shared__ unsigned s_c[kOwnMaxWorld];
+  __shared__ unsigned long long s_base[kOwnMaxWorld];
+  // one chunk of kOwnBlock · 4 groups per workgroup: count, reserve (one global atomic per owner and workgroup), place
+  const int64_t lo = (int64_t)blockIdx.x * kOwnBlock * 4;
+  for (unsigned r = threadIdx.x; r < world; r += kOwnBlock) s_c[r] = 0;
+  __syncthreads();
+  unsigned own[4], rk[4];
+  unsigned long long k[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t i = lo + u * kOwnBlock + threadIdx.x;
+    own[u] = 0; rk[u] = 0; k[u] = 0;
+    if (i < g) { k[u] = keys[i]; own[u] = owner_of_key(k[u], world); rk[u] = atomicAdd(&s_c[own[u]], 1u); }
+  }
+  __syncthreads();
+  for (unsigned r = threadIdx.x; r < world; r += kOwnBlock) s_base[r] = s_c[r] ? atomicAdd(&cursor[r], (unsigned long long)s_c[r]) : 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t i = lo + u * kOwnBlock + threadIdx.x;
+    if (i >= g) continue;
+    const unsigned r = own[u];
+    const long long n_r = size[r];
+    unsigned long long* blk = sendbuf + base[r] * 4;
+    const long long e = (long long)s_base[r] + rk[u];
+    blk[e] = k[u];
+    blk[n_r + e] = sums[i];
+    blk[2 * n_r + e] = (unsigned long long)cnts[i];
+    blk[3 * n_r + e] = (unsigned long long)(firsts[i] + row_offset);
+  }
+}
+}  // namespace
 
 // ---- C4 / C5 as single calls: what a Go host runs per record-batch shard — no Python in between -----------------
 // small host vector ↔ every rank (sizes): through the device for RCCL, directly for a host transport
@@ -388,37 +450,42 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   int rc;
   // ---- 1: owners and the send blocks (block r = four columns of g_r values, back to back)
+  if (W > kOwnMaxWorld) return ah_fail(c, AH_EINVALID, "merge_groups: world beyond %d", kOwnMaxWorld);
   uint8_t* a0;
-  if ((rc = arena_reserve(m, pad((size_t)g * 8) * 6 + pad((size_t)g * 4) + pad((size_t)g / 8 + 128) + 4096, &a0)) != AH_OK) return rc;
+  if ((rc = arena_reserve(m, pad((size_t)g * 32) + pad((size_t)W * 8) * 4 + 4096, &a0)) != AH_OK) return rc;
   size_t o = 0;
   auto take = [&](size_t b) { uint8_t* q = a0 + o; o += pad(b); return q; };
-  int64_t* gfirst = (int64_t*)take((size_t)g * 8);
-  int32_t* owner = (int32_t*)take((size_t)g * 4);
-  uint8_t* mask = take((size_t)g / 8 + 128);
+  uint8_t* gfirst = take(8);   // (anchor of the block's base for the re-reservation below)
+  unsigned long long* d_counts = (unsigned long long*)take((size_t)W * 8);
+  unsigned long long* d_cursor = (unsigned long long*)take((size_t)W * 8);
+  long long* d_base = (long long*)take((size_t)W * 8);
+  long long* d_size = (long long*)take((size_t)W * 8);
   uint8_t* sendbuf = take((size_t)g * 32);
   const size_t phase1 = o;
   std::vector<int64_t> scnt(W, 0);
   if (g > 0) {
-    if ((rc = ah_arithmetic_arr_scalar(c, AH_INT64, 0 /*ADD*/, first_rows, &row_offset, gfirst, g)) != AH_OK) return rc;
     if (W == 1) {
       scnt[0] = g;
-      const void* cols[4] = {keys, sums, counts, gfirst};
-      for (int k = 0; k < 4; k++) if ((rc = ah_copy_async(c, sendbuf + (size_t)k * (size_t)g * 8, cols[k], (size_t)g * 8)) != AH_OK) return rc;
+      if ((rc = ah_arithmetic_arr_scalar(c, AH_INT64, 0 /*ADD*/, first_rows, &row_offset, sendbuf + (size_t)3 * (size_t)g * 8, g)) != AH_OK) return rc;
+      const void* cols[3] = {keys, sums, counts};
+      for (int k = 0; k < 3; k++) if ((rc = ah_copy_async(c, sendbuf + (size_t)k * (size_t)g * 8, cols[k], (size_t)g * 8)) != AH_OK) return rc;
     } else {
-      if ((rc = ah_hash_partition_u64(c, keys, g, W, owner)) != AH_OK) return rc;
-      int64_t done = 0;
-      for (int r = 0; r < W; r++) {
-        const int32_t rr = r;
-        if ((rc = ah_comparison(c, AH_CMP_EQ, AH_SHAPE_AS, AH_INT32, owner, &rr, mask, g, 0)) != AH_OK) return rc;
-        int64_t n_r = 0;
-        if ((rc = ah_filter_count(c, mask, nullptr, 0, g, AH_DROP_NULLS, &n_r)) != AH_OK) return rc;
-        scnt[r] = n_r;
-        const void* cols[4] = {keys, sums, counts, gfirst};
-        for (int k = 0; k < 4 && n_r > 0; k++)
-          if ((rc = ah_filter_primitive(c, 8, cols[k], nullptr, 0, mask, nullptr, 0, g, AH_DROP_NULLS, n_r, sendbuf + (size_t)done * 32 + (size_t)k * (size_t)n_r * 8,
-                                        nullptr, nullptr)) != AH_OK) return rc;
-        done += n_r;
-      }
+      AH_HIP(c, hipMemsetAsync(d_counts, 0, pad((size_t)W * 8) * 2, c->stream));   // counts and cursors
+      const unsigned hgrid = ah_stream_grid(c, ah_ceil_div(g, kOwnBlock), 4);
+      owner_hist_kernel<<<hgrid, kOwnBlock, 0, c->stream>>>((const unsigned long long*)keys, g, (unsigned)W, d_counts);
+      AH_LAUNCH_CHECK(c);
+      AH_HIP(c, hipMemcpyAsync(scnt.data(), d_counts, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+      AH_HIP(c, hipStreamSynchronize(c->stream));
+      std::vector<long long> hb(W), hs(W);
+      long long run = 0;
+      for (int r = 0; r < W; r++) { hb[r] = run; hs[r] = (long long)scnt[r]; run += hs[r]; }
+      AH_HIP(c, hipMemcpyAsync(d_base, hb.data(), (size_t)W * 8, hipMemcpyHostToDevice, c->stream));
+      AH_HIP(c, hipMemcpyAsync(d_size, hs.data(), (size_t)W * 8, hipMemcpyHostToDevice, c->stream));
+      owner_scatter_kernel<<<(unsigned)ah_ceil_div(g, (int64_t)kOwnBlock * 4), kOwnBlock, 0, c->stream>>>(
+          (const unsigned long long*)keys, (const unsigned long long*)sums, (const long long*)counts, (const long long*)first_rows, (long long)row_offset, g, (unsigned)W,
+          d_base, d_size, d_cursor, (unsigned long long*)sendbuf);
+      AH_LAUNCH_CHECK(c);
+      AH_HIP(c, hipStreamSynchronize(c->stream));   // hb / hs are stack vectors: the copies above must have read them
     }
   }
   // ---- 2: sizes, then the tuples
@@ -496,25 +563,17 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
   if (G > capacity) return ah_fail(c, AH_EINVALID, "merge_groups: %lld groups, the outputs hold %lld", (long long)G, (long long)capacity);
   if (G == 0) return AH_OK;
   if (!out_keys || !out_sums || !out_counts || !out_first_rows) return ah_fail(c, AH_EINVALID, "merge_groups: null output");
-  // blocks of 4 columns × mx (padded) per rank; then the columns are laid end to end, rank order
-  uint8_t* b0;
+  // blocks of 4 columns × mx (padded) per rank; then the columns are laid end to end, rank order.  All of it in the communicator's
+  // SECOND block: the first still holds the re-aggregated columns
+  uint8_t* blk_local;
+  if ((rc = arena2_reserve(m, pad((size_t)mx * 32) + pad((size_t)mx * 32 * (size_t)W) + pad((size_t)G * 8) * 5 + 4096, &blk_local)) != AH_OK) return rc;
+  uint8_t* b0 = blk_local + pad((size_t)mx * 32);
   {
-    // a third reservation: the re-aggregation's temporaries are dead except ok / osum / csum / ofirst_rows (copied into the block first)
-    uint8_t* blk_local = nullptr;
-    AH_HIP(c, hipMalloc((void**)&blk_local, (size_t)mx * 32 + 64));
     const void* cols[4] = {ok, osum, csum, ofirst_rows};
-    for (int k = 0; k < 4; k++)
-      if (ng > 0 && hipMemcpyAsync(blk_local + (size_t)k * (size_t)mx * 8, cols[k], (size_t)ng * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
-        (void)hipFree(blk_local);
-        return ah_fail(c, AH_EHIP, "merge_groups: copy failed");
-      }
-    rc = arena_reserve(m, pad((size_t)mx * 32 * (size_t)W) + pad((size_t)G * 8) * 5 + 4096, &b0);
-    if (rc == AH_OK) {
-      if (W == 1) rc = ah_copy_async(c, b0, blk_local, (size_t)mx * 32);
-      else rc = ah_comm_allgather(m, blk_local, b0, mx * 32);
-    }
-    if (rc == AH_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = ah_fail(c, AH_EHIP, "merge_groups: sync failed");
-    (void)hipFree(blk_local);
+    for (int k = 0; k < 4 && ng > 0; k++)
+      if ((rc = ah_copy_async(c, blk_local + (size_t)k * (size_t)mx * 8, cols[k], (size_t)ng * 8)) != AH_OK) return rc;
+    if (W == 1) rc = ah_copy_async(c, b0, blk_local, (size_t)mx * 32);
+    else rc = ah_comm_allgather(m, blk_local, b0, mx * 32);
     if (rc != AH_OK) return rc;
   }
   uint8_t* colbase = b0 + pad((size_t)mx * 32 * (size_t)W);
