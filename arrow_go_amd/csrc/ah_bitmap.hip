@@ -235,8 +235,7 @@ AH_EXPORT int ah_count_set_bits(ah_ctx* c, const uint8_t* bits, int64_t off, int
   unsigned long long* total = (unsigned long long*)c->dscalars;
   int rc = ah_popcount_async(c, bits, off, nbits, total);
   if (rc != AH_OK) return rc;
-  AH_HIP(c, hipMemcpyAsync(c->pinned, total, sizeof(*total), hipMemcpyDeviceToHost, c->stream));
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  { int mrc = ah_mailbox_read(c, total, 1, (unsigned long long*)c->pinned); if (mrc != AH_OK) return mrc; }
   *out_host = (int64_t) * (volatile uint64_t*)c->pinned;
   return AH_OK;
 }

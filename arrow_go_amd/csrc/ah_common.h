@@ -64,6 +64,7 @@ struct ah_ctx {
   int opt_sort_msd;            // sort_indices: 0 LSD passes only, 1 auto (ARROWHIP_SORT_MSD)
   int opt_scan_segment_log2;   // cumulative_sum: bytes of input per segment (ARROWHIP_SCAN_SEGMENT_LOG2; 0 = one segment)
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
+  int capturing;           // between ah_graph_begin and ah_graph_end: the compute stream records instead of running
   ah_filter_cache fcache;  // ah_filter.hip
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;

@@ -139,6 +139,7 @@ __global__ void mailbox_post_kernel(const unsigned long long* __restrict__ src, 
 }  // namespace
 int ah_mailbox_read(ah_ctx* c, const unsigned long long* dev_words, int nwords, unsigned long long* out_host) {
   if (nwords < 1 || nwords > 7) return ah_fail(c, AH_EINVALID, "mailbox_read: 1..7 words");
+  if (c->capturing) { c->capturing = 2; return ah_fail(c, AH_EINVALID, "this call returns a value to the host: it cannot be recorded into a graph"); }
   unsigned long long* mb = c->mailbox + 8;   // the second half: the first belongs to ah_filter_count
   const unsigned long long seq = ++c->mailbox_seq;
   mailbox_post_kernel<<<1, 1, 0, c->stream>>>(dev_words, nwords, mb, seq);
@@ -358,3 +359,73 @@ AH_EXPORT int ah_wait_event(ah_ctx* c, void* hip_event_ptr) {
 }
 
 AH_EXPORT int ah_device_id(ah_ctx* c) { return c ? c->device : -1; }
+
+
+// ---- hipGraph capture of a sequence of calls ---------------------------------------------------------------------------------
+// Small columns and chains of cheap kernels are LAUNCH-bound: a bitmap AND over 2^27 rows is 9 µs, most of it launch latency, and
+// an Add → Compare → fused-sum chain over 2^16 rows spends more time between its kernels than in them.  Between ah_graph_begin
+// and ah_graph_end the context's compute stream is in capture mode: the entry points called there record their launches (and
+// memsets / device copies) into a graph instead of running them; ah_graph_launch replays the whole sequence with ONE submission.
+// Capturable are the calls that neither wait for the device nor (re)allocate: the element-wise kernels, comparisons, bitmap ops,
+// the *_dev flavours (sum, fused compare-filter-sum, filter, take), cumulative_sum without a null count — after one eager
+// warm-up call of the same sequence, so that the scratch arenas have their size.  A call that would have to wait (anything with
+// a *_host result) fails with the runtime's capture error and invalidates the capture; ah_graph_end then reports it.
+struct ah_graph {
+  ah_ctx* ctx;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+AH_EXPORT int ah_graph_begin(ah_ctx* c) {
+  AH_ENTER(c);
+  if (c->capturing) return ah_fail(c, AH_EINVALID, "graph_begin: already capturing");
+  AH_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  c->capturing = 1;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_graph_end(ah_ctx* c, ah_graph** out) {
+  if (!c) return AH_EINVALID;
+  c->err[0] = 0;
+  if (!out) return ah_fail(c, AH_EINVALID, "graph_end: null out pointer");
+  *out = nullptr;
+  if (!c->capturing) return ah_fail(c, AH_EINVALID, "graph_end: not capturing");
+  const bool poisoned = c->capturing == 2;
+  c->capturing = 0;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (e == hipSuccess && g && poisoned) {
+    (void)hipGraphDestroy(g);
+    return ah_fail(c, AH_EINVALID, "graph_end: a recorded call needed a value on the host — nothing was run, the capture is dropped");
+  }
+  if (e != hipSuccess || !g) {
+    (void)hipGetLastError();
+    return ah_fail(c, AH_EHIP, "graph_end: the capture was invalidated (%s) — a captured call waited for the device or allocated", hipGetErrorString(e));
+  }
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); return ah_fail(c, AH_EHIP, "graph_end: hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+  ah_graph* r = (ah_graph*)calloc(1, sizeof(ah_graph));
+  if (!r) { (void)hipGraphExecDestroy(x); (void)hipGraphDestroy(g); return ah_fail(c, AH_EINVALID, "graph_end: out of memory"); }
+  r->ctx = c; r->graph = g; r->exec = x;
+  *out = r;
+  return AH_OK;
+}
+
+AH_EXPORT int ah_graph_launch(ah_ctx* c, ah_graph* g) {
+  AH_ENTER(c);
+  if (!g || g->ctx != c) return ah_fail(c, AH_EINVALID, "graph_launch: not a graph of this context");
+  if (c->capturing) return ah_fail(c, AH_EINVALID, "graph_launch: the context is capturing");
+  AH_HIP(c, hipGraphLaunch(g->exec, c->stream));
+  return AH_OK;
+}
+
+AH_EXPORT int ah_graph_destroy(ah_graph* g) {
+  if (!g) return AH_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  free(g);
+  return AH_OK;
+}

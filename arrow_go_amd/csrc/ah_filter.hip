@@ -432,6 +432,7 @@ AH_EXPORT int ah_filter_count(ah_ctx* c, const uint8_t* fdata, const uint8_t* fv
   if (n == 0) return AH_OK;
   if (!fdata) return ah_fail(c, AH_EINVALID, "filter_count: null filter data");
   int* tile_local; int64_t* super_off; int64_t* total; int64_t ntiles;
+  if (c->capturing) { c->capturing = 2; return ah_fail(c, AH_EINVALID, "filter_count returns a value to the host: it cannot be recorded into a graph"); }
   const unsigned long long seq = ++c->mailbox_seq;
   int rc = run_counts<8>(c, fdata, fvalid, foff, n, null_sel, &tile_local, &super_off, &total, &ntiles, /*to_cache=*/true, seq);
   if (rc != AH_OK) return rc;

@@ -203,8 +203,7 @@ int fused_host(ah_ctx* c, int cmpop, const T* x, const uint8_t* valid, int64_t o
   int64_t* dcnt = (int64_t*)&c->dscalars[9];
   int rc = fused_dev<T>(c, cmpop, x, valid, off, n, thr, dsum, dcnt);
   if (rc != AH_OK) return rc;
-  AH_HIP(c, hipMemcpyAsync(c->pinned, dsum, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  { int mrc = ah_mailbox_read(c, (const unsigned long long*)dsum, 2, (unsigned long long*)c->pinned); if (mrc != AH_OK) return mrc; }
   if (out_sum_host) memcpy(out_sum_host, (const void*)&c->pinned[0], sizeof(T));
   if (out_count_host) memcpy(out_count_host, (const void*)&c->pinned[1], sizeof(int64_t));
   return AH_OK;

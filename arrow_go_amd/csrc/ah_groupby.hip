@@ -824,8 +824,7 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
   else gs_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(g_key, g_sum, g_cnt, g_first, n, firsts, wordprefix, tileoff, (unsigned long long*)out_keys,
                                                             (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id);
   AH_LAUNCH_CHECK(c);
-  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // oversize, total, null id
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // oversize, total, null id
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a bucket beyond one wave (a key with hundreds of rows): the id-based path redoes the call
   if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
@@ -928,8 +927,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
                                                             (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kFlatStride, kSlots);
   AH_LAUNCH_CHECK(c);
-  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition outgrew its LDS table: the id-based path redoes the call
   if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
@@ -997,8 +995,7 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
   else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
                                                             (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
   AH_LAUNCH_CHECK(c);
-  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;
   if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
@@ -1047,8 +1044,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
       AH_LAUNCH_CHECK(c);
       if ((rc = ah_popcount_async(c, (const uint8_t*)bm, 0, kBits, ones + half)) != AH_OK) return rc;
     }
-    AH_HIP(c, hipMemcpyAsync(&c->pinned[8], ones, 16, hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = ah_mailbox_read(c, ones, 2, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;
     const double sampled = (double)groups * 64.0;
     const double dh = distinct(*(volatile uint64_t*)&c->pinned[8], sampled / 2), ds = distinct(*(volatile uint64_t*)&c->pinned[9], sampled);
     double est = gb_extrapolate(ds, sampled, (double)n);
@@ -1170,8 +1166,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
                                                             (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
   AH_LAUNCH_CHECK(c);
-  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[21], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition held far more keys than estimated: the caller's path redoes the call
   if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];

@@ -845,8 +845,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
     bool restart = false, small = false, direct = false, compact = false;
     uint64_t d0 = 0;
     if (prefix < n && cap < cap_max) {
-      AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[4], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      AH_HIP(c, hipStreamSynchronize(c->stream));
+      if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[4], 2, (unsigned long long*)c->pinned)) != AH_OK) return rc;
       d0 = *(volatile uint64_t*)&c->pinned[0];
       bool ovf = *(volatile unsigned*)&c->pinned[1] != 0;
       if (part_undecided && !ovf) {   // 2^21 rows hold enough repeats to tell 2^25 keys from 2^26: up to ≈ 36 M expected keys take the two-cut path
@@ -913,8 +912,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
         AH_LAUNCH_CHECK(c);
         lo = probe_end;
         if (probe_end < n) {
-          AH_HIP(c, hipMemcpyAsync(c->pinned, misses, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-          AH_HIP(c, hipStreamSynchronize(c->stream));
+          if ((rc = ah_mailbox_read(c, misses, 1, (unsigned long long*)c->pinned)) != AH_OK) return rc;
           if (*(volatile uint64_t*)c->pinned * 8 < (uint64_t)(probe_end - prefix)) {
             insert_small_kernel<<<sgrid, kSmallBlock, 0, c->stream>>>(keys.keys, valid, off, probe_end, n, encode_nulls,
                                                                       table, cap, skeys, sids, (unsigned*)out_ids, distinct, overflow, misses);
@@ -937,8 +935,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
         AH_LAUNCH_CHECK(c);
         lo = probe_end;
         if (probe_end < n) {
-          AH_HIP(c, hipMemcpyAsync(c->pinned, misses, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-          AH_HIP(c, hipStreamSynchronize(c->stream));
+          if ((rc = ah_mailbox_read(c, misses, 1, (unsigned long long*)c->pinned)) != AH_OK) return rc;
           if (*(volatile uint64_t*)c->pinned * 64 < (uint64_t)(probe_end - seg_lo)) {
             insert_compact_kernel<<<ah_stream_grid(c, ah_ceil_div(n - lo, (int64_t)kBlock * kCompactRows)), kBlock, 0, c->stream>>>(
                 keys.keys, valid, off, lo, n, encode_nulls, table, cap, ctab, ccap - 1, (unsigned*)out_ids, distinct, overflow, misses);
@@ -952,9 +949,11 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
                                                       (unsigned*)out_ids, 0x80000000u, (unsigned)prefix, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
       }
-      AH_HIP(c, hipMemcpyAsync(c->pinned, misses, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      AH_HIP(c, hipMemcpyAsync(&c->pinned[1], overflow, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      AH_HIP(c, hipStreamSynchronize(c->stream));
+      {   // dscalars[4 … 8] = distinct, overflow, total, null id, misses: one polled read
+        unsigned long long w5[5];
+        if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[4], 5, w5)) != AH_OK) return rc;
+        c->pinned[0] = w5[4]; c->pinned[1] = w5[1];
+      }
       ranked = *(volatile uint64_t*)&c->pinned[0] == 0 && *(volatile unsigned*)&c->pinned[1] == 0;
       *(volatile uint64_t*)c->pinned = *(volatile uint64_t*)&c->pinned[1];  // overflow flag where the check below reads it
     } else {
@@ -963,8 +962,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
                                                       (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
       }
-      AH_HIP(c, hipMemcpyAsync(c->pinned, overflow, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      AH_HIP(c, hipStreamSynchronize(c->stream));
+      if ((rc = ah_mailbox_read(c, (const unsigned long long*)overflow, 1, (unsigned long long*)c->pinned)) != AH_OK) return rc;
     }
     if (*(volatile unsigned*)c->pinned) {
       if (cap >= cap_max) return ah_fail(c, AH_EINVALID, "hash: table overflow at maximum capacity (internal error)");
@@ -979,8 +977,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
       emit_kernel<<<ah_stream_grid(c, ah_ceil_div(rows, (int64_t)kBlock * 4)), kBlock, 0, c->stream>>>(table, out_ids, rows, direct_from);
       AH_LAUNCH_CHECK(c);
     }
-    AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[6], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[6], 2, (unsigned long long*)c->pinned)) != AH_OK) return rc;
     res->ndict = (int64_t) * (volatile uint64_t*)&c->pinned[0];
     res->null_id = *(volatile int32_t*)&c->pinned[1];
     return AH_OK;

@@ -513,8 +513,7 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
     enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, P, ntiles, n, out_ids);
     AH_LAUNCH_CHECK(c);
   }
-  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[30], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[30], 3, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;   // overflow, total, null id
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition held more keys than its table admits: the global-table path redoes the call
   if (out_ndict) *out_ndict = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_id) *out_null_id = *(volatile int32_t*)&c->pinned[10];
@@ -618,8 +617,7 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
     enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id1, prows1, cnt1, toffs1, nb1, ntiles, n, out_ids);
     AH_LAUNCH_CHECK(c);
   }
-  AH_HIP(c, hipMemcpyAsync(&c->pinned[8], &c->dscalars[30], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));   // overflow, total, null id
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[30], 3, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;   // overflow, total, null id
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;
   if (out_ndict) *out_ndict = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_id) *out_null_id = *(volatile int32_t*)&c->pinned[10];

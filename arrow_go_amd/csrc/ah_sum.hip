@@ -200,8 +200,8 @@ int sum_host(ah_ctx* c, const T* buf, size_t len, T* res_host) {
   T* dres = (T*)c->dscalars;
   int rc = sum_dev<T, Acc>(c, buf, len, dres);
   if (rc != AH_OK) return rc;
-  AH_HIP(c, hipMemcpyAsync(c->pinned, dres, sizeof(T), hipMemcpyDeviceToHost, c->stream));
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  static_assert(sizeof(T) == 8, "one mailbox word");
+  if ((rc = ah_mailbox_read(c, (const unsigned long long*)dres, 1, (unsigned long long*)c->pinned)) != AH_OK) return rc;
   memcpy(res_host, c->pinned, sizeof(T));
   return AH_OK;
 }

@@ -434,8 +434,7 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
     AH_LAUNCH_CHECK(c);
     return AH_OK;
   }
-  AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[1], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[1], 2, (unsigned long long*)c->pinned)) != AH_OK) return rc;
   uint64_t bad_pos = *(volatile uint64_t*)&c->pinned[0];
   uint64_t nvalid = *(volatile uint64_t*)&c->pinned[1];
   if (bad_pos != ~0ull) {
@@ -486,8 +485,7 @@ AH_EXPORT int ah_take_boolean(ah_ctx* c, const uint8_t* data, const uint8_t* vva
     int rc = ah_popcount_async(c, out_valid, 0, nidx, valid_total);
     if (rc != AH_OK) return rc;
   }
-  AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[1], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  AH_HIP(c, hipStreamSynchronize(c->stream));
+  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[1], 2, (unsigned long long*)c->pinned); if (mrc != AH_OK) return mrc; }
   const uint64_t bad_pos = *(volatile uint64_t*)&c->pinned[0];
   const uint64_t nvalid = *(volatile uint64_t*)&c->pinned[1];
   if (bad_pos != ~0ull) {

@@ -571,8 +571,7 @@ int ah_take_binned_try(ah_ctx* c, int byte_width, const void* values, const uint
     }
 #undef AH_S
     AH_LAUNCH_CHECK(c);
-    AH_HIP(c, hipMemcpyAsync(&c->pinned[8], hits, sizeof(*hits), hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
+    { int mrc = ah_mailbox_read(c, hits, 1, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }
     const uint64_t h = *(volatile uint64_t*)&c->pinned[8] & 0xffffffffull, h1 = *(volatile uint64_t*)&c->pinned[8] >> 32;
     if (h * 4 > 64 * 255) {  // more than a quarter of the sampled neighbours sit within one 128-byte line
       // … and where most neighbours name ADJACENT values the direct path takes V rows per lane with merged 16-byte accesses

@@ -152,6 +152,21 @@ class Ingest:
         return r.value
 
 
+class Graph:
+    """ah_graph: a captured sequence of calls, replayed with one submission (include/arrowhip.h, "hipGraph capture")"""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.handle = ctx, handle
+
+    def launch(self) -> None:
+        check(self.ctx.handle, lib.ah_graph_launch(self.ctx.handle, self.handle))
+
+    def close(self) -> None:
+        if self.handle:
+            lib.ah_graph_destroy(self.handle)
+            self.handle = None
+
+
 class Comm:
     """ah_comm: this rank's RCCL communicator on an ah_ctx's compute stream (include/arrowhip.h, "multi-GPU exchange").
     Buffers are device pointers (ints, DeviceBuffers, or anything with .data_ptr())."""
@@ -248,6 +263,15 @@ class Context:
     def set_option(self, name: str, value: int) -> None:
         """measurement / test switch of this context (ah_ctx_set_option); never changes a result"""
         check(self.handle, lib.ah_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    # ---- hipGraph capture -------------------------------------------------------------------------------------------------
+    def graph_begin(self) -> None:
+        check(self.handle, lib.ah_graph_begin(self.handle))
+
+    def graph_end(self) -> "Graph":
+        h = C.c_void_p()
+        check(self.handle, lib.ah_graph_end(self.handle, C.byref(h)))
+        return Graph(self, h)
 
     def alloc_pinned(self, nbytes: int) -> PinnedBuffer:
         return PinnedBuffer(self, nbytes)

@@ -425,6 +425,48 @@ def host_ingest_legs(ctx, rows):
     return out
 
 
+def graph_replay_legs(ctx):
+    """Launch-bound chains (config C1's size class): Add → Compare → bitmap AND → fused compare-filter-sum → Sum over Int64 columns of
+    2^16 and 2^20 rows, timed eager (five submissions) and as one captured hipGraph (ah_graph_*)."""
+    import arrow_go_amd as ah
+    N = ah._native
+    out = {}
+    for lg in (16, 20):
+        n = 1 << lg
+        rng = np.random.default_rng(lg)
+        a = ctx.to_device(rng.integers(-1000, 1000, n, dtype=np.int64)); b = ctx.to_device(rng.integers(-1000, 1000, n, dtype=np.int64))
+        c = ctx.alloc(n * 8); m1, m2, m3 = (ctx.alloc(n // 8 + 64) for _ in range(3))
+        m2.memset(0xA5)
+        r1, r2 = ctx.alloc(16), ctx.alloc(8)
+        thr = np.array([5], np.int64)
+
+        def chain():
+            ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, a, b, c, n)
+            ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT64, c, thr, m1, n, 0)
+            ctx.bitmap_op(N.BIT_AND, m1, 0, m2, 0, m3, 0, n)
+            ctx.cmp_filter_sum_i64_dev(N.CMP_GT, c, m2, 0, n, 5, r1)
+            ctx.sum_int64_dev(c, n, r2)
+
+        chain(); ctx.sync()
+        ctx.graph_begin(); chain(); g = ctx.graph_end()
+        reps = 200
+
+        def timed(fn):
+            fn()
+            ctx.event_record(1002)
+            for _ in range(reps):
+                fn()
+            ctx.event_record(1003)
+            return ctx.event_elapsed_ms(1002, 1003) / reps
+
+        eager, replay = timed(chain), timed(g.launch)
+        out[f"2^{lg}_rows"] = {"calls": 5, "eager_ms": round(eager, 5), "graph_ms": round(replay, 5), "speedup": round(eager / replay, 2)}
+        g.close()
+        for d in (a, b, c, m1, m2, m3, r1, r2):
+            d.free()
+    return out
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE JSON line: libraries that chat on fd 1 (RCCL's version
@@ -626,6 +668,10 @@ def main():
                 result["host_ingest"] = host_ingest_legs(ctx, rows)
             except Exception as e:
                 result["host_ingest"] = {"error": repr(e)}
+            try:
+                result["graph_replay"] = graph_replay_legs(ctx)
+            except Exception as e:
+                result["graph_replay"] = {"error": repr(e)}
             if isinstance(result["kernels"].get("ceiling_copy_kernel"), dict):
                 result["roofline"]["measured_copy_GB/s"] = result["kernels"]["ceiling_copy_kernel"]["GB/s"]
         if world == 1 and not args.no_cpu_baseline:

@@ -148,6 +148,18 @@ int ah_memset_async(ah_ctx* ctx, void* dptr, int byte_value, size_t nbytes); /* 
  * (arrow/array/concat.go:159-180 concatBuffers) when chunked inputs are laid end to end in HBM */
 int ah_copy_async(ah_ctx* ctx, void* dst, const void* src, size_t nbytes);
 int ah_sync(ah_ctx* ctx);
+/* ---- hipGraph capture: many launch-bound calls, one submission ----------------------------------------------------------------
+ * No reference analogue.  Between ah_graph_begin and ah_graph_end the calls on this context are RECORDED, not run; ah_graph_launch
+ * replays the sequence (same pointers, same lengths — new contents) with one submission to the compute stream.  Capturable: the
+ * calls that neither wait for the device nor allocate — element-wise arithmetic, comparisons, bitmap / Kleene ops, copies and
+ * memsets, the *_dev flavours (ah_sum_*_dev, ah_cmp_filter_sum_*_dev, ah_filter_primitive_dev, ah_take_primitive_dev),
+ * ah_cumulative_sum without a null count — after ONE eager call of the same sequence (the scratch arenas get their size there).
+ * A call with a *_host result invalidates the capture; ah_graph_end then fails and nothing was run. */
+typedef struct ah_graph ah_graph;
+int ah_graph_begin(ah_ctx* ctx);
+int ah_graph_end(ah_ctx* ctx, ah_graph** out);
+int ah_graph_launch(ah_ctx* ctx, ah_graph* graph);
+int ah_graph_destroy(ah_graph* graph);
 /* pin / unpin memory the host already owns (hipHostRegister) — e.g. a Go []byte for the duration of one cgo call; copies from
  * pageable memory are staged by the runtime and overlap nothing */
 int ah_host_register(ah_ctx* ctx, void* hptr, size_t nbytes);

@@ -1721,3 +1721,66 @@ def test_power_floats_close(hip, orc_be, dtype):
             fin = np.isfinite(E)
             assert np.array_equal(G[~fin & ~np.isnan(E)], E[~fin & ~np.isnan(E)])
             assert np.all(np.abs(G[fin] - E[fin]) <= 4 * np.finfo(dtype).eps * np.abs(E[fin]) + np.finfo(dtype).tiny), np.max(np.abs(G[fin] - E[fin]) / np.maximum(np.abs(E[fin]), 1e-300))
+
+
+def test_graph_capture_replays_a_chain(ctx):
+    """ah_graph_begin / _end / _launch: an Add → Compare → bitmap AND → fused compare-filter-sum → Sum chain over a small column is
+    recorded once and replayed with new contents under the same pointers; every replay equals numpy on the contents of that
+    moment, and a call that has to wait for the device invalidates the capture instead of running half a sequence."""
+    import arrow_go_amd as ah
+    N = ah._native
+    rng = np.random.default_rng(77)
+    n = (1 << 16) + 77
+    thr = np.array([5], np.int64)
+    da, db = ctx.alloc(n * 8), ctx.alloc(n * 8)
+    dc = ctx.alloc(n * 8)
+    dmask, dother, dand = ctx.alloc(n // 8 + 64), ctx.alloc(n // 8 + 64), ctx.alloc(n // 8 + 64)
+    dfused, dsum = ctx.alloc(16), ctx.alloc(8)
+    other = rng.integers(0, 256, n // 8 + 64, dtype=np.uint8)
+    dother.upload(other)
+
+    def chain():
+        ctx.arithmetic(N.INT64, N.OP_ADD, N.SHAPE_AA, da, db, dc, n)
+        ctx.comparison(N.CMP_GT, N.SHAPE_AS, N.INT64, dc, thr, dmask, n, 0)
+        ctx.bitmap_op(N.BIT_AND, dmask, 0, dother, 0, dand, 0, n)
+        ctx.cmp_filter_sum_i64_dev(N.CMP_GT, dc, dother, 0, n, int(thr[0]), dfused)
+        ctx.sum_int64_dev(dc, n, dsum)
+
+    def check_against(a, b):
+        c = a + b
+        obits = np.unpackbits(other, bitorder="little")[:n].astype(bool)
+        assert dc.download(np.int64, n).tobytes() == c.tobytes()
+        got = np.unpackbits(dand.download(np.uint8, (n + 7) // 8), bitorder="little")[:n].astype(bool)
+        assert np.array_equal(got, (c > thr[0]) & obits)
+        fs = dfused.download(np.int64, 2)
+        sel = (c > thr[0]) & obits
+        assert int(fs[0]) == int(c[sel].sum()) and int(fs[1]) == int(sel.sum())
+        assert int(dsum.download(np.int64, 1)[0]) == int(c.sum())
+
+    a = rng.integers(-1000, 1000, n, dtype=np.int64); b = rng.integers(-1000, 1000, n, dtype=np.int64)
+    da.upload(a); db.upload(b)
+    chain()                                  # eager warm-up: the scratch arenas get their size
+    check_against(a, b)
+    ctx.graph_begin()
+    chain()
+    g = ctx.graph_end()
+    for seed in (1, 2, 3):
+        r2 = np.random.default_rng(seed)
+        a = r2.integers(-1000, 1000, n, dtype=np.int64); b = r2.integers(-1000, 1000, n, dtype=np.int64)
+        da.upload(a); db.upload(b)
+        dc.memset(0); dand.memset(0); dfused.memset(0); dsum.memset(0)
+        g.launch()
+        check_against(a, b)
+    g.close()
+    # a call with a host result cannot be recorded: the capture is dropped, the context stays usable
+    ctx.graph_begin()
+    with pytest.raises(ah.ArrowHipError):
+        ctx.sum_int64(dc, n)
+        ctx.graph_end()
+    try:
+        ctx.graph_end()
+    except ah.ArrowHipError:
+        pass
+    assert ctx.sum_int64(dc, n) == int((a + b).sum())
+    for d in (da, db, dc, dmask, dother, dand, dfused, dsum):
+        d.free()
