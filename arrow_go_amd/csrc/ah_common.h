@@ -68,6 +68,7 @@ struct ah_ctx {
   ah_filter_cache fcache;  // ah_filter.hip
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;
+  int opt_take_vec_nt;     // nontemporal hints of the clustered take (7 all, 5 index + output, 4 output, 0 none)
   // 2 × 8 words of coherent (fine-grained) pinned host memory kernels can store to: {value, sequence number} for ah_filter_count, {≤ 7 words, sequence number} for ah_mailbox_read.  A count the host
   // must see before it can go on (ah_filter_count) is polled here instead of paying a stream synchronisation's wake-up.
   unsigned long long* mailbox;

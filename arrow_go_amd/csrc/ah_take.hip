@@ -34,7 +34,8 @@ template <> struct UIntOf<2> { using type = uint16_t; };
 template <> struct UIntOf<4> { using type = uint32_t; };
 template <> struct UIntOf<8> { using type = uint64_t; };
 
-template <int W, typename IdxT, bool HAS_VALID>
+// NT: the index vector and the output are streamed once — nontemporal, so that they do not push the gathered values' lines out of L2
+template <int W, typename IdxT, bool HAS_VALID, bool NT>
 __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ values_v, const uint8_t* __restrict__ vvalid, int64_t voff,
                                                        uint64_t nvalues, const IdxT* __restrict__ idx, const uint8_t* __restrict__ ivalid,
                                                        int64_t ioff, int64_t nidx, void* __restrict__ out_v, uint8_t* __restrict__ out_valid,
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
       raw[k] = 0;
       ib[k] = 0xff;
       if (i < nidx) {
-        raw[k] = idx[i];
+        raw[k] = NT ? __builtin_nontemporal_load(&idx[i]) : idx[i];
         if (ivalid != nullptr) ib[k] = ivalid[(ioff + i) >> 3];
       }
     }
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       const int64_t i = base + (int64_t)k * kBlock;
-      if (i < nidx) out[i] = v[k];
+      if (i < nidx) {
+        if (NT) __builtin_nontemporal_store(v[k], &out[i]);
+        else out[i] = v[k];
+      }
       if (HAS_VALID) {
         uint64_t word = __ballot(ok[k]);
         const int64_t i0 = i - lane;  // first row of this wave's 64 (multiple of 64)
@@ -128,6 +132,27 @@ __global__ __launch_bounds__(kBlock) void take_kernel(const void* __restrict__ v
 // decision: loop shape only).  Chosen when the 64 × 255 neighbour sample of ah_take_binned.hip says "clustered".
 template <typename IdxT, int V>
 struct alignas(sizeof(IdxT)) IdxVec { IdxT v[V]; };
+// the same 16 (or V·sizeof(IdxT)) bytes as a native vector of element alignment: what __builtin_nontemporal_load/store accept.  The
+// columns of a clustered take are streamed once — without the hint the index vector and the output evict the values' lines from L2
+template <typename T, int V>
+using TakeRaw __attribute__((aligned(sizeof(T)))) = T __attribute__((ext_vector_type(V)));
+template <typename S, typename T, int V>
+__device__ __forceinline__ S take_ld(const T* p, bool nt) {
+  static_assert(sizeof(S) == sizeof(T) * V, "carrier size");
+  if (nt) {
+    const TakeRaw<T, V> raw = __builtin_nontemporal_load(reinterpret_cast<const TakeRaw<T, V>*>(p));
+    S r;
+#pragma unroll
+    for (int j = 0; j < V; j++) r.v[j] = raw[j];
+    return r;
+  }
+  return *reinterpret_cast<const S*>(p);
+}
+template <typename S, typename T, int V>
+__device__ __forceinline__ void take_st(T* p, const S& x, bool nt) {
+  if (nt) __builtin_nontemporal_store(__builtin_bit_cast(TakeRaw<T, V>, x), reinterpret_cast<TakeRaw<T, V>*>(p));
+  else *reinterpret_cast<S*>(p) = x;
+}
 #ifndef AH_TAKE_VEC_STEPS
 #define AH_TAKE_VEC_STEPS 1
 #endif
@@ -136,7 +161,7 @@ constexpr int kVecSteps = AH_TAKE_VEC_STEPS;   // steps per workgroup
 template <int CTRL>
 __device__ __forceinline__ unsigned take_dpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
 
-template <int W, typename IdxT, bool HAS_VALID>
+template <int W, typename IdxT, bool HAS_VALID, int NT>
 __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict__ values_v, const uint8_t* __restrict__ vvalid, int64_t voff,
                                                            uint64_t nvalues, const IdxT* __restrict__ idx, const uint8_t* __restrict__ ivalid,
                                                            int64_t ioff, int64_t nidx, void* __restrict__ out_v, uint8_t* __restrict__ out_valid,
@@ -144,6 +169,8 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
   using T = typename UIntOf<W>::type;
   using UIdx = typename std::make_unsigned<IdxT>::type;
   constexpr int V = 16 / W;          // rows per lane (2 or 4)
+  const int64_t vbytes = (voff + (int64_t)nvalues + 7) >> 3;   // bytes of the value validity bitmap
+  constexpr bool nt_idx = NT & 1, nt_val = NT & 2, nt_out = NT & 4;   // (a run-time switch would be merged away: the two loads of one address fold into a plain one)
   constexpr int K = 4;               // groups per lane per step: 4 index loads, then 4 value loads in flight
   constexpr unsigned kAll = (1u << V) - 1u;
   const T* __restrict__ values = (const T*)values_v;
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
     for (int k = 0; k < K; k++) {
       const int64_t r = (gb + (int64_t)k * kBlock) * V;
       if (r + V <= nidx) {
-        ivn[k] = *reinterpret_cast<const IdxVec<IdxT, V>*>(idx + r);
+        ivn[k] = take_ld<IdxVec<IdxT, V>, IdxT, V>(idx + r, nt_idx);
       } else {
 #pragma unroll
         for (int j = 0; j < V; j++) ivn[k].v[j] = r + j < nidx ? idx[r + j] : (IdxT)0;
@@ -221,10 +248,19 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
     for (int k = 0; k < K; k++) {
       vbits[k] = kAll;
       if (merged[k]) {
-        const ah_vec16<T> t = *reinterpret_cast<const ah_vec16<T>*>(values + lo[k]);
+        const ah_vec16<T> t = take_ld<ah_vec16<T>, T, V>(values + lo[k], nt_val);
         unsigned b = 0xffffu;
         const int64_t p = voff + (int64_t)lo[k];   // validity bits p … p + V − 1: one byte, or two neighbours
-        if (HAS_VALID && vvalid != nullptr) b = (unsigned)vvalid[p >> 3] | ((unsigned)vvalid[(p + V - 1) >> 3] << 8);
+        if (HAS_VALID && vvalid != nullptr) {
+          const int64_t by = p >> 3;
+          if (by + 1 < vbytes) {   // one unaligned 2-byte load (byte loads cost a request each: 8 per lane and step were the nulls path's gap)
+            uint16_t h;
+            __builtin_memcpy(&h, vvalid + by, 2);
+            b = h;
+          } else {
+            b = (unsigned)vvalid[by] | ((unsigned)vvalid[(p + V - 1) >> 3] << 8);
+          }
+        }
         unsigned vb = 0;
 #pragma unroll
         for (int j = 0; j < V; j++) {
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
       for (int j = 0; j < V; j++)
         if (!((good >> j) & 1u)) x[k].v[j] = 0;   // a null output keeps payload 0 (:959-973)
       if (r + V <= nidx) {
-        *reinterpret_cast<ah_vec16<T>*>(out + r) = x[k];
+        take_st<ah_vec16<T>, T, V>(out + r, x[k], nt_out);
       } else {
 #pragma unroll
         for (int j = 0; j < V; j++) if (r + j < nidx) out[r + j] = x[k].v[j];
@@ -283,23 +319,38 @@ int launch_take(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t vo
     if (c->take_clustered_hint) {   // set by the neighbour sample of ah_take_binned_try: adjacent index slots mostly name adjacent values
       constexpr int V = 16 / W;
       const unsigned vgrid = ah_stream_grid(c, ah_ceil_div(ah_ceil_div(ah_ceil_div(nidx, V), (int64_t)kBlock * 4), kVecSteps), 0);
-      if (out_valid)
-        take_vec_kernel<W, IdxT, true><<<vgrid, kBlock, 0, c->stream>>>(values, vvalid, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
-                                                                        nidx, out_values, out_valid, first_bad);
-      else
-        take_vec_kernel<W, IdxT, false><<<vgrid, kBlock, 0, c->stream>>>(values, nullptr, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
-                                                                         nidx, out_values, nullptr, first_bad);
+      auto go = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        if (out_valid)
+          take_vec_kernel<W, IdxT, true, NT><<<vgrid, kBlock, 0, c->stream>>>(values, vvalid, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
+                                                                              nidx, out_values, out_valid, first_bad);
+        else
+          take_vec_kernel<W, IdxT, false, NT><<<vgrid, kBlock, 0, c->stream>>>(values, nullptr, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
+                                                                               nidx, out_values, nullptr, first_bad);
+      };
+      // option take_vec_nt (measurement switch): 7 = every stream nontemporal (default), 5 = index + output, 4 = output only, 0 = none
+      switch (c->opt_take_vec_nt) {
+        case 0: go(std::integral_constant<int, 0>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 5: go(std::integral_constant<int, 5>{}); break;
+        default: go(std::integral_constant<int, 7>{}); break;
+      }
       AH_LAUNCH_CHECK(c);
       return AH_OK;
     }
   }
   unsigned grid = ah_stream_grid(c, ah_ceil_div(nidx, (int64_t)kBlock * kUnroll));
-  if (out_valid)
-    take_kernel<W, IdxT, true><<<grid, kBlock, 0, c->stream>>>(values, vvalid, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
-                                                               nidx, out_values, out_valid, first_bad, valid_total);
-  else
-    take_kernel<W, IdxT, false><<<grid, kBlock, 0, c->stream>>>(values, nullptr, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
-                                                                nidx, out_values, nullptr, first_bad, valid_total);
+  const bool nt = c->opt_take_vec_nt != 0 && nidx * (int64_t)W >= ((int64_t)8 << 20);   // small outputs stay in L2 for their consumer
+  auto go = [&](auto nt_tag) {
+    constexpr bool NT = decltype(nt_tag)::value;
+    if (out_valid)
+      take_kernel<W, IdxT, true, NT><<<grid, kBlock, 0, c->stream>>>(values, vvalid, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
+                                                                     nidx, out_values, out_valid, first_bad, valid_total);
+    else
+      take_kernel<W, IdxT, false, NT><<<grid, kBlock, 0, c->stream>>>(values, nullptr, voff, (uint64_t)nvalues, (const IdxT*)idx, ivalid, ioff,
+                                                                      nidx, out_values, nullptr, first_bad, valid_total);
+  };
+  if (nt) go(std::true_type{}); else go(std::false_type{});
   AH_LAUNCH_CHECK(c);
   return AH_OK;
 }
