@@ -172,6 +172,8 @@ int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t*
 // mailbox — a cheaper "I need this number before I go on" than a copy + stream synchronisation.  Everything enqueued before it has
 // completed when it returns, like a synchronisation of the stream up to that point.
 int ah_mailbox_read(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, unsigned long long* out_host);
+int ah_mailbox_read2(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, const unsigned long long* dev_words2, int nwords2,
+                     unsigned long long* out_host);
 // Grow-only scratch arena. Contents are undefined after the call.
 int ah_scratch_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // A second grow-only arena for entry points that call a scratch user (the scan) while their own temporaries are
@@ -204,6 +206,27 @@ template <typename T>
 struct alignas(sizeof(T)) ah_vec16 {
   T v[16 / sizeof(T)];
 };
+
+// 16 bytes at ELEMENT alignment with a nontemporal hint.  Through a native vector type and element-wise moves: a __builtin_bit_cast
+// of the loaded vector to the carrier struct compiles to a plain load (seen in the ISA of the first clustered-take kernel), and so
+// does a run-time choice between a hinted and a plain access of one address — make the hint a template parameter.
+template <typename T>
+using ah_raw16 __attribute__((aligned(sizeof(T)))) = T __attribute__((ext_vector_type(16 / sizeof(T))));
+template <typename T>
+__device__ __forceinline__ ah_vec16<T> ah_ld16_nt(const T* p) {
+  const ah_raw16<T> raw = __builtin_nontemporal_load(reinterpret_cast<const ah_raw16<T>*>(p));
+  ah_vec16<T> r;
+#pragma unroll
+  for (int j = 0; j < (int)(16 / sizeof(T)); j++) r.v[j] = raw[j];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void ah_st16_nt(T* p, const ah_vec16<T>& x) {
+  ah_raw16<T> raw;
+#pragma unroll
+  for (int j = 0; j < (int)(16 / sizeof(T)); j++) raw[j] = x.v[j];
+  __builtin_nontemporal_store(raw, reinterpret_cast<ah_raw16<T>*>(p));
+}
 
 template <typename T>
 __device__ __forceinline__ T ah_wave_sum(T v) {

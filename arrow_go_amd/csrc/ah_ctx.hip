@@ -134,17 +134,24 @@ AH_EXPORT const char* ah_last_error(ah_ctx* c) { return c ? c->err : "null conte
 // ---- a few device words the host must see before it can go on: posted to coherent pinned memory by a one-thread kernel and polled,
 // instead of hipMemcpyAsync + hipStreamSynchronize (whose wake-up costs ≈ 15 µs: more than many of the passes it sits between)
 namespace {
-__global__ void mailbox_post_kernel(const unsigned long long* __restrict__ src, int nwords, unsigned long long* mailbox, unsigned long long seq) {
+__global__ void mailbox_post_kernel(const unsigned long long* __restrict__ src, int nwords, const unsigned long long* __restrict__ src2, int nwords2,
+                                    unsigned long long* mailbox, unsigned long long seq) {
   for (int i = 0; i < nwords; i++) __hip_atomic_store(&mailbox[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int i = 0; i < nwords2; i++) __hip_atomic_store(&mailbox[nwords + i], src2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&mailbox[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
 int ah_mailbox_read(ah_ctx* c, const unsigned long long* dev_words, int nwords, unsigned long long* out_host) {
-  if (nwords < 1 || nwords > 7) return ah_fail(c, AH_EINVALID, "mailbox_read: 1..7 words");
+  return ah_mailbox_read2(c, dev_words, nwords, nullptr, 0, out_host);
+}
+// words from two places (a count in one arena, a flag in another) in one post
+int ah_mailbox_read2(ah_ctx* c, const unsigned long long* dev_words, int nwords, const unsigned long long* dev_words2, int nwords2,
+                     unsigned long long* out_host) {
+  if (nwords < 1 || nwords2 < 0 || nwords + nwords2 > 7) return ah_fail(c, AH_EINVALID, "mailbox_read: 1..7 words");
   if (c->capturing) { c->capturing = 2; return ah_fail(c, AH_EINVALID, "this call returns a value to the host: it cannot be recorded into a graph"); }
   unsigned long long* mb = c->mailbox + 8;   // the second half: the first belongs to ah_filter_count
   const unsigned long long seq = ++c->mailbox_seq;
-  mailbox_post_kernel<<<1, 1, 0, c->stream>>>(dev_words, nwords, mb, seq);
+  mailbox_post_kernel<<<1, 1, 0, c->stream>>>(dev_words, nwords, dev_words2, nwords2, mb, seq);
   AH_LAUNCH_CHECK(c);
   bool seen = false;
   const auto t0 = std::chrono::steady_clock::now();
@@ -157,7 +164,7 @@ int ah_mailbox_read(ah_ctx* c, const unsigned long long* dev_words, int nwords, 
     AH_HIP(c, hipStreamSynchronize(c->stream));
     if (__atomic_load_n(&mb[7], __ATOMIC_ACQUIRE) != seq) return ah_fail(c, AH_EHIP, "mailbox_read: the post kernel did not report");
   }
-  for (int i = 0; i < nwords; i++) out_host[i] = __atomic_load_n(&mb[i], __ATOMIC_RELAXED);
+  for (int i = 0; i < nwords + nwords2; i++) out_host[i] = __atomic_load_n(&mb[i], __ATOMIC_RELAXED);
   return AH_OK;
 }
 
