@@ -68,6 +68,9 @@ struct ah_ctx {
   ah_filter_cache fcache;  // ah_filter.hip
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;
+  int opt_encode_dict_compact;  // partition-first encode: the dictionary = the key column compacted by the first-occurrence bitmap (0 never, 1 from 1024 partitions on, 2 always)
+  int opt_encode_table_batch;   // partition-first encode: the table pass probes its four records' first groups together (1) or one by one (0)
+  int opt_encode_unperm_group;  // partition-first encode: tiles per workgroup in the final un-permute (1 or 4)
   int opt_take_vec_nt;     // nontemporal hints of the clustered take (7 all, 5 index + output, 4 output, 0 none)
   // 2 × 8 words of coherent (fine-grained) pinned host memory kernels can store to: {value, sequence number} for ah_filter_count, {≤ 7 words, sequence number} for ah_mailbox_read.  A count the host
   // must see before it can go on (ah_filter_count) is polled here instead of paying a stream synchronisation's wake-up.
@@ -171,6 +174,7 @@ int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t*
 // internal (ah_ctx.hip): 1..7 device words (8 bytes each, written by work already on the compute stream) → host, through the polled
 // mailbox — a cheaper "I need this number before I go on" than a copy + stream synchronisation.  Everything enqueued before it has
 // completed when it returns, like a synchronisation of the stream up to that point.
+int ah_compact_u64_by_bits(ah_ctx* ctx, const uint64_t* values, const uint8_t* bits, int64_t n, uint64_t* out_values, int64_t* out_rows);   // ah_filter.hip
 int ah_mailbox_read(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, unsigned long long* out_host);
 int ah_mailbox_read2(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, const unsigned long long* dev_words2, int nwords2,
                      unsigned long long* out_host);

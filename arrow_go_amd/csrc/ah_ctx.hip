@@ -49,6 +49,9 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_scan_segment_log2 = env_int("ARROWHIP_SCAN_SEGMENT_LOG2", 0);   // 0 = one segment: segments measured slower
   c->opt_take_gather_lds = env_int("ARROWHIP_TAKE_GATHER_LDS", 1);   // 1: the window's validity bits in LDS (ah_take_binned.hip)
   c->opt_take_vec_nt = env_int("ARROWHIP_TAKE_VEC_NT", 7);
+  c->opt_encode_unperm_group = env_int("ARROWHIP_ENCODE_UNPERM_GROUP", 4);
+  c->opt_encode_table_batch = env_int("ARROWHIP_ENCODE_TABLE_BATCH", 1);
+  c->opt_encode_dict_compact = env_int("ARROWHIP_ENCODE_DICT_COMPACT", 1);
   c->opt_take_vec = env_int("ARROWHIP_TAKE_VEC", 1);   // 0: one row per lane always, 1: V rows per lane when the sample says clustered, 2: always
   c->opt_take_gather_load = env_int("ARROWHIP_TAKE_GATHER_LOAD", 0);   // 0 plain, 1 nontemporal, 2 L1-bypassing (sc1)
   return AH_OK;
@@ -116,6 +119,9 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "take_gather_lds")) c->opt_take_gather_lds = (int)value;
   else if (!strcmp(name, "take_vec")) c->opt_take_vec = (int)value;
   else if (!strcmp(name, "take_vec_nt")) c->opt_take_vec_nt = (int)value;
+  else if (!strcmp(name, "encode_unperm_group")) c->opt_encode_unperm_group = (int)value;
+  else if (!strcmp(name, "encode_table_batch")) c->opt_encode_table_batch = (int)value;
+  else if (!strcmp(name, "encode_dict_compact")) c->opt_encode_dict_compact = (int)value;
   else if (!strcmp(name, "take_gather_load")) c->opt_take_gather_load = (int)value;
   else if (!strcmp(name, "groupby_partition")) c->opt_groupby_partition = (int)value;
   else if (!strcmp(name, "groupby_keys")) c->opt_groupby_keys = (int)value;

@@ -523,6 +523,23 @@ AH_EXPORT int ah_filter_primitive_dev(ah_ctx* c, int byte_width, const void* val
   return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);
 }
 
+// internal (ah_hash_part.hip): out_values[j] = values[r], out_rows[j] = r for the set bits r of `bits` (bit 0 of byte 0 = row 0) in ascending
+// order — a dictionary in first-occurrence order is the key column compacted by its "first occurrence" bitmap.  No host round trip.
+int ah_compact_u64_by_bits(ah_ctx* c, const uint64_t* values, const uint8_t* bits, int64_t n, uint64_t* out_values, int64_t* out_rows) {
+  if (n <= 0 || (!out_values && !out_rows)) return AH_OK;
+  // the tile prefixes go to the filter cache's block, NOT to the scratch arena: the caller (the encode in progress) keeps a table there
+  // that it returns to if the partition-first attempt is abandoned
+  int* tile_local; int64_t* super_off; int64_t* total; int64_t ntiles;
+  int rc = run_counts<8>(c, bits, nullptr, 0, n, 0, &tile_local, &super_off, &total, &ntiles, /*to_cache=*/true, ++c->mailbox_seq);
+  c->fcache.valid = false;   // this call's own tables, not a count left for a fill
+  if (rc != AH_OK) return rc;
+  unsigned long long* unused = (unsigned long long*)&c->dscalars[2];
+  if (out_values) launch_compact<8, false, false>(c, ntiles, values, nullptr, 0, bits, nullptr, 0, n, 0, super_off, tile_local, out_values, nullptr, unused);
+  if (out_rows) launch_compact<8, false, true>(c, ntiles, nullptr, nullptr, 0, bits, nullptr, 0, n, 0, super_off, tile_local, out_rows, nullptr, unused);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
+
 AH_EXPORT int ah_filter_to_indices(ah_ctx* c, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,
                                    int null_sel, int64_t n_out, uint32_t* out_idx, uint8_t* out_valid,
                                    int64_t* out_null_count_host) {

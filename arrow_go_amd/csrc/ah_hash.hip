@@ -833,7 +833,9 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
             if (est / (double)(1 << lp) > kpp1) {
               lp = 11;
               while (lp < 13 && est / (double)(1 << lp) > 2200.0) lp++;
-              if (est / (double)(1 << lp) > 2200.0) slots2 = 8192;   // 18 … 36 M keys: 8192 partitions with the large tables
+              // 21 … 36 M keys: 8192 partitions with the large tables.  (The small ones take 3072 keys; 2600 expected leaves room for the
+              // estimate's ± 9 % at this cardinality — 128 repeats among the 2^16 sampled rows — and the partitions' own spread.)
+              if (est / (double)(1 << lp) > 2600.0) slots2 = 8192;
             }
             bool done;
             int prc = try_partitioned(lp, &done, slots2);
@@ -852,7 +854,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
         const double est = estimate_distinct((double)d0, (double)prefix, (double)n);
         if (est <= 8192.0 * 4400.0) {
           bool done;
-          int prc = try_partitioned(13, &done, est / 8192.0 > 2200.0 ? 8192 : 4096);
+          int prc = try_partitioned(13, &done, est / 8192.0 > 2600.0 ? 8192 : 4096);
           if (prc != AH_OK || done) return prc;
         }
       }

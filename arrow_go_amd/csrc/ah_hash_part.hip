@@ -50,7 +50,7 @@ __device__ __forceinline__ unsigned enc_group(unsigned long long key) {   // fir
 }
 
 // ---- 3: one workgroup per partition ------------------------------------------------------------------------------------------
-template <int S>
+template <int S, bool BATCH>
 __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long long* __restrict__ pkeys, const unsigned* __restrict__ prows,
                                                               const unsigned* __restrict__ binstart, int encode_nulls,
                                                               unsigned long long* __restrict__ tab_key, unsigned* __restrict__ tab_first,
@@ -112,6 +112,75 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
 #pragma unroll
     for (int u = 0; u < U; u++) { k[u] = nk[u]; rw[u] = nrw[u]; }
     if (b + kStep < r1) load_step(b + kStep);
+    if constexpr (BATCH) {
+    // Most records find their key where the table already has it (a partition holds ~4096 keys and 64 × as many records), so the
+    // U records' first slot groups are read TOGETHER — 2 U ds_read_b128 in flight, one wait — and only a record whose key is not
+    // in front of the first empty slot of its group (a new key, or a probe sequence that goes on) takes the serial find-or-claim
+    // loop.  One record at a time, the pass spent half its wave cycles parked on LDS round trips (4 waves per SIMD: a partition
+    // is one workgroup, 256 partitions one workgroup per CU).
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    unsigned g[U];
+    u64x2 qa[U], qc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) g[u] = enc_group<S>(k[u]);
+    static_assert(U == 4, "the batched probe below is written for four records");
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
+        "ds_read_b128 %2, %9\n\tds_read_b128 %3, %9 offset:16\n\t"
+        "ds_read_b128 %4, %10\n\tds_read_b128 %5, %10 offset:16\n\t"
+        "ds_read_b128 %6, %11\n\tds_read_b128 %7, %11 offset:16\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(qa[0]), "=&v"(qc[0]), "=&v"(qa[1]), "=&v"(qc[1]), "=&v"(qa[2]), "=&v"(qc[2]), "=&v"(qa[3]), "=&v"(qc[3])
+        : "v"(lkey_base + g[0] * 8u), "v"(lkey_base + g[1] * 8u), "v"(lkey_base + g[2] * 8u), "v"(lkey_base + g[3] * 8u)
+        : "memory");
+    int js[U];
+    unsigned rows[U];
+    unsigned pend = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      rows[u] = rw[u] & kRowMask;
+      int j = -3;   // −3: not a record of this partition
+      if (i < r1) {
+        const unsigned long long key = k[u];
+        if (rw[u] & kKeyNull) j = encode_nulls ? S + 1 : -2;
+        else if (key == kEmpty) j = S;
+        else if (p_slot >= 0 && p_key == key) j = p_slot;
+        else {
+          const bool h0 = qa[u].x == key, h1 = qa[u].y == key, h2 = qc[u].x == key, h3 = qc[u].y == key;
+          const bool e0 = qa[u].x == kEmpty, e1 = qa[u].y == kEmpty, e2 = qc[u].x == kEmpty;
+          if (h0 || (!e0 && (h1 || (!e1 && (h2 || (!e2 && h3)))))) j = (int)g[u] + (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3);
+          else { j = -4; pend |= 1u << u; }   // −4: to the find-or-claim loop below
+          p_key = key; p_slot = j;            // (a pending slot is negative: the next record does not reuse it)
+        }
+      }
+      js[u] = j;
+    }
+    // the stragglers of all U records in ONE divergent phase: some lane of a wave always has one (a twentieth of the records × 64
+    // lanes), so a per-record fallback would run the serial loop for every record after all
+    while (pend) {
+      const int u = __builtin_ctz(pend);
+      pend &= pend - 1;
+      const unsigned long long key = u == 0 ? k[0] : u == 1 ? k[1] : u == 2 ? k[2] : k[3];
+      const int j = slot_of(key);
+      if (u == 0) js[0] = j; else if (u == 1) js[1] = j; else if (u == 2) js[2] = j; else js[3] = j;
+      if (key == p_key) p_slot = j;
+    }
+    unsigned fr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) fr[u] = js[u] >= 0 ? l_first[js[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      const int j = js[u];
+      if (j >= 0) {
+        if (fr[u] > rows[u]) atomicMin(&l_first[j], rows[u]);   // rows of a key arrive mostly in ascending order: a read is half an atomic
+      } else if (j == -1) {
+        full = true;
+      }
+      if (rec_slot && j != -3) rec_slot[i] = j >= 0 ? (unsigned short)j : kMaskedSlot;
+    }
+    } else {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t i = b + u * kThreads + t;
@@ -128,6 +197,7 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
         full = true;
       }
       if (rec_slot) rec_slot[i] = j >= 0 ? (unsigned short)j : kMaskedSlot;
+    }
     }
   }
   if (full) atomicExch(overflow, 1u);
@@ -146,29 +216,94 @@ __global__ __launch_bounds__(kBlock) void enc_assign_kernel(const unsigned long 
                                                              const unsigned long long* __restrict__ firsts, const unsigned* __restrict__ wordprefix,
                                                              const int64_t* __restrict__ tileoff, unsigned long long* __restrict__ dict,
                                                              long long* __restrict__ first_rows, int* __restrict__ null_id, int slots) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
-    const unsigned fr = tab_first[s];
-    if (fr == kNoRow) continue;
-    const unsigned id = rank_of_row(fr, firsts, wordprefix, tileoff);
-    tab_first[s] = id;
-    const int in_part = (int)(s % (slots + 8));
-    unsigned long long key = tab_key[s];
-    if (in_part == slots) key = kEmpty;
-    if (in_part == slots + 1) { key = 0; *null_id = (int)id; }   // GetDictArrayData: the null slot keeps the fresh buffer's zero
-    if (dict) dict[id] = key;
-    if (first_rows) first_rows[id] = (long long)fr;
+  // four slots per lane, their chains (first row → bitmap word, word prefix, tile offset → id → three scattered stores) side by
+  // side: one slot per iteration left every wave with a single dependent chain of five round trips (2^24 keys: 1.0 ms for this pass)
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * U;
+  for (int64_t s0 = (int64_t)blockIdx.x * kBlock * U + threadIdx.x; s0 < nslots; s0 += stride) {
+    unsigned fr[U], id[U];
+    unsigned long long key[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t s = s0 + (int64_t)u * kBlock;
+      fr[u] = s < nslots ? tab_first[s] : kNoRow;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t s = s0 + (int64_t)u * kBlock;
+      id[u] = 0; key[u] = 0;
+      if (fr[u] != kNoRow) {
+        id[u] = rank_of_row(fr[u], firsts, wordprefix, tileoff);
+        key[u] = tab_key[s];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t s = s0 + (int64_t)u * kBlock;
+      if (fr[u] == kNoRow) continue;
+      tab_first[s] = id[u];
+      const int in_part = (int)(s % (slots + 8));
+      unsigned long long k = key[u];
+      if (in_part == slots) k = kEmpty;
+      if (in_part == slots + 1) { k = 0; *null_id = (int)id[u]; }   // GetDictArrayData: the null slot keeps the fresh buffer's zero
+      if (dict) dict[id[u]] = k;
+      if (first_rows) first_rows[id[u]] = (long long)fr[u];
+    }
   }
+}
+
+// the null entry: its id (when no assign pass ran: from the null slot of table 0, where all null keys went) and its dictionary value —
+// GetDictArrayData leaves the fresh buffer's zero there, whatever bits the first null row holds
+__global__ void enc_null_entry_kernel(const unsigned* __restrict__ tab_first, int slots, int need_rank, const unsigned long long* __restrict__ firsts,
+                                      const unsigned* __restrict__ wordprefix, const int64_t* __restrict__ tileoff, int* __restrict__ null_id,
+                                      unsigned long long* __restrict__ dict) {
+  if (need_rank) {
+    const unsigned fr = tab_first[slots + 1];
+    if (fr != kNoRow) *null_id = (int)rank_of_row(fr, firsts, wordprefix, tileoff);
+  }
+  const int id = *null_id;
+  if (id >= 0 && dict) dict[id] = 0;
+}
+
+// ids of the slots + the dictionary (and the first rows) in id order.  compact = false: every used slot writes its key to dict[id] —
+// ids follow first rows, so these are scattered 8-byte stores, two per key, behind two scattered reads (2^24 keys: 0.87 ms).
+// compact = true: the dictionary is the key column itself compacted by the first-occurrence bitmap (ah_filter.hip: tiles without a
+// first occurrence are never fetched, the output leaves as whole lines), and the slots only look their ids up — or nothing at
+// all when the caller wants no ids (unique).
+int enc_emit(ah_ctx* c, bool compact, bool need_ids, const unsigned long long* tab_key, unsigned* tab_first, int64_t nslots, const unsigned long long* firsts,
+             const unsigned* wordprefix, const int64_t* tileoff, const uint64_t* keys, int64_t n, uint64_t* out_dict, int64_t* out_first_rows, int* null_id,
+             int slots) {
+  const unsigned agrid = ah_stream_grid(c, ah_ceil_div(nslots, (int64_t)kBlock * 4));
+  if (!compact) {
+    enc_assign_kernel<<<agrid, kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (unsigned long long*)out_dict,
+                                                       (long long*)out_first_rows, null_id, slots);
+    AH_LAUNCH_CHECK(c);
+    return AH_OK;
+  }
+  int rc = ah_compact_u64_by_bits(c, keys, (const uint8_t*)firsts, n, out_dict, out_first_rows);
+  if (rc != AH_OK) return rc;
+  if (need_ids) {
+    enc_assign_kernel<<<agrid, kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff, nullptr, nullptr, null_id, slots);
+    AH_LAUNCH_CHECK(c);
+  }
+  enc_null_entry_kernel<<<1, 1, 0, c->stream>>>(tab_first, slots, need_ids ? 0 : 1, firsts, wordprefix, tileoff, null_id, (unsigned long long*)out_dict);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
 }
 
 // ---- 5: slot numbers → ids, in partition order ---------------------------------------------------------------------------------
 template <int S>
 __global__ __launch_bounds__(kThreads) void enc_resolve_kernel(const unsigned short* __restrict__ rec_slot, const unsigned* __restrict__ tab_id,
-                                                                const unsigned* __restrict__ binstart, int* __restrict__ rec_id) {
+                                                                const unsigned* __restrict__ binstart, int* __restrict__ rec_id, int split) {
   constexpr int kLS = S + 2, kStride = S + 8;
   __shared__ unsigned l_id[kLS];
-  const int t = threadIdx.x, part = blockIdx.x;
-  const int64_t r0 = binstart[part], r1 = binstart[part + 1];
+  // `split` workgroups share a partition's records (each loads the partition's 32 KiB id table): with one workgroup per
+  // partition 256 partitions put 16 waves on a CU and the pass waited on memory 90 % of its time (2.4 TB/s)
+  const int t = threadIdx.x, part = blockIdx.x / split, piece = blockIdx.x % split;
+  const int64_t p0 = binstart[part], p1 = binstart[part + 1];
+  const int64_t per = (((p1 - p0 + split - 1) / split) + 63) & ~(int64_t)63;
+  const int64_t r0 = p0 + piece * per, r1 = r0 + per < p1 ? r0 + per : p1;
+  if (r0 >= r1) return;
   for (int j = t; j < kLS; j += kThreads) l_id[j] = tab_id[(int64_t)part * kStride + j];
   __syncthreads();
   constexpr int U = 8;
@@ -244,6 +379,88 @@ __global__ __launch_bounds__(kThreads) void enc_unpermute_kernel(const int* __re
   }
 }
 
+// The same for G CONSECUTIVE tiles per workgroup.  Inside a partition the runs of consecutive tiles lie one after the other, so the
+// group's records of a partition are ONE run G times as long (256 partitions: 16 records = 64 bytes per tile, 256 bytes per group
+// of four) — the per-tile kernel read 64-byte pieces at 2.3 TB/s.  The group's ids are staged in LDS (G · 16 KiB) and leave as whole
+// lines.
+template <int G>
+__global__ __launch_bounds__(kThreads) void enc_unpermute_group_kernel(const int* __restrict__ rec_id, const unsigned* __restrict__ prows,
+                                                                       const unsigned* __restrict__ cnt_tm, const unsigned* __restrict__ toffs, int nb,
+                                                                       int64_t ntiles, int64_t n, int32_t* __restrict__ out_ids) {
+  __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_goff[kMaxBins], s_wsum[kThreads / 64];
+  __shared__ int s_out[G * kGbTile];
+  const int64_t ngroups = (ntiles + G - 1) / G;
+  const int64_t grp = xcd_contiguous_tile(ngroups);
+  if (grp < 0) return;
+  const int64_t tile0 = grp * G;
+  unsigned excl = 0, cnt = 0;
+  if ((int)threadIdx.x < nb) {
+    excl = toffs[tile0 * nb + threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+      if (tile0 + g < ntiles) cnt += cnt_tm[(tile0 + g) * nb + threadIdx.x];
+  }
+  s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  if ((int)threadIdx.x < nb) s_goff[threadIdx.x] = excl - s_start[threadIdx.x];
+  __syncthreads();
+  const int64_t base = tile0 * kGbTile;
+  const int grp_n = n - base >= (int64_t)G * kGbTile ? G * kGbTile : (int)(n - base);
+#pragma unroll 1
+  for (int c = 0; c < G; c++) {
+    int lo[kGbRows], hi[kGbRows];
+#pragma unroll
+    for (int k = 0; k < kGbRows; k++) { lo[k] = 0; hi[k] = nb - 1; }
+#pragma unroll 1
+    for (int step = 0; step < 10; step++) {   // 2^10 = kMaxBins
+#pragma unroll
+      for (int k = 0; k < kGbRows; k++) {
+        const int mid = (lo[k] + hi[k] + 1) >> 1;
+        const bool le = s_start[mid] <= (unsigned)(c * kGbTile + k * kThreads + threadIdx.x);
+        lo[k] = le ? mid : lo[k];
+        hi[k] = le ? hi[k] : mid - 1;
+      }
+    }
+    int id[kGbRows];
+    unsigned rw[kGbRows];
+#pragma unroll
+    for (int k = 0; k < kGbRows; k++) {
+      const int lp = c * kGbTile + k * kThreads + threadIdx.x;
+      id[k] = 0; rw[k] = 0;
+      if (lp < grp_n) {
+        const int64_t e = (int64_t)s_goff[lo[k]] + lp;
+        id[k] = __builtin_nontemporal_load(&rec_id[e]);
+        rw[k] = __builtin_nontemporal_load(&prows[e]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kGbRows; k++)
+      if (c * kGbTile + k * kThreads + (int)threadIdx.x < grp_n) s_out[(int64_t)(rw[k] & kRowMask) - base] = id[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < G * kGbRows; k++) {
+    const int i = k * kThreads + threadIdx.x;
+    if (i < grp_n) __builtin_nontemporal_store(s_out[i], &out_ids[base + i]);
+  }
+}
+
+void launch_enc_unpermute(ah_ctx* c, const int* rec_id, const unsigned* prows, const unsigned* cnt_tm, const unsigned* toffs, int nb, int64_t ntiles,
+                          int64_t n, int32_t* out_ids) {
+  const int G = c->opt_encode_unperm_group;
+  if (G > 1) {
+    const int g = G >= 8 ? 8 : (G >= 4 ? 4 : 2);
+    const int64_t ngroups = (ntiles + g - 1) / g;
+    const unsigned grid = (unsigned)(((ngroups + 7) / 8) * 8);
+    if (g == 8) enc_unpermute_group_kernel<8><<<grid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, nb, ntiles, n, out_ids);
+    else if (g == 4) enc_unpermute_group_kernel<4><<<grid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, nb, ntiles, n, out_ids);
+    else enc_unpermute_group_kernel<2><<<grid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, nb, ntiles, n, out_ids);
+  } else {
+    enc_unpermute_kernel<<<(unsigned)(((ntiles + 7) / 8) * 8), kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, nb, ntiles, n, out_ids);
+  }
+}
+
 
 // ---- more than 1024 partitions: a second cut ---------------------------------------------------------------------------------------
 // Beyond ≈ 4.5 M keys 1024 LDS tables are not enough, and one scatter into thousands of partitions would write runs of one or two
@@ -268,7 +485,8 @@ __global__ __launch_bounds__(kThreads) void e2_hist_kernel(const unsigned long l
 #pragma unroll
   for (int u = 0; u < kMsRows; u++) {
     const int64_t i = r.lo + u * kThreads + threadIdx.x;
-    if (i < r.hi) atomicAdd(&s_h[e2_digit(__builtin_nontemporal_load(&pkeys[i]), __builtin_nontemporal_load(&prows[i]), lp, mask)], 1u);
+    // (null keys all sit in parent 0: the other 63 parents' histograms read the keys alone, 8 instead of 12 bytes per record)
+    if (i < r.hi) atomicAdd(&s_h[e2_digit(__builtin_nontemporal_load(&pkeys[i]), r.parent == 0 ? __builtin_nontemporal_load(&prows[i]) : 0u, lp, mask)], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nb; b += kThreads) cnt[r.id * nb + b] = s_h[b];
@@ -494,23 +712,24 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lp, P, ntiles, toffs, pkeys, nullptr, prows, nullptr);
   AH_LAUNCH_CHECK(c);
   // ---- 3: tables
-  if (slots == kESlots2) enc_table_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
-  else enc_table_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  if (slots == kESlots2) { if (c->opt_encode_table_batch) enc_table_kernel<kESlots2, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
+  else { if (c->opt_encode_table_batch) enc_table_kernel<kESlots, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
   AH_LAUNCH_CHECK(c);
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
   AH_LAUNCH_CHECK(c);
-  enc_assign_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff,
-                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id, slots);
-  AH_LAUNCH_CHECK(c);
+  // (measured at 2^26 rows: from 2^22 keys on — 1024 partitions — the compaction wins; below, the slots' few scattered stores are cheaper than its pass)
+  if ((rc = enc_emit(c, c->opt_encode_dict_compact >= 2 || (c->opt_encode_dict_compact == 1 && lp >= 10), out_ids != nullptr, tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (const uint64_t*)k64, n, (uint64_t*)out_dict,
+                     (int64_t*)out_first_rows, null_id, slots)) != AH_OK) return rc;
   if (out_ids) {
     // ---- 5, 6: ids per record, then per row
-    if (slots == kESlots2) enc_resolve_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
-    else enc_resolve_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id);
+    const int rsplit = P >= 1024 ? 1 : (int)(1024 / P);   // ≥ 1024 workgroups: one per partition leaves a CU 16 waves
+    if (slots == kESlots2) enc_resolve_kernel<kESlots2><<<(unsigned)(P * rsplit), kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id, rsplit);
+    else enc_resolve_kernel<kESlots><<<(unsigned)(P * rsplit), kThreads, 0, c->stream>>>(rec_slot, tab_first, binstart, rec_id, rsplit);
     AH_LAUNCH_CHECK(c);
-    enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id, prows, cnt_tm, toffs, P, ntiles, n, out_ids);
+    launch_enc_unpermute(c, rec_id, prows, cnt_tm, toffs, P, ntiles, n, out_ids);
     AH_LAUNCH_CHECK(c);
   }
   if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[30], 3, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;   // overflow, total, null id
@@ -598,23 +817,23 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   e2_scatter_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, toffs2, pkeys2, prows2, pj2);
   AH_LAUNCH_CHECK(c);
   // ---- tables, ranks, ids: as in the one-level path, one workgroup per final partition
-  if (slots == kESlots2) enc_table_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
-  else enc_table_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);
+  if (slots == kESlots2) enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
+  else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
   AH_LAUNCH_CHECK(c);
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
   AH_LAUNCH_CHECK(c);
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
   AH_LAUNCH_CHECK(c);
-  enc_assign_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff,
-                                                                                            (unsigned long long*)out_dict, (long long*)out_first_rows, null_id, slots);
-  AH_LAUNCH_CHECK(c);
+  if ((rc = enc_emit(c, c->opt_encode_dict_compact >= 1, out_ids != nullptr, tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (const uint64_t*)k64, n, (uint64_t*)out_dict,
+                     (int64_t*)out_first_rows, null_id, slots)) != AH_OK) return rc;
   if (out_ids) {
-    if (slots == kESlots2) enc_resolve_kernel<kESlots2><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2);
-    else enc_resolve_kernel<kESlots><<<(unsigned)P, kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2);
+    const int rsplit = P >= 1024 ? 1 : (int)(1024 / P);   // ≥ 1024 workgroups: one per partition leaves a CU 16 waves
+    if (slots == kESlots2) enc_resolve_kernel<kESlots2><<<(unsigned)(P * rsplit), kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2, rsplit);
+    else enc_resolve_kernel<kESlots><<<(unsigned)(P * rsplit), kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2, rsplit);
     AH_LAUNCH_CHECK(c);
     e2_unpermute_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec_id2, pj2, cnt2, toffs2, n, pstart, nb1, nb2, rec_id1);
     AH_LAUNCH_CHECK(c);
-    enc_unpermute_kernel<<<tgrid, kThreads, 0, c->stream>>>(rec_id1, prows1, cnt1, toffs1, nb1, ntiles, n, out_ids);
+    launch_enc_unpermute(c, rec_id1, prows1, cnt1, toffs1, nb1, ntiles, n, out_ids);
     AH_LAUNCH_CHECK(c);
   }
   if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[30], 3, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;   // overflow, total, null id
