@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
   const int64_t gbase = (int64_t)part * kStride;
   for (int j = t; j < kStride; j += kThreads) {
     const unsigned fr = j < kLS ? l_first[j] : kNoRow;
-    if (j < kLS) tab_key[gbase + j] = l_key[j];
+    if (j < kLS && tab_key) tab_key[gbase + j] = l_key[j];   // (not wanted when the dictionary is compacted from the column)
     tab_first[gbase + j] = fr;
     if (fr != kNoRow) atomicOr(&firsts[fr >> 6], 1ull << (fr & 63));
   }
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
 __global__ __launch_bounds__(kBlock) void enc_assign_kernel(const unsigned long long* __restrict__ tab_key, unsigned* __restrict__ tab_first, int64_t nslots,
                                                              const unsigned long long* __restrict__ firsts, const unsigned* __restrict__ wordprefix,
                                                              const int64_t* __restrict__ tileoff, unsigned long long* __restrict__ dict,
-                                                             long long* __restrict__ first_rows, int* __restrict__ null_id, int slots) {
+                                                             long long* __restrict__ first_rows, int* __restrict__ null_id, int slots,
+                                                             const ulonglong2* __restrict__ rank_rec) {
   // four slots per lane, their chains (first row → bitmap word, word prefix, tile offset → id → three scattered stores) side by
   // side: one slot per iteration left every wave with a single dependent chain of five round trips (2^24 keys: 1.0 ms for this pass)
   constexpr int U = 4;
@@ -233,8 +234,13 @@ __global__ __launch_bounds__(kBlock) void enc_assign_kernel(const unsigned long 
       const int64_t s = s0 + (int64_t)u * kBlock;
       id[u] = 0; key[u] = 0;
       if (fr[u] != kNoRow) {
-        id[u] = rank_of_row(fr[u], firsts, wordprefix, tileoff);
-        key[u] = tab_key[s];
+        if (rank_rec) {   // {bitmap word, ranks below the word} in ONE 16-byte gather instead of three gathers from three arrays
+          const ulonglong2 rr = rank_rec[fr[u] >> 6];
+          id[u] = (unsigned)rr.y + (unsigned)__popcll(rr.x & ((1ull << (fr[u] & 63)) - 1));
+        } else {
+          id[u] = rank_of_row(fr[u], firsts, wordprefix, tileoff);
+        }
+        if (dict) key[u] = tab_key[s];
       }
     }
 #pragma unroll
@@ -265,6 +271,12 @@ __global__ void enc_null_entry_kernel(const unsigned* __restrict__ tab_first, in
   if (id >= 0 && dict) dict[id] = 0;
 }
 
+__global__ __launch_bounds__(kBlock) void rank_rec_kernel(const unsigned long long* __restrict__ firsts, const unsigned* __restrict__ wordprefix,
+                                                           const int64_t* __restrict__ tileoff, int64_t nwords, ulonglong2* __restrict__ rec) {
+  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w < nwords) rec[w] = make_ulonglong2(firsts[w], (unsigned long long)(tileoff[w >> 5] + wordprefix[w]));
+}
+
 // ids of the slots + the dictionary (and the first rows) in id order.  compact = false: every used slot writes its key to dict[id] —
 // ids follow first rows, so these are scattered 8-byte stores, two per key, behind two scattered reads (2^24 keys: 0.87 ms).
 // compact = true: the dictionary is the key column itself compacted by the first-occurrence bitmap (ah_filter.hip: tiles without a
@@ -276,14 +288,22 @@ int enc_emit(ah_ctx* c, bool compact, bool need_ids, const unsigned long long* t
   const unsigned agrid = ah_stream_grid(c, ah_ceil_div(nslots, (int64_t)kBlock * 4));
   if (!compact) {
     enc_assign_kernel<<<agrid, kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (unsigned long long*)out_dict,
-                                                       (long long*)out_first_rows, null_id, slots);
+                                                       (long long*)out_first_rows, null_id, slots, nullptr);
     AH_LAUNCH_CHECK(c);
     return AH_OK;
   }
   int rc = ah_compact_u64_by_bits(c, keys, (const uint8_t*)firsts, n, out_dict, out_first_rows);
   if (rc != AH_OK) return rc;
   if (need_ids) {
-    enc_assign_kernel<<<agrid, kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff, nullptr, nullptr, null_id, slots);
+    // the key table is not read any more (the dictionary came from the column): its block holds the rank records
+    const int64_t nwords = ah_ceil_div(n, 64);
+    ulonglong2* rec = nullptr;
+    if (nslots * 8 >= nwords * 16) {
+      rec = (ulonglong2*)tab_key;
+      rank_rec_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, wordprefix, tileoff, nwords, rec);
+      AH_LAUNCH_CHECK(c);
+    }
+    enc_assign_kernel<<<agrid, kBlock, 0, c->stream>>>(tab_key, tab_first, nslots, firsts, wordprefix, tileoff, nullptr, nullptr, null_id, slots, rec);
     AH_LAUNCH_CHECK(c);
   }
   enc_null_entry_kernel<<<1, 1, 0, c->stream>>>(tab_first, slots, need_ids ? 0 : 1, firsts, wordprefix, tileoff, null_id, (unsigned long long*)out_dict);
@@ -712,16 +732,18 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lp, P, ntiles, toffs, pkeys, nullptr, prows, nullptr);
   AH_LAUNCH_CHECK(c);
   // ---- 3: tables
-  if (slots == kESlots2) { if (c->opt_encode_table_batch) enc_table_kernel<kESlots2, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
-  else { if (c->opt_encode_table_batch) enc_table_kernel<kESlots, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
+  // (measured at 2^26 rows: from 2^22 keys on — 1024 partitions — the compaction wins; below, the slots' few scattered stores are cheaper than its pass)
+  const bool compact = c->opt_encode_dict_compact >= 2 || (c->opt_encode_dict_compact == 1 && lp >= 10);
+  unsigned long long* tab_key_out = compact ? nullptr : tab_key;
+  if (slots == kESlots2) { if (c->opt_encode_table_batch) enc_table_kernel<kESlots2, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
+  else { if (c->opt_encode_table_batch) enc_table_kernel<kESlots, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
   AH_LAUNCH_CHECK(c);
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
   AH_LAUNCH_CHECK(c);
-  // (measured at 2^26 rows: from 2^22 keys on — 1024 partitions — the compaction wins; below, the slots' few scattered stores are cheaper than its pass)
-  if ((rc = enc_emit(c, c->opt_encode_dict_compact >= 2 || (c->opt_encode_dict_compact == 1 && lp >= 10), out_ids != nullptr, tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (const uint64_t*)k64, n, (uint64_t*)out_dict,
+  if ((rc = enc_emit(c, compact, out_ids != nullptr, tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (const uint64_t*)k64, n, (uint64_t*)out_dict,
                      (int64_t*)out_first_rows, null_id, slots)) != AH_OK) return rc;
   if (out_ids) {
     // ---- 5, 6: ids per record, then per row
@@ -817,14 +839,16 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   e2_scatter_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, toffs2, pkeys2, prows2, pj2);
   AH_LAUNCH_CHECK(c);
   // ---- tables, ranks, ids: as in the one-level path, one workgroup per final partition
-  if (slots == kESlots2) enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
-  else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
+  const bool compact = c->opt_encode_dict_compact >= 1;
+  unsigned long long* tab_key_out = compact ? nullptr : tab_key;
+  if (slots == kESlots2) enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
+  else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
   AH_LAUNCH_CHECK(c);
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
   AH_LAUNCH_CHECK(c);
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
   AH_LAUNCH_CHECK(c);
-  if ((rc = enc_emit(c, c->opt_encode_dict_compact >= 1, out_ids != nullptr, tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (const uint64_t*)k64, n, (uint64_t*)out_dict,
+  if ((rc = enc_emit(c, compact, out_ids != nullptr, tab_key, tab_first, nslots, firsts, wordprefix, tileoff, (const uint64_t*)k64, n, (uint64_t*)out_dict,
                      (int64_t*)out_first_rows, null_id, slots)) != AH_OK) return rc;
   if (out_ids) {
     const int rsplit = P >= 1024 ? 1 : (int)(1024 / P);   // ≥ 1024 workgroups: one per partition leaves a CU 16 waves

@@ -69,9 +69,14 @@ def parse():
     p.add_argument("--no-c5-merge", action="store_true",
                    help="C5 secondary line: skip the merge of the per-GPU aggregates by key-hash owner (all-to-all of group tuples over "
                         "RCCL), which is ON whenever more than one rank runs — the config is 'partitioned by key-hash over xGMI'")
-    p.add_argument("--collectives", choices=["ah", "torch"], default="ah",
+    p.add_argument("--collectives", choices=["auto", "ah", "torch"], default="auto",
                    help="who performs the data-path collectives under torch.distributed.run: 'ah' = ah_comm_* of libarrowhip.so (RCCL through "
-                        "the C ABI, on the library's stream — what a Go host would call), 'torch' = torch.distributed's nccl group")
+                        "the C ABI, on the library's stream — what a Go host would call; a failure to set it up is fatal), 'torch' = "
+                        "torch.distributed's nccl group, 'auto' (default) = 'ah', and if EVERY rank agrees it could not be set up, 'torch' with the "
+                        "reason written into config.collectives (never silently)")
+    p.add_argument("--secondary-timeout", type=float, default=420.0,
+                   help="multi-GPU runs: seconds the sections after the headline (C4 / C5 lines) may take before rank 0 prints the headline "
+                        "line without them and every rank exits — a rank stuck in a collective must not cost the run its number")
     p.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table")
     p.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch of the Add kernel from a rocprofv3 --pmc pass")
     return p.parse_args()
@@ -490,16 +495,35 @@ def main():
     import arrow_go_amd as ah
     N = ah._native
     comm = None
+    comm_note = None
     if use_dist:
         ctx = ah.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        if args.collectives == "ah":
+        if args.collectives in ("ah", "auto"):
             # rank 0's RCCL unique id reaches the others over the launcher's process group; from here on the data-path
-            # collectives are C-ABI calls on the library's own stream
-            # no fallback: `--collectives ah` either measures ah_comm_* or fails (a silent switch to torch's collectives would put
-            # another library's numbers under this one's name); `--collectives torch` is the explicit alternative
-            uid = [ah.Comm.unique_id() if rank == 0 else None]
+            # collectives are C-ABI calls on the library's own stream.
+            # `--collectives ah`: no fallback — it either measures ah_comm_* or fails (a silent switch to torch's collectives would put
+            # another library's numbers under this one's name).  `auto`: the ranks vote; only if the communicator could be set up on
+            # NONE of them (librccl not loadable, …) the run goes on with torch's group and says so in config.collectives.
+            err = None
+            try:
+                uid = [ah.Comm.unique_id() if rank == 0 else None]
+            except Exception as e:
+                uid, err = [None], e
             dist.broadcast_object_list(uid, src=0)
-            comm = ah.Comm(ctx, rank, world, uid[0])
+            if uid[0] is not None:
+                try:
+                    comm = ah.Comm(ctx, rank, world, uid[0])
+                except Exception as e:
+                    err = e
+            else:
+                err = err or RuntimeError("rank 0 could not create the RCCL unique id")
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(ok)
+            if int(ok.item()) != world:
+                if args.collectives == "ah" or int(ok.item()) != 0:
+                    raise RuntimeError(f"bench: ah_comm set up on {int(ok.item())} of {world} ranks: {err!r}")
+                comm_note = f"torch.distributed (ah_comm could not be set up on any rank: {err!r})"
+                print("bench: " + comm_note, file=sys.stderr)
     else:
         ctx = ah.Context(0)
 
@@ -553,6 +577,53 @@ def main():
     ms_per_step = dt * 1e3 / max(args.steps, 1)
     add_ms = [ctx.event_elapsed_ms(2 * i, 2 * i + 1) for i in range(args.steps)]
     add_avg_ms = float(np.mean(add_ms)) if add_ms else float("nan")
+
+    result = None
+    if rank == 0:
+        bytes_per_step = 32.0 * rows * args.gpus
+        value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
+        achieved = 24.0 * rows / (add_avg_ms * 1e-3) / 1e9
+        result = {
+            "metric": "GB/s processed per kernel (Sum/Add/Filter/Take) vs HBM roofline",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64+f64", "data": "synthetic",
+            "config": {"workload": "C2: Int64 Add (array+array) + Float64 Sum over contiguous Arrow value buffers resident in HBM"
+                                   + (" + 8-byte RCCL all-reduce of the partial sums" + (" (ah_comm_allreduce_sum)" if comm is not None else " (torch.distributed)")
+                                      if use_dist else ""),
+                       "rows_per_gpu": rows, "bytes_per_row_per_step": 32,
+                       "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective",
+                       "collectives": ("ah_comm (RCCL through the C ABI)" if comm is not None else (comm_note or "torch.distributed")) if use_dist else "none (single process)"},
+            "roofline": {"bound": "hbm", "kernel": "binary_kernel<uint64, ADD, array∘array> (Int64 Add)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": args.traffic if args.traffic is not None else pmc_traffic(rows)[0],
+                         "traffic_source": "--traffic" if args.traffic is not None else pmc_traffic(rows)[1],
+                         "avg_launch_ms": round(add_avg_ms, 5), "algorithmic_bytes_per_launch": int(24 * rows)},
+        }
+    # One JSON line, whatever happens after this point: with more than one rank the secondary sections contain collectives, and a
+    # rank that fails or hangs inside one would leave the others waiting at a barrier.  A watchdog prints the headline without them
+    # and ends every rank.
+    import threading
+    emit_lock, emitted, secondary_done = threading.Lock(), [False], threading.Event()
+
+    def emit(res):
+        with emit_lock:
+            if not emitted[0]:
+                emitted[0] = True
+                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+
+    def watchdog():
+        if secondary_done.wait(args.secondary_timeout):
+            return
+        if rank == 0:
+            res = dict(result)
+            res["c4_filter_aggregate"] = res["c5_group_by"] = {"error": f"not finished after {args.secondary_timeout:.0f} s (--secondary-timeout): headline printed by the watchdog"}
+            emit(res)
+        os._exit(0)
+
+    if world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
 
     # Secondary line (config C4, the 1/2/4/8-GPU curve of the record-batch-sharded filter + aggregate): every rank runs the
     # fused Compare(>) → Filter → Sum over its 2^27-row Int64 shard, the 16-byte (sum, count) partial is all-reduced.
@@ -636,27 +707,6 @@ def main():
         c5 = {"error": repr(e)}
 
     if rank == 0:
-        bytes_per_step = 32.0 * rows * args.gpus
-        value = bytes_per_step / (ms_per_step * 1e-3) / 1e9
-        achieved = 24.0 * rows / (add_avg_ms * 1e-3) / 1e9
-        result = {
-            "metric": "GB/s processed per kernel (Sum/Add/Filter/Take) vs HBM roofline",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64+f64", "data": "synthetic",
-            "config": {"workload": "C2: Int64 Add (array+array) + Float64 Sum over contiguous Arrow value buffers resident in HBM"
-                                   + (" + 8-byte RCCL all-reduce of the partial sums" + (" (ah_comm_allreduce_sum)" if comm is not None else " (torch.distributed)")
-                                      if use_dist else ""),
-                       "rows_per_gpu": rows, "bytes_per_row_per_step": 32,
-                       "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective",
-                       "collectives": ("ah_comm (RCCL through the C ABI)" if comm is not None else "torch.distributed") if use_dist else "none (single process)"},
-            "roofline": {"bound": "hbm", "kernel": "binary_kernel<uint64, ADD, array∘array> (Int64 Add)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": args.traffic if args.traffic is not None else pmc_traffic(rows)[0],
-                         "traffic_source": "--traffic" if args.traffic is not None else pmc_traffic(rows)[1],
-                         "avg_launch_ms": round(add_avg_ms, 5), "algorithmic_bytes_per_launch": int(24 * rows)},
-        }
         result["c4_filter_aggregate"] = c4
         result["c5_group_by"] = c5
         if world == 1 and not args.no_kernels:
@@ -683,7 +733,8 @@ def main():
                 result["cpu_baseline_mt"] = cpu_baseline_mt()
             except Exception as e:
                 result["cpu_baseline_mt"] = {"error": repr(e)}
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+        emit(result)
+    secondary_done.set()
     if comm is not None:
         comm.close()
     if use_dist:
