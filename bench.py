@@ -74,7 +74,7 @@ def parse():
                         "the C ABI, on the library's stream — what a Go host would call; a failure to set it up is fatal), 'torch' = "
                         "torch.distributed's nccl group, 'auto' (default) = 'ah', and if EVERY rank agrees it could not be set up, 'torch' with the "
                         "reason written into config.collectives (never silently)")
-    p.add_argument("--secondary-timeout", type=float, default=420.0,
+    p.add_argument("--secondary-timeout", type=float, default=150.0,
                    help="multi-GPU runs: seconds the sections after the headline (C4 / C5 lines) may take before rank 0 prints the headline "
                         "line without them and every rank exits — a rank stuck in a collective must not cost the run its number")
     p.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table")
