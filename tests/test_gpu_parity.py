@@ -839,6 +839,59 @@ def test_hash_sum_f64_wide_range(hip, orc_be, ctx, mode):
                 assert got != 0.0 or exact == 0, (mode, card, k)   # what the one-scale version returned for every ordinary group
 
 
+@pytest.mark.parametrize("case", ["ordinary", "outlier_missed_by_the_sample", "outlier_within_the_margin", "wide_but_fits", "too_wide"])
+def test_hash_sum_f64_scale_from_sample(hip, orc_be, ctx, case):
+    """The no-cut group-by (≤ 2048 groups, ≥ 2^22 rows) takes its fixed-point scale from 2^18 sampled values + 4 binades and lets the
+    aggregate pass verify it (csrc/ah_groupby.hip, fx_guess_check_kernel).  Whatever the sample saw, the sums must be the exact
+    per-group sums, correctly rounded — with the guess, with the full absmax pass (option groupby_scale_guess 0) and run to run:
+    an outlier the sample cannot see (handed to the id-based path), one inside the margin, a column 36 binades wide (fits the guess),
+    one 60 binades wide (handed over)."""
+    import math
+    from fractions import Fraction
+    rng = np.random.default_rng(912)
+    n = (1 << 22) + 777
+    keys = rng.integers(0, 900, n).astype(np.int64) * 1000003
+    fv = rng.uniform(0.5, 1.0, n) * rng.choice([-1.0, 1.0], n)      # one binade, so that the cases below control the range
+    fv[rng.integers(0, n, 50)] = 0.0
+    lone = 64 * 12345 + 17          # the sample reads rows 0 … 63 of every (n / 4096 rounded down to 64)-row stride: this row is never in it
+    stride = (n // 4096) & ~63
+    assert lone % stride >= 64
+    if case == "outlier_missed_by_the_sample":
+        fv[lone] = 3.0e9            # 2^31: beyond the margin (4) + the accumulator's slack (2)
+    elif case == "outlier_within_the_margin":
+        fv[lone] = 40.0             # 2^5 above the sampled maximum's binade
+    elif case == "wide_but_fits":
+        fv[rng.integers(0, n, 2000)] *= 2.0 ** -36   # guess = sampled exponent + 4: 40 binades to cover, 42 allowed
+    elif case == "too_wide":
+        fv[rng.integers(0, n, 2000)] *= 2.0 ** -60
+    vvalid = rand_bits(rng, n + 8, 0.9)
+    ok = np.unpackbits(vvalid, bitorder="little")[3:3 + n].astype(bool)
+    ok[lone] = True
+    vvalid = np.packbits(np.concatenate([np.ones(3, bool), ok, np.ones(8, bool)]), bitorder="little")
+    res = {}
+    try:
+        for guess in (1, 0):
+            ctx.set_option("groupby_scale_guess", guess)
+            res[guess] = hip.hash_sum("f64", keys, None, 0, fv, vvalid, 3)
+        ctx.set_option("groupby_scale_guess", 1)
+        again = hip.hash_sum("f64", keys, None, 0, fv, vvalid, 3)
+    finally:
+        ctx.set_option("groupby_scale_guess", 1)
+    e = orc_be.hash_sum("f64", keys, None, 0, fv, vvalid, 3)
+    g = res[1]
+    assert g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes()
+    assert g[1].tobytes() == again[1].tobytes()
+    if case != "too_wide":          # one scale for the call, no addend truncated: both ways are the correctly rounded exact sums
+        assert g[1].tobytes() == res[0][1].tobytes()
+    pos = {int(k): i for i, k in enumerate(g[0].view(np.int64))}
+    for k, (exact, cnt, gmax) in _exact_group_sums(keys, fv, ok, 900).items():
+        got = float(g[1][pos[k]])
+        if case == "too_wide":      # per-group scales: the documented bound
+            assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)) + Fraction(gmax) * cnt / 2**93, (case, k, got, float(exact))
+        else:
+            assert abs(Fraction(got) - exact) <= Fraction(0.5 * math.ulp(got)), (case, k, got, float(exact))
+
+
 # ---- fused ---------------------------------------------------------------------------------
 def test_fused_vs_unfused_chain(hip, orc_be):
     rng = np.random.default_rng(81)
