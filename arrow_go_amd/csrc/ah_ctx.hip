@@ -391,6 +391,8 @@ struct ah_graph {
   ah_ctx* ctx;
   hipGraph_t graph;
   hipGraphExec_t exec;
+  void* scratch;   // the arenas the recorded launches point into: a later call that grows one frees the block the graph still names
+  void* temp;
 };
 
 AH_EXPORT int ah_graph_begin(ah_ctx* c) {
@@ -425,6 +427,7 @@ AH_EXPORT int ah_graph_end(ah_ctx* c, ah_graph** out) {
   ah_graph* r = (ah_graph*)calloc(1, sizeof(ah_graph));
   if (!r) { (void)hipGraphExecDestroy(x); (void)hipGraphDestroy(g); return ah_fail(c, AH_EINVALID, "graph_end: out of memory"); }
   r->ctx = c; r->graph = g; r->exec = x;
+  r->scratch = c->scratch; r->temp = c->temp;
   *out = r;
   return AH_OK;
 }
@@ -433,6 +436,8 @@ AH_EXPORT int ah_graph_launch(ah_ctx* c, ah_graph* g) {
   AH_ENTER(c);
   if (!g || g->ctx != c) return ah_fail(c, AH_EINVALID, "graph_launch: not a graph of this context");
   if (c->capturing) return ah_fail(c, AH_EINVALID, "graph_launch: the context is capturing");
+  if (g->scratch != c->scratch || g->temp != c->temp)
+    return ah_fail(c, AH_EINVALID, "graph_launch: a call since the recording grew one of the context's work areas (the recorded launches point into the old block) — record the sequence again");
   AH_HIP(c, hipGraphLaunch(g->exec, c->stream));
   return AH_OK;
 }

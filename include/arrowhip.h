@@ -154,7 +154,8 @@ int ah_sync(ah_ctx* ctx);
  * calls that neither wait for the device nor allocate — element-wise arithmetic, comparisons, bitmap / Kleene ops, copies and
  * memsets, the *_dev flavours (ah_sum_*_dev, ah_cmp_filter_sum_*_dev, ah_filter_primitive_dev, ah_take_primitive_dev),
  * ah_cumulative_sum without a null count — after ONE eager call of the same sequence (the scratch arenas get their size there).
- * A call with a *_host result invalidates the capture; ah_graph_end then fails and nothing was run. */
+ * A call with a *_host result invalidates the capture; ah_graph_end then fails and nothing was run.  The recorded launches point into
+ * the context's work areas: if a later, larger call grows one of them, ah_graph_launch refuses the stale graph (AH_EINVALID) — record again. */
 typedef struct ah_graph ah_graph;
 int ah_graph_begin(ah_ctx* ctx);
 int ah_graph_end(ah_ctx* ctx, ah_graph** out);

@@ -1776,12 +1776,13 @@ def test_power_floats_close(hip, orc_be, dtype):
             assert np.all(np.abs(G[fin] - E[fin]) <= 4 * np.finfo(dtype).eps * np.abs(E[fin]) + np.finfo(dtype).tiny), np.max(np.abs(G[fin] - E[fin]) / np.maximum(np.abs(E[fin]), 1e-300))
 
 
-def test_graph_capture_replays_a_chain(ctx):
+def test_graph_capture_replays_a_chain():
     """ah_graph_begin / _end / _launch: an Add → Compare → bitmap AND → fused compare-filter-sum → Sum chain over a small column is
     recorded once and replayed with new contents under the same pointers; every replay equals numpy on the contents of that
     moment, and a call that has to wait for the device invalidates the capture instead of running half a sequence."""
     import arrow_go_amd as ah
     N = ah._native
+    ctx = ah.Context(0)      # its own context: the last part needs work areas that have not grown yet
     rng = np.random.default_rng(77)
     n = (1 << 16) + 77
     thr = np.array([5], np.int64)
@@ -1824,7 +1825,15 @@ def test_graph_capture_replays_a_chain(ctx):
         dc.memset(0); dand.memset(0); dfused.memset(0); dsum.memset(0)
         g.launch()
         check_against(a, b)
+    # a larger call grows the context's scratch area: the graph's launches would point into the freed block — refused
+    big = rng.integers(0, 1 << 20, 1 << 22, dtype=np.int64)
+    dk, di, dd = ctx.to_device(big), ctx.alloc(big.size * 4), ctx.alloc((big.size + 1) * 8)
+    ctx.hash_u64_encode(dk, None, 0, big.size, False, di, None, dd)
+    with pytest.raises(ah.ArrowHipError, match="record the sequence again"):
+        g.launch()
     g.close()
+    for d in (dk, di, dd):
+        d.free()
     # a call with a host result cannot be recorded: the capture is dropped, the context stays usable
     ctx.graph_begin()
     with pytest.raises(ah.ArrowHipError):
@@ -1837,3 +1846,4 @@ def test_graph_capture_replays_a_chain(ctx):
     assert ctx.sum_int64(dc, n) == int((a + b).sum())
     for d in (da, db, dc, dmask, dother, dand, dfused, dsum):
         d.free()
+    ctx.close()
