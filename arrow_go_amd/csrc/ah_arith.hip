@@ -73,7 +73,7 @@ __device__ __forceinline__ void vstore(V* p, V v) {
 // ext-vector accesses; otherwise element-aligned 16-byte structs (Arrow slices).
 template <typename T, int OP, int SHAPE, bool ALIGNED, bool NT>
 __global__ __launch_bounds__(kBlock) void binary_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                                         T* __restrict__ out, int64_t len, T scalar) {
+                                                         T* __restrict__ out, int64_t len, T scalar, unsigned xmap) {
   constexpr int V = 16 / sizeof(T);
   using VT = typename std::conditional<ALIGNED, Vec16<T>, ah_vec16<T>>::type;
   const int64_t nvec = len / V;
@@ -81,7 +81,9 @@ __global__ __launch_bounds__(kBlock) void binary_kernel(const T* __restrict__ a,
   const VT* bv = (const VT*)b;
   VT* ov = (VT*)out;
   const int64_t stride = (int64_t)gridDim.x * kBlock * kUnroll;
-  int64_t i = (int64_t)blockIdx.x * kBlock * kUnroll + threadIdx.x;
+  // xmap (measurement switch arith_xcd_map): block b runs on XCD b & 7 — give every XCD one contiguous eighth of the columns
+  const unsigned bid = xmap ? (blockIdx.x & 7u) * xmap + (blockIdx.x >> 3) : blockIdx.x;
+  int64_t i = (int64_t)bid * kBlock * kUnroll + threadIdx.x;
   auto compute = [&](const VT& x, const VT& y) {
     VT o;
 #pragma unroll
@@ -162,12 +164,14 @@ int launch_binary(ah_ctx* c, const void* a, const void* b, void* out, int64_t le
   bool aligned = (((uintptr_t)a | (uintptr_t)out | (SHAPE == 0 ? (uintptr_t)b : 0)) & 15) == 0;
   int64_t iters = ah_ceil_div(len / V + 1, (int64_t)kBlock * kUnroll);
   unsigned grid = ah_stream_grid(c, iters, /*default_bpc=*/0);
+  unsigned xmap = 0;
+  if (c->opt_arith_xcd_map && grid >= 64) { grid = (grid + 7u) & ~7u; xmap = grid >> 3; }
   const T* pa = (const T*)a; const T* pb = (const T*)b; T* po = (T*)out;
   if (aligned) {
-    if (c->tune_nt) binary_kernel<T, OP, SHAPE, true, true><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar);
-    else binary_kernel<T, OP, SHAPE, true, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar);
+    if (c->tune_nt) binary_kernel<T, OP, SHAPE, true, true><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
+    else binary_kernel<T, OP, SHAPE, true, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
   } else {
-    binary_kernel<T, OP, SHAPE, false, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar);
+    binary_kernel<T, OP, SHAPE, false, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
   }
   AH_LAUNCH_CHECK(c);
   return AH_OK;

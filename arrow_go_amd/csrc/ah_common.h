@@ -68,6 +68,7 @@ struct ah_ctx {
   ah_filter_cache fcache;  // ah_filter.hip
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;
+  int opt_arith_xcd_map;        // element-wise binary kernels: every XCD streams one contiguous eighth of the columns (1) or the blocks' natural interleave (0)
   int opt_groupby_scale_guess;  // no-cut Float64 group-by: fixed-point scale from a sample, verified by the aggregate pass (1) or from a pass over all values (0)
   int opt_encode_dict_compact;  // partition-first encode: the dictionary = the key column compacted by the first-occurrence bitmap (0 never, 1 from 1024 partitions on, 2 always)
   int opt_encode_table_batch;   // partition-first encode: the table pass probes its four records' first groups together (1) or one by one (0)
