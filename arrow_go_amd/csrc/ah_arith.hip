@@ -104,15 +104,16 @@ __global__ __launch_bounds__(kBlock) void binary_kernel(const T* __restrict__ a,
         x[k] = vload<VT, NT>(&av[i + (int64_t)k * kBlock]);
         if (SHAPE == 0) y[k] = vload<VT, NT>(&bv[i + (int64_t)k * kBlock]);
       } else {
-        x[k] = av[i + (int64_t)k * kBlock];
-        if (SHAPE == 0) y[k] = bv[i + (int64_t)k * kBlock];
+        x[k] = NT ? ah_ld16_nt<T>((const T*)(av + (i + (int64_t)k * kBlock))) : ah_ld16<T>((const T*)(av + (i + (int64_t)k * kBlock)));
+        if (SHAPE == 0) y[k] = NT ? ah_ld16_nt<T>((const T*)(bv + (i + (int64_t)k * kBlock))) : ah_ld16<T>((const T*)(bv + (i + (int64_t)k * kBlock)));
       }
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
       VT o = compute(x[k], y[k]);
       if constexpr (ALIGNED) vstore<VT, NT>(&ov[i + (int64_t)k * kBlock], o);
-      else ov[i + (int64_t)k * kBlock] = o;
+      else if constexpr (NT) ah_st16_nt<T>((T*)(ov + (i + (int64_t)k * kBlock)), o);
+      else ah_st16<T>((T*)(ov + (i + (int64_t)k * kBlock)), o);
     }
   }
 #pragma unroll
@@ -144,13 +145,13 @@ __global__ __launch_bounds__(kBlock) void unary_kernel(const ST* __restrict__ a,
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
     VT x, o;
-    if constexpr (ALIGNED) x = vload<VT, NT>(&av[i]); else x = av[i];
+    if constexpr (ALIGNED) x = vload<VT, NT>(&av[i]); else x = ah_ld16<ST>((const ST*)(av + i));
 #pragma unroll
     for (int e = 0; e < V; e++) {
       if constexpr (ALIGNED) o[e] = apply_unary<ST, OP>(x[e]);
       else o.v[e] = apply_unary<ST, OP>(x.v[e]);
     }
-    if constexpr (ALIGNED) vstore<VT, NT>(&ov[i], o); else ov[i] = o;
+    if constexpr (ALIGNED) vstore<VT, NT>(&ov[i], o); else ah_st16<ST>((ST*)(ov + i), o);
   }
   if (blockIdx.x == 0) {
     int64_t j = nvec * V + threadIdx.x;
@@ -170,8 +171,9 @@ int launch_binary(ah_ctx* c, const void* a, const void* b, void* out, int64_t le
   if (aligned) {
     if (c->tune_nt) binary_kernel<T, OP, SHAPE, true, true><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
     else binary_kernel<T, OP, SHAPE, true, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
-  } else {
-    binary_kernel<T, OP, SHAPE, false, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
+  } else {   // an element-aligned slice: the same 16-byte accesses and hints at the elements' alignment
+    if (c->tune_nt) binary_kernel<T, OP, SHAPE, false, true><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
+    else binary_kernel<T, OP, SHAPE, false, false><<<grid, kBlock, 0, c->stream>>>(pa, pb, po, len, scalar, xmap);
   }
   AH_LAUNCH_CHECK(c);
   return AH_OK;
@@ -277,7 +279,7 @@ __device__ __forceinline__ ah_vec16<ST> load16(const ST* base, int64_t i, bool a
     const Vec16<ST> t = __builtin_nontemporal_load((const Vec16<ST>*)base + i);
     __builtin_memcpy(&v, &t, 16);
   } else {
-    v = ((const ah_vec16<ST>*)base)[i];
+    v = ah_ld16<ST>(base + i * (int64_t)(16 / sizeof(ST)));
   }
   return v;
 }
@@ -288,7 +290,7 @@ __device__ __forceinline__ void store16(ST* base, int64_t i, const ah_vec16<ST>&
     __builtin_memcpy(&t, &v, 16);
     __builtin_nontemporal_store(t, (Vec16<ST>*)base + i);
   } else {
-    ((ah_vec16<ST>*)base)[i] = v;
+    ah_st16<ST>(base + i * (int64_t)(16 / sizeof(ST)), v);
   }
 }
 

@@ -42,7 +42,7 @@ __device__ __forceinline__ ah_vec16<ST> load16(const ST* base, int64_t i, bool a
     const Vec16<ST> t = __builtin_nontemporal_load((const Vec16<ST>*)base + i);
     __builtin_memcpy(&v, &t, 16);
   } else {
-    v = ((const ah_vec16<ST>*)base)[i];
+    v = ah_ld16<ST>(base + i * (int64_t)(16 / sizeof(ST)));
   }
   return v;
 }
@@ -53,7 +53,7 @@ __device__ __forceinline__ void store16(ST* base, int64_t i, const ah_vec16<ST>&
     __builtin_memcpy(&t, &v, 16);
     __builtin_nontemporal_store(t, (Vec16<ST>*)base + i);
   } else {
-    ((ah_vec16<ST>*)base)[i] = v;
+    ah_st16<ST>(base + i * (int64_t)(16 / sizeof(ST)), v);
   }
 }
 

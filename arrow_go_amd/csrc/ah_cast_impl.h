@@ -29,6 +29,12 @@ __device__ __forceinline__ V load_vec(const void* p) {
   if constexpr (NT) {
     using R = typename Raw<sizeof(V)>::type;
     return __builtin_bit_cast(V, __builtin_nontemporal_load((const R*)p));
+  } else if constexpr (sizeof(V) == 16) {
+    // element-aligned 16 bytes (an Arrow slice): through a native vector of the struct's alignment — the struct load itself compiles
+    // to 12 + 4 or 8 + 8 bytes (ah_common.h, ah_ld16)
+    using RU = ah_raw16<typename std::remove_cv<typename std::remove_reference<decltype(((V*)nullptr)->v[0])>::type>::type>;
+    const RU raw = *(const RU*)p;
+    return __builtin_bit_cast(V, raw);
   } else {
     return *(const V*)p;
   }
@@ -38,6 +44,9 @@ __device__ __forceinline__ void store_vec(void* p, const V& v) {
   if constexpr (NT) {
     using R = typename Raw<sizeof(V)>::type;
     __builtin_nontemporal_store(__builtin_bit_cast(R, v), (R*)p);
+  } else if constexpr (sizeof(V) == 16) {
+    using RU = ah_raw16<typename std::remove_cv<typename std::remove_reference<decltype(((V*)nullptr)->v[0])>::type>::type>;
+    *(RU*)p = __builtin_bit_cast(RU, v);
   } else {
     *(V*)p = v;
   }

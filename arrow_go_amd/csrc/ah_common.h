@@ -235,6 +235,25 @@ __device__ __forceinline__ void ah_st16_nt(T* p, const ah_vec16<T>& x) {
   __builtin_nontemporal_store(raw, reinterpret_cast<ah_raw16<T>*>(p));
 }
 
+// the same without the hint: what an element-aligned Arrow slice is read and written with.  `*(const ah_vec16<T>*)p` compiles to
+// 2 × 8 bytes (T = 8 bytes), 12 + 4 (4 bytes), 12 + 2 + 1 + 1 (1 byte) — the struct's alignment is its element's — where one
+// 16-byte access through the native vector type is legal on gfx950 (unaligned-access mode) and is what the memory pipeline wants.
+template <typename T>
+__device__ __forceinline__ ah_vec16<T> ah_ld16(const T* p) {
+  const ah_raw16<T> raw = *reinterpret_cast<const ah_raw16<T>*>(p);
+  ah_vec16<T> r;
+#pragma unroll
+  for (int j = 0; j < (int)(16 / sizeof(T)); j++) r.v[j] = raw[j];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void ah_st16(T* p, const ah_vec16<T>& x) {
+  ah_raw16<T> raw;
+#pragma unroll
+  for (int j = 0; j < (int)(16 / sizeof(T)); j++) raw[j] = x.v[j];
+  *reinterpret_cast<ah_raw16<T>*>(p) = raw;
+}
+
 template <typename T>
 __device__ __forceinline__ T ah_wave_sum(T v) {
 #pragma unroll

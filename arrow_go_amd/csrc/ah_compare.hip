@@ -123,9 +123,12 @@ __global__ __launch_bounds__(kBlock) void compare_kernel(const T* __restrict__ a
         if constexpr (ALIGNED && NT) {
           x[k] = __builtin_nontemporal_load(&av[base + (int64_t)k * kBlock]);
           if (SHAPE == 0) y[k] = __builtin_nontemporal_load(&bv[base + (int64_t)k * kBlock]);
-        } else {
+        } else if constexpr (ALIGNED) {
           x[k] = av[base + (int64_t)k * kBlock];
           if (SHAPE == 0) y[k] = bv[base + (int64_t)k * kBlock];
+        } else {
+          x[k] = ah_ld16<T>((const T*)(av + (base + (int64_t)k * kBlock)));
+          if (SHAPE == 0) y[k] = ah_ld16<T>((const T*)(bv + (base + (int64_t)k * kBlock)));
         }
       }
 #pragma unroll

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const void* __restrict_
     bits_k[k] = (unsigned)((s_sel[e0 >> 6] >> (e0 & 63)) & ((1u << V) - 1));
     if (!INDICES && bits_k[k] != 0) {  // nothing selected here → the line is never fetched
       if (e0 + V <= rows_left) {
-        xv[k] = NT ? ah_ld16_nt<T>(values + b + e0) : *(const ah_vec16<T>*)(values + b + e0);
+        xv[k] = NT ? ah_ld16_nt<T>(values + b + e0) : ah_ld16<T>(values + b + e0);
       } else {  // ragged end of the column: stay in bounds
 #pragma unroll
         for (int e = 0; e < V; e++) xv[k].v[e] = (e0 + e < rows_left) ? values[b + e0 + e] : (T)0;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const void* __restrict_
 #pragma unroll
     for (int e = 0; e < V; e++) x.v[e] = stage[head + i * V + e];
     if (NT) ah_st16_nt<T>(dst + head + i * V, x);
-    else *(ah_vec16<T>*)(dst + head + i * V) = x;
+    else ah_st16<T>(dst + head + i * V, x);
   }
   if (tid < tile_count - tail0) dst[tail0 + tid] = stage[tail0 + tid];
 

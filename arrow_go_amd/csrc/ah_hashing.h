@@ -185,7 +185,6 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long
   unsigned im = 0;
   constexpr int U = 4;
   const int64_t nvec = n >> 1;
-  const ah_vec16<unsigned long long>* __restrict__ v2 = reinterpret_cast<const ah_vec16<unsigned long long>*>(vals);
   // one value: a finite non-zero |x| inside the current [min exponent, max] changes nothing and skips the validity read
   auto one = [&](unsigned long long raw, int64_t i) {
     const unsigned long long b = raw & 0x7fffffffffffffffull;   // |x| of finite values order like their bit patterns
@@ -200,7 +199,8 @@ __global__ __launch_bounds__(kBlock) void absmax_kernel(const unsigned long long
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t j = base + (int64_t)u * kBlock;
-      if (j < nvec) x[u] = v2[j];   // element-aligned 16-byte load (a slice need not be 16-byte aligned)
+      if (j < nvec) x[u] = ah_ld16_nt<unsigned long long>(vals + 2 * j);   // element-aligned 16-byte load (a slice need not be 16-byte aligned) — through the
+                                                                             // native vector type: the struct load compiled to two 8-byte loads (ah_common.h)
       else { x[u].v[0] = 0; x[u].v[1] = 0; }
     }
 #pragma unroll

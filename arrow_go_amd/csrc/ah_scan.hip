@@ -84,7 +84,7 @@ __device__ __forceinline__ void load_chunk(const T* __restrict__ in, const uint8
     if (e0 + V <= n) {
       ah_vec16<T> v;
       if (ALN) v = __builtin_bit_cast(ah_vec16<T>, __builtin_nontemporal_load((const u32x4*)(in + e0)));
-      else v = *(const ah_vec16<T>*)(in + e0);
+      else v = ah_ld16<T>(in + e0);
 #pragma unroll
       for (int j = 0; j < V; j++) x[k][j] = v.v[j];
     } else {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const T* __restrict__
     }
     if (e0 + V <= n) {
       if (ALN) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), (u32x4*)(out + e0));
-      else *(ah_vec16<T>*)(out + e0) = o;
+      else ah_st16<T>(out + e0, o);
     } else {
 #pragma unroll
       for (int j = 0; j < V; j++) if (e0 + j < n) out[e0 + j] = o.v[j];

@@ -146,12 +146,16 @@ __device__ __forceinline__ S take_ld(const T* p, bool nt) {
     for (int j = 0; j < V; j++) r.v[j] = raw[j];
     return r;
   }
-  return *reinterpret_cast<const S*>(p);
+  const TakeRaw<T, V> raw = *reinterpret_cast<const TakeRaw<T, V>*>(p);   // one access of V elements (the struct load is split)
+  S r;
+#pragma unroll
+  for (int j = 0; j < V; j++) r.v[j] = raw[j];
+  return r;
 }
 template <typename S, typename T, int V>
 __device__ __forceinline__ void take_st(T* p, const S& x, bool nt) {
   if (nt) __builtin_nontemporal_store(__builtin_bit_cast(TakeRaw<T, V>, x), reinterpret_cast<TakeRaw<T, V>*>(p));
-  else *reinterpret_cast<S*>(p) = x;
+  else *reinterpret_cast<TakeRaw<T, V>*>(p) = __builtin_bit_cast(TakeRaw<T, V>, x);
 }
 #ifndef AH_TAKE_VEC_STEPS
 #define AH_TAKE_VEC_STEPS 1
