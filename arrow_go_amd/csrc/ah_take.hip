@@ -136,25 +136,22 @@ struct alignas(sizeof(IdxT)) IdxVec { IdxT v[V]; };
 // columns of a clustered take are streamed once — without the hint the index vector and the output evict the values' lines from L2
 template <typename T, int V>
 using TakeRaw __attribute__((aligned(sizeof(T)))) = T __attribute__((ext_vector_type(V)));
-template <typename S, typename T, int V>
-__device__ __forceinline__ S take_ld(const T* p, bool nt) {
+// NT is a TEMPLATE parameter: behind a run-time (or merely inlined) switch the hinted and the plain access of one address and one
+// type are merged into a plain one — the hints of this kernel were lost that way twice (ISA check: `nt` on the loads and stores)
+template <typename S, typename T, int V, bool NT>
+__device__ __forceinline__ S take_ld(const T* p) {
   static_assert(sizeof(S) == sizeof(T) * V, "carrier size");
-  if (nt) {
-    const TakeRaw<T, V> raw = __builtin_nontemporal_load(reinterpret_cast<const TakeRaw<T, V>*>(p));
-    S r;
-#pragma unroll
-    for (int j = 0; j < V; j++) r.v[j] = raw[j];
-    return r;
-  }
-  const TakeRaw<T, V> raw = *reinterpret_cast<const TakeRaw<T, V>*>(p);   // one access of V elements (the struct load is split)
+  TakeRaw<T, V> raw;
+  if constexpr (NT) raw = __builtin_nontemporal_load(reinterpret_cast<const TakeRaw<T, V>*>(p));
+  else raw = *reinterpret_cast<const TakeRaw<T, V>*>(p);   // (one access of V elements: a load of the carrier struct is split)
   S r;
 #pragma unroll
   for (int j = 0; j < V; j++) r.v[j] = raw[j];
   return r;
 }
-template <typename S, typename T, int V>
-__device__ __forceinline__ void take_st(T* p, const S& x, bool nt) {
-  if (nt) __builtin_nontemporal_store(__builtin_bit_cast(TakeRaw<T, V>, x), reinterpret_cast<TakeRaw<T, V>*>(p));
+template <typename S, typename T, int V, bool NT>
+__device__ __forceinline__ void take_st(T* p, const S& x) {
+  if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(TakeRaw<T, V>, x), reinterpret_cast<TakeRaw<T, V>*>(p));
   else *reinterpret_cast<TakeRaw<T, V>*>(p) = __builtin_bit_cast(TakeRaw<T, V>, x);
 }
 #ifndef AH_TAKE_VEC_STEPS
@@ -192,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
     for (int k = 0; k < K; k++) {
       const int64_t r = (gb + (int64_t)k * kBlock) * V;
       if (r + V <= nidx) {
-        ivn[k] = take_ld<IdxVec<IdxT, V>, IdxT, V>(idx + r, nt_idx);
+        ivn[k] = take_ld<IdxVec<IdxT, V>, IdxT, V, nt_idx>(idx + r);
       } else {
 #pragma unroll
         for (int j = 0; j < V; j++) ivn[k].v[j] = r + j < nidx ? idx[r + j] : (IdxT)0;
@@ -252,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
     for (int k = 0; k < K; k++) {
       vbits[k] = kAll;
       if (merged[k]) {
-        const ah_vec16<T> t = take_ld<ah_vec16<T>, T, V>(values + lo[k], nt_val);
+        const ah_vec16<T> t = take_ld<ah_vec16<T>, T, V, nt_val>(values + lo[k]);
         unsigned b = 0xffffu;
         const int64_t p = voff + (int64_t)lo[k];   // validity bits p … p + V − 1: one byte, or two neighbours
         if (HAS_VALID && vvalid != nullptr) {
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
       for (int j = 0; j < V; j++)
         if (!((good >> j) & 1u)) x[k].v[j] = 0;   // a null output keeps payload 0 (:959-973)
       if (r + V <= nidx) {
-        take_st<ah_vec16<T>, T, V>(out + r, x[k], nt_out);
+        take_st<ah_vec16<T>, T, V, nt_out>(out + r, x[k]);
       } else {
 #pragma unroll
         for (int j = 0; j < V; j++) if (r + j < nidx) out[r + j] = x[k].v[j];
