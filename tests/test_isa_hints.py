@@ -27,6 +27,13 @@ EXPECT = {
         (r"compact_kernelILi8ELb1ELb0ELb1E", {"global_load_dwordx4 nt": 4, "global_store_dwordx4 nt": 1}),
         (r"compact_kernelILi4ELb1ELb0ELb1E", {"global_load_dwordx4 nt": 4, "global_store_dwordx4 nt": 1}),
     ],
+    "ah_ctx.hip": [(r"copy16_kernel", {"global_load_dwordx4 nt": 4, "global_store_dwordx4 nt": 4})],   # the measured ceiling; ah_copy_async
+    "ah_sum.hip": [
+        (r"sum_partials_kernelIdN\w*AccDDELb1E", {"global_load_dwordx4 nt": 4}),
+        (r"sum_partials_kernelImN\w*AccU64ELb1E", {"global_load_dwordx4 nt": 4}),
+    ],
+    "ah_compare.hip": [(r"compare_kernelIlLi2ELi1ELb1ELb1E", {"global_load_dwordx4 nt": 4})],          # greater(Int64 array, scalar)
+    "ah_fused.hip": [(r"fused_kernelIlLi2ELb0ELb1E", {"global_load_dwordx4 nt": 4})],                   # C4: Compare(>) → Filter → Sum
     "ah_arith.hip": [
         (r"binary_kernelImLi0ELi0ELb1ELb1E", {"global_load_dwordx4 nt": 8, "global_store_dwordx4 nt": 4}),   # aligned Int64 Add: the headline kernel
         (r"binary_kernelImLi0ELi0ELb0ELb1E", {"global_load_dwordx4 nt": 8, "global_store_dwordx4 nt": 4}),   # … over an element-aligned slice
