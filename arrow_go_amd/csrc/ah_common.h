@@ -70,6 +70,7 @@ struct ah_ctx {
   int opt_take_vec;
   int opt_arith_xcd_map;        // element-wise binary kernels: every XCD streams one contiguous eighth of the columns (1) or the blocks' natural interleave (0)
   int opt_groupby_scale_guess;  // no-cut Float64 group-by: fixed-point scale from a sample, verified by the aggregate pass (1) or from a pass over all values (0)
+  int opt_encode_unperm2_group; // two-cut encode: the level-2 un-permute over 4 consecutive virtual tiles per workgroup (4, the default) or one per workgroup (0)
   int opt_encode_resolve_wgs;   // partition-first encode: workgroups of the resolve pass (partitions are split to reach it)
   int opt_encode_dict_compact;  // partition-first encode: the dictionary = the key column compacted by the first-occurrence bitmap (0 never, 1 from 1024 partitions on, 2 always)
   int opt_encode_table_batch;   // partition-first encode: the table pass probes its four records' first groups together (1) or one by one (0)

@@ -53,6 +53,7 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_encode_table_batch = env_int("ARROWHIP_ENCODE_TABLE_BATCH", 1);
   c->opt_encode_dict_compact = env_int("ARROWHIP_ENCODE_DICT_COMPACT", 1);
   c->opt_encode_resolve_wgs = env_int("ARROWHIP_ENCODE_RESOLVE_WGS", 1024);
+  c->opt_encode_unperm2_group = env_int("ARROWHIP_ENCODE_UNPERM2_GROUP", 4);
   c->opt_groupby_scale_guess = env_int("ARROWHIP_GROUPBY_SCALE_GUESS", 1);
   c->opt_arith_xcd_map = env_int("ARROWHIP_ARITH_XCD_MAP", 0);
   c->opt_take_vec = env_int("ARROWHIP_TAKE_VEC", 1);   // 0: one row per lane always, 1: V rows per lane when the sample says clustered, 2: always
@@ -125,6 +126,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "encode_unperm_group")) c->opt_encode_unperm_group = (int)value;
   else if (!strcmp(name, "encode_table_batch")) c->opt_encode_table_batch = (int)value;
   else if (!strcmp(name, "encode_dict_compact")) c->opt_encode_dict_compact = (int)value;
+  else if (!strcmp(name, "encode_unperm2_group")) c->opt_encode_unperm2_group = (int)value;
   else if (!strcmp(name, "encode_resolve_wgs")) c->opt_encode_resolve_wgs = value < 1 ? 1 : (int)value;
   else if (!strcmp(name, "groupby_scale_guess")) c->opt_groupby_scale_guess = (int)value;
   else if (!strcmp(name, "arith_xcd_map")) c->opt_arith_xcd_map = (int)value;

@@ -693,6 +693,115 @@ __global__ __launch_bounds__(kThreads) void e2_unpermute_kernel(const int* __res
   }
 }
 
+
+// (option encode_unperm2_group: 4 = default, 0 = one virtual tile per workgroup.  Built last in round 3: 2^24 keys 2.64 → 2.60 ms)
+// the level-2 un-permute over G consecutive virtual tiles of a parent per workgroup, as enc_unpermute_group_kernel does for level 1
+// (353 → 205 µs there).  Inside a digit the runs of consecutive virtual tiles lie one after the other (e2_offs2_kernel walks the tiles
+// in order), so the group reads ONE run per digit, G times as long (nb2 = 128 digits: 32 records per tile).  A record's tile inside
+// the group follows from its offset in the group's run of its digit (cumulative counts per digit in LDS); its 2-byte position is
+// relative to that tile.  Needs nparents ≤ 64 (the two-cut path always has 64).
+template <int G>
+__global__ __launch_bounds__(kThreads) void e2_unpermute_group_kernel(const int* __restrict__ rec_id, const unsigned short* __restrict__ rec_j,
+                                                                       const unsigned* __restrict__ cnt, const unsigned* __restrict__ toffs, int64_t n,
+                                                                       const unsigned* __restrict__ pstart, int nparents, int nb, int* __restrict__ rec_id1) {
+  static_assert(G >= 2 && G <= 4, "cumulative counts of up to three earlier tiles");
+  __shared__ unsigned s_tiles[64], s_tstart[64], s_gstart[64];
+  __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_goff[kThreads], s_wsum[kThreads / 64];
+  __shared__ unsigned s_cum[G - 1][128];
+  __shared__ int s_out[G * kMsTile];
+  __shared__ int s_pick;
+  const int t = threadIdx.x;
+  // tiles and groups per parent, in the class-major parent order the tile numbering of the count / offset tables uses (ms_tile)
+  if (t < 64) {
+    unsigned tiles = 0;
+    if (t < nparents) { const int p = ms_parent_of(t, nparents); tiles = (pstart[p + 1] - pstart[p] + kMsTile - 1) / kMsTile; }
+    const unsigned groups = (tiles + G - 1) / G;
+    unsigned it = tiles, ig = groups;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned a = __shfl_up(it, o, 64), b = __shfl_up(ig, o, 64);
+      if (t >= o) { it += a; ig += b; }
+    }
+    s_tiles[t] = tiles; s_tstart[t] = it - tiles; s_gstart[t] = ig - groups;
+  }
+  if (t == 0) s_pick = -1;
+  __syncthreads();
+  if (t < nparents) {
+    const unsigned groups = (s_tiles[t] + G - 1) / G;
+    if (groups && s_gstart[t] <= blockIdx.x && blockIdx.x < s_gstart[t] + groups) s_pick = t;
+  }
+  __syncthreads();
+  const int j = s_pick;
+  if (j < 0) return;
+  const int p = ms_parent_of(j, nparents);
+  const unsigned g = blockIdx.x - s_gstart[j];
+  const int64_t vt0 = (int64_t)s_tstart[j] + (int64_t)g * G;
+  const int gt = (int)(s_tiles[j] - g * G < (unsigned)G ? s_tiles[j] - g * G : (unsigned)G);   // tiles in this group
+  const int64_t lo = (int64_t)pstart[p] + (int64_t)g * G * kMsTile;
+  const int64_t pend = (int64_t)pstart[p + 1], hi = lo + (int64_t)gt * kMsTile < pend ? lo + (int64_t)gt * kMsTile : pend;
+  // per digit: the group's record count, the cumulative counts after each of its tiles, where its run starts
+  unsigned excl = 0, c = 0;
+  if (t < nb) {
+    excl = toffs[vt0 * nb + t];
+#pragma unroll
+    for (int q = 0; q < G; q++) {
+      if (q < gt) c += cnt[(vt0 + q) * nb + t];
+      if (q < G - 1) s_cum[q][t] = c;
+    }
+  }
+  s_cnt[t] = t < nb ? c : 0u;
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  if (t < nb) s_goff[t] = excl - s_start[t];
+  __syncthreads();
+  const int group_n = (int)(hi - lo);
+#pragma unroll 1
+  for (int ch = 0; ch < G; ch++) {
+    int dlo[kMsRows], dhi[kMsRows];
+#pragma unroll
+    for (int k = 0; k < kMsRows; k++) { dlo[k] = 0; dhi[k] = nb - 1; }
+#pragma unroll 1
+    for (int step = 0; step < 8; step++) {   // 2^7 ≥ nb
+#pragma unroll
+      for (int k = 0; k < kMsRows; k++) {
+        const int mid = (dlo[k] + dhi[k] + 1) >> 1;
+        const bool le = s_start[mid] <= (unsigned)(ch * kMsTile + k * kThreads + t);
+        dlo[k] = le ? mid : dlo[k];
+        dhi[k] = le ? dhi[k] : mid - 1;
+      }
+    }
+    int id[kMsRows];
+    unsigned short jp[kMsRows];
+#pragma unroll
+    for (int k = 0; k < kMsRows; k++) {
+      const int lp = ch * kMsTile + k * kThreads + t;
+      id[k] = 0; jp[k] = 0;
+      if (lp < group_n) {
+        const int64_t e = (int64_t)s_goff[dlo[k]] + lp;
+        id[k] = __builtin_nontemporal_load(&rec_id[e]);
+        jp[k] = __builtin_nontemporal_load(&rec_j[e]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMsRows; k++) {
+      const int lp = ch * kMsTile + k * kThreads + t;
+      if (lp < group_n) {
+        const unsigned q = (unsigned)lp - s_start[dlo[k]];   // offset in the group's run of this digit
+        int tile = 0;
+#pragma unroll
+        for (int w = 0; w < G - 1; w++) tile += q >= s_cum[w][dlo[k]] ? 1 : 0;
+        s_out[tile * kMsTile + jp[k]] = id[k];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < G * kMsRows; k++) {
+    const int i = k * kThreads + t;
+    if (i < group_n) __builtin_nontemporal_store(s_out[i], &rec_id1[lo + i]);
+  }
+}
+
 }  // namespace
 
 // Called by encode_core (ah_hash.hip) for 8-byte keys.  lp = log2 of the number of partitions (8 … 10).  *used = 1: out_* hold the
@@ -881,7 +990,10 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
     if (slots == kESlots2) enc_resolve_kernel<kESlots2><<<(unsigned)(P * rsplit), kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2, rsplit);
     else enc_resolve_kernel<kESlots><<<(unsigned)(P * rsplit), kThreads, 0, c->stream>>>(rec_slot, tab_first, bstart, rec_id2, rsplit);
     AH_LAUNCH_CHECK(c);
-    e2_unpermute_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec_id2, pj2, cnt2, toffs2, n, pstart, nb1, nb2, rec_id1);
+    if (c->opt_encode_unperm2_group >= 2 && nb1 <= 64 && nb2 <= 128)
+      e2_unpermute_group_kernel<4><<<(unsigned)(ah_ceil_div(ntiles + nb1, 4) + nb1), kThreads, 0, c->stream>>>(rec_id2, pj2, cnt2, toffs2, n, pstart, nb1, nb2, rec_id1);
+    else
+      e2_unpermute_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec_id2, pj2, cnt2, toffs2, n, pstart, nb1, nb2, rec_id1);
     AH_LAUNCH_CHECK(c);
     launch_enc_unpermute(c, rec_id1, prows1, cnt1, toffs1, nb1, ntiles, n, out_ids);
     AH_LAUNCH_CHECK(c);
