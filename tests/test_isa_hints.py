@@ -3,7 +3,8 @@
 They have been lost silently twice: `__builtin_nontemporal_load` through a `__builtin_bit_cast` to the carrier struct compiled to a plain
 load, and a hinted and a plain access of one address and type behind an inlined switch were merged into the plain one — the clustered
 Take ran 12 % slower each time and every parity test stayed green.  This test disassembles the kernels and looks for `nt` on their 16-byte
-accesses."""
+accesses — and, while the disassembly is there, checks the register / scratch budgets whose violation costs a kernel
+its second workgroup per CU."""
 import os
 import re
 import shutil
@@ -41,13 +42,37 @@ EXPECT = {
 }
 
 
+# source → [(mangled-name regex, max VGPRs or None, max scratch bytes)]: the occupancy cliffs of DESIGN.md §8 — a 1024-thread kernel that runs two
+# workgroups per CU has 64 registers (the group-by scatter at 66: 0.44 → 0.64 ms), 256-thread kernels with 8 waves per SIMD the same
+RESOURCES = {
+    "ah_groupby.hip": [
+        (r"gb_scatter_kernelILb1E", 64, 0),
+        (r"gb_aggregate_kernelILb1ELb0E", 128, 0),
+    ],
+    "ah_hash_part.hip": [
+        (r"gb_scatter_kernelILb0E", 64, 0),
+        (r"enc_unpermute_group_kernelILi4E", 64, 0),
+        (r"e2_unpermute_group_kernelILi4E", 64, 0),
+        (r"enc_table_kernelILi8192ELb1E", 128, 0),
+    ],
+    "ah_take.hip": [(r"take_vec_kernelILi8EiLb[01]ELi7E", 64, 0)],
+}
+
+
 def _disassemble(src, outdir):
     out = os.path.join(outdir, src + ".s")
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-S",
                         "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     mix, cur = {}, None
-    for line in open(out):
+    res = {}
+    text = open(out).read()
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        body = m.group(2)
+        v = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        p = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        res[m.group(1)] = (int(v.group(1)) if v else 0, int(p.group(1)) if p else 0)
+    for line in text.splitlines(keepends=True):
         m = re.match(r"^(_Z\w+):", line)
         if m:
             cur = m.group(1)
@@ -61,18 +86,29 @@ def _disassemble(src, outdir):
             if m:
                 k = m.group(1) + (" nt" if re.search(r"\bnt\b", line) else "")
                 mix[cur][k] = mix[cur].get(k, 0) + 1
-    return mix
+    return mix, res
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
-def test_streaming_kernels_carry_their_nontemporal_hints():
+def test_streaming_kernels_carry_their_nontemporal_hints_and_stay_inside_their_register_budgets():
+    sources = sorted(set(EXPECT) | set(RESOURCES))
     with tempfile.TemporaryDirectory() as d:
-        with ThreadPoolExecutor(len(EXPECT)) as ex:
-            mixes = dict(zip(EXPECT, ex.map(lambda s: _disassemble(s, d), EXPECT)))
+        with ThreadPoolExecutor(len(sources)) as ex:
+            parsed = dict(zip(sources, ex.map(lambda s: _disassemble(s, d), sources)))
     for src, checks in EXPECT.items():
+        mixes = parsed[src][0]
         for pat, want in checks:
-            hits = [k for k in mixes[src] if re.search(pat, k)]
+            hits = [k for k in mixes if re.search(pat, k)]
             assert hits, f"{src}: no kernel matches {pat}"
             for k in hits:
                 for ins, n in want.items():
-                    assert mixes[src][k].get(ins, 0) >= n, f"{src}: {k}: expected ≥ {n} × '{ins}', ISA has {mixes[src][k]}"
+                    assert mixes[k].get(ins, 0) >= n, f"{src}: {k}: expected ≥ {n} × '{ins}', ISA has {mixes[k]}"
+    for src, checks in RESOURCES.items():
+        res = parsed[src][1]
+        for pat, max_vgpr, max_scratch in checks:
+            hits = [k for k in res if re.search(pat, k)]
+            assert hits, f"{src}: no kernel matches {pat}"
+            for k in hits:
+                vgpr, scratch = res[k]
+                assert vgpr <= max_vgpr, f"{src}: {k}: {vgpr} VGPRs, budget {max_vgpr}"
+                assert scratch <= max_scratch, f"{src}: {k}: {scratch} bytes of scratch, budget {max_scratch}"
