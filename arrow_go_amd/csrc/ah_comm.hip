@@ -14,6 +14,7 @@
 #include <vector>
 #include <rccl/rccl.h>
 #include "ah_common.h"
+#include "ah_ddsum.h"
 
 struct ah_comm {
   ah_ctx* ctx;
@@ -398,27 +399,31 @@ AH_EXPORT int ah_comm_cmp_filter_sum_f64(ah_comm* m, int cmpop, const double* x,
   ah_ctx* c = m->ctx;
   AH_ENTER(c);
   if (!out_sum_host || !out_count_host) return ah_fail(c, AH_EINVALID, "comm_cmp_filter_sum: null result pointer");
-  if (m->world > 1024) return ah_fail(c, AH_EINVALID, "comm_cmp_filter_sum: world too large");
-  double* part = (double*)&c->dscalars[40];     // [40] sum, [41] count
-  int64_t* cnt = (int64_t*)&c->dscalars[41];
-  int rc = ah_cmp_filter_sum_f64_dev(c, cmpop, x, valid, off, n_local, threshold, part, cnt);
+  if (m->world > 768) return ah_fail(c, AH_EINVALID, "comm_cmp_filter_sum: world too large");   // 40 bytes per rank in the 32 KiB area
+  double* part = (double*)&c->dscalars[40];     // [40..43] {s, e, bs, be} of ah_ddsum.h, [44] count, [45] this rank's rounded sum (unused)
+  int64_t* cnt = (int64_t*)&c->dscalars[44];
+  int rc = ah_fused_f64_parts_dev(c, cmpop, x, valid, off, n_local, threshold, (double*)&c->dscalars[45], cnt, part);
   if (rc != AH_OK) return rc;
-  // Float64: an all-reduce adds in whatever order the ring runs; every rank gets every partial instead (16 bytes each) and
-  // adds them in RANK order — the same bytes on every rank and in every run of a given world size
+  // Float64: an all-reduce adds in whatever order the ring runs; every rank gets every rank's UN-ROUNDED accumulator instead
+  // (40 bytes each), merges them in rank order in double-double and rounds ONCE — the same bytes on every rank and in every
+  // run, and for every world size within 1 ULP of the exact sum over the undivided column like ah_cmp_filter_sum_f64 itself
+  // (rounding every rank's sum first would cost up to world ULPs and would turn [1e308 | 1e308 | −1e308] into +inf);
+  // non-finite rows follow the extended reals (ah_ddsum.h) however they fall over the ranks
   uint8_t* all = (uint8_t*)&c->dscalars[64];
-  if ((rc = ah_comm_allgather(m, part, all, 16)) != AH_OK) return rc;
-  std::vector<uint64_t> h((size_t)m->world * 2);
+  if ((rc = ah_comm_allgather(m, part, all, 40)) != AH_OK) return rc;
+  std::vector<uint64_t> h((size_t)m->world * 5);
   AH_HIP(c, hipMemcpyAsync(h.data(), all, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
-  double s = 0.0;
+  ah_ddx acc;
+  ah_ddx_init(acc);
   int64_t n = 0;
   for (int r = 0; r < m->world; r++) {
-    double p;
-    memcpy(&p, &h[2 * (size_t)r], 8);
-    s += p;
-    n += (int64_t)h[2 * (size_t)r + 1];
+    ah_ddx p;
+    memcpy(&p, &h[5 * (size_t)r], 32);
+    ah_ddx_merge(acc, p);
+    n += (int64_t)h[5 * (size_t)r + 4];
   }
-  *out_sum_host = s;
+  *out_sum_host = ah_ddx_result(acc);
   *out_count_host = n;
   return AH_OK;
 }

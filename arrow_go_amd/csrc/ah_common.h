@@ -166,8 +166,11 @@ int ah_groupby_partitioned_try(ah_ctx* ctx, int is_f64, const uint64_t* keys, co
                                int64_t* out_first_rows, int64_t* out_ngroups, int32_t* out_null_group, int* used);
 // internal (ah_sum.hip): the workgroup partials of one chunk written to a caller-owned array (16 bytes reserved per partial; *n_written
 // counts 8-byte partials for the integer sums, 16-byte ones for Float64), and the one final reduction over all of them
-int ah_sum_chunk_partials(ah_ctx* ctx, int is_f64, const void* buf, size_t len, void* partials16, int max_partials, int* n_written);
-int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials16, int n, void* res_dev);
+int ah_fused_f64_parts_dev(ah_ctx* ctx, int cmpop, const double* x, const uint8_t* valid, int64_t off, int64_t n, double threshold,
+                           double* out_sum_dev, int64_t* out_count_dev, double* out_parts_dev);
+size_t ah_sum_partial_bytes(int is_f64);
+int ah_sum_chunk_partials(ah_ctx* ctx, int is_f64, const void* buf, size_t len, void* partials, int max_partials, int* n_written);
+int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials, int n, void* res_dev);
 // internal (ah_hash_part.hip): unique / dictionary_encode of 8-byte keys by partitions of the key hash, 2^lp of them (8 … 10);
 // temporaries in the temp arena; *used says whether out_* hold the result
 int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,

@@ -173,7 +173,8 @@ static int ingest_sum(ah_ingest* g, int is_f64, const void* host, size_t len, vo
   const size_t rows_per_chunk = g->chunk_bytes / 8;
   const size_t nchunks = (len + rows_per_chunk - 1) / rows_per_chunk;
   constexpr int kMaxPartials = 512;
-  AHI(grow(c, (uint8_t**)&g->partials, &g->partials_bytes, nchunks * kMaxPartials * 16));
+  const size_t part_bytes = ah_sum_partial_bytes(is_f64);
+  AHI(grow(c, (uint8_t**)&g->partials, &g->partials_bytes, nchunks * kMaxPartials * part_bytes));
   std::vector<int> nparts(nchunks, 0);
   int total_parts = 0;
   for (size_t k = 0; k < nchunks; k++) {
@@ -181,8 +182,8 @@ static int ingest_sum(ah_ingest* g, int is_f64, const void* host, size_t len, vo
     const size_t r0 = k * rows_per_chunk, rows = len - r0 < rows_per_chunk ? len - r0 : rows_per_chunk;
     int rc = slot_upload(g, s, 0, (const uint8_t*)host + r0 * 8, rows * 8, true);
     if (rc == AH_OK) rc = slot_uploaded(g, s, false);
-    // integer partials are 8 bytes each, double-double ones 16: both are packed back to back so that the final kernel sees one array
-    if (rc == AH_OK) rc = ah_sum_chunk_partials(c, is_f64, g->slots[s].buf[0], rows, (uint8_t*)g->partials + (size_t)total_parts * (is_f64 ? 16 : 8),
+    // every chunk's partials are packed back to back so that the final kernel sees one array
+    if (rc == AH_OK) rc = ah_sum_chunk_partials(c, is_f64, g->slots[s].buf[0], rows, (uint8_t*)g->partials + (size_t)total_parts * part_bytes,
                                                 kMaxPartials, &nparts[k]);
     if (rc == AH_OK) rc = slot_computed(g, s);
     if (rc != AH_OK) return fail_drained(g, rc);

@@ -11,7 +11,8 @@
 // larger than the 256 MiB Infinity Cache at the benchmark size), UNROLL loads in
 // flight per lane, grid-stride over ≈8 workgroups per CU.
 //
-// Float64 numerics: each lane keeps a double-double (s, e) accumulator updated
+// Float64 numerics: each lane keeps a double-double (s, e) accumulator (plus a second, scaled one for rows ≥ 2^960, ±inf
+// and NaN: ah_ddsum.h — the result follows the extended reals) updated
 // with Knuth's TwoSum (6 flops/elem ≈ 7 TFLOP/s at 8 TB/s — an order of magnitude
 // under the fp64 VALU peak, so it is free under the memory bound).  Lanes, waves
 // and workgroups are merged in double-double as well, so the result is the exact
@@ -19,51 +20,52 @@
 // the true sum.  The reference's two paths (sequential vs 32 strided partials)
 // differ from EACH OTHER by more than that on general data.
 #include "ah_common.h"
+#include "ah_ddsum.h"
 
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;  // 16-byte loads in flight per lane
 
+// (s, e) for the rows below 2^960, (bs, be) — scaled by 2^-128 — for the rest: ah_ddsum.h
 struct AccDD {
-  double s, e;
-  __device__ __forceinline__ void init() { s = 0.0; e = 0.0; }
-  __device__ __forceinline__ void add(double x) {
-    double t = s + x;
-    double bp = t - s;
-    double err = (s - (t - bp)) + (x - bp);
-    s = t;
-    e += err;
-  }
-  __device__ __forceinline__ void merge(double os, double oe) {
-    double t = s + os;
-    double bp = t - s;
-    double err = (s - (t - bp)) + (os - bp);
-    s = t;
-    e += err + oe;
-  }
-  __device__ __forceinline__ void merge(const AccDD& o) { merge(o.s, o.e); }
+  ah_ddx a;
+  __device__ __forceinline__ void init() { ah_ddx_init(a); }
+  __device__ __forceinline__ void add(double x) { ah_ddx_add(a, x); }
+  // rows known to be below 2^960 (the caller looked at the whole group's high words)
+  __device__ __forceinline__ void add_small(double x) { ah_dd_add(a.s, a.e, x); }
+  __device__ __forceinline__ void merge(const AccDD& o) { ah_ddx_merge(a, o.a); }
   __device__ __forceinline__ void wave_reduce() {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      double os = __shfl_down(s, o, 64);
-      double oe = __shfl_down(e, o, 64);
-      merge(os, oe);
+      ah_ddx t;
+      t.s = __shfl_down(a.s, o, 64);
+      t.e = __shfl_down(a.e, o, 64);
+      t.bs = __shfl_down(a.bs, o, 64);
+      t.be = __shfl_down(a.be, o, 64);
+      ah_ddx_merge(a, t);
     }
   }
-  __device__ __forceinline__ double result() const { return s + e; }
+  __device__ __forceinline__ double result() const { return ah_ddx_result(a); }
+  static __device__ __forceinline__ unsigned hi_abs(double x) { return ah_dd_hi_abs(x); }
+  static constexpr unsigned kBigHi = AH_DDX_BIG_HI;
+  static constexpr bool kClassed = true;
 };
 
 struct AccU64 {
   uint64_t s;
   __device__ __forceinline__ void init() { s = 0; }
   __device__ __forceinline__ void add(uint64_t x) { s += x; }
+  __device__ __forceinline__ void add_small(uint64_t x) { s += x; }
   __device__ __forceinline__ void merge(const AccU64& o) { s += o.s; }
   __device__ __forceinline__ void wave_reduce() {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   }
   __device__ __forceinline__ uint64_t result() const { return s; }
+  static __device__ __forceinline__ unsigned hi_abs(uint64_t) { return 0; }
+  static constexpr unsigned kBigHi = 1;
+  static constexpr bool kClassed = false;   // integers have one class
 };
 
 template <typename T>
@@ -84,16 +86,12 @@ __device__ __forceinline__ void block_reduce_store(Acc acc, Acc* out) {
   }
 }
 
-// One partial per workgroup. buf_v points at the 16-byte-aligned body (nvec
-// 2-element vectors); head/tail (≤ 1 element each) are folded in by block 0.
-template <typename T, typename Acc, bool NT>
-__global__ __launch_bounds__(kBlock) void sum_partials_kernel(const Vec2<T>* __restrict__ body, int64_t nvec,
-                                                               const T* __restrict__ head, int nhead,
-                                                               const T* __restrict__ tail, int ntail,
-                                                               Acc* __restrict__ partials) {
-  Acc a0, a1;
-  a0.init();
-  a1.init();
+// One lane's walk over its share of the body.  CAREFUL = false: every row goes through the unguarded TwoSum (the loop of an
+// ordinary column: loads and additions overlap, nothing branches) and the largest high word met is returned; CAREFUL = true: every
+// row is classed first (ah_ddx_add).
+template <typename T, typename Acc, bool NT, bool CAREFUL>
+__device__ __forceinline__ unsigned sum_walk(const Vec2<T>* __restrict__ body, int64_t nvec, Acc& a0, Acc& a1) {
+  unsigned top = 0;
   const int64_t stride = (int64_t)gridDim.x * kBlock * kUnroll;
   int64_t i = (int64_t)blockIdx.x * kBlock * kUnroll + threadIdx.x;
   // full iterations: all kUnroll loads issued before any use
@@ -106,8 +104,14 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const Vec2<T>* __r
     }
 #pragma unroll
     for (int k = 0; k < kUnroll; k++) {
-      a0.add(v[k].x);
-      a1.add(v[k].y);
+      if (CAREFUL) {
+        a0.add(v[k].x);
+        a1.add(v[k].y);
+      } else {
+        a0.add_small(v[k].x);
+        a1.add_small(v[k].y);
+        top = max(top, max(Acc::hi_abs(v[k].x), Acc::hi_abs(v[k].y)));
+      }
     }
   }
   // ragged last iteration
@@ -119,6 +123,30 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const Vec2<T>* __r
       a0.add(v.x);
       a1.add(v.y);
     }
+  }
+  return top;
+}
+
+// One partial per workgroup. body points at the 16-byte-aligned region (nvec
+// 2-element vectors); head/tail (≤ 1 element each) are folded in by block 0.
+//
+// Float64: the first walk treats every row as an ordinary one and only REMEMBERS the largest high word it met (one AND and
+// one MAX per row beside the seven additions).  A wave in which some lane met a row ≥ 2^960, ±inf or NaN throws its sums away
+// and walks its share again with every row classed (ah_ddsum.h): an ordinary column never takes a branch inside the loop, a
+// column with a few special rows re-reads the shares of the few waves that met them, a column full of them costs two reads.
+template <typename T, typename Acc, bool NT>
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(const Vec2<T>* __restrict__ body, int64_t nvec,
+                                                               const T* __restrict__ head, int nhead,
+                                                               const T* __restrict__ tail, int ntail,
+                                                               Acc* __restrict__ partials) {
+  Acc a0, a1;
+  a0.init();
+  a1.init();
+  const unsigned top = sum_walk<T, Acc, NT, false>(body, nvec, a0, a1);
+  if (Acc::kClassed && __any(top >= Acc::kBigHi)) {   // wave-uniform
+    a0.init();
+    a1.init();
+    (void)sum_walk<T, Acc, NT, true>(body, nvec, a0, a1);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int k = 0; k < nhead; k++) a0.add(head[k]);
@@ -208,15 +236,16 @@ int sum_host(ah_ctx* c, const T* buf, size_t len, T* res_host) {
 
 }  // namespace
 
-// internal (ah_ingest.hip): 16 bytes per partial whatever the type
-int ah_sum_chunk_partials(ah_ctx* c, int is_f64, const void* buf, size_t len, void* partials16, int max_partials, int* n_written) {
-  if (is_f64) return sum_chunk<double, AccDD>(c, (const double*)buf, len, (AccDD*)partials16, max_partials, n_written);
-  return sum_chunk<uint64_t, AccU64>(c, (const uint64_t*)buf, len, (AccU64*)partials16, max_partials * 2, n_written);
+// internal (ah_ingest.hip): ah_sum_partial_bytes(is_f64) bytes per partial
+size_t ah_sum_partial_bytes(int is_f64) { return is_f64 ? sizeof(AccDD) : sizeof(AccU64); }
+int ah_sum_chunk_partials(ah_ctx* c, int is_f64, const void* buf, size_t len, void* partials, int max_partials, int* n_written) {
+  if (is_f64) return sum_chunk<double, AccDD>(c, (const double*)buf, len, (AccDD*)partials, max_partials, n_written);
+  return sum_chunk<uint64_t, AccU64>(c, (const uint64_t*)buf, len, (AccU64*)partials, max_partials, n_written);
 }
-int ah_sum_finish_partials(ah_ctx* c, int is_f64, const void* partials16, int n, void* res_dev) {
+int ah_sum_finish_partials(ah_ctx* c, int is_f64, const void* partials, int n, void* res_dev) {
   if (n <= 0) { AH_HIP(c, hipMemsetAsync(res_dev, 0, 8, c->stream)); return AH_OK; }
-  if (is_f64) sum_final_kernel<double, AccDD><<<1, kBlock, 0, c->stream>>>((const AccDD*)partials16, n, (double*)res_dev);
-  else sum_final_kernel<uint64_t, AccU64><<<1, kBlock, 0, c->stream>>>((const AccU64*)partials16, n, (uint64_t*)res_dev);
+  if (is_f64) sum_final_kernel<double, AccDD><<<1, kBlock, 0, c->stream>>>((const AccDD*)partials, n, (double*)res_dev);
+  else sum_final_kernel<uint64_t, AccU64><<<1, kBlock, 0, c->stream>>>((const AccU64*)partials, n, (uint64_t*)res_dev);
   AH_LAUNCH_CHECK(c);
   return AH_OK;
 }

@@ -324,45 +324,6 @@ func (x *Context) IsIn(byteWidth int, values, valid unsafe.Pointer, off, n int64
 		C.int64_t(setN), C.int(nullBehavior), (*C.uint8_t)(outData), (*C.uint8_t)(outValid), C.int64_t(outBitOffset)))
 }
 
-// Comm is this rank's RCCL communicator on the Context's compute stream (one process per GPU; SURVEY.md §8e).  Rank 0 makes
-// the id with CommUniqueID and the launcher ships the 128 bytes to the other ranks.
-type Comm struct {
-	x *Context
-	c *C.ah_comm
-}
-
-func CommUniqueID() (id [128]byte, err error) {
-	if st := C.ah_comm_unique_id(unsafe.Pointer(&id[0])); st != C.AH_OK {
-		err = fmt.Errorf("arrowhip: ah_comm_unique_id failed (status %d): is librccl.so loadable?", int(st))
-	}
-	return
-}
-
-func (x *Context) NewComm(rank, world int, id [128]byte) (*Comm, error) {
-	var c *C.ah_comm
-	if err := x.err(C.ah_comm_init(x.c, C.int(rank), C.int(world), unsafe.Pointer(&id[0]), &c)); err != nil {
-		return nil, err
-	}
-	return &Comm{x: x, c: c}, nil
-}
-
-func (m *Comm) Close() { C.ah_comm_destroy(m.c) }
-
-// AllReduceSum: C4's only exchange step — the 16-byte {sum, count} of CmpFilterSumInt64Dev, in place.
-func (m *Comm) AllReduceSum(typ arrow.Type, send, recv unsafe.Pointer, count int64) error {
-	return m.x.err(C.ah_comm_allreduce_sum(m.c, C.int(typ), send, recv, C.int64_t(count)))
-}
-
-func (m *Comm) AllGather(send, recv unsafe.Pointer, nbytesPerRank int64) error {
-	return m.x.err(C.ah_comm_allgather(m.c, send, recv, C.int64_t(nbytesPerRank)))
-}
-
-// AllToAllV: the ragged exchange of group tuples for C5's key-hash-owner merge; sizes and offsets in bytes, one per rank.
-func (m *Comm) AllToAllV(send unsafe.Pointer, sendBytes, sendOffs []int64, recv unsafe.Pointer, recvBytes, recvOffs []int64) error {
-	p := func(v []int64) *C.int64_t { return (*C.int64_t)(unsafe.Pointer(&v[0])) }
-	return m.x.err(C.ah_comm_alltoallv(m.c, send, p(sendBytes), p(sendOffs), recv, p(recvBytes), p(recvOffs)))
-}
-
 // HashBinaryEncode mirrors doAppendBinary over BinaryMemoTable (vector_hash.go:288-325): ids in first-seen
 // order and, per dictionary entry, the row that first held it; the dictionary itself is
 // TakeBinary(values, firstRows[:ndict]).

@@ -8,7 +8,6 @@ package arrowhip
 import "C"
 
 import (
-	"fmt"
 	"unsafe"
 
 	"github.com/apache/arrow-go/v18/arrow"
@@ -111,56 +110,4 @@ func (i *Ingest) FilterPrimitive(w int, values, vvalid []byte, voff, n, nOut int
 	var nc C.int64_t
 	err = i.ctx.err(C.ah_ingest_filter_primitive(i.g, C.int(w), unsafe.Pointer(&values[0]), vv, C.int64_t(voff), C.int64_t(n), C.int64_t(nOut), op, ov, &nc))
 	return int64(nc), err
-}
-
-// ---- configs C4 / C5 as single calls (include/arrowhip.h "configs C4 / C5 as single calls") -----------------------------------
-
-// Comm is ah_comm: this rank's communicator (RCCL over xGMI; one process per GPU).
-type Comm struct {
-	ctx *Context
-	m   *C.ah_comm
-}
-
-// UniqueID: rank 0 makes it, the launcher ships the 128 bytes to the other ranks.
-func UniqueID() ([128]byte, error) {
-	var id [128]byte
-	if st := C.ah_comm_unique_id(unsafe.Pointer(&id[0])); st != C.AH_OK {
-		return id, fmt.Errorf("arrowhip: ah_comm_unique_id failed (is librccl.so loadable?)")
-	}
-	return id, nil
-}
-
-func (x *Context) NewComm(rank, world int, id [128]byte) (*Comm, error) {
-	var m *C.ah_comm
-	if err := x.err(C.ah_comm_init(x.c, C.int(rank), C.int(world), unsafe.Pointer(&id[0]), &m)); err != nil {
-		return nil, err
-	}
-	return &Comm{ctx: x, m: m}, nil
-}
-
-func (c *Comm) Close() {
-	if c.m != nil {
-		C.ah_comm_destroy(c.m)
-		c.m = nil
-	}
-}
-
-// CmpFilterSumInt64: config C4 over this rank's shard (device pointers) → the global (sum, count) on every rank.
-func (c *Comm) CmpFilterSumInt64(cmpop int, x, valid unsafe.Pointer, off, nLocal, threshold int64) (sum, count int64, err error) {
-	var s, n C.int64_t
-	err = c.ctx.err(C.ah_comm_cmp_filter_sum_i64(c.m, C.int(cmpop), (*C.int64_t)(x), (*C.uint8_t)(valid), C.int64_t(off), C.int64_t(nLocal), C.int64_t(threshold), &s, &n))
-	return int64(s), int64(n), err
-}
-
-// MergeGroups: config C5 — this rank's local aggregate (outputs of HashSum) → all groups in global first-seen order.
-func (c *Comm) MergeGroups(isF64 bool, keys, sums, counts, firstRows unsafe.Pointer, nLocal, rowOffset, capacity int64,
-	outKeys, outSums, outCounts, outFirstRows unsafe.Pointer) (int64, error) {
-	f := C.int(0)
-	if isF64 {
-		f = 1
-	}
-	var g C.int64_t
-	err := c.ctx.err(C.ah_comm_merge_groups(c.m, f, (*C.uint64_t)(keys), sums, (*C.int64_t)(counts), (*C.int64_t)(firstRows), C.int64_t(nLocal), C.int64_t(rowOffset),
-		C.int64_t(capacity), (*C.uint64_t)(outKeys), outSums, (*C.int64_t)(outCounts), (*C.int64_t)(outFirstRows), &g))
-	return int64(g), err
 }

@@ -19,7 +19,7 @@ import (
 // entry points) and the pytest suite.
 //
 // Two registration routes (SURVEY.md §8b):
-//   Register     — route (i): new functions ("add_unchecked_hip", "greater_hip", "array_filter_hip", …) in a CHILD
+//   Register     — route (i): new functions ("add_hip", "add_unchecked_hip", "greater_hip", "array_filter_hip", …) in a CHILD
 //                  registry (registry.go:69-73) carried by the returned context's ExecCtx (executor.go:110-112).
 //   SwapInPlace  — route (ii): the stock functions keep their names, dispatch and DispatchBest promotion; only the
 //                  ExecFn of the kernels this library covers is replaced, through funcImpl.Kernels()
@@ -125,11 +125,6 @@ func binaryExec(x *Context, typ arrow.Type, w int, op int8) exec.ArrayKernelExec
 	return func(_ *exec.KernelCtx, batch *exec.ExecSpan, out *exec.ExecResult) error {
 		n := out.Len
 		ob := out.Buffers[1].Buf[int(out.Offset)*w : (int(out.Offset)+int(n))*w]
-		do, err := x.Alloc(len(ob) + 64)
-		if err != nil {
-			return err
-		}
-		defer do.Free()
 		l, r := &batch.Values[0], &batch.Values[1]
 		// A large span of two arrays never sits in HBM whole: the chunked ingest (ingest.go → ah_ingest_arithmetic_binary) uploads
 		// chunk k + 1 while chunk k computes and chunk k − 1 downloads — 0.95 of the PCIe link instead of 0.66 for
@@ -151,6 +146,11 @@ func binaryExec(x *Context, typ arrow.Type, w int, op int8) exec.ArrayKernelExec
 			}
 			return ing.ArithmeticBinary(typ, op, lb, rb, ob, n)
 		}
+		do, err := x.Alloc(len(ob) + 64) // after the ingest branch: a large span never has its whole output in HBM
+		if err != nil {
+			return err
+		}
+		defer do.Free()
 		var kerr error
 		switch {
 		case l.IsArray() && r.IsArray():
@@ -182,6 +182,51 @@ func binaryExec(x *Context, typ arrow.Type, w int, op int8) exec.ArrayKernelExec
 		}
 		if kerr != nil {
 			return kerr
+		}
+		return do.Download(ob)
+	}
+}
+
+// checkedExec == ScalarBinaryNotNull over OpAddChecked / OpSubChecked / OpMulChecked (kernels/base_arithmetic.go:249-286,
+// kernels/helpers.go:284-380): the kernels behind the DEFAULT compute.Add / Subtract / Multiply ("add", "subtract",
+// "multiply": compute/arithmetic.go:635-636, 1095-1105).  Null slots are skipped (ADD / SUB leave 0 under them), an overflow in a
+// valid slot fails the call with arrow.ErrInvalid "overflow" (AH_EOVERFLOW → Context.err); floats have no checked flavour and
+// run the unchecked leaf (base_arithmetic_amd64.go:109-117) — the C entry point makes that choice itself.
+func checkedExec(x *Context, typ arrow.Type, w int, op int8) exec.ArrayKernelExec {
+	return func(_ *exec.KernelCtx, batch *exec.ExecSpan, out *exec.ExecResult) error {
+		n := out.Len
+		ob := out.Buffers[1].Buf[int(out.Offset)*w : (int(out.Offset)+int(n))*w]
+		l, r := &batch.Values[0], &batch.Values[1]
+		do, err := x.Alloc(len(ob) + 64)
+		if err != nil {
+			return err
+		}
+		defer do.Free()
+		var lp, lv, rp, rv unsafe.Pointer
+		var lo, ro int64
+		shape, scalarValid := shapeAA, true
+		if l.IsArray() {
+			dl, err := x.stage(&l.Array, w)
+			if err != nil {
+				return err
+			}
+			defer dl.free()
+			lp, lv, lo = dl.vals.Ptr, dl.validPtr(), dl.voff
+		} else {
+			lp, shape, scalarValid = scalarBytes(l.Scalar), shapeSA, l.Scalar.IsValid()
+		}
+		if r.IsArray() {
+			dr, err := x.stage(&r.Array, w)
+			if err != nil {
+				return err
+			}
+			defer dr.free()
+			rp, rv, ro = dr.vals.Ptr, dr.validPtr(), dr.voff
+		} else {
+			rp, shape, scalarValid = scalarBytes(r.Scalar), shapeAS, r.Scalar.IsValid()
+		}
+		if err := x.ArithmeticChecked(typ, op, shape, lp, lv, lo, rp, rv, ro, scalarValid, do.Ptr, n); err != nil {
+			return err
 		}
 		return do.Download(ob)
 	}
@@ -493,7 +538,7 @@ func perType(types []arrow.DataType, outType func(arrow.DataType) exec.OutputTyp
 // Register installs the GPU kernels in a child registry under "<name>_hip" and returns a context that carries it:
 //
 //	ctx, _ := arrowhip.Register(context.Background(), gpu)
-//	sum, _ := compute.CallFunction(ctx, "add_unchecked_hip", nil, a, b)
+//	sum, _ := compute.CallFunction(ctx, "add_hip", nil, a, b)            // checked, like compute.Add
 //	mask, _ := compute.CallFunction(ctx, "greater_hip", nil, sum, compute.NewDatum(int64(0)))
 //	kept, _ := compute.CallFunction(ctx, "array_filter_hip", compute.DefaultFilterOptions(), sum, mask)
 //
@@ -507,6 +552,10 @@ func Register(parent context.Context, x *Context) (context.Context, error) {
 	for name, op := range map[string]int8{"add_unchecked_hip": opAdd, "subtract_unchecked_hip": opSub, "multiply_unchecked_hip": opMul} {
 		op := op
 		specs = append(specs, funcSpec{name, perType(numeric, same, func(dt arrow.DataType) exec.ArrayKernelExec { return binaryExec(x, dt.ID(), width(dt), op) })})
+	}
+	for name, op := range map[string]int8{"add_hip": opAdd, "subtract_hip": opSub, "multiply_hip": opMul} { // the checked defaults
+		op := op
+		specs = append(specs, funcSpec{name, perType(numeric, same, func(dt arrow.DataType) exec.ArrayKernelExec { return checkedExec(x, dt.ID(), width(dt), op) })})
 	}
 	for name, c := range map[string]struct {
 		op   int
@@ -625,6 +674,11 @@ func SwapInPlace(x *Context) (restore func(), err error) {
 	for name, op := range map[string]int8{"add_unchecked": opAdd, "subtract_unchecked": opSub, "multiply_unchecked": opMul} {
 		op := op
 		swapScalar(name, func(dt arrow.DataType) exec.ArrayKernelExec { return binaryExec(x, dt.ID(), width(dt), op) })
+	}
+	// "add" / "subtract" / "multiply" — what compute.Add / Subtract / Multiply call unless NoCheckOverflow is set (arithmetic.go:1095-1105)
+	for name, op := range map[string]int8{"add": opAdd, "subtract": opSub, "multiply": opMul} {
+		op := op
+		swapScalar(name, func(dt arrow.DataType) exec.ArrayKernelExec { return checkedExec(x, dt.ID(), width(dt), op) })
 	}
 	for name, c := range map[string]int{"equal": cmpEQ, "not_equal": cmpNE, "greater": cmpGT, "greater_equal": cmpGE} {
 		c := c // "less" / "less_equal" are registered with flipped kernels of these (scalar_compare.go:73-99): swapped for free

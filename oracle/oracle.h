@@ -55,6 +55,7 @@ enum { ORC_OK = 0, ORC_EINVALID = 1, ORC_EINDEX = 2, ORC_EOVERFLOW = 3 };
 void orc_sum_float64_seq(const double* buf, size_t len, double* res);
 void orc_sum_float64_avx2order(const double* buf, size_t len, double* res);
 void orc_sum_float64_exact(const double* buf, size_t len, double* res);
+void orc_sum_float64_xreal(const double* buf, size_t len, double* res);   /* extended reals: ±inf, NaN, intermediate overflow */
 void orc_sum_int64(const int64_t* buf, size_t len, int64_t* res);
 void orc_sum_uint64(const uint64_t* buf, size_t len, uint64_t* res);
 

@@ -124,3 +124,93 @@ void orc_sum_uint64(const uint64_t* buf, size_t len, uint64_t* res) {
   for (size_t i = 0; i < len; i++) acc += buf[i];
   *res = acc;
 }
+
+/*
+ * The sum over the EXTENDED reals, rounded once — the yardstick for inputs that hold ±inf, NaN, or finite values whose
+ * running sum overflows in one summation order and not in another.  Both reference orders above return this value whenever
+ * neither overflows on the way (any NaN addend or both infinities → NaN; only +inf / −inf → that infinity; finite addends →
+ * the exact sum rounded to nearest even, ±inf only if THAT is beyond DBL_MAX); where they overflow in an intermediate sum
+ * they disagree with each other (tests/test_oracle_vs_reference.py shows a vector), so the order-free value is the rule.
+ *
+ * Method (deliberately unlike the double-double of the HIP kernels): a fixed-point superaccumulator — every finite double is
+ * an integer multiple of 2^-1074 below 2^1024, so the sum of < 2^63 of them fits 2098 + 63 bits.  72 limbs of 32 bits kept
+ * carry-save in int64 (normalised every 2^20 rows), sign-magnitude at the end, round to nearest even.
+ */
+#define XR_LIMBS 72
+static void xr_normalise(int64_t* l) {
+  int64_t carry = 0;
+  for (int i = 0; i < XR_LIMBS; i++) {
+    int64_t v = l[i] + carry;
+    carry = v >> 32;                 /* arithmetic shift: floor division */
+    l[i] = v & 0xffffffffLL;
+  }
+  l[XR_LIMBS - 1] += carry << 32;    /* the top limb keeps the sign */
+}
+
+void orc_sum_float64_xreal(const double* buf, size_t len, double* res) {
+  int64_t l[XR_LIMBS];
+  for (int i = 0; i < XR_LIMBS; i++) l[i] = 0;
+  int has_nan = 0, has_pinf = 0, has_ninf = 0;
+  size_t since = 0;
+  for (size_t k = 0; k < len; k++) {
+    uint64_t u;
+    __builtin_memcpy(&u, &buf[k], 8);
+    const int neg = (int)(u >> 63);
+    const int ex = (int)((u >> 52) & 0x7ff);
+    uint64_t m = u & 0xfffffffffffffULL;
+    if (ex == 0x7ff) {
+      if (m) has_nan = 1; else if (neg) has_ninf = 1; else has_pinf = 1;
+      continue;
+    }
+    int p;                           /* value = m · 2^(p − 1074) */
+    if (ex == 0) p = 0; else { m |= 1ULL << 52; p = ex - 1; }
+    if (m == 0) continue;
+    const int w = p >> 5, sh = p & 31;
+    /* m << sh spans up to 85 bits: three 32-bit pieces */
+    const uint64_t lo = m << sh;                         /* low 64 bits */
+    const uint64_t hi = sh ? (m >> (64 - sh)) : 0;       /* bits 64.. */
+    const int64_t a0 = (int64_t)(lo & 0xffffffffULL), a1 = (int64_t)(lo >> 32), a2 = (int64_t)hi;
+    if (neg) { l[w] -= a0; l[w + 1] -= a1; l[w + 2] -= a2; }
+    else { l[w] += a0; l[w + 1] += a1; l[w + 2] += a2; }
+    if (++since == (1u << 20)) { xr_normalise(l); since = 0; }
+  }
+  if (has_nan || (has_pinf && has_ninf)) { *res = NAN; return; }
+  if (has_pinf) { *res = INFINITY; return; }
+  if (has_ninf) { *res = -INFINITY; return; }
+  xr_normalise(l);
+  int negative = l[XR_LIMBS - 1] < 0;
+  if (negative) {                    /* two's complement → magnitude */
+    int64_t carry = 1;
+    for (int i = 0; i < XR_LIMBS - 1; i++) {
+      int64_t v = ((~l[i]) & 0xffffffffLL) + carry;
+      carry = v >> 32;
+      l[i] = v & 0xffffffffLL;
+    }
+    l[XR_LIMBS - 1] = ~l[XR_LIMBS - 1] + carry;
+  }
+  /* top set bit */
+  int top = -1;
+  for (int i = XR_LIMBS - 1; i >= 0 && top < 0; i--) {
+    uint64_t v = (uint64_t)l[i];
+    if (v) top = i * 32 + (63 - __builtin_clzll(v));
+  }
+  if (top < 0) { *res = 0.0; return; }   /* +0, like 0.0 + (−0.0) */
+#define XR_BIT(b) ((b) < 0 ? 0 : (int)(((uint64_t)l[(b) >> 5] >> ((b) & 31)) & 1))
+  uint64_t mant = 0;
+  double r;
+  if (top < 52) {                    /* subnormal or the smallest normals: every bit fits, exact */
+    for (int b = top; b >= 0; b--) mant = (mant << 1) | (uint64_t)XR_BIT(b);
+    __builtin_memcpy(&r, &mant, 8);  /* m · 2^-1074 has exactly this bit pattern */
+  } else {
+    for (int b = top; b > top - 53; b--) mant = (mant << 1) | (uint64_t)XR_BIT(b);
+    const int guard = XR_BIT(top - 53);
+    int sticky = 0;
+    for (int b = top - 54; b >= 0 && !sticky; b--) sticky = XR_BIT(b);
+    int e = top - 52 + 1;            /* biased exponent of mant · 2^(top−52−1074) */
+    if (guard && (sticky || (mant & 1))) { mant++; if (mant >> 53) { mant >>= 1; e++; } }
+    if (e >= 0x7ff) r = INFINITY;
+    else { uint64_t bits = ((uint64_t)e << 52) | (mant & 0xfffffffffffffULL); __builtin_memcpy(&r, &bits, 8); }
+  }
+#undef XR_BIT
+  *res = negative ? -r : r;
+}

@@ -37,19 +37,35 @@ dx = ctx.to_device(x[lo:hi]); dxf = ctx.to_device(xf[lo:hi]); dv = ctx.to_device
 for thr in (-5 * 10**8, 0, 7 * 10**8):
     assert sg.cmp_filter_sum(2, dx, dv, 0, hi - lo, thr, np.int64) == o.cmp_filter_sum_i64(2, x, vall, 0, thr), thr
 gotf = sg.cmp_filter_sum(2, dxf, dv, 0, hi - lo, 0.25, np.float64)
-parts = []
-for r in range(world):
-    l2, h2 = shard_bounds(n, r, world)
-    _, s_exact, _c = o.cmp_filter_sum_f64(2, xf[l2:h2], np.packbits(valid_bits[l2:h2], bitorder="little"), 0, 0.25)
-    parts.append(s_exact)
-tot = 0.0
-for p in parts:   # rank order: what every rank must have, bit for bit
-    tot += p
-assert gotf[1] == int(((xf > 0.25) & valid_bits).sum())
-assert abs(gotf[0] - tot) <= 4 * np.spacing(abs(tot)) * world, (gotf[0], tot)    # each partial is within 1 ULP of its exact sum
+# every rank's UN-ROUNDED double-double accumulator is gathered and merged in rank order, rounded once: within 1 ULP of the exact
+# sum over the undivided column whatever the world size (orc_sum_float64_xreal: the fixed-point superaccumulator)
+kept = xf[(xf > 0.25) & valid_bits]
+exact = float(o.sum_float64_xreal(kept))
+assert gotf[1] == kept.size
+assert abs(gotf[0] - exact) <= np.spacing(abs(exact)), (gotf[0], exact)
 allf = [None] * world
 dist.all_gather_object(allf, float(gotf[0]).hex())
 assert len(set(allf)) == 1, allf                                                    # the same bytes on every rank
+# non-finite rows and overflow follow the extended reals however the rows fall over the ranks (arrow/math/float64.go:41-47 for the
+# cases in which the reference's orders agree): the special row in the first / last rank's shard, in both, finite overflow across ranks
+inf, nan = np.inf, np.nan
+for label, edits in (("+inf on the first rank", {3: inf}), ("+inf on the last rank", {n - 2: inf}), ("+inf and -inf on different ranks", {5: inf, n - 7: -inf}),
+                     ("-inf only", {n // 2: -inf}), ("NaN is dropped by the compare", {11: nan, n - 11: nan}),
+                     ("finite overflow across ranks", {1: 1e308, n // 2 + 1: 1e308, n - 3: 1e308}),
+                     ("intermediate overflow only", {1: 1e308, 2: 1e308, n - 3: -1e308, n - 4: -1e308})):
+    y = xf.copy()
+    vb = valid_bits.copy()
+    for i, v in edits.items():
+        y[i] = v
+        vb[i] = True
+    dy = ctx.to_device(y[lo:hi]); dvb = ctx.to_device(np.packbits(vb[lo:hi], bitorder="little"), pad=64)
+    thr = -np.inf
+    got = sg.cmp_filter_sum(3, dy, dvb, 0, hi - lo, thr, np.float64)     # x >= -inf: everything but NaN
+    keep = y[(y >= thr) & vb]
+    want = float(o.sum_float64_xreal(keep))
+    assert got[1] == keep.size, label
+    assert (np.isnan(want) and np.isnan(got[0])) or got[0] == want or (np.isfinite(want) and abs(got[0] - want) <= np.spacing(abs(want))), (label, got[0], want)
+    assert np.isfinite(got[0]) == np.isfinite(want) and np.isnan(got[0]) == np.isnan(want), (label, got[0], want)
 
 
 def local_aggregate(kind, keys, vals):

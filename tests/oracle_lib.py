@@ -49,6 +49,7 @@ class Oracle:
             "orc_sum_float64_seq": (None, [vp, sz, vp]),
             "orc_sum_float64_avx2order": (None, [vp, sz, vp]),
             "orc_sum_float64_exact": (None, [vp, sz, vp]),
+            "orc_sum_float64_xreal": (None, [vp, sz, vp]),
             "orc_sum_int64": (None, [vp, sz, vp]),
             "orc_sum_uint64": (None, [vp, sz, vp]),
             "orc_arithmetic_binary": (it, [it, i8, vp, vp, vp, i64]),
@@ -103,6 +104,7 @@ class Oracle:
     def sum_float64_seq(self, a): return self._sum("orc_sum_float64_seq", a, np.float64)
     def sum_float64_avx2order(self, a): return self._sum("orc_sum_float64_avx2order", a, np.float64)
     def sum_float64_exact(self, a): return self._sum("orc_sum_float64_exact", a, np.float64)
+    def sum_float64_xreal(self, a): return self._sum("orc_sum_float64_xreal", a, np.float64)
     def sum_int64(self, a): return self._sum("orc_sum_int64", a, np.int64)
     def sum_uint64(self, a): return self._sum("orc_sum_uint64", a, np.uint64)
 

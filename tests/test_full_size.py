@@ -185,6 +185,50 @@ def test_c5_hash_2_26(hip, orc_be, lg, dist):
         same(g[k], e[k], f"hash_sum f64 {what}")
 
 
+def test_c2_float64_sum_nonfinite_2_27(ctx):
+    """Float64 Sum and the fused C4 sum at 2^27 rows with ±inf / NaN / overflowing rows in the head, the body, the odd tail and the last
+    workgroup: the extended-real rule of csrc/ah_ddsum.h — the value both reference orders return (arrow/math/float64.go:41-47) — and
+    the ordinary column still within 1 ULP of the exact sum"""
+    import math
+    from tests import oracle_lib as OL
+    o, ref = OL.load_oracle(), OL.load_reference()
+    rng = np.random.default_rng(2027)
+    n = N27 - 1                                   # odd tail row
+    base = rng.standard_normal(n)
+    d = ctx.alloc(base.nbytes + 64)
+    inf, nan = math.inf, math.nan
+    exact = float(o.sum_float64_xreal(base))
+    for misalign in (0, 1):
+        d.upload(base, misalign * 8)
+        got = ctx.sum_float64(d.ptr + misalign * 8, n)
+        assert abs(got - exact) <= math.ulp(exact), (got, exact)
+    for label, edits, want in (("+inf head", {0: inf}, inf), ("-inf tail", {n - 1: -inf}, -inf), ("nan body", {n // 2 + 1: nan}, nan),
+                               ("both infinities, far apart", {1: inf, n - 2: -inf}, nan), ("+inf in the last workgroup", {n - 4097: inf}, inf),
+                               ("finite overflow", {7: 1e308, n // 3: 1e308, n - 9: 1e308}, inf),
+                               ("negative finite overflow", {8: -1e308, n // 3: -1e308, n - 10: -1.5e308}, -inf),
+                               ("intermediate overflow only", {7: 1e308, n // 3: 1e308, n // 3 + 2: -1e308, n - 9: -1e308}, None)):
+        col = base.copy()
+        for i, v in edits.items():
+            col[i] = v
+        if want is None:
+            want = float(o.sum_float64_xreal(col))
+            assert math.isfinite(want)
+        elif ref is not None:
+            for which in ("seq", "avx2"):
+                r = float(ref.sum(which, col))
+                assert (math.isnan(r) and math.isnan(want)) or r == want, (label, which, r)
+        d.upload(col, 8)
+        got = ctx.sum_float64(d.ptr + 8, n)
+        ok = (math.isnan(got) and math.isnan(want)) or got == want or (math.isfinite(want) and abs(got - want) <= math.ulp(want))
+        assert ok, (label, got, want)
+        s, c = ctx.cmp_filter_sum_f64(3, d.ptr + 8, None, 0, n, -inf)       # x >= -inf keeps every row but NaN
+        keep_nan = any(isinstance(v, float) and math.isnan(v) for v in edits.values())
+        assert c == n - (1 if keep_nan else 0), (label, c)
+        want_f = float(o.sum_float64_xreal(col[~np.isnan(col)])) if keep_nan else want
+        ok = (math.isnan(s) and math.isnan(want_f)) or s == want_f or (math.isfinite(want_f) and abs(s - want_f) <= math.ulp(want_f))
+        assert ok, (label, "fused", s, want_f)
+
+
 def test_c2_sum_and_cumulative_sum_2_27(hip, orc_be, column):
     a, av = column
     assert hip.sum(a) == orc_be.sum(a)
