@@ -187,7 +187,7 @@ _SIGS.update({
     "ah_comm_init_transport": [_vp, _int, _int, C.POINTER(AhTransport), _pvp],
     "ah_comm_cmp_filter_sum_i64": [_vp, _int, _vp, _vp, _i64, _i64, _i64, _pi64, _pi64],
     "ah_comm_cmp_filter_sum_f64": [_vp, _int, _vp, _vp, _i64, _i64, C.c_double, _pd, _pi64],
-    "ah_comm_merge_groups": [_vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _pi64],
+    "ah_comm_merge_groups": [_vp, _int, _vp, _vp, _vp, _vp, _i64, C.c_int32, _i64, _i64, _vp, _vp, _vp, _vp, _pi64, _pi32],
     "ah_graph_begin": [_vp],
     "ah_graph_end": [_vp, _pvp],
     "ah_graph_launch": [_vp, _vp],

@@ -26,6 +26,7 @@ struct ah_comm {
   uint8_t* arena; size_t arena_bytes;     // merge_groups: bucketing, exchange and re-aggregation
   uint8_t* arena2; size_t arena2_bytes;   // merge_groups: the gathered groups (reserved while the first still holds live data)
   uint8_t* stage; size_t stage_bytes;
+  uint8_t* gather; size_t gather_bytes;   // comm_allgather_host over RCCL: the (world + 1) × count words of a size table
 };
 
 namespace {
@@ -233,6 +234,7 @@ AH_EXPORT int ah_comm_destroy(ah_comm* m) {
   if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
   if (m->arena) (void)hipFree(m->arena);
   if (m->arena2) (void)hipFree(m->arena2);
+  if (m->gather) (void)hipFree(m->gather);
   if (m->stage) (void)hipHostFree(m->stage);
   free(m);
   return AH_OK;
@@ -366,8 +368,11 @@ static int comm_allgather_host(ah_comm* m, const int64_t* mine, int count, int64
     const int trc = m->transport.allgather(m->transport.user, mine, all, (int64_t)nb);
     return trc ? transport_fail(c, "allgather", trc) : AH_OK;
   }
-  if ((size_t)(m->world + 1) * nb > 4096 * 8) return ah_fail(c, AH_EINVALID, "comm: size vector too long");
-  uint8_t* d = (uint8_t*)&c->dscalars[64];   // the popcount partials area: idle between kernels
+  uint8_t* d = (uint8_t*)&c->dscalars[64];   // the popcount partials area (32 KiB): idle between kernels
+  if ((size_t)(m->world + 1) * nb > 4096 * 8) {   // a world × world size table from 64 ranks on: a block of the communicator's own
+    int grc = arena_reserve_in(m, &m->gather, &m->gather_bytes, (size_t)(m->world + 1) * nb, &d);
+    if (grc != AH_OK) return grc;
+  }
   AH_HIP(c, hipMemcpyAsync(d, mine, nb, hipMemcpyHostToDevice, c->stream));
   AH_NCCL(c, g_rccl.AllGather(d, d + nb, nb, ncclUint8, m->comm, c->stream));
   AH_HIP(c, hipMemcpyAsync(all, d + nb, nb * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
@@ -440,20 +445,59 @@ AH_EXPORT int ah_comm_cmp_filter_sum_f64(ah_comm* m, int cmpop, const double* x,
 //     (kernels/vector_hash.go:359-385, 721-741: first-seen order)
 // All device buffers; out_* hold up to `capacity` groups.  *out_ngroups_host = number of global groups; AH_EINVALID with that
 // number set when `capacity` is too small (nothing written).
+//
+// The NULL group (ah_hash_sum_* reports it as out_null_group: a group whose key slot holds 0 but which is not the key 0) has no key
+// to be owned by: it is taken out of the local columns, every rank's null tuple travels in one small all-gather, every rank merges
+// them in rank order (Float64: through the same fixed-point re-aggregation as the owners', so the bytes agree on all ranks), and
+// the merged group joins the others before the final ordering by first row.  *out_null_group_host = its position, −1 if no rank had one.
 AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys, const void* sums, const int64_t* counts, const int64_t* first_rows,
-                                   int64_t ngroups_local, int64_t row_offset, int64_t capacity, uint64_t* out_keys, void* out_sums,
-                                   int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups_host) {
+                                   int64_t ngroups_local, int32_t null_group_local, int64_t row_offset, int64_t capacity, uint64_t* out_keys,
+                                   void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups_host,
+                                   int32_t* out_null_group_host) {
   if (!m) return AH_EINVALID;
   ah_ctx* c = m->ctx;
   AH_ENTER(c);
   if (!out_ngroups_host) return ah_fail(c, AH_EINVALID, "merge_groups: null result pointer");
   *out_ngroups_host = 0;
+  if (out_null_group_host) *out_null_group_host = -1;
   const int W = m->world;
-  const int64_t g = ngroups_local;
+  int64_t g = ngroups_local;
   if (g < 0 || capacity < 0) return ah_fail(c, AH_EINVALID, "merge_groups: negative count");
   if (g > 0 && (!keys || !sums || !counts || !first_rows)) return ah_fail(c, AH_EINVALID, "merge_groups: null input");
+  if (null_group_local < -1 || (int64_t)null_group_local >= g) return ah_fail(c, AH_EINVALID, "merge_groups: null group %d of %lld groups", (int)null_group_local, (long long)g);
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   int rc;
+  // ---- 0: the null group leaves the local columns; {has one, sum bits, count, global first row} of every rank to every rank
+  int64_t null_mine[4] = {0, 0, 0, 0};
+  if (null_group_local >= 0) {
+    const size_t at = (size_t)null_group_local * 8;
+    null_mine[0] = 1;
+    AH_HIP(c, hipMemcpyAsync(&null_mine[1], (const uint8_t*)sums + at, 8, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipMemcpyAsync(&null_mine[2], (const uint8_t*)counts + at, 8, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipMemcpyAsync(&null_mine[3], (const uint8_t*)first_rows + at, 8, hipMemcpyDeviceToHost, c->stream));
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    null_mine[3] += row_offset;
+    // the other g − 1 groups, closed up, in the communicator's second block (free until step 4)
+    uint8_t* cmp;
+    if ((rc = arena2_reserve(m, pad((size_t)g * 8) * 4 + 4096, &cmp)) != AH_OK) return rc;
+    const void* cols[4] = {keys, sums, counts, first_rows};
+    const void* closed[4];
+    const size_t before = (size_t)null_group_local * 8, after = (size_t)(g - 1 - null_group_local) * 8;
+    for (int k = 0; k < 4; k++) {
+      uint8_t* dst = cmp + (size_t)k * pad((size_t)g * 8);
+      if (before && (rc = ah_copy_async(c, dst, cols[k], before)) != AH_OK) return rc;
+      if (after && (rc = ah_copy_async(c, dst + before, (const uint8_t*)cols[k] + before + 8, after)) != AH_OK) return rc;
+      closed[k] = dst;
+    }
+    keys = (const uint64_t*)closed[0]; sums = closed[1]; counts = (const int64_t*)closed[2]; first_rows = (const int64_t*)closed[3];
+    g -= 1;
+  }
+  std::vector<int64_t> null_all((size_t)W * 4, 0);
+  if (W == 1) memcpy(null_all.data(), null_mine, sizeof(null_mine));
+  else if ((rc = comm_allgather_host(m, null_mine, 4, null_all.data())) != AH_OK) return rc;
+  int n_null_ranks = 0;
+  for (int r = 0; r < W; r++) n_null_ranks += null_all[(size_t)r * 4] != 0;
+  const int64_t has_null = n_null_ranks > 0 ? 1 : 0;
   // ---- 1: owners and the send blocks (block r = four columns of g_r values, back to back)
   if (W > kOwnMaxWorld) return ah_fail(c, AH_EINVALID, "merge_groups: world beyond %d", kOwnMaxWorld);
   uint8_t* a0;
@@ -508,7 +552,10 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
     uint8_t* keep = nullptr;
     if (g > 0) {
       AH_HIP(c, hipMalloc((void**)&keep, (size_t)g * 32));
-      AH_HIP(c, hipMemcpyAsync(keep, sendbuf, (size_t)g * 32, hipMemcpyDeviceToDevice, c->stream));
+      if (hipMemcpyAsync(keep, sendbuf, (size_t)g * 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+        (void)hipFree(keep);
+        return ah_fail(c, AH_EHIP, "merge_groups: copy failed");
+      }
     }
     rc = arena_reserve(m, need2, &a0);
     if (rc == AH_OK && g > 0) {
@@ -564,16 +611,17 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
   else if ((rc = comm_allgather_host(m, &ng_local, 1, gcnt.data())) != AH_OK) return rc;
   int64_t G = 0, mx = 0;
   for (int r = 0; r < W; r++) { G += gcnt[r]; mx = gcnt[r] > mx ? gcnt[r] : mx; }
-  *out_ngroups_host = G;
-  if (G > capacity) return ah_fail(c, AH_EINVALID, "merge_groups: %lld groups, the outputs hold %lld", (long long)G, (long long)capacity);
-  if (G == 0) return AH_OK;
+  const int64_t GT = G + has_null;   // with the merged null group
+  *out_ngroups_host = GT;
+  if (GT > capacity) return ah_fail(c, AH_EINVALID, "merge_groups: %lld groups, the outputs hold %lld", (long long)GT, (long long)capacity);
+  if (GT == 0) return AH_OK;
   if (!out_keys || !out_sums || !out_counts || !out_first_rows) return ah_fail(c, AH_EINVALID, "merge_groups: null output");
   // blocks of 4 columns × mx (padded) per rank; then the columns are laid end to end, rank order.  All of it in the communicator's
   // SECOND block: the first still holds the re-aggregated columns
   uint8_t* blk_local;
-  if ((rc = arena2_reserve(m, pad((size_t)mx * 32) + pad((size_t)mx * 32 * (size_t)W) + pad((size_t)G * 8) * 5 + 4096, &blk_local)) != AH_OK) return rc;
+  if ((rc = arena2_reserve(m, pad((size_t)mx * 32) + pad((size_t)mx * 32 * (size_t)W) + pad((size_t)GT * 8) * 5 + pad((size_t)GT / 8 + 64) + pad((size_t)W * 8) * 8 + 4096, &blk_local)) != AH_OK) return rc;
   uint8_t* b0 = blk_local + pad((size_t)mx * 32);
-  {
+  if (G > 0) {
     const void* cols[4] = {ok, osum, csum, ofirst_rows};
     for (int k = 0; k < 4 && ng > 0; k++)
       if ((rc = ah_copy_async(c, blk_local + (size_t)k * (size_t)mx * 8, cols[k], (size_t)ng * 8)) != AH_OK) return rc;
@@ -583,9 +631,11 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
   }
   uint8_t* colbase = b0 + pad((size_t)mx * 32 * (size_t)W);
   uint8_t* col[4];
-  for (int k = 0; k < 4; k++) col[k] = colbase + (size_t)k * pad((size_t)G * 8);
-  uint64_t* order = (uint64_t*)(colbase + 4 * pad((size_t)G * 8));
-  {
+  for (int k = 0; k < 4; k++) col[k] = colbase + (size_t)k * pad((size_t)GT * 8);
+  uint64_t* order = (uint64_t*)(colbase + 4 * pad((size_t)GT * 8));
+  uint8_t* before_bits = (uint8_t*)order + pad((size_t)GT * 8);
+  uint8_t* nullwork = before_bits + pad((size_t)GT / 8 + 64);   // 8 arrays of W words
+  if (G > 0) {
     int64_t at = 0;
     for (int r = 0; r < W; r++) {
       const size_t nb = (size_t)gcnt[r] * 8;
@@ -594,11 +644,56 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
       at += gcnt[r];
     }
   }
+  // ---- 4b: the merged null group becomes tuple G: {0, Σ sums, Σ counts, the smallest global first row}
+  std::vector<int64_t> nk, ns, ncnt;   // (host staging: alive until the synchronisation at the end)
+  int64_t null_tuple[4] = {0, 0, 0, 0};
+  if (has_null) {
+    int64_t first = INT64_MAX, cnt = 0;
+    uint64_t isum = 0;
+    for (int r = 0; r < W; r++) {
+      const int64_t* t = &null_all[(size_t)r * 4];
+      if (!t[0]) continue;
+      nk.push_back(0); ns.push_back(t[1]); ncnt.push_back(t[2]);
+      isum += (uint64_t)t[1];
+      cnt += t[2];
+      if (t[3] < first) first = t[3];
+    }
+    null_tuple[1] = (int64_t)isum; null_tuple[2] = cnt; null_tuple[3] = first;
+    const size_t wpad = pad((size_t)W * 8);
+    for (int k = 0; k < 4; k++)
+      if (k != 1 || !is_f64 || n_null_ranks == 1) AH_HIP(c, hipMemcpyAsync(col[k] + (size_t)G * 8, &null_tuple[k], 8, hipMemcpyHostToDevice, c->stream));
+    if (is_f64 && n_null_ranks == 1) {
+      AH_HIP(c, hipMemcpyAsync(col[1] + (size_t)G * 8, &ns[0], 8, hipMemcpyHostToDevice, c->stream));   // one partial: its own bytes
+    } else if (is_f64) {
+      // several partial sums: the owners' re-aggregation (ah_hash_sum_f64 over tuples of one key), on every rank alike
+      uint64_t* dk = (uint64_t*)nullwork;
+      double* dsum = (double*)(nullwork + wpad);
+      uint64_t* okk = (uint64_t*)(nullwork + 2 * wpad);
+      double* osm = (double*)(nullwork + 3 * wpad);
+      int64_t* oc = (int64_t*)(nullwork + 4 * wpad);
+      int64_t* of = (int64_t*)(nullwork + 5 * wpad);
+      AH_HIP(c, hipMemcpyAsync(dk, nk.data(), nk.size() * 8, hipMemcpyHostToDevice, c->stream));
+      AH_HIP(c, hipMemcpyAsync(dsum, ns.data(), ns.size() * 8, hipMemcpyHostToDevice, c->stream));
+      int64_t one = 0;
+      if ((rc = ah_hash_sum_f64(c, dk, nullptr, 0, dsum, nullptr, 0, (int64_t)nk.size(), okk, osm, oc, of, &one, nullptr)) != AH_OK) return rc;
+      if (one != 1) return ah_fail(c, AH_EINVALID, "merge_groups: internal error (null group merge)");
+      if ((rc = ah_copy_async(c, col[1] + (size_t)G * 8, osm, 8)) != AH_OK) return rc;
+    }
+    // its position in first-seen order = the groups first seen before it (first rows are distinct: a row has one key)
+    if (G > 0) {
+      int64_t pos = 0;
+      if ((rc = ah_comparison(c, AH_CMP_GT, AH_SHAPE_SA, AH_INT64, &null_tuple[3], col[3], before_bits, G, 0)) != AH_OK) return rc;
+      if ((rc = ah_count_set_bits(c, before_bits, 0, G, &pos)) != AH_OK) return rc;
+      if (out_null_group_host) *out_null_group_host = (int32_t)pos;
+    } else if (out_null_group_host) {
+      *out_null_group_host = 0;
+    }
+  }
   // ---- 5: global first-seen order
-  if ((rc = ah_sort_indices(c, AH_INT64, col[3], nullptr, 0, G, 0, 0, order)) != AH_OK) return rc;
+  if ((rc = ah_sort_indices(c, AH_INT64, col[3], nullptr, 0, GT, 0, 0, order)) != AH_OK) return rc;
   void* outs[4] = {out_keys, out_sums, out_counts, out_first_rows};
   for (int k = 0; k < 4; k++)
-    if ((rc = ah_take_primitive(c, 8, col[k], nullptr, 0, G, 8, 0, order, nullptr, 0, G, 0, outs[k], nullptr, nullptr, nullptr)) != AH_OK) return rc;
+    if ((rc = ah_take_primitive(c, 8, col[k], nullptr, 0, GT, 8, 0, order, nullptr, 0, GT, 0, outs[k], nullptr, nullptr, nullptr)) != AH_OK) return rc;
   AH_HIP(c, hipStreamSynchronize(c->stream));
   return AH_OK;
 }

@@ -66,6 +66,7 @@ struct ah_ctx {
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   int capturing;           // between ah_graph_begin and ah_graph_end: the compute stream records instead of running
   ah_filter_cache fcache;  // ah_filter.hip
+  int opt_filter_cache;    // 1: ah_filter_count leaves its tile prefixes for the fill (default on a stream of the context's own), 0: the fill recounts (default on a shared stream)
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;
   int opt_arith_xcd_map;        // element-wise binary kernels: every XCD streams one contiguous eighth of the columns (1) or the blocks' natural interleave (0)

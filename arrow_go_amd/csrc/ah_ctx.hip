@@ -79,6 +79,10 @@ static int ctx_create(int device_id, void* stream, bool borrow, ah_ctx** out) {
   }
   int rc = ctx_init_common(c);
   if (rc != AH_OK) { fprintf(stderr, "arrowhip: ctx init failed: %s\n", c->err); free(c); return rc; }
+  // ah_filter_count leaves its tile prefixes for the fill that follows; only this context's own entry points drop them.  On a
+  // stream shared with another producer (torch, a second ah_ctx) a foreign kernel may rewrite the mask in between, so there the
+  // fill always recounts unless the caller vouches for the mask (ah_ctx_set_option "filter_cache" 1)
+  c->opt_filter_cache = c->owns_stream ? 1 : 0;
   *out = c;
   return AH_OK;
 }
@@ -138,6 +142,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "encode_part_min")) c->opt_encode_part_min = (int)value;
   else if (!strcmp(name, "encode_part_slots")) c->opt_encode_part_slots = (int)value;
   else if (!strcmp(name, "sort_msd")) c->opt_sort_msd = (int)value;
+  else if (!strcmp(name, "filter_cache")) { c->opt_filter_cache = value != 0; if (!value) c->fcache.valid = false; }
   else if (!strcmp(name, "scan_segment_log2")) c->opt_scan_segment_log2 = (int)value;
   else return ah_fail(c, AH_EINVALID, "set_option: unknown option '%s'", name);
   return AH_OK;
@@ -404,7 +409,8 @@ struct ah_graph {
 AH_EXPORT int ah_graph_begin(ah_ctx* c) {
   AH_ENTER(c);
   if (c->capturing) return ah_fail(c, AH_EINVALID, "graph_begin: already capturing");
-  AH_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  // relaxed: begin, the recorded calls and end may each run on another OS thread (a goroutine migrates); the context serialises them
+  AH_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
   c->capturing = 1;
   return AH_OK;
 }

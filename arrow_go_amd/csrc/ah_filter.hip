@@ -468,7 +468,7 @@ AH_EXPORT int ah_filter_count(ah_ctx* c, const uint8_t* fdata, const uint8_t* fv
   ah_filter_cache& fc = c->fcache;
   fc.fdata = fdata; fc.fvalid = fvalid; fc.foff = foff; fc.n = n; fc.null_sel = null_sel; fc.tile_rows = TileBytes<8>() / 8;
   fc.ntiles = ntiles; fc.super_off = super_off; fc.tile_local = tile_local; fc.total = total;
-  fc.valid = true;
+  fc.valid = c->opt_filter_cache != 0;   // never on a shared stream: a foreign kernel may rewrite the mask before the fill
   return AH_OK;
 }
 

@@ -802,6 +802,16 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
     // into millions of CAS / atomicMin on a few addresses (200 µs for 1024 keys).  A few thousand rows first,
     // then the rest mostly finds settled slots and issues no atomics at all.
     bool part_undecided = false;
+    // A partition-first attempt that voids itself (a partition's table overflowed: the head of the column misled the estimate)
+    // has already sent ids home — over the slot numbers this path keeps in out_ids for the rows it has inserted.  Put them
+    // back: every key of those rows sits in the table, so the second insert only probes (no claim, no counter moves).
+    auto restore_slot_numbers = [&](int64_t rows) -> int {
+      if (!out_ids || rows <= 0) return AH_OK;
+      insert_kernel<K><<<ah_stream_grid(c, ah_ceil_div(rows, (int64_t)kBlock * kInsertRows)), kBlock, 0, c->stream>>>(
+          keys, valid, off, 0, rows, encode_nulls, table, cap, (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
+      AH_LAUNCH_CHECK(c);
+      return AH_OK;
+    };
     {
       int64_t lo = 0;
       for (int64_t hi : {(int64_t)1 << 12, (int64_t)1 << 16, prefix}) {
@@ -840,6 +850,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
             bool done;
             int prc = try_partitioned(lp, &done, slots2);
             if (prc != AH_OK || done) return prc;
+            if ((prc = restore_slot_numbers(hi)) != AH_OK) return prc;
           }
         }
       }
@@ -856,6 +867,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
           bool done;
           int prc = try_partitioned(13, &done, est / 8192.0 > 2600.0 ? 8192 : 4096);
           if (prc != AH_OK || done) return prc;
+          if ((prc = restore_slot_numbers(prefix)) != AH_OK) return prc;
         }
       }
       if (ovf || d0 > cap / 4) {

@@ -213,12 +213,18 @@ class Comm:
         return s.value, n.value
 
     def merge_groups(self, is_f64: bool, keys, sums, counts, first_rows, ngroups_local: int, row_offset: int, capacity: int,
-                     out_keys, out_sums, out_counts, out_first_rows) -> int:
+                     out_keys, out_sums, out_counts, out_first_rows, null_group_local: int = -1, with_null_group: bool = False):
+        """→ the global group count; with_null_group: → (count, position of the merged null group or -1).  null_group_local is what
+        hash_sum reported for this rank's shard."""
         g = C.c_int64()
-        check(self.ctx.handle, lib.ah_comm_merge_groups(self.handle, int(is_f64), _ptr(keys), _ptr(sums), _ptr(counts), _ptr(first_rows),
-                                                        ngroups_local, row_offset, capacity, _ptr(out_keys), _ptr(out_sums), _ptr(out_counts),
-                                                        _ptr(out_first_rows), C.byref(g)))
-        return g.value
+        ng = C.c_int32(-1)
+        try:
+            check(self.ctx.handle, lib.ah_comm_merge_groups(self.handle, int(is_f64), _ptr(keys), _ptr(sums), _ptr(counts), _ptr(first_rows),
+                                                            ngroups_local, int(null_group_local), row_offset, capacity, _ptr(out_keys), _ptr(out_sums),
+                                                            _ptr(out_counts), _ptr(out_first_rows), C.byref(g), C.byref(ng)))
+        finally:
+            self.last_ngroups = g.value      # set even when the capacity was too small
+        return (g.value, ng.value) if with_null_group else g.value
 
     def allreduce_sum(self, type_id: int, send, recv, count: int) -> None:
         check(self.ctx.handle, lib.ah_comm_allreduce_sum(self.handle, type_id, _ptr(send), _ptr(recv), count))

@@ -112,7 +112,8 @@ class ShardedGpu:
         return self.comm.cmp_filter_sum_f64(cmpop, x, valid, off, n_local, float(thr))
 
     def merge_groups(self, is_f64: bool, keys, sums, counts, first_rows, ngroups_local: int, row_offset: int, capacity: int,
-                     out_keys, out_sums, out_counts, out_first_rows) -> int:
-        """device pointers in and out; returns the global group count"""
+                     out_keys, out_sums, out_counts, out_first_rows, null_group_local: int = -1, with_null_group: bool = False):
+        """device pointers in and out; returns the global group count (with_null_group: and the merged null group's position);
+        null_group_local = the null group hash_sum reported for this rank's shard, -1 for none"""
         return self.comm.merge_groups(is_f64, keys, sums, counts, first_rows, ngroups_local, row_offset, capacity,
-                                      out_keys, out_sums, out_counts, out_first_rows)
+                                      out_keys, out_sums, out_counts, out_first_rows, null_group_local, with_null_group)

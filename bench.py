@@ -77,6 +77,11 @@ def parse():
     p.add_argument("--secondary-timeout", type=float, default=150.0,
                    help="multi-GPU runs: seconds the sections after the headline (C4 / C5 lines) may take before rank 0 prints the headline "
                         "line without them and every rank exits — a rank stuck in a collective must not cost the run its number")
+    p.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
+                   help="multi-rank runs: 'rccl' (default) = one GPU per rank, ah_comm over RCCL / xGMI; 'gloo' = the host-transport communicator "
+                        "(ah_comm_init_transport) carried by a gloo group, every rank on device LOCAL_RANK mod the visible devices — lets the "
+                        "bench's own N > 1 code (communicator vote, watchdog, C4 / C5 with the owner merge) run on a 1-GPU box; not a measurement")
+    p.add_argument("--dump", default=None, help="rank 0 writes the last C4 result and the merged C5 groups to this .npz (tests compare them with the oracle)")
     p.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table")
     p.add_argument("--traffic", type=float, default=None, help="HBM bytes/launch of the Add kernel from a rocprofv3 --pmc pass")
     return p.parse_args()
@@ -490,13 +495,26 @@ def main():
         # torch FIRST: its bundled libamdhip64 must be the one HIP runtime in the process
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.transport == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())   # several ranks share a device
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    gloo = use_dist and args.transport == "gloo"
+    tdev = "cpu" if gloo else f"cuda:{local_rank}"   # where the launcher's own little tensors (votes, times) live
     import arrow_go_amd as ah
     N = ah._native
     comm = None
     comm_note = None
-    if use_dist:
+    if gloo:
+        from arrow_go_amd.distributed import GlooTransport
+        ctx = ah.Context(local_rank)
+        gloo_transport = GlooTransport(dist)
+        comm = ah.Comm.from_transport(ctx, rank, world, gloo_transport)
+        comm_note = "ah_comm over the host transport (gloo) — functional run of the multi-rank code, not a measurement"
+    elif use_dist:
         ctx = ah.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
         if args.collectives in ("ah", "auto"):
             # rank 0's RCCL unique id reaches the others over the launcher's process group; from here on the data-path
@@ -532,7 +550,7 @@ def main():
     ca = fill_random(ctx, a, rows, np.int64, 10 + rank)
     cb = fill_random(ctx, b, rows, np.int64, 20 + rank)
     cx = fill_random(ctx, x, rows, np.float64, 30 + rank)
-    if use_dist:
+    if use_dist and not gloo:
         part = torch.zeros(1, dtype=torch.float64, device=f"cuda:{local_rank}")
         part_ptr = part.data_ptr()
     else:
@@ -542,7 +560,8 @@ def main():
     def barrier():
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not gloo:
+                torch.cuda.synchronize()
         ctx.sync()
 
     def step(i, mark):
@@ -571,7 +590,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / max(args.steps, 1)
@@ -593,7 +612,7 @@ def main():
                                       if use_dist else ""),
                        "rows_per_gpu": rows, "bytes_per_row_per_step": 32,
                        "parallelism": f"record-batch shards, one per GPU (x{args.gpus}), no data-path collective",
-                       "collectives": ("ah_comm (RCCL through the C ABI)" if comm is not None else (comm_note or "torch.distributed")) if use_dist else "none (single process)"},
+                       "collectives": (comm_note if gloo else "ah_comm (RCCL through the C ABI)" if comm is not None else (comm_note or "torch.distributed")) if use_dist else "none (single process)"},
             "roofline": {"bound": "hbm", "kernel": "binary_kernel<uint64, ADD, array∘array> (Int64 Add)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -630,16 +649,18 @@ def main():
     # Same protocol as above — barrier, K steps, barrier, MAX over ranks — reported next to the headline, never as `value`.
     c4 = None
     try:
-        if use_dist:
+        if use_dist and not gloo:
             pair = torch.zeros(2, dtype=torch.int64, device=f"cuda:{local_rank}")
             pair_ptr = pair.data_ptr()
         else:
             pair_buf = ctx.alloc(64)
             pair_ptr = pair_buf.ptr
 
+        c4_last = [None]
+
         def c4_step():
             if comm is not None:
-                comm.cmp_filter_sum_i64(N.CMP_GT, a, None, 0, rows, 0)   # ONE C-ABI call: fused kernel + 16-byte all-reduce + the result on the host
+                c4_last[0] = comm.cmp_filter_sum_i64(N.CMP_GT, a, None, 0, rows, 0)   # ONE C-ABI call: fused kernel + 16-byte all-reduce + the result on the host
                 return
             ctx.cmp_filter_sum_i64_dev(N.CMP_GT, a, None, 0, rows, 0, pair_ptr)
             if use_dist:
@@ -654,7 +675,7 @@ def main():
         barrier()
         c4_dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([c4_dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([c4_dt], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c4_dt = float(t.item())
         c4_ms = c4_dt * 1e3 / max(args.steps, 1)
@@ -695,10 +716,16 @@ def main():
         barrier()
         c5_dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([c5_dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([c5_dt], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             c5_dt = float(t.item())
         c5_ms = c5_dt * 1e3 / c5_steps
+        if args.dump and rank == 0:
+            gcount = ngroups[0]
+            src = mbufs if merge else obufs
+            np.savez(args.dump, c4=np.array(c4_last[0] if c4_last[0] is not None else (0, 0), np.int64), merged=np.array([1 if merge else 0]),
+                     keys=src[0].download(np.uint64, gcount), sums=src[1].download(np.float64, gcount), counts=src[2].download(np.int64, gcount),
+                     first_rows=src[3].download(np.int64, gcount))
         c5 = {"workload": "C5: hash + sum group-by over Int64 keys / Float64 values per GPU" + (", merged by key-hash owner (ah_comm_merge_groups: all-to-all of group tuples)" if merge else
                                                                                                         " (local aggregate; the owner merge over RCCL runs when world > 1 with --collectives ah)"),
               "ms_per_step": round(c5_ms, 4), "Grows/s": round(hrows * args.gpus / (c5_ms * 1e-3) / 1e9, 2), "rows_per_gpu": hrows,

@@ -91,12 +91,14 @@ func (c *Comm) CmpFilterSumFloat64(cmpop int, x, valid unsafe.Pointer, off, nLoc
 	return float64(s), int64(n), err
 }
 
-// MergeGroups: config C5 — this rank's local aggregate (outputs of HashSumFloat64 / HashSumInt64) → all groups in global
-// first-seen order on every rank.
-func (c *Comm) MergeGroups(isF64 bool, keys, sums, counts, firstRows unsafe.Pointer, nLocal, rowOffset, capacity int64,
-	outKeys, outSums, outCounts, outFirstRows unsafe.Pointer) (int64, error) {
+// MergeGroups: config C5 — this rank's local aggregate (outputs of HashSumFloat64 / HashSumInt64, nullGroupLocal = the null group
+// they reported, -1 for none) → all groups in global first-seen order on every rank; nullGroup = the merged null group's position
+// (-1: no rank had one).
+func (c *Comm) MergeGroups(isF64 bool, keys, sums, counts, firstRows unsafe.Pointer, nLocal int64, nullGroupLocal int32, rowOffset, capacity int64,
+	outKeys, outSums, outCounts, outFirstRows unsafe.Pointer) (ngroups int64, nullGroup int32, err error) {
 	var g C.int64_t
-	err := c.ctx.err(C.ah_comm_merge_groups(c.m, boolInt(isF64), (*C.uint64_t)(keys), sums, (*C.int64_t)(counts), (*C.int64_t)(firstRows), C.int64_t(nLocal), C.int64_t(rowOffset),
-		C.int64_t(capacity), (*C.uint64_t)(outKeys), outSums, (*C.int64_t)(outCounts), (*C.int64_t)(outFirstRows), &g))
-	return int64(g), err
+	var ng C.int32_t
+	err = c.ctx.err(C.ah_comm_merge_groups(c.m, boolInt(isF64), (*C.uint64_t)(keys), sums, (*C.int64_t)(counts), (*C.int64_t)(firstRows), C.int64_t(nLocal), C.int32_t(nullGroupLocal),
+		C.int64_t(rowOffset), C.int64_t(capacity), (*C.uint64_t)(outKeys), outSums, (*C.int64_t)(outCounts), (*C.int64_t)(outFirstRows), &g, &ng))
+	return int64(g), int32(ng), err
 }

@@ -127,8 +127,11 @@ const char* ah_last_error(ah_ctx* ctx); /* never NULL; owned by ctx */
  * "hash_direct" (unique / dictionary_encode: 0 ids in a separate pass … 2 default, 3 without the re-packed table),
  * "groupby_partition" (hash + sum: 0 id-based path only, 1 auto, k >= 5 always 2^(k-2) partitions, 2 sort-based, 3 / 4 two levels,
  * -2 no cut), "groupby_keys" (expected keys per partition the auto choice aims at, default 1280), "sort_msd" (sort_indices:
- * 0 LSD passes only, 1 auto).  Defaults come from the ARROWHIP_* environment variables of the same names at context
- * creation. */
+ * 0 LSD passes only, 1 auto), "filter_cache" (1: ah_filter_count leaves its tile prefixes for the ah_filter_primitive that
+ * follows, dropped by every entry point of THIS context that may write device memory — the default of ah_ctx_create; 0: the fill
+ * always recounts — the default of ah_ctx_create_on_stream, where another producer on the shared stream may rewrite the mask
+ * between the two calls; set it to 1 there only if nothing else writes the mask in between).  Defaults come from the ARROWHIP_*
+ * environment variables of the same names at context creation. */
 int ah_ctx_set_option(ah_ctx* ctx, const char* name, int64_t value);
 const char* ah_version(void);
 int ah_device_count(int* n_host);
@@ -520,10 +523,15 @@ int ah_comm_cmp_filter_sum_f64(ah_comm* comm, int cmpop, const double* x, const 
  * the reproducible sums of ah_hash_sum_f64) -> ragged all-gather -> ordered by global first row: the groups, in the order, that
  * unique / dictionary_encode over the undivided column gives (kernels/vector_hash.go:359-385, 721-741).  Every rank receives all
  * groups.  Device buffers; out_* hold `capacity` groups; *out_ngroups_host = the global group count — AH_EINVALID with that
- * count set (and nothing written) when capacity is too small.  Synchronises. */
+ * count set (and nothing written) when capacity is too small.  Synchronises.
+ * The NULL group: null_group_local = what ah_hash_sum_* reported in *out_null_group_host for this rank's shard (−1: none).  A null
+ * key has no hash owner — its group (key slot 0, like the local aggregate's) is merged on every rank from the ranks' null tuples
+ * in rank order, takes its place in the first-seen order, and *out_null_group_host (nullable) = its position, −1 if no rank had
+ * one.  A column holding both null keys and the key 0 therefore yields two groups, as over the undivided column. */
 int ah_comm_merge_groups(ah_comm* comm, int is_f64, const uint64_t* keys, const void* sums, const int64_t* counts, const int64_t* first_rows,
-                         int64_t ngroups_local, int64_t row_offset, int64_t capacity, uint64_t* out_keys, void* out_sums,
-                         int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups_host);
+                         int64_t ngroups_local, int32_t null_group_local, int64_t row_offset, int64_t capacity, uint64_t* out_keys,
+                         void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups_host,
+                         int32_t* out_null_group_host);
 
 /* ---- numeric cast (row §8(f)-2) ----------------------------------------------------------------
  * replaces castNumberToNumberUnsafe → castNumericUnsafe (kernels/cast_numeric.go:28-131; AVX2 leaf

@@ -105,6 +105,46 @@ assert np.all(np.abs(ms - es) <= 1e-9 * np.maximum(1.0, np.abs(es)))
 digests = [None] * world
 dist.all_gather_object(digests, ms.tobytes().hex()[:64] + str(hash(ms.tobytes())))
 assert len({d[:64] for d in digests}) == 1
+# null keys AND the key 0 in one column (the local aggregates hold the null group with key slot 0): two groups, as over the undivided
+# column; the null group on every rank, on one rank only, first seen before / after the key 0, values Int64 and general Float64
+def merged_with_nulls(kind, keys, kvalid_bits, vals, lo_, hi_, capacity):
+    m = hi_ - lo_
+    dk = ctx.to_device(keys[lo_:hi_]); dvv = ctx.to_device(vals[lo_:hi_])
+    dkv = ctx.to_device(np.packbits(kvalid_bits[lo_:hi_], bitorder="little"), pad=64)
+    outs = [ctx.alloc((m + 1) * 8 + 64) for _ in range(4)]
+    ng, nid = ctx.hash_sum(kind, dk, dkv, 0, dvv, None, 0, m, outs[0], outs[1], outs[2], outs[3])
+    res = [ctx.alloc(capacity * 8 + 64) for _ in range(4)]
+    G, gnull = sg.merge_groups(kind == "f64", outs[0], outs[1], outs[2], outs[3], ng, lo_, capacity, *res, null_group_local=nid, with_null_group=True)
+    sdt = np.float64 if kind == "f64" else np.int64
+    return G, gnull, res[0].download(np.uint64, G), res[1].download(sdt, G), res[2].download(np.int64, G), res[3].download(np.int64, G)
+
+
+for variant in ("nulls everywhere", "nulls on the last rank only", "null first, key 0 later", "only nulls"):
+    kz = rng.integers(0, 50, n).astype(np.int64)             # 0 is one of the keys
+    kvb = np.ones(n, bool)
+    if variant == "nulls everywhere":
+        kvb = rng.random(n) < 0.8
+    elif variant == "nulls on the last rank only":
+        kvb[n - 100:] = rng.random(100) < 0.5
+    elif variant == "null first, key 0 later":
+        kvb[0] = False; kz[:1000] = 7; kz[5000] = 0
+    else:
+        kvb[:] = False
+    kpack = np.packbits(kvb, bitorder="little")
+    for kind, vals in (("i64", rng.integers(-2**40, 2**40, n, dtype=np.int64)), ("f64", rng.integers(-1000, 1000, n).astype(np.float64))):
+        G, gnull, mk, ms, mc, mf = merged_with_nulls(kind, kz, kvb, vals, lo, hi, n + 1)
+        ek, es, ec, enull, ef = o.hash_sum(kind, kz, kpack, 0, vals, None, 0)
+        assert G == ek.size and gnull == enull, (variant, kind, G, ek.size, gnull, enull)
+        assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes(), (variant, kind)
+    # general doubles: the null group's sum must be the same bytes on every rank and within the group-by tolerance of the oracle's
+    gvals = rng.standard_normal(n)
+    G, gnull, mk, ms, mc, mf = merged_with_nulls("f64", kz, kvb, gvals, lo, hi, n + 1)
+    ek, es, ec, enull, ef = o.hash_sum("f64", kz, kpack, 0, gvals, None, 0)
+    assert gnull == enull and mk.tobytes() == ek.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes(), variant
+    assert np.all(np.abs(ms - es) <= 1e-9 * np.maximum(1.0, np.abs(es))), variant
+    digs = [None] * world
+    dist.all_gather_object(digs, ms.tobytes().hex())
+    assert len(set(digs)) == 1, variant
 # ragged: rank 0 contributes no group at all; too small a capacity is an error that names the count
 l0, h0 = shard_bounds(n, 0, world)
 k2, v2 = keys[h0:], rng.integers(-2**40, 2**40, n, dtype=np.int64)[h0:]

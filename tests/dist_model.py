@@ -139,30 +139,54 @@ class ShardedCompute:
                                               part.data_ptr(), part.data_ptr() + 8)
             self.coll.all_reduce_sum(torch, part)  # wrapping int64 sum: exact in any order — 16 bytes on the wire
             return int(part[0].item()), int(part[1].item())
-        s = torch.zeros(1, dtype=torch.float64, device=self.device)
+        from tests import ddx_model as DD
+        s = torch.zeros(4, dtype=torch.float64, device=self.device)       # {s, e, bs, be}: csrc/ah_ddsum.h, un-rounded
         c = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.local.cmp_filter_sum_partial(cmpop, x_ptr, valid_ptr, off, n_local, thr, dtype, s.data_ptr(), c.data_ptr())
-        # float64: all-gather the partials and add them in RANK order on every rank, so the
-        # result is bit-identical across ranks and runs (an all-reduce's order is not)
+        # float64: all-gather the un-rounded accumulators and merge them in RANK order on every rank, round once: bit-identical across
+        # ranks and runs (an all-reduce's order is not) and within 1 ULP of the exact sum over the undivided column for any world size
         parts = self.coll.all_gather_rows(torch, s)
         self.coll.all_reduce_sum(torch, c)
-        total = 0.0
-        for p in parts[:, 0].tolist():
-            total += float(p)
-        return total, int(c.item())
+        acc = DD.zero()
+        for p in parts.tolist():
+            DD.merge(acc, p)
+        return DD.result(acc), int(c.item())
 
     # ---- C5: hash group-by sum ----------------------------------------------------------------
     def merge_groups(self, torch, keys: np.ndarray, sums: np.ndarray, counts: np.ndarray, first_rows: np.ndarray,
-                     row_offset: int):
+                     row_offset: int, null_group_local: int = -1, with_null_group: bool = False):
         """Plan A merge, host-array convenience form: this rank's LOCAL aggregate (group key bit
         patterns (uint64), partial sum, valid-value count, first local row) → the global groups in
-        order of global first occurrence, on every rank.  The work happens in merge_groups_t."""
+        order of global first occurrence, on every rank.  The work happens in merge_groups_t.
+        null_group_local: index of the null-key group in the local aggregate (-1: none).  It has no key to be owned by: it leaves the
+        local columns, every rank's null tuple travels in one small all-gather, is merged in rank order on every rank and joins the
+        others before the ordering by first row (ah_comm_merge_groups, csrc/ah_comm.hip)."""
         is_float = sums.dtype == np.float64
         cols = np.stack([keys.view(np.int64), sums.view(np.int64), counts.astype(np.int64),
                          first_rows.astype(np.int64) + np.int64(row_offset)])
+        mine = np.zeros(4, np.int64)
+        if null_group_local >= 0:
+            mine[0], mine[1:] = 1, cols[1:, null_group_local]
+            cols = np.delete(cols, null_group_local, axis=1)
+        nulls = self.coll.all_gather_rows(torch, torch.from_numpy(mine).to(self.device)).cpu().numpy()      # [world, 4]
         rows = self.merge_groups_t(torch, torch.from_numpy(np.ascontiguousarray(cols)).to(self.device), is_float).cpu().numpy()
+        null_pos = -1
+        have = nulls[nulls[:, 0] != 0]
+        if have.shape[0]:
+            if is_float:
+                tot = np.float64(0.0)
+                for v in have[:, 1].view(np.float64):          # rank order
+                    tot = tot + v
+                sbits = np.array([tot]).view(np.int64)[0]
+            else:
+                with np.errstate(over="ignore"):
+                    sbits = have[:, 1].view(np.uint64).sum(dtype=np.uint64).view(np.int64) if have.shape[0] > 1 else have[0, 1]
+            tup = np.array([0, sbits, have[:, 2].sum(), have[:, 3].min()], np.int64)
+            null_pos = int((rows[3] < tup[3]).sum())
+            rows = np.concatenate([rows[:, :null_pos], tup[:, None], rows[:, null_pos:]], axis=1)
         out_sums = rows[1].view(np.float64) if is_float else rows[1]
-        return rows[0].view(np.uint64), out_sums, rows[2], rows[3]
+        res = (rows[0].view(np.uint64), out_sums, rows[2], rows[3])
+        return res + (null_pos,) if with_null_group else res
 
     def merge_groups_t(self, torch, cols, is_float: bool):
         """cols: [4, g] int64 tensor on this rank's device — rows = key bits, sum bits, count,

@@ -52,9 +52,15 @@ class OracleLocal:
             buf = np.array([s, c], np.int64)
             ctypes.memmove(out_sum_ptr, buf.ctypes.data, 16)
         else:
-            _, s, c = self.o.cmp_filter_sum_f64(cmpop, x[:n], valid, off, thr)
-            ctypes.memmove(out_sum_ptr, np.array([s], np.float64).ctypes.data, 8)
-            ctypes.memmove(out_count_ptr, np.array([c], np.int64).ctypes.data, 8)
+            # the shard's un-rounded accumulator {s, e, bs, be}: the Python restatement of csrc/ah_ddsum.h over the kept rows
+            from tests import ddx_model as DD
+            from tests.oracle_lib import unpack_bits
+            xs = np.asarray(x[:n], np.float64)
+            ok = unpack_bits(valid, off, n).astype(bool) if valid is not None else np.ones(n, bool)
+            keep = xs[ok & {0: xs == thr, 1: xs != thr, 2: xs > thr, 3: xs >= thr}[cmpop]]
+            acc = DD.accumulate(keep.tolist(), lanes=64)
+            ctypes.memmove(out_sum_ptr, np.array(acc, np.float64).ctypes.data, 32)
+            ctypes.memmove(out_count_ptr, np.array([keep.size], np.int64).ctypes.data, 8)
 
 
     # ---- the three merge steps, numpy on CPU tensors (HipLocal runs them on the GPU) ----
@@ -169,10 +175,23 @@ def _worker(rank, world, port, q):
             l2, h2 = shard_bounds(n, r, world)
             _, s_exact, _c = o.cmp_filter_sum_f64(GT, xf[l2:h2], np.packbits(valid_bits[l2:h2], bitorder="little"), 0, 0.25)
             parts.append(s_exact)
-        tot = 0.0
-        for p in parts:
-            tot += p
-        assert gotf[0] == tot and gotf[1] == int(((xf > 0.25) & valid_bits).sum())
+        # one rounding for the whole column whatever the world size: within 1 ULP of the exact sum (the superaccumulator), and — the
+        # protocol's point — NOT the rank-ordered sum of rounded partials when those differ
+        kept = xf[(xf > 0.25) & valid_bits]
+        exact = float(o.sum_float64_xreal(kept))
+        assert abs(gotf[0] - exact) <= np.spacing(abs(exact)) and gotf[1] == kept.size, (gotf, exact, parts)
+        # ±inf / overflow across ranks follow the extended reals (tests/test_ddsum_host.py has the single-process cases)
+        for edits, want in (({3: np.inf}, np.inf), ({3: np.inf, n - 2: -np.inf}, np.nan), ({1: 1e308, n // 2 + 1: 1e308, n - 3: 1e308}, np.inf),
+                            ({1: 1e308, 2: 1e308, n - 3: -1e308, n - 4: -1e308}, None)):
+            y = xf.copy()
+            for i, v in edits.items():
+                y[i] = v
+            ones = np.full((n + 7) // 8, 0xFF, np.uint8)
+            l2, h2 = shard_bounds(n, rank, world)
+            gy = sc.cmp_filter_sum(torch, 3, y[l2:h2], None, 0, h2 - l2, -np.inf, np.float64)      # x >= -inf
+            w = float(o.sum_float64_xreal(y)) if want is None else want
+            assert (np.isnan(w) and np.isnan(gy[0])) or gy[0] == w or (np.isfinite(w) and abs(gy[0] - w) <= np.spacing(abs(w))), (edits, gy, w)
+            del ones
         # C5: local aggregate per shard → owner all-to-all → merge → global first-seen order
         keys = rng.integers(0, 777, n).astype(np.int64) * 1000003
         vals = rng.integers(-2**40, 2**40, n, dtype=np.int64)
@@ -187,6 +206,19 @@ def _worker(rank, world, port, q):
         mk, ms, mc, mf = sc.merge_groups(torch, lk, ls, lc, lf, lo)
         ek, es, ec, _nid, ef = o.hash_sum("f64", keys, None, 0, fv, None, 0)
         assert mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes()
+        # null keys next to the key 0: the null group is merged outside the owner exchange and lands at its first-seen position
+        kz = rng.integers(0, 40, n).astype(np.int64)
+        for variant in range(3):
+            kvb = rng.random(n) < 0.8 if variant == 0 else np.ones(n, bool)
+            if variant == 1:
+                kvb[n - 50:] = False                           # nulls on the last rank only
+            if variant == 2:
+                kvb[0] = False; kz[:500] = 7; kz[900] = 0       # null first, key 0 later
+            kpack_all = np.packbits(kvb, bitorder="little")
+            lk, ls, lc, lnull, lf = o.hash_sum("i64", kz[lo:hi], np.packbits(kvb[lo:hi], bitorder="little"), 0, vals[lo:hi], None, 0)
+            mk, ms, mc, mf, mnull = sc.merge_groups(torch, lk, ls, lc, lf, lo, null_group_local=lnull, with_null_group=True)
+            ek, es, ec, enull, ef = o.hash_sum("i64", kz, kpack_all, 0, vals, None, 0)
+            assert mnull == enull and mk.tobytes() == ek.tobytes() and ms.tobytes() == es.tobytes() and mc.tobytes() == ec.tobytes() and mf.tobytes() == ef.tobytes(), variant
         # the same steps through the C-ABI-shaped provider (AhCommCollectives over a byte-level comm): block packing and
         # offsets for world > 1; ragged on purpose (rank 0 contributes no groups at all in the second round)
         from tests.dist_model import AhCommCollectives

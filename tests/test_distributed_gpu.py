@@ -31,3 +31,48 @@ def test_comm_entries_several_ranks_on_one_gpu(world):
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     assert "dist_gpu_ranks ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_filter_count_cache_is_off_on_a_shared_stream():
+    """ah_ctx_create_on_stream: a foreign kernel (torch, on the shared stream) rewrites the mask between ah_filter_count and
+    ah_filter_primitive; the fill must follow the new mask, never the count's stale tile prefixes (scripts/shared_stream_filter_check.py)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "shared_stream_filter_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "shared_stream_filter_check ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_world2_one_gpu(tmp_path):
+    """bench.py's OWN multi-rank code (communicator set-up, max-over-ranks timing, the watchdog thread, the C4 / C5 secondary sections with
+    the owner merge) with two ranks on one GPU over the host-transport communicator (--transport gloo): exactly ONE JSON line, C4 and C5
+    present, and their values == the oracle over the UNDIVIDED data (the concatenation of the ranks' seeded shards)."""
+    import json
+    import numpy as np
+    from tests import oracle_lib as OL
+    rows, world = 1 << 22, 2
+    dump = str(tmp_path / "bench_world2.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", "29671",
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rows", str(rows), "--steps", "3", "--warmup", "1", "--transport", "gloo", "--dump", dump],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == world and res["steps"] == 3 and res["value"] > 0
+    c4, c5 = res["c4_filter_aggregate"], res["c5_group_by"]
+    assert "error" not in c4 and "error" not in c5, (c4, c5)
+    assert "merged by key-hash owner" in c5["workload"] and c5["n_gpus"] == world
+    # the same seeded columns bench.py builds (fill_random: one chunk of min(rows, 2^22) rows per column, seeds 10 / 30 / 77 + rank)
+    o = OL.load_oracle()
+    a = np.concatenate([np.random.default_rng(10 + k).integers(-2**62, 2**62, rows, dtype=np.int64) for k in range(world)])
+    x = np.concatenate([np.random.default_rng(30 + k).uniform(-1e6, 1e6, rows) for k in range(world)])
+    keys = np.concatenate([(np.random.default_rng(77 + k).integers(0, 1 << 16, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)[:rows] for k in range(world)])
+    d = np.load(dump)
+    assert d["merged"][0] == 1
+    assert tuple(d["c4"].tolist()) == o.cmp_filter_sum_i64(2, a, None, 0, 0)                    # C4: Σ and count of a > 0 over both shards
+    ek, es, ec, _nid, ef = o.hash_sum("f64", keys, None, 0, x, None, 0)                          # C5 over the undivided columns
+    assert c5["groups"] == ek.size
+    assert d["keys"].tobytes() == ek.tobytes() and d["counts"].tobytes() == ec.tobytes() and d["first_rows"].tobytes() == ef.tobytes()
+    assert np.all(np.abs(d["sums"] - es) <= 1e-9 * np.maximum(1.0, np.abs(es)))                 # (the oracle adds in row order; the device sum is the correctly rounded one)

@@ -526,6 +526,25 @@ def test_hash_encode_capacity_estimates(hip, orc_be):
         assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3], name
 
 
+def test_hash_encode_voided_partition_attempt_keeps_prefix_ids(hip, orc_be):
+    """automatic mode, a head that misleads WITHOUT a capacity restart afterwards: the first 2^21 rows draw from 4·10^5 keys (the look
+    after 2^16 rows estimates ≈ 4·10^5 → one cut into 256 partitions), the rest bring the total to 1.8·10^6 (≈ 7000 keys per partition:
+    the LDS tables overflow, the attempt voids itself AFTER its ids went home).  The global-table path carries on from row 2^16 with
+    d0 ≈ 4·10^5 ≤ cap / 4 — no restart — so the slot numbers of rows [0, 2^16) must have been put back (they held the voided
+    attempt's ids: wrong ids, and indices beyond the table)"""
+    rng = np.random.default_rng(6701)
+    n = (1 << 22) + 4321
+    head = 1 << 21
+    for total_keys in (1_800_000, 1_200_000):
+        k = np.concatenate([rng.integers(0, 400_000, head), rng.integers(0, total_keys, n - head)])
+        keys = (k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+        valid = rand_bits(rng, n + 16, 0.95)
+        for v, off, enc in ((None, 0, False), (valid, 3, True), (valid, 3, False)):
+            g, e = hip.hash_encode(keys, v, off, enc), orc_be.hash_encode(keys, v, off, enc)
+            assert g[0].tobytes() == e[0].tobytes(), (total_keys, off, enc)
+            assert g[1].tobytes() == e[1].tobytes() and g[2].tobytes() == e[2].tobytes() and g[3] == e[3], (total_keys, off, enc)
+
+
 def test_hash_encode_low_cardinality_lds_path(hip, orc_be):
     # more rows than the 2^21-row prefix and ≤ 4096 keys in it: the main pass looks keys up in LDS
     rng = np.random.default_rng(68)
