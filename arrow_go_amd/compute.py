@@ -67,6 +67,15 @@ lib.ahc_ipc_inspect.argtypes = [_vp, C.c_int64, C.c_char_p, C.c_int64]
 lib.ahc_expr_eval.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]
 
 
+class _ExprNode(C.Structure):   # ahc_expr_node of include/arrowhip_compute.h
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32), ("name", C.c_char_p), ("options", C.c_char_p), ("nargs", C.c_int32), ("args", C.POINTER(C.c_int32))]
+
+
+lib.ahc_expr_eval_tree.argtypes = [_vp, C.POINTER(_ExprNode), C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(C.c_char_p), C.c_int, C.POINTER(_vp), C.c_int,
+                                   C.POINTER(_vp), C.POINTER(C.c_int)]
+lib.ahc_expr_eval_substrait.argtypes = [_vp, C.c_void_p, C.c_int64, C.c_int, C.POINTER(_vp), C.POINTER(C.c_char_p), C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]
+
+
 # ---- Arrow C (Device) Data Interface structs (arrow/cdata/abi.h) ------------------------------------
 class CArrowSchema(C.Structure):
     pass
@@ -495,6 +504,67 @@ class Session:
                 lib.ahc_datum_release(out)
         finally:
             for d in cols + lits:
+                lib.ahc_datum_release(d)
+
+    def eval_expression_tree(self, tree, columns, names=None, fuse: bool = True):
+        """The reference's own tree shape (compute.Expression: Literal | field reference | Call{name, args, options},
+        arrow/compute/expression.go:52-78, 278-290) through ahc_expr_eval_tree.  tree: ("call", name, [subtrees], options text or None) |
+        ("field", position or name) | ("lit", pyarrow scalar).  Returns (result, fused)."""
+        nodes, lits, keep = [], [], []
+
+        def walk(t):
+            if t[0] == "lit":
+                lits.append(t[1])
+                nodes.append(_ExprNode(0, len(lits) - 1, None, None, 0, None))
+            elif t[0] == "field":
+                by_name = isinstance(t[1], str)
+                nodes.append(_ExprNode(1, -1 if by_name else int(t[1]), t[1].encode() if by_name else None, None, 0, None))
+            elif t[0] == "call":
+                pos = [walk(a) for a in t[2]]
+                arr = (C.c_int32 * max(len(pos), 1))(*pos)
+                keep.append(arr)
+                opts = t[3].encode() if len(t) > 3 and t[3] else None
+                nodes.append(_ExprNode(2, 0, t[1].encode(), opts, len(pos), C.cast(arr, C.POINTER(C.c_int32))))
+            else:
+                raise ValueError(f"expression node kind {t[0]!r}")
+            return len(nodes) - 1
+
+        walk(tree)
+        cols = [self._to_datum(c) for c in columns]
+        ld = [self._to_datum(l) for l in lits]
+        try:
+            na = (_ExprNode * len(nodes))(*nodes)
+            ca = (_vp * max(len(cols), 1))(*cols)
+            la = (_vp * max(len(ld), 1))(*ld)
+            nm = (C.c_char_p * max(len(cols), 1))(*[n.encode() for n in names]) if names is not None else None
+            out, fused = _vp(), C.c_int()
+            self._check(lib.ahc_expr_eval_tree(self.h, na, len(nodes), len(cols), ca, nm, len(ld), la, int(fuse), C.byref(out), C.byref(fused)))
+            try:
+                return self._export(out), bool(fused.value)
+            finally:
+                lib.ahc_datum_release(out)
+        finally:
+            for d in cols + ld:
+                lib.ahc_datum_release(d)
+
+    def eval_substrait(self, message: bytes, columns, names=None, fuse: bool = True):
+        """exprs.ExecuteScalarSubstrait (arrow/compute/exprs/exec.go:465-488): `message` is a serialized substrait.ExtendedExpression
+        with one referred expression; columns (pyarrow arrays / scalars / DeviceArrays) in base-schema order, or matched by `names`.
+        Returns (result, fused)."""
+        message = bytes(message)
+        cols = [self._to_datum(c) for c in columns]
+        try:
+            ca = (_vp * max(len(cols), 1))(*cols)
+            nm = (C.c_char_p * max(len(cols), 1))(*[n.encode() for n in names]) if names is not None else None
+            buf = C.create_string_buffer(message, len(message))
+            out, fused = _vp(), C.c_int()
+            self._check(lib.ahc_expr_eval_substrait(self.h, C.cast(buf, C.c_void_p), len(message), len(cols), ca, nm, int(fuse), C.byref(out), C.byref(fused)))
+            try:
+                return self._export(out), bool(fused.value)
+            finally:
+                lib.ahc_datum_release(out)
+        finally:
+            for d in cols:
                 lib.ahc_datum_release(d)
 
     # -- arrow/math

@@ -460,6 +460,23 @@ struct ExecBatch {
 Status ExecuteScalarExpression(ExecCtx* ctx, const ExprPtr& expr, const ExecBatch& batch, Datum* out, bool fuse = true,
                                bool* fused_out = nullptr);
 
+// ---- the Substrait front end (substrait.cc): exprs.ExecuteScalarSubstrait (arrow/compute/exprs/exec.go:465-488) -----------------
+// a parsed substrait.ExtendedExpression: the base schema (types this layer does not carry are nullptr + their Substrait name) and
+// one Expression per referred expression (or the status that says why it could not be built)
+struct SubstraitExtended {
+  std::vector<std::string> names;
+  std::vector<const DataType*> types;
+  std::vector<std::string> type_names;
+  std::vector<ExprPtr> exprs;
+  std::vector<Status> expr_status;
+  std::vector<std::string> out_names;
+};
+Status ParseSubstraitExtended(const uint8_t* bytes, int64_t len, SubstraitExtended* out);
+// cols: the input's columns (arrays or scalars) — by position in the base schema when col_names is empty, else matched by name
+// (missing fields become null scalars, makeExecBatch exec.go:384-438)
+Status ExecuteScalarSubstrait(ExecCtx* ctx, const uint8_t* bytes, int64_t len, const std::vector<Datum>& cols, const std::vector<std::string>& col_names,
+                              Datum* out, bool fuse = true, bool* fused_out = nullptr);
+
 }  // namespace compute
 
 // ---- arrow/math (float64.go:25-39, int64.go, uint64.go) ---------------------------------

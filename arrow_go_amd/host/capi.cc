@@ -671,6 +671,83 @@ AHC_EXPORT int ahc_expr_eval(ahc_session* s, const char* text, int ncols, ahc_da
   return 0;
 }
 
+// compute.Expression as the reference shapes it (Literal | Parameter | Call, arrow/compute/expression.go:52-78, 278-290), post-order
+AHC_EXPORT int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, int n_nodes, int ncols, ahc_datum** cols, const char* const* col_names,
+                                  int nlits, ahc_datum** lits, int fuse, ahc_datum** out, int* fused_out) {
+  *out = nullptr;
+  if (!nodes || n_nodes <= 0) return Fail(s, Status::Make(StatusCode::Invalid, "nil expression"));   // exprs/exec.go:441-443
+  std::vector<compute::ExprPtr> built((size_t)n_nodes);
+  for (int i = 0; i < n_nodes; i++) {
+    const ahc_expr_node& nd = nodes[i];
+    switch (nd.kind) {
+      case AHC_EXPR_LITERAL:
+        if (nd.index < 0 || nd.index >= nlits || lits[nd.index]->d.kind != DatumKind::Scalar)
+          return Fail(s, Status::Make(StatusCode::Invalid, "expression node " + std::to_string(i) + ": literal " + std::to_string(nd.index) + " is not a scalar datum of the call"));
+        built[(size_t)i] = compute::NewLiteral(lits[nd.index]->d.scalar);
+        break;
+      case AHC_EXPR_FIELD_REF:
+        if (nd.index >= 0) built[(size_t)i] = compute::NewRef(nd.index);
+        else if (nd.name && *nd.name) built[(size_t)i] = compute::NewFieldRef(nd.name);
+        else return Fail(s, Status::Make(StatusCode::Invalid, "expression node " + std::to_string(i) + ": field reference without index or name"));
+        break;
+      case AHC_EXPR_CALL: {
+        if (!nd.name || !*nd.name) return Fail(s, Status::Make(StatusCode::Invalid, "expression node " + std::to_string(i) + ": call without a function name"));
+        if (nd.nargs < 0 || (nd.nargs > 0 && !nd.args)) return Fail(s, Status::Make(StatusCode::Invalid, "expression node " + std::to_string(i) + ": bad argument list"));
+        std::vector<compute::ExprPtr> args;
+        for (int k = 0; k < nd.nargs; k++) {
+          if (nd.args[k] < 0 || nd.args[k] >= i)
+            return Fail(s, Status::Make(StatusCode::Invalid, "expression node " + std::to_string(i) + ": argument " + std::to_string(nd.args[k]) + " does not come before its call"));
+          args.push_back(built[(size_t)nd.args[k]]);
+        }
+        std::shared_ptr<compute::FunctionOptions> opts;
+        if (nd.options && *nd.options) {
+          auto po = std::make_shared<ParsedOptions>();
+          ParseOptions(nd.options, po.get());
+          if (po->pick) opts = std::shared_ptr<compute::FunctionOptions>(po, const_cast<compute::FunctionOptions*>(po->pick));
+        }
+        built[(size_t)i] = compute::NewCall(nd.name, args, opts);
+        break;
+      }
+      default:
+        return Fail(s, Status::Make(StatusCode::Invalid, "expression node " + std::to_string(i) + ": unknown kind " + std::to_string(nd.kind)));
+    }
+  }
+  compute::ExecBatch batch;
+  bool have_len = false;
+  for (int i = 0; i < ncols; i++) {
+    batch.names.push_back(col_names && col_names[i] ? col_names[i] : "c" + std::to_string(i));
+    batch.values.push_back(cols[i]->d);
+    if (cols[i]->d.kind == DatumKind::Array) { batch.len = cols[i]->d.array->length; have_len = true; }
+  }
+  if (!have_len) batch.len = 1;
+  Datum res;
+  bool fused = false;
+  Status st = compute::ExecuteScalarExpression(&s->ectx, built.back(), batch, &res, fuse != 0, &fused);
+  if (!st.ok()) return Fail(s, st);
+  if (fused_out) *fused_out = fused;
+  *out = new ahc_datum{res};
+  return 0;
+}
+
+// exprs.ExecuteScalarSubstrait (arrow/compute/exprs/exec.go:465-488) over a serialized ExtendedExpression: substrait.cc
+AHC_EXPORT int ahc_expr_eval_substrait(ahc_session* s, const uint8_t* bytes, int64_t len, int ncols, ahc_datum** cols, const char* const* col_names,
+                                       int fuse, ahc_datum** out, int* fused_out) {
+  *out = nullptr;
+  std::vector<Datum> c;
+  std::vector<std::string> names;
+  for (int i = 0; i < ncols; i++) {
+    c.push_back(cols[i]->d);
+    if (col_names) names.push_back(col_names[i] ? col_names[i] : "");
+  }
+  Datum res;
+  bool fused = false;
+  Status st = compute::ExecuteScalarSubstrait(&s->ectx, bytes, len, c, names, &res, fuse != 0, &fused);
+  if (!st.ok()) return Fail(s, st);
+  if (fused_out) *fused_out = fused;
+  *out = new ahc_datum{res};
+  return 0;
+}
+
 // ---- chunked datums (compute.ChunkedDatum, datum.go:186-230) ----------------------------------------------------
 // A chunked datum is assembled from array datums already on the device (the arrays stay owned by the caller).
 AHC_EXPORT int ahc_chunked_from_arrays(ahc_session* s, int type_id, int n, ahc_datum** arrays, ahc_datum** out) {

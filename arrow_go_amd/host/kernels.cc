@@ -253,10 +253,23 @@ static Status ExecCompare(KernelCtx* k, const ExecSpan& b, ExecResult* out, int 
   return s->FromStatus(ah_comparison(s->ctx(), cmpop, shape, (int)in_type->id, l, r, out->buffers[1].buf + out->offset / 8, out->len, (int)(out->offset % 8)));
 }
 
+static Status ExecBoolBinary(KernelCtx* k, const ExecSpan& b, ExecResult* out, int bitop);
+
 void RegisterScalarComparisons(FunctionRegistry* reg) {
   struct C { const char* name; int op; };
   for (C c : {C{"equal", AH_CMP_EQ}, C{"not_equal", AH_CMP_NE}, C{"greater", AH_CMP_GT}, C{"greater_equal", AH_CMP_GE}}) {
     auto fn = std::make_shared<ScalarFunction>(c.name, Arity{2, false});
+    if (c.op == AH_CMP_EQ || c.op == AH_CMP_NE) {
+      // Boolean × Boolean, the first kernels of CompareKernels(CmpEQ / CmpNE) (kernels/scalar_comparisons.go:612-666: boolEQ / boolNE
+      // over the data bitmaps, validity by NullIntersection): equal = XNOR, not_equal = XOR of the data bits
+      exec::ScalarKernel k;
+      k.sig.in_types = {Type::BOOL, Type::BOOL};
+      k.sig.out_is_first_input = false;
+      k.sig.out_type = Type::BOOL;
+      const int bitop = c.op == AH_CMP_EQ ? AH_BIT_XNOR : AH_BIT_XOR;
+      k.exec_fn = [bitop](KernelCtx* kc, const ExecSpan& b, ExecResult* o) { return ExecBoolBinary(kc, b, o, bitop); };
+      fn->AddKernel(std::move(k));
+    }
     for (Type t : kNumericTypes) {
       exec::ScalarKernel k;
       k.sig.in_types = {t, t};

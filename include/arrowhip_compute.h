@@ -166,6 +166,36 @@ int ahc_math_sum(ahc_session* s, ahc_datum* d, double* f64, int64_t* i64, uint64
  * the whole tree where the generator covers it (*fused_out says whether), else call by call — same bytes either way. */
 int ahc_expr_eval(ahc_session* s, const char* text, int ncols, ahc_datum** cols, int nlits, ahc_datum** lits, int fuse,
                   ahc_datum** out, int* fused_out);
+/* The same executor fed with the reference's own tree shape instead of text: compute.Expression is Literal{datum} |
+ * Parameter{field reference} | Call{funcName, args, options} (arrow/compute/expression.go:52-78, 278-290, NewLiteral :596,
+ * NewFieldRef / NewRef :610, NewCall :617).  nodes[] holds the tree in post-order — a call's arguments come before it, the root is
+ * the LAST node; a field reference is a column position, or index = -1 and a name resolved against col_names (FieldRef.FindOne:
+ * "no match for field reference"); a literal is a position in lits[] (scalar datums); a call carries the options text of
+ * ahc_call.  Same fusion rule and same bytes as ahc_expr_eval. */
+#define AHC_EXPR_LITERAL 0
+#define AHC_EXPR_FIELD_REF 1
+#define AHC_EXPR_CALL 2
+typedef struct ahc_expr_node {
+  int32_t kind;
+  int32_t index;          /* LITERAL: position in lits[]; FIELD_REF: column position or -1 (by name) */
+  const char* name;       /* CALL: function name; FIELD_REF by name */
+  const char* options;    /* CALL: options text (nullable) */
+  int32_t nargs;          /* CALL */
+  const int32_t* args;    /* CALL: positions in nodes[] of the arguments, each smaller than this node's */
+} ahc_expr_node;
+int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, int n_nodes, int ncols, ahc_datum** cols, const char* const* col_names,
+                       int nlits, ahc_datum** lits, int fuse, ahc_datum** out, int* fused_out);
+/* exprs.ExecuteScalarSubstrait (arrow/compute/exprs/exec.go:465-488): `bytes` is a serialized substrait.ExtendedExpression with ONE
+ * referred expression — scalar functions of the default extension set (add / subtract / multiply / divide / power / sqrt / abs with
+ * their `overflow` option, equal / not_equal / lt / lte / gt / gte / is_null / is_not_null / is_nan, and / or / not), root field
+ * references, primitive literals (unsigned ones as arrow-go's type variations or Arrow C++'s user-defined types), casts.  cols: the
+ * input's columns in the order of the base schema, or — with col_names — matched by name, missing fields being null scalars
+ * (makeExecBatch, exec.go:384-438); a column whose type differs from the schema's is arrow.ErrInvalid "referenced field … was …,
+ * but should have been …"; what the reference's executor refuses is refused with its error class (ErrNotImplemented: measures,
+ * several referred expressions, if-then, nested references, unknown functions, SATURATE, RETURN_NULL casts; ErrInvalid: no
+ * expression, unspecified cast behaviour).  All-scalar input gives a scalar datum. */
+int ahc_expr_eval_substrait(ahc_session* s, const uint8_t* bytes, int64_t len, int ncols, ahc_datum** cols, const char* const* col_names,
+                            int fuse, ahc_datum** out, int* fused_out);
 
 /* ---- Arrow IPC → HBM (ipc.NewReader / Reader.Next, arrow/ipc/reader.go:97-300) ------------------------------------ */
 /* stream or file format, uncompressed bodies; each RecordBatch body goes to the device in one copy and the columns are

@@ -707,16 +707,17 @@ class Checker:
         for f in self.pkg.funcs:
             env, body = self._env(f)
             self._check_c_calls(f, env, body)
-            self._check_c_names(f, body)
             self._check_selectors(f, env, body)
+        for fname, toks in self.pkg.files.items():      # every C.AH_* of the file, package-level initialisers included
+            self._check_c_names(fname, toks)
         return self
 
-    def _check_c_names(self, f, body):
-        for i in range(len(body) - 2):
-            if body[i].kind == "ident" and body[i].text == "C" and body[i + 1].text == "." and body[i + 2].kind == "ident":
-                nm = body[i + 2].text
+    def _check_c_names(self, fname, toks):
+        for i in range(len(toks) - 2):
+            if toks[i].kind == "ident" and toks[i].text == "C" and toks[i + 1].text == "." and toks[i + 2].kind == "ident":
+                nm = toks[i + 2].text
                 if nm.startswith("AH_") and nm not in self.consts:
-                    self.errors.append(f"{f.file}:{body[i].line}: C.{nm} is not declared by include/arrowhip.h")
+                    self.errors.append(f"{fname}:{toks[i].line}: C.{nm} is not declared by include/arrowhip.h")
 
     def _check_c_calls(self, f, env, body):
         i, n = 0, len(body)

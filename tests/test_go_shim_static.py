@@ -79,6 +79,7 @@ MUTATIONS = [
     ("unsafe.Pointer for a typed pointer", "math.go", "(*C.uint64_t)(values), C.size_t(n), &r", "values, C.size_t(n), &r", r"ah_sum_uint64 argument 2 `values` has type unsafe\.Pointer"),
     ("unknown entry point", "extra.go", "C.ah_ingest_wait(i.g)", "C.ah_ingest_waitall(i.g)", r"C\.ah_ingest_waitall is not declared"),
     ("unknown constant", "arrowhip.go", "C.AH_SHIFT_DIVIDE", "C.AH_SHIFT_DIVIDED", r"C\.AH_SHIFT_DIVIDED is not declared"),
+    ("unknown constant in a package-level table", "expr_lower.go", '"invert": C.AH_X_INVERT', '"invert": C.AH_X_NOT', r"C\.AH_X_NOT is not declared"),
     ("unused import", "math.go", '"unsafe"\n', '"unsafe"\n\t"fmt"\n', r'"fmt" imported and not used'),
     ("unknown field", "comm.go", "C.ah_comm_destroy(c.m)", "C.ah_comm_destroy(c.comm)", r"type Comm has no field or method comm"),
     ("unknown method", "register.go", "g, err := x.NewIngest(0, 0)", "g, err := x.MakeIngest(0, 0)", r"type Context has no field or method MakeIngest"),
