@@ -66,6 +66,8 @@ struct ah_ctx {
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   int capturing;           // between ah_graph_begin and ah_graph_end: the compute stream records instead of running
   ah_filter_cache fcache;  // ah_filter.hip
+  int opt_groupby_seed;    // direct group-by: 1 (default) the workgroups' LDS tables start from the quick look's keys and are added up slot by slot, 0 empty tables merged with atomics
+  int opt_groupby_lean;    // direct group-by: 0 always keep a pending group per lane, 1 (default) leave it out when the quick look says neighbouring rows rarely share a key, 2 always leave it out
   int opt_filter_cache;    // 1: ah_filter_count leaves its tile prefixes for the fill (default on a stream of the context's own), 0: the fill recounts (default on a shared stream)
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;
@@ -184,6 +186,15 @@ int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t*
 // completed when it returns, like a synchronisation of the stream up to that point.
 int ah_compact_u64_by_bits(ah_ctx* ctx, const uint64_t* values, const uint8_t* bits, int64_t n, uint64_t* out_values, int64_t* out_rows);   // ah_filter.hip
 int ah_mailbox_read(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, unsigned long long* out_host);
+int ah_mailbox_begin(ah_ctx* ctx, unsigned long long** mb_out, unsigned long long* seq_out);
+int ah_mailbox_wait(ah_ctx* ctx, unsigned long long seq, int nwords, unsigned long long* out_host);
+#if defined(__HIPCC__)
+// ONE thread of a kernel, after everything it reports is final (and visible to it): ≤ 7 words, then the sequence number
+__device__ __forceinline__ void ah_mailbox_post(unsigned long long* mb, unsigned long long seq, const unsigned long long* words, int nwords) {
+  for (int i = 0; i < nwords; i++) __hip_atomic_store(&mb[i], words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&mb[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 int ah_mailbox_read2(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, const unsigned long long* dev_words2, int nwords2,
                      unsigned long long* out_host);
 // Grow-only scratch arena. Contents are undefined after the call.

@@ -83,6 +83,8 @@ static int ctx_create(int device_id, void* stream, bool borrow, ah_ctx** out) {
   // stream shared with another producer (torch, a second ah_ctx) a foreign kernel may rewrite the mask in between, so there the
   // fill always recounts unless the caller vouches for the mask (ah_ctx_set_option "filter_cache" 1)
   c->opt_filter_cache = c->owns_stream ? 1 : 0;
+  c->opt_groupby_lean = 1;
+  c->opt_groupby_seed = 1;
   *out = c;
   return AH_OK;
 }
@@ -142,6 +144,8 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "encode_part_min")) c->opt_encode_part_min = (int)value;
   else if (!strcmp(name, "encode_part_slots")) c->opt_encode_part_slots = (int)value;
   else if (!strcmp(name, "sort_msd")) c->opt_sort_msd = (int)value;
+  else if (!strcmp(name, "groupby_lean")) c->opt_groupby_lean = (int)value;
+  else if (!strcmp(name, "groupby_seed")) c->opt_groupby_seed = (int)value;
   else if (!strcmp(name, "filter_cache")) { c->opt_filter_cache = value != 0; if (!value) c->fcache.valid = false; }
   else if (!strcmp(name, "scan_segment_log2")) c->opt_scan_segment_log2 = (int)value;
   else return ah_fail(c, AH_EINVALID, "set_option: unknown option '%s'", name);
@@ -162,6 +166,31 @@ __global__ void mailbox_post_kernel(const unsigned long long* __restrict__ src, 
 }  // namespace
 int ah_mailbox_read(ah_ctx* c, const unsigned long long* dev_words, int nwords, unsigned long long* out_host) {
   return ah_mailbox_read2(c, dev_words, nwords, nullptr, 0, out_host);
+}
+// A kernel that knows its own results posts them itself (ah_mailbox_post, ah_common.h) as its last act — no post kernel behind it:
+// ah_mailbox_begin hands out the words and the sequence number to pass to that kernel, ah_mailbox_wait polls for them.
+int ah_mailbox_begin(ah_ctx* c, unsigned long long** mb_out, unsigned long long* seq_out) {
+  if (c->capturing) { c->capturing = 2; return ah_fail(c, AH_EINVALID, "this call returns a value to the host: it cannot be recorded into a graph"); }
+  *mb_out = c->mailbox + 8;
+  *seq_out = ++c->mailbox_seq;
+  return AH_OK;
+}
+int ah_mailbox_wait(ah_ctx* c, unsigned long long seq, int nwords, unsigned long long* out_host) {
+  if (nwords < 1 || nwords > 7) return ah_fail(c, AH_EINVALID, "mailbox_wait: 1..7 words");
+  unsigned long long* mb = c->mailbox + 8;
+  bool seen = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; spin++) {
+    if (__atomic_load_n(&mb[7], __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+    __builtin_ia32_pause();
+    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+  }
+  if (!seen) {
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(&mb[7], __ATOMIC_ACQUIRE) != seq) return ah_fail(c, AH_EHIP, "mailbox_wait: the kernel did not report");
+  }
+  for (int i = 0; i < nwords; i++) out_host[i] = __atomic_load_n(&mb[i], __ATOMIC_RELAXED);
+  return AH_OK;
 }
 // words from two places (a count in one arena, a flag in another) in one post
 int ah_mailbox_read2(ah_ctx* c, const unsigned long long* dev_words, int nwords, const unsigned long long* dev_words2, int nwords2,

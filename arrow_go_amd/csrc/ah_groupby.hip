@@ -111,6 +111,47 @@ __device__ __noinline__ long long gb_global_slot(unsigned long long* __restrict_
   return -1;
 }
 
+// Find or claim the slot of `key` in an LDS table of kSlots keys (not the all-ones key, not a null).  Linear probing over aligned
+// groups of 4 slots, a group per step (32 bytes of LDS, one wait): a wave walks as far as its unluckiest lane, and at load ¼ one
+// slot per step meant 3–4 dependent round trips per row for the wave.  The first slot of the probe order that holds the key or is
+// empty decides (no deletions: a key never sits behind an empty slot of its own probe order).  The eight comparisons stay
+// booleans (lane masks in scalar registers, combined by the scalar unit); per-lane integer masks cost three vector instructions
+// per comparison.  Two multiplies: inside a partition the keys agree in the top bits of gb_mix, so a different function is wanted
+// anyway.  → slot, or −1 when the table has admitted kSoftLimit keys (tickets are never returned: "full" sticks).
+// lkey_base = the LDS byte address of l_key.  Used by the aggregate pass and by the quick look that SEEDS its tables: both must
+// place a key the same way.
+__device__ __forceinline__ int gb_lds_slot(unsigned lkey_base, unsigned long long* l_key, unsigned* s_used, unsigned long long key) {
+  unsigned g = ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 20) & (unsigned)(kSlots - 4);
+  for (;;) {
+    // Two ds_read_b128, spelled out: the compiler splits either 16-byte half into a ds_read2_b64 (it does not see the
+    // alignment through the loop-carried slot number), which serves 16 lanes per LDS cycle over 32 banks where
+    // ds_read_b128 serves 16 lanes over 64 — and bank conflicts are ¾ of this kernel's LDS time (SQ_LDS_BANK_CONFLICT).
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 a, c;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(c) : "v"(lkey_base + g * 8u) : "memory");
+    const bool h0 = a.x == key, h1 = a.y == key, h2 = c.x == key, h3 = c.y == key;
+    const bool e0 = a.x == kEmpty, e1 = a.y == kEmpty, e2 = c.x == kEmpty, e3 = c.y == kEmpty;
+    const bool y0 = h0 || e0, y1 = h1 || e1, y2 = h2 || e2, y3 = h3 || e3;
+    if (!(y0 || y1 || y2 || y3)) { g = (g + 4) & (kSlots - 1); continue; }
+    const int j = (int)g + (y0 ? 0 : y1 ? 1 : y2 ? 2 : 3);
+    if (h0 || (!e0 && (h1 || (!e1 && (h2 || (!e2 && h3)))))) return j;   // the key sits in front of the first empty slot (a key is in the table once)
+    // first empty slot of the probe order: claim it
+    if (atomicAdd(s_used, 1u) >= (unsigned)kSoftLimit) return -1;
+    const unsigned long long cur = atomicCAS(&l_key[j], kEmpty, key);
+    if (cur == kEmpty || cur == key) return j;
+    // another key took it meanwhile: look at the group again
+  }
+}
+
+// The direct path's per-workgroup results for SEEDED slots (see gb_aggregate_kernel, flat == 2): [workgroup][kLSlots] planes, plain stores
+struct GbStaging {
+  unsigned long long* lo;
+  unsigned long long* hi;
+  unsigned* cnt;
+  unsigned* first;
+};
+
 template <bool FX>
 __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsigned long long lo, unsigned long long hi, unsigned cntflags, unsigned first) {
   if (FX) { if (lo | hi) fx_add(gt.lo, gt.hi, (size_t)s, lo, hi); }
@@ -137,12 +178,18 @@ __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsi
 //     wave-uniform loops): half the dependent LDS round trips per row, same instruction count — 6 % SLOWER.  Latency is not it.
 // What is left is fewer instructions per row, and the ones that remain are the algorithm: eight 64-bit compares per probe
 // step, a 128-bit fixed-point split, two 128-bit adds, five LDS operations.
-template <bool FX, bool DIRECT = false>
+template <bool FX, bool DIRECT = false, bool LEAN = false>
 __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                                  const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
                                                                  const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat,
                                                                  const uint8_t* __restrict__ kvalid, int64_t koff, const uint8_t* __restrict__ vvalid,
-                                                                 int64_t voff, int64_t nrows, int64_t seg_rows, unsigned* __restrict__ tile_range = nullptr) {
+                                                                 int64_t voff, int64_t nrows, int64_t seg_rows, unsigned* __restrict__ tile_range = nullptr,
+                                                                 const unsigned long long* __restrict__ seed_keys = nullptr, unsigned seed_used = 0,
+                                                                 GbStaging st = GbStaging{nullptr, nullptr, nullptr, nullptr}) {
+  // seed_keys (flat == 2 only): the key plane of an LDS table holding the keys a quick look found — EVERY workgroup starts from
+  // it, so a seeded key has the same slot in all of them and their results for it are added up slot by slot afterwards
+  // (gd_reduce_kernel) instead of 256 workgroups × groups × 5 atomics on one global table (0.1 ms per 1024 groups, serialised in
+  // L2).  Keys the look did not see are placed behind the seeded ones as they come and leave through the atomic merge as before.
   // flat = 2 ("direct", ≤ 2048 expected groups): no cut at all — keys / vals ARE the columns, a workgroup takes 2^18 consecutive rows
   // and the chunks are merged into ONE global table with atomics.
   // flat = 1: one workgroup per partition (blockIdx = partition; thousands of partitions from the two-level cut), tables of
@@ -220,33 +267,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     if (__builtin_expect(kw != 0 || key == kEmpty, 0)) {
       j = kw ? kSlots + 1 : kSlots;
     } else {
-      // Linear probing over aligned groups of 4 slots, a group per step (32 bytes of LDS, one wait): a wave walks as
-      // far as its unluckiest lane, and at load ¼ one slot per step meant 3–4 dependent round trips per row for the wave.
-      // The first slot of the probe order that holds the key or is empty decides (no deletions: a key never sits behind
-      // an empty slot of its own probe order).  The eight comparisons stay booleans (lane masks in scalar registers,
-      // combined by the scalar unit); per-lane integer masks cost three vector instructions per comparison.
-      // Two multiplies: inside a partition the keys agree in the top bits of gb_mix, so a different function is wanted anyway.
-      unsigned g = ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 20) & (unsigned)(kSlots - 4);
-      for (;;) {
-        // Two ds_read_b128, spelled out: the compiler splits either 16-byte half into a ds_read2_b64 (it does not see the
-        // alignment through the loop-carried slot number), which serves 16 lanes per LDS cycle over 32 banks where
-        // ds_read_b128 serves 16 lanes over 64 — and bank conflicts are ¾ of this kernel's LDS time (SQ_LDS_BANK_CONFLICT).
-        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        u64x2 a, c;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(a), "=&v"(c) : "v"(lkey_base + g * 8u) : "memory");
-        const bool h0 = a.x == key, h1 = a.y == key, h2 = c.x == key, h3 = c.y == key;
-        const bool e0 = a.x == kEmpty, e1 = a.y == kEmpty, e2 = c.x == kEmpty, e3 = c.y == kEmpty;
-        const bool y0 = h0 || e0, y1 = h1 || e1, y2 = h2 || e2, y3 = h3 || e3;
-        if (!(y0 || y1 || y2 || y3)) { g = (g + 4) & (kSlots - 1); continue; }
-        j = (int)g + (y0 ? 0 : y1 ? 1 : y2 ? 2 : 3);
-        if (h0 || (!e0 && (h1 || (!e1 && (h2 || (!e2 && h3)))))) break;   // the key sits in front of the first empty slot (a key is in the table once)
-        // first empty slot of the probe order: claim it
-        if (atomicAdd(&s_used, 1u) >= (unsigned)kSoftLimit) { j = -1; break; }   // tickets are never returned: "full" sticks
-        const unsigned long long cur = atomicCAS(&l_key[j], kEmpty, key);
-        if (cur == kEmpty || cur == key) break;
-        // another key took it meanwhile: look at the group again
-      }
+      j = gb_lds_slot(lkey_base, l_key, &s_used, key);
     }
     if (__builtin_expect(j >= 0, 1)) {
       if (FX) {
@@ -325,8 +346,8 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     gbase = (int64_t)part * kGStride;
   }
   if (r0 < r1) {
-  for (int j = t; j < kLSlots; j += kThreads) { l_key[j] = kEmpty; l_lo[j] = 0; if (FX) l_hi[j] = 0; l_cnt[j] = 0; l_first[j] = kNoRow; }
-  if (t == 0) { s_used = 0; s_direct = 0; }
+  for (int j = t; j < kLSlots; j += kThreads) { l_key[j] = (DIRECT && seed_keys && j < kSlots) ? seed_keys[j] : kEmpty; l_lo[j] = 0; if (FX) l_hi[j] = 0; l_cnt[j] = 0; l_first[j] = kNoRow; }
+  if (t == 0) { s_used = DIRECT && seed_keys ? seed_used : 0u; s_direct = 0; }
   __syncthreads();
   went_direct = false;
   p_live = false;
@@ -335,7 +356,11 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   // state with the back edge's and puts "at most 3 loads outstanding" in front of the row processing — which in the steady state
   // means waiting for the prefetch just issued: the pipeline below never overlapped anything (seen in the ISA, not in a profile).
   __builtin_amdgcn_s_waitcnt(0);
-  for (int64_t b = r0; b < r1; b += kStep) {
+  // One step of U rows per lane.  LEAN = false: a row with the key of the lane's previous row joins the pending group in registers
+  // (see above: skewed columns).  LEAN = true (chosen by the host from the quick look: rows 1024 apart — a lane's consecutive rows —
+  // rarely share a key): every row goes to the table at once; the pending group's bookkeeping, ≈ 20 of a row's ≈ 140 vector
+  // instructions and nine registers, would buy nothing (every row flushed the pending group anyway).
+  auto step = [&](int64_t b) {
     unsigned long long k[U], v[U];
     unsigned rw[U];
 #pragma unroll
@@ -371,6 +396,10 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       }
       const unsigned kw = rwu & kKeyNull;
       if (DIRECT) k[u] = kw ? 0ull : k[u];   // one key for all null rows (the partition pass has done this for the other modes)
+      if (LEAN) {
+        if (live) flush_row(k[u], kw, lo, hi, cf, row);
+        continue;
+      }
       const bool same = !live || (p_live && p_key == k[u] && p_kw == kw);
       if (!same) {
         if (p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
@@ -383,8 +412,9 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       p_cf = (p_cf + (cf & kCntMask)) | (cf & ~kCntMask);   // < 2^19 rows per chunk: the count cannot reach the flag bits
       p_first = row < p_first ? row : p_first;
     }
-  }
-  if (p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
+  };
+  for (int64_t b = r0; b < r1; b += kStep) step(b);
+  if (!LEAN && p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
   if (went_direct) s_direct = 1;
   __syncthreads();
   if (!multi && !s_direct) {
@@ -406,6 +436,15 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   } else {
     for (int j = t; j < kLSlots; j += kThreads) {
       const unsigned fr = l_first[j];
+      if (DIRECT && seed_keys && (j >= kSlots || seed_keys[j] != kEmpty)) {
+        // a seeded slot (and the two special ones, whose place is fixed): this workgroup's share of it, used or not
+        const size_t o = (size_t)blockIdx.x * kLSlots + (size_t)j;
+        st.lo[o] = l_lo[j];
+        if (FX) st.hi[o] = l_hi[j];
+        st.cnt[o] = l_cnt[j];
+        st.first[o] = fr;
+        continue;
+      }
       if (fr == kNoRow) continue;
       long long gs;
       if (j >= kSlots) gs = gbase + kGSlots + (j - kSlots);
@@ -1021,16 +1060,304 @@ __global__ __launch_bounds__(256) void fx_guess_check_kernel(const unsigned* __r
   }
 }
 
+// ---- the direct path's prologue and epilogue: one kernel each ---------------------------------------------------------------------
+// Around a 0.42 ms aggregate pass the direct path used to launch sixteen small kernels (two sample passes + two popcounts + a post,
+// seven memsets, sample max, guess, guess check, mark, word prefix, scan, emit, a post): ≈ 0.16 ms of launches and single-workgroup
+// passes for a table of ≤ 2048 groups.  Now: a QUICK LOOK (one workgroup counts the distinct keys of 2^16 spread rows in an LDS
+// table and takes the largest sampled |value|; it posts both to the host itself), one kernel that initialises everything, the
+// aggregate pass, and one kernel that checks the scale guess, ranks the ≤ 8200 table entries by first row (by counting, in LDS),
+// writes the groups out and posts {flags, group count, null group}.
+constexpr int kQlGroups = 2048;                      // × 8 consecutive rows = 2^14 sampled rows: ONE workgroup does the look (2^16 rows cost it 56 µs of
+                                                     // probing; 2^13 rows 26 µs instead of 34, but the aggregate pass then ran 8 % SLOWER at 2^10 and 2^11
+                                                     // groups: measured, kept at 2^14).  A column SORTED by key shows ≥ 2048 distinct keys this way
+                                                     // (beyond the 1800 the direct path is taken for) unless it really has few
+constexpr int kQlRun = 8;
+__global__ __launch_bounds__(1024) void gq_quicklook_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
+                                                             const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                             int64_t n, int64_t stride, unsigned long long* __restrict__ seed_keys,
+                                                             unsigned long long* mb, unsigned long long seq) {
+  // the table of the aggregate pass (same size, same placement: gb_lds_slot) — what it holds at the end is the SEED every
+  // workgroup of that pass starts from
+  __shared__ __attribute__((aligned(16))) unsigned long long s_key[kSlots];
+  __shared__ unsigned s_used, s_special, s_repeat, s_pairs;
+  __shared__ unsigned long long s_max;
+  const int t = threadIdx.x;
+  for (int j = t; j < kSlots; j += 1024) s_key[j] = kEmpty;
+  if (t == 0) { s_used = 0; s_special = 0; s_max = 0; s_repeat = 0; s_pairs = 0; }
+  __syncthreads();
+  const unsigned lkey_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)s_key;
+  unsigned long long m = 0;
+  unsigned rep = 0, pairs = 0;
+  // sixteen rows per lane at a time, all their loads (key, value, the two validity bytes) in flight together: one row per
+  // trip made the look a chain of 64 dependent HBM latencies (96 µs)
+  constexpr int kB = kQlGroups * kQlRun / 1024;   // rows per lane
+  constexpr int kGpi = 1024 / kQlRun;             // groups per sweep of the workgroup
+  for (int k0 = 0; k0 < 1; k0++) {
+    unsigned long long kk[kB], vv[kB], k2[kB];
+    unsigned char kb[kB], vb[kB];
+#pragma unroll
+    for (int u = 0; u < kB; u++) {
+      const int64_t i = (int64_t)(u * kGpi + t / kQlRun) * stride + (t % kQlRun);
+      const bool in = i < n;
+      kk[u] = in ? keys[i] : 0ull;
+      k2[u] = i + kThreads < n ? keys[i + kThreads] : ~kk[u];   // the row the aggregate pass's lane takes next
+      vv[u] = in && vals ? vals[i] : 0ull;
+      kb[u] = in && kvalid ? kvalid[(koff + i) >> 3] : (unsigned char)0xFF;
+      vb[u] = in && vvalid ? vvalid[(voff + i) >> 3] : (unsigned char)0xFF;
+    }
+#pragma unroll
+    for (int u = 0; u < kB; u++) {
+      const int64_t i = (int64_t)(u * kGpi + t / kQlRun) * stride + (t % kQlRun);
+      if (i >= n) continue;
+      if (!((kb[u] >> ((koff + i) & 7)) & 1)) {
+        if (!(s_special & 1u)) atomicOr(&s_special, 1u);   // the null group
+      } else {
+        const unsigned long long key = kk[u];
+        rep += key == k2[u] ? 1u : 0u;
+        pairs++;
+        if (key == kEmpty) atomicOr(&s_special, 2u);       // the all-ones key has a slot of its own
+        else if (__hip_atomic_load(&s_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)kSoftLimit) (void)gb_lds_slot(lkey_base, s_key, &s_used, key);
+      }
+      if (vals && ((vb[u] >> ((voff + i) & 7)) & 1)) {
+        const unsigned long long b = vv[u] & 0x7fffffffffffffffull;
+        if ((b >> 52) != 0x7ff && b > m) m = b;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long x = __shfl_down(m, o, 64);
+    m = x > m ? x : m;
+  }
+  if ((t & 63) == 0 && m) atomicMax(&s_max, m);
+  atomicAdd(&s_repeat, rep);
+  atomicAdd(&s_pairs, pairs);
+  __syncthreads();
+  for (int j = t; j < kSlots; j += 1024) seed_keys[j] = s_key[j];
+  if (t == 0) {
+    // {distinct keys among the sampled rows (tickets: ≥ kSoftLimit = "many"), largest sampled |value|, of the sampled rows how many
+    // share the key of the row 1024 further on}
+    const unsigned used = s_used < (unsigned)kSoftLimit ? s_used : (unsigned)kSoftLimit;
+    const unsigned long long w[4] = {(unsigned long long)used + (s_special & 1u) + ((s_special >> 1) & 1u), s_max,
+                                     ((unsigned long long)s_pairs << 32) | s_repeat, (unsigned long long)used};
+    __threadfence();   // the seed is read by the next kernels of the stream: ordered by the stream; the fence is for the post below
+    ah_mailbox_post(mb, seq, w, 4);
+  }
+}
+
+// the seeded slots' shares of all workgroups, added up slot by slot (no atomics, no probing: a seeded key has ONE slot everywhere).
+// A block takes 64 slots; its 16 waves each add up a sixteenth of the workgroups (one thread per slot walking all 256 workgroups
+// was a chain of 256 dependent latencies: 100 µs), then the 16 partial sums meet in LDS.
+constexpr int kRedSlots = 64;
+template <bool FX>
+__global__ __launch_bounds__(1024) void gd_reduce_kernel(GbStaging st, int nwg, const unsigned long long* __restrict__ seed_keys, GbTable rt) {
+  __shared__ unsigned long long s_lo[16][kRedSlots], s_hi[16][kRedSlots];
+  __shared__ unsigned s_cnt[16][kRedSlots], s_flags[16][kRedSlots], s_first[16][kRedSlots];
+  const int sx = threadIdx.x & (kRedSlots - 1), wy = threadIdx.x >> 6;
+  const int j = (int)blockIdx.x * kRedSlots + sx;
+  const bool seeded = j < kLSlots && (j >= kSlots || seed_keys[j] != kEmpty);
+  unsigned long long lo = 0, hi = 0;
+  unsigned cnt = 0, flags = 0, first = kNoRow;
+  if (seeded) {
+    constexpr int kW = 4;
+    for (int w0 = wy; w0 < nwg; w0 += 16 * kW) {
+      unsigned long long l[kW], h[kW];
+      unsigned c[kW], f[kW];
+#pragma unroll
+      for (int u = 0; u < kW; u++) {
+        const int w = w0 + 16 * u;
+        const bool in = w < nwg;
+        const size_t o = (size_t)w * kLSlots + (size_t)j;
+        l[u] = in ? st.lo[o] : 0ull;
+        h[u] = in && FX ? st.hi[o] : 0ull;
+        c[u] = in ? st.cnt[o] : 0u;
+        f[u] = in ? st.first[o] : kNoRow;
+      }
+#pragma unroll
+      for (int u = 0; u < kW; u++) {
+        const unsigned long long nl = lo + l[u];
+        hi += h[u] + (nl < lo ? 1ull : 0ull);
+        lo = nl;
+        cnt += c[u] & kCntMask;
+        flags |= c[u] & ~kCntMask;
+        first = f[u] < first ? f[u] : first;
+      }
+    }
+  }
+  s_lo[wy][sx] = lo; s_hi[wy][sx] = hi; s_cnt[wy][sx] = cnt; s_flags[wy][sx] = flags; s_first[wy][sx] = first;
+  __syncthreads();
+  if (wy == 0 && j < kLSlots) {
+    for (int w = 1; w < 16; w++) {
+      const unsigned long long nl = lo + s_lo[w][sx];
+      hi += s_hi[w][sx] + (nl < lo ? 1ull : 0ull);
+      lo = nl;
+      cnt += s_cnt[w][sx];
+      flags |= s_flags[w][sx];
+      first = s_first[w][sx] < first ? s_first[w][sx] : first;
+    }
+    rt.key[j] = j < kSlots ? seed_keys[j] : (j == kSlots ? kEmpty : 0ull);
+    rt.lo[j] = lo;
+    if (FX) rt.hi[j] = hi;
+    rt.cnt[j] = cnt | flags;
+    rt.first[j] = first;
+  }
+}
+
+// everything the direct path starts from: the global table empty, the per-workgroup exponent ranges zero, the call's scalars
+__global__ __launch_bounds__(256) void gd_prep_kernel(GbTable gt, int64_t nslots, unsigned* __restrict__ tile_range, int ntile_words,
+                                                      unsigned long long* __restrict__ dscal20, unsigned long long* __restrict__ range,
+                                                      int has_guess, unsigned long long guess_bits) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < nslots; s += stride) {
+    gt.key[s] = kEmpty; gt.lo[s] = 0; gt.hi[s] = 0; gt.cnt[s] = 0; gt.first[s] = kNoRow;
+  }
+  for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < ntile_words; s += stride) tile_range[s] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dscal20[0] = 0; dscal20[1] = 0; dscal20[2] = 0;   // [20] unused, [21] overflow / redo flags, [22] total
+    dscal20[3] = ~0ull;                               // [23] null id: none
+    if (has_guess) {   // fx_guess_kernel: the sampled maximum's exponent + kGuessMargin binades
+      int e = (int)((guess_bits >> 52) & 0x7ff);
+      e = (e ? e : 1) + kGuessMargin;
+      range[0] = (unsigned long long)(e > 0x7fe ? 0x7fe : e) << 52;
+    } else {
+      range[0] = 0;
+    }
+    range[1] = 0;
+  }
+}
+
+// the epilogue: scale-guess check (fx_guess_check_kernel), first-seen ranks by counting, the groups written out, the post.
+// Entries come from two tables: rt (nullable) — the seeded slots added up by gd_reduce_kernel — and gt, the global table the
+// unseeded keys (or, without a seed, all keys) were merged into.  A key is in one of them only.
+// kFinBlocks workgroups: each gathers ALL used entries into its LDS (12 loads per lane), then ranks its share of them — sixteen
+// lanes per entry, each counting a sixteenth of the first rows below the entry's (one workgroup ranking 2048 entries alone was
+// 4 M comparisons on one CU: 70 µs).  The last workgroup to finish posts {flags, groups, null group}.
+constexpr int kFinMax = kLSlots + kGStride;
+constexpr int kFinBlocks = 16;
+template <bool FX>
+__global__ __launch_bounds__(1024) void gd_finish_kernel(GbTable rt, GbTable gt, const unsigned* __restrict__ tile_range, int nblocks, int check_guess,
+                                                          unsigned long long* __restrict__ range, unsigned* __restrict__ flag, unsigned* __restrict__ done,
+                                                          int* __restrict__ null_id,
+                                                          unsigned long long* __restrict__ out_keys, unsigned long long* __restrict__ out_sums,
+                                                          long long* __restrict__ out_counts, long long* __restrict__ out_first_rows,
+                                                          unsigned long long* mb, unsigned long long seq) {
+  __shared__ __attribute__((aligned(16))) unsigned s_first[kFinMax + 64];
+  __shared__ unsigned short s_slot[kFinMax];
+  __shared__ unsigned short s_mine[kFinMax / kFinBlocks + 64];   // this workgroup's share: the entries whose table position ≡ blockIdx (mod kFinBlocks) —
+  __shared__ unsigned s_e[16], s_i[16];                          // a rule every workgroup agrees on, whatever order its own gathering came out in
+  __shared__ unsigned s_used, s_nmine, s_last;
+  const int t = threadIdx.x;
+  if (t == 0) { s_used = 0; s_nmine = 0; }
+  if (check_guess && blockIdx.x == 0) {   // (block-uniform)
+    unsigned emax = 0, imin = 0;
+    for (int b = t; b < nblocks; b += 1024) {
+      const unsigned a = tile_range[2 * b], c = tile_range[2 * b + 1];
+      emax = a > emax ? a : emax;
+      imin = c > imin ? c : imin;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned a = __shfl_down(emax, o, 64), c = __shfl_down(imin, o, 64);
+      emax = a > emax ? a : emax;
+      imin = c > imin ? c : imin;
+    }
+    if ((t & 63) == 0) { s_e[t >> 6] = emax; s_i[t >> 6] = imin; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < 16; w++) { emax = s_e[w] > emax ? s_e[w] : emax; imin = s_i[w] > imin ? s_i[w] : imin; }
+      const int eg = (int)((range[0] >> 52) & 0x7ff);
+      if ((int)emax > eg + 2) atomicOr(flag, 2u);                              // the guess was too low: the accumulators may have wrapped
+      if (imin && eg - (0x7ff - (int)imin) > 42) atomicOr(flag, 2u);          // too wide for one scale
+      range[1] = imin;
+    }
+  }
+  __syncthreads();
+  // the used entries of both tables, in any order (twelve independent loads per lane in flight)
+  constexpr int kPer = (kFinMax + 1023) / 1024;
+  unsigned fr[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; u++) {
+    const int sidx = u * 1024 + t;
+    fr[u] = kNoRow;
+    if (sidx < kLSlots) { if (rt.first) fr[u] = rt.first[sidx]; }
+    else if (sidx < kFinMax) fr[u] = gt.first[sidx - kLSlots];
+  }
+#pragma unroll
+  for (int u = 0; u < kPer; u++) {
+    if (fr[u] != kNoRow) {
+      const unsigned e = atomicAdd(&s_used, 1u);
+      s_first[e] = fr[u];
+      s_slot[e] = (unsigned short)(u * 1024 + t);
+      if ((unsigned)(u * 1024 + t) % (unsigned)kFinBlocks == blockIdx.x) s_mine[atomicAdd(&s_nmine, 1u)] = (unsigned short)e;
+    }
+  }
+  __syncthreads();
+  const unsigned used = s_used, nmine = s_nmine;
+  if (t < 64) s_first[used + t] = kNoRow;   // padding of the last sweep's reads: larger than every first row, never counted
+  __syncthreads();
+  int sh = 0;
+  if (FX) sh = fx_shift(range[0]);
+  const unsigned sub = t & 15u;
+  for (unsigned m = (unsigned)t >> 4; m < ((nmine + 63u) & ~63u); m += 64u) {   // (the 16 lanes of an entry stay together)
+    const bool live = m < nmine;
+    const unsigned e = live ? (unsigned)s_mine[m] : 0u;
+    const unsigned first = live ? s_first[e] : 0u;
+    unsigned id = 0;
+    for (unsigned j = sub * 4u; j < used; j += 64u) {
+      const uint4 q = *(const uint4*)&s_first[j];
+      id += (q.x < first) + (q.y < first) + (q.z < first) + (q.w < first);
+    }
+    id += __shfl_xor(id, 8, 64); id += __shfl_xor(id, 4, 64); id += __shfl_xor(id, 2, 64); id += __shfl_xor(id, 1, 64);
+    if (!live || sub != 0) continue;
+    const int sidx = (int)s_slot[e];
+    const bool from_rt = sidx < kLSlots;
+    const GbTable& tb = from_rt ? rt : gt;
+    const int sl = from_rt ? sidx : sidx - kLSlots;
+    const int special = from_rt ? kSlots : kGSlots;
+    unsigned long long key = tb.key[sl];
+    if (sl == special) key = kEmpty;
+    if (sl == special + 1) { key = 0; *null_id = (int)id; }   // the null group's key slot keeps the fresh buffer's zero
+    out_keys[id] = key;
+    const unsigned cf = tb.cnt[sl];
+    out_counts[id] = (long long)(cf & kCntMask);
+    if (FX) {
+      const unsigned f = cf >> 29;
+      double r;
+      if (f) r = (f & 1u) || (f & 6u) == 6u ? __builtin_nan("") : ((f & 2u) ? __builtin_inf() : -__builtin_inf());
+      else r = fx_to_double(tb.lo[sl], tb.hi[sl], sh);
+      out_sums[id] = __builtin_bit_cast(unsigned long long, r);
+    } else {
+      out_sums[id] = tb.lo[sl];
+    }
+    if (out_first_rows) out_first_rows[id] = (long long)first;
+  }
+  __syncthreads();
+  if (t == 0) {
+    __threadfence();
+    s_last = atomicAdd(done, 1u) == (unsigned)kFinBlocks - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last && t == 0) {
+    __threadfence();
+    const unsigned fl = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nid = __hip_atomic_load(null_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w[3] = {(unsigned long long)fl, (unsigned long long)used, (unsigned long long)(long long)nid};
+    ah_mailbox_post(mb, seq, w, 3);
+  }
+}
+
+// guess_bits (nullable): the largest sampled |value| the caller's quick look saw — the scale guess then needs no sample pass here
 static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
                      int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
-                     int32_t* out_null_group, int* used) {
+                     int32_t* out_null_group, int* used, const unsigned long long* guess_bits = nullptr, bool lean = false,
+                     const unsigned long long* seed_keys = nullptr, unsigned seed_used = 0) {
   *used = 0;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int64_t nslots = kGStride;
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
   const unsigned dgrid = (unsigned)ah_ceil_div(n, (int64_t)1 << kChunkLog2);
-  const size_t need = pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2 + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8) +
-                      pad((size_t)dgrid * 8);
+  const size_t stage_rows = seed_keys ? (size_t)dgrid * kLSlots : 0;
+  const size_t need = pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2 + pad((size_t)dgrid * 8) + pad(stage_rows * 8) * 2 + pad(stage_rows * 4) * 2 +
+                      pad((size_t)kLSlots * 8) * 3 + pad((size_t)kLSlots * 4) * 2;
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -1042,63 +1369,67 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
   gt.hi = (unsigned long long*)take((size_t)nslots * 8);
   gt.cnt = (unsigned*)take((size_t)nslots * 4);
   gt.first = (unsigned*)take((size_t)nslots * 4);
-  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
-  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
-  int* tilecnt = (int*)take((size_t)nrt * 4);
-  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
   unsigned* tile_range = (unsigned*)take((size_t)dgrid * 8);
+  GbStaging st{nullptr, nullptr, nullptr, nullptr};
+  GbTable rt{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (seed_keys) {
+    st.lo = (unsigned long long*)take(stage_rows * 8);
+    st.hi = (unsigned long long*)take(stage_rows * 8);
+    st.cnt = (unsigned*)take(stage_rows * 4);
+    st.first = (unsigned*)take(stage_rows * 4);
+    rt.key = (unsigned long long*)take((size_t)kLSlots * 8);
+    rt.lo = (unsigned long long*)take((size_t)kLSlots * 8);
+    rt.hi = (unsigned long long*)take((size_t)kLSlots * 8);
+    rt.cnt = (unsigned*)take((size_t)kLSlots * 4);
+    rt.first = (unsigned*)take((size_t)kLSlots * 4);
+  }
   unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
-  unsigned long long* total = (unsigned long long*)&c->dscalars[22];
-  int* null_id = (int*)&c->dscalars[23];
-  AH_HIP(c, hipMemsetAsync(gt.key, 0xFF, (size_t)nslots * 8, c->stream));
-  AH_HIP(c, hipMemsetAsync(gt.lo, 0, pad((size_t)nslots * 8) * 2 + (size_t)nslots * 4, c->stream));   // lo, hi, cnt are adjacent
-  AH_HIP(c, hipMemsetAsync(gt.first, 0xFF, (size_t)nslots * 4, c->stream));
-  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
-  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
   const unsigned long long* k64 = (const unsigned long long*)keys;
   const unsigned long long* v64 = (const unsigned long long*)vals;
   const bool guess = is_f64 && c->opt_groupby_scale_guess && n >= ((int64_t)1 << 22);
+  const bool host_guess = guess && guess_bits != nullptr;
+  gd_prep_kernel<<<16, 256, 0, c->stream>>>(gt, nslots, tile_range, (int)(2 * dgrid), (unsigned long long*)&c->dscalars[20], absmax, host_guess ? 1 : 0,
+                                            host_guess ? *guess_bits : 0ull);
+  AH_LAUNCH_CHECK(c);
   if (is_f64 && !guess) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
     absmax_kernel<<<ah_stream_grid(c, ah_ceil_div(n, (int64_t)kBlock * 8), 2), kBlock, 0, c->stream>>>(v64, vvalid, voff, n, absmax);
     AH_LAUNCH_CHECK(c);
     fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);
   }
-  if (guess) {              // … or a guess from a sample, checked against what the aggregate pass sees (above)
+  if (guess && !host_guess) {   // … or a guess from a sample of its own (the caller had no quick look), checked like the host's
     const int64_t stride = (n / kGuessGroups) & ~(int64_t)63;
-    AH_HIP(c, hipMemsetAsync(tile_range, 0, (size_t)dgrid * 8, c->stream));
     fx_sample_max_kernel<<<kGuessGroups / 4, 256, 0, c->stream>>>(v64, vvalid, voff, n, kGuessGroups, stride, absmax);
     AH_LAUNCH_CHECK(c);
     fx_guess_kernel<<<1, 1, 0, c->stream>>>(absmax);
     AH_LAUNCH_CHECK(c);
   }
   const unsigned grid = dgrid;
-  if (is_f64) gb_aggregate_kernel<true, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n, 0, guess ? tile_range : nullptr);
-  else gb_aggregate_kernel<false, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n, 0);
+  unsigned* trng = guess ? tile_range : nullptr;
+  if (is_f64 && lean) gb_aggregate_kernel<true, true, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n, 0, trng, seed_keys, seed_used, st);
+  else if (is_f64) gb_aggregate_kernel<true, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n, 0, trng, seed_keys, seed_used, st);
+  else gb_aggregate_kernel<false, true><<<grid, kThreads, 0, c->stream>>>(k64, v64, nullptr, nullptr, 1, gt, absmax, overflow, 2, kvalid, koff, vvalid, voff, n, 0, nullptr, seed_keys, seed_used, st);
   AH_LAUNCH_CHECK(c);
-  if (guess) {
-    fx_guess_check_kernel<<<1, 256, 0, c->stream>>>(tile_range, (int)dgrid, absmax, overflow);
+  if (seed_keys) {   // the seeded slots of all workgroups, slot by slot
+    if (is_f64) gd_reduce_kernel<true><<<(unsigned)ah_ceil_div((int64_t)kLSlots, kRedSlots), 1024, 0, c->stream>>>(st, (int)dgrid, seed_keys, rt);
+    else gd_reduce_kernel<false><<<(unsigned)ah_ceil_div((int64_t)kLSlots, kRedSlots), 1024, 0, c->stream>>>(st, (int)dgrid, seed_keys, rt);
     AH_LAUNCH_CHECK(c);
   }
-  gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
+  unsigned long long* mb;
+  unsigned long long seq, w[3];
+  if ((rc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return rc;
+  unsigned* done = (unsigned*)&c->dscalars[20];   // zeroed by gd_prep_kernel
+  int* null_id = (int*)&c->dscalars[23];           // −1 from gd_prep_kernel
+  if (is_f64) gd_finish_kernel<true><<<kFinBlocks, 1024, 0, c->stream>>>(rt, gt, tile_range, (int)dgrid, guess ? 1 : 0, absmax, overflow, done, null_id, (unsigned long long*)out_keys,
+                                                                        (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, mb, seq);
+  else gd_finish_kernel<false><<<kFinBlocks, 1024, 0, c->stream>>>(rt, gt, tile_range, (int)dgrid, 0, absmax, overflow, done, null_id, (unsigned long long*)out_keys,
+                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, mb, seq);
   AH_LAUNCH_CHECK(c);
-  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
-  AH_LAUNCH_CHECK(c);
-  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
-  AH_LAUNCH_CHECK(c);
-  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
-  if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
-  else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
-  AH_LAUNCH_CHECK(c);
-  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
-  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;
-  if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
-  if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
+  if ((rc = ah_mailbox_wait(c, seq, 3, w)) != AH_OK) return rc;   // {overflow / redo flags, groups, null group}
+  if ((unsigned)w[0]) return AH_OK;
+  if (out_ngroups) *out_ngroups = (int64_t)w[1];
+  if (out_null_group) *out_null_group = (int32_t)(long long)w[2];
   *used = 1;
   return AH_OK;
 }
@@ -1126,6 +1457,31 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   if (mode > 1) {
     lp = mode - 2 < 3 ? 3 : (mode - 2 > 10 ? 10 : mode - 2);
   } else {
+    if (is_f64) {
+      // the quick look: 2^16 spread rows, one workgroup, posted by the kernel itself (≈ 15 µs against ≈ 75 for the two-point sample
+      // below).  A column with few enough groups for the direct path is decided here, with the value maximum its scale guess needs.
+      unsigned long long* mb;
+      unsigned long long seq, w[4];
+      void* seedbuf;   // the look's key table: the seed of the direct path's LDS tables (the scratch arena: the direct path's own temporaries are in the other one)
+      int qrc = ah_scratch_reserve(c, (size_t)kSlots * 8, &seedbuf);
+      if (qrc != AH_OK) return qrc;
+      if ((qrc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return qrc;
+      const int64_t qstride = ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) ? ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) : kQlRun;
+      gq_quicklook_kernel<<<1, 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff, n, qstride,
+                                                     (unsigned long long*)seedbuf, mb, seq);
+      AH_LAUNCH_CHECK(c);
+      if ((qrc = ah_mailbox_wait(c, seq, 4, w)) != AH_OK) return qrc;
+      const double qrows = (double)(n < (int64_t)kQlGroups * kQlRun ? n : (int64_t)kQlGroups * kQlRun);
+      if (w[0] <= 1800 && gb_extrapolate((double)w[0], qrows, (double)n) <= 2048.0) {
+        // rows 1024 apart are a lane's consecutive rows in the aggregate pass: where fewer than one in eight of them share a key the
+        // pending-group registers are left out (gb_aggregate_kernel, LEAN)
+        const unsigned pairs = (unsigned)(w[2] >> 32), rep = (unsigned)w[2];
+        const bool lean = c->opt_groupby_lean != 0 && (c->opt_groupby_lean == 2 || (pairs >= 256 && rep * 8u < pairs));
+        const bool seed = c->opt_groupby_seed != 0;
+        return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used, &w[1], lean,
+                         seed ? (const unsigned long long*)seedbuf : nullptr, (unsigned)w[3]);
+      }
+    }
     constexpr int kSampleGroups = 1 << 15;            // × 64 consecutive rows = 2^21 sampled rows
     constexpr unsigned kBits = 1u << 24;
     const int64_t groups = (n / 64 < kSampleGroups ? n / 64 : kSampleGroups) & ~(int64_t)1;

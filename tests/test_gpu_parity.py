@@ -858,6 +858,47 @@ def test_hash_sum_f64_wide_range(hip, orc_be, ctx, mode):
                 assert got != 0.0 or exact == 0, (mode, card, k)   # what the one-scale version returned for every ordinary group
 
 
+@pytest.mark.parametrize("seed,lean", [(1, 1), (1, 0), (1, 2), (0, 1), (0, 2)])
+def test_hash_sum_direct_path_seeded_tables(hip, orc_be, ctx, seed, lean):
+    """The direct group-by (few groups, ≥ 2^21 rows; csrc/ah_groupby.hip): a quick look over 2^14 spread rows builds the key table every
+    workgroup STARTS from (option groupby_seed), so a seeded key has one slot everywhere and the workgroups' results are added up slot
+    by slot; keys the look did not see — here: keys that occur only in a few late rows, the all-ones key, the null key — take the
+    atomic merge into the global table; the pending-group registers are left out when neighbouring rows rarely share a key
+    (groupby_lean).  Every combination must give the oracle's groups, counts, first rows, null group and (integer-valued, exact in any
+    order) sums, byte for byte, run to run."""
+    rng = np.random.default_rng(2024)
+    n = (1 << 22) + 4099
+    for variant in ("uniform", "late keys", "runs"):
+        k = rng.integers(0, 700, n).astype(np.int64)
+        if variant == "late keys":
+            k[n - 5000:] = 10_000 + rng.integers(0, 300, 5000)       # 300 keys no sampled row holds: they are placed behind the seeded ones
+            k[n - 2] = -1                                             # the all-ones key, once
+        if variant == "runs":
+            k = np.repeat(rng.integers(0, 700, n // 4096 + 1), 4096)[:n].astype(np.int64)   # a lane's consecutive rows (1024 apart) mostly share a key
+        keys = (k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64) if variant != "late keys" else k
+        vals = rng.integers(-2**20, 2**20, n).astype(np.float64)
+        vals[rng.integers(0, n, 20)] = np.inf
+        vals[rng.integers(0, n, 5)] = np.nan
+        kvalid = rand_bits(rng, n + 16, 0.97)
+        vvalid = rand_bits(rng, n + 16, 0.9)
+        try:
+            ctx.set_option("groupby_seed", seed)
+            ctx.set_option("groupby_lean", lean)
+            g = hip.hash_sum("f64", keys, kvalid, 5, vals, vvalid, 3)
+            again = hip.hash_sum("f64", keys, kvalid, 5, vals, vvalid, 3)
+            gi = hip.hash_sum("i64", keys, kvalid, 5, vals.astype(np.int64, copy=False) if False else rng.integers(-2**40, 2**40, n, dtype=np.int64), None, 0)
+        finally:
+            ctx.set_option("groupby_seed", 1)
+            ctx.set_option("groupby_lean", 1)
+        e = orc_be.hash_sum("f64", keys, kvalid, 5, vals, vvalid, 3)
+        assert g[3] == e[3], (variant, "null group")
+        for i, what in ((0, "group keys"), (2, "counts"), (4, "first rows")):
+            assert g[i].tobytes() == e[i].tobytes(), (variant, what)
+        assert same_bits_or_both_nan(g[1], e[1]), (variant, "sums")
+        assert g[1].tobytes() == again[1].tobytes(), (variant, "run to run")
+        assert gi[0].tobytes() == e[0].tobytes(), (variant, "int64 group keys")
+
+
 @pytest.mark.parametrize("case", ["ordinary", "outlier_missed_by_the_sample", "outlier_within_the_margin", "wide_but_fits", "too_wide"])
 def test_hash_sum_f64_scale_from_sample(hip, orc_be, ctx, case):
     """The no-cut group-by (≤ 2048 groups, ≥ 2^22 rows) takes its fixed-point scale from 2^18 sampled values + 4 binades and lets the
