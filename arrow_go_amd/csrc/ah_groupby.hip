@@ -100,6 +100,7 @@ static_assert(kSlots == 1 << 12 && kGSlots == 1 << 13, "slot hashes take the top
 
 // slot of `key` in partition table `base` (find or claim); −1 = table full → overflow flag, row dropped (the host falls back)
 __device__ __noinline__ long long gb_global_slot(unsigned long long* __restrict__ gkey, long long base, unsigned long long key, unsigned* __restrict__ overflow) {
+  if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;   // void already: the result is discarded
   unsigned j = gb_gslot(gb_hash32(key));
   for (int probes = 0; probes < kGSlots; probes++) {
     unsigned long long cur = gkey[base + j];
@@ -413,7 +414,12 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       p_first = row < p_first ? row : p_first;
     }
   };
-  for (int64_t b = r0; b < r1; b += kStep) step(b);
+  for (int64_t b = r0; b < r1; b += kStep) {
+    // the attempt is void (a table overflowed: far more groups than estimated): stop feeding a full global table, whose every
+    // probe walks all of it — a wrongly chosen direct path cost 0.9 s that way
+    if (flat != 1 && __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    step(b);
+  }
   if (!LEAN && p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
   if (went_direct) s_direct = 1;
   __syncthreads();
@@ -1067,81 +1073,117 @@ __global__ __launch_bounds__(256) void fx_guess_check_kernel(const unsigned* __r
 // table and takes the largest sampled |value|; it posts both to the host itself), one kernel that initialises everything, the
 // aggregate pass, and one kernel that checks the scale guess, ranks the ≤ 8200 table entries by first row (by counting, in LDS),
 // writes the groups out and posts {flags, group count, null group}.
-constexpr int kQlGroups = 2048;                      // × 8 consecutive rows = 2^14 sampled rows: ONE workgroup does the look (2^16 rows cost it 56 µs of
-                                                     // probing; 2^13 rows 26 µs instead of 34, but the aggregate pass then ran 8 % SLOWER at 2^10 and 2^11
-                                                     // groups: measured, kept at 2^14).  A column SORTED by key shows ≥ 2048 distinct keys this way
-                                                     // (beyond the 1800 the direct path is taken for) unless it really has few
-constexpr int kQlRun = 8;
+constexpr int kQlGroups = 2048;                      // × 8 consecutive rows = 2^14 sampled rows.  ONE workgroup does the look, i.e. one CU executes all of it:
+constexpr int kQlRun = 8;                            // ≈ 2000 instructions per lane for 16 rows = 35 µs (2^16 rows: 56 µs; 2^13 rows: 26 µs, but the aggregate pass
+                                                     // then ran 8 % slower at 2^10 / 2^11 groups; 512 runs of 32 rows: 45 µs — it is not address translation).
+                                                     // A column SORTED by key shows ≥ 2048 distinct keys this way (beyond the 1800 the direct path is taken for)
+                                                     // unless it really has few; the neighbour statistic below catches clustered columns in general
+// first row of sample group g: evenly spread, but JITTERED inside its stride — a column that repeats with a period the stride
+// divides (a table built by tiling one block, as benchmarks do) showed an equidistant sample the same few rows over and over:
+// 65 536 groups looked like 1024 and took the direct path (and its full global table: 0.9 s)
+__device__ __forceinline__ int64_t gq_row(int g, int64_t stride) {
+  // (multiply-high instead of a remainder: a 64-bit `%` is a hundred instructions, and thirty-two of them per lane were two thirds of
+  // the look's 35 µs)
+  const unsigned room = stride > kQlRun ? (unsigned)(stride - kQlRun) : 0u;   // strides are below 2^18 (n < 2^29 rows / 2048 groups)
+  const unsigned jit = (unsigned)(((unsigned long long)((unsigned)g * 2654435761u) * (unsigned long long)(room + 1u)) >> 32);
+  return (int64_t)g * stride + (int64_t)(jit & ~(unsigned)(kQlRun - 1));
+}
+// gb_lds_slot on a table in GLOBAL memory shared by several workgroups (coherent loads, device-scope CAS): same probe order, same
+// "first slot that holds the key or is empty" rule — so the table it leaves is one gb_lds_slot could have built
+__device__ __forceinline__ int gq_global_slot(unsigned long long* __restrict__ g_key, unsigned* __restrict__ g_tickets, unsigned long long key) {
+  unsigned g = ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 20) & (unsigned)(kSlots - 4);
+  for (;;) {
+    unsigned long long q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = __hip_atomic_load(&g_key[g + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int j = -1;
+    bool hit = false;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+      if (q[k] == key) { j = (int)g + k; hit = true; }
+      else if (q[k] == kEmpty) { j = (int)g + k; hit = false; }
+    }
+    if (j < 0) { g = (g + 4) & (kSlots - 1); continue; }
+    if (hit) return j;
+    // (counted on SUCCESS, unlike gb_lds_slot's tickets: sixteen thousand lanes meet an empty table at once here)
+    if (__hip_atomic_load(g_tickets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u >= (unsigned)kSoftLimit) return -1;   // (the word holds count − 1: see qs below)
+    const unsigned long long cur = atomicCAS(&g_key[j], kEmpty, key);
+    if (cur == kEmpty) { atomicAdd(g_tickets, 1u); return j; }
+    if (cur == key) return j;
+  }
+}
+
+// qs: the look's words in device memory, all preset to ones by ONE memset together with the seed table in front of them, so every
+// counter reads "stored + 1": [0] tickets, [1] special bits (stored inverted: AND clears), [2] repeats, [3] pairs, [4] neighbours,
+// [5] workgroups done, [6..7] ~(largest |value|) as a 64-bit minimum.
+constexpr int kQlBlocks = kQlGroups * kQlRun / 1024;   // one row per lane: the look's latency is one row's, not sixteen rows' on one CU (35–50 µs)
 __global__ __launch_bounds__(1024) void gq_quicklook_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
                                                              const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
-                                                             int64_t n, int64_t stride, unsigned long long* __restrict__ seed_keys,
+                                                             int64_t n, int64_t stride, unsigned long long* __restrict__ seed_keys, unsigned* __restrict__ qs,
                                                              unsigned long long* mb, unsigned long long seq) {
-  // the table of the aggregate pass (same size, same placement: gb_lds_slot) — what it holds at the end is the SEED every
-  // workgroup of that pass starts from
-  __shared__ __attribute__((aligned(16))) unsigned long long s_key[kSlots];
-  __shared__ unsigned s_used, s_special, s_repeat, s_pairs;
-  __shared__ unsigned long long s_max;
+  __shared__ unsigned s_last, s_held;
   const int t = threadIdx.x;
-  for (int j = t; j < kSlots; j += 1024) s_key[j] = kEmpty;
-  if (t == 0) { s_used = 0; s_special = 0; s_max = 0; s_repeat = 0; s_pairs = 0; }
-  __syncthreads();
-  const unsigned lkey_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)s_key;
+  constexpr int kGpi = 1024 / kQlRun;             // groups per workgroup
+  const int64_t i = gq_row((int)blockIdx.x * kGpi + t / kQlRun, stride) + (t % kQlRun);
+  const bool in = i < n;
+  const unsigned long long key = in ? keys[i] : 0ull;
+  const unsigned long long k2 = i + kThreads < n ? keys[i + kThreads] : ~key;   // the row the aggregate pass's lane takes next
+  const unsigned long long vv = in && vals ? vals[i] : 0ull;
+  const bool kv = in && (!kvalid || ((kvalid[(koff + i) >> 3] >> ((koff + i) & 7)) & 1));
+  const bool vok = in && vals && (!vvalid || ((vvalid[(voff + i) >> 3] >> ((voff + i) & 7)) & 1));
+  const unsigned long long kprev = __shfl_up(key, 1, 64);   // the row in front (same sample group unless t starts one)
+  const bool kprev_ok = __shfl_up((int)kv, 1, 64) != 0;
+  unsigned special = 0;
+  if (in && !kv) special = 1u;                       // the null group
+  if (kv && key == kEmpty) special |= 2u;            // the all-ones key has a slot of its own
+  // a lane whose key its left neighbour or the wave's first lane also holds leaves the insert to that lane: a column with one
+  // dominant key would otherwise send sixteen thousand CAS to one address (53 µs)
+  const unsigned long long key0 = __shfl(key, 0, 64);
+  const bool kv0 = __shfl((int)kv, 0, 64) != 0;
+  const bool dup = ((t & 63) != 0 && kv0 && key == key0) || ((t & 63) != 0 && kprev_ok && key == kprev);
+  if (kv && key != kEmpty && !dup) (void)gq_global_slot(seed_keys, &qs[0], key);
+  const unsigned long long rep_m = __ballot(kv && key == k2), pair_m = __ballot(kv), adj_m = __ballot(kv && kprev_ok && (t % kQlRun) != 0 && key == kprev);
   unsigned long long m = 0;
-  unsigned rep = 0, pairs = 0;
-  // sixteen rows per lane at a time, all their loads (key, value, the two validity bytes) in flight together: one row per
-  // trip made the look a chain of 64 dependent HBM latencies (96 µs)
-  constexpr int kB = kQlGroups * kQlRun / 1024;   // rows per lane
-  constexpr int kGpi = 1024 / kQlRun;             // groups per sweep of the workgroup
-  for (int k0 = 0; k0 < 1; k0++) {
-    unsigned long long kk[kB], vv[kB], k2[kB];
-    unsigned char kb[kB], vb[kB];
-#pragma unroll
-    for (int u = 0; u < kB; u++) {
-      const int64_t i = (int64_t)(u * kGpi + t / kQlRun) * stride + (t % kQlRun);
-      const bool in = i < n;
-      kk[u] = in ? keys[i] : 0ull;
-      k2[u] = i + kThreads < n ? keys[i + kThreads] : ~kk[u];   // the row the aggregate pass's lane takes next
-      vv[u] = in && vals ? vals[i] : 0ull;
-      kb[u] = in && kvalid ? kvalid[(koff + i) >> 3] : (unsigned char)0xFF;
-      vb[u] = in && vvalid ? vvalid[(voff + i) >> 3] : (unsigned char)0xFF;
-    }
-#pragma unroll
-    for (int u = 0; u < kB; u++) {
-      const int64_t i = (int64_t)(u * kGpi + t / kQlRun) * stride + (t % kQlRun);
-      if (i >= n) continue;
-      if (!((kb[u] >> ((koff + i) & 7)) & 1)) {
-        if (!(s_special & 1u)) atomicOr(&s_special, 1u);   // the null group
-      } else {
-        const unsigned long long key = kk[u];
-        rep += key == k2[u] ? 1u : 0u;
-        pairs++;
-        if (key == kEmpty) atomicOr(&s_special, 2u);       // the all-ones key has a slot of its own
-        else if (__hip_atomic_load(&s_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)kSoftLimit) (void)gb_lds_slot(lkey_base, s_key, &s_used, key);
-      }
-      if (vals && ((vb[u] >> ((voff + i) & 7)) & 1)) {
-        const unsigned long long b = vv[u] & 0x7fffffffffffffffull;
-        if ((b >> 52) != 0x7ff && b > m) m = b;
-      }
-    }
-  }
+  if (vok) { const unsigned long long b = vv & 0x7fffffffffffffffull; if ((b >> 52) != 0x7ff) m = b; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long x = __shfl_down(m, o, 64);
     m = x > m ? x : m;
+    special |= __shfl_down(special, o, 64);
   }
-  if ((t & 63) == 0 && m) atomicMax(&s_max, m);
-  atomicAdd(&s_repeat, rep);
-  atomicAdd(&s_pairs, pairs);
+  if ((t & 63) == 0) {   // one update per wave and word
+    if (rep_m) atomicAdd(&qs[2], (unsigned)__popcll(rep_m));
+    if (pair_m) atomicAdd(&qs[3], (unsigned)__popcll(pair_m));
+    if (adj_m) atomicAdd(&qs[4], (unsigned)__popcll(adj_m));
+    if (special) atomicAnd(&qs[1], ~special);
+    if (m) atomicMin((unsigned long long*)&qs[6], ~m);
+  }
   __syncthreads();
-  for (int j = t; j < kSlots; j += 1024) seed_keys[j] = s_key[j];
   if (t == 0) {
-    // {distinct keys among the sampled rows (tickets: ≥ kSoftLimit = "many"), largest sampled |value|, of the sampled rows how many
-    // share the key of the row 1024 further on}
-    const unsigned used = s_used < (unsigned)kSoftLimit ? s_used : (unsigned)kSoftLimit;
-    const unsigned long long w[4] = {(unsigned long long)used + (s_special & 1u) + ((s_special >> 1) & 1u), s_max,
-                                     ((unsigned long long)s_pairs << 32) | s_repeat, (unsigned long long)used};
-    __threadfence();   // the seed is read by the next kernels of the stream: ordered by the stream; the fence is for the post below
-    ah_mailbox_post(mb, seq, w, 4);
+    __threadfence();
+    s_last = atomicAdd(&qs[5], 1u) + 1u == (unsigned)kQlBlocks - 1u ? 1u : 0u;   // (stored + 1 = done before this one)
+    s_held = 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // the last workgroup counts the keys the table holds (tickets over-count: lanes meeting one new key at once each take one)
+  unsigned mine = 0;
+  for (int j = t; j < kSlots; j += 1024) mine += __hip_atomic_load(&seed_keys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kEmpty ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if ((t & 63) == 0) atomicAdd(&s_held, mine);
+  __syncthreads();
+  if (t == 0) {
+    auto rd = [&](int k) { return __hip_atomic_load(&qs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const unsigned sp = ~rd(1) & 3u;
+    const unsigned used = s_held;   // ≥ kSoftLimit − a few: "many" (inserts stop there)
+    const unsigned long long mx = ~__hip_atomic_load((unsigned long long*)&qs[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // {distinct keys among the sampled rows, largest sampled |value|, pairs | rows sharing the key of the row 1024 further on,
+    //  keys in the seed table, neighbouring rows sharing a key}
+    const unsigned long long w[5] = {(unsigned long long)used + (sp & 1u) + ((sp >> 1) & 1u), mx,
+                                     ((unsigned long long)(rd(3) + 1u) << 32) | (rd(2) + 1u), (unsigned long long)used, (unsigned long long)(rd(4) + 1u)};
+    ah_mailbox_post(mb, seq, w, 5);
   }
 }
 
@@ -1457,22 +1499,31 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   if (mode > 1) {
     lp = mode - 2 < 3 ? 3 : (mode - 2 > 10 ? 10 : mode - 2);
   } else {
+    double est = -1.0;
+    bool heavy_tail = false;
     if (is_f64) {
-      // the quick look: 2^16 spread rows, one workgroup, posted by the kernel itself (≈ 15 µs against ≈ 75 for the two-point sample
+      // the quick look: 2^14 spread rows, one workgroup, posted by the kernel itself (≈ 35 µs against ≈ 75 for the two-point sample
       // below).  A column with few enough groups for the direct path is decided here, with the value maximum its scale guess needs.
       unsigned long long* mb;
-      unsigned long long seq, w[4];
+      unsigned long long seq, w[5];
       void* seedbuf;   // the look's key table: the seed of the direct path's LDS tables (the scratch arena: the direct path's own temporaries are in the other one)
-      int qrc = ah_scratch_reserve(c, (size_t)kSlots * 8, &seedbuf);
+      int qrc = ah_scratch_reserve(c, (size_t)kSlots * 8 + 64, &seedbuf);
       if (qrc != AH_OK) return qrc;
+      AH_HIP(c, hipMemsetAsync(seedbuf, 0xFF, (size_t)kSlots * 8 + 64, c->stream));   // the empty table and the look's words (all "−1")
       if ((qrc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return qrc;
       const int64_t qstride = ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) ? ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) : kQlRun;
-      gq_quicklook_kernel<<<1, 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff, n, qstride,
-                                                     (unsigned long long*)seedbuf, mb, seq);
+      gq_quicklook_kernel<<<kQlBlocks, 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff, n, qstride,
+                                                             (unsigned long long*)seedbuf, (unsigned*)((uint8_t*)seedbuf + (size_t)kSlots * 8), mb, seq);
       AH_LAUNCH_CHECK(c);
-      if ((qrc = ah_mailbox_wait(c, seq, 4, w)) != AH_OK) return qrc;
+      if ((qrc = ah_mailbox_wait(c, seq, 5, w)) != AH_OK) return qrc;
       const double qrows = (double)(n < (int64_t)kQlGroups * kQlRun ? n : (int64_t)kQlGroups * kQlRun);
-      if (w[0] <= 1800 && gb_extrapolate((double)w[0], qrows, (double)n) <= 2048.0) {
+      // neighbouring rows that share a key: once in d rows where d keys are drawn evenly; far more often = a clustered (sorted, run-
+      // length) column, whose 512 sample runs say little about its distinct count — left to the 2^21-row sample below
+      const double adj_rate = (double)w[4] / (qrows > 64.0 ? qrows * (double)(kQlRun - 1) / (double)kQlRun : 1e30);
+      const bool clustered = w[0] > 1 && adj_rate > 4.0 / (double)w[0] + 0.02;
+      // (up to 3000 expected groups — the LDS table admits 3584 —, where the old rule sent ≤ 2048 here: with seeded tables the
+      // merge no longer grows with the group count, 2^11 groups: 0.83 → 0.6 ms)
+      if (!clustered && w[0] <= 2800 && gb_extrapolate((double)w[0], qrows, (double)n) <= 3000.0) {
         // rows 1024 apart are a lane's consecutive rows in the aggregate pass: where fewer than one in eight of them share a key the
         // pending-group registers are left out (gb_aggregate_kernel, LEAN)
         const unsigned pairs = (unsigned)(w[2] >> 32), rep = (unsigned)w[2];
@@ -1481,7 +1532,12 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
         return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used, &w[1], lean,
                          seed ? (const unsigned long long*)seedbuf : nullptr, (unsigned)w[3]);
       }
+      // (The look's own two points — a 2^16-bit linear-counting bitmap read after half of the sample groups and after all — were
+      // tried as the estimate for up to ≈ 10^5 groups too, sparing the 2^21-row sample below: evenly drawn keys came out within 2 %,
+      // but a Zipf(1.1) column over 2^20 keys looked like 7000 keys in 2^14 rows, got 32 partitions and took 5.9 ms instead of 1.5.
+      // The tail of such a column is only seen by a sample of millions of rows: the look decides the direct path and nothing else.)
     }
+    if (est < 0.0) {
     constexpr int kSampleGroups = 1 << 15;            // × 64 consecutive rows = 2^21 sampled rows
     constexpr unsigned kBits = 1u << 24;
     const int64_t groups = (n / 64 < kSampleGroups ? n / 64 : kSampleGroups) & ~(int64_t)1;
@@ -1503,15 +1559,16 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
     if ((rc = ah_mailbox_read(c, ones, 2, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;
     const double sampled = (double)groups * 64.0;
     const double dh = distinct(*(volatile uint64_t*)&c->pinned[8], sampled / 2), ds = distinct(*(volatile uint64_t*)&c->pinned[9], sampled);
-    double est = gb_extrapolate(ds, sampled, (double)n);
+    est = gb_extrapolate(ds, sampled, (double)n);
     if (est <= 2048.0 && is_f64) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
-    if (est <= 4300.0) return AH_OK;                   // all groups still fit the id-based path's LDS table: ≈ 1 ms there, no better here
     // Keys drawn evenly from C values give a curve that the second half of the sample must follow; a heavy-tailed column
     // (Zipf) keeps bringing new keys long after that curve has flattened, and its full distinct count is several times the
     // even-draw extrapolation — give those columns 4× the partitions rather than let the LDS tables overflow into the
     // global ones (measured: 0.45 → 0.89 ms in the aggregate pass of a Zipf(1.1) column over 2^20 keys)
     const double dh_even = gb_extrapolate(ds, sampled, sampled / 2);
-    const bool heavy_tail = dh < 0.93 * dh_even;
+    heavy_tail = dh < 0.93 * dh_even;
+    }
+    if (est <= 4300.0) return AH_OK;                   // all groups still fit the id-based path's LDS table: ≈ 1 ms there, no better here
     // Expected keys per partition: ≈ 1024–1280 (a quarter of the LDS table) while that needs ≤ 256 partitions; beyond, the
     // scatter's runs get short (4096-row tiles / 1024 partitions = 4 rows) and costs more than fuller tables do — up to 2100
     // keys per partition then (the table admits 3584).  Measured at 2^26 rows (`scripts/bench_gb_keys.py`): 2^19 groups 1.62 →
@@ -1606,6 +1663,8 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   nwg = nwg < 1 ? 1 : (nwg > c->num_cu ? c->num_cu : nwg);
   const int64_t seg_rows = ah_ceil_div(n, nwg);
   const unsigned grid = (unsigned)ah_ceil_div(n, seg_rows);
+  // (the row-by-row LEAN mode of the direct path was measured here too, on evenly spread keys: 1.227 ms against 1.217 at 2^16 groups,
+  // 1.546 against 1.563 at 2^20 — nothing, although it frees eight registers: this pass is not bound by its instruction count alone)
   if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
   else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
   AH_LAUNCH_CHECK(c);

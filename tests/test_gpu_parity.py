@@ -899,6 +899,32 @@ def test_hash_sum_direct_path_seeded_tables(hip, orc_be, ctx, seed, lean):
         assert gi[0].tobytes() == e[0].tobytes(), (variant, "int64 group keys")
 
 
+def test_hash_sum_quick_look_on_a_periodic_column(hip, orc_be, ctx):
+    """A column built by tiling one block (period 2^16 rows, 40 000 keys) — what benchmarks do.  An equidistant sample whose stride
+    divides the period reads the same 128 rows over and over and takes 40 000 groups for 128: the direct path was chosen, its global
+    table filled up and every further row walked all of it (0.9 s for 2^26 rows).  The quick look's sample positions are jittered
+    inside their strides, and a voided attempt stops feeding its tables; the result is the oracle's either way."""
+    import time
+    rng = np.random.default_rng(404)
+    block = (rng.integers(0, 40_000, 1 << 16).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    n = 1 << 23
+    keys = np.tile(block, n >> 16)
+    vals = rng.integers(-1000, 1000, n).astype(np.float64)
+    g = hip.hash_sum("f64", keys, None, 0, vals, None, 0)
+    e = orc_be.hash_sum("f64", keys, None, 0, vals, None, 0)
+    for i in (0, 1, 2, 4):
+        assert g[i].tobytes() == e[i].tobytes(), i
+    # … and it must not fall off a cliff: device-resident, a second call, generously bounded (the cliff was 100 ms at this size)
+    dk, dv = ctx.to_device(keys), ctx.to_device(vals)
+    outs = [ctx.alloc((n + 1) * 8 + 64) for _ in range(4)]
+    ctx.hash_sum("f64", dk, None, 0, dv, None, 0, n, *outs)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.hash_sum("f64", dk, None, 0, dv, None, 0, n, *outs)
+    ctx.sync()
+    assert time.perf_counter() - t0 < 0.02, time.perf_counter() - t0
+
+
 @pytest.mark.parametrize("case", ["ordinary", "outlier_missed_by_the_sample", "outlier_within_the_margin", "wide_but_fits", "too_wide"])
 def test_hash_sum_f64_scale_from_sample(hip, orc_be, ctx, case):
     """The no-cut group-by (≤ 2048 groups, ≥ 2^22 rows) takes its fixed-point scale from 2^18 sampled values + 4 binades and lets the
