@@ -84,6 +84,7 @@ static int ctx_create(int device_id, void* stream, bool borrow, ah_ctx** out) {
   // fill always recounts unless the caller vouches for the mask (ah_ctx_set_option "filter_cache" 1)
   c->opt_filter_cache = c->owns_stream ? 1 : 0;
   c->opt_groupby_lean = 1;
+  c->opt_scan_onepass = 1;
   c->opt_groupby_seed = 1;
   *out = c;
   return AH_OK;
@@ -105,6 +106,7 @@ AH_EXPORT void ah_ctx_destroy(ah_ctx* c) {
   if (c->dscalars) (void)hipFree(c->dscalars);
   if (c->mailbox) (void)hipHostFree(c->mailbox);
   if (c->fcache.buf) (void)hipFree(c->fcache.buf);
+  if (c->scan_recs) (void)hipFree(c->scan_recs);
   if (c->temp) (void)hipFree(c->temp);
   (void)hipEventDestroy(c->ev_copy);
   (void)hipEventDestroy(c->ev_compute);
@@ -144,6 +146,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "encode_part_min")) c->opt_encode_part_min = (int)value;
   else if (!strcmp(name, "encode_part_slots")) c->opt_encode_part_slots = (int)value;
   else if (!strcmp(name, "sort_msd")) c->opt_sort_msd = (int)value;
+  else if (!strcmp(name, "scan_onepass")) c->opt_scan_onepass = (int)value;
   else if (!strcmp(name, "groupby_lean")) c->opt_groupby_lean = (int)value;
   else if (!strcmp(name, "groupby_seed")) c->opt_groupby_seed = (int)value;
   else if (!strcmp(name, "filter_cache")) { c->opt_filter_cache = value != 0; if (!value) c->fcache.valid = false; }

@@ -432,6 +432,181 @@ int run_scan_vpt(ah_ctx* c, const void* values, const uint8_t* valid, int64_t of
   return run_scan_aln<T, A, CHECKED, 4>(c, values, valid, off, n, limit, start, out);
 }
 
+// ---- ONE pass for unchecked integer sums without nulls: decoupled look-back over LARGE tiles ----------------------------------------
+// 16 bytes of traffic per Int64 row instead of the 24 of reduce-then-scan.  The look-back's hand-offs cross XCDs (≈ 3 µs each, two on
+// every tile's critical path), which sank the 32 KiB-tile version of round 1 (0.69–0.88 ms for 2^27 Int64 rows, §3.4 of DESIGN.md).
+// What changed (scripts/micro/scan_onepass.hip, measured step by step): a workgroup of 1024 lanes parks 128 KiB of the column in
+// registers, so the 256 resident tiles are 32 MiB of streaming per generation (5 µs in, 5 µs out) around those hand-offs: 0.52 ms;
+// the in-tile scan writes its prefixes over the data (no second register array): 0.45 ms; the eight 64-lane scans per wave use DPP
+// moves (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31) instead of six ds_bpermute round trips each: 0.40 ms = 5.4 TB/s of the 16
+// algorithmic bytes per row.  Smaller tiles with more workgroups per CU are slower (2 × 64 KiB: 0.47 ms, 4 × 32 KiB: 0.63),
+// larger ones spill (160 KiB: 0.40, 192 KiB: 0.44); all sixteen waves looking back together (one round for 1024 predecessors): 0.48.
+// Tiles are taken in TICKET order (a workgroup only waits for tiles whose workgroups already run: no co-residency assumption);
+// records are self-validating words {marker : 32 | payload : 32} moved with relaxed agent-scope atomics, the marker carrying a
+// per-context epoch so that the record array is never cleared; integers only: wrap-around sums are associative, so the result does not
+// depend on which predecessors' aggregates a look-back happened to find (float sums would).
+typedef unsigned long long u64;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_mov32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dpp_move(unsigned v) { return dpp_mov32<CTRL, ROW_MASK>(v); }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ u64 dpp_move(u64 v) {
+  return ((u64)dpp_mov32<CTRL, ROW_MASK>((unsigned)(v >> 32)) << 32) | dpp_mov32<CTRL, ROW_MASK>((unsigned)v);
+}
+template <typename E>
+__device__ __forceinline__ E wave_incl_scan_dpp(E v) {   // a lane without a source keeps 0
+  v += dpp_move<0x111, 0xF>(v);   // row_shr:1
+  v += dpp_move<0x112, 0xF>(v);   // row_shr:2
+  v += dpp_move<0x114, 0xF>(v);   // row_shr:4
+  v += dpp_move<0x118, 0xF>(v);   // row_shr:8
+  v += dpp_move<0x142, 0xA>(v);   // row_bcast:15 → rows 1 and 3
+  v += dpp_move<0x143, 0xC>(v);   // row_bcast:31 → rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ unsigned read_lane63(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ u64 read_lane63(u64 v) { return ((u64)read_lane63((unsigned)(v >> 32)) << 32) | read_lane63((unsigned)v); }
+
+constexpr int kOpThreads = 1024;
+constexpr int kOpVpt = 8;                 // 16-byte vectors per lane: 128 KiB tiles
+constexpr int kOpRecWords = 4;            // per tile: {aggregate lo, hi, inclusive lo, hi}
+__device__ __forceinline__ void op_rec_store(u64* rec, unsigned marker, u64 v) {
+  __hip_atomic_store(&rec[0], ((u64)marker << 32) | (v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&rec[1], ((u64)marker << 32) | (v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool op_rec_load(const u64* rec, unsigned marker, u64* v) {
+  const u64 a = __hip_atomic_load(&rec[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load(&rec[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((unsigned)(a >> 32) != marker || (unsigned)(b >> 32) != marker) return false;
+  *v = (a & 0xffffffffull) | (b << 32);
+  return true;
+}
+
+// E = the accumulator = the element's unsigned twin (uint32 / uint64): rows are summed modulo 2^32 / 2^64
+template <typename E>
+__global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_onepass_kernel(
+    const E* __restrict__ in, E* __restrict__ out, int64_t n, E start, u64* __restrict__ recs, unsigned* __restrict__ ticket, unsigned ticket_base, unsigned epoch) {
+  constexpr int V = 16 / sizeof(E);
+  typedef E EV __attribute__((ext_vector_type(V)));
+  constexpr int TILE = kOpThreads * kOpVpt * V;   // rows
+  __shared__ E s_wave[kOpThreads / 64];
+  __shared__ E s_prefix;
+  __shared__ unsigned s_tile;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned m_agg = epoch * 4u + 1u, m_inc = epoch * 4u + 2u;
+  const int64_t ntiles = (n + TILE - 1) / TILE;
+  for (;;) {
+    if (t == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile >= ntiles) return;
+    const int64_t wbase = tile * TILE + (int64_t)wave * (64 * kOpVpt * V);
+    EV x[kOpVpt];
+#pragma unroll
+    for (int k = 0; k < kOpVpt; k++) {
+      const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
+      if (e + V <= n) x[k] = __builtin_nontemporal_load((const EV*)(in + e));
+      else {
+#pragma unroll
+        for (int j = 0; j < V; j++) x[k][j] = e + j < n ? in[e + j] : (E)0;
+      }
+    }
+    // x[k] becomes the inclusive prefix of its rows inside the wave's chunk, in place
+    E run = 0;
+#pragma unroll
+    for (int k = 0; k < kOpVpt; k++) {
+#pragma unroll
+      for (int j = 1; j < V; j++) x[k][j] += x[k][j - 1];
+      const E s = x[k][V - 1], inc = wave_incl_scan_dpp<E>(s);
+      const E pre = run + inc - s;
+      run += read_lane63(inc);
+#pragma unroll
+      for (int j = 0; j < V; j++) x[k][j] += pre;
+    }
+    if (lane == 0) s_wave[wave] = run;
+    __syncthreads();
+    E wpre = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kOpThreads / 64; w++) { const E v = s_wave[w]; if (w < wave) wpre += v; total += v; }
+    if (wave == 0) {   // publish the aggregate, look back, publish the inclusive prefix
+      u64* mine = recs + (size_t)tile * kOpRecWords;
+      E excl = start;
+      if (tile == 0) {
+        if (lane == 0) op_rec_store(mine + 2, m_inc, (u64)(E)(start + total));
+      } else {
+        if (lane == 0) op_rec_store(mine, m_agg, (u64)total);
+        E acc = 0;
+        for (int64_t back = tile - 1;; back -= 64) {
+          const int64_t p = back - lane;
+          u64 v = 0;
+          int kind = 0;   // 0 before tile 0, 1 aggregate, 2 inclusive
+          if (p >= 0) {
+            const u64* r = recs + (size_t)p * kOpRecWords;
+            for (;;) {
+              if (op_rec_load(r + 2, m_inc, &v)) { kind = 2; break; }
+              if (op_rec_load(r, m_agg, &v)) { kind = 1; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          const u64 incm = __ballot(kind == 2);
+          const int stop = incm ? __builtin_ctzll(incm) : 64;   // the nearest predecessor with an inclusive prefix
+          u64 contrib = (lane <= stop && kind != 0) ? v : 0;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) contrib += __shfl_down(contrib, o, 64);
+          acc += (E)__shfl(contrib, 0, 64);
+          if (incm || back - 63 <= 0) break;
+        }
+        excl = acc;   // (holds `start` through tile 0's inclusive record)
+        if (lane == 0) op_rec_store(mine + 2, m_inc, (u64)(E)(excl + total));
+      }
+      if (lane == 0) s_prefix = excl;
+    }
+    __syncthreads();
+    const E base = s_prefix + wpre;
+#pragma unroll
+    for (int k = 0; k < kOpVpt; k++) {
+      const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
+#pragma unroll
+      for (int j = 0; j < V; j++) x[k][j] += base;
+      if (e + V <= n) __builtin_nontemporal_store(x[k], (EV*)(out + e));
+      else {
+#pragma unroll
+        for (int j = 0; j < V; j++) if (e + j < n) out[e + j] = x[k][j];
+      }
+    }
+    __syncthreads();   // s_tile / s_wave are taken again
+  }
+}
+
+template <typename E>
+int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out) {
+  constexpr int TILE = kOpThreads * kOpVpt * (16 / (int)sizeof(E));
+  const int64_t ntiles = ah_ceil_div(n, (int64_t)TILE);
+  const size_t need = (size_t)ntiles * kOpRecWords * 8 + 64;
+  if (need > c->scan_recs_bytes) {   // the context's own record array: only this kernel writes it, so every stale word carries an older epoch
+    AH_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->scan_recs) AH_HIP(c, hipFree(c->scan_recs));
+    c->scan_recs = nullptr; c->scan_recs_bytes = 0;
+    const size_t want = (need + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    AH_HIP(c, hipMalloc(&c->scan_recs, want));
+    AH_HIP(c, hipMemsetAsync(c->scan_recs, 0, want, c->stream));
+    c->scan_recs_bytes = want;
+    c->scan_epoch = 0;
+    c->scan_ticket_base = 0;
+  }
+  int64_t grid = ntiles < c->num_cu ? ntiles : c->num_cu;   // one workgroup per CU (104 registers × 1024 lanes), tiles by ticket
+  if (c->scan_epoch >= (1u << 29) || (uint64_t)c->scan_ticket_base + (uint64_t)ntiles + (uint64_t)grid >= (1ull << 31)) {   // before a marker or the ticket wraps
+    AH_HIP(c, hipMemsetAsync(c->scan_recs, 0, c->scan_recs_bytes, c->stream));
+    c->scan_epoch = 0;
+    c->scan_ticket_base = 0;
+  }
+  c->scan_epoch++;
+  u64* recs = (u64*)c->scan_recs;
+  unsigned* ticket = (unsigned*)((uint8_t*)c->scan_recs + c->scan_recs_bytes - 64);   // the last 64 bytes: the ticket word (zeroed with the array)
+  scan_onepass_kernel<E><<<(unsigned)grid, kOpThreads, 0, c->stream>>>((const E*)values, (E*)out, n, start, recs, ticket, c->scan_ticket_base, c->scan_epoch);
+  AH_LAUNCH_CHECK(c);
+  c->scan_ticket_base += (unsigned)(ntiles + grid);   // every tile's ticket plus the one each workgroup takes to find out it is done
+  return AH_OK;
+}
+
 template <typename T>
 int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t limit, const void* start_host,
                   int checked, void* out) {
@@ -441,6 +616,11 @@ int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t o
     return run_scan_vpt<T, double, false>(c, values, valid, off, n, limit, (double)start, out);
   } else {
     // unchecked: wraparound commutes with truncation, so the narrowest accumulator ≥ T does
+    // (not while a graph records: the epoch and the ticket base are host state a replay would repeat)
+    if (!checked && !valid && sizeof(T) >= 4 && c->opt_scan_onepass && !c->capturing && n >= ((int64_t)1 << 18) && ((((uintptr_t)values) | ((uintptr_t)out)) & 15) == 0 && c->tune_nt) {
+      if constexpr (sizeof(T) == 8) return run_onepass<unsigned long long>(c, values, n, (unsigned long long)start, out);
+      else if constexpr (sizeof(T) == 4) return run_onepass<unsigned>(c, values, n, (unsigned)start, out);
+    }
     if (!checked) {
       if constexpr (sizeof(T) == 8) return run_scan_vpt<T, unsigned long long, false>(c, values, valid, off, n, limit, (unsigned long long)start, out);
       else return run_scan_vpt<T, unsigned, false>(c, values, valid, off, n, limit, (unsigned)start, out);

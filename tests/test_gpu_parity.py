@@ -899,6 +899,32 @@ def test_hash_sum_direct_path_seeded_tables(hip, orc_be, ctx, seed, lean):
         assert gi[0].tobytes() == e[0].tobytes(), (variant, "int64 group keys")
 
 
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.int32, np.uint32], ids=str)
+def test_cumulative_sum_one_pass(hip, orc_be, ctx, dtype):
+    """cumulative_sum of unchecked 4- / 8-byte integers without nulls takes ONE pass (decoupled look-back over 128 KiB tiles,
+    csrc/ah_scan.hip scan_onepass_kernel) from 2^18 rows on: sizes around the tile size (16 384 Int64 / 32 768 Int32 rows), more tiles than
+    one look-back window (64) and than one generation of resident workgroups (256), a start value, wrap-around — all byte-equal to the
+    sequential oracle and to the reduce-then-scan path (option scan_onepass 0), and the same bytes call after call (the record array is
+    never cleared: epochs)."""
+    rng = np.random.default_rng(31)
+    info = np.iinfo(dtype)
+    tile = 1024 * 8 * (16 // np.dtype(dtype).itemsize)
+    for n in (1 << 18, (1 << 18) + 1, 17 * tile - 1, 17 * tile, 17 * tile + 1, 70 * tile + 123, 300 * tile + 7, (1 << 23) + 5):
+        a = rng.integers(info.min, info.max, n, dtype=dtype, endpoint=True)
+        start = dtype(rng.integers(info.min, info.max, dtype=dtype))
+        e = orc_be.cumulative_sum(a, None, 0, start=start)
+        try:
+            g = hip.cumulative_sum(a, None, 0, start=start)
+            g2 = hip.cumulative_sum(a, None, 0, start=start)
+            ctx.set_option("scan_onepass", 0)
+            g0 = hip.cumulative_sum(a, None, 0, start=start)
+        finally:
+            ctx.set_option("scan_onepass", 1)
+        assert g[0] == e[0] == STATUS_OK
+        assert g[1].tobytes() == e[1].tobytes(), (n, "vs oracle")
+        assert g[1].tobytes() == g2[1].tobytes() == g0[1].tobytes(), (n, "run to run / vs reduce-then-scan")
+
+
 def test_hash_sum_quick_look_on_a_periodic_column(hip, orc_be, ctx):
     """A column built by tiling one block (period 2^16 rows, 40 000 keys) — what benchmarks do.  An equidistant sample whose stride
     divides the period reads the same 128 rows over and over and takes 40 000 groups for 128: the direct path was chosen, its global
