@@ -1113,12 +1113,12 @@ int hash_sum(ah_ctx* c, const uint64_t* keys, const uint8_t* kvalid, int64_t kof
 static int ids_validity(ah_ctx* c, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, uint8_t* out_ids_valid) {
   // indices validity: all set when nulls are encoded (or there is no validity);
   // otherwise the input validity (NullEncodingMask, vector_hash.go:224-230)
+  // the bitmap is this call's to define up to its last byte: the bits behind row n − 1 are zero (ah_copy_bitmap and ah_set_bits_to keep
+  // what lies outside their range — right for an executor's slice, wrong for a fresh output whose memory held something else before)
   int rc;
+  AH_HIP(c, hipMemsetAsync(out_ids_valid, 0, (size_t)((n + 7) / 8), c->stream));
   if (valid && !encode_nulls) rc = ah_copy_bitmap(c, valid, off, n, out_ids_valid, 0, 0);
-  else {
-    AH_HIP(c, hipMemsetAsync(out_ids_valid, 0, (size_t)((n + 7) / 8), c->stream));
-    rc = ah_set_bits_to(c, out_ids_valid, 0, n, 1);
-  }
+  else rc = ah_set_bits_to(c, out_ids_valid, 0, n, 1);
   if (rc != AH_OK) return rc;
   AH_HIP(c, hipStreamSynchronize(c->stream));
   return AH_OK;

@@ -144,6 +144,12 @@ class HipBackend:
         self.c = ctx
 
     # -- helpers
+    def _dirty(self, nbytes):
+        """an output buffer whose memory held something else before (0xA5 …): a kernel that defines only part of its last byte shows"""
+        buf = self.c.alloc(nbytes)
+        buf.memset(0xA5)
+        return buf
+
     def _up(self, arr, misalign=0):
         """upload; returns (buffer, device pointer of element 0)"""
         if arr is None:
@@ -158,7 +164,7 @@ class HipBackend:
         if bits is None:
             return None, None
         a = np.ascontiguousarray(bits, dtype=np.uint8)
-        buf = self.c.alloc(a.nbytes + 64)
+        buf = self._dirty(a.nbytes + 64)
         buf.upload(a)
         return buf, buf.ptr
 
@@ -177,7 +183,7 @@ class HipBackend:
         tid = OL.TYPE_IDS[arr.dtype]
         lb, lp = (None, l) if shape == 2 else self._up(l, misalign)
         rb, rp = (None, r) if shape == 1 else self._up(r, misalign)
-        ob = self.c.alloc(arr.nbytes + 128)
+        ob = self._dirty(arr.nbytes + 128)
         op_ptr = ob.ptr + misalign * arr.dtype.itemsize
         self.c.arithmetic(tid, op, shape, lp, rp, op_ptr, arr.size)
         return ob.download(arr.dtype, arr.size, misalign * arr.dtype.itemsize)
@@ -185,7 +191,7 @@ class HipBackend:
     def arithmetic_unary(self, op, a, misalign=0):
         a = np.ascontiguousarray(a)
         ib, ip = self._up(a, misalign)
-        ob = self.c.alloc(a.nbytes + 128)
+        ob = self._dirty(a.nbytes + 128)
         self.c.arithmetic_unary(OL.TYPE_IDS[a.dtype], op, ip, ob.ptr + misalign * a.dtype.itemsize, a.size)
         return ob.download(a.dtype, a.size, misalign * a.dtype.itemsize)
 
@@ -197,7 +203,7 @@ class HipBackend:
         rb, rp = (None, r) if shape == 1 else self._up(r)
         lvb, lvp = self._upbits(lvalid)
         rvb, rvp = self._upbits(rvalid)
-        ob = self.c.alloc(arr.nbytes + 64)
+        ob = self._dirty(arr.nbytes + 64)
         ob.memset(0xCD)
         try:
             self.c.arithmetic_checked(OL.TYPE_IDS[arr.dtype], op, shape, lp, lvp, loff, rp, rvp, roff, scalar_valid, ob, arr.size)
@@ -211,7 +217,7 @@ class HipBackend:
         import arrow_go_amd as ah
         values = np.ascontiguousarray(values)
         vb, vp = self._up(values); vvb, vvp = self._upbits(valid)
-        ob = self.c.alloc(values.nbytes + 64); ob.memset(0xCD)
+        ob = self._dirty(values.nbytes + 64); ob.memset(0xCD)
         m = None if multiple is None else np.array([multiple], values.dtype)
         try:
             self.c.round(OL.TYPE_IDS[values.dtype], vp, vvp, off, values.size, ndigits, mode, m, OL.load_oracle().pow10(abs(ndigits)), ob)
@@ -228,7 +234,7 @@ class HipBackend:
         rb, rp = (None, r) if (shape == 1 or r is None) else self._up(r)
         lvb, lvp = self._upbits(lvalid)
         rvb, rvp = self._upbits(rvalid)
-        ob = self.c.alloc(arr.nbytes + 64)
+        ob = self._dirty(arr.nbytes + 64)
         ob.memset(0xCD)
         st, msg = STATUS_OK, ""
         try:
@@ -293,9 +299,9 @@ class HipBackend:
         vvb, vvp = self._upbits(vvalid)
         fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
         n_out = self.c.filter_count(fp, fvp, foff, n, null_sel)
-        ob = self.c.alloc(n_out * w + 128)
+        ob = self._dirty(n_out * w + 128)
         ob.memset(0xCD)  # the library must not rely on a pre-zeroed value buffer
-        ovb = self.c.alloc((n_out + 7) // 8 + 64) if want_valid else None
+        ovb = self._dirty((n_out + 7) // 8 + 64) if want_valid else None
         if ovb is not None:
             ovb.memset(0xCD)
         nulls = self.c.filter_primitive(w, vp, vvp, voff, fp, fvp, foff, n, null_sel, n_out, ob, ovb)
@@ -306,8 +312,8 @@ class HipBackend:
     def filter_to_indices(self, fdata, fvalid, foff, n, null_sel, want_valid):
         fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
         n_out = self.c.filter_count(fp, fvp, foff, n, null_sel)
-        ob = self.c.alloc(n_out * 4 + 128)
-        ovb = self.c.alloc((n_out + 7) // 8 + 64) if want_valid else None
+        ob = self._dirty(n_out * 4 + 128)
+        ovb = self._dirty((n_out + 7) // 8 + 64) if want_valid else None
         nulls = self.c.filter_to_indices(fp, fvp, foff, n, null_sel, n_out, ob, ovb)
         return ob.download(np.uint32, n_out), (ovb.download(np.uint8, (n_out + 7) // 8) if want_valid else None), nulls
 
@@ -316,9 +322,9 @@ class HipBackend:
         values = np.ascontiguousarray(values); idx = np.ascontiguousarray(idx)
         vb, vp = self._up(values); vvb, vvp = self._upbits(vvalid)
         ib, ip = self._up(idx); ivb, ivp = self._upbits(ivalid)
-        ob = self.c.alloc(idx.size * values.dtype.itemsize + 64)
+        ob = self._dirty(idx.size * values.dtype.itemsize + 64)
         ob.memset(0xCD)
-        ovb = self.c.alloc((idx.size + 7) // 8 + 64) if want_valid else None
+        ovb = self._dirty((idx.size + 7) // 8 + 64) if want_valid else None
         try:
             nulls = self.c.take_primitive(values.dtype.itemsize, vp, vvp, voff, values.size, idx.dtype.itemsize,
                                           idx.dtype.kind == "i", ip, ivp, ioff, idx.size, bounds_check, ob, ovb)
@@ -337,11 +343,11 @@ class HipBackend:
         vb, vp = self._up(values, misalign)
         vvb, vvp = self._upbits(vvalid)
         fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
-        ob = self.c.alloc(n * w + 128); ob.memset(0xCD)
-        ovb = self.c.alloc((n + 7) // 8 + 64) if want_valid else None
+        ob = self._dirty(n * w + 128); ob.memset(0xCD)
+        ovb = self._dirty((n + 7) // 8 + 64) if want_valid else None
         if ovb is not None:
             ovb.memset(0xCD)
-        st = self.c.alloc(64); st.memset(0xCD)
+        st = self._dirty(64); st.memset(0xCD)
         self.c.filter_primitive_dev(w, vp, vvp, voff, fp, fvp, foff, n, null_sel, ob, ovb, st)
         n_out, nulls = (int(v) for v in st.download(np.int64, 2))
         out = ob.download(values.dtype, n_out)
@@ -353,9 +359,9 @@ class HipBackend:
         values = np.ascontiguousarray(values); idx = np.ascontiguousarray(idx)
         vb, vp = self._up(values); vvb, vvp = self._upbits(vvalid)
         ib, ip = self._up(idx); ivb, ivp = self._upbits(ivalid)
-        ob = self.c.alloc(idx.size * values.dtype.itemsize + 64); ob.memset(0xCD)
-        ovb = self.c.alloc((idx.size + 7) // 8 + 64) if want_valid else None
-        st = self.c.alloc(64); st.memset(0xCD)
+        ob = self._dirty(idx.size * values.dtype.itemsize + 64); ob.memset(0xCD)
+        ovb = self._dirty((idx.size + 7) // 8 + 64) if want_valid else None
+        st = self._dirty(64); st.memset(0xCD)
         self.c.take_primitive_dev(values.dtype.itemsize, vp, vvp, voff, values.size, idx.dtype.itemsize, idx.dtype.kind == "i",
                                   ip, ivp, ioff, idx.size, ob, ovb, st)
         bad, nulls = (int(v) for v in st.download(np.uint64, 2))
@@ -369,9 +375,9 @@ class HipBackend:
         n = values.size
         w = values.dtype.itemsize
         vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
-        ob = self.c.alloc(n * w + 128)
+        ob = self._dirty(n * w + 128)
         ob.memset(0xCD)  # the library must write every row, including the zero payload of null rows
-        ovb = self.c.alloc((n + 7) // 8 + 64) if valid is not None else None
+        ovb = self._dirty((n + 7) // 8 + 64) if valid is not None else None
         if ovb is not None:
             ovb.memset(0xFF)  # prepareCumulativeOutput pre-fills the validity with ones; only bits [0, n) are the library's
         sb = np.array([start], dtype=values.dtype).tobytes() if start is not None else None
@@ -390,7 +396,7 @@ class HipBackend:
         values = np.ascontiguousarray(values)
         od = np.dtype(out_dtype)
         vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
-        ob = self.c.alloc(values.size * od.itemsize + 128)
+        ob = self._dirty(values.size * od.itemsize + 128)
         ob.memset(0xCD)
         try:
             self.c.cast_numeric(OL.TYPE_IDS[values.dtype], OL.TYPE_IDS[od], vp, vvp, off, values.size, allow_int_overflow,
@@ -404,7 +410,7 @@ class HipBackend:
         values = np.ascontiguousarray(values)
         od = np.dtype(out_dtype)
         vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
-        ob = self.c.alloc(values.size * od.itemsize + 128)
+        ob = self._dirty(values.size * od.itemsize + 128)
         ob.memset(0xCD)
         try:
             self.c.shift_time(values.dtype.itemsize * 8, od.itemsize * 8, op, factor, check, vp, vvp, off, values.size, ob.ptr + misalign * od.itemsize)
@@ -415,7 +421,7 @@ class HipBackend:
     def cast_bool_to_numeric(self, bits, off, n, out_dtype):
         od = np.dtype(out_dtype)
         bb, bp = self._upbits(bits)
-        ob = self.c.alloc(n * od.itemsize + 64)
+        ob = self._dirty(n * od.itemsize + 64)
         ob.memset(0xCD)
         self.c.cast_bool_to_numeric(OL.TYPE_IDS[od], bp, off, n, ob)
         return ob.download(od, n)
@@ -426,7 +432,7 @@ class HipBackend:
         vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
         sb, sp = self._up(set_values) if set_values.size else (None, None); svb, svp = self._upbits(set_valid)
         nb = (out_off + n + 7) // 8 + 1
-        odb = self.c.alloc(nb + 64); ovb = self.c.alloc(nb + 64)
+        odb = self._dirty(nb + 64); ovb = self._dirty(nb + 64)
         odb.memset(fill); ovb.memset(fill)
         self.c.is_in(values.dtype.itemsize, vp, vvp, off, n, sp, svp, set_off, set_values.size, null_behavior, odb, ovb, out_off)
         return odb.download(np.uint8, nb), ovb.download(np.uint8, nb)
@@ -439,13 +445,13 @@ class HipBackend:
         w = offsets.dtype.itemsize
         ofb, ofp = self._up(offsets); db, dp = self._up(data) if data.size else (None, None)
         vvb, vvp = self._upbits(vvalid); ib, ip = self._up(idx) if n else (None, None); ivb, ivp = self._upbits(ivalid)
-        oob = self.c.alloc((n + 1) * w + 64); oob.memset(0xCD)
-        ovb = self.c.alloc((n + 7) // 8 + 64) if want_valid else None
+        oob = self._dirty((n + 1) * w + 64); oob.memset(0xCD)
+        ovb = self._dirty((n + 7) // 8 + 64) if want_valid else None
         try:
             nulls, total = self.c.take_binary_offsets(w, ofp, vvp, voff, nvalues, idx.dtype.itemsize, idx.dtype.kind == "i", ip, ivp, ioff, n, oob, ovb)
         except ah.ErrIndex as e:
             return STATUS_EINDEX, None, None, None, 0, int(str(e).split()[0])
-        odb = self.c.alloc(total + 64); odb.memset(0xCD)
+        odb = self._dirty(total + 64); odb.memset(0xCD)
         self.c.take_binary_data(w, ofp, dp, voff, idx.dtype.itemsize, ip, n, oob, odb)
         return (STATUS_OK, oob.download(offsets.dtype, n + 1), odb.download(np.uint8, total),
                 (ovb.download(np.uint8, (n + 7) // 8) if want_valid else None), nulls, 0)
@@ -457,12 +463,12 @@ class HipBackend:
         ofb, ofp = self._up(offsets); db, dp = self._up(data) if data.size else (None, None)
         vvb, vvp = self._upbits(vvalid); fb, fp = self._upbits(fdata); fvb, fvp = self._upbits(fvalid)
         n_out = self.c.filter_count(fp, fvp, foff, n, null_sel)
-        ib = self.c.alloc(n_out * 4 + 64); ivb = self.c.alloc((n_out + 7) // 8 + 64)
+        ib = self._dirty(n_out * 4 + 64); ivb = self._dirty((n_out + 7) // 8 + 64)
         idx_nulls = self.c.filter_to_indices(fp, fvp, foff, n, null_sel, n_out, ib, ivb)
-        oob = self.c.alloc((n_out + 1) * w + 64)
-        ovb = self.c.alloc((n_out + 7) // 8 + 64) if want_valid else None
+        oob = self._dirty((n_out + 1) * w + 64)
+        ovb = self._dirty((n_out + 7) // 8 + 64) if want_valid else None
         nulls, total = self.c.take_binary_offsets(w, ofp, vvp, voff, n, 4, False, ib, ivb if idx_nulls else None, 0, n_out, oob, ovb)
-        odb = self.c.alloc(total + 64)
+        odb = self._dirty(total + 64)
         self.c.take_binary_data(w, ofp, dp, voff, 4, ib, n_out, oob, odb)
         return (oob.download(offsets.dtype, n_out + 1), odb.download(np.uint8, total),
                 (ovb.download(np.uint8, (n_out + 7) // 8) if want_valid else None), nulls)
@@ -475,7 +481,7 @@ class HipBackend:
             vb, vp = self._up(values); vvb, vvp = self._upbits(valid)
             keep += [vb, vvb]
             keys.append((OL.TYPE_IDS[values.dtype], vp, vvp, off, desc, nfirst))
-        ob = self.c.alloc(n * 8 + 64)
+        ob = self._dirty(n * 8 + 64)
         self.c.sort_indices_multi(keys, n, ob)
         return ob.download(np.uint64, n)
 
@@ -488,7 +494,7 @@ class HipBackend:
         values = np.ascontiguousarray(values)
         n = values.size
         vb, vp = self._up(values, misalign); vvb, vvp = self._upbits(valid)
-        ob = self.c.alloc(n * 8 + 64)
+        ob = self._dirty(n * 8 + 64)
         ob.memset(0xCD)
         self.c.sort_indices(OL.TYPE_IDS[values.dtype], vp, vvp, off, n, descending, nulls_at_start, ob)
         return ob.download(np.uint64, n)
@@ -497,21 +503,21 @@ class HipBackend:
         keys = np.ascontiguousarray(keys).view(np.uint64)
         n = keys.size
         kb, kp = self._up(keys); vb, vp = self._upbits(valid)
-        idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); db = self.c.alloc((n + 1) * 8 + 64)
+        idb = self._dirty(n * 4 + 64); idvb = self._dirty((n + 7) // 8 + 64); db = self._dirty((n + 1) * 8 + 64)
         nd, nid = self.c.hash_u64_encode(kp, vp, off, n, encode_nulls, idb, idvb, db)
         return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), db.download(np.uint64, nd), nid
 
     def hash_binary_encode(self, offsets, data, valid, off, n, encode_nulls):
         offsets = np.ascontiguousarray(offsets); data = np.ascontiguousarray(data, dtype=np.uint8)
         ofb, ofp = self._up(offsets); db, dp = self._up(data) if data.size else (None, None); vb, vp = self._upbits(valid)
-        idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); frb = self.c.alloc((n + 1) * 8 + 64)
+        idb = self._dirty(n * 4 + 64); idvb = self._dirty((n + 7) // 8 + 64); frb = self._dirty((n + 1) * 8 + 64)
         nd, nid = self.c.hash_binary_encode(offsets.dtype.itemsize, ofp, dp, vp, off, n, encode_nulls, idb, idvb, frb)
         return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), frb.download(np.int64, nd), nid
 
     def hash_fixed_encode(self, data, w, valid, off, n, encode_nulls):
         data = np.ascontiguousarray(data, dtype=np.uint8)
         db, dp = self._up(data); vb, vp = self._upbits(valid)
-        idb = self.c.alloc(n * 4 + 64); idvb = self.c.alloc((n + 7) // 8 + 64); frb = self.c.alloc((n + 1) * 8 + 64); dcb = self.c.alloc((n + 1) * w + 64)
+        idb = self._dirty(n * 4 + 64); idvb = self._dirty((n + 7) // 8 + 64); frb = self._dirty((n + 1) * 8 + 64); dcb = self._dirty((n + 1) * w + 64)
         nd, nid = self.c.hash_fixed_encode(w, dp, vp, off, n, encode_nulls, idb, idvb, frb, dcb)
         return idb.download(np.int32, n), idvb.download(np.uint8, (n + 7) // 8), frb.download(np.int64, nd), nid, dcb.download(np.uint8, nd * w)
 
@@ -520,8 +526,8 @@ class HipBackend:
         n = keys.size
         kb, kp = self._up(keys); kvb, kvp = self._upbits(kvalid)
         xb, xp = self._up(vals); xvb, xvp = self._upbits(vvalid)
-        okb = self.c.alloc((n + 1) * 8 + 64); osb = self.c.alloc((n + 1) * 8 + 64); ocb = self.c.alloc((n + 1) * 8 + 64)
-        ofb = self.c.alloc((n + 1) * 8 + 64)
+        okb = self._dirty((n + 1) * 8 + 64); osb = self._dirty((n + 1) * 8 + 64); ocb = self._dirty((n + 1) * 8 + 64)
+        ofb = self._dirty((n + 1) * 8 + 64)
         ng, nid = self.c.hash_sum(kind, kp, kvp, koff, xp, xvp, voff, n, okb, osb, ocb, ofb)
         return okb.download(np.uint64, ng), osb.download(vals.dtype, ng), ocb.download(np.int64, ng), nid, ofb.download(np.int64, ng)
 
