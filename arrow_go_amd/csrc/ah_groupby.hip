@@ -49,9 +49,7 @@ constexpr int kChunkLog2 = 18;                       // records per aggregate wo
 constexpr unsigned kCntMask = 0x1fffffffu;           // count word: bits 29..31 = NaN / +inf / −inf seen
 // largest finite |value| — and the smallest exponent, inverted (fx_inv_exp, ah_hashing.h) — of the call from the per-tile pairs the scatter
 // pass leaves (plain stores per tile: 65 536 atomicMax on one address cost 0.8 ms — 12 ns each, serialised)
-// (flag: the "redo on the id-based path" word, bit 1 set for a column too wide for one scale — fx_range_check_kernel's job, one launch less)
-__global__ __launch_bounds__(1024) void gb_max_kernel(const unsigned long long* __restrict__ tile_rng, int64_t ntiles, unsigned long long* __restrict__ range,
-                                                       unsigned* __restrict__ flag = nullptr) {
+__global__ __launch_bounds__(1024) void gb_max_kernel(const unsigned long long* __restrict__ tile_rng, int64_t ntiles, unsigned long long* __restrict__ range) {
   __shared__ unsigned long long s_max[16], s_imin[16];
   unsigned long long m = 0, im = 0;
   for (int64_t i = threadIdx.x; i < ntiles; i += 1024) {
@@ -71,7 +69,6 @@ __global__ __launch_bounds__(1024) void gb_max_kernel(const unsigned long long* 
     for (int w = 1; w < 16; w++) { m = s_max[w] > m ? s_max[w] : m; im = s_imin[w] > im ? s_imin[w] : im; }
     range[0] = m;
     range[1] = im;
-    if (flag && fx_wide(m, im)) atomicOr(flag, 2u);
   }
 }
 
@@ -1095,7 +1092,11 @@ __device__ __forceinline__ int64_t gq_row(int g, int64_t stride) {
 // "first slot that holds the key or is empty" rule — so the table it leaves is one gb_lds_slot could have built
 __device__ __forceinline__ int gq_global_slot(unsigned long long* __restrict__ g_key, unsigned* __restrict__ g_tickets, unsigned long long key) {
   unsigned g = ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 20) & (unsigned)(kSlots - 4);
-  for (;;) {
+  // A BOUNDED walk: the admission count below is read before the CAS, so lanes that read it together can take the table past
+  // kSoftLimit — to completely full, if enough of them are in flight — and an unbounded probe for a key that is not in a full
+  // table never ends.  (Sixteen thousand lanes never got there in hundreds of calls; a variant of this kernel with half a million
+  // lanes in flight did on its first run and hung the device until the watchdog.)  −1 = "not seeded", which every caller handles.
+  for (int probes = 0; probes < kSlots / 4 + 8; probes++) {
     unsigned long long q[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) q[k] = __hip_atomic_load(&g_key[g + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1114,16 +1115,17 @@ __device__ __forceinline__ int gq_global_slot(unsigned long long* __restrict__ g
     if (cur == kEmpty) { atomicAdd(g_tickets, 1u); return j; }
     if (cur == key) return j;
   }
+  return -1;
 }
 
 // qs: the look's words in device memory, all preset to ones by ONE memset together with the seed table in front of them, so every
 // counter reads "stored + 1": [0] tickets, [1] special bits (stored inverted: AND clears), [2] repeats, [3] pairs, [4] neighbours,
 // [5] workgroups done, [6..7] ~(largest |value|) as a 64-bit minimum.
 constexpr int kQlBlocks = kQlGroups * kQlRun / 1024;   // one row per lane: the look's latency is one row's, not sixteen rows' on one CU (35–50 µs)
-__device__ __forceinline__ void gq_quicklook_rows(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
-                                                  const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
-                                                  int64_t n, int64_t stride, unsigned long long* __restrict__ seed_keys, unsigned* __restrict__ qs,
-                                                  unsigned long long* mb, unsigned long long seq) {
+__global__ __launch_bounds__(1024) void gq_quicklook_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
+                                                             const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                             int64_t n, int64_t stride, unsigned long long* __restrict__ seed_keys, unsigned* __restrict__ qs,
+                                                             unsigned long long* mb, unsigned long long seq) {
   __shared__ unsigned s_last, s_held;
   const int t = threadIdx.x;
   constexpr int kGpi = 1024 / kQlRun;             // groups per workgroup
@@ -1190,22 +1192,6 @@ __device__ __forceinline__ void gq_quicklook_rows(const unsigned long long* __re
   }
 }
 
-// The look and the 2^21-row distinct-count sample in ONE launch: workgroups [0, nlook) are the look (latency-bound: a handful of
-// dependent cross-XCD round trips on sixteen CUs), the rest mark the sample's two bitmaps on the CUs the look leaves idle.  A call
-// the look sends to the direct path never reads the bitmaps; any other call has them ready when the look's answer arrives, where
-// it used to start two sample launches and two counts only then (2^16 groups: 1.35 → see DESIGN §3.2).
-__global__ __launch_bounds__(1024) void gq_look_sample_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
-                                                               const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
-                                                               int64_t n, int64_t stride, unsigned long long* __restrict__ seed_keys, unsigned* __restrict__ qs,
-                                                               unsigned long long* mb, unsigned long long seq, int nlook, int64_t sgroups, int64_t sstride,
-                                                               unsigned* __restrict__ bm_a, unsigned* __restrict__ bm_b, unsigned mmask) {
-  if ((int)blockIdx.x < nlook) {
-    gq_quicklook_rows(keys, kvalid, koff, vals, vvalid, voff, n, stride, seed_keys, qs, mb, seq);
-    return;
-  }
-  gb_sample_rows((int64_t)blockIdx.x - nlook, keys, kvalid, koff, n, sgroups, sstride, bm_a, bm_b, mmask);
-}
-
 // the seeded slots' shares of all workgroups, added up slot by slot (no atomics, no probing: a seeded key has ONE slot everywhere).
 // A block takes 64 slots; its 16 waves each add up a sixteenth of the workgroups (one thread per slot walking all 256 workgroups
 // was a chain of 256 dependent latencies: 100 µs), then the 16 partial sums meet in LDS.
@@ -1261,22 +1247,6 @@ __global__ __launch_bounds__(1024) void gd_reduce_kernel(GbStaging st, int nwg, 
     if (FX) rt.hi[j] = hi;
     rt.cnt[j] = cnt | flags;
     rt.first[j] = first;
-  }
-}
-
-// everything the one-level partitioned path starts from, in one launch (it was seven fills): the partitions' global tables empty,
-// the first-row bitmap clear, the call's scalars
-__global__ __launch_bounds__(256) void gp_prep_kernel(GbTable gt, int64_t nslots, unsigned long long* __restrict__ firsts, int64_t nwords,
-                                                      unsigned long long* __restrict__ dscal20, unsigned long long* __restrict__ range) {
-  const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (int64_t s = t0; s < nslots; s += stride) {
-    gt.key[s] = kEmpty; gt.lo[s] = 0; gt.hi[s] = 0; gt.cnt[s] = 0; gt.first[s] = kNoRow;
-  }
-  for (int64_t s = t0; s < nwords; s += stride) firsts[s] = 0;
-  if (t0 == 0) {
-    dscal20[0] = 0; dscal20[1] = 0; dscal20[2] = 0;   // [20] unused, [21] overflow / redo flags, [22] total
-    dscal20[3] = ~0ull;                               // [23] null id: none
-    range[0] = 0; range[1] = 0;
   }
 }
 
@@ -1525,6 +1495,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   unsigned* overflow = (unsigned*)&c->dscalars[21];
   unsigned long long* total = (unsigned long long*)&c->dscalars[22];
   int* null_id = (int*)&c->dscalars[23];
+  unsigned long long* ones = (unsigned long long*)&c->dscalars[24];   // [24], [25]: the two sample points
   // ---- 0: how many partitions?
   int lp;
   if (mode == -2) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
@@ -1535,36 +1506,24 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   } else {
     double est = -1.0;
     bool heavy_tail = false;
-    // One fill, one launch: the quick look (Float64 sums: 2^14 spread rows → distinct keys, value maximum, neighbour statistics and the
-    // key table that seeds the direct path) and, on the CUs the look leaves idle, the 2^21-row sample behind the partition count.
-    // Layout of the block (the scratch arena: the direct path's own temporaries are in the other one), all of it preset to 0xFF:
-    //   [seed keys: kSlots × 8][the look's words, the sample's counters: 64 bytes][bitmap A: 2 MiB][bitmap B: 2 MiB]
-    constexpr int kSampleGroups = 1 << 15;            // × 64 consecutive rows = 2^21 sampled rows
-    constexpr unsigned kBits = 1u << 24;
-    const int64_t groups = (n / 64 < kSampleGroups ? n / 64 : kSampleGroups) & ~(int64_t)1;
-    const int64_t stride = ((n / groups) & ~(int64_t)63) ? ((n / groups) & ~(int64_t)63) : 64;
-    void* seedbuf;
-    int rc = ah_scratch_reserve(c, (size_t)kSlots * 8 + 64 + 2 * (size_t)(kBits / 8), &seedbuf);
-    if (rc != AH_OK) return rc;
-    unsigned* qs = (unsigned*)((uint8_t*)seedbuf + (size_t)kSlots * 8);
-    unsigned* bm_a = (unsigned*)((uint8_t*)seedbuf + (size_t)kSlots * 8 + 64);
-    unsigned* bm_b = bm_a + kBits / 32;
-    AH_HIP(c, hipMemsetAsync(seedbuf, 0xFF, (size_t)kSlots * 8 + 64 + 2 * (size_t)(kBits / 8), c->stream));
-    unsigned long long* mb = nullptr;
-    unsigned long long seq = 0;
-    const int nlook = is_f64 ? kQlBlocks : 0;
-    if (nlook && (rc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return rc;
-    const int64_t qstride = ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) ? ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) : kQlRun;
-    gq_look_sample_kernel<<<(unsigned)(nlook + ah_ceil_div(groups, 16)), 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff, n,
-                                                                                               qstride, (unsigned long long*)seedbuf, qs, mb, seq, nlook, groups, stride, bm_a, bm_b, kBits - 1);
-    AH_LAUNCH_CHECK(c);
     if (is_f64) {
-      // A column with few enough groups for the direct path is decided by the look alone, with the value maximum its scale guess needs.
-      unsigned long long w[5];
-      if ((rc = ah_mailbox_wait(c, seq, 5, w)) != AH_OK) return rc;
+      // the quick look: 2^14 spread rows, one workgroup, posted by the kernel itself (≈ 35 µs against ≈ 75 for the two-point sample
+      // below).  A column with few enough groups for the direct path is decided here, with the value maximum its scale guess needs.
+      unsigned long long* mb;
+      unsigned long long seq, w[5];
+      void* seedbuf;   // the look's key table: the seed of the direct path's LDS tables (the scratch arena: the direct path's own temporaries are in the other one)
+      int qrc = ah_scratch_reserve(c, (size_t)kSlots * 8 + 64, &seedbuf);
+      if (qrc != AH_OK) return qrc;
+      AH_HIP(c, hipMemsetAsync(seedbuf, 0xFF, (size_t)kSlots * 8 + 64, c->stream));   // the empty table and the look's words (all "−1")
+      if ((qrc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return qrc;
+      const int64_t qstride = ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) ? ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) : kQlRun;
+      gq_quicklook_kernel<<<kQlBlocks, 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff, n, qstride,
+                                                             (unsigned long long*)seedbuf, (unsigned*)((uint8_t*)seedbuf + (size_t)kSlots * 8), mb, seq);
+      AH_LAUNCH_CHECK(c);
+      if ((qrc = ah_mailbox_wait(c, seq, 5, w)) != AH_OK) return qrc;
       const double qrows = (double)(n < (int64_t)kQlGroups * kQlRun ? n : (int64_t)kQlGroups * kQlRun);
       // neighbouring rows that share a key: once in d rows where d keys are drawn evenly; far more often = a clustered (sorted, run-
-      // length) column, whose 2048 sample runs say little about its distinct count — left to the 2^21-row sample below
+      // length) column, whose 512 sample runs say little about its distinct count — left to the 2^21-row sample below
       const double adj_rate = (double)w[4] / (qrows > 64.0 ? qrows * (double)(kQlRun - 1) / (double)kQlRun : 1e30);
       const bool clustered = w[0] > 1 && adj_rate > 4.0 / (double)w[0] + 0.02;
       // (up to 3000 expected groups — the LDS table admits 3584 —, where the old rule sent ≤ 2048 here: with seeded tables the
@@ -1579,23 +1538,32 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
                          seed ? (const unsigned long long*)seedbuf : nullptr, (unsigned)w[3]);
       }
       // (The look's own two points — a 2^16-bit linear-counting bitmap read after half of the sample groups and after all — were
-      // tried as the estimate for up to ≈ 10^5 groups too, sparing the 2^21-row sample: evenly drawn keys came out within 2 %,
+      // tried as the estimate for up to ≈ 10^5 groups too, sparing the 2^21-row sample below: evenly drawn keys came out within 2 %,
       // but a Zipf(1.1) column over 2^20 keys looked like 7000 keys in 2^14 rows, got 32 partitions and took 5.9 ms instead of 1.5.
       // The tail of such a column is only seen by a sample of millions of rows: the look decides the direct path and nothing else.)
     }
-    {
+    if (est < 0.0) {
+    constexpr int kSampleGroups = 1 << 15;            // × 64 consecutive rows = 2^21 sampled rows
+    constexpr unsigned kBits = 1u << 24;
+    const int64_t groups = (n / 64 < kSampleGroups ? n / 64 : kSampleGroups) & ~(int64_t)1;
+    const int64_t stride = ((n / groups) & ~(int64_t)63) ? ((n / groups) & ~(int64_t)63) : 64;
+    unsigned* bm;
+    int rc = ah_temp_reserve(c, kBits / 8, (void**)&bm);
+    if (rc != AH_OK) return rc;
+    AH_HIP(c, hipMemsetAsync(bm, 0, kBits / 8, c->stream));
     auto distinct = [&](uint64_t set, double rows) {   // linear counting: M·ln(M / zeros)
       const double z = (double)kBits - (double)set;
       const double d = z < 1.0 ? rows : -(double)kBits * log(z / (double)kBits);
       return d > rows ? rows : d;
     };
-    unsigned long long w2[2];
-    if ((rc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return rc;
-    gb_sample_count_kernel<<<kScBlocks, 1024, 0, c->stream>>>((const uint4*)bm_a, (const uint4*)bm_b, (int)(kBits / 128), (unsigned long long*)(qs + 8), qs + 12, mb, seq);
-    AH_LAUNCH_CHECK(c);
-    if ((rc = ah_mailbox_wait(c, seq, 2, w2)) != AH_OK) return rc;
+    for (int half = 0; half < 2; half++) {
+      gb_sample_kernel<<<(unsigned)ah_ceil_div(groups / 2, 16), 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, n, groups, stride, half, 2, bm, kBits - 1);
+      AH_LAUNCH_CHECK(c);
+      if ((rc = ah_popcount_async(c, (const uint8_t*)bm, 0, kBits, ones + half)) != AH_OK) return rc;
+    }
+    if ((rc = ah_mailbox_read(c, ones, 2, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;
     const double sampled = (double)groups * 64.0;
-    const double dh = distinct(w2[0], sampled / 2), ds = distinct(w2[1], sampled);
+    const double dh = distinct(*(volatile uint64_t*)&c->pinned[8], sampled / 2), ds = distinct(*(volatile uint64_t*)&c->pinned[9], sampled);
     est = gb_extrapolate(ds, sampled, (double)n);
     if (est <= 2048.0 && is_f64) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
     // Keys drawn evenly from C values give a curve that the second half of the sample must follow; a heavy-tailed column
@@ -1664,8 +1632,13 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
   unsigned* prows = (unsigned*)take((size_t)n * 4);
   unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 16);
-  gp_prep_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots > nwords ? nslots : nwords, (int64_t)256 * 4), 8), 256, 0, c->stream>>>(gt, nslots, firsts, nwords, (unsigned long long*)&c->dscalars[20], absmax);
-  AH_LAUNCH_CHECK(c);
+  AH_HIP(c, hipMemsetAsync(gt.key, 0xFF, (size_t)nslots * 8, c->stream));
+  AH_HIP(c, hipMemsetAsync(gt.lo, 0, pad((size_t)nslots * 8) * 2 + (size_t)nslots * 4, c->stream));   // lo, hi, cnt are adjacent
+  AH_HIP(c, hipMemsetAsync(gt.first, 0xFF, (size_t)nslots * 4, c->stream));
+  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));   // absmax, overflow, total
+  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
+  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
   const unsigned long long* k64 = (const unsigned long long*)keys;
   const unsigned long long* v64 = (const unsigned long long*)vals;
   // ---- 1, 2: cut
@@ -1682,7 +1655,9 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
                                                        is_f64 ? tile_max : nullptr);
   AH_LAUNCH_CHECK(c);
   if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
-    gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax, overflow);   // … and a wide column goes to the id-based path (per-group scales)
+    gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+    fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);
   }
   // ---- 3: aggregate

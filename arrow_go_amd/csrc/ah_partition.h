@@ -25,59 +25,23 @@ __device__ __forceinline__ uint64_t gb_mix(uint64_t k) {
 __device__ __forceinline__ unsigned gb_part(uint64_t m, int lp) { return (unsigned)(m >> (64 - lp)); }   // lp = 3 … 10
 
 // ---- 0: distinct estimate by linear counting over a strided sample ---------------------------------------------------
-// Sample group g = 64 consecutive rows near g · stride (JITTERED inside the stride in steps of 8 rows: a column that repeats with
-// a period the stride divides — a table built by tiling one block — shows an equidistant sample the same few rows over and over).
-// Even groups mark bitmap A, odd groups bitmap B: |A| and |A ∪ B| are two points of the distinct-count curve from ONE launch
-// (the first version ran the even groups, read the popcount, then the odd ones: two launches and two counts in a row).  The bitmaps
-// start as all ones and a seen key CLEARS its bit, so that one 0xFF fill prepares them together with the quick look's key table
-// (ah_groupby.hip).  A 1024-entry filter in LDS drops the keys this workgroup has just seen: without it a hot key sends every
-// sampled row to ONE bitmap word — 2^21 same-address atomics = 0.65 ms, and still 0.49 ms with a look-before-set on a Zipf column.
-__device__ __forceinline__ void gb_sample_rows(int64_t blk, const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
-                                               int64_t n, int64_t ngroups, int64_t stride, unsigned* __restrict__ bm_a, unsigned* __restrict__ bm_b, unsigned mmask) {
+// Sample group g = 64 consecutive rows at g · stride; the launch covers groups g0, g0 + 2, g0 + 4, … (the host runs the even
+// groups, reads the bitmap's popcount, then the odd ones: two points of the distinct-count curve).  A 1024-entry filter
+// in LDS drops the keys this workgroup has just seen: without it a hot key sends every sampled row to ONE bitmap word —
+// 2^21 same-address atomics = 0.65 ms, and still 0.49 ms with a look-before-set on a Zipf column.
+__global__ __launch_bounds__(1024) void gb_sample_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
+                                                          int64_t n, int64_t ngroups, int64_t stride, int g0, int gstep, unsigned* __restrict__ bm, unsigned mmask) {
   __shared__ unsigned long long s_seen[1024];
   s_seen[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t g = blk * 16 + (threadIdx.x >> 6);
-  const unsigned room = stride > 64 ? (unsigned)(stride - 64) : 0u;   // strides are below 2^15 (n < 2^29 rows, ≥ 2^15 groups whenever stride > 64)
-  const unsigned jit = (unsigned)(((unsigned long long)((unsigned)g * 2654435761u) * (unsigned long long)(room + 1u)) >> 32) & ~7u;
-  const int64_t i = g * stride + (int64_t)jit + (threadIdx.x & 63);
+  const int64_t g = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * gstep + g0;
+  const int64_t i = g * stride + (threadIdx.x & 63);
   if (g >= ngroups || i >= n || !ah_bit(kvalid, koff + i)) return;
   const uint64_t m = gb_mix(keys[i]) | 1ull;
   const unsigned f = (unsigned)(m >> 44) & 1023u;
   if (atomicExch(&s_seen[f], m) == m) return;   // an LDS atomic, so that of the lanes holding a hot key at this instant only one goes on
   const unsigned b = (unsigned)(m >> 20) & mmask;
-  unsigned* bm = (g & 1) ? bm_b : bm_a;
-  if ((__hip_atomic_load(&bm[b >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b & 31)) & 1u) atomicAnd(&bm[b >> 5], ~(1u << (b & 31)));
-}
-
-// |A| and |A ∪ B| (cleared bits), posted by the last workgroup; cnt[0..1] and *done start as all ones ("−1")
-constexpr int kScBlocks = 64;
-__global__ __launch_bounds__(1024) void gb_sample_count_kernel(const uint4* __restrict__ bm_a, const uint4* __restrict__ bm_b, int nvec, unsigned long long* __restrict__ cnt,
-                                                                unsigned* __restrict__ done, unsigned long long* mb, unsigned long long seq) {
-  __shared__ unsigned s_last;
-  unsigned a = 0, ab = 0;
-  for (int j = (int)blockIdx.x * 1024 + (int)threadIdx.x; j < nvec; j += kScBlocks * 1024) {
-    const uint4 x = bm_a[j], y = bm_b[j];
-    a += (unsigned)(__popc(~x.x) + __popc(~x.y) + __popc(~x.z) + __popc(~x.w));
-    ab += (unsigned)(__popc(~(x.x & y.x)) + __popc(~(x.y & y.y)) + __popc(~(x.z & y.z)) + __popc(~(x.w & y.w)));
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); ab += __shfl_down(ab, o, 64); }
-  if ((threadIdx.x & 63) == 0) {
-    if (a) atomicAdd(&cnt[0], (unsigned long long)a);
-    if (ab) atomicAdd(&cnt[1], (unsigned long long)ab);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(done, 1u) + 1u == (unsigned)kScBlocks - 1u ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!s_last || threadIdx.x != 0) return;
-  __threadfence();
-  const unsigned long long w[2] = {__hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull,
-                                   __hip_atomic_load(&cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull};
-  ah_mailbox_post(mb, seq, w, 2);
+  if (!((__hip_atomic_load(&bm[b >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b & 31)) & 1u)) atomicOr(&bm[b >> 5], 1u << (b & 31));
 }
 
 // ---- 1: per (tile, partition) counts ----------------------------------------------------------------------------------
