@@ -27,7 +27,7 @@ SIZES = [0, 1, 2, 3, 15, 16, 17, 63, 64, 65, 255, 257, 1023, 1025, 2047, 2048, 2
 
 @pytest.fixture(scope="module")
 def hip(ctx):
-    return HipBackend(ctx)
+    return HipBackend(ctx, dirty_outputs=True)
 
 
 @pytest.fixture(scope="module")
