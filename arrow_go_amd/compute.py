@@ -64,6 +64,7 @@ lib.ahc_scalar_set_logical.argtypes = [_vp, _vp, C.c_char_p]
 lib.ahc_ipc_bytes_uploaded.argtypes = [_vp]
 lib.ahc_ipc_bytes_uploaded.restype = C.c_int64
 lib.ahc_ipc_inspect.argtypes = [_vp, C.c_int64, C.c_char_p, C.c_int64]
+lib.ahc_substrait_inspect.argtypes = [_vp, C.c_int64, C.c_char_p, C.c_int64]
 lib.ahc_expr_eval.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]
 
 
@@ -221,6 +222,19 @@ def _as_bytes_ptr(buf):
         return keep, addr, mv.nbytes
     keep = (C.c_char * mv.nbytes).from_buffer(mv)
     return keep, C.addressof(keep), mv.nbytes
+
+
+
+def inspect_substrait(buf) -> str:
+    """What the Substrait reader understood of a serialized ExtendedExpression, without a device (ahc_substrait_inspect):
+    "name:type,…|output_name=expression|…"; raises the reference's error class for a message the reader refuses as a whole."""
+    keep, addr, n = _as_bytes_ptr(buf)
+    out = C.create_string_buffer(1 << 16)
+    rc = lib.ahc_substrait_inspect(addr, n, out, len(out))
+    text = out.value.decode(errors="replace")
+    if rc != 0:
+        raise _ERRS.get(rc, ArrowError)(text)
+    return text
 
 
 def ipc_inspect(buf):

@@ -748,6 +748,45 @@ AHC_EXPORT int ahc_expr_eval_substrait(ahc_session* s, const uint8_t* bytes, int
   return 0;
 }
 
+// Parses a serialized ExtendedExpression without a device and renders what it understood — the parser's own test entry (runs where
+// there is no GPU; the reader takes bytes from outside the process, so truncated and random inputs are part of its tests):
+//   "name:type,…|output_name=rendered expression|…"    literals as type(hex of the payload), null literals as type(null),
+//   field references as $index, options as the mapped function name shows them (add vs add_unchecked); an expression the
+//   executor would refuse renders as "!" + its error text.  A malformed message → the status code, the error text in out.
+static std::string RenderExpr(const compute::Expression& e) {
+  switch (e.kind) {
+    case compute::Expression::LITERAL: {
+      const ScalarPtr& sc = e.literal.scalar;
+      if (!sc || !sc->type) return "?";
+      if (!sc->valid) return std::string(sc->type->name) + "(null)";
+      std::string hex;
+      const int bytes = sc->type->id == Type::BOOL ? 1 : (sc->type->bit_width + 7) / 8;
+      for (int i = bytes - 1; i >= 0; i--) { char b[3]; snprintf(b, sizeof b, "%02x", sc->value[i]); hex += b; }
+      return std::string(sc->type->name) + "(" + hex + ")";
+    }
+    case compute::Expression::FIELD_REF: return e.field_name.empty() ? "$" + std::to_string(e.field_index) : e.field_name;
+    default: {
+      std::string t = e.function + "(";
+      for (size_t i = 0; i < e.args.size(); i++) t += (i ? ", " : "") + (e.args[i] ? RenderExpr(*e.args[i]) : std::string("?"));
+      if (auto co = std::dynamic_pointer_cast<compute::CastOptions>(e.options))
+        t += std::string(" -> ") + (co->ToType ? co->ToType->name : "?") + (co->AllowIntOverflow && co->AllowFloatTruncate ? " unsafe" : " safe");
+      return t + ")";
+    }
+  }
+}
+AHC_EXPORT int ahc_substrait_inspect(const uint8_t* bytes, int64_t len, char* out, int64_t cap) {
+  auto put = [&](const std::string& t) { if (cap > 0) { snprintf(out, (size_t)cap, "%s", t.c_str()); } };
+  compute::SubstraitExtended x;
+  Status st = compute::ParseSubstraitExtended(bytes, len, &x);
+  if (!st.ok()) { put(st.ToString()); return (int)st.code; }
+  std::string text;
+  for (size_t i = 0; i < x.names.size(); i++) text += (i ? "," : "") + x.names[i] + ":" + (x.types[i] ? std::string(x.types[i]->name) : "?" + x.type_names[i]);
+  for (size_t i = 0; i < x.exprs.size(); i++)
+    text += "|" + x.out_names[i] + "=" + (x.expr_status[i].ok() && x.exprs[i] ? RenderExpr(*x.exprs[i]) : "!" + x.expr_status[i].ToString());
+  put(text);
+  return 0;
+}
+
 // ---- chunked datums (compute.ChunkedDatum, datum.go:186-230) ----------------------------------------------------
 // A chunked datum is assembled from array datums already on the device (the arrays stay owned by the caller).
 AHC_EXPORT int ahc_chunked_from_arrays(ahc_session* s, int type_id, int n, ahc_datum** arrays, ahc_datum** out) {

@@ -197,6 +197,12 @@ int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, int n_nodes, 
 int ahc_expr_eval_substrait(ahc_session* s, const uint8_t* bytes, int64_t len, int ncols, ahc_datum** cols, const char* const* col_names,
                             int fuse, ahc_datum** out, int* fused_out);
 
+/* The same reader without a device: parses `bytes` and renders what it understood into out (NUL-terminated, truncated to cap) as
+ * "name:type,…|output_name=expression|…" — literals as type(hex payload) or type(null), field references as $index, casts as cast(x -> type unsafe), an
+ * expression the executor would refuse as "!" + its error text.  A malformed message returns the status code with the error text in out.
+ * Needs no session and no GPU: the CPU tests of the wire-format reader (truncated and random bytes included) go through it. */
+int ahc_substrait_inspect(const uint8_t* bytes, int64_t len, char* out, int64_t cap);
+
 /* ---- Arrow IPC → HBM (ipc.NewReader / Reader.Next, arrow/ipc/reader.go:97-300) ------------------------------------ */
 /* stream or file format, uncompressed bodies; each RecordBatch body goes to the device in one copy and the columns are
  * slices of it.  `bytes` must stay valid until ahc_ipc_close. */
