@@ -65,6 +65,7 @@ lib.ahc_ipc_bytes_uploaded.argtypes = [_vp]
 lib.ahc_ipc_bytes_uploaded.restype = C.c_int64
 lib.ahc_ipc_inspect.argtypes = [_vp, C.c_int64, C.c_char_p, C.c_int64]
 lib.ahc_substrait_inspect.argtypes = [_vp, C.c_int64, C.c_char_p, C.c_int64]
+lib.ahc_dispatch_best.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int64]
 lib.ahc_expr_eval.argtypes = [_vp, C.c_char_p, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]
 
 
@@ -224,6 +225,23 @@ def _as_bytes_ptr(buf):
     return keep, C.addressof(keep), mv.nbytes
 
 
+
+def dispatch_best(function: str, types):
+    """fn.DispatchBest(types...) without executing (ahc_dispatch_best): pyarrow types in → the argument types of the chosen kernel
+    as pyarrow types; raises the reference's error class (ErrNotImplemented "has no kernel matching input types", KeyError …)."""
+    ids = {"bool": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7, "uint64": 8, "int64": 9, "float": 11, "double": 12,
+           "string": 13, "binary": 14, "large_string": 34, "large_binary": 35}
+    back = {v: k for k, v in ids.items()}
+    n = len(types)
+    tin = (C.c_int * n)(*[ids[str(t)] for t in types])
+    tout = (C.c_int * n)()
+    err = C.create_string_buffer(1024)
+    rc = lib.ahc_dispatch_best(function.encode(), n, tin, tout, err, len(err))
+    if rc != 0:
+        raise _ERRS.get(rc, ArrowError)(err.value.decode(errors="replace"))
+    import pyarrow as pa
+    named = {"float": pa.float32(), "double": pa.float64(), "bool": pa.bool_()}
+    return [named.get(back[i], None) or getattr(pa, back[i])() for i in tout]
 
 def inspect_substrait(buf) -> str:
     """What the Substrait reader understood of a serialized ExtendedExpression, without a device (ahc_substrait_inspect):

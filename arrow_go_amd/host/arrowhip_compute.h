@@ -342,7 +342,7 @@ class ScalarFunction : public Function {  // functions.go:239-290
  public:
   ScalarFunction(std::string name, Arity arity) : Function(std::move(name), arity, FuncKind::Scalar) {}
   Status AddKernel(exec::ScalarKernel k);
-  int NumKernels() const override { return (int)kernels_.size(); }
+  int NumKernels() const override;   // a flipped comparison counts the kernels it shares with its base (scalar_compare.go:73-99)
   // funcImpl.Kernels() (functions.go:220-226): live pointers — the in-place swap route
   std::vector<exec::ScalarKernel*> Kernels();
   Status DispatchExact(const std::vector<const DataType*>& types, const exec::ScalarKernel** out) const;  // :199-218

@@ -60,6 +60,38 @@ AHC_EXPORT int ahc_function_num_kernels(const char* name) {
   return f ? f->NumKernels() : -1;
 }
 
+// fn.DispatchBest(types...) (ScalarFunction; functions.go:199-218 + arithmeticFunction / compareFunction.DispatchBest) or DispatchExact
+// (VectorFunction) WITHOUT executing anything: the argument types the chosen kernel takes go to out_type_ids (the implicit casts the
+// executor would insert are type_ids → out_type_ids).  The registry is process-global and needs no device: the reference's
+// CheckDispatchBest tables run through this on a machine without a GPU.  Error text into err (NUL-terminated, cap bytes).
+AHC_EXPORT int ahc_dispatch_best(const char* function, int nargs, const int* type_ids, int* out_type_ids, char* err, int64_t cap) {
+  auto fail = [&](const Status& st) { if (err && cap > 0) snprintf(err, (size_t)cap, "%s", st.ToString().c_str()); return (int)st.code; };
+  if (err && cap > 0) err[0] = 0;
+  auto* f = compute::GetFunctionRegistry()->GetFunction(function ? function : "");
+  if (!f) return fail(Status::Make(StatusCode::KeyError, std::string("function '") + (function ? function : "") + "' not found"));
+  Status ar = f->CheckArity((size_t)(nargs < 0 ? 0 : nargs));
+  if (!ar.ok()) return fail(ar);
+  std::vector<const DataType*> types;
+  for (int i = 0; i < nargs; i++) {
+    const DataType* t = GetDataType((Type)type_ids[i]);
+    if (!t) return fail(Status::Make(StatusCode::Invalid, "unknown type id " + std::to_string(type_ids[i])));
+    types.push_back(t);
+  }
+  Status st;
+  if (f->Kind() == compute::FuncKind::Scalar) {
+    const exec::ScalarKernel* k = nullptr;
+    st = static_cast<compute::ScalarFunction*>(f)->DispatchBest(&types, &k);
+  } else if (f->Kind() == compute::FuncKind::Vector) {
+    const exec::VectorKernel* k = nullptr;
+    st = static_cast<compute::VectorFunction*>(f)->DispatchExact(types, &k);
+  } else {
+    st = Status::Make(StatusCode::NotImplemented, "meta functions dispatch when they execute");
+  }
+  if (!st.ok()) return fail(st);
+  for (int i = 0; i < nargs; i++) out_type_ids[i] = (int)types[i]->id;
+  return 0;
+}
+
 static const DataType* TypeFromFormat(const char* f) {
   if (f && f[0] == 't') return TemporalStorage(f);  // timestamps, dates, times, durations: integers with a label
   if (!f || !f[0] || f[1]) return nullptr;

@@ -443,7 +443,32 @@ const DataType* CommonNumeric(const std::vector<const DataType*>& types) {
   return GetDataType(Type::INT8);
 }
 
+int ScalarFunction::NumKernels() const {
+  if (!flipped_of.empty() && kernels_.empty())
+    if (auto* base = GetFunctionRegistry()->GetFunction(flipped_of)) return base->NumKernels();
+  return (int)kernels_.size();
+}
+
 Status ScalarFunction::DispatchBest(std::vector<const DataType*>* types, const exec::ScalarKernel** out) const {
+  if (!flipped_of.empty() && types->size() == 2) {
+    // "less" / "less_equal" hold the kernels of "greater" / "greater_equal" with the arguments exchanged (makeFlippedCompare,
+    // scalar_compare.go:73-99, 134-135): what the reference's DispatchBest reports for (l, r) is what the base reports for (r, l)
+    auto* base = dynamic_cast<const ScalarFunction*>(GetFunctionRegistry()->GetFunction(flipped_of));
+    if (!base) return Status::Make(StatusCode::KeyError, "function '" + flipped_of + "' not found");
+    std::vector<const DataType*> sw = {(*types)[1], (*types)[0]};
+    Status fs = base->DispatchBest(&sw, out);
+    if (!fs.ok()) {   // under this function's name, the arguments in the caller's order
+      std::string m = fs.msg;
+      const std::string from = "function '" + flipped_of + "'";
+      const size_t at = m.find(from);
+      if (at != std::string::npos) m.replace(at, from.size(), "function '" + name_ + "'");
+      return fs.code == StatusCode::NotImplemented ? Status::Make(StatusCode::NotImplemented, "function '" + name_ + "' has no kernel matching input types " + TypesToString(*types))
+                                                   : Status::Make(fs.code, m);
+    }
+    (*types)[0] = sw[1];
+    (*types)[1] = sw[0];
+    return fs;
+  }
   Status st = DispatchExact(*types, out);
   if (!st.ok() && promote_to_float && types->size() == 1 && IsInteger((*types)[0]->id)) {
     std::vector<const DataType*> promoted{GetDataType(Type::FLOAT64)};
@@ -1057,7 +1082,7 @@ const std::map<std::string, TemporalRule>& TemporalRules() {
       {"equal", TemporalRule::Same}, {"not_equal", TemporalRule::Same}, {"greater", TemporalRule::Same}, {"greater_equal", TemporalRule::Same},
       {"less", TemporalRule::Same}, {"less_equal", TemporalRule::Same}, {"is_in", TemporalRule::Same},
       {"add", TemporalRule::Add}, {"add_unchecked", TemporalRule::Add},
-      {"subtract", TemporalRule::Sub}, {"subtract_unchecked", TemporalRule::Sub},
+      {"subtract", TemporalRule::Sub}, {"subtract_unchecked", TemporalRule::Sub}, {"sub", TemporalRule::Sub}, {"sub_unchecked", TemporalRule::Sub},
       {"cast", TemporalRule::Cast}};
   return r;
 }

@@ -86,7 +86,7 @@ static Status ExecuteUnfused(ExecCtx* ctx, const Expression& e, const ExecBatch&
 
 static const std::map<std::string, int>& FusibleOps() {
   static const std::map<std::string, int> m = {
-      {"add", AH_X_ADD_CHECKED}, {"add_unchecked", AH_X_ADD}, {"subtract", AH_X_SUB_CHECKED}, {"subtract_unchecked", AH_X_SUB},
+      {"add", AH_X_ADD_CHECKED}, {"add_unchecked", AH_X_ADD}, {"subtract", AH_X_SUB_CHECKED}, {"subtract_unchecked", AH_X_SUB}, {"sub", AH_X_SUB_CHECKED}, {"sub_unchecked", AH_X_SUB},
       {"multiply", AH_X_MUL_CHECKED}, {"multiply_unchecked", AH_X_MUL}, {"negate_unchecked", AH_X_NEGATE},
       {"abs_unchecked", AH_X_ABS}, {"sign", AH_X_SIGN}, {"equal", AH_X_EQ}, {"not_equal", AH_X_NE}, {"greater", AH_X_GT},
       {"greater_equal", AH_X_GE}, {"less", AH_X_LT}, {"less_equal", AH_X_LE}, {"and", AH_X_AND}, {"or", AH_X_OR},

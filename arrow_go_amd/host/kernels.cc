@@ -140,6 +140,9 @@ void RegisterScalarArithmetic(FunctionRegistry* reg) {
   reg->AddFunction(MakeArith("add_unchecked", AH_OP_ADD, false), false);
   reg->AddFunction(MakeArith("subtract", AH_OP_SUB_CHECKED, true), false);
   reg->AddFunction(MakeArith("subtract_unchecked", AH_OP_SUB, false), false);
+  // … and under the names compute.Subtract itself calls: impl(ctx, "sub", …) + "_unchecked" with NoCheckOverflow (arithmetic.go:679-682, 1115-1117)
+  reg->AddFunction(MakeArith("sub", AH_OP_SUB_CHECKED, true), false);
+  reg->AddFunction(MakeArith("sub_unchecked", AH_OP_SUB, false), false);
   reg->AddFunction(MakeArith("multiply", AH_OP_MUL_CHECKED, true), false);
   reg->AddFunction(MakeArith("multiply_unchecked", AH_OP_MUL, false), false);
   // the pure-Go rest of the registry that is exact (arithmetic.go:784-785, 822-840, 855-856, 944-995)

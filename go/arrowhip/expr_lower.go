@@ -47,7 +47,7 @@ type ExprTree struct {
 // exprOps: the functions the generated kernel covers (csrc/ah_expr.hip) — anything else makes LowerExpr refuse and the caller
 // evaluates the tree node by node through CallFunction, which gives the same bytes.
 var exprOps = map[string]int32{
-	"add": C.AH_X_ADD_CHECKED, "add_unchecked": C.AH_X_ADD, "subtract": C.AH_X_SUB_CHECKED, "subtract_unchecked": C.AH_X_SUB,
+	"add": C.AH_X_ADD_CHECKED, "add_unchecked": C.AH_X_ADD, "subtract": C.AH_X_SUB_CHECKED, "subtract_unchecked": C.AH_X_SUB, "sub": C.AH_X_SUB_CHECKED, "sub_unchecked": C.AH_X_SUB,
 	"multiply": C.AH_X_MUL_CHECKED, "multiply_unchecked": C.AH_X_MUL, "negate_unchecked": C.AH_X_NEGATE, "abs_unchecked": C.AH_X_ABS,
 	"sign": C.AH_X_SIGN, "equal": C.AH_X_EQ, "not_equal": C.AH_X_NE, "greater": C.AH_X_GT, "greater_equal": C.AH_X_GE,
 	"less": C.AH_X_LT, "less_equal": C.AH_X_LE, "and": C.AH_X_AND, "or": C.AH_X_OR, "xor": C.AH_X_XOR, "and_not": C.AH_X_AND_NOT,

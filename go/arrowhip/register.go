@@ -671,12 +671,14 @@ func SwapInPlace(x *Context) (restore func(), err error) {
 			}
 		}
 	}
-	for name, op := range map[string]int8{"add_unchecked": opAdd, "subtract_unchecked": opSub, "multiply_unchecked": opMul} {
+	// (compute.Subtract itself calls "sub" / "sub_unchecked", arithmetic.go:1115-1117; "subtract*" are the same kernels under the
+	// names the expression layer and Arrow C++ use, arithmetic.go:679-682 — both pairs are swapped)
+	for name, op := range map[string]int8{"add_unchecked": opAdd, "subtract_unchecked": opSub, "sub_unchecked": opSub, "multiply_unchecked": opMul} {
 		op := op
 		swapScalar(name, func(dt arrow.DataType) exec.ArrayKernelExec { return binaryExec(x, dt.ID(), width(dt), op) })
 	}
 	// "add" / "subtract" / "multiply" — what compute.Add / Subtract / Multiply call unless NoCheckOverflow is set (arithmetic.go:1095-1105)
-	for name, op := range map[string]int8{"add": opAdd, "subtract": opSub, "multiply": opMul} {
+	for name, op := range map[string]int8{"add": opAdd, "subtract": opSub, "sub": opSub, "multiply": opMul} {
 		op := op
 		swapScalar(name, func(dt arrow.DataType) exec.ArrayKernelExec { return checkedExec(x, dt.ID(), width(dt), op) })
 	}

@@ -107,6 +107,11 @@ const char* ahc_last_error(ahc_session* s); /* never NULL; owned by the session 
 int ahc_num_functions(void);
 int ahc_has_function(const char* name);
 int ahc_function_num_kernels(const char* name);
+/* fn.DispatchBest(types...) of a scalar function (functions.go:199-218; arithmeticFunction / compareFunction.DispatchBest:
+ * arithmetic.go:112-142, scalar_compare.go:37-63) or DispatchExact of a vector function, without executing: out_type_ids receives
+ * the argument types of the chosen kernel (type ids as in ahc_datum_type_id), i.e. the implicit casts the executor would insert.
+ * Needs no session and no GPU.  Error text into err. */
+int ahc_dispatch_best(const char* function, int nargs, const int* type_ids, int* out_type_ids, char* err, int64_t cap);
 /* AddAlias / AddFunction(allowOverwrite) on the session's child registry (registry.go:69-73, 97-135) */
 int ahc_registry_add_alias(ahc_session* s, const char* alias, const char* existing, int allow_overwrite);
 

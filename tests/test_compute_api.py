@@ -123,6 +123,19 @@ def test_dispatch_errors(sess):
 
 
 @pytest.mark.gpu
+def test_sub_is_the_name_compute_subtract_calls(sess):
+    """compute.Subtract → impl(ctx, "sub", …), "sub_unchecked" with NoCheckOverflow (arithmetic.go:679-682, 1115-1117): the same kernels as
+    "subtract" / "subtract_unchecked", overflow rule included"""
+    from arrow_go_amd import compute as ac
+    a, b = pa.array([5, None, -7, 2**31 - 1], pa.int32()), pa.array([7, 1, None, 1], pa.int32())
+    assert sess.call_function("sub", [a, b]).to_pylist() == sess.call_function("subtract", [a, b]).to_pylist() == [-2, None, None, 2**31 - 2]
+    lo = pa.array([-2**31, 3], pa.int32())
+    assert sess.call_function("sub_unchecked", [lo, pa.array([1, 1], pa.int32())]).to_pylist() == [2**31 - 1, 2]      # wraps
+    with pytest.raises(ac.ErrInvalid, match="overflow"):
+        sess.call_function("sub", [lo, pa.array([1, 1], pa.int32())])
+
+
+@pytest.mark.gpu
 def test_child_registry_alias(sess):
     # registry.go:69-73 NewChildRegistry + AddFunction(allowOverwrite)
     from arrow_go_amd import compute as ac

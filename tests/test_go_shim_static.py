@@ -42,7 +42,9 @@ def test_checked_arithmetic_is_wired(chk):
     callers = {c.func for c in chk.calls if c.cname == "ah_arithmetic_checked"}
     assert callers == {"Context.ArithmeticChecked"}
     src = open(os.path.join(G.GO_DIR, "register.go")).read()
-    assert re.search(r'"add": opAdd, "subtract": opSub, "multiply": opMul', src)
+    # … "sub" too: compute.Subtract itself calls impl(ctx, "sub", …) (+ "_unchecked" with NoCheckOverflow), arithmetic.go:679-682, 1115-1117
+    assert re.search(r'"add": opAdd, "subtract": opSub, "sub": opSub, "multiply": opMul', src)
+    assert re.search(r'"add_unchecked": opAdd, "subtract_unchecked": opSub, "sub_unchecked": opSub, "multiply_unchecked": opMul', src)
     assert re.search(r'"add_hip": opAdd, "subtract_hip": opSub, "multiply_hip": opMul', src)
     assert "checkedExec(x, dt.ID(), width(dt), op)" in src
     # AH_EOVERFLOW → arrow.ErrInvalid (the reference's errOverflow is fmt.Errorf("%w: overflow", arrow.ErrInvalid))
