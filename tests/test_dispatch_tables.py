@@ -92,3 +92,21 @@ def test_registry_holds_the_reference_names_of_the_path():
     # an alias pair is ONE set of kernels under two names
     for a, b in (("sub", "subtract"), ("sub_unchecked", "subtract_unchecked")):
         assert ac.lib.ahc_function_num_kernels(a.encode()) == ac.lib.ahc_function_num_kernels(b.encode()) > 0
+
+
+def test_can_cast_numeric_and_boolean():
+    """compute.CanCast(from, to) = "the target's cast function has a kernel for from's id" (cast.go:947-959); the rows of TestCanCast
+    (cast_test.go:334-375) over the types this layer casts: every numeric type and Boolean to every numeric type and Boolean.  The
+    per-target functions carry the reference's names (cast.go:788, 838-880: cast_boolean, cast_int8 … cast_float, cast_double); a cast to
+    the SAME type never reaches them (the `cast` meta function returns its input when the types are equal, cast.go:52-54, here too)."""
+    nums = [I8, U8, I16, U16, I32, U32, I64, U64, F32, F64]
+    fn = {pa.bool_(): "cast_boolean", F32: "cast_float", F64: "cast_double"}
+    for to in nums + [pa.bool_()]:
+        name = fn.get(to, f"cast_{to}")
+        assert ac.lib.ahc_has_function(name.encode()), name
+        for frm in nums + [pa.bool_()]:
+            if frm == to:
+                continue
+            assert ac.dispatch_best(name, [frm]) == [frm], (frm, to)
+    for wrong in ("cast_float32", "cast_float64", "cast_bool"):
+        assert not ac.lib.ahc_has_function(wrong.encode())
