@@ -683,9 +683,20 @@ func SwapInPlace(x *Context) (restore func(), err error) {
 		swapScalar(name, func(dt arrow.DataType) exec.ArrayKernelExec { return checkedExec(x, dt.ID(), width(dt), op) })
 	}
 	for name, c := range map[string]int{"equal": cmpEQ, "not_equal": cmpNE, "greater": cmpGT, "greater_equal": cmpGE} {
-		c := c // "less" / "less_equal" are registered with flipped kernels of these (scalar_compare.go:73-99): swapped for free
+		c := c
 		swapScalar(name, func(dt arrow.DataType) exec.ArrayKernelExec { return compareExec(x, dt.ID(), width(dt), c, false) })
 	}
+	// "less" / "less_equal" do NOT follow for free: makeFlippedCompare (scalar_compare.go:84-99) copies each kernel of "greater" /
+	// "greater_equal" and captures its ExecFn VALUE in the copy's data (unflippedExec) when the registry is built, so replacing
+	// greater's ExecFn afterwards leaves the flipped copies on the CPU loop.  Their own ExecFn (flippedCompare) is replaced here by
+	// the same comparison with the operands exchanged.
+	for name, c := range map[string]int{"less": cmpGT, "less_equal": cmpGE} {
+		c := c
+		swapScalar(name, func(dt arrow.DataType) exec.ArrayKernelExec { return compareExec(x, dt.ID(), width(dt), c, true) })
+	}
+	// The stock selection functions hold ONE kernel for every fixed-width primitive type (exec.Primitive(), vector_selection.go:2340-2360):
+	// the wrapper decides per call — integers and float32 / float64 of 1, 2, 4 or 8 bytes go to the HIP kernel of that width, everything
+	// else the matcher admits (booleans, float16, temporal and interval types) stays where it was.
 	swapVector := func(name string, second arrow.DataType, mk func(w int) exec.ArrayKernelExec) {
 		fn, ok := reg.GetFunction(name)
 		if !ok {
@@ -696,20 +707,28 @@ func SwapInPlace(x *Context) (restore func(), err error) {
 			return
 		}
 		for _, k := range ks.Kernels() {
-			for _, dt := range numeric { // the stock selection kernels match "any fixed width of w bytes": swap them for numeric inputs only
+			matches := false
+			for _, dt := range numeric {
 				if k.Signature.MatchesInputs([]arrow.DataType{dt, second}) {
-					k, old, w := k, k.ExecFn, width(dt)
-					hip := mk(w)
-					k.ExecFn = func(ctx *exec.KernelCtx, b *exec.ExecSpan, o *exec.ExecResult) error {
-						if arrow.IsNumeric(b.Values[0].Array.Type.ID()) && width(b.Values[0].Array.Type) == w { // the matcher is wider than our kernel
-							return hip(ctx, b, o)
-						}
-						return old(ctx, b, o)
-					}
-					undo = append(undo, func() { k.ExecFn = old })
+					matches = true
 					break
 				}
 			}
+			if !matches {
+				continue
+			}
+			k, old := k, k.ExecFn
+			hip := map[int]exec.ArrayKernelExec{1: mk(1), 2: mk(2), 4: mk(4), 8: mk(8)}
+			k.ExecFn = func(ctx *exec.KernelCtx, b *exec.ExecSpan, o *exec.ExecResult) error {
+				t := b.Values[0].Array.Type
+				if id := t.ID(); arrow.IsInteger(id) || id == arrow.FLOAT32 || id == arrow.FLOAT64 {
+					if h, ok := hip[width(t)]; ok {
+						return h(ctx, b, o)
+					}
+				}
+				return old(ctx, b, o)
+			}
+			undo = append(undo, func() { k.ExecFn = old })
 		}
 	}
 	swapVector("array_filter", arrow.FixedWidthTypes.Boolean, func(w int) exec.ArrayKernelExec { return filterExec(x, w) })

@@ -15,6 +15,7 @@ shipped with a type declared twice).  It is not a Go compiler.  It checks what a
 Arguments whose type cannot be derived are reported as `unverified` (with the expression), never silently passed."""
 from __future__ import annotations
 
+import json
 import os
 import re
 import subprocess
@@ -23,6 +24,7 @@ from dataclasses import dataclass, field
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GO_DIR = os.path.join(ROOT, "go", "arrowhip")
 HEADER = os.path.join(ROOT, "include", "arrowhip.h")
+GO_EXPORTS = os.path.join(ROOT, "tests", "golden", "go_reference_exports.json")
 
 # ---------------------------------------------------------------------------------------------------------------- C header
 
@@ -163,6 +165,8 @@ class Func:
     body: list
     file: str
     line: int
+    nparams: int = 0           # parameters as written (unnamed ones included)
+    variadic: bool = False
 
 
 @dataclass
@@ -367,7 +371,8 @@ def _scan_func(pkg, fname, raw, i):
         k = _match(raw, j)
         body = raw[j + 1:k]
         j = k + 1
-    pkg.funcs.append(Func(name, recv_name, recv_type, {nm: ty for nm, ty in params if nm}, results, named, body, fname, line))
+    pkg.funcs.append(Func(name, recv_name, recv_type, {nm: ty for nm, ty in params if nm}, results, named, body, fname, line,
+                          len(params), bool(params) and (params[-1][1] or "").startswith("...")))
     pkg.decls.append(("method" if recv_type else "func", f"{recv_type}.{name}" if recv_type else name, fname, line))
     return j
 
@@ -512,6 +517,8 @@ class Checker:
     def __init__(self, pkg: Package, protos, consts):
         self.pkg, self.protos, self.consts = pkg, protos, consts
         self.errors = list(pkg.errors)
+        self.ext = json.load(open(GO_EXPORTS)) if os.path.exists(GO_EXPORTS) else {}   # exported names of the imported arrow-go packages
+        self.ext_checked = 0      # pkg.Name uses and members of external types that were looked up
         self.calls = []
         self.methods = {}
         self.func_results = {}
@@ -535,6 +542,14 @@ class Checker:
     def _locals(self, body, env):
         n = len(body)
         for i, t in enumerate(body):
+            if t.kind == "ident" and t.text == "func" and i + 1 < n and body[i + 1].kind == "op" and body[i + 1].text == "(":
+                # a function literal: its parameters are names of the enclosing body too (flat scoping: the ExecFn closures of
+                # register.go — `return func(ctx *exec.KernelCtx, batch *exec.ExecSpan, out *exec.ExecResult) error { … }`)
+                close = _match(body, i + 1)
+                for nm, ty in _parse_param_list(body[i + 2:close]):
+                    if nm and nm != "_" and ty:
+                        env.setdefault(nm, ty)
+                continue
             if t.kind == "ident" and t.text == "var" and i + 1 < n and body[i + 1].kind == "ident":
                 j = i + 1
                 names = []
@@ -710,7 +725,69 @@ class Checker:
             self._check_selectors(f, env, body)
         for fname, toks in self.pkg.files.items():      # every C.AH_* of the file, package-level initialisers included
             self._check_c_names(fname, toks)
+            self._check_ext_symbols(fname, toks)
         return self
+
+    # -- the arrow-go packages the shim imports: every pkg.Name must be exported by that package, every member selected on a value of
+    #    one of its types must be a field or a method of that type (tests/golden/go_reference_exports.json, written by
+    #    scripts/gen_go_exports.py from the reference's sources)
+    def _ext_type(self, path, name):
+        info = self.ext.get(path, {}).get("types", {}).get(name)
+        seen = 0
+        while info is not None and not info["fields"] and not info["methods"] and info.get("underlying") and seen < 4:
+            u = info["underlying"]
+            if "." in u:
+                return None
+            info = self.ext.get(path, {}).get("types", {}).get(u)
+            seen += 1
+        return info
+
+    def _ext_members(self, path, name, depth=0):
+        """(fields {name: type}, methods set, open) — open: an embedded type could not be resolved, so absence proves nothing"""
+        info = self._ext_type(path, name)
+        if info is None or depth > 6:
+            return {}, set(), True
+        fields, methods, is_open = dict(info["fields"]), set(info["methods"]), False
+        for e in info.get("embeds", []):
+            f2, m2, o2 = self._ext_members(path, e, depth + 1)
+            for k, v in f2.items():
+                fields.setdefault(k, v)
+            methods |= m2
+            is_open = is_open or o2
+        return fields, methods, is_open
+
+    def _check_ext_symbols(self, fname, toks):
+        imports = {loc: pth for loc, (pth, _) in self.pkg.imports.get(fname, {}).items() if pth in self.ext}
+        for i in range(len(toks) - 2):
+            t = toks[i]
+            if t.kind != "ident" or t.text not in imports or (i > 0 and toks[i - 1].kind == "op" and toks[i - 1].text == "."):
+                continue
+            if not (toks[i + 1].kind == "op" and toks[i + 1].text == "." and toks[i + 2].kind == "ident"):
+                continue
+            self.ext_checked += 1
+            if toks[i + 2].text not in self.ext[imports[t.text]]["symbols"]:
+                self.errors.append(f"{fname}:{toks[i + 2].line}: {t.text}.{toks[i + 2].text} is not exported by {imports[t.text]}")
+                continue
+            self._check_ext_arity(fname, toks, i + 2, imports[t.text], toks[i + 2].text, f"{t.text}.{toks[i + 2].text}")
+
+    def _check_ext_arity(self, fname, toks, at, path, key, shown):
+        """toks[at] names a function / method of an imported package; if a call follows, its argument count must fit the declaration"""
+        shape = self.ext.get(path, {}).get("funcs", {}).get(key)
+        k = at + 1
+        if k < len(toks) and toks[k].kind == "op" and toks[k].text == "[":     # explicit type arguments
+            k = _match(toks, k) + 1
+        if shape is None or not (k < len(toks) and toks[k].kind == "op" and toks[k].text == "("):
+            return
+        close = _match(toks, k)
+        args = [g for g in _split_commas(toks[k + 1:close]) if g]
+        if len(args) == 1 and args[0][-1].kind == "op" and args[0][-1].text == ")" and len(args[0]) > 2:
+            return                                   # f(g()) may spread a multi-value result
+        if any(g[-1].kind == "op" and g[-1].text == "..." for g in args):
+            return                                   # f(xs...)
+        nparams, variadic = shape
+        self.ext_checked += 1
+        if (variadic and len(args) < nparams - 1) or (not variadic and len(args) != nparams):
+            self.errors.append(f"{fname}:{toks[at].line}: {shown} called with {len(args)} arguments, arrow-go declares {nparams}{' (variadic)' if variadic else ''}")
 
     def _check_c_names(self, fname, toks):
         for i in range(len(toks) - 2):
@@ -777,10 +854,14 @@ class Checker:
                 continue
             ty = env.get(t.text)
             j = i
+            ext_path = None      # set while the chain walks through types of an imported package
             while j + 2 < n and body[j + 1].kind == "op" and body[j + 1].text == "." and body[j + 2].kind == "ident":
                 base = self._strip(ty) or ""
-                if base not in self.pkg.structs:
-                    break
+                if base not in self.pkg.structs or ext_path:
+                    ext_path, ty, j, stop = self._ext_step(f, t, body, j, base, ext_path)
+                    if stop:
+                        break
+                    continue
                 nm = body[j + 2].text
                 fields = self.pkg.structs[base]
                 if nm in fields:
@@ -791,6 +872,38 @@ class Checker:
                     self.errors.append(f"{f.file}:{body[j + 2].line}: {t.text}.{nm}: type {base} has no field or method {nm}")
                     break
                 j += 2
+
+    def _ext_step(self, f, root, body, j, base, ext_path):
+        """one `.name` step on a value whose type belongs to an imported package → (package path, member type, new j, stop)"""
+        imports = {loc: pth for loc, (pth, _) in self.pkg.imports.get(f.file, {}).items() if pth in self.ext}
+        base = re.sub(r"^(\[\d*\]|\*)+", "", base)
+        if "." in base:
+            loc, name = base.split(".", 1)
+            path = imports.get(loc)
+            if path is None and ext_path:      # a type of a third package named from inside the external one (scalar.Scalar from exec)
+                path = next((p for p in self.ext if p.rsplit("/", 1)[-1] == loc), None)
+        else:
+            path, name = ext_path, base
+        name = name.split("[")[0]
+        if path is None or self._ext_type(path, name) is None:
+            return None, None, j, True
+        fields, methods, is_open = self._ext_members(path, name)
+        nm = body[j + 2].text
+        self.ext_checked += 1
+        if nm in fields:
+            ty = fields[nm]
+            j += 2
+            # an index right behind a slice / array field: its element
+            if j + 1 < len(body) and body[j + 1].kind == "op" and body[j + 1].text == "[" and re.match(r"\[\d*\]", ty or ""):
+                j = _match(body, j + 1)
+                ty = re.sub(r"^\[\d*\]", "", ty)
+            return path, ty, j, False
+        if nm in methods or is_open:
+            if nm in methods:      # declared on this type itself (not through an embedded one): the call's shape is known
+                self._check_ext_arity(f.file, body, j + 2, path, f"{name}.{nm}", f"{root.text}….{nm}")
+            return path, None, j, True
+        self.errors.append(f"{f.file}:{body[j + 2].line}: {root.text}….{nm}: type {path.rsplit('/', 1)[-1]}.{name} has no field or method {nm}")
+        return path, None, j, True
 
     # -- reports
     def bound(self):

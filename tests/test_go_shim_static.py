@@ -51,6 +51,37 @@ def test_checked_arithmetic_is_wired(chk):
     assert re.search(r"case C\.AH_EINVALID, C\.AH_EOVERFLOW:\s*return fmt\.Errorf\(\"%w: %s\", arrow\.ErrInvalid", open(os.path.join(G.GO_DIR, "arrowhip.go")).read())
 
 
+def test_arrow_go_symbols_and_members_exist(chk):
+    """every `pkg.Name` the shim writes is exported by that arrow-go package, every field / method it selects on a value of an arrow-go
+    type exists on that type (embedded types and aliases followed) — the round-4 package called arrow.IsNumeric, which arrow-go does not
+    have.  The list of exported names is a committed fixture (scripts/gen_go_exports.py reads the reference's sources); where the
+    reference is present the fixture must be current."""
+    assert chk.ext, "tests/golden/go_reference_exports.json is missing"
+    assert chk.ext_checked >= 250
+    if os.path.isdir("/root/reference/arrow"):
+        import subprocess, sys
+        assert subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_go_exports.py"), "--check"]).returncode == 0, \
+            "regenerate: python scripts/gen_go_exports.py"
+
+
+def test_vector_swap_dispatches_on_the_runtime_width():
+    """array_take / array_filter hold ONE kernel for all fixed-width primitives (exec.Primitive(), vector_selection.go:2340-2360): the
+    wrapper must pick the HIP kernel by the width of the column it is handed, not by the first type that matched the signature"""
+    src = open(os.path.join(G.GO_DIR, "register.go")).read()
+    assert "hip := map[int]exec.ArrayKernelExec{1: mk(1), 2: mk(2), 4: mk(4), 8: mk(8)}" in src
+    assert "hip[width(t)]" in src
+
+
+def test_flipped_comparisons_are_swapped_themselves():
+    """makeFlippedCompare (scalar_compare.go:84-99) copies greater's kernels and captures their ExecFn VALUE (flippedData.unflippedExec)
+    when the registry is built: swapping "greater" in place does not reach "less" / "less_equal" — SwapInPlace must replace their ExecFn
+    too (the same comparison, operands exchanged)"""
+    src = open(os.path.join(G.GO_DIR, "register.go")).read()
+    assert re.search(r'map\[string\]int\{"less": cmpGT, "less_equal": cmpGE\}', src)
+    assert "compareExec(x, dt.ID(), width(dt), c, true)" in src
+    assert "swapped for free" not in src
+
+
 def test_math_shaped_like_arrow_math(chk):
     """arrow/math/float64.go:25-39: Float64Funcs.Sum(*array.Float64) float64 — same shape on the GPU context"""
     sigs = {(f.recv_type, f.name): (f.params, f.results) for f in chk.pkg.funcs}
@@ -86,6 +117,15 @@ MUTATIONS = [
     ("unknown field", "comm.go", "C.ah_comm_destroy(c.m)", "C.ah_comm_destroy(c.comm)", r"type Comm has no field or method comm"),
     ("unknown method", "register.go", "g, err := x.NewIngest(0, 0)", "g, err := x.MakeIngest(0, 0)", r"type Context has no field or method MakeIngest"),
     ("build tag lost", "graph.go", "//go:build hip\n", "", r"no '//go:build hip' line"),
+    # against the arrow-go packages the shim imports (tests/golden/go_reference_exports.json)
+    ("symbol arrow-go does not export", "register.go", "arrow.IsInteger(id)", "arrow.IsNumeric(id)", r"arrow\.IsNumeric is not exported by github.com/apache/arrow-go/v18/arrow"),
+    ("member an arrow-go type does not have", "register.go", "out.Buffers[1].WrapBuffer(data)", "out.Buffers[1].Wrap(data)", r"type exec\.BufferSpan has no field or method Wrap"),
+    ("field of an arrow-go struct misspelt", "register.go", "values, indices := &batch.Values[0].Array, &batch.Values[1].Array", "values, indices := &batch.Values[0].Arr, &batch.Values[1].Array", r"type exec\.ExecValue has no field or method Arr"),
+    ("arrow-go function called with the wrong number of arguments", "register.go", "compute.NewChildRegistry(compute.GetFunctionRegistry())", "compute.NewChildRegistry(compute.GetFunctionRegistry(), nil)",
+     r"compute\.NewChildRegistry called with 2 arguments, arrow-go declares 1"),
+    ("arrow-go method called with the wrong number of arguments", "register.go", "out.Buffers[1].WrapBuffer(data)", "out.Buffers[1].WrapBuffer(data, true)",
+     r"WrapBuffer called with 2 arguments, arrow-go declares 1"),
+    ("method of an embedded arrow-go type misspelt", "math.go", "a.Len()", "a.Length()", r"type array\.Float64 has no field or method Length"),
 ]
 
 
