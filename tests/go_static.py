@@ -723,6 +723,7 @@ class Checker:
             env, body = self._env(f)
             self._check_c_calls(f, env, body)
             self._check_selectors(f, env, body)
+            self._check_unused_locals(f, body)
         for fname, toks in self.pkg.files.items():      # every C.AH_* of the file, package-level initialisers included
             self._check_c_names(fname, toks)
             self._check_ext_symbols(fname, toks)
@@ -872,6 +873,32 @@ class Checker:
                     self.errors.append(f"{f.file}:{body[j + 2].line}: {t.text}.{nm}: type {base} has no field or method {nm}")
                     break
                 j += 2
+
+    _GO_KEYWORDS = {"if", "for", "switch", "select", "case", "go", "defer", "return", "else", "range", "var", "func"}
+
+    def _check_unused_locals(self, f, body):
+        """`declared and not used` is a compile error in Go: a local introduced by := or var must occur again somewhere in the function
+        (flat scoping: a name declared in two scopes and used in one of them is not seen)"""
+        n, decl = len(body), {}
+        for i, t in enumerate(body):
+            if t.kind == "op" and t.text == ":=":
+                k = i - 1
+                while k >= 0 and body[k].line == t.line and (body[k].kind == "ident" or (body[k].kind == "op" and body[k].text == ",")):
+                    if body[k].kind == "ident" and body[k].text != "_" and body[k].text not in self._GO_KEYWORDS:
+                        decl.setdefault(body[k].text, []).append(body[k].line)
+                    k -= 1
+            elif t.kind == "ident" and t.text == "var" and i + 1 < n and body[i + 1].kind == "ident":
+                j = i + 1
+                while True:
+                    if body[j].text != "_":
+                        decl.setdefault(body[j].text, []).append(body[j].line)
+                    if j + 2 < n and body[j + 1].kind == "op" and body[j + 1].text == "," and body[j + 2].kind == "ident":
+                        j += 2
+                    else:
+                        break
+        for name, lines in decl.items():
+            if sum(1 for t in body if t.kind == "ident" and t.text == name) <= len(lines):
+                self.errors.append(f"{f.file}:{lines[0]}: {name} declared and not used (in {f.name})")
 
     def _ext_step(self, f, root, body, j, base, ext_path):
         """one `.name` step on a value whose type belongs to an imported package → (package path, member type, new j, stop)"""
