@@ -757,7 +757,18 @@ class Checker:
             is_open = is_open or o2
         return fields, methods, is_open
 
+    _WELL_KNOWN_PACKAGES = {"fmt", "errors", "unsafe", "runtime", "sync", "math", "sort", "strings", "context", "os", "reflect", "time", "bytes", "atomic",
+                            "arrow", "compute", "exec", "scalar", "bitutil", "array", "memory"}
+
     def _check_ext_symbols(self, fname, toks):
+        # a package used but not imported by THIS file ("undefined: fmt"): imports are per file in Go
+        have = set(self.pkg.imports.get(fname, {}))
+        for i in range(len(toks) - 1):
+            t = toks[i]
+            if (t.kind == "ident" and t.text in self._WELL_KNOWN_PACKAGES and t.text not in have and toks[i + 1].kind == "op" and toks[i + 1].text == "."
+                    and not (i > 0 and toks[i - 1].kind == "op" and toks[i - 1].text == ".")):
+                self.errors.append(f"{fname}:{t.line}: undefined: {t.text} (used but not imported by this file)")
+                have.add(t.text)
         imports = {loc: pth for loc, (pth, _) in self.pkg.imports.get(fname, {}).items() if pth in self.ext}
         for i in range(len(toks) - 2):
             t = toks[i]

@@ -117,6 +117,7 @@ MUTATIONS = [
     ("unknown field", "comm.go", "C.ah_comm_destroy(c.m)", "C.ah_comm_destroy(c.comm)", r"type Comm has no field or method comm"),
     ("unknown method", "register.go", "g, err := x.NewIngest(0, 0)", "g, err := x.MakeIngest(0, 0)", r"type Context has no field or method MakeIngest"),
     ("build tag lost", "graph.go", "//go:build hip\n", "", r"no '//go:build hip' line"),
+    ("package used but not imported", "comm.go", '\t"fmt"\n', "", r"undefined: fmt"),
     ("local declared and not used", "math.go", "func NewMath(", "func unusedLocal() int {\n\tleft, right := 1, 2\n\treturn left\n}\n\nfunc NewMath(", r"right declared and not used"),
     # against the arrow-go packages the shim imports (tests/golden/go_reference_exports.json)
     ("symbol arrow-go does not export", "register.go", "arrow.IsInteger(id)", "arrow.IsNumeric(id)", r"arrow\.IsNumeric is not exported by github.com/apache/arrow-go/v18/arrow"),
