@@ -519,6 +519,7 @@ class Checker:
         self.errors = list(pkg.errors)
         self.ext = json.load(open(GO_EXPORTS)) if os.path.exists(GO_EXPORTS) else {}   # exported names of the imported arrow-go packages
         self.ext_checked = 0      # pkg.Name uses and members of external types that were looked up
+        self.local_calls_checked = 0
         self.calls = []
         self.methods = {}
         self.func_results = {}
@@ -724,6 +725,7 @@ class Checker:
             self._check_c_calls(f, env, body)
             self._check_selectors(f, env, body)
             self._check_unused_locals(f, body)
+            self._check_local_calls(f, env, body)
         for fname, toks in self.pkg.files.items():      # every C.AH_* of the file, package-level initialisers included
             self._check_c_names(fname, toks)
             self._check_ext_symbols(fname, toks)
@@ -879,11 +881,39 @@ class Checker:
                 if nm in fields:
                     ty = fields[nm]
                 elif nm in self.methods.get(base, {}):
+                    self._check_local_arity(f.file, body, j + 2, self.methods[base][nm], f"{base}.{nm}")
                     break
                 else:
                     self.errors.append(f"{f.file}:{body[j + 2].line}: {t.text}.{nm}: type {base} has no field or method {nm}")
                     break
                 j += 2
+
+    def _check_local_arity(self, fname, toks, at, decl, shown):
+        """toks[at] names a function / method of THIS package; a call's argument count must fit its declaration"""
+        k = at + 1
+        if not (k < len(toks) and toks[k].kind == "op" and toks[k].text == "("):
+            return
+        close = _match(toks, k)
+        args = [g for g in _split_commas(toks[k + 1:close]) if g]
+        if len(args) == 1 and args[0][-1].kind == "op" and args[0][-1].text == ")" and len(args[0]) > 2:
+            return                                   # f(g()) may spread a multi-value result
+        if any(g[-1].kind == "op" and g[-1].text == "..." for g in args):
+            return
+        self.local_calls_checked += 1
+        if (decl.variadic and len(args) < decl.nparams - 1) or (not decl.variadic and len(args) != decl.nparams):
+            self.errors.append(f"{fname}:{toks[at].line}: {shown} called with {len(args)} arguments, declared with {decl.nparams}{' (variadic)' if decl.variadic else ''}")
+
+    def _check_local_calls(self, f, env, body):
+        """name(…) where name is a package-level function of this package (and not shadowed by a local)"""
+        pkg_funcs = {g.name: g for g in self.pkg.funcs if not g.recv_type}
+        for i, t in enumerate(body):
+            if t.kind != "ident" or t.text not in pkg_funcs or t.text in env:
+                continue
+            if i > 0 and body[i - 1].kind == "op" and body[i - 1].text == ".":
+                continue
+            if i > 0 and body[i - 1].kind == "ident" and body[i - 1].text == "func":
+                continue
+            self._check_local_arity(f.file, body, i, pkg_funcs[t.text], t.text)
 
     _GO_KEYWORDS = {"if", "for", "switch", "select", "case", "go", "defer", "return", "else", "range", "var", "func"}
 

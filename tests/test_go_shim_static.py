@@ -57,7 +57,7 @@ def test_arrow_go_symbols_and_members_exist(chk):
     have.  The list of exported names is a committed fixture (scripts/gen_go_exports.py reads the reference's sources); where the
     reference is present the fixture must be current."""
     assert chk.ext, "tests/golden/go_reference_exports.json is missing"
-    assert chk.ext_checked >= 250
+    assert chk.ext_checked >= 250 and chk.local_calls_checked >= 150   # (calls of the package's own functions / methods: argument counts)
     if os.path.isdir("/root/reference/arrow"):
         import subprocess, sys
         assert subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_go_exports.py"), "--check"]).returncode == 0, \
@@ -117,6 +117,8 @@ MUTATIONS = [
     ("unknown field", "comm.go", "C.ah_comm_destroy(c.m)", "C.ah_comm_destroy(c.comm)", r"type Comm has no field or method comm"),
     ("unknown method", "register.go", "g, err := x.NewIngest(0, 0)", "g, err := x.MakeIngest(0, 0)", r"type Context has no field or method MakeIngest"),
     ("build tag lost", "graph.go", "//go:build hip\n", "", r"no '//go:build hip' line"),
+    ("own method called with an argument missing", "register.go", "return finishVector(ctx, out, values.Type, n, nulls, w, do, dvo)", "return finishVector(ctx, out, values.Type, n, nulls, w, do)",
+     r"finishVector called with 7 arguments, declared with 8"),
     ("package used but not imported", "comm.go", '\t"fmt"\n', "", r"undefined: fmt"),
     ("local declared and not used", "math.go", "func NewMath(", "func unusedLocal() int {\n\tleft, right := 1, 2\n\treturn left\n}\n\nfunc NewMath(", r"right declared and not used"),
     # against the arrow-go packages the shim imports (tests/golden/go_reference_exports.json)
