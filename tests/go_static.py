@@ -531,6 +531,7 @@ class Checker:
 
     # -- environments
     def _env(self, f: Func):
+        self._cur = f
         env = dict(self.pkg.vars)
         env.update(f.params)
         env.update(f.named_results)
@@ -575,6 +576,8 @@ class Checker:
                 k = i - 1
                 lhs = []
                 while k >= 0 and body[k].line == t.line and (body[k].kind == "ident" or (body[k].kind == "op" and body[k].text == ",")):
+                    if body[k].kind == "ident" and body[k].text in self._GO_KEYWORDS:     # `if err := …`, `for i, v := range …`
+                        break
                     if body[k].kind == "ident":
                         lhs.insert(0, body[k].text)
                     k -= 1
@@ -601,6 +604,8 @@ class Checker:
                             env[nm] = ty
                 elif len(exprs) == 1:                       # multi-value call
                     tys = self._call_results(exprs[0], env)
+                    if tys and len(tys) != len(lhs) and getattr(self, "_cur", None) is not None:
+                        self.errors.append(f"{self._cur.file}:{t.line}: assignment mismatch: {len(lhs)} variables but the call returns {len(tys)} values")
                     if tys and len(tys) == len(lhs):
                         for nm, ty in zip(lhs, tys):
                             env[nm] = ty

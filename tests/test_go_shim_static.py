@@ -119,6 +119,7 @@ MUTATIONS = [
     ("build tag lost", "graph.go", "//go:build hip\n", "", r"no '//go:build hip' line"),
     ("own method called with an argument missing", "register.go", "return finishVector(ctx, out, values.Type, n, nulls, w, do, dvo)", "return finishVector(ctx, out, values.Type, n, nulls, w, do)",
      r"finishVector called with 7 arguments, declared with 8"),
+    ("two variables for a call that returns three", "register.go", "ndict, nullID, err := x.HashU64Encode(", "ndict, err := x.HashU64Encode(", r"assignment mismatch: 2 variables but the call returns 3 values"),
     ("package used but not imported", "comm.go", '\t"fmt"\n', "", r"undefined: fmt"),
     ("local declared and not used", "math.go", "func NewMath(", "func unusedLocal() int {\n\tleft, right := 1, 2\n\treturn left\n}\n\nfunc NewMath(", r"right declared and not used"),
     # against the arrow-go packages the shim imports (tests/golden/go_reference_exports.json)
