@@ -85,12 +85,14 @@ def struct_embeds_of(src):
 def scan(rel):
     d = os.path.join(REF, rel)
     pkg = G.Package()
-    ifaces, sembeds = {}, {}
+    ifaces, sembeds, aliases = {}, {}, {}
     for fn in sorted(os.listdir(d)):
         if fn.endswith(".go") and not fn.endswith("_test.go"):
             src = open(os.path.join(d, fn)).read()
             G._scan_file(pkg, fn, G.tokenize(src))
             ifaces.update(interfaces_of(src))
+            for am in re.finditer(r"(?m)^(?:type\s+|\t)([A-Za-z_][A-Za-z_0-9]*)\s*=\s*([A-Za-z_][A-Za-z_0-9.]*)\s*$", re.sub(r"//[^\n]*", "", src)):
+                aliases[am.group(1)] = am.group(2)
             sembeds.update(struct_embeds_of(src))
     symbols = sorted({q for kind, q, _, _ in pkg.decls if "." not in q and exported(q)})
     types = {}
@@ -103,6 +105,8 @@ def scan(rel):
         types[name] = {"fields": {}, "methods": im[0] if im else [], "embeds": im[1] if im else sorted(set(sembeds.get(name, [])))}   # (generic structs land here)
         if re.fullmatch(r"[A-Za-z_][A-Za-z_0-9.]*", text.strip()):   # `type ExecResult = ArraySpan`, `type Type int`
             types[name]["underlying"] = text.strip()
+            if aliases.get(name) == text.strip():
+                types[name]["alias"] = True     # `type X = Y`: X and Y are the same type
     for f in pkg.funcs:
         if f.recv_type and exported(f.name):
             base = f.recv_type.split("[")[0]

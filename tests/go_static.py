@@ -520,6 +520,7 @@ class Checker:
         self.ext = json.load(open(GO_EXPORTS)) if os.path.exists(GO_EXPORTS) else {}   # exported names of the imported arrow-go packages
         self.ext_checked = 0      # pkg.Name uses and members of external types that were looked up
         self.local_calls_checked = 0
+        self.local_args_typed = 0
         self.calls = []
         self.methods = {}
         self.func_results = {}
@@ -886,14 +887,14 @@ class Checker:
                 if nm in fields:
                     ty = fields[nm]
                 elif nm in self.methods.get(base, {}):
-                    self._check_local_arity(f.file, body, j + 2, self.methods[base][nm], f"{base}.{nm}")
+                    self._check_local_arity(f.file, body, j + 2, self.methods[base][nm], f"{base}.{nm}", env)
                     break
                 else:
                     self.errors.append(f"{f.file}:{body[j + 2].line}: {t.text}.{nm}: type {base} has no field or method {nm}")
                     break
                 j += 2
 
-    def _check_local_arity(self, fname, toks, at, decl, shown):
+    def _check_local_arity(self, fname, toks, at, decl, shown, env=None):
         """toks[at] names a function / method of THIS package; a call's argument count must fit its declaration"""
         k = at + 1
         if not (k < len(toks) and toks[k].kind == "op" and toks[k].text == "("):
@@ -907,6 +908,47 @@ class Checker:
         self.local_calls_checked += 1
         if (decl.variadic and len(args) < decl.nparams - 1) or (not decl.variadic and len(args) != decl.nparams):
             self.errors.append(f"{fname}:{toks[at].line}: {shown} called with {len(args)} arguments, declared with {decl.nparams}{' (variadic)' if decl.variadic else ''}")
+            return
+        # argument TYPES, where both sides are known: Go converts nothing implicitly between named types (int64 → int is an error);
+        # untyped constants, nil and interface-typed parameters are left alone
+        ptypes = list(decl.params.values())
+        if env is None or decl.variadic or len(ptypes) != len(args):
+            return
+        for pos, (a, want) in enumerate(zip(args, ptypes)):
+            got = self._expr_type(a, env)
+            if got is None or want is None or got.startswith("untyped") or want in ("any", "interface{}", "error") or "func(" in want:
+                continue
+            self.local_args_typed += 1
+            if self._same_go_type(fname, got, want):
+                continue
+            self.errors.append(f"{fname}:{toks[at].line}: {shown} argument {pos + 1} `{_join(a)}` has type {got}, the parameter is {want}")
+
+    def _same_go_type(self, fname, a, b):
+        na, nb = a.replace(" ", ""), b.replace(" ", "")
+        if na == nb:
+            return True
+        imports = {loc: pth for loc, (pth, _) in self.pkg.imports.get(fname, {}).items() if pth in self.ext}
+
+        def canon(t):      # follow `type X = Y` of the imported packages (exec.ExecResult = exec.ArraySpan)
+            m = re.fullmatch(r"((?:\*|\[\d*\])*)([A-Za-z_]\w*)\.([A-Za-z_]\w*)", t)
+            if not m or m.group(2) not in imports:
+                return t
+            info = self.ext[imports[m.group(2)]]["types"].get(m.group(3))
+            if info and info.get("alias") and "." not in info.get("underlying", "."):
+                return m.group(1) + m.group(2) + "." + info["underlying"]
+            return t
+        if canon(na) == canon(nb):
+            return True
+        # an interface parameter of this package or of arrow-go accepts whatever implements it: not decided here
+        base = nb.lstrip("*")
+        if base in self.pkg.named_types and self.pkg.named_types[base].startswith("interface"):
+            return True
+        m = re.fullmatch(r"([A-Za-z_]\w*)\.([A-Za-z_]\w*)", nb)
+        if m and m.group(1) in imports:
+            info = self.ext[imports[m.group(1)]]["types"].get(m.group(2))
+            if info is None or (not info["fields"] and not info.get("underlying")):      # an interface (or unknown): left alone
+                return True
+        return False
 
     def _check_local_calls(self, f, env, body):
         """name(…) where name is a package-level function of this package (and not shadowed by a local)"""
@@ -918,7 +960,7 @@ class Checker:
                 continue
             if i > 0 and body[i - 1].kind == "ident" and body[i - 1].text == "func":
                 continue
-            self._check_local_arity(f.file, body, i, pkg_funcs[t.text], t.text)
+            self._check_local_arity(f.file, body, i, pkg_funcs[t.text], t.text, env)
 
     _GO_KEYWORDS = {"if", "for", "switch", "select", "case", "go", "defer", "return", "else", "range", "var", "func"}
 

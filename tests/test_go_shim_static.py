@@ -57,7 +57,7 @@ def test_arrow_go_symbols_and_members_exist(chk):
     have.  The list of exported names is a committed fixture (scripts/gen_go_exports.py reads the reference's sources); where the
     reference is present the fixture must be current."""
     assert chk.ext, "tests/golden/go_reference_exports.json is missing"
-    assert chk.ext_checked >= 250 and chk.local_calls_checked >= 150   # (calls of the package's own functions / methods: argument counts)
+    assert chk.ext_checked >= 250 and chk.local_calls_checked >= 150 and chk.local_args_typed >= 150   # (calls of the package's own functions / methods: counts and types)
     if os.path.isdir("/root/reference/arrow"):
         import subprocess, sys
         assert subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_go_exports.py"), "--check"]).returncode == 0, \
@@ -120,6 +120,8 @@ MUTATIONS = [
     ("own method called with an argument missing", "register.go", "return finishVector(ctx, out, values.Type, n, nulls, w, do, dvo)", "return finishVector(ctx, out, values.Type, n, nulls, w, do)",
      r"finishVector called with 7 arguments, declared with 8"),
     ("two variables for a call that returns three", "register.go", "ndict, nullID, err := x.HashU64Encode(", "ndict, err := x.HashU64Encode(", r"assignment mismatch: 2 variables but the call returns 3 values"),
+    ("int64 passed where the package's own function takes an int", "register.go", "return finishVector(ctx, out, values.Type, n, nulls, w, do, dvo)", "return finishVector(ctx, out, values.Type, n, nulls, nulls, do, dvo)",
+     r"finishVector argument 6 `nulls` has type int64, the parameter is int"),
     ("package used but not imported", "comm.go", '\t"fmt"\n', "", r"undefined: fmt"),
     ("local declared and not used", "math.go", "func NewMath(", "func unusedLocal() int {\n\tleft, right := 1, 2\n\treturn left\n}\n\nfunc NewMath(", r"right declared and not used"),
     # against the arrow-go packages the shim imports (tests/golden/go_reference_exports.json)
