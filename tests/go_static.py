@@ -521,6 +521,7 @@ class Checker:
         self.ext_checked = 0      # pkg.Name uses and members of external types that were looked up
         self.local_calls_checked = 0
         self.local_args_typed = 0
+        self.returns_checked = 0
         self.calls = []
         self.methods = {}
         self.func_results = {}
@@ -732,6 +733,7 @@ class Checker:
             self._check_selectors(f, env, body)
             self._check_unused_locals(f, body)
             self._check_local_calls(f, env, body)
+            self._check_returns(f)
         for fname, toks in self.pkg.files.items():      # every C.AH_* of the file, package-level initialisers included
             self._check_c_names(fname, toks)
             self._check_ext_symbols(fname, toks)
@@ -962,6 +964,47 @@ class Checker:
                 continue
             self._check_local_arity(f.file, body, i, pkg_funcs[t.text], t.text, env)
 
+    def _check_returns(self, f):
+        """every `return` of the function itself (function literals inside it have their own results and are skipped) carries as many
+        values as the signature has results"""
+        raw, i = f.body, 0
+        n = len(raw)
+        while i < n:
+            t = raw[i]
+            if t.kind == "ident" and t.text == "func" and i + 1 < n and raw[i + 1].kind == "op" and raw[i + 1].text == "(":
+                k = _match(raw, i + 1) + 1
+                while k < n and not (raw[k].kind == "op" and raw[k].text == "{"):
+                    if raw[k].kind == "op" and raw[k].text == "(":
+                        k = _match(raw, k)
+                    k += 1
+                if k < n:
+                    i = _match(raw, k) + 1
+                    continue
+            if t.kind == "ident" and t.text == "return":
+                j, depth, expr = i + 1, 0, []
+                while j < n:
+                    u = raw[j]
+                    if u.kind == "op" and u.text in "([{":
+                        depth += 1
+                    elif u.kind == "op" and u.text in ")]}":
+                        if depth == 0:
+                            break
+                        depth -= 1
+                    if depth == 0 and (u.kind == "nl" or (u.kind == "op" and u.text == ";")):
+                        break
+                    if u.kind != "nl":
+                        expr.append(u)
+                    j += 1
+                parts = [g for g in _split_commas(expr) if g]
+                want = len(f.results)
+                self.returns_checked += 1
+                spreads = len(parts) == 1 and parts[0][-1].kind == "op" and parts[0][-1].text == ")" and want > 1 and not (
+                    parts[0][0].kind == "ident" and parts[0][0].text in self._CONVERSIONS and parts[0][1].kind == "op" and parts[0][1].text == "(")
+                if not spreads and len(parts) != want and not (not parts and f.named_results):
+                    self.errors.append(f"{f.file}:{t.line}: {f.name} returns {len(parts)} values here, its signature has {want}")
+            i += 1
+
+    _CONVERSIONS = {"int", "int8", "int16", "int32", "int64", "uint", "uint8", "uint16", "uint32", "uint64", "float32", "float64", "bool", "string", "byte", "uintptr"}
     _GO_KEYWORDS = {"if", "for", "switch", "select", "case", "go", "defer", "return", "else", "range", "var", "func"}
 
     def _check_unused_locals(self, f, body):

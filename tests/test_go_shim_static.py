@@ -122,6 +122,7 @@ MUTATIONS = [
     ("two variables for a call that returns three", "register.go", "ndict, nullID, err := x.HashU64Encode(", "ndict, err := x.HashU64Encode(", r"assignment mismatch: 2 variables but the call returns 3 values"),
     ("int64 passed where the package's own function takes an int", "register.go", "return finishVector(ctx, out, values.Type, n, nulls, w, do, dvo)", "return finishVector(ctx, out, values.Type, n, nulls, nulls, do, dvo)",
      r"finishVector argument 6 `nulls` has type int64, the parameter is int"),
+    ("a return with a value missing", "arrowhip.go", "\treturn int64(r), err\n}", "\treturn int64(r)\n}", r"returns 1 values here, its signature has 2"),
     ("package used but not imported", "comm.go", '\t"fmt"\n', "", r"undefined: fmt"),
     ("local declared and not used", "math.go", "func NewMath(", "func unusedLocal() int {\n\tleft, right := 1, 2\n\treturn left\n}\n\nfunc NewMath(", r"right declared and not used"),
     # against the arrow-go packages the shim imports (tests/golden/go_reference_exports.json)
