@@ -71,6 +71,7 @@ struct ah_ctx {
   size_t scan_recs_bytes;
   unsigned scan_epoch, scan_ticket_base;
   int opt_groupby_seed;    // direct group-by: 1 (default) the workgroups' LDS tables start from the quick look's keys and are added up slot by slot, 0 empty tables merged with atomics
+  int opt_groupby_reserve; // partitioned group-by: 1 (default) the scatter reserves its runs in per-(partition, XCD) regions sized from the sample — no histogram pass —, 0 histogram → offsets → scatter
   int opt_groupby_lean;    // direct group-by: 0 always keep a pending group per lane, 1 (default) leave it out when the quick look says neighbouring rows rarely share a key, 2 always leave it out
   int opt_filter_cache;    // 1: ah_filter_count leaves its tile prefixes for the fill (default on a stream of the context's own), 0: the fill recounts (default on a shared stream)
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
@@ -178,6 +179,7 @@ int ah_fused_f64_parts_dev(ah_ctx* ctx, int cmpop, const double* x, const uint8_
 size_t ah_sum_partial_bytes(int is_f64);
 int ah_sum_chunk_partials(ah_ctx* ctx, int is_f64, const void* buf, size_t len, void* partials, int max_partials, int* n_written);
 int ah_sum_finish_partials(ah_ctx* ctx, int is_f64, const void* partials, int n, void* res_dev);
+int ah_sum_short_f64(ah_ctx* ctx, const void* buf, size_t len, void* res_dev);   // ≤ 31 rows: the reference's sequential order
 // internal (ah_hash_part.hip): unique / dictionary_encode of 8-byte keys by partitions of the key hash, 2^lp of them (8 … 10);
 // temporaries in the temp arena; *used says whether out_* hold the result
 int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,

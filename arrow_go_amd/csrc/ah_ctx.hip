@@ -86,6 +86,7 @@ static int ctx_create(int device_id, void* stream, bool borrow, ah_ctx** out) {
   c->opt_groupby_lean = 1;
   c->opt_scan_onepass = 1;
   c->opt_groupby_seed = 1;
+  c->opt_groupby_reserve = 1;
   *out = c;
   return AH_OK;
 }
@@ -149,6 +150,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "scan_onepass")) c->opt_scan_onepass = (int)value;
   else if (!strcmp(name, "groupby_lean")) c->opt_groupby_lean = (int)value;
   else if (!strcmp(name, "groupby_seed")) c->opt_groupby_seed = (int)value;
+  else if (!strcmp(name, "groupby_reserve")) c->opt_groupby_reserve = (int)value;
   else if (!strcmp(name, "filter_cache")) { c->opt_filter_cache = value != 0; if (!value) c->fcache.valid = false; }
   else if (!strcmp(name, "scan_segment_log2")) c->opt_scan_segment_log2 = (int)value;
   else return ah_fail(c, AH_EINVALID, "set_option: unknown option '%s'", name);

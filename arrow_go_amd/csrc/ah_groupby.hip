@@ -179,14 +179,19 @@ __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsi
 //     wave-uniform loops): half the dependent LDS round trips per row, same instruction count — 6 % SLOWER.  Latency is not it.
 // What is left is fewer instructions per row, and the ones that remain are the algorithm: eight 64-bit compares per probe
 // step, a 128-bit fixed-point split, two 128-bit adds, five LDS operations.
-template <bool FX, bool DIRECT = false, bool LEAN = false>
+// SEG (flat == 0 behind the RESERVING scatter, ah_partition.h 1b): the records of a partition lie in kGbRegions regions of the record
+// arrays; r0 / r1 / binstart are DENSE positions and seg_vstart / seg_delta turn one into a physical position.  The row loop runs over
+// the dense positions of the whole partition as before — a step that lies inside one region (all but seven per partition) adds one
+// uniform offset to its addresses, a step across a region boundary looks its regions up lane by lane.
+template <bool FX, bool DIRECT = false, bool LEAN = false, bool SEG = false>
 __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                                  const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
                                                                  const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat,
                                                                  const uint8_t* __restrict__ kvalid, int64_t koff, const uint8_t* __restrict__ vvalid,
                                                                  int64_t voff, int64_t nrows, int64_t seg_rows, unsigned* __restrict__ tile_range = nullptr,
                                                                  const unsigned long long* __restrict__ seed_keys = nullptr, unsigned seed_used = 0,
-                                                                 GbStaging st = GbStaging{nullptr, nullptr, nullptr, nullptr}) {
+                                                                 GbStaging st = GbStaging{nullptr, nullptr, nullptr, nullptr},
+                                                                 const unsigned* __restrict__ seg_vstart = nullptr, const unsigned* __restrict__ seg_delta = nullptr) {
   // seed_keys (flat == 2 only): the key plane of an LDS table holding the keys a quick look found — EVERY workgroup starts from
   // it, so a seeded key has the same slot in all of them and their results for it are added up slot by slot afterwards
   // (gd_reduce_kernel) instead of 256 workgroups × groups × 5 atomics on one global table (0.1 ms per 1024 groups, serialised in
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   __shared__ unsigned s_used, s_direct;
   __shared__ int s_part;
   __shared__ unsigned long long s_snap[2];
+  __shared__ unsigned s_vs[SEG ? kGbRegions + 1 : 1], s_dl[SEG ? kGbRegions : 1];   // the current partition's regions: dense starts (+ its end), physical − dense
   const int t = threadIdx.x;
   int part;
   bool multi;
@@ -300,20 +306,38 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   constexpr int64_t kStep = (int64_t)kThreads * U;
   unsigned long long nk[U], nv[U];
   unsigned nrw[U];                         // the row word — direct mode: the row's two validity BYTES, decoded when the row is processed
-  auto load_step = [&](int64_t b, auto full) {
+  int xs = 0;                              // SEG: the region the loads are in (uniform; only moves forward inside a partition)
+  unsigned seg_dl = 0;                     //      its physical − dense offset
+  auto load_step = [&](int64_t b, auto full, auto across) {
     constexpr bool kFull = decltype(full)::value;
+    constexpr bool kAcross = decltype(across)::value;   // SEG: the step crosses a region boundary — every lane finds its rows' regions
+    int64_t phys[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      phys[u] = i;
+      if (SEG) {
+        unsigned d = seg_dl;
+        if (kAcross) {
+          d = s_dl[0];
+#pragma unroll
+          for (int x = 1; x < kGbRegions; x++) d = i >= (int64_t)s_vs[x] ? s_dl[x] : d;   // the last region starting at or before i (empty ones start where the next does)
+        }
+        phys[u] = i + (int64_t)d;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t i = b + u * kThreads + t;
       const bool in = kFull || i < r1;
-      nk[u] = in ? __builtin_nontemporal_load(&keys[i]) : 0ull;
-      nv[u] = in ? __builtin_nontemporal_load(&vals[i]) : 0ull;
+      nk[u] = in ? __builtin_nontemporal_load(&keys[phys[u]]) : 0ull;
+      nv[u] = in ? __builtin_nontemporal_load(&vals[phys[u]]) : 0ull;
     }
     if (!DIRECT) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int64_t i = b + u * kThreads + t;
-        nrw[u] = (kFull || i < r1) ? __builtin_nontemporal_load(&prows[i]) : 0u;
+        nrw[u] = (kFull || i < r1) ? __builtin_nontemporal_load(&prows[phys[u]]) : 0u;
       }
     } else {
 #pragma unroll
@@ -335,8 +359,17 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     }
   };
   auto load_any = [&](int64_t b) {
-    if (b + kStep <= r1) load_step(b, std::true_type{});
-    else if (b < r1) load_step(b, std::false_type{});
+    if (SEG) {
+      if (b >= r1) return;
+      while (xs < kGbRegions - 1 && b >= (int64_t)s_vs[xs + 1]) xs++;   // (uniform)
+      seg_dl = s_dl[xs];
+      const int64_t region_end = (int64_t)s_vs[xs + 1], lim = region_end < r1 ? region_end : r1;
+      if (b + kStep <= lim) load_step(b, std::true_type{}, std::false_type{});
+      else load_step(b, std::false_type{}, std::true_type{});
+      return;
+    }
+    if (b + kStep <= r1) load_step(b, std::true_type{}, std::false_type{});
+    else if (b < r1) load_step(b, std::false_type{}, std::false_type{});
   };
   for (;;) {   // one pass per partition segment of this workgroup's share (flat modes: exactly one)
   if (flat == 0) {
@@ -349,6 +382,11 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   if (r0 < r1) {
   for (int j = t; j < kLSlots; j += kThreads) { l_key[j] = (DIRECT && seed_keys && j < kSlots) ? seed_keys[j] : kEmpty; l_lo[j] = 0; if (FX) l_hi[j] = 0; l_cnt[j] = 0; l_first[j] = kNoRow; }
   if (t == 0) { s_used = DIRECT && seed_keys ? seed_used : 0u; s_direct = 0; }
+  if (SEG) {
+    if (t <= kGbRegions) s_vs[t] = seg_vstart[part * kGbRegions + t];
+    if (t < kGbRegions) s_dl[t] = seg_delta[part * kGbRegions + t];
+    xs = 0;
+  }
   __syncthreads();
   went_direct = false;
   p_live = false;
@@ -415,9 +453,13 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     }
   };
   for (int64_t b = r0; b < r1; b += kStep) {
-    // the attempt is void (a table overflowed: far more groups than estimated): stop feeding a full global table, whose every
-    // probe walks all of it — a wrongly chosen direct path cost 0.9 s that way
-    if (flat != 1 && __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    // DIRECT only — the attempt is void (a table overflowed: far more groups than estimated): stop feeding a full global table, whose
+    // every probe walks all of it — a wrongly chosen direct path cost 0.9 s that way.  (The partitioned path's only route into a
+    // global table, gb_global_slot, looks at the flag itself; polling it here — an agent-scope load whose wait sits in front of the
+    // software-pipelined row loads — cost that path 30 µs of its 422: round 4's regression, profiles/r04_bench_kernel_stats.csv.)
+    if constexpr (DIRECT) {
+      if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
     step(b);
   }
   if (!LEAN && p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
@@ -1096,10 +1138,16 @@ __device__ __forceinline__ int gq_global_slot(unsigned long long* __restrict__ g
   // kSoftLimit — to completely full, if enough of them are in flight — and an unbounded probe for a key that is not in a full
   // table never ends.  (Sixteen thousand lanes never got there in hundreds of calls; a variant of this kernel with half a million
   // lanes in flight did on its first run and hung the device until the watchdog.)  −1 = "not seeded", which every caller handles.
+  // The admission count travels WITH every probe round's four key loads (one wait for five loads): once the table has admitted its
+  // kSoftLimit keys the column has "many" groups and nothing else is wanted from the look — a lane leaves at once instead of walking
+  // a nearly full table for a key that is not in it (at 2^16 groups fourteen thousand lanes did, thirty rounds of cross-XCD
+  // round trips each: the look took 138 µs there, profiles/r04_bench_kernel_stats.csv).  A lane whose key IS seeded may leave
+  // without finding it: "not seeded" is a valid answer for every caller, and the host reads the full table as "many".
   for (int probes = 0; probes < kSlots / 4 + 8; probes++) {
     unsigned long long q[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) q[k] = __hip_atomic_load(&g_key[g + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_load(g_tickets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u >= (unsigned)kSoftLimit) return -1;   // (the word holds count − 1: see qs below)
     int j = -1;
     bool hit = false;
 #pragma unroll
@@ -1109,25 +1157,39 @@ __device__ __forceinline__ int gq_global_slot(unsigned long long* __restrict__ g
     }
     if (j < 0) { g = (g + 4) & (kSlots - 1); continue; }
     if (hit) return j;
-    // (counted on SUCCESS, unlike gb_lds_slot's tickets: sixteen thousand lanes meet an empty table at once here)
-    if (__hip_atomic_load(g_tickets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u >= (unsigned)kSoftLimit) return -1;   // (the word holds count − 1: see qs below)
+    // (counted on SUCCESS, unlike gb_lds_slot's tickets: sixteen thousand lanes meet an empty table at once here — and counted once
+    // per WAVE and round: three and a half thousand single increments of one word are 43 µs of same-address atomics, 12 ns each)
     const unsigned long long cur = atomicCAS(&g_key[j], kEmpty, key);
-    if (cur == kEmpty) { atomicAdd(g_tickets, 1u); return j; }
-    if (cur == key) return j;
+    const unsigned long long won = __ballot(cur == kEmpty);   // among the lanes that are in this round
+    if (won && (int)(threadIdx.x & 63) == __builtin_ctzll(won)) atomicAdd(g_tickets, (unsigned)__popcll(won));
+    if (cur == kEmpty || cur == key) return j;
   }
   return -1;
 }
 
 // qs: the look's words in device memory, all preset to ones by ONE memset together with the seed table in front of them, so every
 // counter reads "stored + 1": [0] tickets, [1] special bits (stored inverted: AND clears), [2] repeats, [3] pairs, [4] neighbours,
-// [5] workgroups done, [6..7] ~(largest |value|) as a 64-bit minimum.
+// [5] workgroups done, [6..7] ~(largest |value|) as a 64-bit minimum, [8] "many": cleared by a workgroup whose own 1024 rows say so.
 constexpr int kQlBlocks = kQlGroups * kQlRun / 1024;   // one row per lane: the look's latency is one row's, not sixteen rows' on one CU (35–50 µs)
+// A workgroup first counts the distinct keys of ITS 1024 rows in an LDS table.  More than kQlLocalMany of them: the column has far
+// more groups than the direct path takes, whatever the other workgroups see — 1024 rows drawn from G keys show G·(1 − e^(−1024/G))
+// distinct ones at most (evenly drawn keys show the most): 866 ± 10 for G = 3000, the direct path's limit, 920 from G ≈ 4300 on.
+// Such a workgroup clears word [8] and stays away from the shared table — on a column of 2^16 groups all sixteen do, and the look
+// is one launch with no cross-XCD traffic at all instead of fourteen thousand lanes filling a 4096-slot table by CAS, four rounds
+// per group of slots (51 µs; 138 µs before the admission count travelled with every probe round).  Otherwise only the lane that
+// brought a key into the workgroup's table goes on to the shared one: a column of 16 groups sends 16 keys per workgroup, not 900.
+constexpr int kQlLocalSlots = 2048, kQlLocalMany = 920;
 __global__ __launch_bounds__(1024) void gq_quicklook_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
                                                              const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
                                                              int64_t n, int64_t stride, unsigned long long* __restrict__ seed_keys, unsigned* __restrict__ qs,
                                                              unsigned long long* mb, unsigned long long seq) {
-  __shared__ unsigned s_last, s_held;
+  __shared__ unsigned s_last, s_held, s_local;
+  __shared__ unsigned long long s_tab[kQlLocalSlots];
   const int t = threadIdx.x;
+  s_tab[t] = kEmpty;
+  s_tab[t + 1024] = kEmpty;
+  if (t == 0) s_local = 0;
+  __syncthreads();
   constexpr int kGpi = 1024 / kQlRun;             // groups per workgroup
   const int64_t i = gq_row((int)blockIdx.x * kGpi + t / kQlRun, stride) + (t % kQlRun);
   const bool in = i < n;
@@ -1146,7 +1208,20 @@ __global__ __launch_bounds__(1024) void gq_quicklook_kernel(const unsigned long 
   const unsigned long long key0 = __shfl(key, 0, 64);
   const bool kv0 = __shfl((int)kv, 0, 64) != 0;
   const bool dup = ((t & 63) != 0 && kv0 && key == key0) || ((t & 63) != 0 && kprev_ok && key == kprev);
-  if (kv && key != kEmpty && !dup) (void)gq_global_slot(seed_keys, &qs[0], key);
+  bool mine = kv && key != kEmpty && !dup;
+  if (mine) {   // the workgroup's own table: the first lane to bring a key keeps it
+    unsigned h = (((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> (32 - 11);
+    for (;;) {
+      const unsigned long long cur = atomicCAS(&s_tab[h], kEmpty, key);
+      if (cur == kEmpty) { atomicAdd(&s_local, 1u); break; }
+      if (cur == key) { mine = false; break; }
+      h = (h + 1) & (kQlLocalSlots - 1);
+    }
+  }
+  __syncthreads();
+  const bool local_many = s_local > (unsigned)kQlLocalMany;   // (uniform)
+  if (local_many) { if (t == 0) atomicAnd(&qs[8], 0u); }
+  else if (mine) (void)gq_global_slot(seed_keys, &qs[0], key);
   const unsigned long long rep_m = __ballot(kv && key == k2), pair_m = __ballot(kv), adj_m = __ballot(kv && kprev_ok && (t % kQlRun) != 0 && key == kprev);
   unsigned long long m = 0;
   if (vok) { const unsigned long long b = vv & 0x7fffffffffffffffull; if ((b >> 52) != 0x7ff) m = b; }
@@ -1173,16 +1248,16 @@ __global__ __launch_bounds__(1024) void gq_quicklook_kernel(const unsigned long 
   if (!s_last) return;
   __threadfence();
   // the last workgroup counts the keys the table holds (tickets over-count: lanes meeting one new key at once each take one)
-  unsigned mine = 0;
-  for (int j = t; j < kSlots; j += 1024) mine += __hip_atomic_load(&seed_keys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kEmpty ? 1u : 0u;
+  unsigned held = 0;
+  for (int j = t; j < kSlots; j += 1024) held += __hip_atomic_load(&seed_keys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kEmpty ? 1u : 0u;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-  if ((t & 63) == 0) atomicAdd(&s_held, mine);
+  for (int o = 32; o > 0; o >>= 1) held += __shfl_down(held, o, 64);
+  if ((t & 63) == 0) atomicAdd(&s_held, held);
   __syncthreads();
   if (t == 0) {
     auto rd = [&](int k) { return __hip_atomic_load(&qs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const unsigned sp = ~rd(1) & 3u;
-    const unsigned used = s_held;   // ≥ kSoftLimit − a few: "many" (inserts stop there)
+    const unsigned used = rd(8) == 0u ? (s_held > (unsigned)kSoftLimit ? s_held : (unsigned)kSoftLimit) : s_held;   // ≥ kSoftLimit − a few: "many" (inserts stop there; a workgroup said so)
     const unsigned long long mx = ~__hip_atomic_load((unsigned long long*)&qs[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // {distinct keys among the sampled rows, largest sampled |value|, pairs | rows sharing the key of the row 1024 further on,
     //  keys in the seed table, neighbouring rows sharing a key}
@@ -1399,6 +1474,9 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
                      int32_t* out_null_group, int* used, const unsigned long long* guess_bits = nullptr, bool lean = false,
                      const unsigned long long* seed_keys = nullptr, unsigned seed_used = 0) {
   *used = 0;
+  // a seed table at or beyond the admission limit must never reach gb_lds_slot, whose probe loop relies on empty slots being there
+  // (the caller's "≤ 2800 distinct" gate already says so; this is the guard at the place that would hang)
+  if (seed_keys && seed_used >= (unsigned)kSoftLimit) { seed_keys = nullptr; seed_used = 0; }
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int64_t nslots = kGStride;
   const unsigned dgrid = (unsigned)ah_ceil_div(n, (int64_t)1 << kChunkLog2);
@@ -1481,6 +1559,163 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
   return AH_OK;
 }
 
+// one launch instead of seven memsets (each ≈ 5 µs of launch on a path that is a chain of small kernels): up to 8 {address, 16-byte
+// words, 32-bit pattern} jobs, every workgroup takes its share of each
+struct GbFill { uint4* p[8]; unsigned long long n16[8]; unsigned v[8]; int njobs; unsigned long long* ones; };
+__global__ __launch_bounds__(256) void gb_fill_kernel(GbFill f) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int j = 0; j < f.njobs; j++) {
+    const uint4 w = {f.v[j], f.v[j], f.v[j], f.v[j]};
+    uint4* __restrict__ q = f.p[j];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)f.n16[j]; i += stride) q[i] = w;
+  }
+  if (f.ones && blockIdx.x == 0 && threadIdx.x == 0) *f.ones = ~0ull;   // (inside a word this thread has just filled: the last job's first)
+}
+
+// steps 1 … 4 of the partition-first group-by for 2^lp partitions.  hist (nullable): the sample's [8][1024] row counts — the
+// RESERVING scatter is used (no histogram pass; ah_partition.h 1b) and *redo = 4 says a region was too small (the caller runs the
+// call again without hist).  *used = 1: out_* hold the result.
+static int gb_cut_aggregate(ah_ctx* c, int is_f64, int lp, const unsigned* hist, double sample_scale, const uint64_t* keys, const uint8_t* kvalid, int64_t koff,
+                            const void* vals, const uint8_t* vvalid, int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts,
+                            int64_t* out_first_rows, int64_t* out_ngroups, int32_t* out_null_group, int* used, unsigned* redo) {
+  *used = 0;
+  *redo = 0;
+  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
+  unsigned* overflow = (unsigned*)&c->dscalars[21];
+  unsigned long long* total = (unsigned long long*)&c->dscalars[22];
+  int* null_id = (int*)&c->dscalars[23];
+  const bool reserve = hist != nullptr;
+  const int P = 1 << lp;
+  const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
+  const int64_t nslots = (int64_t)P * kGStride;
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const int64_t xrows = ((ntiles + 7) >> 3) * kGbTile;   // rows of the tiles one XCD takes (xcd_contiguous_tile)
+  // record arrays: dense (n rows) behind the offsets table; regions (≤ 1.5 n + slack, gb_layout_kernel checks) + kGbTile spare rows otherwise
+  const int64_t cap_rows = reserve ? n + n / 2 + (int64_t)P * kGbRegions * 96 : n;
+  const int64_t rec_rows = reserve ? cap_rows + kGbTile : n;
+  const int nreg = P * kGbRegions;
+  // ---- temporaries (one reservation)
+  const size_t table = reserve ? 0 : (size_t)P * (size_t)ntiles * 4;
+  const size_t need = pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2 + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
+                      pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) +
+                      pad((size_t)rec_rows * 8) * 2 + pad((size_t)rec_rows * 4) + pad((size_t)ntiles * 16) + pad((size_t)(nreg + 1) * 4) * 5;
+  uint8_t* base;
+  int rc = ah_temp_reserve(c, need, (void**)&base);
+  if (rc != AH_OK) return rc;
+  size_t used_b = 0;
+  auto take = [&](size_t b) { uint8_t* q = base + used_b; used_b += pad(b); return q; };
+  GbTable gt;
+  gt.key = (unsigned long long*)take((size_t)nslots * 8);
+  gt.lo = (unsigned long long*)take((size_t)nslots * 8);
+  gt.hi = (unsigned long long*)take((size_t)nslots * 8);
+  gt.cnt = (unsigned*)take((size_t)nslots * 4);
+  gt.first = (unsigned*)take((size_t)nslots * 4);
+  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
+  int* tilecnt = (int*)take((size_t)nrt * 4);
+  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
+  unsigned* cnt_tm = (unsigned*)take(table);
+  unsigned* toffs = (unsigned*)take(table);
+  unsigned* gsum = (unsigned*)take((size_t)ngrp * P * 4);
+  unsigned* binstart = (unsigned*)take((size_t)(P + 1) * 4);
+  unsigned long long* pkeys = (unsigned long long*)take((size_t)rec_rows * 8);
+  unsigned long long* pvals = (unsigned long long*)take((size_t)rec_rows * 8);
+  unsigned* prows = (unsigned*)take((size_t)rec_rows * 4);
+  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 16);
+  unsigned* rstart = (unsigned*)take((size_t)(nreg + 1) * 4);
+  unsigned* rcap = (unsigned*)take((size_t)(nreg + 1) * 4);
+  unsigned* cursor = (unsigned*)take((size_t)(nreg + 1) * 4);
+  unsigned* vstart = (unsigned*)take((size_t)(nreg + 1) * 4);
+  unsigned* delta = (unsigned*)take((size_t)(nreg + 1) * 4);
+  {
+    // everything the call starts from, one launch: empty tables (lo, hi, cnt are adjacent), no first rows, the call's scalars
+    GbFill f;
+    f.njobs = 7;
+    f.p[0] = (uint4*)gt.key; f.n16[0] = pad((size_t)nslots * 8) / 16; f.v[0] = 0xFFFFFFFFu;
+    f.p[1] = (uint4*)gt.lo; f.n16[1] = (pad((size_t)nslots * 8) * 2 + pad((size_t)nslots * 4)) / 16; f.v[1] = 0u;
+    f.p[2] = (uint4*)gt.first; f.n16[2] = pad((size_t)nslots * 4) / 16; f.v[2] = 0xFFFFFFFFu;
+    f.p[3] = (uint4*)firsts; f.n16[3] = pad((size_t)nwords * 8) / 16; f.v[3] = 0u;
+    f.p[4] = (uint4*)&c->dscalars[20]; f.n16[4] = 1; f.v[4] = 0u;                 // [20] unused, [21] overflow / redo flags
+    f.p[5] = (uint4*)&c->dscalars[28]; f.n16[5] = 1; f.v[5] = 0u;                 // [28], [29] value range
+    f.p[6] = (uint4*)&c->dscalars[22]; f.n16[6] = 1; f.v[6] = 0u;                 // [22] total, [23] …
+    f.ones = (unsigned long long*)null_id;                                         // … null id: none
+    gb_fill_kernel<<<(unsigned)(c->num_cu * 4), 256, 0, c->stream>>>(f);
+    AH_LAUNCH_CHECK(c);
+  }
+  const unsigned long long* k64 = (const unsigned long long*)keys;
+  const unsigned long long* v64 = (const unsigned long long*)vals;
+  // ---- 1, 2: cut
+  const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
+  if (reserve) {
+    gb_layout_kernel<<<1, 1024, 0, c->stream>>>(hist, lp, n, xrows, sample_scale, cap_rows, rstart, rcap, cursor, overflow);
+    AH_LAUNCH_CHECK(c);
+    gb_scatter_kernel<true, true><<<tgrid, kThreads, 0, c->stream>>>(k64, kvalid, koff, v64, vvalid, voff, n, lp, P, ntiles, nullptr, pkeys, pvals, prows,
+                                                                     is_f64 ? tile_max : nullptr, rstart, rcap, cursor, overflow, (unsigned)cap_rows);
+    AH_LAUNCH_CHECK(c);
+    // the regions as the aggregate pass walks them + the value range (gb_max_kernel and fx_range_check_kernel in one)
+    gb_segments_kernel<<<1, 1024, 0, c->stream>>>(rstart, rcap, cursor, P, n, vstart, delta, binstart, overflow, is_f64 ? tile_max : nullptr, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+  } else {
+  gb_hist_kernel<<<tgrid, kGbHistThreads, 0, c->stream>>>(k64, kvalid, koff, n, lp, P, ntiles, cnt_tm);
+  AH_LAUNCH_CHECK(c);
+  colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, P, ntiles, gsum);
+  AH_LAUNCH_CHECK(c);
+  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, P, ngrp, n, binstart);
+  AH_LAUNCH_CHECK(c);
+  tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, gsum, P, ntiles, toffs);
+  AH_LAUNCH_CHECK(c);
+  gb_scatter_kernel<true><<<tgrid, kThreads, 0, c->stream>>>(k64, kvalid, koff, v64, vvalid, voff, n, lp, P, ntiles, toffs, pkeys, pvals, prows,
+                                                       is_f64 ? tile_max : nullptr);
+  AH_LAUNCH_CHECK(c);
+  if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
+    gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+    AH_LAUNCH_CHECK(c);
+    fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
+    AH_LAUNCH_CHECK(c);
+  }
+  }
+  // ---- 3: aggregate
+  // One workgroup fits a CU: one round of equal shares (≥ 2^17 records each: a table costs its 136 KiB to set up and to write
+  // out).  Shares of the size of a partition where the partitions are smaller — 1024 workgroups for 1024 partitions, handed out
+  // by the hardware as CUs come free — measured SLOWER (2^20 groups: 1.89 → 2.12 ms).
+  int64_t nwg = n >> 17;
+  nwg = nwg < 1 ? 1 : (nwg > c->num_cu ? c->num_cu : nwg);
+  const int64_t seg_rows = ah_ceil_div(n, nwg);
+  const unsigned grid = (unsigned)ah_ceil_div(n, seg_rows);
+  // (the row-by-row LEAN mode of the direct path was measured here too, on evenly spread keys: 1.227 ms against 1.217 at 2^16 groups,
+  // 1.546 against 1.563 at 2^20 — nothing, although it frees eight registers: this pass is not bound by its instruction count alone)
+  const GbStaging nost{nullptr, nullptr, nullptr, nullptr};
+  if (reserve) {
+    if (is_f64) gb_aggregate_kernel<true, false, false, true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows, nullptr, nullptr, 0, nost, vstart, delta);
+    else gb_aggregate_kernel<false, false, false, true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows, nullptr, nullptr, 0, nost, vstart, delta);
+  } else {
+    if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
+    else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
+  }
+  AH_LAUNCH_CHECK(c);
+  // ---- 4: rank the groups by first row, write them out
+  gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
+  AH_LAUNCH_CHECK(c);
+  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  AH_LAUNCH_CHECK(c);
+  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
+  AH_LAUNCH_CHECK(c);
+  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
+  if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
+  else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
+                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
+  AH_LAUNCH_CHECK(c);
+  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
+  *redo = *(volatile unsigned*)&c->pinned[8];
+  if (*redo) return AH_OK;   // a partition held far more keys than estimated (1), a wide column (2): the caller's path redoes the call; a region too small (4): once more with the histogram
+  if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
+  if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
+  *used = 1;
+  return AH_OK;
+}
+
 // Called by ah_hash_sum_* before the id-based path.  *used = 1: out_* hold the result; 0: not applicable (small input,
 // too many expected groups, or the estimate was so far off that a partition's table overflowed) — the caller runs the
 // id-based path, which accepts anything.
@@ -1490,12 +1725,47 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   *used = 0;
   const int mode = c->opt_groupby_partition;   // 0 never, 1 auto, 2: always sort-based, 3 / 4: always the two-level cut with 2^11 / 2^13 partitions, k ≥ 5: always LDS tables in 2^(k − 2) partitions (tests, measurements)
   if (mode == 0 || n >= kMaxRows || n < 1 || (mode == 1 && n < ((int64_t)1 << 21))) return AH_OK;
-  auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
-  unsigned* overflow = (unsigned*)&c->dscalars[21];
-  unsigned long long* total = (unsigned long long*)&c->dscalars[22];
-  int* null_id = (int*)&c->dscalars[23];
-  unsigned long long* ones = (unsigned long long*)&c->dscalars[24];   // [24], [25]: the two sample points
+  // the scratch arena holds what must survive the temporaries' reservation further down: the look's key table + words, the sample's
+  // two counts + done word, its histogram and its two bitmaps (the last three adjacent: one memset)
+  constexpr int kSampleGroups = 1 << 15;            // × 64 consecutive rows = 2^21 sampled rows
+  constexpr unsigned kBits = 1u << 24;
+  constexpr size_t kSeedBytes = (size_t)kSlots * 8 + 256, kAccBytes = 256, kHistBytes = (size_t)kGbRegions * 1024 * 4, kBmBytes = 2 * (size_t)(kBits / 8);
+  uint8_t* sbase = nullptr;
+  if (mode == 1 || mode > 4) {
+    int src = ah_scratch_reserve(c, kSeedBytes + kAccBytes + kHistBytes + kBmBytes, (void**)&sbase);
+    if (src != AH_OK) return src;
+  }
+  void* seedbuf = sbase;
+  unsigned long long* sample_acc = (unsigned long long*)(sbase + kSeedBytes);   // [0] |A|, [1] |A ∪ B|, [2] workgroups done
+  unsigned* hist_buf = (unsigned*)(sbase + kSeedBytes + kAccBytes);
+  unsigned* sample_bm = (unsigned*)(sbase + kSeedBytes + kAccBytes + kHistBytes);
+  const unsigned* sample_hist = nullptr;   // set once the sample has filled hist_buf: the reserving scatter sizes its regions from it
+  double sample_scale = 0.0;
+  // the 2^21-row sample: two points of the distinct-count curve (linear counting) and, for the reserving scatter, the rows by
+  // {eighth of the column, 1024 hash buckets}.  Three launches: one memset, the sample, the count that posts to the mailbox.
+  const int64_t sgroups = (n / 64 < kSampleGroups ? n / 64 : kSampleGroups) & ~(int64_t)1;
+  const double sampled = (double)sgroups * 64.0;
+  auto run_sample = [&](uint64_t* set_half, uint64_t* set_full) -> int {
+    const int64_t stride = ((n / sgroups) & ~(int64_t)63) ? ((n / sgroups) & ~(int64_t)63) : 64;
+    const int64_t xrows = ((ah_ceil_div(n, kGbTile) + 7) >> 3) * kGbTile;
+    const bool want_hist = c->opt_groupby_reserve != 0;
+    AH_HIP(c, hipMemsetAsync(sample_acc, 0, kAccBytes + kHistBytes + kBmBytes, c->stream));
+    const unsigned half_grid = (unsigned)ah_ceil_div(sgroups / 2, 16 * kSampleBatches);
+    gb_sample_kernel<<<2 * half_grid, 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, n, sgroups, stride, sample_bm, kBits - 1,
+                                                            want_hist ? hist_buf : nullptr, xrows);
+    AH_LAUNCH_CHECK(c);
+    unsigned long long* mb;
+    unsigned long long seq, w[2];
+    int rc = ah_mailbox_begin(c, &mb, &seq);
+    if (rc != AH_OK) return rc;
+    gb_sample_finish_kernel<<<256, 256, 0, c->stream>>>((const unsigned long long*)sample_bm, (int64_t)(kBits / 64), sample_acc, (unsigned*)&sample_acc[2], mb, seq);
+    AH_LAUNCH_CHECK(c);
+    if ((rc = ah_mailbox_wait(c, seq, 2, w)) != AH_OK) return rc;
+    *set_half = w[0];
+    *set_full = w[1];
+    if (want_hist) { sample_hist = hist_buf; sample_scale = (double)n / sampled; }
+    return AH_OK;
+  };
   // ---- 0: how many partitions?
   int lp;
   if (mode == -2) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
@@ -1503,6 +1773,11 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
   if (mode == 2) return gs_groupby(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
   if (mode > 1) {
     lp = mode - 2 < 3 ? 3 : (mode - 2 > 10 ? 10 : mode - 2);
+    if (c->opt_groupby_reserve != 0 && sgroups >= 2) {   // a forced partition count (tests, measurements): the sample runs for its histogram alone
+      uint64_t a, b;
+      int rc = run_sample(&a, &b);
+      if (rc != AH_OK) return rc;
+    }
   } else {
     double est = -1.0;
     bool heavy_tail = false;
@@ -1511,9 +1786,8 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
       // below).  A column with few enough groups for the direct path is decided here, with the value maximum its scale guess needs.
       unsigned long long* mb;
       unsigned long long seq, w[5];
-      void* seedbuf;   // the look's key table: the seed of the direct path's LDS tables (the scratch arena: the direct path's own temporaries are in the other one)
-      int qrc = ah_scratch_reserve(c, (size_t)kSlots * 8 + 64, &seedbuf);
-      if (qrc != AH_OK) return qrc;
+      // seedbuf: the look's key table, the seed of the direct path's LDS tables (the scratch arena: the direct path's own temporaries are in the other one)
+      int qrc;
       AH_HIP(c, hipMemsetAsync(seedbuf, 0xFF, (size_t)kSlots * 8 + 64, c->stream));   // the empty table and the look's words (all "−1")
       if ((qrc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return qrc;
       const int64_t qstride = ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) ? ((n / kQlGroups) & ~(int64_t)(kQlRun - 1)) : kQlRun;
@@ -1543,27 +1817,15 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
       // The tail of such a column is only seen by a sample of millions of rows: the look decides the direct path and nothing else.)
     }
     if (est < 0.0) {
-    constexpr int kSampleGroups = 1 << 15;            // × 64 consecutive rows = 2^21 sampled rows
-    constexpr unsigned kBits = 1u << 24;
-    const int64_t groups = (n / 64 < kSampleGroups ? n / 64 : kSampleGroups) & ~(int64_t)1;
-    const int64_t stride = ((n / groups) & ~(int64_t)63) ? ((n / groups) & ~(int64_t)63) : 64;
-    unsigned* bm;
-    int rc = ah_temp_reserve(c, kBits / 8, (void**)&bm);
-    if (rc != AH_OK) return rc;
-    AH_HIP(c, hipMemsetAsync(bm, 0, kBits / 8, c->stream));
     auto distinct = [&](uint64_t set, double rows) {   // linear counting: M·ln(M / zeros)
       const double z = (double)kBits - (double)set;
       const double d = z < 1.0 ? rows : -(double)kBits * log(z / (double)kBits);
       return d > rows ? rows : d;
     };
-    for (int half = 0; half < 2; half++) {
-      gb_sample_kernel<<<(unsigned)ah_ceil_div(groups / 2, 16), 1024, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, n, groups, stride, half, 2, bm, kBits - 1);
-      AH_LAUNCH_CHECK(c);
-      if ((rc = ah_popcount_async(c, (const uint8_t*)bm, 0, kBits, ones + half)) != AH_OK) return rc;
-    }
-    if ((rc = ah_mailbox_read(c, ones, 2, (unsigned long long*)&c->pinned[8])) != AH_OK) return rc;
-    const double sampled = (double)groups * 64.0;
-    const double dh = distinct(*(volatile uint64_t*)&c->pinned[8], sampled / 2), ds = distinct(*(volatile uint64_t*)&c->pinned[9], sampled);
+    uint64_t set_half = 0, set_full = 0;
+    int rc = run_sample(&set_half, &set_full);
+    if (rc != AH_OK) return rc;
+    const double dh = distinct(set_half, sampled / 2), ds = distinct(set_full, sampled);
     est = gb_extrapolate(ds, sampled, (double)n);
     if (est <= 2048.0 && is_f64) return gb_direct(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
     // Keys drawn evenly from C values give a curve that the second half of the sample must follow; a heavy-tailed column
@@ -1600,96 +1862,13 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
       while (lp < 10 && est / (double)(1 << lp) > kpp_many) lp++;
     }
   }
-  const int P = 1 << lp;
-  const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
-  const int64_t nslots = (int64_t)P * kGStride;
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
-  // ---- temporaries (one reservation)
-  const size_t table = (size_t)P * (size_t)ntiles * 4;
-  const size_t need = pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2 + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
-                      pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) +
-                      pad((size_t)n * 8) * 2 + pad((size_t)n * 4) + pad((size_t)ntiles * 16);
-  uint8_t* base;
-  int rc = ah_temp_reserve(c, need, (void**)&base);
-  if (rc != AH_OK) return rc;
-  size_t used_b = 0;
-  auto take = [&](size_t b) { uint8_t* q = base + used_b; used_b += pad(b); return q; };
-  GbTable gt;
-  gt.key = (unsigned long long*)take((size_t)nslots * 8);
-  gt.lo = (unsigned long long*)take((size_t)nslots * 8);
-  gt.hi = (unsigned long long*)take((size_t)nslots * 8);
-  gt.cnt = (unsigned*)take((size_t)nslots * 4);
-  gt.first = (unsigned*)take((size_t)nslots * 4);
-  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
-  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
-  int* tilecnt = (int*)take((size_t)nrt * 4);
-  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
-  unsigned* cnt_tm = (unsigned*)take(table);
-  unsigned* toffs = (unsigned*)take(table);
-  unsigned* gsum = (unsigned*)take((size_t)ngrp * P * 4);
-  unsigned* binstart = (unsigned*)take((size_t)(P + 1) * 4);
-  unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
-  unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
-  unsigned* prows = (unsigned*)take((size_t)n * 4);
-  unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 16);
-  AH_HIP(c, hipMemsetAsync(gt.key, 0xFF, (size_t)nslots * 8, c->stream));
-  AH_HIP(c, hipMemsetAsync(gt.lo, 0, pad((size_t)nslots * 8) * 2 + (size_t)nslots * 4, c->stream));   // lo, hi, cnt are adjacent
-  AH_HIP(c, hipMemsetAsync(gt.first, 0xFF, (size_t)nslots * 4, c->stream));
-  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));   // absmax, overflow, total
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
-  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
-  const unsigned long long* k64 = (const unsigned long long*)keys;
-  const unsigned long long* v64 = (const unsigned long long*)vals;
-  // ---- 1, 2: cut
-  const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
-  gb_hist_kernel<<<tgrid, kGbHistThreads, 0, c->stream>>>(k64, kvalid, koff, n, lp, P, ntiles, cnt_tm);
-  AH_LAUNCH_CHECK(c);
-  colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, P, ntiles, gsum);
-  AH_LAUNCH_CHECK(c);
-  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, P, ngrp, n, binstart);
-  AH_LAUNCH_CHECK(c);
-  tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, gsum, P, ntiles, toffs);
-  AH_LAUNCH_CHECK(c);
-  gb_scatter_kernel<true><<<tgrid, kThreads, 0, c->stream>>>(k64, kvalid, koff, v64, vvalid, voff, n, lp, P, ntiles, toffs, pkeys, pvals, prows,
-                                                       is_f64 ? tile_max : nullptr);
-  AH_LAUNCH_CHECK(c);
-  if (is_f64) {   // the fixed-point scale needs the largest finite |value| before the first addend is converted
-    gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
-    AH_LAUNCH_CHECK(c);
-    fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
-    AH_LAUNCH_CHECK(c);
-  }
-  // ---- 3: aggregate
-  // One workgroup fits a CU: one round of equal shares (≥ 2^17 records each: a table costs its 136 KiB to set up and to write
-  // out).  Shares of the size of a partition where the partitions are smaller — 1024 workgroups for 1024 partitions, handed out
-  // by the hardware as CUs come free — measured SLOWER (2^20 groups: 1.89 → 2.12 ms).
-  int64_t nwg = n >> 17;
-  nwg = nwg < 1 ? 1 : (nwg > c->num_cu ? c->num_cu : nwg);
-  const int64_t seg_rows = ah_ceil_div(n, nwg);
-  const unsigned grid = (unsigned)ah_ceil_div(n, seg_rows);
-  // (the row-by-row LEAN mode of the direct path was measured here too, on evenly spread keys: 1.227 ms against 1.217 at 2^16 groups,
-  // 1.546 against 1.563 at 2^20 — nothing, although it frees eight registers: this pass is not bound by its instruction count alone)
-  if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
-  else gb_aggregate_kernel<false><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);
-  AH_LAUNCH_CHECK(c);
-  // ---- 4: rank the groups by first row, write them out
-  gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
-  AH_LAUNCH_CHECK(c);
-  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
-  AH_LAUNCH_CHECK(c);
-  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
-  AH_LAUNCH_CHECK(c);
-  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
-  if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
-  else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kGStride, kGSlots);
-  AH_LAUNCH_CHECK(c);
-  { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
-  if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition held far more keys than estimated: the caller's path redoes the call
-  if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
-  if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];
-  *used = 1;
-  return AH_OK;
+  // the reserving scatter (ah_partition.h 1b) first when the sample left its histogram; a region that turned out too small: once more
+  // with the histogram pass
+  unsigned redo = 0;
+  int rc = gb_cut_aggregate(c, is_f64, lp, sample_hist, sample_scale, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows,
+                            out_ngroups, out_null_group, used, &redo);
+  if (rc == AH_OK && !*used && sample_hist && redo == 4u)
+    rc = gb_cut_aggregate(c, is_f64, lp, nullptr, 0.0, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups,
+                          out_null_group, used, &redo);
+  return rc;
 }

@@ -177,7 +177,16 @@ static int ingest_sum(ah_ingest* g, int is_f64, const void* host, size_t len, vo
   AHI(grow(c, (uint8_t**)&g->partials, &g->partials_bytes, nchunks * kMaxPartials * part_bytes));
   std::vector<int> nparts(nchunks, 0);
   int total_parts = 0;
-  for (size_t k = 0; k < nchunks; k++) {
+  // a whole Float64 column of ≤ 31 rows is summed left to right by one lane, as both reference paths do (ah_sum.hip)
+  const bool short_f64 = is_f64 && len <= 31;
+  if (short_f64) {
+    int rc = slot_upload(g, 0, 0, host, len * 8, true);
+    if (rc == AH_OK) rc = slot_uploaded(g, 0, false);
+    if (rc == AH_OK) rc = ah_sum_short_f64(c, g->slots[0].buf[0], len, g->dres);
+    if (rc == AH_OK) rc = slot_computed(g, 0);
+    if (rc != AH_OK) return fail_drained(g, rc);
+  }
+  for (size_t k = 0; k < nchunks && !short_f64; k++) {
     const int s = (int)(k % g->depth);
     const size_t r0 = k * rows_per_chunk, rows = len - r0 < rows_per_chunk ? len - r0 : rows_per_chunk;
     int rc = slot_upload(g, s, 0, (const uint8_t*)host + r0 * 8, rows * 8, true);
@@ -189,7 +198,7 @@ static int ingest_sum(ah_ingest* g, int is_f64, const void* host, size_t len, vo
     if (rc != AH_OK) return fail_drained(g, rc);
     total_parts += nparts[k];
   }
-  int rc = ah_sum_finish_partials(c, is_f64, g->partials, total_parts, g->dres);
+  int rc = short_f64 ? AH_OK : ah_sum_finish_partials(c, is_f64, g->partials, total_parts, g->dres);
   if (rc != AH_OK) return fail_drained(g, rc);
   AH_HIP(c, hipMemcpyAsync(g->hres, g->dres, 8, hipMemcpyDeviceToHost, c->stream));
   AHI(drain(g));

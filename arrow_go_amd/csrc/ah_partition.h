@@ -29,19 +29,221 @@ __device__ __forceinline__ unsigned gb_part(uint64_t m, int lp) { return (unsign
 // groups, reads the bitmap's popcount, then the odd ones: two points of the distinct-count curve).  A 1024-entry filter
 // in LDS drops the keys this workgroup has just seen: without it a hot key sends every sampled row to ONE bitmap word —
 // 2^21 same-address atomics = 0.65 ms, and still 0.49 ms with a look-before-set on a Zipf column.
+// A workgroup takes kSampleBatches × 16 sample groups, sixteen (one per wave) at a time.
+// hist (nullable): [8][1024] counts of the sampled rows by {eighth of the column — the tiles the scatter gives to one XCD
+// (xcd_contiguous_tile), xrows rows each —, top 10 bits of gb_mix (a null key: bucket 0, as the scatter puts it)}: what the
+// reserving scatter's regions are sized from (gb_layout_kernel).  Counted in LDS for the eighth the workgroup starts in (every
+// workgroup but seven lies inside one), one global atomic per touched bucket and workgroup.
+// ONE launch covers both halves: the first half of the grid takes the even sample groups and marks bitmap A (bm), the second half the
+// odd groups and bitmap B (bm + nwords): |A| and |A ∪ B| are the two points of the curve, counted and posted by gb_sample_finish_kernel.
+constexpr int kSampleBatches = 4;
 __global__ __launch_bounds__(1024) void gb_sample_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
-                                                          int64_t n, int64_t ngroups, int64_t stride, int g0, int gstep, unsigned* __restrict__ bm, unsigned mmask) {
+                                                          int64_t n, int64_t ngroups, int64_t stride, unsigned* __restrict__ bm, unsigned mmask,
+                                                          unsigned* __restrict__ hist, int64_t xrows) {
   __shared__ unsigned long long s_seen[1024];
+  __shared__ unsigned s_hist[1024];
   s_seen[threadIdx.x] = 0;
+  s_hist[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t g = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * gstep + g0;
-  const int64_t i = g * stride + (threadIdx.x & 63);
-  if (g >= ngroups || i >= n || !ah_bit(kvalid, koff + i)) return;
-  const uint64_t m = gb_mix(keys[i]) | 1ull;
-  const unsigned f = (unsigned)(m >> 44) & 1023u;
-  if (atomicExch(&s_seen[f], m) == m) return;   // an LDS atomic, so that of the lanes holding a hot key at this instant only one goes on
-  const unsigned b = (unsigned)(m >> 20) & mmask;
-  if (!((__hip_atomic_load(&bm[b >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b & 31)) & 1u)) atomicOr(&bm[b >> 5], 1u << (b & 31));
+  const int half = blockIdx.x >= gridDim.x / 2 ? 1 : 0;
+  const int64_t blk = (int64_t)blockIdx.x - (half ? gridDim.x / 2 : 0);
+  bm += half ? ((size_t)mmask + 1) / 32 : 0;
+  const int64_t gfirst = (blk * 16 * kSampleBatches) * 2 + half;
+  const int x0 = hist ? (int)((gfirst * stride) / xrows) : 0;   // (uniform)
+  for (int r = 0; r < kSampleBatches; r++) {
+    const int64_t g = ((blk * kSampleBatches + r) * 16 + (threadIdx.x >> 6)) * 2 + half;
+    const int64_t i = g * stride + (threadIdx.x & 63);
+    const bool in = g < ngroups && i < n;
+    const bool kv = in && ah_bit(kvalid, koff + i);
+    const uint64_t mix = kv ? gb_mix(keys[i]) : 0ull;
+    if (hist && in) {
+      const unsigned b = kv ? (unsigned)(mix >> 54) : 0u;
+      const int x = (int)(i / xrows);
+      if (x == x0) atomicAdd(&s_hist[b], 1u);
+      else atomicAdd(&hist[(x < 7 ? x : 7) * 1024 + (int)b], 1u);
+    }
+    if (!kv) continue;
+    const uint64_t m = mix | 1ull;
+    const unsigned f = (unsigned)(m >> 44) & 1023u;
+    if (atomicExch(&s_seen[f], m) == m) continue;   // an LDS atomic, so that of the lanes holding a hot key at this instant only one goes on
+    const unsigned b = (unsigned)(m >> 20) & mmask;
+    if (!((__hip_atomic_load(&bm[b >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b & 31)) & 1u)) atomicOr(&bm[b >> 5], 1u << (b & 31));
+  }
+  if (hist) {
+    __syncthreads();
+    const unsigned cnt = s_hist[threadIdx.x];
+    if (cnt) atomicAdd(&hist[(x0 < 7 ? x0 : 7) * 1024 + (int)threadIdx.x], cnt);
+  }
+}
+// |A| and |A ∪ B| of the two bitmaps (nwords64 64-bit words each), posted to the host's mailbox by the last workgroup to finish —
+// one launch where two popcounts (two kernels each) and a posting kernel were five.  acc: two words, zero on entry; done: one word, zero.
+__global__ __launch_bounds__(256) void gb_sample_finish_kernel(const unsigned long long* __restrict__ bm, int64_t nwords64, unsigned long long* __restrict__ acc,
+                                                               unsigned* __restrict__ done, unsigned long long* mb, unsigned long long seq) {
+  __shared__ unsigned long long s_a[4], s_u[4];
+  __shared__ unsigned s_last;
+  unsigned long long a = 0, u = 0;
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords64; w += (int64_t)gridDim.x * 256) {
+    const unsigned long long x = bm[w], y = bm[nwords64 + w];
+    a += (unsigned long long)__popcll(x);
+    u += (unsigned long long)__popcll(x | y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); u += __shfl_down(u, o, 64); }
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_u[threadIdx.x >> 6] = u; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], s_a[0] + s_a[1] + s_a[2] + s_a[3]);
+    atomicAdd(&acc[1], s_u[0] + s_u[1] + s_u[2] + s_u[3]);
+    __threadfence();
+    s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long w[2] = {__hip_atomic_load(&acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                     __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+    ah_mailbox_post(mb, seq, w, 2);
+  }
+}
+
+// ---- 1b: regions instead of offsets (the reserving scatter) -----------------------------------------------------------------
+// The histogram pass reads the whole key column only to tell every tile where its run of every partition starts.  The
+// reserving scatter does without it: every (partition, XCD) pair owns a REGION of the record arrays, a tile reserves its run
+// with one returning atomicAdd on the region's cursor, and the passes behind it walk the regions through a table of
+// {virtual start, physical − virtual} per region (gb_segments_kernel).  One region per XCD and partition, not one per
+// partition: the runs one XCD appends to a partition stay neighbours in THAT XCD's L2 and leave as whole lines, exactly
+// as behind the offsets table — one cursor per partition interleaves the eight XCDs' runs line by line and the pass gets
+// SLOWER than hist + scatter from 512 partitions on (scripts/micro/scatter_reserve.hip, profiles/r05_scatter_reserve_micro.txt).
+// Which tile's run comes first inside a region depends on timing; nothing downstream depends on the order of a partition's
+// records (fixed-point sums, counts, minima of first rows; first-occurrence minima in the encode).
+// Region capacities come from the 2^21-row sample alone: (sampled rows S of the region + 6·√(S + 1)) × rows per sampled row + 64 —
+// six standard deviations of a count that is binomial in the region's true size, so a region of an honestly sampled column is too
+// small once in 10^9; all regions together need n + 6·√(regions · sampled rows) · scale ≤ 1.37 n rows at 1024 × 8 regions (the arrays
+// hold 1.5 n).  (A floor of 1.25 × the even share, the first version, pushed a Zipf column's total beyond that: its light
+// partitions were given far more than they hold.)  A region that turns out too small raises bit 2 of the redo word and the call
+// is redone with the histogram — a column whose hot keys the sample did not see in proportion.
+constexpr int kGbRegions = 8;   // regions per partition: the XCD (blockIdx & 7) the tile runs on
+__global__ __launch_bounds__(1024) void gb_layout_kernel(const unsigned* __restrict__ hist, int lp, int64_t n, int64_t xrows, double scale, int64_t cap_rows,
+                                                          unsigned* __restrict__ rstart, unsigned* __restrict__ rcap, unsigned* __restrict__ cursor,
+                                                          unsigned* __restrict__ redo) {
+  __shared__ unsigned s_tot[kMaxBins], s_start[kMaxBins], s_wsum[kThreads / 64];
+  __shared__ unsigned s_sum[kGbRegions][kMaxBins];
+  const int p = threadIdx.x, P = 1 << lp;
+  // the 1024 buckets of each eighth → P partitions (partition = the bucket's top lp bits): thread t brings bucket t of every eighth
+#pragma unroll
+  for (int x = 0; x < kGbRegions; x++) s_sum[x][p] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int x = 0; x < kGbRegions; x++) {
+    const unsigned h = hist[x * 1024 + p];
+    if (h) atomicAdd(&s_sum[x][p >> (10 - lp)], h);
+  }
+  __syncthreads();
+  unsigned cap[kGbRegions];
+  unsigned tot = 0;
+#pragma unroll
+  for (int x = 0; x < kGbRegions; x++) {
+    cap[x] = 0;
+    if (p < P) {
+      const unsigned sc = s_sum[x][p];
+      const int64_t rows_x = n - x * xrows < 0 ? 0 : (n - x * xrows < xrows ? n - x * xrows : xrows);   // rows of this eighth of the column
+      double want = ((double)sc + 6.0 * sqrt((double)sc + 1.0)) * scale + 64.0;
+      if (want > (double)rows_x) want = (double)rows_x;          // a region never needs more than its eighth's rows
+      cap[x] = ((unsigned)want + 15u) & ~15u;                    // regions start on whole lines of the 8-byte arrays
+      tot += cap[x];
+    }
+  }
+  s_tot[p] = tot;
+  __syncthreads();
+  block_excl_scan(s_tot, s_start, s_wsum, P);
+  if (p < P) {
+    unsigned at = s_start[p];
+#pragma unroll
+    for (int x = 0; x < kGbRegions; x++) {
+      rstart[p * kGbRegions + x] = at;
+      rcap[p * kGbRegions + x] = cap[x];
+      cursor[p * kGbRegions + x] = 0;
+      at += cap[x];
+    }
+    if (p == P - 1 && (int64_t)at > cap_rows) atomicOr(redo, 4u);   // the record arrays cannot hold the regions
+  }
+}
+
+// after the reserving scatter: the regions as seen by the passes behind it.  vstart[r] = position of region r's first record in
+// the DENSE order (partition by partition, XCD by XCD inside a partition; vstart[P·8] = n), delta[r] = physical − dense position,
+// binstart[p] = vstart[8p] (binstart[P] = n).  A cursor beyond its capacity or a total that is not n: bit 2 of the redo word.
+// tile_rng (nullable): the scatter's per-tile value ranges, reduced HERE to range[0..1] (gb_max_kernel) and checked
+// (fx_range_check_kernel) — two launches less on a path that is a chain of small launches.
+__global__ __launch_bounds__(1024) void gb_segments_kernel(const unsigned* __restrict__ rstart, const unsigned* __restrict__ rcap, const unsigned* __restrict__ cursor,
+                                                            int P, int64_t n, unsigned* __restrict__ vstart, unsigned* __restrict__ delta,
+                                                            unsigned* __restrict__ binstart, unsigned* __restrict__ redo,
+                                                            const unsigned long long* __restrict__ tile_rng, int64_t ntiles, unsigned long long* __restrict__ range) {
+  __shared__ unsigned s_tot[kMaxBins], s_start[kMaxBins], s_wsum[kThreads / 64];
+  __shared__ unsigned long long s_max[16], s_imin[16];
+  const int p = threadIdx.x;
+  unsigned cnt[kGbRegions];
+  unsigned tot = 0;
+  bool over = (*redo & 4u) != 0;   // void already (gb_layout_kernel: the regions did not fit the arrays)
+#pragma unroll
+  for (int x = 0; x < kGbRegions; x++) {
+    cnt[x] = 0;
+    if (p < P) {
+      cnt[x] = cursor[p * kGbRegions + x];
+      over = over || cnt[x] > rcap[p * kGbRegions + x];
+      tot += cnt[x];
+    }
+  }
+  // a void attempt leaves NO records to the passes behind it (cursors beyond their capacities are not positions in the arrays)
+  if (__syncthreads_or(over ? 1 : 0)) {
+    if (p < P) {
+      binstart[p] = 0;
+#pragma unroll
+      for (int x = 0; x < kGbRegions; x++) { vstart[p * kGbRegions + x] = 0; delta[p * kGbRegions + x] = 0; }
+    }
+    if (p == 0) { vstart[P * kGbRegions] = 0; binstart[P] = 0; atomicOr(redo, 4u); range[0] = 0; range[1] = 0; }
+    return;
+  }
+  s_tot[p] = tot;
+  __syncthreads();
+  block_excl_scan(s_tot, s_start, s_wsum, P);
+  if (p < P) {
+    unsigned at = s_start[p];
+    binstart[p] = at;
+#pragma unroll
+    for (int x = 0; x < kGbRegions; x++) {
+      vstart[p * kGbRegions + x] = at;
+      delta[p * kGbRegions + x] = rstart[p * kGbRegions + x] - at;
+      at += cnt[x];
+    }
+    if (p == P - 1) {
+      vstart[P * kGbRegions] = at;
+      binstart[P] = at;
+      if ((int64_t)at != n) over = true;
+    }
+    if (over) atomicOr(redo, 4u);
+  }
+  if (tile_rng) {
+    unsigned long long m = 0, im = 0;
+    for (int64_t i = threadIdx.x; i < ntiles; i += 1024) {
+      const unsigned long long t = tile_rng[2 * i], ti = tile_rng[2 * i + 1];
+      m = t > m ? t : m;
+      im = ti > im ? ti : im;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_down(m, o, 64), ti = __shfl_down(im, o, 64);
+      m = t > m ? t : m;
+      im = ti > im ? ti : im;
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = m; s_imin[threadIdx.x >> 6] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 16; w++) { m = s_max[w] > m ? s_max[w] : m; im = s_imin[w] > im ? s_imin[w] : im; }
+      range[0] = m;
+      range[1] = im;
+      if (fx_wide(m, im)) atomicOr(redo, 2u);
+    }
+  }
 }
 
 // ---- 1: per (tile, partition) counts ----------------------------------------------------------------------------------
@@ -83,12 +285,17 @@ __global__ __launch_bounds__(kGbHistThreads) void gb_hist_kernel(const unsigned 
 
 // ---- 2: records in partition order ------------------------------------------------------------------------------------
 // HAS_VALS = false: records are {key, row | null flag} only (unique / dictionary_encode, ah_hash_part.hip)
-template <bool HAS_VALS>
+// RESERVE = true: no offsets table — the tile reserves its runs in the regions of (partition, blockIdx & 7) (see 1b above);
+// toffs is null, rstart / rcap / cursor / redo describe the regions.
+template <bool HAS_VALS, bool RESERVE = false>
 __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
                                                                const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
                                                                int64_t n, int lp, int nb, int64_t ntiles, const unsigned* __restrict__ toffs,
                                                                unsigned long long* __restrict__ pkeys, unsigned long long* __restrict__ pvals,
-                                                               unsigned* __restrict__ prows, unsigned long long* __restrict__ tile_max) {
+                                                               unsigned* __restrict__ prows, unsigned long long* __restrict__ tile_max,
+                                                               const unsigned* __restrict__ rstart = nullptr, const unsigned* __restrict__ rcap = nullptr,
+                                                               unsigned* __restrict__ cursor = nullptr, unsigned* __restrict__ redo = nullptr,
+                                                               unsigned trash_base = 0) {
   __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_goff[kMaxBins], s_wsum[kThreads / 64];
   __shared__ unsigned long long s_stage[kGbTile];
   __shared__ uint16_t s_bin[kGbTile];
@@ -97,6 +304,13 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
   // consecutive tiles on ONE XCD: the runs they append to a partition meet in that XCD's L2 and leave as whole lines
   const int64_t tile = xcd_contiguous_tile(ntiles);
   if (tile < 0) return;
+  if (RESERVE) {   // void already (the regions did not fit the arrays, or an earlier tile's run did not fit its region): nothing to write
+    if (threadIdx.x == 0) s_wsum[0] = __hip_atomic_load(redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u;
+    __syncthreads();
+    const unsigned dead = s_wsum[0];
+    __syncthreads();
+    if (dead) return;
+  }
   s_cnt[threadIdx.x] = 0;
   const int64_t base = tile * kGbTile;
   unsigned long long k[kGbRows], v[kGbRows];
@@ -110,7 +324,7 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
     v[u] = (HAS_VALS && live[u]) ? __builtin_nontemporal_load(&vals[i]) : 0ull;
   }
   unsigned goff_excl = 0;
-  if ((int)threadIdx.x < nb) goff_excl = toffs[tile * nb + threadIdx.x];
+  if (!RESERVE && (int)threadIdx.x < nb) goff_excl = toffs[tile * nb + threadIdx.x];
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kGbRows; u++) {
@@ -137,8 +351,23 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
     }
   }
   __syncthreads();
+  bool over = false;
+  if (RESERVE && (int)threadIdx.x < nb) {
+    // the tile's run of partition b starts where the region's cursor stood: one returning atomic per (tile, partition with rows),
+    // issued as soon as the counts are final and consumed after the scan below
+    const unsigned cnt = s_cnt[threadIdx.x];
+    if (cnt) {
+      const int r = (int)threadIdx.x * kGbRegions + (int)(blockIdx.x & (kGbRegions - 1));
+      const unsigned at = atomicAdd(&cursor[r], cnt);
+      over = at + cnt > rcap[r];
+      goff_excl = rstart[r] + at;
+    }
+  }
   block_excl_scan(s_cnt, s_start, s_wsum, nb);
-  if ((int)threadIdx.x < nb) s_goff[threadIdx.x] = goff_excl - s_start[threadIdx.x];
+  // a run that does not fit its region goes to kGbTile spare rows behind the regions (trash_base; position = the staged position):
+  // the call is void and redone with the histogram.  (mod 2^32 below: a region may start below the tile's own prefix)
+  if ((int)threadIdx.x < nb) s_goff[threadIdx.x] = over ? trash_base : goff_excl - s_start[threadIdx.x];
+  if (RESERVE && over) atomicOr(redo, 4u);
   const int tile_n = n - base >= kGbTile ? kGbTile : (int)(n - base);
   // three rounds through one staging buffer: keys, value bits, row words
 #pragma unroll
@@ -149,7 +378,8 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
 #pragma unroll
   for (int u = 0; u < kGbRows; u++) {
     const int q = u * kThreads + threadIdx.x;
-    dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
+    if (RESERVE) dst[u] = q < tile_n ? (int64_t)(unsigned)(s_goff[s_bin[q]] + (unsigned)q) : -1;
+    else dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
     if (dst[u] >= 0) pkeys[dst[u]] = s_stage[q];   // PLAIN stores: a partition's short runs (32 bytes at 1024 partitions) from consecutive tiles meet in this XCD's L2 and
                                                    // leave as whole lines — with nontemporal hints the pass ran 2× slower at 2^20 groups (2^26 rows: 1.46 → 3.1 ms per call)
   }

@@ -167,6 +167,18 @@ __global__ __launch_bounds__(kBlock) void sum_final_kernel(const Acc* __restrict
   if (threadIdx.x == 0) *out = (T)res.result();
 }
 
+// Float64 columns of at most 31 rows: ONE lane, acc = +0.0, acc += x left to right.  Up to 31 rows the reference's AVX2 kernel
+// is this very loop (arrow/math/_lib/float64_avx2.s:16-17: cmp rsi, 31 ; jbe → the scalar vaddsd loop at .LBB0_4) and so is the
+// pure-Go path (arrow/math/float64.go:41-47): there is exactly one reference answer, intermediate overflow included
+// ([1e308, 1e308, -1e308] → +inf), and this kernel returns its bytes.  From 32 rows on the two reference orders differ from each
+// other and the order-free accumulator above answers.
+constexpr size_t kSeqRows = 31;
+__global__ void sum_seq_f64_kernel(const double* __restrict__ buf, int n, double* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = 0; i < n; i++) acc += buf[i];
+  *out = acc;
+}
+
 template <typename T, typename Acc>
 int sum_dev(ah_ctx* c, const T* buf, size_t len, T* res_dev) {
   if (len == 0) {
@@ -174,6 +186,13 @@ int sum_dev(ah_ctx* c, const T* buf, size_t len, T* res_dev) {
     return AH_OK;
   }
   if (((uintptr_t)buf & (sizeof(T) - 1)) != 0) return ah_fail(c, AH_EINVALID, "sum: buffer not element-aligned");
+  if constexpr (Acc::kClassed) {
+    if (len <= kSeqRows) {
+      sum_seq_f64_kernel<<<1, 1, 0, c->stream>>>((const double*)buf, (int)len, (double*)res_dev);
+      AH_LAUNCH_CHECK(c);
+      return AH_OK;
+    }
+  }
   // peel to 16-byte alignment (≤ 1 element), vector body, ≤ 1 element tail
   int nhead = (int)((((uintptr_t)buf & 15) != 0) ? 1 : 0);
   if ((size_t)nhead > len) nhead = (int)len;
@@ -241,6 +260,10 @@ size_t ah_sum_partial_bytes(int is_f64) { return is_f64 ? sizeof(AccDD) : sizeof
 int ah_sum_chunk_partials(ah_ctx* c, int is_f64, const void* buf, size_t len, void* partials, int max_partials, int* n_written) {
   if (is_f64) return sum_chunk<double, AccDD>(c, (const double*)buf, len, (AccDD*)partials, max_partials, n_written);
   return sum_chunk<uint64_t, AccU64>(c, (const uint64_t*)buf, len, (AccU64*)partials, max_partials, n_written);
+}
+// internal (ah_ingest.hip): a whole Float64 column of ≤ 31 rows that arrived in one chunk — the reference's sequential order
+int ah_sum_short_f64(ah_ctx* c, const void* buf, size_t len, void* res_dev) {
+  return sum_dev<double, AccDD>(c, (const double*)buf, len, (double*)res_dev);
 }
 int ah_sum_finish_partials(ah_ctx* c, int is_f64, const void* partials, int n, void* res_dev) {
   if (n <= 0) { AH_HIP(c, hipMemsetAsync(res_dev, 0, 8, c->stream)); return AH_OK; }

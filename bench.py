@@ -171,6 +171,47 @@ def cpu_baseline_mt():
                       f"repetitions ({best[2]:.1f} ms per step; whole measurement {time.perf_counter() - t0:.0f} s)", "all": r}
 
 
+def cpu_baseline_c3_c5():
+    """CPU baselines beside configs C3 and C5: the oracle's C ports of the reference's Go kernels (the reference has no assembly for
+    them) on the host cores — PrimitiveFilter at s = 0.5 with 10 % nulls and PrimitiveTake with uniformly random Int32 indices and
+    10 % nulls on both sides (kernels/vector_selection.go:267-395, 878-988), on 1 thread and on all cores (contiguous shards, as a
+    chunked column under ExecCtx.NumParallel); dictionary_encode over 2^16 keys and the hash + sum built on it
+    (hashing/xxh3_memo_table_types.go:283-294, vector_hash.go:359-385) on ONE core — the reference feeds every chunk through one memo
+    table.  2^24 rows; the ports are checked against the reference's golden vectors (tests/test_golden.py) before anything is timed."""
+    import subprocess
+    import numpy as np
+    from tests import test_golden as TG
+    from tests.backends import OracleBackend
+    be = OracleBackend()
+    TG.test_filter_vectors(be, np.int64, False)
+    TG.test_filter_null_payload_rules(be)
+    TG.test_take_vectors(be, np.int64, np.int32)
+    TG.test_unique_vectors(be, np.int64)
+    TG.test_dictionary_encode_vectors(be)
+    TG.test_dictionary_encode_resizes_memo_table(be)
+    exe = os.path.join(ROOT, "oracle", "_ref", "bench_port_mt")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/bench_port_mt not built (make -C oracle port_bench)"}, {"error": "oracle/_ref/bench_port_mt not built"}
+    nproc = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    r = json.loads(subprocess.run([exe, os.path.join(ROOT, "oracle"), "24", "1", str(nproc)], capture_output=True, text=True, timeout=300, check=True).stdout)
+    took = time.perf_counter() - t0
+    note = (f"oracle C ports (kind 'port': the reference's kernels for this config are Go, restated in oracle/orc_select.c / orc_hash.c and pinned to its "
+            f"golden vectors, checked again before this timing), {r['rows']} rows, best of 3 repetitions; whole measurement {took:.0f} s")
+    f1, fn = r["filter_int64_nulls10_sel0.50_threads1"], r[f"filter_int64_nulls10_sel0.50_threads{nproc}"]
+    t1, tn = r["take_int64_random_i32_nulls10_threads1"], r[f"take_int64_random_i32_nulls10_threads{nproc}"]
+    c3 = {"value": f1["GB/s"], "unit": "GB/s (Filter s = 0.5, 10 % nulls: algorithmic bytes, as the GPU line counts them)", "cores": 1, "kind": "port",
+          "sample": "PrimitiveFilter (Drop) " + note,
+          "filter": {"threads1": f1, f"threads{nproc}": fn}, "take_random_i32_nulls10": {"threads1": t1, f"threads{nproc}": tn},
+          "all_cores": {"cores": nproc, "filter_GB/s": fn["GB/s"], "take_GB/s": tn["GB/s"]}}
+    e1, h1 = r["dictionary_encode_int64_2^16_keys_threads1"], r["hash_sum_float64_2^16_groups_threads1"]
+    c5 = {"value": h1["Mrows/s"], "unit": "M rows/s (hash + sum, 2^16 groups)", "cores": 1, "kind": "port",
+          "sample": "dictionary_encode + row-order accumulation " + note + "; one core only: the reference's memo table is one sequential structure "
+                    "shared by all chunks of a column (vector_hash.go), so there is no N-core figure to quote for it",
+          "dictionary_encode_2^16_keys": e1, "hash_sum_float64_2^16_groups": h1}
+    return c3, c5
+
+
 def random_bits(rng, n, p, pad=64):
     """n Bernoulli(p) bits packed LSB-first"""
     out = np.zeros(n // 8 + pad, np.uint8)
@@ -760,6 +801,10 @@ def main():
                 result["cpu_baseline_mt"] = cpu_baseline_mt()
             except Exception as e:
                 result["cpu_baseline_mt"] = {"error": repr(e)}
+            try:
+                result["cpu_baseline_c3"], result["cpu_baseline_c5"] = cpu_baseline_c3_c5()
+            except Exception as e:
+                result["cpu_baseline_c3"] = result["cpu_baseline_c5"] = {"error": repr(e)}
         emit(result)
     secondary_done.set()
     if comm is not None:

@@ -20,7 +20,9 @@ for lg, zipf in ((12, False), (16, False), (18, False), (20, False), (20, True),
         k = (rng.zipf(1.1, 1 << 22) % (1 << lg)) if zipf else rng.integers(0, 1 << lg, 1 << 22)
         keys.upload((k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64), off * 8)
     r = {}
-    r["f64_ms"] = timed(lambda: ctx.hash_sum("f64", keys, None, 0, vals, None, 0, n, *[o.ptr for o in outs]), reps=10)
-    r["i64_ms"] = timed(lambda: ctx.hash_sum("i64", keys, None, 0, vals, None, 0, n, *[o.ptr for o in outs]))
+    for reserve in (0, 1):   # histogram → offsets → scatter against the reserving scatter (ah_partition.h 1b)
+        ctx.set_option("groupby_reserve", reserve)
+        r[f"f64_reserve{reserve}_ms"] = timed(lambda: ctx.hash_sum("f64", keys, None, 0, vals, None, 0, n, *[o.ptr for o in outs]), reps=10)
+        r[f"i64_reserve{reserve}_ms"] = timed(lambda: ctx.hash_sum("i64", keys, None, 0, vals, None, 0, n, *[o.ptr for o in outs]))
     res[f"2^{lg}{'_zipf' if zipf else ''}"] = r
 print(json.dumps(res))

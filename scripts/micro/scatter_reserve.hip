@@ -8,7 +8,8 @@
 //   /tmp/scatter_reserve [log2 rows = 26] [log2 groups = 16]
 // Prints µs per kernel for both pipelines at 64 and 1024 partitions and checks that every partition holds the same multiset of
 // {key, value, row} records either way (an order-independent checksum per partition).
-// NOT RUN YET: written after the round's GPU budget was spent; it compiles for gfx950.
+// Round 5: each partition's region can be cut into NX sub-regions, one per XCD (cursor (p, blockIdx & 7)): the runs one XCD appends
+// to a partition then stay neighbours in THAT L2 and leave as whole lines, as they do behind the offsets table.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -24,7 +25,7 @@ namespace {
 template <bool HAS_VALS>
 __global__ __launch_bounds__(kThreads) void gb_scatter_reserve_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ kvalid, int64_t koff,
                                                                const unsigned long long* __restrict__ vals, const uint8_t* __restrict__ vvalid, int64_t voff,
-                                                               int64_t n, int lp, int nb, int64_t ntiles, const unsigned* __restrict__ rstart, const unsigned* __restrict__ rcap,
+                                                               int64_t n, int lp, int nb, int nx, int64_t ntiles, const unsigned* __restrict__ rstart, const unsigned* __restrict__ rcap,
                                                                unsigned* __restrict__ cursor, unsigned* __restrict__ overflow,
                                                                unsigned long long* __restrict__ pkeys, unsigned long long* __restrict__ pvals,
                                                                unsigned* __restrict__ prows, unsigned long long* __restrict__ tile_max) {
@@ -81,9 +82,10 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_reserve_kernel(const unsi
   if ((int)threadIdx.x < nb) {
     const unsigned cnt = s_cnt[threadIdx.x];
     if (cnt) {
-      const unsigned at = atomicAdd(&cursor[threadIdx.x], cnt);
-      over = at + cnt > rcap[threadIdx.x];
-      goff_excl = rstart[threadIdx.x] + at;
+      const int seg = (int)threadIdx.x * nx + (nx > 1 ? (int)(blockIdx.x & 7) % nx : 0);
+      const unsigned at = atomicAdd(&cursor[seg], cnt);
+      over = at + cnt > rcap[seg];
+      goff_excl = rstart[seg] + at;
     }
   }
   block_excl_scan(s_cnt, s_start, s_wsum, nb);
@@ -166,11 +168,11 @@ __global__ void gen_kernel(unsigned long long* keys, unsigned long long* vals, i
 
 // order-independent checksum and count of the records in [start[p], start[p] + cnt[p])
 __global__ void check_kernel(const unsigned long long* pkeys, const unsigned long long* pvals, const unsigned* prows, const unsigned* start, const unsigned* cnt,
-                             int lp, unsigned long long* sums, unsigned* bad) {
-  const int p = blockIdx.x;
+                             int lp, int nx, unsigned long long* sums, unsigned* bad) {
+  const int p = blockIdx.x / nx;
   unsigned long long s = 0;
-  for (unsigned j = threadIdx.x; j < cnt[p]; j += blockDim.x) {
-    const size_t q = (size_t)start[p] + j;
+  for (unsigned j = threadIdx.x; j < cnt[blockIdx.x]; j += blockDim.x) {
+    const size_t q = (size_t)start[blockIdx.x] + j;
     s += gb_mix(pkeys[q] ^ (pvals[q] * 0xD6E8FEB86659FD93ull) ^ ((unsigned long long)prows[q] << 17));
     if (gb_part(gb_mix(pkeys[q]), lp) != (unsigned)p) atomicAdd(bad, 1u);
   }
@@ -187,22 +189,23 @@ int main(int argc, char** argv) {
   unsigned long long *keys, *vals, *pkeys, *pvals, *pkeys2, *pvals2, *tile_max, *sums;
   unsigned *prows, *prows2, *cnt_tm, *toffs, *gsum, *binstart, *rstart, *rcap, *cursor, *flags;
   const int64_t ntiles = (n + kGbTile - 1) / kGbTile, ngrp = (ntiles + kGroupTiles - 1) / kGroupTiles;
-  const size_t cap_rows = (size_t)(n * 5 / 4) + (size_t)kMaxBins * 4096 + 4096;
+  const size_t cap_rows = (size_t)(n * 5 / 4) + (size_t)kMaxBins * 8 * 1024 + 4096;
   CK(hipMalloc(&keys, n * 8)); CK(hipMalloc(&vals, n * 8));
   CK(hipMalloc(&pkeys, n * 8)); CK(hipMalloc(&pvals, n * 8)); CK(hipMalloc(&prows, n * 4));
   CK(hipMalloc(&pkeys2, cap_rows * 8)); CK(hipMalloc(&pvals2, cap_rows * 8)); CK(hipMalloc(&prows2, cap_rows * 4));
   CK(hipMalloc(&cnt_tm, (size_t)ntiles * kMaxBins * 4)); CK(hipMalloc(&toffs, (size_t)ntiles * kMaxBins * 4)); CK(hipMalloc(&gsum, (size_t)ngrp * kMaxBins * 4));
-  CK(hipMalloc(&binstart, (kMaxBins + 1) * 4)); CK(hipMalloc(&rstart, kMaxBins * 4)); CK(hipMalloc(&rcap, kMaxBins * 4)); CK(hipMalloc(&cursor, kMaxBins * 4));
+  CK(hipMalloc(&binstart, (kMaxBins + 1) * 4)); CK(hipMalloc(&rstart, kMaxBins * 8 * 4)); CK(hipMalloc(&rcap, kMaxBins * 8 * 4)); CK(hipMalloc(&cursor, kMaxBins * 8 * 4));
   CK(hipMalloc(&flags, 64)); CK(hipMalloc(&tile_max, (size_t)ntiles * 16)); CK(hipMalloc(&sums, 2 * kMaxBins * 8));
   gen_kernel<<<(unsigned)((n + 255) / 256), 256>>>(keys, vals, n, 1ull << lgg);
   CK(hipDeviceSynchronize());
   hipEvent_t ev[8];
   for (auto& e : ev) CK(hipEventCreate(&e));
   const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
-  for (int lp : {6, 10}) {
+  for (int lpnx : {6, 9, 10, 6 + 16, 9 + 16, 10 + 16}) {
+    const int lp = lpnx & 15, nx = lpnx >= 16 ? 8 : 1;
     const int P = 1 << lp;
     float best[6] = {1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f};
-    std::vector<unsigned> h_start(P + 1), h_rstart(P), h_rcap(P), h_cnt(P), h_cur(P);
+    std::vector<unsigned> h_start(P + 1), h_rstart(P * nx), h_rcap(P * nx), h_cnt(P), h_cur(P * nx);
     for (int rep = 0; rep < 5; rep++) {
       // ---- as shipped: hist → offsets (3 kernels) → scatter
       CK(hipEventRecord(ev[0]));
@@ -220,17 +223,20 @@ int main(int argc, char** argv) {
       unsigned at = 0;
       for (int p = 0; p < P; p++) {
         h_cnt[p] = h_start[p + 1] - h_start[p];
-        h_rcap[p] = h_cnt[p] + h_cnt[p] / 4 + 4096;
-        h_rstart[p] = at;
-        at += h_rcap[p];
+        for (int x = 0; x < nx; x++) {
+          const unsigned share = h_cnt[p] / nx;
+          h_rcap[p * nx + x] = (share + share / 4 + (nx > 1 ? 1024 : 4096) + 15u) & ~15u;   // (sub-regions start on 128-byte lines of the key array)
+          h_rstart[p * nx + x] = at;
+          at += h_rcap[p * nx + x];
+        }
       }
       if ((size_t)at > cap_rows) { fprintf(stderr, "regions need %u rows, %zu allocated\n", at, cap_rows); return 1; }
-      CK(hipMemcpy(rstart, h_rstart.data(), P * 4, hipMemcpyHostToDevice));
-      CK(hipMemcpy(rcap, h_rcap.data(), P * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(rstart, h_rstart.data(), P * nx * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(rcap, h_rcap.data(), P * nx * 4, hipMemcpyHostToDevice));
       CK(hipEventRecord(ev[4]));
-      CK(hipMemsetAsync(cursor, 0, P * 4));
+      CK(hipMemsetAsync(cursor, 0, P * nx * 4));
       CK(hipMemsetAsync(flags, 0, 64));
-      gb_scatter_reserve_kernel<true><<<tgrid, kThreads>>>(keys, nullptr, 0, vals, nullptr, 0, n, lp, P, ntiles, rstart, rcap, cursor, flags, pkeys2, pvals2, prows2, tile_max);
+      gb_scatter_reserve_kernel<true><<<tgrid, kThreads>>>(keys, nullptr, 0, vals, nullptr, 0, n, lp, P, nx, ntiles, rstart, rcap, cursor, flags, pkeys2, pvals2, prows2, tile_max);
       CK(hipEventRecord(ev[5]));
       CK(hipDeviceSynchronize());
       const float t[6] = {ms_between(ev[0], ev[1]), ms_between(ev[1], ev[2]), ms_between(ev[2], ev[3]), ms_between(ev[0], ev[3]), ms_between(ev[4], ev[5]), 0};
@@ -239,17 +245,17 @@ int main(int argc, char** argv) {
     // ---- same records either way?
     unsigned h_flags[2];
     CK(hipMemcpy(h_flags, flags, 8, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(h_cur.data(), cursor, P * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h_cur.data(), cursor, P * nx * 4, hipMemcpyDeviceToHost));
     bool ok = h_flags[0] == 0;
-    for (int p = 0; p < P; p++) ok = ok && h_cur[p] == h_cnt[p];
+    for (int p = 0; p < P; p++) { unsigned t = 0; for (int x = 0; x < nx; x++) t += h_cur[p * nx + x]; ok = ok && t == h_cnt[p]; }
     CK(hipMemset(sums, 0, 2 * kMaxBins * 8));
     CK(hipMemset(flags, 0, 64));
     unsigned *d_start_a, *d_cnt;
     CK(hipMalloc(&d_start_a, P * 4)); CK(hipMalloc(&d_cnt, P * 4));
     CK(hipMemcpy(d_start_a, h_start.data(), P * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_cnt, h_cnt.data(), P * 4, hipMemcpyHostToDevice));
-    check_kernel<<<P, 1024>>>(pkeys, pvals, prows, d_start_a, d_cnt, lp, sums, flags + 1);
-    check_kernel<<<P, 1024>>>(pkeys2, pvals2, prows2, rstart, d_cnt, lp, sums + kMaxBins, flags + 1);
+    check_kernel<<<P, 1024>>>(pkeys, pvals, prows, d_start_a, d_cnt, lp, 1, sums, flags + 1);
+    check_kernel<<<P * nx, 1024>>>(pkeys2, pvals2, prows2, rstart, cursor, lp, nx, sums + kMaxBins, flags + 1);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h_sums(2 * kMaxBins);
     CK(hipMemcpy(h_sums.data(), sums, 2 * kMaxBins * 8, hipMemcpyDeviceToHost));
@@ -257,8 +263,9 @@ int main(int argc, char** argv) {
     for (int p = 0; p < P; p++) ok = ok && h_sums[p] == h_sums[kMaxBins + p];
     ok = ok && h_flags[1] == 0;
     CK(hipFree(d_start_a)); CK(hipFree(d_cnt));
-    printf("2^%d rows, 2^%d groups, %4d partitions: hist %.1f us + offsets %.1f us + scatter %.1f us = %.1f us | fill + reserving scatter %.1f us | %s\n", lgn, lgg, P,
+    printf("2^%d rows, 2^%d groups, %4d partitions x %d regions: hist %.1f us + offsets %.1f us + scatter %.1f us = %.1f us | fill + reserving scatter %.1f us | %s\n", lgn, lgg, P, nx,
            best[0] * 1e3f, best[1] * 1e3f, best[2] * 1e3f, best[3] * 1e3f, best[4] * 1e3f, ok ? "same records" : "MISMATCH");
+    fflush(stdout);
   }
   return 0;
 }

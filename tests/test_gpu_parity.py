@@ -671,6 +671,47 @@ def test_hash_sum_partition_first(hip, orc_be, ctx, n, card, mode, hot):
         assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes(), k
 
 
+@pytest.mark.parametrize("mode", [5, 8, 11, 12])
+def test_hash_sum_reserving_scatter(hip, orc_be, ctx, mode):
+    """ah_partition.h 1b: the scatter that reserves its runs in per-(partition, XCD) regions sized from the key sample (option
+    groupby_reserve, the default) against the histogram → offsets → scatter pipeline: the same bytes, on evenly spread keys, with a hot
+    key and null keys (partition 0), and on a column whose hot key the sample CANNOT see in proportion — every sampled row (64 of each
+    256) avoids it — so that its region overflows, the attempt is void and the call is redone with the histogram."""
+    rng = np.random.default_rng(900 + mode)
+    n = (1 << 23) + 4321
+    cases = []
+    keys, kvalid, vvalid = _hash_sum_cases(rng, n, 40000 if mode < 11 else 900000, 0.0)
+    cases.append(("even", keys, kvalid, vvalid))
+    keys, kvalid, vvalid = _hash_sum_cases(rng, n, 40000 if mode < 11 else 900000, 0.3)
+    cases.append(("hot", keys, kvalid, vvalid))
+    keys, kvalid, vvalid = _hash_sum_cases(rng, n, 40000 if mode < 11 else 900000, 0.0)
+    hidden = (np.arange(n) % 256 >= 64) & (np.arange(n) < (1 << 20))      # the sample reads rows g·256 … g·256 + 63
+    keys[hidden] = 11 * 1000003
+    cases.append(("hidden hot key", keys, kvalid, vvalid))
+    for name, keys, kvalid, vvalid in cases:
+        iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+        fv = (1.0 + rng.random(n)) * np.exp(rng.uniform(-12, 12, n)) * rng.choice([-1.0, 1.0], n)
+        res = {}
+        try:
+            ctx.set_option("groupby_partition", mode)
+            for reserve in (0, 1):
+                ctx.set_option("groupby_reserve", reserve)
+                res[reserve] = [hip.hash_sum(k, keys, kvalid, 3, v, vvalid, 5) for k, v in (("i64", iv), ("f64", fv))]
+            again = hip.hash_sum("f64", keys, kvalid, 3, fv, vvalid, 5)
+        finally:
+            ctx.set_option("groupby_partition", 1)
+            ctx.set_option("groupby_reserve", 1)
+        for a, b in zip(res[0], res[1]):
+            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes(), (name, mode)
+            assert a[3] == b[3] and a[4].tobytes() == b[4].tobytes(), (name, mode)
+        assert again[1].tobytes() == res[1][1][1].tobytes(), (name, mode)      # run to run
+        e = orc_be.hash_sum("i64", keys, kvalid, 3, iv, vvalid, 5)
+        g = res[1][0]
+        for a, b in zip(g[:3], e[:3]):
+            assert a.tobytes() == b.tobytes(), (name, mode)
+        assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes(), (name, mode)
+
+
 def test_hash_sum_partition_first_auto(hip, orc_be):
     """the automatic choice (≥ 2^21 rows; partitions from a sampled distinct estimate), skewed keys included"""
     rng = np.random.default_rng(77)

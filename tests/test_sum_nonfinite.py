@@ -2,7 +2,11 @@
 ah_sum_float64, ah_sum_float64_dev, ah_cmp_filter_sum_f64, ah_cmp_filter_sum_f64_dev, ah_ingest_sum_float64 (and, with two and
 three ranks on one GPU, ah_comm_cmp_filter_sum_f64: scripts/dist_gpu_ranks.py; at 2^27 rows: tests/test_full_size.py).
 
-The rule: the sum over the extended reals, rounded once.  Expected values come from the oracle's fixed-point
+Columns of at most 31 rows through the three Sum entry points are the exception: there both reference paths are ONE sequential loop
+(arrow/math/_lib/float64_avx2.s:16-17 `cmp rsi, 31 ; jbe`, arrow/math/float64.go:41-47) and the device returns that loop's bytes,
+intermediate overflow included (tests/test_sum_short.py); the fused chain has no reference counterpart and stays on the rule.
+
+The rule, from 32 rows on: the sum over the extended reals, rounded once.  Expected values come from the oracle's fixed-point
 superaccumulator (orc_sum_float64_xreal) and — for every case in which the reference's two summation orders agree with each other —
 from BOTH reference orders run here: oracle/_ref's AVX2 machine code (ref.sum("avx2")) and its strict-sequential C (ref.sum("seq")),
 arrow/math/float64.go:41-47, _lib/float64.c:20-26.  The special rows are placed where the kernel treats rows differently: the
@@ -28,7 +32,8 @@ CASES = {
     "+inf twice": ([inf, inf], True),
     "three 1e308": ([1e308] * 3, True),
     "three -1e308": ([-1e308] * 3, True),
-    # the running sum of a reference order may or may not pass through ±inf here, depending on where the rows sit: only the rule is checked
+    # from 32 rows on the running sum of a reference order may or may not pass through ±inf here, depending on where the rows sit:
+    # only the rule is checked (up to 31 rows there is one reference order, and seq_sum below is it)
     "1e308 twice and back": ([1e308, 1e308, -1e308, -1e308], False),
     "overflow then the other infinity": ([1e308, 1e308, 1e308, -inf], False),
 }
@@ -61,6 +66,21 @@ def place(rng, n, special, where):
     return col
 
 
+def seq_sum(col):
+    """acc = +0.0; acc += x left to right in IEEE doubles: arrow/math/float64.go:41-47, and _lib/float64_avx2.s below 32 rows"""
+    acc = 0.0
+    for v in col.tolist():
+        acc += v
+    return acc
+
+
+def check_short(got, col, ref, label):
+    want = seq_sum(col)
+    assert same(got, want) and (math.isnan(want) or np.float64(got).tobytes() == np.float64(want).tobytes()), (label, got, want)
+    if ref is not None:
+        assert same(want, float(ref.sum("seq", col))) and same(want, float(ref.sum("avx2", col))), label
+
+
 def check_value(got, want, label):
     if math.isfinite(want):
         assert math.isfinite(got) and abs(got - want) <= math.ulp(want), (label, got, want)
@@ -90,9 +110,15 @@ def test_sum_float64_extended_reals(ctx, refs, name, n):
             buf.upload(col, misalign * 8)
             p = buf.ptr + misalign * 8
             label = (name, where, n, misalign)
-            check_value(ctx.sum_float64(p, n), want, label)                      # ah_sum_float64
+            got = ctx.sum_float64(p, n)                                          # ah_sum_float64
             ctx.sum_float64_dev(p, n, res)                                       # ah_sum_float64_dev
-            check_value(float(res.download(np.float64, 1)[0]), want, label)
+            got_dev = float(res.download(np.float64, 1)[0])
+            if n <= 31:
+                check_short(got, col, ref, label)
+                check_short(got_dev, col, ref, label)
+                continue
+            check_value(got, want, label)
+            check_value(got_dev, want, label)
 
 
 @pytest.mark.parametrize("n", [3, 8192, (1 << 20) + 7])
@@ -147,7 +173,10 @@ def test_ingest_sum_float64_extended_reals(ctx, refs, chunk_kib, depth):
                     pb = ctx.alloc_pinned(col.nbytes + 64)
                     v = pb.view(np.float64, n)
                     v[...] = col
-                    check_value(ing.sum_float64(v, n), want, (name, where, n))
+                    if n <= 31:
+                        check_short(ing.sum_float64(v, n), col, ref, (name, where, n))
+                    else:
+                        check_value(ing.sum_float64(v, n), want, (name, where, n))
                     pb.free()
     finally:
         ing.close()
