@@ -66,10 +66,10 @@ struct ah_ctx {
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   int capturing;           // between ah_graph_begin and ah_graph_end: the compute stream records instead of running
   ah_filter_cache fcache;  // ah_filter.hip
-  int opt_scan_onepass;    // cumulative_sum of unchecked 4- and 8-byte integers without nulls: 1 (default) one pass with decoupled look-back over 128 KiB tiles, 0 reduce-then-scan
+  int opt_scan_onepass;    // cumulative_sum of 4- and 8-byte integers (checked or not, nulls or not): 1 (default) one pass with decoupled look-back over 128 KiB tiles, 0 reduce-then-scan, 3 one pass for unchecked columns without nulls only
   void* scan_recs;         // … its tile records (only that kernel writes them: stale words carry older epochs) and, in the last 64 bytes, its ticket word
   size_t scan_recs_bytes;
-  unsigned scan_epoch, scan_ticket_base;
+  unsigned scan_epoch;
   int opt_groupby_seed;    // direct group-by: 1 (default) the workgroups' LDS tables start from the quick look's keys and are added up slot by slot, 0 empty tables merged with atomics
   int opt_groupby_reserve; // partitioned group-by: 1 (default) the scatter reserves its runs in per-(partition, XCD) regions sized from the sample — no histogram pass —, 0 histogram → offsets → scatter
   int opt_groupby_lean;    // direct group-by: 0 always keep a pending group per lane, 1 (default) leave it out when the quick look says neighbouring rows rarely share a key, 2 always leave it out

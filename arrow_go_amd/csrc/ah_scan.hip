@@ -480,10 +480,38 @@ __device__ __forceinline__ bool op_rec_load(const u64* rec, unsigned marker, u64
   return true;
 }
 
-// E = the accumulator = the element's unsigned twin (uint32 / uint64): rows are summed modulo 2^32 / 2^64
-template <typename E>
+// The validity bits of the lane's kOpVpt vectors, packed (bit k·V + j = element j of vector k).  The wave's chunk is 512·V rows =
+// 8·V bitmap words: lane w < 8·V reads word w (any bit offset; rows at or beyond `end` — the first null when nulls are not skipped,
+// or n — read as null), and every lane picks its V bits of vector k out of lane k·V + (lane·V >> 6)'s word with one cross-lane read.
+// ONE register per lane through the look-back (eight words would not fit: the first version, scalar loads per vector, spilled).
+template <int V>
+__device__ __forceinline__ unsigned op_lane_bits(const uint8_t* __restrict__ valid, int64_t off, int64_t wbase, int64_t end, int lane) {
+  u64 myword = 0;
+  if (lane < kOpVpt * V) {
+    const int64_t wpos = wbase + 64 * (int64_t)lane, left = end - wpos;
+    myword = ah_load_bits64(valid, off + wpos, left >= 64 ? 64 : (left < 0 ? 0 : (int)left));
+  }
+  unsigned vbits = 0;
+#pragma unroll
+  for (int k = 0; k < kOpVpt; k++) {
+    const u64 w = __shfl(myword, k * V + ((lane * V) >> 6), 64);
+    vbits |= ((unsigned)(w >> ((lane * V) & 63)) & ((1u << V) - 1u)) << (k * V);
+  }
+  return vbits;
+}
+
+// E = the accumulator = the element's unsigned twin (uint32 / uint64): rows are summed modulo 2^32 / 2^64.
+// NULLS: a null row (validity bit 0, or a row from `limit` on) adds nothing and its output is the zero of a fresh buffer
+// (vector_cumulative.go:270-284, 300-318).
+// CHECKED (vector_cumulative.go:147-160 checkedAddSigned / Unsigned at every step of the sequential loop): with s_i the running sum
+// modulo 2^W, "some running sum left the type's range" ⟺ "some step s_(i−1) + x_i overflows as an addition of W-bit numbers" — the
+// first sum to leave the range comes from an exact s_(i−1), so its step's test fires; no sum leaves it ⟹ every s_i is exact and no
+// test fires.  Each row's test needs s_(i−1), s_i and x_i = s_i − s_(i−1) only: the prefixes this kernel has anyway.  SIGNED picks
+// the test.  The flag is a sticky word all tiles OR into; nothing travels through the look-back records.
+template <typename E, bool NULLS = false, bool CHECKED = false, bool SIGNED = false>
 __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_onepass_kernel(
-    const E* __restrict__ in, E* __restrict__ out, int64_t n, E start, u64* __restrict__ recs, unsigned* __restrict__ ticket, unsigned ticket_base, unsigned epoch) {
+    const E* __restrict__ in, E* __restrict__ out, int64_t n, E start, u64* __restrict__ recs, unsigned* __restrict__ ticket, unsigned ticket_base, unsigned epoch,
+    const uint8_t* __restrict__ valid = nullptr, int64_t off = 0, int64_t limit = 0, unsigned* __restrict__ overflow = nullptr) {
   constexpr int V = 16 / sizeof(E);
   typedef E EV __attribute__((ext_vector_type(V)));
   constexpr int TILE = kOpThreads * kOpVpt * V;   // rows
@@ -500,6 +528,8 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     if (tile >= ntiles) return;
     const int64_t wbase = tile * TILE + (int64_t)wave * (64 * kOpVpt * V);
     EV x[kOpVpt];
+    unsigned vbits = 0;
+    if (NULLS) vbits = op_lane_bits<V>(valid, off, wbase, limit < n ? limit : n, lane);
 #pragma unroll
     for (int k = 0; k < kOpVpt; k++) {
       const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
@@ -507,6 +537,10 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       else {
 #pragma unroll
         for (int j = 0; j < V; j++) x[k][j] = e + j < n ? in[e + j] : (E)0;
+      }
+      if (NULLS) {
+#pragma unroll
+        for (int j = 0; j < V; j++) x[k][j] = ((vbits >> (k * V + j)) & 1u) ? x[k][j] : (E)0;
       }
     }
     // x[k] becomes the inclusive prefix of its rows inside the wave's chunk, in place
@@ -561,23 +595,44 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     __syncthreads();
     const E base = s_prefix + wpre;
+    unsigned ovacc = 0;   // CHECKED: bit 31 = some step overflowed
+    E carry_in = base;   // CHECKED: the running sum in front of the wave's vector k
 #pragma unroll
     for (int k = 0; k < kOpVpt; k++) {
       const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
 #pragma unroll
       for (int j = 0; j < V; j++) x[k][j] += base;
+      if (CHECKED) {
+        // the running sum in front of the lane's first element: the last element of the lane to the left, or what the wave's vector started from
+        E prev = __shfl_up(x[k][V - 1], 1, 64);
+        if (lane == 0) prev = carry_in;
+        carry_in = read_lane63(x[k][V - 1]);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+          const E s = x[k][j], xi = s - prev;
+          if (SIGNED) ovacc |= (unsigned)(((prev ^ s) & (xi ^ s)) >> (sizeof(E) * 8 - 32));   // bit 31: both operands' signs differ from the sum's
+          else ovacc |= s < prev ? 0x80000000u : 0u;                                          // carry out
+          prev = s;
+        }
+      }
+      if (NULLS) {   // a null row's output is the zero of a fresh buffer
+#pragma unroll
+        for (int j = 0; j < V; j++) x[k][j] = ((vbits >> (k * V + j)) & 1u) ? x[k][j] : (E)0;
+      }
       if (e + V <= n) __builtin_nontemporal_store(x[k], (EV*)(out + e));
       else {
 #pragma unroll
         for (int j = 0; j < V; j++) if (e + j < n) out[e + j] = x[k][j];
       }
     }
+    if (CHECKED && __any((ovacc >> 31) != 0u) && lane == 0) atomicOr(overflow, 1u);
     __syncthreads();   // s_tile / s_wave are taken again
   }
 }
 
+// mode: bit 0 nulls (valid / limit), bit 1 checked, bit 2 signed (checked only)
 template <typename E>
-int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out) {
+int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, int mode = 0, const uint8_t* valid = nullptr, int64_t off = 0, int64_t limit = 0) {
   constexpr int TILE = kOpThreads * kOpVpt * (16 / (int)sizeof(E));
   const int64_t ntiles = ah_ceil_div(n, (int64_t)TILE);
   const size_t need = (size_t)ntiles * kOpRecWords * 8 + 64;
@@ -590,20 +645,35 @@ int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out) {
     AH_HIP(c, hipMemsetAsync(c->scan_recs, 0, want, c->stream));
     c->scan_recs_bytes = want;
     c->scan_epoch = 0;
-    c->scan_ticket_base = 0;
   }
   int64_t grid = ntiles < c->num_cu ? ntiles : c->num_cu;   // one workgroup per CU (104 registers × 1024 lanes), tiles by ticket
-  if (c->scan_epoch >= (1u << 29) || (uint64_t)c->scan_ticket_base + (uint64_t)ntiles + (uint64_t)grid >= (1ull << 31)) {   // before a marker or the ticket wraps
+  if (c->scan_epoch >= (1u << 29)) {   // before a marker wraps
     AH_HIP(c, hipMemsetAsync(c->scan_recs, 0, c->scan_recs_bytes, c->stream));
     c->scan_epoch = 0;
-    c->scan_ticket_base = 0;
   }
   c->scan_epoch++;
   u64* recs = (u64*)c->scan_recs;
-  unsigned* ticket = (unsigned*)((uint8_t*)c->scan_recs + c->scan_recs_bytes - 64);   // the last 64 bytes: the ticket word (zeroed with the array)
-  scan_onepass_kernel<E><<<(unsigned)grid, kOpThreads, 0, c->stream>>>((const E*)values, (E*)out, n, start, recs, ticket, c->scan_ticket_base, c->scan_epoch);
+  unsigned* ticket = (unsigned*)((uint8_t*)c->scan_recs + c->scan_recs_bytes - 64);   // the last 64 bytes: the ticket word
+  // the ticket starts from zero in EVERY launch (a 4-byte memset in stream order): a launch that did not run to its end — a fault, an
+  // asynchronous error — cannot leave the word out of step with a count the host keeps (the first version kept a running base)
+  AH_HIP(c, hipMemsetAsync(ticket, 0, sizeof(unsigned), c->stream));
+  unsigned* overflow = (unsigned*)&c->dscalars[13];
+  if (mode & 2) AH_HIP(c, hipMemsetAsync(overflow, 0, sizeof(uint64_t), c->stream));
+  const E* vin = (const E*)values;
+  E* vout = (E*)out;
+  const unsigned g = (unsigned)grid;
+#define AH_OP(NULLS, CHECKED, SIGNED) scan_onepass_kernel<E, NULLS, CHECKED, SIGNED><<<g, kOpThreads, 0, c->stream>>>(vin, vout, n, start, recs, ticket, 0u, c->scan_epoch, valid, off, limit, overflow)
+  switch (mode) {
+    case 0: AH_OP(false, false, false); break;
+    case 1: AH_OP(true, false, false); break;
+    case 2: AH_OP(false, true, false); break;
+    case 3: AH_OP(true, true, false); break;
+    case 6: AH_OP(false, true, true); break;
+    case 7: AH_OP(true, true, true); break;
+    default: return ah_fail(c, AH_EINVALID, "cumulative_sum: bad one-pass mode %d", mode);
+  }
+#undef AH_OP
   AH_LAUNCH_CHECK(c);
-  c->scan_ticket_base += (unsigned)(ntiles + grid);   // every tile's ticket plus the one each workgroup takes to find out it is done
   return AH_OK;
 }
 
@@ -617,9 +687,14 @@ int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t o
   } else {
     // unchecked: wraparound commutes with truncation, so the narrowest accumulator ≥ T does
     // (not while a graph records: the epoch and the ticket base are host state a replay would repeat)
-    if (!checked && !valid && sizeof(T) >= 4 && c->opt_scan_onepass && !c->capturing && n >= ((int64_t)1 << 18) && ((((uintptr_t)values) | ((uintptr_t)out)) & 15) == 0 && c->tune_nt) {
-      if constexpr (sizeof(T) == 8) return run_onepass<unsigned long long>(c, values, n, (unsigned long long)start, out);
-      else if constexpr (sizeof(T) == 4) return run_onepass<unsigned>(c, values, n, (unsigned)start, out);
+    // ONE pass for every 4- / 8-byte integer column — unchecked or checked, with or without nulls (round 5; round 4: unchecked without
+    // nulls only).  The narrow types stay on reduce-then-scan (their tiles would be 2^16 … 2^17 rows of 1 … 2 bytes: not measured).
+    if (sizeof(T) >= 4 && c->opt_scan_onepass && !c->capturing && n >= ((int64_t)1 << 18) && ((((uintptr_t)values) | ((uintptr_t)out)) & 15) == 0 && c->tune_nt &&
+        (c->opt_scan_onepass != 3 || (!checked && !valid))) {   // (3: round 4's gate — unchecked without nulls only; a measurement switch)
+      const bool nulls = valid != nullptr || limit < n;
+      const int mode = (nulls ? 1 : 0) | (checked ? 2 : 0) | (checked && std::is_signed<T>::value ? 4 : 0);
+      if constexpr (sizeof(T) == 8) return run_onepass<unsigned long long>(c, values, n, (unsigned long long)start, out, mode, valid, off, limit);
+      else if constexpr (sizeof(T) == 4) return run_onepass<unsigned>(c, values, n, (unsigned)start, out, mode, valid, off, limit);
     }
     if (!checked) {
       if constexpr (sizeof(T) == 8) return run_scan_vpt<T, unsigned long long, false>(c, values, valid, off, n, limit, (unsigned long long)start, out);

@@ -334,6 +334,15 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     # (f) rows: cumulative_sum (16 B/row algorithmic; 24 moved: reduce-then-scan) and numeric cast (w_in + w_out)
     timed("cumulative_sum_int64", 16 * rows, lambda: ctx.cumulative_sum(N.INT64, a, None, 0, rows, None, False, False, c, None))
     timed("cumulative_sum_float64", 16 * rows, lambda: ctx.cumulative_sum(N.FLOAT64, x, None, 0, rows, None, False, False, c, None))
+    # checked sums need a column whose running sums stay in range: small values (one 2^22-row chunk tiled), 10 % nulls skipped
+    sm = ctx.alloc(rows * 8 + 64)
+    sm_chunk = np.random.default_rng(11).integers(-1000, 1000, min(rows, 1 << 22), dtype=np.int64)
+    for o in range(0, rows, sm_chunk.size):
+        sm.upload(sm_chunk[:min(sm_chunk.size, rows - o)], o * 8)
+    timed("cumulative_sum_checked_int64", 16 * rows, lambda: ctx.cumulative_sum(N.INT64, sm, None, 0, rows, None, False, True, c, None))
+    timed("cumulative_sum_checked_int64_nulls10", 16.25 * rows, lambda: ctx.cumulative_sum(N.INT64, sm, vvalid, 0, rows, None, True, True, c, ovalid))
+    timed("cumulative_sum_int64_nulls10", 16.25 * rows, lambda: ctx.cumulative_sum(N.INT64, a, vvalid, 0, rows, None, True, False, c, ovalid))
+    sm.free()
     timed("cast_int64_to_int32_unsafe", 12 * rows, lambda: ctx.cast_numeric(N.INT64, N.INT32, a, None, 0, rows, True, True, c))
     timed("cast_int32_to_int64", 12 * rows, lambda: ctx.cast_numeric(N.INT32, N.INT64, a, None, 0, rows, False, False, c))
     timed("cast_float64_to_float32", 12 * rows, lambda: ctx.cast_numeric(N.FLOAT64, N.FLOAT32, x, None, 0, rows, False, False, c))

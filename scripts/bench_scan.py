@@ -29,6 +29,16 @@ ms = timed(lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, False,
 res["int64_nulls_skip"] = {"ms": round(ms, 4), "GBps": round((16 + 0.25) * rows / ms / 1e6, 1)}
 ms = timed(lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, False, False, c, ov))
 res["int64_nulls_propagate"] = {"ms": round(ms, 4)}
+ms = timed(lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, True, c, ov))
+res["int64_checked_nulls_skip"] = {"ms": round(ms, 4), "GBps": round((16 + 0.25) * rows / ms / 1e6, 1)}
+# … and the reduce-then-scan path on the same columns (option scan_onepass 0): what rounds 1-4 ran for checked / null-carrying columns
+ctx.set_option("scan_onepass", 0)
+for key, fn in (("int64", lambda: ctx.cumulative_sum(N.INT64, a, None, 0, rows, None, False, False, c, None)),
+                ("int64_checked", lambda: ctx.cumulative_sum(N.INT64, a, None, 0, rows, None, False, True, c, None)),
+                ("int64_nulls_skip", lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, False, c, ov)),
+                ("int64_checked_nulls_skip", lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, True, c, ov))):
+    res[key + "_two_pass"] = {"ms": round(timed(fn), 4)}
+ctx.set_option("scan_onepass", 1)
 # the same column through Sum for scale (8 B/row read only)
 ms = timed(lambda: ctx.sum_int64(a, rows))
 res["sum_int64_for_scale"] = {"ms": round(ms, 4), "GBps": round(8 * rows / ms / 1e6, 1)}

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_lib as OL
-from tests.backends import OracleBackend, HipBackend, STATUS_OK, STATUS_EINVALID, STATUS_EINDEX
+from tests.backends import OracleBackend, HipBackend, STATUS_OK, STATUS_EINVALID, STATUS_EINDEX, STATUS_EOVERFLOW
 
 pytestmark = pytest.mark.gpu
 
@@ -964,6 +964,72 @@ def test_cumulative_sum_one_pass(hip, orc_be, ctx, dtype):
         assert g[0] == e[0] == STATUS_OK
         assert g[1].tobytes() == e[1].tobytes(), (n, "vs oracle")
         assert g[1].tobytes() == g2[1].tobytes() == g0[1].tobytes(), (n, "run to run / vs reduce-then-scan")
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.uint32, np.int64, np.uint64])
+def test_cumulative_sum_one_pass_checked_and_nulls(hip, orc_be, ctx, dtype):
+    """Round 5: the one-pass scan also takes CHECKED sums and columns WITH NULLS (4- / 8-byte integers): a null row adds nothing and
+    keeps the zero of a fresh buffer, nulls skipped or not (then every row from the first null on is null: vector_cumulative.go:270-284);
+    checked: "overflow" exactly when some running sum leaves the type's range (checkedAddSigned / Unsigned, :147-160) — decided from
+    the wrapped prefixes by the step test (csrc/ah_scan.hip).  Byte-equal to the oracle and to reduce-then-scan (option scan_onepass 0),
+    values and validity; overflow in the first tile, in a late tile and at the very last row; a running sum that touches the type's
+    maximum exactly is NOT an overflow."""
+    rng = np.random.default_rng(77)
+    info = np.iinfo(dtype)
+    tile = 1024 * 8 * (16 // np.dtype(dtype).itemsize)
+
+    def both(a, valid, off, **kw):
+        e = orc_be.cumulative_sum(a, valid, off, **kw)
+        try:
+            g = hip.cumulative_sum(a, valid, off, **kw)
+            ctx.set_option("scan_onepass", 0)
+            g0 = hip.cumulative_sum(a, valid, off, **kw)
+        finally:
+            ctx.set_option("scan_onepass", 1)
+        assert g[0] == e[0] == g0[0], (kw, g[0], e[0], g0[0])
+        if e[0] == STATUS_OK:
+            n = a.size
+            assert g[1].tobytes() == e[1].tobytes() == g0[1].tobytes(), kw
+            if valid is not None:
+                bits = lambda b: np.unpackbits(b, bitorder="little")[:n]
+                assert (bits(g[2]) == bits(e[2])).all() and (bits(g0[2]) == bits(e[2])).all(), kw
+            assert g[3] == e[3] == g0[3], kw
+        return e[0]
+
+    small = max(int(info.max // (1 << 27)), 1)     # 2^24 rows of at most `small` cannot leave the range
+    for n in ((1 << 18) + 3, 17 * tile + 1, 70 * tile + 123, (1 << 23) + 5):
+        a = rng.integers(-small if info.min < 0 else 0, small, n, dtype=dtype, endpoint=True)
+        valid = rand_bits(rng, n + 16, 0.9)
+        start = dtype(rng.integers(0, small, dtype=dtype))
+        for off in (0, 5):
+            assert both(a, valid, off, start=start, skip_nulls=True, checked=False) == STATUS_OK
+            assert both(a, valid, off, start=start, skip_nulls=True, checked=True) == STATUS_OK
+        late = valid.copy()
+        late[: (n // 2) // 8] = 0xFF                       # no null in the first half: the first null lies in a late tile
+        assert both(a, late, 0, start=start, skip_nulls=False, checked=True) == STATUS_OK
+        assert both(a, valid, 3, skip_nulls=False, checked=False) == STATUS_OK
+        assert both(a, None, 0, start=start, checked=True) == STATUS_OK
+        # wrap-around (unchecked) with nulls: full-range values
+        wide = rng.integers(info.min, info.max, n, dtype=dtype, endpoint=True)
+        assert both(wide, valid, 0, skip_nulls=True, checked=False) == STATUS_OK
+        assert both(wide, None, 0, checked=True) == STATUS_EOVERFLOW
+        # exactly one step leaves the range, at a chosen row; everything before it stays far inside
+        for where in (5, n // 2 + 11, n - 1):
+            z = np.zeros(n, dtype=dtype)
+            z[0] = info.max - 10
+            z[where] = 10                                    # the running sum touches the maximum: no overflow
+            assert both(z, None, 0, checked=True) == STATUS_OK
+            z[where] = 11                                    # one beyond
+            assert both(z, None, 0, checked=True) == STATUS_EOVERFLOW
+            v = np.full((n + 7) // 8 + 8, 0xFF, np.uint8)
+            v[where // 8] &= ~np.uint8(1 << (where % 8))     # … unless that row is null
+            assert both(z, v, 0, skip_nulls=True, checked=True) == STATUS_OK
+            if info.min < 0:
+                z[0] = info.min + 10
+                z[where] = -11
+                assert both(z, None, 0, checked=True) == STATUS_EOVERFLOW
+                z[where] = -10
+                assert both(z, None, 0, checked=True) == STATUS_OK
 
 
 def test_hash_sum_quick_look_on_a_periodic_column(hip, orc_be, ctx):
