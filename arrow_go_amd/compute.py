@@ -39,6 +39,9 @@ lib.ahc_datum_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.PO
                                C.POINTER(C.c_int), _vp]
 lib.ahc_call.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]
 lib.ahc_export.argtypes = [_vp, _vp, _vp, _vp]
+lib.ahc_import_host.argtypes = [_vp, _vp, _vp, C.POINTER(_vp)]
+lib.ahc_datum_on_host.argtypes = [_vp]
+lib.ahc_session_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
 lib.ahc_math_sum.argtypes = [_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
 lib.ahc_has_function.argtypes = [C.c_char_p]
 lib.ahc_function_num_kernels.argtypes = [C.c_char_p]
@@ -122,6 +125,11 @@ class DeviceArray:
 
     def to_arrow(self):
         return self.session._export(self.h)
+
+    def on_host(self) -> bool:
+        """True for a HOST-resident array: imported with Session.import_host / import_host_buffers, or the result of a call
+        that streamed such arguments through the device (include/arrowhip_compute.h, "HOST-RESIDENT arguments")"""
+        return bool(lib.ahc_datum_on_host(self.h))
 
     def export_device(self):
         """→ (CArrowDeviceArray, CArrowSchema); the caller owns them and must call array.release."""
@@ -395,6 +403,53 @@ class Session:
         sch.release = rel_s
         d = _vp()
         self._check(lib.ahc_import_device(self.h, C.addressof(darr), C.addressof(sch), C.byref(d)))
+        return DeviceArray(self, d)
+
+    def set_option(self, name: str, value: int) -> None:
+        """ExecCtx fields of this session: 'chunk_bytes' (ExecCtx.ChunkSize's role for host-resident arguments), 'host_threshold_bytes'."""
+        self._check(lib.ahc_session_set_option(self.h, name.encode(), int(value)))
+
+    def import_host(self, arr) -> "DeviceArray":
+        """ahc_import_host of a pyarrow array: a flat fixed-width column of at least host_threshold_bytes stays in pyarrow's buffers
+        (pageable memory: correct, but the copies do not overlap — use import_host_buffers with pinned memory for that)"""
+        a = (C.c_uint8 * 80)()
+        s = (C.c_uint8 * 72)()
+        arr._export_to_c(C.addressof(a), C.addressof(s))
+        d = _vp()
+        self._check(lib.ahc_import_host(self.h, C.addressof(a), C.addressof(s), C.byref(d)))
+        return DeviceArray(self, d)
+
+    def import_host_buffers(self, type_name: str, length: int, data_ptr, validity_ptr=None, null_count: int = 0, offset: int = 0,
+                            on_release=None) -> "DeviceArray":
+        """ahc_import_host of raw host buffers (e.g. ah.Context.alloc_pinned memory): they stay where they are and must outlive the
+        returned array; `on_release` is called when the library lets go of them"""
+        fmt = _FORMATS[type_name]
+        bufs = (_vp * 2)(validity_ptr, data_ptr)
+        keep = {"bufs": bufs, "fmt": fmt}
+
+        def _release_array(ptr):
+            ptr.contents.release = C.cast(None, CArrowArray._fields_[8][1])
+            if on_release:
+                on_release()
+
+        def _release_schema(ptr):
+            ptr.contents.release = C.cast(None, CArrowSchema._fields_[7][1])
+
+        rel_a = CArrowArray._fields_[8][1](_release_array)
+        rel_s = CArrowSchema._fields_[7][1](_release_schema)
+        keep["cb"] = (rel_a, rel_s)
+        self._device_imports = getattr(self, "_device_imports", [])
+        self._device_imports.append(keep)  # callbacks must outlive the C side's use of them
+        arr = CArrowArray()
+        arr.length, arr.null_count, arr.offset = length, null_count, offset
+        arr.n_buffers, arr.n_children = 2, 0
+        arr.buffers = C.cast(bufs, C.POINTER(_vp))
+        arr.release = rel_a
+        sch = CArrowSchema()
+        sch.format, sch.name, sch.flags = fmt, b"", 2
+        sch.release = rel_s
+        d = _vp()
+        self._check(lib.ahc_import_host(self.h, C.addressof(arr), C.addressof(sch), C.byref(d)))
         return DeviceArray(self, d)
 
     def _to_datum(self, x):

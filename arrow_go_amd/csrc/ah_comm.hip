@@ -457,19 +457,23 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
   if (!m) return AH_EINVALID;
   ah_ctx* c = m->ctx;
   AH_ENTER(c);
-  if (!out_ngroups_host) return ah_fail(c, AH_EINVALID, "merge_groups: null result pointer");
+  if (!out_ngroups_host) return ah_fail(c, AH_EINVALID, "merge_groups: null result pointer");   // (a caller bug every rank shares: the ranks run the same program)
   *out_ngroups_host = 0;
   if (out_null_group_host) *out_null_group_host = -1;
   const int W = m->world;
   int64_t g = ngroups_local;
-  if (g < 0 || capacity < 0) return ah_fail(c, AH_EINVALID, "merge_groups: negative count");
-  if (g > 0 && (!keys || !sums || !counts || !first_rows)) return ah_fail(c, AH_EINVALID, "merge_groups: null input");
-  if (null_group_local < -1 || (int64_t)null_group_local >= g) return ah_fail(c, AH_EINVALID, "merge_groups: null group %d of %lld groups", (int)null_group_local, (long long)g);
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   int rc;
-  // ---- 0: the null group leaves the local columns; {has one, sum bits, count, global first row} of every rank to every rank
-  int64_t null_mine[4] = {0, 0, 0, 0};
-  if (null_group_local >= 0) {
+  // ---- 0: the null group leaves the local columns; {has one, sum bits, count, global first row, STATUS} of every rank to every rank.
+  // Everything that can fail on ONE rank before the first collective — an argument only this rank got wrong, its arena, its copies —
+  // is caught here and travels in the status word: the ranks fail TOGETHER after the all-gather instead of one returning early and
+  // the others blocking in it.
+  int64_t null_mine[5] = {0, 0, 0, 0, 0};
+  auto step0 = [&]() -> int {
+    if (g < 0 || capacity < 0) return ah_fail(c, AH_EINVALID, "merge_groups: negative count");
+    if (g > 0 && (!keys || !sums || !counts || !first_rows)) return ah_fail(c, AH_EINVALID, "merge_groups: null input");
+    if (null_group_local < -1 || (int64_t)null_group_local >= g) return ah_fail(c, AH_EINVALID, "merge_groups: null group %d of %lld groups", (int)null_group_local, (long long)g);
+    if (null_group_local < 0) return AH_OK;
     const size_t at = (size_t)null_group_local * 8;
     null_mine[0] = 1;
     AH_HIP(c, hipMemcpyAsync(&null_mine[1], (const uint8_t*)sums + at, 8, hipMemcpyDeviceToHost, c->stream));
@@ -479,22 +483,31 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
     null_mine[3] += row_offset;
     // the other g − 1 groups, closed up, in the communicator's second block (free until step 4)
     uint8_t* cmp;
-    if ((rc = arena2_reserve(m, pad((size_t)g * 8) * 4 + 4096, &cmp)) != AH_OK) return rc;
+    int r0;
+    if ((r0 = arena2_reserve(m, pad((size_t)g * 8) * 4 + 4096, &cmp)) != AH_OK) return r0;
     const void* cols[4] = {keys, sums, counts, first_rows};
     const void* closed[4];
     const size_t before = (size_t)null_group_local * 8, after = (size_t)(g - 1 - null_group_local) * 8;
     for (int k = 0; k < 4; k++) {
       uint8_t* dst = cmp + (size_t)k * pad((size_t)g * 8);
-      if (before && (rc = ah_copy_async(c, dst, cols[k], before)) != AH_OK) return rc;
-      if (after && (rc = ah_copy_async(c, dst + before, (const uint8_t*)cols[k] + before + 8, after)) != AH_OK) return rc;
+      if (before && (r0 = ah_copy_async(c, dst, cols[k], before)) != AH_OK) return r0;
+      if (after && (r0 = ah_copy_async(c, dst + before, (const uint8_t*)cols[k] + before + 8, after)) != AH_OK) return r0;
       closed[k] = dst;
     }
     keys = (const uint64_t*)closed[0]; sums = closed[1]; counts = (const int64_t*)closed[2]; first_rows = (const int64_t*)closed[3];
     g -= 1;
-  }
+    return AH_OK;
+  };
+  const int local_rc = step0();
+  if (local_rc != AH_OK) { null_mine[0] = 0; null_mine[4] = local_rc; g = 0; }
+  std::vector<int64_t> gathered((size_t)W * 5, 0);
+  if (W == 1) memcpy(gathered.data(), null_mine, sizeof(null_mine));
+  else if ((rc = comm_allgather_host(m, null_mine, 5, gathered.data())) != AH_OK) return rc;   // (the transport itself failing is every rank's failure)
+  if (local_rc != AH_OK) return local_rc;   // this rank's own error, its message already set
+  for (int r = 0; r < W; r++)
+    if (gathered[(size_t)r * 5 + 4] != 0) return ah_fail(c, (int)gathered[(size_t)r * 5 + 4], "merge_groups: rank %d failed before the exchange (status %d)", r, (int)gathered[(size_t)r * 5 + 4]);
   std::vector<int64_t> null_all((size_t)W * 4, 0);
-  if (W == 1) memcpy(null_all.data(), null_mine, sizeof(null_mine));
-  else if ((rc = comm_allgather_host(m, null_mine, 4, null_all.data())) != AH_OK) return rc;
+  for (int r = 0; r < W; r++) memcpy(&null_all[(size_t)r * 4], &gathered[(size_t)r * 5], 4 * sizeof(int64_t));
   int n_null_ranks = 0;
   for (int r = 0; r < W; r++) n_null_ranks += null_all[(size_t)r * 4] != 0;
   const int64_t has_null = n_null_ranks > 0 ? 1 : 0;

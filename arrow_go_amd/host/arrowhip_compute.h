@@ -85,6 +85,11 @@ struct Buffer {
   bool owned = true;
   std::shared_ptr<void> owner;
   size_t alloc_bytes = 0;  // size class of the block behind dptr when it came from Session::Allocate (0: not pooled)
+  // HOST-resident bytes (dptr is null): a column left where its producer put it (ahc_import_host; `owner` keeps the producer's
+  // ArrowArray) or a result the streaming executor wrote into pinned memory of the session's (host_alloc_bytes != 0: returned to
+  // the session's pinned pool).  Only ArrayData::on_host arrays hold such buffers (hoststream.cc).
+  void* hptr = nullptr;
+  size_t host_alloc_bytes = 0;
   ~Buffer();
 };
 using BufferPtr = std::shared_ptr<Buffer>;
@@ -108,10 +113,20 @@ class Session : public std::enable_shared_from_this<Session> {
   // directions wait for it (ah_upload_async / ah_download_async).  ARROWHIP_POOL_BYTES caps the cache (default 16 GiB; 0 = off).
   void Release(void* dptr, size_t alloc_bytes);
   void TrimPool();
+  // pinned host memory for the results of the streaming executor, pooled like the device blocks (pinning 1 GiB takes longer than
+  // moving it across PCIe)
+  Status AllocatePinned(int64_t nbytes, BufferPtr* out);
+  void ReleasePinned(void* hptr, size_t alloc_bytes);
+  // the session's ah_ingest (three slots of `chunk_bytes`; 0: 32 MiB), created on first use, re-created when the chunk size changes
+  Status Ingest(size_t chunk_bytes, struct ah_ingest** out);
  private:
   ah_ctx* ctx_ = nullptr;
   std::multimap<size_t, void*> pool_;
   size_t pooled_bytes_ = 0, pool_cap_ = (size_t)16 << 30;
+  std::multimap<size_t, void*> pinned_pool_;
+  size_t pinned_pooled_bytes_ = 0;
+  struct ah_ingest* ingest_ = nullptr;
+  size_t ingest_chunk_ = 0;
 };
 
 // ---- arrow.ArrayData (arrow/array.go:54-86) / scalar.Scalar ----------------------------
@@ -130,6 +145,10 @@ struct ArrayData {
   // temporal type ("tsu:UTC", "tdD", "ttm", "tDn" …; empty = a plain column).  CallFunction checks the
   // reference's type rules on it, runs the integer kernel, and labels the result (core.cc, "temporal front end").
   std::string logical;
+  // the buffers are HOST memory (Buffer::hptr): a column imported with ahc_import_host or a result of the streaming executor.
+  // Flat fixed-width columns only.  CallFunction streams such arguments through the device in chunks where the function allows
+  // it and uploads them whole where it does not (hoststream.cc).
+  bool on_host = false;
 };
 using ArrayDataPtr = std::shared_ptr<ArrayData>;
 
@@ -313,7 +332,21 @@ class FunctionRegistry;
 struct ExecCtx {
   FunctionRegistry* Registry = nullptr;
   Session* session = nullptr;
+  // ExecCtx.ChunkSize (executor.go:47-50: "the maximum length of an ExecSpan") for HOST-resident arguments, in bytes of the widest
+  // column of a span: the piece that is uploaded, computed and downloaded while its neighbours are (0: 32 MiB).  Device-resident
+  // arguments are never cut: one launch over the whole column is the right shape there.
+  int64_t ChunkBytes = 0;
+  // ahc_import_host keeps an array on the host from this many value bytes on; smaller ones are uploaded at import
+  int64_t HostThresholdBytes = (int64_t)64 << 20;
 };
+
+// ---- host-resident arguments (hoststream.cc) --------------------------------------------------------------------------------
+// CallFunction for a call with at least one ArrayData::on_host argument.  *handled = true: `out` holds the result (host-resident
+// for the streamed scalar kernels and Filter); false: the function or the argument shapes are not streamable — the caller uploads
+// the arguments whole (MaterializeOnDevice) and takes the usual path.
+Status CallHostResident(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out, bool* handled);
+Status MaterializeOnDevice(Session* s, const ArrayDataPtr& host, ArrayDataPtr* out);
+Status SumHostResident(ExecCtx* ctx, const ArrayData& a, double* f64, int64_t* i64, uint64_t* u64);
 
 enum class FuncKind { Scalar, Vector, Meta };  // functions.go:88-100
 struct Arity { int NArgs; bool IsVarArgs; };

@@ -173,6 +173,79 @@ AHC_EXPORT int ahc_import(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, 
   return 0;
 }
 
+// a host-resident array datum (ahc_import_host, or a result of the streaming executor) is uploaded whole the first time something
+// that cannot stream it needs it; the datum is device-resident from then on
+static Status ToDevice(ahc_session* s, ahc_datum* d) {
+  if (d->d.kind != DatumKind::Array || !d->d.array->on_host) return Status::OK();
+  ArrayDataPtr dev;
+  AHC_RETURN_NOT_OK(compute::MaterializeOnDevice(s->session.get(), d->d.array, &dev));
+  d->d.array = dev;
+  return Status::OK();
+}
+static Status ToDeviceAll(ahc_session* s, int n, ahc_datum** ds) {
+  for (int i = 0; i < n; i++) AHC_RETURN_NOT_OK(ToDevice(s, ds[i]));
+  return Status::OK();
+}
+
+namespace {
+struct HostImportHolder {
+  ArrowArray arr;
+  ~HostImportHolder() { if (arr.release) arr.release(&arr); }
+};
+}  // namespace
+
+// ImportCArray (arrow/cdata/interface.go:153) WITHOUT the upload: a flat fixed-width column of at least ExecCtx.HostThresholdBytes
+// value bytes stays in the producer's buffers (the ArrowArray is moved into the datum and released with it); smaller ones, and every
+// other layout, are imported as ahc_import does.  Pin the buffers (ah_host_alloc_pinned / ah_host_register) for the copies to overlap.
+AHC_EXPORT int ahc_import_host(ahc_session* s, ArrowArray* arr, ArrowSchema* schema, ahc_datum** out) {
+  *out = nullptr;
+  const DataType* t = TypeFromFormat(schema->format);
+  const bool flat = t && !IsBaseBinary(t->id) && !schema->dictionary && !arr->dictionary && arr->n_children == 0 && arr->n_buffers == 2 && arr->buffers[1] != nullptr;
+  // (a Boolean column — a selection vector — counts as the 8-byte column it selects from: it stays with the values it filters)
+  const int64_t as_bytes = flat ? (arr->offset + arr->length) * (int64_t)(t->bit_width == 1 ? 8 : t->bit_width / 8) : 0;
+  if (!flat || as_bytes < s->ectx.HostThresholdBytes) return ahc_import(s, arr, schema, out);
+  auto holder = std::make_shared<HostImportHolder>();
+  holder->arr = *arr;
+  arr->release = nullptr;   // moved
+  Session* ss = s->session.get();
+  auto d = std::make_shared<ArrayData>();
+  d->type = t;
+  if (schema->format[0] == 't') d->logical = schema->format;
+  d->length = holder->arr.length;
+  d->offset = holder->arr.offset;
+  d->null_count = holder->arr.null_count;
+  d->on_host = true;
+  auto wrap = [&](const void* p, int64_t size) {
+    auto b = std::make_shared<Buffer>();
+    ss->Keep(b.get());
+    b->owned = false;
+    b->owner = holder;
+    b->hptr = const_cast<void*>(p);
+    b->size = size;
+    return b;
+  };
+  const int64_t nbits = d->offset + d->length;
+  if (holder->arr.buffers[0] != nullptr && holder->arr.null_count != 0) d->buffers[0] = wrap(holder->arr.buffers[0], (nbits + 7) / 8);
+  else d->null_count = 0;
+  // (an unknown null count, −1, stays unknown: "may have nulls" is all the streaming executor asks)
+  d->buffers[1] = wrap(holder->arr.buffers[1], t->bit_width == 1 ? (nbits + 7) / 8 : nbits * (t->bit_width / 8));
+  if (schema->release) schema->release(schema);
+  *out = new ahc_datum{Datum::Of(d)};
+  return 0;
+}
+AHC_EXPORT int ahc_datum_on_host(ahc_datum* d) { return d->d.kind == DatumKind::Array && d->d.array->on_host ? 1 : 0; }
+
+// the ExecCtx fields of this session: "chunk_bytes" (ExecCtx.ChunkSize's role for host-resident arguments: bytes of the widest column
+// per span, 0 = 32 MiB), "host_threshold_bytes" (ahc_import_host keeps arrays of at least this many value bytes on the host)
+AHC_EXPORT int ahc_session_set_option(ahc_session* s, const char* name, int64_t value) {
+  const std::string n = name ? name : "";
+  if (value < 0) return Fail(s, Status::Make(StatusCode::Invalid, "option '" + n + "': negative value"));
+  if (n == "chunk_bytes") s->ectx.ChunkBytes = value;
+  else if (n == "host_threshold_bytes") s->ectx.HostThresholdBytes = value;
+  else return Fail(s, Status::Make(StatusCode::KeyError, "unknown session option '" + n + "'"));
+  return 0;
+}
+
 AHC_EXPORT int ahc_scalar(ahc_session* s, int type_id, int valid, const void* value8, ahc_datum** out) {
   const DataType* t = GetDataType((Type)type_id);
   if (!t) return Fail(s, Status::Make(StatusCode::NotImplemented, "unsupported scalar type"));
@@ -345,6 +418,19 @@ AHC_EXPORT int ahc_call(ahc_session* s, const char* name, const char* options, i
   ParsedOptions po;
   ParseOptions(options, &po);
   Datum res;
+  bool any_host = false;
+  for (const Datum& d : a) any_host = any_host || (d.kind == DatumKind::Array && d.array->on_host);
+  if (any_host) {
+    // host-resident arguments: span by span through the device where the function can be streamed (hoststream.cc: the reference's
+    // iterateExecSpans with ExecCtx.ChunkSize, executor.go:47-50,499), uploaded whole where it cannot
+    bool handled = false;
+    Status hs = compute::CallHostResident(&s->ectx, name ? name : "", po.pick, a, &res, &handled);
+    if (!hs.ok()) return Fail(s, hs);
+    if (handled) { *out = new ahc_datum{res}; return 0; }
+    hs = ToDeviceAll(s, nargs, args);
+    if (!hs.ok()) return Fail(s, hs);
+    for (int i = 0; i < nargs; i++) a[(size_t)i] = args[i]->d;
+  }
   Status st = compute::CallFunction(&s->ectx, name, po.pick, a, &res);
   if (!st.ok()) return Fail(s, st);
   *out = new ahc_datum{res};
@@ -356,6 +442,10 @@ AHC_EXPORT int ahc_math_sum(ahc_session* s, ahc_datum* d, double* f64, int64_t* 
   const ArrayData& a = *d->d.array;
   Status st;
   if (!a.logical.empty()) return Fail(s, Status::Make(StatusCode::TypeError, "arrow/math has Float64, Int64 and Uint64 Sum only, not " + a.logical));
+  if (a.on_host) {   // chunk by chunk through the device, one final reduction (ah_ingest_sum_*)
+    st = compute::SumHostResident(&s->ectx, a, f64, i64, u64);
+    return st.ok() ? 0 : Fail(s, st);
+  }
   switch (a.type->id) {
     case Type::FLOAT64: st = math::Float64.Sum(s->session.get(), a, f64); break;
     case Type::INT64: st = math::Int64.Sum(s->session.get(), a, i64); break;
@@ -452,10 +542,46 @@ static Status ExportOne(Session* ss, const ArrayData& a, const DataType* t, Arro
 }
 
 // ExportArrowArray-like (arrow/cdata/exports.go): device → freshly malloc'ed host buffers
+namespace {
+struct HostExportPriv {
+  ArrayDataPtr keep;
+  const void* buffer_ptrs[2] = {nullptr, nullptr};
+};
+void ReleaseHostArray(ArrowArray* a) {
+  delete (HostExportPriv*)a->private_data;
+  a->private_data = nullptr;
+  a->release = nullptr;
+}
+}  // namespace
+
 AHC_EXPORT int ahc_export(ahc_session* s, ahc_datum* d, ArrowArray* arr, ArrowSchema* schema) {
   if (d->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "only array datums can be exported"));
   const ArrayData& a = *d->d.array;
   Session* ss = s->session.get();
+  if (a.on_host) {   // ZERO COPY: the consumer gets the host buffers themselves; they live until it releases the array
+    memset(arr, 0, sizeof(*arr));
+    memset(schema, 0, sizeof(*schema));
+    auto* p = new HostExportPriv();
+    p->keep = d->d.array;
+    p->buffer_ptrs[0] = a.buffers[0] && a.null_count != 0 ? a.buffers[0]->hptr : nullptr;
+    p->buffer_ptrs[1] = a.buffers[1] ? a.buffers[1]->hptr : nullptr;
+    arr->length = a.length;
+    arr->null_count = p->buffer_ptrs[0] ? a.null_count : 0;
+    arr->offset = a.offset;
+    arr->n_buffers = 2;
+    arr->buffers = p->buffer_ptrs;
+    arr->release = ReleaseHostArray;
+    arr->private_data = p;
+    schema->format = a.type->format;
+    if (!a.logical.empty()) {
+      schema->private_data = strdup(a.logical.c_str());
+      schema->format = (const char*)schema->private_data;
+    }
+    schema->name = "";
+    schema->flags = 2;  // ARROW_FLAG_NULLABLE
+    schema->release = ReleaseSchema;
+    return 0;
+  }
   if (a.type->id == Type::DICTIONARY) {
     const DataType* it = a.dict_index_type ? a.dict_index_type : GetDataType(Type::INT32);
     Status st;
@@ -595,6 +721,7 @@ void ReleaseDeviceArray(ArrowArray* a) {
 
 AHC_EXPORT int ahc_export_device(ahc_session* s, ahc_datum* d, ArrowDeviceArray* out, ArrowSchema* schema) {
   if (d->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "only array datums can be exported"));
+  { Status hs = ToDevice(s, d); if (!hs.ok()) return Fail(s, hs); }
   const ArrayDataPtr& a = d->d.array;
   if (a->type->id == Type::DICTIONARY) return Fail(s, Status::Make(StatusCode::NotImplemented, "device export of dictionary arrays"));
   Session* ss = s->session.get();
@@ -634,8 +761,9 @@ AHC_EXPORT int ahc_export_device(ahc_session* s, ahc_datum* d, ArrowDeviceArray*
 // test / interop introspection: the device pointers behind an array datum
 AHC_EXPORT int ahc_datum_buffers(ahc_datum* d, void** validity, void** data) {
   if (d->d.kind != DatumKind::Array) return 1;
-  *validity = d->d.array->buffers[0] ? d->d.array->buffers[0]->dptr : nullptr;
-  *data = d->d.array->buffers[1] ? d->d.array->buffers[1]->dptr : nullptr;
+  const bool h = d->d.array->on_host;   // a host-resident array: the HOST pointers (ahc_datum_on_host says which)
+  *validity = d->d.array->buffers[0] ? (h ? d->d.array->buffers[0]->hptr : d->d.array->buffers[0]->dptr) : nullptr;
+  *data = d->d.array->buffers[1] ? (h ? d->d.array->buffers[1]->hptr : d->d.array->buffers[1]->dptr) : nullptr;
   return 0;
 }
 
@@ -683,6 +811,7 @@ struct ExprParser {
 AHC_EXPORT int ahc_expr_eval(ahc_session* s, const char* text, int ncols, ahc_datum** cols, int nlits, ahc_datum** lits, int fuse,
                              ahc_datum** out, int* fused_out) {
   *out = nullptr;
+  { Status hs = ToDeviceAll(s, ncols, cols); if (!hs.ok()) return Fail(s, hs); }
   std::vector<Datum> lit_datums;
   for (int i = 0; i < nlits; i++) lit_datums.push_back(lits[i]->d);
   ExprParser parser{text, &lit_datums, ""};
@@ -708,6 +837,7 @@ AHC_EXPORT int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, in
                                   int nlits, ahc_datum** lits, int fuse, ahc_datum** out, int* fused_out) {
   *out = nullptr;
   if (!nodes || n_nodes <= 0) return Fail(s, Status::Make(StatusCode::Invalid, "nil expression"));   // exprs/exec.go:441-443
+  { Status hs = ToDeviceAll(s, ncols, cols); if (!hs.ok()) return Fail(s, hs); }
   std::vector<compute::ExprPtr> built((size_t)n_nodes);
   for (int i = 0; i < n_nodes; i++) {
     const ahc_expr_node& nd = nodes[i];
@@ -765,6 +895,7 @@ AHC_EXPORT int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, in
 AHC_EXPORT int ahc_expr_eval_substrait(ahc_session* s, const uint8_t* bytes, int64_t len, int ncols, ahc_datum** cols, const char* const* col_names,
                                        int fuse, ahc_datum** out, int* fused_out) {
   *out = nullptr;
+  { Status hs = ToDeviceAll(s, ncols, cols); if (!hs.ok()) return Fail(s, hs); }
   std::vector<Datum> c;
   std::vector<std::string> names;
   for (int i = 0; i < ncols; i++) {
@@ -825,6 +956,7 @@ AHC_EXPORT int ahc_chunked_from_arrays(ahc_session* s, int type_id, int n, ahc_d
   *out = nullptr;
   const DataType* t = GetDataType((Type)type_id);
   if (!t) return Fail(s, Status::Make(StatusCode::Invalid, "unknown type id " + std::to_string(type_id)));
+  { Status hs = ToDeviceAll(s, n, arrays); if (!hs.ok()) return Fail(s, hs); }
   std::vector<ArrayDataPtr> chunks;
   for (int i = 0; i < n; i++) {
     if (arrays[i]->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "chunks must be arrays"));
@@ -848,6 +980,7 @@ AHC_EXPORT int ahc_datum_chunk(ahc_session* s, ahc_datum* d, int i, ahc_datum** 
 // ---- record batches (compute.RecordDatum, datum.go:232-260): named equal-length columns -------------------------
 AHC_EXPORT int ahc_record_from_arrays(ahc_session* s, int n, const char* const* names, ahc_datum** arrays, ahc_datum** out) {
   *out = nullptr;
+  { Status hs = ToDeviceAll(s, n, arrays); if (!hs.ok()) return Fail(s, hs); }
   std::vector<ArrayDataPtr> cols;
   std::vector<std::string> nm;
   int64_t rows = 0;

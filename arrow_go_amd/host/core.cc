@@ -58,6 +58,7 @@ std::string Status::ToString() const {
 // ---- session / buffers ------------------------------------------------------------------
 Buffer::~Buffer() {
   if (owned && dptr && session && session->ctx()) session->Release(dptr, alloc_bytes);
+  if (hptr && host_alloc_bytes && session && session->ctx()) session->ReleasePinned(hptr, host_alloc_bytes);
 }
 
 Status Session::Create(int device_id, std::shared_ptr<Session>* out) {
@@ -68,6 +69,7 @@ Status Session::Create(int device_id, std::shared_ptr<Session>* out) {
   return Status::OK();
 }
 Session::~Session() {
+  if (ingest_) ah_ingest_destroy(ingest_);
   TrimPool();
   if (ctx_) ah_ctx_destroy(ctx_);
 }
@@ -75,6 +77,43 @@ void Session::TrimPool() {
   for (auto& kv : pool_) ah_buf_free(ctx_, kv.second);
   pool_.clear();
   pooled_bytes_ = 0;
+  for (auto& kv : pinned_pool_) ah_host_free_pinned(ctx_, kv.second);
+  pinned_pool_.clear();
+  pinned_pooled_bytes_ = 0;
+}
+Status Session::AllocatePinned(int64_t nbytes, BufferPtr* out) {
+  auto b = std::make_shared<Buffer>();
+  Keep(b.get());
+  b->size = nbytes;
+  b->owned = false;
+  const size_t cls = (((size_t)(nbytes > 0 ? nbytes : 1) + 63) & ~(size_t)63) + 64;   // exact sizes: a repeated call asks for the same ones
+  auto hit = pinned_pool_.find(cls);
+  if (hit != pinned_pool_.end()) {
+    b->hptr = hit->second;
+    pinned_pooled_bytes_ -= cls;
+    pinned_pool_.erase(hit);
+  } else {
+    AHC_RETURN_NOT_OK(FromStatus(ah_host_alloc_pinned(ctx_, cls, &b->hptr)));
+  }
+  b->host_alloc_bytes = cls;
+  *out = std::move(b);
+  return Status::OK();
+}
+void Session::ReleasePinned(void* hptr, size_t alloc_bytes) {
+  if (pinned_pooled_bytes_ + alloc_bytes > ((size_t)8 << 30)) { ah_host_free_pinned(ctx_, hptr); return; }
+  pinned_pool_.emplace(alloc_bytes, hptr);
+  pinned_pooled_bytes_ += alloc_bytes;
+}
+Status Session::Ingest(size_t chunk_bytes, ah_ingest** out) {
+  if (chunk_bytes == 0) chunk_bytes = (size_t)32 << 20;
+  chunk_bytes = (chunk_bytes + 4095) & ~(size_t)4095;
+  if (ingest_ && ingest_chunk_ != chunk_bytes) { ah_ingest_destroy(ingest_); ingest_ = nullptr; }
+  if (!ingest_) {
+    AHC_RETURN_NOT_OK(FromStatus(ah_ingest_create(ctx_, chunk_bytes, 3, &ingest_)));
+    ingest_chunk_ = chunk_bytes;
+  }
+  *out = ingest_;
+  return Status::OK();
 }
 void Session::Release(void* dptr, size_t alloc_bytes) {
   if (alloc_bytes == 0 || pooled_bytes_ + alloc_bytes > pool_cap_) { ah_buf_free(ctx_, dptr); return; }

@@ -1,0 +1,259 @@
+"""CallFunction over HOST-resident arguments: chunked, overlapped execution inside the host mirror (arrow_go_amd/host/hoststream.cc).
+
+The reference's executor cuts a call into spans of at most ExecCtx.ChunkSize rows (arrow/compute/executor.go:47-50, :499
+iterateExecSpans, :658-702).  Here a column imported with ahc_import_host stays in host memory and add / sub / multiply, the
+comparisons, filter and arrow/math Sum stream it through the device span by span (upload k + 1 | kernel k | download k − 1); every
+other function uploads it whole first.  Checked against Arrow C++ (pyarrow.compute) and against this library's own whole-array path,
+value bytes and validity; then the rate of a 1 GiB pinned column against the link's, and a call whose arguments do not fit the HBM
+that is left."""
+import numpy as np
+import pytest
+
+pa = pytest.importorskip("pyarrow")
+import pyarrow.compute as pc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    from arrow_go_amd import compute as ac
+    s = ac.Session(0)
+    s.set_option("host_threshold_bytes", 0)       # every flat column imported with import_host stays on the host
+    s.set_option("chunk_bytes", 64 << 10)          # 8192 Int64 rows per span: dozens of spans on small columns
+    yield s
+    s.close()
+
+
+def column(rng, n, typ, nulls):
+    if pa.types.is_floating(typ):
+        v = rng.uniform(-1e6, 1e6, n)
+    else:
+        v = rng.integers(-10**6, 10**6, n)
+    mask = rng.random(n) < 0.1 if nulls else None
+    return pa.array(v, type=typ, mask=mask)
+
+
+def same(a, b):
+    assert a.type == b.type and len(a) == len(b), (a.type, b.type, len(a), len(b))
+    assert a.null_count == b.null_count
+    assert a.equals(b)
+
+
+@pytest.mark.parametrize("typ", [pa.int64(), pa.float64(), pa.int32(), pa.uint16()])
+@pytest.mark.parametrize("name", ["add", "subtract", "multiply", "add_unchecked", "multiply_unchecked"])
+def test_streamed_arithmetic(sess, name, typ):
+    rng = np.random.default_rng(hash((name, str(typ))) % 2**31)
+    n = 100_003
+    pcf = {"add": pc.add_checked, "subtract": pc.subtract_checked, "multiply": pc.multiply_checked, "add_unchecked": pc.add, "multiply_unchecked": pc.multiply}[name]
+    small = pa.types.is_integer(typ) and typ.bit_width <= 32
+    for lnulls in (False, True):
+        for rnulls in (False, True):
+            a, b = column(rng, n, pa.int64(), lnulls), column(rng, n, pa.int64(), rnulls)
+            if small:     # keep the products inside the narrow type (and a − b ≥ 0 for the unsigned one)
+                a, b = pc.bit_wise_and(a, pa.scalar(63, pa.int64())), pc.bit_wise_and(b, pa.scalar(63, pa.int64()))
+                if pa.types.is_unsigned_integer(typ):
+                    a = pc.bit_wise_or(a, pa.scalar(64, pa.int64()))
+            a, b = a.cast(typ), b.cast(typ)
+            want = pcf(a, b)
+            ha, hb = sess.import_host(a), sess.import_host(b)
+            assert ha.on_host() and hb.on_host()
+            got = sess.call_function(name, [ha, hb], keep_on_device=True)
+            assert got.on_host()                                    # streamed: the result is host-resident
+            same(got.to_arrow(), want)
+            same(sess.call_function(name, [a, b]), want)            # the whole-array path gives the same
+            # array ∘ scalar and scalar ∘ array
+            sc = pa.scalar(3, typ)
+            same(sess.call_function(name, [ha, sc]), pcf(a, sc))
+            sc = pa.scalar(127, typ)
+            same(sess.call_function(name, [sc, hb]), pcf(sc, b))
+    # a null scalar: every row null
+    got = sess.call_function(name, [sess.import_host(a), pa.scalar(None, typ)])
+    assert got.null_count == n
+
+
+def test_streamed_checked_add_overflows(sess):
+    from arrow_go_amd import compute as ac
+    n = 50_000
+    a = np.zeros(n, np.int64)
+    a[n - 7] = np.iinfo(np.int64).max           # in the last span
+    ha, hb = sess.import_host(pa.array(a)), sess.import_host(pa.array(np.ones(n, np.int64)))
+    with pytest.raises(ac.ArrowError, match="overflow"):
+        sess.call_function("add", [ha, hb])
+    same(sess.call_function("add_unchecked", [ha, hb]), pc.add(pa.array(a), pa.array(np.ones(n, np.int64))))
+    # … unless the offending row is null (checked kernels test valid slots only)
+    mask = np.zeros(n, bool)
+    mask[n - 7] = True
+    hc = sess.import_host(pa.array(a, mask=mask))
+    got = sess.call_function("add", [hc, hb])
+    assert got.null_count == 1 and got[n - 8].as_py() == 1
+
+
+@pytest.mark.parametrize("name", ["equal", "not_equal", "greater", "greater_equal", "less", "less_equal"])
+def test_streamed_comparisons(sess, name):
+    rng = np.random.default_rng(len(name))
+    n = 70_001
+    for typ in (pa.int64(), pa.float64(), pa.int8()):
+        a = column(rng, n, pa.int64(), True)
+        b = column(rng, n, pa.int64(), True)
+        if typ == pa.int8():
+            a, b = pc.bit_wise_and(a, pa.scalar(7, pa.int64())), pc.bit_wise_and(b, pa.scalar(7, pa.int64()))
+        a, b = a.cast(typ), b.cast(typ)
+        pcf = getattr(pc, name)
+        ha, hb = sess.import_host(a), sess.import_host(b)
+        got = sess.call_function(name, [ha, hb], keep_on_device=True)
+        assert got.on_host()
+        same(got.to_arrow(), pcf(a, b))
+        sc = pa.scalar(2, typ)
+        same(sess.call_function(name, [ha, sc]), pcf(a, sc))
+        same(sess.call_function(name, [sc, hb]), pcf(sc, b))
+
+
+@pytest.mark.parametrize("null_sel", ["drop", "emit_null"])
+def test_streamed_filter(sess, null_sel):
+    rng = np.random.default_rng(5)
+    n = 200_017
+    for typ in (pa.int64(), pa.float32(), pa.int16()):
+        for vnulls in (False, True):
+            for fnulls in (False, True):
+                v = column(rng, n, pa.int64(), vnulls).cast(pa.float32() if typ == pa.float32() else typ, safe=False)
+                f = pa.array(rng.random(n) < 0.4, mask=(rng.random(n) < 0.1) if fnulls else None)
+                want = pc.filter(v, f, null_selection_behavior=null_sel)
+                got = sess.call_function("filter", [sess.import_host(v), sess.import_host(f)], options=f"null_selection_behavior={null_sel}", keep_on_device=True)
+                assert got.on_host()
+                same(got.to_arrow(), want)
+
+
+def test_streamed_math_sum(sess):
+    rng = np.random.default_rng(9)
+    n = 300_001
+    x = rng.uniform(-1, 1, n)
+    h = sess.import_host(pa.array(x))
+    assert abs(sess.math_sum(h) - float(np.sum(x, dtype=np.longdouble))) <= 1e-9
+    i = rng.integers(-2**40, 2**40, n)
+    assert sess.math_sum(sess.import_host(pa.array(i))) == int(i.sum())
+    short = pa.array([1e308, 1e308, -1e308])                 # ≤ 31 rows: the reference's sequential order, also through the ingest
+    assert sess.math_sum(sess.import_host(short)) == float("inf")
+
+
+def test_other_functions_upload_the_column_whole(sess):
+    rng = np.random.default_rng(10)
+    a = column(rng, 60_000, pa.int64(), True)
+    h = sess.import_host(a)
+    assert h.on_host()
+    same(sess.call_function("negate", [h]), pc.negate_checked(a))      # not streamed: uploaded whole …
+    assert not h.on_host()                                               # … and device-resident from then on
+    same(sess.call_function("add", [h, h]), pc.add_checked(a, a))
+    # mixed residency: the host side is uploaded
+    h2 = sess.import_host(a)
+    dev = sess.call_function("negate", [a], keep_on_device=True)
+    same(sess.call_function("add", [h2, dev]), pc.add_checked(a, pc.negate_checked(a)))
+    # below the threshold nothing stays on the host
+    sess.set_option("host_threshold_bytes", 64 << 20)
+    try:
+        assert not sess.import_host(a).on_host()
+    finally:
+        sess.set_option("host_threshold_bytes", 0)
+
+
+def _pinned_column(ctx, sess, rows, dtype, fill):
+    pb = ctx.alloc_pinned(rows * 8 + 64)
+    v = pb.view(dtype, rows)
+    chunk = fill(1 << 22)
+    for o in range(0, rows, chunk.size):
+        v[o:o + chunk.size] = chunk[:min(chunk.size, rows - o)]
+    return pb, v
+
+
+def test_one_gib_pinned_column_runs_at_the_links_rate(ctx):
+    """ahc_call("add") on 1 GiB pinned columns: 2 GiB cross the link towards the device while 1 GiB comes back; the uploads must run at
+    ≥ 0.90 of what one plain pinned copy of the same size reaches, and the bytes must be the whole-array path's"""
+    import time
+    import arrow_go_amd as ah
+    from arrow_go_amd import compute as ac
+    rows = 1 << 27
+    rng = np.random.default_rng(3)
+    s = ac.Session(0)
+    try:
+        pa_buf, va = _pinned_column(ctx, s, rows, np.int64, lambda m: rng.integers(-2**40, 2**40, m))
+        pb_buf, vb = _pinned_column(ctx, s, rows, np.int64, lambda m: rng.integers(-2**40, 2**40, m))
+        # the link: one plain pinned upload of 1 GiB
+        dev = ctx.alloc(rows * 8)
+        best = 1e9
+        for _ in range(3):
+            ctx.sync()
+            t0 = time.perf_counter()
+            ah._native.check(ctx.handle, ah._native.lib.ah_upload_async(ctx.handle, dev.ptr, pa_buf.ptr, rows * 8))
+            ctx.sync()
+            best = min(best, time.perf_counter() - t0)
+        link = rows * 8 / best / 1e9
+        dev.free()
+        ha = s.import_host_buffers("int64", rows, pa_buf.ptr)
+        hb = s.import_host_buffers("int64", rows, pb_buf.ptr)
+        assert ha.on_host() and hb.on_host()
+        rates = {}
+        for name in ("add", "add_unchecked"):
+            s.call_function(name, [ha, hb], keep_on_device=True).release()      # the first call pins the output block and creates the ingest
+            t_best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                out = s.call_function(name, [ha, hb], keep_on_device=True)
+                t_best = min(t_best, time.perf_counter() - t0)
+                last = out
+                if _ < 2:
+                    out.release()
+            rates[name] = 2 * rows * 8 / t_best / 1e9
+            _, dptr = last.buffers()
+            import ctypes
+            got = np.ctypeslib.as_array((ctypes.c_int64 * rows).from_address(dptr))
+            assert last.on_host() and np.array_equal(got, va + vb), name
+            last.release()
+        print(f"link {link:.1f} GB/s; add {rates['add']:.1f}, add_unchecked {rates['add_unchecked']:.1f} GB/s towards the device")
+        assert rates["add_unchecked"] >= 0.90 * link, (rates, link)
+        assert rates["add"] >= 0.85 * link, (rates, link)          # the checked kernel returns a verdict per span
+        ha.release(); hb.release()
+    finally:
+        s.close()
+        pa_buf.free(); pb_buf.free()
+
+
+def test_columns_larger_than_the_free_hbm(ctx):
+    """the whole-array path needs both arguments and the output resident; the streamed path needs three spans.  Most of the HBM is
+    taken first (never touched), then two 2 GiB host columns are added: the upload-everything path cannot allocate, the streamed
+    path runs."""
+    import arrow_go_amd as ah
+    from arrow_go_amd import compute as ac
+    import ctypes as C
+    free_b, total_b = C.c_size_t(), C.c_size_t()
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
+    rows = 1 << 28                                   # 2 GiB per Int64 column
+    leave = 3 << 30                                  # < 3 × 2 GiB: the whole-array path cannot fit
+    hogs = []
+    s = ac.Session(0)
+    try:
+        want = int(free_b.value) - leave
+        while want > (1 << 30):                      # in 16 GiB pieces; allocated, never touched
+            sz = min(want, 16 << 30)
+            p = C.c_void_p()
+            if hip.hipMalloc(C.byref(p), C.c_size_t(sz)) != 0:
+                break
+            hogs.append(p)
+            want -= sz
+        assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0 and free_b.value < 3 * rows * 8
+        rng = np.random.default_rng(4)
+        pa_buf, va = _pinned_column(ctx, s, rows, np.int64, lambda m: rng.integers(-2**40, 2**40, m))
+        pb_buf, vb = _pinned_column(ctx, s, rows, np.int64, lambda m: rng.integers(-2**40, 2**40, m))
+        ha = s.import_host_buffers("int64", rows, pa_buf.ptr)
+        hb = s.import_host_buffers("int64", rows, pb_buf.ptr)
+        out = s.call_function("add", [ha, hb], keep_on_device=True)
+        _, dptr = out.buffers()
+        got = np.ctypeslib.as_array((C.c_int64 * rows).from_address(dptr))
+        assert out.on_host() and np.array_equal(got, va + vb)
+        assert s.math_sum(ha) == int(va.sum())
+        out.release(); ha.release(); hb.release()
+        pa_buf.free(); pb_buf.free()
+    finally:
+        for p in hogs:
+            hip.hipFree(p)
+        s.close()
