@@ -274,7 +274,26 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
     if (__builtin_expect(kw != 0 || key == kEmpty, 0)) {
       j = kw ? kSlots + 1 : kSlots;
     } else {
-      j = gb_lds_slot(lkey_base, l_key, &s_used, key);
+      // gb_lds_slot, spelled out HERE on the __shared__ arrays themselves: through the function's pointer parameters the table accesses
+      // were addressed as generic pointers (54 more vector instructions in this kernel), and with the row loop's body in a lambda
+      // another 30 — together the 6 % this pass lost between rounds 3 and 4 (422 → 452 µs; read off the ISA: 1093 → 1165 vector
+      // instructions, 1081 now)
+      unsigned g = ((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA6Bu)) >> 20) & (unsigned)(kSlots - 4);
+      for (;;) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 a, c;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(a), "=&v"(c) : "v"(lkey_base + g * 8u) : "memory");
+        const bool h0 = a.x == key, h1 = a.y == key, h2 = c.x == key, h3 = c.y == key;
+        const bool e0 = a.x == kEmpty, e1 = a.y == kEmpty, e2 = c.x == kEmpty, e3 = c.y == kEmpty;
+        const bool y0 = h0 || e0, y1 = h1 || e1, y2 = h2 || e2, y3 = h3 || e3;
+        if (!(y0 || y1 || y2 || y3)) { g = (g + 4) & (kSlots - 1); continue; }
+        j = (int)g + (y0 ? 0 : y1 ? 1 : y2 ? 2 : 3);
+        if (h0 || (!e0 && (h1 || (!e1 && (h2 || (!e2 && h3)))))) break;
+        if (atomicAdd(&s_used, 1u) >= (unsigned)kSoftLimit) { j = -1; break; }
+        const unsigned long long cur = atomicCAS(&l_key[j], kEmpty, key);
+        if (cur == kEmpty || cur == key) break;
+      }
     }
     if (__builtin_expect(j >= 0, 1)) {
       if (FX) {
@@ -399,7 +418,10 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   // (see above: skewed columns).  LEAN = true (chosen by the host from the quick look: rows 1024 apart — a lane's consecutive rows —
   // rarely share a key): every row goes to the table at once; the pending group's bookkeeping, ≈ 20 of a row's ≈ 140 vector
   // instructions and nine registers, would buy nothing (every row flushed the pending group anyway).
-  auto step = [&](int64_t b) {
+  for (int64_t b = r0; b < r1; b += kStep) {
+    if constexpr (DIRECT) {
+      if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
     unsigned long long k[U], v[U];
     unsigned rw[U];
 #pragma unroll
@@ -451,16 +473,6 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
       p_cf = (p_cf + (cf & kCntMask)) | (cf & ~kCntMask);   // < 2^19 rows per chunk: the count cannot reach the flag bits
       p_first = row < p_first ? row : p_first;
     }
-  };
-  for (int64_t b = r0; b < r1; b += kStep) {
-    // DIRECT only — the attempt is void (a table overflowed: far more groups than estimated): stop feeding a full global table, whose
-    // every probe walks all of it — a wrongly chosen direct path cost 0.9 s that way.  (The partitioned path's only route into a
-    // global table, gb_global_slot, looks at the flag itself; polling it here — an agent-scope load whose wait sits in front of the
-    // software-pipelined row loads — cost that path 30 µs of its 422: round 4's regression, profiles/r04_bench_kernel_stats.csv.)
-    if constexpr (DIRECT) {
-      if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-    step(b);
   }
   if (!LEAN && p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
   if (went_direct) s_direct = 1;
@@ -853,7 +865,7 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
   const int64_t nbuckets = (int64_t)1 << lb;
   const int64_t ntiles = ah_ceil_div(n, kMsTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
   const unsigned grid1 = (unsigned)(((ntiles + 7) / 8) * 8);
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const size_t need = pad((size_t)n * 8) * 4 + pad((size_t)n * 4) * 3 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
                       pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)nbuckets + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
                       pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
@@ -956,7 +968,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   const int64_t P = (int64_t)1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kMsTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
   const unsigned grid1 = (unsigned)(((ntiles + 7) / 8) * 8);
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const int64_t nslots = P * kFlatStride;
   const size_t need = pad((size_t)n * 8) * 4 + pad((size_t)n * 4) * 2 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
                       pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
@@ -1589,7 +1601,7 @@ static int gb_cut_aggregate(ah_ctx* c, int is_f64, int lp, const unsigned* hist,
   const int P = 1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
   const int64_t nslots = (int64_t)P * kGStride;
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const int64_t xrows = ((ntiles + 7) >> 3) * kGbTile;   // rows of the tiles one XCD takes (xcd_contiguous_tile)
   // record arrays: dense (n rows) behind the offsets table; regions (≤ 1.5 n + slack, gb_layout_kernel checks) + kGbTile spare rows otherwise
   const int64_t cap_rows = reserve ? n + n / 2 + (int64_t)P * kGbRegions * 96 : n;

@@ -888,7 +888,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
     if (restart) continue;
     // first-seen ranks of the used slots over the first `rows` rows: table[].id, dict, first_rows, total, null_id
     auto rank_slots = [&](int64_t rows) -> int {
-      const int64_t nw = ah_ceil_div(rows, 64), nt = ah_ceil_div(nw, 32);
+      const int64_t nw = ah_ceil_div(rows, 64), nt = rank_tiles(nw);
       AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nw * 8, c->stream));
       mark_kernel<<<ah_stream_grid(c, ah_ceil_div((int64_t)cap + 2, kBlock)), kBlock, 0, c->stream>>>(table, cap + 2, firsts);
       AH_LAUNCH_CHECK(c);

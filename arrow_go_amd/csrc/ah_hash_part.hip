@@ -274,7 +274,7 @@ __global__ void enc_null_entry_kernel(const unsigned* __restrict__ tab_first, in
 __global__ __launch_bounds__(kBlock) void rank_rec_kernel(const unsigned long long* __restrict__ firsts, const unsigned* __restrict__ wordprefix,
                                                            const int64_t* __restrict__ tileoff, int64_t nwords, ulonglong2* __restrict__ rec) {
   const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (w < nwords) rec[w] = make_ulonglong2(firsts[w], (unsigned long long)(tileoff[w >> 5] + wordprefix[w]));
+  if (w < nwords) rec[w] = make_ulonglong2(firsts[w], (unsigned long long)(tileoff[w >> kRankTileLog2] + wordprefix[w]));
 }
 
 // ids of the slots + the dictionary (and the first rows) in id order.  compact = false: every used slot writes its key to dict[id] —
@@ -815,7 +815,7 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   const int P = 1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles);
   const int64_t nslots = (int64_t)P * (slots + 8);
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const size_t table = (size_t)P * (size_t)ntiles * 4;
   const size_t need = pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) + pad((size_t)n * 8) + pad((size_t)n * 4) + pad((size_t)n * 2) +
                       pad((size_t)nslots * 8) + pad((size_t)nslots * 4) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
@@ -909,7 +909,7 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   const int64_t P = (int64_t)1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kGbTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
   const int64_t nslots = P * (slots + 8);
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = ah_ceil_div(nwords, 32);
+  const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const size_t need = pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) + pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) +
                       pad((size_t)n * 8) * 2 + pad((size_t)n * 4) * 2 + pad((size_t)n * 2) * 2 + pad((size_t)nslots * 8) + pad((size_t)nslots * 4) +
                       pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8);

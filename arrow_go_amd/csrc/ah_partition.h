@@ -47,7 +47,7 @@ __global__ __launch_bounds__(1024) void gb_sample_kernel(const unsigned long lon
   __syncthreads();
   const int half = blockIdx.x >= gridDim.x / 2 ? 1 : 0;
   const int64_t blk = (int64_t)blockIdx.x - (half ? gridDim.x / 2 : 0);
-  bm += half ? ((size_t)mmask + 1) / 32 : 0;
+  if (bm) bm += half ? ((size_t)mmask + 1) / 32 : 0;   // bm == nullptr: the histogram alone (the partition-first encode sizes its regions from it)
   const int64_t gfirst = (blk * 16 * kSampleBatches) * 2 + half;
   const int x0 = hist ? (int)((gfirst * stride) / xrows) : 0;   // (uniform)
   for (int r = 0; r < kSampleBatches; r++) {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void gb_sample_kernel(const unsigned long lon
       if (x == x0) atomicAdd(&s_hist[b], 1u);
       else atomicAdd(&hist[(x < 7 ? x : 7) * 1024 + (int)b], 1u);
     }
-    if (!kv) continue;
+    if (!kv || !bm) continue;
     const uint64_t m = mix | 1ull;
     const unsigned f = (unsigned)(m >> 44) & 1023u;
     if (atomicExch(&s_seen[f], m) == m) continue;   // an LDS atomic, so that of the lanes holding a hot key at this instant only one goes on
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
                                                                unsigned* __restrict__ prows, unsigned long long* __restrict__ tile_max,
                                                                const unsigned* __restrict__ rstart = nullptr, const unsigned* __restrict__ rcap = nullptr,
                                                                unsigned* __restrict__ cursor = nullptr, unsigned* __restrict__ redo = nullptr,
-                                                               unsigned trash_base = 0) {
+                                                               unsigned trash_base = 0, unsigned* __restrict__ cnt_out = nullptr,
+                                                               unsigned* __restrict__ toffs_out = nullptr) {
   __shared__ unsigned s_cnt[kMaxBins], s_start[kMaxBins], s_goff[kMaxBins], s_wsum[kThreads / 64];
   __shared__ unsigned long long s_stage[kGbTile];
   __shared__ uint16_t s_bin[kGbTile];
@@ -362,6 +363,9 @@ __global__ __launch_bounds__(kThreads) void gb_scatter_kernel(const unsigned lon
       over = at + cnt > rcap[r];
       goff_excl = rstart[r] + at;
     }
+    // (tile, partition) → {rows, where the run went}: what the histogram pass and the offsets table told the passes that send
+    // per-record results home tile by tile (the encode's un-permute)
+    if (cnt_out) { cnt_out[tile * nb + threadIdx.x] = cnt; toffs_out[tile * nb + threadIdx.x] = goff_excl; }
   }
   block_excl_scan(s_cnt, s_start, s_wsum, nb);
   // a run that does not fit its region goes to kGbTile spare rows behind the regions (trash_base; position = the staged position):

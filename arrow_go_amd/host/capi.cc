@@ -879,7 +879,12 @@ AHC_EXPORT int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, in
   for (int i = 0; i < ncols; i++) {
     batch.names.push_back(col_names && col_names[i] ? col_names[i] : "c" + std::to_string(i));
     batch.values.push_back(cols[i]->d);
-    if (cols[i]->d.kind == DatumKind::Array) { batch.len = cols[i]->d.array->length; have_len = true; }
+    if (cols[i]->d.kind == DatumKind::Array) {
+      // exprs/exec.go makeExecBatch: every array column has the batch's length (as ExecuteScalarSubstrait checks: substrait.cc)
+      if (have_len && cols[i]->d.array->length != batch.len) return Fail(s, Status::Make(StatusCode::Invalid, "mismatched length"));
+      batch.len = cols[i]->d.array->length;
+      have_len = true;
+    }
   }
   if (!have_len) batch.len = 1;
   Datum res;

@@ -266,6 +266,8 @@ def test_substrait_execute_scalar_func_call(sess):
     assert not fused and got.equals(pa.array([6.25, 2.5, -2.25]))
     with pytest.raises(ac.ErrInvalid, match="no match for field reference 'zz'"):
         sess.eval_expression_tree(("call", "add", [("field", "zz"), ("field", 0)]), [a, bcol], names=["a", "b"])
+    with pytest.raises(ac.ErrInvalid, match="mismatched length"):     # makeExecBatch: every array column has the batch's length
+        sess.eval_expression_tree(("call", "add_unchecked", [("field", 0), ("field", 1)]), [a, pa.array([1.0, 2.0])], names=["a", "b"])
 
 
 BORING = [("in", pa.bool_()), ("bool", pa.bool_()), ("i8", pa.int8()), ("i32", pa.int32()), ("u32", pa.uint32()), ("i64", pa.int64()), ("f32", pa.float32()),
