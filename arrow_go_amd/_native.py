@@ -134,6 +134,7 @@ _SIGS = {
     "ah_filter_count": [_vp, _vp, _vp, _i64, _i64, _int, _pi64],
     "ah_filter_primitive": [_vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _int, _i64, _vp, _vp, _pi64],
     "ah_filter_primitive_dev": [_vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp],
+    "ah_filter_primitive_once": [_vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _int, _vp, _vp, _pi64, _pi64],
     "ah_take_primitive_dev": [_vp, _int, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "ah_filter_to_indices": [_vp, _vp, _vp, _i64, _i64, _int, _i64, _vp, _vp, _pi64],
     "ah_take_primitive": [_vp, _int, _vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _i64, _i64, _int, _vp, _vp, _pi64, _pi64],

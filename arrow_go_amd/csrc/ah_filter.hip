@@ -523,6 +523,40 @@ AH_EXPORT int ah_filter_primitive_dev(ah_ctx* c, int byte_width, const void* val
   return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);
 }
 
+// PrimitiveFilter in ONE call for a caller that sizes its output for the worst case (n rows): no count call, no turnaround between two
+// launches — counts and fill run back to back on the stream and the selection count and the output null count come back through the
+// polled mailbox.  A host language pays its call overhead once instead of twice (count → allocate → fill: 0.318 ms from Python for
+// 2^27 rows at s = 0.5, 0.284 from C; the fill itself is 0.263).
+AH_EXPORT int ah_filter_primitive_once(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                                       const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                                       void* out_values, uint8_t* out_valid, int64_t* n_out_host, int64_t* out_null_count_host) {
+  AH_ENTER(c);
+  if (n < 0 || foff < 0 || voff < 0) return ah_fail(c, AH_EINVALID, "filter: negative length/offset");
+  if (!n_out_host) return ah_fail(c, AH_EINVALID, "filter: null result pointer");
+  *n_out_host = 0;
+  if (out_null_count_host) *out_null_count_host = 0;
+  if (n == 0) return AH_OK;
+  if (!fdata || !values || !out_values) return ah_fail(c, AH_EINVALID, "filter: null input buffer");
+  if (((uintptr_t)values | (uintptr_t)out_values) & (uintptr_t)(byte_width - 1))
+    return ah_fail(c, AH_EINVALID, "filter: buffer not element-aligned");
+  if (c->capturing) { c->capturing = 2; return ah_fail(c, AH_EINVALID, "filter_primitive_once returns values to the host: it cannot be recorded into a graph"); }
+  int64_t* status = (int64_t*)&c->dscalars[6];   // [6] rows selected, [7] output nulls
+  int rc;
+  switch (byte_width) {   // n_out = n: the capacity the caller sized the output for
+    case 1: rc = run_filter<1, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
+    case 2: rc = run_filter<2, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
+    case 4: rc = run_filter<4, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
+    case 8: rc = run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
+    default: return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);
+  }
+  if (rc != AH_OK) return rc;
+  unsigned long long back[2];
+  if ((rc = ah_mailbox_read(c, (const unsigned long long*)status, 2, back)) != AH_OK) return rc;
+  *n_out_host = (int64_t)back[0];
+  if (out_null_count_host) *out_null_count_host = (int64_t)back[1];
+  return AH_OK;
+}
+
 // internal (ah_hash_part.hip): out_values[j] = values[r], out_rows[j] = r for the set bits r of `bits` (bit 0 of byte 0 = row 0) in ascending
 // order — a dictionary in first-occurrence order is the key column compacted by its "first occurrence" bitmap.  No host round trip.
 int ah_compact_u64_by_bits(ah_ctx* c, const uint64_t* values, const uint8_t* bits, int64_t n, uint64_t* out_values, int64_t* out_rows) {

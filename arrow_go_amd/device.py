@@ -435,6 +435,15 @@ class Context:
         check(self.handle, lib.ah_filter_primitive_dev(self.handle, byte_width, _ptr(values), _ptr(vvalid), voff, _ptr(fdata),
                                                        _ptr(fvalid), foff, n, null_sel, _ptr(out_values), _ptr(out_valid), _ptr(status_dev)))
 
+    def filter_primitive_once(self, byte_width: int, values, vvalid, voff: int, fdata, fvalid, foff: int, n: int, null_sel: int,
+                              out_values, out_valid):
+        """PrimitiveFilter in ONE call: outputs sized for n rows (the worst case), → (rows selected, output null count)."""
+        k, nulls = C.c_int64(), C.c_int64()
+        check(self.handle, lib.ah_filter_primitive_once(self.handle, byte_width, _ptr(values), _ptr(vvalid), voff, _ptr(fdata),
+                                                        _ptr(fvalid), foff, n, null_sel, _ptr(out_values), _ptr(out_valid),
+                                                        C.byref(k), C.byref(nulls)))
+        return k.value, nulls.value
+
     def take_primitive_dev(self, byte_width: int, values, vvalid, voff: int, nvalues: int, idx_byte_width: int, idx_signed: bool,
                            idx, ivalid, ioff: int, nidx: int, out_values, out_valid, status_dev) -> None:
         """No host round trip: {position of the first out-of-range index or 2^64 − 1, null count} left in `status_dev` (16 bytes)."""

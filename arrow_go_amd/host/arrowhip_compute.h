@@ -246,7 +246,13 @@ namespace compute {
 struct FunctionOptions { virtual ~FunctionOptions() = default; virtual const char* TypeName() const = 0; };
 struct ArithmeticOptions : FunctionOptions { bool NoCheckOverflow = false; const char* TypeName() const override { return "ArithmeticOptions"; } };
 enum NullSelectionBehavior { DropNulls = 0, EmitNulls = 1 };
-struct FilterOptions : FunctionOptions { NullSelectionBehavior NullSelection = DropNulls; const char* TypeName() const override { return "FilterOptions"; } };
+struct FilterOptions : FunctionOptions {
+  NullSelectionBehavior NullSelection = DropNulls;
+  // not in the reference (its PrimitiveFilter always counts first: vector_selection.go:459-475): true = the output is allocated for the
+  // worst case (as many rows as the input) and the kernel runs in ONE call — no count, no second launch after the host has heard back
+  bool WorstCaseOutput = false;
+  const char* TypeName() const override { return "FilterOptions"; }
+};
 struct TakeOptions : FunctionOptions { bool BoundsCheck = true; const char* TypeName() const override { return "TakeOptions"; } };
 enum NullEncodingBehavior { NullEncodingMask = 0, NullEncodingEncode = 1 };
 struct DictionaryEncodeOptions : FunctionOptions { NullEncodingBehavior NullEncoding = NullEncodingMask; const char* TypeName() const override { return "DictionaryEncodeOptions"; } };

@@ -347,6 +347,7 @@ static void ParseOptions(const char* text, ParsedOptions* p) {
     if (eq != std::string::npos) {
       std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
       if (k == "null_selection_behavior") { p->filter.NullSelection = v == "emit_null" ? compute::EmitNulls : compute::DropNulls; p->pick = &p->filter; }
+      else if (k == "output_sizing") { p->filter.WorstCaseOutput = v == "worst_case"; p->pick = &p->filter; }
       if (k == "bounds_check") { p->take.BoundsCheck = v != "0"; p->pick = &p->take; }
       if (k == "to_type") {
         p->cast.ToType = v == "bool" ? GetDataType(Type::BOOL) : nullptr;

@@ -434,6 +434,25 @@ static Status ExecFilter(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
   AHC_RETURN_NOT_OK(values.UpdateNullCount(s));
   AHC_RETURN_NOT_OK(filter.UpdateNullCount(s));
   const uint8_t* fvalid = filter.MayHaveNulls() ? filter.buffers[0].buf : nullptr;
+  if (opts && opts->WorstCaseOutput && values.len > 0 && values.type->bit_width >= 8) {
+    // ONE call (ah_filter_primitive_once): the output is sized for the input's length, the kernel counts and fills back to back and the
+    // host hears the selection count once, at the end — the reference's count → allocate → fill costs a host language two calls and a
+    // turnaround between two launches (0.318 against ≈ 0.29 ms for 2^27 rows at s = 0.5)
+    const int w = values.type->bit_width / 8;
+    out->nulls = (values.nulls == 0 && (null_sel == DropNulls || filter.nulls == 0)) ? 0 : kUnknownNullCount;
+    const bool allocate_validity = values.nulls != 0 || filter.nulls != 0;
+    BufferPtr vb, db;
+    if (allocate_validity) { AHC_RETURN_NOT_OK(k->AllocateBitmap(values.len, &vb)); out->buffers[0].WrapBuffer(vb); }
+    AHC_RETURN_NOT_OK(k->Allocate(values.len * w, &db, /*zero_all=*/false));
+    out->buffers[1].WrapBuffer(db);
+    int64_t n_sel = 0, nulls = 0;
+    const uint8_t* vvalid = values.MayHaveNulls() ? values.buffers[0].buf : nullptr;
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_primitive_once(s->ctx(), w, Values(values), vvalid, values.offset, filter.buffers[1].buf, fvalid, filter.offset,
+                                                             values.len, null_sel, db->dptr, allocate_validity ? (uint8_t*)vb->dptr : nullptr, &n_sel, &nulls)));
+    out->len = n_sel;
+    if (allocate_validity) out->nulls = nulls;
+    return Status::OK();
+  }
   int64_t n_out = 0;
   if (values.len > 0)  // getFilterOutputSize :57-81
     AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_count(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, filter.len, null_sel, &n_out)));

@@ -283,6 +283,10 @@ def per_kernel_table(ctx, rows, a, b, c, x):
         fill_only = out.pop(name + "_fill_only")["ms"]
         timed(name, traffic, call)
         out[name]["fill_only_ms"] = fill_only
+        # the ONE-call flavour for a caller that sizes its output for n rows (ah_filter_primitive_once): counts + fill back to back, the
+        # selection count through the mailbox at the end — no turnaround between two launches
+        timed(name + "_once", traffic, lambda: ctx.filter_primitive_once(8, a, vvalid, 0, fmask, fv, 0, rows, null_sel, c, ovalid))
+        out[name]["one_call_ms"] = out.pop(name + "_once")["ms"]
         out[name]["input_GB/s"] = round(8 * rows / out[name]["ms"] / 1e6, 1)
         out[name]["selected"] = round(n_out / rows, 4)
 

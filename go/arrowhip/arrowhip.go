@@ -229,6 +229,16 @@ func (x *Context) FilterPrimitiveDev(byteWidth int, values, vvalid unsafe.Pointe
 		(*C.uint8_t)(fvalid), C.int64_t(foff), C.int64_t(n), C.int(nullSel), outValues, (*C.uint8_t)(outValid), (*C.int64_t)(statusDev)))
 }
 
+// FilterPrimitiveOnce: PrimitiveFilter in ONE synchronous call for a caller that sizes its outputs for n rows — no count call, no
+// second launch after the host has heard back; the rows selected and the output null count come back through the mailbox.
+func (x *Context) FilterPrimitiveOnce(byteWidth int, values, vvalid unsafe.Pointer, voff int64, fdata, fvalid unsafe.Pointer,
+	foff, n int64, nullSel int, outValues, outValid unsafe.Pointer) (nOut, nulls int64, err error) {
+	var k, r C.int64_t
+	err = x.err(C.ah_filter_primitive_once(x.c, C.int(byteWidth), values, (*C.uint8_t)(vvalid), C.int64_t(voff), (*C.uint8_t)(fdata),
+		(*C.uint8_t)(fvalid), C.int64_t(foff), C.int64_t(n), C.int(nullSel), outValues, (*C.uint8_t)(outValid), &k, &r))
+	return int64(k), int64(r), err
+}
+
 func (x *Context) TakePrimitiveDev(byteWidth int, values, vvalid unsafe.Pointer, voff, nvalues int64, idxWidth int, idxSigned bool,
 	idx, ivalid unsafe.Pointer, ioff, nidx int64, outValues, outValid, statusDev unsafe.Pointer) error {
 	s := C.int(0)

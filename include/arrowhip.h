@@ -346,6 +346,12 @@ int ah_filter_primitive(ah_ctx* ctx, int byte_width, const void* values, const u
 int ah_filter_primitive_dev(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
                             const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
                             void* out_values, uint8_t* out_valid, int64_t* status_dev /* [2] */);
+/* … and the same in ONE synchronous call: outputs sized for n rows as above, the rows selected and the output null count returned to
+ * the host through the polled mailbox — for callers that can afford the worst-case allocation (vector_selection.go:459-475 sizes
+ * exactly, at the price of a count call and a second launch after the host has heard back). */
+int ah_filter_primitive_once(ah_ctx* ctx, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
+                             const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n, int null_sel,
+                             void* out_values, uint8_t* out_valid, int64_t* n_out_host, int64_t* out_null_count_host);
 /* GetTakeIndices (kernels/vector_selection.go:102-236), uint32 flavour: the mask as
  * an index vector so FilterRecordBatch can gather N columns with one scan. */
 int ah_filter_to_indices(ah_ctx* ctx, const uint8_t* fdata, const uint8_t* fvalid, int64_t foff, int64_t n,

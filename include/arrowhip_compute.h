@@ -170,7 +170,9 @@ int ahc_record_column(ahc_session* s, ahc_datum* d, int i, const char** name, ah
 /* ---- calls -------------------------------------------------------------------------------------------------------- */
 /* compute.CallFunction(ctx, name, opts, args...) (compute/exec.go:191-199).  `options` is "key=value;key=value" (NULL
  * or "" = the function's defaults) for the option structs of the registered functions:
- *   FilterOptions  null_selection_behavior=drop|emit_null        TakeOptions  bounds_check=0|1
+ *   FilterOptions  null_selection_behavior=drop|emit_null; output_sizing=exact|worst_case (worst_case: the output is allocated
+ *                  for the input's length and the kernel runs in ONE call — ah_filter_primitive_once — instead of count → allocate → fill)
+ *   TakeOptions    bounds_check=0|1
  *   CastOptions    to_type=<type name>; to_logical=<C Data format>; safe=0; allow_int_overflow= allow_float_truncate=
  *                  allow_time_truncate= allow_time_overflow=0|1
  *   SetOptions     value_set=@<hex address of an array ahc_datum>; null_matching_behavior=match|skip|emit_null|inconclusive

@@ -310,6 +310,20 @@ class HipBackend:
         nulls = self.c.filter_primitive(w, vp, vvp, voff, fp, fvp, foff, n, null_sel, n_out, ob, ovb)
         out = ob.download(values.dtype, n_out)
         ov = ovb.download(np.uint8, (n_out + 7) // 8) if want_valid else None
+        # every Filter of the suite also goes through the one-call entry (ah_filter_primitive_once: outputs sized for n rows, count and
+        # null count through the mailbox) and must give the same rows, validity bits, count and null count
+        ob1 = self._dirty(n * w + 128)
+        ob1.memset(0xCD)
+        ovb1 = self._dirty((n + 7) // 8 + 64) if want_valid else None
+        if ovb1 is not None:
+            ovb1.memset(0xCD)
+        k1, nulls1 = self.c.filter_primitive_once(w, vp, vvp, voff, fp, fvp, foff, n, null_sel, ob1, ovb1)
+        assert k1 == n_out, ("filter_primitive_once: rows selected", k1, n_out)
+        assert ob1.download(values.dtype, n_out).tobytes() == out.tobytes(), "filter_primitive_once: values"
+        if want_valid:
+            assert nulls1 == nulls, ("filter_primitive_once: null count", nulls1, nulls)
+            bits = lambda b: np.unpackbits(b, bitorder="little")[:n_out]
+            assert (bits(ovb1.download(np.uint8, (n_out + 7) // 8)) == bits(ov)).all(), "filter_primitive_once: validity"
         return out, ov, nulls
 
     def filter_to_indices(self, fdata, fvalid, foff, n, null_sel, want_valid):

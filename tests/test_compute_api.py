@@ -775,6 +775,24 @@ def test_fused_equals_three_calls(sess):
     assert sess.call_function("greater_filter_sum", [x, thr]).as_py() == sess.math_sum(kept) == pc.sum(kept).as_py()
 
 
+@pytest.mark.gpu
+def test_filter_worst_case_output_is_one_call(sess):
+    """FilterOptions output_sizing=worst_case: the output is allocated for the input's length and the kernel runs in ONE call
+    (ah_filter_primitive_once) instead of count → allocate → fill; same arrays as the default and as Arrow C++"""
+    rng = np.random.default_rng(17)
+    n = 300_007
+    for typ in (pa.int64(), pa.float32(), pa.uint8()):
+        for vnulls in (False, True):
+            for fnulls in (False, True):
+                v = pa.array(rng.integers(0, 200, n), mask=(rng.random(n) < 0.1) if vnulls else None, type=pa.int64()).cast(typ)
+                f = pa.array(rng.random(n) < 0.5, mask=(rng.random(n) < 0.1) if fnulls else None)
+                for sel in ("drop", "emit_null"):
+                    want = pc.filter(v, f, null_selection_behavior=sel)
+                    got = sess.call_function("filter", [v, f], options=f"null_selection_behavior={sel};output_sizing=worst_case")
+                    base = sess.call_function("filter", [v, f], options=f"null_selection_behavior={sel}")
+                    assert got.equals(want) and base.equals(want) and got.null_count == want.null_count, (typ, vnulls, fnulls, sel)
+
+
 # ---- divide / abs / negate / bit-wise / shifts / sqrt through the registry ------------------------------------
 @pytest.mark.gpu
 def test_extended_arithmetic_functions(sess):
