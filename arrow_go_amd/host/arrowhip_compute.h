@@ -39,6 +39,7 @@ namespace arrowhip {
 enum class Type : int {
   NA = 0, BOOL = 1, UINT8 = 2, INT8 = 3, UINT16 = 4, INT16 = 5, UINT32 = 6, INT32 = 7,
   UINT64 = 8, INT64 = 9, FLOAT16 = 10, FLOAT32 = 11, FLOAT64 = 12, STRING = 13, BINARY = 14,
+  FIXED_SIZE_BINARY = 15, DECIMAL128 = 23, DECIMAL256 = 24,   // arrow.FIXED_SIZE_BINARY / DECIMAL128 / DECIMAL256 (arrow/datatype.go)
   LARGE_STRING = 34, LARGE_BINARY = 35, DICTIONARY = 36
 };
 
@@ -49,6 +50,11 @@ struct DataType {
   const char* format;  // Arrow C Data Interface format string
 };
 const DataType* GetDataType(Type id);  // singletons; nullptr if unsupported
+// FixedSizeBinary / Decimal128 / Decimal256 are PARAMETRIC (byte width; precision, scale): one interned DataType per C Data format
+// ("w:16", "d:20,3", "d:40,5,256").  bit_width = 8 · the value's bytes.  GetDataType(id) of the three ids is a width-less
+// placeholder for dispatch by type id.  Keys of unique / dictionary_encode (vector_hash.go:608-609, 698); no arithmetic on them.
+const DataType* FixedWidthBinaryFromFormat(const std::string& format);   // nullptr: not such a format
+bool IsFixedWidthBinary(Type id);
 bool IsInteger(Type id);
 bool IsSignedInteger(Type id);
 bool IsFloating(Type id);

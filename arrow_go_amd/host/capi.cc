@@ -94,6 +94,7 @@ AHC_EXPORT int ahc_dispatch_best(const char* function, int nargs, const int* typ
 
 static const DataType* TypeFromFormat(const char* f) {
   if (f && f[0] == 't') return TemporalStorage(f);  // timestamps, dates, times, durations: integers with a label
+  if (f && (f[0] == 'w' || f[0] == 'd') && f[1] == ':') return FixedWidthBinaryFromFormat(f);   // FixedSizeBinary, Decimal128 / 256
   if (!f || !f[0] || f[1]) return nullptr;
   for (Type bt : {Type::STRING, Type::BINARY, Type::LARGE_STRING, Type::LARGE_BINARY})
     if (GetDataType(bt)->format[0] == f[0]) return GetDataType(bt);

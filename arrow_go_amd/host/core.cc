@@ -7,6 +7,8 @@
 
 #include <climits>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 
@@ -36,8 +38,41 @@ const DataType* TemporalStorage(const std::string& f) {
 }
 bool IsBaseBinary(Type id) { return id == Type::STRING || id == Type::BINARY || id == Type::LARGE_STRING || id == Type::LARGE_BINARY; }
 
+static const DataType kFixedPlaceholders[] = {{Type::FIXED_SIZE_BINARY, 0, "fixed_size_binary", "w:0"}, {Type::DECIMAL128, 128, "decimal128", "d:38,0"},
+                                              {Type::DECIMAL256, 256, "decimal256", "d:76,0,256"}};
+bool IsFixedWidthBinary(Type id) { return id == Type::FIXED_SIZE_BINARY || id == Type::DECIMAL128 || id == Type::DECIMAL256; }
+const DataType* FixedWidthBinaryFromFormat(const std::string& f) {
+  Type id;
+  int bits = 0;
+  const char* name;
+  if (f.size() > 2 && f[0] == 'w' && f[1] == ':') {   // "w:<bytes>"
+    char* end = nullptr;
+    const long w = strtol(f.c_str() + 2, &end, 10);
+    if (!end || *end || w <= 0 || w > (1 << 20)) return nullptr;
+    id = Type::FIXED_SIZE_BINARY; bits = (int)w * 8; name = "fixed_size_binary";
+  } else if (f.size() > 2 && f[0] == 'd' && f[1] == ':') {   // "d:<precision>,<scale>[,<bits>]"
+    int p = 0, sc = 0, bw = 128;
+    const int got = sscanf(f.c_str() + 2, "%d,%d,%d", &p, &sc, &bw);
+    if (got < 2 || (bw != 128 && bw != 256)) return nullptr;   // (decimal32 / 64 of newer Arrow versions: not in this reference)
+    id = bw == 128 ? Type::DECIMAL128 : Type::DECIMAL256; bits = bw; name = bw == 128 ? "decimal128" : "decimal256";
+  } else {
+    return nullptr;
+  }
+  static std::mutex mu;
+  static std::map<std::string, std::unique_ptr<DataType>> interned;   // (map nodes do not move: the key's bytes are the format string)
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = interned.find(f);
+  if (it == interned.end()) {
+    it = interned.emplace(f, nullptr).first;
+    it->second.reset(new DataType{id, bits, name, it->first.c_str()});
+  }
+  return it->second.get();
+}
+
 const DataType* GetDataType(Type id) {
   if (id == Type::DICTIONARY) return &kDictType;
+  for (auto& t : kFixedPlaceholders)
+    if (t.id == id) return &t;
   for (auto& t : kBinaryTypes)
     if (t.id == id) return &t;
   int i = (int)id;

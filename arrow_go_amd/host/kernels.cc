@@ -909,6 +909,58 @@ static Status ExecHashBinary(KernelCtx* k, const ExecSpan& b, ExecResult* out, b
   return Status::OK();
 }
 
+// FixedSizeBinary / Decimal128 / Decimal256 keys (vector_hash.go:608-609, 698: the BinaryMemoTable over values of one byte width):
+// ah_hash_fixed_encode — ids, index validity, null id as for the var-length keys; the dictionary comes back as ndict values
+static Status ExecHashFixed(KernelCtx* k, const ExecSpan& b, ExecResult* out, bool dict_encode) {
+  Session* s = k->session;
+  ArraySpan keys = b.values[0].array;
+  const DictionaryEncodeOptions* opts = static_cast<const DictionaryEncodeOptions*>(k->state);
+  int encode_nulls = dict_encode ? (opts && opts->NullEncoding == NullEncodingEncode) : 1;
+  AHC_RETURN_NOT_OK(keys.UpdateNullCount(s));
+  const uint8_t* valid = keys.MayHaveNulls() ? keys.buffers[0].buf : nullptr;
+  const int64_t n = keys.len;
+  const int w = keys.type->bit_width / 8;
+  if (w <= 0) return Status::Make(StatusCode::Invalid, "fixed-size binary keys need a byte width");
+  BufferPtr ids, ids_valid, first_rows, dict;
+  AHC_RETURN_NOT_OK(k->Allocate((n + 1) * 8, &first_rows));
+  AHC_RETURN_NOT_OK(k->Allocate((n + 1) * w, &dict));   // at most n + 1 entries; handed on as the dictionary's value buffer
+  if (dict_encode) {
+    AHC_RETURN_NOT_OK(k->Allocate(n * 4, &ids, /*zero_all=*/false));
+    if (valid && !encode_nulls) AHC_RETURN_NOT_OK(k->AllocateBitmap(n, &ids_valid));
+  }
+  int64_t ndict = 0; int32_t null_id = -1;
+  if (n > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_hash_fixed_encode(s->ctx(), w, keys.buffers[1].buf, valid, keys.offset, n, encode_nulls, ids ? (int32_t*)ids->dptr : nullptr,
+                                                         ids_valid ? (uint8_t*)ids_valid->dptr : nullptr, (int64_t*)first_rows->dptr, (uint8_t*)dict->dptr,
+                                                         &ndict, &null_id)));
+  auto d = std::make_shared<ArrayData>();
+  d->type = keys.type;
+  d->length = ndict;
+  d->null_count = null_id >= 0 ? 1 : 0;
+  d->buffers[1] = dict;
+  if (null_id >= 0) {   // GetDictArrayData (arrow/array/util.go:375-384): all ones with the null entry's bit cleared
+    BufferPtr dv;
+    AHC_RETURN_NOT_OK(k->AllocateBitmap(ndict, &dv));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), dv->dptr, 0xFF, (size_t)((ndict + 7) / 8))));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_set_bits_to(s->ctx(), (uint8_t*)dv->dptr, null_id, 1, 0)));
+    d->buffers[0] = dv;
+  }
+  if (!dict_encode) {  // uniqueFinalize (vector_hash.go:721-741)
+    out->type = d->type;
+    out->len = d->length;
+    out->nulls = d->null_count;
+    out->buffers[0].WrapBuffer(d->buffers[0]);
+    out->buffers[1].WrapBuffer(d->buffers[1]);
+    return Status::OK();
+  }
+  out->len = n;
+  out->nulls = ids_valid ? keys.nulls : 0;
+  out->buffers[0].WrapBuffer(ids_valid);
+  out->buffers[1].WrapBuffer(ids);
+  out->dictionary = d;
+  return Status::OK();
+}
+
 void RegisterVectorHash(FunctionRegistry* reg) {
   auto uq = std::make_shared<VectorFunction>("unique", Arity{1, false});
   uq->chunked = VectorFunction::Chunked::SingleArray;
@@ -924,6 +976,17 @@ void RegisterVectorHash(FunctionRegistry* reg) {
     kd.sig.in_types = {t};
     kd.output_is_dictionary = true;
     kd.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHash(k, b, o, true); };
+    de->AddKernel(std::move(kd));
+  }
+  for (Type t : {Type::FIXED_SIZE_BINARY, Type::DECIMAL128, Type::DECIMAL256}) {
+    exec::VectorKernel ku;
+    ku.sig.in_types = {t};
+    ku.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHashFixed(k, b, o, false); };
+    uq->AddKernel(std::move(ku));
+    exec::VectorKernel kd;
+    kd.sig.in_types = {t};
+    kd.output_is_dictionary = true;
+    kd.exec_fn = [](KernelCtx* k, const ExecSpan& b, ExecResult* o) { return ExecHashFixed(k, b, o, true); };
     de->AddKernel(std::move(kd));
   }
   for (Type t : {Type::BINARY, Type::STRING, Type::LARGE_BINARY, Type::LARGE_STRING}) {

@@ -160,6 +160,21 @@ try:
     raise SystemExit("a capacity of 10 groups was accepted")
 except ah.ErrInvalid as e:
     assert str(ek.size) in str(e), str(e)
+# ONE rank gets an argument wrong (a null group beyond its group count): its status travels in the first all-gather and EVERY rank
+# returns an error — nobody is left waiting in a collective for a rank that went home (the advisor's round-4 finding)
+dk = ctx.to_device(keys[lo:hi]); dv = ctx.to_device(np.ones(hi - lo, np.int64))
+outs = [ctx.alloc((hi - lo + 1) * 8 + 64) for _ in range(4)]
+ng_ok, _ = ctx.hash_sum("i64", dk, None, 0, dv, None, 0, hi - lo, outs[0], outs[1], outs[2], outs[3])
+res = [ctx.alloc((n + 1) * 8 + 64) for _ in range(4)]
+bad_null = ng_ok + 5 if rank == world - 1 else -1
+try:
+    sg.merge_groups(False, outs[0], outs[1], outs[2], outs[3], ng_ok, lo, n + 1, *res, null_group_local=bad_null, with_null_group=True)
+    raise SystemExit(f"rank {rank}: a call in which rank {world - 1} passed a null group beyond its groups succeeded")
+except ah.ErrInvalid as e:
+    assert ("null group" in str(e)) if rank == world - 1 else (f"rank {world - 1} failed" in str(e) or world == 1), str(e)
+# … and the communicator is still usable afterwards
+G, mk, ms, mc, mf = merged("i64", mine_k, mine_v, max(lo - h0, 0), n + 1)
+assert mk.tobytes() == ek.tobytes()
 assert not tr.errors, tr.errors
 comm.close()
 dist.barrier()

@@ -793,6 +793,41 @@ def test_filter_worst_case_output_is_one_call(sess):
                     assert got.equals(want) and base.equals(want) and got.null_count == want.null_count, (typ, vnulls, fnulls, sel)
 
 
+@pytest.mark.gpu
+def test_unique_and_dictionary_encode_of_fixed_size_binary_and_decimals(sess):
+    """FixedSizeBinary / Decimal128 / Decimal256 keys through the registry (kernels/vector_hash.go:608-609, 698: the BinaryMemoTable
+    over values of one byte width → ah_hash_fixed_encode): first-seen order, both null encodings, == Arrow C++"""
+    import decimal
+    rng = np.random.default_rng(23)
+    n = 40_000
+    picks = rng.integers(0, 500, n)
+    mask = rng.random(n) < 0.1
+    cols = []
+    for w in (16, 5, 1):
+        vals = [int(p).to_bytes(8, "little").ljust(w, b"\x07")[:w] for p in picks]
+        cols.append(pa.array([None if m else v for v, m in zip(vals, mask)], type=pa.binary(w)))
+    cols.append(pa.array([None if m else decimal.Decimal(int(p)) / 1000 for p, m in zip(picks, mask)], type=pa.decimal128(20, 3)))
+    cols.append(pa.array([None if m else decimal.Decimal(int(p) * 10**30) / 100000 for p, m in zip(picks, mask)], type=pa.decimal256(50, 5)))
+    cols.append(pa.array([decimal.Decimal(int(p)) for p in picks], type=pa.decimal128(9, 0)))          # no nulls
+    for col in cols:
+        got = sess.call_function("unique", [col])
+        want = pc.unique(col)
+        assert got.type == col.type and got.equals(want), col.type
+        for enc in ("mask", "encode"):
+            g = sess.call_function("dictionary_encode", [col], options=f"null_encoding_behavior={enc}")
+            w_ = pc.dictionary_encode(col, null_encoding=enc)
+            assert g.type.value_type == col.type
+            assert g.indices.equals(w_.indices.cast(pa.int32())) and g.dictionary.equals(w_.dictionary), (col.type, enc)
+    # a sliced column (offset ≠ 0) and an empty one
+    sl = cols[0].slice(1234, 5000)
+    assert sess.call_function("unique", [sl]).equals(pc.unique(sl))
+    empty = pa.array([], type=pa.binary(16))
+    assert len(sess.call_function("unique", [empty])) == 0
+    # nothing else is registered for these types: the reference's dispatch error, not a crash
+    with pytest.raises(Exception, match="no kernel matching"):
+        sess.call_function("add", [cols[3], cols[3]])
+
+
 # ---- divide / abs / negate / bit-wise / shifts / sqrt through the registry ------------------------------------
 @pytest.mark.gpu
 def test_extended_arithmetic_functions(sess):

@@ -110,3 +110,17 @@ def test_can_cast_numeric_and_boolean():
             assert ac.dispatch_best(name, [frm]) == [frm], (frm, to)
     for wrong in ("cast_float32", "cast_float64", "cast_bool"):
         assert not ac.lib.ahc_has_function(wrong.encode())
+
+
+def test_hash_kernels_exist_for_fixed_size_binary_and_decimal_keys():
+    """unique / dictionary_encode hold kernels for FixedSizeBinary, Decimal128 and Decimal256 (kernels/vector_hash.go:608-609: the
+    fixed-size-binary-like types share the binary memo table; type ids 15 / 23 / 24 as in arrow/datatype.go), resolved by type id
+    without a device; arithmetic on them is refused with the reference's dispatch error"""
+    import ctypes as C
+    for fn in ("unique", "dictionary_encode"):
+        for tid in (15, 23, 24):
+            tin, tout, err = (C.c_int * 1)(tid), (C.c_int * 1)(), C.create_string_buffer(512)
+            assert ac.lib.ahc_dispatch_best(fn.encode(), 1, tin, tout, err, len(err)) == 0, (fn, tid, err.value)
+            assert tout[0] == tid
+    tin, tout, err = (C.c_int * 2)(23, 23), (C.c_int * 2)(), C.create_string_buffer(512)
+    assert ac.lib.ahc_dispatch_best(b"add", 2, tin, tout, err, len(err)) != 0 and b"no kernel matching" in err.value
