@@ -145,7 +145,7 @@ def _harness():
     os.makedirs(build, exist_ok=True)
     exe = os.path.join(build, "wire_fuzz")
     host = os.path.join(ROOT, "arrow_go_amd", "host")
-    srcs = [os.path.join(HERE, "wire_fuzz.cc")] + [os.path.join(host, f) for f in ("core.cc", "kernels.cc", "expression.cc", "substrait.cc", "ipc.cc", "capi.cc")]
+    srcs = [os.path.join(HERE, "wire_fuzz.cc")] + [os.path.join(host, f) for f in ("core.cc", "kernels.cc", "expression.cc", "substrait.cc", "ipc.cc", "hoststream.cc", "capi.cc")]
     deps = srcs + [os.path.join(host, "arrowhip_compute.h"), os.path.join(host, "ipc.h"), os.path.join(ROOT, "include", "arrowhip_compute.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
         lib = os.path.join(ROOT, "arrow_go_amd")
