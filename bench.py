@@ -744,9 +744,15 @@ def main():
     try:
         hrows = min(rows, 1 << 26)
         krng = np.random.default_rng(77 + rank)
+        # Keys: 2^26 INDEPENDENT draws over 2^16 values, like the kernel table's rows.  Rounds 1-4 tiled ONE 2^22-row block sixteen times:
+        # with every eighth of the column holding the same rows the eight XCDs run the cut in lockstep on identical data (same run lengths,
+        # destinations a constant stride apart) and a sampled key is met by sixteen workgroups at once — an artefact of the generator that
+        # costs the partitioned path ≈ 0.15 ms (scatter 466 -> 563 us, sample 41 -> 107 us in profiles/r05_bench_kernel_stats.csv).  The
+        # tiled column's time is kept beside the line as `ms_per_step_tiled_block_keys` for continuity with the earlier rounds' numbers.
         kchunk = (krng.integers(0, 1 << 16, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
         for off in range(0, hrows, 1 << 22):
             c.upload(kchunk[:min(1 << 22, hrows - off)], off * 8)
+        tiled_ms = None
         # the owner merge is ONE C-ABI call (ah_comm_merge_groups); it runs whenever the ah_comm communicator exists and world > 1
         merge = comm is not None and world > 1 and not args.no_c5_merge
         obufs = [ctx.alloc((hrows + 1) * 8 + 64) for _ in range(4)]
@@ -761,10 +767,21 @@ def main():
                 ng = comm.merge_groups(True, optr[0], optr[1], optr[2], optr[3], ng, rank * hrows, mcap, *mbufs)
             ngroups[0] = int(ng)
 
+        c5_steps = max(1, min(args.steps, 5))
+        if world == 1:   # the tiled column of rounds 1-4 first (continuity), then the independent draws the line is quoted on
+            c5_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(c5_steps):
+                c5_step()
+            barrier()
+            tiled_ms = round((time.perf_counter() - t0) * 1e3 / c5_steps, 4)
+        for off in range(0, hrows, 1 << 22):
+            kc = (krng.integers(0, 1 << 16, min(1 << 22, hrows - off), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+            c.upload(kc, off * 8)
         c5_step()
         barrier()
         t0 = time.perf_counter()
-        c5_steps = max(1, min(args.steps, 5))
         for _ in range(c5_steps):
             c5_step()
         barrier()
@@ -783,7 +800,8 @@ def main():
         c5 = {"workload": "C5: hash + sum group-by over Int64 keys / Float64 values per GPU" + (", merged by key-hash owner (ah_comm_merge_groups: all-to-all of group tuples)" if merge else
                                                                                                         " (local aggregate; the owner merge over RCCL runs when world > 1 with --collectives ah)"),
               "ms_per_step": round(c5_ms, 4), "Grows/s": round(hrows * args.gpus / (c5_ms * 1e-3) / 1e9, 2), "rows_per_gpu": hrows,
-              "groups": ngroups[0], "n_gpus": args.gpus, "steps": c5_steps}
+              "groups": ngroups[0], "n_gpus": args.gpus, "steps": c5_steps, "keys": "2^26 independent draws over 2^16 values per GPU",
+              "ms_per_step_tiled_block_keys": tiled_ms}
     except Exception as e:  # informative only
         c5 = {"error": repr(e)}
 

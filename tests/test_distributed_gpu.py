@@ -68,7 +68,12 @@ def test_bench_world2_one_gpu(tmp_path):
     o = OL.load_oracle()
     a = np.concatenate([np.random.default_rng(10 + k).integers(-2**62, 2**62, rows, dtype=np.int64) for k in range(world)])
     x = np.concatenate([np.random.default_rng(30 + k).uniform(-1e6, 1e6, rows) for k in range(world)])
-    keys = np.concatenate([(np.random.default_rng(77 + k).integers(0, 1 << 16, 1 << 22, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)[:rows] for k in range(world)])
+    def bench_keys(k):   # bench.py's C5 keys: the generator's first 2^22 draws go to the tiled block of rounds 1-4, the column is the draws after it
+        g = np.random.default_rng(77 + k)
+        g.integers(0, 1 << 16, 1 << 22, dtype=np.uint64)
+        parts = [g.integers(0, 1 << 16, min(1 << 22, rows - off), dtype=np.uint64) for off in range(0, rows, 1 << 22)]
+        return (np.concatenate(parts) * np.uint64(0x9E3779B97F4A7C15)).view(np.int64)
+    keys = np.concatenate([bench_keys(k) for k in range(world)])
     d = np.load(dump)
     assert d["merged"][0] == 1
     assert tuple(d["c4"].tolist()) == o.cmp_filter_sum_i64(2, a, None, 0, 0)                    # C4: Σ and count of a > 0 over both shards
