@@ -33,6 +33,10 @@ template <> struct UIntOf<1> { using type = uint8_t; };
 template <> struct UIntOf<2> { using type = uint16_t; };
 template <> struct UIntOf<4> { using type = uint32_t; };
 template <> struct UIntOf<8> { using type = uint64_t; };
+// 16- and 32-byte values — Decimal128 / Decimal256 and FixedSizeBinary of those widths (FSBImpl, vector_selection.go:1997, takes any
+// width byte by byte; here the widths that are whole 16-byte accesses): moved as 2 / 4 × 64-bit vectors, the plain gather kernel only
+template <> struct UIntOf<16> { using type = unsigned long long __attribute__((ext_vector_type(2))); };
+template <> struct UIntOf<32> { using type = unsigned long long __attribute__((ext_vector_type(4))); };
 
 // NT: the index vector and the output are streamed once — nontemporal, so that they do not push the gathered values' lines out of L2
 template <int W, typename IdxT, bool HAS_VALID, bool NT>
@@ -474,6 +478,8 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
     case 2: rc = dispatch_idx<2>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 4: rc = dispatch_idx<4>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 8: rc = dispatch_idx<8>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
+    case 16: rc = dispatch_idx<16>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
+    case 32: rc = dispatch_idx<32>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     default: return ah_fail(c, AH_EINVALID, "invalid values byte width for take");  // :1189
   }
   if (rc != AH_OK) return rc;

@@ -503,6 +503,55 @@ static Status ExecTake(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
   return Status::OK();
 }
 
+// FSBImpl (vector_selection.go:1997-2031; registered for FIXED_SIZE_BINARY, DECIMAL128 and DECIMAL256 at :2344-2346 / :2354-2356):
+// fixed-width values of any byte width are one slot per row.  The device take moves slots of 1, 2, 4, 8, 16 or 32 bytes (the two
+// decimals, UUID-sized and hash-sized binaries); other widths are refused by name rather than copied byte by byte.
+static Status CheckSlotWidth(const ArraySpan& values) {
+  const int w = values.type->bit_width / 8;
+  if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16 || w == 32) return Status::OK();
+  return Status::Make(StatusCode::NotImplemented, "selection of fixed-size binary values: byte widths 1, 2, 4, 8, 16 and 32 are accelerated, not " + std::to_string(w));
+}
+static Status ExecTakeFixed(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  AHC_RETURN_NOT_OK(CheckSlotWidth(b.values[0].array));
+  return ExecTake(k, b, out);
+}
+// the filter of wide slots goes through GetTakeIndices (vector_selection.go:102-236) and the take, like the binary and boolean
+// filters here: ah_filter_primitive's compaction is built for slots of at most 8 bytes
+static Status ExecFilterFixed(KernelCtx* k, const ExecSpan& b, ExecResult* out) {
+  Session* s = k->session;
+  ArraySpan values = b.values[0].array, filter = b.values[1].array;
+  AHC_RETURN_NOT_OK(CheckSlotWidth(values));
+  const int w = values.type->bit_width / 8;
+  if (w <= 8) return ExecFilter(k, b, out);
+  const FilterOptions* opts = static_cast<const FilterOptions*>(k->state);
+  int null_sel = opts ? (int)opts->NullSelection : DropNulls;
+  AHC_RETURN_NOT_OK(values.UpdateNullCount(s));
+  AHC_RETURN_NOT_OK(filter.UpdateNullCount(s));
+  if (values.len >= ((int64_t)1 << 32)) return Status::Make(StatusCode::NotImplemented, "filter of a fixed-size binary column with 2^32 rows or more");
+  const uint8_t* fvalid = filter.MayHaveNulls() ? filter.buffers[0].buf : nullptr;
+  int64_t n_out = 0;
+  if (values.len > 0)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_count(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, filter.len, null_sel, &n_out)));
+  const bool allocate_validity = values.nulls != 0 || filter.nulls != 0;
+  out->len = n_out;
+  BufferPtr ib, ivb, vb, db;
+  AHC_RETURN_NOT_OK(k->Allocate(n_out * 4, &ib));
+  AHC_RETURN_NOT_OK(k->AllocateBitmap(n_out, &ivb));
+  if (allocate_validity) { AHC_RETURN_NOT_OK(k->AllocateBitmap(n_out, &vb)); out->buffers[0].WrapBuffer(vb); }
+  AHC_RETURN_NOT_OK(k->Allocate(n_out * w, &db, /*zero_all=*/false));
+  out->buffers[1].WrapBuffer(db);
+  out->nulls = 0;
+  if (n_out == 0) return Status::OK();
+  int64_t idx_nulls = 0, nulls = 0, bad = 0;
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_filter_to_indices(s->ctx(), filter.buffers[1].buf, fvalid, filter.offset, values.len, null_sel, n_out,
+                                                       (uint32_t*)ib->dptr, (uint8_t*)ivb->dptr, &idx_nulls)));
+  AHC_RETURN_NOT_OK(s->FromStatus(ah_take_primitive(s->ctx(), w, Values(values), values.MayHaveNulls() ? values.buffers[0].buf : nullptr, values.offset, values.len,
+                                                    4, 0, ib->dptr, idx_nulls ? (const uint8_t*)ivb->dptr : nullptr, 0, n_out, /*bounds_check=*/0, db->dptr,
+                                                    allocate_validity ? (uint8_t*)vb->dptr : nullptr, &nulls, &bad)));
+  out->nulls = allocate_validity ? nulls : 0;
+  return Status::OK();
+}
+
 // dictionaryTake / dictionaryFilter (compute/selection.go:497-586): select the INDICES (int32 on the device), keep a pointer
 // to the same dictionary
 static void CarryDictionary(const ArraySpan& in, ExecResult* out) {
@@ -697,6 +746,12 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
     k.exec_fn = ExecFilterBoolean;
     af->AddKernel(std::move(k));
   }
+  for (Type t : {Type::FIXED_SIZE_BINARY, Type::DECIMAL128, Type::DECIMAL256}) {   // vector_selection.go:2344-2346
+    exec::VectorKernel k;
+    k.sig.in_types = {t, Type::BOOL};
+    k.exec_fn = ExecFilterFixed;
+    af->AddKernel(std::move(k));
+  }
   reg->AddFunction(af, false);
   auto at = std::make_shared<VectorFunction>("array_take", Arity{2, false}, &kDefaultTakeOptions);
   at->chunked = VectorFunction::Chunked::Take;
@@ -722,6 +777,14 @@ void RegisterVectorSelection(FunctionRegistry* reg) {
     k.can_execute_chunkwise = false;
     at->AddKernel(std::move(k));
   }
+  for (Type t : {Type::FIXED_SIZE_BINARY, Type::DECIMAL128, Type::DECIMAL256})   // vector_selection.go:2354-2356
+    for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
+      exec::VectorKernel k;
+      k.sig.in_types = {t, it};
+      k.exec_fn = ExecTakeFixed;
+      k.can_execute_chunkwise = false;
+      at->AddKernel(std::move(k));
+    }
   for (Type t : kBinaryTypes)
     for (Type it : {Type::INT8, Type::UINT8, Type::INT16, Type::UINT16, Type::INT32, Type::UINT32, Type::INT64, Type::UINT64}) {
       exec::VectorKernel k;

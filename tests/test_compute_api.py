@@ -36,7 +36,7 @@ def test_registry_has_the_path_functions():
         assert ac.has_function(name), name
     assert not ac.has_function("no_such_function")
     assert ac.function_num_kernels("add") == 10            # one per numeric type
-    assert ac.function_num_kernels("array_take") == 128     # (10 numeric + 4 binary-like + bool + dictionary value types) × 8 index types
+    assert ac.function_num_kernels("array_take") == 152     # (10 numeric + 4 binary-like + bool + dictionary + 3 fixed-width binary value types) × 8 index types
     assert ac.function_num_kernels("filter") == 0           # MetaFunction
     assert ac.function_num_kernels("cast_int64") == 10       # 9 other numeric types + bool
     assert ac.function_num_kernels("cumulative_sum") == 10 and ac.function_num_kernels("cumulative_sum_checked") == 10
@@ -826,6 +826,49 @@ def test_unique_and_dictionary_encode_of_fixed_size_binary_and_decimals(sess):
     # nothing else is registered for these types: the reference's dispatch error, not a crash
     with pytest.raises(Exception, match="no kernel matching"):
         sess.call_function("add", [cols[3], cols[3]])
+
+
+@pytest.mark.gpu
+def test_take_and_filter_of_fixed_size_binary_and_decimals(sess):
+    """FSBImpl (kernels/vector_selection.go:1997-2031, registered at :2344-2346 and :2354-2356): Decimal128 / Decimal256 and binaries
+    of 16 / 32 bytes are 16- and 32-byte slots of the device take; binary(8) and narrower ride the primitive kernels; the filter of
+    wide slots is GetTakeIndices + take.  == Arrow C++ with nulls on both sides, sliced inputs, every index type."""
+    import decimal
+    rng = np.random.default_rng(29)
+    n = 30_011
+    picks = rng.integers(0, 1 << 40, n)
+    mask = rng.random(n) < 0.1
+    cols = []
+    for w in (32, 16, 8, 2):
+        vals = [int(p).to_bytes(8, "little").ljust(w, b"\x05")[:w] for p in picks]
+        cols.append(pa.array([None if m else v for v, m in zip(vals, mask)], type=pa.binary(w)))
+        cols.append(pa.array(vals, type=pa.binary(w)))
+    cols.append(pa.array([None if m else decimal.Decimal(int(p)) / 1000 for p, m in zip(picks, mask)], type=pa.decimal128(20, 3)))
+    cols.append(pa.array([None if m else decimal.Decimal(int(p) * 10**30) / 100000 for p, m in zip(picks, mask)], type=pa.decimal256(50, 5)))
+    for col in cols:
+        for ityp, m in ((pa.int8(), 100), (pa.uint16(), 30_000), (pa.int32(), n), (pa.uint32(), n), (pa.int64(), n), (pa.uint64(), n)):
+            idx = rng.integers(0, m, 20_003)
+            for inulls in (False, True):
+                ia = pa.array(idx, type=ityp, mask=(rng.random(len(idx)) < 0.2) if inulls else None)
+                got = sess.call_function("take", [col, ia])
+                want = pc.take(col, ia)
+                assert got.type == col.type and got.equals(want) and got.null_count == want.null_count, (col.type, ityp, inulls)
+        for fnulls in (False, True):
+            f = pa.array(rng.random(n) < 0.4, mask=(rng.random(n) < 0.15) if fnulls else None)
+            for sel in ("drop", "emit_null"):
+                got = sess.call_function("filter", [col, f], options=f"null_selection_behavior={sel}")
+                want = pc.filter(col, f, null_selection_behavior=sel)
+                assert got.type == col.type and got.equals(want) and got.null_count == want.null_count, (col.type, fnulls, sel)
+        sl, fs = col.slice(777, 9000), pa.array(rng.random(9000) < 0.5)
+        assert sess.call_function("filter", [sl, fs]).equals(pc.filter(sl, fs))
+        assert sess.call_function("take", [sl, pa.array([8999, 0, 5], type=pa.int32())]).equals(pc.take(sl, pa.array([8999, 0, 5])))
+        with pytest.raises(Exception, match="out of bounds"):
+            sess.call_function("take", [sl, pa.array([9000], type=pa.int32())])
+        assert len(sess.call_function("filter", [col.slice(0, 0), pa.array([], type=pa.bool_())])) == 0
+    # other widths are refused by name
+    odd = pa.array([b"abcde", b"fghij"], type=pa.binary(5))
+    with pytest.raises(Exception, match="byte widths 1, 2, 4, 8, 16 and 32"):
+        sess.call_function("take", [odd, pa.array([1, 0], type=pa.int32())])
 
 
 # ---- divide / abs / negate / bit-wise / shifts / sqrt through the registry ------------------------------------

@@ -122,5 +122,14 @@ def test_hash_kernels_exist_for_fixed_size_binary_and_decimal_keys():
             tin, tout, err = (C.c_int * 1)(tid), (C.c_int * 1)(), C.create_string_buffer(512)
             assert ac.lib.ahc_dispatch_best(fn.encode(), 1, tin, tout, err, len(err)) == 0, (fn, tid, err.value)
             assert tout[0] == tid
+    # FSBImpl's selection kernels (kernels/vector_selection.go:2344-2346, :2354-2356): array_filter by a boolean (id 1), array_take by
+    # every integer index type (ids 2 … 9)
+    for tid in (15, 23, 24):
+        tin, tout, err = (C.c_int * 2)(tid, 1), (C.c_int * 2)(), C.create_string_buffer(512)
+        assert ac.lib.ahc_dispatch_best(b"array_filter", 2, tin, tout, err, len(err)) == 0, (tid, err.value)
+        for it in range(2, 10):
+            tin = (C.c_int * 2)(tid, it)
+            assert ac.lib.ahc_dispatch_best(b"array_take", 2, tin, tout, err, len(err)) == 0, (tid, it, err.value)
+            assert (tout[0], tout[1]) == (tid, it)
     tin, tout, err = (C.c_int * 2)(23, 23), (C.c_int * 2)(), C.create_string_buffer(512)
     assert ac.lib.ahc_dispatch_best(b"add", 2, tin, tout, err, len(err)) != 0 and b"no kernel matching" in err.value

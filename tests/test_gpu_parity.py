@@ -385,6 +385,35 @@ def test_take_bit_exact(hip, orc_be, vdtype, idtype):
                     assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
 
 
+@pytest.mark.parametrize("w", [16, 32])
+def test_take_wide_slots_bit_exact(hip, orc_be, w):
+    """FSBImpl's take (vector_selection.go:1997-2031) for 16- and 32-byte slots — Decimal128 / Decimal256 / binary(16|32) — through
+    ah_take_primitive: every index type, nulls on either side, offsets, the first
+    out-of-range index by value"""
+    rng = np.random.default_rng(57 + w)
+    vt = np.dtype(f"V{w}")
+    for nvalues, nidx in [(1, 1), (100, 63), (5000, 4099), (120, 70001), (300_000, 200_003)]:
+        vals = rng.integers(0, 256, (nvalues, w), dtype=np.uint8).view(vt).reshape(-1)
+        for idtype in (np.int8, np.uint16, np.int32, np.uint32, np.int64, np.uint64):
+            hi = min(nvalues, np.iinfo(idtype).max + 1)
+            idx = rng.integers(0, hi, nidx).astype(idtype)
+            for voff, ioff in [(0, 0), (5, 3)]:
+                for vvalid, ivalid in [(None, None), (rand_bits(rng, voff + nvalues + 8, 0.9), rand_bits(rng, ioff + nidx + 8, 0.9))]:
+                    want_valid = vvalid is not None
+                    g = hip.take(vals, vvalid, voff, idx, ivalid, ioff, True, want_valid)
+                    e = orc_be.take(vals, vvalid, voff, idx, ivalid, ioff, True, want_valid)
+                    assert g[0] == e[0] == STATUS_OK
+                    assert g[1].tobytes() == e[1].tobytes(), (w, idtype, nvalues, nidx)
+                    if want_valid:
+                        assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+    vals = rng.integers(0, 256, (1000, w), dtype=np.uint8).view(vt).reshape(-1)
+    idx = rng.integers(0, 1000, 5000).astype(np.int32)
+    idx[[4000, 777]] = [1000, -3]
+    g = hip.take(vals, None, 0, idx, None, 0, True, False)
+    e = orc_be.take(vals, None, 0, idx, None, 0, True, False)
+    assert g[0] == e[0] == STATUS_EINDEX and g[4] == e[4] == -3
+
+
 @pytest.mark.parametrize("vdtype", [np.float32, np.int64, np.uint32, np.float64])
 def test_take_vec_path_bit_exact(ctx, hip, orc_be, vdtype):
     """take_vec_kernel (16 / W adjacent rows per lane; one merged 16-byte load when their indices are consecutive, ascending or
