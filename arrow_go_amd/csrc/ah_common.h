@@ -66,7 +66,7 @@ struct ah_ctx {
   void* expr_cache;        // compiled expression programs (ah_expr.hip)
   int capturing;           // between ah_graph_begin and ah_graph_end: the compute stream records instead of running
   ah_filter_cache fcache;  // ah_filter.hip
-  int opt_scan_onepass;    // cumulative_sum of 4- and 8-byte integers (checked or not, nulls or not): 1 (default) one pass with decoupled look-back over 128 KiB tiles, 0 reduce-then-scan, 3 one pass for unchecked columns without nulls only
+  int opt_scan_onepass;    // cumulative_sum of 4- and 8-byte integers (checked or not, nulls or not): 1 (default) one pass with decoupled look-back over 128 KiB tiles, 0 reduce-then-scan, 2 one pass + separate validity copy / popcount, 3 one pass for unchecked columns without nulls only
   void* scan_recs;         // … its tile records (only that kernel writes them: stale words carry older epochs) and, in the last 64 bytes, its ticket word
   size_t scan_recs_bytes;
   unsigned scan_epoch;

@@ -465,6 +465,13 @@ __device__ __forceinline__ E wave_incl_scan_dpp(E v) {   // a lane without a sou
 __device__ __forceinline__ unsigned read_lane63(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ u64 read_lane63(u64 v) { return ((u64)read_lane63((unsigned)(v >> 32)) << 32) | read_lane63((unsigned)v); }
 
+// all ones where bit `pos` of `bits` is set (v_bfe_i32: the one-bit field sign-extended), else 0 — the AND mask of a row's payload
+template <typename E> __device__ __forceinline__ E op_bit_mask(unsigned bits, int pos) {
+  const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)bits, (unsigned)pos, 1u);
+  if constexpr (sizeof(E) == 8) return ((u64)m << 32) | m;
+  else return (E)m;
+}
+
 constexpr int kOpThreads = 1024;
 constexpr int kOpVpt = 8;                 // 16-byte vectors per lane: 128 KiB tiles
 constexpr int kOpRecWords = 4;            // per tile: {aggregate lo, hi, inclusive lo, hi}
@@ -482,21 +489,46 @@ __device__ __forceinline__ bool op_rec_load(const u64* rec, unsigned marker, u64
 
 // The validity bits of the lane's kOpVpt vectors, packed (bit k·V + j = element j of vector k).  The wave's chunk is 512·V rows =
 // 8·V bitmap words: lane w < 8·V reads word w (any bit offset; rows at or beyond `end` — the first null when nulls are not skipped,
-// or n — read as null), and every lane picks its V bits of vector k out of lane k·V + (lane·V >> 6)'s word with one cross-lane read.
-// ONE register per lane through the look-back (eight words would not fit: the first version, scalar loads per vector, spilled).
+// or n — read as null) and leaves it in the wave's 8·V words of LDS; every lane then reads the BYTE that holds its V bits of vector k
+// — word k·V + (lane·V >> 6), byte (lane·V >> 3) & 7: one base address, eight immediate offsets — and cuts them out with a bit-field
+// extract.  A workgroup is alone on its CU and runs its tiles back to back, so the tile's time is the sum of its phases and every
+// vector instruction in front of the in-tile scan costs 16 cycles (4 waves per SIMD × 4) × 32 tiles ≈ 0.24 µs of the call: the first
+// version (a ds_bpermute pair per vector + 64-bit shift / mask) and the second (v_readlane pairs + selects) spent ≈ 100 of them here,
+// this one ≈ 20.  ONE register per lane through the look-back (eight words would not fit: scalar loads per vector spilled).
+// The same words ARE the output's validity (skip_nulls: the input's bits; otherwise ones up to the first null, `end`, and zeros from
+// there on — the input's bits below `end` are all ones then): with out_valid the loading lanes store them (the last word byte by
+// byte: the bitmap ends with the byte that holds row n − 1, whose bits from row n on stay the caller's) and add their set bits to the
+// workgroup's count.
 template <int V>
-__device__ __forceinline__ unsigned op_lane_bits(const uint8_t* __restrict__ valid, int64_t off, int64_t wbase, int64_t end, int lane) {
-  u64 myword = 0;
+__device__ __forceinline__ unsigned op_lane_bits(const uint8_t* __restrict__ valid, int64_t off, int64_t wbase, int64_t end, int lane,
+                                                 uint8_t* __restrict__ out_valid, int64_t n, unsigned long long* s_count, u64* s_words /* the wave's 8·V */) {
+  static_assert(kOpVpt == 8 && (V == 2 || V == 4), "op_lane_bits: eight vectors of two or four rows");
   if (lane < kOpVpt * V) {
     const int64_t wpos = wbase + 64 * (int64_t)lane, left = end - wpos;
-    myword = ah_load_bits64(valid, off + wpos, left >= 64 ? 64 : (left < 0 ? 0 : (int)left));
+    const u64 myword = ah_load_bits64(valid, off + wpos, left >= 64 ? 64 : (left < 0 ? 0 : (int)left));
+    s_words[lane] = myword;
+    if (out_valid && wpos < n) {
+      if (n - wpos >= 64) *(u64*)(out_valid + (wpos >> 3)) = myword;
+      else {
+        for (int64_t b = 0; b * 8 < n - wpos; b++) {
+          uint8_t v = (uint8_t)(myword >> (8 * b));
+          const int64_t left_bits = n - wpos - 8 * b;   // the bitmap's last byte: the bits from row n on are the caller's (a pre-filled buffer keeps them)
+          if (left_bits < 8) v = (uint8_t)((v & ((1u << left_bits) - 1u)) | (out_valid[(wpos >> 3) + b] & ~((1u << left_bits) - 1u)));
+          out_valid[(wpos >> 3) + b] = v;
+        }
+      }
+      if (myword) atomicAdd(s_count, (unsigned long long)__popcll(myword));
+    }
   }
+  // same wave, LDS operations complete in order: a compiler-level ordering point is all the hand-over needs
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint8_t* mybyte = (const uint8_t*)s_words + ((lane * V) >> 6) * 8 + (((lane * V) >> 3) & 7);
+  const unsigned sh = (unsigned)(lane * V) & 7u;
   unsigned vbits = 0;
 #pragma unroll
-  for (int k = 0; k < kOpVpt; k++) {
-    const u64 w = __shfl(myword, k * V + ((lane * V) >> 6), 64);
-    vbits |= ((unsigned)(w >> ((lane * V) & 63)) & ((1u << V) - 1u)) << (k * V);
-  }
+  for (int k = 0; k < kOpVpt; k++) vbits |= (((unsigned)mybyte[k * V * 8] >> sh) & ((1u << V) - 1u)) << (k * V);
   return vbits;
 }
 
@@ -511,36 +543,59 @@ __device__ __forceinline__ unsigned op_lane_bits(const uint8_t* __restrict__ val
 template <typename E, bool NULLS = false, bool CHECKED = false, bool SIGNED = false>
 __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_onepass_kernel(
     const E* __restrict__ in, E* __restrict__ out, int64_t n, E start, u64* __restrict__ recs, unsigned* __restrict__ ticket, unsigned ticket_base, unsigned epoch,
-    const uint8_t* __restrict__ valid = nullptr, int64_t off = 0, int64_t limit = 0, unsigned* __restrict__ overflow = nullptr) {
+    const uint8_t* __restrict__ valid = nullptr, int64_t off = 0, int64_t limit = 0, unsigned* __restrict__ overflow = nullptr,
+    uint8_t* __restrict__ out_valid = nullptr, unsigned long long* __restrict__ valid_count = nullptr) {
   constexpr int V = 16 / sizeof(E);
   typedef E EV __attribute__((ext_vector_type(V)));
   constexpr int TILE = kOpThreads * kOpVpt * V;   // rows
   __shared__ E s_wave[kOpThreads / 64];
   __shared__ E s_prefix;
   __shared__ unsigned s_tile;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __shared__ unsigned long long s_count;   // NULLS with out_valid: set validity bits of this workgroup's tiles
+  __shared__ u64 s_bits[NULLS ? (kOpThreads / 64) * kOpVpt * V : 1];   // NULLS: every wave's 8·V validity words of the tile (op_lane_bits)
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar: the wave's chunk is addressed from scalar registers)
   const unsigned m_agg = epoch * 4u + 1u, m_inc = epoch * 4u + 2u;
   const int64_t ntiles = (n + TILE - 1) / TILE;
+  if (NULLS && t == 0) s_count = 0;
   for (;;) {
     if (t == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
     __syncthreads();
-    const int64_t tile = s_tile;
-    if (tile >= ntiles) return;
+    const int64_t tile = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)s_tile);
+    if (tile >= ntiles) {
+      if (NULLS && t == 0 && valid_count && s_count) atomicAdd(valid_count, s_count);   // (the tile's last barrier is behind every LDS add)
+      return;
+    }
     const int64_t wbase = tile * TILE + (int64_t)wave * (64 * kOpVpt * V);
     EV x[kOpVpt];
     unsigned vbits = 0;
-    if (NULLS) vbits = op_lane_bits<V>(valid, off, wbase, limit < n ? limit : n, lane);
+    if (NULLS) vbits = op_lane_bits<V>(valid, off, wbase, limit < n ? limit : n, lane, out_valid, n, &s_count, &s_bits[NULLS ? wave * kOpVpt * V : 0]);
+    // the lane's first kfull vectors lie inside the column (all eight unless this is the column's last chunk): a 32-bit test per vector
+    const int lane_rows = (int)(n - wbase < (int64_t)(64 * kOpVpt * V) ? (n - wbase < 0 ? 0 : n - wbase) : (int64_t)(64 * kOpVpt * V)) - lane * V;
+    const int kfull = lane_rows >= V ? (lane_rows - V) / (64 * V) + 1 : 0;
+    const bool whole = wbase + 64 * kOpVpt * V <= n;   // the wave's chunk lies inside the column (scalar: one branch per wave instead of a bounds test per lane and vector)
+    if (whole) {
+      const EV* src = (const EV*)(in + wbase) + lane;
 #pragma unroll
-    for (int k = 0; k < kOpVpt; k++) {
-      const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
-      if (e + V <= n) x[k] = __builtin_nontemporal_load((const EV*)(in + e));
-      else {
+      for (int k = 0; k < kOpVpt; k++) {
+        x[k] = __builtin_nontemporal_load(src + k * 64);
+        if (NULLS) {
 #pragma unroll
-        for (int j = 0; j < V; j++) x[k][j] = e + j < n ? in[e + j] : (E)0;
+          for (int j = 0; j < V; j++) x[k][j] &= op_bit_mask<E>(vbits, k * V + j);
+        }
       }
-      if (NULLS) {
+    } else {
 #pragma unroll
-        for (int j = 0; j < V; j++) x[k][j] = ((vbits >> (k * V + j)) & 1u) ? x[k][j] : (E)0;
+      for (int k = 0; k < kOpVpt; k++) {
+        const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
+        if (e + V <= n) x[k] = __builtin_nontemporal_load((const EV*)(in + e));
+        else {
+#pragma unroll
+          for (int j = 0; j < V; j++) x[k][j] = e + j < n ? in[e + j] : (E)0;
+        }
+        if (NULLS) {
+#pragma unroll
+          for (int j = 0; j < V; j++) x[k][j] &= op_bit_mask<E>(vbits, k * V + j);
+        }
       }
     }
     // x[k] becomes the inclusive prefix of its rows inside the wave's chunk, in place
@@ -595,6 +650,7 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     __syncthreads();
     const E base = s_prefix + wpre;
+    if (NULLS) asm volatile("" : "+v"(vbits));   // a new value to the compiler: the sixteen row masks are cut out of it again, not kept alive through the look-back
     unsigned ovacc = 0;   // CHECKED: bit 31 = some step overflowed
     E carry_in = base;   // CHECKED: the running sum in front of the wave's vector k
 #pragma unroll
@@ -604,7 +660,7 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       for (int j = 0; j < V; j++) x[k][j] += base;
       if (CHECKED) {
         // the running sum in front of the lane's first element: the last element of the lane to the left, or what the wave's vector started from
-        E prev = __shfl_up(x[k][V - 1], 1, 64);
+        E prev = dpp_move<0x138, 0xF>(x[k][V - 1]);   // wave_shr:1 — the left neighbour's last running sum (a ds_bpermute pair per vector before)
         if (lane == 0) prev = carry_in;
         carry_in = read_lane63(x[k][V - 1]);
 #pragma unroll
@@ -617,9 +673,9 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
       }
       if (NULLS) {   // a null row's output is the zero of a fresh buffer
 #pragma unroll
-        for (int j = 0; j < V; j++) x[k][j] = ((vbits >> (k * V + j)) & 1u) ? x[k][j] : (E)0;
+        for (int j = 0; j < V; j++) x[k][j] &= op_bit_mask<E>(vbits, k * V + j);
       }
-      if (e + V <= n) __builtin_nontemporal_store(x[k], (EV*)(out + e));
+      if (k < kfull) __builtin_nontemporal_store(x[k], (EV*)(out + wbase) + lane + k * 64);
       else {
 #pragma unroll
         for (int j = 0; j < V; j++) if (e + j < n) out[e + j] = x[k][j];
@@ -632,7 +688,8 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
 
 // mode: bit 0 nulls (valid / limit), bit 1 checked, bit 2 signed (checked only)
 template <typename E>
-int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, int mode = 0, const uint8_t* valid = nullptr, int64_t off = 0, int64_t limit = 0) {
+int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, int mode = 0, const uint8_t* valid = nullptr, int64_t off = 0, int64_t limit = 0,
+                uint8_t* out_valid = nullptr) {
   constexpr int TILE = kOpThreads * kOpVpt * (16 / (int)sizeof(E));
   const int64_t ntiles = ah_ceil_div(n, (int64_t)TILE);
   const size_t need = (size_t)ntiles * kOpRecWords * 8 + 64;
@@ -658,11 +715,12 @@ int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, in
   // asynchronous error — cannot leave the word out of step with a count the host keeps (the first version kept a running base)
   AH_HIP(c, hipMemsetAsync(ticket, 0, sizeof(unsigned), c->stream));
   unsigned* overflow = (unsigned*)&c->dscalars[13];
-  if (mode & 2) AH_HIP(c, hipMemsetAsync(overflow, 0, sizeof(uint64_t), c->stream));
+  unsigned long long* vcount = (unsigned long long*)&c->dscalars[15];   // out_valid: the kernel writes the output's validity and counts its set bits
+  if ((mode & 2) || out_valid) AH_HIP(c, hipMemsetAsync(overflow, 0, 3 * sizeof(uint64_t), c->stream));   // [13] overflow, [14] (free by now), [15] count
   const E* vin = (const E*)values;
   E* vout = (E*)out;
   const unsigned g = (unsigned)grid;
-#define AH_OP(NULLS, CHECKED, SIGNED) scan_onepass_kernel<E, NULLS, CHECKED, SIGNED><<<g, kOpThreads, 0, c->stream>>>(vin, vout, n, start, recs, ticket, 0u, c->scan_epoch, valid, off, limit, overflow)
+#define AH_OP(NULLS, CHECKED, SIGNED) scan_onepass_kernel<E, NULLS, CHECKED, SIGNED><<<g, kOpThreads, 0, c->stream>>>(vin, vout, n, start, recs, ticket, 0u, c->scan_epoch, valid, off, limit, overflow, out_valid, vcount)
   switch (mode) {
     case 0: AH_OP(false, false, false); break;
     case 1: AH_OP(true, false, false); break;
@@ -679,7 +737,7 @@ int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, in
 
 template <typename T>
 int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t limit, const void* start_host,
-                  int checked, void* out) {
+                  int checked, void* out, uint8_t* out_valid, bool* validity_done) {
   T start = 0;
   if (start_host) memcpy(&start, start_host, sizeof(T));
   if constexpr (std::is_floating_point<T>::value) {
@@ -693,8 +751,12 @@ int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t o
         (c->opt_scan_onepass != 3 || (!checked && !valid))) {   // (3: round 4's gate — unchecked without nulls only; a measurement switch)
       const bool nulls = valid != nullptr || limit < n;
       const int mode = (nulls ? 1 : 0) | (checked ? 2 : 0) | (checked && std::is_signed<T>::value ? 4 : 0);
-      if constexpr (sizeof(T) == 8) return run_onepass<unsigned long long>(c, values, n, (unsigned long long)start, out, mode, valid, off, limit);
-      else if constexpr (sizeof(T) == 4) return run_onepass<unsigned>(c, values, n, (unsigned)start, out, mode, valid, off, limit);
+      // the output's validity and its count come out of the same pass (the words the kernel reads are the words to write) — option
+      // scan_onepass 2 keeps the bitmap copy + popcount of the first version, for measurement
+      uint8_t* ov = (nulls && out_valid && (((uintptr_t)out_valid) & 7) == 0 && c->opt_scan_onepass != 2) ? out_valid : nullptr;
+      *validity_done = ov != nullptr;
+      if constexpr (sizeof(T) == 8) return run_onepass<unsigned long long>(c, values, n, (unsigned long long)start, out, mode, valid, off, limit, ov);
+      else if constexpr (sizeof(T) == 4) return run_onepass<unsigned>(c, values, n, (unsigned)start, out, mode, valid, off, limit, ov);
     }
     if (!checked) {
       if constexpr (sizeof(T) == 8) return run_scan_vpt<T, unsigned long long, false>(c, values, valid, off, n, limit, (unsigned long long)start, out);
@@ -732,21 +794,22 @@ AH_EXPORT int ah_cumulative_sum(ah_ctx* c, int type, const void* values, const u
     if (fn != ~0ull) limit = (int64_t)fn;
   }
   int rc;
+  bool validity_done = false;   // the one-pass kernel wrote out_valid and left its set-bit count in dscalars[15]
   switch (type) {
-    case AH_UINT8: rc = dispatch_scan<uint8_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_INT8: rc = dispatch_scan<int8_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_UINT16: rc = dispatch_scan<uint16_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_INT16: rc = dispatch_scan<int16_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_UINT32: rc = dispatch_scan<uint32_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_INT32: rc = dispatch_scan<int32_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_UINT64: rc = dispatch_scan<uint64_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_INT64: rc = dispatch_scan<int64_t>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_FLOAT32: rc = dispatch_scan<float>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
-    case AH_FLOAT64: rc = dispatch_scan<double>(c, values, valid, off, n, limit, start_host, checked, out_values); break;
+    case AH_UINT8: rc = dispatch_scan<uint8_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_INT8: rc = dispatch_scan<int8_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_UINT16: rc = dispatch_scan<uint16_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_INT16: rc = dispatch_scan<int16_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_UINT32: rc = dispatch_scan<uint32_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_INT32: rc = dispatch_scan<int32_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_UINT64: rc = dispatch_scan<uint64_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_INT64: rc = dispatch_scan<int64_t>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_FLOAT32: rc = dispatch_scan<float>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
+    case AH_FLOAT64: rc = dispatch_scan<double>(c, values, valid, off, n, limit, start_host, checked, out_values, out_valid, &validity_done); break;
     default: return ah_fail(c, AH_ENOTIMPL, "cumulative sum input type must be numeric");
   }
   if (rc != AH_OK) return rc;
-  if (out_valid) {
+  if (out_valid && !validity_done) {
     // validity: skip_nulls → the input's validity; otherwise ones up to the first null, zeros after
     if (valid && skip_nulls) rc = ah_copy_bitmap(c, valid, off, n, out_valid, 0, 0);
     else {
@@ -756,7 +819,7 @@ AH_EXPORT int ah_cumulative_sum(ah_ctx* c, int type, const void* values, const u
     if (rc != AH_OK) return rc;
   }
   bool need_sync = checked || out_null_count_host;
-  if (out_null_count_host && out_valid) {
+  if (out_null_count_host && out_valid && !validity_done) {
     rc = ah_popcount_async(c, out_valid, 0, n, (unsigned long long*)&c->dscalars[15]);
     if (rc != AH_OK) return rc;
   }

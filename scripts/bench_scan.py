@@ -38,6 +38,12 @@ for key, fn in (("int64", lambda: ctx.cumulative_sum(N.INT64, a, None, 0, rows, 
                 ("int64_nulls_skip", lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, False, c, ov)),
                 ("int64_checked_nulls_skip", lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, True, c, ov))):
     res[key + "_two_pass"] = {"ms": round(timed(fn), 4)}
+# … and one pass with the validity copy + popcount as separate launches (option 2: round 5's first version)
+ctx.set_option("scan_onepass", 2)
+for key, fn in (("int64_nulls_skip", lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, False, c, ov)),
+                ("int64_nulls_propagate", lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, False, False, c, ov)),
+                ("int64_checked_nulls_skip", lambda: ctx.cumulative_sum(N.INT64, a, v, 0, rows, None, True, True, c, ov))):
+    res[key + "_separate_validity"] = {"ms": round(timed(fn), 4)}
 ctx.set_option("scan_onepass", 1)
 # the same column through Sum for scale (8 B/row read only)
 ms = timed(lambda: ctx.sum_int64(a, rows))

@@ -405,7 +405,11 @@ class HipBackend:
             assert "overflow" in str(e)
             return STATUS_EOVERFLOW, None, None, 0
         out = ob.download(values.dtype, n, misalign * w)
-        ov = ovb.download(np.uint8, (n + 7) // 8) if ovb is not None else None
+        ov = None
+        if ovb is not None:
+            ovg = ovb.download(np.uint8, (n + 7) // 8 + 16)
+            assert (ovg[(n + 7) // 8:] == 0xFF).all(), "cumulative_sum wrote beyond the validity bitmap's last byte"
+            ov = ovg[:(n + 7) // 8]
         return STATUS_OK, out, ov, nulls
 
     def cast_numeric(self, values, out_dtype, valid=None, off=0, allow_int_overflow=False, allow_float_truncate=False, misalign=0):

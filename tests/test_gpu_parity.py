@@ -1029,6 +1029,8 @@ def test_cumulative_sum_one_pass_checked_and_nulls(hip, orc_be, ctx, dtype):
             if valid is not None:
                 bits = lambda b: np.unpackbits(b, bitorder="little")[:n]
                 assert (bits(g[2]) == bits(e[2])).all() and (bits(g0[2]) == bits(e[2])).all(), kw
+                # whole bytes too: the last byte's bits from row n on are the pre-filled ones (prepareCumulativeOutput), not the kernel's
+                assert g[2].tobytes() == e[2].tobytes() == g0[2].tobytes(), kw
             assert g[3] == e[3] == g0[3], kw
         return e[0]
 
