@@ -212,6 +212,8 @@ int ah_temp_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // internal (ah_bitmap.hip): popcount of bits [off, off+nbits) into *total_dev (8 bytes,
 // device), enqueued on the compute stream; uses dscalars[16..] as partials — no scratch.
 int ah_popcount_async(ah_ctx* ctx, const uint8_t* bits, int64_t off, int64_t nbits, unsigned long long* total_dev);
+// zero a device byte range with one launch on the context's stream (any alignment)
+int ah_zero_bytes(ah_ctx* ctx, void* dptr, size_t nbytes);
 
 static inline int ah_type_width(int type) {
   switch (type) {

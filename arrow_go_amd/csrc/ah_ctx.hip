@@ -316,6 +316,31 @@ AH_EXPORT int ah_memset_async(ah_ctx* c, void* dptr, int byte_value, size_t nbyt
 }
 
 namespace {
+// Zero a byte range in ONE launch.  hipMemsetAsync splits a range that is not a multiple of its vector width into two fill kernels
+// (bulk + tail): behind a host wait — the fill of a two-phase Filter, whose output validity is sized by the count — each of them
+// is a launch the stream sits idle for (≈ 5 µs a piece in the kernel trace, profiles/r05_filter_cache_timeline.txt).
+typedef unsigned zero_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void zero_bytes_kernel(uint8_t* __restrict__ p, size_t n) {
+  const size_t head = ((16 - ((uintptr_t)p & 15)) & 15) < n ? ((16 - ((uintptr_t)p & 15)) & 15) : n;
+  const size_t body = (n - head) / 16, tail0 = head + body * 16;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < head) p[i] = 0;
+  if (i < n - tail0) p[tail0 + i] = 0;
+  zero_v4* q = (zero_v4*)(p + head);
+  const zero_v4 z = {0u, 0u, 0u, 0u};
+  for (size_t j = i; j < body; j += (size_t)gridDim.x * 256) q[j] = z;
+}
+}  // namespace
+
+int ah_zero_bytes(ah_ctx* c, void* dptr, size_t nbytes) {
+  if (nbytes == 0) return AH_OK;
+  const size_t want = (nbytes / 16 + 255) / 256 + 1;
+  zero_bytes_kernel<<<(unsigned)(want < 4096 ? want : 4096), 256, 0, c->stream>>>((uint8_t*)dptr, nbytes);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
+
+namespace {
 // Device-to-device copy written like the streaming kernels of this library (16 bytes per lane and access, nontemporal, four
 // accesses in flight per lane, exact grid): hipMemcpyDtoD reaches 4.8–5.1 TB/s of read + write on this part, this loop the
 // same ≈ 6.3 TB/s plateau as the Add — so it is both what Concatenate moves chunks with and the measured streaming ceiling

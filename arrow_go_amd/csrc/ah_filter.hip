@@ -401,7 +401,7 @@ int run_filter(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t vof
   unsigned long long* valid_total = (unsigned long long*)&c->dscalars[2];
   if (out_valid) {
     if (n_out < 0) return ah_fail(c, AH_EINVALID, "filter: n_out (from ah_filter_count) is required with a validity output");
-    AH_HIP(c, hipMemsetAsync(out_valid, 0, (size_t)((n_out + 7) / 8), c->stream));
+    if ((rc = ah_zero_bytes(c, out_valid, (size_t)((n_out + 7) / 8))) != AH_OK) return rc;   // (one launch: the stream waits for the host here)
     launch_compact<W, true, INDICES>(c, ntiles, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, super_off, tile_local, out_values, out_valid,
                                      valid_total);
   } else {
