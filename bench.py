@@ -240,14 +240,19 @@ def per_kernel_table(ctx, rows, a, b, c, x):
         # warm-up calls: code, TLB — and the clocks.  A line measured right behind a host-side pause (a mask generated with numpy, a
         # column uploaded) read 7 % high with one warm call: the first tens of launches after an idle stretch run below the
         # steady-state clock (scripts/bench_filter_cache.py: the same two-phase Filter 0.2995 ms first, 0.2781 ms a few ms later)
+        for r in range(reps + 1):
+            ctx.event_record(1000 + r)   # (events exist before the timed region)
         for _ in range(warm):
             fn()
         ctx.event_record(1000)
-        for _ in range(reps):
+        for r in range(reps):
             fn()
-        ctx.event_record(1001)
-        ms = ctx.event_elapsed_ms(1000, 1001) / reps
+            ctx.event_record(1001 + r)
+        ms = ctx.event_elapsed_ms(1000, 1000 + reps) / reps
         out[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "bytes": int(nbytes)}
+        each = [ctx.event_elapsed_ms(1000 + r, 1001 + r) for r in range(reps)]
+        if max(each) > 1.3 * min(each):   # a call that took another path or waited for an allocation: shown, not averaged away
+            out[name]["ms_each"] = [round(v, 4) for v in each]
 
     res = ctx.alloc(64)
     # the chip's streaming ceiling in this very session: a device-to-device copy of 1 GiB, 2 bytes moved per byte copied
