@@ -109,8 +109,10 @@ __global__ __launch_bounds__(kBlock) void popcount_kernel(const uint8_t* __restr
   }
 }
 
+// mb != nullptr: the call's last launch also posts {*extra, total} to the host's mailbox (ah_popcount_post)
 __global__ __launch_bounds__(kBlock) void popcount_final_kernel(const unsigned long long* __restrict__ partials, int n,
-                                                                 unsigned long long* __restrict__ total) {
+                                                                 unsigned long long* __restrict__ total, const unsigned long long* __restrict__ extra = nullptr,
+                                                                 unsigned long long* mb = nullptr, unsigned long long seq = 0) {
   uint64_t acc = 0;
   for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[i];
   acc = ah_wave_sum(acc);
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(kBlock) void popcount_final_kernel(const unsigned l
     uint64_t tot = 0;
     for (int k = 0; k < kBlock / 64; k++) tot += sm[k];
     *total = tot;
+    if (mb) { const unsigned long long w[2] = {*extra, tot}; ah_mailbox_post(mb, seq, w, 2); }
   }
 }
 
@@ -190,6 +193,25 @@ int ah_popcount_async(ah_ctx* c, const uint8_t* bits, int64_t off, int64_t nbits
   popcount_final_kernel<<<1, kBlock, 0, c->stream>>>(partials, (int)grid, total_dev);
   AH_LAUNCH_CHECK(c);
   return AH_OK;
+}
+
+// the popcount of [off, off + nbits) into *total_dev AND {*extra_dev, that count} to the host in the same two launches: a call that ends
+// with "count the output's valid rows, then tell the host" spares the posting launch (out_host[0] = *extra_dev, out_host[1] = the count)
+int ah_popcount_post(ah_ctx* c, const uint8_t* bits, int64_t off, int64_t nbits, unsigned long long* total_dev, const unsigned long long* extra_dev,
+                     unsigned long long* out_host) {
+  OutSpan s = make_span((uint8_t*)bits, off, nbits);
+  int64_t g = ah_ceil_div(s.nwords, (int64_t)kBlock * 4);
+  unsigned grid = (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+  unsigned long long* partials = (unsigned long long*)&c->dscalars[64];
+  unsigned long long* mb;
+  unsigned long long seq;
+  int rc = ah_mailbox_begin(c, &mb, &seq);
+  if (rc != AH_OK) return rc;
+  popcount_kernel<<<grid, kBlock, 0, c->stream>>>(bits, off, nbits, partials);
+  AH_LAUNCH_CHECK(c);
+  popcount_final_kernel<<<1, kBlock, 0, c->stream>>>(partials, (int)grid, total_dev, extra_dev, mb, seq);
+  AH_LAUNCH_CHECK(c);
+  return ah_mailbox_wait(c, seq, 2, out_host);
 }
 
 AH_EXPORT int ah_bitmap_op(ah_ctx* c, int op, const uint8_t* l, int64_t loff, const uint8_t* r, int64_t roff,

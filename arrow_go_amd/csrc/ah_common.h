@@ -76,6 +76,16 @@ struct ah_ctx {
   int opt_filter_cache;    // 1: ah_filter_count leaves its tile prefixes for the fill (default on a stream of the context's own), 0: the fill recounts (default on a shared stream)
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;
+  // The neighbour sample of the last Take (ah_take_binned_try), kept for the next call with the SAME index vector — a record batch's
+  // columns are gathered one after the other with one index vector (compute/selection.go:601-677), and the sample + its wait were
+  // ≈ 20 µs of every one of those calls.  Kept like the filter cache: valid only for the Take that directly follows (every other
+  // compute entry point of this context drops it, an upload / copy / memset into the vector's bytes drops it, a Take whose outputs
+  // overlap the vector does not leave one), off by default on a shared stream, sampled again on every 32nd use.  Every Take path
+  // returns the same bytes (tests force each of them): an entry gone stale behind the library's back costs speed, never results.
+  // Option take_hint_cache.
+  bool take_hint_valid, take_hint_live;   // left by the last call / readable by this one (read before AH_ENTER drops it)
+  const void* take_hint_idx; int64_t take_hint_nidx; int take_hint_kind, take_hint_near, take_hint_uses, opt_take_hint_cache;
+  unsigned long long take_hint_word;
   int opt_arith_xcd_map;        // element-wise binary kernels: every XCD streams one contiguous eighth of the columns (1) or the blocks' natural interleave (0)
   int opt_groupby_scale_guess;  // no-cut Float64 group-by: fixed-point scale from a sample, verified by the aggregate pass (1) or from a pass over all values (0)
   int opt_encode_unperm2_group; // two-cut encode: the level-2 un-permute over 4 consecutive virtual tiles per workgroup (4, the default) or one per workgroup (0)
@@ -133,8 +143,15 @@ static inline int ah_fail(ah_ctx* ctx, int code, const char* fmt, ...) {
   do {                                                                 \
     AH_ENTER_KEEP(ctx);                                                \
     (ctx)->fcache.valid = false;                                       \
+    (ctx)->take_hint_valid = false;                                    \
   } while (0)
 
+// does a write to [p, p + nbytes) touch the index vector the Take's path sample was taken from?
+static inline bool ah_take_hint_overlaps(const ah_ctx* c, const void* p, size_t nbytes) {
+  if (!c->take_hint_valid || !c->take_hint_idx) return false;
+  const uintptr_t a = (uintptr_t)p, b = a + nbytes, lo = (uintptr_t)c->take_hint_idx, hi = lo + (size_t)c->take_hint_nidx * (size_t)(c->take_hint_kind / 2);
+  return a < hi && lo < b;
+}
 // does a write to [p, p + nbytes) touch the mask the filter cache was computed from?
 static inline bool ah_fcache_overlaps(const ah_ctx* c, const void* p, size_t nbytes) {
   if (!c->fcache.valid) return false;
@@ -212,6 +229,8 @@ int ah_temp_reserve(ah_ctx* ctx, size_t nbytes, void** out);
 // internal (ah_bitmap.hip): popcount of bits [off, off+nbits) into *total_dev (8 bytes,
 // device), enqueued on the compute stream; uses dscalars[16..] as partials — no scratch.
 int ah_popcount_async(ah_ctx* ctx, const uint8_t* bits, int64_t off, int64_t nbits, unsigned long long* total_dev);
+int ah_popcount_post(ah_ctx* ctx, const uint8_t* bits, int64_t off, int64_t nbits, unsigned long long* total_dev, const unsigned long long* extra_dev,
+                     unsigned long long* out_host /* [2]: *extra_dev, the count */);
 // zero a device byte range with one launch on the context's stream (any alignment)
 int ah_zero_bytes(ah_ctx* ctx, void* dptr, size_t nbytes);
 

@@ -83,6 +83,7 @@ static int ctx_create(int device_id, void* stream, bool borrow, ah_ctx** out) {
   // stream shared with another producer (torch, a second ah_ctx) a foreign kernel may rewrite the mask in between, so there the
   // fill always recounts unless the caller vouches for the mask (ah_ctx_set_option "filter_cache" 1)
   c->opt_filter_cache = c->owns_stream ? 1 : 0;
+  c->opt_take_hint_cache = c->owns_stream ? 1 : 0;   // (same rule: on a shared stream another producer may rewrite the index vector between two calls)
   c->opt_groupby_lean = 1;
   c->opt_scan_onepass = 1;
   c->opt_groupby_seed = 1;
@@ -131,6 +132,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "take_gather_wg_per_cu")) c->opt_take_gather_wg = (int)value;
   else if (!strcmp(name, "take_gather_lds")) c->opt_take_gather_lds = (int)value;
   else if (!strcmp(name, "take_vec")) c->opt_take_vec = (int)value;
+  else if (!strcmp(name, "take_hint_cache")) { c->opt_take_hint_cache = (int)value; c->take_hint_valid = false; }
   else if (!strcmp(name, "take_vec_nt")) c->opt_take_vec_nt = (int)value;
   else if (!strcmp(name, "encode_unperm_group")) c->opt_encode_unperm_group = (int)value;
   else if (!strcmp(name, "encode_table_batch")) c->opt_encode_table_batch = (int)value;
@@ -286,6 +288,7 @@ AH_EXPORT int ah_host_free_pinned(ah_ctx* c, void* hptr) {
 AH_EXPORT int ah_upload_async(ah_ctx* c, void* dptr, const void* hptr, size_t nbytes) {
   AH_ENTER_KEEP(c);
   if (ah_fcache_overlaps(c, dptr, nbytes)) c->fcache.valid = false;
+  if (ah_take_hint_overlaps(c, dptr, nbytes)) c->take_hint_valid = false;
   if (nbytes == 0) return AH_OK;
   // the copy must not overtake compute work that still reads/writes dptr
   AH_HIP(c, hipEventRecord(c->ev_compute, c->stream));
@@ -310,6 +313,7 @@ AH_EXPORT int ah_download_async(ah_ctx* c, void* hptr, const void* dptr, size_t 
 AH_EXPORT int ah_memset_async(ah_ctx* c, void* dptr, int byte_value, size_t nbytes) {
   AH_ENTER_KEEP(c);
   if (ah_fcache_overlaps(c, dptr, nbytes)) c->fcache.valid = false;
+  if (ah_take_hint_overlaps(c, dptr, nbytes)) c->take_hint_valid = false;
   if (nbytes == 0) return AH_OK;
   AH_HIP(c, hipMemsetAsync(dptr, byte_value, nbytes, c->stream));
   return AH_OK;
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(kCopyBlock) void copy16_kernel(const copy_v4* __res
 AH_EXPORT int ah_copy_async(ah_ctx* c, void* dst, const void* src, size_t nbytes) {
   AH_ENTER_KEEP(c);
   if (ah_fcache_overlaps(c, dst, nbytes)) c->fcache.valid = false;
+  if (ah_take_hint_overlaps(c, dst, nbytes)) c->take_hint_valid = false;
   if (nbytes == 0) return AH_OK;
   if (!dst || !src) return ah_fail(c, AH_EINVALID, "copy: null buffer");
   const uintptr_t d = (uintptr_t)dst, s = (uintptr_t)src;

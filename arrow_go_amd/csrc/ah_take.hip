@@ -316,6 +316,14 @@ __global__ __launch_bounds__(kBlock) void take_vec_kernel(const void* __restrict
   }
 }
 
+// first_bad = "none", the popcount's and the sample's words: one launch in front of a Take (three memsets before).
+// (Counting the output's valid rows inside the clustered kernel — one add per wave into a table of partial counts — was built and
+// measured: a workgroup of that kernel lives for ONE step, a wave cannot retire before its atomic is acknowledged, and the kernel went
+// from 487 to 540 µs with 256, with 2^14 and with line-spread counters alike; the popcount pass over the finished bitmap stays.)
+__global__ void take_prep_kernel(unsigned long long* __restrict__ first_bad, unsigned long long* __restrict__ valid_total, unsigned long long* __restrict__ hits) {
+  *first_bad = ~0ull; *valid_total = 0; *hits = 0;
+}
+
 template <int W, typename IdxT>
 int launch_take(ah_ctx* c, const void* values, const uint8_t* vvalid, int64_t voff, int64_t nvalues, const void* idx,
                 const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values, uint8_t* out_valid,
@@ -419,6 +427,14 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
                         int idx_signed, const void* idx, const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values, uint8_t* out_valid,
                         int64_t* out_null_count_host, int64_t* bad_index_host, uint64_t* status_dev);
 
+// the sample this call took (or reused) stays readable for the NEXT Take, unless this call's own outputs overlap the index vector
+static inline void take_leave_hint(ah_ctx* c, const void* idx, int byte_width, int64_t nidx, const void* out_values, const void* out_valid) {
+  if (!c->opt_take_hint_cache || c->take_hint_idx != idx) return;
+  c->take_hint_valid = true;
+  if (ah_take_hint_overlaps(c, out_values, (size_t)nidx * (size_t)byte_width) || (out_valid && ah_take_hint_overlaps(c, out_valid, (size_t)(nidx + 7) / 8)))
+    c->take_hint_valid = false;
+}
+
 }  // namespace
 
 AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, const uint8_t* vvalid, int64_t voff,
@@ -426,7 +442,9 @@ AH_EXPORT int ah_take_primitive(ah_ctx* c, int byte_width, const void* values, c
                                 const uint8_t* ivalid, int64_t ioff, int64_t nidx, int bounds_check,
                                 void* out_values, uint8_t* out_valid, int64_t* out_null_count_host,
                                 int64_t* bad_index_host) {
+  const bool hint_live = c && c->take_hint_valid;   // read before AH_ENTER drops it: this Take is the call the sample was left for
   AH_ENTER(c);
+  c->take_hint_live = hint_live;
   (void)bounds_check;  // the check is fused into the gather and always on (header)
   return take_primitive_core(c, byte_width, values, vvalid, voff, nvalues, idx_byte_width, idx_signed, idx, ivalid, ioff, nidx, out_values, out_valid,
                              out_null_count_host, bad_index_host, nullptr);
@@ -436,7 +454,9 @@ AH_EXPORT int ah_take_primitive_dev(ah_ctx* c, int byte_width, const void* value
                                     int64_t nvalues, int idx_byte_width, int idx_signed, const void* idx,
                                     const uint8_t* ivalid, int64_t ioff, int64_t nidx, void* out_values, uint8_t* out_valid,
                                     uint64_t* status_dev) {
+  const bool hint_live = c && c->take_hint_valid;   // read before AH_ENTER drops it: this Take is the call the sample was left for
   AH_ENTER(c);
+  c->take_hint_live = hint_live;
   if (!status_dev) return ah_fail(c, AH_EINVALID, "take: null status pointer");
   return take_primitive_core(c, byte_width, values, vvalid, voff, nvalues, idx_byte_width, idx_signed, idx, ivalid, ioff, nidx, out_values, out_valid,
                              nullptr, nullptr, status_dev);
@@ -465,8 +485,8 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
   }
   unsigned long long* first_bad = (unsigned long long*)&c->dscalars[1];
   unsigned long long* valid_total = (unsigned long long*)&c->dscalars[2];
-  AH_HIP(c, hipMemsetAsync(first_bad, 0xFF, sizeof(*first_bad), c->stream));
-  AH_HIP(c, hipMemsetAsync(valid_total, 0, sizeof(*valid_total), c->stream));
+  take_prep_kernel<<<1, 1, 0, c->stream>>>(first_bad, valid_total, (unsigned long long*)&c->dscalars[3]);
+  AH_LAUNCH_CHECK(c);
   int rc, binned = 0;
   c->take_clustered_hint = c->opt_take_vec == 2;
   // random indices into a column beyond the caches: bin → gather in L2-sized windows → unpermute (ah_take_binned.hip)
@@ -483,16 +503,19 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
     default: return ah_fail(c, AH_EINVALID, "invalid values byte width for take");  // :1189
   }
   if (rc != AH_OK) return rc;
-  if (out_valid && (out_null_count_host || status_dev)) {
-    rc = ah_popcount_async(c, out_valid, 0, nidx, valid_total);
-    if (rc != AH_OK) return rc;
-  }
   if (status_dev) {   // no round trip: the caller looks at the two words when (and if) it wants to
+    if (out_valid && (rc = ah_popcount_async(c, out_valid, 0, nidx, valid_total)) != AH_OK) return rc;
     take_status_kernel<<<1, 1, 0, c->stream>>>(first_bad, valid_total, out_valid != nullptr, nidx, (unsigned long long*)status_dev);
     AH_LAUNCH_CHECK(c);
+    take_leave_hint(c, idx, byte_width, nidx, out_values, out_valid);
     return AH_OK;
   }
-  if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[1], 2, (unsigned long long*)c->pinned)) != AH_OK) return rc;
+  if (out_valid && out_null_count_host) {
+    // the count of the output's valid rows and the two words for the host from the same two launches
+    unsigned long long w[2];
+    if ((rc = ah_popcount_post(c, out_valid, 0, nidx, valid_total, first_bad, w)) != AH_OK) return rc;
+    c->pinned[0] = w[0]; c->pinned[1] = w[1];
+  } else if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[1], 2, (unsigned long long*)c->pinned)) != AH_OK) return rc;
   uint64_t bad_pos = *(volatile uint64_t*)&c->pinned[0];
   uint64_t nvalid = *(volatile uint64_t*)&c->pinned[1];
   if (bad_pos != ~0ull) {
@@ -511,6 +534,7 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
     return ah_fail(c, AH_EINDEX, "%llu out of bounds", (unsigned long long)raw);
   }
   if (out_null_count_host) *out_null_count_host = out_valid ? nidx - (int64_t)nvalid : 0;
+  take_leave_hint(c, idx, byte_width, nidx, out_values, out_valid);
   return AH_OK;
 }
 

@@ -561,18 +561,27 @@ int ah_take_binned_try(ah_ctx* c, int byte_width, const void* values, const uint
   if (mode == 1) {
     // clustered / sorted / reversed indices stream through the direct kernel at the copy rate — sample 64 × 255 neighbours
     unsigned long long* hits = (unsigned long long*)&c->dscalars[3];
-    AH_HIP(c, hipMemsetAsync(hits, 0, sizeof(*hits), c->stream));
-    const int near = 128 / byte_width;
+    const int near = 128 / byte_width, kind = iw * 2 + (is_signed ? 1 : 0);
+    uint64_t word;
+    if (c->opt_take_hint_cache && c->take_hint_live && !c->capturing && c->take_hint_idx == idx && c->take_hint_nidx == nidx && c->take_hint_kind == kind && c->take_hint_near == near &&
+        c->take_hint_uses < 32) {
+      word = c->take_hint_word;   // the same index vector as the last call's (ah_common.h: speed only, never results)
+      c->take_hint_uses++;
+    } else {
+      AH_HIP(c, hipMemsetAsync(hits, 0, sizeof(*hits), c->stream));
 #define AH_S(IT) sample_kernel<IT><<<64, 256, 0, c->stream>>>((const IT*)idx, nidx, near, hits); break
-    switch (iw * 2 + (is_signed ? 1 : 0)) {
-      case 2: AH_S(uint8_t); case 3: AH_S(int8_t); case 4: AH_S(uint16_t); case 5: AH_S(int16_t);
-      case 8: AH_S(uint32_t); case 9: AH_S(int32_t); case 16: AH_S(uint64_t); case 17: AH_S(int64_t);
-      default: return AH_OK;
-    }
+      switch (kind) {
+        case 2: AH_S(uint8_t); case 3: AH_S(int8_t); case 4: AH_S(uint16_t); case 5: AH_S(int16_t);
+        case 8: AH_S(uint32_t); case 9: AH_S(int32_t); case 16: AH_S(uint64_t); case 17: AH_S(int64_t);
+        default: return AH_OK;
+      }
 #undef AH_S
-    AH_LAUNCH_CHECK(c);
-    { int mrc = ah_mailbox_read(c, hits, 1, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }
-    const uint64_t h = *(volatile uint64_t*)&c->pinned[8] & 0xffffffffull, h1 = *(volatile uint64_t*)&c->pinned[8] >> 32;
+      AH_LAUNCH_CHECK(c);
+      { int mrc = ah_mailbox_read(c, hits, 1, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }
+      word = *(volatile uint64_t*)&c->pinned[8];
+      c->take_hint_idx = idx; c->take_hint_nidx = nidx; c->take_hint_kind = kind; c->take_hint_near = near; c->take_hint_word = word; c->take_hint_uses = 0;
+    }
+    const uint64_t h = word & 0xffffffffull, h1 = word >> 32;
     if (h * 4 > 64 * 255) {  // more than a quarter of the sampled neighbours sit within one 128-byte line
       // … and where most neighbours name ADJACENT values the direct path takes V rows per lane with merged 16-byte accesses
       // (ah_take.hip).  Merely near ones (a sorted random draw: 37 % repeats, 37 % adjacent, 26 % further) keep one row per lane:

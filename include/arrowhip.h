@@ -123,7 +123,10 @@ void ah_ctx_destroy(ah_ctx* ctx);
 const char* ah_last_error(ah_ctx* ctx); /* never NULL; owned by ctx */
 /* measurement / test switches of one context; none changes a result.  "nt" (nontemporal streaming accesses 0|1),
  * "blocks_per_cu" (grid cap of grid-stride kernels, 0 = each kernel's default), "take_binned" (0 never, 1 auto, 2 whenever
- * legal), "take_window_log2" (bytes of values per bin), "take_gather_wg_per_cu", "take_gather_load", "scan_segment_log2",
+ * legal), "take_window_log2" (bytes of values per bin), "take_hint_cache" (1, the default of ah_ctx_create: the neighbour sample that picks a Take's path is kept for the
+ * Take that directly follows with the same index vector — one vector gathers all columns of a record batch —, dropped like the filter cache by every other
+ * compute entry point and by uploads / copies / memsets into the vector, sampled again on every 32nd use; every path returns the same bytes, so an entry
+ * gone stale behind the library's back costs speed, never results; 0, the default of ah_ctx_create_on_stream: sample on every call), "take_gather_wg_per_cu", "take_gather_load", "scan_segment_log2",
  * "hash_direct" (unique / dictionary_encode: 0 ids in a separate pass … 2 default, 3 without the re-packed table),
  * "groupby_partition" (hash + sum: 0 id-based path only, 1 auto, k >= 5 always 2^(k-2) partitions, 2 sort-based, 3 / 4 two levels,
  * -2 no cut), "groupby_keys" (expected keys per partition the auto choice aims at, default 1280), "sort_msd" (sort_indices:

@@ -406,12 +406,69 @@ def test_take_wide_slots_bit_exact(hip, orc_be, w):
                     assert g[1].tobytes() == e[1].tobytes(), (w, idtype, nvalues, nidx)
                     if want_valid:
                         assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
+    # identity, reversed and sorted-with-repeats index vectors (the shapes the 4- / 8-byte kernels special-case), after a clustered
+    # 8-byte take on the same context (its neighbour sample leaves a hint behind)
+    n = 300_000
+    vals = rng.integers(0, 256, (n, w), dtype=np.uint8).view(vt).reshape(-1)
+    small = rng.integers(0, 1 << 60, n).astype(np.int64)
+    ident = np.arange(n, dtype=np.int32)
+    assert hip.take(small, None, 0, ident, None, 0, True, False)[1].tobytes() == small.tobytes()
+    vvalid, ivalid = rand_bits(rng, n + 8, 0.9), rand_bits(rng, n + 8, 0.9)
+    for idx in (ident, ident[::-1].copy(), np.sort(rng.integers(0, n, n)).astype(np.int32)):
+        for vv, iv in ((None, None), (vvalid, ivalid)):
+            g = hip.take(vals, vv, 0, idx, iv, 0, True, vv is not None)
+            e = orc_be.take(vals, vv, 0, idx, iv, 0, True, vv is not None)
+            assert g[0] == e[0] == STATUS_OK and g[1].tobytes() == e[1].tobytes()
+            if vv is not None:
+                assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
     vals = rng.integers(0, 256, (1000, w), dtype=np.uint8).view(vt).reshape(-1)
     idx = rng.integers(0, 1000, 5000).astype(np.int32)
     idx[[4000, 777]] = [1000, -3]
     g = hip.take(vals, None, 0, idx, None, 0, True, False)
     e = orc_be.take(vals, None, 0, idx, None, 0, True, False)
     assert g[0] == e[0] == STATUS_EINDEX and g[4] == e[4] == -3
+
+
+def test_take_hint_cache_stale_is_harmless(ctx, orc_be):
+    """The neighbour sample that picks a Take's path (direct / 16-byte rows per lane / binned) is kept for the Take that directly follows
+    with the same index vector (option take_hint_cache; the filter cache's rules).  The vector rewritten IN PLACE between two calls —
+    identity → random → sorted → identity — through the library (the upload drops the entry) and BEHIND ITS BACK (a second context on
+    the same device writes the bytes: the entry is stale): the results are the oracle's either way — values, validity, null count —
+    as they are with the cache off."""
+    rng = np.random.default_rng(61)
+    nvalues, nidx = 1 << 23, 1 << 20          # 64 MiB of Int64 values, 2^20 indices: where the sample runs
+    vals = rng.integers(-2**62, 2**62, nvalues)
+    vvalid, ivalid = rand_bits(rng, nvalues + 8, 0.9), rand_bits(rng, nidx + 8, 0.9)
+    dv, dvv, div = ctx.to_device(vals), ctx.to_device(vvalid), ctx.to_device(ivalid)
+    didx = ctx.alloc(nidx * 4 + 64)
+    out, ov = ctx.alloc(nidx * 8 + 64), ctx.alloc(nidx // 8 + 64)
+    ident = np.arange(nidx, dtype=np.int32)
+    pats = [ident, rng.integers(0, nvalues, nidx).astype(np.int32), np.sort(rng.integers(0, nvalues, nidx)).astype(np.int32), ident,
+            ident[::-1].copy(), rng.integers(0, nvalues, nidx).astype(np.int32)]
+    import arrow_go_amd as ah
+    from arrow_go_amd._native import lib as _lib, check as _check
+    other = ah.Context(0)
+    try:
+        for cache, foreign in ((1, False), (1, True), (0, False)):
+            ctx.set_option("take_hint_cache", cache)
+            for idx in pats:
+                if foreign:                    # another context's upload: this one's entry is not dropped
+                    _check(other.handle, _lib.ah_upload_async(other.handle, didx.ptr, idx.ctypes.data, idx.nbytes))
+                    other.sync()
+                else:
+                    didx.upload(idx)           # the same device address every time
+                for nulls in (False, True):
+                    for _ in range(2):         # the second call finds the first one's entry
+                        out.memset(0xCD); ov.memset(0xCD)
+                        got_nulls = ctx.take_primitive(8, dv, dvv if nulls else None, 0, nvalues, 4, True, didx, div if nulls else None, 0, nidx, True,
+                                                       out, ov if nulls else None)
+                        e = orc_be.take(vals, vvalid if nulls else None, 0, idx, ivalid if nulls else None, 0, True, nulls)
+                        assert out.download(np.int64, nidx).tobytes() == e[1].tobytes(), (cache, nulls)
+                        if nulls:
+                            assert ov.download(np.uint8, nidx // 8).tobytes() == e[2].tobytes() and got_nulls == e[3], (cache, nulls)
+    finally:
+        ctx.set_option("take_hint_cache", 1)
+        other.close()
 
 
 @pytest.mark.parametrize("vdtype", [np.float32, np.int64, np.uint32, np.float64])
