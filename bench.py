@@ -236,10 +236,11 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     reps = 10
     out = {}
 
-    def timed(name, nbytes, fn, reps=reps, warm=3):
+    def timed(name, nbytes, fn, reps=reps, warm=5):
         # warm-up calls: code, TLB — and the clocks.  A line measured right behind a host-side pause (a mask generated with numpy, a
         # column uploaded) read 7 % high with one warm call: the first tens of launches after an idle stretch run below the
-        # steady-state clock (scripts/bench_filter_cache.py: the same two-phase Filter 0.2995 ms first, 0.2781 ms a few ms later)
+        # steady-state clock (scripts/bench_filter_cache.py: the same two-phase Filter 0.2995 ms first, 0.2781 ms a few ms later); five calls, eight where
+        # a new cardinality makes the first calls size tables and arenas (dictionary_encode at 2^20 keys: 4.5 ms, then 1.27, 1.26, 1.23, 1.20 …)
         for r in range(reps + 1):
             ctx.event_record(1000 + r)   # (events exist before the timed region)
         for _ in range(warm):
@@ -393,8 +394,8 @@ def per_kernel_table(ctx, rows, a, b, c, x):
         c.upload((ranks * mult).view(np.int64))
         del ranks
         tag = "2^%d_%s" % (lg, dist) if dist != "uniform" else "2^%d" % lg
-        timed("dictionary_encode_int64_%s_keys" % tag, 12 * hrows, lambda: ctx.hash_u64_encode(c, None, 0, hrows, False, hids, None, hdic), reps=3)
-        timed("hash_sum_float64_%s_groups" % tag, 16 * hrows, lambda: ctx.hash_sum("f64", c, None, 0, x, None, 0, hrows, hdic, hsum, hcnt), reps=3)
+        timed("dictionary_encode_int64_%s_keys" % tag, 12 * hrows, lambda: ctx.hash_u64_encode(c, None, 0, hrows, False, hids, None, hdic), reps=3, warm=8)   # (the first calls at a new cardinality still size tables and arenas)
+        timed("hash_sum_float64_%s_groups" % tag, 16 * hrows, lambda: ctx.hash_sum("f64", c, None, 0, x, None, 0, hrows, hdic, hsum, hcnt), reps=3, warm=8)
         out["hash_sum_float64_%s_groups" % tag]["Grows/s"] = round(hrows / out["hash_sum_float64_%s_groups" % tag]["ms"] / 1e6, 2)
     for bfr in (res, mask, vvalid, ovalid, idx, hids, hdic, hsum, hcnt):
         bfr.free()
