@@ -540,20 +540,25 @@ AH_EXPORT int ah_filter_primitive_once(ah_ctx* c, int byte_width, const void* va
   if (((uintptr_t)values | (uintptr_t)out_values) & (uintptr_t)(byte_width - 1))
     return ah_fail(c, AH_EINVALID, "filter: buffer not element-aligned");
   if (c->capturing) { c->capturing = 2; return ah_fail(c, AH_EINVALID, "filter_primitive_once returns values to the host: it cannot be recorded into a graph"); }
-  int64_t* status = (int64_t*)&c->dscalars[6];   // [6] rows selected, [7] output nulls
   int rc;
-  switch (byte_width) {   // n_out = n: the capacity the caller sized the output for
-    case 1: rc = run_filter<1, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
-    case 2: rc = run_filter<2, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
-    case 4: rc = run_filter<4, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
-    case 8: rc = run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr, status); break;
+  switch (byte_width) {   // n_out = n: the capacity the caller sized the output for; counts, zeroing and fill are enqueued back to back
+    case 1: rc = run_filter<1, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr); break;
+    case 2: rc = run_filter<2, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr); break;
+    case 4: rc = run_filter<4, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr); break;
+    case 8: rc = run_filter<8, false>(c, values, vvalid, voff, fdata, fvalid, foff, n, null_sel, n, out_values, out_valid, nullptr); break;
     default: return ah_fail(c, AH_EINVALID, "filter: invalid values byte width %d", byte_width);
   }
   if (rc != AH_OK) return rc;
-  unsigned long long back[2];
-  if ((rc = ah_mailbox_read(c, (const unsigned long long*)status, 2, back)) != AH_OK) return rc;
+  // the selection count sits where run_counts left it (dscalars[1]: this call never takes the cached tables); with a validity output the
+  // popcount of its n bits (the bits past the selection are zero) rides along and the popcount's last launch posts both — three small
+  // launches less than the first version (popcount ×2, a status kernel, a posting kernel), which made the one-call entry SLOWER than count + fill
+  const unsigned long long* total_dev = (const unsigned long long*)&c->dscalars[1];
+  unsigned long long back[2] = {0, 0};
+  if (out_valid) rc = ah_popcount_post(c, out_valid, 0, n, (unsigned long long*)&c->dscalars[2], total_dev, back);
+  else rc = ah_mailbox_read(c, total_dev, 1, back);
+  if (rc != AH_OK) return rc;
   *n_out_host = (int64_t)back[0];
-  if (out_null_count_host) *out_null_count_host = (int64_t)back[1];
+  if (out_null_count_host) *out_null_count_host = out_valid ? (int64_t)(back[0] - back[1]) : 0;
   return AH_OK;
 }
 
