@@ -452,6 +452,7 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dpp_move(u
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ u64 dpp_move(u64 v) {
   return ((u64)dpp_mov32<CTRL, ROW_MASK>((unsigned)(v >> 32)) << 32) | dpp_mov32<CTRL, ROW_MASK>((unsigned)v);
 }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned short dpp_move(unsigned short v) { return (unsigned short)dpp_mov32<CTRL, ROW_MASK>((unsigned)v); }
 template <typename E>
 __device__ __forceinline__ E wave_incl_scan_dpp(E v) {   // a lane without a source keeps 0
   v += dpp_move<0x111, 0xF>(v);   // row_shr:1
@@ -464,6 +465,7 @@ __device__ __forceinline__ E wave_incl_scan_dpp(E v) {   // a lane without a sou
 }
 __device__ __forceinline__ unsigned read_lane63(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ u64 read_lane63(u64 v) { return ((u64)read_lane63((unsigned)(v >> 32)) << 32) | read_lane63((unsigned)v); }
+__device__ __forceinline__ unsigned short read_lane63(unsigned short v) { return (unsigned short)read_lane63((unsigned)v); }
 
 // all ones where bit `pos` of `bits` is set (v_bfe_i32: the one-bit field sign-extended), else 0 — the AND mask of a row's payload
 template <typename E> __device__ __forceinline__ E op_bit_mask(unsigned bits, int pos) {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     const int64_t wbase = tile * TILE + (int64_t)wave * (64 * kOpVpt * V);
     EV x[kOpVpt];
     unsigned vbits = 0;
-    if (NULLS) vbits = op_lane_bits<V>(valid, off, wbase, limit < n ? limit : n, lane, out_valid, n, &s_count, &s_bits[NULLS ? wave * kOpVpt * V : 0]);
+    if constexpr (NULLS) vbits = op_lane_bits<V>(valid, off, wbase, limit < n ? limit : n, lane, out_valid, n, &s_count, &s_bits[NULLS ? wave * kOpVpt * V : 0]);
     // the lane's first kfull vectors lie inside the column (all eight unless this is the column's last chunk): a 32-bit test per vector
     const int lane_rows = (int)(n - wbase < (int64_t)(64 * kOpVpt * V) ? (n - wbase < 0 ? 0 : n - wbase) : (int64_t)(64 * kOpVpt * V)) - lane * V;
     const int kfull = lane_rows >= V ? (lane_rows - V) / (64 * V) + 1 : 0;
@@ -721,6 +723,10 @@ int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, in
   E* vout = (E*)out;
   const unsigned g = (unsigned)grid;
 #define AH_OP(NULLS, CHECKED, SIGNED) scan_onepass_kernel<E, NULLS, CHECKED, SIGNED><<<g, kOpThreads, 0, c->stream>>>(vin, vout, n, start, recs, ticket, 0u, c->scan_epoch, valid, off, limit, overflow, out_valid, vcount)
+  if constexpr (sizeof(E) < 4) {   // 2-byte columns: unchecked without nulls only
+    if (mode != 0) return ah_fail(c, AH_EINVALID, "cumulative_sum: one-pass mode %d for a narrow type", mode);
+    AH_OP(false, false, false);
+  } else
   switch (mode) {
     case 0: AH_OP(false, false, false); break;
     case 1: AH_OP(true, false, false); break;
@@ -747,8 +753,14 @@ int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t o
     // (not while a graph records: the epoch and the ticket base are host state a replay would repeat)
     // ONE pass for every 4- / 8-byte integer column — unchecked or checked, with or without nulls (round 5; round 4: unchecked without
     // nulls only).  The narrow types stay on reduce-then-scan (their tiles would be 2^16 … 2^17 rows of 1 … 2 bytes: not measured).
+    // 2-byte columns (round 5, last): the same kernel over tiles of 2^16 rows when unchecked and without nulls (options 3 / 4 keep them on
+    // reduce-then-scan, for measurement).  1-byte columns stay there: their 128 bytes per lane unpack into as many registers (35 spilled).
+    if (sizeof(T) == 2 && c->opt_scan_onepass && c->opt_scan_onepass < 3 && !c->capturing && n >= ((int64_t)1 << 18) && ((((uintptr_t)values) | ((uintptr_t)out)) & 15) == 0 &&
+        c->tune_nt && !checked && !valid && limit >= n) {
+      if constexpr (sizeof(T) == 2) return run_onepass<unsigned short>(c, values, n, (unsigned short)start, out);
+    }
     if (sizeof(T) >= 4 && c->opt_scan_onepass && !c->capturing && n >= ((int64_t)1 << 18) && ((((uintptr_t)values) | ((uintptr_t)out)) & 15) == 0 && c->tune_nt &&
-        (c->opt_scan_onepass != 3 || (!checked && !valid))) {   // (3: round 4's gate — unchecked without nulls only; a measurement switch)
+        (c->opt_scan_onepass < 3 || (!checked && !valid))) {   // (3 / 4: round 4's gate — unchecked 4- / 8-byte columns without nulls only; measurement switches)
       const bool nulls = valid != nullptr || limit < n;
       const int mode = (nulls ? 1 : 0) | (checked ? 2 : 0) | (checked && std::is_signed<T>::value ? 4 : 0);
       // the output's validity and its count come out of the same pass (the words the kernel reads are the words to write) — option

@@ -134,7 +134,7 @@ const char* ah_last_error(ah_ctx* ctx); /* never NULL; owned by ctx */
  * found and are added up slot by slot, 0 empty tables merged with atomics), "groupby_lean" (same path: 0 keep a pending group per lane,
  * 1 leave it out when neighbouring rows rarely share a key, 2 always leave it out), "groupby_reserve" (partitioned hash + sum: 1 the
  * scatter reserves its runs in per-(partition, XCD) regions sized from the key sample — no histogram pass —, 0 histogram first), "scan_onepass" (cumulative_sum of 4- /
- * 8-byte integers: 1 one pass with decoupled look-back, the output's validity and null count written by the same kernel, 0 reduce-then-scan, 2 one pass with
+ * 8-byte integers, and of unchecked 2-byte ones without nulls: 1 one pass with decoupled look-back, the output's validity and null count written by the same kernel, 0 reduce-then-scan, 2 one pass with
  * a separate bitmap copy + popcount, 3 one pass for unchecked columns without nulls only — 2 and 3 are measurement switches), "filter_cache" (1: ah_filter_count leaves its tile prefixes for the ah_filter_primitive that
  * follows, dropped by every entry point of THIS context that may write device memory — the default of ah_ctx_create; 0: the fill
  * always recounts — the default of ah_ctx_create_on_stream, where another producer on the shared stream may rewrite the mask

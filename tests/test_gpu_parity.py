@@ -1033,9 +1033,9 @@ def test_hash_sum_direct_path_seeded_tables(hip, orc_be, ctx, seed, lean):
         assert gi[0].tobytes() == e[0].tobytes(), (variant, "int64 group keys")
 
 
-@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.int32, np.uint32], ids=str)
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.int32, np.uint32, np.int16, np.uint16], ids=str)
 def test_cumulative_sum_one_pass(hip, orc_be, ctx, dtype):
-    """cumulative_sum of unchecked 4- / 8-byte integers without nulls takes ONE pass (decoupled look-back over 128 KiB tiles,
+    """cumulative_sum of unchecked 2- / 4- / 8-byte integers without nulls takes ONE pass (decoupled look-back over 128 KiB tiles,
     csrc/ah_scan.hip scan_onepass_kernel) from 2^18 rows on: sizes around the tile size (16 384 Int64 / 32 768 Int32 rows), more tiles than
     one look-back window (64) and than one generation of resident workgroups (256), a start value, wrap-around — all byte-equal to the
     sequential oracle and to the reduce-then-scan path (option scan_onepass 0), and the same bytes call after call (the record array is
