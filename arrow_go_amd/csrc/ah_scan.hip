@@ -279,7 +279,9 @@ __global__ __launch_bounds__(kBlock) void tile_scan_kernel(const T* __restrict__
       const unsigned long long t = __shfl_down(nf, o, 64);
       nf = t < nf ? t : nf;
     }
-    if (lane == 0) atomicMin(first_nf, nf);
+    // (look before the atomic: in a column that is non-finite from an early row on EVERY wave comes here, and 2^17 same-address
+    // atomicMin were 1.4 of that call's 1.95 ms; a wave whose row cannot lower the word leaves it alone)
+    if (lane == 0 && nf < __hip_atomic_load(first_nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(first_nf, nf);
   }
 }
 
@@ -320,9 +322,36 @@ __global__ __launch_bounds__(kBlock) void sticky_fill_kernel(const uint8_t* __re
   const unsigned long long r2 = *nan_from;
   const T s0 = out[r];   // row r itself is never rewritten
   const T qnan = s0 - s0;  // inf − inf: the NaN this device's adder produces
+  // 16 bytes per lane and store where a whole aligned group lies behind r (and, with a validity bitmap, all its rows are valid);
+  // row by row at the edges and around nulls — a column that turns NaN early is rewritten once more at the streaming rate
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef T TV __attribute__((ext_vector_type(V)));
+  const int64_t first = (int64_t)r + 1;
+  const int64_t g0 = ((uintptr_t)out & 15) == 0 ? first / V : limit;   // (an output that is not 16-byte aligned: row by row throughout)
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)r + 1 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < limit; i += stride)
-    if (ah_bit(valid, off + i)) out[i] = (unsigned long long)i < r2 ? s0 : qnan;
+  for (int64_t g = g0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; g * V < limit; g += stride) {
+    const int64_t i0 = g * V;
+    bool whole = i0 >= first && i0 + V <= limit;
+    if (whole && valid) {
+#pragma unroll
+      for (int j = 0; j < V; j++) whole = whole && ah_bit(valid, off + i0 + j);
+    }
+    if (whole) {
+      TV v;
+#pragma unroll
+      for (int j = 0; j < V; j++) v[j] = (unsigned long long)(i0 + j) < r2 ? s0 : qnan;
+      __builtin_nontemporal_store(v, (TV*)(out + i0));
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        const int64_t i = i0 + j;
+        if (i >= first && i < limit && ah_bit(valid, off + i)) out[i] = (unsigned long long)i < r2 ? s0 : qnan;
+      }
+    }
+  }
+  if (g0 == limit)
+    for (int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < limit; i += stride)
+      if (ah_bit(valid, off + i)) out[i] = (unsigned long long)i < r2 ? s0 : qnan;
 }
 
 // first zero bit of a validity bitmap (or n): where encounteredNull turns on
