@@ -150,3 +150,43 @@ def test_min_max_matches_reference_avx2(o, dtype):
     for n in [1, 3, 15, 16, 17, 31, 33, 64, 1000, 100003]:
         a = rng.integers(info.min, info.max, n, dtype=dtype, endpoint=True)
         assert o.min_max(a) == ref.min_max(a), (dtype, n)
+
+
+def test_oracle_wide_slot_take_vs_arrow_cpp():
+    """FSBImpl's take (kernels/vector_selection.go:1997-2031) as the oracle restates it — orc_take_primitive with slots of 16 and 32
+    bytes — against Arrow C++'s take of binary(16) / binary(32) / decimal128 / decimal256 columns (the independent semantic
+    cross-check of SURVEY §8c: values and validity; a null slot's payload is the fresh buffer's zero in both).  CPU only: this pins
+    the restatement the GPU's 16- / 32-byte Take is compared with (tests/test_gpu_parity.py::test_take_wide_slots_bit_exact)."""
+    pa = pytest.importorskip("pyarrow")
+    import pyarrow.compute as pc
+    o = OL.load_oracle()
+    rng = np.random.default_rng(97)
+    for w in (16, 32):
+        n, m = 5000, 7001
+        raw = rng.integers(0, 256, (n, w), dtype=np.uint8)
+        vmask = rng.random(n) < 0.1
+        col = pa.array([None if z else bytes(r) for r, z in zip(raw, vmask)], type=pa.binary(w))
+        vvalid = np.packbits(~vmask, bitorder="little")
+        for ityp, npt in ((pa.int8(), np.int8), (pa.uint16(), np.uint16), (pa.int32(), np.int32), (pa.uint64(), np.uint64)):
+            hi = min(n, np.iinfo(npt).max + 1)
+            idx = rng.integers(0, hi, m).astype(npt)
+            imask = rng.random(m) < 0.2
+            want = pc.take(col, pa.array(idx, type=ityp, mask=imask))
+            ivalid = np.packbits(~imask, bitorder="little")
+            st, out, ov, nulls, _ = o.take_primitive(raw.view(np.dtype(f"V{w}")).reshape(-1), vvalid, 0, idx, ivalid, 0, True, True)
+            assert st == 0 and nulls == want.null_count
+            got_valid = np.unpackbits(ov, bitorder="little")[:m].astype(bool)
+            assert np.array_equal(got_valid, np.array(want.is_valid()))
+            got = out.view(np.uint8).reshape(m, w)
+            for i in np.flatnonzero(got_valid)[:2000]:
+                assert bytes(got[i]) == want[int(i)].as_py()
+            assert not got[~got_valid].any()      # null slots: zero payload
+    # the same bytes read as decimals: Arrow C++'s take of a decimal128 column == the 16-byte slots moved by the oracle
+    import decimal
+    vals = [decimal.Decimal(int(v)) / 1000 for v in rng.integers(-10**15, 10**15, 300)]
+    dcol = pa.array(vals, type=pa.decimal128(20, 3))
+    idx = rng.integers(0, 300, 1000).astype(np.int32)
+    want = pc.take(dcol, pa.array(idx))
+    slots = np.frombuffer(dcol.buffers()[1], dtype=np.dtype("V16"), count=300)
+    st, out, _, _, _ = o.take_primitive(slots, None, 0, idx, None, 0, True, False)
+    assert st == 0 and out.tobytes() == bytes(want.buffers()[1])[:1000 * 16]
