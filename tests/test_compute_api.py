@@ -871,6 +871,31 @@ def test_take_and_filter_of_fixed_size_binary_and_decimals(sess):
         sess.call_function("take", [odd, pa.array([1, 0], type=pa.int32())])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [128, 256])
+def test_filter_decimal_reference_table(sess, bits):
+    """compute/vector_selection_test.go:656-689 (FilterKernelWithDecimal.TestFilterDecimalNumeric, run for Decimal128 and Decimal256
+    at precision 3, scale 2) through the registry's filter: the table row by row with both null selections, the sliced mask, and
+    the mask of another length refused (arrow.ErrInvalid)."""
+    import decimal
+    from tests.test_oracle_vs_reference import DECIMAL_FILTER_TABLE
+    typ = pa.decimal128(3, 2) if bits == 128 else pa.decimal256(3, 2)
+    arr = lambda vals: pa.array([None if v is None else decimal.Decimal(v) for v in vals], type=typ)
+    for vals, mask, want in DECIMAL_FILTER_TABLE:
+        v, f = arr(vals), pa.array(mask, type=pa.bool_())
+        got = sess.call_function("filter", [v, f], options="null_selection_behavior=emit_null")
+        assert got.type == typ and got.equals(arr(want)), (vals, mask)
+        drop = [w for w, m in zip(want, [m for m in mask if m is None or m]) if m is not None]
+        got = sess.call_function("filter", [v, f], options="null_selection_behavior=drop")
+        assert got.equals(arr(drop)) and got.equals(pc.filter(v, f, null_selection_behavior="drop")), (vals, mask)
+    val = arr(["7.12", "8.00", "9.87"])
+    sliced = pa.array([False, True, True, True, False, True]).slice(3, 3)
+    assert sess.call_function("filter", [val, sliced]).equals(arr(["7.12", "9.87"]))
+    for sel in ("emit_null", "drop"):
+        with pytest.raises(Exception, match="(?i)invalid|length"):
+            sess.call_function("filter", [val, pa.array([], type=pa.bool_())], options=f"null_selection_behavior={sel}")
+
+
 # ---- divide / abs / negate / bit-wise / shifts / sqrt through the registry ------------------------------------
 @pytest.mark.gpu
 def test_extended_arithmetic_functions(sess):

@@ -190,3 +190,52 @@ def test_oracle_wide_slot_take_vs_arrow_cpp():
     slots = np.frombuffer(dcol.buffers()[1], dtype=np.dtype("V16"), count=300)
     st, out, _, _, _ = o.take_primitive(slots, None, 0, idx, None, 0, True, False)
     assert st == 0 and out.tobytes() == bytes(want.buffers()[1])[:1000 * 16]
+
+
+# the reference's own table for Filter on Decimal128 / Decimal256 (precision 3, scale 2): compute/vector_selection_test.go:656-671
+# (FilterKernelWithDecimal.TestFilterDecimalNumeric) — values, mask, expected with DROP … and what EMIT_NULL makes of the same rows
+DECIMAL_FILTER_TABLE = [
+    ([], [], []),
+    (["9.00"], [False], []), (["9.00"], [True], ["9.00"]), (["9.00"], [None], [None]),
+    ([None], [False], []), ([None], [True], [None]), ([None], [None], [None]),
+    (["7.12", "8.00", "9.87"], [False, True, False], ["8.00"]),
+    (["7.12", "8.00", "9.87"], [True, False, True], ["7.12", "9.87"]),
+    ([None, "8.00", "9.87"], [False, True, False], ["8.00"]),
+    (["7.12", "8.00", "9.87"], [None, True, False], [None, "8.00"]),
+    (["7.12", "8.00", "9.87"], [True, None, True], ["7.12", None, "9.87"]),
+]
+
+
+def decimal_slots(vals, width):
+    """["7.12", None, …] at scale 2 → (little-endian two's-complement slots of `width` bytes, validity bits or None)"""
+    raw = np.zeros((len(vals), width), np.uint8)
+    for i, v in enumerate(vals):
+        if v is not None:
+            raw[i] = np.frombuffer(int(round(float(v) * 100)).to_bytes(width, "little", signed=True), np.uint8)
+    valid = OL.pack_bits([v is not None for v in vals]) if any(v is None for v in vals) else None
+    return raw.view(np.dtype(f"V{width}")).reshape(-1), valid
+
+
+@pytest.mark.parametrize("width", [16, 32], ids=["decimal128", "decimal256"])
+def test_oracle_decimal_filter_table(width):
+    """The reference's TestFilterDecimalNumeric rows through the oracle's composition for wide slots — GetTakeIndices
+    (orc_filter_to_indices) + FSBImpl's take (orc_take_primitive, 16- / 32-byte slots) — which is what the device's array_filter of
+    Decimal128 / Decimal256 runs (host/kernels.cc ExecFilterFixed).  The table's expectations are EMIT_NULL's for a null mask slot
+    (`[null]` stays) and identical under DROP when the mask has no nulls; DROP on a null mask slot removes the row."""
+    o = OL.load_oracle()
+    for vals, mask, want in DECIMAL_FILTER_TABLE:
+        slots, vvalid = decimal_slots(vals, width)
+        fdata = OL.pack_bits([bool(m) for m in mask])
+        fvalid = OL.pack_bits([m is not None for m in mask]) if any(m is None for m in mask) else None
+        for null_sel, expect in ((1, want), (0, [w for w, m in zip(want, [m for m in mask if m is None or m]) if m is not None])):
+            n = len(vals)
+            if n == 0:
+                assert expect == []
+                continue
+            idx, iv, _ = o.filter_to_indices(fdata, fvalid, 0, n, null_sel, True)
+            st, out, ov, nulls, _ = o.take_primitive(slots, vvalid, 0, idx, iv if fvalid is not None and null_sel == 1 else None, 0, True, True)
+            assert st == 0 and len(idx) == len(expect), (vals, mask, null_sel)
+            got_valid = np.unpackbits(ov, bitorder="little")[:len(idx)].astype(bool)
+            exp_slots, _ = decimal_slots(expect, width)
+            assert list(got_valid) == [e is not None for e in expect], (vals, mask, null_sel)
+            assert out[:len(idx)][got_valid].tobytes() == exp_slots[got_valid].tobytes(), (vals, mask, null_sel)
