@@ -416,6 +416,42 @@ __global__ __launch_bounds__(kBlock) void take_bool_kernel(const uint8_t* __rest
   }
 }
 
+// Slots of ANY byte width (FSBImpl, vector_selection.go:1997-2031: `copy(buf, valueData[start:start+valueSize])` per row) — what the
+// 1 / 2 / 4 / 8 / 16 / 32-byte kernels above do not take (the reference's own test column is binary(3)).  A row per lane, the slot copied
+// byte by byte; the 64 rows of a wave step share one validity word (ballot).  Not a tuned path: odd widths are rare, the rule is the same.
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void take_bytes_kernel(int w, const uint8_t* __restrict__ values, const uint8_t* __restrict__ vvalid, int64_t voff,
+                                                             uint64_t nvalues, const IdxT* __restrict__ idx, const uint8_t* __restrict__ ivalid,
+                                                             int64_t ioff, int64_t nidx, uint8_t* __restrict__ out, uint8_t* __restrict__ out_valid,
+                                                             unsigned long long* __restrict__ first_bad) {
+  using UIdx = typename std::make_unsigned<IdxT>::type;
+  const int lane = threadIdx.x & 63;
+  const int64_t nchunks = (nidx + 63) >> 6;
+  const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t c = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); c < nchunks; c += wave_stride) {
+    const int64_t i = c * 64 + lane;
+    bool ok = false;
+    uint64_t u = 0;
+    if (i < nidx && ah_bit(ivalid, ioff + i)) {
+      const IdxT s = idx[i];
+      u = (uint64_t)(UIdx)s;
+      if ((std::is_signed<IdxT>::value && s < 0) || u >= nvalues) atomicMin(first_bad, (unsigned long long)i);   // helpers.go:937-939
+      else ok = ah_bit(vvalid, voff + (int64_t)u);
+    }
+    if (i < nidx) {
+      uint8_t* dst = out + i * (int64_t)w;
+      const uint8_t* src = values + u * (uint64_t)w;
+      for (int b = 0; b < w; b++) dst[b] = ok ? src[b] : (uint8_t)0;   // a null output keeps the zero of a fresh buffer
+    }
+    const unsigned long long vword = __ballot(ok);
+    if (out_valid && lane == 0) {
+      const int64_t left = nidx - c * 64;
+      const int nbytes = left >= 64 ? 8 : (int)((left + 7) >> 3);
+      for (int b = 0; b < nbytes; b++) out_valid[c * 8 + b] = (uint8_t)(vword >> (8 * b));
+    }
+  }
+}
+
 // *_dev flavour: {position of the first offending index or UINT64_MAX, output null count} stay in device memory
 __global__ void take_status_kernel(const unsigned long long* __restrict__ first_bad, const unsigned long long* __restrict__ nvalid, int has_valid,
                                    int64_t nidx, unsigned long long* __restrict__ status) {
@@ -500,7 +536,19 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
     case 8: rc = dispatch_idx<8>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 16: rc = dispatch_idx<16>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 32: rc = dispatch_idx<32>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
-    default: return ah_fail(c, AH_EINVALID, "invalid values byte width for take");  // :1189
+    default: {
+      if (byte_width < 1 || byte_width > 4096) return ah_fail(c, AH_EINVALID, "invalid values byte width for take");  // :1189
+      const unsigned grid = ah_stream_grid(c, ah_ceil_div(ah_ceil_div(nidx, 64), kBlock / 64), 8);
+#define AH_TBY(IT) take_bytes_kernel<IT><<<grid, kBlock, 0, c->stream>>>(byte_width, (const uint8_t*)values, vvalid, voff, (uint64_t)nvalues, (const IT*)idx, ivalid, ioff, nidx, (uint8_t*)out_values, out_valid, first_bad); break
+      switch (idx_byte_width * 2 + (idx_signed ? 1 : 0)) {
+        case 2: AH_TBY(uint8_t); case 3: AH_TBY(int8_t); case 4: AH_TBY(uint16_t); case 5: AH_TBY(int16_t);
+        case 8: AH_TBY(uint32_t); case 9: AH_TBY(int32_t); case 16: AH_TBY(uint64_t); case 17: AH_TBY(int64_t);
+        default: return ah_fail(c, AH_EINDEX, "invalid indices byte width");
+      }
+#undef AH_TBY
+      AH_LAUNCH_CHECK(c);
+      rc = AH_OK;
+    }
   }
   if (rc != AH_OK) return rc;
   if (status_dev) {   // no round trip: the caller looks at the two words when (and if) it wants to

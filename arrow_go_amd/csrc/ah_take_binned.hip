@@ -536,7 +536,7 @@ int ah_take_binned_try(ah_ctx* c, int byte_width, const void* values, const uint
   *used = 0;
   const int mode = c->opt_take_binned;               // 0 never, 1 auto, 2 whenever legal
   const int window_log2 = c->opt_take_window_log2;   // bytes of `values` per bin (default 4 MiB: an XCD's L2; 1–4 MiB measured within 5 %)
-  if (mode == 0 || byte_width > 8) return AH_OK;   // (16- / 32-byte values: the plain gather kernel)
+  if (mode == 0 || (byte_width != 1 && byte_width != 2 && byte_width != 4 && byte_width != 8)) return AH_OK;   // (16- / 32-byte and odd-width slots: the plain gather kernels)
   const int64_t vbytes = nvalues * byte_width;
   if (nvalues < 1 || nvalues > ((int64_t)1 << 32) - 1 || nidx > ((int64_t)1 << 32) - 1) return AH_OK;
   if (mode == 1) {

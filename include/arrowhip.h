@@ -363,7 +363,8 @@ int ah_filter_to_indices(ah_ctx* ctx, const uint8_t* fdata, const uint8_t* fvali
                          int64_t* out_null_count_host);
 /* Take == PrimitiveTake (kernels/vector_selection.go:1162-1192 → primitiveTakeImpl
  * :878-988): out[i] = values[idx[i]]; null index or null value → payload 0, validity
- * 0.  byte_width ∈ {1,2,4,8} and, for FSBImpl's slots (:1997-2031: Decimal128/256, 16- and 32-byte binaries), {16,32}.
+ * 0.  byte_width ∈ {1,2,4,8} and, for FSBImpl's slots (:1997-2031: Decimal128/256, 16- and 32-byte binaries), {16,32}; any other
+ * width up to 4096 is copied byte by byte (a plain kernel: the reference's own test column is binary(3)).
  * idx_byte_width ∈ {1,2,4,8}; idx_signed selects the bounds rule of
  * checkIndexBounds (kernels/helpers.go:929-957; only valid index slots are checked).
  * An out-of-range valid index returns AH_EINDEX with the first offender (in index

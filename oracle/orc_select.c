@@ -86,7 +86,7 @@ int orc_take_primitive(int byte_width, const void* values, const uint8_t* vvalid
                        int64_t* out_null_count, int64_t* bad_index) {
   /* 1, 2, 4, 8 = primitiveTakeImpl; any other width = FSBImpl (vector_selection.go:1997-2031: the same visit order, the value copied
    * as valueSize bytes, a null slot left as allocated, i.e. zero) */
-  if (byte_width < 1 || byte_width > 64) return ORC_EINVALID;
+  if (byte_width < 1 || byte_width > 4096) return ORC_EINVALID;
   if (idx_byte_width != 1 && idx_byte_width != 2 && idx_byte_width != 4 && idx_byte_width != 8) return ORC_EINDEX;
   const uint8_t* vin = (const uint8_t*)values;
   uint8_t* vout = (uint8_t*)out_values;

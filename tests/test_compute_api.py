@@ -865,10 +865,46 @@ def test_take_and_filter_of_fixed_size_binary_and_decimals(sess):
         with pytest.raises(Exception, match="out of bounds"):
             sess.call_function("take", [sl, pa.array([9000], type=pa.int32())])
         assert len(sess.call_function("filter", [col.slice(0, 0), pa.array([], type=pa.bool_())])) == 0
-    # other widths are refused by name
-    odd = pa.array([b"abcde", b"fghij"], type=pa.binary(5))
-    with pytest.raises(Exception, match="byte widths 1, 2, 4, 8, 16 and 32"):
-        sess.call_function("take", [odd, pa.array([1, 0], type=pa.int32())])
+    # any other width goes byte by byte
+    odd = pa.array([b"abcde", None, b"fghij"], type=pa.binary(5))
+    assert sess.call_function("take", [odd, pa.array([2, 1, 0, None, 2], type=pa.int32())]).equals(pc.take(odd, pa.array([2, 1, 0, None, 2])))
+    assert sess.call_function("filter", [odd, pa.array([True, None, True])], options="null_selection_behavior=emit_null").equals(
+        pc.filter(odd, pa.array([True, None, True]), null_selection_behavior="emit_null"))
+
+
+@pytest.mark.gpu
+def test_take_fixed_size_binary_reference_table(sess):
+    """compute/vector_selection_test.go:1173-1187 (TakeKernelTestFSB.TestFixedSizeBinary: binary(3), values "aaa" / "bbb" / "ccc"):
+    the three assertTake rows, no validity bitmap without nulls, and the two out-of-bounds index errors (arrow.ErrIndex) — plus random
+    columns of widths 3, 7 and 24 against Arrow C++ for take and filter."""
+    t = pa.binary(3)
+    vals = lambda xs: pa.array(xs, type=t)
+    for v, i, want in ((["aaa", "bbb", "ccc"], [0, 1, 0], ["aaa", "bbb", "aaa"]),
+                       ([None, "bbb", "ccc"], [0, 1, 0], [None, "bbb", None]),
+                       (["aaa", "bbb", "ccc"], [None, 1, 0], [None, "bbb", "aaa"])):
+        enc = lambda xs: [None if x is None else x.encode() for x in xs]
+        for ityp in (pa.int8(), pa.uint8(), pa.int16(), pa.uint16(), pa.int32(), pa.uint32(), pa.int64(), pa.uint64()):   # assertTake runs every index type
+            got = sess.call_function("take", [vals(enc(v)), pa.array(i, type=ityp)])
+            assert got.type == t and got.equals(vals(enc(want))), (v, i, ityp)
+    got = sess.call_function("take", [vals([b"aaa", b"bbb", b"ccc"]), pa.array([0, 1, 0], type=pa.int16())])
+    assert got.null_count == 0 and got.buffers()[0] is None      # assertNoValidityBitmapUnknownNullCountJSON
+    with pytest.raises(Exception, match="out of bounds"):
+        sess.call_function("take", [vals([b"aaa", b"bbb", b"ccc"]), pa.array([0, 9, 0], type=pa.int8())])
+    with pytest.raises(Exception, match="out of bounds"):
+        sess.call_function("take", [vals([b"aaa", b"bbb", b"ccc"]), pa.array([2, 5], type=pa.int64())])
+    rng = np.random.default_rng(41)
+    n = 20_011
+    for w in (3, 7, 24):
+        raw = rng.integers(0, 256, (n, w), dtype=np.uint8)
+        col = pa.array([None if m else bytes(r) for r, m in zip(raw, rng.random(n) < 0.1)], type=pa.binary(w))
+        idx = pa.array(rng.integers(0, n, 15_001), type=pa.int32(), mask=rng.random(15_001) < 0.2)
+        assert sess.call_function("take", [col, idx]).equals(pc.take(col, idx)), w
+        f = pa.array(rng.random(n) < 0.4, mask=rng.random(n) < 0.15)
+        for sel in ("drop", "emit_null"):
+            got = sess.call_function("filter", [col, f], options=f"null_selection_behavior={sel}")
+            assert got.equals(pc.filter(col, f, null_selection_behavior=sel)), (w, sel)
+        sl = col.slice(1000, 5000)
+        assert sess.call_function("take", [sl, pa.array([4999, 0, 17], type=pa.int32())]).equals(pc.take(sl, pa.array([4999, 0, 17])))
 
 
 @pytest.mark.gpu

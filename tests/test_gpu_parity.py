@@ -385,10 +385,10 @@ def test_take_bit_exact(hip, orc_be, vdtype, idtype):
                     assert g[2].tobytes() == e[2].tobytes() and g[3] == e[3]
 
 
-@pytest.mark.parametrize("w", [16, 32])
+@pytest.mark.parametrize("w", [16, 32, 3, 5, 12, 24, 100])
 def test_take_wide_slots_bit_exact(hip, orc_be, w):
-    """FSBImpl's take (vector_selection.go:1997-2031) for 16- and 32-byte slots — Decimal128 / Decimal256 / binary(16|32) — through
-    ah_take_primitive: every index type, nulls on either side, offsets, the first
+    """FSBImpl's take (vector_selection.go:1997-2031) for 16- and 32-byte slots — Decimal128 / Decimal256 / binary(16|32) — and for
+    odd widths (binary(3) is the reference's own test column; the byte-wise kernel) through ah_take_primitive: every index type, nulls on either side, offsets, the first
     out-of-range index by value"""
     rng = np.random.default_rng(57 + w)
     vt = np.dtype(f"V{w}")

@@ -161,7 +161,7 @@ def test_oracle_wide_slot_take_vs_arrow_cpp():
     import pyarrow.compute as pc
     o = OL.load_oracle()
     rng = np.random.default_rng(97)
-    for w in (16, 32):
+    for w in (16, 32, 3, 24):      # (3: the reference's own test column, vector_selection_test.go:1170)
         n, m = 5000, 7001
         raw = rng.integers(0, 256, (n, w), dtype=np.uint8)
         vmask = rng.random(n) < 0.1
