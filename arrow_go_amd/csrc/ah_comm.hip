@@ -688,25 +688,27 @@ AH_EXPORT int ah_comm_merge_groups(ah_comm* m, int is_f64, const uint64_t* keys,
       AH_HIP(c, hipMemcpyAsync(dk, nk.data(), nk.size() * 8, hipMemcpyHostToDevice, c->stream));
       AH_HIP(c, hipMemcpyAsync(dsum, ns.data(), ns.size() * 8, hipMemcpyHostToDevice, c->stream));
       int64_t one = 0;
-      if ((rc = ah_hash_sum_f64(c, dk, nullptr, 0, dsum, nullptr, 0, (int64_t)nk.size(), okk, osm, oc, of, &one, nullptr)) != AH_OK) return rc;
-      if (one != 1) return ah_fail(c, AH_EINVALID, "merge_groups: internal error (null group merge)");
-      if ((rc = ah_copy_async(c, col[1] + (size_t)G * 8, osm, 8)) != AH_OK) return rc;
+      // (an error return from here on first waits for the copies above: they read this frame's null_tuple / nk / ns)
+      auto settle = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
+      if ((rc = ah_hash_sum_f64(c, dk, nullptr, 0, dsum, nullptr, 0, (int64_t)nk.size(), okk, osm, oc, of, &one, nullptr)) != AH_OK) return settle(rc);
+      if (one != 1) return settle(ah_fail(c, AH_EINVALID, "merge_groups: internal error (null group merge)"));
+      if ((rc = ah_copy_async(c, col[1] + (size_t)G * 8, osm, 8)) != AH_OK) return settle(rc);
     }
     // its position in first-seen order = the groups first seen before it (first rows are distinct: a row has one key)
     if (G > 0) {
       int64_t pos = 0;
-      if ((rc = ah_comparison(c, AH_CMP_GT, AH_SHAPE_SA, AH_INT64, &null_tuple[3], col[3], before_bits, G, 0)) != AH_OK) return rc;
-      if ((rc = ah_count_set_bits(c, before_bits, 0, G, &pos)) != AH_OK) return rc;
+      if ((rc = ah_comparison(c, AH_CMP_GT, AH_SHAPE_SA, AH_INT64, &null_tuple[3], col[3], before_bits, G, 0)) != AH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+      if ((rc = ah_count_set_bits(c, before_bits, 0, G, &pos)) != AH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
       if (out_null_group_host) *out_null_group_host = (int32_t)pos;
     } else if (out_null_group_host) {
       *out_null_group_host = 0;
     }
   }
   // ---- 5: global first-seen order
-  if ((rc = ah_sort_indices(c, AH_INT64, col[3], nullptr, 0, GT, 0, 0, order)) != AH_OK) return rc;
+  if ((rc = ah_sort_indices(c, AH_INT64, col[3], nullptr, 0, GT, 0, 0, order)) != AH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
   void* outs[4] = {out_keys, out_sums, out_counts, out_first_rows};
   for (int k = 0; k < 4; k++)
-    if ((rc = ah_take_primitive(c, 8, col[k], nullptr, 0, GT, 8, 0, order, nullptr, 0, GT, 0, outs[k], nullptr, nullptr, nullptr)) != AH_OK) return rc;
+    if ((rc = ah_take_primitive(c, 8, col[k], nullptr, 0, GT, 8, 0, order, nullptr, 0, GT, 0, outs[k], nullptr, nullptr, nullptr)) != AH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
   AH_HIP(c, hipStreamSynchronize(c->stream));
   return AH_OK;
 }
