@@ -128,6 +128,28 @@ const DataType* Unsigned(const std::string& name) {
   return nullptr;
 }
 
+// NamedStruct.names lists the field names depth-first, the names of nested struct fields included (substrait/type.proto; substrait-go's
+// NamedStruct does the same): how many names FOLLOW a column's own name — one per field of every struct inside it, through lists and
+// maps.  The columns of this layer are flat, but a schema may carry a struct column next to the ones an expression uses.
+Status CountNestedNames(Slice in, int depth, size_t* extra) {
+  if (depth > 64) return Status::Make(StatusCode::Invalid, "substrait: type nested too deeply");
+  Reader r(in);
+  Field f;
+  while (r.next(&f)) {
+    if (f.wire != 2 || (f.number != 25 && f.number != 27 && f.number != 28)) continue;   // struct / list / map
+    Reader k(f.sub);
+    Field g;
+    while (k.next(&g)) {
+      if (g.wire != 2 || !(g.number == 1 || (f.number == 28 && g.number == 2))) continue;   // struct.types, list.type, map.key / value
+      if (f.number == 25) ++*extra;
+      AHC_RETURN_NOT_OK(CountNestedNames(g.sub, depth + 1, extra));
+    }
+    if (k.bad) return Malformed("type");
+  }
+  if (r.bad) return Malformed("type");
+  return Status::OK();
+}
+
 Status ReadType(Slice in, const Extensions& ext, SType* out) {
   Reader r(in);
   Field f;
@@ -415,10 +437,10 @@ struct Parser {
     Reader r(in);
     Field f;
     Status st = Status::Make(StatusCode::Invalid, "substrait: empty expression");
-    bool seen = false;
+    // rex_type is a oneof: of several members on the wire the LAST one counts (protobuf's rule; a writer that merges messages
+    // produces exactly that) — every member read replaces what the one before it left
     while (r.next(&f)) {
-      if (f.wire != 2 || seen) continue;
-      seen = true;
+      if (f.wire != 2) continue;
       switch (f.number) {
         case 1: st = Literal(f.sub, out); break;
         case 2: st = FieldRef(f.sub, out); break;
@@ -471,8 +493,10 @@ Status ParseSubstraitExtended(const uint8_t* bytes, int64_t len, SubstraitExtend
       } else if (pass == 2 && f.number == 4) {              // NamedStruct {1 names …, 2 struct {1 types …}}
         Reader n(f.sub);
         Field g;
+        std::vector<std::string> all_names;   // depth-first, nested struct fields included
+        std::vector<size_t> nested;           // per column: names that follow its own
         while (n.next(&g)) {
-          if (g.number == 1 && g.wire == 2) out->names.push_back(g.sub.str());
+          if (g.number == 1 && g.wire == 2) all_names.push_back(g.sub.str());
           else if (g.number == 2 && g.wire == 2) {
             Reader st(g.sub);
             Field h;
@@ -480,13 +504,25 @@ Status ParseSubstraitExtended(const uint8_t* bytes, int64_t len, SubstraitExtend
               if (h.number != 1 || h.wire != 2) continue;
               SType t;
               AHC_RETURN_NOT_OK(ReadType(h.sub, ext, &t));
+              size_t extra = 0;
+              AHC_RETURN_NOT_OK(CountNestedNames(h.sub, 0, &extra));
               out->types.push_back(t.type);
               out->type_names.push_back(t.name);
+              nested.push_back(extra);
             }
             if (st.bad) return Malformed("base schema");
           }
         }
         if (n.bad) return Malformed("base schema");
+        size_t pos = 0, nested_total = 0;
+        for (size_t i = 0; i < nested.size(); i++) {
+          if (pos < all_names.size()) out->names.push_back(all_names[pos]);
+          pos += 1 + nested[i];
+          nested_total += nested[i];
+        }
+        if (pos != all_names.size())
+          return Status::Make(StatusCode::Invalid, "substrait: base schema has " + std::to_string(all_names.size()) + " names for " + std::to_string(nested.size()) +
+                                                       " columns and " + std::to_string(nested_total) + " nested struct fields");
       } else if (pass == 2 && f.number == 3) {              // ExpressionReference {1 expression, 2 measure, 3 output_names …}
         Reader e(f.sub);
         Field g;

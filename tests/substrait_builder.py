@@ -48,6 +48,12 @@ class SB:
         self.funcs = {}                 # (uri, name) → anchor
 
     def typ(self, t):
+        if isinstance(t, tuple):        # ("struct", [(name, type) …]) / ("list", type) / ("map", key type, value type): nested types
+            if t[0] == "struct":
+                return _ld(25, b"".join(_ld(1, self.typ(ft)) for _, ft in t[1]) + _vi(3, 1))
+            if t[0] == "list":
+                return _ld(27, _ld(1, self.typ(t[1])) + _vi(3, 1))
+            return _ld(28, _ld(1, self.typ(t[1])) + _ld(2, self.typ(t[2])) + _vi(4, 1))
         if t in _UNSIGNED:
             base, var = _UNSIGNED[t]
             return _ld(_TYPE_FIELD[base], _vi(1, var) + _vi(2, 1))
@@ -90,7 +96,17 @@ class SB:
             msg += _ld(2, _ld(3, _vi(1, _URI_ANCHOR[uri]) + _vi(2, anchor) + _ld(3, name.encode())))
         for e in exprs:
             msg += _ld(3, (_ld(2, b"\x08\x01") if measure else _ld(1, e)) + _ld(3, b"out"))
-        names = b"".join(_ld(1, n.encode()) for n, _ in self.schema)
+        def dfs(name, t):               # NamedStruct.names: depth-first, the fields of nested structs included
+            out = [name]
+            if isinstance(t, tuple):
+                if t[0] == "struct":
+                    for fn, ft in t[1]:
+                        out += dfs(fn, ft)
+                else:
+                    for sub in t[1:]:
+                        out += dfs(None, sub)[1:]
+            return out
+        names = b"".join(_ld(1, n.encode()) for col, t in self.schema for n in dfs(col, t))
         types = b"".join(_ld(1, self.typ(t)) for _, t in self.schema)
         return msg + _ld(4, names + _ld(2, types + _vi(3, 2)))
 

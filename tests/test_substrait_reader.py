@@ -72,6 +72,27 @@ def test_base_schema_and_literals():
     assert "s:?string" in ac.inspect_substrait(b.build(b.call(CMP, "is_null", b.field(11))))
 
 
+def test_nested_schema_names_and_the_last_oneof_member():
+    """NamedStruct.names is depth-first with the fields of nested structs included (substrait/type.proto): a schema with a struct
+    column (also inside a list / a map) keeps its other columns addressable — the reference executes such a schema as long as the
+    expression does not touch the struct.  And rex_type is a oneof: of two members on the wire the last one counts."""
+    inner = ("struct", [("z", "i64"), ("w", ("list", ("struct", [("q", "i8")])))])
+    b = SB([("a", "i32"), ("s", ("struct", [("x", "i32"), ("y", inner)])), ("m", ("map", "string", ("struct", [("k", "fp64")]))), ("b", "i64")])
+    text = ac.inspect_substrait(b.build(b.call(CMP, "gt", b.field(3), b.lit("i64", 7))))
+    assert text.split("|")[0] == "a:int32,s:?struct,m:?type #28,b:int64", text
+    assert expr_of(text) == "greater($3, int64(0000000000000007))"
+    # a name too few / too many is still refused, with the count of nested fields in the message
+    good = b.build(b.call(CMP, "is_null", b.field(0)))
+    with pytest.raises(ac.ErrInvalid, match="names for .* nested struct fields"):
+        ac.inspect_substrait(good + _ld(4, _ld(1, b"stray")))          # a name that no column accounts for
+    # two members of the oneof: literal, then field reference → the field reference
+    flat = SB([("a", "i32"), ("b", "i32")])
+    both = flat.lit("i32", 5) + flat.field(1)
+    assert expr_of(ac.inspect_substrait(flat.build(flat.call(CMP, "equal", flat.field(0), both)))) == "equal($0, $1)"
+    both = flat.field(1) + flat.lit("i32", 5)
+    assert expr_of(ac.inspect_substrait(flat.build(flat.call(CMP, "equal", flat.field(0), both)))) == "equal($0, int32(00000005))"
+
+
 def test_casts():
     b = SB([("a", "i32"), ("x", "fp64")])
     assert expr_of(ac.inspect_substrait(b.build(b.cast("i64", b.field(0))))) == "cast($0 -> int64 unsafe)"        # THROW_EXCEPTION → UnsafeCastOptions (exec.go:571)
