@@ -56,6 +56,9 @@ RESOURCES = {
         (r"enc_table_kernelILi8192ELb1E", 128, 0),
     ],
     "ah_take.hip": [(r"take_vec_kernelILi8EiLb[01]ELi7E", 64, 0)],
+    # the one-pass cumulative_sum: a workgroup of 1024 lanes per CU = 128 registers, and nothing of the tile in scratch (a CSE of the
+    # sixteen null masks across the look-back once spilled 21 … 49 registers and every parity test stayed green: DESIGN.md §3.4)
+    "ah_scan.hip": [(r"scan_onepass_kernelI[jyt]Lb", 128, 16)],
 }
 
 
