@@ -579,6 +579,7 @@ class Session:
         call node (the reference's executeScalarBatch).  Returns (result, fused)."""
         cols = [self._to_datum(c) for c in columns]
         lits = [self._to_datum(l) for l in literals]
+        borrowed = [x.h.value for x in list(columns) + list(literals) if isinstance(x, DeviceArray)]   # stay owned by their wrappers
         try:
             ca = (_vp * max(len(cols), 1))(*cols)
             la = (_vp * max(len(lits), 1))(*lits)
@@ -591,7 +592,8 @@ class Session:
                 lib.ahc_datum_release(out)
         finally:
             for d in cols + lits:
-                lib.ahc_datum_release(d)
+                if d.value not in borrowed:
+                    lib.ahc_datum_release(d)
 
     def eval_expression_tree(self, tree, columns, names=None, fuse: bool = True):
         """The reference's own tree shape (compute.Expression: Literal | field reference | Call{name, args, options},

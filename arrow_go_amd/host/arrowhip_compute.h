@@ -151,10 +151,14 @@ struct ArrayData {
   // temporal type ("tsu:UTC", "tdD", "ttm", "tDn" …; empty = a plain column).  CallFunction checks the
   // reference's type rules on it, runs the integer kernel, and labels the result (core.cc, "temporal front end").
   std::string logical;
-  // the buffers are HOST memory (Buffer::hptr): a column imported with ahc_import_host or a result of the streaming executor.
-  // Flat fixed-width columns only.  CallFunction streams such arguments through the device in chunks where the function allows
-  // it and uploads them whole where it does not (hoststream.cc).
+  // the buffers are HOST memory (Buffer::hptr, dptr == nullptr): a column imported with ahc_import_host or a result of the
+  // streaming executor.  Flat fixed-width columns only.  compute::CallFunction streams such arguments through the device in chunks
+  // where the function allows it and uploads them whole where it does not (core.cc → hoststream.cc); math::*.Sum streams them;
+  // ExecuteScalarExpression / ExecuteScalarSubstrait upload them before evaluating.  exec::ArraySpan never sees one.
   bool on_host = false;
+  // … and the device-resident copy MaterializeOnDevice made the first time a call that cannot stream needed the column: later
+  // calls (streamable or not) use it instead of crossing the link again.  Lives and dies with the host array.
+  mutable std::shared_ptr<ArrayData> device_twin;
 };
 using ArrayDataPtr = std::shared_ptr<ArrayData>;
 
@@ -358,6 +362,9 @@ struct ExecCtx {
 // the arguments whole (MaterializeOnDevice) and takes the usual path.
 Status CallHostResident(ExecCtx* ctx, const std::string& name, const FunctionOptions* opts, const std::vector<Datum>& args, Datum* out, bool* handled);
 Status MaterializeOnDevice(Session* s, const ArrayDataPtr& host, ArrayDataPtr* out);
+// every host-resident array datum of `values` replaced by a device-resident copy (what CallFunction, the expression executors
+// and the record / chunked entry points do before anything that cannot stream)
+Status MaterializeAllOnDevice(Session* s, std::vector<Datum>* values);
 Status SumHostResident(ExecCtx* ctx, const ArrayData& a, double* f64, int64_t* i64, uint64_t* u64);
 
 enum class FuncKind { Scalar, Vector, Meta };  // functions.go:88-100

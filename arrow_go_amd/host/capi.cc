@@ -234,7 +234,8 @@ AHC_EXPORT int ahc_import_host(ahc_session* s, ArrowArray* arr, ArrowSchema* sch
   *out = new ahc_datum{Datum::Of(d)};
   return 0;
 }
-AHC_EXPORT int ahc_datum_on_host(ahc_datum* d) { return d->d.kind == DatumKind::Array && d->d.array->on_host ? 1 : 0; }
+// 1 while the array's only copy is the host's (an uploaded twin makes it device-resident for every later call)
+AHC_EXPORT int ahc_datum_on_host(ahc_datum* d) { return d->d.kind == DatumKind::Array && d->d.array->on_host && !d->d.array->device_twin ? 1 : 0; }
 
 // the ExecCtx fields of this session: "chunk_bytes" (ExecCtx.ChunkSize's role for host-resident arguments: bytes of the widest column
 // per span, 0 = 32 MiB), "host_threshold_bytes" (ahc_import_host keeps arrays of at least this many value bytes on the host)
@@ -420,19 +421,8 @@ AHC_EXPORT int ahc_call(ahc_session* s, const char* name, const char* options, i
   ParsedOptions po;
   ParseOptions(options, &po);
   Datum res;
-  bool any_host = false;
-  for (const Datum& d : a) any_host = any_host || (d.kind == DatumKind::Array && d.array->on_host);
-  if (any_host) {
-    // host-resident arguments: span by span through the device where the function can be streamed (hoststream.cc: the reference's
-    // iterateExecSpans with ExecCtx.ChunkSize, executor.go:47-50,499), uploaded whole where it cannot
-    bool handled = false;
-    Status hs = compute::CallHostResident(&s->ectx, name ? name : "", po.pick, a, &res, &handled);
-    if (!hs.ok()) return Fail(s, hs);
-    if (handled) { *out = new ahc_datum{res}; return 0; }
-    hs = ToDeviceAll(s, nargs, args);
-    if (!hs.ok()) return Fail(s, hs);
-    for (int i = 0; i < nargs; i++) a[(size_t)i] = args[i]->d;
-  }
+  // (host-resident arguments are compute::CallFunction's business: streamed span by span where the function allows it, uploaded
+  // whole — once, ArrayData::device_twin — where it does not)
   Status st = compute::CallFunction(&s->ectx, name, po.pick, a, &res);
   if (!st.ok()) return Fail(s, st);
   *out = new ahc_datum{res};
@@ -441,10 +431,10 @@ AHC_EXPORT int ahc_call(ahc_session* s, const char* name, const char* options, i
 
 AHC_EXPORT int ahc_math_sum(ahc_session* s, ahc_datum* d, double* f64, int64_t* i64, uint64_t* u64) {
   if (d->d.kind != DatumKind::Array) return Fail(s, Status::Make(StatusCode::Invalid, "math.Sum needs an array"));
-  const ArrayData& a = *d->d.array;
+  const ArrayData& a = d->d.array->on_host && d->d.array->device_twin ? *d->d.array->device_twin : *d->d.array;   // uploaded since: the copy in HBM
   Status st;
   if (!a.logical.empty()) return Fail(s, Status::Make(StatusCode::TypeError, "arrow/math has Float64, Int64 and Uint64 Sum only, not " + a.logical));
-  if (a.on_host) {   // chunk by chunk through the device, one final reduction (ah_ingest_sum_*)
+  if (a.on_host) {   // chunk by chunk through the device, one final reduction (ah_ingest_sum_*), with the session's ChunkBytes
     st = compute::SumHostResident(&s->ectx, a, f64, i64, u64);
     return st.ok() ? 0 : Fail(s, st);
   }
@@ -763,9 +753,11 @@ AHC_EXPORT int ahc_export_device(ahc_session* s, ahc_datum* d, ArrowDeviceArray*
 // test / interop introspection: the device pointers behind an array datum
 AHC_EXPORT int ahc_datum_buffers(ahc_datum* d, void** validity, void** data) {
   if (d->d.kind != DatumKind::Array) return 1;
-  const bool h = d->d.array->on_host;   // a host-resident array: the HOST pointers (ahc_datum_on_host says which)
-  *validity = d->d.array->buffers[0] ? (h ? d->d.array->buffers[0]->hptr : d->d.array->buffers[0]->dptr) : nullptr;
-  *data = d->d.array->buffers[1] ? (h ? d->d.array->buffers[1]->hptr : d->d.array->buffers[1]->dptr) : nullptr;
+  // a host-resident array: the HOST pointers — unless it has been uploaded since (ahc_datum_on_host says which)
+  const ArrayData& a = d->d.array->on_host && d->d.array->device_twin ? *d->d.array->device_twin : *d->d.array;
+  const bool h = a.on_host;
+  *validity = a.buffers[0] ? (h ? a.buffers[0]->hptr : a.buffers[0]->dptr) : nullptr;
+  *data = a.buffers[1] ? (h ? a.buffers[1]->hptr : a.buffers[1]->dptr) : nullptr;
   return 0;
 }
 
@@ -813,7 +805,6 @@ struct ExprParser {
 AHC_EXPORT int ahc_expr_eval(ahc_session* s, const char* text, int ncols, ahc_datum** cols, int nlits, ahc_datum** lits, int fuse,
                              ahc_datum** out, int* fused_out) {
   *out = nullptr;
-  { Status hs = ToDeviceAll(s, ncols, cols); if (!hs.ok()) return Fail(s, hs); }
   std::vector<Datum> lit_datums;
   for (int i = 0; i < nlits; i++) lit_datums.push_back(lits[i]->d);
   ExprParser parser{text, &lit_datums, ""};
@@ -839,7 +830,6 @@ AHC_EXPORT int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, in
                                   int nlits, ahc_datum** lits, int fuse, ahc_datum** out, int* fused_out) {
   *out = nullptr;
   if (!nodes || n_nodes <= 0) return Fail(s, Status::Make(StatusCode::Invalid, "nil expression"));   // exprs/exec.go:441-443
-  { Status hs = ToDeviceAll(s, ncols, cols); if (!hs.ok()) return Fail(s, hs); }
   std::vector<compute::ExprPtr> built((size_t)n_nodes);
   for (int i = 0; i < n_nodes; i++) {
     const ahc_expr_node& nd = nodes[i];
@@ -902,7 +892,6 @@ AHC_EXPORT int ahc_expr_eval_tree(ahc_session* s, const ahc_expr_node* nodes, in
 AHC_EXPORT int ahc_expr_eval_substrait(ahc_session* s, const uint8_t* bytes, int64_t len, int ncols, ahc_datum** cols, const char* const* col_names,
                                        int fuse, ahc_datum** out, int* fused_out) {
   *out = nullptr;
-  { Status hs = ToDeviceAll(s, ncols, cols); if (!hs.ok()) return Fail(s, hs); }
   std::vector<Datum> c;
   std::vector<std::string> names;
   for (int i = 0; i < ncols; i++) {

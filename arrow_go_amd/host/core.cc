@@ -1359,6 +1359,18 @@ Status CallFunction(ExecCtx* ctx, const std::string& name, const FunctionOptions
   FunctionRegistry* reg = ctx && ctx->Registry ? ctx->Registry : GetFunctionRegistry();
   Function* fn = reg->GetFunction(name);
   if (!fn) return Status::Make(StatusCode::KeyError, "function '" + name + "' not found");  // exec.go:191-199
+  // HOST-resident arguments (ArrayData::on_host: their buffers hold no device pointer) never reach a kernel: the call is streamed
+  // span by span where the function allows it, and the host arguments are uploaded whole where it does not (hoststream.cc)
+  for (auto& a : args)
+    if (a.kind == DatumKind::Array && a.array->on_host) {
+      if (!ctx || !ctx->session) return Status::Make(StatusCode::Invalid, "host-resident argument: the ExecCtx carries no session to stream it through");
+      bool handled = false;
+      AHC_RETURN_NOT_OK(CallHostResident(ctx, name, opts, args, out, &handled));
+      if (handled) return Status::OK();
+      std::vector<Datum> dev_args(args);
+      AHC_RETURN_NOT_OK(MaterializeAllOnDevice(ctx->session, &dev_args));
+      return CallFunction(ctx, name, opts, dev_args, out);
+    }
   {
     std::vector<std::string> lg;
     bool any = false;
@@ -1390,22 +1402,27 @@ const Float64Funcs Float64{};
 const Int64Funcs Int64{};
 const Uint64Funcs Uint64{};
 
+// a host-resident array: chunk by chunk through the device, one final reduction (hoststream.cc SumHostResident)
+static compute::ExecCtx HostCtx(Session* s) { compute::ExecCtx c; c.session = s; return c; }
 static const void* ValuesPtr(const ArrayData& a) {
   return (const uint8_t*)a.buffers[1]->dptr + a.offset * (a.type->bit_width / 8);  // Float64Values(): offset applied
 }
 Status Float64Funcs::Sum(Session* s, const ArrayData& a, double* out) const {
   if (a.type->id != Type::FLOAT64) return Status::Make(StatusCode::TypeError, "math.Float64.Sum needs a float64 array");
   if (a.length == 0) { *out = 0; return Status::OK(); }  // float64.go:35-37
+  if (a.on_host) { if (a.device_twin) return Sum(s, *a.device_twin, out); auto c = HostCtx(s); return compute::SumHostResident(&c, a, out, nullptr, nullptr); }
   return s->FromStatus(ah_sum_float64(s->ctx(), (const double*)ValuesPtr(a), (size_t)a.length, out));
 }
 Status Int64Funcs::Sum(Session* s, const ArrayData& a, int64_t* out) const {
   if (a.type->id != Type::INT64) return Status::Make(StatusCode::TypeError, "math.Int64.Sum needs an int64 array");
   if (a.length == 0) { *out = 0; return Status::OK(); }
+  if (a.on_host) { if (a.device_twin) return Sum(s, *a.device_twin, out); auto c = HostCtx(s); return compute::SumHostResident(&c, a, nullptr, out, nullptr); }
   return s->FromStatus(ah_sum_int64(s->ctx(), (const int64_t*)ValuesPtr(a), (size_t)a.length, out));
 }
 Status Uint64Funcs::Sum(Session* s, const ArrayData& a, uint64_t* out) const {
   if (a.type->id != Type::UINT64) return Status::Make(StatusCode::TypeError, "math.Uint64.Sum needs a uint64 array");
   if (a.length == 0) { *out = 0; return Status::OK(); }
+  if (a.on_host) { if (a.device_twin) return Sum(s, *a.device_twin, out); auto c = HostCtx(s); return compute::SumHostResident(&c, a, nullptr, nullptr, out); }
   return s->FromStatus(ah_sum_uint64(s->ctx(), (const uint64_t*)ValuesPtr(a), (size_t)a.length, out));
 }
 }  // namespace math

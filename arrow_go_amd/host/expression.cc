@@ -197,6 +197,13 @@ static bool HasTemporalLiteral(const Expression& e) {
 Status ExecuteScalarExpression(ExecCtx* ctx, const ExprPtr& expr, const ExecBatch& batch, Datum* out, bool fuse, bool* fused_out) {
   if (fused_out) *fused_out = false;
   if (!expr) return Status::Make(StatusCode::Invalid, "nil expression");  // exec.go:441-443
+  // host-resident columns: the fused kernel and the per-node calls both read device buffers — upload them once, here
+  for (auto& v : batch.values)
+    if (v.kind == DatumKind::Array && v.array->on_host) {
+      ExecBatch dev(batch);
+      AHC_RETURN_NOT_OK(MaterializeAllOnDevice(ctx->session, &dev.values));
+      return ExecuteScalarExpression(ctx, expr, dev, out, fuse, fused_out);
+    }
   // temporal operands: the type rules live in CallFunction, so every node goes through it (the fused kernel would
   // compute on the integers without checking that a timestamp meets a duration of its own unit)
   for (auto& v : batch.values)

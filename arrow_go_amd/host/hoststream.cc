@@ -132,6 +132,7 @@ bool SplitArgs(const std::vector<Datum>& args, HostArg* l, HostArg* r) {
   for (int i = 0; i < 2; i++) {
     if (args[i].kind == DatumKind::Array) {
       if (!args[i].array->on_host) return false;   // mixed residency: upload the host side whole
+      if (args[i].array->device_twin) return false;   // already uploaded once: the copy in HBM is nearer than the link
       dst[i]->arr = args[i].array.get();
     } else if (args[i].kind == DatumKind::Scalar) {
       dst[i]->scalar = args[i].scalar.get();
@@ -161,12 +162,17 @@ Status StreamArithmetic(ExecCtx* ctx, int op, bool checked, const HostArg& l, co
   AHC_RETURN_NOT_OK(ResultValidity(s, l, r, n, &dvl, &dvr, &hvalid, &nulls));
   AHC_RETURN_NOT_OK(s->AllocatePinned(n * w, &hvalues));
   const bool null_scalar = (l.scalar && !l.scalar->valid) || (r.scalar && !r.scalar->valid);
-  if (null_scalar) {   // every row is null: payload zero, as a fresh buffer holds (ScalarBinaryNotNull writes nothing)
+  // A null scalar makes every row null, but only ScalarBinaryNotNull — the checked INTEGER add / sub — leaves the payload as
+  // allocated (helpers.go:311-314,340-343: "fast path if one side is entirely null").  Every unchecked op, every float op and
+  // checked multiply run ScalarBinary, which unboxes the scalar's stored value and computes l[i] ∘ value under the all-null
+  // validity (helpers.go:204-222; base_arithmetic.go:273-280 for Mul): those stream like any other call, so the payload is the
+  // whole-array path's (kernels.cc ExecArithUnchecked / ah_arithmetic_checked) byte for byte.
+  if (null_scalar && checked && op != AH_OP_MUL_CHECKED) {
     memset(hvalues->hptr, 0, (size_t)(n * w));
     *out = Datum::Of(MakeHostArray(t, n, hvalues, hvalid, nulls, ""));
     return Status::OK();
   }
-  const int scalar_valid = 1;
+  const int scalar_valid = null_scalar ? 0 : 1;
   auto kernel = [&](int64_t rows, int64_t r0, void* b0, void* b1, void* b2) -> Status {
     const void* lp = l.arr ? b0 : (const void*)l.scalar->value;
     const void* rp = r.arr ? b1 : (const void*)r.scalar->value;
@@ -178,8 +184,9 @@ Status StreamArithmetic(ExecCtx* ctx, int op, bool checked, const HostArg& l, co
       }
     }
     // the span's rows of the whole-column validity bitmaps (on the device since ResultValidity)
-    const uint8_t* lv = l.has_nulls() ? (const uint8_t*)dvl->dptr : nullptr;
-    const uint8_t* rv = r.has_nulls() ? (const uint8_t*)dvr->dptr : nullptr;
+    // (not uploaded under a null scalar — only checked multiply gets here with one, and it never reads validity: ah_arith.hip)
+    const uint8_t* lv = l.has_nulls() && dvl ? (const uint8_t*)dvl->dptr : nullptr;
+    const uint8_t* rv = r.has_nulls() && dvr ? (const uint8_t*)dvr->dptr : nullptr;
     return s->FromStatus(ah_arithmetic_checked(s->ctx(), (int)t->id, (int8_t)op, shape, lp, lv, l.arr ? l.arr->offset + r0 : 0, rp, rv,
                                                r.arr ? r.arr->offset + r0 : 0, scalar_valid, b2, rows));
   };
@@ -200,17 +207,16 @@ Status StreamCompare(ExecCtx* ctx, int cmpop, const HostArg& l, const HostArg& r
   AHC_RETURN_NOT_OK(ResultValidity(s, l, r, n, &dvl, &dvr, &hvalid, &nulls));
   AHC_RETURN_NOT_OK(s->AllocatePinned((n + 7) / 8, &hbits));
   memset(hbits->hptr, 0, (size_t)((n + 7) / 8));
-  const bool null_scalar = (l.scalar && !l.scalar->valid) || (r.scalar && !r.scalar->valid);
-  if (!null_scalar) {
-    auto kernel = [&](int64_t rows, int64_t, void* b0, void* b1, void* b2) -> Status {
-      const void* lp = l.arr ? b0 : (const void*)l.scalar->value;
-      const void* rp = r.arr ? b1 : (const void*)r.scalar->value;
-      // the slot's bytes behind the last row keep whatever an earlier span left: clear the last byte's tail through a whole-byte memset
-      AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), (uint8_t*)b2 + rows / 8, 0, 8)));
-      return s->FromStatus(ah_comparison(s->ctx(), cmpop, shape, (int)t->id, lp, rp, (uint8_t*)b2, rows, 0));
-    };
-    AHC_RETURN_NOT_OK(SpanLoop(ctx, n, l.arr ? l.values() : nullptr, l.arr ? w : 0, r.arr ? r.values() : nullptr, r.arr ? w : 0, (uint8_t*)hbits->hptr, 1, 8, kernel));
-  }
+  // (a null scalar: compareKernel still compares every row with the scalar's stored value — ScalarBinary unboxes it whatever its
+  // validity, helpers.go:204-222 — so the data bitmap under the all-null validity is the whole-array path's, not zeros)
+  auto kernel = [&](int64_t rows, int64_t, void* b0, void* b1, void* b2) -> Status {
+    const void* lp = l.arr ? b0 : (const void*)l.scalar->value;
+    const void* rp = r.arr ? b1 : (const void*)r.scalar->value;
+    // the slot's bytes behind the last row keep whatever an earlier span left: clear the last byte's tail through a whole-byte memset
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), (uint8_t*)b2 + rows / 8, 0, 8)));
+    return s->FromStatus(ah_comparison(s->ctx(), cmpop, shape, (int)t->id, lp, rp, (uint8_t*)b2, rows, 0));
+  };
+  AHC_RETURN_NOT_OK(SpanLoop(ctx, n, l.arr ? l.values() : nullptr, l.arr ? w : 0, r.arr ? r.values() : nullptr, r.arr ? w : 0, (uint8_t*)hbits->hptr, 1, 8, kernel));
   *out = Datum::Of(MakeHostArray(GetDataType(Type::BOOL), n, hbits, hvalid, nulls, ""));
   return Status::OK();
 }
@@ -219,7 +225,7 @@ Status StreamFilter(ExecCtx* ctx, const FunctionOptions* opts, const std::vector
   Session* s = ctx->session;
   if (args.size() != 2 || args[0].kind != DatumKind::Array || args[1].kind != DatumKind::Array) return Status::OK();
   const ArrayData &v = *args[0].array, &f = *args[1].array;
-  if (!v.on_host || !f.on_host || f.type->id != Type::BOOL || v.type->bit_width < 8 || !(IsInteger(v.type->id) || IsFloating(v.type->id))) return Status::OK();
+  if (!v.on_host || !f.on_host || v.device_twin || f.device_twin || f.type->id != Type::BOOL || v.type->bit_width < 8 || !(IsInteger(v.type->id) || IsFloating(v.type->id))) return Status::OK();
   if (v.length != f.length) return Status::OK();   // the reference's error comes from the usual path
   const FilterOptions* fo = static_cast<const FilterOptions*>(opts);
   const int null_sel = fo ? (int)fo->NullSelection : 0;
@@ -249,8 +255,10 @@ Status StreamFilter(ExecCtx* ctx, const FunctionOptions* opts, const std::vector
 
 Status MaterializeOnDevice(Session* s, const ArrayDataPtr& host, ArrayDataPtr* out) {
   if (!host->on_host) { *out = host; return Status::OK(); }
+  if (host->device_twin) { *out = host->device_twin; return Status::OK(); }
   auto d = std::make_shared<ArrayData>(*host);
   d->on_host = false;
+  d->device_twin = nullptr;
   const int64_t nbits = host->offset + host->length;
   const int64_t vbytes = (nbits + 7) / 8;
   const int64_t dbytes = host->type->bit_width == 1 ? vbytes : nbits * (host->type->bit_width / 8);
@@ -264,7 +272,18 @@ Status MaterializeOnDevice(Session* s, const ArrayDataPtr& host, ArrayDataPtr* o
   AHC_RETURN_NOT_OK(s->Allocate(dbytes, &d->buffers[1], /*zero_all=*/false));
   if (dbytes > 0) AHC_RETURN_NOT_OK(s->FromStatus(ah_upload_async(s->ctx(), d->buffers[1]->dptr, host->buffers[1]->hptr, (size_t)dbytes)));
   AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+  host->device_twin = d;
   *out = d;
+  return Status::OK();
+}
+
+Status MaterializeAllOnDevice(Session* s, std::vector<Datum>* values) {
+  for (Datum& d : *values)
+    if (d.kind == DatumKind::Array && d.array->on_host) {
+      ArrayDataPtr dev;
+      AHC_RETURN_NOT_OK(MaterializeOnDevice(s, d.array, &dev));
+      d.array = dev;
+    }
   return Status::OK();
 }
 

@@ -3,8 +3,8 @@
 The reference's executor cuts a call into spans of at most ExecCtx.ChunkSize rows (arrow/compute/executor.go:47-50, :499
 iterateExecSpans, :658-702).  Here a column imported with ahc_import_host stays in host memory and add / sub / multiply, the
 comparisons, filter and arrow/math Sum stream it through the device span by span (upload k + 1 | kernel k | download k − 1); every
-other function uploads it whole first.  Checked against Arrow C++ (pyarrow.compute) and against this library's own whole-array path,
-value bytes and validity; then the rate of a 1 GiB pinned column against the link's, and a call whose arguments do not fit the HBM
+other function uploads it whole first.  Checked against Arrow C++ (pyarrow.compute) — logically — and against this library's own
+whole-array path byte for byte (value bytes under nulls, validity bytes with their tail bits, null count: same_bytes); then the rate of a 1 GiB pinned column against the link's, and a call whose arguments do not fit the HBM
 that is left."""
 import numpy as np
 import pytest
@@ -35,9 +35,43 @@ def column(rng, n, typ, nulls):
 
 
 def same(a, b):
+    """logical equality with Arrow C++'s result"""
     assert a.type == b.type and len(a) == len(b), (a.type, b.type, len(a), len(b))
     assert a.null_count == b.null_count
     assert a.equals(b)
+
+
+def raw(a):
+    """(value bytes of the rows, validity bytes with the last byte's tail bits, null count) of an exported array"""
+    assert a.offset == 0
+    n = len(a)
+    validity, data = a.buffers()[:2]
+    width = a.type.bit_width
+    nbytes = (n + 7) // 8 if width == 1 else n * (width // 8)
+    return (data.to_pybytes()[:nbytes] if data is not None else b"",
+            validity.to_pybytes()[:(n + 7) // 8] if validity is not None else None, a.null_count)
+
+
+def same_bytes(streamed, whole):
+    """the contract of hoststream.cc: the streamed result is the whole-array path's byte for byte — payload under nulls, the bits
+    behind the last row, and whether a validity bitmap exists at all"""
+    assert streamed.type == whole.type and len(streamed) == len(whole)
+    sv, sb, sn = raw(streamed)
+    wv, wb, wn = raw(whole)
+    assert sn == wn, (sn, wn)
+    assert (sb is None) == (wb is None), "one path allocated a validity bitmap, the other did not"
+    assert sb == wb, "validity bytes differ"
+    if sv != wv:
+        w = max(streamed.type.bit_width // 8, 1)
+        i = next(k for k in range(len(sv)) if sv[k] != wv[k]) // w
+        raise AssertionError(f"value bytes differ first at row {i}: streamed {streamed[i:i + 1]} / whole-array {whole[i:i + 1]}")
+
+
+def both(sess, name, host_args, plain_args, options=""):
+    """(streamed result, whole-array result) of one call, as pyarrow arrays"""
+    got = sess.call_function(name, host_args, options=options, keep_on_device=True)
+    assert got.on_host(), f"{name}: not streamed"
+    return got.to_arrow(), sess.call_function(name, plain_args, options=options)
 
 
 @pytest.mark.parametrize("typ", [pa.int64(), pa.float64(), pa.int32(), pa.uint16()])
@@ -58,18 +92,93 @@ def test_streamed_arithmetic(sess, name, typ):
             want = pcf(a, b)
             ha, hb = sess.import_host(a), sess.import_host(b)
             assert ha.on_host() and hb.on_host()
-            got = sess.call_function(name, [ha, hb], keep_on_device=True)
-            assert got.on_host()                                    # streamed: the result is host-resident
-            same(got.to_arrow(), want)
-            same(sess.call_function(name, [a, b]), want)            # the whole-array path gives the same
+            got, whole = both(sess, name, [ha, hb], [a, b])         # streamed: the result is host-resident
+            same(got, want)
+            same(whole, want)
+            same_bytes(got, whole)                                  # … and the whole-array path's bytes
             # array ∘ scalar and scalar ∘ array
             sc = pa.scalar(3, typ)
-            same(sess.call_function(name, [ha, sc]), pcf(a, sc))
+            got, whole = both(sess, name, [ha, sc], [a, sc])
+            same(got, pcf(a, sc))
+            same_bytes(got, whole)
             sc = pa.scalar(127, typ)
-            same(sess.call_function(name, [sc, hb]), pcf(sc, b))
+            got, whole = both(sess, name, [sc, hb], [sc, b])
+            same(got, pcf(sc, b))
+            same_bytes(got, whole)
     # a null scalar: every row null
     got = sess.call_function(name, [sess.import_host(a), pa.scalar(None, typ)])
     assert got.null_count == n
+
+
+@pytest.mark.parametrize("typ", [pa.int64(), pa.float64(), pa.int16(), pa.float32(), pa.uint8()])
+@pytest.mark.parametrize("name", ["add", "subtract", "multiply", "add_unchecked", "subtract_unchecked", "multiply_unchecked",
+                                  "greater", "equal", "less", "not_equal"])
+def test_null_scalar_payload_is_the_whole_array_paths(sess, name, typ):
+    """ScalarBinaryNotNull (checked integer add / sub) leaves the output as allocated under a null scalar
+    (kernels/helpers.go:311-314,340-343); ScalarBinary — every unchecked op, every float op, checked multiply
+    (base_arithmetic.go:273-280) and the comparisons — unboxes the scalar's stored value and computes every row under the
+    all-null validity (helpers.go:204-222).  Both paths of this library must hold the same bytes under those nulls."""
+    rng = np.random.default_rng(zlib_seed(name, typ))
+    n = 40_003                                                       # 5 spans of 8192 Int64 rows; not a multiple of 8
+    a = column(rng, n, pa.int64(), True)
+    a = pc.bit_wise_and(a, pa.scalar(15, pa.int64())).cast(typ)
+    null = pa.scalar(None, typ)
+    for args, plain in (([sess.import_host(a), null], [a, null]), ([null, sess.import_host(a)], [null, a])):
+        got, whole = both(sess, name, args, plain)
+        assert got.null_count == n and whole.null_count == n
+        same_bytes(got, whole)
+    arithmetic = name.split("_")[0] in ("add", "subtract", "multiply")
+    if arithmetic and (name.endswith("_unchecked") or pa.types.is_floating(typ) or name == "multiply"):
+        # the payload is l[i] ∘ 0 — not a block of zeros: a + 0 under the nulls
+        got = sess.call_function(name, [sess.import_host(a), null], keep_on_device=True).to_arrow()
+        vals = np.frombuffer(raw(got)[0], dtype=typ.to_pandas_dtype())
+        src = np.frombuffer(raw(a)[0], dtype=typ.to_pandas_dtype())
+        want = src * 0 if "multiply" in name else src
+        assert np.array_equal(vals, want)
+
+
+def zlib_seed(*parts):
+    import zlib
+    return zlib.crc32("/".join(str(p) for p in parts).encode())
+
+
+def test_checked_add_with_nulls_reuses_slots_without_leaking(sess):
+    """three slots serve 13 spans: under a null row the checked kernel must store the zero value (helpers.go:303-306), not what an
+    earlier span left in the slot — large payloads early, nulls late, both operands, and the rows under nulls hold values that
+    would overflow if they were tested"""
+    rng = np.random.default_rng(77)
+    n = 100_003
+    big = np.iinfo(np.int64).max
+    av = rng.integers(2**61, 2**62, n)
+    bv = rng.integers(2**61, 2**62 - 1, n)
+    am = rng.random(n) < np.linspace(0.0, 0.9, n)                     # ever more nulls towards the end
+    bm = rng.random(n) < 0.2
+    av[am] = big
+    bv[bm] = big                                                      # big + anything overflows: must stay untested
+    a, b = pa.array(av, mask=am), pa.array(bv, mask=bm)
+    for name in ("add", "subtract"):
+        got, whole = both(sess, name, [sess.import_host(a), sess.import_host(b)], [a, b])
+        same_bytes(got, whole)
+        vals = np.frombuffer(raw(got)[0], np.int64)
+        assert not vals[am | bm].any(), "payload under a null row is not the zero value"
+    got, whole = both(sess, "add", [sess.import_host(a), pa.scalar(1, pa.int64())], [a, pa.scalar(1, pa.int64())])
+    same_bytes(got, whole)
+
+
+@pytest.mark.parametrize("n", [8192 * 3, 8192 * 3 + 1, 8192 * 2 + 63, 8192 + 7, 5, 64, 65])
+def test_last_spans_tail_bits(sess, n):
+    """a comparison's data bitmap and the result's validity end inside a byte: the bits behind row n − 1 are the whole-array
+    path's (zero), whatever the slot held before"""
+    rng = np.random.default_rng(n)
+    warm = pa.array(np.full(8192 * 3, -1, np.int64))                  # leaves all-ones bitmaps in every slot
+    sess.call_function("equal", [sess.import_host(warm), sess.import_host(warm)], keep_on_device=True).release()
+    a, b = column(rng, n, pa.int64(), True), column(rng, n, pa.int64(), True)
+    for name in ("greater_equal", "not_equal", "less"):
+        got, whole = both(sess, name, [sess.import_host(a), sess.import_host(b)], [a, b])
+        same_bytes(got, whole)
+        same(got, getattr(pc, name)(a, b))
+    got, whole = both(sess, "add", [sess.import_host(a), sess.import_host(b)], [a, b])
+    same_bytes(got, whole)
 
 
 def test_streamed_checked_add_overflows(sess):
@@ -101,12 +210,16 @@ def test_streamed_comparisons(sess, name):
         a, b = a.cast(typ), b.cast(typ)
         pcf = getattr(pc, name)
         ha, hb = sess.import_host(a), sess.import_host(b)
-        got = sess.call_function(name, [ha, hb], keep_on_device=True)
-        assert got.on_host()
-        same(got.to_arrow(), pcf(a, b))
+        got, whole = both(sess, name, [ha, hb], [a, b])
+        same(got, pcf(a, b))
+        same_bytes(got, whole)
         sc = pa.scalar(2, typ)
-        same(sess.call_function(name, [ha, sc]), pcf(a, sc))
-        same(sess.call_function(name, [sc, hb]), pcf(sc, b))
+        got, whole = both(sess, name, [ha, sc], [a, sc])
+        same(got, pcf(a, sc))
+        same_bytes(got, whole)
+        got, whole = both(sess, name, [sc, hb], [sc, b])
+        same(got, pcf(sc, b))
+        same_bytes(got, whole)
 
 
 @pytest.mark.parametrize("null_sel", ["drop", "emit_null"])
@@ -119,9 +232,9 @@ def test_streamed_filter(sess, null_sel):
                 v = column(rng, n, pa.int64(), vnulls).cast(pa.float32() if typ == pa.float32() else typ, safe=False)
                 f = pa.array(rng.random(n) < 0.4, mask=(rng.random(n) < 0.1) if fnulls else None)
                 want = pc.filter(v, f, null_selection_behavior=null_sel)
-                got = sess.call_function("filter", [sess.import_host(v), sess.import_host(f)], options=f"null_selection_behavior={null_sel}", keep_on_device=True)
-                assert got.on_host()
-                same(got.to_arrow(), want)
+                got, whole = both(sess, "filter", [sess.import_host(v), sess.import_host(f)], [v, f], options=f"null_selection_behavior={null_sel}")
+                same(got, want)
+                same_bytes(got, whole)
 
 
 def test_streamed_math_sum(sess):
@@ -141,9 +254,17 @@ def test_other_functions_upload_the_column_whole(sess):
     a = column(rng, 60_000, pa.int64(), True)
     h = sess.import_host(a)
     assert h.on_host()
-    same(sess.call_function("negate", [h]), pc.negate_checked(a))      # not streamed: uploaded whole …
-    assert not h.on_host()                                               # … and device-resident from then on
-    same(sess.call_function("add", [h, h]), pc.add_checked(a, a))
+    same(sess.call_function("negate", [h]), pc.negate_checked(a))      # not streamed: uploaded whole (inside compute::CallFunction) …
+    assert not h.on_host()                                               # … and device-resident from then on (ArrayData::device_twin)
+    r = sess.call_function("add", [h, h], keep_on_device=True)
+    assert not r.on_host()                                               # the copy in HBM is used, nothing crosses the link again
+    same(r.to_arrow(), pc.add_checked(a, a))
+    assert sess.math_sum(h) == sess.math_sum(a)                        # arrow/math over the uploaded copy
+    # the expression executor takes host columns too (fused and node by node)
+    for fuse in (True, False):
+        h3 = sess.import_host(a)
+        got, _ = sess.eval_expression("add($0,$0)", [h3], fuse=fuse)
+        same(got, pc.add_checked(a, a))
     # mixed residency: the host side is uploaded
     h2 = sess.import_host(a)
     dev = sess.call_function("negate", [a], keep_on_device=True)
