@@ -153,6 +153,45 @@ struct GbStaging {
   unsigned* first;
 };
 
+// ---- group records, binned by first row (the two-level cut's finish) -------------------------------------------------------------------
+// With millions of groups the finish used to be the worst part of the call: one bit per group set by a device-scope atomic at a random
+// word of the n-bit first-occurrence bitmap (617 µs and 514 MiB of write traffic for an 8 MiB bitmap at 2^24 groups), then four 8-byte
+// stores per group to out_*[id] at a random id (1593 µs, 1.5 GiB written for 0.5 GiB of output, every store dirtying its own line).
+// A group's id is the RANK of its first row among all first rows, i.e. monotone in the first row: groups binned by first-row range
+// are binned by id range.  So the groups leave the LDS tables as 32-byte records (one whole sector per store), binned by first row
+// in two reserving scatters (coarse: 2^cshift rows, straight out of the aggregate pass; fine: 4096 rows) — a bin of R rows holds at
+// most R first rows, so every bin has a fixed place [bin·R, bin·R + count) and no histogram pass is needed — and one workgroup per
+// fine bin ranks its ≤ 4096 records with a 4096-bit bitmap in LDS and writes a contiguous id range of the four output columns.
+// The order of the records inside a bin depends on timing; nothing else does (ranks come from the bitmap).
+struct __attribute__((aligned(16))) GbRec {
+  unsigned long long key, lo, hi;   // hi: Float64 sums only
+  unsigned cnt;                     // count | NaN / ±inf flags (kCntMask)
+  unsigned first;                   // first row | kKeyNull for the null group
+};
+static_assert(sizeof(GbRec) == 32, "one record = one 32-byte sector");
+constexpr int kRecFineLog2 = 12;    // rows per fine bin: its records' ranks fit a 64-word bitmap
+constexpr int kRecMaxBins = 512;    // coarse bins, and fine bins per coarse bin: 2^(9 + 9 + 12) rows
+struct GbRecOut {
+  GbRec* recs;          // coarse bin b owns [b << cshift, (b + 1) << cshift)
+  unsigned* ccursor;    // records in each coarse bin so far
+  int cshift, ncoarse;
+};
+__device__ __forceinline__ void gb_rec_store(GbRec* __restrict__ dst, unsigned long long key, unsigned long long lo, unsigned long long hi, unsigned cnt, unsigned first) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  u64x2 a = {key, lo}, b = {hi, (unsigned long long)cnt | ((unsigned long long)first << 32)};
+  u64x2* d = reinterpret_cast<u64x2*>(dst);
+  d[0] = a;
+  d[1] = b;
+}
+__device__ __forceinline__ GbRec gb_rec_load(const GbRec* __restrict__ src) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2* p = reinterpret_cast<const u64x2*>(src);
+  const u64x2 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);
+  GbRec r;
+  r.key = a.x; r.lo = a.y; r.hi = b.x; r.cnt = (unsigned)b.y; r.first = (unsigned)(b.y >> 32);
+  return r;
+}
+
 template <bool FX>
 __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsigned long long lo, unsigned long long hi, unsigned cntflags, unsigned first) {
   if (FX) { if (lo | hi) fx_add(gt.lo, gt.hi, (size_t)s, lo, hi); }
@@ -183,7 +222,7 @@ __device__ __forceinline__ void gb_global_add(const GbTable& gt, int64_t s, unsi
 // arrays; r0 / r1 / binstart are DENSE positions and seg_vstart / seg_delta turn one into a physical position.  The row loop runs over
 // the dense positions of the whole partition as before — a step that lies inside one region (all but seven per partition) adds one
 // uniform offset to its addresses, a step across a region boundary looks its regions up lane by lane.
-template <bool FX, bool DIRECT = false, bool LEAN = false, bool SEG = false>
+template <bool FX, bool DIRECT = false, bool LEAN = false, bool SEG = false, bool RECS = false>
 __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                                  const unsigned* __restrict__ prows, const unsigned* __restrict__ binstart, int nb, GbTable gt,
                                                                  const unsigned long long* __restrict__ absmax, unsigned* __restrict__ overflow, int flat,
@@ -191,7 +230,9 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
                                                                  int64_t voff, int64_t nrows, int64_t seg_rows, unsigned* __restrict__ tile_range = nullptr,
                                                                  const unsigned long long* __restrict__ seed_keys = nullptr, unsigned seed_used = 0,
                                                                  GbStaging st = GbStaging{nullptr, nullptr, nullptr, nullptr},
-                                                                 const unsigned* __restrict__ seg_vstart = nullptr, const unsigned* __restrict__ seg_delta = nullptr) {
+                                                                 const unsigned* __restrict__ seg_vstart = nullptr, const unsigned* __restrict__ seg_delta = nullptr,
+                                                                 GbRecOut ro = GbRecOut{nullptr, nullptr, 0, 0}) {
+  // RECS (flat == 1 only): the table does not leave as a copy — its occupied slots leave as records binned by first row (GbRec above)
   // seed_keys (flat == 2 only): the key plane of an LDS table holding the keys a quick look found — EVERY workgroup starts from
   // it, so a seeded key has the same slot in all of them and their results for it are added up slot by slot afterwards
   // (gd_reduce_kernel) instead of 256 workgroups × groups × 5 atomics on one global table (0.1 ms per 1024 groups, serialised in
@@ -209,6 +250,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   __shared__ int s_part;
   __shared__ unsigned long long s_snap[2];
   __shared__ unsigned s_vs[SEG ? kGbRegions + 1 : 1], s_dl[SEG ? kGbRegions : 1];   // the current partition's regions: dense starts (+ its end), physical − dense
+  __shared__ unsigned s_ccnt[RECS ? kRecMaxBins : 1], s_cbase[RECS ? kRecMaxBins : 1];   // RECS: this table's records per coarse bin, their reserved places
   const int t = threadIdx.x;
   int part;
   bool multi;
@@ -401,6 +443,7 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   if (r0 < r1) {
   for (int j = t; j < kLSlots; j += kThreads) { l_key[j] = (DIRECT && seed_keys && j < kSlots) ? seed_keys[j] : kEmpty; l_lo[j] = 0; if (FX) l_hi[j] = 0; l_cnt[j] = 0; l_first[j] = kNoRow; }
   if (t == 0) { s_used = DIRECT && seed_keys ? seed_used : 0u; s_direct = 0; }
+  if (RECS) for (int b = t; b < kRecMaxBins; b += kThreads) s_ccnt[b] = 0;
   if (SEG) {
     if (t <= kGbRegions) s_vs[t] = seg_vstart[part * kGbRegions + t];
     if (t < kGbRegions) s_dl[t] = seg_delta[part * kGbRegions + t];
@@ -477,7 +520,28 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   if (!LEAN && p_live) flush_row(p_key, p_kw, p_lo, p_hi, p_cf, p_first);
   if (went_direct) s_direct = 1;
   __syncthreads();
-  if (!multi && !s_direct) {
+  if (RECS) {
+    // (flat == 1: always the only workgroup of its partition, and a full table voids the attempt)
+    for (int j = t; j < kLSlots; j += kThreads) {
+      const unsigned fr = l_first[j];
+      if (fr != kNoRow) atomicAdd(&s_ccnt[fr >> ro.cshift], 1u);
+    }
+    __syncthreads();
+    for (int b = t; b < ro.ncoarse; b += kThreads) {
+      const unsigned cn = s_ccnt[b];
+      s_cbase[b] = cn ? atomicAdd(&ro.ccursor[b], cn) : 0u;   // ≤ 2^cshift in all: a bin of R rows holds at most R first rows
+      s_ccnt[b] = 0;
+    }
+    __syncthreads();
+    for (int j = t; j < kLSlots; j += kThreads) {
+      const unsigned fr = l_first[j];
+      if (fr == kNoRow) continue;
+      const unsigned cb = fr >> ro.cshift;
+      const size_t pos = ((size_t)cb << ro.cshift) + s_cbase[cb] + atomicAdd(&s_ccnt[cb], 1u);
+      // the all-ones key lives in slot kSlots (its key word is the empty marker's), the null group in kSlots + 1 (key slot: the fresh buffer's zero)
+      gb_rec_store(&ro.recs[pos], j == kSlots + 1 ? 0ull : l_key[j], l_lo[j], FX ? l_hi[j] : 0ull, l_cnt[j], fr | (j == kSlots + 1 ? kKeyNull : 0u));
+    }
+  } else if (!multi && !s_direct) {
     // the only workgroup of this partition and everything is in LDS: the table leaves as it is
     for (int j = t; j < kSlots; j += kThreads) {
       gt.key[gbase + j] = l_key[j];
@@ -569,6 +633,102 @@ __global__ __launch_bounds__(kBlock) void gb_emit_kernel(GbTable gt, int64_t nsl
       out_sums[id] = __builtin_bit_cast(unsigned long long, r);
     } else {
       out_sums[id] = gt.lo[s];
+    }
+    if (out_first_rows) out_first_rows[id] = (long long)fr;
+  }
+}
+
+// the second reserving scatter: coarse bin → its fine bins of 4096 rows.  One workgroup per (coarse bin, tile of kRecTile records);
+// the grid covers every tile a full bin would have, a workgroup beyond its bin's count leaves at once.
+constexpr int kRecTile = 2048;
+__global__ __launch_bounds__(kThreads) void gbr_split_kernel(const GbRec* __restrict__ recs1, const unsigned* __restrict__ ccursor, int cshift, int fpc_log2,
+                                                             int tiles_per_coarse, GbRec* __restrict__ recs2, unsigned* __restrict__ fcursor) {
+  __shared__ unsigned s_cnt[kRecMaxBins], s_base[kRecMaxBins];
+  const int t = threadIdx.x;
+  const unsigned cb = blockIdx.x / (unsigned)tiles_per_coarse, tile = blockIdx.x % (unsigned)tiles_per_coarse;
+  const unsigned cnt = ccursor[cb], lo = tile * (unsigned)kRecTile;
+  if (lo >= cnt) return;
+  const unsigned hi = cnt - lo < (unsigned)kRecTile ? cnt : lo + (unsigned)kRecTile;
+  const int fpc = 1 << fpc_log2;
+  for (int b = t; b < fpc; b += kThreads) s_cnt[b] = 0;
+  __syncthreads();
+  constexpr int U = kRecTile / kThreads;
+  GbRec r[U];
+  unsigned fl[U], rank[U];
+  const GbRec* src = recs1 + ((size_t)cb << cshift);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const unsigned i = lo + (unsigned)(u * kThreads + t);
+    fl[u] = ~0u;
+    if (i < hi) {
+      r[u] = gb_rec_load(src + i);
+      fl[u] = ((r[u].first & kRowMask) >> kRecFineLog2) & (unsigned)(fpc - 1);
+      rank[u] = atomicAdd(&s_cnt[fl[u]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = t; b < fpc; b += kThreads) {
+    const unsigned cn = s_cnt[b];
+    if (cn) s_base[b] = atomicAdd(&fcursor[((size_t)cb << fpc_log2) + b], cn);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    if (fl[u] == ~0u) continue;
+    const size_t fb = ((size_t)cb << fpc_log2) + fl[u];
+    gb_rec_store(&recs2[(fb << kRecFineLog2) + s_base[fl[u]] + rank[u]], r[u].key, r[u].lo, r[u].hi, r[u].cnt, r[u].first);
+  }
+}
+
+// one workgroup per fine bin: rank = number of first rows below the record's own inside the bin (bitmap in LDS), id = groups of the
+// bins before (fprefix) + rank; the four output columns of the bin are one contiguous id range each
+template <bool FX>
+__global__ __launch_bounds__(256) void gbr_emit_kernel(const GbRec* __restrict__ recs2, const unsigned* __restrict__ fcursor, const int64_t* __restrict__ fprefix,
+                                                        const unsigned long long* __restrict__ absmax, unsigned long long* __restrict__ out_keys,
+                                                        unsigned long long* __restrict__ out_sums, long long* __restrict__ out_counts,
+                                                        long long* __restrict__ out_first_rows, int* __restrict__ null_id) {
+  __shared__ unsigned long long s_bits[64];
+  __shared__ unsigned s_pre[64];
+  const int t = threadIdx.x;
+  const unsigned cnt = fcursor[blockIdx.x];
+  if (!cnt) return;
+  const int64_t base = fprefix[blockIdx.x];
+  const GbRec* src = recs2 + ((size_t)blockIdx.x << kRecFineLog2);
+  if (t < 64) s_bits[t] = 0;
+  __syncthreads();
+  for (unsigned i = t; i < cnt; i += 256) {
+    const unsigned fr = src[i].first & (unsigned)((1 << kRecFineLog2) - 1);
+    atomicOr(&s_bits[fr >> 6], 1ull << (fr & 63));
+  }
+  __syncthreads();
+  if (t < 64) {
+    const unsigned pc = (unsigned)__popcll(s_bits[t]);
+    unsigned inc = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned v = __shfl_up(inc, o, 64);
+      if (t >= o) inc += v;
+    }
+    s_pre[t] = inc - pc;
+  }
+  __syncthreads();
+  int sh = 0;
+  if (FX) sh = fx_shift(*absmax);
+  for (unsigned i = t; i < cnt; i += 256) {
+    const GbRec r = gb_rec_load(src + i);
+    const unsigned fr = r.first & kRowMask, fi = fr & (unsigned)((1 << kRecFineLog2) - 1);
+    const int64_t id = base + s_pre[fi >> 6] + (unsigned)__popcll(s_bits[fi >> 6] & ((1ull << (fi & 63)) - 1));
+    out_keys[id] = r.key;
+    if (r.first & kKeyNull) *null_id = (int)id;
+    out_counts[id] = (long long)(r.cnt & kCntMask);
+    if (FX) {
+      const unsigned f = r.cnt >> 29;
+      double d;
+      if (f) d = (f & 1u) || (f & 6u) == 6u ? __builtin_nan("") : ((f & 2u) ? __builtin_inf() : -__builtin_inf());
+      else d = fx_to_double(r.lo, r.hi, sh);
+      out_sums[id] = __builtin_bit_cast(unsigned long long, d);
+    } else {
+      out_sums[id] = r.lo;
     }
     if (out_first_rows) out_first_rows[id] = (long long)fr;
   }
@@ -968,11 +1128,22 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   const int64_t P = (int64_t)1 << lp;
   const int64_t ntiles = ah_ceil_div(n, kMsTile), ngrp = ah_ceil_div(ntiles, kGroupTiles), nvt = ((ntiles + nb1 + 7) / 8) * 8;
   const unsigned grid1 = (unsigned)(((ntiles + 7) / 8) * 8);
-  const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
-  const int64_t nslots = P * kFlatStride;
-  const size_t need = pad((size_t)n * 8) * 4 + pad((size_t)n * 4) * 2 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
-                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) +
-                      pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad((size_t)nslots * 8) * 3 + pad((size_t)nslots * 4) * 2;
+  // the finish (GbRec): fine bins of 4096 rows, 2^fpc_log2 of them per coarse bin
+  const int64_t nfine_used = ah_ceil_div(n, (int64_t)1 << kRecFineLog2);
+  int fbits = 0;
+  while (((int64_t)1 << fbits) < nfine_used) fbits++;
+  const int fpc_log2 = fbits - fbits / 2, cshift = kRecFineLog2 + fpc_log2;
+  const int ncoarse = (int)ah_ceil_div(n, (int64_t)1 << cshift);
+  if (ncoarse > kRecMaxBins || (1 << fpc_log2) > kRecMaxBins) return AH_OK;   // (beyond 2^30 rows: not this path's)
+  const int64_t nfine = (int64_t)ncoarse << fpc_log2;
+  const size_t nrec = (size_t)ncoarse << cshift;                               // record places: every coarse bin whole (≥ n)
+  // the records of the coarse scatter lie over the first level's rows (free once the second level is cut), those of the fine scatter
+  // over the second level's (free once the aggregate pass has read them): 20 of the 32 bytes per place each
+  const size_t level = pad((size_t)n * 8) * 2 + pad((size_t)n * 4);
+  const size_t extra = nrec * sizeof(GbRec) > level ? pad(nrec * sizeof(GbRec) - level) : 0;
+  const size_t need = (level + extra) * 2 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
+                      pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4) +
+                      pad((size_t)nfine * 8);
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -980,10 +1151,14 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   auto take = [&](size_t b) { uint8_t* q = base + off; off += pad(b); return q; };
   unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
   unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
+  unsigned* prows = (unsigned*)take((size_t)n * 4);
+  if (extra) take(extra);
   unsigned long long* qkeys = (unsigned long long*)take((size_t)n * 8);
   unsigned long long* qvals = (unsigned long long*)take((size_t)n * 8);
-  unsigned* prows = (unsigned*)take((size_t)n * 4);
   unsigned* qrows = (unsigned*)take((size_t)n * 4);
+  if (extra) take(extra);
+  GbRec* recs1 = (GbRec*)pkeys;
+  GbRec* recs2 = (GbRec*)qkeys;
   unsigned* cnt1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
   unsigned* toffs1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
   unsigned* gsum = (unsigned*)take((size_t)ngrp * nb1 * 4);
@@ -992,16 +1167,10 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   unsigned* toffs2 = (unsigned*)take((size_t)nvt * nb2 * 4);
   unsigned* bstart = (unsigned*)take(((size_t)P + 1) * 4);
   unsigned long long* tile_max = (unsigned long long*)take((size_t)ntiles * 16);
-  unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
-  unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
-  int* tilecnt = (int*)take((size_t)nrt * 4);
-  int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
-  GbTable gt;
-  gt.key = (unsigned long long*)take((size_t)nslots * 8);
-  gt.lo = (unsigned long long*)take((size_t)nslots * 8);
-  gt.hi = (unsigned long long*)take((size_t)nslots * 8);
-  gt.cnt = (unsigned*)take((size_t)nslots * 4);
-  gt.first = (unsigned*)take((size_t)nslots * 4);
+  unsigned* ccursor = (unsigned*)take((size_t)kRecMaxBins * 4);
+  unsigned* fcursor = (unsigned*)take((size_t)nfine * 4);
+  int64_t* fprefix = (int64_t*)take((size_t)nfine * 8);
+  GbTable gt{nullptr, nullptr, nullptr, nullptr, nullptr};   // no tables: the groups leave the aggregate pass as records
   unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
   unsigned long long* total = (unsigned long long*)&c->dscalars[22];
@@ -1009,7 +1178,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
   AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
   AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  AH_HIP(c, hipMemsetAsync(ccursor, 0, pad((size_t)kRecMaxBins * 4) + (size_t)nfine * 4, c->stream));   // both cursor arrays (adjacent)
   GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
   gs_hist_kernel<GsColumns><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lp, lb2, (unsigned)(nb1 - 1), nb1, cnt1);
   AH_LAUNCH_CHECK(c);
@@ -1035,20 +1204,24 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   AH_LAUNCH_CHECK(c);
   gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
   AH_LAUNCH_CHECK(c);
-  if (is_f64) gb_aggregate_kernel<true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0);
-  else gb_aggregate_kernel<false><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0);
+  // aggregate: one workgroup per partition; its groups leave as records in the coarse bin of their first row (over p*: free now)
+  const GbRecOut ro{recs1, ccursor, cshift, ncoarse};
+  const GbStaging nost{nullptr, nullptr, nullptr, nullptr};
+  if (is_f64) gb_aggregate_kernel<true, false, false, false, true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0,
+                                                                                                           nullptr, nullptr, 0, nost, nullptr, nullptr, ro);
+  else gb_aggregate_kernel<false, false, false, false, true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0,
+                                                                                                     nullptr, nullptr, 0, nost, nullptr, nullptr, ro);
   AH_LAUNCH_CHECK(c);
-  gb_mark_kernel<<<ah_stream_grid(c, ah_ceil_div(nslots, kBlock)), kBlock, 0, c->stream>>>(gt.first, nslots, firsts);
+  // coarse → fine bins (over q*: the aggregate pass has read them), ids of each fine bin's first group, the output
+  const int tiles_per_coarse = (int)(((int64_t)1 << cshift) / kRecTile);
+  gbr_split_kernel<<<(unsigned)(ncoarse * tiles_per_coarse), kThreads, 0, c->stream>>>(recs1, ccursor, cshift, fpc_log2, tiles_per_coarse, recs2, fcursor);
   AH_LAUNCH_CHECK(c);
-  word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
+  scan_kernel<<<1, 1024, 0, c->stream>>>((const int*)fcursor, nfine, fprefix, total);
   AH_LAUNCH_CHECK(c);
-  scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
-  AH_LAUNCH_CHECK(c);
-  const unsigned egrid = ah_stream_grid(c, ah_ceil_div(nslots, kBlock));
-  if (is_f64) gb_emit_kernel<true><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                                  (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kFlatStride, kSlots);
-  else gb_emit_kernel<false><<<egrid, kBlock, 0, c->stream>>>(gt, nslots, firsts, wordprefix, tileoff, absmax, (unsigned long long*)out_keys,
-                                                            (unsigned long long*)out_sums, (long long*)out_counts, (long long*)out_first_rows, null_id, kFlatStride, kSlots);
+  if (is_f64) gbr_emit_kernel<true><<<(unsigned)nfine, 256, 0, c->stream>>>(recs2, fcursor, fprefix, absmax, (unsigned long long*)out_keys, (unsigned long long*)out_sums,
+                                                                         (long long*)out_counts, (long long*)out_first_rows, null_id);
+  else gbr_emit_kernel<false><<<(unsigned)nfine, 256, 0, c->stream>>>(recs2, fcursor, fprefix, absmax, (unsigned long long*)out_keys, (unsigned long long*)out_sums,
+                                                                   (long long*)out_counts, (long long*)out_first_rows, null_id);
   AH_LAUNCH_CHECK(c);
   { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition outgrew its LDS table: the id-based path redoes the call
