@@ -72,7 +72,7 @@ struct ah_ctx {
   unsigned scan_epoch;
   int opt_groupby_seed;    // direct group-by: 1 (default) the workgroups' LDS tables start from the quick look's keys and are added up slot by slot, 0 empty tables merged with atomics
   int opt_groupby_reserve; // partitioned group-by: 1 (default) the scatter reserves its runs in per-(partition, XCD) regions sized from the sample — no histogram pass —, 0 histogram → offsets → scatter
-  int opt_groupby_lean;    // direct group-by: 0 always keep a pending group per lane, 1 (default) leave it out when the quick look says neighbouring rows rarely share a key, 2 always leave it out
+  int opt_groupby_lean;    // direct group-by: 0 always keep a pending group per lane, 1 (default) leave it out when the quick look says neighbouring rows rarely share a key, 2 always leave it out, 3 also in the partitioned path's aggregate pass (an experiment switch: −3 % on evenly spread keys, profiles/r06_gb_lean.json; a hot key would serialise its partition's LDS atomics)
   int opt_filter_cache;    // 1: ah_filter_count leaves its tile prefixes for the fill (default on a stream of the context's own), 0: the fill recounts (default on a shared stream)
   int take_clustered_hint; // ah_take_binned_try → ah_take.hip: this call's indices looked clustered (1), not (0); option take_vec: 0 never, 1 by the sample, 2 always
   int opt_take_vec;

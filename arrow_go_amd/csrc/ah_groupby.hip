@@ -1904,7 +1904,8 @@ static int gb_cut_aggregate(ah_ctx* c, int is_f64, int lp, const unsigned* hist,
   // 1.546 against 1.563 at 2^20 — nothing, although it frees eight registers: this pass is not bound by its instruction count alone)
   const GbStaging nost{nullptr, nullptr, nullptr, nullptr};
   if (reserve) {
-    if (is_f64) gb_aggregate_kernel<true, false, false, true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows, nullptr, nullptr, 0, nost, vstart, delta);
+    if (is_f64 && c->opt_groupby_lean == 3) gb_aggregate_kernel<true, false, true, true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows, nullptr, nullptr, 0, nost, vstart, delta);
+    else if (is_f64) gb_aggregate_kernel<true, false, false, true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows, nullptr, nullptr, 0, nost, vstart, delta);
     else gb_aggregate_kernel<false, false, false, true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows, nullptr, nullptr, 0, nost, vstart, delta);
   } else {
     if (is_f64) gb_aggregate_kernel<true><<<grid, kThreads, 0, c->stream>>>(pkeys, pvals, prows, binstart, P, gt, absmax, overflow, 0, nullptr, 0, nullptr, 0, 0, seg_rows);

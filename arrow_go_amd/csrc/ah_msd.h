@@ -82,6 +82,28 @@ __global__ __launch_bounds__(kThreads) void ms_offs2_kernel(const unsigned* __re
   const int64_t vt0 = s_start[j], vt1 = vt0 + s_cnt[j];
   __syncthreads();
   const unsigned base = pstart[p];
+  if (nb <= kThreads / 2) {
+    // few digits (the two-level cuts of the group-by and the encode: 64 … 512): kThreads / nb threads per digit, each walking its own
+    // share of the parent's tiles — one thread per digit walked all of them (256 tiles at 2^26 rows and 64 parents: two dependent
+    // loops of 256 steps with 128 of the 1024 threads at work, 98 µs per call)
+    const int d = t & (nb - 1), g = t / nb, G = kThreads / nb;
+    const int64_t per = (vt1 - vt0 + G - 1) / G, a0 = vt0 + g * per, a1 = a0 + per < vt1 ? a0 + per : vt1;
+    unsigned part = 0;
+    for (int64_t vt = a0; vt < a1; vt++) part += cnt[vt * nb + d];
+    s_cnt[t] = part;
+    __syncthreads();
+    unsigned before = 0, tot = 0;   // rows of digit d in the shares before mine / in the whole parent
+    for (int gg = 0; gg < G; gg++) { const unsigned c = s_cnt[gg * nb + d]; before += gg < g ? c : 0u; tot += c; }
+    __syncthreads();
+    s_cnt[t] = t < nb ? tot : 0u;
+    __syncthreads();
+    block_excl_scan(s_cnt, s_start, s_wsum, nb);
+    unsigned run = base + s_start[d] + before;
+    if (g == 0) bstart[(int64_t)p * nb + d] = run;
+    for (int64_t vt = a0; vt < a1; vt++) { toffs[vt * nb + d] = run; run += cnt[vt * nb + d]; }
+    if (p == nparents - 1 && t == 0) bstart[(int64_t)nparents * nb] = (unsigned)n;
+    return;
+  }
   // digits t (and t + 1024 when nb = 2048): totals over the parent's tiles
   unsigned tot[2] = {0, 0};
   for (int64_t vt = vt0; vt < vt1; vt++)
