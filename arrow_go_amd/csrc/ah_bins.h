@@ -53,29 +53,49 @@ __global__ __launch_bounds__(kMaxBins) void colsum_kernel(const unsigned* __rest
 }
 // (b) one workgroup: per bin the exclusive prefix over the groups, then the exclusive prefix over the bins' totals
 //     (= binstart; binstart[nb] = nidx); gsum is overwritten with binstart[b] + prefix of the groups before
+//     mb (nullable): the largest bin's size is posted to the host's mailbox (ah_mailbox_post) — a caller that wants to see the
+//     bins' balance reads it while the passes behind this one already run
 __global__ __launch_bounds__(kMaxBins) void bin_prefix_kernel(unsigned* __restrict__ gsum, int nb, int64_t ngroups, int64_t nidx,
-                                                               unsigned* __restrict__ binstart) {
+                                                               unsigned* __restrict__ binstart, unsigned long long* mb = nullptr, unsigned long long seq = 0) {
   __shared__ unsigned s_tot[kMaxBins], s_start[kMaxBins], s_wsum[kThreads / 64];
-  const int b = threadIdx.x;
-  unsigned run = 0;
+  __shared__ unsigned s_largest;
+  const int t = threadIdx.x;
+  // kMaxBins / nb threads per bin, each walking its own share of the groups (nb = 256, 128 groups: one thread per bin walked them
+  // all, twice, with a quarter of the workgroup at work — 22 µs; nb is a power of two wherever it is below kMaxBins)
+  const int S = nb < kMaxBins && (nb & (nb - 1)) == 0 ? kMaxBins / nb : 1;
+  const int b = S > 1 ? t & (nb - 1) : t, sl = S > 1 ? t / nb : 0;
+  const int64_t per = (ngroups + S - 1) / S, g0 = sl * per, g1 = g0 + per < ngroups ? g0 + per : ngroups;
+  unsigned part = 0;
   if (b < nb) {
 #pragma unroll 8
-    for (int64_t g = 0; g < ngroups; g++) run += gsum[g * nb + b];
+    for (int64_t g = g0; g < g1; g++) part += gsum[g * nb + b];
   }
-  s_tot[b] = b < nb ? run : 0u;
+  s_tot[t] = b < nb ? part : 0u;   // [share][bin]
+  if (t == 0) s_largest = 0;
   __syncthreads();
+  unsigned run = 0, before = 0;     // the bin's total; its rows in the shares before mine
+  if (b < nb)
+    for (int q = 0; q < S; q++) { const unsigned c = s_tot[q * nb + b]; before += q < sl ? c : 0u; run += c; }
+  __syncthreads();
+  s_tot[t] = t < nb ? run : 0u;
+  __syncthreads();
+  if (mb) {
+    if (t < nb) atomicMax(&s_largest, run);
+    __syncthreads();
+    if (t == 0) { const unsigned long long w = s_largest; ah_mailbox_post(mb, seq, &w, 1); }
+  }
   block_excl_scan(s_tot, s_start, s_wsum, nb);
   if (b < nb) {
     const unsigned start = s_start[b];
-    binstart[b] = start;
-    unsigned acc = start;
-    for (int64_t g = 0; g < ngroups; g++) {
+    if (sl == 0) binstart[b] = start;
+    unsigned acc = start + before;
+    for (int64_t g = g0; g < g1; g++) {
       const unsigned c = gsum[g * nb + b];
       gsum[g * nb + b] = acc;
       acc += c;
     }
   }
-  if (b == 0) binstart[nb] = (unsigned)nidx;
+  if (t == 0) binstart[nb] = (unsigned)nidx;
 }
 // (c) inside each group: running offsets tile after tile
 __global__ __launch_bounds__(kMaxBins) void tile_offs_kernel(const unsigned* __restrict__ cnt_tm, const unsigned* __restrict__ gbase, int nb,

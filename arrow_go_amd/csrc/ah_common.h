@@ -59,6 +59,7 @@ struct ah_ctx {
   int opt_groupby_partition;   // hash + sum (ah_groupby.hip): 0 never, 1 auto, k ≥ 2 always with 2^(k−2) partitions (ARROWHIP_GROUPBY_PARTITION)
   int opt_encode_partition;    // unique / dictionary_encode (ah_hash_part.hip): 0 never, 1 auto (by the prefix's distinct count), k ≥ 3: always, 2^k partitions (ARROWHIP_ENCODE_PARTITION)
   int opt_encode_part_slots;   // measurement: LDS table size of the one-cut path (8192 default, 4096)
+  int opt_encode_early_look;   // 1 (default): calls of ≥ 2^24 rows count the first 2^16 rows' distinct keys BEFORE the global table is set up (ah_encode_first_look); 0: the look that falls out of the staged inserts
   int opt_encode_part_min;     // auto: smallest expected distinct count that takes the partition-first path (ARROWHIP_ENCODE_PART_MIN)
   int opt_hash_direct;         // unique / dictionary_encode (ah_hash.hip): 0 ids in a separate pass, 1 direct ids, 2 + LDS / re-packed table (default), 3 no re-packed table (ARROWHIP_HASH_DIRECT)
   int opt_sort_msd;            // sort_indices: 0 LSD passes only, 1 auto (ARROWHIP_SORT_MSD)
@@ -202,6 +203,8 @@ int ah_sum_short_f64(ah_ctx* ctx, const void* buf, size_t len, void* res_dev);  
 int ah_encode_partitioned_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,
                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
 // … and by two cuts, 64 parents × 2^(lp − 6) partitions (lp = 11 … 13) with LDS tables of `slots` = 4096 or 8192 entries
+// distinct valid keys among the first `rows` (≤ 2^16) rows, counted exactly without a table in HBM (ah_hash_part.hip): one launch, one polled wait
+int ah_encode_first_look(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t rows, uint64_t* distinct);
 int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,
                                int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used);
 // internal (ah_ctx.hip): 1..7 device words (8 bytes each, written by work already on the compute stream) → host, through the polled

@@ -26,6 +26,7 @@ static int ctx_init_common(ah_ctx* c) {
   AH_HIP(c, hipEventCreate(&c->t1));
   AH_HIP(c, hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
   AH_HIP(c, hipMalloc((void**)&c->dscalars, (64 + 4096) * sizeof(uint64_t)));
+  AH_HIP(c, hipMemset(c->dscalars, 0, (64 + 4096) * sizeof(uint64_t)));   // (words [33] … [36] are kept zero between calls by the kernels that use them: ah_encode_first_look, e2_offs2_kernel)
   AH_HIP(c, hipHostMalloc((void**)&c->mailbox, 128, hipHostMallocCoherent | hipHostMallocMapped));
   memset(c->mailbox, 0, 128);
   hipDeviceProp_t prop;
@@ -44,6 +45,7 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_hash_direct = env_int("ARROWHIP_HASH_DIRECT", 2);
   c->opt_encode_partition = env_int("ARROWHIP_ENCODE_PARTITION", 1);
   c->opt_encode_part_min = env_int("ARROWHIP_ENCODE_PART_MIN", 300000);
+  c->opt_encode_early_look = env_int("ARROWHIP_ENCODE_EARLY_LOOK", 1);
   c->opt_encode_part_slots = env_int("ARROWHIP_ENCODE_PART_SLOTS", 8192);
   c->opt_sort_msd = env_int("ARROWHIP_SORT_MSD", 1);
   c->opt_scan_segment_log2 = env_int("ARROWHIP_SCAN_SEGMENT_LOG2", 0);   // 0 = one segment: segments measured slower
@@ -147,6 +149,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "hash_direct")) c->opt_hash_direct = (int)value;
   else if (!strcmp(name, "encode_partition")) c->opt_encode_partition = (int)value;
   else if (!strcmp(name, "encode_part_min")) c->opt_encode_part_min = (int)value;
+  else if (!strcmp(name, "encode_early_look")) c->opt_encode_early_look = (int)value;
   else if (!strcmp(name, "encode_part_slots")) c->opt_encode_part_slots = (int)value;
   else if (!strcmp(name, "sort_msd")) c->opt_sort_msd = (int)value;
   else if (!strcmp(name, "scan_onepass")) c->opt_scan_onepass = (int)value;

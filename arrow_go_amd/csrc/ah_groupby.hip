@@ -1207,10 +1207,17 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   unsigned* overflow = (unsigned*)&c->dscalars[21];
   unsigned long long* total = (unsigned long long*)&c->dscalars[22];
   int* null_id = (int*)&c->dscalars[23];
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[20], 0, 3 * sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[28], 0, 2 * sizeof(uint64_t), c->stream));   // value range
-  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(ccursor, 0, pad((size_t)kRecMaxBins * 4) + (size_t)nfine * 4, c->stream));   // both cursor arrays (adjacent)
+  {
+    GbFill f;   // one launch: the call's scalars and both cursor arrays (adjacent)
+    f.njobs = 4;
+    f.p[0] = (uint4*)&c->dscalars[20]; f.n16[0] = 1; f.v[0] = 0u;                 // [20] unused, [21] overflow
+    f.p[1] = (uint4*)&c->dscalars[28]; f.n16[1] = 1; f.v[1] = 0u;                 // [28], [29] value range
+    f.p[2] = (uint4*)ccursor; f.n16[2] = (pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4)) / 16; f.v[2] = 0u;
+    f.p[3] = (uint4*)&c->dscalars[22]; f.n16[3] = 1; f.v[3] = 0u;                 // [22] total, [23] …
+    f.ones = (unsigned long long*)null_id;                                         // … null id: none (the last job's first word: the same thread)
+    gb_fill_kernel<<<64, 256, 0, c->stream>>>(f);
+    AH_LAUNCH_CHECK(c);
+  }
   GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
   gs_hist_kernel<GsColumns><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lp, lb2, (unsigned)(nb1 - 1), nb1, cnt1);
   AH_LAUNCH_CHECK(c);
@@ -1774,19 +1781,6 @@ static int gb_direct(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t*
   if (out_null_group) *out_null_group = (int32_t)(long long)w[2];
   *used = 1;
   return AH_OK;
-}
-
-// one launch instead of seven memsets (each ≈ 5 µs of launch on a path that is a chain of small kernels): up to 8 {address, 16-byte
-// words, 32-bit pattern} jobs, every workgroup takes its share of each
-struct GbFill { uint4* p[8]; unsigned long long n16[8]; unsigned v[8]; int njobs; unsigned long long* ones; };
-__global__ __launch_bounds__(256) void gb_fill_kernel(GbFill f) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int j = 0; j < f.njobs; j++) {
-    const uint4 w = {f.v[j], f.v[j], f.v[j], f.v[j]};
-    uint4* __restrict__ q = f.p[j];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)f.n16[j]; i += stride) q[i] = w;
-  }
-  if (f.ones && blockIdx.x == 0 && threadIdx.x == 0) *f.ones = ~0ull;   // (inside a word this thread has just filled: the last job's first)
 }
 
 // steps 1 … 4 of the partition-first group-by for 2^lp partitions.  hist (nullable): the sample's [8][1024] row counts — the

@@ -756,6 +756,43 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
   }
   // slot numbers travel through the int32 id column: the largest table (2n slots + 2) must stay below 2^32 − 1
   if (n > ((int64_t)1 << 30)) return ah_fail(c, AH_ENOTIMPL, "hash: more than 2^30 rows per call");
+  // the first look's verdict, from the distinct keys d16 among the first 2^16 rows: partitions (and how many), or *undecided (almost every
+  // row was new: the 2^21-row prefix will tell), or neither (the global table).  → AH_OK with *done = true when the partitions answered.
+  auto decide_after_look = [&](double d16, bool overflowed, bool* undecided, bool* done, bool* attempted) -> int {
+    const double hi = (double)((int64_t)1 << 16);
+    *done = false;
+    *attempted = false;
+    const double est = estimate_distinct(d16, hi, (double)n);
+    // (almost) every one of the 2^16 rows was new: ≥ 2^25 keys or so, too few repeats to say how many — the prefix below will tell
+    *undecided = !overflowed && d16 >= 0.999 * hi;
+    if (overflowed || est < (double)c->opt_encode_part_min || est > 8192.0 * 4400.0) return AH_OK;
+    int lp = 8;   // 256 … 1024 partitions of ≤ 4400 expected keys in one cut (8192-slot tables); beyond, two cuts into 2048 … 8192 of ≤ 2200 (4096-slot tables)
+    const double kpp1 = c->opt_encode_part_slots == 4096 ? 2200.0 : 4400.0;
+    while (lp < 10 && est / (double)(1 << lp) > kpp1) lp++;
+    int slots2 = 4096;
+    if (est / (double)(1 << lp) > kpp1) {
+      lp = 11;
+      while (lp < 13 && est / (double)(1 << lp) > 2200.0) lp++;
+      // 21 … 36 M keys: 8192 partitions with the large tables.  (The small ones take 3072 keys; 2600 expected leaves room for the
+      // estimate's ± 9 % at this cardinality — 128 repeats among the 2^16 sampled rows — and the partitions' own spread.)
+      if (est / (double)(1 << lp) > 2600.0) slots2 = 8192;
+    }
+    *attempted = true;
+    return try_partitioned(lp, done, slots2);
+  };
+  // Large calls look BEFORE anything is spent on the global table (ah_encode_first_look: one launch, ≈ 10 µs, against ≈ 90 µs of table
+  // fill + staged inserts + polled read): a call the partitions answer never touches the table.  Small calls (n < 2^24) keep the look
+  // that falls out of the staged inserts — it costs them nothing, and this one would cost a launch and a wait on every call.
+  bool looked = false, look_undecided = false;
+  if constexpr (K::kLdsTable) if (allow_partitioned && c->opt_encode_partition == 1 && n >= ((int64_t)1 << 24) && c->opt_encode_early_look) {
+    uint64_t d16 = 0;
+    int lrc = ah_encode_first_look(c, (const uint64_t*)keys.keys, valid, off, (int64_t)1 << 16, &d16);
+    if (lrc != AH_OK) return lrc;
+    bool done = false, attempted = false;
+    lrc = decide_after_look((double)d16, false, &look_undecided, &done, &attempted);
+    if (lrc != AH_OK || done) return lrc;
+    looked = true;   // (a void attempt left no slot numbers behind: the table has not been touched yet)
+  }
   const int64_t nwords = ah_ceil_div(n, 64);
   const int64_t ntiles = ah_ceil_div(nwords, 32);
   const uint64_t cap_max = next_pow2_u64((uint64_t)n * 2 < 64 ? 64 : (uint64_t)n * 2);
@@ -822,7 +859,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
                                                    (unsigned*)out_ids, 0u, 0u, distinct, overflow, misses);
         AH_LAUNCH_CHECK(c);
         lo = hi;
-        if (K::kLdsTable && allow_partitioned && c->opt_encode_partition == 1 && !resized && hi == ((int64_t)1 << 16) && n >= ((int64_t)1 << 22)) {
+        if (K::kLdsTable && allow_partitioned && c->opt_encode_partition == 1 && !resized && !looked && hi == ((int64_t)1 << 16) && n >= ((int64_t)1 << 22)) {
           // A first look after 2^16 rows: ≈ 3·10^5 … 4.5·10^6 expected keys are more than the LDS / re-packed tables and the caches
           // hold — cut the rows by key hash and give every partition a table in LDS (ah_hash_part.hip; ≤ 4400 expected keys per
           // partition of 256 … 1024).  2^16 rows show 2^19 evenly drawn keys with ≈ 3900 repeats (± 62): the urn model's estimate
@@ -831,30 +868,14 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
           unsigned long long look[2];   // {distinct so far, overflow flag}: polled, not synchronised — this look is on every large call's path
           if ((rc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[4], 2, look)) != AH_OK) return rc;
           c->pinned[0] = look[0]; c->pinned[1] = look[1];
-          const double d16 = (double)*(volatile uint64_t*)&c->pinned[0];
-          const double est = estimate_distinct(d16, (double)hi, (double)n);
-          // (almost) every one of the 2^16 rows was new: ≥ 2^25 keys or so, too few repeats to say how many — the prefix below will tell
-          part_undecided = *(volatile unsigned*)&c->pinned[1] == 0 && d16 >= 0.999 * (double)hi;
-          if (*(volatile unsigned*)&c->pinned[1] == 0 && est >= (double)c->opt_encode_part_min && est <= 8192.0 * 4400.0) {
-            int lp = 8;   // 256 … 1024 partitions of ≤ 4400 expected keys in one cut (8192-slot tables); beyond, two cuts into 2048 … 8192 of ≤ 2200 (4096-slot tables)
-            const double kpp1 = c->opt_encode_part_slots == 4096 ? 2200.0 : 4400.0;
-            while (lp < 10 && est / (double)(1 << lp) > kpp1) lp++;
-            int slots2 = 4096;
-            if (est / (double)(1 << lp) > kpp1) {
-              lp = 11;
-              while (lp < 13 && est / (double)(1 << lp) > 2200.0) lp++;
-              // 21 … 36 M keys: 8192 partitions with the large tables.  (The small ones take 3072 keys; 2600 expected leaves room for the
-              // estimate's ± 9 % at this cardinality — 128 repeats among the 2^16 sampled rows — and the partitions' own spread.)
-              if (est / (double)(1 << lp) > 2600.0) slots2 = 8192;
-            }
-            bool done;
-            int prc = try_partitioned(lp, &done, slots2);
-            if (prc != AH_OK || done) return prc;
-            if ((prc = restore_slot_numbers(hi)) != AH_OK) return prc;
-          }
+          bool done, attempted;
+          int prc = decide_after_look((double)look[0], (unsigned)look[1] != 0, &part_undecided, &done, &attempted);
+          if (prc != AH_OK || done) return prc;
+          if (attempted && (prc = restore_slot_numbers(hi)) != AH_OK) return prc;
         }
       }
     }
+    if (looked && !resized) part_undecided = look_undecided;
     bool restart = false, small = false, direct = false, compact = false;
     uint64_t d0 = 0;
     if (prefix < n && cap < cap_max) {

@@ -543,10 +543,15 @@ __global__ __launch_bounds__(kThreads) void e2_hist_kernel(const unsigned long l
 // after the other (343 µs at 2^26 rows).  Here thread (slice s, digit d) takes a contiguous slice of the parent's tiles,
 // S = 1024 / nb slices per digit; slice totals meet in LDS, one scan, then every thread walks its own slice once more.
 __global__ __launch_bounds__(kThreads) void e2_offs2_kernel(const unsigned* __restrict__ cnt, const unsigned* __restrict__ pstart, int nparents, int nb,
-                                                             unsigned* __restrict__ toffs, unsigned* __restrict__ bstart, int64_t n) {
+                                                             unsigned* __restrict__ toffs, unsigned* __restrict__ bstart, int64_t n,
+                                                             unsigned* __restrict__ largest, unsigned* __restrict__ done, unsigned long long* mb, unsigned long long seq) {
+  // largest / done: two device words, zero on entry and left zero — the largest final partition's size goes to the host's mailbox
+  // from the last workgroup to finish (the host looks at the partitions' balance while the scatter behind this kernel already runs)
   __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_wsum[kThreads / 64];
   __shared__ unsigned s_part[kThreads];   // [slice][digit] totals
+  __shared__ unsigned s_largest;
   const int t = threadIdx.x, p = blockIdx.x;
+  if (t == 0) s_largest = 0;
   unsigned tiles = 0;
   if (t < nparents) { const int q = ms_parent_of(t, nparents); tiles = (pstart[q + 1] - pstart[q] + kMsTile - 1) / kMsTile; }
   s_cnt[t] = tiles;
@@ -565,8 +570,19 @@ __global__ __launch_bounds__(kThreads) void e2_offs2_kernel(const unsigned* __re
   unsigned dtot = 0;
   if (t < nb) for (int q = 0; q < S; q++) dtot += s_part[q * nb + t];
   s_cnt[t] = t < nb ? dtot : 0u;
+  if (t < nb && dtot) atomicMax(&s_largest, dtot);
   __syncthreads();
   block_excl_scan(s_cnt, s_start, s_wsum, nb);
+  if (t == 0) {
+    atomicMax(largest, s_largest);
+    __threadfence();
+    if (atomicAdd(done, 1u) == gridDim.x - 1u) {
+      __threadfence();
+      const unsigned long long w = __hip_atomic_exchange(largest, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ah_mailbox_post(mb, seq, &w, 1);
+    }
+  }
   const unsigned base = pstart[p];
   if (t < nb) bstart[(int64_t)p * nb + t] = base + s_start[t];
   // this thread's running offset = parent start + smaller digits + this digit in earlier slices
@@ -807,6 +823,82 @@ __global__ __launch_bounds__(kThreads) void e2_unpermute_group_kernel(const int*
 // Called by encode_core (ah_hash.hip) for 8-byte keys.  lp = log2 of the number of partitions (8 … 10).  *used = 1: out_* hold the
 // result; 0: not applicable or the attempt was void (a partition outgrew its table, or one partition holds several times its
 // share of the rows) — nothing the caller owns was touched except out_ids / out_dict / out_first_rows, which it rewrites.
+// ---- the first look: distinct keys among the first rows, exactly, in one launch ---------------------------------------------------
+// What decides "global table or partitions, and how many" is the number of distinct keys among the first 2^16 rows (the urn model
+// turns it into the column's expected cardinality, ah_hash.hip).  The global-table path gets that number as a by-product of its
+// staged inserts — behind a table fill of tens of MiB, two insert launches and a polled read, ≈ 90 µs that a call which then goes to
+// the partitions has spent for nothing (2^20 keys in 2^26 rows: 1.198 ms with the look, 1.105 with the partition count forced,
+// profiles/r05_bench_encode_part.json).  This kernel counts the same thing without a table in HBM: kLookWgs workgroups each read all
+// `rows` keys (512 KiB out of L2), keep the 1 / kLookWgs of them whose hash names the workgroup, and count those exactly in an LDS set;
+// the last workgroup to finish posts the total to the host's mailbox.  The count must be exact: at 2^24 keys the 2^16 rows hold
+// ≈ 128 repeats, and a linear-counting bitmap that fits LDS is off by ± 43.
+namespace {
+constexpr int kLookWgs = 64, kLookSlots = 4096;   // ≤ 2^16 rows: 1024 ± 32 keys per workgroup; keys that find no room count as new ("too many to tell")
+__global__ __launch_bounds__(kThreads) void enc_look_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off, int64_t rows,
+                                                            unsigned long long* __restrict__ acc, unsigned* __restrict__ done, unsigned long long* mb,
+                                                            unsigned long long seq) {
+  __shared__ unsigned long long l_key[kLookSlots];
+  __shared__ unsigned s_new, s_last, s_ones;
+  const int t = threadIdx.x;
+  for (int j = t; j < kLookSlots; j += kThreads) l_key[j] = kEmpty;
+  if (t == 0) { s_new = 0; s_ones = 0; }
+  __syncthreads();
+  unsigned mine = 0;
+  constexpr int U = 16;   // loads in flight per lane: the pass is four round trips to L2 long (U = 4: sixteen, 32 µs)
+  for (int64_t b = 0; b < rows; b += (int64_t)kThreads * U) {
+    unsigned long long k[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const int64_t i = b + u * kThreads + t; k[u] = i < rows ? keys[i] : 0ull; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = b + u * kThreads + t;
+      if (i >= rows || !ah_bit(valid, off + i)) continue;
+      // a 32-bit hash (two quarter-rate multiplies): every workgroup hashes ALL the rows, and with the 64-bit mixer of the partition
+      // passes that was the whole kernel (32 µs: 64 × 2^16 × two 64-bit multiplies)
+      const unsigned m = ((unsigned)k[u] ^ ((unsigned)(k[u] >> 32) * 0x9E3779B1u)) * 0x85EBCA6Bu;
+      if ((m >> 26) != blockIdx.x) continue;   // kLookWgs = 64: the top six bits
+      if (k[u] == kEmpty) { if (atomicExch(&s_ones, 1u) == 0u) mine++; continue; }   // the all-ones key is the set's empty marker: counted on the side
+      unsigned j = (m >> 10) & (unsigned)(kLookSlots - 1);
+      bool placed = false;
+      for (int probes = 0; probes < kLookSlots && !placed; probes++) {
+        unsigned long long cur = l_key[j];
+        if (cur == kEmpty) cur = atomicCAS(&l_key[j], kEmpty, k[u]);
+        if (cur == kEmpty) { mine++; placed = true; }
+        else if (cur == k[u]) placed = true;
+        j = (j + 1) & (unsigned)(kLookSlots - 1);
+      }
+      if (!placed) mine++;
+    }
+  }
+  if (mine) atomicAdd(&s_new, mine);
+  __syncthreads();
+  if (t == 0) {
+    atomicAdd(acc, (unsigned long long)s_new);
+    __threadfence();
+    s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
+    if (s_last) {
+      __threadfence();
+      const unsigned long long w = __hip_atomic_exchange(acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // both words are left zero for the next call
+      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ah_mailbox_post(mb, seq, &w, 1);
+    }
+  }
+}
+
+}  // namespace
+// distinct valid keys among the first `rows` (≤ 2^16) rows → *distinct.  One launch and a polled wait.
+int ah_encode_first_look(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t rows, uint64_t* distinct) {
+  unsigned long long* acc = (unsigned long long*)&c->dscalars[33];   // [33] the count, [34] the workgroups that have finished: zero on entry, zeroed again by the last workgroup
+  unsigned long long *mb, seq, w;
+  int rc = ah_mailbox_begin(c, &mb, &seq);
+  if (rc != AH_OK) return rc;
+  enc_look_kernel<<<kLookWgs, kThreads, 0, c->stream>>>((const unsigned long long*)keys, valid, off, rows, acc, (unsigned*)&c->dscalars[34], mb, seq);
+  AH_LAUNCH_CHECK(c);
+  if ((rc = ah_mailbox_wait(c, seq, 1, &w)) != AH_OK) return rc;
+  *distinct = (uint64_t)w;
+  return AH_OK;
+}
+
 int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* valid, int64_t off, int64_t n, int encode_nulls, int lp, int slots,
                               int32_t* out_ids, uint64_t* out_dict, int64_t* out_first_rows, int64_t* out_ndict, int32_t* out_null_id, int* used) {
   *used = 0;
@@ -841,9 +933,15 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   unsigned* overflow = (unsigned*)&c->dscalars[30];
   unsigned long long* total = (unsigned long long*)&c->dscalars[31];
   int* null_id = (int*)&c->dscalars[32];
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[30], 0, 2 * sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  {
+    GbFill f;   // one launch where three memsets were (≈ 4 µs of gap each)
+    f.njobs = 2;
+    f.p[0] = (uint4*)&c->dscalars[30]; f.n16[0] = 1; f.v[0] = 0u;                 // [30] overflow, [31] total
+    f.ones = (unsigned long long*)null_id;                                         // [32] null id: none
+    f.p[1] = (uint4*)firsts; f.n16[1] = pad((size_t)nwords * 8) / 16; f.v[1] = 0u;
+    gb_fill_kernel<<<(unsigned)(c->num_cu * 2), 256, 0, c->stream>>>(f);
+    AH_LAUNCH_CHECK(c);
+  }
   const unsigned long long* k64 = (const unsigned long long*)keys;
   // ---- 1, 2: cut
   const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
@@ -851,21 +949,20 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   AH_LAUNCH_CHECK(c);
   colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, P, ntiles, gsum);
   AH_LAUNCH_CHECK(c);
-  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, P, ngrp, n, binstart);
+  // one workgroup per partition is only as fast as the largest partition: the sizes are looked at before the tables are built — through
+  // the mailbox, posted by the prefix kernel itself and read while the offsets and the scatter are already running (a copy of
+  // binstart + a stream synchronisation left the device idle for ≈ 15 µs on every call; a lopsided column now costs a scatter
+  // that nobody reads, and such columns rarely get here: the first look sends them to the global table)
+  unsigned long long *mb, seq, largest = 0;
+  if ((rc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return rc;
+  bin_prefix_kernel<<<1, kMaxBins, 0, c->stream>>>(gsum, P, ngrp, n, binstart, mb, seq);
   AH_LAUNCH_CHECK(c);
   tile_offs_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt_tm, gsum, P, ntiles, toffs);
   AH_LAUNCH_CHECK(c);
-  {
-    // one workgroup per partition is only as fast as the largest partition: look at the sizes before anything else is spent
-    std::vector<unsigned> bs((size_t)P + 1);
-    AH_HIP(c, hipMemcpyAsync(bs.data(), binstart, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
-    unsigned mx = 0;
-    for (int p = 0; p < P; p++) mx = bs[p + 1] - bs[p] > mx ? bs[p + 1] - bs[p] : mx;
-    if ((int64_t)mx * P > 3 * n && mx > (1u << 16)) return AH_OK;
-  }
   gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lp, P, ntiles, toffs, pkeys, nullptr, prows, nullptr);
   AH_LAUNCH_CHECK(c);
+  if ((rc = ah_mailbox_wait(c, seq, 1, &largest)) != AH_OK) return rc;
+  if ((int64_t)largest * P > 3 * n && largest > (1u << 16)) return AH_OK;
   // ---- 3: tables
   // (measured at 2^26 rows: from 2^22 keys on — 1024 partitions — the compaction wins; below, the slots' few scattered stores are cheaper than its pass)
   const bool compact = c->opt_encode_dict_compact >= 2 || (c->opt_encode_dict_compact == 1 && lp >= 10);
@@ -942,9 +1039,15 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   unsigned* overflow = (unsigned*)&c->dscalars[30];
   unsigned long long* total = (unsigned long long*)&c->dscalars[31];
   int* null_id = (int*)&c->dscalars[32];
-  AH_HIP(c, hipMemsetAsync(&c->dscalars[30], 0, 2 * sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(null_id, 0xFF, sizeof(uint64_t), c->stream));
-  AH_HIP(c, hipMemsetAsync(firsts, 0, (size_t)nwords * 8, c->stream));
+  {
+    GbFill f;   // one launch where three memsets were (≈ 4 µs of gap each)
+    f.njobs = 2;
+    f.p[0] = (uint4*)&c->dscalars[30]; f.n16[0] = 1; f.v[0] = 0u;                 // [30] overflow, [31] total
+    f.ones = (unsigned long long*)null_id;                                         // [32] null id: none
+    f.p[1] = (uint4*)firsts; f.n16[1] = pad((size_t)nwords * 8) / 16; f.v[1] = 0u;
+    gb_fill_kernel<<<(unsigned)(c->num_cu * 2), 256, 0, c->stream>>>(f);
+    AH_LAUNCH_CHECK(c);
+  }
   const unsigned long long* k64 = (const unsigned long long*)keys;
   // ---- level 1: 64 parents by the top 6 bits of the key hash
   const unsigned tgrid = (unsigned)(((ntiles + 7) / 8) * 8);
@@ -961,18 +1064,15 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   // ---- level 2: every parent into 2^lb2 partitions
   e2_hist_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, cnt2);
   AH_LAUNCH_CHECK(c);
-  e2_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
+  // (the partitions' balance: posted by the offsets kernel, read while the scatter runs — see ah_encode_partitioned_try)
+  unsigned long long *mb, seq, largest = 0;
+  if ((rc = ah_mailbox_begin(c, &mb, &seq)) != AH_OK) return rc;
+  e2_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n, (unsigned*)&c->dscalars[35], (unsigned*)&c->dscalars[36], mb, seq);
   AH_LAUNCH_CHECK(c);
-  {
-    std::vector<unsigned> bs((size_t)P + 1);
-    AH_HIP(c, hipMemcpyAsync(bs.data(), bstart, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    AH_HIP(c, hipStreamSynchronize(c->stream));
-    unsigned mx = 0;
-    for (int64_t p = 0; p < P; p++) mx = bs[p + 1] - bs[p] > mx ? bs[p + 1] - bs[p] : mx;
-    if ((int64_t)mx * P > 3 * n && mx > (1u << 16)) return AH_OK;   // a key that owns a large share of the rows: the other path
-  }
   e2_scatter_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, toffs2, pkeys2, prows2, pj2);
   AH_LAUNCH_CHECK(c);
+  if ((rc = ah_mailbox_wait(c, seq, 1, &largest)) != AH_OK) return rc;
+  if ((int64_t)largest * P > 3 * n && largest > (1u << 16)) return AH_OK;   // a key that owns a large share of the rows: the other path
   // ---- tables, ranks, ids: as in the one-level path, one workgroup per final partition
   const bool compact = c->opt_encode_dict_compact >= 1;
   unsigned long long* tab_key_out = compact ? nullptr : tab_key;
