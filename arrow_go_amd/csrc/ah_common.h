@@ -211,6 +211,7 @@ int ah_encode_partitioned2_try(ah_ctx* ctx, const uint64_t* keys, const uint8_t*
 // mailbox — a cheaper "I need this number before I go on" than a copy + stream synchronisation.  Everything enqueued before it has
 // completed when it returns, like a synchronisation of the stream up to that point.
 int ah_compact_u64_by_bits(ah_ctx* ctx, const uint64_t* values, const uint8_t* bits, int64_t n, uint64_t* out_values, int64_t* out_rows);   // ah_filter.hip
+int ah_check_stall(ah_ctx* ctx);   // AH_EHIP if a kernel reported a stalled look-back since the last check (ah_ctx.hip)
 int ah_mailbox_read(ah_ctx* ctx, const unsigned long long* dev_words, int nwords, unsigned long long* out_host);
 int ah_mailbox_begin(ah_ctx* ctx, unsigned long long** mb_out, unsigned long long* seq_out);
 int ah_mailbox_wait(ah_ctx* ctx, unsigned long long seq, int nwords, unsigned long long* out_host);

@@ -27,8 +27,8 @@ static int ctx_init_common(ah_ctx* c) {
   AH_HIP(c, hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
   AH_HIP(c, hipMalloc((void**)&c->dscalars, (64 + 4096) * sizeof(uint64_t)));
   AH_HIP(c, hipMemset(c->dscalars, 0, (64 + 4096) * sizeof(uint64_t)));   // (words [33] … [36] are kept zero between calls by the kernels that use them: ah_encode_first_look, e2_offs2_kernel)
-  AH_HIP(c, hipHostMalloc((void**)&c->mailbox, 128, hipHostMallocCoherent | hipHostMallocMapped));
-  memset(c->mailbox, 0, 128);
+  AH_HIP(c, hipHostMalloc((void**)&c->mailbox, 256, hipHostMallocCoherent | hipHostMallocMapped));   // [0..7] filter_count, [8..15] ah_mailbox_*, [16] stall reports (ah_scan.hip)
+  memset(c->mailbox, 0, 256);
   hipDeviceProp_t prop;
   AH_HIP(c, hipGetDeviceProperties(&prop, c->device));
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -392,11 +392,18 @@ AH_EXPORT int ah_copy_async(ah_ctx* c, void* dst, const void* src, size_t nbytes
   return AH_OK;
 }
 
+// a kernel that gave up waiting for another workgroup (the one-pass scans' bounded look-back) says so in host-coherent memory
+int ah_check_stall(ah_ctx* c) {
+  if (!c->mailbox || !__atomic_load_n(&c->mailbox[16], __ATOMIC_ACQUIRE)) return AH_OK;
+  __atomic_store_n(&c->mailbox[16], 0ull, __ATOMIC_RELAXED);
+  return ah_fail(c, AH_EHIP, "cumulative_sum: a tile's look-back gave up waiting for a predecessor (results of that call are invalid)");
+}
+
 AH_EXPORT int ah_sync(ah_ctx* c) {
   AH_ENTER_KEEP(c);
   AH_HIP(c, hipStreamSynchronize(c->copy_stream));
   AH_HIP(c, hipStreamSynchronize(c->stream));
-  return AH_OK;
+  return ah_check_stall(c);
 }
 
 AH_EXPORT int ah_timer_start(ah_ctx* c) {

@@ -506,6 +506,11 @@ template <typename E> __device__ __forceinline__ E op_bit_mask(unsigned bits, in
 constexpr int kOpThreads = 1024;
 constexpr int kOpVpt = 8;                 // 16-byte vectors per lane: 128 KiB tiles
 constexpr int kOpRecWords = 4;            // per tile: {aggregate lo, hi, inclusive lo, hi}
+constexpr unsigned kOpSpinLimit = 1u << 22;   // polls of one record (each ≥ 64 clocks of s_sleep + two L2-bypassing loads ≈ 0.3 µs): about a second
+// a look-back that gave up: one word of host-coherent memory (ah_ctx::mailbox[16]) the host reads at its next synchronisation
+__device__ __forceinline__ void op_report_stall(unsigned long long* stall) {
+  if (stall) __hip_atomic_store(stall, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void op_rec_store(u64* rec, unsigned marker, u64 v) {
   __hip_atomic_store(&rec[0], ((u64)marker << 32) | (v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&rec[1], ((u64)marker << 32) | (v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -575,7 +580,7 @@ template <typename E, bool NULLS = false, bool CHECKED = false, bool SIGNED = fa
 __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_onepass_kernel(
     const E* __restrict__ in, E* __restrict__ out, int64_t n, E start, u64* __restrict__ recs, unsigned* __restrict__ ticket, unsigned ticket_base, unsigned epoch,
     const uint8_t* __restrict__ valid = nullptr, int64_t off = 0, int64_t limit = 0, unsigned* __restrict__ overflow = nullptr,
-    uint8_t* __restrict__ out_valid = nullptr, unsigned long long* __restrict__ valid_count = nullptr) {
+    uint8_t* __restrict__ out_valid = nullptr, unsigned long long* __restrict__ valid_count = nullptr, unsigned long long* stall = nullptr) {
   constexpr int V = 16 / sizeof(E);
   typedef E EV __attribute__((ext_vector_type(V)));
   constexpr int TILE = kOpThreads * kOpVpt * V;   // rows
@@ -660,9 +665,13 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           int kind = 0;   // 0 before tile 0, 1 aggregate, 2 inclusive
           if (p >= 0) {
             const u64* r = recs + (size_t)p * kOpRecWords;
-            for (;;) {
+            for (unsigned spins = 0;; spins++) {
               if (op_rec_load(r + 2, m_inc, &v)) { kind = 2; break; }
               if (op_rec_load(r, m_agg, &v)) { kind = 1; break; }
+              // Ticket order means the predecessor's workgroup is running: it reports within microseconds.  One that never does (it
+              // faulted; the record array was overwritten) must not hang the device: after ≈ a second of polling the stall is reported
+              // to the host (checked at the call's own synchronisation and by ah_sync) and the look-back goes on with what it has.
+              if (spins >= kOpSpinLimit) { op_report_stall(stall); v = 0; kind = 2; break; }
               __builtin_amdgcn_s_sleep(1);
             }
           }
@@ -717,14 +726,170 @@ __global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4
   }
 }
 
-// mode: bit 0 nulls (valid / limit), bit 1 checked, bit 2 signed (checked only)
-template <typename E>
-int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, int mode = 0, const uint8_t* valid = nullptr, int64_t off = 0, int64_t limit = 0,
-                uint8_t* out_valid = nullptr) {
-  constexpr int TILE = kOpThreads * kOpVpt * (16 / (int)sizeof(E));
-  const int64_t ntiles = ah_ceil_div(n, (int64_t)TILE);
-  const size_t need = (size_t)ntiles * kOpRecWords * 8 + 64;
-  if (need > c->scan_recs_bytes) {   // the context's own record array: only this kernel writes it, so every stale word carries an older epoch
+// ---- ONE pass for Float64 sums: the same tiles, a look-back whose GROUPING is fixed ------------------------------------------------
+// Float additions do not associate, so the integer kernel's look-back — "add whatever aggregates and prefixes the predecessors have
+// published so far" — would give results that depend on timing.  Here every tile's prefix is ONE fixed expression of tile totals:
+//     tiles come in blocks of 64 and super blocks of 4096;   B_k = tree(T of block k's 64 tiles);   S_j = S_(j−1) + tree(B of super block j);
+//     prefix(t) = (S_(super before t) + tree(B of the blocks before t's in its super block)) + tree(T of the tiles before t in its block)
+// where tree() is a fixed 64-lane shuffle reduction with +0 in the empty lanes, T a tile's total from the fixed in-tile tree.  A tile
+// publishes T as soon as it has it; the last tile of a block publishes B; the last tile of a super block publishes S.  Nobody waits
+// for a PREFIX of a neighbour (only the super-block chain does: one hop per 2^26 rows), so the hand-offs are as short as the integer
+// kernel's, and the bytes are a function of the input alone.  24 → 16 bytes moved per row.
+// Not handled here (they keep reduce-then-scan): nulls, Float32 (its accumulator is double: half a tile's registers more).
+constexpr int kOpFBlk = 64, kOpFSup = kOpFBlk * 64;
+__device__ __forceinline__ double op_f64_dpp_add(double v, u64 moved) { return v + __builtin_bit_cast(double, moved); }
+__device__ __forceinline__ double wave_incl_scan_dpp_f64(double v) {   // lanes without a source add +0
+  v = op_f64_dpp_add(v, dpp_move<0x111, 0xF>(__builtin_bit_cast(u64, v)));
+  v = op_f64_dpp_add(v, dpp_move<0x112, 0xF>(__builtin_bit_cast(u64, v)));
+  v = op_f64_dpp_add(v, dpp_move<0x114, 0xF>(__builtin_bit_cast(u64, v)));
+  v = op_f64_dpp_add(v, dpp_move<0x118, 0xF>(__builtin_bit_cast(u64, v)));
+  v = op_f64_dpp_add(v, dpp_move<0x142, 0xA>(__builtin_bit_cast(u64, v)));
+  v = op_f64_dpp_add(v, dpp_move<0x143, 0xC>(__builtin_bit_cast(u64, v)));
+  return v;
+}
+__device__ __forceinline__ double wave_tree_sum_f64(double v) {   // every lane takes part (empty ones hold +0); the total in lane 0
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return __shfl(v, 0, 64);
+}
+// the record at `rec` once it carries `marker` (bounded: see the integer kernel)
+__device__ __forceinline__ double op_rec_wait_f64(const u64* rec, unsigned marker, unsigned long long* stall) {
+  u64 v = 0;
+  for (unsigned spins = 0;; spins++) {
+    if (op_rec_load(rec, marker, &v)) break;
+    if (spins >= kOpSpinLimit) { op_report_stall(stall); v = 0; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return __builtin_bit_cast(double, v);
+}
+__global__ __launch_bounds__(kOpThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_onepass_f64_kernel(
+    const double* __restrict__ in, double* __restrict__ out, int64_t n, double start, u64* __restrict__ recs, u64* __restrict__ super_recs,
+    unsigned* __restrict__ ticket, unsigned epoch, unsigned long long* __restrict__ first_nf, unsigned long long* stall) {
+  constexpr int V = 2;
+  typedef double DV __attribute__((ext_vector_type(2)));
+  constexpr int TILE = kOpThreads * kOpVpt * V;   // rows
+  __shared__ double s_wave[kOpThreads / 64];
+  __shared__ double s_prefix;
+  __shared__ unsigned s_tile;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const unsigned m_agg = epoch * 4u + 1u, m_blk = epoch * 4u + 2u, m_sup = epoch * 4u + 3u;
+  const int64_t ntiles = (n + TILE - 1) / TILE;
+  for (;;) {
+    if (t == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int64_t tile = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)s_tile);
+    if (tile >= ntiles) break;
+    const int64_t wbase = tile * TILE + (int64_t)wave * (64 * kOpVpt * V);
+    DV x[kOpVpt];
+    const int lane_rows = (int)(n - wbase < (int64_t)(64 * kOpVpt * V) ? (n - wbase < 0 ? 0 : n - wbase) : (int64_t)(64 * kOpVpt * V)) - lane * V;
+    const int kfull = lane_rows >= V ? (lane_rows - V) / (64 * V) + 1 : 0;
+    if (wbase + 64 * kOpVpt * V <= n) {
+      const DV* src = (const DV*)(in + wbase) + lane;
+#pragma unroll
+      for (int k = 0; k < kOpVpt; k++) x[k] = __builtin_nontemporal_load(src + k * 64);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kOpVpt; k++) {
+        const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
+        if (e + V <= n) x[k] = __builtin_nontemporal_load((const DV*)(in + e));
+        else {
+#pragma unroll
+          for (int j = 0; j < V; j++) x[k][j] = e + j < n ? in[e + j] : 0.0;
+        }
+      }
+    }
+    // x[k] becomes the inclusive prefix of its rows inside the wave's chunk, in place.  Exclusive prefixes come from a shift of the
+    // inclusive ones, never from a subtraction (inf − inf)
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < kOpVpt; k++) {
+      x[k][1] += x[k][0];
+      const double inc = wave_incl_scan_dpp_f64(x[k][1]);
+      double ex = __builtin_bit_cast(double, dpp_move<0x138, 0xF>(__builtin_bit_cast(u64, inc)));   // wave_shr:1
+      if (lane == 0) ex = 0.0;
+      const double pre = run + ex;
+      run += __builtin_bit_cast(double, read_lane63(__builtin_bit_cast(u64, inc)));
+      x[k][0] += pre;
+      x[k][1] += pre;
+    }
+    if (lane == 0) s_wave[wave] = run;
+    __syncthreads();
+    double wpre = 0.0, total = 0.0;
+#pragma unroll
+    for (int w = 0; w < kOpThreads / 64; w++) { const double v = s_wave[w]; if (w < wave) wpre += v; total += v; }
+    if (wave == 0) {
+      u64* mine = recs + (size_t)tile * kOpRecWords;
+      if (lane == 0) op_rec_store(mine, m_agg, __builtin_bit_cast(u64, total));
+      const int64_t blk0 = tile & ~(int64_t)(kOpFBlk - 1), sup0 = tile & ~(int64_t)(kOpFSup - 1);
+      const int in_blk = (int)(tile - blk0), blks = (int)((blk0 - sup0) / kOpFBlk);
+      // the tiles before mine in my block (mine too in lane in_blk: the block's total, should I be its last tile)
+      double tv = 0.0;
+      if (lane < in_blk) tv = op_rec_wait_f64(recs + (size_t)(blk0 + lane) * kOpRecWords, m_agg, stall);
+      const double tiles_before = wave_tree_sum_f64(tv);
+      // the blocks before mine in my super block
+      double bv = 0.0;
+      if (lane < blks) bv = op_rec_wait_f64(recs + (size_t)(sup0 + (int64_t)lane * kOpFBlk + kOpFBlk - 1) * kOpRecWords + 2, m_blk, stall);
+      const double blocks_before = wave_tree_sum_f64(bv);
+      double sup = start;
+      if (sup0 > 0) sup = op_rec_wait_f64(super_recs + (size_t)(sup0 / kOpFSup - 1) * 2, m_sup, stall);   // (uniform: every lane polls the same words)
+      const double excl = (sup + blocks_before) + tiles_before;
+      if (in_blk == kOpFBlk - 1) {
+        const double bsum = wave_tree_sum_f64(lane == in_blk ? total : tv);
+        if (lane == 0) op_rec_store(mine + 2, m_blk, __builtin_bit_cast(u64, bsum));
+        if (tile - sup0 == kOpFSup - 1) {
+          const double ssum = wave_tree_sum_f64(lane == blks ? bsum : bv);
+          if (lane == 0) op_rec_store(super_recs + (size_t)(sup0 / kOpFSup) * 2, m_sup, __builtin_bit_cast(u64, sup + ssum));
+        }
+      }
+      if (lane == 0) s_prefix = excl;
+    }
+    __syncthreads();
+    const double base = s_prefix + wpre;
+    unsigned bad = 0;   // bit k·V + j: the running sum of that row is not finite
+#pragma unroll
+    for (int k = 0; k < kOpVpt; k++) {
+      const int64_t e = wbase + ((int64_t)k * 64 + lane) * V;
+      x[k][0] += base;
+      x[k][1] += base;
+#pragma unroll
+      for (int j = 0; j < V; j++) bad |= (x[k][j] - x[k][j] == 0.0) ? 0u : 1u << (k * V + j);   // inf − inf and NaN − NaN are NaN (rows beyond n hold the last prefix: finite or already counted)
+      if (k < kfull) __builtin_nontemporal_store(x[k], (DV*)(out + wbase) + lane + k * 64);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; j++) if (e + j < n) out[e + j] = x[k][j];
+      }
+    }
+    if (__any(bad != 0u)) {   // (never, in a column whose running sums stay finite)
+      unsigned long long nf = ~0ull;
+      if (bad) {
+        const int b = __builtin_ctz(bad);   // the lane's first such row: vector b / V, element b % V
+        const int64_t row = wbase + ((int64_t)(b / V) * 64 + lane) * V + (b % V);
+        if (row < n) nf = (unsigned long long)row;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long v = __shfl_down(nf, o, 64);
+        nf = v < nf ? v : nf;
+      }
+      if (lane == 0 && nf < __hip_atomic_load(first_nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(first_nf, nf);
+    }
+    __syncthreads();   // s_tile / s_wave are taken again
+  }
+}
+
+// what a one-pass launch starts from, in ONE small launch (three memsets were 14 µs of fills in front of a 0.39 ms kernel): the ticket
+// word at zero; `ones` (nullable): two words of all ones (first non-finite row, first NaN row); `zeros` (nullable): three zero words
+// (overflow flag, a spare, the validity count)
+__global__ void op_prep_kernel(unsigned* __restrict__ ticket, unsigned long long* __restrict__ ones, unsigned long long* __restrict__ zeros) {
+  if (threadIdx.x == 0) *ticket = 0u;
+  if (ones && threadIdx.x < 2) ones[threadIdx.x] = ~0ull;
+  if (zeros && threadIdx.x < 3) zeros[threadIdx.x] = 0ull;
+}
+
+// the context's record array for `ntiles` tiles (+ extra_words behind them), a fresh epoch, the ticket word at zero
+static int onepass_prepare(ah_ctx* c, int64_t ntiles, size_t extra_words, u64** recs, unsigned** ticket, unsigned long long* ones = nullptr, unsigned long long* zeros = nullptr) {
+  const size_t need = ((size_t)ntiles * kOpRecWords + extra_words) * 8 + 64;
+  if (need > c->scan_recs_bytes) {   // the context's own record array: only these kernels write it, so every stale word carries an older epoch
     AH_HIP(c, hipStreamSynchronize(c->stream));
     if (c->scan_recs) AH_HIP(c, hipFree(c->scan_recs));
     c->scan_recs = nullptr; c->scan_recs_bytes = 0;
@@ -734,24 +899,37 @@ int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, in
     c->scan_recs_bytes = want;
     c->scan_epoch = 0;
   }
-  int64_t grid = ntiles < c->num_cu ? ntiles : c->num_cu;   // one workgroup per CU (104 registers × 1024 lanes), tiles by ticket
   if (c->scan_epoch >= (1u << 29)) {   // before a marker wraps
     AH_HIP(c, hipMemsetAsync(c->scan_recs, 0, c->scan_recs_bytes, c->stream));
     c->scan_epoch = 0;
   }
   c->scan_epoch++;
-  u64* recs = (u64*)c->scan_recs;
-  unsigned* ticket = (unsigned*)((uint8_t*)c->scan_recs + c->scan_recs_bytes - 64);   // the last 64 bytes: the ticket word
-  // the ticket starts from zero in EVERY launch (a 4-byte memset in stream order): a launch that did not run to its end — a fault, an
+  *recs = (u64*)c->scan_recs;
+  *ticket = (unsigned*)((uint8_t*)c->scan_recs + c->scan_recs_bytes - 64);   // the last 64 bytes: the ticket word
+  // the ticket starts from zero in EVERY launch (in stream order): a launch that did not run to its end — a fault, an
   // asynchronous error — cannot leave the word out of step with a count the host keeps (the first version kept a running base)
-  AH_HIP(c, hipMemsetAsync(ticket, 0, sizeof(unsigned), c->stream));
+  op_prep_kernel<<<1, 64, 0, c->stream>>>(*ticket, ones, zeros);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
+
+// mode: bit 0 nulls (valid / limit), bit 1 checked, bit 2 signed (checked only)
+template <typename E>
+int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, int mode = 0, const uint8_t* valid = nullptr, int64_t off = 0, int64_t limit = 0,
+                uint8_t* out_valid = nullptr) {
+  constexpr int TILE = kOpThreads * kOpVpt * (16 / (int)sizeof(E));
+  const int64_t ntiles = ah_ceil_div(n, (int64_t)TILE);
+  u64* recs;
+  unsigned* ticket;
   unsigned* overflow = (unsigned*)&c->dscalars[13];
   unsigned long long* vcount = (unsigned long long*)&c->dscalars[15];   // out_valid: the kernel writes the output's validity and counts its set bits
-  if ((mode & 2) || out_valid) AH_HIP(c, hipMemsetAsync(overflow, 0, 3 * sizeof(uint64_t), c->stream));   // [13] overflow, [14] (free by now), [15] count
+  int prc = onepass_prepare(c, ntiles, 0, &recs, &ticket, nullptr, ((mode & 2) || out_valid) ? (unsigned long long*)overflow : nullptr);   // [13] overflow, [14] (free by now), [15] count
+  if (prc != AH_OK) return prc;
+  int64_t grid = ntiles < c->num_cu ? ntiles : c->num_cu;   // one workgroup per CU (104 registers × 1024 lanes), tiles by ticket
   const E* vin = (const E*)values;
   E* vout = (E*)out;
   const unsigned g = (unsigned)grid;
-#define AH_OP(NULLS, CHECKED, SIGNED) scan_onepass_kernel<E, NULLS, CHECKED, SIGNED><<<g, kOpThreads, 0, c->stream>>>(vin, vout, n, start, recs, ticket, 0u, c->scan_epoch, valid, off, limit, overflow, out_valid, vcount)
+#define AH_OP(NULLS, CHECKED, SIGNED) scan_onepass_kernel<E, NULLS, CHECKED, SIGNED><<<g, kOpThreads, 0, c->stream>>>(vin, vout, n, start, recs, ticket, 0u, c->scan_epoch, valid, off, limit, overflow, out_valid, vcount, &c->mailbox[16])
   if constexpr (sizeof(E) < 4) {   // 2-byte columns: unchecked without nulls only
     if (mode != 0) return ah_fail(c, AH_EINVALID, "cumulative_sum: one-pass mode %d for a narrow type", mode);
     AH_OP(false, false, false);
@@ -770,12 +948,38 @@ int run_onepass(ah_ctx* c, const void* values, int64_t n, E start, void* out, in
   return AH_OK;
 }
 
+// Float64 without nulls, one pass (scan_onepass_f64_kernel) + the sticky pass of the reduce-then-scan path
+static int run_onepass_f64(ah_ctx* c, const void* values, int64_t n, double start, void* out) {
+  constexpr int TILE = kOpThreads * kOpVpt * 2;
+  const int64_t ntiles = ah_ceil_div(n, (int64_t)TILE);
+  u64* recs;
+  unsigned* ticket;
+  unsigned long long* first_nf = (unsigned long long*)&c->dscalars[9];
+  unsigned long long* nan_from = (unsigned long long*)&c->dscalars[10];
+  int prc = onepass_prepare(c, ntiles, (size_t)(ntiles / kOpFSup + 2) * 2, &recs, &ticket, first_nf);   // + both sticky words: none
+  if (prc != AH_OK) return prc;
+  const unsigned grid = (unsigned)(ntiles < c->num_cu ? ntiles : c->num_cu);
+  scan_onepass_f64_kernel<<<grid, kOpThreads, 0, c->stream>>>((const double*)values, (double*)out, n, start, recs, recs + (size_t)ntiles * kOpRecWords, ticket,
+                                                              c->scan_epoch, first_nf, &c->mailbox[16]);
+  AH_LAUNCH_CHECK(c);
+  const unsigned sgrid = ah_stream_grid(c, ah_ceil_div(n, kBlock), 8);
+  sticky_find_kernel<double><<<sgrid, kBlock, 0, c->stream>>>((const double*)values, nullptr, 0, n, (const double*)out, first_nf, nan_from);
+  AH_LAUNCH_CHECK(c);
+  sticky_fill_kernel<double><<<sgrid, kBlock, 0, c->stream>>>(nullptr, 0, n, (double*)out, first_nf, nan_from);
+  AH_LAUNCH_CHECK(c);
+  return AH_OK;
+}
+
 template <typename T>
 int dispatch_scan(ah_ctx* c, const void* values, const uint8_t* valid, int64_t off, int64_t n, int64_t limit, const void* start_host,
                   int checked, void* out, uint8_t* out_valid, bool* validity_done) {
   T start = 0;
   if (start_host) memcpy(&start, start_host, sizeof(T));
   if constexpr (std::is_floating_point<T>::value) {
+    // Float64 without nulls: one pass with a fixed-grouping look-back (option scan_onepass 5: reduce-then-scan, for measurement)
+    if (sizeof(T) == 8 && c->opt_scan_onepass && c->opt_scan_onepass != 5 && !c->capturing && n >= ((int64_t)1 << 18) && !valid && limit >= n &&
+        ((((uintptr_t)values) | ((uintptr_t)out)) & 15) == 0 && c->tune_nt)
+      return run_onepass_f64(c, values, n, (double)start, out);
     return run_scan_vpt<T, double, false>(c, values, valid, off, n, limit, (double)start, out);
   } else {
     // unchecked: wraparound commutes with truncation, so the narrowest accumulator ≥ T does
@@ -867,6 +1071,7 @@ AH_EXPORT int ah_cumulative_sum(ah_ctx* c, int type, const void* values, const u
   if (need_sync) {
     AH_HIP(c, hipMemcpyAsync(c->pinned, &c->dscalars[13], 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     AH_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = ah_check_stall(c)) != AH_OK) return rc;
     if (checked && (*(volatile unsigned*)&c->pinned[0] & 1u)) return ah_fail(c, AH_EOVERFLOW, "overflow");
     if (out_null_count_host) *out_null_count_host = out_valid ? n - (int64_t) * (volatile uint64_t*)&c->pinned[2] : 0;
   }

@@ -322,10 +322,20 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     ivalid = ctx.to_device(random_bits(rng, rows, 0.9))
     ridx = rng.integers(0, rows, rows, dtype=np.int32)
 
-    def take_case(name, nulls, reps=3):
+    def take_case(name, nulls, reps=3, first_take=False):
         timed(name, (20 + (0.375 if nulls else 0)) * rows,
               lambda: ctx.take_primitive(8, a, vvalid if nulls else None, 0, rows, 4, True, idx, ivalid if nulls else None, 0, rows, True, c,
                                          ovalid if nulls else None), reps=reps)
+        if first_take:
+            # The line above calls Take repeatedly with ONE index vector: from the second call on the context's hint cache (option
+            # take_hint_cache, csrc/ah_take.hip) skips the path sample and its host wait — the steady state of "the second column of a
+            # record batch".  The same calls with the cache off = every call a first Take of its index vector, what rounds 1–4 timed.
+            ctx.set_option("take_hint_cache", 0)
+            try:
+                take_case(name + "_first_take", nulls, reps)
+            finally:
+                ctx.set_option("take_hint_cache", 1)
+            out[name]["first_take_ms"] = out[name + "_first_take"]["ms"]
 
     idx.upload(ridx)
     take_case("take_int64_random_i32_nulls10", True)
@@ -335,11 +345,11 @@ def per_kernel_table(ctx, rows, a, b, c, x):
     ctx.set_option("take_binned", 1)
     ridx.sort()
     idx.upload(ridx)
-    take_case("take_int64_sorted_random_i32_nulls10", True)
+    take_case("take_int64_sorted_random_i32_nulls10", True, first_take=True)
     del ridx
     idx.upload(np.arange(rows, dtype=np.int32))
     take_case("take_int64_identity_i32", False)
-    take_case("take_int64_identity_i32_nulls10", True)
+    take_case("take_int64_identity_i32_nulls10", True, first_take=True)
     idx.upload(np.arange(rows - 1, -1, -1, dtype=np.int32))
     take_case("take_int64_reverse_i32_nulls10", True)
     fmask.free(); fvalid.free(); ivalid.free()
@@ -538,6 +548,57 @@ def graph_replay_legs(ctx):
         g.close()
         for d in (a, b, c, m1, m2, m3, r1, r2):
             d.free()
+    return out
+
+
+def c1_sum_8192(ctx):
+    """Config C1 (BASELINE.json configs[0]): BenchmarkFloat64Funcs_Sum_8192 — arrow/math/float64_test.go:50-75 sums makeArrayFloat64(8192)
+    (buf[i] = i) with math.Float64.Sum.  CPU: the reference's own kernels re-timed here by oracle/_ref/bench_ref (oracle/bench_ref.c:
+    sum_float64_x86 compiled strict-sequential = the noasm order of float64.go:41-47, and the AVX2 path's machine code), one core.
+    GPU: the same 8192 rows through ah_sum_float64 (result to the host: launch + polled read), ah_sum_float64_dev (result stays on the
+    device; launches back to back) and the latter replayed from a captured hipGraph.  µs per call — a launch-bound size: no GB/s, no
+    speed-up claim (one CPU core finishes before a kernel launch has reached the GPU)."""
+    import subprocess
+    n = 8192
+    out = {"rows": n, "unit": "us per call", "input": "makeArrayFloat64(8192): buf[i] = i (float64_test.go:32-48)"}
+    exe = os.path.join(ROOT, "oracle", "_ref", "bench_ref")
+    if os.path.exists(exe):
+        r = json.loads(subprocess.run([exe, os.path.join(ROOT, "oracle", "_ref")], capture_output=True, text=True, timeout=120, check=True).stdout)
+        out["cpu_noasm_order_us"] = round(r["Float64_Sum_noasm_order_8192"]["ns_per_op"] / 1e3, 3)
+        out["cpu_avx2_us"] = round(r["Float64_Sum_avx2_8192"]["ns_per_op"] / 1e3, 3)
+        out["cpu"] = {"cores": 1, "kind": "reference", "sample": "oracle/_ref/bench_ref: 2·10^8 / 8192 calls per kernel, the reference's sum_float64 C source (noasm order) and AVX2 machine code",
+                      "noasm_MB/s": r["Float64_Sum_noasm_order_8192"]["MB/s"], "avx2_MB/s": r["Float64_Sum_avx2_8192"]["MB/s"]}
+    else:
+        out["cpu"] = {"error": "oracle/_ref/bench_ref not built"}
+    x = np.arange(n, dtype=np.float64)
+    dx = ctx.to_device(x)
+    res = ctx.alloc(8)
+    want = float(n * (n - 1) // 2)
+    assert ctx.sum_float64(dx, n) == want, "C1: wrong sum"
+    reps = 500
+    for _ in range(20):
+        ctx.sum_float64(dx, n)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.sum_float64(dx, n)
+    out["gpu_sum_to_host_us"] = round((time.perf_counter() - t0) / reps * 1e6, 2)   # wall clock of the synchronous call, as a Go caller of math.Float64.Sum sees it
+
+    def dev_timed(fn):
+        for _ in range(20):
+            fn()
+        ctx.event_record(1002)
+        for _ in range(reps):
+            fn()
+        ctx.event_record(1003)
+        return round(ctx.event_elapsed_ms(1002, 1003) / reps * 1e3, 2)
+
+    out["gpu_sum_dev_result_us"] = dev_timed(lambda: ctx.sum_float64_dev(dx, n, res))
+    ctx.sync()
+    ctx.graph_begin(); ctx.sum_float64_dev(dx, n, res); g = ctx.graph_end()
+    out["gpu_sum_dev_result_graph_replay_us"] = dev_timed(g.launch)
+    g.close()
+    assert res.download(np.float64, 1)[0] == want, "C1: wrong sum from the device-result flavour"
+    dx.free(); res.free()
     return out
 
 
@@ -831,6 +892,10 @@ def main():
                 result["graph_replay"] = graph_replay_legs(ctx)
             except Exception as e:
                 result["graph_replay"] = {"error": repr(e)}
+            try:
+                result["c1_sum_8192"] = c1_sum_8192(ctx)
+            except Exception as e:
+                result["c1_sum_8192"] = {"error": repr(e)}
             if isinstance(result["kernels"].get("ceiling_copy_kernel"), dict):
                 result["roofline"]["measured_copy_GB/s"] = result["kernels"]["ceiling_copy_kernel"]["GB/s"]
         if world == 1 and not args.no_cpu_baseline:

@@ -241,6 +241,13 @@ def test_c2_sum_and_cumulative_sum_2_27(hip, orc_be, column):
     assert g[0] == e[0] == STATUS_OK and g[3] == e[3]
     same(g[1], e[1], "cumulative_sum skip_nulls payload")
     same(g[2], e[2], "cumulative_sum skip_nulls validity")
+    # Float64, one pass with the fixed-grouping look-back: 2^27 rows = 8192 tiles = two super blocks (the super-block chain is
+    # crossed once); integer-valued addends — every order of additions is exact, so the bytes are the sequential oracle's
+    f = (a % 7).astype(np.float64)
+    g = hip.cumulative_sum(f, None, 0)
+    e = orc_be.cumulative_sum(f, None, 0)
+    assert g[0] == e[0] == STATUS_OK
+    same(g[1], e[1], "cumulative_sum float64 (one pass)")
 
 
 @pytest.mark.parametrize("kind", ["int64", "float64"])

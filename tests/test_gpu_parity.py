@@ -1059,6 +1059,50 @@ def test_cumulative_sum_one_pass(hip, orc_be, ctx, dtype):
         assert g[1].tobytes() == g2[1].tobytes() == g0[1].tobytes(), (n, "run to run / vs reduce-then-scan")
 
 
+def test_cumulative_sum_one_pass_float64(hip, orc_be, ctx):
+    """Round 6: Float64 columns without nulls take ONE pass too (scan_onepass_f64_kernel) — with a look-back whose GROUPING is fixed
+    (tile totals → blocks of 64 tiles → super blocks of 4096, every tree a fixed 64-lane reduction), so the bytes are a function of the
+    input alone: identical call after call, although which predecessor publishes first differs from launch to launch.
+    (1) integer-valued data (every order exact): byte-equal to the sequential oracle and to reduce-then-scan (option scan_onepass 5);
+    (2) general data: the tolerance of test_cumulative_sum_float — at most 64 + n/2^20 additions on the path to an output;
+    (3) a running sum that overflows in a late tile stays ±inf / turns NaN like the sequential loop (vector_cumulative.go:228-318);
+    sizes: around a tile (16 384 rows), more than one block (64 tiles), more tiles than resident workgroups, a start value."""
+    rng = np.random.default_rng(606)
+    tile = 1024 * 8 * 2
+    for n in (1 << 18, (1 << 18) + 1, 17 * tile - 1, 17 * tile + 1, 70 * tile + 123, 300 * tile + 7, (1 << 23) + 5):
+        xi = rng.integers(-3, 4, n).astype(np.float64)
+        e = orc_be.cumulative_sum(xi, None, 0, start=np.float64(2))
+        try:
+            g = hip.cumulative_sum(xi, None, 0, start=np.float64(2))
+            ctx.set_option("scan_onepass", 5)
+            g0 = hip.cumulative_sum(xi, None, 0, start=np.float64(2))
+        finally:
+            ctx.set_option("scan_onepass", 1)
+        assert g[0] == e[0] == STATUS_OK and g[1].tobytes() == e[1].tobytes() == g0[1].tobytes(), n
+        x = rng.standard_normal(n) * 1e3
+        runs = [hip.cumulative_sum(x, None, 0)[1] for _ in range(4)]
+        assert all(r.tobytes() == runs[0].tobytes() for r in runs[1:]), (n, "run to run")
+        exact = np.cumsum(x.astype(np.longdouble))
+        mag = np.cumsum(np.abs(x.astype(np.longdouble)))
+        tol = (n / 2**20 + 64) * 2.0**-53 * mag + 0.5 * 2.0**-52 * np.abs(exact)
+        assert np.all(np.abs(runs[0].astype(np.longdouble) - exact) <= tol), n
+    # overflow in a late tile, back in range right after (the tree alone would return to finite values), then the opposite infinity
+    n = 90 * tile + 11
+    big = np.float64(2.0 ** 1023)
+    x = rng.integers(-4, 5, n).astype(np.float64)
+    r = 77 * tile + 5
+    x[r], x[r + 1], x[r + 2], x[r + 3] = big, big, -big, -big
+    for edit in (None, (n - 2, -np.inf), ((r + n) // 2, np.nan)):
+        y = x.copy()
+        if edit:
+            y[edit[0]] = edit[1]
+        e, g = orc_be.cumulative_sum(y, None, 0)[1], hip.cumulative_sum(y, None, 0)[1]
+        fin = np.isfinite(e)
+        assert np.array_equal(fin, np.isfinite(g)) and g[fin].tobytes() == e[fin].tobytes()
+        assert np.array_equal(np.isnan(e), np.isnan(g)) and np.array_equal(e[np.isinf(e)], g[np.isinf(g)])
+        assert np.isfinite(e[r]) and not np.isfinite(e[r + 1])
+
+
 @pytest.mark.parametrize("dtype", [np.int32, np.uint32, np.int64, np.uint64])
 def test_cumulative_sum_one_pass_checked_and_nulls(hip, orc_be, ctx, dtype):
     """Round 5: the one-pass scan also takes CHECKED sums and columns WITH NULLS (4- / 8-byte integers): a null row adds nothing and
