@@ -529,7 +529,10 @@ int take_primitive_core(ah_ctx* c, int byte_width, const void* values, const uin
   rc = ah_take_binned_try(c, byte_width, values, vvalid, voff, nvalues, idx_byte_width, idx_signed, idx, ivalid, ioff, nidx, out_values, out_valid,
                           first_bad, &binned);
   if (rc != AH_OK) return rc;
-  if (!binned) switch (byte_width) {
+  // 16- and 32-byte slots move as 16-byte vectors: a buffer that is only 8-byte aligned (a sliced FixedSizeBinary / Decimal column, a
+  // zero-copy import) takes the arbitrary-width kernel instead of relying on the hardware's unaligned-access mode
+  const bool wide_misaligned = (byte_width == 16 || byte_width == 32) && ((((uintptr_t)values) | ((uintptr_t)out_values)) & 15) != 0;
+  if (!binned) switch (wide_misaligned ? 0 : byte_width) {
     case 1: rc = dispatch_idx<1>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 2: rc = dispatch_idx<2>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;
     case 4: rc = dispatch_idx<4>(c, idx_byte_width, idx_signed, values, vvalid, voff, nvalues, idx, ivalid, ioff, nidx, out_values, out_valid, first_bad, valid_total); break;

@@ -366,6 +366,8 @@ Status MaterializeOnDevice(Session* s, const ArrayDataPtr& host, ArrayDataPtr* o
 // and the record / chunked entry points do before anything that cannot stream)
 Status MaterializeAllOnDevice(Session* s, std::vector<Datum>* values);
 Status SumHostResident(ExecCtx* ctx, const ArrayData& a, double* f64, int64_t* i64, uint64_t* u64);
+// cumulativeStartValue (vector_cumulative.go:92-116): the Start option safe-cast to the column's type, little-endian in out[8] (kernels.cc)
+Status SafeCastCumulativeStart(const Scalar& start, const DataType* to, uint8_t out[8]);
 
 enum class FuncKind { Scalar, Vector, Meta };  // functions.go:88-100
 struct Arity { int NArgs; bool IsVarArgs; };

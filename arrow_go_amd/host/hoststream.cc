@@ -16,6 +16,8 @@
 //   filter / array_filter                             values and selection vector on the host (ah_ingest_filter_*: two phases, the
 //                                                     selection vector stays on the device between them)
 //   arrow/math Sum (ahc_math_sum)                     ah_ingest_sum_*: every chunk's partials, ONE final reduction
+//   cast                                              numeric → numeric (safe or not): one width in, another out
+//   cumulative_sum [_checked]                         integer columns, nulls skipped or none: the running sum is carried from span to span
 // Validity bitmaps are 1/64 of the values: they are uploaded whole, combined on the device (intersection, as propagateNulls does:
 // executor.go:237-349) and the result's bitmap comes back in one copy.
 #include <cstring>
@@ -251,6 +253,89 @@ Status StreamFilter(ExecCtx* ctx, const FunctionOptions* opts, const std::vector
   return Status::OK();
 }
 
+// numeric → numeric cast (CastIntToInt / CastFloatingToInteger / CastIntegerToFloating / CastFloatingToFloating, kernels/numeric_cast.go:37-71):
+// one input of one width, one output of another; the safe-cast checks look at valid rows only — the span's rows of the whole-column
+// validity bitmap, on the device since ResultValidity — and the first span with an offending row fails the call with the whole-array
+// path's text (spans run in row order: that row is the column's first offender)
+Status StreamCast(ExecCtx* ctx, const CastOptions& co, const ArrayData& a, Datum* out) {
+  Session* s = ctx->session;
+  const DataType *from = a.type, *to = co.ToType;
+  const int64_t n = a.length;
+  const int wi = from->bit_width / 8, wo = to->bit_width / 8;
+  HostArg l, none;
+  l.arr = &a;
+  BufferPtr dvl, dvr, hvalid, hvalues;
+  int64_t nulls = 0;
+  AHC_RETURN_NOT_OK(ResultValidity(s, l, none, n, &dvl, &dvr, &hvalid, &nulls));
+  AHC_RETURN_NOT_OK(s->AllocatePinned(n * wo, &hvalues));
+  auto kernel = [&](int64_t rows, int64_t r0, void* b0, void*, void* b2) -> Status {
+    return s->FromStatus(ah_cast_numeric(s->ctx(), (int)from->id, (int)to->id, b0, l.has_nulls() ? (const uint8_t*)dvl->dptr : nullptr, a.offset + r0, rows,
+                                         co.AllowIntOverflow, co.AllowFloatTruncate, b2));
+  };
+  AHC_RETURN_NOT_OK(SpanLoop(ctx, n, l.values(), wi, nullptr, 0, (uint8_t*)hvalues->hptr, wo, 1, kernel));
+  *out = Datum::Of(MakeHostArray(to, n, hvalues, hvalid, nulls, ""));
+  return Status::OK();
+}
+
+// cumulative_sum / cumulative_sum_checked of an INTEGER column (cumulativeSumExec, kernels/vector_cumulative.go:228-360): span k + 1 starts
+// from the running sum span k ended with — the output of the span's last valid row, read back behind the span's kernel (8 bytes and a
+// wait on the compute stream; the uploads of the spans ahead go on).  Integer sums wrap, so the bytes do not depend on where the spans
+// are cut: they are the whole-array path's.  (Float columns are uploaded whole: their sums depend on the grouping, and the whole-array
+// path's tree is a function of the column's length.)  Nulls: skipped (SkipNulls) or none; with SkipNulls = false everything behind
+// the first null is null and the call takes the whole-array path.
+Status StreamCumulativeSum(ExecCtx* ctx, bool checked, const CumulativeOptions* opts, const ArrayData& a, Datum* out) {
+  Session* s = ctx->session;
+  const DataType* t = a.type;
+  const int64_t n = a.length;
+  const int w = t->bit_width / 8;
+  alignas(8) uint8_t carry[8] = {0};
+  bool have_start = false;
+  if (opts && opts->Start) {
+    if (!opts->Start->valid) return Status::Make(StatusCode::Invalid, "cumulative sum start value must be valid");
+    AHC_RETURN_NOT_OK(SafeCastCumulativeStart(*opts->Start, t, carry));
+    have_start = true;
+  }
+  HostArg l, none;
+  l.arr = &a;
+  const bool nulls_in = l.has_nulls();
+  BufferPtr dvl, hvalid, hvalues, dvalid_out;
+  AHC_RETURN_NOT_OK(s->AllocatePinned(n * w, &hvalues));
+  int64_t nulls = 0;
+  if (nulls_in) {
+    // prepareCumulativeOutput (:211-226): the output's bitmap is pre-set to ones, the kernel writes the rows' bits — the bits behind row
+    // n − 1 in the last byte stay ones, as in the whole-array path
+    AHC_RETURN_NOT_OK(UploadValidity(s, a, &dvl));
+    AHC_RETURN_NOT_OK(s->AllocateBitmap(n, &dvalid_out));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_memset_async(s->ctx(), dvalid_out->dptr, 0xFF, (size_t)((n + 7) / 8))));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_copy_bitmap(s->ctx(), (const uint8_t*)dvl->dptr, a.offset, n, (uint8_t*)dvalid_out->dptr, 0, 0)));
+    int64_t set = 0;
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_count_set_bits(s->ctx(), (const uint8_t*)dvalid_out->dptr, 0, n, &set)));
+    nulls = n - set;
+    AHC_RETURN_NOT_OK(s->AllocatePinned((n + 7) / 8, &hvalid));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), hvalid->hptr, dvalid_out->dptr, (size_t)((n + 7) / 8))));
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+  }
+  const uint8_t* hv = nulls_in ? (const uint8_t*)a.buffers[0]->hptr : nullptr;
+  BufferPtr span_valid;   // the kernel wants somewhere to write a span's validity: scratch, one span's worth (the output's bitmap is made above)
+  auto kernel = [&](int64_t rows, int64_t r0, void* b0, void*, void* b2) -> Status {
+    if (nulls_in && !span_valid) AHC_RETURN_NOT_OK(s->AllocateBitmap(rows + 64, &span_valid));   // (the first span is the longest)
+    AHC_RETURN_NOT_OK(s->FromStatus(ah_cumulative_sum(s->ctx(), (int)t->id, b0, nulls_in ? (const uint8_t*)dvl->dptr : nullptr, a.offset + r0, rows,
+                                                      have_start ? carry : nullptr, 1, checked ? 1 : 0, b2, nulls_in ? (uint8_t*)span_valid->dptr : nullptr, nullptr)));
+    // the running sum behind this span = the output of its last valid row (none: unchanged)
+    int64_t last = rows - 1;
+    if (hv) while (last >= 0 && !((hv[(a.offset + r0 + last) >> 3] >> ((a.offset + r0 + last) & 7)) & 1)) last--;
+    if (last >= 0) {
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_download_async(s->ctx(), carry, (const uint8_t*)b2 + last * w, (size_t)w)));
+      AHC_RETURN_NOT_OK(s->FromStatus(ah_sync(s->ctx())));
+      have_start = true;
+    }
+    return Status::OK();
+  };
+  AHC_RETURN_NOT_OK(SpanLoop(ctx, n, l.values(), w, nullptr, 0, (uint8_t*)hvalues->hptr, w, 1, kernel));
+  *out = Datum::Of(MakeHostArray(t, n, hvalues, hvalid, nulls, ""));
+  return Status::OK();
+}
+
 }  // namespace
 
 Status MaterializeOnDevice(Session* s, const ArrayDataPtr& host, ArrayDataPtr* out) {
@@ -296,6 +381,23 @@ Status CallHostResident(ExecCtx* ctx, const std::string& name, const FunctionOpt
   struct C { const char* name; int op; bool flip; };
   static const C cmps[] = {{"equal", AH_CMP_EQ, false}, {"not_equal", AH_CMP_NE, false}, {"greater", AH_CMP_GT, false}, {"greater_equal", AH_CMP_GE, false},
                            {"less", AH_CMP_GT, true}, {"less_equal", AH_CMP_GE, true}};
+  if (name == "cast" && args.size() == 1 && args[0].kind == DatumKind::Array) {
+    const ArrayData& a = *args[0].array;
+    const CastOptions* co = dynamic_cast<const CastOptions*>(opts);
+    auto numeric = [](const DataType* t) { return t && (IsInteger(t->id) || IsFloating(t->id)); };
+    if (!co || !co->ToLogical.empty() || !a.on_host || a.device_twin || !a.logical.empty() || !numeric(a.type) || !numeric(co->ToType) || a.type->id == co->ToType->id)
+      return Status::OK();   // bool / temporal / identity casts, a missing ToType (the reference's error): the usual path
+    *handled = true;
+    return StreamCast(ctx, *co, a, out);
+  }
+  if ((name == "cumulative_sum" || name == "cumulative_sum_checked") && args.size() == 1 && args[0].kind == DatumKind::Array) {
+    const ArrayData& a = *args[0].array;
+    const CumulativeOptions* co = dynamic_cast<const CumulativeOptions*>(opts);
+    const bool has_nulls = a.buffers[0] && a.null_count != 0;
+    if (!a.on_host || a.device_twin || !a.logical.empty() || !IsInteger(a.type->id) || a.length == 0 || (has_nulls && !(co && co->SkipNulls))) return Status::OK();
+    *handled = true;
+    return StreamCumulativeSum(ctx, name == "cumulative_sum_checked", co, a, out);
+  }
   HostArg l, r;
   for (const A& a : arith) {
     const bool unchecked = name == std::string(a.name) + "_unchecked";

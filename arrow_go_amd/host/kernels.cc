@@ -1307,7 +1307,7 @@ void RegisterVectorSort(FunctionRegistry* reg) {
 // decides (compute/vector_cumulative.go:53-70, kernels/vector_cumulative.go:71-90): integer targets
 // need an in-range, integral value; an integer start for a float target must be exactly representable;
 // float → float is always allowed.  Failure is arrow.ErrInvalid.
-static Status SafeCastStart(const Scalar& start, const DataType* to, uint8_t out[8]) {
+Status SafeCastCumulativeStart(const Scalar& start, const DataType* to, uint8_t out[8]) {
   auto fail = [&](const char* why) {
     return Status::Make(StatusCode::Invalid, std::string("cannot cast cumulative sum start value to ") + to->name + ": " + why);
   };
@@ -1375,7 +1375,7 @@ static Status ExecCumulativeSum(KernelCtx* k, const ExecSpan& b, ExecResult* out
   bool have_start = false;
   if (opts && opts->Start) {
     if (!opts->Start->valid) return Status::Make(StatusCode::Invalid, "cumulative sum start value must be valid");
-    AHC_RETURN_NOT_OK(SafeCastStart(*opts->Start, in.type, start));
+    AHC_RETURN_NOT_OK(SafeCastCumulativeStart(*opts->Start, in.type, start));
     have_start = true;
   }
   out->len = in.len;

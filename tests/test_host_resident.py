@@ -249,6 +249,96 @@ def test_streamed_math_sum(sess):
     assert sess.math_sum(sess.import_host(short)) == float("inf")
 
 
+_TNAME = {pa.int8(): "int8", pa.uint8(): "uint8", pa.int16(): "int16", pa.uint16(): "uint16", pa.int32(): "int32", pa.uint32(): "uint32",
+          pa.int64(): "int64", pa.uint64(): "uint64", pa.float32(): "float", pa.float64(): "double"}
+
+
+@pytest.mark.parametrize("pair", [(pa.int64(), pa.int32()), (pa.int32(), pa.int64()), (pa.float64(), pa.float32()), (pa.int64(), pa.float64()),
+                                  (pa.float64(), pa.int64()), (pa.uint16(), pa.int8()), (pa.float32(), pa.uint8())], ids=str)
+def test_streamed_cast(sess, pair):
+    """numeric → numeric casts of a host-resident column run span by span (CastIntToInt … CastFloatingToFloating,
+    kernels/numeric_cast.go:37-71): the whole-array path's bytes — payload under nulls, validity, tail bits —, safe and unsafe; a value
+    that does not fit fails the safe cast with the whole-array path's error, wherever its span lies; under a null it is not looked at"""
+    from arrow_go_amd import compute as ac
+    src, dst = pair
+    rng = np.random.default_rng(zlib_seed("cast", src, dst))
+    n = 100_003
+    for nulls in (False, True):
+        a = column(rng, n, pa.int64(), nulls)
+        a = pc.bit_wise_and(a, pa.scalar(63, pa.int64())).cast(src)              # 0 … 63: fits every target, integral
+        opt = f"to_type={_TNAME[dst]}"
+        got, whole = both(sess, "cast", [sess.import_host(a)], [a], options=opt)
+        same(got, a.cast(dst))
+        same_bytes(got, whole)
+        got, whole = both(sess, "cast", [sess.import_host(a)], [a], options=opt + ";safe=0")
+        same_bytes(got, whole)
+    # a value the target cannot hold (or would truncate), in the last span
+    bad = {(pa.int64(), pa.int32()): 2**40, (pa.int64(), pa.float64()): 2**53 + 1, (pa.float64(), pa.int64()): 0.5, (pa.uint16(), pa.int8()): 300,
+           (pa.float32(), pa.uint8()): 300.5}.get(pair)
+    if bad is None:          # widening and float → float casts cannot fail
+        return
+    vals = np.zeros(n, src.to_pandas_dtype())
+    vals[n - 11] = bad
+    errs = []
+    for arg in (sess.import_host(pa.array(vals)), pa.array(vals)):
+        with pytest.raises(ac.ArrowError) as ei:
+            sess.call_function("cast", [arg], options=f"to_type={_TNAME[dst]}")
+        errs.append(str(ei.value))
+    assert errs[0] == errs[1], errs
+    mask = np.zeros(n, bool)
+    mask[n - 11] = True
+    m = pa.array(vals, mask=mask)
+    got, whole = both(sess, "cast", [sess.import_host(m)], [m], options=f"to_type={_TNAME[dst]}")
+    same_bytes(got, whole)
+
+
+@pytest.mark.parametrize("typ", [pa.int64(), pa.uint64(), pa.int32(), pa.uint16(), pa.int8()], ids=str)
+def test_streamed_cumulative_sum(sess, typ):
+    """cumulative_sum / cumulative_sum_checked of a host-resident INTEGER column: the running sum travels from span to span (13 spans
+    here), the bytes are the whole-array path's (integer sums wrap: the cut does not matter) — with a start value, with nulls skipped
+    (payload 0 under them, the validity's tail bits ones: prepareCumulativeOutput), with the last rows of a span null; a checked sum
+    that leaves the range in a LATE span fails with "overflow"; float columns and nulls that are not skipped take the whole-array path"""
+    from arrow_go_amd import compute as ac
+    rng = np.random.default_rng(zlib_seed("cumsum", typ))
+    n = 100_003
+    info = np.iinfo(typ.to_pandas_dtype())
+    small = max(int(info.max) // (4 * n), 1)
+    tn = _TNAME[typ]
+    for nulls in (False, True):
+        if info.max < 2**31:      # narrow types: a handful of ones, so that no running sum leaves the range
+            v = (rng.random(n) < 20.0 / n).astype(np.int64)
+        else:
+            v = rng.integers(0 if info.min == 0 else -small, small, n, endpoint=True)
+        mask = None
+        if nulls:
+            mask = rng.random(n) < 0.1
+            mask[8192 - 300:8192] = True                     # the first span (64 KiB of Int64) ends in nulls: its running sum is an earlier row's
+        a = pa.array(v, type=typ, mask=mask)
+        for name in ("cumulative_sum", "cumulative_sum_checked"):
+            for opt in ("skip_nulls=1", f"skip_nulls=1;start={tn}:3"):
+                got, whole = both(sess, name, [sess.import_host(a)], [a], options=opt)
+                same_bytes(got, whole)
+                same(got, (pc.cumulative_sum_checked if name.endswith("checked") else pc.cumulative_sum)(a, start=3 if "start" in opt else 0, skip_nulls=True))
+        if nulls:   # nulls not skipped: every row behind the first null is null — the whole-array path (the column is uploaded)
+            r = sess.call_function("cumulative_sum", [sess.import_host(a)], options="skip_nulls=0", keep_on_device=True)
+            assert not r.on_host()
+            same(r.to_arrow(), pc.cumulative_sum(a, skip_nulls=False))
+    # wrap-around (unchecked) and overflow (checked) in a late span
+    wide = pa.array(rng.integers(info.min, info.max, n, endpoint=True, dtype=typ.to_pandas_dtype()), type=typ)
+    got, whole = both(sess, "cumulative_sum", [sess.import_host(wide)], [wide], options="skip_nulls=1")
+    same_bytes(got, whole)
+    late = np.zeros(n, typ.to_pandas_dtype())
+    late[5] = info.max
+    late[n - 9] = 1
+    for arg in (sess.import_host(pa.array(late)), pa.array(late)):
+        with pytest.raises(ac.ArrowError, match="overflow"):
+            sess.call_function("cumulative_sum_checked", [arg], options="skip_nulls=1")
+    # floats: not streamed
+    f = pa.array(rng.uniform(-1, 1, n))
+    r = sess.call_function("cumulative_sum", [sess.import_host(f)], keep_on_device=True)
+    assert not r.on_host()
+
+
 def test_other_functions_upload_the_column_whole(sess):
     rng = np.random.default_rng(10)
     a = column(rng, 60_000, pa.int64(), True)
