@@ -264,8 +264,16 @@ __global__ __launch_bounds__(kThreads) void gb_aggregate_kernel(const unsigned l
   } else if (flat) {
     part = (int)blockIdx.x;
     multi = false;
-    r0 = binstart[part];
-    r1 = binstart[part + 1];
+    if (seg_rows > 0) {   // behind the RESERVING level-2 scatter: the partition's records lie in its own region of seg_rows places, binstart[] holds its count
+      r0 = (int64_t)part * seg_rows;
+      // a cursor beyond its region: the attempt is void (the host runs the level again behind a histogram).  The runs that did not fit
+      // went to the spare rows, the cursor advanced all the same, so the region's tail was never written: nothing of it is read
+      const int64_t have = (int64_t)binstart[part];
+      r1 = have <= seg_rows ? r0 + have : r0;
+    } else {
+      r0 = binstart[part];
+      r1 = binstart[part + 1];
+    }
   } else {
     // which records?  Equal shares of the partition-ordered records, whatever partitions a share spans: workgroup w takes
     // [w·R, (w + 1)·R) and walks the partition segments inside it, one table per segment.  (One workgroup per CU fits, so a
@@ -821,11 +829,19 @@ __global__ __launch_bounds__(kThreads) void gs_hist_kernel(SRC src, int64_t n, c
   for (int b = threadIdx.x; b < nb; b += kThreads) cnt[r.id * nb + b] = s_h[b];
 }
 
-template <typename SRC>
+// RES (level 2 of the two-level cut, no histogram pass in front of it): child partition c = parent · nb + digit owns the FIXED region
+// [c · cap, (c + 1) · cap) of the record arrays; a tile reserves its run of every digit with one returning atomicAdd on the child's
+// cursor (toffs is null).  The children of hash partitions of millions of evenly spread keys differ by a few per cent (cap = 1.25 ×
+// the even share: ≥ 8 σ); a child that overflows all the same — a key with tens of thousands of rows — sends the run to kMsTile spare
+// rows at trash_base, raises bit 2 of *redo, and the host runs the level again behind a histogram.  All tiles of a parent run on one
+// XCD (ms_tile), so the runs a child receives meet in one L2 as they do behind the offsets table.
+template <typename SRC, bool RES = false>
 __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n, const unsigned* __restrict__ pstart, int nparents, int lb, int shift,
                                                                unsigned mask, int nb, const unsigned* __restrict__ toffs,
                                                                unsigned long long* __restrict__ out_keys, unsigned long long* __restrict__ out_vals,
-                                                               unsigned* __restrict__ out_rows, unsigned long long* __restrict__ tile_max) {
+                                                               unsigned* __restrict__ out_rows, unsigned long long* __restrict__ tile_max,
+                                                               unsigned* __restrict__ cursor = nullptr, unsigned cap = 0, unsigned trash_base = 0,
+                                                               unsigned* __restrict__ redo = nullptr) {
   __shared__ unsigned s_cnt[kMaxNb2], s_start[kMaxNb2], s_goff[kMaxNb2], s_wsum[kThreads / 64];
   __shared__ unsigned s_a[kThreads], s_b[kThreads];
   __shared__ unsigned long long s_stage[kMsTile];
@@ -874,9 +890,22 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
     __syncthreads();
     block_excl_scan(s_a, s_b, s_wsum, kThreads);
     if (t + h * kThreads < nb) {
+      const int d = t + h * kThreads;
       const unsigned st = carry + s_b[t];
-      s_start[t + h * kThreads] = st;
-      s_goff[t + h * kThreads] = toffs[r.id * nb + t + h * kThreads] - st;
+      s_start[d] = st;
+      if (RES) {
+        const unsigned cn = s_cnt[d];
+        unsigned go = trash_base;
+        if (cn) {
+          const unsigned child = (unsigned)r.parent * (unsigned)nb + (unsigned)d;
+          const unsigned at = atomicAdd(&cursor[child], cn);
+          if (at + cn <= cap) go = child * cap + at - st;   // (mod 2^32: a region may start below the tile's own prefix)
+          else atomicOr(redo, 4u);
+        }
+        s_goff[d] = go;
+      } else {
+        s_goff[d] = toffs[r.id * nb + d] - st;
+      }
     }
     if (t == kThreads - 1) s_carry = s_b[t] + s_a[t];
     __syncthreads();
@@ -899,7 +928,8 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
 #pragma unroll
   for (int u = 0; u < kMsRows; u++) {
     const int q = u * kThreads + t;
-    dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
+    if (RES) dst[u] = q < tile_n ? (int64_t)(unsigned)(s_goff[s_bin[q]] + (unsigned)q) : -1;
+    else dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
     if (dst[u] >= 0) out_keys[dst[u]] = s_stage[q];
   }
   __syncthreads();
@@ -1155,7 +1185,11 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
 // side by side.  *used = 1: out_* hold the result.
 static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
                        int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
-                       int32_t* out_null_group, int* used) {
+                       int32_t* out_null_group, int* used, bool reserve2 = true) {
+  // reserve2: the second level's scatter reserves its runs in fixed regions, one per final partition (gs_scatter_kernel, RES) — no
+  // histogram of the first level's output, no offsets table (2^26 rows, 8192 partitions: 254 + 98 µs).  Null keys all go to child 0 of
+  // parent 0 and would overflow its region: such columns keep the histogram.
+  if (kvalid || c->opt_groupby_reserve == 0) reserve2 = false;
   *used = 0;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int lb2 = lp - lp / 2;
@@ -1176,9 +1210,14 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   // over the second level's (free once the aggregate pass has read them): 20 of the 32 bytes per place each
   const size_t level = pad((size_t)n * 8) * 2 + pad((size_t)n * 4);
   const size_t extra = nrec * sizeof(GbRec) > level ? pad(nrec * sizeof(GbRec) - level) : 0;
-  const size_t need = (level + extra) * 2 + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
+  // second level's record arrays: dense (n rows) behind the offsets table; P regions of cap2 rows (1.25 × the even share) + kMsTile spare rows otherwise
+  const unsigned cap2 = (unsigned)((((n / P) * 5 / 4 + 64) + 15) & ~(int64_t)15);
+  const int64_t qrows_n = reserve2 ? P * (int64_t)cap2 + kMsTile : n;
+  const size_t qlevel = pad((size_t)qrows_n * 8) * 2 + pad((size_t)qrows_n * 4);
+  const size_t qblock = qlevel > level + extra ? qlevel : level + extra;
+  const size_t need = (level + extra) + qblock + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
                       pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4) +
-                      pad((size_t)nfine * 8);
+                      pad((size_t)nfine * 8) + pad(((size_t)P + 1) * 4);
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -1188,10 +1227,10 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
   unsigned* prows = (unsigned*)take((size_t)n * 4);
   if (extra) take(extra);
-  unsigned long long* qkeys = (unsigned long long*)take((size_t)n * 8);
-  unsigned long long* qvals = (unsigned long long*)take((size_t)n * 8);
-  unsigned* qrows = (unsigned*)take((size_t)n * 4);
-  if (extra) take(extra);
+  uint8_t* qbase = take(qblock);
+  unsigned long long* qkeys = (unsigned long long*)qbase;
+  unsigned long long* qvals = (unsigned long long*)(qbase + pad((size_t)qrows_n * 8));
+  unsigned* qrows = (unsigned*)(qbase + pad((size_t)qrows_n * 8) * 2);
   GbRec* recs1 = (GbRec*)pkeys;
   GbRec* recs2 = (GbRec*)qkeys;
   unsigned* cnt1 = (unsigned*)take((size_t)ntiles * nb1 * 4);
@@ -1205,6 +1244,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   unsigned* ccursor = (unsigned*)take((size_t)kRecMaxBins * 4);
   unsigned* fcursor = (unsigned*)take((size_t)nfine * 4);
   int64_t* fprefix = (int64_t*)take((size_t)nfine * 8);
+  unsigned* cursor2 = (unsigned*)take(((size_t)P + 1) * 4);
   GbTable gt{nullptr, nullptr, nullptr, nullptr, nullptr};   // no tables: the groups leave the aggregate pass as records
   unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
@@ -1212,11 +1252,12 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   int* null_id = (int*)&c->dscalars[23];
   {
     GbFill f;   // one launch: the call's scalars and both cursor arrays (adjacent)
-    f.njobs = 4;
+    f.njobs = 5;
     f.p[0] = (uint4*)&c->dscalars[20]; f.n16[0] = 1; f.v[0] = 0u;                 // [20] unused, [21] overflow
     f.p[1] = (uint4*)&c->dscalars[28]; f.n16[1] = 1; f.v[1] = 0u;                 // [28], [29] value range
     f.p[2] = (uint4*)ccursor; f.n16[2] = (pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4)) / 16; f.v[2] = 0u;
-    f.p[3] = (uint4*)&c->dscalars[22]; f.n16[3] = 1; f.v[3] = 0u;                 // [22] total, [23] …
+    f.p[3] = (uint4*)cursor2; f.n16[3] = pad(((size_t)P + 1) * 4) / 16; f.v[3] = 0u;   // the children's cursors
+    f.p[4] = (uint4*)&c->dscalars[22]; f.n16[4] = 1; f.v[4] = 0u;                 // [22] total, [23] …
     f.ones = (unsigned long long*)null_id;                                         // … null id: none (the last job's first word: the same thread)
     gb_fill_kernel<<<64, 256, 0, c->stream>>>(f);
     AH_LAUNCH_CHECK(c);
@@ -1240,18 +1281,26 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
     AH_LAUNCH_CHECK(c);
   }
   GsRecords rec{pkeys, pvals, prows};
-  gs_hist_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, cnt2);
-  AH_LAUNCH_CHECK(c);
-  ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
-  AH_LAUNCH_CHECK(c);
-  gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
-  AH_LAUNCH_CHECK(c);
+  if (reserve2) {
+    gs_scatter_kernel<GsRecords, true><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, nullptr, qkeys, qvals, qrows, nullptr,
+                                                                                cursor2, cap2, (unsigned)(P * (int64_t)cap2), overflow);
+    AH_LAUNCH_CHECK(c);
+  } else {
+    gs_hist_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, cnt2);
+    AH_LAUNCH_CHECK(c);
+    ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
+    AH_LAUNCH_CHECK(c);
+    gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
+    AH_LAUNCH_CHECK(c);
+  }
+  const unsigned* part_rows = reserve2 ? cursor2 : bstart;   // flat aggregate: counts of fixed regions, or the dense starts
+  const int64_t part_cap = reserve2 ? (int64_t)cap2 : 0;
   // aggregate: one workgroup per partition; its groups leave as records in the coarse bin of their first row (over p*: free now)
   const GbRecOut ro{recs1, ccursor, cshift, ncoarse};
   const GbStaging nost{nullptr, nullptr, nullptr, nullptr};
-  if (is_f64) gb_aggregate_kernel<true, false, false, false, true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0,
+  if (is_f64) gb_aggregate_kernel<true, false, false, false, true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, part_rows, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, part_cap,
                                                                                                            nullptr, nullptr, 0, nost, nullptr, nullptr, ro);
-  else gb_aggregate_kernel<false, false, false, false, true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, bstart, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, 0,
+  else gb_aggregate_kernel<false, false, false, false, true><<<(unsigned)P, kThreads, 0, c->stream>>>(qkeys, qvals, qrows, part_rows, 0, gt, absmax, overflow, 1, nullptr, 0, nullptr, 0, 0, part_cap,
                                                                                                      nullptr, nullptr, 0, nost, nullptr, nullptr, ro);
   AH_LAUNCH_CHECK(c);
   // coarse → fine bins (over q*: the aggregate pass has read them), ids of each fine bin's first group, the output
@@ -1266,6 +1315,8 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
                                                                    (long long*)out_counts, (long long*)out_first_rows, null_id);
   AH_LAUNCH_CHECK(c);
   { int mrc = ah_mailbox_read(c, (const unsigned long long*)&c->dscalars[21], 3, (unsigned long long*)&c->pinned[8]); if (mrc != AH_OK) return mrc; }   // overflow, total, null id
+  if (reserve2 && (*(volatile unsigned*)&c->pinned[8] & 4u) && !(*(volatile unsigned*)&c->pinned[8] & 3u))   // a child's region was too small: once more behind a histogram
+    return gb2_groupby(c, is_f64, lp, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used, false);
   if (*(volatile unsigned*)&c->pinned[8]) return AH_OK;   // a partition outgrew its LDS table: the id-based path redoes the call
   if (out_ngroups) *out_ngroups = (int64_t) * (volatile uint64_t*)&c->pinned[9];
   if (out_null_group) *out_null_group = *(volatile int32_t*)&c->pinned[10];

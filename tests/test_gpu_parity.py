@@ -764,6 +764,50 @@ def test_hash_sum_partition_first(hip, orc_be, ctx, n, card, mode, hot):
         assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes(), k
 
 
+@pytest.mark.parametrize("mode,card", [(3, 1 << 21), (4, 1 << 22), (4, 3 << 20)])
+def test_hash_sum_two_level_reserving(hip, orc_be, ctx, mode, card):
+    """Round 6, the two-level cut (2048 … 8192 partitions) without key nulls: the second level's scatter RESERVES its runs in fixed
+    regions, one per final partition (gs_scatter_kernel RES: no histogram of the first level's output), and the groups leave the LDS
+    tables as 32-byte records binned by first row (GbRec) — ids from a per-bin bitmap in LDS.  Same bytes as the id-based path and as
+    the oracle, run to run; a key with tens of thousands of rows overflows its partition's region: the attempt is void and the level
+    is run again behind a histogram (option groupby_reserve 0 takes that way from the start: the same bytes again)."""
+    rng = np.random.default_rng(4242 + mode + card % 97)
+    n = (1 << 22) + 77
+    for hot in (0.0, 0.02):
+        keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+        if hot:
+            keys[rng.random(n) < hot] = 7 * 1000003
+        keys[rng.integers(0, n, 5)] = -1                       # the all-ones key: the tables' EMPTY marker
+        vvalid = rand_bits(rng, n + 8, 0.9)
+        iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+        fv = (1.0 + rng.random(n)) * np.exp(rng.uniform(-12, 12, n)) * rng.choice([-1.0, 1.0], n)
+        fv[rng.integers(0, n, 3)] = np.inf
+        fv[rng.integers(0, n, 2)] = np.nan
+        res = {}
+        try:
+            ctx.set_option("groupby_partition", 0)
+            res["ids"] = [hip.hash_sum(k, keys, None, 0, v, vvalid, 5) for k, v in (("i64", iv), ("f64", fv))]
+            ctx.set_option("groupby_partition", mode)
+            res["reserve"] = [hip.hash_sum(k, keys, None, 0, v, vvalid, 5) for k, v in (("i64", iv), ("f64", fv))]
+            again = hip.hash_sum("f64", keys, None, 0, fv, vvalid, 5)
+            ctx.set_option("groupby_reserve", 0)
+            res["hist"] = [hip.hash_sum(k, keys, None, 0, v, vvalid, 5) for k, v in (("i64", iv), ("f64", fv))]
+        finally:
+            ctx.set_option("groupby_partition", 1)
+            ctx.set_option("groupby_reserve", 1)
+        for variant in ("reserve", "hist"):
+            for g, b in zip(res[variant], res["ids"]):
+                assert g[0].tobytes() == b[0].tobytes() and g[2].tobytes() == b[2].tobytes(), (variant, hot, "keys / counts")
+                assert same_bits_or_both_nan(g[1], b[1]), (variant, hot, "sums")
+                assert g[3] == b[3] and g[4].tobytes() == b[4].tobytes(), (variant, hot)
+        assert again[1].tobytes() == res["reserve"][1][1].tobytes(), "run to run"
+        e = orc_be.hash_sum("i64", keys, None, 0, iv, vvalid, 5)
+        g = res["reserve"][0]
+        for a, b in zip(g[:3], e[:3]):
+            assert a.tobytes() == b.tobytes()
+        assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes()
+
+
 @pytest.mark.parametrize("mode", [5, 8, 11, 12])
 def test_hash_sum_reserving_scatter(hip, orc_be, ctx, mode):
     """ah_partition.h 1b: the scatter that reserves its runs in per-(partition, XCD) regions sized from the key sample (option
