@@ -20,7 +20,9 @@
  *     pointer means "all valid" (ArraySpan.Buffers[0].Buf == nil).
  *   - kernels are enqueued on the ctx's compute stream and the call returns without
  *     waiting, EXCEPT when the signature has a *_host output: those calls
- *     synchronise the stream before returning.  ah_sync() waits for everything.
+ *     synchronise the stream before returning.  ah_sync() waits for everything (and returns
+ *     AH_EHIP if a kernel reported since the last synchronisation that it gave up waiting for
+ *     another workgroup — the one-pass cumulative sums' bounded look-back; that call's output is invalid).
  *   - an ah_ctx may be used from any OS thread (every entry point selects the
  *     ctx's device first — Go's executor goroutine may migrate between threads,
  *     compute/exec.go:165) but serves one call at a time.

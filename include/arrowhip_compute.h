@@ -129,11 +129,15 @@ int ahc_export(ahc_session* s, ahc_datum* d, struct ArrowArray* arr, struct Arro
  * columns of at least "host_threshold_bytes" (64 MiB) value bytes: the producer's buffers stay where they are (pin them for the copies
  * to overlap) and are released with the datum.  ahc_call then streams such arguments span by span — upload k + 1, kernel k, download
  * k − 1 on three streams — for add / sub / subtract / multiply [+ _unchecked], equal … less_equal (array ∘ array, array ∘ scalar,
- * scalar ∘ array of one numeric type) and filter / array_filter; ahc_math_sum sums them chunk by chunk with one final reduction.
- * Results of streamed calls are host-resident too (pinned memory of the session's; ahc_export hands the buffers out without a copy,
- * ahc_datum_buffers returns HOST pointers for them).  Every other function uploads a host-resident argument whole the first time it
- * meets it (the datum is device-resident afterwards).  A column larger than the free HBM can be added, compared, filtered and summed
- * this way: only three spans of it are on the device at any time.
+ * scalar ∘ array of one numeric type; a null scalar is handled as the whole-array kernels handle it: only checked integer add / sub
+ * leave the payload untouched), filter / array_filter, cast (numeric → numeric, safe or not) and cumulative_sum[_checked] of integer
+ * columns with nulls skipped or none (the running sum is carried from span to span); ahc_math_sum sums them chunk by chunk with one
+ * final reduction.  The bytes of a streamed result — payload under nulls, validity, its last byte's tail bits — are those of the
+ * whole-array call.  Results of streamed calls are host-resident too (pinned memory of the session's; ahc_export hands the buffers out
+ * without a copy, ahc_datum_buffers returns HOST pointers for them).  Every other function uploads a host-resident argument whole the
+ * first time it meets it; the copy stays with the datum, which counts as device-resident from then on (ahc_datum_on_host → 0,
+ * ahc_datum_buffers → the device pointers, later calls use the copy instead of streaming).  A column larger than the free HBM can be
+ * added, compared, filtered, cast and summed this way: only three spans of it are on the device at any time.
  * ahc_session_set_option: "chunk_bytes" (bytes of the widest column per span: ExecCtx.ChunkSize's role; 0 = 32 MiB),
  * "host_threshold_bytes". */
 int ahc_import_host(ahc_session* s, struct ArrowArray* arr, struct ArrowSchema* schema, ahc_datum** out);
