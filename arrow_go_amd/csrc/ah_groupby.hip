@@ -841,7 +841,7 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
                                                                unsigned long long* __restrict__ out_keys, unsigned long long* __restrict__ out_vals,
                                                                unsigned* __restrict__ out_rows, unsigned long long* __restrict__ tile_max,
                                                                unsigned* __restrict__ cursor = nullptr, unsigned cap = 0, unsigned trash_base = 0,
-                                                               unsigned* __restrict__ redo = nullptr) {
+                                                               unsigned* __restrict__ redo = nullptr, const unsigned* __restrict__ pend = nullptr) {
   __shared__ unsigned s_cnt[kMaxNb2], s_start[kMaxNb2], s_goff[kMaxNb2], s_wsum[kThreads / 64];
   __shared__ unsigned s_a[kThreads], s_b[kThreads];
   __shared__ unsigned long long s_stage[kMsTile];
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
   __shared__ unsigned s_imin[kThreads / 64];
   __shared__ int s_pick;
   __shared__ unsigned s_carry;
-  const TileRange r = ms_tile(pstart, nparents, n, s_a, s_b, s_wsum, &s_pick);
+  const TileRange r = ms_tile(pstart, nparents, n, s_a, s_b, s_wsum, &s_pick, pend);
   if (r.parent < 0) return;
   const int t = threadIdx.x;
   for (int b = t; b < nb; b += kThreads) s_cnt[b] = 0;
@@ -1076,6 +1076,21 @@ __global__ __launch_bounds__(kBlock) void gs_emit_kernel(const unsigned long lon
 
 }  // namespace
 
+// behind the RESERVING level-1 scatter: parent p = the region [p · cap, p · cap + rows), rows = its cursor — or nothing at all when the
+// cursor passed the region's end (the attempt is void: bit 2 of *redo; the runs that did not fit lie elsewhere and the region's tail
+// was never written).  Float64: the value range of the call (gb_max_kernel has reduced it) is checked here too (fx_range_check_kernel).
+__global__ void gs_regions_kernel(const unsigned* __restrict__ cursor, int nparents, unsigned cap, unsigned* __restrict__ pstart, unsigned* __restrict__ pend,
+                                  unsigned* __restrict__ redo, const unsigned long long* __restrict__ range) {
+  const int p = threadIdx.x;
+  if (p < nparents) {
+    const unsigned have = cursor[p], lo = (unsigned)p * cap;
+    pstart[p] = lo;
+    pend[p] = have <= cap ? lo + have : lo;
+    if (have > cap) atomicOr(redo, 4u);
+  }
+  if (p == 0 && range && fx_wide(range[0], range[1])) atomicOr(redo, 2u);
+}
+
 // the sort-based path (gs_* kernels).  *used = 1: out_* hold the result.
 static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
                       int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
@@ -1208,8 +1223,12 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   const size_t nrec = (size_t)ncoarse << cshift;                               // record places: every coarse bin whole (≥ n)
   // the records of the coarse scatter lie over the first level's rows (free once the second level is cut), those of the fine scatter
   // over the second level's (free once the aggregate pass has read them): 20 of the 32 bytes per place each
-  const size_t level = pad((size_t)n * 8) * 2 + pad((size_t)n * 4);
-  const size_t extra = nrec * sizeof(GbRec) > level ? pad(nrec * sizeof(GbRec) - level) : 0;
+  // first level's record arrays: dense (n rows) behind the offsets table; nb1 regions of cap1 rows (1.125 × the even share + a tile) + kMsTile spare rows otherwise
+  const unsigned cap1 = (unsigned)((((n / nb1) * 9 / 8 + kMsTile) + 15) & ~(int64_t)15);
+  const int64_t prows_n = reserve2 ? nb1 * (int64_t)cap1 + kMsTile : n;
+  const size_t plevel = pad((size_t)prows_n * 8) * 2 + pad((size_t)prows_n * 4);
+  const size_t level = plevel > pad(nrec * sizeof(GbRec)) ? plevel : pad(nrec * sizeof(GbRec));   // … and the coarse records lie over them
+  const size_t extra = 0;
   // second level's record arrays: dense (n rows) behind the offsets table; P regions of cap2 rows (1.25 × the even share) + kMsTile spare rows otherwise
   const unsigned cap2 = (unsigned)((((n / P) * 5 / 4 + 64) + 15) & ~(int64_t)15);
   const int64_t qrows_n = reserve2 ? P * (int64_t)cap2 + kMsTile : n;
@@ -1217,16 +1236,16 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   const size_t qblock = qlevel > level + extra ? qlevel : level + extra;
   const size_t need = (level + extra) + qblock + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
                       pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4) +
-                      pad((size_t)nfine * 8) + pad(((size_t)P + 1) * 4);
+                      pad((size_t)nfine * 8) + pad(((size_t)P + 1) * 4) + pad((size_t)(nb1 + 1) * 4) * 2;
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
   size_t off = 0;
   auto take = [&](size_t b) { uint8_t* q = base + off; off += pad(b); return q; };
-  unsigned long long* pkeys = (unsigned long long*)take((size_t)n * 8);
-  unsigned long long* pvals = (unsigned long long*)take((size_t)n * 8);
-  unsigned* prows = (unsigned*)take((size_t)n * 4);
-  if (extra) take(extra);
+  uint8_t* pbase = take(level);
+  unsigned long long* pkeys = (unsigned long long*)pbase;
+  unsigned long long* pvals = (unsigned long long*)(pbase + pad((size_t)prows_n * 8));
+  unsigned* prows = (unsigned*)(pbase + pad((size_t)prows_n * 8) * 2);
   uint8_t* qbase = take(qblock);
   unsigned long long* qkeys = (unsigned long long*)qbase;
   unsigned long long* qvals = (unsigned long long*)(qbase + pad((size_t)qrows_n * 8));
@@ -1245,6 +1264,8 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   unsigned* fcursor = (unsigned*)take((size_t)nfine * 4);
   int64_t* fprefix = (int64_t*)take((size_t)nfine * 8);
   unsigned* cursor2 = (unsigned*)take(((size_t)P + 1) * 4);
+  unsigned* cursor1 = (unsigned*)take((size_t)(nb1 + 1) * 4);
+  unsigned* pend = (unsigned*)take((size_t)(nb1 + 1) * 4);
   GbTable gt{nullptr, nullptr, nullptr, nullptr, nullptr};   // no tables: the groups leave the aggregate pass as records
   unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
@@ -1256,13 +1277,26 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
     f.p[0] = (uint4*)&c->dscalars[20]; f.n16[0] = 1; f.v[0] = 0u;                 // [20] unused, [21] overflow
     f.p[1] = (uint4*)&c->dscalars[28]; f.n16[1] = 1; f.v[1] = 0u;                 // [28], [29] value range
     f.p[2] = (uint4*)ccursor; f.n16[2] = (pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4)) / 16; f.v[2] = 0u;
-    f.p[3] = (uint4*)cursor2; f.n16[3] = pad(((size_t)P + 1) * 4) / 16; f.v[3] = 0u;   // the children's cursors
+    f.p[3] = (uint4*)cursor2; f.n16[3] = (pad(((size_t)P + 1) * 4) + pad((size_t)(nb1 + 1) * 4)) / 16; f.v[3] = 0u;   // the children's and the parents' cursors (adjacent)
     f.p[4] = (uint4*)&c->dscalars[22]; f.n16[4] = 1; f.v[4] = 0u;                 // [22] total, [23] …
     f.ones = (unsigned long long*)null_id;                                         // … null id: none (the last job's first word: the same thread)
     gb_fill_kernel<<<64, 256, 0, c->stream>>>(f);
     AH_LAUNCH_CHECK(c);
   }
   GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
+  if (reserve2) {
+    // level 1 reserves too: parent d owns the region [d · cap1, …); its runs come from all eight XCDs, 64 records (512 bytes of keys) at a
+    // time — long enough not to share many lines (one cursor per partition only loses against the offsets table from 512 partitions on)
+    gs_scatter_kernel<GsColumns, true><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lp, lb2, (unsigned)(nb1 - 1), nb1, nullptr, pkeys, pvals, prows,
+                                                                        is_f64 ? tile_max : nullptr, cursor1, cap1, (unsigned)(nb1 * (int64_t)cap1), overflow);
+    AH_LAUNCH_CHECK(c);
+    if (is_f64) {
+      gb_max_kernel<<<1, 1024, 0, c->stream>>>(tile_max, ntiles, absmax);
+      AH_LAUNCH_CHECK(c);
+    }
+    gs_regions_kernel<<<1, 64, 0, c->stream>>>(cursor1, nb1, cap1, pstart, pend, overflow, is_f64 ? absmax : nullptr);   // nb1 ≤ 64
+    AH_LAUNCH_CHECK(c);
+  } else {
   gs_hist_kernel<GsColumns><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lp, lb2, (unsigned)(nb1 - 1), nb1, cnt1);
   AH_LAUNCH_CHECK(c);
   colsum_kernel<<<(unsigned)ngrp, kMaxBins, 0, c->stream>>>(cnt1, nb1, ntiles, gsum);
@@ -1280,10 +1314,11 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
     fx_range_check_kernel<<<1, 1, 0, c->stream>>>(absmax, overflow);   // a wide column goes to the id-based path (per-group scales)
     AH_LAUNCH_CHECK(c);
   }
+  }
   GsRecords rec{pkeys, pvals, prows};
   if (reserve2) {
     gs_scatter_kernel<GsRecords, true><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, nullptr, qkeys, qvals, qrows, nullptr,
-                                                                                cursor2, cap2, (unsigned)(P * (int64_t)cap2), overflow);
+                                                                                cursor2, cap2, (unsigned)(P * (int64_t)cap2), overflow, pend);
     AH_LAUNCH_CHECK(c);
   } else {
     gs_hist_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, cnt2);

@@ -22,8 +22,10 @@ struct TileRange { int64_t lo, hi, id; int parent; };   // id = row of the count
 // block → XCD rule; only speed depends on it), and blocks left over in one class take the tiles another class has too many of.
 __device__ __forceinline__ int ms_parent_of(int j, int nparents) { const int per = nparents >> 3; return ((j % per) << 3) | (j / per); }
 // all threads call
+// pend (nullable): parent p's rows are [pstart[p], pend[p]) — parents that are REGIONS with room behind their rows (the reserving
+// level-1 scatter of the group-by) — instead of [pstart[p], pstart[p + 1]).
 __device__ __forceinline__ TileRange ms_tile(const unsigned* __restrict__ pstart, int nparents, int64_t n, unsigned* s_cnt, unsigned* s_start,
-                                             unsigned* s_wsum, int* s_pick) {
+                                             unsigned* s_wsum, int* s_pick, const unsigned* __restrict__ pend = nullptr) {
   TileRange r{0, 0, 0, -1};
   if (!pstart) {
     const int64_t tile = xcd_contiguous_tile((n + kMsTile - 1) / kMsTile);
@@ -32,7 +34,7 @@ __device__ __forceinline__ TileRange ms_tile(const unsigned* __restrict__ pstart
   }
   const int t = threadIdx.x, per = nparents >> 3;
   unsigned tiles = 0;
-  if (t < nparents) { const int p = ms_parent_of(t, nparents); tiles = (pstart[p + 1] - pstart[p] + kMsTile - 1) / kMsTile; }
+  if (t < nparents) { const int p = ms_parent_of(t, nparents); tiles = ((pend ? pend[p] : pstart[p + 1]) - pstart[p] + kMsTile - 1) / kMsTile; }
   s_cnt[t] = tiles;
   if (t == 0) *s_pick = -1;
   __syncthreads();
@@ -57,7 +59,7 @@ __device__ __forceinline__ TileRange ms_tile(const unsigned* __restrict__ pstart
   const int j = *s_pick;
   if (j < 0) return r;
   const int p = ms_parent_of(j, nparents);
-  const int64_t b0 = pstart[p], b1 = pstart[p + 1];
+  const int64_t b0 = pstart[p], b1 = pend ? pend[p] : pstart[p + 1];
   r.lo = b0 + (int64_t)(g - s_start[j]) * kMsTile;
   r.hi = r.lo + kMsTile < b1 ? r.lo + kMsTile : b1;
   r.id = g;
