@@ -19,7 +19,7 @@ rows = 1 << args.rows_log2
 hrows = min(rows, 1 << 26)
 WORKLOADS = ["add_int64", "sum_float64", "copy_kernel", "filter_sel0.01", "filter_sel0.50", "filter_sel0.90", "filter_sel0.50_masknulls_emit", "filter_sel0.50_count_and_fill",
              "take_random_nulls10", "take_random", "take_random_nulls10_direct", "take_identity_nulls10", "take_identity", "take_reverse_nulls10", "take_stride8_calib", "take_stride16_calib",
-             "cumulative_sum_int64", "dict_encode_2^10", "dict_encode_2^16", "dict_encode_2^20", "dict_encode_2^22", "dict_encode_2^24", "dict_encode_2^20_zipf", "unique_2^20",
+             "cumulative_sum_int64", "cumulative_sum_float64", "dict_encode_2^10", "dict_encode_2^16", "dict_encode_2^20", "dict_encode_2^22", "dict_encode_2^24", "dict_encode_2^20_zipf", "unique_2^20",
              "hash_sum_2^10", "hash_sum_2^16", "hash_sum_2^20", "hash_sum_2^24", "hash_sum_2^20_zipf", "sort_indices_int64_2^27"]
 if args.list:
     print("\n".join(WORKLOADS)); sys.exit(0)
@@ -86,6 +86,7 @@ def build(name):
         st = int(name[11:].split("_")[0])
         return setup_take(lambda: ((np.arange(rows, dtype=np.int64) * st) % rows).astype(np.int32), False, 0)
     if name == "cumulative_sum_int64": return lambda: ctx.cumulative_sum(N.INT64, a, None, 0, rows, None, False, False, c, None)
+    if name == "cumulative_sum_float64": return lambda: ctx.cumulative_sum(N.FLOAT64, x, None, 0, rows, None, False, False, c, None)
     if name.startswith("unique"):
         setup_keys(int(name.split("^")[1]), False)
         return lambda: ctx.hash_u64_encode(keys, None, 0, hrows, False, None, None, hdic)
