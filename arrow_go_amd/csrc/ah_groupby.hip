@@ -841,7 +841,10 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
                                                                unsigned long long* __restrict__ out_keys, unsigned long long* __restrict__ out_vals,
                                                                unsigned* __restrict__ out_rows, unsigned long long* __restrict__ tile_max,
                                                                unsigned* __restrict__ cursor = nullptr, unsigned cap = 0, unsigned trash_base = 0,
-                                                               unsigned* __restrict__ redo = nullptr, const unsigned* __restrict__ pend = nullptr) {
+                                                               unsigned* __restrict__ redo = nullptr, const unsigned* __restrict__ pend = nullptr,
+                                                               int sub8 = 0) {
+  // sub8: the "parents" are the 8 per-XCD regions of each true parent, numbered q = (p >> 3) · 64 + x · 8 + (p & 7) (gs_subregions_kernel):
+  // q & 7 = p & 7, so all eight regions of a parent are tiled on ONE XCD (ms_tile's classes) and its children's runs meet in one L2
   __shared__ unsigned s_cnt[kMaxNb2], s_start[kMaxNb2], s_goff[kMaxNb2], s_wsum[kThreads / 64];
   __shared__ unsigned s_a[kThreads], s_b[kThreads];
   __shared__ unsigned long long s_stage[kMsTile];
@@ -897,7 +900,8 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
         const unsigned cn = s_cnt[d];
         unsigned go = trash_base;
         if (cn) {
-          const unsigned child = (unsigned)r.parent * (unsigned)nb + (unsigned)d;
+          const unsigned parent = sub8 ? (((unsigned)r.parent >> 6) << 3) | ((unsigned)r.parent & 7u) : (unsigned)r.parent;
+          const unsigned child = parent * (unsigned)nb + (unsigned)d;
           const unsigned at = atomicAdd(&cursor[child], cn);
           if (at + cn <= cap) go = child * cap + at - st;   // (mod 2^32: a region may start below the tile's own prefix)
           else atomicOr(redo, 4u);
@@ -1091,6 +1095,52 @@ __global__ void gs_regions_kernel(const unsigned* __restrict__ cursor, int npare
   if (p == 0 && range && fx_wide(range[0], range[1])) atomicOr(redo, 2u);
 }
 
+// behind gb_scatter_kernel<…, RESERVE> as the FIRST level of the two-level cut: region (p, x) — parent p's rows from the tiles XCD x
+// ran — becomes "parent" q = (p >> 3) · 64 + x · 8 + (p & 7) of the second level's tiling: [sstart[q], send[q]).  A cursor beyond its
+// region voids the attempt (nothing of any region is read).  The scatter's per-tile value ranges are reduced and checked here
+// (what gb_segments_kernel does behind the one-level cut).
+__global__ __launch_bounds__(1024) void gs_subregions_kernel(const unsigned* __restrict__ rstart, const unsigned* __restrict__ rcap, const unsigned* __restrict__ cursor,
+                                                             int nb1, unsigned* __restrict__ sstart, unsigned* __restrict__ send, unsigned* __restrict__ redo,
+                                                             const unsigned long long* __restrict__ tile_rng, int64_t ntiles, unsigned long long* __restrict__ range) {
+  __shared__ unsigned long long s_max[16], s_imin[16];
+  const int t = threadIdx.x;
+  bool over = (*redo & 4u) != 0;   // void already (gb_layout_kernel: the regions did not fit the arrays)
+  unsigned have = 0, lo = 0;
+  int q = -1;
+  if (t < nb1 * kGbRegions) {
+    const int p = t / kGbRegions, x = t % kGbRegions;
+    q = ((p >> 3) << 6) | (x << 3) | (p & 7);
+    have = cursor[t];
+    lo = rstart[t];
+    over = over || have > rcap[t];
+  }
+  const bool dead = __syncthreads_or(over ? 1 : 0) != 0;
+  if (q >= 0) { sstart[q] = lo; send[q] = dead ? lo : lo + have; }
+  if (dead && t == 0) atomicOr(redo, 4u);
+  if (tile_rng) {
+    unsigned long long m = 0, im = 0;
+    for (int64_t i = t; i < ntiles; i += 1024) {
+      const unsigned long long a = tile_rng[2 * i], b = tile_rng[2 * i + 1];
+      m = a > m ? a : m;
+      im = b > im ? b : im;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = __shfl_down(m, o, 64), b = __shfl_down(im, o, 64);
+      m = a > m ? a : m;
+      im = b > im ? b : im;
+    }
+    if ((t & 63) == 0) { s_max[t >> 6] = m; s_imin[t >> 6] = im; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < 16; w++) { m = s_max[w] > m ? s_max[w] : m; im = s_imin[w] > im ? s_imin[w] : im; }
+      range[0] = m;
+      range[1] = im;
+      if (fx_wide(m, im)) atomicOr(redo, 2u);
+    }
+  }
+}
+
 // the sort-based path (gs_* kernels).  *used = 1: out_* hold the result.
 static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
                       int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
@@ -1200,11 +1250,15 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
 // side by side.  *used = 1: out_* hold the result.
 static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, const uint8_t* kvalid, int64_t koff, const void* vals, const uint8_t* vvalid,
                        int64_t voff, int64_t n, uint64_t* out_keys, void* out_sums, int64_t* out_counts, int64_t* out_first_rows, int64_t* out_ngroups,
-                       int32_t* out_null_group, int* used, bool reserve2 = true) {
+                       int32_t* out_null_group, int* used, bool reserve2 = true, const unsigned* hist = nullptr, double hist_scale = 0.0) {
   // reserve2: the second level's scatter reserves its runs in fixed regions, one per final partition (gs_scatter_kernel, RES) — no
   // histogram of the first level's output, no offsets table (2^26 rows, 8192 partitions: 254 + 98 µs).  Null keys all go to child 0 of
   // parent 0 and would overflow its region: such columns keep the histogram.
   if (kvalid || c->opt_groupby_reserve == 0) reserve2 = false;
+  // hist (the 2^21-row sample's [8][1024] row counts, when the caller ran it): the first level is the one-level cut's own reserving
+  // scatter (gb_scatter_kernel<…, RESERVE>: a region per parent and XCD, sized from the sample; 0.48 ms where the two-level machinery's
+  // level-1 kernel takes 0.64–0.72) and the second level tiles those regions
+  const bool xreg = reserve2 && hist != nullptr;
   *used = 0;
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int lb2 = lp - lp / 2;
@@ -1225,7 +1279,8 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   // over the second level's (free once the aggregate pass has read them): 20 of the 32 bytes per place each
   // first level's record arrays: dense (n rows) behind the offsets table; nb1 regions of cap1 rows (1.125 × the even share + a tile) + kMsTile spare rows otherwise
   const unsigned cap1 = (unsigned)((((n / nb1) * 9 / 8 + kMsTile) + 15) & ~(int64_t)15);
-  const int64_t prows_n = reserve2 ? nb1 * (int64_t)cap1 + kMsTile : n;
+  const int64_t xcap_rows = n + n / 2 + (int64_t)nb1 * kGbRegions * 96;   // gb_layout_kernel's regions (as in gb_cut_aggregate)
+  const int64_t prows_n = xreg ? xcap_rows + kGbTile : (reserve2 ? nb1 * (int64_t)cap1 + kMsTile : n);
   const size_t plevel = pad((size_t)prows_n * 8) * 2 + pad((size_t)prows_n * 4);
   const size_t level = plevel > pad(nrec * sizeof(GbRec)) ? plevel : pad(nrec * sizeof(GbRec));   // … and the coarse records lie over them
   const size_t extra = 0;
@@ -1236,7 +1291,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   const size_t qblock = qlevel > level + extra ? qlevel : level + extra;
   const size_t need = (level + extra) + qblock + pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) +
                       pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) + pad((size_t)ntiles * 16) + pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4) +
-                      pad((size_t)nfine * 8) + pad(((size_t)P + 1) * 4) + pad((size_t)(nb1 + 1) * 4) * 2;
+                      pad((size_t)nfine * 8) + pad(((size_t)P + 1) * 4) + pad((size_t)(nb1 * kGbRegions + 1) * 4) * 5;
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -1264,8 +1319,12 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   unsigned* fcursor = (unsigned*)take((size_t)nfine * 4);
   int64_t* fprefix = (int64_t*)take((size_t)nfine * 8);
   unsigned* cursor2 = (unsigned*)take(((size_t)P + 1) * 4);
-  unsigned* cursor1 = (unsigned*)take((size_t)(nb1 + 1) * 4);
-  unsigned* pend = (unsigned*)take((size_t)(nb1 + 1) * 4);
+  const int nsub = nb1 * kGbRegions;   // ≤ 512
+  unsigned* cursor1 = (unsigned*)take((size_t)(nsub + 1) * 4);
+  unsigned* pend = (unsigned*)take((size_t)(nsub + 1) * 4);
+  unsigned* sstart = (unsigned*)take((size_t)(nsub + 1) * 4);
+  unsigned* rstart1 = (unsigned*)take((size_t)(nsub + 1) * 4);
+  unsigned* rcap1 = (unsigned*)take((size_t)(nsub + 1) * 4);
   GbTable gt{nullptr, nullptr, nullptr, nullptr, nullptr};   // no tables: the groups leave the aggregate pass as records
   unsigned long long* absmax = (unsigned long long*)&c->dscalars[28];   // [28], [29]: the value range (ah_hashing.h)
   unsigned* overflow = (unsigned*)&c->dscalars[21];
@@ -1277,14 +1336,28 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
     f.p[0] = (uint4*)&c->dscalars[20]; f.n16[0] = 1; f.v[0] = 0u;                 // [20] unused, [21] overflow
     f.p[1] = (uint4*)&c->dscalars[28]; f.n16[1] = 1; f.v[1] = 0u;                 // [28], [29] value range
     f.p[2] = (uint4*)ccursor; f.n16[2] = (pad((size_t)kRecMaxBins * 4) + pad((size_t)nfine * 4)) / 16; f.v[2] = 0u;
-    f.p[3] = (uint4*)cursor2; f.n16[3] = (pad(((size_t)P + 1) * 4) + pad((size_t)(nb1 + 1) * 4)) / 16; f.v[3] = 0u;   // the children's and the parents' cursors (adjacent)
+    f.p[3] = (uint4*)cursor2; f.n16[3] = (pad(((size_t)P + 1) * 4) + pad((size_t)(nsub + 1) * 4)) / 16; f.v[3] = 0u;   // the children's and the parents' cursors (adjacent)
     f.p[4] = (uint4*)&c->dscalars[22]; f.n16[4] = 1; f.v[4] = 0u;                 // [22] total, [23] …
     f.ones = (unsigned long long*)null_id;                                         // … null id: none (the last job's first word: the same thread)
     gb_fill_kernel<<<64, 256, 0, c->stream>>>(f);
     AH_LAUNCH_CHECK(c);
   }
   GsColumns col{(const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff};
-  if (reserve2) {
+  const unsigned* l2_start = pstart;
+  int l2_parents = nb1, l2_sub8 = 0;
+  if (xreg) {
+    const int lb1 = lp - lb2;
+    const int64_t gtiles = ah_ceil_div(n, kGbTile), xrows = ((gtiles + 7) >> 3) * kGbTile;
+    gb_layout_kernel<<<1, 1024, 0, c->stream>>>(hist, lb1, n, xrows, hist_scale, xcap_rows, rstart1, rcap1, cursor1, overflow);
+    AH_LAUNCH_CHECK(c);
+    gb_scatter_kernel<true, true><<<(unsigned)(((gtiles + 7) / 8) * 8), kThreads, 0, c->stream>>>((const unsigned long long*)keys, kvalid, koff, (const unsigned long long*)vals, vvalid, voff,
+                                                                                               n, lb1, nb1, gtiles, nullptr, pkeys, pvals, prows, is_f64 ? tile_max : nullptr,
+                                                                                               rstart1, rcap1, cursor1, overflow, (unsigned)xcap_rows);
+    AH_LAUNCH_CHECK(c);
+    gs_subregions_kernel<<<1, 1024, 0, c->stream>>>(rstart1, rcap1, cursor1, nb1, sstart, pend, overflow, is_f64 ? tile_max : nullptr, gtiles, absmax);
+    AH_LAUNCH_CHECK(c);
+    l2_start = sstart; l2_parents = nsub; l2_sub8 = 1;
+  } else if (reserve2) {
     // level 1 reserves too: parent d owns the region [d · cap1, …); its runs come from all eight XCDs, 64 records (512 bytes of keys) at a
     // time — long enough not to share many lines (one cursor per partition only loses against the offsets table from 512 partitions on)
     gs_scatter_kernel<GsColumns, true><<<grid1, kThreads, 0, c->stream>>>(col, n, nullptr, 1, lp, lb2, (unsigned)(nb1 - 1), nb1, nullptr, pkeys, pvals, prows,
@@ -1317,8 +1390,9 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   }
   GsRecords rec{pkeys, pvals, prows};
   if (reserve2) {
-    gs_scatter_kernel<GsRecords, true><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, nullptr, qkeys, qvals, qrows, nullptr,
-                                                                                cursor2, cap2, (unsigned)(P * (int64_t)cap2), overflow, pend);
+    const unsigned nvt2 = xreg ? (unsigned)(((ntiles + nsub + 7) / 8) * 8) : (unsigned)nvt;   // every region's last tile may be short
+    gs_scatter_kernel<GsRecords, true><<<nvt2, kThreads, 0, c->stream>>>(rec, n, l2_start, l2_parents, lp, 0, (unsigned)(nb2 - 1), nb2, nullptr, qkeys, qvals, qrows, nullptr,
+                                                                       cursor2, cap2, (unsigned)(P * (int64_t)cap2), overflow, pend, l2_sub8);
     AH_LAUNCH_CHECK(c);
   } else {
     gs_hist_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, cnt2);
@@ -2158,7 +2232,7 @@ int ah_groupby_partitioned_try(ah_ctx* c, int is_f64, const uint64_t* keys, cons
       if (est <= 8192.0 * kpp_many) {   // 17 M: 8192 partitions of ≤ 2100 expected keys (2^24 groups in 2^26 rows: 5.3 ms this way, 6.3 ms sort-based)
         int lp2 = 11;
         while (lp2 < 13 && est / (double)(1 << lp2) > 1280.0) lp2++;   // (2100 here: 2^22 groups 3 % slower, 2^23 3 % faster)
-        return gb2_groupby(c, is_f64, lp2, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
+        return gb2_groupby(c, is_f64, lp2, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used, true, sample_hist, sample_scale);
       }
       return gs_groupby(c, is_f64, keys, kvalid, koff, vals, vvalid, voff, n, out_keys, out_sums, out_counts, out_first_rows, out_ngroups, out_null_group, used);
     }

@@ -36,12 +36,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ≈ 6.3 TB/s
 
 
-PMC_PROFILE = "r05_pmc_by_workload.json"   # THIS round's counters (scripts/prof_workloads.py + pmc_by_workload.py on the GPU box)
+PMC_PROFILE = "r06_pmc_by_workload.json"   # THIS round's counters (scripts/prof_workloads.py + pmc_by_workload.py on the GPU box)
 
 
 def pmc_traffic(rows):
     """(HBM bytes per launch of the Int64 Add kernel, where the figure comes from): the current round's committed rocprofv3
-    PMC passes (profiles/r05_pmc_by_workload.json — FETCH_SIZE with the calibrated gfx950 streaming factor + WRITE_SIZE), or
+    PMC passes (profiles/r06_pmc_by_workload.json — FETCH_SIZE with the calibrated gfx950 streaming factor + WRITE_SIZE), or
     (None, why) when that file is absent or was taken at another size — never an older round's file."""
     path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     try:
