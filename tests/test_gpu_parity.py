@@ -808,6 +808,37 @@ def test_hash_sum_two_level_reserving(hip, orc_be, ctx, mode, card):
         assert g[3] == e[3] and g[4].tobytes() == e[4].tobytes()
 
 
+@pytest.mark.parametrize("hot", [0.0, 0.02])
+def test_hash_sum_two_level_auto(hip, orc_be, ctx, hot):
+    """the two-level cut as the dispatcher reaches it (option groupby_partition 1): 2^23 rows over 3·2^20 evenly drawn keys — the 2^21-row
+    sample says ≈ 3 M groups and leaves its [8][1024] histogram, so the FIRST level is the one-level cut's reserving scatter (a region per
+    parent and XCD, gb_scatter_kernel RESERVE) and the second level tiles those regions (gs_subregions_kernel); with a key that owns 2 % of
+    the rows a final partition's region overflows and the level runs again behind a histogram.  Bytes of the id-based path and the oracle."""
+    rng = np.random.default_rng(2323 + int(hot * 100))
+    n = (1 << 23) + 77
+    keys = rng.integers(0, 3 << 20, n).astype(np.int64) * 1000003
+    if hot:
+        keys[rng.random(n) < hot] = 7 * 1000003
+    vvalid = rand_bits(rng, n + 8, 0.9)
+    iv = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+    fv = (1.0 + rng.random(n)) * np.exp(rng.uniform(-12, 12, n)) * rng.choice([-1.0, 1.0], n)
+    try:
+        ctx.set_option("groupby_partition", 0)
+        base = [hip.hash_sum(k, keys, None, 0, v, vvalid, 5) for k, v in (("i64", iv), ("f64", fv))]
+    finally:
+        ctx.set_option("groupby_partition", 1)
+    got = [hip.hash_sum(k, keys, None, 0, v, vvalid, 5) for k, v in (("i64", iv), ("f64", fv))]
+    again = hip.hash_sum("f64", keys, None, 0, fv, vvalid, 5)
+    for g, b in zip(got, base):
+        assert g[0].tobytes() == b[0].tobytes() and g[1].tobytes() == b[1].tobytes() and g[2].tobytes() == b[2].tobytes()
+        assert g[3] == b[3] and g[4].tobytes() == b[4].tobytes()
+    assert again[1].tobytes() == got[1][1].tobytes()
+    e = orc_be.hash_sum("i64", keys, None, 0, iv, vvalid, 5)
+    for a, b in zip(got[0][:3], e[:3]):
+        assert a.tobytes() == b.tobytes()
+    assert got[0][3] == e[3] and got[0][4].tobytes() == e[4].tobytes()
+
+
 @pytest.mark.parametrize("mode", [5, 8, 11, 12])
 def test_hash_sum_reserving_scatter(hip, orc_be, ctx, mode):
     """ah_partition.h 1b: the scatter that reserves its runs in per-(partition, XCD) regions sized from the key sample (option
