@@ -835,8 +835,10 @@ __global__ __launch_bounds__(kThreads) void gs_hist_kernel(SRC src, int64_t n, c
 // the even share: ≥ 8 σ); a child that overflows all the same — a key with tens of thousands of rows — sends the run to kMsTile spare
 // rows at trash_base, raises bit 2 of *redo, and the host runs the level again behind a histogram.  All tiles of a parent run on one
 // XCD (ms_tile), so the runs a child receives meet in one L2 as they do behind the offsets table.
-template <typename SRC, bool RES = false>
-__global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n, const unsigned* __restrict__ pstart, int nparents, int lb, int shift,
+// (≤ 64 registers: two workgroups per CU.  At 68–71 — the 64-bit destinations of four rows — only one fitted and the pass ran at
+// 3.5 TB/s where the one-level scatter, built the same way, runs at 5.0.)
+template <typename SRC, bool RES = false, bool RANGE = true>   // RANGE = false: tile_max is null (level 2) — the range bookkeeping and its registers are compiled out
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void gs_scatter_kernel(SRC src, int64_t n, const unsigned* __restrict__ pstart, int nparents, int lb, int shift,
                                                                unsigned mask, int nb, const unsigned* __restrict__ toffs,
                                                                unsigned long long* __restrict__ out_keys, unsigned long long* __restrict__ out_vals,
                                                                unsigned* __restrict__ out_rows, unsigned long long* __restrict__ tile_max,
@@ -874,9 +876,9 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
     dg[u] = (gs_bucket(k[u], rw[u] & kKeyNull, lb) >> shift) & mask;
     rank[u] = live[u] ? atomicAdd(&s_cnt[dg[u]], 1u) : 0u;
     const unsigned long long a = v[u] & 0x7fffffffffffffffull;
-    if (tile_max && live[u] && !(rw[u] & kValNull) && (a >> 52) != 0x7ff && a != 0) { vmax = a > vmax ? a : vmax; vimin = fx_inv_exp(a) > vimin ? fx_inv_exp(a) : vimin; }
+    if (RANGE && tile_max && live[u] && !(rw[u] & kValNull) && (a >> 52) != 0x7ff && a != 0) { vmax = a > vmax ? a : vmax; vimin = fx_inv_exp(a) > vimin ? fx_inv_exp(a) : vimin; }
   }
-  if (tile_max) {
+  if (RANGE && tile_max) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned long long x = __shfl_down(vmax, o, 64);
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
     carry += s_carry;
     __syncthreads();
   }
-  if (tile_max && t == 0) {
+  if (RANGE && tile_max && t == 0) {
     unsigned long long x = s_max[0];
     unsigned xi = s_imin[0];
     for (int w = 1; w < kThreads / 64; w++) { x = s_max[w] > x ? s_max[w] : x; xi = s_imin[w] > xi ? s_imin[w] : xi; }
@@ -928,13 +930,13 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
   for (int u = 0; u < kMsRows; u++)
     if (live[u]) { const unsigned q = s_start[dg[u]] + rank[u]; s_stage[q] = k[u]; s_bin[q] = (uint16_t)dg[u]; }
   __syncthreads();
-  int64_t dst[kMsRows];
+  constexpr unsigned kNone = ~0u;   // positions are below 2^32 − 1 (≤ 2^29 rows, regions within 1.5 n)
+  unsigned dst[kMsRows];
 #pragma unroll
   for (int u = 0; u < kMsRows; u++) {
     const int q = u * kThreads + t;
-    if (RES) dst[u] = q < tile_n ? (int64_t)(unsigned)(s_goff[s_bin[q]] + (unsigned)q) : -1;
-    else dst[u] = q < tile_n ? (int64_t)s_goff[s_bin[q]] + q : -1;
-    if (dst[u] >= 0) out_keys[dst[u]] = s_stage[q];
+    dst[u] = q < tile_n ? s_goff[s_bin[q]] + (unsigned)q : kNone;   // (mod 2^32 in both modes: the offsets table's entries are positions too)
+    if (dst[u] != kNone) out_keys[dst[u]] = s_stage[q];
   }
   __syncthreads();
 #pragma unroll
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kMsRows; u++)
-    if (dst[u] >= 0) out_vals[dst[u]] = s_stage[u * kThreads + t];
+    if (dst[u] != kNone) out_vals[dst[u]] = s_stage[u * kThreads + t];
   __syncthreads();
   unsigned* s_stage32 = reinterpret_cast<unsigned*>(s_stage);
 #pragma unroll
@@ -952,7 +954,7 @@ __global__ __launch_bounds__(kThreads) void gs_scatter_kernel(SRC src, int64_t n
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kMsRows; u++)
-    if (dst[u] >= 0) out_rows[dst[u]] = s_stage32[u * kThreads + t];
+    if (dst[u] != kNone) out_rows[dst[u]] = s_stage32[u * kThreads + t];
 }
 
 // sort element: (key, null-key flag | row) decides; li = position in the bucket before the sort (| null-value flag) finds the value
@@ -1216,7 +1218,7 @@ static int gs_groupby(ah_ctx* c, int is_f64, const uint64_t* keys, const uint8_t
   AH_LAUNCH_CHECK(c);
   ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
   AH_LAUNCH_CHECK(c);
-  gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lb, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
+  gs_scatter_kernel<GsRecords, false, false><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lb, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
   AH_LAUNCH_CHECK(c);
   // buckets → group records at the position of each group's first row (p* are free again: they take the records)
   unsigned long long *g_key = pkeys, *g_sum = pvals;
@@ -1391,7 +1393,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
   GsRecords rec{pkeys, pvals, prows};
   if (reserve2) {
     const unsigned nvt2 = xreg ? (unsigned)(((ntiles + nsub + 7) / 8) * 8) : (unsigned)nvt;   // every region's last tile may be short
-    gs_scatter_kernel<GsRecords, true><<<nvt2, kThreads, 0, c->stream>>>(rec, n, l2_start, l2_parents, lp, 0, (unsigned)(nb2 - 1), nb2, nullptr, qkeys, qvals, qrows, nullptr,
+    gs_scatter_kernel<GsRecords, true, false><<<nvt2, kThreads, 0, c->stream>>>(rec, n, l2_start, l2_parents, lp, 0, (unsigned)(nb2 - 1), nb2, nullptr, qkeys, qvals, qrows, nullptr,
                                                                        cursor2, cap2, (unsigned)(P * (int64_t)cap2), overflow, pend, l2_sub8);
     AH_LAUNCH_CHECK(c);
   } else {
@@ -1399,7 +1401,7 @@ static int gb2_groupby(ah_ctx* c, int is_f64, int lp, const uint64_t* keys, cons
     AH_LAUNCH_CHECK(c);
     ms_offs2_kernel<<<(unsigned)nb1, kThreads, 0, c->stream>>>(cnt2, pstart, nb1, nb2, toffs2, bstart, n);
     AH_LAUNCH_CHECK(c);
-    gs_scatter_kernel<GsRecords><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
+    gs_scatter_kernel<GsRecords, false, false><<<(unsigned)nvt, kThreads, 0, c->stream>>>(rec, n, pstart, nb1, lp, 0, (unsigned)(nb2 - 1), nb2, toffs2, qkeys, qvals, qrows, nullptr);
     AH_LAUNCH_CHECK(c);
   }
   const unsigned* part_rows = reserve2 ? cursor2 : bstart;   // flat aggregate: counts of fixed regions, or the dense starts
