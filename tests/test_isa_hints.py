@@ -48,6 +48,9 @@ RESOURCES = {
     "ah_groupby.hip": [
         (r"gb_scatter_kernelILb1E", 64, 0),
         (r"gb_aggregate_kernelILb1ELb0E", 128, 0),
+        # the two-level cut's scatter (round 6): at 68–71 registers one workgroup of 1024 per CU — level 2 ran at 3.5 TB/s, 772 µs; at 64: 660
+        (r"gs_scatter_kernelINS_9GsRecordsE", 64, 16),
+        (r"gbr_emit_kernel", 64, 0),
     ],
     "ah_hash_part.hip": [
         (r"gb_scatter_kernelILb0E", 64, 0),
@@ -58,7 +61,7 @@ RESOURCES = {
     "ah_take.hip": [(r"take_vec_kernelILi8EiLb[01]ELi7E", 64, 0)],
     # the one-pass cumulative_sum: a workgroup of 1024 lanes per CU = 128 registers, and nothing of the tile in scratch (a CSE of the
     # sixteen null masks across the look-back once spilled 21 … 49 registers and every parity test stayed green: DESIGN.md §3.4)
-    "ah_scan.hip": [(r"scan_onepass_kernelI[jyt]Lb", 128, 16)],
+    "ah_scan.hip": [(r"scan_onepass_kernelI[jyt]Lb", 128, 16), (r"scan_onepass_f64_kernel", 128, 0)],
 }
 
 
