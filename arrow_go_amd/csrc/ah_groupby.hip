@@ -926,11 +926,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))
     tile_max[2 * r.id + 1] = xi;
   }
   const int tile_n = (int)(r.hi - r.lo);
-#pragma unroll
-  for (int u = 0; u < kMsRows; u++)
-    if (live[u]) { const unsigned q = s_start[dg[u]] + rank[u]; s_stage[q] = k[u]; s_bin[q] = (uint16_t)dg[u]; }
-  __syncthreads();
   constexpr unsigned kNone = ~0u;   // positions are below 2^32 − 1 (≤ 2^29 rows, regions within 1.5 n)
+  unsigned pos[kMsRows];            // the row's place in the staged tile, once: digit and rank are dead from here on (four registers and
+#pragma unroll                      // eight LDS reads less than looking s_start up again in each of the three rounds)
+  for (int u = 0; u < kMsRows; u++) {
+    pos[u] = live[u] ? s_start[dg[u]] + rank[u] : kNone;
+    if (pos[u] != kNone) { s_stage[pos[u]] = k[u]; s_bin[pos[u]] = (uint16_t)dg[u]; }
+  }
+  __syncthreads();
   unsigned dst[kMsRows];
 #pragma unroll
   for (int u = 0; u < kMsRows; u++) {
@@ -941,7 +944,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kMsRows; u++)
-    if (live[u]) s_stage[s_start[dg[u]] + rank[u]] = v[u];
+    if (pos[u] != kNone) s_stage[pos[u]] = v[u];
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kMsRows; u++)
@@ -950,7 +953,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))
   unsigned* s_stage32 = reinterpret_cast<unsigned*>(s_stage);
 #pragma unroll
   for (int u = 0; u < kMsRows; u++)
-    if (live[u]) s_stage32[s_start[dg[u]] + rank[u]] = rw[u];
+    if (pos[u] != kNone) s_stage32[pos[u]] = rw[u];
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kMsRows; u++)
