@@ -59,6 +59,7 @@ struct ah_ctx {
   int opt_groupby_partition;   // hash + sum (ah_groupby.hip): 0 never, 1 auto, k ≥ 2 always with 2^(k−2) partitions (ARROWHIP_GROUPBY_PARTITION)
   int opt_encode_partition;    // unique / dictionary_encode (ah_hash_part.hip): 0 never, 1 auto (by the prefix's distinct count), k ≥ 3: always, 2^k partitions (ARROWHIP_ENCODE_PARTITION)
   int opt_encode_part_slots;   // measurement: LDS table size of the one-cut path (8192 default, 4096)
+  int opt_encode_byte_map;     // partition-first encode: first occurrences marked by plain byte stores into a byte map that one pass packs into the bitmap (1) or by device-scope atomicOr on the bitmap's words (0)
   int opt_encode_early_look;   // 1 (default): calls of ≥ 2^24 rows count the first 2^16 rows' distinct keys BEFORE the global table is set up (ah_encode_first_look); 0: the look that falls out of the staged inserts
   int opt_encode_part_min;     // auto: smallest expected distinct count that takes the partition-first path (ARROWHIP_ENCODE_PART_MIN)
   int opt_hash_direct;         // unique / dictionary_encode (ah_hash.hip): 0 ids in a separate pass, 1 direct ids, 2 + LDS / re-packed table (default), 3 no re-packed table (ARROWHIP_HASH_DIRECT)

@@ -46,6 +46,7 @@ static int ctx_init_common(ah_ctx* c) {
   c->opt_encode_partition = env_int("ARROWHIP_ENCODE_PARTITION", 1);
   c->opt_encode_part_min = env_int("ARROWHIP_ENCODE_PART_MIN", 300000);
   c->opt_encode_early_look = env_int("ARROWHIP_ENCODE_EARLY_LOOK", 1);
+  c->opt_encode_byte_map = env_int("ARROWHIP_ENCODE_BYTE_MAP", 1);
   c->opt_encode_part_slots = env_int("ARROWHIP_ENCODE_PART_SLOTS", 8192);
   c->opt_sort_msd = env_int("ARROWHIP_SORT_MSD", 1);
   c->opt_scan_segment_log2 = env_int("ARROWHIP_SCAN_SEGMENT_LOG2", 0);   // 0 = one segment: segments measured slower
@@ -150,6 +151,7 @@ AH_EXPORT int ah_ctx_set_option(ah_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "encode_partition")) c->opt_encode_partition = (int)value;
   else if (!strcmp(name, "encode_part_min")) c->opt_encode_part_min = (int)value;
   else if (!strcmp(name, "encode_early_look")) c->opt_encode_early_look = (int)value;
+  else if (!strcmp(name, "encode_byte_map")) c->opt_encode_byte_map = (int)value;
   else if (!strcmp(name, "encode_part_slots")) c->opt_encode_part_slots = (int)value;
   else if (!strcmp(name, "sort_msd")) c->opt_sort_msd = (int)value;
   else if (!strcmp(name, "scan_onepass")) c->opt_scan_onepass = (int)value;

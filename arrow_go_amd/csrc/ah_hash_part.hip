@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
                                                               const unsigned* __restrict__ binstart, int encode_nulls,
                                                               unsigned long long* __restrict__ tab_key, unsigned* __restrict__ tab_first,
                                                               unsigned short* __restrict__ rec_slot, unsigned long long* __restrict__ firsts,
-                                                              unsigned* __restrict__ overflow) {
+                                                              unsigned* __restrict__ overflow, uint8_t* __restrict__ fbytes = nullptr) {
   constexpr int kLS = S + 2, kStride = S + 8, kSoft = S / 4 * 3;
   __shared__ __attribute__((aligned(16))) unsigned long long l_key[kLS];
   __shared__ unsigned l_first[kLS];
@@ -207,8 +207,31 @@ __global__ __launch_bounds__(kThreads) void enc_table_kernel(const unsigned long
     const unsigned fr = j < kLS ? l_first[j] : kNoRow;
     if (j < kLS && tab_key) tab_key[gbase + j] = l_key[j];   // (not wanted when the dictionary is compacted from the column)
     tab_first[gbase + j] = fr;
-    if (fr != kNoRow) atomicOr(&firsts[fr >> 6], 1ull << (fr & 63));
+    if (fr != kNoRow) {
+      if (fbytes) fbytes[fr] = 1;   // a plain byte store into the byte map (enc_bytes_to_bits_kernel packs it): no device-scope read-modify-write per key
+      else atomicOr(&firsts[fr >> 6], 1ull << (fr & 63));
+    }
   }
+}
+
+// byte map (one byte per row, 1 = a first occurrence) → the bitmap: a lane packs 64 bytes into one word
+__global__ __launch_bounds__(kBlock) void enc_bytes_to_bits_kernel(const uint8_t* __restrict__ fbytes, int64_t nwords, unsigned long long* __restrict__ firsts) {
+  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w >= nwords) return;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2* src = reinterpret_cast<const u64x2*>(fbytes + w * 64);
+  unsigned long long bits = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const u64x2 v = __builtin_nontemporal_load(src + q);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      // eight bytes of 0 / 1 → eight bits: the bytes' low bits gathered by a multiply (0x0102040810204080 puts byte k's bit at position 56 + k)
+      const unsigned long long x = (h ? v.y : v.x) & 0x0101010101010101ull;
+      bits |= ((x * 0x0102040810204080ull) >> 56) << (q * 16 + h * 8);
+    }
+  }
+  firsts[w] = bits;
 }
 
 // ---- 4: ids of the used slots (tab_first is overwritten with them), the dictionary -----------------------------------------------
@@ -910,7 +933,7 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const size_t table = (size_t)P * (size_t)ntiles * 4;
   const size_t need = pad(table) * 2 + pad((size_t)ngrp * P * 4) + pad((size_t)(P + 1) * 4) + pad((size_t)n * 8) + pad((size_t)n * 4) + pad((size_t)n * 2) +
-                      pad((size_t)nslots * 8) + pad((size_t)nslots * 4) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
+                      pad((size_t)nslots * 8) + pad((size_t)nslots * 4) + pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad((size_t)nwords * 64);
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -926,6 +949,8 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   unsigned long long* tab_key = (unsigned long long*)take((size_t)nslots * 8);
   unsigned* tab_first = (unsigned*)take((size_t)nslots * 4);
   unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  // (from 1024 partitions on — ≈ 4·10^6 keys: below, the map's fill and packing cost what the atomics cost)
+  uint8_t* fbytes = (c->opt_encode_byte_map == 2 || (c->opt_encode_byte_map == 1 && lp >= 10)) ? (uint8_t*)take((size_t)nwords * 64) : nullptr;
   unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
   int* tilecnt = (int*)take((size_t)nrt * 4);
   int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
@@ -938,7 +963,9 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
     f.njobs = 2;
     f.p[0] = (uint4*)&c->dscalars[30]; f.n16[0] = 1; f.v[0] = 0u;                 // [30] overflow, [31] total
     f.ones = (unsigned long long*)null_id;                                         // [32] null id: none
-    f.p[1] = (uint4*)firsts; f.n16[1] = pad((size_t)nwords * 8) / 16; f.v[1] = 0u;
+    if (fbytes) { f.p[1] = (uint4*)fbytes; f.n16[1] = (size_t)nwords * 4; }   // the byte map (the bitmap is then written whole)
+    else { f.p[1] = (uint4*)firsts; f.n16[1] = pad((size_t)nwords * 8) / 16; }
+    f.v[1] = 0u;
     gb_fill_kernel<<<(unsigned)(c->num_cu * 2), 256, 0, c->stream>>>(f);
     AH_LAUNCH_CHECK(c);
   }
@@ -967,10 +994,14 @@ int ah_encode_partitioned_try(ah_ctx* c, const uint64_t* keys, const uint8_t* va
   // (measured at 2^26 rows: from 2^22 keys on — 1024 partitions — the compaction wins; below, the slots' few scattered stores are cheaper than its pass)
   const bool compact = c->opt_encode_dict_compact >= 2 || (c->opt_encode_dict_compact == 1 && lp >= 10);
   unsigned long long* tab_key_out = compact ? nullptr : tab_key;
-  if (slots == kESlots2) { if (c->opt_encode_table_batch) enc_table_kernel<kESlots2, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
-  else { if (c->opt_encode_table_batch) enc_table_kernel<kESlots, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow); }
+  if (slots == kESlots2) { if (c->opt_encode_table_batch) enc_table_kernel<kESlots2, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow, fbytes); else enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow, fbytes); }
+  else { if (c->opt_encode_table_batch) enc_table_kernel<kESlots, true><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow, fbytes); else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys, prows, binstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow, fbytes); }
   AH_LAUNCH_CHECK(c);
   // ---- 4: rank
+  if (fbytes) {
+    enc_bytes_to_bits_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(fbytes, nwords, firsts);
+    AH_LAUNCH_CHECK(c);
+  }
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
   AH_LAUNCH_CHECK(c);
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);
@@ -1009,7 +1040,7 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const size_t need = pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) + pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) +
                       pad((size_t)n * 8) * 2 + pad((size_t)n * 4) * 2 + pad((size_t)n * 2) * 2 + pad((size_t)nslots * 8) + pad((size_t)nslots * 4) +
-                      pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8);
+                      pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad((size_t)nwords * 64);
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -1031,6 +1062,7 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   unsigned long long* tab_key = (unsigned long long*)take((size_t)nslots * 8);
   unsigned* tab_first = (unsigned*)take((size_t)nslots * 4);
   unsigned long long* firsts = (unsigned long long*)take((size_t)nwords * 8);
+  uint8_t* fbytes = c->opt_encode_byte_map ? (uint8_t*)take((size_t)nwords * 64) : nullptr;
   unsigned* wordprefix = (unsigned*)take((size_t)nwords * 4);
   int* tilecnt = (int*)take((size_t)nrt * 4);
   int64_t* tileoff = (int64_t*)take((size_t)nrt * 8);
@@ -1044,7 +1076,9 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
     f.njobs = 2;
     f.p[0] = (uint4*)&c->dscalars[30]; f.n16[0] = 1; f.v[0] = 0u;                 // [30] overflow, [31] total
     f.ones = (unsigned long long*)null_id;                                         // [32] null id: none
-    f.p[1] = (uint4*)firsts; f.n16[1] = pad((size_t)nwords * 8) / 16; f.v[1] = 0u;
+    if (fbytes) { f.p[1] = (uint4*)fbytes; f.n16[1] = (size_t)nwords * 4; }   // the byte map (the bitmap is then written whole)
+    else { f.p[1] = (uint4*)firsts; f.n16[1] = pad((size_t)nwords * 8) / 16; }
+    f.v[1] = 0u;
     gb_fill_kernel<<<(unsigned)(c->num_cu * 2), 256, 0, c->stream>>>(f);
     AH_LAUNCH_CHECK(c);
   }
@@ -1076,9 +1110,13 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   // ---- tables, ranks, ids: as in the one-level path, one workgroup per final partition
   const bool compact = c->opt_encode_dict_compact >= 1;
   unsigned long long* tab_key_out = compact ? nullptr : tab_key;
-  if (slots == kESlots2) enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
-  else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow);   // small partitions: the batched probe's registers cost more than its waits
+  if (slots == kESlots2) enc_table_kernel<kESlots2, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow, fbytes);   // small partitions: the batched probe's registers cost more than its waits
+  else enc_table_kernel<kESlots, false><<<(unsigned)P, kThreads, 0, c->stream>>>(pkeys2, prows2, bstart, encode_nulls, tab_key_out, tab_first, out_ids ? rec_slot : nullptr, firsts, overflow, fbytes);   // small partitions: the batched probe's registers cost more than its waits
   AH_LAUNCH_CHECK(c);
+  if (fbytes) {
+    enc_bytes_to_bits_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(fbytes, nwords, firsts);
+    AH_LAUNCH_CHECK(c);
+  }
   word_prefix_kernel<<<(unsigned)ah_ceil_div(nwords, kBlock), kBlock, 0, c->stream>>>(firsts, nwords, wordprefix, tilecnt);
   AH_LAUNCH_CHECK(c);
   scan_kernel<<<1, 1024, 0, c->stream>>>(tilecnt, nrt, tileoff, total);

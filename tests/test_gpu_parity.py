@@ -977,6 +977,28 @@ def test_hash_encode_partitioned(hip, orc_be, ctx, lp):
         ctx.set_option("encode_partition", 1)
 
 
+@pytest.mark.parametrize("lp,byte_map", [(8, 2), (8, 0), (11, 1), (11, 0)])
+def test_hash_encode_first_occurrence_marks(hip, orc_be, ctx, lp, byte_map):
+    """the first-occurrence bitmap of the partition-first encode, both ways (option encode_byte_map): one device-scope atomicOr per key on
+    the bitmap's words, or a plain byte store per key into a byte map that enc_bytes_to_bits_kernel packs (round 6: at 2^24 keys the
+    2^24 read-modify-writes cost ≈ 0.2 ms of 2.7) — the same ids, dictionary and null id as the sequential memo table, for a length that
+    ends inside a bitmap word and inside a 64-byte group of the map"""
+    rng = np.random.default_rng(900 + lp + byte_map)
+    try:
+        ctx.set_option("encode_partition", lp)
+        ctx.set_option("encode_byte_map", byte_map)
+        for n, card in (((1 << 20) + 37, 1 << 19), ((1 << 21) + 77, (1 << 21) + 77)):
+            keys = rng.integers(0, card, n).astype(np.int64) * 1000003
+            keys[rng.integers(0, n, 3)] = -1
+            valid = rand_bits(rng, n + 16, 0.9)
+            for enc in (False, True):
+                g, e = hip.hash_encode(keys, valid, 5, enc), orc_be.hash_encode(keys, valid, 5, enc)
+                assert g[2].size == e[2].size and g[3] == e[3] and g[0].tobytes() == e[0].tobytes() and g[2].tobytes() == e[2].tobytes(), (n, enc)
+    finally:
+        ctx.set_option("encode_partition", 1)
+        ctx.set_option("encode_byte_map", 1)
+
+
 def test_hash_encode_partitioned_auto(hip, orc_be, ctx):
     """the automatic choice: ≥ 2^22 rows and a prefix that promises between encode_part_min and 4.5 M keys"""
     rng = np.random.default_rng(79)
