@@ -867,7 +867,35 @@ __global__ __launch_bounds__(kThreads) void enc_look_kernel(const unsigned long 
   if (t == 0) { s_new = 0; s_ones = 0; }
   __syncthreads();
   unsigned mine = 0;
-  constexpr int U = 16;   // loads in flight per lane: the pass is four round trips to L2 long (U = 4: sixteen, 32 µs)
+  // Only 1 / 64 of the rows are this workgroup's: a lane that probed as soon as it met one held its wave for a whole probe sequence
+  // — in two of three steps SOME lane has one — and the pass was forty serial LDS round trips per wave (32 µs).  The wave's rows of
+  // interest are queued (ballot + prefix count, LDS) and probed together once the queue holds a wave's worth.
+  __shared__ unsigned long long s_queue[kThreads / 64][128];
+  const int lane = t & 63, wave = t >> 6;
+  unsigned long long* q = s_queue[wave];
+  int queued = 0;   // (wave-uniform)
+  auto insert = [&](unsigned long long key) {
+    if (key == kEmpty) { if (atomicExch(&s_ones, 1u) == 0u) mine++; return; }   // the all-ones key is the set's empty marker: counted on the side
+    const unsigned m = ((unsigned)key ^ ((unsigned)(key >> 32) * 0x9E3779B1u)) * 0x85EBCA6Bu;
+    unsigned j = (m >> 10) & (unsigned)(kLookSlots - 1);
+    bool placed = false;
+    for (int probes = 0; probes < kLookSlots && !placed; probes++) {
+      unsigned long long cur = l_key[j];
+      if (cur == kEmpty) cur = atomicCAS(&l_key[j], kEmpty, key);
+      if (cur == kEmpty) { mine++; placed = true; }
+      else if (cur == key) placed = true;
+      j = (j + 1) & (unsigned)(kLookSlots - 1);
+    }
+    if (!placed) mine++;
+  };
+  auto drain = [&](int from) {   // the queue's entries from `from` on, one per lane
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (from + lane < queued) insert(q[from + lane]);
+    __builtin_amdgcn_wave_barrier();
+  };
+  constexpr int U = 16;   // loads in flight per lane: the pass is four round trips to L2 long
   for (int64_t b = 0; b < rows; b += (int64_t)kThreads * U) {
     unsigned long long k[U];
 #pragma unroll
@@ -875,24 +903,22 @@ __global__ __launch_bounds__(kThreads) void enc_look_kernel(const unsigned long 
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t i = b + u * kThreads + t;
-      if (i >= rows || !ah_bit(valid, off + i)) continue;
-      // a 32-bit hash (two quarter-rate multiplies): every workgroup hashes ALL the rows, and with the 64-bit mixer of the partition
-      // passes that was the whole kernel (32 µs: 64 × 2^16 × two 64-bit multiplies)
+      // a 32-bit hash (two quarter-rate multiplies): every workgroup hashes ALL the rows
       const unsigned m = ((unsigned)k[u] ^ ((unsigned)(k[u] >> 32) * 0x9E3779B1u)) * 0x85EBCA6Bu;
-      if ((m >> 26) != blockIdx.x) continue;   // kLookWgs = 64: the top six bits
-      if (k[u] == kEmpty) { if (atomicExch(&s_ones, 1u) == 0u) mine++; continue; }   // the all-ones key is the set's empty marker: counted on the side
-      unsigned j = (m >> 10) & (unsigned)(kLookSlots - 1);
-      bool placed = false;
-      for (int probes = 0; probes < kLookSlots && !placed; probes++) {
-        unsigned long long cur = l_key[j];
-        if (cur == kEmpty) cur = atomicCAS(&l_key[j], kEmpty, k[u]);
-        if (cur == kEmpty) { mine++; placed = true; }
-        else if (cur == k[u]) placed = true;
-        j = (j + 1) & (unsigned)(kLookSlots - 1);
+      const bool in = i < rows && ah_bit(valid, off + i) && (m >> 26) == blockIdx.x;   // kLookWgs = 64: the top six bits
+      const unsigned long long mask = __ballot(in);
+      if (in) q[queued + __popcll(mask & ((1ull << lane) - 1ull))] = k[u];
+      queued += __popcll(mask);
+      if (queued >= 64) {   // (uniform) at most 127 queued: the first 64 go now
+        drain(0);
+        const unsigned long long rest = lane + 64 < queued ? q[lane + 64] : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (lane + 64 < queued) q[lane] = rest;
+        queued -= 64;
       }
-      if (!placed) mine++;
     }
   }
+  drain(0);
   if (mine) atomicAdd(&s_new, mine);
   __syncthreads();
   if (t == 0) {
