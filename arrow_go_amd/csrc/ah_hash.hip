@@ -780,7 +780,7 @@ int encode_core(ah_ctx* c, const K keys, const uint8_t* valid, int64_t off, int6
     *attempted = true;
     return try_partitioned(lp, done, slots2);
   };
-  // Large calls look BEFORE anything is spent on the global table (ah_encode_first_look: one launch, ≈ 10 µs, against ≈ 90 µs of table
+  // Large calls look BEFORE anything is spent on the global table (ah_encode_first_look: one launch, ≈ 25 µs, against ≈ 90 µs of table
   // fill + staged inserts + polled read): a call the partitions answer never touches the table.  Small calls (n < 2^24) keep the look
   // that falls out of the staged inserts — it costs them nothing, and this one would cost a launch and a wait on every call.
   bool looked = false, look_undecided = false;
