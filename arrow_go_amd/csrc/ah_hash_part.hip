@@ -543,11 +543,12 @@ __device__ __forceinline__ unsigned e2_digit(unsigned long long key, unsigned rw
 
 __global__ __launch_bounds__(kThreads) void e2_hist_kernel(const unsigned long long* __restrict__ pkeys, const unsigned* __restrict__ prows, int64_t n,
                                                             const unsigned* __restrict__ pstart, int nparents, int lp, unsigned mask, int nb,
-                                                            unsigned* __restrict__ cnt) {
+                                                            unsigned* __restrict__ cnt, const TileRange* __restrict__ tile_table = nullptr) {
   __shared__ unsigned s_h[kThreads];
   __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_wsum[kThreads / 64];
   __shared__ int s_pick;
-  const TileRange r = ms_tile(pstart, nparents, n, s_cnt, s_start, s_wsum, &s_pick);
+  // (tile_table: this launch's tiles precomputed — a histogram's workgroup lives ≈ 5 µs, ms_tile's loads, scan and barriers were 2 of them)
+  const TileRange r = tile_table ? tile_table[blockIdx.x] : ms_tile(pstart, nparents, n, s_cnt, s_start, s_wsum, &s_pick);
   if (r.parent < 0) return;
   for (int b = threadIdx.x; b < nb; b += kThreads) s_h[b] = 0;
   __syncthreads();
@@ -1066,7 +1067,7 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   const int64_t nwords = ah_ceil_div(n, 64), nrt = rank_tiles(nwords);
   const size_t need = pad((size_t)ntiles * nb1 * 4) * 2 + pad((size_t)ngrp * nb1 * 4) + pad((size_t)(nb1 + 1) * 4) + pad((size_t)nvt * nb2 * 4) * 2 + pad(((size_t)P + 1) * 4) +
                       pad((size_t)n * 8) * 2 + pad((size_t)n * 4) * 2 + pad((size_t)n * 2) * 2 + pad((size_t)nslots * 8) + pad((size_t)nslots * 4) +
-                      pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad((size_t)nwords * 64);
+                      pad((size_t)nwords * 8) + pad((size_t)nwords * 4) + pad((size_t)nrt * 4) + pad((size_t)nrt * 8) + pad((size_t)nwords * 64) + pad((size_t)nvt * sizeof(TileRange));
   uint8_t* base;
   int rc = ah_temp_reserve(c, need, (void**)&base);
   if (rc != AH_OK) return rc;
@@ -1122,7 +1123,10 @@ int ah_encode_partitioned2_try(ah_ctx* c, const uint64_t* keys, const uint8_t* v
   gb_scatter_kernel<false><<<tgrid, kThreads, 0, c->stream>>>(k64, valid, off, nullptr, nullptr, 0, n, lb1, nb1, ntiles, toffs1, pkeys1, nullptr, prows1, nullptr);
   AH_LAUNCH_CHECK(c);
   // ---- level 2: every parent into 2^lb2 partitions
-  e2_hist_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, cnt2);
+  TileRange* tile_table = (TileRange*)take((size_t)nvt * sizeof(TileRange));
+  ms_tile_table_kernel<<<(unsigned)ah_ceil_div(nvt, kThreads), kThreads, 0, c->stream>>>(pstart, nullptr, nb1, (unsigned)nvt, tile_table);
+  AH_LAUNCH_CHECK(c);
+  e2_hist_kernel<<<(unsigned)nvt, kThreads, 0, c->stream>>>(pkeys1, prows1, n, pstart, nb1, lp, (unsigned)(nb2 - 1), nb2, cnt2, tile_table);
   AH_LAUNCH_CHECK(c);
   // (the partitions' balance: posted by the offsets kernel, read while the scatter runs — see ah_encode_partitioned_try)
   unsigned long long *mb, seq, largest = 0;

@@ -67,6 +67,53 @@ __device__ __forceinline__ TileRange ms_tile(const unsigned* __restrict__ pstart
   return r;
 }
 
+// ms_tile for EVERY block of a launch of `nblocks` workgroups, written to a table the launch reads instead: ms_tile costs each
+// workgroup ≈ 2 µs of loads, a block scan and half a dozen barriers before its first row is requested.  A scatter's workgroup lives
+// ten times that long and does not notice (measured: profiles/r06_negative_results.txt); a histogram's lives 5 µs.  One thread per
+// block; the same arithmetic (blockIdx → b, gridDim → nblocks).
+__global__ __launch_bounds__(kThreads) void ms_tile_table_kernel(const unsigned* __restrict__ pstart, const unsigned* __restrict__ pend, int nparents,
+                                                                  unsigned nblocks, TileRange* __restrict__ table) {
+  __shared__ unsigned s_cnt[kThreads], s_start[kThreads], s_wsum[kThreads / 64];
+  const int t = threadIdx.x, per = nparents >> 3;
+  unsigned tiles = 0;
+  if (t < nparents) { const int p = ms_parent_of(t, nparents); tiles = ((pend ? pend[p] : pstart[p + 1]) - pstart[p] + kMsTile - 1) / kMsTile; }
+  s_cnt[t] = tiles;
+  __syncthreads();
+  block_excl_scan(s_cnt, s_start, s_wsum, nparents);
+  const unsigned b = blockIdx.x * (unsigned)kThreads + (unsigned)t;
+  if (b >= nblocks) return;
+  const unsigned x = b & 7, q = b >> 3, nblk = nblocks >> 3;
+  auto class_lo = [&](unsigned c) { return s_start[c * per]; };
+  auto class_n = [&](unsigned c) { return (c == 7 ? s_start[nparents - 1] + s_cnt[nparents - 1] : s_start[(c + 1) * per]) - s_start[c * per]; };
+  long long g = -1;
+  if (q < class_n(x)) {
+    g = class_lo(x) + q;
+  } else {
+    unsigned spare = q - class_n(x);
+    for (unsigned c = 0; c < x; c++) spare += nblk > class_n(c) ? nblk - class_n(c) : 0u;
+    for (unsigned c = 0; c < 8 && g < 0; c++) {
+      const unsigned surplus = class_n(c) > nblk ? class_n(c) - nblk : 0u;
+      if (spare < surplus) g = class_lo(c) + nblk + spare; else spare -= surplus;
+    }
+  }
+  TileRange r{0, 0, 0, -1};
+  if (g >= 0) {
+    int lo = 0, hi = nparents - 1;   // the last j with s_start[j] ≤ g that has tiles (entries without tiles share their successor's start)
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((long long)s_start[mid] <= g) lo = mid; else hi = mid - 1; }
+    int j = lo;
+    while (j > 0 && !s_cnt[j]) j--;
+    if (s_cnt[j] && (long long)s_start[j] <= g && g < (long long)s_start[j] + s_cnt[j]) {
+      const int p = ms_parent_of(j, nparents);
+      const int64_t b0 = pstart[p], b1 = pend ? pend[p] : pstart[p + 1];
+      r.lo = b0 + (int64_t)(g - s_start[j]) * kMsTile;
+      r.hi = r.lo + kMsTile < b1 ? r.lo + kMsTile : b1;
+      r.id = g;
+      r.parent = p;
+    }
+  }
+  table[b] = r;
+}
+
 // ---- level 2 offsets: one workgroup per parent -------------------------------------------------------------------------
 // toffs[vt][d] = position of virtual tile vt's first row of digit d = parent start + rows of smaller digits in the parent
 // + rows of digit d in the parent's earlier tiles;  bstart[parent · nb + d] = first row of bucket (parent, d)
