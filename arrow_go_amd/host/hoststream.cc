@@ -385,7 +385,7 @@ Status CallHostResident(ExecCtx* ctx, const std::string& name, const FunctionOpt
     const ArrayData& a = *args[0].array;
     const CastOptions* co = dynamic_cast<const CastOptions*>(opts);
     auto numeric = [](const DataType* t) { return t && (IsInteger(t->id) || IsFloating(t->id)); };
-    if (!co || !co->ToLogical.empty() || !a.on_host || a.device_twin || !a.logical.empty() || !numeric(a.type) || !numeric(co->ToType) || a.type->id == co->ToType->id)
+    if (!co || !co->ToLogical.empty() || !a.on_host || a.device_twin || !a.logical.empty() || a.length == 0 || !numeric(a.type) || !numeric(co->ToType) || a.type->id == co->ToType->id)
       return Status::OK();   // bool / temporal / identity casts, a missing ToType (the reference's error): the usual path
     *handled = true;
     return StreamCast(ctx, *co, a, out);
